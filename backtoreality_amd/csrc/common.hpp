@@ -1,0 +1,84 @@
+// common.hpp -- shared helpers for the gfx950 kernels behind include/btr_pointnet2.h.
+// Wave = 64 lanes everywhere (CDNA4); no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/btr_pointnet2.h"
+
+namespace btr {
+
+constexpr int kWave = 64;
+
+// Thread-local error text behind btr_last_error().
+inline char *err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+inline int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// The reference printf+exit(-1)s on a failed launch (include/cuda_utils.h:35-44); we report.
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+  return BTR_OK;
+}
+
+inline hipStream_t as_stream(btr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------- wave helpers
+// DPP lane exchange inside a row of 16 lanes (VALU-latency, no LDS crossbar trip).
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+// max over each row of 16 lanes, result replicated in all 16 lanes of the row.
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+  unsigned t;
+  t = dpp_u32<0xB1>(v);  v = v > t ? v : t;  // quad_perm [1,0,3,2]
+  t = dpp_u32<0x4E>(v);  v = v > t ? v : t;  // quad_perm [2,3,0,1]
+  t = dpp_u32<0x141>(v); v = v > t ? v : t;  // row_half_mirror
+  t = dpp_u32<0x140>(v); v = v > t ? v : t;  // row_mirror
+  return v;
+}
+
+// max over the whole 64-lane wave, returned wave-uniform (SGPR).
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = row16_max_u32(v);
+  unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+  unsigned b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32);
+  unsigned d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  a = a > b ? a : b;
+  c = c > d ? c : d;
+  return a > c ? a : c;
+}
+
+__device__ __forceinline__ float row16_sum_f32(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+  return v;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+}  // namespace btr
+
+#define BTR_REQUIRE(cond, ...)                                              \
+  do {                                                                      \
+    if (!(cond)) return ::btr::fail(BTR_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
+  } while (0)

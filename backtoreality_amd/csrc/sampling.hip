@@ -1,0 +1,284 @@
+// sampling.hip -- gather_points(+grad) and furthest point sampling for gfx950.
+//
+// Replaces src/sampling_gpu.cu of the reference (citations: see include/btr_pointnet2.h).
+// Built with -ffp-contract=off: the f32 distance must round exactly as the reference source
+// writes it, because the sampled indices are compared bit-exactly against the oracle.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace btr {
+
+// ------------------------------------------------------------------------------------ gather
+// out[r, j] = points[r, idx[r / c, j]] for r in [0, b*c): one thread per output element,
+// lanes along j (coalesced idx read + out write; the gather itself hits L2).
+__global__ __launch_bounds__(256) void gather_points_kernel(
+    int c, int n, int m, long long total, const float *__restrict__ points,
+    const int *__restrict__ idx, float *__restrict__ out) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
+       t += (long long)gridDim.x * 256) {
+    const long long row = t / m;
+    const int j = (int)(t - row * m);
+    const long long bi = row / c;
+    const int a = idx[bi * m + j];
+    out[t] = points[row * n + a];
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_points_grad_kernel(
+    int c, int n, int m, long long total, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_points) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
+       t += (long long)gridDim.x * 256) {
+    const long long row = t / m;
+    const int j = (int)(t - row * m);
+    const long long bi = row / c;
+    const int a = idx[bi * m + j];
+    atomicAdd(grad_points + row * n + a, grad_out[t]);
+  }
+}
+
+// --------------------------------------------------------------------------------------- FPS
+// Selection rule (bit-exact with sampling_gpu.cu:74-178 for block size `bs`):
+//   next = argmax over non-skipped points of key(k) = (d2(k), -tk(k)),
+//   tk(k) = bitreverse_{log2 bs}(k mod bs) * ceil(n/bs) + k / bs
+// which is exactly what the reference's strided per-thread scan (first strict max) followed by
+// its shared-memory tree (`v2 > v1 ? i2 : i1`) computes.  The key is carried as two u32:
+//   hi = float_bits(d2) + 1   (d2 >= 0, so the bits are monotone; 0 = "nothing competes")
+//   lo = 0xffffffff - tk(k)
+struct FpsSlot {
+  unsigned hi, lo;
+  int k;
+  float x, y, z;
+  int pad0, pad1;
+};
+
+__device__ __forceinline__ unsigned fps_tk(int k, int bs, int log2bs, int cpb) {
+  const unsigned r = log2bs == 0 ? 0u : (__brev((unsigned)(k & (bs - 1))) >> (32 - log2bs));
+  return r * (unsigned)cpb + (unsigned)(k >> log2bs);
+}
+
+// One workgroup of T threads per batch element.  REGS: every thread keeps its PPT points
+// (x,y,z,min-dist) in VGPRs for the whole run (n <= T*PPT); otherwise points stream from
+// L2/HBM every iteration with the running min-dist in `temp` (negative = skipped point).
+// Per iteration: per-lane best -> DPP wave arg-max -> one LDS slot per wave -> one barrier ->
+// every wave re-reduces the <=16 slots on its own (double-buffered slots, so one barrier).
+template <int T, int PPT, bool REGS>
+__global__ __launch_bounds__(T) void fps_kernel(int n, int m, int bs, int log2bs,
+                                                const float *__restrict__ dataset,
+                                                float *__restrict__ temp,
+                                                int *__restrict__ idxs) {
+  constexpr int NW = T / 64;
+  __shared__ FpsSlot slots[2][NW > 1 ? NW : 1];
+
+  const int bi = blockIdx.x;
+  dataset += (size_t)bi * n * 3;
+  temp += (size_t)bi * n;
+  idxs += (size_t)bi * m;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int cpb = (n + bs - 1) >> log2bs;
+
+  // point 0: the start, and the answer whenever nothing competes (best=-1, besti=0 in the
+  // reference, sampling_gpu.cu:95-96)
+  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
+
+  float px[PPT], py[PPT], pz[PPT], pt[PPT];
+  unsigned plo[PPT];
+  if (REGS) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int k = tid + i * T;
+      px[i] = py[i] = pz[i] = 0.f;
+      pt[i] = -1.f;
+      plo[i] = 0;
+      if (k < n) {
+        px[i] = dataset[k * 3 + 0];
+        py[i] = dataset[k * 3 + 1];
+        pz[i] = dataset[k * 3 + 2];
+        const float mag = (px[i] * px[i]) + (py[i] * py[i]) + (pz[i] * pz[i]);
+        pt[i] = ((double)mag <= 1e-3) ? -1.f : 1e10f;  // sampling_gpu.cu:105-106
+        plo[i] = 0xffffffffu - fps_tk(k, bs, log2bs, cpb);
+      }
+    }
+  } else {
+    for (int k = tid; k < n; k += T) {
+      const float x = dataset[k * 3 + 0], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
+      const float mag = (x * x) + (y * y) + (z * z);
+      temp[k] = ((double)mag <= 1e-3) ? -1.f : 1e10f;
+    }
+  }
+
+  if (tid == 0) idxs[0] = 0;
+  float x1 = x0, y1 = y0, z1 = z0;
+
+  for (int j = 1; j < m; ++j) {
+    unsigned bhi = 0, blo = 0;
+    int bk = 0;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    if (REGS) {
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const bool valid = pt[i] >= 0.f;
+        const float d2 = valid ? fminf(d, pt[i]) : pt[i];
+        pt[i] = d2;
+        const unsigned hi = valid ? (__float_as_uint(d2) + 1u) : 0u;
+        const bool better = hi > bhi || (hi == bhi && plo[i] > blo);
+        bhi = better ? hi : bhi;
+        blo = better ? plo[i] : blo;
+        bk = better ? tid + i * T : bk;
+        bx = better ? px[i] : bx;
+        by = better ? py[i] : by;
+        bz = better ? pz[i] : bz;
+      }
+    } else {
+      for (int k = tid; k < n; k += T) {
+        const float t = temp[k];
+        if (t < 0.f) continue;
+        const float x = dataset[k * 3 + 0], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
+        const float dx = x - x1, dy = y - y1, dz = z - z1;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const float d2 = fminf(d, t);
+        temp[k] = d2;
+        const unsigned hi = __float_as_uint(d2) + 1u;
+        const unsigned lo = 0xffffffffu - fps_tk(k, bs, log2bs, cpb);
+        const bool better = hi > bhi || (hi == bhi && lo > blo);
+        bhi = better ? hi : bhi;
+        blo = better ? lo : blo;
+        bk = better ? k : bk;
+        bx = better ? x : bx;
+        by = better ? y : by;
+        bz = better ? z : bz;
+      }
+    }
+
+    // wave arg-max of (hi, lo); keys are unique per point so exactly one lane matches
+    const unsigned mh = wave_max_u32(bhi);
+    const unsigned ml = wave_max_u32(bhi == mh ? blo : 0u);
+    const bool win = (bhi == mh) && (blo == ml);
+    int nk;
+    float nx, ny, nz;
+    if (NW == 1) {
+      if (mh == 0) {
+        nk = 0; nx = x0; ny = y0; nz = z0;
+      } else {
+        const int w = __builtin_ctzll(__ballot(win));
+        nk = __builtin_amdgcn_readlane(bk, w);
+        nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), w));
+        ny = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), w));
+        nz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), w));
+      }
+    } else {
+      FpsSlot *sl = slots[j & 1];
+      if (mh == 0) {
+        if (lane == 0) sl[wave] = FpsSlot{0u, 0u, 0, x0, y0, z0, 0, 0};
+      } else if (win) {
+        sl[wave] = FpsSlot{mh, ml, bk, bx, by, bz, 0, 0};
+      }
+      __syncthreads();
+      const int s = lane & 15;
+      FpsSlot v = FpsSlot{0u, 0u, 0, x0, y0, z0, 0, 0};
+      if (s < NW) v = sl[s];
+      const unsigned gh = row16_max_u32(v.hi);
+      const unsigned gl = row16_max_u32(v.hi == gh ? v.lo : 0u);
+      // first row (lanes 0..15) holds every slot: pick the matching lane there
+      const unsigned long long match = __ballot(v.hi == gh && v.lo == gl) & 0xffffull;
+      const int w = __builtin_ctzll(match);
+      nk = __builtin_amdgcn_readlane(v.k, w);
+      nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), w));
+      ny = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), w));
+      nz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), w));
+    }
+    x1 = nx; y1 = ny; z1 = nz;
+    if (tid == 0) idxs[j] = nk;
+  }
+}
+
+template <int T, int PPT, bool REGS>
+static int launch_fps(int b, int n, int m, int bs, int log2bs, const float *dataset,
+                      float *temp, int *idxs, hipStream_t s) {
+  hipLaunchKernelGGL((fps_kernel<T, PPT, REGS>), dim3(b), dim3(T), 0, s, n, m, bs, log2bs,
+                     dataset, temp, idxs);
+  return check_launch("furthest_point_sampling");
+}
+
+static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                        int bs, hipStream_t s) {
+  if (m <= 0 || b <= 0) return BTR_OK;  // sampling_gpu.cu:78
+  BTR_REQUIRE(n > 0 && dataset && idxs, "furthest_point_sampling: n=%d must be > 0", n);
+  BTR_REQUIRE(bs >= 1 && bs <= 512 && (bs & (bs - 1)) == 0,
+              "furthest_point_sampling: block_size %d is not a power of two in [1,512]", bs);
+  BTR_REQUIRE((long long)n + 512 < 0x7fffffffLL, "furthest_point_sampling: n too large");
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  if (n <= 64) return launch_fps<64, 1, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+  if (n <= 256) return launch_fps<256, 1, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+  if (n <= 1024) return launch_fps<256, 4, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+  if (n <= 4096) return launch_fps<1024, 4, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+  if (n <= 8192) return launch_fps<1024, 8, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+  BTR_REQUIRE(temp != nullptr, "furthest_point_sampling: temp scratch required for n=%d", n);
+  return launch_fps<1024, 1, false>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+}
+
+}  // namespace btr
+
+using namespace btr;
+
+extern "C" {
+
+int btr_abi_version(void) { return BTR_ABI_VERSION; }
+
+const char *btr_last_error(void) { return err_buf(); }
+
+// include/cuda_utils.h:20-24, evaluated in double like the reference.
+int btr_opt_n_threads(int work_size) {
+  if (work_size <= 0) return 1;
+  const int pow_2 = (int)(std::log(static_cast<double>(work_size)) / std::log(2.0));
+  int v = 1 << pow_2;
+  if (v > 512) v = 512;
+  if (v < 1) v = 1;
+  return v;
+}
+
+int btr_furthest_point_sampling_bs(int b, int n, int m, const float *dataset, float *temp,
+                                   int *idxs, int block_size, btr_stream_t stream) {
+  return fps_dispatch(b, n, m, dataset, temp, idxs, block_size, as_stream(stream));
+}
+
+int btr_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                int *idxs, btr_stream_t stream) {
+  return fps_dispatch(b, n, m, dataset, temp, idxs, btr_opt_n_threads(n), as_stream(stream));
+}
+
+int btr_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                      float *out, btr_stream_t stream) {
+  const long long total = (long long)b * c * npoints;
+  if (total <= 0) return BTR_OK;
+  BTR_REQUIRE(points && idx && out && n > 0, "gather_points: null pointer or n=%d", n);
+  const int grid = (int)std::min<long long>(cdiv(total, 256), 256 * 8);
+  hipLaunchKernelGGL(gather_points_kernel, dim3(grid), dim3(256), 0, as_stream(stream), c, n,
+                     npoints, total, points, idx, out);
+  return check_launch("gather_points");
+}
+
+int btr_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                           const int *idx, float *grad_points, btr_stream_t stream) {
+  const long long nout = (long long)b * c * n;
+  if (nout <= 0) return BTR_OK;
+  BTR_REQUIRE(grad_points, "gather_points_grad: null output");
+  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * nout, as_stream(stream));
+  if (e != hipSuccess) return fail((int)e, "gather_points_grad memset: %s", hipGetErrorString(e));
+  const long long total = (long long)b * c * npoints;
+  if (total <= 0) return BTR_OK;
+  BTR_REQUIRE(grad_out && idx, "gather_points_grad: null pointer");
+  const int grid = (int)std::min<long long>(cdiv(total, 256), 256 * 8);
+  hipLaunchKernelGGL(gather_points_grad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), c,
+                     n, npoints, total, grad_out, idx, grad_points);
+  return check_launch("gather_points_grad");
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+"""`pointnet2._ext` for MI355X: the nine callables of the reference's pybind module
+(/root/reference/detection/Votenet/pointnet2/_ext_src/src/bindings.cpp:11-24), implemented as a
+thin ctypes shim over the C ABI of ``libbtr_pointnet2.so`` (include/btr_pointnet2.h).
+
+The shim does what the reference's C++ wrappers do (src/{sampling,ball_query,group_points,
+interpolate}.cpp): check contiguity / dtype / device (utils.h:10-30 -> RuntimeError), allocate
+the result on the input's device, and enqueue the kernel on the CURRENT stream of that device
+without synchronising.  CPU tensors raise ``RuntimeError("CPU not supported")`` exactly like
+the reference (e.g. ball_query.cpp:33): there is no CPU fallback in the product path, and a
+missing HIP library is an ImportError at import time, never a silent downgrade.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libbtr_pointnet2.so")
+
+_vp = ctypes.c_void_p
+_ci = ctypes.c_int
+_cf = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/btr_pointnet2.h one to one.
+_SIGNATURES = {
+    "btr_abi_version": (_ci, []),
+    "btr_last_error": (ctypes.c_char_p, []),
+    "btr_opt_n_threads": (_ci, [_ci]),
+    "btr_furthest_point_sampling": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp]),
+    "btr_furthest_point_sampling_bs": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp]),
+    "btr_gather_points": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
+    "btr_gather_points_grad": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
+    "btr_ball_query": (_ci, [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp]),
+    "btr_ball_query_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
+    "btr_ball_query_ws": (_ci, [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "btr_group_points": (_ci, [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
+    "btr_group_points_grad": (_ci, [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
+    "btr_three_nn": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "btr_three_interpolate": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "btr_three_interpolate_grad": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "Could not import _ext: %s is missing.\n"
+            "Build the HIP extension first: python -c 'import __graft_entry__ as g; g.build()' "
+            "(or python backtoreality_amd/build.py)." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = stale .so: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.btr_abi_version() != 1:
+        raise ImportError("libbtr_pointnet2.so ABI %d != 1: rebuild" % lib.btr_abi_version())
+    return lib
+
+
+_lib = _load()
+
+
+# ------------------------------------------------------------------------------------ checks
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check(t, name, kind, like=None):
+    _require(isinstance(t, torch.Tensor), "%s must be a tensor" % name)
+    _require(t.is_contiguous(), "%s must be a contiguous tensor" % name)
+    if kind == "float":
+        _require(t.dtype == torch.float32, "%s must be a float tensor" % name)
+    else:
+        _require(t.dtype == torch.int32, "%s must be an int tensor" % name)
+    if like is not None and like.is_cuda:
+        _require(t.is_cuda, "%s must be a CUDA tensor" % name)
+        _require(t.device == like.device, "%s must be on %s" % (name, like.device))
+
+
+def _gpu_only(t):
+    _require(t.is_cuda, "CPU not supported")
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _call(fn, *args):
+    rc = fn(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" %
+                           (fn.__name__, rc, _lib.btr_last_error().decode(errors="replace")))
+
+
+class _on(object):
+    """Device guard: the reference has none (it relies on the caller's current device)."""
+
+    def __init__(self, t):
+        self.idx = t.device.index
+        self.guard = None
+
+    def __enter__(self):
+        if self.idx != torch.cuda.current_device():
+            self.guard = torch.cuda.device(self.idx)
+            self.guard.__enter__()
+        return self.idx
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        return False
+
+
+# -------------------------------------------------------------------------- the nine callables
+def furthest_point_sampling(points, nsamples):
+    """(B,N,3) f32 -> (B,nsamples) i32.  sampling.cpp:70-91."""
+    _check(points, "points", "float")
+    _gpu_only(points)
+    _require(points.dim() == 3 and points.size(2) == 3, "points must be (B, N, 3)")
+    B, N, _ = points.shape
+    nsamples = int(nsamples)
+    out = torch.empty((B, max(nsamples, 0)), dtype=torch.int32, device=points.device)
+    if nsamples <= 0 or B == 0:
+        return out
+    temp = torch.empty((B, N), dtype=torch.float32, device=points.device)
+    with _on(points) as dev:
+        _call(_lib.btr_furthest_point_sampling, B, N, nsamples, _p(points), _p(temp), _p(out),
+              _stream(dev))
+    return out
+
+
+def furthest_point_sampling_bs(points, nsamples, block_size):
+    """Test hook: FPS with the reference block size forced (tie-break per instantiation)."""
+    _check(points, "points", "float")
+    _gpu_only(points)
+    B, N, _ = points.shape
+    out = torch.empty((B, max(int(nsamples), 0)), dtype=torch.int32, device=points.device)
+    temp = torch.empty((B, N), dtype=torch.float32, device=points.device)
+    with _on(points) as dev:
+        _call(_lib.btr_furthest_point_sampling_bs, B, N, int(nsamples), _p(points), _p(temp),
+              _p(out), int(block_size), _stream(dev))
+    return out
+
+
+def gather_points(points, idx):
+    """(B,C,N) f32, (B,M) i32 -> (B,C,M).  sampling.cpp:20-44."""
+    _check(points, "points", "float")
+    _check(idx, "idx", "int", like=points)
+    _gpu_only(points)
+    B, C, N = points.shape
+    M = idx.size(1)
+    out = torch.empty((B, C, M), dtype=torch.float32, device=points.device)
+    with _on(points) as dev:
+        _call(_lib.btr_gather_points, B, C, N, M, _p(points), _p(idx), _p(out), _stream(dev))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """(B,C,M) f32, (B,M) i32, n -> (B,C,n).  sampling.cpp:46-69."""
+    _check(grad_out, "grad_out", "float")
+    _check(idx, "idx", "int", like=grad_out)
+    _gpu_only(grad_out)
+    B, C, M = grad_out.shape
+    out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
+    with _on(grad_out) as dev:
+        _call(_lib.btr_gather_points_grad, B, C, int(n), M, _p(grad_out), _p(idx), _p(out),
+              _stream(dev))
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """(B,M,3), (B,N,3) f32 -> (B,M,nsample) i32.  C++ argument order, ball_query.cpp:13-37."""
+    _check(new_xyz, "new_xyz", "float")
+    _check(xyz, "xyz", "float", like=new_xyz)
+    _gpu_only(new_xyz)
+    B, M, _ = new_xyz.shape
+    N = xyz.size(1)
+    nsample = int(nsample)
+    out = torch.empty((B, M, nsample), dtype=torch.int32, device=new_xyz.device)
+    ws_bytes = _lib.btr_ball_query_workspace_bytes(B, N, M, nsample)
+    ws = (torch.empty((ws_bytes,), dtype=torch.uint8, device=new_xyz.device)
+          if ws_bytes else None)
+    with _on(new_xyz) as dev:
+        _call(_lib.btr_ball_query_ws, B, N, M, float(radius), nsample, _p(new_xyz), _p(xyz),
+              _p(out), _p(ws), ws_bytes, _stream(dev))
+    return out
+
+
+def group_points(points, idx):
+    """(B,C,N) f32, (B,M,S) i32 -> (B,C,M,S).  group_points.cpp:17-40."""
+    _check(points, "points", "float")
+    _check(idx, "idx", "int", like=points)
+    _gpu_only(points)
+    B, C, N = points.shape
+    _, M, S = idx.shape
+    out = torch.empty((B, C, M, S), dtype=torch.float32, device=points.device)
+    with _on(points) as dev:
+        _call(_lib.btr_group_points, B, C, N, M, S, _p(points), _p(idx), _p(out), _stream(dev))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """(B,C,M,S) f32, (B,M,S) i32, n -> (B,C,n).  group_points.cpp:42-65."""
+    _check(grad_out, "grad_out", "float")
+    _check(idx, "idx", "int", like=grad_out)
+    _gpu_only(grad_out)
+    B, C, M, S = grad_out.shape
+    out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
+    with _on(grad_out) as dev:
+        _call(_lib.btr_group_points_grad, B, C, int(n), M, S, _p(grad_out), _p(idx), _p(out),
+              _stream(dev))
+    return out
+
+
+def three_nn(unknowns, knows):
+    """(B,n,3), (B,m,3) -> [dist2 (B,n,3) f32 (squared), idx (B,n,3) i32].  interpolate.cpp:19-45."""
+    _check(unknowns, "unknowns", "float")
+    _check(knows, "knows", "float", like=unknowns)
+    _gpu_only(unknowns)
+    B, n, _ = unknowns.shape
+    m = knows.size(1)
+    dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknowns.device)
+    idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknowns.device)
+    with _on(unknowns) as dev:
+        _call(_lib.btr_three_nn, B, n, m, _p(unknowns), _p(knows), _p(dist2), _p(idx),
+              _stream(dev))
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """(B,C,m) f32, (B,n,3) i32, (B,n,3) f32 -> (B,C,n).  interpolate.cpp:47-75."""
+    _check(points, "points", "float")
+    _check(idx, "idx", "int", like=points)
+    _check(weight, "weight", "float", like=points)
+    _gpu_only(points)
+    B, C, m = points.shape
+    n = idx.size(1)
+    out = torch.empty((B, C, n), dtype=torch.float32, device=points.device)
+    with _on(points) as dev:
+        _call(_lib.btr_three_interpolate, B, C, m, n, _p(points), _p(idx), _p(weight), _p(out),
+              _stream(dev))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """(B,C,n) f32, idx, weight, m -> (B,C,m).  interpolate.cpp:76-104."""
+    _check(grad_out, "grad_out", "float")
+    _check(idx, "idx", "int", like=grad_out)
+    _check(weight, "weight", "float", like=grad_out)
+    _gpu_only(grad_out)
+    B, C, n = grad_out.shape
+    out = torch.empty((B, C, int(m)), dtype=torch.float32, device=grad_out.device)
+    with _on(grad_out) as dev:
+        _call(_lib.btr_three_interpolate_grad, B, C, n, int(m), _p(grad_out), _p(idx),
+              _p(weight), _p(out), _stream(dev))
+    return out
+
+
+def opt_n_threads(work_size):
+    return int(_lib.btr_opt_n_threads(int(work_size)))

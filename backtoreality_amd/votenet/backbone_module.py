@@ -1,0 +1,60 @@
+"""PointNet++ backbone of VoteNet: four set-abstraction layers and two feature-propagation
+layers with the hyper-parameters hard-coded in the reference
+(detection/Votenet/models/backbone_module.py:35-72) and the same attribute names
+(`sa1..sa4`, `fp1`, `fp2`), so the state-dict keys are `backbone_net.sa1.mlp_module.layer0...`.
+"""
+import torch
+import torch.nn as nn
+
+from ..pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+
+# (npoint, radius, nsample, mlp-after-input) per SA layer -- backbone_module.py:35-69
+SA_SPECS = (
+    (2048, 0.2, 64, (64, 64, 128)),
+    (1024, 0.4, 32, (128, 128, 256)),
+    (512, 0.8, 16, (128, 128, 256)),
+    (256, 1.2, 16, (128, 128, 256)),
+)
+
+
+class Pointnet2Backbone(nn.Module):
+    def __init__(self, input_feature_dim=0, fp2_out=256):
+        super().__init__()
+        cin = input_feature_dim
+        for i, (npoint, radius, nsample, widths) in enumerate(SA_SPECS, start=1):
+            setattr(self, "sa%d" % i, PointnetSAModuleVotes(
+                npoint=npoint, radius=radius, nsample=nsample, mlp=[cin] + list(widths),
+                use_xyz=True, normalize_xyz=True))
+            cin = widths[-1]
+        self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+        self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, fp2_out])
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud: torch.Tensor, end_points=None):
+        """pointcloud (B, N, 3 + input_feature_dim) -> end_points with sa{1..4}_{xyz,features},
+        sa1_inds, sa2_inds, fp2_{xyz,features,inds} (backbone_module.py:83-133)."""
+        end_points = end_points if end_points else {}
+        xyz, features = self._break_up_pc(pointcloud)
+        for i in (1, 2, 3, 4):
+            xyz, features, fps_inds = getattr(self, "sa%d" % i)(xyz, features)
+            if i <= 2:
+                end_points["sa%d_inds" % i] = fps_inds
+            end_points["sa%d_xyz" % i] = xyz
+            end_points["sa%d_features" % i] = features
+
+        features = self.fp1(end_points["sa3_xyz"], end_points["sa4_xyz"],
+                            end_points["sa3_features"], end_points["sa4_features"])
+        features = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"],
+                            end_points["sa2_features"], features)
+        end_points["fp2_features"] = features
+        end_points["fp2_xyz"] = end_points["sa2_xyz"]
+        num_seed = end_points["fp2_xyz"].shape[1]
+        # FPS over an FPS-ordered prefix returns 0..k-1, so the seeds' indices into the input
+        # cloud are the first num_seed entries of sa1_inds (backbone_module.py:113-132)
+        end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:num_seed]
+        return end_points

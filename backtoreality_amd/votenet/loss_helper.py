@@ -1,0 +1,185 @@
+"""VoteNet loss: device-agnostic counterpart of detection/Votenet/models/loss_helper.py
+(`get_loss` :336-400 and the three terms it sums) and detection/Votenet/utils/nn_distance.py.
+Same arithmetic, same `end_points` keys; the reference's hard-coded `.cuda()` /
+`torch.cuda.FloatTensor` allocations become allocations on the inputs' device.
+Stock torch ops only -- this is the caller of the hot path, not part of it.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+FAR_THRESHOLD = 0.6
+NEAR_THRESHOLD = 0.3
+GT_VOTE_FACTOR = 3  # GT votes per point
+OBJECTNESS_CLS_WEIGHTS = [0.2, 0.8]  # more weight on positive objectness
+
+
+def huber_loss(error, delta=1.0):
+    """0.5*x^2 for |x| <= delta, else 0.5*delta^2 + delta*(|x|-delta) (nn_distance.py:15-32)."""
+    abs_error = torch.abs(error)
+    quadratic = torch.clamp(abs_error, max=delta)
+    linear = abs_error - quadratic
+    return 0.5 * quadratic ** 2 + delta * linear
+
+
+def nn_distance(pc1, pc2, l1smooth=False, delta=1.0, l1=False):
+    """Brute-force chamfer terms between pc1 (B,N,C) and pc2 (B,M,C) (nn_distance.py:34-61):
+    -> dist1 (B,N), idx1 (B,N), dist2 (B,M), idx2 (B,M)."""
+    pc_diff = pc1.unsqueeze(2) - pc2.unsqueeze(1)  # (B,N,M,C), broadcast instead of repeat
+    if l1smooth:
+        pc_dist = torch.sum(huber_loss(pc_diff, delta), dim=-1)
+    elif l1:
+        pc_dist = torch.sum(torch.abs(pc_diff), dim=-1)
+    else:
+        pc_dist = torch.sum(pc_diff ** 2, dim=-1)
+    dist1, idx1 = torch.min(pc_dist, dim=2)
+    dist2, idx2 = torch.min(pc_dist, dim=1)
+    return dist1, idx1, dist2, idx2
+
+
+def _masked_mean(values, mask):
+    return torch.sum(values * mask) / (torch.sum(mask) + 1e-6)
+
+
+def compute_vote_loss(end_points):
+    """Seeds on objects must vote for (one of) their GT centres (loss_helper.py:24-69)."""
+    B, num_seed = end_points['seed_xyz'].shape[0], end_points['seed_xyz'].shape[1]
+    vote_xyz = end_points['vote_xyz']             # (B, num_seed*vote_factor, 3)
+    seed_inds = end_points['seed_inds'].long()    # (B, num_seed) into the input cloud
+
+    seed_gt_votes_mask = torch.gather(end_points['vote_label_mask'], 1, seed_inds)
+    inds9 = seed_inds.view(B, num_seed, 1).repeat(1, 1, 3 * GT_VOTE_FACTOR)
+    seed_gt_votes = torch.gather(end_points['vote_label'], 1, inds9)
+    seed_gt_votes = seed_gt_votes + end_points['seed_xyz'].repeat(1, 1, 3)
+
+    vote_xyz_r = vote_xyz.view(B * num_seed, -1, 3)
+    gt_r = seed_gt_votes.view(B * num_seed, GT_VOTE_FACTOR, 3)
+    _, _, dist2, _ = nn_distance(vote_xyz_r, gt_r, l1=True)
+    votes_dist, _ = torch.min(dist2, dim=1)
+    votes_dist = votes_dist.view(B, num_seed)
+    return _masked_mean(votes_dist, seed_gt_votes_mask.float())
+
+
+def compute_objectness_loss(end_points):
+    """Label proposals by distance to the nearest GT centre (loss_helper.py:111-152)."""
+    agg = end_points['aggregated_vote_xyz']
+    gt_center = end_points['center_label'][:, :, 0:3]
+    B, K = gt_center.shape[0], agg.shape[1]
+    dist1, ind1, _, _ = nn_distance(agg, gt_center)
+
+    euclidean_dist1 = torch.sqrt(dist1 + 1e-6)
+    objectness_label = torch.zeros((B, K), dtype=torch.long, device=agg.device)
+    objectness_mask = torch.zeros((B, K), device=agg.device)
+    objectness_label[euclidean_dist1 < NEAR_THRESHOLD] = 1
+    objectness_mask[euclidean_dist1 < NEAR_THRESHOLD] = 1
+    objectness_mask[euclidean_dist1 > FAR_THRESHOLD] = 1
+
+    scores = end_points['objectness_scores']
+    weight = torch.tensor(OBJECTNESS_CLS_WEIGHTS, dtype=scores.dtype, device=scores.device)
+    criterion = nn.CrossEntropyLoss(weight, reduction='none')
+    loss = criterion(scores.transpose(2, 1), objectness_label)
+    loss = _masked_mean(loss, objectness_mask)
+    return loss, objectness_label, objectness_mask, ind1
+
+
+def compute_box_and_sem_cls_loss(end_points, config):
+    """Centre / heading / size / semantic-class terms (loss_helper.py:154-228)."""
+    num_heading_bin = config.num_heading_bin
+    num_size_cluster = config.num_size_cluster
+    mean_size_arr = config.mean_size_arr
+
+    object_assignment = end_points['object_assignment']
+    B = object_assignment.shape[0]
+    dev = object_assignment.device
+    objectness_label = end_points['objectness_label'].float()
+    ce = nn.CrossEntropyLoss(reduction='none')
+
+    # centre: chamfer in both directions
+    pred_center = end_points['center']
+    gt_center = end_points['center_label'][:, :, 0:3]
+    dist1, _, dist2, _ = nn_distance(pred_center, gt_center)
+    center_loss = (_masked_mean(dist1, objectness_label) +
+                   _masked_mean(dist2, end_points['box_label_mask']))
+
+    # heading
+    heading_class_label = torch.gather(end_points['heading_class_label'], 1, object_assignment)
+    heading_class_loss = ce(end_points['heading_scores'].transpose(2, 1), heading_class_label)
+    heading_class_loss = _masked_mean(heading_class_loss, objectness_label)
+
+    heading_residual_label = torch.gather(end_points['heading_residual_label'], 1,
+                                          object_assignment)
+    heading_residual_normalized_label = heading_residual_label / (np.pi / num_heading_bin)
+    K = heading_class_label.shape[1]
+    heading_one_hot = torch.zeros((B, K, num_heading_bin), device=dev)
+    heading_one_hot.scatter_(2, heading_class_label.unsqueeze(-1), 1)
+    heading_reg_loss = huber_loss(
+        torch.sum(end_points['heading_residuals_normalized'] * heading_one_hot, -1) -
+        heading_residual_normalized_label, delta=1.0)
+    heading_reg_loss = _masked_mean(heading_reg_loss, objectness_label)
+
+    # size
+    size_class_label = torch.gather(end_points['size_class_label'], 1, object_assignment)
+    size_class_loss = ce(end_points['size_scores'].transpose(2, 1), size_class_label)
+    size_class_loss = _masked_mean(size_class_loss, objectness_label)
+
+    size_residual_label = torch.gather(end_points['size_residual_label'], 1,
+                                       object_assignment.unsqueeze(-1).repeat(1, 1, 3))
+    size_one_hot = torch.zeros((B, K, num_size_cluster), device=dev)
+    size_one_hot.scatter_(2, size_class_label.unsqueeze(-1), 1)
+    size_one_hot_tiled = size_one_hot.unsqueeze(-1).repeat(1, 1, 1, 3)
+    predicted_size_residual_normalized = torch.sum(
+        end_points['size_residuals_normalized'] * size_one_hot_tiled, 2)
+    mean_size = torch.from_numpy(mean_size_arr.astype(np.float32)).to(dev)
+    mean_size = mean_size.unsqueeze(0).unsqueeze(0)
+    mean_size_label = torch.sum(size_one_hot_tiled * mean_size, 2)
+    size_residual_label_normalized = size_residual_label / mean_size_label
+    size_reg_loss = torch.mean(
+        huber_loss(predicted_size_residual_normalized - size_residual_label_normalized,
+                   delta=1.0), -1)
+    size_reg_loss = _masked_mean(size_reg_loss, objectness_label)
+
+    # semantic class
+    sem_cls_label = torch.gather(end_points['sem_cls_label'], 1, object_assignment)
+    sem_cls_loss = ce(end_points['sem_cls_scores'].transpose(2, 1), sem_cls_label)
+    sem_cls_loss = _masked_mean(sem_cls_loss, objectness_label)
+
+    return (center_loss, heading_class_loss, heading_reg_loss, size_class_loss, size_reg_loss,
+            sem_cls_loss)
+
+
+def get_loss(end_points, config):
+    """Total VoteNet loss; fills end_points with every term (loss_helper.py:336-400)."""
+    vote_loss = compute_vote_loss(end_points)
+    end_points['vote_loss'] = vote_loss
+
+    objectness_loss, objectness_label, objectness_mask, object_assignment = \
+        compute_objectness_loss(end_points)
+    end_points['objectness_loss'] = objectness_loss
+    end_points['objectness_label'] = objectness_label
+    end_points['objectness_mask'] = objectness_mask
+    end_points['object_assignment'] = object_assignment
+    total = float(objectness_label.shape[0] * objectness_label.shape[1])
+    end_points['pos_ratio'] = torch.sum(objectness_label.float()) / total
+    end_points['neg_ratio'] = torch.sum(objectness_mask.float()) / total - end_points['pos_ratio']
+
+    (center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss,
+     sem_cls_loss) = compute_box_and_sem_cls_loss(end_points, config)
+    end_points['center_loss'] = center_loss
+    end_points['heading_cls_loss'] = heading_cls_loss
+    end_points['heading_reg_loss'] = heading_reg_loss
+    end_points['size_cls_loss'] = size_cls_loss
+    end_points['size_reg_loss'] = size_reg_loss
+    end_points['sem_cls_loss'] = sem_cls_loss
+    box_loss = (center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss +
+                size_reg_loss)
+    end_points['box_loss'] = box_loss
+
+    loss = vote_loss + 0.5 * objectness_loss + box_loss + 0.1 * sem_cls_loss
+    loss = loss * 10
+    end_points['loss'] = loss
+
+    obj_pred_val = torch.argmax(end_points['objectness_scores'], 2)
+    obj_acc = torch.sum((obj_pred_val == objectness_label.long()).float() * objectness_mask) / \
+        (torch.sum(objectness_mask) + 1e-6)
+    end_points['obj_acc'] = obj_acc
+    return loss, end_points

@@ -1,0 +1,96 @@
+"""Vote aggregation + proposal head (detection/Votenet/models/proposal_module.py).
+
+`vote_aggregation` is the hot-path piece: a fifth set-abstraction layer run on the votes
+(npoint=num_proposal, r=0.3, nsample=16, mlp [256,128,128,128], :66-73), whose `xyz` input
+requires grad, so backward reaches group_points_grad AND gather_points_grad.  The head
+(3x Conv1d) and `decode_scores` (:18-50) are stock torch ops.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..pointnet2 import pointnet2_utils
+from ..pointnet2.pointnet2_modules import PointnetSAModuleVotes
+
+
+def decode_scores(net, end_points, num_class, num_heading_bin, num_size_cluster, mean_size_arr):
+    """Split the (B, 2+3+NH*2+NS*4+NC, K) head output into named predictions (:18-50)."""
+    t = net.transpose(2, 1)  # (B, K, channels)
+    B, K = t.shape[0], t.shape[1]
+    NH, NS = num_heading_bin, num_size_cluster
+
+    end_points['objectness_scores'] = t[:, :, 0:2]
+    end_points['center'] = end_points['aggregated_vote_xyz'] + t[:, :, 2:5]
+
+    o = 5
+    end_points['heading_scores'] = t[:, :, o:o + NH]
+    hres = t[:, :, o + NH:o + 2 * NH]
+    end_points['heading_residuals_normalized'] = hres  # in [-1, 1]
+    end_points['heading_residuals'] = hres * (np.pi / NH)
+
+    o += 2 * NH
+    size_scores = t[:, :, o:o + NS]
+    sres = t[:, :, o + NS:o + 4 * NS].view([B, K, NS, 3])
+    end_points['size_scores'] = size_scores
+    end_points['size_residuals_normalized'] = sres
+    mean_size = torch.from_numpy(mean_size_arr.astype(np.float32)).to(net.device)
+    mean_size = mean_size.unsqueeze(0).unsqueeze(0)
+    end_points['size_residuals'] = sres * mean_size
+    size_recover = mean_size + end_points['size_residuals']  # (B, K, NS, 3)
+    pred_cls = torch.argmax(size_scores, -1)
+    pred_cls = pred_cls.unsqueeze(-1).unsqueeze(-1).repeat(1, 1, 1, 3)
+    end_points['pred_size'] = torch.gather(size_recover, 2, pred_cls).squeeze_(2)  # (B, K, 3)
+
+    end_points['sem_cls_scores'] = t[:, :, o + 4 * NS:]
+    return end_points
+
+
+class ProposalModule(nn.Module):
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr,
+                 num_proposal, sampling, seed_feat_dim=256):
+        super().__init__()
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_size_cluster = num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        self.num_proposal = num_proposal
+        self.sampling = sampling
+        self.seed_feat_dim = seed_feat_dim
+
+        self.vote_aggregation = PointnetSAModuleVotes(
+            npoint=self.num_proposal, radius=0.3, nsample=16,
+            mlp=[self.seed_feat_dim, 128, 128, 128], use_xyz=True, normalize_xyz=True)
+
+        out_ch = 2 + 3 + num_heading_bin * 2 + num_size_cluster * 4 + self.num_class
+        self.conv1 = nn.Conv1d(128, 128, 1)
+        self.conv2 = nn.Conv1d(128, 128, 1)
+        self.conv3 = nn.Conv1d(128, out_ch, 1)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.bn2 = nn.BatchNorm1d(128)
+
+    def forward(self, xyz, features, end_points):
+        """xyz (B,K,3) votes, features (B,C,K) -> end_points with the decoded proposals."""
+        if self.sampling == 'vote_fps':
+            xyz, features, sample_inds = self.vote_aggregation(xyz, features)
+        elif self.sampling == 'seed_fps':
+            # FPS on the seeds, then aggregate the votes of the chosen seeds (:97-100)
+            sample_inds = pointnet2_utils.furthest_point_sample(end_points['seed_xyz'],
+                                                                self.num_proposal)
+            xyz, features, _ = self.vote_aggregation(xyz, features, sample_inds)
+        elif self.sampling == 'random':
+            num_seed = end_points['seed_xyz'].shape[1]
+            sample_inds = torch.randint(0, num_seed, (xyz.shape[0], self.num_proposal),
+                                        dtype=torch.int, device=xyz.device)
+            xyz, features, _ = self.vote_aggregation(xyz, features, sample_inds)
+        else:
+            raise ValueError('Unknown sampling strategy: %s' % (self.sampling,))
+        end_points['aggregated_vote_xyz'] = xyz            # (B, num_proposal, 3)
+        end_points['aggregated_vote_features'] = features  # (B, 128, num_proposal)
+        end_points['aggregated_vote_inds'] = sample_inds   # (B, num_proposal)
+
+        net = F.relu(self.bn1(self.conv1(features)))
+        net = F.relu(self.bn2(self.conv2(net)))
+        net = self.conv3(net)
+        return decode_scores(net, end_points, self.num_class, self.num_heading_bin,
+                             self.num_size_cluster, self.mean_size_arr)

@@ -1,0 +1,126 @@
+"""Deterministic synthetic scenes with the batch-dict schema of the reference's datasets
+(detection/Votenet/scannet/scannet_detection_dataset.py:197-219).
+
+There is no ScanNet / Matterport data offline, so benchmarks and parity tests run on generated
+rooms: scene `i` is drawn from numpy.random.default_rng(1000 + i).
+  * surface-room (default): a box-shaped room U(4,8) x U(4,8) x U(2.4,3) m with its origin at
+    a corner; 35 % of the points on the floor, 35 % on the four walls, 30 % on the faces of
+    8-16 random boxes (0.3-1.5 m) standing on the floor; Gaussian jitter sigma = 5 mm;
+    shuffled.  This mimics the surface density of an indoor scan (the ball-query hit counts
+    depend on it).
+  * uniform-volume: points uniform in the same extents (sparse / stress variant).
+The height feature is z - percentile(z, 0.99) as in the loader (:122-125).
+"""
+import numpy as np
+import torch
+
+from .config import DatasetConfig
+
+
+def _points_on_box_faces(rng, n, center, size):
+    """n points uniform (by area) on the 5 visible faces of an axis-aligned box."""
+    sx, sy, sz = size
+    areas = np.array([sx * sy, sx * sz, sx * sz, sy * sz, sy * sz])  # top, +-y, +-x
+    face = rng.choice(5, size=n, p=areas / areas.sum())
+    u = rng.uniform(-0.5, 0.5, size=(n, 3)) * size
+    u[face == 0, 2] = 0.5 * sz
+    u[face == 1, 1] = 0.5 * sy
+    u[face == 2, 1] = -0.5 * sy
+    u[face == 3, 0] = 0.5 * sx
+    u[face == 4, 0] = -0.5 * sx
+    return u + center
+
+
+def make_scene(index, num_points=40000, config=None, use_height=True, kind="surface",
+               extent_scale=1.0):
+    """One scene as a dict of numpy arrays (same keys/dtypes as the reference loader)."""
+    config = config or DatasetConfig(22, 1, 22)
+    rng = np.random.default_rng(1000 + int(index))
+    ext = np.array([rng.uniform(4, 8), rng.uniform(4, 8), rng.uniform(2.4, 3.0)])
+    ext[:2] *= extent_scale
+    nbox = int(rng.integers(8, 17))
+    sizes = rng.uniform(0.3, 1.5, size=(nbox, 3))
+    centers = np.empty((nbox, 3))
+    centers[:, 0] = rng.uniform(0.5 * sizes[:, 0], ext[0] - 0.5 * sizes[:, 0])
+    centers[:, 1] = rng.uniform(0.5 * sizes[:, 1], ext[1] - 0.5 * sizes[:, 1])
+    centers[:, 2] = 0.5 * sizes[:, 2]
+
+    N = int(num_points)
+    votes = np.zeros((N, 3))
+    vote_mask = np.zeros((N,), np.int64)
+    if kind == "surface":
+        n_floor = int(0.35 * N)
+        n_wall = int(0.35 * N)
+        n_obj = N - n_floor - n_wall
+        floor = np.stack([rng.uniform(0, ext[0], n_floor), rng.uniform(0, ext[1], n_floor),
+                          np.zeros(n_floor)], 1)
+        w = rng.integers(0, 4, n_wall)
+        t = rng.uniform(0, 1, n_wall)
+        wall = np.empty((n_wall, 3))
+        wall[:, 2] = rng.uniform(0, ext[2], n_wall)
+        wall[:, 0] = np.where(w == 0, 0.0, np.where(w == 1, ext[0], t * ext[0]))
+        wall[:, 1] = np.where(w == 2, 0.0, np.where(w == 3, ext[1], t * ext[1]))
+        per = rng.multinomial(n_obj, np.full(nbox, 1.0 / nbox))
+        obj, obj_vote = [], []
+        for b in range(nbox):
+            p = _points_on_box_faces(rng, per[b], centers[b], sizes[b])
+            obj.append(p)
+            obj_vote.append(centers[b] - p)
+        obj = np.concatenate(obj, 0)
+        pts = np.concatenate([floor, wall, obj], 0)
+        votes[n_floor + n_wall:] = np.concatenate(obj_vote, 0)
+        vote_mask[n_floor + n_wall:] = 1
+        pts = pts + rng.normal(0.0, 0.005, size=pts.shape)
+    elif kind == "uniform":
+        pts = rng.uniform(0, 1, size=(N, 3)) * ext
+        inside = np.zeros((N,), bool)
+        for b in range(nbox):
+            m = np.all(np.abs(pts - centers[b]) <= 0.5 * sizes[b], axis=1) & ~inside
+            votes[m] = centers[b] - pts[m]
+            inside |= m
+        vote_mask[inside] = 1
+    else:
+        raise ValueError(kind)
+    perm = rng.permutation(N)
+    pts, votes, vote_mask = pts[perm], votes[perm], vote_mask[perm]
+
+    pc = pts.astype(np.float32)
+    if use_height:
+        floor_h = np.percentile(pc[:, 2], 0.99)
+        pc = np.concatenate([pc, (pc[:, 2] - floor_h)[:, None]], 1).astype(np.float32)
+
+    K = config.max_num_obj
+    size_cls = rng.integers(0, config.num_size_cluster, nbox)
+    ret = {
+        'point_clouds': pc,
+        'center_label': np.zeros((K, 3), np.float32),
+        'heading_class_label': np.zeros((K,), np.int64),
+        'heading_residual_label': np.zeros((K,), np.float32),
+        'size_class_label': np.zeros((K,), np.int64),
+        'size_residual_label': np.zeros((K, 3), np.float32),
+        'sem_cls_label': np.zeros((K,), np.int64),
+        'box_label_mask': np.zeros((K,), np.float32),
+        'vote_label': np.tile(votes, (1, 3)).astype(np.float32),  # 3 identical GT votes
+        'vote_label_mask': vote_mask,
+    }
+    ret['center_label'][:nbox] = centers
+    ret['size_class_label'][:nbox] = size_cls
+    ret['size_residual_label'][:nbox] = sizes - config.mean_size_arr[size_cls]
+    ret['sem_cls_label'][:nbox] = size_cls % config.num_class
+    ret['box_label_mask'][:nbox] = 1.0
+    if config.num_heading_bin > 1:
+        ret['heading_class_label'][:nbox] = rng.integers(0, config.num_heading_bin, nbox)
+        ret['heading_residual_label'][:nbox] = rng.uniform(
+            -0.5, 0.5, nbox) * (2 * np.pi / config.num_heading_bin)
+    return ret
+
+
+def make_batch(first_index, batch_size, num_points=40000, config=None, use_height=True,
+               kind="surface", extent_scale=1.0, device=None):
+    """Stack `batch_size` consecutive scenes into a dict of torch tensors on `device`."""
+    scenes = [make_scene(first_index + i, num_points, config, use_height, kind, extent_scale)
+              for i in range(batch_size)]
+    batch = {k: torch.from_numpy(np.stack([s[k] for s in scenes], 0)) for k in scenes[0]}
+    if device is not None:
+        batch = {k: v.to(device) for k, v in batch.items()}
+    return batch

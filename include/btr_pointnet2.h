@@ -1,0 +1,121 @@
+/*
+ * btr_pointnet2.h -- C ABI of libbtr_pointnet2.so: the MI355X (gfx950) replacement for the
+ * native layer of the reference's `pointnet2._ext` extension.
+ *
+ * What it replaces.  The reference's pybind module (src/bindings.cpp:11-24) exposes nine
+ * functions whose C++ wrappers (src/{sampling,ball_query,group_points,interpolate}.cpp) check
+ * the tensors, allocate the result and call one `*_kernel_wrapper(int sizes..., const float*,
+ * ..., float*)` C function per op, which launches the CUDA kernel on the current stream.
+ * Those nine `*_kernel_wrapper` functions are the native boundary; each entry point below is
+ * the drop-in for one of them, with the same argument order and meaning plus
+ *   - a trailing `btr_stream_t` (the reference reads at::cuda::getCurrentCUDAStream() itself),
+ *   - an `int` status (0 = ok; the reference printf+exit(-1)s, include/cuda_utils.h:35-44).
+ * All pointers are DEVICE pointers to contiguous row-major arrays; sizes are element counts.
+ * No torch / ATen types cross this boundary.  Calls enqueue work on `stream` and return
+ * without synchronising.  Inputs are never written.  Unlike the reference (whose wrappers
+ * depend on torch::zeros-initialised outputs) every output element is fully defined by the
+ * call itself: callers may pass uninitialised memory.
+ *
+ * File:line citations are relative to
+ *   /root/reference/detection/Votenet/pointnet2/_ext_src/   (identical copy under GroupFree3D).
+ */
+#ifndef BTR_POINTNET2_H_
+#define BTR_POINTNET2_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *btr_stream_t; /* a hipStream_t; NULL = the null stream */
+
+#define BTR_OK 0
+#define BTR_ERR_INVALID_ARGUMENT (-1) /* bad size / null pointer; nothing was launched */
+/* positive values are hipError_t codes from the failed launch */
+
+/* Library identification: returns BTR_ABI_VERSION the .so was built with. */
+#define BTR_ABI_VERSION 1
+int btr_abi_version(void);
+
+/* Thread-local description of the last non-zero status returned on this thread ("" if none). */
+const char *btr_last_error(void);
+
+/* include/cuda_utils.h:20-24 `opt_n_threads`: the reference's block-size rule.  Exposed
+ * because the FPS tie-break depends on it (see btr_furthest_point_sampling). */
+int btr_opt_n_threads(int work_size);
+
+/* -------------------------------------------------------------------------------------------
+ * Replaces furthest_point_sampling_kernel_wrapper(b, n, m, dataset, temp, idxs)
+ *   decl src/sampling.cpp:16-18, def src/sampling_gpu.cu:180-234, kernel :74-178.
+ * dataset (b,n,3) f32 -> idxs (b,m) i32.  temp is the (b,n) f32 scratch of the reference
+ * signature; it is overwritten (no pre-fill with 1e10 needed, src/sampling.cpp:78-80) and its
+ * contents after the call are unspecified.
+ * Bit-exact semantics: idxs[0]=0; points with x*x+y*y+z*z <= 1e-3 never compete; distances
+ * in f32 exactly as written (no FMA contraction); ties between equal maxima resolve as the
+ * reference's 2^k-thread shared-memory tree does for block size opt_n_threads(n): smallest
+ * (bitreverse(k mod bs), k).  m <= 0 is a no-op.
+ * ------------------------------------------------------------------------------------------- */
+int btr_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                int *idxs, btr_stream_t stream);
+
+/* Same, with the reference block size given explicitly (1,2,4,...,512): used by parity tests
+ * to exercise the tie-break for every template instantiation of the reference kernel. */
+int btr_furthest_point_sampling_bs(int b, int n, int m, const float *dataset, float *temp,
+                                   int *idxs, int block_size, btr_stream_t stream);
+
+/* Replaces gather_points_kernel_wrapper(b, c, n, npoints, points, idx, out)
+ *   decl src/sampling.cpp:9-11, def src/sampling_gpu.cu:27-36, kernel :13-25.
+ * out[b,c,j] = points[b,c,idx[b,j]];  points (b,c,n) f32, idx (b,npoints) i32. */
+int btr_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                      float *out, btr_stream_t stream);
+
+/* Replaces gather_points_grad_kernel_wrapper(b, c, n, npoints, grad_out, idx, grad_points)
+ *   decl src/sampling.cpp:12-14, def src/sampling_gpu.cu:54-62, kernel :39-52.
+ * grad_points (b,c,n) = scatter-add of grad_out (b,c,npoints); zeroed by this call. */
+int btr_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                           const int *idx, float *grad_points, btr_stream_t stream);
+
+/* Replaces query_ball_point_kernel_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx)
+ *   decl src/ball_query.cpp:9-11, def src/ball_query_gpu.cu:51-59, kernel :14-49.
+ * new_xyz (b,m,3), xyz (b,n,3) f32 -> idx (b,m,nsample) i32: first nsample k (ascending) with
+ * d2 < radius*radius (f32, strict), short rows padded with the first hit, empty rows zero. */
+int btr_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int *idx, btr_stream_t stream);
+
+/* Replaces group_points_kernel_wrapper(b, c, n, npoints, nsample, points, idx, out)
+ *   decl src/group_points.cpp:9-11, def src/group_points_gpu.cu:35-44, kernel :13-33.
+ * out[b,c,j,k] = points[b,c,idx[b,j,k]]. */
+int btr_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                     const int *idx, float *out, btr_stream_t stream);
+
+/* Replaces group_points_grad_kernel_wrapper(b, c, n, npoints, nsample, grad_out, idx,
+ * grad_points)  decl src/group_points.cpp:13-15, def src/group_points_gpu.cu:71-80,
+ * kernel :48-69.  grad_points (b,c,n) zeroed by this call, then scatter-added. */
+int btr_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                          const int *idx, float *grad_points, btr_stream_t stream);
+
+/* Replaces three_nn_kernel_wrapper(b, n, m, unknown, known, dist2, idx)
+ *   decl src/interpolate.cpp:9-10, def src/interpolate_gpu.cu:66-73, kernel :14-64.
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) f32 SQUARED distances, idx (b,n,3) i32;
+ * earliest index wins ties; m < 3 leaves +inf / index 0 in the unused slots. */
+int btr_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                 int *idx, btr_stream_t stream);
+
+/* Replaces three_interpolate_kernel_wrapper(b, c, m, n, points, idx, weight, out)
+ *   decl src/interpolate.cpp:11-13, def src/interpolate_gpu.cu:108-117, kernel :77-106.
+ * out[b,c,j] = points[b,c,i1]*w1 + points[b,c,i2]*w2 + points[b,c,i3]*w3 (left to right). */
+int btr_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                          const float *weight, float *out, btr_stream_t stream);
+
+/* Replaces three_interpolate_grad_kernel_wrapper(b, c, n, m, grad_out, idx, weight,
+ * grad_points)  decl src/interpolate.cpp:14-17, def src/interpolate_gpu.cu:150-159,
+ * kernel :121-148.  grad_points (b,c,m) zeroed by this call, then scatter-added. */
+int btr_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                               const int *idx, const float *weight, float *grad_points,
+                               btr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTR_POINTNET2_H_ */
