@@ -209,7 +209,8 @@ static int launch_fps(int b, int n, int m, int bs, int log2bs, const float *data
 static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,
                         int bs, hipStream_t s) {
   if (m <= 0 || b <= 0) return BTR_OK;  // sampling_gpu.cu:78
-  BTR_REQUIRE(n > 0 && dataset && idxs, "furthest_point_sampling: n=%d must be > 0", n);
+  BTR_REQUIRE(n > 0 && dataset && idxs,
+              "furthest_point_sampling: null pointer or n=%d <= 0", n);
   BTR_REQUIRE(bs >= 1 && bs <= 512 && (bs & (bs - 1)) == 0,
               "furthest_point_sampling: block_size %d is not a power of two in [1,512]", bs);
   BTR_REQUIRE((long long)n + 512 < 0x7fffffffLL, "furthest_point_sampling: n too large");

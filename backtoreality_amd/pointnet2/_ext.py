@@ -91,8 +91,37 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-def _call(fn, *args):
+_TIMING = None  # None = off; else list of (op, shape-key, start_event, end_event)
+
+
+def timing_begin():
+    """Start recording a HIP event pair around every kernel launch made through this module
+    (on the launch stream).  Used by bench.py for the live per-kernel durations."""
+    global _TIMING
+    _TIMING = []
+
+
+def timing_end():
+    """Stop recording; returns {(op, shape-key): [ms per launch, ...]} (synchronises)."""
+    global _TIMING
+    rec, _TIMING = _TIMING or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for op, key, e0, e1 in rec:
+        out.setdefault((op, key), []).append(e0.elapsed_time(e1))
+    return out
+
+
+def _call(fn, *args, key=None):
+    timed = _TIMING is not None and key is not None
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = fn(*args)
+    if timed:
+        e1.record()
+        _TIMING.append((fn.__name__.replace("btr_", "").replace("_ws", ""), key, e0, e1))
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" %
                            (fn.__name__, rc, _lib.btr_last_error().decode(errors="replace")))
@@ -131,7 +160,7 @@ def furthest_point_sampling(points, nsamples):
     temp = torch.empty((B, N), dtype=torch.float32, device=points.device)
     with _on(points) as dev:
         _call(_lib.btr_furthest_point_sampling, B, N, nsamples, _p(points), _p(temp), _p(out),
-              _stream(dev))
+              _stream(dev), key=(B, N, nsamples))
     return out
 
 
@@ -188,7 +217,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
           if ws_bytes else None)
     with _on(new_xyz) as dev:
         _call(_lib.btr_ball_query_ws, B, N, M, float(radius), nsample, _p(new_xyz), _p(xyz),
-              _p(out), _p(ws), ws_bytes, _stream(dev))
+              _p(out), _p(ws), ws_bytes, _stream(dev), key=(B, N, M, nsample))
     return out
 
 
@@ -201,7 +230,8 @@ def group_points(points, idx):
     _, M, S = idx.shape
     out = torch.empty((B, C, M, S), dtype=torch.float32, device=points.device)
     with _on(points) as dev:
-        _call(_lib.btr_group_points, B, C, N, M, S, _p(points), _p(idx), _p(out), _stream(dev))
+        _call(_lib.btr_group_points, B, C, N, M, S, _p(points), _p(idx), _p(out), _stream(dev),
+              key=(B, C, N, M, S))
     return out
 
 
@@ -214,7 +244,7 @@ def group_points_grad(grad_out, idx, n):
     out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
     with _on(grad_out) as dev:
         _call(_lib.btr_group_points_grad, B, C, int(n), M, S, _p(grad_out), _p(idx), _p(out),
-              _stream(dev))
+              _stream(dev), key=(B, C, int(n), M, S))
     return out
 
 

@@ -83,6 +83,13 @@ int btr_gather_points_grad(int b, int c, int n, int npoints, const float *grad_o
 int btr_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                    const float *xyz, int *idx, btr_stream_t stream);
 
+/* Same with caller-provided scratch (what the torch shim uses: its caching allocator is
+ * stream-ordered and free).  btr_ball_query itself takes the scratch from hipMallocAsync. */
+size_t btr_ball_query_workspace_bytes(int b, int n, int m, int nsample);
+int btr_ball_query_ws(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                      const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                      btr_stream_t stream);
+
 /* Replaces group_points_kernel_wrapper(b, c, n, npoints, nsample, points, idx, out)
  *   decl src/group_points.cpp:9-11, def src/group_points_gpu.cu:35-44, kernel :13-33.
  * out[b,c,j,k] = points[b,c,idx[b,j,k]]. */

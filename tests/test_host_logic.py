@@ -1,0 +1,154 @@
+"""Host-side mirror of the reference interface: names, signatures, state-dict keys, error
+behaviour (no GPU needed)."""
+import inspect
+import subprocess
+import sys
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from backtoreality_amd.pointnet2 import pointnet2_modules as M
+from backtoreality_amd.pointnet2 import pointnet2_utils as U
+from backtoreality_amd.pointnet2 import pytorch_utils as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_public_names_of_pointnet2_utils():
+    for name in ("furthest_point_sample", "gather_operation", "three_nn", "three_interpolate",
+                 "grouping_operation", "ball_query", "QueryAndGroup", "GroupAll",
+                 "FurthestPointSampling", "GatherOperation", "ThreeNN", "ThreeInterpolate",
+                 "GroupingOperation", "BallQuery", "RandomDropout"):
+        assert hasattr(U, name), name
+    sig = inspect.signature(U.QueryAndGroup.__init__)
+    assert list(sig.parameters)[1:] == ["radius", "nsample", "use_xyz", "ret_grouped_xyz",
+                                        "normalize_xyz", "sample_uniformly", "ret_unique_cnt"]
+
+
+def test_modules_are_keyword_only_like_the_reference():
+    with pytest.raises(TypeError):
+        M.PointnetSAModuleVotes([1, 8], 16, 0.2, 8)
+    with pytest.raises(TypeError):
+        M.PointnetFPModule([4, 4])
+    for name in ("PointnetSAModuleVotes", "PointnetFPModule", "PointnetSAModuleCenters",
+                 "PointnetSAModuleMSG", "PointnetSAModule", "PointnetSAModuleMSGVotes",
+                 "PointnetLFPModuleMSG", "_PointnetSAModuleBase"):
+        assert hasattr(M, name)
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    sa = M.PointnetSAModuleVotes(npoint=8, radius=0.2, nsample=4, mlp=[1, 8, 16], use_xyz=True)
+    keys = list(sa.state_dict().keys())
+    assert keys[:6] == ["mlp_module.layer0.conv.weight", "mlp_module.layer0.bn.bn.weight",
+                        "mlp_module.layer0.bn.bn.bias", "mlp_module.layer0.bn.bn.running_mean",
+                        "mlp_module.layer0.bn.bn.running_var",
+                        "mlp_module.layer0.bn.bn.num_batches_tracked"]
+    assert sa.state_dict()["mlp_module.layer0.conv.weight"].shape == (8, 4, 1, 1)  # +3 xyz
+    fp = M.PointnetFPModule(mlp=[6, 4])
+    assert "mlp.layer0.conv.weight" in fp.state_dict()
+    # bias only without batch norm (pytorch_utils.py:87)
+    assert "layer0.conv.bias" in P.SharedMLP([3, 4], bn=False).state_dict()
+    assert "layer0.conv.bias" not in P.SharedMLP([3, 4], bn=True).state_dict()
+    blk = P.Conv1d(3, 4, bn=True, preact=True)
+    assert [n for n, _ in blk.named_children()] == ["bn", "activation", "conv"]
+    assert blk.bn.bn.num_features == 3
+    fc = P.FC(3, 4, bn=True)
+    assert [n for n, _ in fc.named_children()] == ["fc", "bn", "activation"]
+
+
+def test_bn_momentum_scheduler():
+    net = P.SharedMLP([3, 4, 5], bn=True)
+    sched = P.BNMomentumScheduler(net, lambda e: max(0.5 * 0.5 ** (e // 20), 0.001))
+    assert net.layer0.bn.bn.momentum == 0.5
+    sched.step(40)
+    assert net.layer1.bn.bn.momentum == 0.125
+    with pytest.raises(RuntimeError):
+        P.BNMomentumScheduler(object(), lambda e: 0.1)
+
+
+def test_product_ext_refuses_cpu_tensors():
+    from backtoreality_amd.pointnet2 import _ext
+    assert U._ext is _ext
+    x = torch.zeros(1, 8, 3)
+    for call in (lambda: _ext.furthest_point_sampling(x, 2),
+                 lambda: _ext.ball_query(x, x, 0.1, 2),
+                 lambda: _ext.three_nn(x, x),
+                 lambda: _ext.gather_points(torch.zeros(1, 3, 8), torch.zeros(1, 2, dtype=torch.int32)),
+                 lambda: U.furthest_point_sample(x, 2)):
+        with pytest.raises(RuntimeError, match="CPU not supported"):
+            call()
+    with pytest.raises(RuntimeError, match="contiguous"):
+        _ext.furthest_point_sampling(torch.zeros(1, 3, 8).transpose(1, 2), 2)
+
+
+def test_query_and_group_and_group_all(oracle_ext):
+    rng = np.random.default_rng(0)
+    xyz = torch.from_numpy(rng.uniform(0.3, 2, (2, 64, 3)).astype(np.float32))
+    feats = torch.from_numpy(rng.standard_normal((2, 5, 64)).astype(np.float32))
+    inds = U.furthest_point_sample(xyz, 8)
+    new_xyz = U.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    g = U.QueryAndGroup(0.7, 6, use_xyz=True, ret_grouped_xyz=True, normalize_xyz=True)
+    nf, gx = g(xyz, new_xyz, feats)
+    assert nf.shape == (2, 8, 8, 6) and gx.shape == (2, 3, 8, 6)
+    idx = U.ball_query(0.7, 6, xyz, new_xyz).long()
+    want = (torch.gather(xyz, 1, idx.view(2, -1, 1).expand(-1, -1, 3)).view(2, 8, 6, 3)
+            - new_xyz.unsqueeze(2)) / 0.7
+    torch.testing.assert_close(gx.permute(0, 2, 3, 1), want)
+    assert U.QueryAndGroup(0.7, 6, use_xyz=False)(xyz, new_xyz, feats).shape == (2, 5, 8, 6)
+    with pytest.raises(AssertionError):
+        U.QueryAndGroup(0.7, 6, use_xyz=False)(xyz, new_xyz, None)
+    ga = U.GroupAll(use_xyz=True, ret_grouped_xyz=True)
+    nf, gx = ga(xyz, None, feats)
+    assert nf.shape == (2, 8, 1, 64) and gx.shape == (2, 3, 1, 64)
+    # sample_uniformly keeps every row a multiset of its unique neighbours (:336-345)
+    torch.manual_seed(0)
+    gu = U.QueryAndGroup(0.7, 6, use_xyz=True, sample_uniformly=True, ret_unique_cnt=True)
+    nf, cnt = gu(xyz, new_xyz, feats)
+    assert nf.shape == (2, 8, 8, 6) and cnt.shape == (2, 8) and cnt.min() >= 1
+
+
+def test_sa_variants_run(oracle_ext):
+    rng = np.random.default_rng(1)
+    xyz = torch.from_numpy(rng.uniform(0.3, 2, (2, 96, 3)).astype(np.float32))
+    feats = torch.from_numpy(rng.standard_normal((2, 4, 96)).astype(np.float32)).requires_grad_()
+    torch.manual_seed(0)
+    sa = M.PointnetSAModuleVotes(npoint=16, radius=0.6, nsample=8, mlp=[4, 8, 8], use_xyz=True,
+                                 normalize_xyz=True)
+    new_xyz, nf, inds = sa(xyz, feats)
+    assert new_xyz.shape == (2, 16, 3) and nf.shape == (2, 8, 16) and inds.dtype == torch.int32
+    nf.sum().backward()
+    assert feats.grad.abs().sum() > 0
+    # given indices are used as they are (:234-237)
+    given = torch.arange(16, dtype=torch.int32).repeat(2, 1)
+    nx2, _, i2 = sa(xyz, feats, given)
+    assert torch.equal(i2, given) and torch.equal(nx2, xyz[:, :16])
+    for pooling in ("avg", "rbf"):
+        m = M.PointnetSAModuleVotes(npoint=16, radius=0.6, nsample=8, mlp=[4, 8], pooling=pooling)
+        assert m(xyz, feats)[1].shape == (2, 8, 16)
+    centers = M.PointnetSAModuleCenters(npoint=5, radius=0.8, nsample=16, mlp=[4, 8])
+    assert centers(xyz, feats, xyz[:, :5].contiguous()).shape == (2, 8, 5)
+    msg = M.PointnetSAModuleMSG(npoint=16, radii=[0.4, 0.8], nsamples=[4, 8],
+                                mlps=[[4, 8], [4, 16]])
+    nx, nf = msg(xyz, feats)
+    assert nf.shape == (2, 24, 16)
+    msgv = M.PointnetSAModuleMSGVotes(npoint=16, radii=[0.4], nsamples=[4], mlps=[[4, 8]])
+    assert msgv(xyz, feats)[2].shape == (2, 16)
+    lfp = M.PointnetLFPModuleMSG(mlps=[[4, 8]], radii=[0.6], nsamples=[8], post_mlp=[8 + 3, 6])
+    out = lfp(xyz[:, :16].contiguous(), xyz, torch.zeros(2, 3, 16), feats)
+    assert out.shape == (2, 6, 16)
+
+
+def test_drop_in_top_level_imports_like_reference_scripts():
+    """train_Votenet_FSB.py:35-38 does sys.path.append(ROOT/pointnet2) and imports
+    pointnet2_modules / pointnet2_utils / pytorch_utils as top-level modules."""
+    code = (
+        "import sys; sys.path.append(%r)\n"
+        "import pointnet2_modules, pointnet2_utils, pytorch_utils\n"
+        "from pointnet2_modules import PointnetSAModuleVotes, PointnetFPModule\n"
+        "import pointnet2._ext as e\n"
+        "assert pointnet2_utils._ext is e and callable(e.ball_query)\n"
+        "print('ok')\n" % os.path.join(ROOT, "backtoreality_amd", "pointnet2"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr

@@ -1,0 +1,184 @@
+"""GPU parity: every op of the C ABI (through `pointnet2._ext`) against the CPU oracle.
+Indices must be bit-exact; float outputs of pure copies bit-exact; scatter-adds (atomics,
+unordered) within 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from backtoreality_amd.votenet import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _ext():
+    from backtoreality_amd.pointnet2 import _ext
+    return _ext
+
+
+def _scene_xyz(B, N, first=0, kind="surface"):
+    return np.stack([synthetic.make_scene(first + i, N, use_height=False, kind=kind)['point_clouds']
+                     for i in range(B)], 0)
+
+
+def _t(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+# ----------------------------------------------------------------------------------- FPS
+@pytest.mark.parametrize("B,N,M", [(2, 64, 16), (3, 200, 50), (2, 1000, 256), (2, 2048, 1024),
+                                   (2, 4096, 2048), (1, 7000, 300), (2, 20000, 512)])
+def test_fps_matches_oracle(cuda, B, N, M):
+    xyz = _scene_xyz(B, N)
+    ref = oracle.furthest_point_sampling(xyz, M)
+    got = _ext().furthest_point_sampling(_t(xyz, cuda), M).cpu().numpy()
+    assert got.dtype == np.int32
+    np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("bs", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512])
+@pytest.mark.parametrize("N", [1500, 9000])
+def test_fps_tie_break_every_block_size(cuda, bs, N):
+    """Duplicated points force exact ties; the winner must follow the reference's tree for
+    every template instantiation of its kernel (sampling_gpu.cu:121-174)."""
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0.2, 3.0, size=(2, N // 3, 3)).astype(np.float32)
+    xyz = np.concatenate([base, base, base], 1)
+    ref = oracle.furthest_point_sampling(xyz, 200, block_size=bs)
+    got = _ext().furthest_point_sampling_bs(_t(xyz, cuda), 200, bs).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_origin_skip_and_degenerate(cuda):
+    rng = np.random.default_rng(11)
+    xyz = rng.uniform(-2, 2, size=(2, 3000, 3)).astype(np.float32)
+    xyz[:, 100:400] *= 0.01          # inside the x^2+y^2+z^2 <= 1e-3 ball: never selected
+    xyz[1, 0] = 0.0                  # index 0 is always the first sample, even if skipped
+    ref = oracle.furthest_point_sampling(xyz, 500)
+    got = _ext().furthest_point_sampling(_t(xyz, cuda), 500).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    allzero = np.zeros((1, 300, 3), np.float32)  # nothing competes -> every index is 0
+    got = _ext().furthest_point_sampling(_t(allzero, cuda), 10).cpu().numpy()
+    np.testing.assert_array_equal(got, np.zeros((1, 10), np.int32))
+    assert _ext().furthest_point_sampling(_t(xyz, cuda), 0).shape == (2, 0)
+
+
+def test_fps_prefix_invariant(cuda):
+    """FPS over an FPS-ordered prefix returns arange (backbone_module.py:113-132 relies on it)."""
+    xyz = _scene_xyz(2, 8192)
+    x = _t(xyz, cuda)
+    inds = _ext().furthest_point_sampling(x, 2048)
+    sub = torch.gather(x, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    again = _ext().furthest_point_sampling(sub, 1024).cpu().numpy()
+    np.testing.assert_array_equal(again, np.tile(np.arange(1024, dtype=np.int32), (2, 1)))
+
+
+# ---------------------------------------------------------------------------- ball query
+@pytest.mark.parametrize("B,N,M,r,S", [(2, 4096, 512, 0.2, 64), (2, 2048, 1024, 0.4, 32),
+                                       (2, 1024, 512, 0.8, 16), (3, 512, 256, 1.2, 16),
+                                       (1, 300, 77, 0.3, 5), (2, 20000, 2048, 0.2, 64)])
+def test_ball_query_matches_oracle(cuda, B, N, M, r, S):
+    xyz = _scene_xyz(B, N)
+    inds = oracle.furthest_point_sampling(xyz, M)
+    new_xyz = np.take_along_axis(xyz, inds[:, :, None].astype(np.int64), 1)
+    ref = oracle.ball_query(new_xyz, xyz, r, S)
+    got = _ext().ball_query(_t(new_xyz, cuda), _t(xyz, cuda), r, S).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_ball_query_edge_cases(cuda):
+    xyz = np.zeros((1, 70, 3), np.float32)
+    xyz[0, :, 0] = np.arange(70) * 0.5
+    centres = np.array([[[100.0, 0, 0], [0.0, 0, 0], [0.5, 0, 0], [10.0, 0, 0]]], np.float32)
+    # empty ball -> zeros; short ball -> padded with first hit; d2 == r2 is excluded (strict <)
+    ref = oracle.ball_query(centres, xyz, 0.5, 4)
+    got = _ext().ball_query(_t(centres, cuda), _t(xyz, cuda), 0.5, 4).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    np.testing.assert_array_equal(got[0, 0], [0, 0, 0, 0])
+    np.testing.assert_array_equal(got[0, 2], [1, 1, 1, 1])
+    ref = oracle.ball_query(centres, xyz, 1.25, 4)   # full ball -> first 4 in index order
+    got = _ext().ball_query(_t(centres, cuda), _t(xyz, cuda), 1.25, 4).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+# -------------------------------------------------------------------- gather / group (+grad)
+@pytest.mark.parametrize("B,C,N,M", [(2, 3, 4096, 2048), (3, 7, 100, 33), (2, 288, 1024, 256)])
+def test_gather_points(cuda, B, C, N, M):
+    rng = np.random.default_rng(0)
+    pts = rng.standard_normal((B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, (B, M)).astype(np.int32)
+    got = _ext().gather_points(_t(pts, cuda), _t(idx, cuda)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.gather_points(pts, idx))
+    go = rng.standard_normal((B, C, M)).astype(np.float32)
+    idx[:, : M // 2] = idx[:, :1]  # heavy collisions
+    got = _ext().gather_points_grad(_t(go, cuda), _t(idx, cuda), N).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.gather_points_grad(go, idx, N), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,N,M,S", [(2, 4, 4096, 512, 64), (2, 131, 2048, 256, 32),
+                                       (1, 259, 512, 64, 16), (3, 5, 50, 7, 3)])
+def test_group_points(cuda, B, C, N, M, S):
+    rng = np.random.default_rng(1)
+    pts = rng.standard_normal((B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, (B, M, S)).astype(np.int32)
+    idx[:, :, S // 2:] = idx[:, :, :1]  # padded rows repeat their first neighbour
+    got = _ext().group_points(_t(pts, cuda), _t(idx, cuda)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.group_points(pts, idx))
+    go = rng.standard_normal((B, C, M, S)).astype(np.float32)
+    got = _ext().group_points_grad(_t(go, cuda), _t(idx, cuda), N).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.group_points_grad(go, idx, N), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------ three_nn / interp
+@pytest.mark.parametrize("B,n,m", [(2, 512, 256), (2, 1024, 512), (1, 100, 2), (2, 33, 3)])
+def test_three_nn(cuda, B, n, m):
+    rng = np.random.default_rng(2)
+    unknown = rng.uniform(0, 4, (B, n, 3)).astype(np.float32)
+    known = rng.uniform(0, 4, (B, m, 3)).astype(np.float32)
+    if m >= 3:
+        known[:, 2] = known[:, 0]  # exact tie: earliest index must win
+    d_ref, i_ref = oracle.three_nn(unknown, known)
+    d, i = _ext().three_nn(_t(unknown, cuda), _t(known, cuda))
+    np.testing.assert_array_equal(i.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d.cpu().numpy(), d_ref)  # inf where m < 3
+
+
+@pytest.mark.parametrize("B,C,m,n", [(2, 256, 256, 512), (2, 256, 512, 1024), (1, 3, 10, 7)])
+def test_three_interpolate(cuda, B, C, m, n):
+    rng = np.random.default_rng(3)
+    pts = rng.standard_normal((B, C, m)).astype(np.float32)
+    idx = rng.integers(0, m, (B, n, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, (B, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    got = _ext().three_interpolate(_t(pts, cuda), _t(idx, cuda), _t(w, cuda)).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.three_interpolate(pts, idx, w))
+    go = rng.standard_normal((B, C, n)).astype(np.float32)
+    got = _ext().three_interpolate_grad(_t(go, cuda), _t(idx, cuda), _t(w, cuda), m).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.three_interpolate_grad(go, idx, w, m), rtol=1e-4,
+                               atol=1e-5)
+
+
+def test_reference_gradcheck_three_interpolate(cuda):
+    """The reference's only test (pointnet2_test.py:18-30): gradcheck of three_interpolate on
+    a (1,2,4) tensor with fixed idx/weight, atol=rtol=1e-1."""
+    from backtoreality_amd.pointnet2 import pointnet2_utils
+    feats = torch.tensor([[[1., 2., 3., 4.], [5., 6., 7., 8.]]], device=cuda, requires_grad=True)
+    idx = torch.tensor([[[0, 1, 2], [1, 2, 3]]], dtype=torch.int32, device=cuda)
+    weight = torch.tensor([[[1., 1., 1.], [2., 2., 2.]]], device=cuda)
+    assert torch.autograd.gradcheck(
+        lambda f: pointnet2_utils.three_interpolate(f, idx, weight), (feats,), atol=1e-1,
+        rtol=1e-1, eps=1e-2, nondet_tol=1e-3)
+
+
+def test_errors_match_reference(cuda):
+    e = _ext()
+    x = torch.zeros(1, 10, 3)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        e.furthest_point_sampling(x, 2)
+    xc = torch.zeros(1, 10, 3, device=cuda)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        e.furthest_point_sampling(xc.transpose(1, 2).transpose(1, 2)[:, ::2], 2)
+    with pytest.raises(RuntimeError, match="int tensor"):
+        e.gather_points(torch.zeros(1, 3, 10, device=cuda), torch.zeros(1, 4, device=cuda))
+    with pytest.raises(RuntimeError, match="float tensor"):
+        e.three_nn(xc.double(), xc)
