@@ -1,0 +1,374 @@
+// fps_bucket.hip -- furthest point sampling for large scenes (n > 4096) on gfx950:
+// Morton-bucketed points + exact bounding-box pruning, one workgroup (one CU) per scene.
+//
+// Why: FPS is a chain of m-1 dependent arg-max steps; a 40 000-point scene does not fit one
+// CU's registers (640 KB of x,y,z,min-dist), and a cross-CU exchange costs >= 1 us per step
+// (MI355X_MICROARCH.md price list), so the per-step work is cut instead:
+//   * fps_sort_kernel   counting-sorts the scene by a 15-bit Morton cell (32^3 grid, LDS
+//     histogram) into buckets of 64 consecutive points = one wave-wide load each;
+//   * fps_bucket_kernel keeps, per bucket, its bounding box and its current best key
+//     (max min-dist, tie key, coordinates) lane-parallel in VGPRs.  A new sample s only
+//     touches buckets whose box lower bound d_box(s) is below the bucket's max min-dist.
+// Exactness of the pruning: d_box is evaluated with the SAME f32 expression as the point
+// distance, on the per-axis clamp of s to the box.  Every f32 operation involved (subtract,
+// square, add) is monotone in |x2 - x1|, so d_box <= d(p) holds for the ROUNDED values of
+// every point p of the bucket; if d_box >= max min-dist, min(d, temp) leaves every temp
+// unchanged, bit for bit.  The bucket order only affects speed: keys (d2, tie key) are unique
+// per point, so the arg-max -- and therefore the result -- is independent of the sort.
+// Selection rule / tie-break: identical to sampling.hip (reference sampling_gpu.cu:74-178).
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace btr {
+
+constexpr int kSortThreads = 1024;
+constexpr int kCells = 32768;  // 32^3 Morton cells
+
+__device__ __forceinline__ unsigned spread5(unsigned v) {  // 5 bits -> every third bit
+  v &= 31u;
+  v = (v | (v << 8)) & 0x100Fu;
+  v = (v | (v << 4)) & 0x10C3u;
+  v = (v | (v << 2)) & 0x1249u;
+  return v;
+}
+
+__device__ __forceinline__ int morton_cell(float x, float y, float z, float mnx, float mny,
+                                           float mnz, float scale) {
+  const int qx = min(31, max(0, (int)((x - mnx) * scale)));
+  const int qy = min(31, max(0, (int)((y - mny) * scale)));
+  const int qz = min(31, max(0, (int)((z - mnz) * scale)));
+  return (int)(spread5(qx) | (spread5(qy) << 1) | (spread5(qz) << 2));
+}
+
+// One workgroup per scene.  Output: spts[np] = {x, y, z, t0} with t0 = 1e10 (competing) or -1
+// (skipped by the |p|^2 <= 1e-3 rule, or padding), sk[np] = original index (-1 for padding),
+// np = 64 * ceil(n / 64), both in Morton-cell order.
+__global__ __launch_bounds__(kSortThreads) void fps_sort_kernel(
+    int n, int np, const float *__restrict__ dataset, float4 *__restrict__ spts,
+    int *__restrict__ sk) {
+  extern __shared__ __attribute__((aligned(16))) int smem[];
+  int *hist = smem;                       // kCells
+  float *red = (float *)(smem + kCells);  // 6 * 16 floats
+  int *wsum = smem + kCells + 96;         // 16 ints
+
+  const int bi = blockIdx.x;
+  dataset += (size_t)bi * n * 3;
+  spts += (size_t)bi * np;
+  sk += (size_t)bi * np;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // 1. scene bounding box
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int k = tid; k < n; k += kSortThreads) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = dataset[k * 3 + a];
+      mn[a] = fminf(mn[a], v);
+      mx[a] = fmaxf(mx[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+    }
+    if (lane == 0) {
+      red[a * 16 + wave] = mn[a];
+      red[(3 + a) * 16 + wave] = mx[a];
+    }
+  }
+  for (int c = tid; c < kCells; c += kSortThreads) hist[c] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float lo = red[a * 16], hi = red[(3 + a) * 16];
+    for (int w = 1; w < 16; ++w) {
+      lo = fminf(lo, red[a * 16 + w]);
+      hi = fmaxf(hi, red[(3 + a) * 16 + w]);
+    }
+    mn[a] = lo;
+    mx[a] = hi;
+  }
+  const float ext = fmaxf(fmaxf(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+  const float scale = ext > 0.f ? 32.f / ext : 0.f;
+
+  // 2. histogram over Morton cells (LDS atomics)
+  for (int k = tid; k < n; k += kSortThreads) {
+    const int c = morton_cell(dataset[k * 3], dataset[k * 3 + 1], dataset[k * 3 + 2], mn[0],
+                              mn[1], mn[2], scale);
+    atomicAdd(&hist[c], 1);
+  }
+  __syncthreads();
+
+  // 3. exclusive scan: 32 consecutive cells per thread, then a block scan of the partials
+  constexpr int PER = kCells / kSortThreads;
+  int local[PER];
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    local[i] = hist[tid * PER + i];
+    sum += local[i];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  int run = base + incl - sum;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    hist[tid * PER + i] = run;
+    run += local[i];
+  }
+  __syncthreads();
+
+  // 4. scatter (order inside a cell is arbitrary: it cannot change the result)
+  for (int k = tid; k < n; k += kSortThreads) {
+    const float x = dataset[k * 3], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
+    const int c = morton_cell(x, y, z, mn[0], mn[1], mn[2], scale);
+    const int pos = atomicAdd(&hist[c], 1);
+    const float mag = (x * x) + (y * y) + (z * z);
+    const float t0 = ((double)mag <= 1e-3) ? -1.f : 1e10f;  // sampling_gpu.cu:105-106
+    spts[pos] = make_float4(x, y, z, t0);
+    sk[pos] = k;
+  }
+  __syncthreads();
+  // 5. pad the last bucket with non-competing copies of the last sorted point
+  if (n + tid < np) {
+    float4 p = spts[n - 1];
+    p.w = -1.f;
+    spts[n + tid] = p;
+    sk[n + tid] = -1;
+  }
+}
+
+__device__ __forceinline__ unsigned fps_tk2(int k, int bs, int log2bs, int cpb) {
+  const unsigned r = log2bs == 0 ? 0u : (__brev((unsigned)(k & (bs - 1))) >> (32 - log2bs));
+  return r * (unsigned)cpb + (unsigned)(k >> log2bs);
+}
+
+struct TieParams {
+  int bs, log2bs, cpb;
+};
+
+// max over the wave of `hi`; winner = the lane with that hi and, on exact ties (duplicated
+// points), the largest lo.  lo is only looked at when two lanes tie.  Returns the lane.
+template <typename LoFn>
+__device__ __forceinline__ int wave_argmax(unsigned hi, LoFn lo_of_lane, unsigned &mh) {
+  mh = wave_max_u32(hi);
+  const unsigned long long cand = __ballot(hi == mh);
+  if (__builtin_popcountll(cand) == 1) return __builtin_ctzll(cand);
+  const unsigned lo = (hi == mh) ? lo_of_lane() : 0u;
+  const unsigned ml = wave_max_u32(lo);
+  return __builtin_ctzll(__ballot(hi == mh && lo == ml));
+}
+
+struct BSlot {
+  unsigned hi, lo;
+  int k;
+  float x, y, z;
+  int pad0, pad1;
+};
+
+__device__ __forceinline__ float rl_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// One workgroup of NW waves per scene.  Every lane keeps the state of SL buckets: bucket b
+// lives in wave b % NW, lane (b / NW) % 64, slot b / (64 NW) (neighbouring buckets go to
+// different waves: the few buckets a late sample touches update in parallel -- each update is
+// an L2 round trip plus a wave reduction, so 16 waves beat 4 here: measured 2.85 vs 5.4 ms on
+// 8 x 40000 -> 2048).
+template <int NW, int SL>
+__global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int m, int bs,
+                                                         int log2bs,
+                                                         const float *__restrict__ dataset,
+                                                         float4 *__restrict__ spts,
+                                                         const int *__restrict__ sk,
+                                                         int *__restrict__ idxs) {
+  __shared__ BSlot slots[2][NW];
+
+  const int bi = blockIdx.x;
+  dataset += (size_t)bi * n * 3;
+  spts += (size_t)bi * np;
+  sk += (size_t)bi * np;
+  idxs += (size_t)bi * m;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = np >> 6;
+  const TieParams tp{bs, log2bs, (n + bs - 1) >> log2bs};
+
+  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
+
+  // ---- per-slot bucket state (registers; every loop over s is fully unrolled)
+  float bx0[SL], by0[SL], bz0[SL], bx1[SL], by1[SL], bz1[SL];  // bounding box
+  unsigned mhi[SL], mlo[SL];                                   // best key of the bucket
+  int mk[SL];                                                  // ... its original index
+  float mx[SL], my[SL], mz[SL];                                // ... and coordinates
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    const int myb = (s * 64 + lane) * NW + wave;
+    bx0[s] = by0[s] = bz0[s] = bx1[s] = by1[s] = bz1[s] = 0.f;
+    mhi[s] = mlo[s] = 0u;
+    mk[s] = 0;
+    mx[s] = my[s] = mz[s] = 0.f;
+    if (myb < nb) {
+      const float4 *p = spts + (size_t)myb * 64;
+      float4 q = p[0];
+      float ax0 = q.x, ax1 = q.x, ay0 = q.y, ay1 = q.y, az0 = q.z, az1 = q.z;
+      bool any = q.w >= 0.f;
+#pragma unroll 8
+      for (int i = 1; i < 64; ++i) {
+        q = p[i];
+        ax0 = fminf(ax0, q.x); ax1 = fmaxf(ax1, q.x);
+        ay0 = fminf(ay0, q.y); ay1 = fmaxf(ay1, q.y);
+        az0 = fminf(az0, q.z); az1 = fmaxf(az1, q.z);
+        any |= q.w >= 0.f;
+      }
+      bx0[s] = ax0; bx1[s] = ax1; by0[s] = ay0; by1[s] = ay1; bz0[s] = az0; bz1[s] = az1;
+      mhi[s] = any ? __float_as_uint(1e10f) + 1u : 0u;  // competing points start at 1e10
+    }
+  }
+
+  if (tid == 0) idxs[0] = 0;
+  float sx = x0, sy = y0, sz = z0;
+
+  for (int j = 1; j < m; ++j) {
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      // lower bound of the distance from the sample to the bucket, rounded exactly like the
+      // point distance (see the header comment): skip the bucket when it cannot change
+      const float cx = fminf(fmaxf(sx, bx0[s]), bx1[s]);
+      const float cy = fminf(fmaxf(sy, by0[s]), by1[s]);
+      const float cz = fminf(fmaxf(sz, bz0[s]), bz1[s]);
+      const float ex = cx - sx, ey = cy - sy, ez = cz - sz;
+      const float dbox = ex * ex + ey * ey + ez * ez;
+      const bool active = (__float_as_uint(dbox) + 1u) < mhi[s];  // mhi == 0: none competes
+      unsigned long long todo = __ballot(active);
+      while (todo) {
+        const int i = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int b = (s * 64 + i) * NW + wave;
+        float4 *pp = spts + (size_t)b * 64 + lane;
+        const float4 p = *pp;
+        const int k = sk[(size_t)b * 64 + lane];
+        const float dx = p.x - sx, dy = p.y - sy, dz = p.z - sz;
+        const float d = dx * dx + dy * dy + dz * dz;
+        const bool valid = p.w >= 0.f;
+        const float t = valid ? fminf(d, p.w) : p.w;
+        if (t != p.w) pp->w = t;
+        const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
+        unsigned mh;
+        const int w = wave_argmax(
+            hi, [&]() { return 0xffffffffu - fps_tk2(k, tp.bs, tp.log2bs, tp.cpb); }, mh);
+        const int wk = __builtin_amdgcn_readlane(k, w);  // wave-uniform: scalar tie key
+        const unsigned wlo = 0xffffffffu - fps_tk2(wk, tp.bs, tp.log2bs, tp.cpb);
+        const bool mine = lane == i;  // the lane slot that keeps this bucket's state
+        mhi[s] = mine ? mh : mhi[s];
+        mlo[s] = mine ? wlo : mlo[s];
+        mk[s] = mine ? wk : mk[s];
+        mx[s] = mine ? rl_f(p.x, w) : mx[s];
+        my[s] = mine ? rl_f(p.y, w) : my[s];
+        mz[s] = mine ? rl_f(p.z, w) : mz[s];
+      }
+    }
+
+    // lane best over its slots, wave best over its lanes, block best over the waves
+    unsigned lh = mhi[0], ll = mlo[0];
+    int lk = mk[0];
+    float lx = mx[0], ly = my[0], lz = mz[0];
+#pragma unroll
+    for (int s = 1; s < SL; ++s) {
+      const bool better = mhi[s] > lh || (mhi[s] == lh && mlo[s] > ll);
+      lh = better ? mhi[s] : lh;
+      ll = better ? mlo[s] : ll;
+      lk = better ? mk[s] : lk;
+      lx = better ? mx[s] : lx;
+      ly = better ? my[s] : ly;
+      lz = better ? mz[s] : lz;
+    }
+    unsigned wh;
+    const int wl = wave_argmax(lh, [&]() { return ll; }, wh);
+    BSlot *sl = slots[j & 1];
+    if (lane == wl) sl[wave] = BSlot{wh, ll, lk, lx, ly, lz, 0, 0};
+    __syncthreads();
+    BSlot v = BSlot{0u, 0u, 0, 0.f, 0.f, 0.f, 0, 0};
+    if (lane < NW) v = sl[lane];
+    unsigned gh;
+    const int gl = wave_argmax(v.hi, [&]() { return v.lo; }, gh);
+    int nk;
+    if (gh == 0) {  // nothing competes: best=-1, besti=0 in the reference
+      nk = 0; sx = x0; sy = y0; sz = z0;
+    } else {
+      nk = __builtin_amdgcn_readlane(v.k, gl);
+      sx = rl_f(v.x, gl); sy = rl_f(v.y, gl); sz = rl_f(v.z, gl);
+    }
+    if (tid == 0) idxs[j] = nk;
+  }
+}
+
+struct FpsPlan {
+  int nb, np;
+  size_t pts_bytes, k_bytes;
+};
+
+static FpsPlan fps_plan(int b, int n) {
+  FpsPlan p;
+  p.nb = cdiv(n, 64);
+  p.np = p.nb * 64;
+  p.pts_bytes = sizeof(float4) * (size_t)b * p.np;
+  p.k_bytes = sizeof(int) * (size_t)b * p.np;
+  return p;
+}
+
+constexpr int kBucketWaves = 16;
+constexpr int kBucketMaxSlots = 2;
+constexpr int kBucketMaxN = kBucketMaxSlots * kBucketWaves * 64 * 64;  // 131072 points/scene
+
+bool fps_bucket_supported(int n) { return n > 0 && n <= kBucketMaxN; }
+
+size_t fps_bucket_workspace_bytes(int b, int n) {
+  if (b <= 0 || !fps_bucket_supported(n)) return 0;
+  const FpsPlan p = fps_plan(b, n);
+  return p.pts_bytes + p.k_bytes;
+}
+
+int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int bs, int log2bs,
+                      void *workspace, size_t workspace_bytes, hipStream_t s) {
+  const FpsPlan p = fps_plan(b, n);
+  BTR_REQUIRE(workspace && workspace_bytes >= p.pts_bytes + p.k_bytes,
+              "furthest_point_sampling: workspace of %zu bytes required, got %zu",
+              p.pts_bytes + p.k_bytes, workspace_bytes);
+  float4 *spts = (float4 *)workspace;
+  int *sk = (int *)((char *)workspace + p.pts_bytes);
+  const size_t lds = sizeof(int) * (kCells + 96 + 16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)fps_sort_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail((int)e, "fps_sort attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fps_sort_kernel, dim3(b), dim3(kSortThreads), lds, s, n, p.np, dataset,
+                     spts, sk);
+  int rc = check_launch("furthest_point_sampling(sort)");
+  if (rc) return rc;
+  if (p.nb <= kBucketWaves * 64)
+    hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1>), dim3(b), dim3(kBucketWaves * 64),
+                       0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
+  else
+    hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2>), dim3(b), dim3(kBucketWaves * 64),
+                       0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
+  return check_launch("furthest_point_sampling(bucket)");
+}
+
+}  // namespace btr

@@ -5,6 +5,7 @@
 // writes it, because the sampled indices are compared bit-exactly against the oracle.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -206,8 +207,22 @@ static int launch_fps(int b, int n, int m, int bs, int log2bs, const float *data
   return check_launch("furthest_point_sampling");
 }
 
+// fps_bucket.hip
+bool fps_bucket_supported(int n);
+size_t fps_bucket_workspace_bytes(int b, int n);
+int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int bs, int log2bs,
+                      void *workspace, size_t workspace_bytes, hipStream_t s);
+
+constexpr int kFpsRegsMaxN = 4096;  // up to here every point lives in VGPRs for the whole run
+
+// BTR_FPS_IMPL=stream forces the plain streaming kernel for large n (A/B and cross-checks).
+static bool fps_force_stream() {
+  const char *e = getenv("BTR_FPS_IMPL");
+  return e && e[0] == 's';
+}
+
 static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,
-                        int bs, hipStream_t s) {
+                        int bs, void *ws, size_t ws_bytes, hipStream_t s) {
   if (m <= 0 || b <= 0) return BTR_OK;  // sampling_gpu.cu:78
   BTR_REQUIRE(n > 0 && dataset && idxs,
               "furthest_point_sampling: null pointer or n=%d <= 0", n);
@@ -216,11 +231,16 @@ static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, 
   BTR_REQUIRE((long long)n + 512 < 0x7fffffffLL, "furthest_point_sampling: n too large");
   int log2bs = 0;
   while ((1 << log2bs) < bs) ++log2bs;
+  // register-resident kernels: at most 4 waves (one per SIMD) so the serial arg-max chain of
+  // a step is never slowed by a co-resident wave
   if (n <= 64) return launch_fps<64, 1, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
   if (n <= 256) return launch_fps<256, 1, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+  if (n <= 512) return launch_fps<256, 2, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
   if (n <= 1024) return launch_fps<256, 4, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
-  if (n <= 4096) return launch_fps<1024, 4, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
-  if (n <= 8192) return launch_fps<1024, 8, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+  if (n <= 2048) return launch_fps<256, 8, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+  if (n <= kFpsRegsMaxN) return launch_fps<256, 16, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
+  if (fps_bucket_supported(n) && ws != nullptr && !fps_force_stream())
+    return fps_bucket_launch(b, n, m, dataset, idxs, bs, log2bs, ws, ws_bytes, s);
   BTR_REQUIRE(temp != nullptr, "furthest_point_sampling: temp scratch required for n=%d", n);
   return launch_fps<1024, 1, false>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
 }
@@ -245,14 +265,43 @@ int btr_opt_n_threads(int work_size) {
   return v;
 }
 
+size_t btr_furthest_point_sampling_workspace_bytes(int b, int n, int m) {
+  if (b <= 0 || m <= 1 || n <= kFpsRegsMaxN || fps_force_stream()) return 0;
+  return fps_bucket_workspace_bytes(b, n);
+}
+
+int btr_furthest_point_sampling_ws(int b, int n, int m, const float *dataset, float *temp,
+                                   int *idxs, int block_size, void *workspace,
+                                   size_t workspace_bytes, btr_stream_t stream) {
+  const int bs = block_size > 0 ? block_size : btr_opt_n_threads(n);
+  return fps_dispatch(b, n, m, dataset, temp, idxs, bs, workspace, workspace_bytes,
+                      as_stream(stream));
+}
+
+static int fps_with_own_workspace(int b, int n, int m, const float *dataset, float *temp,
+                                  int *idxs, int bs, btr_stream_t stream) {
+  const size_t ws = btr_furthest_point_sampling_workspace_bytes(b, n, m);
+  void *w = nullptr;
+  hipStream_t s = as_stream(stream);
+  if (ws) {
+    hipError_t e = hipMallocAsync(&w, ws, s);
+    if (e != hipSuccess)
+      return fail((int)e, "furthest_point_sampling workspace: %s", hipGetErrorString(e));
+  }
+  const int rc = btr_furthest_point_sampling_ws(b, n, m, dataset, temp, idxs, bs, w, ws, stream);
+  if (w) (void)hipFreeAsync(w, s);
+  return rc;
+}
+
 int btr_furthest_point_sampling_bs(int b, int n, int m, const float *dataset, float *temp,
                                    int *idxs, int block_size, btr_stream_t stream) {
-  return fps_dispatch(b, n, m, dataset, temp, idxs, block_size, as_stream(stream));
+  BTR_REQUIRE(block_size >= 1, "furthest_point_sampling: block_size %d < 1", block_size);
+  return fps_with_own_workspace(b, n, m, dataset, temp, idxs, block_size, stream);
 }
 
 int btr_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
                                 int *idxs, btr_stream_t stream) {
-  return fps_dispatch(b, n, m, dataset, temp, idxs, btr_opt_n_threads(n), as_stream(stream));
+  return fps_with_own_workspace(b, n, m, dataset, temp, idxs, 0, stream);
 }
 
 int btr_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,

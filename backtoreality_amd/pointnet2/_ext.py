@@ -29,6 +29,8 @@ _SIGNATURES = {
     "btr_opt_n_threads": (_ci, [_ci]),
     "btr_furthest_point_sampling": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_furthest_point_sampling_bs": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp]),
+    "btr_furthest_point_sampling_workspace_bytes": (_sz, [_ci, _ci, _ci]),
+    "btr_furthest_point_sampling_ws": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _sz, _vp]),
     "btr_gather_points": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_gather_points_grad": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_ball_query": (_ci, [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp]),
@@ -157,10 +159,22 @@ def furthest_point_sampling(points, nsamples):
     out = torch.empty((B, max(nsamples, 0)), dtype=torch.int32, device=points.device)
     if nsamples <= 0 or B == 0:
         return out
-    temp = torch.empty((B, N), dtype=torch.float32, device=points.device)
+    return _fps(points, nsamples, 0, out)
+
+
+def _fps(points, nsamples, block_size, out):
+    B, N, _ = points.shape
+    ws_bytes = _lib.btr_furthest_point_sampling_workspace_bytes(B, N, nsamples)
+    if ws_bytes:   # bucketed kernel: scratch from torch's stream-ordered caching allocator
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device)
+        temp = None
+    else:          # register-resident kernel (no scratch) or streaming kernel (uses temp)
+        ws = None
+        temp = torch.empty((B, N), dtype=torch.float32, device=points.device)
     with _on(points) as dev:
-        _call(_lib.btr_furthest_point_sampling, B, N, nsamples, _p(points), _p(temp), _p(out),
-              _stream(dev), key=(B, N, nsamples))
+        _call(_lib.btr_furthest_point_sampling_ws, B, N, nsamples, _p(points), _p(temp),
+              _p(out), int(block_size), _p(ws), ws_bytes, _stream(dev),
+              key=(B, N, nsamples))
     return out
 
 
@@ -170,11 +184,10 @@ def furthest_point_sampling_bs(points, nsamples, block_size):
     _gpu_only(points)
     B, N, _ = points.shape
     out = torch.empty((B, max(int(nsamples), 0)), dtype=torch.int32, device=points.device)
-    temp = torch.empty((B, N), dtype=torch.float32, device=points.device)
-    with _on(points) as dev:
-        _call(_lib.btr_furthest_point_sampling_bs, B, N, int(nsamples), _p(points), _p(temp),
-              _p(out), int(block_size), _stream(dev))
-    return out
+    _require(int(block_size) >= 1, "block_size must be >= 1")
+    if int(nsamples) <= 0 or B == 0:
+        return out
+    return _fps(points, int(nsamples), int(block_size), out)
 
 
 def gather_points(points, idx):

@@ -64,6 +64,16 @@ int btr_furthest_point_sampling(int b, int n, int m, const float *dataset, float
 int btr_furthest_point_sampling_bs(int b, int n, int m, const float *dataset, float *temp,
                                    int *idxs, int block_size, btr_stream_t stream);
 
+/* Same with caller-provided scratch and an optional forced block size (0 = opt_n_threads(n)).
+ * Large scenes (n > 4096) use a Morton-bucketed, bounding-box-pruned kernel that needs
+ * btr_furthest_point_sampling_workspace_bytes() of scratch; the two entry points above take it
+ * from hipMallocAsync.  With workspace == NULL large scenes fall back to the streaming kernel
+ * (same results, slower), which uses `temp`. */
+size_t btr_furthest_point_sampling_workspace_bytes(int b, int n, int m);
+int btr_furthest_point_sampling_ws(int b, int n, int m, const float *dataset, float *temp,
+                                   int *idxs, int block_size, void *workspace,
+                                   size_t workspace_bytes, btr_stream_t stream);
+
 /* Replaces gather_points_kernel_wrapper(b, c, n, npoints, points, idx, out)
  *   decl src/sampling.cpp:9-11, def src/sampling_gpu.cu:27-36, kernel :13-25.
  * out[b,c,j] = points[b,c,idx[b,j]];  points (b,c,n) f32, idx (b,npoints) i32. */

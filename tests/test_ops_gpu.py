@@ -49,6 +49,42 @@ def test_fps_tie_break_every_block_size(cuda, bs, N):
     np.testing.assert_array_equal(got, ref)
 
 
+def test_fps_full_size_and_both_large_kernels(cuda, monkeypatch):
+    """BASELINE configs[1] size (B=8, N=40000, M=2048): the bucketed kernel and the streaming
+    kernel (BTR_FPS_IMPL=stream) both reproduce the oracle bit for bit."""
+    xyz = _scene_xyz(8, 40000)
+    ref = oracle.furthest_point_sampling(xyz, 2048)
+    x = _t(xyz, cuda)
+    got = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    monkeypatch.setenv("BTR_FPS_IMPL", "stream")
+    got = _ext().furthest_point_sampling(x[:2], 600).cpu().numpy()
+    np.testing.assert_array_equal(got, ref[:2, :600])
+
+
+@pytest.mark.parametrize("kind,N", [("uniform", 30000), ("surface", 65536), ("surface", 4097),
+                                    ("surface", 80000)])
+def test_fps_bucketed_other_distributions(cuda, kind, N):
+    xyz = _scene_xyz(2, N, first=20, kind=kind)
+    ref = oracle.furthest_point_sampling(xyz, 700)
+    got = _ext().furthest_point_sampling(_t(xyz, cuda), 700).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_bucketed_skip_rule_and_all_duplicates(cuda):
+    rng = np.random.default_rng(12)
+    xyz = rng.uniform(-3, 3, size=(2, 12000, 3)).astype(np.float32)
+    xyz[:, 500:900] *= 0.004          # a cluster inside the skipped ball around the origin
+    xyz[1, 3000:6000] = xyz[1, 2999]  # 3001 identical points: long exact ties
+    ref = oracle.furthest_point_sampling(xyz, 900)
+    got = _ext().furthest_point_sampling(_t(xyz, cuda), 900).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    same = np.tile(np.array([[1.5, -2.0, 0.25]], np.float32), (1, 9000, 1))
+    ref = oracle.furthest_point_sampling(same, 50)
+    got = _ext().furthest_point_sampling(_t(same, cuda), 50).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
 def test_fps_origin_skip_and_degenerate(cuda):
     rng = np.random.default_rng(11)
     xyz = rng.uniform(-2, 2, size=(2, 3000, 3)).astype(np.float32)
