@@ -1,0 +1,814 @@
+// sa_mlp.hip -- the per-group shared MLP + max-pool of a PointNet++ set-abstraction layer
+// (reference: pointnet2_utils.QueryAndGroup :317-376 + pytorch_utils.SharedMLP :11-36 +
+// F.max_pool2d, pointnet2_modules.py:243-267) as hand-written gfx950 kernels.
+//
+// The reference materialises the grouped tensor (B, 3+C, npoint, nsample) in NCHW and runs
+// cuDNN 1x1 conv / BatchNorm / ReLU / max-pool as separate passes over it.  Here activations
+// live channel-last, one row per (b, centre, sample): r = (b*M + m)*S + s, so that
+//   * the 1x1 conv is a plain (rows x C_in) . (C_out x C_in)^T contraction on the f32 MFMA
+//     (v_mfma_f32_32x32x2_f32, exact f32, 157 TF peak) with LDS-staged 128-row tiles;
+//   * train-mode BatchNorm splits into (a) per-channel sum / sum-of-squares accumulated in
+//     the GEMM epilogue (per-workgroup partials, reduced in f64: deterministic, no atomics),
+//     (b) the affine+ReLU applied in the NEXT GEMM's prologue while the tile is staged to
+//     LDS -- post-activation tensors are never written to HBM;
+//   * max-pool + BN + ReLU of the last layer is one pass that also records the arg-max.
+// Backward mirrors it: BN/ReLU/max-pool backward are folded into small elementwise passes,
+// dgrad re-uses the NT GEMM (with W^T), wgrad is a TN GEMM reducing over rows with
+// per-chunk partials (deterministic).
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace btr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 128;      // rows per workgroup tile
+constexpr int kBK = 32;       // reduction chunk staged in LDS
+constexpr int kLd = kBK + 4;  // padded LDS row (floats): conflict-free ds_read_b128
+
+// ----------------------------------------------------------------------------- group gather
+// X0[r][c], r = (b*M + m)*S + s:  c < 3: (xyz[b, idx, c] - new_xyz[b, m, c]) * inv_radius
+// (pointnet2_utils.py:348-352; torch's GPU `x / scalar` is a multiply by the f32 reciprocal),
+// 3 <= c < 3+C: features_cl[b, idx, c-3]; columns up to ldx are zero padding.
+__global__ __launch_bounds__(256) void sa_gather_kernel(
+    int N, int M, int S, int C, int ldx, int use_xyz, float inv_radius,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats_cl, const int *__restrict__ idx, float *__restrict__ X) {
+  const long long rows = (long long)gridDim.y * M * S;  // gridDim.y = B
+  const int bi = blockIdx.y;
+  const int cw = ldx;  // columns written per row
+  const int tpr = min(64, cw);  // threads cooperating on a row (power of two not required)
+  const int rows_per_block = 256 / tpr;
+  const int lr = threadIdx.x / tpr, lc = threadIdx.x % tpr;
+  if (lr >= rows_per_block) return;
+  const long long ms = (long long)M * S;
+  for (long long jk = (long long)blockIdx.x * rows_per_block + lr; jk < ms;
+       jk += (long long)gridDim.x * rows_per_block) {
+    const int m = (int)(jk / S);
+    const int ii = idx[(size_t)bi * ms + jk];
+    float *out = X + ((size_t)bi * ms + jk) * ldx;
+    const float *f = feats_cl ? feats_cl + ((size_t)bi * N + ii) * C : nullptr;
+    const int xoff = use_xyz ? 3 : 0;
+    for (int c = lc; c < cw; c += tpr) {
+      float v = 0.f;
+      if (c < xoff) {
+        v = (xyz[((size_t)bi * N + ii) * 3 + c] - new_xyz[((size_t)bi * M + m) * 3 + c]) *
+            inv_radius;
+      } else if (c - xoff < C) {
+        v = f[c - xoff];
+      }
+      out[c] = v;
+    }
+  }
+  (void)rows;
+}
+
+// ------------------------------------------------------------------------ NT GEMM (MFMA f32)
+// C[r][n] = sum_k f(A[r][k]) * W[n][k],  f(y) = PRO ? max(pa[k]*y + pb[k], 0) : y.
+// Workgroup = 4 waves, tile 128 rows x BN columns, K staged BK=32 at a time.  Lanes 0-31 of
+// a wave feed the first half of each staged K chunk to the MFMA, lanes 32-63 the second half
+// (the MFMA's two k slots), so every lane reads 4 consecutive k with one ds_read_b128.
+// STATS: per-column sum and sum of squares of C over the rows this workgroup processed are
+// written to part[blockIdx.x][0..1][n] (grid-stride over row tiles, reduced later in f64).
+template <int BN, bool PRO, bool STATS>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(
+    const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
+    float *__restrict__ C, int ldc, int R, int N, int K, const float *__restrict__ pa,
+    const float *__restrict__ pb, float *__restrict__ part) {
+  constexpr int WN = BN / 64;      // waves along N
+  constexpr int WM = 4 / WN;       // waves along M
+  constexpr int MI = kBM / WM / 32;  // 32-row MFMA tiles per wave
+  constexpr int NJ = 2;            // 32-col MFMA tiles per wave
+  __shared__ __attribute__((aligned(16))) float As[kBM * kLd];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * kLd];
+  __shared__ float red[STATS ? 2 * WM * BN : 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int n_blk = blockIdx.y * BN;
+
+  float s1[NJ], s2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
+
+  const int ntiles = (R + kBM - 1) / kBM;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int r0 = tile * kBM;
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += kBK) {
+      // ---- stage A (with the previous layer's BN+ReLU applied on the fly) and W
+      const int kq = (tid & 7) * 4;
+      const int kk = k0 + kq;
+      float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRO && kk < K) {  // K is padded to a multiple of 4 by the caller
+        fa = *reinterpret_cast<const float4 *>(pa + kk);
+        fb = *reinterpret_cast<const float4 *>(pb + kk);
+      }
+#pragma unroll
+      for (int p = 0; p < kBM / 32; ++p) {
+        const int row = (tid >> 3) + 32 * p;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + row < R && kk < K) {
+          v = *reinterpret_cast<const float4 *>(A + (size_t)(r0 + row) * lda + kk);
+          if (PRO) {
+            v.x = fmaxf(fmaf(fa.x, v.x, fb.x), 0.f);
+            v.y = fmaxf(fmaf(fa.y, v.y, fb.y), 0.f);
+            v.z = fmaxf(fmaf(fa.z, v.z, fb.z), 0.f);
+            v.w = fmaxf(fmaf(fa.w, v.w, fb.w), 0.f);
+          }
+        }
+        *reinterpret_cast<float4 *>(&As[row * kLd + kq]) = v;
+      }
+#pragma unroll
+      for (int p = 0; p < BN / 32; ++p) {
+        const int row = (tid >> 3) + 32 * p;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n_blk + row < N && kk < K)
+          v = *reinterpret_cast<const float4 *>(W + (size_t)(n_blk + row) * ldw + kk);
+        *reinterpret_cast<float4 *>(&Bs[row * kLd + kq]) = v;
+      }
+      __syncthreads();
+      // ---- 16 MFMA k-steps on the staged chunk
+#pragma unroll
+      for (int t4 = 0; t4 < kBK / 2; t4 += 4) {
+        float4 af[MI], bf[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          af[i] = *reinterpret_cast<const float4 *>(
+              &As[(wm * (kBM / WM) + i * 32 + l31) * kLd + h * (kBK / 2) + t4]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          bf[j] = *reinterpret_cast<const float4 *>(
+              &Bs[(wn * 64 + j * 32 + l31) * kLd + h * (kBK / 2) + t4]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+    // ---- epilogue: D layout col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n_blk + wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = r0 + wm * (kBM / WM) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          const float c = acc[i][j][v];
+          if (row < R && col < N) C[(size_t)row * ldc + col] = c;
+          if (STATS) {  // rows >= R hold exact zeros (A staged as 0): no masking needed
+            s1[j] += c;
+            s2[j] = fmaf(c, c, s2[j]);
+          }
+        }
+      }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      s1[j] += __shfl_xor(s1[j], 32);
+      s2[j] += __shfl_xor(s2[j], 32);
+      if (h == 0) {
+        red[(0 * WM + wm) * BN + wn * 64 + j * 32 + l31] = s1[j];
+        red[(1 * WM + wm) * BN + wn * 64 + j * 32 + l31] = s2[j];
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += 256) {
+      const int which = c / BN, col = c % BN;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) s += red[(which * WM + w) * BN + col];
+      if (n_blk + col < N)
+        part[((size_t)blockIdx.x * 2 + which) * N + n_blk + col] = s;
+    }
+  }
+}
+
+// ------------------------------------------------- parallel reduction of per-workgroup partials
+// part[nblk][2][N] -> (s1, s2) for channel c in f64.  A 256-thread block covers 16 channels x
+// 16 slices of the nblk axis; the result is valid in the threads with ty == 0.
+__device__ __forceinline__ void reduce_partials16(const float *__restrict__ part, int nblk,
+                                                  int N, int c, int tx, int ty, double &s1,
+                                                  double &s2) {
+  __shared__ double red[2][16][17];
+  s1 = 0.0;
+  s2 = 0.0;
+  if (c < N)
+    for (int b = ty; b < nblk; b += 16) {
+      s1 += (double)part[((size_t)b * 2 + 0) * N + c];
+      s2 += (double)part[((size_t)b * 2 + 1) * N + c];
+    }
+  red[0][ty][tx] = s1;
+  red[1][ty][tx] = s2;
+  __syncthreads();
+  if (ty == 0) {
+#pragma unroll
+    for (int y = 1; y < 16; ++y) {
+      s1 += red[0][y][tx];
+      s2 += red[1][y][tx];
+    }
+  }
+}
+
+// --------------------------------------------------------------- BN statistics -> affine form
+// part[nblk][2][N] -> mean, biased var; scale a = gamma*invstd, shift b = beta - mean*a; also
+// saves mean / invstd for backward and updates the running statistics exactly like
+// nn.BatchNorm2d in training mode (unbiased variance, momentum).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    int N, int nblk, double count, float eps, float momentum, const float *__restrict__ part,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ scale,
+    float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out,
+    float *__restrict__ running_mean, float *__restrict__ running_var) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + tx;
+  double s1, s2;
+  reduce_partials16(part, nblk, N, n, tx, ty, s1, s2);
+  if (ty != 0 || n >= N) return;
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float a = gamma[n] * invstd;
+  scale[n] = a;
+  shift[n] = beta[n] - (float)mean * a;
+  mean_out[n] = (float)mean;
+  invstd_out[n] = invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+    running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
+  }
+}
+
+// -------------------------------------------------------------- BN + ReLU + max-pool (fwd)
+// out[b][c][m] = max_s relu(a[c]*Y[r][c] + b[c]) (first maximal s, like F.max_pool2d);
+// arg[(b*M+m)*C + c] = that s;  out_cl[b][m][c] = same values channel-last (next layer's
+// gather source).  One thread per (row-group, channel); lanes along c -> coalesced Y reads.
+__global__ __launch_bounds__(256) void sa_pool_kernel(int M, int S, int C, int ldy,
+                                                      const float *__restrict__ Y,
+                                                      const float *__restrict__ scale,
+                                                      const float *__restrict__ shift,
+                                                      float *__restrict__ out,
+                                                      float *__restrict__ out_cl,
+                                                      unsigned char *__restrict__ arg,
+                                                      long long groups) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= groups * C) return;
+  const long long g = t / C;  // g = b*M + m
+  const int c = (int)(t - g * C);
+  const float a = scale[c], b = shift[c];
+  const float *y = Y + (size_t)g * S * ldy + c;
+  float best = -1.f;
+  int bs = 0;
+  for (int s = 0; s < S; ++s) {
+    const float v = fmaxf(fmaf(a, y[(size_t)s * ldy], b), 0.f);
+    if (v > best) {
+      best = v;
+      bs = s;
+    }
+  }
+  const long long bi = g / M;
+  const int m = (int)(g - bi * M);
+  out[((size_t)bi * C + c) * M + m] = best;
+  if (out_cl) out_cl[(size_t)g * C + c] = best;
+  arg[(size_t)g * C + c] = (unsigned char)bs;
+}
+
+// ------------------------------------------- max-pool + ReLU + BN backward, statistics pass
+// g = dOut[b][c][m] where out > 0 (ReLU), routed to row s* = arg;  accumulates per channel
+// sum(g) and sum(g * xhat) with xhat = (Y[r*][c] - mean)*invstd  -> part[blk][2][C].
+__global__ __launch_bounds__(256) void sa_pool_bwd_stats_kernel(
+    int M, int S, int C, int ldy, const float *__restrict__ Y, const float *__restrict__ dout,
+    const float *__restrict__ out, const unsigned char *__restrict__ arg,
+    const float *__restrict__ mean, const float *__restrict__ invstd, long long groups,
+    float *__restrict__ part) {
+  // block handles all channels (c = threadIdx.x + 256*i) for a strided set of groups
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mu = mean[c], is = invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (long long g = blockIdx.x; g < groups; g += gridDim.x) {
+      const long long bi = g / M;
+      const int m = (int)(g - bi * M);
+      const size_t o = ((size_t)bi * C + c) * M + m;
+      if (out[o] > 0.f) {
+        const float gr = dout[o];
+        const int s = arg[(size_t)g * C + c];
+        const float xh = (Y[((size_t)g * S + s) * ldy + c] - mu) * is;
+        s1 += gr;
+        s2 = fmaf(gr, xh, s2);
+      }
+    }
+    part[((size_t)blockIdx.x * 2 + 0) * C + c] = s1;
+    part[((size_t)blockIdx.x * 2 + 1) * C + c] = s2;
+  }
+}
+
+// part[nblk][2][C] -> m1 = sum(g)/count, m2 = sum(g*xhat)/count, dgamma = sum(g*xhat),
+// dbeta = sum(g).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nblk, double count,
+                                                              const float *__restrict__ part,
+                                                              float *__restrict__ m1,
+                                                              float *__restrict__ m2,
+                                                              float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
+  double s1, s2;
+  reduce_partials16(part, nblk, C, c, tx, ty, s1, s2);
+  if (ty != 0 || c >= C) return;
+  m1[c] = (float)(s1 / count);
+  m2[c] = (float)(s2 / count);
+  dgamma[c] = (float)s2;
+  dbeta[c] = (float)s1;
+}
+
+// dY[r][c] = a[c] * (g[r][c] - m1[c] - xhat[r][c]*m2[c]) written IN PLACE over Y, for the
+// pooled (last) layer: g[r][c] = dOut if (s == arg && out > 0) else 0.
+__global__ __launch_bounds__(256) void sa_pool_bwd_apply_kernel(
+    int M, int S, int C, int ldy, float *__restrict__ Y, const float *__restrict__ dout,
+    const float *__restrict__ out, const unsigned char *__restrict__ arg,
+    const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ scale, const float *__restrict__ m1, const float *__restrict__ m2,
+    long long groups) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= groups * C) return;
+  const long long g = t / C;
+  const int c = (int)(t - g * C);
+  const long long bi = g / M;
+  const int m = (int)(g - bi * M);
+  const size_t o = ((size_t)bi * C + c) * M + m;
+  const float gr = out[o] > 0.f ? dout[o] : 0.f;
+  const int sa = arg[(size_t)g * C + c];
+  const float mu = mean[c], is = invstd[c], a = scale[c], c1 = m1[c], c2 = m2[c];
+  float *y = Y + (size_t)g * S * ldy + c;
+  for (int s = 0; s < S; ++s) {
+    const float xh = (y[(size_t)s * ldy] - mu) * is;
+    const float gg = s == sa ? gr : 0.f;
+    y[(size_t)s * ldy] = a * (gg - c1 - xh * c2);
+  }
+}
+
+// Hidden layers: G holds dX (gradient w.r.t. the post-ReLU activation).  Pass 1 (stats):
+// g = G * (a*Y + b > 0);  part <- sum(g), sum(g*xhat).   Pass 2 (apply, in place on G):
+// G <- a * (g - m1 - xhat*m2).  Rows x channels elementwise, lanes along c.
+constexpr int kBnBwdMaxC = 256;
+
+// Statistics pass: every thread owns 4 consecutive channels (one float4 per row) and walks
+// the rows assigned to its row slot; C % 4 == 0, C <= 256, so a row is covered by C/4 <= 64
+// lanes and a 256-thread block streams 256/(C/4) rows per iteration with 16-byte loads.
+__global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(
+    long long R, int C, int ld, const float *__restrict__ G, const float *__restrict__ Y,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ part) {
+  __shared__ float red[2][256 * 4];
+  const int tpr = C >> 2;             // threads per row
+  const int slots = 256 / tpr;        // rows per block iteration
+  const int slot = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (slot < slots) {
+    const float4 a = *reinterpret_cast<const float4 *>(scale + c4);
+    const float4 b = *reinterpret_cast<const float4 *>(shift + c4);
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c4);
+    const float4 is = *reinterpret_cast<const float4 *>(invstd + c4);
+    for (long long r = (long long)blockIdx.x * slots + slot; r < R;
+         r += (long long)gridDim.x * slots) {
+      const float4 y = *reinterpret_cast<const float4 *>(Y + (size_t)r * ld + c4);
+      float4 g = *reinterpret_cast<const float4 *>(G + (size_t)r * ld + c4);
+      g.x = fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f;
+      g.y = fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f;
+      g.z = fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f;
+      g.w = fmaf(a.w, y.w, b.w) > 0.f ? g.w : 0.f;
+      s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+      s2.x = fmaf(g.x, (y.x - mu.x) * is.x, s2.x);
+      s2.y = fmaf(g.y, (y.y - mu.y) * is.y, s2.y);
+      s2.z = fmaf(g.z, (y.z - mu.z) * is.z, s2.z);
+      s2.w = fmaf(g.w, (y.w - mu.w) * is.w, s2.w);
+    }
+  }
+  *reinterpret_cast<float4 *>(&red[0][threadIdx.x * 4]) = s1;
+  *reinterpret_cast<float4 *>(&red[1][threadIdx.x * 4]) = s2;
+  __syncthreads();
+  for (int q = threadIdx.x; q < 2 * C; q += 256) {
+    const int which = q / C, c = q - which * C;
+    float acc = 0.f;
+    for (int sl = 0; sl < slots; ++sl) acc += red[which][(sl * tpr + (c >> 2)) * 4 + (c & 3)];
+    part[((size_t)blockIdx.x * 2 + which) * C + c] = acc;
+  }
+}
+
+// In-place apply, float4 per thread (C % 4 == 0).
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
+    long long R, int C, int ld, float *__restrict__ G, const float *__restrict__ Y,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ m1, const float *__restrict__ m2) {
+  const int cq = C >> 2;
+  const long long total = R * (long long)cq;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
+       t += (long long)gridDim.x * 256) {
+    const long long r = t / cq;
+    const int c4 = (int)(t - r * cq) * 4;
+    const float4 y = *reinterpret_cast<const float4 *>(Y + (size_t)r * ld + c4);
+    float4 g = *reinterpret_cast<float4 *>(G + (size_t)r * ld + c4);
+    const float4 a = *reinterpret_cast<const float4 *>(scale + c4);
+    const float4 b = *reinterpret_cast<const float4 *>(shift + c4);
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c4);
+    const float4 is = *reinterpret_cast<const float4 *>(invstd + c4);
+    const float4 c1 = *reinterpret_cast<const float4 *>(m1 + c4);
+    const float4 c2 = *reinterpret_cast<const float4 *>(m2 + c4);
+    g.x = a.x * ((fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f) - c1.x - (y.x - mu.x) * is.x * c2.x);
+    g.y = a.y * ((fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f) - c1.y - (y.y - mu.y) * is.y * c2.y);
+    g.z = a.z * ((fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f) - c1.z - (y.z - mu.z) * is.z * c2.z);
+    g.w = a.w * ((fmaf(a.w, y.w, b.w) > 0.f ? g.w : 0.f) - c1.w - (y.w - mu.w) * is.w * c2.w);
+    *reinterpret_cast<float4 *>(G + (size_t)r * ld + c4) = g;
+  }
+}
+
+// ------------------------------------------------------------------------ TN GEMM (wgrad)
+// dW[n][k] = sum_r G[r][n] * f(X[r][k]),  f as in the NT GEMM (the layer's input is the
+// previous layer's pre-BN output).  Workgroup tile 64(n) x 64(k), 4 waves = 2x2 MFMA tiles,
+// reduction over a chunk of rows staged 32 at a time; partials -> pw[chunk][N][K].
+template <bool PRO>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(
+    const float *__restrict__ G, int ldg, const float *__restrict__ X, int ldx, int R, int N,
+    int K, const float *__restrict__ pa, const float *__restrict__ pb, int rows_per_chunk,
+    float *__restrict__ pw) {
+  constexpr int BR = 32;
+  __shared__ __attribute__((aligned(16))) float Gs[BR * 68];
+  __shared__ __attribute__((aligned(16))) float Xs[BR * 68];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int chunk = blockIdx.z;
+  const int rbeg = chunk * rows_per_chunk;
+  const int rend = min(R, rbeg + rows_per_chunk);
+
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+
+  const int c4 = (tid & 15) * 4;  // 16 threads x float4 = 64 columns
+  const int rr = tid >> 4;        // 16 rows per pass, 2 passes
+  float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (PRO && k0 + c4 < K) {
+    fa = *reinterpret_cast<const float4 *>(pa + k0 + c4);
+    fb = *reinterpret_cast<const float4 *>(pb + k0 + c4);
+  }
+  for (int r0 = rbeg; r0 < rend; r0 += BR) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = rr + 16 * p;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < rend) {
+        if (n0 + c4 < N) g = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * ldg + n0 + c4);
+        if (k0 + c4 < K) {
+          x = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + c4);
+          if (PRO) {
+            x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
+            x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
+            x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
+            x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
+          }
+        }
+      }
+      *reinterpret_cast<float4 *>(&Gs[row * 68 + c4]) = g;
+      *reinterpret_cast<float4 *>(&Xs[row * 68 + c4]) = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < BR / 2; ++t) {
+      const float a = Gs[(2 * t + h) * 68 + wn * 32 + l31];
+      const float b = Xs[(2 * t + h) * 68 + wk * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float *out = pw + (size_t)chunk * N * K;
+  const int col = k0 + wk * 32 + l31;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int row = n0 + wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+    if (row < N && col < K) out[(size_t)row * K + col] = acc[v];
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(int total, int chunks,
+                                                            const float *__restrict__ pw,
+                                                            float *__restrict__ dw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += (double)pw[(size_t)c * total + i];
+  dw[i] = (float)s;
+}
+
+// ------------------------------------------------------------- scatter of dX0 (layer-0 dgrad)
+// dX0[r][c] -> c < 3: d xyz[b, idx, c] += v/radius, d new_xyz[b, m, c] -= v/radius;
+// c >= 3: d features[b, idx, c-3] += v.  Instead of float atomics on (B,C,N) (what
+// group_points_grad does) the neighbour lists are inverted once per call:
+//   refs[b][off[n] .. off[n+1]) = the rows jk = m*S+s of batch b whose idx == n
+// (integer atomics only), then one wave per point sums its rows -- each a contiguous run of
+// C floats -- and writes the point's gradient channel-last.
+__global__ __launch_bounds__(256) void csr_count_kernel(long long ms, int N,
+                                                        const int *__restrict__ idx,
+                                                        int *__restrict__ cnt) {
+  const int bi = blockIdx.y;
+  for (long long jk = (long long)blockIdx.x * 256 + threadIdx.x; jk < ms;
+       jk += (long long)gridDim.x * 256)
+    atomicAdd(cnt + (size_t)bi * (N + 1) + idx[(size_t)bi * ms + jk], 1);
+}
+
+// One block per batch element: exclusive scan of cnt[0..N) -> off[0..N], cursor = off.
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int N, int *__restrict__ cnt_off,
+                                                        int *__restrict__ cursor) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int *c = cnt_off + (size_t)bi * (N + 1);
+  int *cur = cursor + (size_t)bi * N;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + tid;
+    const int v = i < N ? c[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int pre = carry_s;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    const int excl = pre + incl - v;
+    if (i < N) {
+      c[i] = excl;
+      cur[i] = excl;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = excl + v;
+    __syncthreads();
+  }
+  if (tid == 0) c[N] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void csr_fill_kernel(long long ms, int N,
+                                                       const int *__restrict__ idx,
+                                                       int *__restrict__ cursor,
+                                                       int *__restrict__ refs) {
+  const int bi = blockIdx.y;
+  for (long long jk = (long long)blockIdx.x * 256 + threadIdx.x; jk < ms;
+       jk += (long long)gridDim.x * 256) {
+    const int pos = atomicAdd(cursor + (size_t)bi * N + idx[(size_t)bi * ms + jk], 1);
+    refs[(size_t)bi * ms + pos] = (int)jk;
+  }
+}
+
+// One wave per point n: dfeat_cl[b][n][c] = sum over refs of dX0[ref][xoff + c];
+// dxyz[b][n][0..3) = (sum of dX0[ref][0..3)) * inv_radius.
+__global__ __launch_bounds__(256) void csr_reduce_kernel(
+    int N, long long ms, int C, int ldx, int xoff, float inv_radius,
+    const float *__restrict__ dX, const int *__restrict__ off, const int *__restrict__ refs,
+    float *__restrict__ dfeat_cl, float *__restrict__ dxyz) {
+  const int bi = blockIdx.y;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const int beg = off[(size_t)bi * (N + 1) + n], end = off[(size_t)bi * (N + 1) + n + 1];
+  const int *rf = refs + (size_t)bi * ms;
+  const float *base = dX + (size_t)bi * ms * ldx;
+  if (dfeat_cl) {
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + lane;
+      float acc = 0.f;
+      if (c < C)
+        for (int i = beg; i < end; ++i) acc += base[(size_t)rf[i] * ldx + xoff + c];
+      if (c < C) dfeat_cl[((size_t)bi * N + n) * C + c] = acc;
+    }
+  }
+  if (dxyz && lane < 3) {
+    float acc = 0.f;
+    for (int i = beg; i < end; ++i) acc += base[(size_t)rf[i] * ldx + lane];
+    dxyz[((size_t)bi * N + n) * 3 + lane] = acc * inv_radius;
+  }
+}
+
+// dnew_xyz[b][m][c] = -(sum_s dX0[(b,m,s)][c]) * inv_radius  (rows of a centre are contiguous)
+__global__ __launch_bounds__(256) void centre_grad_kernel(long long groups, int S, int ldx,
+                                                          float inv_radius,
+                                                          const float *__restrict__ dX,
+                                                          float *__restrict__ dnew_xyz) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= groups * 3) return;
+  const long long g = t / 3;
+  const int c = (int)(t - g * 3);
+  float acc = 0.f;
+  for (int s2 = 0; s2 < S; ++s2) acc += dX[((size_t)g * S + s2) * ldx + c];
+  dnew_xyz[t] = -acc * inv_radius;
+}
+
+}  // namespace btr
+
+using namespace btr;
+
+extern "C" {
+
+// Rows of X0: (b*M+m)*S+s; ldx >= use_xyz*3 + C, multiple of 4.  feats_cl may be NULL (C=0).
+int btr_sa_gather(int b, int n, int m, int s, int c, int ldx, int use_xyz, float radius_div,
+                  const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx,
+                  float *x0, btr_stream_t stream) {
+  if (b <= 0 || m <= 0 || s <= 0) return BTR_OK;
+  BTR_REQUIRE(xyz && new_xyz && idx && x0 && ldx >= (use_xyz ? 3 : 0) + c && ldx % 4 == 0,
+              "sa_gather: bad arguments (ldx=%d, c=%d)", ldx, c);
+  BTR_REQUIRE(c == 0 || feats_cl, "sa_gather: features missing");
+  const int tpr = std::min(64, ldx);
+  const int rpb = 256 / tpr;
+  const long long ms = (long long)m * s;
+  const int gx = (int)std::min<long long>(cdiv(ms, rpb), 4096);
+  const float inv = radius_div != 0.f ? 1.0f / radius_div : 1.0f;
+  hipLaunchKernelGGL(sa_gather_kernel, dim3(gx, b), dim3(256), 0, as_stream(stream), n, m, s, c,
+                     ldx, use_xyz, inv, xyz, new_xyz, feats_cl, idx, x0);
+  return check_launch("sa_gather");
+}
+
+// Number of workgroups (= rows of the `part` buffer) btr_sa_gemm_nt uses along rows.
+int btr_sa_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, kBM), 1024)); }
+
+// C[rows][n] = f(A)[rows][k] . W[n][k]^T;  pa/pb != NULL: f = relu(pa*y+pb) per k;
+// part != NULL: per-workgroup column sums / sums of squares -> part[grid][2][n].
+int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
+                   float *c, int ldc, const float *pa, const float *pb, float *part,
+                   btr_stream_t stream) {
+  if (rows <= 0 || n <= 0) return BTR_OK;
+  BTR_REQUIRE(a && w && c && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
+              "sa_gemm_nt: k=%d lda=%d ldw=%d must be multiples of 4", k, lda, ldw);
+  BTR_REQUIRE((pa == nullptr) == (pb == nullptr), "sa_gemm_nt: pa/pb must come together");
+  const int gx = btr_sa_gemm_grid(rows);
+  hipStream_t s = as_stream(stream);
+  const bool pro = pa != nullptr, st = part != nullptr;
+#define BTR_GEMM(BN, P, S)                                                                   \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S>), dim3(gx, cdiv(n, BN)), dim3(256), 0, s, a,  \
+                     lda, w, ldw, c, ldc, rows, n, k, pa, pb, part)
+  if (n <= 64) {
+    if (pro) { if (st) BTR_GEMM(64, true, true); else BTR_GEMM(64, true, false); }
+    else     { if (st) BTR_GEMM(64, false, true); else BTR_GEMM(64, false, false); }
+  } else {
+    if (pro) { if (st) BTR_GEMM(128, true, true); else BTR_GEMM(128, true, false); }
+    else     { if (st) BTR_GEMM(128, false, true); else BTR_GEMM(128, false, false); }
+  }
+#undef BTR_GEMM
+  return check_launch("sa_gemm_nt");
+}
+
+int btr_sa_bn_finalize(int n, int nblk, double count, float eps, float momentum,
+                       const float *part, const float *gamma, const float *beta, float *scale,
+                       float *shift, float *mean, float *invstd, float *running_mean,
+                       float *running_var, btr_stream_t stream) {
+  if (n <= 0) return BTR_OK;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(n, 16)), dim3(256), 0, as_stream(stream), n,
+                     nblk, count, eps, momentum, part, gamma, beta, scale, shift, mean, invstd,
+                     running_mean, running_var);
+  return check_launch("sa_bn_finalize");
+}
+
+int btr_sa_pool(int b, int m, int s, int c, int ldy, const float *y, const float *scale,
+                const float *shift, float *out, float *out_cl, unsigned char *arg,
+                btr_stream_t stream) {
+  const long long groups = (long long)b * m;
+  if (groups <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(s <= 255, "sa_pool: nsample %d > 255", s);
+  hipLaunchKernelGGL(sa_pool_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
+                     as_stream(stream), m, s, c, ldy, y, scale, shift, out, out_cl, arg, groups);
+  return check_launch("sa_pool");
+}
+
+int btr_sa_pool_bwd(int b, int m, int s, int c, int ldy, float *y, const float *dout,
+                    const float *out, const unsigned char *arg, const float *mean,
+                    const float *invstd, const float *scale, float *part /*[256][2][c]*/,
+                    float *m1, float *m2, float *dgamma, float *dbeta, btr_stream_t stream) {
+  const long long groups = (long long)b * m;
+  if (groups <= 0 || c <= 0) return BTR_OK;
+  hipStream_t st = as_stream(stream);
+  const int nblk = (int)std::min<long long>(groups, 256);
+  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, m, s, c, ldy, y,
+                     dout, out, arg, mean, invstd, groups, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 16)), dim3(256), 0, st, c, nblk,
+                     (double)groups * s, part, m1, m2, dgamma, dbeta);
+  hipLaunchKernelGGL(sa_pool_bwd_apply_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0, st, m,
+                     s, c, ldy, y, dout, out, arg, mean, invstd, scale, m1, m2, groups);
+  return check_launch("sa_pool_bwd");
+}
+
+// In place: g (gradient w.r.t. the post-ReLU activation of a hidden layer) -> gradient w.r.t.
+// the layer's pre-BN output y; also dgamma/dbeta.  part: [256][2][c] floats.
+int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
+                       const float *scale, const float *shift, const float *mean,
+                       const float *invstd, float *part, float *m1, float *m2, float *dgamma,
+                       float *dbeta, btr_stream_t stream) {
+  if (rows <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(c <= kBnBwdMaxC && c % 4 == 0 && ld % 4 == 0,
+              "sa_bn_relu_bwd: %d channels must be a multiple of 4 and <= %d", c, kBnBwdMaxC);
+  hipStream_t st = as_stream(stream);
+  const int nblk = (int)std::min<long long>(cdiv(rows, 256 / (c / 4)), 1024);
+  hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ld, g, y,
+                     scale, shift, mean, invstd, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 16)), dim3(256), 0, st, c, nblk,
+                     (double)rows, part, m1, m2, dgamma, dbeta);
+  const int gx = (int)std::min<long long>(cdiv(rows * (c / 4), 256), 256 * 16);
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx), dim3(256), 0, st, rows, c, ld, g, y,
+                     scale, shift, mean, invstd, m1, m2);
+  return check_launch("sa_bn_relu_bwd");
+}
+
+// Number of row chunks btr_sa_gemm_tn uses; the caller provides pw[chunks][n][k] floats.
+int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
+  const int tiles = cdiv(n, 64) * cdiv(k, 64);
+  int chunks = std::max(1, std::min(1024 / tiles, 128));
+  chunks = std::min(chunks, std::max(1, rows / 512));
+  return chunks;
+}
+
+// dW[n][k] = sum_r G[r][n] * f(X[r][k]).
+int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float *x, int ldx,
+                   const float *pa, const float *pb, float *pw, float *dw,
+                   btr_stream_t stream) {
+  if (n <= 0 || k <= 0) return BTR_OK;
+  BTR_REQUIRE(g && x && pw && dw && ldg % 4 == 0 && ldx % 4 == 0 && n % 4 == 0 && k % 4 == 0,
+              "sa_gemm_tn: sizes must be multiples of 4 (n=%d k=%d)", n, k);
+  hipStream_t st = as_stream(stream);
+  const int chunks = btr_sa_gemm_tn_chunks(rows, n, k);
+  const int rpc = cdiv(cdiv(rows, chunks), 32) * 32;
+  const dim3 grid(cdiv(n, 64), cdiv(k, 64), chunks);
+  if (pa)
+    hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n,
+                       k, pa, pb, rpc, pw);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n,
+                       k, pa, pb, rpc, pw);
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(n * k, 256)), dim3(256), 0, st, n * k,
+                     chunks, pw, dw);
+  return check_launch("sa_gemm_tn");
+}
+
+size_t btr_sa_scatter_workspace_bytes(int b, int n, int m, int s) {
+  if (b <= 0) return 0;
+  return sizeof(int) * ((size_t)b * (n + 1) + (size_t)b * n + (size_t)b * m * s);
+}
+
+// Every output is fully written (no zero-init needed); any of them may be NULL.
+// dfeat_cl is CHANNEL-LAST (b,n,c); dxyz (b,n,3); dnew_xyz (b,m,3).
+int btr_sa_scatter(int b, int n, int m, int s, int c, int ldx, int use_xyz, float radius_div,
+                   const float *dx0, const int *idx, float *dfeat_cl, float *dxyz,
+                   float *dnew_xyz, void *workspace, size_t workspace_bytes,
+                   btr_stream_t stream) {
+  if (b <= 0 || m <= 0 || s <= 0 || n <= 0) return BTR_OK;
+  hipStream_t st = as_stream(stream);
+  const long long ms = (long long)m * s;
+  const float inv = radius_div != 0.f ? 1.0f / radius_div : 1.0f;
+  const int xoff = use_xyz ? 3 : 0;
+  if (!use_xyz) dxyz = dnew_xyz = nullptr;
+  if (c <= 0) dfeat_cl = nullptr;
+  if (dfeat_cl || dxyz) {
+    BTR_REQUIRE(workspace && workspace_bytes >= btr_sa_scatter_workspace_bytes(b, n, m, s),
+                "sa_scatter: workspace too small");
+    int *cnt_off = (int *)workspace;
+    int *cursor = cnt_off + (size_t)b * (n + 1);
+    int *refs = cursor + (size_t)b * n;
+    hipError_t e = hipMemsetAsync(cnt_off, 0, sizeof(int) * (size_t)b * (n + 1), st);
+    if (e != hipSuccess) return fail((int)e, "sa_scatter memset: %s", hipGetErrorString(e));
+    const int gx = (int)std::min<long long>(cdiv(ms, 256), 1024);
+    hipLaunchKernelGGL(csr_count_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cnt_off);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(b), dim3(1024), 0, st, n, cnt_off, cursor);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cursor, refs);
+    hipLaunchKernelGGL(csr_reduce_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, st, n, ms, c, ldx,
+                       xoff, inv, dx0, cnt_off, refs, dfeat_cl, dxyz);
+  }
+  if (dnew_xyz) {
+    const long long groups = (long long)b * m;
+    hipLaunchKernelGGL(centre_grad_kernel, dim3(cdiv(groups * 3, 256)), dim3(256), 0, st, groups,
+                       s, ldx, inv, dx0, dnew_xyz);
+  }
+  return check_launch("sa_scatter");
+}
+
+}  // extern "C"

@@ -20,6 +20,8 @@ LIB_PATH = os.path.join(_PKG, "lib", "libbtr_pointnet2.so")
 _vp = ctypes.c_void_p
 _ci = ctypes.c_int
 _cf = ctypes.c_float
+_cd = ctypes.c_double
+_ll = ctypes.c_longlong
 _sz = ctypes.c_size_t
 
 # name -> (restype, argtypes); mirrors include/btr_pointnet2.h one to one.
@@ -41,6 +43,22 @@ _SIGNATURES = {
     "btr_three_nn": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
     "btr_three_interpolate": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
     "btr_three_interpolate_grad": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
+    # fused set-abstraction MLP (used by fused_sa.py)
+    "btr_sa_gather": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _cf, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "btr_sa_gemm_grid": (_ci, [_ci]),
+    "btr_sa_gemm_nt": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp]),
+    "btr_sa_bn_finalize": (_ci, [_ci, _ci, _cd, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp]),
+    "btr_sa_pool": (_ci, [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "btr_sa_pool_bwd": (_ci, [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _vp, _vp, _vp]),
+    "btr_sa_bn_relu_bwd": (_ci, [_ll, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp]),
+    "btr_sa_gemm_tn_chunks": (_ci, [_ci, _ci, _ci]),
+    "btr_sa_gemm_tn": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "btr_sa_scatter_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
+    "btr_sa_scatter": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _cf, _vp, _vp, _vp, _vp, _vp,
+                             _vp, _sz, _vp]),
 }
 
 

@@ -1,0 +1,234 @@
+"""Fused grouping + shared MLP + max-pool of a set-abstraction layer on MI355X.
+
+Computes exactly what `QueryAndGroup` -> `SharedMLP(bn=True)` -> `F.max_pool2d` compute in the
+reference (pointnet2_utils.py:317-376, pytorch_utils.py:11-36, pointnet2_modules.py:243-267,
+train-mode BatchNorm with batch statistics), forward and backward, but through the `btr_sa_*`
+kernels of libbtr_pointnet2.so (csrc/sa_mlp.hip): channel-last activations, f32-MFMA GEMMs
+with the previous layer's BN+ReLU fused into the operand load and the BN statistics fused
+into the epilogue; the (B, 3+C, npoint, nsample) tensor and the post-activation tensors never
+exist in HBM.  Used by `PointnetSAModuleVotes` when its configuration allows (see
+`can_fuse`); `BTR_FUSED_SA=0` disables it (the unfused path runs the nine `_ext` ops + torch).
+"""
+import os
+
+import torch
+from torch.autograd import Function
+
+if __package__:
+    from . import _ext
+    from . import pointnet2_utils
+else:  # top-level import, like the reference's scripts (sys.path.append(.../pointnet2))
+    import pointnet2._ext as _ext
+    import pointnet2_utils
+_call, _lib, _on, _p, _stream = _ext._call, _ext._lib, _ext._on, _ext._p, _ext._stream
+
+
+def enabled():
+    return os.environ.get("BTR_FUSED_SA", "1") != "0"
+
+
+def _ceil4(v):
+    return (v + 3) // 4 * 4
+
+
+def _f32(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+class FusedSAFunction(Function):
+    """forward(xyz, new_xyz, features|None, idx, meta, *params) -> (B, C_last, M)
+
+    meta: dict(radius_div, use_xyz, bns=[nn.BatchNorm2d...]); params = (W0, g0, b0, W1, ...)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, idx, meta, *params):
+        dev = xyz.device
+        B, N, _ = xyz.shape
+        M, S = idx.shape[1], idx.shape[2]
+        C = features.shape[1] if features is not None else 0
+        use_xyz = 1 if meta["use_xyz"] else 0
+        rdiv = float(meta["radius_div"])
+        bns = meta["bns"]
+        L = len(params) // 3
+        R = B * M * S
+        K0 = 3 * use_xyz + C
+        K0p = _ceil4(K0)
+        xyz = xyz.contiguous()
+        new_xyz = new_xyz.contiguous()
+        feats_cl = None
+        if C:
+            feats_cl = getattr(features, "_btr_channel_last", None)
+            if feats_cl is None or feats_cl.shape != (B, N, C):
+                feats_cl = features.transpose(1, 2).contiguous()
+
+        with _on(xyz) as d:
+            st = _stream(d)
+            X0 = _f32((R, K0p), dev)
+            _call(_lib.btr_sa_gather, B, N, M, S, C, K0p, use_xyz, rdiv, _p(xyz), _p(new_xyz),
+                  _p(feats_cl), _p(idx), _p(X0), st)
+            grid = _lib.btr_sa_gemm_grid(R)
+            Ys, stats, Ws = [], [], []
+            A, lda, K = X0, K0p, K0p
+            pa = pb = None
+            for l in range(L):
+                W, gamma, beta = params[3 * l:3 * l + 3]
+                Nl = W.shape[0]
+                W2 = W.reshape(Nl, -1)
+                if W2.shape[1] != K:  # layer 0 with a padded input width
+                    Wp = torch.zeros((Nl, K), dtype=torch.float32, device=dev)
+                    Wp[:, :W2.shape[1]] = W2
+                    W2 = Wp
+                W2 = W2.contiguous()
+                Y = _f32((R, Nl), dev)
+                part = _f32((grid, 2, Nl), dev)
+                _call(_lib.btr_sa_gemm_nt, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl, _p(pa),
+                      _p(pb), _p(part), st)
+                scale, shift, mean, invstd = (_f32((Nl,), dev) for _ in range(4))
+                bn = bns[l]
+                if bn.momentum is None:
+                    mom = 1.0 / float(bn.num_batches_tracked.item() + 1)
+                else:
+                    mom = float(bn.momentum)
+                track = bn.track_running_stats and bn.running_mean is not None
+                _call(_lib.btr_sa_bn_finalize, Nl, grid, float(R), float(bn.eps), mom, _p(part),
+                      _p(gamma), _p(beta), _p(scale), _p(shift), _p(mean), _p(invstd),
+                      _p(bn.running_mean if track else None),
+                      _p(bn.running_var if track else None), st)
+                if track:
+                    bn.num_batches_tracked += 1
+                Ys.append(Y)
+                Ws.append(W2)
+                stats.append((scale, shift, mean, invstd))
+                A, lda, K = Y, Nl, Nl
+                pa, pb = scale, shift
+            CL = Ys[-1].shape[1]
+            out = _f32((B, CL, M), dev)
+            out_cl = _f32((B, M, CL), dev)
+            arg = torch.empty((B * M, CL), dtype=torch.uint8, device=dev)
+            _call(_lib.btr_sa_pool, B, M, S, CL, CL, _p(Ys[-1]), _p(stats[-1][0]),
+                  _p(stats[-1][1]), _p(out), _p(out_cl), _p(arg), st)
+
+        out._btr_channel_last = out_cl  # lets the next fused layer skip a transpose
+        ctx.dims = (B, N, M, S, C, use_xyz, rdiv, K0, K0p, L)
+        ctx.pshapes = [p.shape for p in params]
+        # save_for_backward (not attributes): saving the OUTPUT through an attribute would
+        # create a ctx <-> out reference cycle that only the cyclic GC frees (GBs per step)
+        flat_stats = [t for st4 in stats for t in st4]
+        ctx.save_for_backward(idx, X0, arg, out, *Ys, *Ws, *flat_stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, N, M, S, C, use_xyz, rdiv, K0, K0p, L = ctx.dims
+        pshapes = ctx.pshapes
+        saved = ctx.saved_tensors
+        idx, X0, arg, out = saved[0:4]
+        Ys = list(saved[4:4 + L])
+        Ws = list(saved[4 + L:4 + 2 * L])
+        flat = saved[4 + 2 * L:]
+        stats = [tuple(flat[4 * l:4 * l + 4]) for l in range(L)]
+        dev = dout.device
+        R = B * M * S
+        dout = dout.contiguous()
+        need_xyz, need_new, need_feat = ctx.needs_input_grad[0:3]
+        grads = [None] * (3 * L)
+        dxyz = dnew = dfeat = None
+
+        with _on(dout) as d:
+            st = _stream(d)
+            # ---- last layer: max-pool + ReLU + BN backward, in place over Y_last
+            CL = Ys[-1].shape[1]
+            scale, shift, mean, invstd = stats[-1]
+            part = _f32((256, 2, CL), dev)
+            m1, m2, dg, db = (_f32((CL,), dev) for _ in range(4))
+            _call(_lib.btr_sa_pool_bwd, B, M, S, CL, CL, _p(Ys[-1]), _p(dout), _p(out), _p(arg),
+                  _p(mean), _p(invstd), _p(scale), _p(part), _p(m1), _p(m2), _p(dg), _p(db), st)
+            grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = dg, db
+            dY = Ys[-1]
+            for l in range(L - 1, -1, -1):
+                Nl = dY.shape[1]
+                W2 = Ws[l]
+                K = W2.shape[1]
+                if l == 0:
+                    Xsrc, ldx, pa, pb = X0, K0p, None, None
+                else:
+                    Xsrc, ldx = Ys[l - 1], Ys[l - 1].shape[1]
+                    pa, pb = stats[l - 1][0], stats[l - 1][1]
+                # weight gradient: dW[n][k] = sum_r dY[r][n] * X_l[r][k]
+                chunks = _lib.btr_sa_gemm_tn_chunks(R, Nl, K)
+                pw = _f32((chunks, Nl, K), dev)
+                dW = _f32((Nl, K), dev)
+                _call(_lib.btr_sa_gemm_tn, R, Nl, K, _p(dY), Nl, _p(Xsrc), ldx, _p(pa), _p(pb),
+                      _p(pw), _p(dW), st)
+                kin = pshapes[3 * l][1]
+                grads[3 * l] = dW[:, :kin].reshape(pshapes[3 * l])
+                # input gradient: dX_l[r][k] = sum_n dY[r][n] * W[n][k]
+                if l > 0 or need_xyz or need_new or need_feat:
+                    Wt = W2.t().contiguous()  # (K, Nl)
+                    G = _f32((R, K), dev)
+                    _call(_lib.btr_sa_gemm_nt, R, K, Nl, _p(dY), Nl, _p(Wt), Nl, _p(G), K,
+                          None, None, None, st)
+                    if l > 0:
+                        sc, sh, mu, isd = stats[l - 1]
+                        part = _f32((1024, 2, K), dev)
+                        m1, m2, dg, db = (_f32((K,), dev) for _ in range(4))
+                        _call(_lib.btr_sa_bn_relu_bwd, R, K, K, _p(G), _p(Ys[l - 1]), _p(sc),
+                              _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2), _p(dg), _p(db),
+                              st)
+                        grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = dg, db
+                        dY = G
+                    else:
+                        dfeat_cl = None
+                        if need_feat and C:
+                            dfeat_cl = _f32((B, N, C), dev)
+                        if need_xyz and use_xyz:
+                            dxyz = _f32((B, N, 3), dev)
+                        if need_new and use_xyz:
+                            dnew = _f32((B, M, 3), dev)
+                        wsb = _lib.btr_sa_scatter_workspace_bytes(B, N, M, S)
+                        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+                        _call(_lib.btr_sa_scatter, B, N, M, S, C, K0p, use_xyz, rdiv, _p(G),
+                              _p(idx), _p(dfeat_cl), _p(dxyz), _p(dnew), _p(ws), wsb, st)
+                        if dfeat_cl is not None:
+                            dfeat = dfeat_cl.transpose(1, 2).contiguous()
+        return (dxyz, dnew, dfeat, None, None) + tuple(grads)
+
+
+def can_fuse(module, xyz, features):
+    """True when `module` (a _SingleScaleSA) is in the configuration the fused kernels cover:
+    ball-query grouping, max-pool, every MLP layer = bias-free 1x1 conv + BatchNorm2d + ReLU,
+    training mode (batch statistics), CUDA tensors."""
+    import torch.nn as nn
+    if not (enabled() and xyz.is_cuda and module.training and module.pooling == 'max'):
+        return False
+    g = module.grouper
+    if not isinstance(g, pointnet2_utils.QueryAndGroup) or g.sample_uniformly:
+        return False
+    if g.nsample > 255 or len(module.mlp_module) == 0:
+        return False
+    for layer in module.mlp_module:
+        names = [n for n, _ in layer.named_children()]
+        if names != ["conv", "bn", "activation"]:
+            return False
+        if layer.conv.bias is not None or layer.conv.kernel_size != (1, 1):
+            return False
+        if not isinstance(layer.activation, nn.ReLU) or not isinstance(layer.bn.bn, nn.BatchNorm2d):
+            return False
+        if layer.bn.bn.weight is None:
+            return False
+    return features is None or features.dtype == torch.float32
+
+
+def fused_group_mlp_max(module, xyz, new_xyz, features):
+    """Drop-in for grouper + mlp_module + max-pool of a _SingleScaleSA module."""
+    g = module.grouper
+    idx = pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz)
+    params = []
+    bns = []
+    for layer in module.mlp_module:
+        params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
+        bns.append(layer.bn.bn)
+    meta = {"radius_div": g.radius if g.normalize_xyz else 1.0, "use_xyz": g.use_xyz, "bns": bns}
+    if features is None and not g.use_xyz:
+        raise AssertionError("Cannot have not features and not use xyz as a feature!")
+    return FusedSAFunction.apply(xyz, new_xyz, features, idx, meta, *params)

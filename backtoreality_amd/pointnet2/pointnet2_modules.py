@@ -15,12 +15,14 @@ import torch.nn.functional as F
 if __package__:
     from . import pointnet2_utils
     from . import pytorch_utils as pt_utils
+    from . import fused_sa
 else:
     import os
     import sys
     sys.path.append(os.path.dirname(os.path.abspath(__file__)))
     import pointnet2_utils
     import pytorch_utils as pt_utils
+    import fused_sa
 
 
 def _sample_centres(xyz, npoint, inds=None):
@@ -137,6 +139,9 @@ class _SingleScaleSA(nn.Module):
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
     def _group_and_pool(self, xyz, new_xyz, features):
+        if new_xyz is not None and fused_sa.can_fuse(self, xyz, features):
+            # MI355X fast path: grouping + shared MLP + max-pool as fused HIP kernels
+            return fused_sa.fused_group_mlp_max(self, xyz, new_xyz, features), None
         grouped = self.grouper(xyz, new_xyz, features)
         unique_cnt = grouped[2] if self.ret_unique_cnt else None
         grouped_features, grouped_xyz = grouped[0], grouped[1]

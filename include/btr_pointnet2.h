@@ -132,6 +132,72 @@ int btr_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out
                                const int *idx, const float *weight, float *grad_points,
                                btr_stream_t stream);
 
+/* ===========================================================================================
+ * Fused set-abstraction MLP (extension beyond the reference's nine native functions).
+ *
+ * The reference runs the per-group shared MLP + max-pool of PointnetSAModuleVotes
+ * (pointnet2_modules.py:243-267: QueryAndGroup -> SharedMLP -> F.max_pool2d) as stock torch
+ * ops on a materialised (B, 3+C, npoint, nsample) tensor.  The entry points below are the
+ * building blocks of the MI355X replacement used by backtoreality_amd/pointnet2/fused_sa.py:
+ * activations are channel-last with one row per (batch, centre, sample),
+ * r = (b*m + j)*s + k, leading dimension a multiple of 4 floats.
+ * =========================================================================================== */
+
+/* x0[r][0..ldx): use_xyz ? (xyz[b,idx,:]-new_xyz[b,j,:])/radius_div : -, then the c feature
+ * channels gathered from feats_cl (b,n,c) (channel-last), zero padded up to ldx. */
+int btr_sa_gather(int b, int n, int m, int s, int c, int ldx, int use_xyz, float radius_div,
+                  const float *xyz, const float *new_xyz, const float *feats_cl, const int *idx,
+                  float *x0, btr_stream_t stream);
+
+/* c[rows][n] = f(a)[rows][k] . w[n][k]^T on the f32 MFMA; f = relu(pa[k]*y + pb[k]) when
+ * pa/pb are given (the previous layer's BatchNorm+ReLU fused into the operand load);
+ * part != NULL: per-workgroup column sums and sums of squares -> part[grid][2][n] with
+ * grid = btr_sa_gemm_grid(rows) (BatchNorm statistics without a second pass). */
+int btr_sa_gemm_grid(int rows);
+int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
+                   float *c, int ldc, const float *pa, const float *pb, float *part,
+                   btr_stream_t stream);
+
+/* part[nblk][2][n] -> per-channel scale/shift (gamma*invstd, beta-mean*scale), mean, invstd;
+ * updates running_mean/var like nn.BatchNorm2d in training mode when they are non-NULL. */
+int btr_sa_bn_finalize(int n, int nblk, double count, float eps, float momentum,
+                       const float *part, const float *gamma, const float *beta, float *scale,
+                       float *shift, float *mean, float *invstd, float *running_mean,
+                       float *running_var, btr_stream_t stream);
+
+/* out[b][c][j] = max_k relu(scale*y + shift) (+ channel-last copy, + arg-max k as u8). */
+int btr_sa_pool(int b, int m, int s, int c, int ldy, const float *y, const float *scale,
+                const float *shift, float *out, float *out_cl, unsigned char *arg,
+                btr_stream_t stream);
+
+/* Backward of pool+ReLU+BN: y is overwritten IN PLACE by dL/dy; part: [256][2][c] scratch. */
+int btr_sa_pool_bwd(int b, int m, int s, int c, int ldy, float *y, const float *dout,
+                    const float *out, const unsigned char *arg, const float *mean,
+                    const float *invstd, const float *scale, float *part, float *m1, float *m2,
+                    float *dgamma, float *dbeta, btr_stream_t stream);
+
+/* Backward of ReLU+BN of a hidden layer: g (dL/d activation) -> dL/dy IN PLACE.
+ * c % 4 == 0, c <= 256; part: [1024][2][c] scratch. */
+int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
+                       const float *scale, const float *shift, const float *mean,
+                       const float *invstd, float *part, float *m1, float *m2, float *dgamma,
+                       float *dbeta, btr_stream_t stream);
+
+/* dw[n][k] = sum_r g[r][n] * f(x[r][k]) (weight gradient); pw: [chunks][n][k] scratch with
+ * chunks = btr_sa_gemm_tn_chunks(rows, n, k). */
+int btr_sa_gemm_tn_chunks(int rows, int n, int k);
+int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float *x, int ldx,
+                   const float *pa, const float *pb, float *pw, float *dw, btr_stream_t stream);
+
+/* dL/dx0 back to the layer inputs: dfeat_cl (b,n,c) CHANNEL-LAST, dxyz (b,n,3), dnew_xyz
+ * (b,m,3); each may be NULL and is fully written otherwise.  The neighbour lists are inverted
+ * (integer atomics) and each point sums its rows: no float atomics. */
+size_t btr_sa_scatter_workspace_bytes(int b, int n, int m, int s);
+int btr_sa_scatter(int b, int n, int m, int s, int c, int ldx, int use_xyz, float radius_div,
+                   const float *dx0, const int *idx, float *dfeat_cl, float *dxyz,
+                   float *dnew_xyz, void *workspace, size_t workspace_bytes,
+                   btr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-kernel time inside ONE steady-state step of a rocprofv3 rocpd trace: the window between
+the last two launches of a marker kernel (default: the large-scene FPS kernel, once per step).
+Usage: rocpd_step.py results.db [marker-substring] [out.md]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    marker = sys.argv[2] if len(sys.argv) > 2 else "fps_bucket_kernel"
+    c = db.cursor()
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    rows = c.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+    marks = [s for (n, s, e) in rows if marker in n]
+    if len(marks) < 2:
+        raise SystemExit("marker %r seen %d times" % (marker, len(marks)))
+    t0, t1 = marks[-2], marks[-1]
+    agg = {}
+    for n, s, e in rows:
+        if t0 <= s < t1:
+            a = agg.setdefault(n, [0, 0])
+            a[0] += 1
+            a[1] += e - s
+    busy = sum(v[1] for v in agg.values())
+    lines = ["step window: %.3f ms wall, %.3f ms kernel-busy, %d dispatches" % (
+        (t1 - t0) / 1e6, busy / 1e6, sum(v[0] for v in agg.values())), "",
+        "| kernel | calls | total us | % of busy |", "|---|---|---|---|"]
+    for n, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        short = n if len(n) <= 100 else n[:97] + "..."
+        lines.append("| `%s` | %d | %.1f | %.2f |" % (short, cnt, tot / 1e3, 100.0 * tot / busy))
+    text = "\n".join(lines) + "\n"
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write(text)
+    else:
+        print(text)
+
+
+if __name__ == "__main__":
+    main()
