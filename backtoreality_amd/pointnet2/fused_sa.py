@@ -82,7 +82,7 @@ class FusedSAFunction(Function):
                 Y = _f32((R, Nl), dev)
                 part = _f32((grid, 2, Nl), dev)
                 _call(_lib.btr_sa_gemm_nt, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl, _p(pa),
-                      _p(pb), _p(part), st)
+                      _p(pb), _p(part), st, key=(R, Nl, K))
                 scale, shift, mean, invstd = (_f32((Nl,), dev) for _ in range(4))
                 bn = bns[l]
                 if bn.momentum is None:
@@ -159,7 +159,7 @@ class FusedSAFunction(Function):
                 pw = _f32((chunks, Nl, K), dev)
                 dW = _f32((Nl, K), dev)
                 _call(_lib.btr_sa_gemm_tn, R, Nl, K, _p(dY), Nl, _p(Xsrc), ldx, _p(pa), _p(pb),
-                      _p(pw), _p(dW), st)
+                      _p(pw), _p(dW), st, key=(R, Nl, K))
                 kin = pshapes[3 * l][1]
                 grads[3 * l] = dW[:, :kin].reshape(pshapes[3 * l])
                 # input gradient: dX_l[r][k] = sum_n dY[r][n] * W[n][k]
@@ -167,7 +167,7 @@ class FusedSAFunction(Function):
                     Wt = W2.t().contiguous()  # (K, Nl)
                     G = _f32((R, K), dev)
                     _call(_lib.btr_sa_gemm_nt, R, K, Nl, _p(dY), Nl, _p(Wt), Nl, _p(G), K,
-                          None, None, None, st)
+                          None, None, None, st, key=(R, K, Nl))
                     if l > 0:
                         sc, sh, mu, isd = stats[l - 1]
                         part = _f32((1024, 2, K), dev)
