@@ -18,6 +18,8 @@
 // Selection rule / tie-break: identical to sampling.hip (reference sampling_gpu.cu:74-178).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -188,7 +190,7 @@ __device__ __forceinline__ float rl_f(float v, int l) {
 // different waves: the few buckets a late sample touches update in parallel -- each update is
 // an L2 round trip plus a wave reduction, so 16 waves beat 4 here: measured 2.85 vs 5.4 ms on
 // 8 x 40000 -> 2048).
-template <int NW, int SL>
+template <int NW, int SL, int UB>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int m, int bs,
                                                          int log2bs,
                                                          const float *__restrict__ dataset,
@@ -254,31 +256,67 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       const float dbox = ex * ex + ey * ey + ez * ez;
       const bool active = (__float_as_uint(dbox) + 1u) < mhi[s];  // mhi == 0: none competes
       unsigned long long todo = __ballot(active);
+      // Up to UB touched buckets per trip: all their loads are issued first (one L2 round
+      // trip for the group), then the UB independent reduction chains run interleaved.
       while (todo) {
-        const int i = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int b = (s * 64 + i) * NW + wave;
-        float4 *pp = spts + (size_t)b * 64 + lane;
-        const float4 p = *pp;
-        const int k = sk[(size_t)b * 64 + lane];
-        const float dx = p.x - sx, dy = p.y - sy, dz = p.z - sz;
-        const float d = dx * dx + dy * dy + dz * dz;
-        const bool valid = p.w >= 0.f;
-        const float t = valid ? fminf(d, p.w) : p.w;
-        if (t != p.w) pp->w = t;
-        const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
-        unsigned mh;
-        const int w = wave_argmax(
-            hi, [&]() { return 0xffffffffu - fps_tk2(k, tp.bs, tp.log2bs, tp.cpb); }, mh);
-        const int wk = __builtin_amdgcn_readlane(k, w);  // wave-uniform: scalar tie key
-        const unsigned wlo = 0xffffffffu - fps_tk2(wk, tp.bs, tp.log2bs, tp.cpb);
-        const bool mine = lane == i;  // the lane slot that keeps this bucket's state
-        mhi[s] = mine ? mh : mhi[s];
-        mlo[s] = mine ? wlo : mlo[s];
-        mk[s] = mine ? wk : mk[s];
-        mx[s] = mine ? rl_f(p.x, w) : mx[s];
-        my[s] = mine ? rl_f(p.y, w) : my[s];
-        mz[s] = mine ? rl_f(p.z, w) : mz[s];
+        int bi_[UB];
+        float4 p_[UB];
+        int k_[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          bi_[u] = todo ? __builtin_ctzll(todo) : -1;
+          todo &= todo - 1;  // 0 stays 0
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int b = (s * 64 + max(bi_[u], 0)) * NW + wave;
+          if (bi_[u] >= 0) {
+            p_[u] = spts[(size_t)b * 64 + lane];
+            k_[u] = sk[(size_t)b * 64 + lane];
+          } else {
+            p_[u] = make_float4(0.f, 0.f, 0.f, -1.f);
+            k_[u] = 0;
+          }
+        }
+        unsigned hi_[UB], mh_[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const float dx = p_[u].x - sx, dy = p_[u].y - sy, dz = p_[u].z - sz;
+          const float d = dx * dx + dy * dy + dz * dz;
+          const bool valid = p_[u].w >= 0.f;
+          const float t = valid ? fminf(d, p_[u].w) : p_[u].w;
+          if (bi_[u] >= 0 && t != p_[u].w) {
+            const int b = (s * 64 + bi_[u]) * NW + wave;
+            spts[(size_t)b * 64 + lane].w = t;
+          }
+          hi_[u] = valid ? __float_as_uint(t) + 1u : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) mh_[u] = wave_max_u32(hi_[u]);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (bi_[u] < 0) continue;  // wave-uniform
+          const unsigned long long cand = __ballot(hi_[u] == mh_[u]);
+          int w;
+          if (__builtin_popcountll(cand) == 1) {
+            w = __builtin_ctzll(cand);
+          } else {  // exact tie (duplicated points) or an all-skipped bucket
+            const unsigned lo = (hi_[u] == mh_[u])
+                                    ? 0xffffffffu - fps_tk2(k_[u], tp.bs, tp.log2bs, tp.cpb)
+                                    : 0u;
+            const unsigned ml = wave_max_u32(lo);
+            w = __builtin_ctzll(__ballot(hi_[u] == mh_[u] && lo == ml));
+          }
+          const int wk = __builtin_amdgcn_readlane(k_[u], w);  // wave-uniform: scalar tie key
+          const unsigned wlo = 0xffffffffu - fps_tk2(wk, tp.bs, tp.log2bs, tp.cpb);
+          const bool mine = lane == bi_[u];  // the lane slot that keeps this bucket's state
+          mhi[s] = mine ? mh_[u] : mhi[s];
+          mlo[s] = mine ? wlo : mlo[s];
+          mk[s] = mine ? wk : mk[s];
+          mx[s] = mine ? rl_f(p_[u].x, w) : mx[s];
+          my[s] = mine ? rl_f(p_[u].y, w) : my[s];
+          mz[s] = mine ? rl_f(p_[u].z, w) : mz[s];
+        }
       }
     }
 
@@ -362,11 +400,29 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
                      spts, sk);
   int rc = check_launch("furthest_point_sampling(sort)");
   if (rc) return rc;
+  // (waves, unroll) default 16,1; BTR_FPS_CFG="NW,UB" selects another instantiation (tuning)
+  int nw = kBucketWaves, ub = 1;
+  if (const char *e = getenv("BTR_FPS_CFG")) sscanf(e, "%d,%d", &nw, &ub);
+  const int sl = cdiv(p.nb, nw * 64);
+#define BTR_FPS_B(NW_, SL_, UB_)                                                              \
+  if (nw == NW_ && sl == SL_ && ub == UB_) {                                                  \
+    hipLaunchKernelGGL((fps_bucket_kernel<NW_, SL_, UB_>), dim3(b), dim3(NW_ * 64), 0, s, n, \
+                       p.np, m, bs, log2bs, dataset, spts, sk, idxs);                         \
+    return check_launch("furthest_point_sampling(bucket)");                                   \
+  }
+  BTR_FPS_B(16, 1, 1) BTR_FPS_B(16, 2, 1) BTR_FPS_B(16, 1, 2) BTR_FPS_B(16, 2, 2)
+  BTR_FPS_B(8, 1, 1) BTR_FPS_B(8, 2, 1) BTR_FPS_B(8, 3, 1) BTR_FPS_B(8, 4, 1)
+  BTR_FPS_B(8, 1, 2) BTR_FPS_B(8, 2, 2) BTR_FPS_B(8, 3, 2) BTR_FPS_B(8, 4, 2)
+  BTR_FPS_B(8, 2, 4)
+  BTR_FPS_B(4, 1, 2) BTR_FPS_B(4, 2, 2) BTR_FPS_B(4, 3, 2) BTR_FPS_B(4, 4, 2)
+  BTR_FPS_B(4, 1, 4) BTR_FPS_B(4, 2, 4) BTR_FPS_B(4, 3, 4) BTR_FPS_B(4, 4, 4)
+#undef BTR_FPS_B
+  // fall back to the default shape
   if (p.nb <= kBucketWaves * 64)
-    hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1>), dim3(b), dim3(kBucketWaves * 64),
+    hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
   else
-    hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2>), dim3(b), dim3(kBucketWaves * 64),
+    hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
   return check_launch("furthest_point_sampling(bucket)");
 }

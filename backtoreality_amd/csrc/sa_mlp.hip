@@ -95,6 +95,56 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
   for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
 
   const int ntiles = (R + kBM - 1) / kBM;
+  const int nkc = (K + kBK - 1) / kBK;
+  const int kq = (tid & 7) * 4;  // this thread's 4 consecutive k inside a staged chunk
+  const int srow = tid >> 3;     // ... and its row (+32*p)
+
+  // Register-staged software pipeline over the flattened (tile, k-chunk) sequence: the global
+  // loads of step q+1 are in flight while the MFMAs of step q run (T14 "issue early, write
+  // late"); the BN+ReLU prologue is applied when the registers are written to LDS.
+  float4 ra[kBM / 32], rb[BN / 32];
+  auto fetch = [&](int tile, int kc) {
+    const int r0 = tile * kBM, kk = kc * kBK + kq;
+#pragma unroll
+    for (int p = 0; p < kBM / 32; ++p) {
+      const int row = srow + 32 * p;
+      ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < R && kk < K)
+        ra[p] = *reinterpret_cast<const float4 *>(A + (size_t)(r0 + row) * lda + kk);
+    }
+#pragma unroll
+    for (int p = 0; p < BN / 32; ++p) {
+      const int row = srow + 32 * p;
+      rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n_blk + row < N && kk < K)
+        rb[p] = *reinterpret_cast<const float4 *>(W + (size_t)(n_blk + row) * ldw + kk);
+    }
+  };
+  auto stage = [&](int tile, int kc) {
+    const int r0 = tile * kBM, kk = kc * kBK + kq;
+    float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PRO && kk < K) {  // K is padded to a multiple of 4 by the caller
+      fa = *reinterpret_cast<const float4 *>(pa + kk);
+      fb = *reinterpret_cast<const float4 *>(pb + kk);
+    }
+#pragma unroll
+    for (int p = 0; p < kBM / 32; ++p) {
+      const int row = srow + 32 * p;
+      float4 v = ra[p];
+      if (PRO && r0 + row < R && kk < K) {  // padded rows / columns must stay exactly 0
+        v.x = fmaxf(fmaf(fa.x, v.x, fb.x), 0.f);
+        v.y = fmaxf(fmaf(fa.y, v.y, fb.y), 0.f);
+        v.z = fmaxf(fmaf(fa.z, v.z, fb.z), 0.f);
+        v.w = fmaxf(fmaf(fa.w, v.w, fb.w), 0.f);
+      }
+      *reinterpret_cast<float4 *>(&As[row * kLd + kq]) = v;
+    }
+#pragma unroll
+    for (int p = 0; p < BN / 32; ++p)
+      *reinterpret_cast<float4 *>(&Bs[(srow + 32 * p) * kLd + kq]) = rb[p];
+  };
+
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x, 0);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int r0 = tile * kBM;
     f32x16 acc[MI][NJ];
@@ -105,39 +155,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    for (int k0 = 0; k0 < K; k0 += kBK) {
-      // ---- stage A (with the previous layer's BN+ReLU applied on the fly) and W
-      const int kq = (tid & 7) * 4;
-      const int kk = k0 + kq;
-      float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (PRO && kk < K) {  // K is padded to a multiple of 4 by the caller
-        fa = *reinterpret_cast<const float4 *>(pa + kk);
-        fb = *reinterpret_cast<const float4 *>(pb + kk);
-      }
-#pragma unroll
-      for (int p = 0; p < kBM / 32; ++p) {
-        const int row = (tid >> 3) + 32 * p;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + row < R && kk < K) {
-          v = *reinterpret_cast<const float4 *>(A + (size_t)(r0 + row) * lda + kk);
-          if (PRO) {
-            v.x = fmaxf(fmaf(fa.x, v.x, fb.x), 0.f);
-            v.y = fmaxf(fmaf(fa.y, v.y, fb.y), 0.f);
-            v.z = fmaxf(fmaf(fa.z, v.z, fb.z), 0.f);
-            v.w = fmaxf(fmaf(fa.w, v.w, fb.w), 0.f);
-          }
-        }
-        *reinterpret_cast<float4 *>(&As[row * kLd + kq]) = v;
-      }
-#pragma unroll
-      for (int p = 0; p < BN / 32; ++p) {
-        const int row = (tid >> 3) + 32 * p;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n_blk + row < N && kk < K)
-          v = *reinterpret_cast<const float4 *>(W + (size_t)(n_blk + row) * ldw + kk);
-        *reinterpret_cast<float4 *>(&Bs[row * kLd + kq]) = v;
-      }
+    for (int kc = 0; kc < nkc; ++kc) {
+      stage(tile, kc);
       __syncthreads();
+      // issue the next step's global loads before the MFMAs of this one
+      if (kc + 1 < nkc)
+        fetch(tile, kc + 1);
+      else if (tile + (int)gridDim.x < ntiles)
+        fetch(tile + gridDim.x, 0);
       // ---- 16 MFMA k-steps on the staged chunk
 #pragma unroll
       for (int t4 = 0; t4 < kBK / 2; t4 += 4) {
@@ -473,27 +498,38 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     fa = *reinterpret_cast<const float4 *>(pa + k0 + c4);
     fb = *reinterpret_cast<const float4 *>(pb + k0 + c4);
   }
+  float4 rg[2], rx[2];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = rr + 16 * p;
+      rg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < rend) {
+        if (n0 + c4 < N)
+          rg[p] = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * ldg + n0 + c4);
+        if (k0 + c4 < K)
+          rx[p] = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + c4);
+      }
+    }
+  };
+  if (rbeg < rend) fetch(rbeg);
   for (int r0 = rbeg; r0 < rend; r0 += BR) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int row = rr + 16 * p;
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r0 + row < rend) {
-        if (n0 + c4 < N) g = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * ldg + n0 + c4);
-        if (k0 + c4 < K) {
-          x = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + c4);
-          if (PRO) {
-            x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
-            x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
-            x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
-            x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
-          }
-        }
+      float4 x = rx[p];
+      if (PRO && r0 + row < rend && k0 + c4 < K) {
+        x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
+        x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
+        x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
+        x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
       }
-      *reinterpret_cast<float4 *>(&Gs[row * 68 + c4]) = g;
+      *reinterpret_cast<float4 *>(&Gs[row * 68 + c4]) = rg[p];
       *reinterpret_cast<float4 *>(&Xs[row * 68 + c4]) = x;
     }
     __syncthreads();
+    if (r0 + BR < rend) fetch(r0 + BR);  // next rows in flight during the MFMAs
 #pragma unroll
     for (int t = 0; t < BR / 2; ++t) {
       const float a = Gs[(2 * t + h) * 68 + wn * 32 + l31];
@@ -743,8 +779,8 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
 // Number of row chunks btr_sa_gemm_tn uses; the caller provides pw[chunks][n][k] floats.
 int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
   const int tiles = cdiv(n, 64) * cdiv(k, 64);
-  int chunks = std::max(1, std::min(1024 / tiles, 128));
-  chunks = std::min(chunks, std::max(1, rows / 512));
+  int chunks = std::max(1, std::min(2048 / tiles, 1024));  // ~2048 workgroups in flight
+  chunks = std::min(chunks, std::max(1, rows / 256));
   return chunks;
 }
 

@@ -112,13 +112,17 @@ def _stream(dev):
 
 
 _TIMING = None  # None = off; else list of (op, shape-key, start_event, end_event)
+_TIMING_FILTER = None
 
 
-def timing_begin():
-    """Start recording a HIP event pair around every kernel launch made through this module
-    (on the launch stream).  Used by bench.py for the live per-kernel durations."""
-    global _TIMING
+def timing_begin(select=None):
+    """Start recording a HIP event pair around kernel launches made through this module (on
+    the launch stream).  `select(op, key) -> bool` restricts which launches are bracketed (an
+    event pair costs a few microseconds of host time).  Used by bench.py for the live
+    per-kernel durations."""
+    global _TIMING, _TIMING_FILTER
     _TIMING = []
+    _TIMING_FILTER = select
 
 
 def timing_end():
@@ -134,6 +138,8 @@ def timing_end():
 
 def _call(fn, *args, key=None):
     timed = _TIMING is not None and key is not None
+    if timed and _TIMING_FILTER is not None:
+        timed = _TIMING_FILTER(fn.__name__.replace("btr_", "").replace("_ws", ""), key)
     if timed:
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)

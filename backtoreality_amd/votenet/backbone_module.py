@@ -3,9 +3,12 @@ layers with the hyper-parameters hard-coded in the reference
 (detection/Votenet/models/backbone_module.py:35-72) and the same attribute names
 (`sa1..sa4`, `fp1`, `fp2`), so the state-dict keys are `backbone_net.sa1.mlp_module.layer0...`.
 """
+import os
+
 import torch
 import torch.nn as nn
 
+from ..pointnet2 import pointnet2_utils
 from ..pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 
 # (npoint, radius, nsample, mlp-after-input) per SA layer -- backbone_module.py:35-69
@@ -35,13 +38,45 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
+    def _fps_pyramid(self, xyz):
+        """Sampling indices of all four SA levels.  They depend on coordinates only, so levels
+        2-4 run on a side HIP stream while the main stream is busy with SA1's grouped MLP (FPS
+        is a chain of dependent steps occupying one CU per scene: nothing else can hide it).
+        Returns [(inds, ready_event or None)] per level; same indices as the sequential order
+        of the reference (pointnet2_modules.py:233-240 inside each SA layer)."""
+        npoints = [getattr(self, "sa%d" % i).npoint for i in (1, 2, 3, 4)]
+        inds1 = pointnet2_utils.furthest_point_sample(xyz, npoints[0])
+        out = [(inds1, None)]
+        if not xyz.is_cuda or os.environ.get("BTR_OVERLAP_FPS", "1") == "0":
+            return out + [(None, None)] * 3
+        main = torch.cuda.current_stream(xyz.device)
+        if getattr(self, "_side_stream", None) is None or self._side_stream.device != xyz.device:
+            self._side_stream = torch.cuda.Stream(device=xyz.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            cur, inds = xyz, inds1
+            for npoint in npoints[1:]:
+                cur = torch.gather(cur, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+                inds = pointnet2_utils.furthest_point_sample(cur, npoint)
+                inds.record_stream(main)
+                cur.record_stream(side)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                out.append((inds, ev))
+        return out
+
     def forward(self, pointcloud: torch.Tensor, end_points=None):
         """pointcloud (B, N, 3 + input_feature_dim) -> end_points with sa{1..4}_{xyz,features},
         sa1_inds, sa2_inds, fp2_{xyz,features,inds} (backbone_module.py:83-133)."""
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
+        pyramid = self._fps_pyramid(xyz)
         for i in (1, 2, 3, 4):
-            xyz, features, fps_inds = getattr(self, "sa%d" % i)(xyz, features)
+            inds, ready = pyramid[i - 1]
+            if ready is not None:
+                torch.cuda.current_stream(xyz.device).wait_event(ready)
+            xyz, features, fps_inds = getattr(self, "sa%d" % i)(xyz, features, inds)
             if i <= 2:
                 end_points["sa%d_inds" % i] = fps_inds
             end_points["sa%d_xyz" % i] = xyz
