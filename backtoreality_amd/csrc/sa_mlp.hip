@@ -469,92 +469,124 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
 
 // ------------------------------------------------------------------------ TN GEMM (wgrad)
 // dW[n][k] = sum_r G[r][n] * f(X[r][k]),  f as in the NT GEMM (the layer's input is the
-// previous layer's pre-BN output).  Workgroup tile 64(n) x 64(k), 4 waves = 2x2 MFMA tiles,
-// reduction over a chunk of rows staged 32 at a time; partials -> pw[chunk][N][K].
-template <bool PRO>
+// previous layer's pre-BN output).  Workgroup tile (32*TNW)(n) x 64(k): wave w < TNW owns the
+// 32 n-rows w*32.. and both 32-wide k tiles (TNW = 4), or with TNW = 2 the four waves form a
+// 2x2 grid of 32x32 tiles.  The reduction runs over a chunk of rows staged 32 at a time with
+// the next rows prefetched into registers; per-chunk partials -> pw[chunk][N][K], reduced by
+// reduce_chunks_kernel in a fixed order (deterministic).
+template <int TNW, bool PRO>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(
     const float *__restrict__ G, int ldg, const float *__restrict__ X, int ldx, int R, int N,
     int K, const float *__restrict__ pa, const float *__restrict__ pb, int rows_per_chunk,
     float *__restrict__ pw) {
   constexpr int BR = 32;
-  __shared__ __attribute__((aligned(16))) float Gs[BR * 68];
-  __shared__ __attribute__((aligned(16))) float Xs[BR * 68];
+  constexpr int TN = 32 * TNW;      // n columns of G staged per step
+  constexpr int LG = TN + 4, LX = 68;
+  constexpr int KT = TNW == 4 ? 2 : 1;  // 32-wide k tiles per wave
+  constexpr int GP = TN / 32;           // float4 passes for G: (TN/4 threads per row)
+  __shared__ __attribute__((aligned(16))) float Gs[BR * LG];
+  __shared__ __attribute__((aligned(16))) float Xs[BR * LX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = TNW == 4 ? wave : (wave >> 1);
+  const int wk = TNW == 4 ? 0 : (wave & 1);
   const int l31 = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * 64;
   const int chunk = blockIdx.z;
   const int rbeg = chunk * rows_per_chunk;
   const int rend = min(R, rbeg + rows_per_chunk);
 
-  f32x16 acc;
+  f32x16 acc[KT];
 #pragma unroll
-  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  for (int q = 0; q < KT; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
 
-  const int c4 = (tid & 15) * 4;  // 16 threads x float4 = 64 columns
-  const int rr = tid >> 4;        // 16 rows per pass, 2 passes
+  // X: 16 threads x float4 cover 64 k columns, 16 rows per pass, 2 passes
+  const int xc4 = (tid & 15) * 4, xr = tid >> 4;
+  // G: TN/4 threads x float4 cover TN n columns, 256/(TN/4) rows per pass
+  constexpr int GT = TN / 4, GR = 256 / GT, GPASS = BR / GR;
+  const int gc4 = (tid % GT) * 4, gr = tid / GT;
   float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (PRO && k0 + c4 < K) {
-    fa = *reinterpret_cast<const float4 *>(pa + k0 + c4);
-    fb = *reinterpret_cast<const float4 *>(pb + k0 + c4);
+  if (PRO && k0 + xc4 < K) {
+    fa = *reinterpret_cast<const float4 *>(pa + k0 + xc4);
+    fb = *reinterpret_cast<const float4 *>(pb + k0 + xc4);
   }
-  float4 rg[2], rx[2];
+  float4 rg[GPASS], rx[2];
   auto fetch = [&](int r0) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = rr + 16 * p;
+    for (int p = 0; p < GPASS; ++p) {
+      const int row = gr + GR * p;
       rg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < rend && n0 + gc4 < N)
+        rg[p] = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * ldg + n0 + gc4);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = xr + 16 * p;
       rx[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r0 + row < rend) {
-        if (n0 + c4 < N)
-          rg[p] = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * ldg + n0 + c4);
-        if (k0 + c4 < K)
-          rx[p] = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + c4);
-      }
+      if (r0 + row < rend && k0 + xc4 < K)
+        rx[p] = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + xc4);
     }
   };
   if (rbeg < rend) fetch(rbeg);
   for (int r0 = rbeg; r0 < rend; r0 += BR) {
 #pragma unroll
+    for (int p = 0; p < GPASS; ++p)
+      *reinterpret_cast<float4 *>(&Gs[(gr + GR * p) * LG + gc4]) = rg[p];
+#pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const int row = rr + 16 * p;
+      const int row = xr + 16 * p;
       float4 x = rx[p];
-      if (PRO && r0 + row < rend && k0 + c4 < K) {
+      if (PRO && r0 + row < rend && k0 + xc4 < K) {
         x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
         x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
         x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
         x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
       }
-      *reinterpret_cast<float4 *>(&Gs[row * 68 + c4]) = rg[p];
-      *reinterpret_cast<float4 *>(&Xs[row * 68 + c4]) = x;
+      *reinterpret_cast<float4 *>(&Xs[row * LX + xc4]) = x;
     }
     __syncthreads();
     if (r0 + BR < rend) fetch(r0 + BR);  // next rows in flight during the MFMAs
 #pragma unroll
     for (int t = 0; t < BR / 2; ++t) {
-      const float a = Gs[(2 * t + h) * 68 + wn * 32 + l31];
-      const float b = Xs[(2 * t + h) * 68 + wk * 32 + l31];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      const float a = Gs[(2 * t + h) * LG + wn * 32 + l31];
+#pragma unroll
+      for (int q = 0; q < KT; ++q) {
+        const float b = Xs[(2 * t + h) * LX + (wk + q) * 32 + l31];
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
   float *out = pw + (size_t)chunk * N * K;
-  const int col = k0 + wk * 32 + l31;
 #pragma unroll
-  for (int v = 0; v < 16; ++v) {
-    const int row = n0 + wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-    if (row < N && col < K) out[(size_t)row * K + col] = acc[v];
+  for (int q = 0; q < KT; ++q) {
+    const int col = k0 + (wk + q) * 32 + l31;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = n0 + wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+      if (row < N && col < K) out[(size_t)row * K + col] = acc[q][v];
+    }
   }
 }
 
+// dw[i] = sum over chunks of pw[chunk][i], fixed order; 16 elements x 16 chunk slices per block.
 __global__ __launch_bounds__(256) void reduce_chunks_kernel(int total, int chunks,
                                                             const float *__restrict__ pw,
                                                             float *__restrict__ dw) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
+  __shared__ double red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + tx;
   double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += (double)pw[(size_t)c * total + i];
-  dw[i] = (float)s;
+  if (i < total)
+    for (int c = ty; c < chunks; c += 16) s += (double)pw[(size_t)c * total + i];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < total) {
+#pragma unroll
+    for (int y = 1; y < 16; ++y) s += red[y][tx];
+    dw[i] = (float)s;
+  }
 }
 
 // ------------------------------------------------------------- scatter of dX0 (layer-0 dgrad)
@@ -777,8 +809,10 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
 }
 
 // Number of row chunks btr_sa_gemm_tn uses; the caller provides pw[chunks][n][k] floats.
+static int tn_tile_n(int n) { return n >= 128 ? 128 : 64; }
+
 int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
-  const int tiles = cdiv(n, 64) * cdiv(k, 64);
+  const int tiles = cdiv(n, tn_tile_n(n)) * cdiv(k, 64);
   int chunks = std::max(1, std::min(2048 / tiles, 1024));  // ~2048 workgroups in flight
   chunks = std::min(chunks, std::max(1, rows / 256));
   return chunks;
@@ -794,14 +828,18 @@ int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float 
   hipStream_t st = as_stream(stream);
   const int chunks = btr_sa_gemm_tn_chunks(rows, n, k);
   const int rpc = cdiv(cdiv(rows, chunks), 32) * 32;
-  const dim3 grid(cdiv(n, 64), cdiv(k, 64), chunks);
-  if (pa)
-    hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n,
-                       k, pa, pb, rpc, pw);
-  else
-    hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n,
-                       k, pa, pb, rpc, pw);
-  hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(n * k, 256)), dim3(256), 0, st, n * k,
+  const int tn = tn_tile_n(n);
+  const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
+#define BTR_TN(W, P)                                                                          \
+  hipLaunchKernelGGL((gemm_tn_kernel<W, P>), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n, \
+                     k, pa, pb, rpc, pw)
+  if (tn == 128) {
+    if (pa) BTR_TN(4, true); else BTR_TN(4, false);
+  } else {
+    if (pa) BTR_TN(2, true); else BTR_TN(2, false);
+  }
+#undef BTR_TN
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(n * k, 16)), dim3(256), 0, st, n * k,
                      chunks, pw, dw);
   return check_launch("sa_gemm_tn");
 }

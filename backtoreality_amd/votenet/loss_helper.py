@@ -37,6 +37,16 @@ def nn_distance(pc1, pc2, l1smooth=False, delta=1.0, l1=False):
     return dist1, idx1, dist2, idx2
 
 
+_OBJ_W = {}
+
+
+def _objectness_weights(like):
+    key = (like.device, like.dtype)
+    if key not in _OBJ_W:
+        _OBJ_W[key] = torch.tensor(OBJECTNESS_CLS_WEIGHTS, dtype=like.dtype, device=like.device)
+    return _OBJ_W[key]
+
+
 def _masked_mean(values, mask):
     return torch.sum(values * mask) / (torch.sum(mask) + 1e-6)
 
@@ -75,7 +85,7 @@ def compute_objectness_loss(end_points):
     objectness_mask[euclidean_dist1 > FAR_THRESHOLD] = 1
 
     scores = end_points['objectness_scores']
-    weight = torch.tensor(OBJECTNESS_CLS_WEIGHTS, dtype=scores.dtype, device=scores.device)
+    weight = _objectness_weights(scores)
     criterion = nn.CrossEntropyLoss(weight, reduction='none')
     loss = criterion(scores.transpose(2, 1), objectness_label)
     loss = _masked_mean(loss, objectness_mask)
@@ -129,8 +139,14 @@ def compute_box_and_sem_cls_loss(end_points, config):
     size_one_hot_tiled = size_one_hot.unsqueeze(-1).repeat(1, 1, 1, 3)
     predicted_size_residual_normalized = torch.sum(
         end_points['size_residuals_normalized'] * size_one_hot_tiled, 2)
-    mean_size = torch.from_numpy(mean_size_arr.astype(np.float32)).to(dev)
-    mean_size = mean_size.unsqueeze(0).unsqueeze(0)
+    cache = getattr(config, "_mean_size_dev", None)  # the reference re-uploads it every step
+    if cache is None or cache.device != dev:
+        cache = torch.from_numpy(mean_size_arr.astype(np.float32)).to(dev)
+        try:
+            config._mean_size_dev = cache
+        except AttributeError:
+            pass
+    mean_size = cache.unsqueeze(0).unsqueeze(0)
     mean_size_label = torch.sum(size_one_hot_tiled * mean_size, 2)
     size_residual_label_normalized = size_residual_label / mean_size_label
     size_reg_loss = torch.mean(

@@ -14,8 +14,11 @@ from ..pointnet2 import pointnet2_utils
 from ..pointnet2.pointnet2_modules import PointnetSAModuleVotes
 
 
-def decode_scores(net, end_points, num_class, num_heading_bin, num_size_cluster, mean_size_arr):
-    """Split the (B, 2+3+NH*2+NS*4+NC, K) head output into named predictions (:18-50)."""
+def decode_scores(net, end_points, num_class, num_heading_bin, num_size_cluster, mean_size_arr,
+                  mean_size_dev=None):
+    """Split the (B, 2+3+NH*2+NS*4+NC, K) head output into named predictions (:18-50).
+    `mean_size_dev`: the (NS,3) table already on the device (the reference re-uploads the
+    numpy array on every call, :40 -- a synchronous H2D copy per step)."""
     t = net.transpose(2, 1)  # (B, K, channels)
     B, K = t.shape[0], t.shape[1]
     NH, NS = num_heading_bin, num_size_cluster
@@ -34,8 +37,9 @@ def decode_scores(net, end_points, num_class, num_heading_bin, num_size_cluster,
     sres = t[:, :, o + NS:o + 4 * NS].view([B, K, NS, 3])
     end_points['size_scores'] = size_scores
     end_points['size_residuals_normalized'] = sres
-    mean_size = torch.from_numpy(mean_size_arr.astype(np.float32)).to(net.device)
-    mean_size = mean_size.unsqueeze(0).unsqueeze(0)
+    if mean_size_dev is None or mean_size_dev.device != net.device:
+        mean_size_dev = torch.from_numpy(mean_size_arr.astype(np.float32)).to(net.device)
+    mean_size = mean_size_dev.unsqueeze(0).unsqueeze(0)
     end_points['size_residuals'] = sres * mean_size
     size_recover = mean_size + end_points['size_residuals']  # (B, K, NS, 3)
     pred_cls = torch.argmax(size_scores, -1)
@@ -68,6 +72,11 @@ class ProposalModule(nn.Module):
         self.conv3 = nn.Conv1d(128, out_ch, 1)
         self.bn1 = nn.BatchNorm1d(128)
         self.bn2 = nn.BatchNorm1d(128)
+        # device copy of the size table; non-persistent so the state dict keeps the
+        # reference's keys
+        self.register_buffer("_mean_size_dev",
+                             torch.from_numpy(np.asarray(mean_size_arr, np.float32)),
+                             persistent=False)
 
     def forward(self, xyz, features, end_points):
         """xyz (B,K,3) votes, features (B,C,K) -> end_points with the decoded proposals."""
@@ -93,4 +102,4 @@ class ProposalModule(nn.Module):
         net = F.relu(self.bn2(self.conv2(net)))
         net = self.conv3(net)
         return decode_scores(net, end_points, self.num_class, self.num_heading_bin,
-                             self.num_size_cluster, self.mean_size_arr)
+                             self.num_size_cluster, self.mean_size_arr, self._mean_size_dev)
