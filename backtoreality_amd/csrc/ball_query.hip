@@ -9,6 +9,7 @@
 // concatenates the per-segment hit lists in segment order, stops at nsample, and applies the
 // reference's padding rule (first hit repeated; empty row = zeros).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -93,6 +94,46 @@ __global__ __launch_bounds__(256) void bq_merge_kernel(long long rows, int nsamp
   idx[t] = found ? val : (have_first ? first : 0);
 }
 
+// Small scenes: one wave per centre, lanes over 64 consecutive points (coalesced, the scene
+// stays in L1/L2), hits compacted in index order with ballot + prefix popcount, early exit
+// once nsample hits are found (ball_query_gpu.cu:32).
+__global__ __launch_bounds__(256) void bq_wave_kernel(int n, int m, int nsample, float radius2,
+                                                      const float *__restrict__ new_xyz,
+                                                      const float *__restrict__ xyz,
+                                                      int *__restrict__ idx) {
+  const int bi = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  xyz += (size_t)bi * n * 3;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int j = blockIdx.x * 4 + wave; j < m; j += gridDim.x * 4) {
+    const float *c = new_xyz + ((size_t)bi * m + j) * 3;
+    const float new_x = c[0], new_y = c[1], new_z = c[2];
+    int *row = idx + ((size_t)bi * m + j) * nsample;
+    int cnt = 0, first = 0;
+    for (int kb = 0; kb < n && cnt < nsample; kb += 64) {
+      const int k = kb + lane;
+      bool hit = false;
+      if (k < n) {
+        const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+        const float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) +
+                         (new_z - z) * (new_z - z);
+        hit = d2 < radius2;
+      }
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        if (cnt == 0) first = kb + __builtin_ctzll(mask);
+        const int pos = cnt + __builtin_popcountll(mask & lt);
+        if (hit && pos < nsample) row[pos] = k;
+        cnt += __builtin_popcountll(mask);
+      }
+    }
+    const int fill = cnt == 0 ? 0 : first;
+    for (int l = min(cnt, nsample) + lane; l < nsample; l += 64) row[l] = fill;
+  }
+}
+
+constexpr int kBqWaveMaxN = 8192;
+
 struct BqPlan {
   int mtiles, S, seg_len;
   size_t hits_bytes, cnt_bytes;
@@ -101,6 +142,12 @@ struct BqPlan {
 static BqPlan bq_plan(int b, int n, int m, int nsample) {
   BqPlan p;
   p.mtiles = cdiv(m, 64);
+  if (n < kBqWaveMaxN) {  // wave-per-centre kernel: no scratch
+    p.S = 1;
+    p.seg_len = std::max(n, 1);
+    p.hits_bytes = p.cnt_bytes = 0;
+    return p;
+  }
   const long long waves = (long long)b * p.mtiles;
   int S = (int)std::max<long long>(1, 2048 / std::max<long long>(1, waves));
   S = std::min(S, std::max(1, n / 512));
@@ -118,6 +165,19 @@ static BqPlan bq_plan(int b, int n, int m, int nsample) {
   return p;
 }
 
+// ball_query_grid.hip
+bool bq_grid_supported(int n, int m, int nsample);
+size_t bq_grid_workspace_bytes(int b, int n);
+int bq_grid_launch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                   const float *xyz, int *idx, void *ws, size_t ws_bytes, hipStream_t s);
+
+// BTR_BQ_IMPL=brute forces the brute-force scan for large scenes (A/B and cross-checks).
+static bool bq_use_grid(int n, int m, int nsample) {
+  const char *e = getenv("BTR_BQ_IMPL");
+  if (e && e[0] == 'b') return false;
+  return bq_grid_supported(n, m, nsample);
+}
+
 }  // namespace btr
 
 using namespace btr;
@@ -126,6 +186,7 @@ extern "C" {
 
 size_t btr_ball_query_workspace_bytes(int b, int n, int m, int nsample) {
   if (b <= 0 || n <= 0 || m <= 0 || nsample <= 0) return 0;
+  if (bq_use_grid(n, m, nsample)) return bq_grid_workspace_bytes(b, n);
   const BqPlan p = bq_plan(b, n, m, nsample);
   return p.hits_bytes + p.cnt_bytes;
 }
@@ -141,8 +202,17 @@ int btr_ball_query_ws(int b, int n, int m, float radius, int nsample, const floa
     return e == hipSuccess ? BTR_OK : fail((int)e, "ball_query memset: %s", hipGetErrorString(e));
   }
   BTR_REQUIRE(new_xyz && xyz, "ball_query: null input");
+  if (bq_use_grid(n, m, nsample))
+    return bq_grid_launch(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace,
+                          workspace_bytes, s);
   const BqPlan p = bq_plan(b, n, m, nsample);
   const float radius2 = radius * radius;  // ball_query_gpu.cu:27
+  if (n < kBqWaveMaxN) {
+    const int gx = std::min(cdiv(m, 4), 1024);
+    hipLaunchKernelGGL(bq_wave_kernel, dim3(gx, b), dim3(256), 0, s, n, m, nsample, radius2,
+                       new_xyz, xyz, idx);
+    return check_launch("ball_query(wave)");
+  }
   if (p.S == 1) {
     hipLaunchKernelGGL((bq_scan_kernel<true>), dim3(p.mtiles, 1, b), dim3(64), 0, s, n, m,
                        nsample, 1, p.seg_len, radius2, new_xyz, xyz, idx, (int *)nullptr,

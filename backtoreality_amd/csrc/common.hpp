@@ -74,6 +74,15 @@ __device__ __forceinline__ float row16_sum_f32(float v) {
   return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
+// waits for every outstanding GLOBAL store/load of the wave; kernels whose waves exchange data
+// through LDS alone (the FPS arg-max slots) must not pay a memory round trip per barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace btr

@@ -190,13 +190,22 @@ __device__ __forceinline__ float rl_f(float v, int l) {
 // different waves: the few buckets a late sample touches update in parallel -- each update is
 // an L2 round trip plus a wave reduction, so 16 waves beat 4 here: measured 2.85 vs 5.4 ms on
 // 8 x 40000 -> 2048).
-template <int NW, int SL, int UB>
+template <int NW, int SL, int UB, bool PROF = false>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int m, int bs,
-                                                         int log2bs,
-                                                         const float *__restrict__ dataset,
-                                                         float4 *__restrict__ spts,
-                                                         const int *__restrict__ sk,
-                                                         int *__restrict__ idxs) {
+                                                             int log2bs,
+                                                             const float *__restrict__ dataset,
+                                                             float4 *__restrict__ spts,
+                                                             const int *__restrict__ sk,
+                                                             int *__restrict__ idxs,
+                                                             unsigned long long *dbg = nullptr) {
+  // PROF: s_memtime phase counters (tuning builds only; BTR_FPS_PROF=1 in tools/)
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0, nact = 0;
+#define BTR_PH(i)                                                  \
+  if (PROF) {                                                      \
+    const unsigned long long now = __builtin_amdgcn_s_memtime();   \
+    tph[i] += now - tlast;                                         \
+    tlast = now;                                                   \
+  }
   __shared__ BSlot slots[2][NW];
 
   const int bi = blockIdx.x;
@@ -244,6 +253,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
   if (tid == 0) idxs[0] = 0;
   float sx = x0, sy = y0, sz = z0;
 
+  if (PROF) tlast = __builtin_amdgcn_s_memtime();
   for (int j = 1; j < m; ++j) {
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
@@ -256,6 +266,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       const float dbox = ex * ex + ey * ey + ez * ez;
       const bool active = (__float_as_uint(dbox) + 1u) < mhi[s];  // mhi == 0: none competes
       unsigned long long todo = __ballot(active);
+      if (PROF) nact += __builtin_popcountll(todo);
+      BTR_PH(0)
       // Up to UB touched buckets per trip: all their loads are issued first (one L2 round
       // trip for the group), then the UB independent reduction chains run interleaved.
       while (todo) {
@@ -320,6 +332,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       }
     }
 
+    BTR_PH(1)
     // lane best over its slots, wave best over its lanes, block best over the waves
     unsigned lh = mhi[0], ll = mlo[0];
     int lk = mk[0];
@@ -336,22 +349,36 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
     }
     unsigned wh;
     const int wl = wave_argmax(lh, [&]() { return ll; }, wh);
-    BSlot *sl = slots[j & 1];
-    if (lane == wl) sl[wave] = BSlot{wh, ll, lk, lx, ly, lz, 0, 0};
-    __syncthreads();
-    BSlot v = BSlot{0u, 0u, 0, 0.f, 0.f, 0.f, 0, 0};
-    if (lane < NW) v = sl[lane];
-    unsigned gh;
-    const int gl = wave_argmax(v.hi, [&]() { return v.lo; }, gh);
-    int nk;
-    if (gh == 0) {  // nothing competes: best=-1, besti=0 in the reference
-      nk = 0; sx = x0; sy = y0; sz = z0;
-    } else {
-      nk = __builtin_amdgcn_readlane(v.k, gl);
-      sx = rl_f(v.x, gl); sy = rl_f(v.y, gl); sz = rl_f(v.z, gl);
+    if (lane == wl) slots[0][wave] = BSlot{wh, ll, lk, lx, ly, lz, 0, 0};
+    BTR_PH(2)
+    lds_barrier();
+    BTR_PH(3)
+    // Only wave 0 reduces the NW slots (the scalar unit is shared by the whole CU: 16 waves
+    // doing the same readlane/s_max sequence serialise on it); the winner goes back through
+    // LDS and every wave picks it up with one broadcast read after the second barrier.
+    if (wave == 0) {
+      BSlot v = BSlot{0u, 0u, 0, 0.f, 0.f, 0.f, 0, 0};
+      if (lane < NW) v = slots[0][lane];
+      unsigned gh;
+      const int gl = wave_argmax(v.hi, [&]() { return v.lo; }, gh);
+      if (gh == 0) {  // nothing competes: best=-1, besti=0 in the reference
+        if (lane == 0) slots[1][0] = BSlot{0u, 0u, 0, x0, y0, z0, 0, 0};
+      } else if (lane == gl) {
+        slots[1][0] = v;
+      }
     }
-    if (tid == 0) idxs[j] = nk;
+    lds_barrier();
+    const BSlot win = slots[1][0];
+    sx = win.x; sy = win.y; sz = win.z;
+    if (tid == 0) idxs[j] = win.k;
+    BTR_PH(4)
   }
+  if (PROF && lane == 0 && dbg) {
+    unsigned long long *o = dbg + ((size_t)bi * NW + wave) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = tph[i];
+    o[5] = nact;
+  }
+#undef BTR_PH
 }
 
 struct FpsPlan {
@@ -400,6 +427,24 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
                      spts, sk);
   int rc = check_launch("furthest_point_sampling(sort)");
   if (rc) return rc;
+  if (getenv("BTR_FPS_PROF")) {  // tuning only: phase counters -> first bytes of idxs' scratch
+    static unsigned long long *dbg = nullptr;
+    if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 64 * 16 * 8);
+    hipLaunchKernelGGL((fps_bucket_kernel<16, 1, 1, true>), dim3(b), dim3(1024), 0, s, n, p.np, m,
+                       bs, log2bs, dataset, spts, sk, idxs, dbg);
+    (void)hipStreamSynchronize(s);
+    unsigned long long h[16 * 8];
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    const char *names[5] = {"bbox-test", "bucket-update", "wave-argmax+slot", "barrier",
+                            "block-argmax"};
+    for (int w = 0; w < 16; w += 5) {
+      fprintf(stderr, "[fps prof] scene 0 wave %2d:", w);
+      for (int i = 0; i < 5; ++i)
+        fprintf(stderr, " %s %.0f", names[i], (double)h[w * 8 + i] / (m - 1));
+      fprintf(stderr, " cycles/step; touched buckets/step %.2f\n", (double)h[w * 8 + 5] / (m - 1));
+    }
+    return check_launch("furthest_point_sampling(bucket,prof)");
+  }
   // (waves, unroll) default 16,1; BTR_FPS_CFG="NW,UB" selects another instantiation (tuning)
   int nw = kBucketWaves, ub = 1;
   if (const char *e = getenv("BTR_FPS_CFG")) sscanf(e, "%d,%d", &nw, &ub);

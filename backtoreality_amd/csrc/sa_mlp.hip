@@ -483,7 +483,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
   constexpr int TN = 32 * TNW;      // n columns of G staged per step
   constexpr int LG = TN + 4, LX = 68;
   constexpr int KT = TNW == 4 ? 2 : 1;  // 32-wide k tiles per wave
-  constexpr int GP = TN / 32;           // float4 passes for G: (TN/4 threads per row)
   __shared__ __attribute__((aligned(16))) float Gs[BR * LG];
   __shared__ __attribute__((aligned(16))) float Xs[BR * LX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, int bs, int log2bs
       } else if (win) {
         sl[wave] = FpsSlot{mh, ml, bk, bx, by, bz, 0, 0};
       }
-      __syncthreads();
+      lds_barrier();
       const int s = lane & 15;
       FpsSlot v = FpsSlot{0u, 0u, 0, x0, y0, z0, 0, 0};
       if (s < NW) v = sl[s];

@@ -122,6 +122,42 @@ def test_ball_query_matches_oracle(cuda, B, N, M, r, S):
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("kind,B,N,M,r,S", [("surface", 8, 40000, 2048, 0.2, 64),
+                                             ("uniform", 2, 30000, 1024, 0.3, 32),
+                                             ("surface", 2, 80000, 2048, 0.2, 64),
+                                             ("surface", 2, 9000, 300, 0.05, 8),
+                                             ("surface", 2, 20000, 64, 0.8, 16)])
+def test_ball_query_grid_matches_oracle_and_brute_force(cuda, monkeypatch, kind, B, N, M, r, S):
+    """Large scenes take the grid-culled kernel; it must reproduce the oracle and the
+    brute-force HIP kernel (BTR_BQ_IMPL=brute) bit for bit (BASELINE size included)."""
+    xyz = _scene_xyz(B, N, kind=kind)
+    inds = oracle.furthest_point_sampling(xyz[:, : min(N, 20000)], M)
+    new_xyz = np.take_along_axis(xyz, inds[:, :, None].astype(np.int64), 1)
+    new_xyz[:, -1] += 50.0   # a centre far outside the scene -> empty row
+    new_xyz[:, -2, 2] -= 0.15  # and one below the floor
+    ref = oracle.ball_query(new_xyz, xyz, r, S)
+    got = _ext().ball_query(_t(new_xyz, cuda), _t(xyz, cuda), r, S).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    monkeypatch.setenv("BTR_BQ_IMPL", "brute")
+    got = _ext().ball_query(_t(new_xyz, cuda), _t(xyz, cuda), r, S).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_ball_query_grid_duplicates_and_dense(cuda):
+    rng = np.random.default_rng(21)
+    xyz = rng.uniform(0, 2, size=(1, 12000, 3)).astype(np.float32)
+    xyz[0, 4000:9000] = xyz[0, 3999]          # 5001 identical points in one cell
+    centres = np.concatenate([xyz[:, 3999:4000], xyz[:, :50]], 1)
+    ref = oracle.ball_query(centres, xyz, 0.1, 32)
+    got = _ext().ball_query(_t(centres, cuda), _t(xyz, cuda), 0.1, 32).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    flat = np.zeros((1, 10000, 3), np.float32)  # zero-extent scene
+    flat[0, :, 0] = 1.0
+    ref = oracle.ball_query(flat[:, :5], flat, 0.2, 16)
+    got = _ext().ball_query(_t(flat[:, :5].copy(), cuda), _t(flat, cuda), 0.2, 16).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
 def test_ball_query_edge_cases(cuda):
     xyz = np.zeros((1, 70, 3), np.float32)
     xyz[0, :, 0] = np.arange(70) * 0.5
