@@ -157,6 +157,21 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(substr):
+    """HBM bytes per launch of the kernel whose name contains `substr`, from the committed
+    rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py from
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE doubled per
+    the gfx950 correction in MI355X_MICROARCH.md).  None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        ks = json.load(fh)["kernels"]
+    cands = [(v["read_bytes_corrected"] + v["write_bytes"], k) for k, v in ks.items()
+             if substr in k]
+    return max(cands)[0] if cands else None
+
+
 def roofline_objects(kernels, detail, detail_steps):
     """kernels / detail: {(op, shape-key): [ms, ...]} from the HIP-event timer in `_ext`
     (`kernels`: inside the timed region; `detail`: the instrumented steps after it).
@@ -183,8 +198,10 @@ def roofline_objects(kernels, detail, detail_steps):
         ach = nbytes / (ms * 1e-3) / 1e9
         res["ball_query_roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                      "traffic": None, "shape": [b, n, m, s], "avg_ms": ms,
-                                      "distance_tests": b * n * m}
+                                      "traffic": pmc_traffic("bq_grid_query_kernel"),
+                                      "algorithmic_bytes": nbytes,
+                                      "shape": [b, n, m, s], "avg_ms": ms,
+                                      "note": "grid-culled query incl. grid build (5 launches)"}
     # grouped shared MLP: every f32-MFMA GEMM launch of the fused SA path (fwd NT with BN
     # prologue/epilogue, dgrad NT, wgrad TN); flops = 2*rows*n*k per launch
     gemm = [(k, t) for (o, k), t in detail.items() if o in ("sa_gemm_nt", "sa_gemm_tn")]
@@ -204,8 +221,13 @@ def roofline_objects(kernels, detail, detail_steps):
         nbytes = b * (12 * n + 4 * m)
         ach = nbytes / (ms * 1e-3) / 1e9
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "kernel": "fps_kernel", "shape": [b, n, m], "avg_ms": ms,
+                           "frac": ach / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic("fps_bucket_kernel"),
+                           "algorithmic_bytes": nbytes,
+                           "kernel": "fps_bucket_kernel (+fps_sort_kernel)",
+                           "shape": [b, n, m], "avg_ms": ms,
+                           "note": "bound by m-1 dependent arg-max steps per scene (one CU per "
+                                   "scene), not by bytes: see iterations_per_s",
                            "streaming_GBs": b * (m - 1) * n * 20 / (ms * 1e-3) / 1e9,
                            "iterations_per_s": b * (m - 1) / (ms * 1e-3)}
     return res
