@@ -218,7 +218,7 @@ constexpr int kFpsRegsMaxN = 4096;  // up to here every point lives in VGPRs for
 // BTR_FPS_IMPL=stream forces the plain streaming kernel for large n (A/B and cross-checks).
 static bool fps_force_stream() {
   const char *e = getenv("BTR_FPS_IMPL");
-  return e && e[0] == 's';
+  return e && e[0] == 's' && e[1] == 't';  // "stream" ("single" selects a bucket variant)
 }
 
 static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,

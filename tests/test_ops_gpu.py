@@ -60,6 +60,29 @@ def test_fps_full_size_and_both_large_kernels(cuda, monkeypatch):
     monkeypatch.setenv("BTR_FPS_IMPL", "stream")
     got = _ext().furthest_point_sampling(x[:2], 600).cpu().numpy()
     np.testing.assert_array_equal(got, ref[:2, :600])
+    monkeypatch.setenv("BTR_FPS_IMPL", "multi")   # several samples per round, still exact
+    got = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_multi_sample_rounds_ties_and_skips(cuda, monkeypatch):
+    monkeypatch.setenv("BTR_FPS_IMPL", "multi")
+    rng = np.random.default_rng(12)
+    xyz = rng.uniform(-3, 3, size=(2, 12000, 3)).astype(np.float32)
+    xyz[:, 500:900] *= 0.004
+    xyz[1, 3000:6000] = xyz[1, 2999]
+    ref = oracle.furthest_point_sampling(xyz, 900)
+    got = _ext().furthest_point_sampling(_t(xyz, cuda), 900).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    for bs in (1, 8, 512):
+        base = rng.uniform(0.2, 3.0, size=(1, 3000, 3)).astype(np.float32)
+        dup = np.concatenate([base, base, base], 1)
+        ref = oracle.furthest_point_sampling(dup, 300, block_size=bs)
+        got = _ext().furthest_point_sampling_bs(_t(dup, cuda), 300, bs).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+    same = np.tile(np.array([[1.5, -2.0, 0.25]], np.float32), (1, 9000, 1))
+    got = _ext().furthest_point_sampling(_t(same, cuda), 50).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.furthest_point_sampling(same, 50))
 
 
 @pytest.mark.parametrize("kind,N", [("uniform", 30000), ("surface", 65536), ("surface", 4097),
