@@ -690,17 +690,7 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
       if (!dbg2) (void)hipMalloc(&dbg2, sizeof(unsigned long long) * 4096);
       rd = dbg2;
     }
-    if (!single && !getenv("BTR_FPS_CFG")) {
-      int ub = 2, km = 8;
-      if (const char *t = getenv("BTR_FPS_MULTI")) sscanf(t, "%d,%d", &ub, &km);
-#define BTR_M(UB_, KM_)                                                                       \
-  if (p.nb <= 16 * 64 && ub == UB_ && km == KM_)                                              \
-    hipLaunchKernelGGL((fps_bucket_multi_kernel<16, 1, UB_, KM_>), dim3(b), dim3(1024), 0, s, \
-                       n, p.np, m, bs, log2bs, dataset, spts, sk, idxs, rd);                  \
-  else
-      BTR_M(1, 2) BTR_M(1, 4) BTR_M(2, 4) BTR_M(4, 4) BTR_M(1, 8) BTR_M(4, 8) BTR_M(2, 2)
-      BTR_M(4, 16) BTR_M(2, 16)
-#undef BTR_M
+    if (!single) {
       if (p.nb <= 16 * 64)
         hipLaunchKernelGGL((fps_bucket_multi_kernel<16, 1, 2, 8>), dim3(b), dim3(1024), 0, s, n,
                            p.np, m, bs, log2bs, dataset, spts, sk, idxs, rd);
@@ -717,24 +707,7 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
       return check_launch("furthest_point_sampling(bucket,multi)");
     }
   }
-  // (waves, unroll) default 16,1; BTR_FPS_CFG="NW,UB" selects another instantiation (tuning)
-  int nw = kBucketWaves, ub = 1;
-  if (const char *e = getenv("BTR_FPS_CFG")) sscanf(e, "%d,%d", &nw, &ub);
-  const int sl = cdiv(p.nb, nw * 64);
-#define BTR_FPS_B(NW_, SL_, UB_)                                                              \
-  if (nw == NW_ && sl == SL_ && ub == UB_) {                                                  \
-    hipLaunchKernelGGL((fps_bucket_kernel<NW_, SL_, UB_>), dim3(b), dim3(NW_ * 64), 0, s, n, \
-                       p.np, m, bs, log2bs, dataset, spts, sk, idxs);                         \
-    return check_launch("furthest_point_sampling(bucket)");                                   \
-  }
-  BTR_FPS_B(16, 1, 1) BTR_FPS_B(16, 2, 1) BTR_FPS_B(16, 1, 2) BTR_FPS_B(16, 2, 2)
-  BTR_FPS_B(8, 1, 1) BTR_FPS_B(8, 2, 1) BTR_FPS_B(8, 3, 1) BTR_FPS_B(8, 4, 1)
-  BTR_FPS_B(8, 1, 2) BTR_FPS_B(8, 2, 2) BTR_FPS_B(8, 3, 2) BTR_FPS_B(8, 4, 2)
-  BTR_FPS_B(8, 2, 4)
-  BTR_FPS_B(4, 1, 2) BTR_FPS_B(4, 2, 2) BTR_FPS_B(4, 3, 2) BTR_FPS_B(4, 4, 2)
-  BTR_FPS_B(4, 1, 4) BTR_FPS_B(4, 2, 4) BTR_FPS_B(4, 3, 4) BTR_FPS_B(4, 4, 4)
-#undef BTR_FPS_B
-  // fall back to the default shape
+  // one-sample-per-step kernel: 16 waves, one bucket per trip (measured best)
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);

@@ -29,16 +29,15 @@ __global__ __launch_bounds__(64) void three_nn_kernel(int n, int m,
   for (int k = 0; k < m; ++k) {
     const float x = known[k * 3 + 0], y = known[k * 3 + 1], z = known[k * 3 + 2];
     const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
-    if (d < best1) {
-      best3 = best2; besti3 = besti2;
-      best2 = best1; besti2 = besti1;
-      best1 = d;     besti1 = k;
-    } else if (d < best2) {
-      best3 = best2; besti3 = besti2;
-      best2 = d;     besti2 = k;
-    } else if (d < best3) {
-      best3 = d;     besti3 = k;
-    }
+    // branch-free form of the reference's if / else-if / else-if insertion (:39-54):
+    // strict `<` against the current 1st/2nd/3rd keeps the earliest index on ties
+    const bool c1 = d < best1, c2 = d < best2, c3 = d < best3;
+    best3 = c2 ? best2 : (c3 ? d : best3);
+    besti3 = c2 ? besti2 : (c3 ? k : besti3);
+    best2 = c1 ? best1 : (c2 ? d : best2);
+    besti2 = c1 ? besti1 : (c2 ? k : besti2);
+    best1 = c1 ? d : best1;
+    besti1 = c1 ? k : besti1;
   }
   float *d2 = dist2 + ((size_t)bi * n + j) * 3;
   int *id = idx + ((size_t)bi * n + j) * 3;

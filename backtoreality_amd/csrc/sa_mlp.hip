@@ -665,12 +665,34 @@ __global__ __launch_bounds__(256) void csr_reduce_kernel(
   const int *rf = refs + (size_t)bi * ms;
   const float *base = dX + (size_t)bi * ms * ldx;
   if (dfeat_cl) {
-    for (int c0 = 0; c0 < C; c0 += 64) {
-      const int c = c0 + lane;
-      float acc = 0.f;
-      if (c < C)
-        for (int i = beg; i < end; ++i) acc += base[(size_t)rf[i] * ldx + xoff + c];
-      if (c < C) dfeat_cl[((size_t)bi * N + n) * C + c] = acc;
+    // up to 4 channels per lane (C <= 256), 4 neighbour rows in flight per iteration
+    for (int c0 = 0; c0 < C; c0 += 256) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      int i = beg;
+      for (; i + 4 <= end; i += 4) {
+        const float *r0 = base + (size_t)rf[i] * ldx + xoff;
+        const float *r1 = base + (size_t)rf[i + 1] * ldx + xoff;
+        const float *r2 = base + (size_t)rf[i + 2] * ldx + xoff;
+        const float *r3 = base + (size_t)rf[i + 3] * ldx + xoff;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + q * 64 + lane;
+          if (c < C) acc[q] += (r0[c] + r1[c]) + (r2[c] + r3[c]);
+        }
+      }
+      for (; i < end; ++i) {
+        const float *r0 = base + (size_t)rf[i] * ldx + xoff;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c0 + q * 64 + lane;
+          if (c < C) acc[q] += r0[c];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + q * 64 + lane;
+        if (c < C) dfeat_cl[((size_t)bi * N + n) * C + c] = acc[q];
+      }
     }
   }
   if (dxyz && lane < 3) {
@@ -719,7 +741,7 @@ int btr_sa_gather(int b, int n, int m, int s, int c, int ldx, int use_xyz, float
 }
 
 // Number of workgroups (= rows of the `part` buffer) btr_sa_gemm_nt uses along rows.
-int btr_sa_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, kBM), 1024)); }
+int btr_sa_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, kBM), 512)); }
 
 // C[rows][n] = f(A)[rows][k] . W[n][k]^T;  pa/pb != NULL: f = relu(pa*y+pb) per k;
 // part != NULL: per-workgroup column sums / sums of squares -> part[grid][2][n].
@@ -796,7 +818,7 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
   BTR_REQUIRE(c <= kBnBwdMaxC && c % 4 == 0 && ld % 4 == 0,
               "sa_bn_relu_bwd: %d channels must be a multiple of 4 and <= %d", c, kBnBwdMaxC);
   hipStream_t st = as_stream(stream);
-  const int nblk = (int)std::min<long long>(cdiv(rows, 256 / (c / 4)), 1024);
+  const int nblk = (int)std::min<long long>(cdiv(rows, 256 / (c / 4)), 512);
   hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ld, g, y,
                      scale, shift, mean, invstd, part);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 16)), dim3(256), 0, st, c, nblk,

@@ -199,3 +199,120 @@ def get_loss(end_points, config):
         (torch.sum(objectness_mask) + 1e-6)
     end_points['obj_acc'] = obj_acc
     return loss, end_points
+
+
+# ------------------------------------------------------------------ Back-to-Reality (DA) loss
+def compute_weak_vote_loss(end_points):
+    """Votes only need to land on SOME object centre (loss_helper.py:71-109): chamfer in both
+    directions between the votes and the GT centres, L1."""
+    B, num_seed = end_points['seed_xyz'].shape[0], end_points['seed_xyz'].shape[1]
+    vote_xyz = end_points['vote_xyz']
+    gt_center = end_points['center_label'][:, :, 0:3]
+    dist1, _, dist2, _ = nn_distance(vote_xyz, gt_center, l1=True)
+    votes_dist, _ = torch.min(dist1.view(B, num_seed, -1), dim=2)
+    box_label_mask = end_points['box_label_mask']
+    object_weight = torch.ones_like(end_points['sem_cls_label'])
+    return torch.mean(votes_dist) + torch.sum(dist2 * object_weight * box_label_mask) / \
+        (torch.sum(box_label_mask) + 1e-6)
+
+
+def compute_center_and_sem_cls_loss(end_points, config):
+    """Centre, size-class and semantic-class terms only (weak labels) (loss_helper.py:242-308)."""
+    object_assignment = end_points['object_assignment']
+    objectness_label = end_points['objectness_label'].float()
+    ce = nn.CrossEntropyLoss(reduction='none')
+    pred_center = end_points['center']
+    gt_center = end_points['center_label'][:, :, 0:3]
+    dist1, _, dist2, _ = nn_distance(pred_center, gt_center)
+    center_loss = (_masked_mean(dist1, objectness_label) +
+                   _masked_mean(dist2, end_points['box_label_mask']))
+    size_class_label = torch.gather(end_points['size_class_label'], 1, object_assignment)
+    size_class_loss = ce(end_points['size_scores'].transpose(2, 1), size_class_label)
+    size_class_loss = _masked_mean(size_class_loss, objectness_label)
+    sem_cls_label = torch.gather(end_points['sem_cls_label'], 1, object_assignment)
+    sem_cls_loss = ce(end_points['sem_cls_scores'].transpose(2, 1), sem_cls_label)
+    sem_cls_loss = _masked_mean(sem_cls_loss, objectness_label)
+    return center_loss, size_class_loss, sem_cls_loss
+
+
+def focal_loss(inputs, targets, gamma):
+    """mean over the batch of -(1 - p_t)^gamma * log(p_t), p = softmax(inputs)
+    (FocalLoss with alpha = 1, loss_helper.py:466-545)."""
+    P = torch.softmax(inputs, dim=-1)
+    probs = torch.gather(P, 1, targets.view(-1, 1))
+    return (-torch.pow(1 - probs, gamma) * probs.log()).mean()
+
+
+def _objectness_bookkeeping(end_points):
+    loss, label, mask, assignment = compute_objectness_loss(end_points)
+    end_points['objectness_loss'] = loss
+    end_points['objectness_label'] = label
+    end_points['objectness_mask'] = mask
+    end_points['object_assignment'] = assignment
+    total = float(label.shape[0] * label.shape[1])
+    end_points['pos_ratio'] = torch.sum(label.float()) / total
+    end_points['neg_ratio'] = torch.sum(mask.float()) / total - end_points['pos_ratio']
+    return loss
+
+
+def get_loss_DA(end_points_S, end_points_T, config):
+    """Loss of one Back-to-Reality step over a source (virtual, fully labelled) and a target
+    (real, weakly labelled) branch (loss_helper.py:548-664): source terms weighted 0.1, focal
+    + squared domain losses weighted 0.5 through the gradient-reversal layers."""
+    source_coefficient = 0.1
+    vote_loss_S = compute_weak_vote_loss(end_points_S)
+    vote_loss_T = compute_weak_vote_loss(end_points_T)
+    end_points_S['vote_loss'] = vote_loss_S
+    end_points_T['vote_loss'] = vote_loss_T
+    vote_loss = source_coefficient * vote_loss_S + vote_loss_T
+
+    objectness_loss = source_coefficient * _objectness_bookkeeping(end_points_S) + \
+        _objectness_bookkeeping(end_points_T)
+
+    (center_loss_S, heading_cls_loss, heading_reg_loss, size_cls_loss_S, size_reg_loss,
+     sem_cls_loss_S) = compute_box_and_sem_cls_loss(end_points_S, config)
+    end_points_S['center_loss'] = center_loss_S
+    end_points_S['heading_cls_loss'] = heading_cls_loss
+    end_points_S['heading_reg_loss'] = heading_reg_loss
+    end_points_S['size_cls_loss'] = size_cls_loss_S
+    end_points_S['size_reg_loss'] = size_reg_loss
+    end_points_S['sem_cls_loss'] = sem_cls_loss_S
+    box_loss_S = (center_loss_S + 0.1 * heading_cls_loss + heading_reg_loss +
+                  0.1 * size_cls_loss_S + size_reg_loss)
+    end_points_S['box_loss'] = box_loss_S
+
+    center_loss_T, size_cls_loss_T, sem_cls_loss_T = \
+        compute_center_and_sem_cls_loss(end_points_T, config)
+    end_points_T['center_loss'] = center_loss_T
+    end_points_T['size_cls_loss'] = size_cls_loss_T
+    end_points_T['sem_cls_loss'] = sem_cls_loss_T
+    box_loss_T = center_loss_T + 0.1 * size_cls_loss_T
+
+    box_loss = source_coefficient * box_loss_S + box_loss_T
+    sem_cls_loss = source_coefficient * sem_cls_loss_S + sem_cls_loss_T
+
+    da_coefficient = 0.5
+    g_S = end_points_S['global_d_pred']
+    l_S = end_points_S['local_d_pred'].transpose(1, 2).contiguous()
+    domain_S = torch.zeros(g_S.size(0), dtype=torch.long, device=g_S.device)
+    w_S = end_points_S['objectness_label'].unsqueeze(-1)
+    source_dloss = da_coefficient * torch.mean(l_S ** 2 * w_S) + \
+        da_coefficient * focal_loss(g_S, domain_S, 3)
+    g_T = end_points_T['global_d_pred']
+    l_T = end_points_T['local_d_pred'].transpose(1, 2).contiguous()
+    domain_T = torch.ones(g_T.size(0), dtype=torch.long, device=g_T.device)
+    w_T = end_points_T['objectness_label'].unsqueeze(-1)
+    target_dloss = da_coefficient * torch.mean((1 - l_T) ** 2 * w_T) + \
+        da_coefficient * focal_loss(g_T, domain_T, 3)
+    DA_loss = source_dloss + target_dloss
+    end_points_S['DA_loss'] = DA_loss
+
+    loss = vote_loss + 0.5 * objectness_loss + box_loss + 0.1 * sem_cls_loss + DA_loss
+    loss = loss * 10
+    end_points_S['loss'] = loss
+
+    obj_pred_val = torch.argmax(end_points_S['objectness_scores'], 2)
+    label_S, mask_S = end_points_S['objectness_label'], end_points_S['objectness_mask']
+    end_points_S['obj_acc'] = torch.sum((obj_pred_val == label_S.long()).float() * mask_S) / \
+        (torch.sum(mask_S) + 1e-6)
+    return loss, end_points_S, end_points_T

@@ -14,6 +14,7 @@ import torch.distributed as dist
 
 from . import loss_helper
 from .votenet import VoteNet
+from .votenet_da import VoteNet_DA
 
 
 def init_distributed(backend=None):
@@ -35,11 +36,12 @@ def init_distributed(backend=None):
 
 
 def build_model(cfg, device, input_feature_dim=1, num_proposal=256, vote_factor=1,
-                sampling='vote_fps', seed=0):
-    """Random-init VoteNet (weights from torch.manual_seed(seed), modules constructed in the
-    reference's order) on `device`."""
+                sampling='vote_fps', seed=0, domain_adaptation=False):
+    """Random-init VoteNet (or VoteNet_DA) (weights from torch.manual_seed(seed), modules
+    constructed in the reference's order) on `device`."""
     torch.manual_seed(seed)
-    net = VoteNet(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster, cfg.mean_size_arr,
+    cls = VoteNet_DA if domain_adaptation else VoteNet
+    net = cls(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster, cfg.mean_size_arr,
                   input_feature_dim=input_feature_dim, num_proposal=num_proposal,
                   vote_factor=vote_factor, sampling=sampling)
     return net.to(device)
@@ -72,3 +74,21 @@ def train_step(net, optimizer, batch, cfg):
     loss.backward()
     optimizer.step()
     return loss, end_points
+
+
+def train_step_br(net, optimizer, batch_S, batch_T, cfg):
+    """One Back-to-Reality step (detection/Votenet/train_Votenet_BR.py:267-289): the SAME
+    VoteNet_DA runs a source (virtual scenes) and a target (real scenes) forward -- BatchNorm
+    running statistics are updated twice -- then one `get_loss_DA`, one backward, one Adam
+    step.  Two scenes batches = 2 x batch scenes of hot-path work per step."""
+    optimizer.zero_grad(set_to_none=True)
+    end_points_S = net({'point_clouds': batch_S['point_clouds']})
+    end_points_T = net({'point_clouds': batch_T['point_clouds']})
+    for key in batch_S:
+        end_points_S[key] = batch_S[key]
+    for key in batch_T:
+        end_points_T[key] = batch_T[key]
+    loss, end_points_S, end_points_T = loss_helper.get_loss_DA(end_points_S, end_points_T, cfg)
+    loss.backward()
+    optimizer.step()
+    return loss, end_points_S, end_points_T

@@ -34,6 +34,9 @@ def parse():
     p.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     p.add_argument("--points", type=int, default=40000)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--workload", choices=["fsb", "br"], default="fsb",
+                   help="fsb: VoteNet FSB step (BASELINE configs[1], the headline); br: the "
+                        "two-branch Back-to-Reality step (configs[2]), 2 x batch scenes per step")
     p.add_argument("--cpu-points", type=int, default=40000)
     return p.parse_args()
 
@@ -92,11 +95,17 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = config.scannet_md40()
-    net = train.build_model(cfg, dev)
+    br = args.workload == "br"
+    net = train.build_model(cfg, dev, domain_adaptation=br)
     ddp = train.wrap_ddp(net, dev)
     opt = train.make_optimizer(net)
     B = args.batch
     batch = synthetic.make_batch(rank * B, B, args.points, cfg, device=dev)  # resident in HBM
+    if br:  # source + target branch: two forwards, one backward (train_Votenet_BR.py:267-289)
+        batch_T = synthetic.make_batch(100000 + rank * B, B, args.points, cfg, device=dev)
+        train_step = lambda n, o, b, c: train.train_step_br(n, o, b, batch_T, c)[:2]  # noqa: E731
+    else:
+        train_step = train.train_step
 
     def barrier():
         torch.cuda.synchronize()
@@ -105,7 +114,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        train.train_step(ddp, opt, batch, cfg)
+        train_step(ddp, opt, batch, cfg)
     barrier()
     # Timed region: HIP event pairs only around the two kernels the metric names (the
     # large-scene FPS = dominant hand-written kernel, and the SA1 ball query): 2 pairs/step.
@@ -113,7 +122,7 @@ def main():
                       and key[1] > 4096)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        train.train_step(ddp, opt, batch, cfg)
+        train_step(ddp, opt, batch, cfg)
     barrier()
     elapsed = time.perf_counter() - t0
     kernels = _ext.timing_end()
@@ -122,7 +131,7 @@ def main():
     detail_steps = 3
     _ext.timing_begin()
     for _ in range(detail_steps):
-        train.train_step(ddp, opt, batch, cfg)
+        train_step(ddp, opt, batch, cfg)
     barrier()
     detail = _ext.timing_end()
     if world > 1:
@@ -131,7 +140,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        scenes = world * B * args.steps
+        scenes = world * B * args.steps * (2 if br else 1)
         out = {
             "metric": "scenes/sec (40k-pt VoteNet fwd+bwd)",
             "value": scenes / elapsed,
@@ -145,8 +154,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "VoteNet FSB train step (fwd+loss+bwd+Adam), %d points, "
-                                   "batch %d per GPU, scannet-md40 heads" % (args.points, B),
+            "config": {"workload": ("VoteNet BR (VoteNet_DA, source+target forward, get_loss_DA, "
+                                    "one backward, Adam), 2 x %d scenes of %d points per GPU"
+                                    if br else
+                                    "VoteNet FSB train step (fwd+loss+bwd+Adam), %d points, "
+                                    "batch %d per GPU, scannet-md40 heads") %
+                                   ((B, args.points) if br else (args.points, B)),
                        "points": args.points, "batch_per_gpu": B, "parallelism": "dp%d" % world},
         }
         out.update(roofline_objects(kernels, detail, detail_steps))
