@@ -38,6 +38,39 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
+    def prefetch_sampling(self, pointcloud):
+        """Start the sampling pyramid of `pointcloud` on the side stream NOW and return a
+        handle to pass to forward(..., sampling=handle).  Sampling depends on coordinates
+        only, so a caller that runs several forwards per step (the Back-to-Reality step runs a
+        source and a target branch, train_Votenet_BR.py:277-278) can overlap the second
+        branch's FPS with the first branch's forward.  Same indices as computing them inline."""
+        xyz, _ = self._break_up_pc(pointcloud)
+        if not xyz.is_cuda or os.environ.get("BTR_OVERLAP_FPS", "1") == "0":
+            return None
+        main = torch.cuda.current_stream(xyz.device)
+        side = self._get_side_stream(xyz.device)
+        side.wait_stream(main)
+        npoints = [getattr(self, "sa%d" % i).npoint for i in (1, 2, 3, 4)]
+        out = []
+        with torch.cuda.stream(side):
+            cur, inds = xyz, None
+            for li, npoint in enumerate(npoints):
+                if li > 0:
+                    cur = torch.gather(cur, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+                    cur.record_stream(side)
+                inds = pointnet2_utils.furthest_point_sample(cur, npoint)
+                inds.record_stream(main)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                out.append((inds, ev))
+        xyz.record_stream(side)
+        return out
+
+    def _get_side_stream(self, device):
+        if getattr(self, "_side_stream", None) is None or self._side_stream.device != device:
+            self._side_stream = torch.cuda.Stream(device=device)
+        return self._side_stream
+
     def _fps_pyramid(self, xyz):
         """Sampling indices of all four SA levels.  They depend on coordinates only, so levels
         2-4 run on a side HIP stream while the main stream is busy with SA1's grouped MLP (FPS
@@ -50,9 +83,7 @@ class Pointnet2Backbone(nn.Module):
         if not xyz.is_cuda or os.environ.get("BTR_OVERLAP_FPS", "1") == "0":
             return out + [(None, None)] * 3
         main = torch.cuda.current_stream(xyz.device)
-        if getattr(self, "_side_stream", None) is None or self._side_stream.device != xyz.device:
-            self._side_stream = torch.cuda.Stream(device=xyz.device)
-        side = self._side_stream
+        side = self._get_side_stream(xyz.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             cur, inds = xyz, inds1
@@ -66,12 +97,13 @@ class Pointnet2Backbone(nn.Module):
                 out.append((inds, ev))
         return out
 
-    def forward(self, pointcloud: torch.Tensor, end_points=None):
+    def forward(self, pointcloud: torch.Tensor, end_points=None, sampling=None):
         """pointcloud (B, N, 3 + input_feature_dim) -> end_points with sa{1..4}_{xyz,features},
-        sa1_inds, sa2_inds, fp2_{xyz,features,inds} (backbone_module.py:83-133)."""
+        sa1_inds, sa2_inds, fp2_{xyz,features,inds} (backbone_module.py:83-133).
+        `sampling`: optional handle from prefetch_sampling(pointcloud)."""
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
-        pyramid = self._fps_pyramid(xyz)
+        pyramid = sampling if sampling is not None else self._fps_pyramid(xyz)
         for i in (1, 2, 3, 4):
             inds, ready = pyramid[i - 1]
             if ready is not None:

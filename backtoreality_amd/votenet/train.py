@@ -61,16 +61,29 @@ def make_optimizer(net, lr=1e-3, weight_decay=0.0):
     return torch.optim.Adam(net.parameters(), lr=lr, weight_decay=weight_decay)
 
 
-def train_step(net, optimizer, batch, cfg):
+def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None):
     """One optimisation step on `batch` (dict of tensors already on the model's device).
     Returns (loss tensor, end_points).  No host synchronisation inside (the reference's
-    `.item()` statistics, FSB:234-237, are left to the caller)."""
+    `.item()` statistics, FSB:234-237, are left to the caller).
+
+    Optional software pipelining for loops that already hold the NEXT batch (what a data
+    loader with prefetch gives): pass `next_batch` and the sampling pyramid of that batch
+    (coordinates only, independent of the weights) is launched on the side stream under this
+    step's backward; the returned end_points['next_sampling'] is then passed as `sampling` to
+    the next call.  Results are identical to the unpipelined loop; bench.py does NOT use it."""
     optimizer.zero_grad(set_to_none=True)
-    end_points = net({'point_clouds': batch['point_clouds']})
+    inputs = {'point_clouds': batch['point_clouds']}
+    if sampling is not None:
+        inputs['sampling'] = sampling
+    end_points = net(inputs)
     for key in batch:
         assert key not in end_points
         end_points[key] = batch[key]
     loss, end_points = loss_helper.get_loss(end_points, cfg)
+    if next_batch is not None:
+        core = net.module if hasattr(net, "module") else net
+        end_points['next_sampling'] = core.backbone_net.prefetch_sampling(
+            next_batch['point_clouds'])
     loss.backward()
     optimizer.step()
     return loss, end_points
@@ -82,8 +95,12 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg):
     running statistics are updated twice -- then one `get_loss_DA`, one backward, one Adam
     step.  Two scenes batches = 2 x batch scenes of hot-path work per step."""
     optimizer.zero_grad(set_to_none=True)
+    # the target branch's sampling pyramid (coordinates only) runs on the side stream under
+    # the source branch's forward
+    core = net.module if hasattr(net, "module") else net
+    sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
     end_points_S = net({'point_clouds': batch_S['point_clouds']})
-    end_points_T = net({'point_clouds': batch_T['point_clouds']})
+    end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T})
     for key in batch_S:
         end_points_S[key] = batch_S[key]
     for key in batch_T:

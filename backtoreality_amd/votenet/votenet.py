@@ -30,7 +30,8 @@ class VoteNet(nn.Module):
 
     def forward(self, inputs):
         """inputs['point_clouds'] (B, N, 3 + input_feature_dim) -> end_points dict."""
-        end_points = self.backbone_net(inputs['point_clouds'], {})
+        end_points = self.backbone_net(inputs['point_clouds'], {},
+                                       sampling=inputs.get('sampling'))
 
         xyz = end_points['fp2_xyz']
         features = end_points['fp2_features']

@@ -56,7 +56,8 @@ class VoteNet_DA(nn.Module):
                                           [nn.Conv1d(128, 1, 1)]))
 
     def forward(self, inputs):
-        end_points = self.backbone_net(inputs['point_clouds'], {})
+        end_points = self.backbone_net(inputs['point_clouds'], {},
+                                       sampling=inputs.get('sampling'))
         xyz = end_points['fp2_xyz']
         features = end_points['fp2_features']
         end_points['seed_inds'] = end_points['fp2_inds']
