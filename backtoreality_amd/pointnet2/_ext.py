@@ -59,6 +59,9 @@ _SIGNATURES = {
     "btr_sa_scatter_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
     "btr_sa_scatter": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _cf, _vp, _vp, _vp, _vp, _vp,
                              _vp, _sz, _vp]),
+    # fused VoteNet loss (used by votenet/fused_loss.py)
+    "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 25),
+    "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 27),
 }
 
 

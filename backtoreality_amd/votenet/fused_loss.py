@@ -1,0 +1,136 @@
+"""The VoteNet loss as three HIP kernels (csrc/votenet_loss.hip) instead of ~250 torch launches.
+
+`loss_helper.get_loss` (reference: detection/Votenet/models/loss_helper.py:336-400) dispatches
+here when everything it needs is on the GPU; `BTR_FUSED_LOSS=0` keeps the op-by-op torch
+composition, which is the definition this path is tested against (tests/test_fused_loss_gpu.py)
+and which is itself pinned by the reference golden (tests/golden/votenet_fsb_step.npz).
+
+Differences visible to a caller: the per-term entries of `end_points` ('vote_loss', ...) are
+detached views of one statistics tensor -- only `loss` carries the autograd graph (the
+reference's training loop only ever calls `loss.backward()`, train.py:263).
+"""
+import os
+
+import torch
+from torch.autograd import Function
+
+from ..pointnet2 import _ext
+
+_lib = _ext._lib
+
+STAT_KEYS = ('loss', 'vote_loss', 'objectness_loss', 'center_loss', 'heading_cls_loss',
+             'heading_reg_loss', 'size_cls_loss', 'size_reg_loss', 'sem_cls_loss', 'box_loss',
+             'pos_ratio', 'neg_ratio', 'obj_acc')
+_LABEL_KEYS = ('vote_label', 'vote_label_mask', 'center_label', 'box_label_mask',
+               'heading_class_label', 'heading_residual_label', 'size_class_label',
+               'size_residual_label', 'sem_cls_label')
+_LABEL_DTYPES = (torch.float32, torch.int64, torch.float32, torch.float32, torch.int64,
+                 torch.float32, torch.int64, torch.float32, torch.int64)
+HEAD_KEY = '_head_output'  # raw (B, Cout, K) proposal-head output, stored by ProposalModule
+
+
+def enabled():
+    return os.environ.get("BTR_FUSED_LOSS", "1") != "0"
+
+
+def can_fuse(end_points, config):
+    """The fused kernels cover vote_factor 1, K <= 1024 proposals, <= 256 GT slots, all CUDA."""
+    if not enabled() or HEAD_KEY not in end_points:
+        return False
+    net = end_points[HEAD_KEY]
+    if not (net.is_cuda and net.dtype == torch.float32):
+        return False
+    if end_points['vote_xyz'].shape[1] != end_points['seed_xyz'].shape[1]:
+        return False
+    if net.shape[2] > 1024 or end_points['center_label'].shape[1] > 256:
+        return False
+    cout = 5 + 2 * config.num_heading_bin + 4 * config.num_size_cluster + config.num_class
+    if net.shape[1] != cout or end_points['center_label'].shape[2] != 3:
+        return False
+    return all(end_points[k].is_cuda and end_points[k].dtype == d
+               for k, d in zip(_LABEL_KEYS, _LABEL_DTYPES))
+
+
+class FusedVoteNetLoss(Function):
+    @staticmethod
+    def forward(ctx, net, agg_xyz, vote_xyz, seed_xyz, seed_inds, mean_size, dims, *labels):
+        nh, ns, nc = dims
+        B, cout, K = net.shape
+        K2, S1, N = labels[2].shape[1], seed_xyz.shape[1], labels[0].shape[1]
+        dev = net.device
+        if seed_inds.dtype != torch.int32:
+            seed_inds = seed_inds.int()
+        net, agg_xyz, vote_xyz, seed_xyz, seed_inds = (
+            t.contiguous() for t in (net, agg_xyz, vote_xyz, seed_xyz, seed_inds))
+        labels = tuple(t.contiguous() for t in labels)
+        objectness_label = torch.empty((B, K), dtype=torch.int64, device=dev)
+        objectness_mask = torch.empty((B, K), dtype=torch.float32, device=dev)
+        object_assignment = torch.empty((B, K), dtype=torch.int64, device=dev)
+        j1c = torch.empty((B, K), dtype=torch.int32, device=dev)
+        k2c = torch.empty((B, K2), dtype=torch.int32, device=dev)
+        vote_arg = torch.empty((B, S1), dtype=torch.int8, device=dev)
+        part = torch.empty((B, 16), dtype=torch.float32, device=dev)
+        stats = torch.empty((13,), dtype=torch.float32, device=dev)
+        norm = torch.empty((4,), dtype=torch.float32, device=dev)
+        p = _ext._p
+        with _ext._on(net) as d:
+            _ext._call(_lib.btr_votenet_loss_fwd, B, K, K2, nh, ns, nc, S1, N, cout, p(net),
+                       p(agg_xyz), p(vote_xyz), p(seed_xyz), p(seed_inds),
+                       *[p(t) for t in labels], p(mean_size), p(objectness_label),
+                       p(objectness_mask), p(object_assignment), p(j1c), p(k2c), p(vote_arg),
+                       p(part), p(stats), p(norm), _ext._stream(d))
+        ctx.dims = (B, K, K2, nh, ns, nc, S1, N, cout)
+        ctx.save_for_backward(net, agg_xyz, vote_xyz, seed_xyz, seed_inds, mean_size, norm,
+                              objectness_label, objectness_mask, object_assignment, j1c, k2c,
+                              vote_arg, *labels)
+        loss = stats[0].clone()
+        ctx.mark_non_differentiable(stats, objectness_label, objectness_mask, object_assignment)
+        return loss, stats, objectness_label, objectness_mask, object_assignment
+
+    @staticmethod
+    def backward(ctx, gloss, *_unused):
+        (net, agg_xyz, vote_xyz, seed_xyz, seed_inds, mean_size, norm, objectness_label,
+         objectness_mask, object_assignment, j1c, k2c, vote_arg, *labels) = ctx.saved_tensors
+        B, K, K2, nh, ns, nc, S1, N, cout = ctx.dims
+        gout = gloss.reshape(1).to(torch.float32).contiguous()
+        dnet = torch.empty_like(net)
+        dagg = torch.empty_like(agg_xyz)
+        dvote = torch.empty_like(vote_xyz)
+        p = _ext._p
+        with _ext._on(net) as d:
+            _ext._call(_lib.btr_votenet_loss_bwd, B, K, K2, nh, ns, nc, S1, N, cout, p(gout),
+                       p(norm), p(net), p(agg_xyz), p(vote_xyz), p(seed_xyz), p(seed_inds),
+                       *[p(t) for t in labels], p(mean_size), p(objectness_label),
+                       p(objectness_mask), p(object_assignment), p(j1c), p(k2c), p(vote_arg),
+                       p(dnet), p(dagg), p(dvote), _ext._stream(d))
+        return (dnet, dagg, dvote, None, None, None, None) + (None,) * len(labels)
+
+
+def _mean_size(config, dev):
+    cache = getattr(config, "_mean_size_dev", None)
+    if cache is None or cache.device != dev:
+        import numpy as np
+        cache = torch.from_numpy(np.ascontiguousarray(config.mean_size_arr, np.float32)).to(dev)
+        try:
+            config._mean_size_dev = cache
+        except AttributeError:
+            pass
+    return cache
+
+
+def get_loss(end_points, config):
+    """Same contract as loss_helper.get_loss: returns (loss, end_points) with every term,
+    'objectness_label', 'objectness_mask' and 'object_assignment' filled in."""
+    net = end_points[HEAD_KEY]
+    dims = (config.num_heading_bin, config.num_size_cluster, config.num_class)
+    loss, stats, label, mask, assignment = FusedVoteNetLoss.apply(
+        net, end_points['aggregated_vote_xyz'], end_points['vote_xyz'], end_points['seed_xyz'],
+        end_points['seed_inds'], _mean_size(config, net.device), dims,
+        *[end_points[k] for k in _LABEL_KEYS])
+    for i, k in enumerate(STAT_KEYS):
+        end_points[k] = stats[i]
+    end_points['loss'] = loss
+    end_points['objectness_label'] = label
+    end_points['objectness_mask'] = mask
+    end_points['object_assignment'] = assignment
+    return loss, end_points

@@ -2,7 +2,8 @@
 (`get_loss` :336-400 and the three terms it sums) and detection/Votenet/utils/nn_distance.py.
 Same arithmetic, same `end_points` keys; the reference's hard-coded `.cuda()` /
 `torch.cuda.FloatTensor` allocations become allocations on the inputs' device.
-Stock torch ops only -- this is the caller of the hot path, not part of it.
+Stock torch ops here; `get_loss` on GPU tensors dispatches to the fused HIP kernels of
+fused_loss.py (the caller right after the hot path).
 """
 import numpy as np
 import torch
@@ -164,7 +165,14 @@ def compute_box_and_sem_cls_loss(end_points, config):
 
 
 def get_loss(end_points, config):
-    """Total VoteNet loss; fills end_points with every term (loss_helper.py:336-400)."""
+    """Total VoteNet loss; fills end_points with every term (loss_helper.py:336-400).
+    On the GPU the whole loss and its gradient run as three HIP kernels (fused_loss.py);
+    the composition below is the definition (and the path for CPU tensors, vote_factor > 1
+    or BTR_FUSED_LOSS=0)."""
+    if end_points['seed_xyz'].is_cuda:
+        from . import fused_loss
+        if fused_loss.can_fuse(end_points, config):
+            return fused_loss.get_loss(end_points, config)
     vote_loss = compute_vote_loss(end_points)
     end_points['vote_loss'] = vote_loss
 

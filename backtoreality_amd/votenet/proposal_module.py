@@ -101,5 +101,6 @@ class ProposalModule(nn.Module):
         net = F.relu(self.bn1(self.conv1(features)))
         net = F.relu(self.bn2(self.conv2(net)))
         net = self.conv3(net)
+        end_points['_head_output'] = net  # raw (B, Cout, K) scores for the fused loss
         return decode_scores(net, end_points, self.num_class, self.num_heading_bin,
                              self.num_size_cluster, self.mean_size_arr, self._mean_size_dev)

@@ -198,6 +198,47 @@ int btr_sa_scatter(int b, int n, int m, int s, int c, int ldx, int use_xyz, floa
                    float *dnew_xyz, void *workspace, size_t workspace_bytes,
                    btr_stream_t stream);
 
+/* ---- VoteNet loss, forward + backward (the caller right after the hot path).
+ * Replaces the ~250 torch launches of detection/Votenet/models/loss_helper.py:336-400
+ * (compute_vote_loss :24-69, compute_objectness_loss :111-152, compute_box_and_sem_cls_loss
+ * :154-228; nn_distance utils/nn_distance.py:34-61) with three kernels.  vote_factor 1.
+ *   net (b,cout,k): raw proposal-head output, channels as proposal_module.py:18-50
+ *     [objectness 2 | centre offset 3 | heading scores nh | heading residuals nh |
+ *      size scores ns | size residuals ns*3 | semantic nc];  agg_xyz (b,k,3); vote_xyz,
+ *   seed_xyz (b,s1,3); seed_inds (b,s1) i32 into the n input points; labels as the dataset
+ *   batch dict (scannet_detection_dataset.py:197-219): vote_label (b,n,9), vote_label_mask
+ *   (b,n) i64, center_label (b,k2,3), box_label_mask (b,k2), heading_class_label (b,k2) i64,
+ *   heading_residual_label (b,k2), size_class_label (b,k2) i64, size_residual_label (b,k2,3),
+ *   sem_cls_label (b,k2) i64, mean_size (ns,3).
+ * Outputs: objectness_label (b,k) i64, objectness_mask (b,k) f32, object_assignment (b,k) i64;
+ *   stats[13] = loss, vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg,
+ *   sem_cls, box, pos_ratio, neg_ratio, obj_acc.  Kept for the backward: j1c (b,k) i32,
+ *   k2c (b,k2) i32, vote_arg (b,s1) i8, part (b,16) f32, norm (4) f32. */
+int btr_votenet_loss_fwd(int b, int k, int k2, int nh, int ns, int nc, int s1, int n, int cout,
+                         const float *net, const float *agg_xyz, const float *vote_xyz,
+                         const float *seed_xyz, const int *seed_inds, const float *vote_label,
+                         const long long *vote_label_mask, const float *center_label,
+                         const float *box_label_mask, const long long *heading_class_label,
+                         const float *heading_residual_label, const long long *size_class_label,
+                         const float *size_residual_label, const long long *sem_cls_label,
+                         const float *mean_size, long long *objectness_label,
+                         float *objectness_mask, long long *object_assignment, int *j1c, int *k2c,
+                         signed char *vote_arg, float *part, float *stats, float *norm,
+                         btr_stream_t stream);
+/* dnet (b,cout,k), dagg (b,k,3), dvote (b,s1,3) <- d loss / d input, times gout[0]. */
+int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, int n, int cout,
+                         const float *gout, const float *norm, const float *net,
+                         const float *agg_xyz, const float *vote_xyz, const float *seed_xyz,
+                         const int *seed_inds, const float *vote_label,
+                         const long long *vote_label_mask, const float *center_label,
+                         const float *box_label_mask, const long long *heading_class_label,
+                         const float *heading_residual_label, const long long *size_class_label,
+                         const float *size_residual_label, const long long *sem_cls_label,
+                         const float *mean_size, const long long *objectness_label,
+                         const float *objectness_mask, const long long *object_assignment,
+                         const int *j1c, const int *k2c, const signed char *vote_arg, float *dnet,
+                         float *dagg, float *dvote, btr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
