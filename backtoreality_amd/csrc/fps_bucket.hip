@@ -44,12 +44,27 @@ __device__ __forceinline__ int morton_cell(float x, float y, float z, float mnx,
   return (int)(spread5(qx) | (spread5(qy) << 1) | (spread5(qz) << 2));
 }
 
-// One workgroup per scene.  Output: spts[np] = {x, y, z, t0} with t0 = 1e10 (competing) or -1
-// (skipped by the |p|^2 <= 1e-3 rule, or padding), sk[np] = original index (-1 for padding),
-// np = 64 * ceil(n / 64), both in Morton-cell order.
+// Bucket storage: structure of arrays per bucket of 64 points -- x[64] y[64] z[64] k[64] (k =
+// bits of the original index): every component of a bucket is one fully coalesced 256-byte
+// wave load into its own register (a float4-per-point load needs 4 consecutive registers,
+// and the register shuffles around a PREFETCHED float4 wait for its load).
+__device__ __forceinline__ size_t soa_at(size_t pos, int comp) {
+  return (pos >> 6) * 256 + (size_t)comp * 64 + (pos & 63);
+}
+__device__ __forceinline__ float4 soa_point(const float *sp, size_t pos) {
+  return make_float4(sp[soa_at(pos, 0)], sp[soa_at(pos, 1)], sp[soa_at(pos, 2)],
+                     sp[soa_at(pos, 3)]);
+}
+
+// One workgroup per scene.  Output: spts = the bucket-SoA points {x, y, z, bits(original index)}
+// (read-only from here on; index -1 for padding) and tmin[np] = 1e10 (competing) or -1 (skipped by the
+// |p|^2 <= 1e-3 rule, or padding), np = 64 * ceil(n / 64), both in Morton-cell order.
+// The min-dists live in their OWN array: the per-bucket write-back is then 2 full 128-B lines
+// instead of 64 dwords strewn over 8 lines -- with 16 waves doing it the strided form costs
+// ~1050 cycles per dependent bucket load, the contiguous one ~490 (tools/probe/lat_probe.hip).
 __global__ __launch_bounds__(kSortThreads) void fps_sort_kernel(
     int n, int np, const float *__restrict__ dataset, float4 *__restrict__ spts,
-    int *__restrict__ sk) {
+    float *__restrict__ tmin) {
   extern __shared__ __attribute__((aligned(16))) int smem[];
   int *hist = smem;                       // kCells
   float *red = (float *)(smem + kCells);  // 6 * 16 floats
@@ -58,7 +73,7 @@ __global__ __launch_bounds__(kSortThreads) void fps_sort_kernel(
   const int bi = blockIdx.x;
   dataset += (size_t)bi * n * 3;
   spts += (size_t)bi * np;
-  sk += (size_t)bi * np;
+  tmin += (size_t)bi * np;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // 1. scene bounding box
@@ -140,16 +155,22 @@ __global__ __launch_bounds__(kSortThreads) void fps_sort_kernel(
     const int pos = atomicAdd(&hist[c], 1);
     const float mag = (x * x) + (y * y) + (z * z);
     const float t0 = ((double)mag <= 1e-3) ? -1.f : 1e10f;  // sampling_gpu.cu:105-106
-    spts[pos] = make_float4(x, y, z, t0);
-    sk[pos] = k;
+    float *sp = (float *)spts;
+    sp[soa_at(pos, 0)] = x;
+    sp[soa_at(pos, 1)] = y;
+    sp[soa_at(pos, 2)] = z;
+    sp[soa_at(pos, 3)] = __int_as_float(k);
+    tmin[pos] = t0;
   }
   __syncthreads();
   // 5. pad the last bucket with non-competing copies of the last sorted point
   if (n + tid < np) {
-    float4 p = spts[n - 1];
-    p.w = -1.f;
-    spts[n + tid] = p;
-    sk[n + tid] = -1;
+    float *sp = (float *)spts;
+    sp[soa_at(n + tid, 0)] = sp[soa_at(n - 1, 0)];
+    sp[soa_at(n + tid, 1)] = sp[soa_at(n - 1, 1)];
+    sp[soa_at(n + tid, 2)] = sp[soa_at(n - 1, 2)];
+    sp[soa_at(n + tid, 3)] = __int_as_float(-1);
+    tmin[n + tid] = -1.f;
   }
 }
 
@@ -174,10 +195,10 @@ __device__ __forceinline__ int wave_argmax(unsigned hi, LoFn lo_of_lane, unsigne
   return __builtin_ctzll(__ballot(hi == mh && lo == ml));
 }
 
-struct BSlot {
-  unsigned hi, lo;
-  int k;
+struct BSlot {  // (x, y) on an even dword pair, like the float4 point: packed f32 math without
+  unsigned hi, lo;  // register shuffles (a shuffle of a prefetched point waits for its load)
   float x, y, z;
+  int k;
   int pad0, pad1;
 };
 
@@ -194,12 +215,12 @@ template <int NW, int SL, int UB, bool PROF = false>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int m, int bs,
                                                              int log2bs,
                                                              const float *__restrict__ dataset,
-                                                             float4 *__restrict__ spts,
-                                                             const int *__restrict__ sk,
+                                                             const float4 *__restrict__ spts,
+                                                             float *__restrict__ tmin,
                                                              int *__restrict__ idxs,
                                                              unsigned long long *dbg = nullptr) {
   // PROF: s_memtime phase counters (tuning builds only; BTR_FPS_PROF=1 in tools/)
-  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0, nact = 0;
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, nact = 0;
 #define BTR_PH(i)                                                  \
   if (PROF) {                                                      \
     const unsigned long long now = __builtin_amdgcn_s_memtime();   \
@@ -211,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
   const int bi = blockIdx.x;
   dataset += (size_t)bi * n * 3;
   spts += (size_t)bi * np;
-  sk += (size_t)bi * np;
+  tmin += (size_t)bi * np;
   idxs += (size_t)bi * m;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,17 +254,17 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
     mk[s] = 0;
     mx[s] = my[s] = mz[s] = 0.f;
     if (myb < nb) {
-      const float4 *p = spts + (size_t)myb * 64;
-      float4 q = p[0];
-      float ax0 = q.x, ax1 = q.x, ay0 = q.y, ay1 = q.y, az0 = q.z, az1 = q.z;
-      bool any = q.w >= 0.f;
+      const float *bp = (const float *)spts + (size_t)myb * 256;
+      const float *tm = tmin + (size_t)myb * 64;
+      float ax0 = bp[0], ax1 = ax0, ay0 = bp[64], ay1 = ay0, az0 = bp[128], az1 = az0;
+      bool any = tm[0] >= 0.f;
 #pragma unroll 8
       for (int i = 1; i < 64; ++i) {
-        q = p[i];
-        ax0 = fminf(ax0, q.x); ax1 = fmaxf(ax1, q.x);
-        ay0 = fminf(ay0, q.y); ay1 = fmaxf(ay1, q.y);
-        az0 = fminf(az0, q.z); az1 = fmaxf(az1, q.z);
-        any |= q.w >= 0.f;
+        const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
+        ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
+        ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
+        az0 = fminf(az0, qz); az1 = fmaxf(az1, qz);
+        any |= tm[i] >= 0.f;
       }
       bx0[s] = ax0; bx1[s] = ax1; by0[s] = ay0; by1[s] = ay1; bz0[s] = az0; bz1[s] = az1;
       mhi[s] = any ? __float_as_uint(1e10f) + 1u : 0u;  // competing points start at 1e10
@@ -254,7 +275,15 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
   float sx = x0, sy = y0, sz = z0;
 
   if (PROF) tlast = __builtin_amdgcn_s_memtime();
+  int wl = 0;         // this wave's best lane / key: only changes when one of the wave's
+  unsigned wh = 0u;   // buckets is touched, so idle waves reuse it
+  bool fresh = false;
   for (int j = 1; j < m; ++j) {
+    bool touched = false;
+    // SL == 1 fast path: the wave best is tracked in SGPRs while the buckets update
+    unsigned bh = 0u;
+    int bl = 0;
+    bool ambig = true;
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
       // lower bound of the distance from the sample to the bucket, rounded exactly like the
@@ -266,69 +295,110 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       const float dbox = ex * ex + ey * ey + ez * ez;
       const bool active = (__float_as_uint(dbox) + 1u) < mhi[s];  // mhi == 0: none competes
       unsigned long long todo = __ballot(active);
-      if (PROF) nact += __builtin_popcountll(todo);
+      if (PROF) {
+        nact += __builtin_popcountll(todo);
+        if (bi == 0 && lane == 0 && j < 2048)  // per-step touched-bucket count of this wave
+          ((unsigned char *)(dbg + 4096))[j * NW + wave] =
+              (unsigned char)min(255, __builtin_popcountll(todo));
+      }
       BTR_PH(0)
-      // Up to UB touched buckets per trip: all their loads are issued first (one L2 round
-      // trip for the group), then the UB independent reduction chains run interleaved.
-      while (todo) {
-        int bi_[UB];
-        float4 p_[UB];
-        int k_[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          bi_[u] = todo ? __builtin_ctzll(todo) : -1;
-          todo &= todo - 1;  // 0 stays 0
+      if (todo == 0) continue;
+      touched = true;
+      // Software-pipelined trips: the NEXT touched bucket's loads are in flight while the
+      // current one is reduced, and the arg-max over the lanes whose buckets are NOT touched
+      // runs under the first load's L2 latency.
+      // (two register sets A/B, loop unrolled by two: loop-carried copies of the prefetched
+      // registers would force the wait for the loads to the top of the loop)
+      auto fetch = [&](int b, size_t &o, float4 &p, float &t) {
+        const size_t bkt = (size_t)((s * 64 + b) * NW + wave);
+        const float *bp = (const float *)spts + bkt * 256 + lane;
+        o = bkt * 64 + lane;
+        p.x = bp[0];
+        p.y = bp[64];
+        p.z = bp[128];
+        p.w = bp[192];
+        t = tmin[o];
+      };
+      auto process = [&](int cb, size_t co, const float4 &p, float t0) {
+        if (PROF) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          BTR_PH(5)
         }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int b = (s * 64 + max(bi_[u], 0)) * NW + wave;
-          if (bi_[u] >= 0) {
-            p_[u] = spts[(size_t)b * 64 + lane];
-            k_[u] = sk[(size_t)b * 64 + lane];
-          } else {
-            p_[u] = make_float4(0.f, 0.f, 0.f, -1.f);
-            k_[u] = 0;
+        // (plain v_sub_f32 through asm: the SLP vectoriser would pair (y, z) for a packed
+        // subtract and shuffle the just-prefetched registers, i.e. wait for the load at once)
+        float dx, dy, dz;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(p.x), "v"(sx));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(p.y), "v"(sy));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(p.z), "v"(sz));
+        const float d = dx * dx + dy * dy + dz * dz;
+        const bool valid = t0 >= 0.f;
+        const float t = valid ? fminf(d, t0) : t0;
+        if (t != t0) tmin[co] = t;
+        const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
+        const unsigned mh = wave_max_u32(hi);
+        const unsigned long long cand = __ballot(hi == mh);
+        const int kk = __float_as_int(p.w);
+        int w;
+        if (__builtin_popcountll(cand) == 1) {
+          w = __builtin_ctzll(cand);
+        } else {  // exact tie (duplicated points) or an all-skipped bucket
+          const unsigned lo = (hi == mh) ? 0xffffffffu - fps_tk2(kk, tp.bs, tp.log2bs, tp.cpb)
+                                         : 0u;
+          const unsigned ml = wave_max_u32(lo);
+          w = __builtin_ctzll(__ballot(hi == mh && lo == ml));
+        }
+        const int wk = __builtin_amdgcn_readlane(kk, w);  // wave-uniform: scalar tie key
+        const unsigned wlo = 0xffffffffu - fps_tk2(wk, tp.bs, tp.log2bs, tp.cpb);
+        const float wx = rl_f(p.x, w), wy = rl_f(p.y, w), wz = rl_f(p.z, w);
+        const bool mine = lane == cb;  // the lane slot that keeps this bucket's state
+        mhi[s] = mine ? mh : mhi[s];
+        mlo[s] = mine ? wlo : mlo[s];
+        mk[s] = mine ? wk : mk[s];
+        mx[s] = mine ? wx : mx[s];
+        my[s] = mine ? wy : my[s];
+        mz[s] = mine ? wz : mz[s];
+        if (SL == 1) {
+          if (mh > bh) {
+            bh = mh;
+            bl = cb;
+            ambig = false;
+          } else if (mh == bh) {
+            ambig = true;
           }
         }
-        unsigned hi_[UB], mh_[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const float dx = p_[u].x - sx, dy = p_[u].y - sy, dz = p_[u].z - sz;
-          const float d = dx * dx + dy * dy + dz * dz;
-          const bool valid = p_[u].w >= 0.f;
-          const float t = valid ? fminf(d, p_[u].w) : p_[u].w;
-          if (bi_[u] >= 0 && t != p_[u].w) {
-            const int b = (s * 64 + bi_[u]) * NW + wave;
-            spts[(size_t)b * 64 + lane].w = t;
-          }
-          hi_[u] = valid ? __float_as_uint(t) + 1u : 0u;
+      };
+      int bA = __builtin_ctzll(todo), bB = 0;
+      todo &= todo - 1;
+      size_t oA, oB = 0;
+      float4 pA, pB = make_float4(0.f, 0.f, 0.f, 0.f);
+      float tA, tB = 0.f;
+      fetch(bA, oA, pA, tA);
+      if (SL == 1) {
+        const unsigned rv = active ? 0u : mhi[0];
+        bh = wave_max_u32(rv);
+        const unsigned long long rc = __ballot(rv == bh);
+        bl = __builtin_ctzll(rc);
+        ambig = __builtin_popcountll(rc) > 1;
+      }
+      // (process() is called separately on the prefetching and the non-prefetching path: at
+      // a join the compiler's s_waitcnt would have to cover both, i.e. wait for the prefetch)
+      for (;;) {
+        if (todo == 0) {
+          process(bA, oA, pA, tA);
+          break;
         }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) mh_[u] = wave_max_u32(hi_[u]);
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          if (bi_[u] < 0) continue;  // wave-uniform
-          const unsigned long long cand = __ballot(hi_[u] == mh_[u]);
-          int w;
-          if (__builtin_popcountll(cand) == 1) {
-            w = __builtin_ctzll(cand);
-          } else {  // exact tie (duplicated points) or an all-skipped bucket
-            const unsigned lo = (hi_[u] == mh_[u])
-                                    ? 0xffffffffu - fps_tk2(k_[u], tp.bs, tp.log2bs, tp.cpb)
-                                    : 0u;
-            const unsigned ml = wave_max_u32(lo);
-            w = __builtin_ctzll(__ballot(hi_[u] == mh_[u] && lo == ml));
-          }
-          const int wk = __builtin_amdgcn_readlane(k_[u], w);  // wave-uniform: scalar tie key
-          const unsigned wlo = 0xffffffffu - fps_tk2(wk, tp.bs, tp.log2bs, tp.cpb);
-          const bool mine = lane == bi_[u];  // the lane slot that keeps this bucket's state
-          mhi[s] = mine ? mh_[u] : mhi[s];
-          mlo[s] = mine ? wlo : mlo[s];
-          mk[s] = mine ? wk : mk[s];
-          mx[s] = mine ? rl_f(p_[u].x, w) : mx[s];
-          my[s] = mine ? rl_f(p_[u].y, w) : my[s];
-          mz[s] = mine ? rl_f(p_[u].z, w) : mz[s];
+        bB = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        fetch(bB, oB, pB, tB);
+        process(bA, oA, pA, tA);
+        if (todo == 0) {
+          process(bB, oB, pB, tB);
+          break;
         }
+        bA = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        fetch(bA, oA, pA, tA);
+        process(bB, oB, pB, tB);
       }
     }
 
@@ -347,36 +417,49 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       ly = better ? my[s] : ly;
       lz = better ? mz[s] : lz;
     }
-    unsigned wh;
-    const int wl = wave_argmax(lh, [&]() { return ll; }, wh);
-    if (lane == wl) slots[0][wave] = BSlot{wh, ll, lk, lx, ly, lz, 0, 0};
+    if (SL == 1 && touched && !ambig) {
+      wl = bl;
+      wh = bh;
+    } else if (touched || !fresh) {
+      wl = wave_argmax(lh, [&]() { return ll; }, wh);
+    }
+    fresh = true;
+    // One barrier per step: the per-wave slots are double-buffered (a wave can only reach
+    // the write of step j+2 after every wave passed the barrier of step j+1, i.e. after all
+    // reads of step j), and EVERY wave reduces the NW slots itself with row DPP ops and
+    // fetches the winner with one broadcast LDS read -- no second barrier, no readlanes
+    // (3.07 -> 2.80 ms on 8 x 40000 -> 2048 against a leader-wave reduction + 2nd barrier).
+    BSlot *sl = slots[j & 1];
+    if (lane == wl) sl[wave] = BSlot{wh, ll, lx, ly, lz, lk, 0, 0};
     BTR_PH(2)
     lds_barrier();
     BTR_PH(3)
-    // Only wave 0 reduces the NW slots (the scalar unit is shared by the whole CU: 16 waves
-    // doing the same readlane/s_max sequence serialise on it); the winner goes back through
-    // LDS and every wave picks it up with one broadcast read after the second barrier.
-    if (wave == 0) {
-      BSlot v = BSlot{0u, 0u, 0, 0.f, 0.f, 0.f, 0, 0};
-      if (lane < NW) v = slots[0][lane];
-      unsigned gh;
-      const int gl = wave_argmax(v.hi, [&]() { return v.lo; }, gh);
-      if (gh == 0) {  // nothing competes: best=-1, besti=0 in the reference
-        if (lane == 0) slots[1][0] = BSlot{0u, 0u, 0, x0, y0, z0, 0, 0};
-      } else if (lane == gl) {
-        slots[1][0] = v;
-      }
+    const int r = lane & 15;
+    const unsigned h = r < NW ? sl[r].hi : 0u;
+    const unsigned gh = row16_max_u32(h);
+    const unsigned long long cand = __ballot(h == gh) & 0xFFFFull;
+    int ws;
+    if (__builtin_popcountll(cand) == 1) {
+      ws = __builtin_ctzll(cand);
+    } else {
+      const unsigned l = (h == gh && r < NW) ? sl[r].lo : 0u;
+      const unsigned gl = row16_max_u32(l);
+      ws = __builtin_ctzll(__ballot(h == gh && l == gl) & 0xFFFFull);
     }
-    lds_barrier();
-    const BSlot win = slots[1][0];
-    sx = win.x; sy = win.y; sz = win.z;
-    if (tid == 0) idxs[j] = win.k;
+    if (__builtin_amdgcn_readfirstlane(gh) == 0u) {  // nothing competes: best=-1, besti=0
+      sx = x0; sy = y0; sz = z0;
+      if (tid == 0) idxs[j] = 0;
+    } else {
+      const BSlot win = sl[ws];
+      sx = win.x; sy = win.y; sz = win.z;
+      if (tid == 0) idxs[j] = win.k;
+    }
     BTR_PH(4)
   }
   if (PROF && lane == 0 && dbg) {
     unsigned long long *o = dbg + ((size_t)bi * NW + wave) * 8;
-    for (int i = 0; i < 5; ++i) o[i] = tph[i];
-    o[5] = nact;
+    for (int i = 0; i < 6; ++i) o[i] = tph[i];
+    o[6] = nact;
   }
 #undef BTR_PH
 }
@@ -408,7 +491,7 @@ struct MSlot {
 template <int NW, int SL, int UB, int KMAX>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
     int n, int np, int m, int bs, int log2bs, const float *__restrict__ dataset,
-    float4 *__restrict__ spts, const int *__restrict__ sk, int *__restrict__ idxs,
+    const float4 *__restrict__ spts, float *__restrict__ tmin, int *__restrict__ idxs,
     unsigned long long *dbg) {
   static_assert(NW <= 16 && KMAX <= NW, "slots are reduced by one 16-lane row");
   __shared__ MSlot wslot[NW];
@@ -418,7 +501,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
   const int bi = blockIdx.x;
   dataset += (size_t)bi * n * 3;
   spts += (size_t)bi * np;
-  sk += (size_t)bi * np;
+  tmin += (size_t)bi * np;
   idxs += (size_t)bi * m;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -438,17 +521,17 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
     mk[s] = 0;
     mx[s] = my[s] = mz[s] = 0.f;
     if (myb < nb) {
-      const float4 *p = spts + (size_t)myb * 64;
-      float4 q = p[0];
-      float ax0 = q.x, ax1 = q.x, ay0 = q.y, ay1 = q.y, az0 = q.z, az1 = q.z;
-      bool any = q.w >= 0.f;
+      const float *bp = (const float *)spts + (size_t)myb * 256;
+      const float *tm = tmin + (size_t)myb * 64;
+      float ax0 = bp[0], ax1 = ax0, ay0 = bp[64], ay1 = ay0, az0 = bp[128], az1 = az0;
+      bool any = tm[0] >= 0.f;
 #pragma unroll 8
       for (int i = 1; i < 64; ++i) {
-        q = p[i];
-        ax0 = fminf(ax0, q.x); ax1 = fmaxf(ax1, q.x);
-        ay0 = fminf(ay0, q.y); ay1 = fmaxf(ay1, q.y);
-        az0 = fminf(az0, q.z); az1 = fmaxf(az1, q.z);
-        any |= q.w >= 0.f;
+        const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
+        ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
+        ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
+        az0 = fminf(az0, qz); az1 = fmaxf(az1, qz);
+        any |= tm[i] >= 0.f;
       }
       bx0[s] = ax0; bx1[s] = ax1; by0[s] = ay0; by1[s] = ay1; bz0[s] = az0; bz1[s] = az1;
       mhi[s] = any ? __float_as_uint(1e10f) + 1u : 0u;  // placeholder until the first pass
@@ -493,8 +576,9 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
         for (int u = 0; u < UB; ++u) {
           const int b = (s * 64 + max(bi_[u], 0)) * NW + wave;
           if (bi_[u] >= 0) {
-            p_[u] = spts[(size_t)b * 64 + lane];
-            k_[u] = sk[(size_t)b * 64 + lane];
+            p_[u] = soa_point((const float *)spts, (size_t)b * 64 + lane);
+            k_[u] = __float_as_int(p_[u].w);
+            p_[u].w = tmin[(size_t)b * 64 + lane];
           } else {
             p_[u] = make_float4(0.f, 0.f, 0.f, -1.f);
             k_[u] = 0;
@@ -515,7 +599,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
           }
           if (t != p_[u].w) {
             const int b = (s * 64 + bi_[u]) * NW + wave;
-            spts[(size_t)b * 64 + lane].w = t;
+            tmin[(size_t)b * 64 + lane] = t;
           }
           const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
           unsigned mh;
@@ -648,7 +732,7 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
               "furthest_point_sampling: workspace of %zu bytes required, got %zu",
               p.pts_bytes + p.k_bytes, workspace_bytes);
   float4 *spts = (float4 *)workspace;
-  int *sk = (int *)((char *)workspace + p.pts_bytes);
+  float *sk = (float *)((char *)workspace + p.pts_bytes);  // the min-dist array
   const size_t lds = sizeof(int) * (kCells + 96 + 16);
   static bool attr_set = false;
   if (!attr_set) {
@@ -671,11 +755,34 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
     (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
     const char *names[5] = {"bbox-test", "bucket-update", "wave-argmax+slot", "barrier",
                             "block-argmax"};
+    {
+      static unsigned char cnt[2048 * 16];
+      (void)hipMemcpy(cnt, dbg + 4096, sizeof(cnt), hipMemcpyDeviceToHost);
+      double tot = 0, mx = 0;
+      int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int steps = std::min(m, 2048);
+      for (int j = 1; j < steps; ++j) {
+        int t = 0, mm = 0;
+        for (int w = 0; w < 16; ++w) {
+          t += cnt[j * 16 + w];
+          mm = std::max<int>(mm, cnt[j * 16 + w]);
+        }
+        tot += t;
+        mx += mm;
+        hist[std::min(mm, 7)]++;
+      }
+      fprintf(stderr, "[fps prof] scene 0: touched buckets/step total %.2f, max over waves %.2f,"
+              " balanced would be %.2f; hist(max) =", tot / (steps - 1), mx / (steps - 1),
+              tot / (steps - 1) / 16.0);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %d", hist[i]);
+      fprintf(stderr, "\n");
+    }
     for (int w = 0; w < 16; w += 5) {
       fprintf(stderr, "[fps prof] scene 0 wave %2d:", w);
       for (int i = 0; i < 5; ++i)
         fprintf(stderr, " %s %.0f", names[i], (double)h[w * 8 + i] / (m - 1));
-      fprintf(stderr, " cycles/step; touched buckets/step %.2f\n", (double)h[w * 8 + 5] / (m - 1));
+      fprintf(stderr, " load-wait %.0f cycles/step; touched buckets/step %.2f\n",
+              (double)h[w * 8 + 5] / (m - 1), (double)h[w * 8 + 6] / (m - 1));
     }
     return check_launch("furthest_point_sampling(bucket,prof)");
   }
