@@ -228,27 +228,43 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 }
 
 // ------------------------------------------------- parallel reduction of per-workgroup partials
-// part[nblk][2][N] -> (s1, s2) for channel c in f64.  A 256-thread block covers 16 channels x
-// 16 slices of the nblk axis; the result is valid in the threads with ty == 0.
-__device__ __forceinline__ void reduce_partials16(const float *__restrict__ part, int nblk,
-                                                  int N, int c, int tx, int ty, double &s1,
-                                                  double &s2) {
-  __shared__ double red[2][16][17];
+// part[nblk][2][N] -> (s1, s2) for channel c in f64.  A 256-thread block covers 4 channels x
+// 64 slices of the nblk axis (these launches are latency-bound: 8 loads per thread instead of
+// 32 took each of them from ~10 us to ~4 us); the result is valid in the threads with ty == 0.
+constexpr int kRedCh = 4, kRedSl = 64;
+__device__ __forceinline__ void reduce_partials(const float *__restrict__ part, int nblk, int N,
+                                                int c, int tx, int ty, double &s1, double &s2) {
+  __shared__ double red[2][kRedSl][kRedCh + 1];
+  __shared__ double red2[2][8][kRedCh + 1];
   s1 = 0.0;
   s2 = 0.0;
   if (c < N)
-    for (int b = ty; b < nblk; b += 16) {
+#pragma unroll 8
+    for (int b = ty; b < nblk; b += kRedSl) {
       s1 += (double)part[((size_t)b * 2 + 0) * N + c];
       s2 += (double)part[((size_t)b * 2 + 1) * N + c];
     }
   red[0][ty][tx] = s1;
   red[1][ty][tx] = s2;
   __syncthreads();
-  if (ty == 0) {
+  if (ty < 8) {  // fixed-order tree: 8 slices per thread, then 8 threads
+    double a = 0.0, b = 0.0;
 #pragma unroll
-    for (int y = 1; y < 16; ++y) {
-      s1 += red[0][y][tx];
-      s2 += red[1][y][tx];
+    for (int y = 0; y < 8; ++y) {
+      a += red[0][ty * 8 + y][tx];
+      b += red[1][ty * 8 + y][tx];
+    }
+    red2[0][ty][tx] = a;
+    red2[1][ty][tx] = b;
+  }
+  __syncthreads();
+  if (ty == 0) {
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      s1 += red2[0][y][tx];
+      s2 += red2[1][y][tx];
     }
   }
 }
@@ -262,10 +278,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ scale,
     float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out,
     float *__restrict__ running_mean, float *__restrict__ running_var) {
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int n = blockIdx.x * 16 + tx;
+  const int tx = threadIdx.x & (kRedCh - 1), ty = threadIdx.x / kRedCh;
+  const int n = blockIdx.x * kRedCh + tx;
   double s1, s2;
-  reduce_partials16(part, nblk, N, n, tx, ty, s1, s2);
+  reduce_partials(part, nblk, N, n, tx, ty, s1, s2);
   if (ty != 0 || n >= N) return;
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;
@@ -354,10 +370,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nblk, d
                                                               float *__restrict__ m2,
                                                               float *__restrict__ dgamma,
                                                               float *__restrict__ dbeta) {
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + tx;
+  const int tx = threadIdx.x & (kRedCh - 1), ty = threadIdx.x / kRedCh;
+  const int c = blockIdx.x * kRedCh + tx;
   double s1, s2;
-  reduce_partials16(part, nblk, C, c, tx, ty, s1, s2);
+  reduce_partials(part, nblk, C, c, tx, ty, s1, s2);
   if (ty != 0 || c >= C) return;
   m1[c] = (float)(s1 / count);
   m2[c] = (float)(s2 / count);
@@ -569,21 +585,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
   }
 }
 
-// dw[i] = sum over chunks of pw[chunk][i], fixed order; 16 elements x 16 chunk slices per block.
+// dw[i] = sum over chunks of pw[chunk][i], fixed order; EL elements x SL chunk slices per block
+// (4 x 64 for the small weight matrices, whose launches are latency-bound; 16 x 16 keeps the
+// reads of the large ones coalesced).
+template <int EL, int SL>
 __global__ __launch_bounds__(256) void reduce_chunks_kernel(int total, int chunks,
                                                             const float *__restrict__ pw,
                                                             float *__restrict__ dw) {
-  __shared__ double red[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int i = blockIdx.x * 16 + tx;
+  static_assert(EL * SL == 256, "one block");
+  __shared__ double red[SL][EL + 1];
+  const int tx = threadIdx.x % EL, ty = threadIdx.x / EL;
+  const int i = blockIdx.x * EL + tx;
   double s = 0.0;
   if (i < total)
-    for (int c = ty; c < chunks; c += 16) s += (double)pw[(size_t)c * total + i];
+#pragma unroll 8
+    for (int c = ty; c < chunks; c += SL) s += (double)pw[(size_t)c * total + i];
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && i < total) {
+    s = 0.0;
+    for (int y0 = 0; y0 < SL; y0 += 8) {  // fixed order
+      double a = 0.0;
 #pragma unroll
-    for (int y = 1; y < 16; ++y) s += red[y][tx];
+      for (int y = 0; y < 8; ++y) a += red[y0 + y][tx];
+      s += a;
+    }
     dw[i] = (float)s;
   }
 }
@@ -774,7 +800,7 @@ int btr_sa_bn_finalize(int n, int nblk, double count, float eps, float momentum,
                        float *shift, float *mean, float *invstd, float *running_mean,
                        float *running_var, btr_stream_t stream) {
   if (n <= 0) return BTR_OK;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(n, 16)), dim3(256), 0, as_stream(stream), n,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(n, kRedCh)), dim3(256), 0, as_stream(stream), n,
                      nblk, count, eps, momentum, part, gamma, beta, scale, shift, mean, invstd,
                      running_mean, running_var);
   return check_launch("sa_bn_finalize");
@@ -801,7 +827,7 @@ int btr_sa_pool_bwd(int b, int m, int s, int c, int ldy, float *y, const float *
   const int nblk = (int)std::min<long long>(groups, 256);
   hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, m, s, c, ldy, y,
                      dout, out, arg, mean, invstd, groups, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 16)), dim3(256), 0, st, c, nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c, nblk,
                      (double)groups * s, part, m1, m2, dgamma, dbeta);
   hipLaunchKernelGGL(sa_pool_bwd_apply_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0, st, m,
                      s, c, ldy, y, dout, out, arg, mean, invstd, scale, m1, m2, groups);
@@ -821,7 +847,7 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
   const int nblk = (int)std::min<long long>(cdiv(rows, 256 / (c / 4)), 512);
   hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ld, g, y,
                      scale, shift, mean, invstd, part);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 16)), dim3(256), 0, st, c, nblk,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c, nblk,
                      (double)rows, part, m1, m2, dgamma, dbeta);
   const int gx = (int)std::min<long long>(cdiv(rows * (c / 4), 256), 256 * 16);
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx), dim3(256), 0, st, rows, c, ld, g, y,
@@ -860,8 +886,12 @@ int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float 
     if (pa) BTR_TN(2, true); else BTR_TN(2, false);
   }
 #undef BTR_TN
-  hipLaunchKernelGGL(reduce_chunks_kernel, dim3(cdiv(n * k, 16)), dim3(256), 0, st, n * k,
-                     chunks, pw, dw);
+  if (n * k <= 1024 && chunks >= 64)
+    hipLaunchKernelGGL((reduce_chunks_kernel<4, 64>), dim3(cdiv(n * k, 4)), dim3(256), 0, st,
+                       n * k, chunks, pw, dw);
+  else
+    hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(n * k, 16)), dim3(256), 0, st,
+                       n * k, chunks, pw, dw);
   return check_launch("sa_gemm_tn");
 }
 

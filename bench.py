@@ -34,6 +34,8 @@ def parse():
     p.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     p.add_argument("--points", type=int, default=40000)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-pipelined", action="store_true",
+                   help="skip the secondary (informational) software-pipelined loop")
     p.add_argument("--workload", choices=["fsb", "br"], default="fsb",
                    help="fsb: VoteNet FSB step (BASELINE configs[1], the headline); br: the "
                         "two-branch Back-to-Reality step (configs[2]), 2 x batch scenes per step")
@@ -138,7 +140,7 @@ def main():
     # prefetched on the side stream under this step's backward (train.train_step(next_batch=)).
     # Every step still computes one full pyramid; nothing is cached across steps.
     pipelined = None
-    if not br:
+    if not br and not args.no_pipelined:
         _, end = train.train_step(ddp, opt, batch, cfg, next_batch=batch)  # primes the pipe
         barrier()
         t1 = time.perf_counter()
@@ -242,9 +244,14 @@ def roofline_objects(kernels, detail, detail_steps):
         flops = sum(2.0 * k[0] * k[1] * k[2] * len(t) for k, t in gemm) / steps
         ms = sum(sum(t) for _, t in gemm) / steps
         ach = flops / (ms * 1e-3) / 1e12
+        # the same launches against the HBM roof: f32 operands + result moved once
+        gbytes = sum(4.0 * (k[0] * (k[1] + k[2]) + k[1] * k[2]) * len(t) for k, t in gemm) / steps
+        hbm = gbytes / (ms * 1e-3) / 1e9
         res["mlp_roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
                                "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
                                "traffic": None, "kernel": "gemm_nt_kernel + gemm_tn_kernel",
+                               "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_step": gbytes,
                                "gflop_per_step": flops / 1e9, "ms_per_step": ms,
                                "launches_per_step": sum(len(t) for _, t in gemm) / steps}
     fps = pick("furthest_point_sampling")

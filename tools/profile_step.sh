@@ -1,0 +1,16 @@
+#!/bin/bash
+# One-step kernel profile on the GPU box:  tools/profile_step.sh <tag>  ->  gpurun_out/<tag>/
+# (rocprofv3 --kernel-trace over a short bench run, summarised on the box: the rocpd database
+# is too large to travel).
+set -e
+TAG=${1:-prof}
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/$TAG
+rocprofv3 --kernel-trace -d /tmp/$TAG -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-pipelined > /tmp/$TAG.log 2>&1
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/$TAG
+DB=$(find /tmp/$TAG -name "*.db" | head -1)
+python tools/rocpd_step.py $DB fps_bucket_kernel gpurun_out/$TAG/one_step.md
+python tools/rocpd_stats.py $DB > gpurun_out/$TAG/kernel_stats.md 2>/dev/null || true
+tail -1 /tmp/$TAG.log > gpurun_out/$TAG/bench.json
+head -3 gpurun_out/$TAG/one_step.md
