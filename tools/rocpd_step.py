@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Per-kernel time inside ONE steady-state step of a rocprofv3 rocpd trace: the window between
-the last two launches of a marker kernel (default: the large-scene FPS kernel, once per step).
+"""Per-kernel time inside ONE steady-state step of a rocprofv3 rocpd trace: a window between
+two consecutive launches of a marker kernel (default: the large-scene FPS kernel, once per
+step) -- the one with the MEDIAN wall time among the windows shorter than 1.5x the shortest
+(warm-up and bench.py's fully instrumented detail steps are longer).
 Usage: rocpd_step.py results.db [marker-substring] [out.md]"""
 import sqlite3
 import sys
@@ -16,7 +18,9 @@ def main():
     marks = [s for (n, s, e) in rows if marker in n]
     if len(marks) < 2:
         raise SystemExit("marker %r seen %d times" % (marker, len(marks)))
-    t0, t1 = marks[-2], marks[-1]
+    wins = sorted((b - a, a, b) for a, b in zip(marks[:-1], marks[1:]))
+    wins = [w for w in wins if w[0] <= 1.5 * wins[0][0]]
+    _, t0, t1 = wins[len(wins) // 2]
     agg = {}
     for n, s, e in rows:
         if t0 <= s < t1:
