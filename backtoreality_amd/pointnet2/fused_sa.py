@@ -67,7 +67,7 @@ class FusedSAFunction(Function):
             _call(_lib.btr_sa_gather, B, N, M, S, C, K0p, use_xyz, rdiv, _p(xyz), _p(new_xyz),
                   _p(feats_cl), _p(idx), _p(X0), st)
             grid = _lib.btr_sa_gemm_grid(R)
-            Ys, stats, Ws = [], [], []
+            Ys, stats, Ws, counters = [], [], [], []
             A, lda, K = X0, K0p, K0p
             pa = pb = None
             for l in range(L):
@@ -95,7 +95,7 @@ class FusedSAFunction(Function):
                       _p(bn.running_mean if track else None),
                       _p(bn.running_var if track else None), st)
                 if track:
-                    bn.num_batches_tracked += 1
+                    counters.append(bn.num_batches_tracked)
                 Ys.append(Y)
                 Ws.append(W2)
                 stats.append((scale, shift, mean, invstd))
@@ -107,6 +107,8 @@ class FusedSAFunction(Function):
             arg = torch.empty((B * M, CL), dtype=torch.uint8, device=dev)
             _call(_lib.btr_sa_pool, B, M, S, CL, CL, _p(Ys[-1]), _p(stats[-1][0]),
                   _p(stats[-1][1]), _p(out), _p(out_cl), _p(arg), st)
+            if counters:  # one launch for the layer's num_batches_tracked += 1
+                torch._foreach_add_(counters, 1)
 
         out._btr_channel_last = out_cl  # lets the next fused layer skip a transpose
         ctx.dims = (B, N, M, S, C, use_xyz, rdiv, K0, K0p, L)

@@ -57,8 +57,11 @@ def wrap_ddp(net, device):
 
 
 def make_optimizer(net, lr=1e-3, weight_decay=0.0):
-    """Adam, lr 1e-3 (train_Votenet_FSB.py:172)."""
-    return torch.optim.Adam(net.parameters(), lr=lr, weight_decay=weight_decay)
+    """Adam, lr 1e-3 (train_Votenet_FSB.py:172).  On the GPU the fused multi-tensor
+    implementation (same update rule, two launches instead of ~10 per step)."""
+    params = list(net.parameters())
+    fused = bool(params) and all(p.is_cuda for p in params)
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
 
 
 def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None):
