@@ -174,6 +174,139 @@ __global__ __launch_bounds__(kSortThreads) void fps_sort_kernel(
   }
 }
 
+// ---- the same counting sort with MANY workgroups per scene (the one-workgroup version
+// streams the scene three times through a single CU: 157 us on 8 x 40000, all of it on the
+// step's critical path).  meta[b] = 6 order-preserving uint keys (max of ~key(min), max of
+// key(max)) accumulated with integer atomics; cells[b][32768] = histogram -> exclusive scan
+// -> scatter cursor.  The order inside a cell depends on the atomics and cannot change the
+// FPS result (see the header).
+__device__ __forceinline__ unsigned f32_key(float f) {  // monotone float -> uint
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+struct SortBox {
+  float mnx, mny, mnz, scale;
+};
+__device__ __forceinline__ SortBox sort_box(const unsigned *__restrict__ meta) {
+  const float mnx = key_f32(~meta[0]), mny = key_f32(~meta[1]), mnz = key_f32(~meta[2]);
+  const float mxx = key_f32(meta[3]), mxy = key_f32(meta[4]), mxz = key_f32(meta[5]);
+  const float ext = fmaxf(fmaxf(mxx - mnx, mxy - mny), mxz - mnz);
+  return SortBox{mnx, mny, mnz, ext > 0.f ? 32.f / ext : 0.f};
+}
+
+__global__ __launch_bounds__(256) void fps_sortm_bbox_kernel(int n,
+                                                             const float *__restrict__ dataset,
+                                                             unsigned *__restrict__ meta) {
+  __shared__ unsigned red[6][4];
+  const int bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  dataset += (size_t)bi * n * 3;
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int k = blockIdx.x * 256 + tid; k < n; k += gridDim.x * 256) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = dataset[k * 3 + a];
+      mn[a] = fminf(mn[a], v);
+      mx[a] = fmaxf(mx[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+    }
+    if (lane == 0) {
+      red[a][wave] = ~f32_key(mn[a]);
+      red[3 + a][wave] = f32_key(mx[a]);
+    }
+  }
+  __syncthreads();
+  if (tid < 6) {
+    const unsigned v = max(max(red[tid][0], red[tid][1]), max(red[tid][2], red[tid][3]));
+    atomicMax(&meta[(size_t)bi * 8 + tid], v);
+  }
+}
+
+__global__ __launch_bounds__(256) void fps_sortm_hist_kernel(int n,
+                                                             const float *__restrict__ dataset,
+                                                             const unsigned *__restrict__ meta,
+                                                             int *__restrict__ cells) {
+  const int bi = blockIdx.y;
+  dataset += (size_t)bi * n * 3;
+  const SortBox bx = sort_box(meta + (size_t)bi * 8);
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+    const int c = morton_cell(dataset[k * 3], dataset[k * 3 + 1], dataset[k * 3 + 2], bx.mnx,
+                              bx.mny, bx.mnz, bx.scale);
+    atomicAdd(&cells[(size_t)bi * kCells + c], 1);
+  }
+}
+
+// exclusive scan of the 32768 cell counts of one scene, in place
+__global__ __launch_bounds__(kSortThreads) void fps_sortm_scan_kernel(int *__restrict__ cells) {
+  __shared__ int wsum[16];
+  int *hist = cells + (size_t)blockIdx.x * kCells;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int PER = kCells / kSortThreads;
+  int local[PER];
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    local[i] = hist[tid * PER + i];
+    sum += local[i];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int run = incl - sum;
+  for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    hist[tid * PER + i] = run;
+    run += local[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void fps_sortm_scatter_kernel(
+    int n, int np, const float *__restrict__ dataset, const unsigned *__restrict__ meta,
+    int *__restrict__ cells, float4 *__restrict__ spts, float *__restrict__ tmin) {
+  const int bi = blockIdx.y;
+  dataset += (size_t)bi * n * 3;
+  float *sp = (float *)(spts + (size_t)bi * np);
+  tmin += (size_t)bi * np;
+  const SortBox bx = sort_box(meta + (size_t)bi * 8);
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+    const float x = dataset[k * 3], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
+    const int c = morton_cell(x, y, z, bx.mnx, bx.mny, bx.mnz, bx.scale);
+    const int pos = atomicAdd(&cells[(size_t)bi * kCells + c], 1);
+    const float mag = (x * x) + (y * y) + (z * z);
+    sp[soa_at(pos, 0)] = x;
+    sp[soa_at(pos, 1)] = y;
+    sp[soa_at(pos, 2)] = z;
+    sp[soa_at(pos, 3)] = __int_as_float(k);
+    tmin[pos] = ((double)mag <= 1e-3) ? -1.f : 1e10f;  // sampling_gpu.cu:105-106
+  }
+  // padding of the last bucket: index -1 (kept out of the bucket's bounding box), tmin < 0
+  // (never competes); the coordinates only have to be finite
+  if (blockIdx.x == 0 && n + (int)threadIdx.x < np) {
+    const int pos = n + threadIdx.x;
+    sp[soa_at(pos, 0)] = dataset[0];
+    sp[soa_at(pos, 1)] = dataset[1];
+    sp[soa_at(pos, 2)] = dataset[2];
+    sp[soa_at(pos, 3)] = __int_as_float(-1);
+    tmin[pos] = -1.f;
+  }
+}
+
 __device__ __forceinline__ unsigned fps_tk2(int k, int bs, int log2bs, int cpb) {
   const unsigned r = log2bs == 0 ? 0u : (__brev((unsigned)(k & (bs - 1))) >> (32 - log2bs));
   return r * (unsigned)cpb + (unsigned)(k >> log2bs);
@@ -260,6 +393,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       bool any = tm[0] >= 0.f;
 #pragma unroll 8
       for (int i = 1; i < 64; ++i) {
+        if (__float_as_int(bp[192 + i]) < 0) continue;  // padding slot: not in the box
         const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
         ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
         ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
@@ -527,6 +661,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
       bool any = tm[0] >= 0.f;
 #pragma unroll 8
       for (int i = 1; i < 64; ++i) {
+        if (__float_as_int(bp[192 + i]) < 0) continue;  // padding slot: not in the box
         const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
         ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
         ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
@@ -701,7 +836,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
 
 struct FpsPlan {
   int nb, np;
-  size_t pts_bytes, k_bytes;
+  size_t pts_bytes, k_bytes, sort_bytes;  // sort_bytes: cells[b][32768] + meta[b][8]
 };
 
 static FpsPlan fps_plan(int b, int n) {
@@ -710,6 +845,7 @@ static FpsPlan fps_plan(int b, int n) {
   p.np = p.nb * 64;
   p.pts_bytes = sizeof(float4) * (size_t)b * p.np;
   p.k_bytes = sizeof(int) * (size_t)b * p.np;
+  p.sort_bytes = sizeof(int) * (size_t)b * (kCells + 8);
   return p;
 }
 
@@ -722,27 +858,43 @@ bool fps_bucket_supported(int n) { return n > 0 && n <= kBucketMaxN; }
 size_t fps_bucket_workspace_bytes(int b, int n) {
   if (b <= 0 || !fps_bucket_supported(n)) return 0;
   const FpsPlan p = fps_plan(b, n);
-  return p.pts_bytes + p.k_bytes;
+  return p.pts_bytes + p.k_bytes + p.sort_bytes;
 }
 
 int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int bs, int log2bs,
                       void *workspace, size_t workspace_bytes, hipStream_t s) {
   const FpsPlan p = fps_plan(b, n);
-  BTR_REQUIRE(workspace && workspace_bytes >= p.pts_bytes + p.k_bytes,
+  BTR_REQUIRE(workspace && workspace_bytes >= p.pts_bytes + p.k_bytes + p.sort_bytes,
               "furthest_point_sampling: workspace of %zu bytes required, got %zu",
-              p.pts_bytes + p.k_bytes, workspace_bytes);
+              p.pts_bytes + p.k_bytes + p.sort_bytes, workspace_bytes);
   float4 *spts = (float4 *)workspace;
   float *sk = (float *)((char *)workspace + p.pts_bytes);  // the min-dist array
-  const size_t lds = sizeof(int) * (kCells + 96 + 16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)fps_sort_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return fail((int)e, "fps_sort attr: %s", hipGetErrorString(e));
-    attr_set = true;
+  // BTR_FPS_SORT=single: the one-workgroup-per-scene sort (A/B); default: multi-workgroup
+  static const bool single_sort = getenv("BTR_FPS_SORT") && getenv("BTR_FPS_SORT")[0] == 's';
+  if (single_sort) {
+    const size_t lds = sizeof(int) * (kCells + 96 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void *)fps_sort_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail((int)e, "fps_sort attr: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(fps_sort_kernel, dim3(b), dim3(kSortThreads), lds, s, n, p.np, dataset,
+                       spts, sk);
+  } else {
+    int *cells = (int *)((char *)workspace + p.pts_bytes + p.k_bytes);
+    unsigned *meta = (unsigned *)(cells + (size_t)b * kCells);
+    hipError_t e = hipMemsetAsync(cells, 0, p.sort_bytes, s);
+    if (e != hipSuccess) return fail((int)e, "fps sort memset: %s", hipGetErrorString(e));
+    const int gx = std::max(1, std::min(cdiv(n, 1024), 64));
+    hipLaunchKernelGGL(fps_sortm_bbox_kernel, dim3(gx, b), dim3(256), 0, s, n, dataset, meta);
+    hipLaunchKernelGGL(fps_sortm_hist_kernel, dim3(gx, b), dim3(256), 0, s, n, dataset, meta,
+                       cells);
+    hipLaunchKernelGGL(fps_sortm_scan_kernel, dim3(b), dim3(kSortThreads), 0, s, cells);
+    hipLaunchKernelGGL(fps_sortm_scatter_kernel, dim3(gx, b), dim3(256), 0, s, n, p.np, dataset,
+                       meta, cells, spts, sk);
   }
-  hipLaunchKernelGGL(fps_sort_kernel, dim3(b), dim3(kSortThreads), lds, s, n, p.np, dataset,
-                     spts, sk);
   int rc = check_launch("furthest_point_sampling(sort)");
   if (rc) return rc;
   if (getenv("BTR_FPS_PROF")) {  // tuning only: phase counters -> first bytes of idxs' scratch
