@@ -72,11 +72,17 @@ __global__ __launch_bounds__(256) void sa_gather_kernel(
 // (the MFMA's two k slots), so every lane reads 4 consecutive k with one ds_read_b128.
 // STATS: per-column sum and sum of squares of C over the rows this workgroup processed are
 // written to part[blockIdx.x][0..1][n] (grid-stride over row tiles, reduced later in f64).
-template <int BN, bool PRO, bool STATS>
+// PRO == 2 ("pooled gradient"): A is the pooled layer's pre-BN output Y and the operand is the
+// gradient w.r.t. it, formed on the fly (the dense dY never exists in HBM):
+//   dY[r][k] = pa[k]*Y[r][k] + pb[k] + (r % S == parg[r/S][k] ? pdcl[r/S][k] : 0)
+// (pa = alpha, pb = beta, pdcl = scale*dOut where the pooled output is > 0; see
+// btr_sa_pool_bwd_coef).
+template <int BN, int PRO, bool STATS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
     float *__restrict__ C, int ldc, int R, int N, int K, const float *__restrict__ pa,
-    const float *__restrict__ pb, float *__restrict__ part) {
+    const float *__restrict__ pb, float *__restrict__ part,
+    const unsigned char *__restrict__ parg, const float *__restrict__ pdcl, int S) {
   constexpr int WN = BN / 64;      // waves along N
   constexpr int WM = 4 / WN;       // waves along M
   constexpr int MI = kBM / WM / 32;  // 32-row MFMA tiles per wave
@@ -103,14 +109,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
   // loads of step q+1 are in flight while the MFMAs of step q run (T14 "issue early, write
   // late"); the BN+ReLU prologue is applied when the registers are written to LDS.
   float4 ra[kBM / 32], rb[BN / 32];
+  // PRO == 2: the sparse part of dY (one entry per group and channel) is added to the staged
+  // tile in LDS by one thread per (group of the tile, k column): 2 registers of prefetch
+  // instead of an arg word + a float4 per staged row (which cost a wave of occupancy).
+  const int sp_gi = tid >> 5, sp_k = tid & 31;  // S >= 16 and S | 128: at most 8 groups/tile
+  unsigned sp_arg = 0;
+  float sp_d = 0.f;
+  bool sp_on = false;
   auto fetch = [&](int tile, int kc) {
     const int r0 = tile * kBM, kk = kc * kBK + kq;
 #pragma unroll
     for (int p = 0; p < kBM / 32; ++p) {
       const int row = srow + 32 * p;
       ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r0 + row < R && kk < K)
+      if (r0 + row < R && kk < K) {
         ra[p] = *reinterpret_cast<const float4 *>(A + (size_t)(r0 + row) * lda + kk);
+      }
+    }
+    if (PRO == 2) {
+      const int k1 = kc * kBK + sp_k;
+      const long long g = (long long)r0 / S + sp_gi;
+      sp_on = sp_gi * S < kBM && g * S < R && k1 < K;
+      if (sp_on) {
+        sp_arg = parg[(size_t)g * K + k1];
+        sp_d = pdcl[(size_t)g * K + k1];
+      }
     }
 #pragma unroll
     for (int p = 0; p < BN / 32; ++p) {
@@ -131,11 +154,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     for (int p = 0; p < kBM / 32; ++p) {
       const int row = srow + 32 * p;
       float4 v = ra[p];
-      if (PRO && r0 + row < R && kk < K) {  // padded rows / columns must stay exactly 0
+      if (PRO == 1 && r0 + row < R && kk < K) {  // padded rows / columns must stay exactly 0
         v.x = fmaxf(fmaf(fa.x, v.x, fb.x), 0.f);
         v.y = fmaxf(fmaf(fa.y, v.y, fb.y), 0.f);
         v.z = fmaxf(fmaf(fa.z, v.z, fb.z), 0.f);
         v.w = fmaxf(fmaf(fa.w, v.w, fb.w), 0.f);
+      }
+      if (PRO == 2 && r0 + row < R && kk < K) {  // dense part: alpha*y + beta
+        v.x = fmaf(fa.x, v.x, fb.x);
+        v.y = fmaf(fa.y, v.y, fb.y);
+        v.z = fmaf(fa.z, v.z, fb.z);
+        v.w = fmaf(fa.w, v.w, fb.w);
       }
       *reinterpret_cast<float4 *>(&As[row * kLd + kq]) = v;
     }
@@ -158,6 +187,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     for (int kc = 0; kc < nkc; ++kc) {
       stage(tile, kc);
       __syncthreads();
+      if (PRO == 2) {  // sparse part: the arg-max row of every (group, channel) of this tile
+        if (sp_on) As[(sp_gi * S + (int)sp_arg) * kLd + sp_k] += sp_d;
+        __syncthreads();
+      }
       // issue the next step's global loads before the MFMAs of this one
       if (kc + 1 < nkc)
         fetch(tile, kc + 1);
@@ -381,6 +414,32 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nblk, d
   dbeta[c] = (float)s1;
 }
 
+// Coefficients of the pooled layer's gradient for the GEMM prologues (no dense dY pass):
+//   dY[r][c] = alpha[c]*Y[r][c] + beta[c] + (r % S == arg[g][c] ? dcl[g][c] : 0),  g = r / S
+// with alpha = -a*invstd*m2, beta = -a*m1 - alpha*mean, dcl = a*dOut where out > 0 (else 0),
+// which is a[c]*(g - m1 - xhat*m2) regrouped.
+__global__ __launch_bounds__(256) void sa_pool_coef_kernel(
+    int M, int C, long long groups, const float *__restrict__ dout,
+    const float *__restrict__ out, const float *__restrict__ scale,
+    const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ m1, const float *__restrict__ m2, float *__restrict__ dcl,
+    float *__restrict__ alpha, float *__restrict__ beta) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= groups * C) return;
+  const long long g = t / C;
+  const int c = (int)(t - g * C);
+  const long long bi = g / M;
+  const int m = (int)(g - bi * M);
+  const size_t o = ((size_t)bi * C + c) * M + m;
+  const float a = scale[c];
+  dcl[t] = out[o] > 0.f ? a * dout[o] : 0.f;
+  if (g == 0) {
+    const float al = -a * invstd[c] * m2[c];
+    alpha[c] = al;
+    beta[c] = -a * m1[c] - al * mean[c];
+  }
+}
+
 // dY[r][c] = a[c] * (g[r][c] - m1[c] - xhat[r][c]*m2[c]) written IN PLACE over Y, for the
 // pooled (last) layer: g[r][c] = dOut if (s == arg && out > 0) else 0.
 __global__ __launch_bounds__(256) void sa_pool_bwd_apply_kernel(
@@ -490,11 +549,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
 // 2x2 grid of 32x32 tiles.  The reduction runs over a chunk of rows staged 32 at a time with
 // the next rows prefetched into registers; per-chunk partials -> pw[chunk][N][K], reduced by
 // reduce_chunks_kernel in a fixed order (deterministic).
-template <int TNW, bool PRO>
+// GPOOL: G is the pooled layer's pre-BN output Y and the gradient operand is formed on the fly
+// exactly as in gemm_nt_kernel's PRO == 2 (galpha/gbeta per n column, garg/gdcl per group).
+template <int TNW, bool PRO, bool GPOOL = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(
     const float *__restrict__ G, int ldg, const float *__restrict__ X, int ldx, int R, int N,
     int K, const float *__restrict__ pa, const float *__restrict__ pb, int rows_per_chunk,
-    float *__restrict__ pw) {
+    float *__restrict__ pw, const unsigned char *__restrict__ garg = nullptr,
+    const float *__restrict__ gdcl = nullptr, const float *__restrict__ galpha = nullptr,
+    const float *__restrict__ gbeta = nullptr, int S = 1) {
   constexpr int BR = 32;
   constexpr int TN = 32 * TNW;      // n columns of G staged per step
   constexpr int LG = TN + 4, LX = 68;
@@ -526,14 +589,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     fa = *reinterpret_cast<const float4 *>(pa + k0 + xc4);
     fb = *reinterpret_cast<const float4 *>(pb + k0 + xc4);
   }
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (GPOOL && n0 + gc4 < N) {
+    ga = *reinterpret_cast<const float4 *>(galpha + n0 + gc4);
+    gb = *reinterpret_cast<const float4 *>(gbeta + n0 + gc4);
+  }
   float4 rg[GPASS], rx[2];
+  // GPOOL: sparse part added in LDS by one thread per (group of the 32-row step, n column)
+  const int sp_gi = tid / TN, sp_n = tid % TN;
+  unsigned sp_arg = 0;
+  float sp_d = 0.f;
+  bool sp_on = false;
   auto fetch = [&](int r0) {
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       const int row = gr + GR * p;
       rg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r0 + row < rend && n0 + gc4 < N)
+      if (r0 + row < rend && n0 + gc4 < N) {
         rg[p] = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * ldg + n0 + gc4);
+      }
+    }
+    if (GPOOL) {
+      const long long g = (long long)r0 / S + sp_gi;
+      sp_on = sp_gi * S < BR && g * S < rend && n0 + sp_n < N;
+      if (sp_on) {
+        sp_arg = garg[(size_t)g * N + n0 + sp_n];
+        sp_d = gdcl[(size_t)g * N + n0 + sp_n];
+        const long long lr = g * S + sp_arg - r0;  // local row of the arg-max inside this step
+        sp_on = lr >= 0 && lr < BR && g * S + sp_arg < rend;
+        sp_arg = (unsigned)lr;
+      }
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -546,8 +631,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
   if (rbeg < rend) fetch(rbeg);
   for (int r0 = rbeg; r0 < rend; r0 += BR) {
 #pragma unroll
-    for (int p = 0; p < GPASS; ++p)
-      *reinterpret_cast<float4 *>(&Gs[(gr + GR * p) * LG + gc4]) = rg[p];
+    for (int p = 0; p < GPASS; ++p) {
+      float4 v = rg[p];
+      if (GPOOL && r0 + gr + GR * p < rend && n0 + gc4 < N) {  // dense part
+        v.x = fmaf(ga.x, v.x, gb.x);
+        v.y = fmaf(ga.y, v.y, gb.y);
+        v.z = fmaf(ga.z, v.z, gb.z);
+        v.w = fmaf(ga.w, v.w, gb.w);
+      }
+      *reinterpret_cast<float4 *>(&Gs[(gr + GR * p) * LG + gc4]) = v;
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int row = xr + 16 * p;
@@ -561,6 +654,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
       *reinterpret_cast<float4 *>(&Xs[row * LX + xc4]) = x;
     }
     __syncthreads();
+    if (GPOOL) {
+      if (sp_on) Gs[(int)sp_arg * LG + sp_n] += sp_d;
+      __syncthreads();
+    }
     if (r0 + BR < rend) fetch(r0 + BR);  // next rows in flight during the MFMAs
 #pragma unroll
     for (int t = 0; t < BR / 2; ++t) {
@@ -783,13 +880,14 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
   const bool pro = pa != nullptr, st = part != nullptr;
 #define BTR_GEMM(BN, P, S)                                                                   \
   hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S>), dim3(gx, cdiv(n, BN)), dim3(256), 0, s, a,  \
-                     lda, w, ldw, c, ldc, rows, n, k, pa, pb, part)
+                     lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,                             \
+                     (const unsigned char *)nullptr, (const float *)nullptr, 1)
   if (n <= 64) {
-    if (pro) { if (st) BTR_GEMM(64, true, true); else BTR_GEMM(64, true, false); }
-    else     { if (st) BTR_GEMM(64, false, true); else BTR_GEMM(64, false, false); }
+    if (pro) { if (st) BTR_GEMM(64, 1, true); else BTR_GEMM(64, 1, false); }
+    else     { if (st) BTR_GEMM(64, 0, true); else BTR_GEMM(64, 0, false); }
   } else {
-    if (pro) { if (st) BTR_GEMM(128, true, true); else BTR_GEMM(128, true, false); }
-    else     { if (st) BTR_GEMM(128, false, true); else BTR_GEMM(128, false, false); }
+    if (pro) { if (st) BTR_GEMM(128, 1, true); else BTR_GEMM(128, 1, false); }
+    else     { if (st) BTR_GEMM(128, 0, true); else BTR_GEMM(128, 0, false); }
   }
 #undef BTR_GEMM
   return check_launch("sa_gemm_nt");
@@ -832,6 +930,50 @@ int btr_sa_pool_bwd(int b, int m, int s, int c, int ldy, float *y, const float *
   hipLaunchKernelGGL(sa_pool_bwd_apply_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0, st, m,
                      s, c, ldy, y, dout, out, arg, mean, invstd, scale, m1, m2, groups);
   return check_launch("sa_pool_bwd");
+}
+
+// Same statistics as btr_sa_pool_bwd, but instead of writing the dense dY over y it returns
+// the coefficients (dcl [b*m][c], alpha [c], beta [c]) from which btr_sa_gemm_nt_pool /
+// btr_sa_gemm_tn_pool form dY inside their operand staging.  y is left untouched.
+int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, const float *dout,
+                         const float *out, const unsigned char *arg, const float *mean,
+                         const float *invstd, const float *scale, float *part /*[256][2][c]*/,
+                         float *m1, float *m2, float *dgamma, float *dbeta, float *dcl,
+                         float *alpha, float *beta, btr_stream_t stream) {
+  const long long groups = (long long)b * m;
+  if (groups <= 0 || c <= 0) return BTR_OK;
+  hipStream_t st = as_stream(stream);
+  const int nblk = (int)std::min<long long>(groups, 256);
+  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, m, s, c, ldy, y,
+                     dout, out, arg, mean, invstd, groups, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c, nblk,
+                     (double)groups * s, part, m1, m2, dgamma, dbeta);
+  hipLaunchKernelGGL(sa_pool_coef_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0, st, m, c,
+                     groups, dout, out, scale, mean, invstd, m1, m2, dcl, alpha, beta);
+  return check_launch("sa_pool_bwd_coef");
+}
+
+// dX[rows][n] = dY . Wt^T with dY formed from (y, arg, dcl, alpha, beta) on the fly; k = the
+// pooled layer's channel count (row length of arg / dcl), s = samples per group.
+int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const float *w, int ldw,
+                        float *c, int ldc, int s, const unsigned char *arg, const float *dcl,
+                        const float *alpha, const float *beta, btr_stream_t stream) {
+  if (rows <= 0 || n <= 0) return BTR_OK;
+  BTR_REQUIRE(y && w && c && arg && dcl && alpha && beta && s > 0 && k > 0 && k % 4 == 0 &&
+                  ldy % 4 == 0 && ldw % 4 == 0,
+              "sa_gemm_nt_pool: bad arguments (k=%d ldy=%d ldw=%d s=%d)", k, ldy, ldw, s);
+  BTR_REQUIRE(s >= 16 && s <= 255 && (kBM % s == 0 || s % kBM == 0),
+              "sa_gemm_nt_pool: nsample %d must be 16, 32, 64 or 128", s);
+  const int gx = btr_sa_gemm_grid(rows);
+  hipStream_t st = as_stream(stream);
+  if (n <= 64)
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 2, false>), dim3(gx, cdiv(n, 64)), dim3(256), 0, st, y,
+                       ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl, s);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 2, false>), dim3(gx, cdiv(n, 128)), dim3(256), 0, st,
+                       y, ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl,
+                       s);
+  return check_launch("sa_gemm_nt_pool");
 }
 
 // In place: g (gradient w.r.t. the post-ReLU activation of a hidden layer) -> gradient w.r.t.
@@ -893,6 +1035,41 @@ int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float 
     hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(n * k, 16)), dim3(256), 0, st,
                        n * k, chunks, pw, dw);
   return check_launch("sa_gemm_tn");
+}
+
+// dW[n][k] = sum_r dY[r][n] * f(X[r][k]) with dY formed from (y, arg, dcl, alpha, beta) on the
+// fly (n = the pooled layer's channel count); otherwise as btr_sa_gemm_tn.
+int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
+                        const unsigned char *arg, const float *dcl, const float *alpha,
+                        const float *beta, const float *x, int ldx, const float *pa,
+                        const float *pb, float *pw, float *dw, btr_stream_t stream) {
+  if (n <= 0 || k <= 0) return BTR_OK;
+  BTR_REQUIRE(y && x && pw && dw && arg && dcl && alpha && beta && s > 0 && ldy % 4 == 0 &&
+                  ldx % 4 == 0 && n % 4 == 0 && k % 4 == 0,
+              "sa_gemm_tn_pool: sizes must be multiples of 4 (n=%d k=%d)", n, k);
+  BTR_REQUIRE(s >= 16 && s <= 255 && (32 % s == 0 || s % 32 == 0),
+              "sa_gemm_tn_pool: nsample %d must be 16 or a multiple of 32", s);
+  hipStream_t st = as_stream(stream);
+  const int chunks = btr_sa_gemm_tn_chunks(rows, n, k);
+  const int rpc = cdiv(cdiv(rows, chunks), 32) * 32;
+  const int tn = tn_tile_n(n);
+  const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
+#define BTR_TNP(W, P)                                                                         \
+  hipLaunchKernelGGL((gemm_tn_kernel<W, P, true>), grid, dim3(256), 0, st, y, ldy, x, ldx,    \
+                     rows, n, k, pa, pb, rpc, pw, arg, dcl, alpha, beta, s)
+  if (tn == 128) {
+    if (pa) BTR_TNP(4, true); else BTR_TNP(4, false);
+  } else {
+    if (pa) BTR_TNP(2, true); else BTR_TNP(2, false);
+  }
+#undef BTR_TNP
+  if (n * k <= 1024 && chunks >= 64)
+    hipLaunchKernelGGL((reduce_chunks_kernel<4, 64>), dim3(cdiv(n * k, 4)), dim3(256), 0, st,
+                       n * k, chunks, pw, dw);
+  else
+    hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(n * k, 16)), dim3(256), 0, st,
+                       n * k, chunks, pw, dw);
+  return check_launch("sa_gemm_tn_pool");
 }
 
 size_t btr_sa_scatter_workspace_bytes(int b, int n, int m, int s) {

@@ -59,6 +59,11 @@ _SIGNATURES = {
     "btr_sa_scatter_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
     "btr_sa_scatter": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _cf, _vp, _vp, _vp, _vp, _vp,
                              _vp, _sz, _vp]),
+    "btr_sa_pool_bwd_coef": (_ci, [_ci, _ci, _ci, _ci, _ci] + [_vp] * 16),
+    "btr_sa_gemm_nt_pool": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _vp, _vp,
+                                  _vp, _vp, _vp]),
+    "btr_sa_gemm_tn_pool": (_ci, [_ci, _ci, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci,
+                                  _vp, _vp, _vp, _vp, _vp]),
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 25),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 27),

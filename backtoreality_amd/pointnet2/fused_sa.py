@@ -138,13 +138,26 @@ class FusedSAFunction(Function):
 
         with _on(dout) as d:
             st = _stream(d)
-            # ---- last layer: max-pool + ReLU + BN backward, in place over Y_last
+            # ---- last layer: max-pool + ReLU + BN backward.  Default: only the statistics
+            # and the per-group coefficients are computed; the dense dY of the pooled layer
+            # is formed inside the operand staging of its two GEMMs and never reaches HBM
+            # (BTR_POOLGRAD=0: written in place over Y_last by btr_sa_pool_bwd).
             CL = Ys[-1].shape[1]
             scale, shift, mean, invstd = stats[-1]
             part = _f32((256, 2, CL), dev)
             m1, m2, dg, db = (_f32((CL,), dev) for _ in range(4))
-            _call(_lib.btr_sa_pool_bwd, B, M, S, CL, CL, _p(Ys[-1]), _p(dout), _p(out), _p(arg),
-                  _p(mean), _p(invstd), _p(scale), _p(part), _p(m1), _p(m2), _p(dg), _p(db), st)
+            pool = None
+            if _pool_grad_in_prologue(S):
+                dcl = _f32((B * M, CL), dev)
+                alpha, beta = _f32((CL,), dev), _f32((CL,), dev)
+                _call(_lib.btr_sa_pool_bwd_coef, B, M, S, CL, CL, _p(Ys[-1]), _p(dout), _p(out),
+                      _p(arg), _p(mean), _p(invstd), _p(scale), _p(part), _p(m1), _p(m2),
+                      _p(dg), _p(db), _p(dcl), _p(alpha), _p(beta), st)
+                pool = (dcl, alpha, beta)
+            else:
+                _call(_lib.btr_sa_pool_bwd, B, M, S, CL, CL, _p(Ys[-1]), _p(dout), _p(out),
+                      _p(arg), _p(mean), _p(invstd), _p(scale), _p(part), _p(m1), _p(m2),
+                      _p(dg), _p(db), st)
             grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = dg, db
             dY = Ys[-1]
             for l in range(L - 1, -1, -1):
@@ -156,20 +169,31 @@ class FusedSAFunction(Function):
                 else:
                     Xsrc, ldx = Ys[l - 1], Ys[l - 1].shape[1]
                     pa, pb = stats[l - 1][0], stats[l - 1][1]
+                pooled = pool is not None and l == L - 1  # dY is still Y_last + coefficients
                 # weight gradient: dW[n][k] = sum_r dY[r][n] * X_l[r][k]
                 chunks = _lib.btr_sa_gemm_tn_chunks(R, Nl, K)
                 pw = _f32((chunks, Nl, K), dev)
                 dW = _f32((Nl, K), dev)
-                _call(_lib.btr_sa_gemm_tn, R, Nl, K, _p(dY), Nl, _p(Xsrc), ldx, _p(pa), _p(pb),
-                      _p(pw), _p(dW), st, key=(R, Nl, K))
+                if pooled:
+                    _call(_lib.btr_sa_gemm_tn_pool, R, Nl, K, _p(dY), Nl, S, _p(arg),
+                          _p(pool[0]), _p(pool[1]), _p(pool[2]), _p(Xsrc), ldx, _p(pa), _p(pb),
+                          _p(pw), _p(dW), st, key=(R, Nl, K))
+                else:
+                    _call(_lib.btr_sa_gemm_tn, R, Nl, K, _p(dY), Nl, _p(Xsrc), ldx, _p(pa),
+                          _p(pb), _p(pw), _p(dW), st, key=(R, Nl, K))
                 kin = pshapes[3 * l][1]
                 grads[3 * l] = dW[:, :kin].reshape(pshapes[3 * l])
                 # input gradient: dX_l[r][k] = sum_n dY[r][n] * W[n][k]
                 if l > 0 or need_xyz or need_new or need_feat:
                     Wt = W2.t().contiguous()  # (K, Nl)
                     G = _f32((R, K), dev)
-                    _call(_lib.btr_sa_gemm_nt, R, K, Nl, _p(dY), Nl, _p(Wt), Nl, _p(G), K,
-                          None, None, None, st, key=(R, K, Nl))
+                    if pooled:
+                        _call(_lib.btr_sa_gemm_nt_pool, R, K, Nl, _p(dY), Nl, _p(Wt), Nl, _p(G),
+                              K, S, _p(arg), _p(pool[0]), _p(pool[1]), _p(pool[2]), st,
+                              key=(R, K, Nl))
+                    else:
+                        _call(_lib.btr_sa_gemm_nt, R, K, Nl, _p(dY), Nl, _p(Wt), Nl, _p(G), K,
+                              None, None, None, st, key=(R, K, Nl))
                     if l > 0:
                         sc, sh, mu, isd = stats[l - 1]
                         part = _f32((1024, 2, K), dev)
@@ -194,6 +218,12 @@ class FusedSAFunction(Function):
                         if dfeat_cl is not None:
                             dfeat = dfeat_cl.transpose(1, 2).contiguous()
         return (dxyz, dnew, dfeat, None, None) + tuple(grads)
+
+
+def _pool_grad_in_prologue(nsample):
+    """The GEMM-prologue form of the pooled layer's gradient needs whole groups per staged
+    tile (128 rows in the NT kernel, 32 in the TN kernel)."""
+    return nsample in (16, 32, 64, 128) and os.environ.get("BTR_POOLGRAD", "1") != "0"
 
 
 def can_fuse(module, xyz, features):

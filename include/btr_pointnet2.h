@@ -198,6 +198,26 @@ int btr_sa_scatter(int b, int n, int m, int s, int c, int ldx, int use_xyz, floa
                    float *dnew_xyz, void *workspace, size_t workspace_bytes,
                    btr_stream_t stream);
 
+/* Pooled-layer backward without a dense dY pass.  btr_sa_pool_bwd_coef computes the BatchNorm
+ * backward statistics of the max-pooled (last) layer like btr_sa_pool_bwd, but leaves y
+ * untouched and returns dcl [b*m][c], alpha [c], beta [c] with
+ *   dY[r][c] = alpha[c]*y[r][c] + beta[c] + (r % s == arg[r/s][c] ? dcl[r/s][c] : 0);
+ * btr_sa_gemm_nt_pool (input gradient, dX = dY . W) and btr_sa_gemm_tn_pool (weight gradient,
+ * dW = dY^T . f(x)) form dY inside their operand staging.  Replaces the F.max_pool2d / ReLU /
+ * BatchNorm2d backward of pointnet2_modules.py:258-266 for the last SharedMLP layer. */
+int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, const float *dout,
+                         const float *out, const unsigned char *arg, const float *mean,
+                         const float *invstd, const float *scale, float *part, float *m1,
+                         float *m2, float *dgamma, float *dbeta, float *dcl, float *alpha,
+                         float *beta, btr_stream_t stream);
+int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const float *w, int ldw,
+                        float *c, int ldc, int s, const unsigned char *arg, const float *dcl,
+                        const float *alpha, const float *beta, btr_stream_t stream);
+int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
+                        const unsigned char *arg, const float *dcl, const float *alpha,
+                        const float *beta, const float *x, int ldx, const float *pa,
+                        const float *pb, float *pw, float *dw, btr_stream_t stream);
+
 /* ---- VoteNet loss, forward + backward (the caller right after the hot path).
  * Replaces the ~250 torch launches of detection/Votenet/models/loss_helper.py:336-400
  * (compute_vote_loss :24-69, compute_objectness_loss :111-152, compute_box_and_sem_cls_loss
