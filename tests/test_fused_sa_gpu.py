@@ -43,6 +43,7 @@ def _run(sa, xyz, feats, inds, xyz_grad):
     (1024, 256, 0.3, 16, [256, 128, 128, 128], 256, True),   # vote aggregation: xyz needs grad
     (1024, 128, 0.8, 16, [0, 32, 48], 0, True),              # no features (GroupFree), 2 layers
     (700, 100, 0.5, 7, [5, 20], 5, True),                    # ragged sizes, single layer
+    (3000, 64, 1.0, 128, [3, 32, 64], 3, True),              # one group = one 128-row GEMM tile
 ])
 def test_fused_matches_unfused(cuda, monkeypatch, N, npoint, radius, S, mlp, C, xyz_grad):
     B = 2
@@ -87,3 +88,35 @@ def test_fused_path_is_taken_and_eval_falls_back(cuda, monkeypatch):
     sa.eval()
     sa(xyz, None)
     assert calls == [1]  # eval mode (running statistics) uses the unfused path
+
+
+@pytest.mark.parametrize("poolgrad", ["1", "0"])
+def test_pooled_gradient_paths_agree(cuda, monkeypatch, poolgrad):
+    """Pooled layer backward: gradient formed inside the GEMM operand staging (default) and
+    the dense in-place pass (BTR_POOLGRAD=0) against the unfused composition, with negative
+    BatchNorm scales in the pooled layer (the arg-max then sits on the per-group minimum of
+    the pre-BN output)."""
+    B, N, npoint, S = 2, 2048, 256, 32
+    xyz = torch.from_numpy(np.stack([synthetic.make_scene(60 + i, N, use_height=False)[
+        'point_clouds'] for i in range(B)], 0)).to(cuda)
+    torch.manual_seed(1)
+    feats = torch.randn(B, 16, N, device=cuda)
+    sa = M.PointnetSAModuleVotes(npoint=npoint, radius=0.4, nsample=S, mlp=[16, 32, 64],
+                                 use_xyz=True, normalize_xyz=True).to(cuda)
+    with torch.no_grad():
+        for layer in sa.mlp_module:
+            layer.bn.bn.weight.uniform_(-1.5, 1.5)
+            layer.bn.bn.bias.uniform_(-0.3, 0.3)
+    ref_mod = copy.deepcopy(sa)
+    from backtoreality_amd.pointnet2 import pointnet2_utils
+    inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    monkeypatch.setenv("BTR_FUSED_SA", "0")
+    ref = _run(ref_mod, xyz, feats, inds, True)
+    monkeypatch.setenv("BTR_FUSED_SA", "1")
+    monkeypatch.setenv("BTR_POOLGRAD", poolgrad)
+    got = _run(sa, xyz, feats, inds, True)
+    for k in sorted(ref):
+        if ref[k] is None:
+            continue
+        tol = 1e-4 if k in ("out", "new_xyz") or "running" in k or "tracked" in k else 5e-4
+        assert _rel(got[k], ref[k]) < tol, (k, _rel(got[k], ref[k]))
