@@ -78,11 +78,13 @@ __global__ __launch_bounds__(256) void sa_gather_kernel(
 // (pa = alpha, pb = beta, pdcl = scale*dOut where the pooled output is > 0; see
 // btr_sa_pool_bwd_coef).
 template <int BN, int PRO, bool STATS>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(
+// (second launch bound: at least 2 waves per SIMD, i.e. <= 256 VGPRs -- two workgroups per
+// CU; without it the PRO == 2 / BN = 128 variant allocates 292 and runs alone on its CU)
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
     float *__restrict__ C, int ldc, int R, int N, int K, const float *__restrict__ pa,
     const float *__restrict__ pb, float *__restrict__ part,
-    const unsigned char *__restrict__ parg, const float *__restrict__ pdcl, int S) {
+    const unsigned char *__restrict__ parg, const float *__restrict__ pdcl, int SSH) {
   constexpr int WN = BN / 64;      // waves along N
   constexpr int WM = 4 / WN;       // waves along M
   constexpr int MI = kBM / WM / 32;  // 32-row MFMA tiles per wave
@@ -127,9 +129,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
       }
     }
     if (PRO == 2) {
-      const int k1 = kc * kBK + sp_k;
-      const long long g = (long long)r0 / S + sp_gi;
-      sp_on = sp_gi * S < kBM && g * S < R && k1 < K;
+      const int k1 = kc * kBK + sp_k;  // (group size S = 1 << SSH: shifts, no divisions)
+      const int g = (r0 >> SSH) + sp_gi;
+      sp_on = (sp_gi << SSH) < kBM && (g << SSH) < R && k1 < K;
       if (sp_on) {
         sp_arg = parg[(size_t)g * K + k1];
         sp_d = pdcl[(size_t)g * K + k1];
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
       stage(tile, kc);
       __syncthreads();
       if (PRO == 2) {  // sparse part: the arg-max row of every (group, channel) of this tile
-        if (sp_on) As[(sp_gi * S + (int)sp_arg) * kLd + sp_k] += sp_d;
+        if (sp_on) As[((sp_gi << SSH) + (int)sp_arg) * kLd + sp_k] += sp_d;
         __syncthreads();
       }
       // issue the next step's global loads before the MFMAs of this one
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     int K, const float *__restrict__ pa, const float *__restrict__ pb, int rows_per_chunk,
     float *__restrict__ pw, const unsigned char *__restrict__ garg = nullptr,
     const float *__restrict__ gdcl = nullptr, const float *__restrict__ galpha = nullptr,
-    const float *__restrict__ gbeta = nullptr, int S = 1) {
+    const float *__restrict__ gbeta = nullptr, int SSH = 0) {
   constexpr int BR = 32;
   constexpr int TN = 32 * TNW;      // n columns of G staged per step
   constexpr int LG = TN + 4, LX = 68;
@@ -610,13 +612,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
       }
     }
     if (GPOOL) {
-      const long long g = (long long)r0 / S + sp_gi;
-      sp_on = sp_gi * S < BR && g * S < rend && n0 + sp_n < N;
+      const int g = (r0 >> SSH) + sp_gi;  // group size S = 1 << SSH
+      sp_on = (sp_gi << SSH) < BR && (g << SSH) < rend && n0 + sp_n < N;
       if (sp_on) {
         sp_arg = garg[(size_t)g * N + n0 + sp_n];
         sp_d = gdcl[(size_t)g * N + n0 + sp_n];
-        const long long lr = g * S + sp_arg - r0;  // local row of the arg-max inside this step
-        sp_on = lr >= 0 && lr < BR && g * S + sp_arg < rend;
+        const int lr = (g << SSH) + (int)sp_arg - r0;  // local row of the arg-max in this step
+        sp_on = lr >= 0 && lr < BR && (g << SSH) + (int)sp_arg < rend;
         sp_arg = (unsigned)lr;
       }
     }
@@ -863,6 +865,12 @@ int btr_sa_gather(int b, int n, int m, int s, int c, int ldx, int use_xyz, float
   return check_launch("sa_gather");
 }
 
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
 // Number of workgroups (= rows of the `part` buffer) btr_sa_gemm_nt uses along rows.
 int btr_sa_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, kBM), 512)); }
 
@@ -881,7 +889,7 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
 #define BTR_GEMM(BN, P, S)                                                                   \
   hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S>), dim3(gx, cdiv(n, BN)), dim3(256), 0, s, a,  \
                      lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,                             \
-                     (const unsigned char *)nullptr, (const float *)nullptr, 1)
+                     (const unsigned char *)nullptr, (const float *)nullptr, 0)
   if (n <= 64) {
     if (pro) { if (st) BTR_GEMM(64, 1, true); else BTR_GEMM(64, 1, false); }
     else     { if (st) BTR_GEMM(64, 0, true); else BTR_GEMM(64, 0, false); }
@@ -962,17 +970,18 @@ int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const f
   BTR_REQUIRE(y && w && c && arg && dcl && alpha && beta && s > 0 && k > 0 && k % 4 == 0 &&
                   ldy % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt_pool: bad arguments (k=%d ldy=%d ldw=%d s=%d)", k, ldy, ldw, s);
-  BTR_REQUIRE(s >= 16 && s <= 255 && (kBM % s == 0 || s % kBM == 0),
+  BTR_REQUIRE(s == 16 || s == 32 || s == 64 || s == 128,
               "sa_gemm_nt_pool: nsample %d must be 16, 32, 64 or 128", s);
+  const int ssh = ilog2(s);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
   if (n <= 64)
     hipLaunchKernelGGL((gemm_nt_kernel<64, 2, false>), dim3(gx, cdiv(n, 64)), dim3(256), 0, st, y,
-                       ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl, s);
+                       ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl, ssh);
   else
     hipLaunchKernelGGL((gemm_nt_kernel<128, 2, false>), dim3(gx, cdiv(n, 128)), dim3(256), 0, st,
                        y, ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl,
-                       s);
+                       ssh);
   return check_launch("sa_gemm_nt_pool");
 }
 
@@ -1047,8 +1056,9 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
   BTR_REQUIRE(y && x && pw && dw && arg && dcl && alpha && beta && s > 0 && ldy % 4 == 0 &&
                   ldx % 4 == 0 && n % 4 == 0 && k % 4 == 0,
               "sa_gemm_tn_pool: sizes must be multiples of 4 (n=%d k=%d)", n, k);
-  BTR_REQUIRE(s >= 16 && s <= 255 && (32 % s == 0 || s % 32 == 0),
-              "sa_gemm_tn_pool: nsample %d must be 16 or a multiple of 32", s);
+  BTR_REQUIRE(s == 16 || s == 32 || s == 64 || s == 128,
+              "sa_gemm_tn_pool: nsample %d must be 16, 32, 64 or 128", s);
+  const int ssh = ilog2(s);
   hipStream_t st = as_stream(stream);
   const int chunks = btr_sa_gemm_tn_chunks(rows, n, k);
   const int rpc = cdiv(cdiv(rows, chunks), 32) * 32;
@@ -1056,7 +1066,7 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
   const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
 #define BTR_TNP(W, P)                                                                         \
   hipLaunchKernelGGL((gemm_tn_kernel<W, P, true>), grid, dim3(256), 0, st, y, ldy, x, ldx,    \
-                     rows, n, k, pa, pb, rpc, pw, arg, dcl, alpha, beta, s)
+                     rows, n, k, pa, pb, rpc, pw, arg, dcl, alpha, beta, ssh)
   if (tn == 128) {
     if (pa) BTR_TNP(4, true); else BTR_TNP(4, false);
   } else {
