@@ -24,6 +24,11 @@ constexpr int kNSums = 16;
 
 struct LossDims {
   int B, K, K2, NH, NS, NC, S1, N, Cout;
+  // Back-to-Reality (get_loss_DA, loss_helper.py:548-664): per-term weights of
+  // (vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg, sem_cls) in
+  // loss/10, and vote_mode 1 = compute_weak_vote_loss (:71-109) instead of compute_vote_loss.
+  float w[8];
+  int vote_mode;
 };
 
 __device__ __forceinline__ float huber1(float e) {  // delta = 1 (nn_distance.py:15-32)
@@ -46,7 +51,7 @@ __device__ __forceinline__ float lse(const float *p, size_t cs, int n, float &mx
 
 enum {  // block / batch sums
   S_LABEL, S_MASK, S_BOXMASK, S_VOTEMASK, S_OBJ, S_D1C, S_D2C, S_HCLS, S_HREG, S_SCLS, S_SREG,
-  S_SEM, S_VOTE, S_ACC
+  S_SEM, S_VOTE, S_ACC, S_D2V
 };
 
 __global__ __launch_bounds__(256) void loss_terms_kernel(
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
     const long long *__restrict__ sem_cls_label, const float *__restrict__ mean_size,
     long long *__restrict__ objectness_label, float *__restrict__ objectness_mask,
     long long *__restrict__ object_assignment, int *__restrict__ j1c, int *__restrict__ k2c,
-    signed char *__restrict__ vote_arg, float *__restrict__ part) {
+    signed char *__restrict__ vote_arg, float *__restrict__ part, int *__restrict__ i2v) {
   __shared__ float gt[kMaxObj * 3];
   __shared__ float cen[kMaxProp * 3];
   __shared__ float red[kNSums][4];
@@ -144,25 +149,55 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
     sums[S_D2C] += best * bm;
     sums[S_BOXMASK] += bm;
   }
-  // vote loss (vote_factor 1): min over the 3 GT votes of the L1 distance
-  for (int i = tid; i < d.S1; i += 256) {
-    const size_t so = (size_t)b * d.S1 + i;
-    const int pi = seed_inds[so];
-    const float m = (float)vote_label_mask[(size_t)b * d.N + pi];
-    const float *vl = vote_label + ((size_t)b * d.N + pi) * 9;
-    const float sx = seed_xyz[so * 3], sy = seed_xyz[so * 3 + 1], sz = seed_xyz[so * 3 + 2];
-    const float vx = vote_xyz[so * 3], vy = vote_xyz[so * 3 + 1], vz = vote_xyz[so * 3 + 2];
-    float best = 3.0e38f;
-    int bc = 0;
+  if (d.vote_mode == 0) {
+    // vote loss (vote_factor 1): min over the 3 GT votes of the L1 distance
+    for (int i = tid; i < d.S1; i += 256) {
+      const size_t so = (size_t)b * d.S1 + i;
+      const int pi = seed_inds[so];
+      const float m = (float)vote_label_mask[(size_t)b * d.N + pi];
+      const float *vl = vote_label + ((size_t)b * d.N + pi) * 9;
+      const float sx = seed_xyz[so * 3], sy = seed_xyz[so * 3 + 1], sz = seed_xyz[so * 3 + 2];
+      const float vx = vote_xyz[so * 3], vy = vote_xyz[so * 3 + 1], vz = vote_xyz[so * 3 + 2];
+      float best = 3.0e38f;
+      int bc = 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float q = fabsf(vx - (vl[c * 3] + sx)) + fabsf(vy - (vl[c * 3 + 1] + sy)) +
-                      fabsf(vz - (vl[c * 3 + 2] + sz));
-      if (q < best) { best = q; bc = c; }
+      for (int c = 0; c < 3; ++c) {
+        const float q = fabsf(vx - (vl[c * 3] + sx)) + fabsf(vy - (vl[c * 3 + 1] + sy)) +
+                        fabsf(vz - (vl[c * 3 + 2] + sz));
+        if (q < best) { best = q; bc = c; }
+      }
+      vote_arg[so] = (signed char)bc;
+      sums[S_VOTE] += best * m;
+      sums[S_VOTEMASK] += m;
     }
-    vote_arg[so] = (signed char)bc;
-    sums[S_VOTE] += best * m;
-    sums[S_VOTEMASK] += m;
+  } else {
+    // weak vote loss: L1 chamfer between the votes and ALL GT-centre slots (padding
+    // included, like the reference), votes -> nearest centre averaged over every seed,
+    // centres -> nearest vote averaged over the real boxes
+    for (int i = tid; i < d.S1; i += 256) {
+      const size_t so = (size_t)b * d.S1 + i;
+      const float vx = vote_xyz[so * 3], vy = vote_xyz[so * 3 + 1], vz = vote_xyz[so * 3 + 2];
+      float best = 3.0e38f;
+      int bj = 0;
+      for (int j = 0; j < d.K2; ++j) {
+        const float q = fabsf(vx - gt[j * 3]) + fabsf(vy - gt[j * 3 + 1]) + fabsf(vz - gt[j * 3 + 2]);
+        if (q < best) { best = q; bj = j; }
+      }
+      vote_arg[so] = (signed char)(unsigned char)bj;
+      sums[S_VOTE] += best;
+    }
+    for (int j = tid; j < d.K2; j += 256) {
+      const float gx = gt[j * 3], gy = gt[j * 3 + 1], gz = gt[j * 3 + 2];
+      const float *v = vote_xyz + (size_t)b * d.S1 * 3;
+      float best = 3.0e38f;
+      int bi2 = 0;
+      for (int i = 0; i < d.S1; ++i) {
+        const float q = fabsf(v[i * 3] - gx) + fabsf(v[i * 3 + 1] - gy) + fabsf(v[i * 3 + 2] - gz);
+        if (q < best) { best = q; bi2 = i; }
+      }
+      i2v[(size_t)b * d.K2 + j] = bi2;
+      sums[S_D2V] += best * box_label_mask[(size_t)b * d.K2 + j];
+    }
   }
   // block reduction of the sums
 #pragma unroll
@@ -180,8 +215,9 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
 // stats[0..12] = loss, vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg,
 // sem_cls, box, pos_ratio, neg_ratio, obj_acc;  norm[0..3] = 1/(sum+1e-6) of label, mask,
 // boxmask, votemask.
-__global__ void loss_reduce_kernel(int B, int K, const float *__restrict__ part,
+__global__ void loss_reduce_kernel(LossDims d, const float *__restrict__ part,
                                    float *__restrict__ stats, float *__restrict__ norm) {
+  const int B = d.B, K = d.K;
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float s[kNSums];
   for (int i = 0; i < kNSums; ++i) {
@@ -191,13 +227,17 @@ __global__ void loss_reduce_kernel(int B, int K, const float *__restrict__ part,
   }
   const float nl = 1.f / (s[S_LABEL] + 1e-6f), nm = 1.f / (s[S_MASK] + 1e-6f);
   const float nb = 1.f / (s[S_BOXMASK] + 1e-6f), nv = 1.f / (s[S_VOTEMASK] + 1e-6f);
-  const float vote = s[S_VOTE] * nv, obj = s[S_OBJ] * nm;
+  const float vote = d.vote_mode == 0
+                         ? s[S_VOTE] * nv
+                         : s[S_VOTE] / ((float)B * (float)d.S1) + s[S_D2V] * nb;
+  const float obj = s[S_OBJ] * nm;
   const float center = s[S_D1C] * nl + s[S_D2C] * nb;
   const float hcls = s[S_HCLS] * nl, hreg = s[S_HREG] * nl, scls = s[S_SCLS] * nl;
   const float sreg = s[S_SREG] * nl, sem = s[S_SEM] * nl;
   const float box = center + 0.1f * hcls + hreg + 0.1f * scls + sreg;
   const float total = (float)B * (float)K;
-  stats[0] = (vote + 0.5f * obj + box + 0.1f * sem) * 10.f;
+  stats[0] = (d.w[0] * vote + d.w[1] * obj + d.w[2] * center + d.w[3] * hcls + d.w[4] * hreg +
+              d.w[5] * scls + d.w[6] * sreg + d.w[7] * sem) * 10.f;
   stats[1] = vote; stats[2] = obj; stats[3] = center; stats[4] = hcls; stats[5] = hreg;
   stats[6] = scls; stats[7] = sreg; stats[8] = sem; stats[9] = box;
   stats[10] = s[S_LABEL] / total;
@@ -219,7 +259,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
     const long long *__restrict__ objectness_label, const float *__restrict__ objectness_mask,
     const long long *__restrict__ object_assignment, const int *__restrict__ j1c,
     const int *__restrict__ k2c, const signed char *__restrict__ vote_arg,
-    float *__restrict__ dnet, float *__restrict__ dagg, float *__restrict__ dvote) {
+    float *__restrict__ dnet, float *__restrict__ dagg, float *__restrict__ dvote,
+    const int *__restrict__ i2v) {
   __shared__ float gt[kMaxObj * 3];
   __shared__ float bm[kMaxObj];
   __shared__ int kc[kMaxObj];
@@ -245,7 +286,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
     {
       float mx;
       const float l = lse(nb + k, cs, 2, mx);
-      const float w = (label ? 0.8f : 0.2f) * mask * nm * 0.5f * g10;
+      const float w = (label ? 0.8f : 0.2f) * mask * nm * d.w[1] * g10;
       gb[0 * cs + k] = w * (expf(nb[k] - l) - (label == 0 ? 1.f : 0.f));
       gb[1 * cs + k] = w * (expf(nb[cs + k] - l) - (label == 1 ? 1.f : 0.f));
     }
@@ -261,7 +302,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
         gy += 2.f * (cy - gt[j * 3 + 1]) * bm[j] * nbx;
         gz += 2.f * (cz - gt[j * 3 + 2]) * bm[j] * nbx;
       }
-    gx *= g10; gy *= g10; gz *= g10;
+    gx *= g10 * d.w[2]; gy *= g10 * d.w[2]; gz *= g10 * d.w[2];
     gb[2 * cs + k] = gx; gb[3 * cs + k] = gy; gb[4 * cs + k] = gz;
     dagg[o * 3] = gx; dagg[o * 3 + 1] = gy; dagg[o * 3 + 2] = gz;
     // heading / size / semantic
@@ -274,23 +315,23 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
       float mx;
       const float l = lse(nb + oH * cs + k, cs, d.NH, mx);
       for (int c = 0; c < d.NH; ++c)
-        gb[(oH + c) * cs + k] = 0.1f * wl * (expf(nb[(oH + c) * cs + k] - l) - (c == hcl ? 1.f : 0.f));
+        gb[(oH + c) * cs + k] = d.w[3] * wl * (expf(nb[(oH + c) * cs + k] - l) - (c == hcl ? 1.f : 0.f));
       const float htar = heading_residual_label[jo] / (3.14159265358979323846f / (float)d.NH);
-      const float ge = huber1_grad(nb[(oHR + hcl) * cs + k] - htar) * wl;
+      const float ge = huber1_grad(nb[(oHR + hcl) * cs + k] - htar) * wl * d.w[4];
       for (int c = 0; c < d.NH; ++c) gb[(oHR + c) * cs + k] = c == hcl ? ge : 0.f;
     }
     {
       float mx;
       const float l = lse(nb + oS * cs + k, cs, d.NS, mx);
       for (int c = 0; c < d.NS; ++c)
-        gb[(oS + c) * cs + k] = 0.1f * wl * (expf(nb[(oS + c) * cs + k] - l) - (c == scl ? 1.f : 0.f));
+        gb[(oS + c) * cs + k] = d.w[5] * wl * (expf(nb[(oS + c) * cs + k] - l) - (c == scl ? 1.f : 0.f));
       for (int c = 0; c < d.NS; ++c)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           float g = 0.f;
           if (c == scl) {
             const float tar = size_residual_label[jo * 3 + t] / mean_size[scl * 3 + t];
-            g = huber1_grad(nb[(oSR + c * 3 + t) * cs + k] - tar) * wl / 3.f;
+            g = huber1_grad(nb[(oSR + c * 3 + t) * cs + k] - tar) * wl * d.w[6] / 3.f;
           }
           gb[(oSR + c * 3 + t) * cs + k] = g;
         }
@@ -299,20 +340,43 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
       float mx;
       const float l = lse(nb + oC * cs + k, cs, d.NC, mx);
       for (int c = 0; c < d.NC; ++c)
-        gb[(oC + c) * cs + k] = 0.1f * wl * (expf(nb[(oC + c) * cs + k] - l) - (c == sem ? 1.f : 0.f));
+        gb[(oC + c) * cs + k] = d.w[7] * wl * (expf(nb[(oC + c) * cs + k] - l) - (c == sem ? 1.f : 0.f));
     }
   }
   // votes
-  for (int i = tid; i < d.S1; i += 256) {
-    const size_t so = (size_t)b * d.S1 + i;
-    const int pi = seed_inds[so];
-    const float m = (float)vote_label_mask[(size_t)b * d.N + pi] * nv * g10;
-    const int c = vote_arg[so];
-    const float *vl = vote_label + ((size_t)b * d.N + pi) * 9 + c * 3;
+  if (d.vote_mode == 0) {
+    for (int i = tid; i < d.S1; i += 256) {
+      const size_t so = (size_t)b * d.S1 + i;
+      const int pi = seed_inds[so];
+      const float m = (float)vote_label_mask[(size_t)b * d.N + pi] * nv * g10 * d.w[0];
+      const int c = vote_arg[so];
+      const float *vl = vote_label + ((size_t)b * d.N + pi) * 9 + c * 3;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const float e = vote_xyz[so * 3 + t] - (vl[t] + seed_xyz[so * 3 + t]);
-      dvote[so * 3 + t] = m * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+      for (int t = 0; t < 3; ++t) {
+        const float e = vote_xyz[so * 3 + t] - (vl[t] + seed_xyz[so * 3 + t]);
+        dvote[so * 3 + t] = m * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+      }
+    }
+  } else {
+    const float w1 = g10 * d.w[0] / ((float)d.B * (float)d.S1), w2 = g10 * d.w[0] * nbx;
+    for (int i = tid; i < d.S1; i += 256) {
+      const size_t so = (size_t)b * d.S1 + i;
+      const int j1 = (unsigned char)vote_arg[so];
+      float g[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const float e = vote_xyz[so * 3 + t] - gt[j1 * 3 + t];
+        g[t] = w1 * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+      }
+      for (int j = 0; j < d.K2; ++j)
+        if (i2v[(size_t)b * d.K2 + j] == i && bm[j] != 0.f) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const float e = vote_xyz[so * 3 + t] - gt[j * 3 + t];
+            g[t] += w2 * bm[j] * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+          }
+        }
+      dvote[so * 3] = g[0]; dvote[so * 3 + 1] = g[1]; dvote[so * 3 + 2] = g[2];
     }
   }
 }
@@ -337,20 +401,22 @@ int btr_votenet_loss_fwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
                          const float *mean_size, long long *objectness_label,
                          float *objectness_mask, long long *object_assignment, int *j1c, int *k2c,
                          signed char *vote_arg, float *part, float *stats, float *norm,
-                         btr_stream_t stream) {
+                         const float *weights8, int vote_mode, int *i2v, btr_stream_t stream) {
   if (b <= 0) return BTR_OK;
   BTR_REQUIRE(k > 0 && k <= kMaxProp && k2 > 0 && k2 <= kMaxObj &&
                   cout == 5 + 2 * nh + 4 * ns + nc,
               "votenet_loss: unsupported sizes (k=%d k2=%d cout=%d)", k, k2, cout);
-  const LossDims d{b, k, k2, nh, ns, nc, s1, n, cout};
+  BTR_REQUIRE(weights8 && (vote_mode == 0 || i2v), "votenet_loss: weights / i2v missing");
+  LossDims d{b, k, k2, nh, ns, nc, s1, n, cout, {0, 0, 0, 0, 0, 0, 0, 0}, vote_mode};
+  for (int i = 0; i < 8; ++i) d.w[i] = weights8[i];
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(loss_terms_kernel, dim3(b), dim3(256), 0, st, d, net, agg_xyz, vote_xyz,
                      seed_xyz, seed_inds, vote_label, vote_label_mask, center_label,
                      box_label_mask, heading_class_label, heading_residual_label,
                      size_class_label, size_residual_label, sem_cls_label, mean_size,
                      objectness_label, objectness_mask, object_assignment, j1c, k2c, vote_arg,
-                     part);
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, st, b, k, part, stats, norm);
+                     part, i2v);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, st, d, part, stats, norm);
   return check_launch("votenet_loss_fwd");
 }
 
@@ -366,15 +432,18 @@ int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
                          const float *mean_size, const long long *objectness_label,
                          const float *objectness_mask, const long long *object_assignment,
                          const int *j1c, const int *k2c, const signed char *vote_arg, float *dnet,
-                         float *dagg, float *dvote, btr_stream_t stream) {
+                         float *dagg, float *dvote, const float *weights8, int vote_mode,
+                         const int *i2v, btr_stream_t stream) {
   if (b <= 0) return BTR_OK;
-  const LossDims d{b, k, k2, nh, ns, nc, s1, n, cout};
+  BTR_REQUIRE(weights8 && (vote_mode == 0 || i2v), "votenet_loss: weights / i2v missing");
+  LossDims d{b, k, k2, nh, ns, nc, s1, n, cout, {0, 0, 0, 0, 0, 0, 0, 0}, vote_mode};
+  for (int i = 0; i < 8; ++i) d.w[i] = weights8[i];
   hipLaunchKernelGGL(loss_grad_kernel, dim3(b), dim3(256), 0, as_stream(stream), d, gout, norm,
                      net, agg_xyz, vote_xyz, seed_xyz, seed_inds, vote_label, vote_label_mask,
                      center_label, box_label_mask, heading_class_label, heading_residual_label,
                      size_class_label, size_residual_label, sem_cls_label, mean_size,
                      objectness_label, objectness_mask, object_assignment, j1c, k2c, vote_arg,
-                     dnet, dagg, dvote);
+                     dnet, dagg, dvote, i2v);
   return check_launch("votenet_loss_bwd");
 }
 

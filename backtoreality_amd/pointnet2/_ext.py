@@ -65,8 +65,8 @@ _SIGNATURES = {
     "btr_sa_gemm_tn_pool": (_ci, [_ci, _ci, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci,
                                   _vp, _vp, _vp, _vp, _vp]),
     # fused VoteNet loss (used by votenet/fused_loss.py)
-    "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 25),
-    "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 27),
+    "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
+    "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
 }
 
 

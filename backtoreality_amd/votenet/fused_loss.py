@@ -9,6 +9,7 @@ Differences visible to a caller: the per-term entries of `end_points` ('vote_los
 detached views of one statistics tensor -- only `loss` carries the autograd graph (the
 reference's training loop only ever calls `loss.backward()`, train.py:263).
 """
+import ctypes
 import os
 
 import torch
@@ -27,6 +28,11 @@ _LABEL_KEYS = ('vote_label', 'vote_label_mask', 'center_label', 'box_label_mask'
 _LABEL_DTYPES = (torch.float32, torch.int64, torch.float32, torch.float32, torch.int64,
                  torch.float32, torch.int64, torch.float32, torch.int64)
 HEAD_KEY = '_head_output'  # raw (B, Cout, K) proposal-head output, stored by ProposalModule
+# weights of (vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg, sem_cls)
+# in loss / 10
+W_FSB = (1.0, 0.5, 1.0, 0.1, 1.0, 0.1, 1.0, 0.1)             # get_loss, loss_helper.py:375-385
+W_DA_SOURCE = tuple(0.1 * w for w in W_FSB)                   # get_loss_DA :575-600 (x 0.1)
+W_DA_TARGET = (1.0, 0.5, 1.0, 0.0, 0.0, 0.1, 0.0, 0.1)        # weak labels: no heading / size reg
 
 
 def enabled():
@@ -54,7 +60,7 @@ def can_fuse(end_points, config):
 class FusedVoteNetLoss(Function):
     @staticmethod
     def forward(ctx, net, agg_xyz, vote_xyz, seed_xyz, seed_inds, mean_size, dims, *labels):
-        nh, ns, nc = dims
+        nh, ns, nc, weights, vote_mode = dims
         B, cout, K = net.shape
         K2, S1, N = labels[2].shape[1], seed_xyz.shape[1], labels[0].shape[1]
         dev = net.device
@@ -72,14 +78,17 @@ class FusedVoteNetLoss(Function):
         part = torch.empty((B, 16), dtype=torch.float32, device=dev)
         stats = torch.empty((13,), dtype=torch.float32, device=dev)
         norm = torch.empty((4,), dtype=torch.float32, device=dev)
+        i2v = torch.empty((B, K2), dtype=torch.int32, device=dev) if vote_mode else None
+        w8 = (ctypes.c_float * 8)(*weights)
         p = _ext._p
         with _ext._on(net) as d:
             _ext._call(_lib.btr_votenet_loss_fwd, B, K, K2, nh, ns, nc, S1, N, cout, p(net),
                        p(agg_xyz), p(vote_xyz), p(seed_xyz), p(seed_inds),
                        *[p(t) for t in labels], p(mean_size), p(objectness_label),
                        p(objectness_mask), p(object_assignment), p(j1c), p(k2c), p(vote_arg),
-                       p(part), p(stats), p(norm), _ext._stream(d))
+                       p(part), p(stats), p(norm), w8, int(vote_mode), p(i2v), _ext._stream(d))
         ctx.dims = (B, K, K2, nh, ns, nc, S1, N, cout)
+        ctx.weights, ctx.vote_mode, ctx.i2v = tuple(weights), int(vote_mode), i2v
         ctx.save_for_backward(net, agg_xyz, vote_xyz, seed_xyz, seed_inds, mean_size, norm,
                               objectness_label, objectness_mask, object_assignment, j1c, k2c,
                               vote_arg, *labels)
@@ -102,7 +111,8 @@ class FusedVoteNetLoss(Function):
                        p(norm), p(net), p(agg_xyz), p(vote_xyz), p(seed_xyz), p(seed_inds),
                        *[p(t) for t in labels], p(mean_size), p(objectness_label),
                        p(objectness_mask), p(object_assignment), p(j1c), p(k2c), p(vote_arg),
-                       p(dnet), p(dagg), p(dvote), _ext._stream(d))
+                       p(dnet), p(dagg), p(dvote), (ctypes.c_float * 8)(*ctx.weights),
+                       ctx.vote_mode, p(ctx.i2v), _ext._stream(d))
         return (dnet, dagg, dvote, None, None, None, None) + (None,) * len(labels)
 
 
@@ -118,11 +128,34 @@ def _mean_size(config, dev):
     return cache
 
 
+def _apply(end_points, config, weights, vote_mode):
+    net = end_points[HEAD_KEY]
+    dims = (config.num_heading_bin, config.num_size_cluster, config.num_class, weights,
+            vote_mode)
+    return FusedVoteNetLoss.apply(
+        net, end_points['aggregated_vote_xyz'], end_points['vote_xyz'], end_points['seed_xyz'],
+        end_points['seed_inds'], _mean_size(config, net.device), dims,
+        *[end_points[k] for k in _LABEL_KEYS])
+
+
+def get_loss_branch(end_points, config, weights, keys):
+    """One branch of get_loss_DA: the weighted sum (x 10) of the branch's terms with the weak
+    vote loss; fills `keys` (a subset of STAT_KEYS) plus the objectness bookkeeping."""
+    loss, stats, label, mask, assignment = _apply(end_points, config, weights, 1)
+    for i, k in enumerate(STAT_KEYS):
+        if k in keys:
+            end_points[k] = stats[i]
+    end_points['objectness_label'] = label
+    end_points['objectness_mask'] = mask
+    end_points['object_assignment'] = assignment
+    return loss
+
+
 def get_loss(end_points, config):
     """Same contract as loss_helper.get_loss: returns (loss, end_points) with every term,
     'objectness_label', 'objectness_mask' and 'object_assignment' filled in."""
     net = end_points[HEAD_KEY]
-    dims = (config.num_heading_bin, config.num_size_cluster, config.num_class)
+    dims = (config.num_heading_bin, config.num_size_cluster, config.num_class, W_FSB, 0)
     loss, stats, label, mask, assignment = FusedVoteNetLoss.apply(
         net, end_points['aggregated_vote_xyz'], end_points['vote_xyz'], end_points['seed_xyz'],
         end_points['seed_inds'], _mean_size(config, net.device), dims,

@@ -267,6 +267,10 @@ def get_loss_DA(end_points_S, end_points_T, config):
     """Loss of one Back-to-Reality step over a source (virtual, fully labelled) and a target
     (real, weakly labelled) branch (loss_helper.py:548-664): source terms weighted 0.1, focal
     + squared domain losses weighted 0.5 through the gradient-reversal layers."""
+    if end_points_S['seed_xyz'].is_cuda:
+        from . import fused_loss
+        if fused_loss.can_fuse(end_points_S, config) and fused_loss.can_fuse(end_points_T, config):
+            return _get_loss_DA_fused(end_points_S, end_points_T, config, fused_loss)
     source_coefficient = 0.1
     vote_loss_S = compute_weak_vote_loss(end_points_S)
     vote_loss_T = compute_weak_vote_loss(end_points_T)
@@ -299,6 +303,23 @@ def get_loss_DA(end_points_S, end_points_T, config):
     box_loss = source_coefficient * box_loss_S + box_loss_T
     sem_cls_loss = source_coefficient * sem_cls_loss_S + sem_cls_loss_T
 
+    DA_loss = _domain_loss(end_points_S, end_points_T)
+    end_points_S['DA_loss'] = DA_loss
+
+    loss = vote_loss + 0.5 * objectness_loss + box_loss + 0.1 * sem_cls_loss + DA_loss
+    loss = loss * 10
+    end_points_S['loss'] = loss
+
+    obj_pred_val = torch.argmax(end_points_S['objectness_scores'], 2)
+    label_S, mask_S = end_points_S['objectness_label'], end_points_S['objectness_mask']
+    end_points_S['obj_acc'] = torch.sum((obj_pred_val == label_S.long()).float() * mask_S) / \
+        (torch.sum(mask_S) + 1e-6)
+    return loss, end_points_S, end_points_T
+
+
+def _domain_loss(end_points_S, end_points_T):
+    """Focal loss on the global domain classifier + squared loss on the local one, both
+    through the gradient-reversal layers (loss_helper.py:618-650)."""
     da_coefficient = 0.5
     g_S = end_points_S['global_d_pred']
     l_S = end_points_S['local_d_pred'].transpose(1, 2).contiguous()
@@ -312,15 +333,21 @@ def get_loss_DA(end_points_S, end_points_T, config):
     w_T = end_points_T['objectness_label'].unsqueeze(-1)
     target_dloss = da_coefficient * torch.mean((1 - l_T) ** 2 * w_T) + \
         da_coefficient * focal_loss(g_T, domain_T, 3)
-    DA_loss = source_dloss + target_dloss
+    return source_dloss + target_dloss
+
+
+def _get_loss_DA_fused(end_points_S, end_points_T, config, fused_loss):
+    """get_loss_DA with each branch's detection terms (forward + gradient) in the fused HIP
+    kernels; only the domain losses stay torch ops.  Same end_points keys as above."""
+    keys_S = ('vote_loss', 'objectness_loss', 'center_loss', 'heading_cls_loss',
+              'heading_reg_loss', 'size_cls_loss', 'size_reg_loss', 'sem_cls_loss', 'box_loss',
+              'pos_ratio', 'neg_ratio', 'obj_acc')
+    keys_T = ('vote_loss', 'objectness_loss', 'center_loss', 'size_cls_loss', 'sem_cls_loss',
+              'pos_ratio', 'neg_ratio')
+    loss_S = fused_loss.get_loss_branch(end_points_S, config, fused_loss.W_DA_SOURCE, keys_S)
+    loss_T = fused_loss.get_loss_branch(end_points_T, config, fused_loss.W_DA_TARGET, keys_T)
+    DA_loss = _domain_loss(end_points_S, end_points_T)
     end_points_S['DA_loss'] = DA_loss
-
-    loss = vote_loss + 0.5 * objectness_loss + box_loss + 0.1 * sem_cls_loss + DA_loss
-    loss = loss * 10
+    loss = loss_S + loss_T + DA_loss * 10
     end_points_S['loss'] = loss
-
-    obj_pred_val = torch.argmax(end_points_S['objectness_scores'], 2)
-    label_S, mask_S = end_points_S['objectness_label'], end_points_S['objectness_mask']
-    end_points_S['obj_acc'] = torch.sum((obj_pred_val == label_S.long()).float() * mask_S) / \
-        (torch.sum(mask_S) + 1e-6)
     return loss, end_points_S, end_points_T

@@ -233,7 +233,13 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
  * Outputs: objectness_label (b,k) i64, objectness_mask (b,k) f32, object_assignment (b,k) i64;
  *   stats[13] = loss, vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg,
  *   sem_cls, box, pos_ratio, neg_ratio, obj_acc.  Kept for the backward: j1c (b,k) i32,
- *   k2c (b,k2) i32, vote_arg (b,s1) i8, part (b,16) f32, norm (4) f32. */
+ *   k2c (b,k2) i32, vote_arg (b,s1) i8, part (b,16) f32, norm (4) f32.
+ * weights8 (HOST pointer): weights of (vote, objectness, center, heading_cls, heading_reg,
+ *   size_cls, size_reg, sem_cls) in loss/10 -- get_loss: {1, .5, 1, .1, 1, .1, 1, .1}.
+ * vote_mode 1 + i2v (b,k2) i32 scratch: the weakly supervised vote term of the
+ *   Back-to-Reality loss (compute_weak_vote_loss, loss_helper.py:71-109; get_loss_DA
+ *   :548-664 is two such calls with the source / target weights) instead of
+ *   compute_vote_loss. */
 int btr_votenet_loss_fwd(int b, int k, int k2, int nh, int ns, int nc, int s1, int n, int cout,
                          const float *net, const float *agg_xyz, const float *vote_xyz,
                          const float *seed_xyz, const int *seed_inds, const float *vote_label,
@@ -244,7 +250,7 @@ int btr_votenet_loss_fwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
                          const float *mean_size, long long *objectness_label,
                          float *objectness_mask, long long *object_assignment, int *j1c, int *k2c,
                          signed char *vote_arg, float *part, float *stats, float *norm,
-                         btr_stream_t stream);
+                         const float *weights8, int vote_mode, int *i2v, btr_stream_t stream);
 /* dnet (b,cout,k), dagg (b,k,3), dvote (b,s1,3) <- d loss / d input, times gout[0]. */
 int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, int n, int cout,
                          const float *gout, const float *norm, const float *net,
@@ -257,7 +263,8 @@ int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
                          const float *mean_size, const long long *objectness_label,
                          const float *objectness_mask, const long long *object_assignment,
                          const int *j1c, const int *k2c, const signed char *vote_arg, float *dnet,
-                         float *dagg, float *dvote, btr_stream_t stream);
+                         float *dagg, float *dvote, const float *weights8, int vote_mode,
+                         const int *i2v, btr_stream_t stream);
 
 #ifdef __cplusplus
 }

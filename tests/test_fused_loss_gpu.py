@@ -133,3 +133,54 @@ def test_fused_loss_falls_back_only_when_it_must(cuda, monkeypatch):
                                    cfg)
     monkeypatch.setenv("BTR_FUSED_LOSS", "0")
     assert not fused_loss.can_fuse(end, cfg)
+
+
+def test_fused_da_loss_matches_torch_composition(cuda, monkeypatch):
+    """get_loss_DA (Back-to-Reality): both branches through the fused kernels (weak vote loss,
+    source / target term weights) against the torch composition."""
+    cfg = config.scannet_md40()
+    case_S = _case(cfg, cuda, 4, 256, 1024, 6000, seed=21)
+    case_T = _case(cfg, cuda, 4, 256, 1024, 6000, seed=22)
+    g = torch.Generator().manual_seed(3)
+    gd = [torch.randn(4, 2, generator=g).to(cuda) for _ in range(2)]
+    ld = [torch.rand(4, 1, 256, generator=g).to(cuda) for _ in range(2)]
+
+    def run(fused):
+        monkeypatch.setenv("BTR_FUSED_LOSS", "1" if fused else "0")
+        ends, leaves = [], []
+        for case, gdp, ldp in zip((case_S, case_T), gd, ld):
+            batch, net, agg, seed_inds, seed_xyz, vote_xyz = case
+            net = net.clone().requires_grad_(True)
+            agg = agg.clone().requires_grad_(True)
+            vote = vote_xyz.clone().requires_grad_(True)
+            gdp = gdp.clone().requires_grad_(True)
+            ldp = ldp.clone().requires_grad_(True)
+            end = {'aggregated_vote_xyz': agg, 'seed_xyz': seed_xyz, 'seed_inds': seed_inds,
+                   'vote_xyz': vote, fused_loss.HEAD_KEY: net, 'global_d_pred': gdp,
+                   'local_d_pred': ldp}
+            proposal_module.decode_scores(net, end, cfg.num_class, cfg.num_heading_bin,
+                                          cfg.num_size_cluster, cfg.mean_size_arr)
+            end.update(batch)
+            ends.append(end)
+            leaves.append((net, agg, vote, gdp, ldp))
+        loss, eS, eT = loss_helper.get_loss_DA(ends[0], ends[1], cfg)
+        loss.backward()
+        return loss.detach(), eS, eT, [[t.grad for t in lv] for lv in leaves]
+
+    l_t, eS_t, eT_t, g_t = run(False)
+    l_f, eS_f, eT_f, g_f = run(True)
+    assert abs(float(l_f) - float(l_t)) <= 1e-5 * abs(float(l_t))
+    for k in ('vote_loss', 'objectness_loss', 'center_loss', 'heading_cls_loss',
+              'heading_reg_loss', 'size_cls_loss', 'size_reg_loss', 'sem_cls_loss', 'box_loss',
+              'pos_ratio', 'neg_ratio', 'obj_acc', 'DA_loss'):
+        a, b = float(eS_f[k]), float(eS_t[k])
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), ("S", k, a, b)
+    for k in ('vote_loss', 'objectness_loss', 'center_loss', 'size_cls_loss', 'sem_cls_loss'):
+        a, b = float(eT_f[k]), float(eT_t[k])
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), ("T", k, a, b)
+    for e_f, e_t in ((eS_f, eS_t), (eT_f, eT_t)):
+        assert torch.equal(e_f['objectness_label'], e_t['objectness_label'])
+        assert torch.equal(e_f['objectness_mask'], e_t['objectness_mask'])
+    for branch in range(2):
+        for a, b in zip(g_f[branch], g_t[branch]):
+            assert _close(a, b), (branch, float((a - b).abs().max()), float(b.abs().max()))
