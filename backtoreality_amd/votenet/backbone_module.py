@@ -48,7 +48,9 @@ class Pointnet2Backbone(nn.Module):
         if not xyz.is_cuda or os.environ.get("BTR_OVERLAP_FPS", "1") == "0":
             return None
         main = torch.cuda.current_stream(xyz.device)
-        side = self._get_side_stream(xyz.device)
+        # its own stream: on the stream forward() uses for levels 2-4 the prefetched pyramid
+        # would queue in front of them and stall the forward it is supposed to hide under
+        side = self._get_side_stream(xyz.device, "_prefetch_stream")
         side.wait_stream(main)
         npoints = [getattr(self, "sa%d" % i).npoint for i in (1, 2, 3, 4)]
         out = []
@@ -66,10 +68,10 @@ class Pointnet2Backbone(nn.Module):
         xyz.record_stream(side)
         return out
 
-    def _get_side_stream(self, device):
-        if getattr(self, "_side_stream", None) is None or self._side_stream.device != device:
-            self._side_stream = torch.cuda.Stream(device=device)
-        return self._side_stream
+    def _get_side_stream(self, device, name="_side_stream"):
+        if getattr(self, name, None) is None or getattr(self, name).device != device:
+            setattr(self, name, torch.cuda.Stream(device=device))
+        return getattr(self, name)
 
     def _fps_pyramid(self, xyz):
         """Sampling indices of all four SA levels.  They depend on coordinates only, so levels

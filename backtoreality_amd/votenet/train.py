@@ -64,6 +64,19 @@ def make_optimizer(net, lr=1e-3, weight_decay=0.0):
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
 
 
+def freeze_gc():
+    """Call once after the model, the optimizer state and the first (warm-up) steps exist.
+    A step creates thousands of short-lived Python objects; every ~70 000 of them CPython runs
+    a full (generation-2) collection that walks every tracked object of the process -- model,
+    optimizer state, module dicts -- and costs several milliseconds of pure host time: 6 ms
+    per Back-to-Reality step (26.3 -> 20.2 ms/step, tools/br_times.py).  `gc.freeze()` moves
+    everything alive now into the permanent generation, so later collections only look at
+    what the steps themselves allocate."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None):
     """One optimisation step on `batch` (dict of tensors already on the model's device).
     Returns (loss tensor, end_points).  No host synchronisation inside (the reference's

@@ -118,6 +118,7 @@ def main():
     for _ in range(args.warmup):
         train_step(ddp, opt, batch, cfg)
     barrier()
+    train.freeze_gc()  # host runtime hygiene (see train.freeze_gc); no effect on the GPU work
     # Timed region: HIP event pairs only around the two kernels the metric names (the
     # large-scene FPS = dominant hand-written kernel, and the SA1 ball query): 2 pairs/step.
     _ext.timing_begin(lambda op, key: op in ("furthest_point_sampling", "ball_query")

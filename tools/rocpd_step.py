@@ -3,7 +3,7 @@
 two consecutive launches of a marker kernel (default: the large-scene FPS kernel, once per
 step) -- the one with the MEDIAN wall time among the windows shorter than 1.5x the shortest
 (warm-up and bench.py's fully instrumented detail steps are longer).
-Usage: rocpd_step.py results.db [marker-substring] [out.md]"""
+Usage: rocpd_step.py results.db [marker-substring] [out.md] [markers-per-step]"""
 import sqlite3
 import sys
 
@@ -16,6 +16,8 @@ def main():
     name_col = "name" if "name" in cols else "kernel_name"
     rows = c.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
     marks = [s for (n, s, e) in rows if marker in n]
+    per_step = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    marks = marks[::per_step]
     if len(marks) < 2:
         raise SystemExit("marker %r seen %d times" % (marker, len(marks)))
     wins = sorted((b - a, a, b) for a, b in zip(marks[:-1], marks[1:]))
