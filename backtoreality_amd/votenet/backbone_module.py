@@ -9,7 +9,8 @@ import torch
 import torch.nn as nn
 
 from ..pointnet2 import pointnet2_utils
-from ..pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+from ..pointnet2.pointnet2_modules import (PointnetFPModule, PointnetSAModuleCenters,
+                                           PointnetSAModuleVotes)
 
 # (npoint, radius, nsample, mlp-after-input) per SA layer -- backbone_module.py:35-69
 SA_SPECS = (
@@ -21,7 +22,12 @@ SA_SPECS = (
 
 
 class Pointnet2Backbone(nn.Module):
-    def __init__(self, input_feature_dim=0, fp2_out=256):
+    """center_refine=True is the reference's `Pointnet2Backbone_jitter`
+    (backbone_module.py:136-262): an extra set-abstraction head `ctjt_head` pooled around GIVEN
+    centres (the noisy GT box centres) whose output, concatenated with the one-hot class of
+    each centre, feeds the centre-jitter regressor of the CenterRefine recipe."""
+
+    def __init__(self, input_feature_dim=0, fp2_out=256, center_refine=False, num_class=22):
         super().__init__()
         cin = input_feature_dim
         for i, (npoint, radius, nsample, widths) in enumerate(SA_SPECS, start=1):
@@ -31,6 +37,11 @@ class Pointnet2Backbone(nn.Module):
             cin = widths[-1]
         self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
         self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, fp2_out])
+        self.num_class = num_class
+        if center_refine:  # backbone_module.py:188-195
+            self.ctjt_head = PointnetSAModuleCenters(npoint=64, radius=0.8, nsample=16,
+                                                     mlp=[256, 128], use_xyz=True,
+                                                     normalize_xyz=False)
 
     @staticmethod
     def _break_up_pc(pc):
@@ -99,10 +110,13 @@ class Pointnet2Backbone(nn.Module):
                 out.append((inds, ev))
         return out
 
-    def forward(self, pointcloud: torch.Tensor, end_points=None, sampling=None):
+    def forward(self, pointcloud: torch.Tensor, end_points=None, sampling=None, center_xyz=None,
+                center_cls=None):
         """pointcloud (B, N, 3 + input_feature_dim) -> end_points with sa{1..4}_{xyz,features},
         sa1_inds, sa2_inds, fp2_{xyz,features,inds} (backbone_module.py:83-133).
-        `sampling`: optional handle from prefetch_sampling(pointcloud)."""
+        `sampling`: optional handle from prefetch_sampling(pointcloud).
+        center_xyz (B,64,3) / center_cls (B,64) i64 (center_refine backbones only): adds
+        'center_features' (B, 128 + num_class, 64) (backbone_module.py:257-260)."""
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
         pyramid = sampling if sampling is not None else self._fps_pyramid(xyz)
@@ -126,4 +140,10 @@ class Pointnet2Backbone(nn.Module):
         # FPS over an FPS-ordered prefix returns 0..k-1, so the seeds' indices into the input
         # cloud are the first num_seed entries of sa1_inds (backbone_module.py:113-132)
         end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:num_seed]
+        if center_xyz is not None:
+            center_features = self.ctjt_head(end_points["sa2_xyz"], features,
+                                             center_xyz.contiguous())
+            onehot = torch.nn.functional.one_hot(center_cls, self.num_class)
+            end_points["center_features"] = torch.cat(
+                [center_features, onehot.transpose(1, 2).to(center_features.dtype)], dim=1)
         return end_points

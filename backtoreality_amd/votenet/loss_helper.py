@@ -351,3 +351,30 @@ def _get_loss_DA_fused(end_points_S, end_points_T, config, fused_loss):
     loss = loss_S + loss_T + DA_loss * 10
     end_points_S['loss'] = loss
     return loss, end_points_S, end_points_T
+
+
+def compute_jitter_loss(end_points):
+    """Mean squared error between the displacement applied to the GT centres and the
+    regressed one (loss_helper.py:667-672)."""
+    return ((end_points['center_jitter'] -
+             end_points['jitter_pred'].transpose(1, 2).contiguous()) ** 2).mean()
+
+
+def get_loss_DA_jitter(end_points_S, end_points_T, epoch, config):
+    """CenterRefine loss (loss_helper.py:675-803): the GT centres are first moved back by the
+    known (source) / predicted (target, detached) displacement, ramped in over 60 epochs; then
+    get_loss_DA plus 0.1 x the source jitter-regression loss.  (The reference edits the batch
+    tensors in place; here the corrected centres replace the end_points entries instead.)"""
+    if epoch > -1:
+        ramp = min(epoch / 60.0, 1.0)
+        end_points_S['center_label'] = (end_points_S['center_label'] -
+                                        ramp * end_points_S['center_jitter'])
+        corr_T = end_points_T['jitter_pred'].transpose(1, 2) * \
+            end_points_T['box_label_mask'].unsqueeze(-1)
+        end_points_T['center_label'] = (end_points_T['center_label'] - ramp * corr_T).detach()
+    jitter_loss_S = compute_jitter_loss(end_points_S)
+    end_points_S['jitter_loss'] = jitter_loss_S
+    loss, end_points_S, end_points_T = get_loss_DA(end_points_S, end_points_T, config)
+    loss = loss + jitter_loss_S * (0.1 * 10)
+    end_points_S['loss'] = loss
+    return loss, end_points_S, end_points_T

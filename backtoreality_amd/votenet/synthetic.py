@@ -32,8 +32,11 @@ def _points_on_box_faces(rng, n, center, size):
 
 
 def make_scene(index, num_points=40000, config=None, use_height=True, kind="surface",
-               extent_scale=1.0):
-    """One scene as a dict of numpy arrays (same keys/dtypes as the reference loader)."""
+               extent_scale=1.0, center_jitter=0.0):
+    """One scene as a dict of numpy arrays (same keys/dtypes as the reference loader).
+    center_jitter > 0 (CenterRefine recipe, scannet_detection_dataset.py:78-86,190-200): the
+    GT centres are displaced by size * U(-jitter/2, jitter/2) and the displacement is returned
+    as 'center_jitter' (drawn from its own generator: every other field is unchanged)."""
     config = config or DatasetConfig(22, 1, 22)
     rng = np.random.default_rng(1000 + int(index))
     ext = np.array([rng.uniform(4, 8), rng.uniform(4, 8), rng.uniform(2.4, 3.0)])
@@ -112,14 +115,20 @@ def make_scene(index, num_points=40000, config=None, use_height=True, kind="surf
         ret['heading_class_label'][:nbox] = rng.integers(0, config.num_heading_bin, nbox)
         ret['heading_residual_label'][:nbox] = rng.uniform(
             -0.5, 0.5, nbox) * (2 * np.pi / config.num_heading_bin)
+    if center_jitter:
+        delta = (np.random.default_rng(5000 + int(index)).random((K, 3)) - 0.5) * center_jitter
+        size_gts = np.zeros((K, 3))
+        size_gts[:nbox] = sizes
+        ret['center_jitter'] = (size_gts * delta).astype(np.float32)
+        ret['center_label'] = (ret['center_label'] + ret['center_jitter']).astype(np.float32)
     return ret
 
 
 def make_batch(first_index, batch_size, num_points=40000, config=None, use_height=True,
-               kind="surface", extent_scale=1.0, device=None):
+               kind="surface", extent_scale=1.0, device=None, center_jitter=0.0):
     """Stack `batch_size` consecutive scenes into a dict of torch tensors on `device`."""
-    scenes = [make_scene(first_index + i, num_points, config, use_height, kind, extent_scale)
-              for i in range(batch_size)]
+    scenes = [make_scene(first_index + i, num_points, config, use_height, kind, extent_scale,
+                         center_jitter) for i in range(batch_size)]
     batch = {k: torch.from_numpy(np.stack([s[k] for s in scenes], 0)) for k in scenes[0]}
     if device is not None:
         batch = {k: v.to(device) for k, v in batch.items()}

@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 from . import loss_helper
 from .votenet import VoteNet
-from .votenet_da import VoteNet_DA
+from .votenet_da import VoteNet_DA, VoteNet_DA_jitter
 
 
 def init_distributed(backend=None):
@@ -36,11 +36,11 @@ def init_distributed(backend=None):
 
 
 def build_model(cfg, device, input_feature_dim=1, num_proposal=256, vote_factor=1,
-                sampling='vote_fps', seed=0, domain_adaptation=False):
-    """Random-init VoteNet (or VoteNet_DA) (weights from torch.manual_seed(seed), modules
-    constructed in the reference's order) on `device`."""
+                sampling='vote_fps', seed=0, domain_adaptation=False, center_refine=False):
+    """Random-init VoteNet (or VoteNet_DA / VoteNet_DA_jitter) (weights from
+    torch.manual_seed(seed), modules constructed in the reference's order) on `device`."""
     torch.manual_seed(seed)
-    cls = VoteNet_DA if domain_adaptation else VoteNet
+    cls = VoteNet_DA_jitter if center_refine else (VoteNet_DA if domain_adaptation else VoteNet)
     net = cls(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster, cfg.mean_size_arr,
                   input_feature_dim=input_feature_dim, num_proposal=num_proposal,
                   vote_factor=vote_factor, sampling=sampling)
@@ -51,8 +51,12 @@ def wrap_ddp(net, device):
     """DistributedDataParallel when a process group is up, else the bare module."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         ids = [device.index] if device.type == "cuda" else None
+        # the CenterRefine model's jitter_netD has no loss term (commented out in the
+        # reference, loss_helper.py:776,787), so its parameters never receive a gradient
+        unused = bool(getattr(net, "center_refine", False))
         return torch.nn.parallel.DistributedDataParallel(net, device_ids=ids,
-                                                         broadcast_buffers=False)
+                                                         broadcast_buffers=False,
+                                                         find_unused_parameters=unused)
     return net
 
 
@@ -122,6 +126,29 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg):
     for key in batch_T:
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = loss_helper.get_loss_DA(end_points_S, end_points_T, cfg)
+    loss.backward()
+    optimizer.step()
+    return loss, end_points_S, end_points_T
+
+
+def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0):
+    """One CenterRefine step (detection/Votenet/train_Votenet_BR_CenterRefine.py:254-276): like
+    train_step_br, but both forwards also pool features around the (noisy) GT centres and
+    regress their displacement; batches need 'center_jitter' (synthetic.make_batch(...,
+    center_jitter=0.1))."""
+    optimizer.zero_grad(set_to_none=True)
+    core = net.module if hasattr(net, "module") else net
+    sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
+    end_points_S = net({'point_clouds': batch_S['point_clouds']}, batch_S['center_label'],
+                       batch_S['sem_cls_label'])
+    end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T},
+                       batch_T['center_label'], batch_T['sem_cls_label'])
+    for key in batch_S:
+        end_points_S[key] = batch_S[key]
+    for key in batch_T:
+        end_points_T[key] = batch_T[key]
+    loss, end_points_S, end_points_T = loss_helper.get_loss_DA_jitter(
+        end_points_S, end_points_T, epoch, cfg)
     loss.backward()
     optimizer.step()
     return loss, end_points_S, end_points_T

@@ -32,6 +32,8 @@ def _conv_bn_relu(cin, cout):
 
 
 class VoteNet_DA(nn.Module):
+    center_refine = False  # VoteNet_DA_jitter: backbone with the centre head
+
     def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr,
                  input_feature_dim=0, num_proposal=128, vote_factor=1, sampling='vote_fps'):
         super().__init__()
@@ -45,7 +47,9 @@ class VoteNet_DA(nn.Module):
         self.vote_factor = vote_factor
         self.sampling = sampling
 
-        self.backbone_net = Pointnet2Backbone(input_feature_dim=self.input_feature_dim)
+        self.backbone_net = Pointnet2Backbone(input_feature_dim=self.input_feature_dim,
+                                              center_refine=self.center_refine,
+                                              num_class=num_class)
         self.vgen = VotingModule(self.vote_factor, 256)
         self.pnet = ProposalModule(num_class, num_heading_bin, num_size_cluster, mean_size_arr,
                                    num_proposal, sampling)
@@ -55,9 +59,11 @@ class VoteNet_DA(nn.Module):
         self.local_netD = nn.Sequential(*(_conv_bn_relu(128, 128) + _conv_bn_relu(128, 128) +
                                           [nn.Conv1d(128, 1, 1)]))
 
-    def forward(self, inputs):
+    def forward(self, inputs, center_xyz=None, center_cls=None):
         end_points = self.backbone_net(inputs['point_clouds'], {},
-                                       sampling=inputs.get('sampling'))
+                                       sampling=inputs.get('sampling'),
+                                       center_xyz=center_xyz, center_cls=center_cls)
+        self._center_heads(end_points, center_xyz, before_voting=True)
         xyz = end_points['fp2_xyz']
         features = end_points['fp2_features']
         end_points['seed_inds'] = end_points['fp2_inds']
@@ -74,4 +80,33 @@ class VoteNet_DA(nn.Module):
         end_points['global_d_pred'] = self.global_netD2(torch.mean(g, dim=2))  # (B,2)
         local = self.local_netD(grad_reverse(end_points['aggregated_vote_features']))
         end_points['local_d_pred'] = torch.sigmoid(local)  # (B,1,num_proposal)
+        self._center_heads(end_points, center_xyz, before_voting=False)
         return end_points
+
+    def _center_heads(self, end_points, center_xyz, before_voting):
+        pass
+
+
+class VoteNet_DA_jitter(VoteNet_DA):
+    """CenterRefine network (votenet_DA.py:179-333, train_Votenet_BR_CenterRefine.py:189):
+    VoteNet_DA over the centre-head backbone plus `jitter_net` (regresses the displacement of
+    each noisy GT centre from its pooled features + class one-hot) and `jitter_netD` (domain
+    classifier on the same features behind the gradient-reversal layer).  Sub-module names and
+    creation order match the reference."""
+    center_refine = True
+
+    def __init__(self, num_class, *args, **kwargs):
+        super().__init__(num_class, *args, **kwargs)
+        cf = 128 + num_class
+        self.jitter_netD = nn.Sequential(*(_conv_bn_relu(cf, 128) + _conv_bn_relu(128, 128) +
+                                           [nn.Conv1d(128, 1, 1)]))
+        self.jitter_net = nn.Sequential(*(_conv_bn_relu(cf, 64) + [nn.Conv1d(64, 3, 1)]))
+
+    def _center_heads(self, end_points, center_xyz, before_voting):
+        if center_xyz is None:
+            return
+        if before_voting:  # votenet_DA.py:291-292
+            end_points['jitter_pred'] = self.jitter_net(end_points['center_features'])  # B,3,64
+        else:              # :324-327
+            d = self.jitter_netD(grad_reverse(end_points['center_features']))
+            end_points['jitter_d_pred'] = torch.sigmoid(d)  # B,1,64

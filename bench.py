@@ -36,9 +36,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pipelined", action="store_true",
                    help="skip the secondary (informational) software-pipelined loop")
-    p.add_argument("--workload", choices=["fsb", "br"], default="fsb",
+    p.add_argument("--workload", choices=["fsb", "br", "cr"], default="fsb",
                    help="fsb: VoteNet FSB step (BASELINE configs[1], the headline); br: the "
-                        "two-branch Back-to-Reality step (configs[2]), 2 x batch scenes per step")
+                        "two-branch Back-to-Reality step (configs[2]), 2 x batch scenes per step; "
+                        "cr: br + the CenterRefine centre head / jitter regressor")
     p.add_argument("--cpu-points", type=int, default=40000)
     return p.parse_args()
 
@@ -97,15 +98,23 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = config.scannet_md40()
-    br = args.workload == "br"
-    net = train.build_model(cfg, dev, domain_adaptation=br)
+    br = args.workload in ("br", "cr")
+    cr = args.workload == "cr"
+    net = train.build_model(cfg, dev, domain_adaptation=br, center_refine=cr)
     ddp = train.wrap_ddp(net, dev)
     opt = train.make_optimizer(net)
     B = args.batch
-    batch = synthetic.make_batch(rank * B, B, args.points, cfg, device=dev)  # resident in HBM
+    jit = 0.1 if cr else 0.0
+    batch = synthetic.make_batch(rank * B, B, args.points, cfg, device=dev,
+                                 center_jitter=jit)  # resident in HBM
     if br:  # source + target branch: two forwards, one backward (train_Votenet_BR.py:267-289)
-        batch_T = synthetic.make_batch(100000 + rank * B, B, args.points, cfg, device=dev)
-        train_step = lambda n, o, b, c: train.train_step_br(n, o, b, batch_T, c)[:2]  # noqa: E731
+        batch_T = synthetic.make_batch(100000 + rank * B, B, args.points, cfg, device=dev,
+                                       center_jitter=jit)
+        if cr:
+            train_step = lambda n, o, b, c: train.train_step_br_jitter(  # noqa: E731
+                n, o, b, batch_T, c, epoch=30)[:2]
+        else:
+            train_step = lambda n, o, b, c: train.train_step_br(n, o, b, batch_T, c)[:2]  # noqa: E731
     else:
         train_step = train.train_step
 
@@ -170,8 +179,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("VoteNet BR (VoteNet_DA, source+target forward, get_loss_DA, "
-                                    "one backward, Adam), 2 x %d scenes of %d points per GPU"
+            "config": {"workload": (("VoteNet BR CenterRefine (VoteNet_DA_jitter, " if cr else
+                                     "VoteNet BR (VoteNet_DA, ") +
+                                    "source+target forward, get_loss_DA%s, one backward, Adam), "
+                                    "2 x %%d scenes of %%d points per GPU" % ("_jitter" if cr
+                                                                              else "")
                                     if br else
                                     "VoteNet FSB train step (fwd+loss+bwd+Adam), %d points, "
                                     "batch %d per GPU, scannet-md40 heads") %
