@@ -152,3 +152,27 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0):
     loss.backward()
     optimizer.step()
     return loss, end_points_S, end_points_T
+
+
+# ------------------------------------------------------------------ checkpoints
+def save_checkpoint(path, net, optimizer, epoch, loss=None):
+    """`checkpoint.tar` in the reference's wire format (train_Votenet_FSB.py:310-318): keys
+    'epoch' (the NEXT epoch to run), 'optimizer_state_dict', 'loss', 'model_state_dict' (of the
+    bare module when wrapped in DataParallel / DistributedDataParallel)."""
+    core = net.module if hasattr(net, "module") else net
+    torch.save({'epoch': int(epoch) + 1,
+                'optimizer_state_dict': optimizer.state_dict(),
+                'loss': loss,
+                'model_state_dict': core.state_dict()}, path)
+
+
+def load_checkpoint(path, net, optimizer=None, map_location="cpu"):
+    """Counterpart of train_Votenet_FSB.py:174-181; accepts checkpoints written by the
+    reference (same parameter / buffer names, see the golden state signatures).  Returns the
+    epoch to resume from."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    core = net.module if hasattr(net, "module") else net
+    core.load_state_dict(ckpt['model_state_dict'])
+    if optimizer is not None and ckpt.get('optimizer_state_dict') is not None:
+        optimizer.load_state_dict(ckpt['optimizer_state_dict'])
+    return int(ckpt.get('epoch', 0))

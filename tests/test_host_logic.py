@@ -152,3 +152,30 @@ def test_drop_in_top_level_imports_like_reference_scripts():
         "print('ok')\n" % os.path.join(ROOT, "backtoreality_amd", "pointnet2"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_checkpoint_round_trip_in_the_reference_format(tmp_path, oracle_ext):
+    """checkpoint.tar keys as written by train_Votenet_FSB.py:310-318; a resumed model takes
+    the same next step as the original."""
+    import torch
+    from backtoreality_amd.votenet import config, synthetic, train
+    cfg = config.scannet_md40()
+    batch = synthetic.make_batch(0, 1, 1024, cfg)
+    net = train.build_model(cfg, torch.device("cpu"), seed=0)
+    opt = train.make_optimizer(net)
+    train.train_step(net, opt, batch, cfg)
+    path = str(tmp_path / "checkpoint.tar")
+    train.save_checkpoint(path, net, opt, epoch=4, loss=1.5)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(raw) == {'epoch', 'optimizer_state_dict', 'loss', 'model_state_dict'}
+    assert raw['epoch'] == 5 and raw['loss'] == 1.5
+    assert list(raw['model_state_dict']) == list(net.state_dict())
+
+    net2 = train.build_model(cfg, torch.device("cpu"), seed=123)   # different init
+    opt2 = train.make_optimizer(net2)
+    assert train.load_checkpoint(path, net2, opt2) == 5
+    l1, _ = train.train_step(net, opt, batch, cfg)
+    l2, _ = train.train_step(net2, opt2, batch, cfg)
+    assert float(l1) == float(l2)
+    for (n, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), n
