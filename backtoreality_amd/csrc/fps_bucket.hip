@@ -1,11 +1,11 @@
 // fps_bucket.hip -- furthest point sampling for large scenes (n > 4096) on gfx950:
-// Morton-bucketed points + exact bounding-box pruning, one workgroup (one CU) per scene.
+// Hilbert-curve buckets + exact bounding-box pruning, one workgroup (one CU) per scene.
 //
 // Why: FPS is a chain of m-1 dependent arg-max steps; a 40 000-point scene does not fit one
 // CU's registers (640 KB of x,y,z,min-dist), and a cross-CU exchange costs >= 1 us per step
 // (MI355X_MICROARCH.md price list), so the per-step work is cut instead:
-//   * fps_sort_kernel   counting-sorts the scene by a 15-bit Morton cell (32^3 grid, LDS
-//     histogram) into buckets of 64 consecutive points = one wave-wide load each;
+//   * fps_sortm_*_kernel counting-sort the scene by a 15-bit Hilbert cell (32^3 grid) into
+//     buckets of 64 consecutive points = one wave-wide load each;
 //   * fps_bucket_kernel keeps, per bucket, its bounding box and its current best key
 //     (max min-dist, tie key, coordinates) lane-parallel in VGPRs.  A new sample s only
 //     touches buckets whose box lower bound d_box(s) is below the bucket's max min-dist.
@@ -26,22 +26,60 @@
 namespace btr {
 
 constexpr int kSortThreads = 1024;
-constexpr int kCells = 32768;  // 32^3 Morton cells
+constexpr int kGridBits = 5;                 // 32^3 cells (64^3 was measured: 9.4 vs 9.6 touched
+constexpr int kCells = 1 << (3 * kGridBits);  // buckets per sample, but +0.3 ms of sort)
 
-__device__ __forceinline__ unsigned spread5(unsigned v) {  // 5 bits -> every third bit
-  v &= 31u;
-  v = (v | (v << 8)) & 0x100Fu;
-  v = (v | (v << 4)) & 0x10C3u;
-  v = (v | (v << 2)) & 0x1249u;
+__device__ __forceinline__ unsigned spread3(unsigned v) {  // <= 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
   return v;
+}
+
+// Cell index of a point on a (2^bits)^3 grid along a space-filling curve.  Hilbert order
+// (Skilling's transpose algorithm) instead of Morton order: consecutive cells are always face
+// neighbours, so a bucket (64 consecutive points) never straddles one of the Z curve's jumps
+// and its bounding box is tighter -- 9.6 instead of 13.1 buckets pass the box test per sample
+// (2.63 -> 2.25 ms on 8 x 40000 -> 2048).  The order only affects speed, never the result (see
+// the header).  BTR_FPS_CURVE=morton: Z order.
+__device__ bool g_fps_morton = false;
+
+__device__ __forceinline__ int hilbert3(unsigned x0, unsigned x1, unsigned x2, int bits) {
+  unsigned X[3] = {x0, x1, x2};
+  const unsigned M = 1u << (bits - 1);
+  for (unsigned Q = M; Q > 1u; Q >>= 1) {  // inverse undo excess work
+    const unsigned P = Q - 1u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const unsigned t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];  // Gray encode
+  X[2] ^= X[1];
+  unsigned t = 0;
+  for (unsigned Q = M; Q > 1u; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1u;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  // transposed index: bit k of X[i] is bit 3k + (2 - i) of the Hilbert index
+  return (int)((spread3(X[0]) << 2) | (spread3(X[1]) << 1) | spread3(X[2]));
 }
 
 __device__ __forceinline__ int morton_cell(float x, float y, float z, float mnx, float mny,
                                            float mnz, float scale) {
-  const int qx = min(31, max(0, (int)((x - mnx) * scale)));
-  const int qy = min(31, max(0, (int)((y - mny) * scale)));
-  const int qz = min(31, max(0, (int)((z - mnz) * scale)));
-  return (int)(spread5(qx) | (spread5(qy) << 1) | (spread5(qz) << 2));
+  constexpr int bits = kGridBits, top = (1 << bits) - 1;  // scale = 2^bits / extent
+  const int qx = min(top, max(0, (int)((x - mnx) * scale)));
+  const int qy = min(top, max(0, (int)((y - mny) * scale)));
+  const int qz = min(top, max(0, (int)((z - mnz) * scale)));
+  if (g_fps_morton) return (int)(spread3(qx) | (spread3(qy) << 1) | (spread3(qz) << 2));
+  return hilbert3((unsigned)qx, (unsigned)qy, (unsigned)qz, bits);
 }
 
 // Bucket storage: structure of arrays per bucket of 64 points -- x[64] y[64] z[64] k[64] (k =
@@ -56,127 +94,14 @@ __device__ __forceinline__ float4 soa_point(const float *sp, size_t pos) {
                      sp[soa_at(pos, 3)]);
 }
 
-// One workgroup per scene.  Output: spts = the bucket-SoA points {x, y, z, bits(original index)}
-// (read-only from here on; index -1 for padding) and tmin[np] = 1e10 (competing) or -1 (skipped by the
-// |p|^2 <= 1e-3 rule, or padding), np = 64 * ceil(n / 64), both in Morton-cell order.
+// The counting sort: output spts = the bucket-SoA points {x, y, z, bits(original index)}
+// (read-only from here on; index -1 for padding) and tmin[np] = 1e10 (competing) or -1
+// (skipped by the |p|^2 <= 1e-3 rule, or padding), np = 64 * ceil(n / 64), both in curve order.
 // The min-dists live in their OWN array: the per-bucket write-back is then 2 full 128-B lines
 // instead of 64 dwords strewn over 8 lines -- with 16 waves doing it the strided form costs
 // ~1050 cycles per dependent bucket load, the contiguous one ~490 (tools/probe/lat_probe.hip).
-__global__ __launch_bounds__(kSortThreads) void fps_sort_kernel(
-    int n, int np, const float *__restrict__ dataset, float4 *__restrict__ spts,
-    float *__restrict__ tmin) {
-  extern __shared__ __attribute__((aligned(16))) int smem[];
-  int *hist = smem;                       // kCells
-  float *red = (float *)(smem + kCells);  // 6 * 16 floats
-  int *wsum = smem + kCells + 96;         // 16 ints
-
-  const int bi = blockIdx.x;
-  dataset += (size_t)bi * n * 3;
-  spts += (size_t)bi * np;
-  tmin += (size_t)bi * np;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  // 1. scene bounding box
-  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int k = tid; k < n; k += kSortThreads) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float v = dataset[k * 3 + a];
-      mn[a] = fminf(mn[a], v);
-      mx[a] = fmaxf(mx[a], v);
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
-      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
-    }
-    if (lane == 0) {
-      red[a * 16 + wave] = mn[a];
-      red[(3 + a) * 16 + wave] = mx[a];
-    }
-  }
-  for (int c = tid; c < kCells; c += kSortThreads) hist[c] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float lo = red[a * 16], hi = red[(3 + a) * 16];
-    for (int w = 1; w < 16; ++w) {
-      lo = fminf(lo, red[a * 16 + w]);
-      hi = fmaxf(hi, red[(3 + a) * 16 + w]);
-    }
-    mn[a] = lo;
-    mx[a] = hi;
-  }
-  const float ext = fmaxf(fmaxf(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
-  const float scale = ext > 0.f ? 32.f / ext : 0.f;
-
-  // 2. histogram over Morton cells (LDS atomics)
-  for (int k = tid; k < n; k += kSortThreads) {
-    const int c = morton_cell(dataset[k * 3], dataset[k * 3 + 1], dataset[k * 3 + 2], mn[0],
-                              mn[1], mn[2], scale);
-    atomicAdd(&hist[c], 1);
-  }
-  __syncthreads();
-
-  // 3. exclusive scan: 32 consecutive cells per thread, then a block scan of the partials
-  constexpr int PER = kCells / kSortThreads;
-  int local[PER];
-  int sum = 0;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    local[i] = hist[tid * PER + i];
-    sum += local[i];
-  }
-  int incl = sum;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off);
-    if (lane >= off) incl += v;
-  }
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  int run = base + incl - sum;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    hist[tid * PER + i] = run;
-    run += local[i];
-  }
-  __syncthreads();
-
-  // 4. scatter (order inside a cell is arbitrary: it cannot change the result)
-  for (int k = tid; k < n; k += kSortThreads) {
-    const float x = dataset[k * 3], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
-    const int c = morton_cell(x, y, z, mn[0], mn[1], mn[2], scale);
-    const int pos = atomicAdd(&hist[c], 1);
-    const float mag = (x * x) + (y * y) + (z * z);
-    const float t0 = ((double)mag <= 1e-3) ? -1.f : 1e10f;  // sampling_gpu.cu:105-106
-    float *sp = (float *)spts;
-    sp[soa_at(pos, 0)] = x;
-    sp[soa_at(pos, 1)] = y;
-    sp[soa_at(pos, 2)] = z;
-    sp[soa_at(pos, 3)] = __int_as_float(k);
-    tmin[pos] = t0;
-  }
-  __syncthreads();
-  // 5. pad the last bucket with non-competing copies of the last sorted point
-  if (n + tid < np) {
-    float *sp = (float *)spts;
-    sp[soa_at(n + tid, 0)] = sp[soa_at(n - 1, 0)];
-    sp[soa_at(n + tid, 1)] = sp[soa_at(n - 1, 1)];
-    sp[soa_at(n + tid, 2)] = sp[soa_at(n - 1, 2)];
-    sp[soa_at(n + tid, 3)] = __int_as_float(-1);
-    tmin[n + tid] = -1.f;
-  }
-}
-
-// ---- the same counting sort with MANY workgroups per scene (the one-workgroup version
-// streams the scene three times through a single CU: 157 us on 8 x 40000, all of it on the
-// step's critical path).  meta[b] = 6 order-preserving uint keys (max of ~key(min), max of
+// MANY workgroups per scene (a one-workgroup version streamed the scene three times through
+// a single CU: 157 us on 8 x 40000, all of it on the step's critical path).  meta[b] = 6 order-preserving uint keys (max of ~key(min), max of
 // key(max)) accumulated with integer atomics; cells[b][32768] = histogram -> exclusive scan
 // -> scatter cursor.  The order inside a cell depends on the atomics and cannot change the
 // FPS result (see the header).
@@ -195,7 +120,7 @@ __device__ __forceinline__ SortBox sort_box(const unsigned *__restrict__ meta) {
   const float mnx = key_f32(~meta[0]), mny = key_f32(~meta[1]), mnz = key_f32(~meta[2]);
   const float mxx = key_f32(meta[3]), mxy = key_f32(meta[4]), mxz = key_f32(meta[5]);
   const float ext = fmaxf(fmaxf(mxx - mnx, mxy - mny), mxz - mnz);
-  return SortBox{mnx, mny, mnz, ext > 0.f ? 32.f / ext : 0.f};
+  return SortBox{mnx, mny, mnz, ext > 0.f ? (float)(1 << kGridBits) / ext : 0.f};
 }
 
 __global__ __launch_bounds__(256) void fps_sortm_bbox_kernel(int n,
@@ -353,7 +278,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
                                                              int *__restrict__ idxs,
                                                              unsigned long long *dbg = nullptr) {
   // PROF: s_memtime phase counters (tuning builds only; BTR_FPS_PROF=1 in tools/)
-  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, nact = 0;
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, nact = 0, nuse = 0, nchg = 0;
 #define BTR_PH(i)                                                  \
   if (PROF) {                                                      \
     const unsigned long long now = __builtin_amdgcn_s_memtime();   \
@@ -468,6 +393,11 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
         const bool valid = t0 >= 0.f;
         const float t = valid ? fminf(d, t0) : t0;
         if (t != t0) tmin[co] = t;
+        if (PROF) {
+          const unsigned long long ch = __ballot(t != t0);
+          nuse += ch ? 1 : 0;
+          nchg += __builtin_popcountll(ch);
+        }
         const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
         const unsigned mh = wave_max_u32(hi);
         const unsigned long long cand = __ballot(hi == mh);
@@ -594,6 +524,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
     unsigned long long *o = dbg + ((size_t)bi * NW + wave) * 8;
     for (int i = 0; i < 6; ++i) o[i] = tph[i];
     o[6] = nact;
+    o[7] = (nuse << 32) | (nchg & 0xffffffffull);
   }
 #undef BTR_PH
 }
@@ -869,20 +800,18 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
               p.pts_bytes + p.k_bytes + p.sort_bytes, workspace_bytes);
   float4 *spts = (float4 *)workspace;
   float *sk = (float *)((char *)workspace + p.pts_bytes);  // the min-dist array
-  // BTR_FPS_SORT=single: the one-workgroup-per-scene sort (A/B); default: multi-workgroup
-  static const bool single_sort = getenv("BTR_FPS_SORT") && getenv("BTR_FPS_SORT")[0] == 's';
-  if (single_sort) {
-    const size_t lds = sizeof(int) * (kCells + 96 + 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void *)fps_sort_kernel,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return fail((int)e, "fps_sort attr: %s", hipGetErrorString(e));
-      attr_set = true;
+  {
+    static int curve_set = -1;
+    const char *cv = getenv("BTR_FPS_CURVE");
+    const int want = (cv && cv[0] == 'm') ? 1 : 0;
+    if (curve_set != want) {
+      const bool flag = want == 1;
+      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fps_morton), &flag, sizeof(bool), 0,
+                                   hipMemcpyHostToDevice, s);
+      curve_set = want;
     }
-    hipLaunchKernelGGL(fps_sort_kernel, dim3(b), dim3(kSortThreads), lds, s, n, p.np, dataset,
-                       spts, sk);
-  } else {
+  }
+  {
     int *cells = (int *)((char *)workspace + p.pts_bytes + p.k_bytes);
     unsigned *meta = (unsigned *)(cells + (size_t)b * kCells);
     hipError_t e = hipMemsetAsync(cells, 0, p.sort_bytes, s);
@@ -933,8 +862,11 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
       fprintf(stderr, "[fps prof] scene 0 wave %2d:", w);
       for (int i = 0; i < 5; ++i)
         fprintf(stderr, " %s %.0f", names[i], (double)h[w * 8 + i] / (m - 1));
-      fprintf(stderr, " load-wait %.0f cycles/step; touched buckets/step %.2f\n",
-              (double)h[w * 8 + 5] / (m - 1), (double)h[w * 8 + 6] / (m - 1));
+      fprintf(stderr, " load-wait %.0f cycles/step; touched buckets/step %.2f, of which %.2f "
+              "changed a min-dist (%.1f points per useful trip)\n",
+              (double)h[w * 8 + 5] / (m - 1), (double)h[w * 8 + 6] / (m - 1),
+              (double)(h[w * 8 + 7] >> 32) / (m - 1),
+              (double)(h[w * 8 + 7] & 0xffffffffull) / (double)std::max<unsigned long long>(1, h[w * 8 + 7] >> 32));
     }
     return check_launch("furthest_point_sampling(bucket,prof)");
   }
