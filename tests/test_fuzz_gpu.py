@@ -1,0 +1,75 @@
+"""Seeded random shapes for the index-producing ops against the CPU oracle: sizes that are not
+multiples of 64 / 256, more samples than points, clustered and degenerate clouds (planes,
+duplicates, points at the origin that the FPS skip rule drops), radii from "nothing inside" to
+"everything inside".  Indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _ext():
+    from backtoreality_amd.pointnet2 import _ext
+    return _ext
+
+
+def _cloud(rng, B, N, kind):
+    if kind == "uniform":
+        x = rng.uniform(-2, 2, size=(B, N, 3))
+    elif kind == "plane":            # coplanar: many near-equal distances
+        x = rng.uniform(0, 3, size=(B, N, 3))
+        x[..., 2] = 0.25
+    elif kind == "clusters":
+        c = rng.uniform(-3, 3, size=(B, 6, 3))
+        x = c[:, rng.integers(0, 6, N)] + rng.normal(0, 0.05, size=(B, N, 3))
+    elif kind == "duplicates":       # exact ties everywhere
+        base = rng.uniform(0.1, 2, size=(B, max(1, N // 4), 3))
+        x = base[:, rng.integers(0, base.shape[1], N)]
+    elif kind == "origin":           # a third of the points inside the |p|^2 <= 1e-3 skip ball
+        x = rng.uniform(-1, 1, size=(B, N, 3))
+        x[:, ::3] *= 0.01
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(x.astype(np.float32))
+
+
+KINDS = ("uniform", "plane", "clusters", "duplicates", "origin")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fps_random_shapes(cuda, seed):
+    rng = np.random.default_rng(100 + seed)
+    B = int(rng.integers(1, 4))
+    N = int(rng.choice([1, 2, 63, 64, 65, 257, 1000, 4095, 4097, 6001, 9999]))
+    M = int(rng.choice([1, 2, N, max(1, N // 3), min(2 * N, 700)]))
+    xyz = _cloud(rng, B, N, KINDS[seed % len(KINDS)])
+    ref = oracle.furthest_point_sampling(xyz, M)
+    got = _ext().furthest_point_sampling(torch.from_numpy(xyz).to(cuda), M).cpu().numpy()
+    np.testing.assert_array_equal(got, ref, err_msg="B=%d N=%d M=%d" % (B, N, M))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_ball_query_and_three_nn_random_shapes(cuda, seed):
+    rng = np.random.default_rng(200 + seed)
+    B = int(rng.integers(1, 4))
+    N = int(rng.choice([1, 7, 64, 500, 3000, 8191, 8192, 12001]))
+    M = int(rng.choice([1, 5, 64, 333, 1024]))
+    S = int(rng.choice([1, 3, 16, 64, 100]))
+    kind = KINDS[seed % len(KINDS)]
+    xyz = _cloud(rng, B, N, kind)
+    new_xyz = _cloud(rng, B, M, kind) if seed % 2 else xyz[:, rng.integers(0, N, M)].copy()
+    radius = float(rng.choice([1e-4, 0.05, 0.3, 1.0, 50.0]))
+    ref = oracle.ball_query(new_xyz, xyz, radius, S)
+    got = _ext().ball_query(torch.from_numpy(new_xyz).to(cuda), torch.from_numpy(xyz).to(cuda),
+                            radius, S).cpu().numpy()
+    np.testing.assert_array_equal(got, ref, err_msg="B=%d N=%d M=%d S=%d r=%g" % (B, N, M, S,
+                                                                                   radius))
+    if N >= 3:
+        d_ref, i_ref = oracle.three_nn(new_xyz, xyz)
+        d_got, i_got = _ext().three_nn(torch.from_numpy(new_xyz).to(cuda),
+                                       torch.from_numpy(xyz).to(cuda))
+        np.testing.assert_array_equal(i_got.cpu().numpy(), i_ref)
+        np.testing.assert_array_equal(d_got.cpu().numpy(), d_ref)
