@@ -210,15 +210,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         for (int j = 0; j < NJ; ++j)
           bf[j] = *reinterpret_cast<const float4 *>(
               &Bs[(wn * 64 + j * 32 + l31) * kLd + h * (kBK / 2) + t4]);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-          }
+        // k component outermost: consecutive MFMAs go to DIFFERENT accumulators
+#define BTR_MFMA_STEP(C)                                                                        \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].C, bf[j].C, acc[i][j], 0, 0, 0);
+        BTR_MFMA_STEP(x)
+        BTR_MFMA_STEP(y)
+        BTR_MFMA_STEP(z)
+        BTR_MFMA_STEP(w)
+#undef BTR_MFMA_STEP
       }
       __syncthreads();
     }
