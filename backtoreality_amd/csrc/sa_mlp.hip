@@ -65,6 +65,18 @@ __global__ __launch_bounds__(256) void sa_gather_kernel(
   (void)rows;
 }
 
+// First-layer recompute ("RC"): a set-abstraction layer whose input has <= 4 columns (SA1:
+// xyz + height) does not store its first pre-BN output y0 = X0 . W0^T (rows x 64 floats, 268 MB
+// at the benchmark shape): every consumer rebuilds the 4 values it needs from the 16-byte input
+// row and 4 weight rows.  Same expression everywhere, so the ReLU masks agree.
+__device__ __forceinline__ float rc_dot4(const float4 x, const float4 w) {
+  return fmaf(x.w, w.w, fmaf(x.z, w.z, fmaf(x.y, w.y, x.x * w.x)));
+}
+__device__ __forceinline__ float4 rc_y4(const float4 x, const float *__restrict__ w0, int k) {
+  const float4 *w = reinterpret_cast<const float4 *>(w0) + k;  // W0[k..k+3][0..3]
+  return make_float4(rc_dot4(x, w[0]), rc_dot4(x, w[1]), rc_dot4(x, w[2]), rc_dot4(x, w[3]));
+}
+
 // ------------------------------------------------------------------------ NT GEMM (MFMA f32)
 // C[r][n] = sum_k f(A[r][k]) * W[n][k],  f(y) = PRO ? max(pa[k]*y + pb[k], 0) : y.
 // Workgroup = 4 waves, tile 128 rows x BN columns, K staged BK=32 at a time.  Lanes 0-31 of
@@ -125,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       const int row = srow + 32 * p;
       ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r0 + row < R && kk < K) {
-        ra[p] = *reinterpret_cast<const float4 *>(A + (size_t)(r0 + row) * lda + kk);
+        ra[p] = PRO == 3 ? *reinterpret_cast<const float4 *>(A + (size_t)(r0 + row) * 4)
+                         : *reinterpret_cast<const float4 *>(A + (size_t)(r0 + row) * lda + kk);
       }
     }
     if (PRO == 2) {
@@ -161,6 +174,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         v.y = fmaxf(fmaf(fa.y, v.y, fb.y), 0.f);
         v.z = fmaxf(fmaf(fa.z, v.z, fb.z), 0.f);
         v.w = fmaxf(fmaf(fa.w, v.w, fb.w), 0.f);
+      }
+      if (PRO == 3 && r0 + row < R && kk < K) {  // y0 rebuilt from the 4-column input row
+        const float4 y = rc_y4(v, pdcl, kk);      // (pdcl carries W0 [K][4] in this mode)
+        v.x = fmaxf(fmaf(fa.x, y.x, fb.x), 0.f);
+        v.y = fmaxf(fmaf(fa.y, y.y, fb.y), 0.f);
+        v.z = fmaxf(fmaf(fa.z, y.z, fb.z), 0.f);
+        v.w = fmaxf(fmaf(fa.w, y.w, fb.w), 0.f);
       }
       if (PRO == 2 && r0 + row < R && kk < K) {  // dense part: alpha*y + beta
         v.x = fmaf(fa.x, v.x, fb.x);
@@ -198,9 +218,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         fetch(tile, kc + 1);
       else if (tile + (int)gridDim.x < ntiles)
         fetch(tile + gridDim.x, 0);
-      // ---- 16 MFMA k-steps on the staged chunk
+      // ---- 16 MFMA k-steps on the staged chunk (group t4 holds k = t4..t4+3 in lanes 0-31
+      // and 16+t4.. in lanes 32-63: a chunk with <= t4 valid columns has nothing left -- the
+      // K = 4 first layer runs one group instead of four)
+      const int kleft = K - kc * kBK;
 #pragma unroll
       for (int t4 = 0; t4 < kBK / 2; t4 += 4) {
+        if (t4 >= kleft) break;
         float4 af[MI], bf[NJ];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -232,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         for (int v = 0; v < 16; ++v) {
           const int row = r0 + wm * (kBM / WM) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
           const float c = acc[i][j][v];
-          if (row < R && col < N) C[(size_t)row * ldc + col] = c;
+          if (C != nullptr && row < R && col < N) C[(size_t)row * ldc + col] = c;
           if (STATS) {  // rows >= R hold exact zeros (A staged as 0): no masking needed
             s1[j] += c;
             s2[j] = fmaf(c, c, s2[j]);
@@ -516,6 +540,104 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(
   }
 }
 
+// RC layer 0, statistics: as bn_relu_bwd_stats_kernel with y rebuilt from X0 (ld 4) and W0.
+__global__ __launch_bounds__(256) void bn_relu_bwd_stats_rc_kernel(
+    long long R, int C, int ld, const float *__restrict__ G, const float *__restrict__ X0,
+    const float *__restrict__ W0, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ invstd, float *__restrict__ part) {
+  __shared__ float red[2][256 * 4];
+  const int tpr = C >> 2;
+  const int slots = 256 / tpr;
+  const int slot = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (slot < slots) {
+    const float4 a = *reinterpret_cast<const float4 *>(scale + c4);
+    const float4 b = *reinterpret_cast<const float4 *>(shift + c4);
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c4);
+    const float4 is = *reinterpret_cast<const float4 *>(invstd + c4);
+    for (long long r = (long long)blockIdx.x * slots + slot; r < R;
+         r += (long long)gridDim.x * slots) {
+      const float4 y = rc_y4(*reinterpret_cast<const float4 *>(X0 + (size_t)r * 4), W0, c4);
+      float4 g = *reinterpret_cast<const float4 *>(G + (size_t)r * ld + c4);
+      g.x = fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f;
+      g.y = fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f;
+      g.z = fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f;
+      g.w = fmaf(a.w, y.w, b.w) > 0.f ? g.w : 0.f;
+      s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+      s2.x = fmaf(g.x, (y.x - mu.x) * is.x, s2.x);
+      s2.y = fmaf(g.y, (y.y - mu.y) * is.y, s2.y);
+      s2.z = fmaf(g.z, (y.z - mu.z) * is.z, s2.z);
+      s2.w = fmaf(g.w, (y.w - mu.w) * is.w, s2.w);
+    }
+  }
+  *reinterpret_cast<float4 *>(&red[0][threadIdx.x * 4]) = s1;
+  *reinterpret_cast<float4 *>(&red[1][threadIdx.x * 4]) = s2;
+  __syncthreads();
+  for (int q = threadIdx.x; q < 2 * C; q += 256) {
+    const int which = q / C, c = q - which * C;
+    float acc = 0.f;
+    for (int sl = 0; sl < slots; ++sl) acc += red[which][(sl * tpr + (c >> 2)) * 4 + (c & 3)];
+    part[((size_t)blockIdx.x * 2 + which) * C + c] = acc;
+  }
+}
+
+// RC layer 0, apply + weight gradient in one pass: dY0 = a*(mask*g - m1 - xhat*m2) is formed per
+// row and immediately contracted with the input row, dW0[c][0..3] += dY0[c] * X0[r][0..3]; dY0
+// itself is never written (layer 0 has no other consumer when the inputs need no gradient).
+// pw[blk][C][4] per-block partials, reduced by reduce_chunks_kernel.
+__global__ __launch_bounds__(256) void bn_relu_bwd_wgrad0_rc_kernel(
+    long long R, int C, int ld, const float *__restrict__ G, const float *__restrict__ X0,
+    const float *__restrict__ W0, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ m1,
+    const float *__restrict__ m2, float *__restrict__ pw) {
+  __shared__ float red[256 * 16];
+  const int tpr = C >> 2;
+  const int slots = 256 / tpr;
+  const int slot = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
+  float4 w[4];  // w[i] = partial dW0[c4 + i][0..3]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (slot < slots) {
+    const float4 a = *reinterpret_cast<const float4 *>(scale + c4);
+    const float4 b = *reinterpret_cast<const float4 *>(shift + c4);
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c4);
+    const float4 is = *reinterpret_cast<const float4 *>(invstd + c4);
+    const float4 c1 = *reinterpret_cast<const float4 *>(m1 + c4);
+    const float4 c2 = *reinterpret_cast<const float4 *>(m2 + c4);
+    for (long long r = (long long)blockIdx.x * slots + slot; r < R;
+         r += (long long)gridDim.x * slots) {
+      const float4 x = *reinterpret_cast<const float4 *>(X0 + (size_t)r * 4);
+      const float4 y = rc_y4(x, W0, c4);
+      const float4 g = *reinterpret_cast<const float4 *>(G + (size_t)r * ld + c4);
+      float d[4];
+      d[0] = a.x * ((fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f) - c1.x - (y.x - mu.x) * is.x * c2.x);
+      d[1] = a.y * ((fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f) - c1.y - (y.y - mu.y) * is.y * c2.y);
+      d[2] = a.z * ((fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f) - c1.z - (y.z - mu.z) * is.z * c2.z);
+      d[3] = a.w * ((fmaf(a.w, y.w, b.w) > 0.f ? g.w : 0.f) - c1.w - (y.w - mu.w) * is.w * c2.w);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w[i].x = fmaf(d[i], x.x, w[i].x);
+        w[i].y = fmaf(d[i], x.y, w[i].y);
+        w[i].z = fmaf(d[i], x.z, w[i].z);
+        w[i].w = fmaf(d[i], x.w, w[i].w);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<float4 *>(&red[(threadIdx.x * 4 + i) * 4]) = w[i];
+  __syncthreads();
+  // red[(thread*4 + i)*4 + j]: thread = slot*tpr + c/4, i = c%4 -> sum over slots
+  for (int q = threadIdx.x; q < C * 4; q += 256) {
+    const int c = q >> 2, j = q & 3;
+    float acc = 0.f;
+    for (int sl = 0; sl < slots; ++sl) acc += red[((sl * tpr + (c >> 2)) * 4 + (c & 3)) * 4 + j];
+    pw[(size_t)blockIdx.x * C * 4 + q] = acc;
+  }
+}
+
 // In-place apply, float4 per thread (C % 4 == 0).
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
     long long R, int C, int ld, float *__restrict__ G, const float *__restrict__ Y,
@@ -553,13 +675,16 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
 // reduce_chunks_kernel in a fixed order (deterministic).
 // GPOOL: G is the pooled layer's pre-BN output Y and the gradient operand is formed on the fly
 // exactly as in gemm_nt_kernel's PRO == 2 (galpha/gbeta per n column, garg/gdcl per group).
-template <int TNW, bool PRO, bool GPOOL = false>
+// XRC: the X operand is relu(bn(y0)) with y0 rebuilt from the 4-column input rows (X = X0,
+// xw0 = W0 [K][4]); implies PRO.
+template <int TNW, bool PRO, bool GPOOL = false, bool XRC = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(
     const float *__restrict__ G, int ldg, const float *__restrict__ X, int ldx, int R, int N,
     int K, const float *__restrict__ pa, const float *__restrict__ pb, int rows_per_chunk,
     float *__restrict__ pw, const unsigned char *__restrict__ garg = nullptr,
     const float *__restrict__ gdcl = nullptr, const float *__restrict__ galpha = nullptr,
-    const float *__restrict__ gbeta = nullptr, int SSH = 0) {
+    const float *__restrict__ gbeta = nullptr, int SSH = 0,
+    const float *__restrict__ xw0 = nullptr) {
   constexpr int BR = 32;
   constexpr int TN = 32 * TNW;      // n columns of G staged per step
   constexpr int LG = TN + 4, LX = 68;
@@ -627,7 +752,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
       const int row = xr + 16 * p;
       rx[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r0 + row < rend && k0 + xc4 < K)
-        rx[p] = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + xc4);
+        rx[p] = XRC ? *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * 4)
+                    : *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + xc4);
     }
   };
   if (rbeg < rend) fetch(rbeg);
@@ -647,6 +773,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     for (int p = 0; p < 2; ++p) {
       const int row = xr + 16 * p;
       float4 x = rx[p];
+      if (XRC && r0 + row < rend && k0 + xc4 < K) x = rc_y4(x, xw0, k0 + xc4);
       if (PRO && r0 + row < rend && k0 + xc4 < K) {
         x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
         x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
@@ -880,7 +1007,7 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
                    float *c, int ldc, const float *pa, const float *pb, float *part,
                    btr_stream_t stream) {
   if (rows <= 0 || n <= 0) return BTR_OK;
-  BTR_REQUIRE(a && w && c && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
+  BTR_REQUIRE(a && w && (c || part) && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt: k=%d lda=%d ldw=%d must be multiples of 4", k, lda, ldw);
   BTR_REQUIRE((pa == nullptr) == (pb == nullptr), "sa_gemm_nt: pa/pb must come together");
   const int gx = btr_sa_gemm_grid(rows);
@@ -985,6 +1112,97 @@ int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const f
   return check_launch("sa_gemm_nt_pool");
 }
 
+// Number of row chunks btr_sa_gemm_tn uses; the caller provides pw[chunks][n][k] floats.
+static int tn_tile_n(int n) { return n >= 128 ? 128 : 64; }
+
+int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
+  const int tiles = cdiv(n, tn_tile_n(n)) * cdiv(k, 64);
+  int chunks = std::max(1, std::min(2048 / tiles, 1024));  // ~2048 workgroups in flight
+  chunks = std::min(chunks, std::max(1, rows / 256));
+  return chunks;
+}
+
+// ---- first-layer recompute (input rows of <= 4 columns, x0 with leading dimension 4; w0 is
+// the first layer's weight [k][4]).  See rc_y4.
+// C[rows][n] = relu(pa*(x0.w0^T)+pb) . W^T  (the second layer's forward; k = first layer width)
+int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, const float *w,
+                      int ldw, float *c, int ldc, const float *pa, const float *pb, float *part,
+                      btr_stream_t stream) {
+  if (rows <= 0 || n <= 0) return BTR_OK;
+  BTR_REQUIRE(x0 && w0 && w && c && pa && pb && k > 0 && k % 4 == 0 && ldw % 4 == 0,
+              "sa_gemm_nt_rc: null pointer or k=%d ldw=%d not multiples of 4", k, ldw);
+  const int gx = btr_sa_gemm_grid(rows);
+  hipStream_t st = as_stream(stream);
+#define BTR_NTRC(BN, S)                                                                       \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, 3, S>), dim3(gx, cdiv(n, BN)), dim3(256), 0, st, x0, \
+                     4, w, ldw, c, ldc, rows, n, k, pa, pb, part,                              \
+                     (const unsigned char *)nullptr, w0, 0)
+  if (n <= 64) { if (part) BTR_NTRC(64, true); else BTR_NTRC(64, false); }
+  else         { if (part) BTR_NTRC(128, true); else BTR_NTRC(128, false); }
+#undef BTR_NTRC
+  return check_launch("sa_gemm_nt_rc");
+}
+
+// dW[n][k] = sum_r G[r][n] * relu(pa*(x0.w0^T)+pb)[r][k]  (the second layer's weight gradient)
+int btr_sa_gemm_tn_rc(int rows, int n, int k, const float *g, int ldg, const float *x0,
+                      const float *w0, const float *pa, const float *pb, float *pw, float *dw,
+                      btr_stream_t stream) {
+  if (n <= 0 || k <= 0) return BTR_OK;
+  BTR_REQUIRE(g && x0 && w0 && pa && pb && pw && dw && ldg % 4 == 0 && n % 4 == 0 && k % 4 == 0,
+              "sa_gemm_tn_rc: sizes must be multiples of 4 (n=%d k=%d)", n, k);
+  hipStream_t st = as_stream(stream);
+  const int chunks = btr_sa_gemm_tn_chunks(rows, n, k);
+  const int rpc = cdiv(cdiv(rows, chunks), 32) * 32;
+  const int tn = tn_tile_n(n);
+  const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
+  if (tn == 128)
+    hipLaunchKernelGGL((gemm_tn_kernel<4, true, false, true>), grid, dim3(256), 0, st, g, ldg, x0,
+                       4, rows, n, k, pa, pb, rpc, pw, (const unsigned char *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
+                       w0);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<2, true, false, true>), grid, dim3(256), 0, st, g, ldg, x0,
+                       4, rows, n, k, pa, pb, rpc, pw, (const unsigned char *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
+                       w0);
+  if (n * k <= 1024 && chunks >= 64)
+    hipLaunchKernelGGL((reduce_chunks_kernel<4, 64>), dim3(cdiv(n * k, 4)), dim3(256), 0, st,
+                       n * k, chunks, pw, dw);
+  else
+    hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(n * k, 16)), dim3(256), 0, st,
+                       n * k, chunks, pw, dw);
+  return check_launch("sa_gemm_tn_rc");
+}
+
+// Workgroups (= rows of pw [blocks][c][4]) btr_sa_bn_relu_bwd_rc uses for the weight gradient.
+int btr_sa_rc_wgrad_blocks(long long rows, int c) {
+  return (int)std::max<long long>(1, std::min<long long>(cdiv(rows, 256 / (c / 4)), 512));
+}
+
+// First layer's BN+ReLU backward with y0 recomputed, fused with its weight gradient: g
+// [rows][c] (gradient w.r.t. the post-ReLU activation) is only read; outputs dgamma, dbeta
+// (and m1, m2) and dw0 [c][4] = dY0^T . x0.  part: [512][2][c], pw: [blocks][c][4] floats.
+int btr_sa_bn_relu_bwd_rc(long long rows, int c, int ldg, const float *g, const float *x0,
+                          const float *w0, const float *scale, const float *shift,
+                          const float *mean, const float *invstd, float *part, float *m1,
+                          float *m2, float *dgamma, float *dbeta, float *pw, float *dw0,
+                          btr_stream_t stream) {
+  if (rows <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(c <= kBnBwdMaxC && c % 4 == 0 && ldg % 4 == 0,
+              "sa_bn_relu_bwd_rc: %d channels must be a multiple of 4 and <= %d", c, kBnBwdMaxC);
+  hipStream_t st = as_stream(stream);
+  const int nblk = btr_sa_rc_wgrad_blocks(rows, c);
+  hipLaunchKernelGGL(bn_relu_bwd_stats_rc_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ldg, g,
+                     x0, w0, scale, shift, mean, invstd, part);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c, nblk,
+                     (double)rows, part, m1, m2, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_relu_bwd_wgrad0_rc_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ldg, g,
+                     x0, w0, scale, shift, mean, invstd, m1, m2, pw);
+  hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(c * 4, 16)), dim3(256), 0, st,
+                     c * 4, nblk, pw, dw0);
+  return check_launch("sa_bn_relu_bwd_rc");
+}
+
 // In place: g (gradient w.r.t. the post-ReLU activation of a hidden layer) -> gradient w.r.t.
 // the layer's pre-BN output y; also dgamma/dbeta.  part: [256][2][c] floats.
 int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
@@ -1004,16 +1222,6 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx), dim3(256), 0, st, rows, c, ld, g, y,
                      scale, shift, mean, invstd, m1, m2);
   return check_launch("sa_bn_relu_bwd");
-}
-
-// Number of row chunks btr_sa_gemm_tn uses; the caller provides pw[chunks][n][k] floats.
-static int tn_tile_n(int n) { return n >= 128 ? 128 : 64; }
-
-int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
-  const int tiles = cdiv(n, tn_tile_n(n)) * cdiv(k, 64);
-  int chunks = std::max(1, std::min(2048 / tiles, 1024));  // ~2048 workgroups in flight
-  chunks = std::min(chunks, std::max(1, rows / 256));
-  return chunks;
 }
 
 // dW[n][k] = sum_r G[r][n] * f(X[r][k]).

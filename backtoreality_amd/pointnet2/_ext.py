@@ -59,6 +59,10 @@ _SIGNATURES = {
     "btr_sa_scatter_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
     "btr_sa_scatter": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _cf, _vp, _vp, _vp, _vp, _vp,
                              _vp, _sz, _vp]),
+    "btr_sa_gemm_nt_rc": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp]),
+    "btr_sa_gemm_tn_rc": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "btr_sa_rc_wgrad_blocks": (_ci, [_ll, _ci]),
+    "btr_sa_bn_relu_bwd_rc": (_ci, [_ll, _ci, _ci] + [_vp] * 15),
     "btr_sa_pool_bwd_coef": (_ci, [_ci, _ci, _ci, _ci, _ci] + [_vp] * 16),
     "btr_sa_gemm_nt_pool": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _vp, _vp,
                                   _vp, _vp, _vp]),

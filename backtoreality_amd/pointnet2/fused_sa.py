@@ -70,6 +70,10 @@ class FusedSAFunction(Function):
             Ys, stats, Ws, counters = [], [], [], []
             A, lda, K = X0, K0p, K0p
             pa = pb = None
+            # First-layer recompute (SA1: 4 input columns, nobody needs the input gradient):
+            # the first pre-BN output is never stored; its consumers rebuild it from X0.
+            rc = (K0p == 4 and L >= 3 and not any(ctx.needs_input_grad[0:3]) and
+                  os.environ.get("BTR_SA_RECOMPUTE", "1") != "0")
             for l in range(L):
                 W, gamma, beta = params[3 * l:3 * l + 3]
                 Nl = W.shape[0]
@@ -79,10 +83,19 @@ class FusedSAFunction(Function):
                     Wp[:, :W2.shape[1]] = W2
                     W2 = Wp
                 W2 = W2.contiguous()
-                Y = _f32((R, Nl), dev)
                 part = _f32((grid, 2, Nl), dev)
-                _call(_lib.btr_sa_gemm_nt, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl, _p(pa),
-                      _p(pb), _p(part), st, key=(R, Nl, K))
+                if rc and l == 0:    # statistics only
+                    Y = _f32((0, Nl), dev)
+                    _call(_lib.btr_sa_gemm_nt, R, Nl, K, _p(A), lda, _p(W2), K, None, Nl, None,
+                          None, _p(part), st, key=(R, Nl, K))
+                elif rc and l == 1:  # A = relu(bn(X0 . W0^T)) rebuilt while staging
+                    Y = _f32((R, Nl), dev)
+                    _call(_lib.btr_sa_gemm_nt_rc, R, Nl, K, _p(X0), _p(Ws[0]), _p(W2), K, _p(Y),
+                          Nl, _p(pa), _p(pb), _p(part), st, key=(R, Nl, K))
+                else:
+                    Y = _f32((R, Nl), dev)
+                    _call(_lib.btr_sa_gemm_nt, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl,
+                          _p(pa), _p(pb), _p(part), st, key=(R, Nl, K))
                 scale, shift, mean, invstd = (_f32((Nl,), dev) for _ in range(4))
                 bn = bns[l]
                 if bn.momentum is None:
@@ -112,6 +125,7 @@ class FusedSAFunction(Function):
 
         out._btr_channel_last = out_cl  # lets the next fused layer skip a transpose
         ctx.dims = (B, N, M, S, C, use_xyz, rdiv, K0, K0p, L)
+        ctx.rc = rc
         ctx.pshapes = [p.shape for p in params]
         # save_for_backward (not attributes): saving the OUTPUT through an attribute would
         # create a ctx <-> out reference cycle that only the cyclic GC frees (GBs per step)
@@ -170,11 +184,16 @@ class FusedSAFunction(Function):
                     Xsrc, ldx = Ys[l - 1], Ys[l - 1].shape[1]
                     pa, pb = stats[l - 1][0], stats[l - 1][1]
                 pooled = pool is not None and l == L - 1  # dY is still Y_last + coefficients
+                if ctx.rc and l == 0:
+                    break  # layer 0 was finished by btr_sa_bn_relu_bwd_rc below
                 # weight gradient: dW[n][k] = sum_r dY[r][n] * X_l[r][k]
                 chunks = _lib.btr_sa_gemm_tn_chunks(R, Nl, K)
                 pw = _f32((chunks, Nl, K), dev)
                 dW = _f32((Nl, K), dev)
-                if pooled:
+                if ctx.rc and l == 1:  # X = relu(bn(X0 . W0^T)) rebuilt while staging
+                    _call(_lib.btr_sa_gemm_tn_rc, R, Nl, K, _p(dY), Nl, _p(X0), _p(Ws[0]),
+                          _p(pa), _p(pb), _p(pw), _p(dW), st, key=(R, Nl, K))
+                elif pooled:
                     _call(_lib.btr_sa_gemm_tn_pool, R, Nl, K, _p(dY), Nl, S, _p(arg),
                           _p(pool[0]), _p(pool[1]), _p(pool[2]), _p(Xsrc), ldx, _p(pa), _p(pb),
                           _p(pw), _p(dW), st, key=(R, Nl, K))
@@ -198,9 +217,21 @@ class FusedSAFunction(Function):
                         sc, sh, mu, isd = stats[l - 1]
                         part = _f32((1024, 2, K), dev)
                         m1, m2, dg, db = (_f32((K,), dev) for _ in range(4))
-                        _call(_lib.btr_sa_bn_relu_bwd, R, K, K, _p(G), _p(Ys[l - 1]), _p(sc),
-                              _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2), _p(dg), _p(db),
-                              st)
+                        if ctx.rc and l == 1:
+                            # layer 0: BN+ReLU backward with y0 rebuilt from X0, fused with the
+                            # layer's weight gradient -- dY0 is never written
+                            nb = _lib.btr_sa_rc_wgrad_blocks(R, K)
+                            pw0 = _f32((nb, K, 4), dev)
+                            dW0 = _f32((K, 4), dev)
+                            _call(_lib.btr_sa_bn_relu_bwd_rc, R, K, K, _p(G), _p(X0),
+                                  _p(Ws[0]), _p(sc), _p(sh), _p(mu), _p(isd), _p(part), _p(m1),
+                                  _p(m2), _p(dg), _p(db), _p(pw0), _p(dW0), st)
+                            kin0 = pshapes[0][1]
+                            grads[0] = dW0[:, :kin0].reshape(pshapes[0])
+                        else:
+                            _call(_lib.btr_sa_bn_relu_bwd, R, K, K, _p(G), _p(Ys[l - 1]),
+                                  _p(sc), _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2),
+                                  _p(dg), _p(db), st)
                         grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = dg, db
                         dY = G
                     else:

@@ -253,7 +253,7 @@ def roofline_objects(kernels, detail, detail_steps):
                                       "note": "grid-culled query incl. grid build (5 launches)"}
     # grouped shared MLP: every f32-MFMA GEMM launch of the fused SA path (fwd NT with BN
     # prologue/epilogue, dgrad NT, wgrad TN); flops = 2*rows*n*k per launch
-    gemm = [(k, t) for (o, k), t in detail.items() if o in ("sa_gemm_nt", "sa_gemm_tn", "sa_gemm_nt_pool", "sa_gemm_tn_pool")]
+    gemm = [(k, t) for (o, k), t in detail.items() if o in ("sa_gemm_nt", "sa_gemm_tn", "sa_gemm_nt_pool", "sa_gemm_tn_pool", "sa_gemm_nt_rc", "sa_gemm_tn_rc")]
     if gemm:
         steps = detail_steps
         flops = sum(2.0 * k[0] * k[1] * k[2] * len(t) for k, t in gemm) / steps

@@ -198,6 +198,29 @@ int btr_sa_scatter(int b, int n, int m, int s, int c, int ldx, int use_xyz, floa
                    float *dnew_xyz, void *workspace, size_t workspace_bytes,
                    btr_stream_t stream);
 
+/* First-layer recompute.  A set-abstraction layer whose gathered input has <= 4 columns (SA1:
+ * relative xyz + height; x0 [rows][4]) does not need its first pre-BN output y0 = x0 . w0^T
+ * (rows x k floats) in HBM: btr_sa_gemm_nt with c == NULL only produces its BatchNorm
+ * statistics, and the consumers rebuild y0 from the 16-byte input row:
+ *   btr_sa_gemm_nt_rc      second layer forward,   A = relu(pa * y0 + pb)
+ *   btr_sa_gemm_tn_rc      second layer weight gradient, X = relu(pa * y0 + pb)
+ *   btr_sa_bn_relu_bwd_rc  first layer BN+ReLU backward fused with its weight gradient
+ *                          (dw0 [k][4]); the dense dY0 is never written either.
+ * Replaces, for that layer, the Conv2d / BatchNorm2d / ReLU forward and backward of
+ * pytorch_utils.py:11-36 as used by pointnet2_modules.py:243-267. */
+int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, const float *w,
+                      int ldw, float *c, int ldc, const float *pa, const float *pb, float *part,
+                      btr_stream_t stream);
+int btr_sa_gemm_tn_rc(int rows, int n, int k, const float *g, int ldg, const float *x0,
+                      const float *w0, const float *pa, const float *pb, float *pw, float *dw,
+                      btr_stream_t stream);
+int btr_sa_rc_wgrad_blocks(long long rows, int c);
+int btr_sa_bn_relu_bwd_rc(long long rows, int c, int ldg, const float *g, const float *x0,
+                          const float *w0, const float *scale, const float *shift,
+                          const float *mean, const float *invstd, float *part, float *m1,
+                          float *m2, float *dgamma, float *dbeta, float *pw, float *dw0,
+                          btr_stream_t stream);
+
 /* Pooled-layer backward without a dense dY pass.  btr_sa_pool_bwd_coef computes the BatchNorm
  * backward statistics of the max-pooled (last) layer like btr_sa_pool_bwd, but leaves y
  * untouched and returns dcl [b*m][c], alpha [c], beta [c] with

@@ -120,3 +120,46 @@ def test_pooled_gradient_paths_agree(cuda, monkeypatch, poolgrad):
             continue
         tol = 1e-4 if k in ("out", "new_xyz") or "running" in k or "tracked" in k else 5e-4
         assert _rel(got[k], ref[k]) < tol, (k, _rel(got[k], ref[k]))
+
+
+@pytest.mark.parametrize("recompute", ["1", "0"])
+@pytest.mark.parametrize("C,mlp", [(1, [1, 64, 64, 128]), (0, [0, 32, 48, 64])])
+def test_first_layer_recompute(cuda, monkeypatch, recompute, C, mlp):
+    """SA1 configuration (<= 4 input columns, inputs without gradient): the first pre-BN output
+    is not stored; the second layer's forward / weight gradient and the first layer's backward
+    rebuild it from the 16-byte input rows (BTR_SA_RECOMPUTE=0: stored, as everywhere else).
+    Negative BatchNorm scales in the first layer exercise the recomputed ReLU masks."""
+    B, N, npoint, S = 2, 4096, 512, 64
+    xyz = torch.from_numpy(np.stack([synthetic.make_scene(80 + i, N, use_height=False)[
+        'point_clouds'] for i in range(B)], 0)).to(cuda)
+    torch.manual_seed(2)
+    feats = torch.randn(B, C, N, device=cuda) if C else None
+    sa = M.PointnetSAModuleVotes(npoint=npoint, radius=0.2, nsample=S, mlp=list(mlp),
+                                 use_xyz=True, normalize_xyz=True).to(cuda)
+    with torch.no_grad():
+        for layer in sa.mlp_module:
+            layer.bn.bn.weight.uniform_(-1.5, 1.5)
+            layer.bn.bn.bias.uniform_(-0.3, 0.3)
+    ref_mod = copy.deepcopy(sa)
+    from backtoreality_amd.pointnet2 import pointnet2_utils
+    inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+
+    def run(mod):
+        _, out, _ = mod(xyz, feats, inds)     # no input requires a gradient
+        torch.manual_seed(3)
+        (out * torch.randn_like(out)).sum().backward()
+        g = {"out": out.detach()}
+        for n, p in mod.named_parameters():
+            g["d" + n] = p.grad
+        for n, b in mod.named_buffers():
+            g[n] = b.detach().clone().float()
+        return g
+
+    monkeypatch.setenv("BTR_FUSED_SA", "0")
+    ref = run(ref_mod)
+    monkeypatch.setenv("BTR_FUSED_SA", "1")
+    monkeypatch.setenv("BTR_SA_RECOMPUTE", recompute)
+    got = run(sa)
+    for k in sorted(ref):
+        tol = 1e-4 if k == "out" or "running" in k or "tracked" in k else 5e-4
+        assert _rel(got[k], ref[k]) < tol, (k, _rel(got[k], ref[k]))
