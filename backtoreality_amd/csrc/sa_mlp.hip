@@ -1052,12 +1052,12 @@ int btr_sa_pool(int b, int m, int s, int c, int ldy, const float *y, const float
 
 int btr_sa_pool_bwd(int b, int m, int s, int c, int ldy, float *y, const float *dout,
                     const float *out, const unsigned char *arg, const float *mean,
-                    const float *invstd, const float *scale, float *part /*[256][2][c]*/,
+                    const float *invstd, const float *scale, float *part /*[1024][2][c]*/,
                     float *m1, float *m2, float *dgamma, float *dbeta, btr_stream_t stream) {
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   hipStream_t st = as_stream(stream);
-  const int nblk = (int)std::min<long long>(groups, 256);
+  const int nblk = (int)std::min<long long>(groups, 1024);
   hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, m, s, c, ldy, y,
                      dout, out, arg, mean, invstd, groups, part);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c, nblk,
@@ -1072,13 +1072,13 @@ int btr_sa_pool_bwd(int b, int m, int s, int c, int ldy, float *y, const float *
 // btr_sa_gemm_tn_pool form dY inside their operand staging.  y is left untouched.
 int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, const float *dout,
                          const float *out, const unsigned char *arg, const float *mean,
-                         const float *invstd, const float *scale, float *part /*[256][2][c]*/,
+                         const float *invstd, const float *scale, float *part /*[1024][2][c]*/,
                          float *m1, float *m2, float *dgamma, float *dbeta, float *dcl,
                          float *alpha, float *beta, btr_stream_t stream) {
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   hipStream_t st = as_stream(stream);
-  const int nblk = (int)std::min<long long>(groups, 256);
+  const int nblk = (int)std::min<long long>(groups, 1024);
   hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, m, s, c, ldy, y,
                      dout, out, arg, mean, invstd, groups, part);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c, nblk,

@@ -158,7 +158,7 @@ class FusedSAFunction(Function):
             # (BTR_POOLGRAD=0: written in place over Y_last by btr_sa_pool_bwd).
             CL = Ys[-1].shape[1]
             scale, shift, mean, invstd = stats[-1]
-            part = _f32((256, 2, CL), dev)
+            part = _f32((1024, 2, CL), dev)
             m1, m2, dg, db = (_f32((CL,), dev) for _ in range(4))
             pool = None
             if _pool_grad_in_prologue(S):

@@ -170,7 +170,7 @@ int btr_sa_pool(int b, int m, int s, int c, int ldy, const float *y, const float
                 const float *shift, float *out, float *out_cl, unsigned char *arg,
                 btr_stream_t stream);
 
-/* Backward of pool+ReLU+BN: y is overwritten IN PLACE by dL/dy; part: [256][2][c] scratch. */
+/* Backward of pool+ReLU+BN: y is overwritten IN PLACE by dL/dy; part: [1024][2][c] scratch. */
 int btr_sa_pool_bwd(int b, int m, int s, int c, int ldy, float *y, const float *dout,
                     const float *out, const unsigned char *arg, const float *mean,
                     const float *invstd, const float *scale, float *part, float *m1, float *m2,
