@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256) void ti_reduce_kernel(
     if (c0 + l < c) grad_points[((size_t)bi * c + c0 + l) * m + j] = acc[l];
 }
 
+// sa_mlp.hip: count + scan + fill of an inverted index list by one workgroup per batch element
+bool csr_small_supported(int n_bins);
+void csr_small_launch(int b, long long entries, int n_bins, const int *idx, int *off, int *refs,
+                      hipStream_t st);
+
 }  // namespace btr
 
 using namespace btr;
@@ -218,11 +223,16 @@ int btr_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out
     if (e != hipSuccess)
       return fail((int)e, "three_interpolate_grad workspace: %s", hipGetErrorString(e));
     int *off = (int *)ws, *cursor = (int *)(ws + off_b), *refs = (int *)(ws + off_b + cur_b);
-    (void)hipMemsetAsync(off, 0, off_b, st);
-    hipLaunchKernelGGL(ti_count_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx, off);
-    hipLaunchKernelGGL(ti_scan_kernel, dim3(b), dim3(256), 0, st, m, off, cursor);
-    hipLaunchKernelGGL(ti_fill_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx,
-                       cursor, refs);
+    if (csr_small_supported(m)) {
+      csr_small_launch(b, n3, m, idx, off, refs, st);
+    } else {
+      (void)hipMemsetAsync(off, 0, off_b, st);
+      hipLaunchKernelGGL(ti_count_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx,
+                         off);
+      hipLaunchKernelGGL(ti_scan_kernel, dim3(b), dim3(256), 0, st, m, off, cursor);
+      hipLaunchKernelGGL(ti_fill_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx,
+                         cursor, refs);
+    }
     hipLaunchKernelGGL(ti_reduce_kernel, dim3(cdiv(m, 64), cdiv(c, 4 * kTiCpt), b), dim3(256), 0,
                        st, c, n, m, grad_out, weight, off, refs, grad_points);
     (void)hipFreeAsync(ws, st);

@@ -903,6 +903,64 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(long long ms, int N,
   }
 }
 
+// Small scenes (N <= kCsrSmallN points): the whole inversion -- count, exclusive scan, fill --
+// by ONE workgroup per batch element with the counters in LDS.  The four-launch global-atomic
+// version spreads a scene's updates over every XCD, so its integer atomics are resolved at
+// device scope (23 us per launch for 262 144 updates); here they are LDS atomics.
+constexpr int kCsrSmallN = 8192;
+__global__ __launch_bounds__(1024) void csr_small_kernel(long long ms, int N,
+                                                         const int *__restrict__ idx,
+                                                         int *__restrict__ off,
+                                                         int *__restrict__ refs) {
+  __shared__ int cnt[kCsrSmallN];
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  idx += (size_t)bi * ms;
+  refs += (size_t)bi * ms;
+  off += (size_t)bi * (N + 1);
+  for (int i = tid; i < N; i += 1024) cnt[i] = 0;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (long long jk = tid; jk < ms; jk += 1024) atomicAdd(&cnt[idx[jk]], 1);
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {  // exclusive scan, 1024 bins at a time
+    const int i = base + tid;
+    const int v = i < N ? cnt[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int pre = carry_s;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    const int excl = pre + incl - v;
+    if (i < N) {
+      cnt[i] = excl;  // becomes the fill cursor
+      off[i] = excl;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = excl + v;
+    __syncthreads();
+  }
+  if (tid == 0) off[N] = carry_s;
+  for (long long jk = tid; jk < ms; jk += 1024) {
+    const int pos = atomicAdd(&cnt[idx[jk]], 1);
+    refs[pos] = (int)jk;
+  }
+}
+
+// (host entry for other translation units: interpolate.hip inverts its 3-NN lists with it)
+bool csr_small_supported(int n_bins) { return n_bins > 0 && n_bins <= kCsrSmallN; }
+void csr_small_launch(int b, long long entries, int n_bins, const int *idx, int *off, int *refs,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(csr_small_kernel, dim3(b), dim3(1024), 0, st, entries, n_bins, idx, off,
+                     refs);
+}
+
 // One wave per point n: dfeat_cl[b][n][c] = sum over refs of dX0[ref][xoff + c];
 // dxyz[b][n][0..3) = (sum of dX0[ref][0..3)) * inv_radius.
 __global__ __launch_bounds__(256) void csr_reduce_kernel(
@@ -1314,12 +1372,17 @@ int btr_sa_scatter(int b, int n, int m, int s, int c, int ldx, int use_xyz, floa
     int *cnt_off = (int *)workspace;
     int *cursor = cnt_off + (size_t)b * (n + 1);
     int *refs = cursor + (size_t)b * n;
-    hipError_t e = hipMemsetAsync(cnt_off, 0, sizeof(int) * (size_t)b * (n + 1), st);
-    if (e != hipSuccess) return fail((int)e, "sa_scatter memset: %s", hipGetErrorString(e));
-    const int gx = (int)std::min<long long>(cdiv(ms, 256), 1024);
-    hipLaunchKernelGGL(csr_count_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cnt_off);
-    hipLaunchKernelGGL(csr_scan_kernel, dim3(b), dim3(1024), 0, st, n, cnt_off, cursor);
-    hipLaunchKernelGGL(csr_fill_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cursor, refs);
+    if (n <= kCsrSmallN) {
+      hipLaunchKernelGGL(csr_small_kernel, dim3(b), dim3(1024), 0, st, ms, n, idx, cnt_off, refs);
+    } else {
+      hipError_t e = hipMemsetAsync(cnt_off, 0, sizeof(int) * (size_t)b * (n + 1), st);
+      if (e != hipSuccess) return fail((int)e, "sa_scatter memset: %s", hipGetErrorString(e));
+      const int gx = (int)std::min<long long>(cdiv(ms, 256), 1024);
+      hipLaunchKernelGGL(csr_count_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cnt_off);
+      hipLaunchKernelGGL(csr_scan_kernel, dim3(b), dim3(1024), 0, st, n, cnt_off, cursor);
+      hipLaunchKernelGGL(csr_fill_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cursor,
+                         refs);
+    }
     hipLaunchKernelGGL(csr_reduce_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, st, n, ms, c, ldx,
                        xoff, inv, dx0, cnt_off, refs, dfeat_cl, dxyz);
   }
