@@ -392,6 +392,49 @@ __global__ __launch_bounds__(256) void sa_pool_kernel(int M, int S, int C, int l
   arg[(size_t)g * C + c] = (unsigned char)bs;
 }
 
+// Same with four channels per thread (C % 4 == 0, ldy % 4 == 0): 16-byte loads, four
+// independent max chains per thread.
+__global__ __launch_bounds__(256) void sa_pool4_kernel(int M, int S, int C, int ldy,
+                                                       const float *__restrict__ Y,
+                                                       const float *__restrict__ scale,
+                                                       const float *__restrict__ shift,
+                                                       float *__restrict__ out,
+                                                       float *__restrict__ out_cl,
+                                                       unsigned char *__restrict__ arg,
+                                                       long long groups) {
+  const int cq = C >> 2;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= groups * cq) return;
+  const long long g = t / cq;
+  const int c = (int)(t - g * cq) * 4;
+  const float4 a = *reinterpret_cast<const float4 *>(scale + c);
+  const float4 b = *reinterpret_cast<const float4 *>(shift + c);
+  const float *y = Y + (size_t)g * S * ldy + c;
+  float best[4] = {-1.f, -1.f, -1.f, -1.f};
+  int bs[4] = {0, 0, 0, 0};
+#pragma unroll 4
+  for (int s = 0; s < S; ++s) {
+    const float4 q = *reinterpret_cast<const float4 *>(y + (size_t)s * ldy);
+    const float v[4] = {fmaxf(fmaf(a.x, q.x, b.x), 0.f), fmaxf(fmaf(a.y, q.y, b.y), 0.f),
+                        fmaxf(fmaf(a.z, q.z, b.z), 0.f), fmaxf(fmaf(a.w, q.w, b.w), 0.f)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (v[i] > best[i]) {
+        best[i] = v[i];
+        bs[i] = s;
+      }
+  }
+  const long long bi = g / M;
+  const int m = (int)(g - bi * M);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[((size_t)bi * C + c + i) * M + m] = best[i];
+  if (out_cl)
+    *reinterpret_cast<float4 *>(out_cl + (size_t)g * C + c) =
+        make_float4(best[0], best[1], best[2], best[3]);
+  *reinterpret_cast<unsigned *>(arg + (size_t)g * C + c) =
+      (unsigned)bs[0] | ((unsigned)bs[1] << 8) | ((unsigned)bs[2] << 16) | ((unsigned)bs[3] << 24);
+}
+
 // ------------------------------------------- max-pool + ReLU + BN backward, statistics pass
 // g = dOut[b][c][m] where out > 0 (ReLU), routed to row s* = arg;  accumulates per channel
 // sum(g) and sum(g * xhat) with xhat = (Y[r*][c] - mean)*invstd  -> part[blk][2][C].
@@ -1103,8 +1146,14 @@ int btr_sa_pool(int b, int m, int s, int c, int ldy, const float *y, const float
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(s <= 255, "sa_pool: nsample %d > 255", s);
-  hipLaunchKernelGGL(sa_pool_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
-                     as_stream(stream), m, s, c, ldy, y, scale, shift, out, out_cl, arg, groups);
+  if (c % 4 == 0 && ldy % 4 == 0)
+    hipLaunchKernelGGL(sa_pool4_kernel, dim3(cdiv(groups * (c / 4), 256)), dim3(256), 0,
+                       as_stream(stream), m, s, c, ldy, y, scale, shift, out, out_cl, arg,
+                       groups);
+  else
+    hipLaunchKernelGGL(sa_pool_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
+                       as_stream(stream), m, s, c, ldy, y, scale, shift, out, out_cl, arg,
+                       groups);
   return check_launch("sa_pool");
 }
 
