@@ -1224,7 +1224,7 @@ static int tn_tile_n(int n) { return n >= 128 ? 128 : 64; }
 
 int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
   const int tiles = cdiv(n, tn_tile_n(n)) * cdiv(k, 64);
-  int chunks = std::max(1, std::min(2048 / tiles, 1024));  // ~2048 workgroups in flight
+  int chunks = std::max(1, std::min(1024 / tiles, 1024));  // ~1024 workgroups in flight
   chunks = std::min(chunks, std::max(1, rows / 256));
   return chunks;
 }
