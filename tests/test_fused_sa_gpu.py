@@ -44,6 +44,7 @@ def _run(sa, xyz, feats, inds, xyz_grad):
     (1024, 128, 0.8, 16, [0, 32, 48], 0, True),              # no features (GroupFree), 2 layers
     (700, 100, 0.5, 7, [5, 20], 5, True),                    # ragged sizes, single layer
     (3000, 64, 1.0, 128, [3, 32, 64], 3, True),              # one group = one 128-row GEMM tile
+    (9000, 256, 0.3, 16, [8, 32, 64], 8, True),              # N > 8192: global-atomic inversion
 ])
 def test_fused_matches_unfused(cuda, monkeypatch, N, npoint, radius, S, mlp, C, xyz_grad):
     B = 2

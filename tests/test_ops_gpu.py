@@ -238,7 +238,8 @@ def test_three_nn(cuda, B, n, m):
     np.testing.assert_array_equal(d.cpu().numpy(), d_ref)  # inf where m < 3
 
 
-@pytest.mark.parametrize("B,C,m,n", [(2, 256, 256, 512), (2, 256, 512, 1024), (1, 3, 10, 7)])
+@pytest.mark.parametrize("B,C,m,n", [(2, 256, 256, 512), (2, 256, 512, 1024), (1, 3, 10, 7),
+                                     (2, 5, 9000, 3000)])  # m > 8192: global-atomic inversion
 def test_three_interpolate(cuda, B, C, m, n):
     rng = np.random.default_rng(3)
     pts = rng.standard_normal((B, C, m)).astype(np.float32)
