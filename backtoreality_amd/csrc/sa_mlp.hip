@@ -509,6 +509,81 @@ __global__ __launch_bounds__(256) void sa_pool_coef_kernel(
   }
 }
 
+// Statistics + dcl of the pooled layer in one pass over (dout, out) only: tile = 16 channels x
+// 64 centres of one batch element, lanes along the centre axis (coalesced reads of the
+// (B, C, M) tensors); xhat at the arg-max row is recovered from the pooled output
+// (out = a*y + b, out > 0) instead of gathered from Y (|a| ~ 0: gathered).  part row =
+// b * ceil(M/64) + centre tile; dcl is written channel-last through an LDS transpose.
+__global__ __launch_bounds__(256) void sa_pool_bwd_tile_kernel(
+    int M, int S, int C, int ldy, const float *__restrict__ Y, const float *__restrict__ dout,
+    const float *__restrict__ out, const unsigned char *__restrict__ arg,
+    const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ part,
+    float *__restrict__ dcl) {
+  __shared__ float tile[64][17];
+  const int bi = blockIdx.z, c0 = blockIdx.y * 16, m0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = m0 + lane;
+  const size_t prow = ((size_t)bi * gridDim.x + blockIdx.x) * 2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cl = wave + 4 * i, c = c0 + cl;
+    float g = 0.f, gx = 0.f, dv = 0.f;
+    if (c < C && m < M) {
+      const size_t o = ((size_t)bi * C + c) * M + m;
+      const float ov = out[o];
+      if (ov > 0.f) {
+        g = dout[o];
+        const float a = scale[c];
+        float y;
+        if (fabsf(a) > 1e-20f) {
+          y = (ov - shift[c]) / a;
+        } else {
+          const size_t grp = (size_t)bi * M + m;
+          y = Y[(grp * S + arg[grp * C + c]) * ldy + c];
+        }
+        gx = g * ((y - mean[c]) * invstd[c]);
+        dv = a * g;
+      }
+    }
+    tile[lane][cl] = dv;
+    float s1 = g, s2 = gx;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      s1 += __shfl_xor(s1, off);
+      s2 += __shfl_xor(s2, off);
+    }
+    if (lane == 0 && c < C) {
+      part[(prow + 0) * C + c] = s1;
+      part[(prow + 1) * C + c] = s2;
+    }
+  }
+  __syncthreads();
+  const int tm = threadIdx.x >> 2, tc = (threadIdx.x & 3) * 4;  // 64 centres x 4 float4
+  if (m0 + tm < M && c0 + tc < C) {
+    float *dst = dcl + ((size_t)bi * M + m0 + tm) * C + c0 + tc;
+    if (c0 + tc + 3 < C) {
+      *reinterpret_cast<float4 *>(dst) =
+          make_float4(tile[tm][tc], tile[tm][tc + 1], tile[tm][tc + 2], tile[tm][tc + 3]);
+    } else {
+      for (int q = 0; q < 4 && c0 + tc + q < C; ++q) dst[q] = tile[tm][tc + q];
+    }
+  }
+}
+
+// alpha / beta of the pooled layer's dense gradient part (see sa_pool_coef_kernel)
+__global__ __launch_bounds__(256) void sa_pool_ab_kernel(
+    int C, const float *__restrict__ scale, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ m1,
+    const float *__restrict__ m2, float *__restrict__ alpha, float *__restrict__ beta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float a = scale[c];
+  const float al = -a * invstd[c] * m2[c];
+  alpha[c] = al;
+  beta[c] = -a * m1[c] - al * mean[c];
+}
+
 // dY[r][c] = a[c] * (g[r][c] - m1[c] - xhat[r][c]*m2[c]) written IN PLACE over Y, for the
 // pooled (last) layer: g[r][c] = dOut if (s == arg && out > 0) else 0.
 __global__ __launch_bounds__(256) void sa_pool_bwd_apply_kernel(
@@ -1179,12 +1254,23 @@ int btr_sa_pool_bwd(int b, int m, int s, int c, int ldy, float *y, const float *
 // btr_sa_gemm_tn_pool form dY inside their operand staging.  y is left untouched.
 int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, const float *dout,
                          const float *out, const unsigned char *arg, const float *mean,
-                         const float *invstd, const float *scale, float *part /*[1024][2][c]*/,
-                         float *m1, float *m2, float *dgamma, float *dbeta, float *dcl,
-                         float *alpha, float *beta, btr_stream_t stream) {
+                         const float *invstd, const float *scale, const float *shift,
+                         float *part /*[1024][2][c]*/, float *m1, float *m2, float *dgamma,
+                         float *dbeta, float *dcl, float *alpha, float *beta,
+                         btr_stream_t stream) {
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   hipStream_t st = as_stream(stream);
+  const long long tiles = (long long)b * cdiv(m, 64);
+  if (shift != nullptr && tiles <= 1024 && c % 4 == 0 && b < 65536) {
+    hipLaunchKernelGGL(sa_pool_bwd_tile_kernel, dim3(cdiv(m, 64), cdiv(c, 16), b), dim3(256), 0,
+                       st, m, s, c, ldy, y, dout, out, arg, mean, invstd, scale, shift, part, dcl);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c,
+                       (int)tiles, (double)groups * s, part, m1, m2, dgamma, dbeta);
+    hipLaunchKernelGGL(sa_pool_ab_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, c, scale, mean,
+                       invstd, m1, m2, alpha, beta);
+    return check_launch("sa_pool_bwd_coef(tile)");
+  }
   const int nblk = (int)std::min<long long>(groups, 1024);
   hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, m, s, c, ldy, y,
                      dout, out, arg, mean, invstd, groups, part);

@@ -165,8 +165,8 @@ class FusedSAFunction(Function):
                 dcl = _f32((B * M, CL), dev)
                 alpha, beta = _f32((CL,), dev), _f32((CL,), dev)
                 _call(_lib.btr_sa_pool_bwd_coef, B, M, S, CL, CL, _p(Ys[-1]), _p(dout), _p(out),
-                      _p(arg), _p(mean), _p(invstd), _p(scale), _p(part), _p(m1), _p(m2),
-                      _p(dg), _p(db), _p(dcl), _p(alpha), _p(beta), st)
+                      _p(arg), _p(mean), _p(invstd), _p(scale), _p(shift), _p(part), _p(m1),
+                      _p(m2), _p(dg), _p(db), _p(dcl), _p(alpha), _p(beta), st)
                 pool = (dcl, alpha, beta)
             else:
                 _call(_lib.btr_sa_pool_bwd, B, M, S, CL, CL, _p(Ys[-1]), _p(dout), _p(out),

@@ -230,9 +230,9 @@ int btr_sa_bn_relu_bwd_rc(long long rows, int c, int ldg, const float *g, const 
  * BatchNorm2d backward of pointnet2_modules.py:258-266 for the last SharedMLP layer. */
 int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, const float *dout,
                          const float *out, const unsigned char *arg, const float *mean,
-                         const float *invstd, const float *scale, float *part, float *m1,
-                         float *m2, float *dgamma, float *dbeta, float *dcl, float *alpha,
-                         float *beta, btr_stream_t stream);
+                         const float *invstd, const float *scale, const float *shift,
+                         float *part, float *m1, float *m2, float *dgamma, float *dbeta,
+                         float *dcl, float *alpha, float *beta, btr_stream_t stream);
 int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const float *w, int ldw,
                         float *c, int ldc, int s, const unsigned char *arg, const float *dcl,
                         const float *alpha, const float *beta, btr_stream_t stream);
