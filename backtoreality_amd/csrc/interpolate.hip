@@ -47,6 +47,75 @@ __global__ __launch_bounds__(64) void three_nn_kernel(int n, int m,
   id[0] = besti1; id[1] = besti2; id[2] = besti3;
 }
 
+// Same result with 8 lanes per query: each lane scans a contiguous slice of the known points
+// (ascending indices, strict `<`), then the sorted triples are merged pairwise under the order
+// the sequential scan realises -- smaller distance first, smaller index first on equal
+// distances.  The one-lane-per-query kernel leaves the chip nearly empty at the FP-module sizes
+// (1024 queries x 512 known points per scene: 49 us -> ~15 us).
+struct Top3 {
+  float d1, d2, d3;
+  int i1, i2, i3;
+};
+__device__ __forceinline__ bool nn_less(float d, int k, float bd, int bk) {
+  return d < bd || (d == bd && k < bk);
+}
+__device__ __forceinline__ void nn_insert(Top3 &t, float d, int k) {
+  const bool c1 = nn_less(d, k, t.d1, t.i1), c2 = nn_less(d, k, t.d2, t.i2),
+             c3 = nn_less(d, k, t.d3, t.i3);
+  t.d3 = c2 ? t.d2 : (c3 ? d : t.d3);
+  t.i3 = c2 ? t.i2 : (c3 ? k : t.i3);
+  t.d2 = c1 ? t.d1 : (c2 ? d : t.d2);
+  t.i2 = c1 ? t.i1 : (c2 ? k : t.i2);
+  t.d1 = c1 ? d : t.d1;
+  t.i1 = c1 ? k : t.i1;
+}
+
+__global__ __launch_bounds__(64) void three_nn_split_kernel(int n, int m,
+                                                            const float *__restrict__ unknown,
+                                                            const float *__restrict__ known,
+                                                            float *__restrict__ dist2,
+                                                            int *__restrict__ idx) {
+  const int bi = blockIdx.y;
+  const int part = threadIdx.x & 7;
+  const int j = blockIdx.x * 8 + (threadIdx.x >> 3);
+  const int jj = min(j, n - 1);
+  known += (size_t)bi * m * 3;
+  const float *u = unknown + ((size_t)bi * n + jj) * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  const float inf = __builtin_huge_valf();
+  Top3 t{inf, inf, inf, 0, 0, 0};
+  const int per = (m + 7) / 8;
+  const int k1 = min(m, (part + 1) * per);
+  for (int k = part * per; k < k1; ++k) {
+    const float x = known[k * 3 + 0], y = known[k * 3 + 1], z = known[k * 3 + 2];
+    const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+    const bool c1 = d < t.d1, c2 = d < t.d2, c3 = d < t.d3;  // indices ascend inside a slice
+    t.d3 = c2 ? t.d2 : (c3 ? d : t.d3);
+    t.i3 = c2 ? t.i2 : (c3 ? k : t.i3);
+    t.d2 = c1 ? t.d1 : (c2 ? d : t.d2);
+    t.i2 = c1 ? t.i1 : (c2 ? k : t.i2);
+    t.d1 = c1 ? d : t.d1;
+    t.i1 = c1 ? k : t.i1;
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    const float od1 = __shfl_xor(t.d1, off), od2 = __shfl_xor(t.d2, off),
+                od3 = __shfl_xor(t.d3, off);
+    const int oi1 = __shfl_xor(t.i1, off), oi2 = __shfl_xor(t.i2, off),
+              oi3 = __shfl_xor(t.i3, off);
+    // an empty slot is (inf, 0): never inserted (inf < inf is false, and 0 < 0 is false)
+    if (od1 < inf) nn_insert(t, od1, oi1);
+    if (od2 < inf) nn_insert(t, od2, oi2);
+    if (od3 < inf) nn_insert(t, od3, oi3);
+  }
+  if (part == 0 && j < n) {
+    float *d2 = dist2 + ((size_t)bi * n + j) * 3;
+    int *id = idx + ((size_t)bi * n + j) * 3;
+    d2[0] = t.d1; d2[1] = t.d2; d2[2] = t.d3;
+    id[0] = t.i1; id[1] = t.i2; id[2] = t.i3;
+  }
+}
+
 constexpr int kInterpCh = 8;  // channels per thread
 
 __global__ __launch_bounds__(256) void three_interpolate_kernel(
@@ -187,8 +256,12 @@ int btr_three_nn(int b, int n, int m, const float *unknown, const float *known, 
   if (b <= 0 || n <= 0) return BTR_OK;
   BTR_REQUIRE(unknown && dist2 && idx && (m <= 0 || known), "three_nn: null pointer");
   BTR_REQUIRE(b < 65536, "three_nn: batch too large");
-  hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 64), b), dim3(64), 0, as_stream(stream), n,
-                     std::max(m, 0), unknown, known, dist2, idx);
+  if (m >= 64)
+    hipLaunchKernelGGL(three_nn_split_kernel, dim3(cdiv(n, 8), b), dim3(64), 0,
+                       as_stream(stream), n, m, unknown, known, dist2, idx);
+  else
+    hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 64), b), dim3(64), 0, as_stream(stream), n,
+                       std::max(m, 0), unknown, known, dist2, idx);
   return check_launch("three_nn");
 }
 
