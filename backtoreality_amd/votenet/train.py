@@ -68,6 +68,16 @@ def make_optimizer(net, lr=1e-3, weight_decay=0.0):
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
 
 
+def enable_conv_autotune():
+    """`torch.backends.cudnn.benchmark = True` like the reference's GroupFree3D scripts
+    (train_GF_FSB.py:454-455): on ROCm MIOpen then benchmarks its solvers for every new
+    convolution shape (the 1x1 convolutions of the FP / voting / proposal layers) the first time
+    it sees it -- tens of seconds in the first step, 0.2 ms per step afterwards (10.0 -> 9.8
+    ms).  The hand-written kernels are not affected."""
+    torch.backends.cudnn.enabled = True
+    torch.backends.cudnn.benchmark = True
+
+
 def freeze_gc():
     """Call once after the model, the optimizer state and the first (warm-up) steps exist.
     A step creates thousands of short-lived Python objects; every ~70 000 of them CPython runs

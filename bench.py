@@ -34,6 +34,11 @@ def parse():
     p.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     p.add_argument("--points", type=int, default=40000)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--conv-autotune", action="store_true",
+                   help="torch.backends.cudnn.benchmark = True (like the reference's GroupFree3D "
+                        "scripts): MIOpen searches its solvers for the FP / voting / proposal "
+                        "convolutions in an extra untimed priming step (1-3 min on a fresh "
+                        "machine); measured 10.0 -> 9.76 ms/step")
     p.add_argument("--no-pipelined", action="store_true",
                    help="skip the secondary (informational) software-pipelined loop")
     p.add_argument("--workload", choices=["fsb", "br", "cr"], default="fsb",
@@ -126,6 +131,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.conv_autotune:
+        # One-time set-up, never timed: MIOpen's solver search for the stock convolution
+        # layers (train.enable_conv_autotune) happens in this priming step, whatever --warmup
+        # is.  Off by default: on a fresh machine the search takes 1-3 minutes.
+        train.enable_conv_autotune()
+        train_step(ddp, opt, batch, cfg)
+        barrier()
     for _ in range(args.warmup):
         train_step(ddp, opt, batch, cfg)
     barrier()
