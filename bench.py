@@ -290,7 +290,7 @@ def roofline_objects(kernels, detail, detail_steps):
                            "frac": ach / HBM_PEAK_GBS,
                            "traffic": pmc_traffic("fps_bucket_kernel"),
                            "algorithmic_bytes": nbytes,
-                           "kernel": "fps_bucket_kernel (+fps_sort_kernel)",
+                           "kernel": "fps_bucket_kernel (+fps_sortm_*_kernel)",
                            "shape": [b, n, m], "avg_ms": ms,
                            "note": "bound by m-1 dependent arg-max steps per scene (one CU per "
                                    "scene), not by bytes: see iterations_per_s",
