@@ -287,6 +287,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
   }
   __shared__ BSlot slots[2][NW];
 
+  __builtin_amdgcn_s_setprio(3);  // latency chain: issue ahead of co-resident streaming waves
   const int bi = blockIdx.x;
   dataset += (size_t)bi * n * 3;
   spts += (size_t)bi * np;

@@ -207,6 +207,152 @@ static int launch_fps(int b, int n, int m, int bs, int log2bs, const float *data
   return check_launch("furthest_point_sampling");
 }
 
+// ---------------------------------------------------------- register-resident FPS, n <= 4096
+// Same selection rule, restated so that a step costs ~9 VALU instructions per point instead of
+// ~25: the running min-dist is kept as its float bit pattern in a signed int (d2 >= +0 orders
+// like the int; a skipped or padding point holds the bits of -1.0f, a negative int that
+// `min` preserves and `max` never picks), so update + lane arg-max are integer min/max; only the
+// VALUE of the maximum is reduced over the wave.  The point that holds it is located afterwards
+// (`pm`: which of my points equal the wave maximum) and the (-tk) tie-break is evaluated only
+// when more than one point holds the maximum.  Winner coordinates come from an LDS copy of the
+// points, so a slot is just (bits(d2), k).
+template <int NW>
+__device__ __forceinline__ int rown_max_i32(int v) {
+  int t;
+  if (NW > 1) { t = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); v = v > t ? v : t; }
+  if (NW > 2) { t = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true); v = v > t ? v : t; }
+  if (NW > 4) { t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true); v = v > t ? v : t; }
+  if (NW > 8) { t = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true); v = v > t ? v : t; }
+  return v;
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = rown_max_i32<16>(v);
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  const int ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+
+template <int NW, int PPT>
+__global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs, int log2bs,
+                                                           const float *__restrict__ dataset,
+                                                           int *__restrict__ idxs) {
+  constexpr int T = NW * 64;
+  constexpr int kSkip = (int)0xBF800000u;  // bits of -1.0f
+  __shared__ float lx[T * PPT], ly[T * PPT], lz[T * PPT];
+  __shared__ int2 slots[2][NW];
+
+  // a dependent chain of short steps: when the scene shares its CU with streaming work from
+  // another HIP stream (the backbone runs levels 2-4 beside SA1's grouped MLP), issue first
+  __builtin_amdgcn_s_setprio(3);
+  const int bi = blockIdx.x;
+  dataset += (size_t)bi * n * 3;
+  idxs += (size_t)bi * m;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cpb = (n + bs - 1) >> log2bs;
+
+  float px[PPT], py[PPT], pz[PPT];
+  int pt[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = i * T + tid;
+    px[i] = py[i] = pz[i] = 0.f;
+    pt[i] = kSkip;
+    if (k < n) {
+      px[i] = dataset[k * 3 + 0];
+      py[i] = dataset[k * 3 + 1];
+      pz[i] = dataset[k * 3 + 2];
+      const float mag = (px[i] * px[i]) + (py[i] * py[i]) + (pz[i] * pz[i]);
+      pt[i] = ((double)mag <= 1e-3) ? kSkip : __float_as_int(1e10f);  // sampling_gpu.cu:105-106
+    }
+    lx[k] = px[i];
+    ly[k] = py[i];
+    lz[k] = pz[i];
+  }
+  __syncthreads();
+  // point 0: the start, and the answer whenever nothing competes (best=-1, besti=0 in the
+  // reference, sampling_gpu.cu:95-96)
+  float x1 = lx[0], y1 = ly[0], z1 = lz[0];
+  if (tid == 0) idxs[0] = 0;
+
+  for (int j = 1; j < m; ++j) {
+    int mi = kSkip;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+      const int d = __float_as_int(dx * dx + dy * dy + dz * dz);
+      pt[i] = d < pt[i] ? d : pt[i];
+      mi = mi > pt[i] ? mi : pt[i];
+    }
+    const int mw = wave_max_i32(mi);
+    int wk = 0;
+    if (mw >= 0) {
+      unsigned pm = 0;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) pm |= (pt[i] == mw) ? (1u << i) : 0u;
+      const unsigned long long lm = __ballot(pm != 0);
+      const int l0 = __builtin_ctzll(lm);
+      const unsigned pm0 = (unsigned)__builtin_amdgcn_readlane((int)pm, l0);
+      if ((lm & (lm - 1)) == 0 && (pm0 & (pm0 - 1)) == 0) {
+        wk = __builtin_ctz(pm0) * T + wave * 64 + l0;
+      } else {  // several points hold the maximum: smallest tk wins
+        unsigned blo = 0;
+        int bk = 0;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+          const int k = i * T + tid;
+          const unsigned lo = 0xffffffffu - fps_tk(k, bs, log2bs, cpb);
+          const bool better = ((pm >> i) & 1u) && lo > blo;
+          blo = better ? lo : blo;
+          bk = better ? k : bk;
+        }
+        const unsigned ml = wave_max_u32(blo);
+        wk = __builtin_amdgcn_readlane(bk, __builtin_ctzll(__ballot(blo == ml && pm != 0)));
+      }
+    }
+    int nk;
+    if (NW == 1) {
+      nk = wk;
+      x1 = lx[nk]; y1 = ly[nk]; z1 = lz[nk];
+    } else {
+      int2 *sl = slots[j & 1];
+      if (lane == 0) sl[wave] = make_int2(mw, wk);
+      lds_barrier();
+      const int2 v = sl[lane & (NW - 1)];
+      const float cx = lx[v.y], cy = ly[v.y], cz = lz[v.y];
+      const int gh = rown_max_i32<NW>(v.x);
+      constexpr unsigned long long kSlots = (1ull << NW) - 1ull;
+      unsigned long long match = __ballot(v.x == gh) & kSlots;
+      if (match & (match - 1)) {  // the same maximum in several waves (or nothing competes)
+        const unsigned lo = v.x == gh ? 0xffffffffu - fps_tk(v.y, bs, log2bs, cpb) : 0u;
+        unsigned t = lo;  // unsigned max over the NW slot lanes
+        if (NW > 1) { unsigned o = dpp_u32<0xB1>(t); t = t > o ? t : o; }
+        if (NW > 2) { unsigned o = dpp_u32<0x4E>(t); t = t > o ? t : o; }
+        if (NW > 4) { unsigned o = dpp_u32<0x141>(t); t = t > o ? t : o; }
+        if (NW > 8) { unsigned o = dpp_u32<0x140>(t); t = t > o ? t : o; }
+        match = __ballot(v.x == gh && lo == t) & kSlots;
+      }
+      const int w = __builtin_ctzll(match);
+      nk = __builtin_amdgcn_readlane(v.y, w);
+      x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), w));
+      y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), w));
+      z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), w));
+    }
+    if (tid == 0) idxs[j] = nk;
+  }
+}
+
+template <int NW, int PPT>
+static int launch_fps_regs(int b, int n, int m, int bs, int log2bs, const float *dataset,
+                           int *idxs, hipStream_t s) {
+  hipLaunchKernelGGL((fps_regs_kernel<NW, PPT>), dim3(b), dim3(NW * 64), 0, s, n, m, bs, log2bs,
+                     dataset, idxs);
+  return check_launch("furthest_point_sampling");
+}
+
 // fps_bucket.hip
 bool fps_bucket_supported(int n);
 size_t fps_bucket_workspace_bytes(int b, int n);
@@ -221,6 +367,23 @@ static bool fps_force_stream() {
   return e && e[0] == 's' && e[1] == 't';  // "stream" ("single" selects a bucket variant)
 }
 
+// BTR_FPS_REGS=legacy keeps the first register-resident kernel (A/B); BTR_FPS_REGS_NW=1|4|8|16
+// overrides the number of waves per scene.
+static bool fps_regs_legacy() {
+  const char *e = getenv("BTR_FPS_REGS");
+  return e && e[0] == 'l';
+}
+
+static int fps_regs_waves(int n) {
+  int nw = n <= 512 ? 1 : 4;  // measured: tools/fps_small_ab.py
+  if (const char *e = getenv("BTR_FPS_REGS_NW")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 4 || v == 8 || v == 16) nw = v;
+  }
+  if (nw == 1 && n > 1024) nw = 4;  // one wave holds at most 16 points per lane
+  return nw;
+}
+
 static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,
                         int bs, void *ws, size_t ws_bytes, hipStream_t s) {
   if (m <= 0 || b <= 0) return BTR_OK;  // sampling_gpu.cu:78
@@ -233,6 +396,19 @@ static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, 
   while ((1 << log2bs) < bs) ++log2bs;
   // register-resident kernels: at most 4 waves (one per SIMD) so the serial arg-max chain of
   // a step is never slowed by a co-resident wave
+  if (n <= kFpsRegsMaxN && !fps_regs_legacy()) {
+    int nw = fps_regs_waves(n);
+    const int per = (n + nw * 64 - 1) / (nw * 64);
+#define BTR_FPS_REGS(NW, PPT) \
+  if (nw == NW && per <= PPT) return launch_fps_regs<NW, PPT>(b, n, m, bs, log2bs, dataset, idxs, s)
+    BTR_FPS_REGS(1, 1); BTR_FPS_REGS(1, 2); BTR_FPS_REGS(1, 4); BTR_FPS_REGS(1, 8);
+    BTR_FPS_REGS(1, 16);
+    BTR_FPS_REGS(4, 1); BTR_FPS_REGS(4, 2); BTR_FPS_REGS(4, 4); BTR_FPS_REGS(4, 8);
+    BTR_FPS_REGS(4, 16);
+    BTR_FPS_REGS(8, 1); BTR_FPS_REGS(8, 2); BTR_FPS_REGS(8, 4); BTR_FPS_REGS(8, 8);
+    BTR_FPS_REGS(16, 1); BTR_FPS_REGS(16, 2); BTR_FPS_REGS(16, 4);
+#undef BTR_FPS_REGS
+  }
   if (n <= 64) return launch_fps<64, 1, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
   if (n <= 256) return launch_fps<256, 1, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
   if (n <= 512) return launch_fps<256, 2, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);

@@ -12,5 +12,6 @@ mkdir -p gpurun_out/$TAG
 DB=$(find /tmp/$TAG -name "*.db" | head -1)
 python tools/rocpd_step.py $DB fps_bucket_kernel gpurun_out/$TAG/one_step.md
 python tools/rocpd_stats.py $DB > gpurun_out/$TAG/kernel_stats.md 2>/dev/null || true
+python tools/rocpd_timeline.py $DB fps_bucket_kernel gpurun_out/$TAG/timeline.txt || true
 tail -1 /tmp/$TAG.log > gpurun_out/$TAG/bench.json
 head -3 gpurun_out/$TAG/one_step.md
