@@ -71,6 +71,10 @@ _SIGNATURES = {
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
+    # evaluation-side box arithmetic (used by votenet/ap_helper.py)
+    "btr_nms_boxes": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, ctypes.c_double, _ci, _vp, _vp]),
+    "btr_points_in_boxes": (_ci, [_ci] * 5 + [_vp] * 6),
+    "btr_box3d_iou": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -339,6 +343,73 @@ def three_interpolate_grad(grad_out, idx, weight, m):
         _call(_lib.btr_three_interpolate_grad, B, C, n, int(m), _p(grad_out), _p(idx),
               _p(weight), _p(out), _stream(dev))
     return out
+
+
+def _check64(t, name, like):
+    _require(isinstance(t, torch.Tensor) and t.is_contiguous() and t.dtype == torch.float64,
+             "%s must be a contiguous double tensor" % name)
+    _require(t.is_cuda and t.device == like.device, "%s must be on %s" % (name, like.device))
+
+
+def nms_boxes(boxes, score, threshold, old_type=False, cls=None, valid=None):
+    """Greedy NMS per scene (utils/nms.py:42-156).  boxes (B,K,4|6) f64 [mins, maxs], score
+    (B,K) f64, cls (B,K) i32 or None, valid (B,K) u8 or None -> pick (B,K) u8."""
+    _require(isinstance(boxes, torch.Tensor), "boxes must be a tensor")
+    _gpu_only(boxes)
+    _check64(boxes, "boxes", boxes)
+    _check64(score, "score", boxes)
+    _require(boxes.dim() == 3 and boxes.size(2) in (4, 6), "boxes must be (B, K, 4) or (B, K, 6)")
+    B, K, D = boxes.shape
+    _require(tuple(score.shape) == (B, K), "score must be (B, K)")
+    if cls is not None:
+        _check(cls, "cls", "int", like=boxes)
+        _require(tuple(cls.shape) == (B, K), "cls must be (B, K)")
+    if valid is not None:
+        _require(valid.dtype == torch.uint8 and valid.is_contiguous() and valid.is_cuda and
+                 tuple(valid.shape) == (B, K), "valid must be a contiguous (B, K) uint8 tensor")
+    pick = torch.empty((B, K), dtype=torch.uint8, device=boxes.device)
+    with _on(boxes) as dev:
+        _call(_lib.btr_nms_boxes, B, K, D // 2, _p(boxes), _p(score), _p(cls), _p(valid),
+              float(threshold), int(bool(old_type)), _p(pick), _stream(dev))
+    return pick
+
+
+def points_in_boxes(points, center, size, angle, cap):
+    """count (B,K) i32 = min(cap, points of scene b inside box k); points (B,N,C>=3) f32 in
+    upright-depth coordinates, boxes as get_3d_box takes them (camera coordinates), f64."""
+    _check(points, "points", "float")
+    _gpu_only(points)
+    _require(points.dim() == 3 and points.size(2) >= 3, "points must be (B, N, >=3)")
+    for t, name in ((center, "center"), (size, "size"), (angle, "angle")):
+        _check64(t, name, points)
+    B, N, C = points.shape
+    K = angle.size(1)
+    _require(tuple(center.shape) == (B, K, 3) and tuple(size.shape) == (B, K, 3) and
+             tuple(angle.shape) == (B, K), "center/size must be (B, K, 3), angle (B, K)")
+    count = torch.empty((B, K), dtype=torch.int32, device=points.device)
+    with _on(points) as dev:
+        _call(_lib.btr_points_in_boxes, B, N, K, C, int(cap), _p(points), _p(center), _p(size),
+              _p(angle), _p(count), _stream(dev))
+    return count
+
+
+def box3d_iou(corners1, corners2):
+    """(S,P,8,3) f64 x (S,G,8,3) f64 -> (S,P,G) f64: box3d_iou of utils/box_util.py:98-128."""
+    _require(isinstance(corners1, torch.Tensor), "corners1 must be a tensor")
+    _gpu_only(corners1)
+    _check64(corners1, "corners1", corners1)
+    _check64(corners2, "corners2", corners1)
+    _require(corners1.dim() == 4 and tuple(corners1.shape[2:]) == (8, 3) and
+             corners2.dim() == 4 and tuple(corners2.shape[2:]) == (8, 3) and
+             corners1.size(0) == corners2.size(0), "corners must be (S, P, 8, 3) and (S, G, 8, 3)")
+    S, P, G = corners1.size(0), corners1.size(1), corners2.size(1)
+    iou = torch.empty((S, P, G), dtype=torch.float64, device=corners1.device)
+    with _on(corners1) as dev:
+        for s0 in range(0, S, 32768):
+            s1 = min(S, s0 + 32768)
+            _call(_lib.btr_box3d_iou, s1 - s0, P, G, _p(corners1[s0:s1]), _p(corners2[s0:s1]),
+                  _p(iou[s0:s1]), _stream(dev))
+    return iou
 
 
 def opt_n_threads(work_size):

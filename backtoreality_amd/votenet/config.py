@@ -18,6 +18,37 @@ class DatasetConfig(object):
             mean_size_arr = rng.uniform(0.3, 1.8, size=(self.num_size_cluster, 3))
         self.mean_size_arr = np.asarray(mean_size_arr, dtype=np.float64)
         assert self.mean_size_arr.shape == (self.num_size_cluster, 3)
+        # ScanNet boxes are axis aligned: class2angle is constant 0 there
+        # (scannet/model_util_scannet.py:102-106); with heading bins it is the bin centre plus
+        # the residual (matterport/model_util_matterport.py:51-62).
+        self.axis_aligned = self.num_heading_bin == 1
+
+    def class2angle(self, pred_cls, residual, to_label_format=True):
+        """Inverse of angle2class for one box (scalars), float64."""
+        if self.axis_aligned:
+            return 0
+        angle = pred_cls * (2 * np.pi / float(self.num_heading_bin)) + residual
+        if to_label_format and angle > np.pi:
+            angle = angle - 2 * np.pi
+        return angle
+
+    def class2size(self, pred_cls, residual, ratio=1.0):
+        """Inverse of size2class: mean size of the cluster + residual (l, w, h), float64."""
+        return (self.mean_size_arr[pred_cls, :] + residual) * ratio
+
+    def class2angle_batch(self, pred_cls, residual):
+        """class2angle over tensors: (…) int64, (…) float -> (…) float64."""
+        import torch
+        if self.axis_aligned:
+            return torch.zeros(pred_cls.shape, dtype=torch.float64, device=pred_cls.device)
+        angle = pred_cls.double() * (2 * np.pi / float(self.num_heading_bin)) + residual.double()
+        return torch.where(angle > np.pi, angle - 2 * np.pi, angle)
+
+    def class2size_batch(self, pred_cls, residual):
+        """class2size over tensors: (…) int64, (…, 3) float -> (…, 3) float64."""
+        import torch
+        mean = torch.from_numpy(self.mean_size_arr).to(pred_cls.device)
+        return mean[pred_cls] + residual.double()
 
 
 def scannet_md40():

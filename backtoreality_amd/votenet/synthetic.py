@@ -133,3 +133,64 @@ def make_batch(first_index, batch_size, num_points=40000, config=None, use_heigh
     if device is not None:
         batch = {k: v.to(device) for k, v in batch.items()}
     return batch
+
+
+def make_eval_case(seed, batch_size, num_points, config, num_proposal=256, device=None):
+    """A labelled batch plus synthetic HEAD OUTPUTS for the evaluation path (ap_helper): about
+    70 % of the proposals sit near a ground-truth box (centre / size / heading / class perturbed),
+    the rest are random boxes in the room with low objectness, so that NMS, the confidence
+    threshold and both true and false positives all occur.  Every class of the config owns at
+    least one ground-truth box when the batch holds enough boxes.  Returns a dict with the
+    batch labels and 'center', 'heading_scores', 'heading_residuals', 'size_scores',
+    'size_residuals', 'sem_cls_scores', 'objectness_scores' (CPU tensors unless `device`)."""
+    batch = make_batch(seed, batch_size, num_points, config)
+    rng = np.random.default_rng(9000 + int(seed))
+    B, K = batch_size, num_proposal
+    NH, NS, NC = config.num_heading_bin, config.num_size_cluster, config.num_class
+    mask = batch['box_label_mask'].numpy()
+    sem = batch['sem_cls_label'].numpy().copy()
+    t = 0
+    for i in range(B):
+        for j in range(mask.shape[1]):
+            if mask[i, j] == 1:
+                sem[i, j] = t % NC
+                t += 1
+    batch['sem_cls_label'] = torch.from_numpy(sem)
+    gc = batch['center_label'].numpy()
+    ghc, ghr = batch['heading_class_label'].numpy(), batch['heading_residual_label'].numpy()
+    gsc, gsr = batch['size_class_label'].numpy(), batch['size_residual_label'].numpy()
+    pc = batch['point_clouds'].numpy()
+
+    center = np.zeros((B, K, 3), np.float32)
+    hs = rng.normal(0, 1, (B, K, NH)).astype(np.float32)
+    hr = rng.normal(0, 0.05, (B, K, NH)).astype(np.float32)
+    ss = rng.normal(0, 1, (B, K, NS)).astype(np.float32)
+    sr = rng.normal(0, 0.05, (B, K, NS, 3)).astype(np.float32)
+    sc = rng.normal(0, 1, (B, K, NC)).astype(np.float32)
+    ob = np.zeros((B, K, 2), np.float32)
+    for i in range(B):
+        valid = np.nonzero(mask[i] == 1)[0]
+        lo, hi = pc[i, :, :3].min(0), pc[i, :, :3].max(0)
+        for k in range(K):
+            if valid.size and rng.random() < 0.7:
+                g = valid[rng.integers(0, valid.size)]
+                center[i, k] = gc[i, g] + rng.normal(0, 0.08, 3)
+                hs[i, k, ghc[i, g]] += 4.0
+                hr[i, k, ghc[i, g]] += ghr[i, g]
+                ss[i, k, gsc[i, g]] += 4.0
+                sr[i, k, gsc[i, g]] += gsr[i, g]
+                sc[i, k, sem[i, g] if rng.random() < 0.85 else rng.integers(0, NC)] += 3.0
+                ob[i, k] = (-1.0, 1.0) + rng.normal(0, 0.8, 2)
+            else:
+                center[i, k] = rng.uniform(lo, hi)
+                ob[i, k] = (1.5, -1.5) + rng.normal(0, 1.0, 2)
+    out = dict(batch)
+    out.update({
+        'center': torch.from_numpy(center), 'heading_scores': torch.from_numpy(hs),
+        'heading_residuals': torch.from_numpy(hr), 'size_scores': torch.from_numpy(ss),
+        'size_residuals': torch.from_numpy(sr), 'sem_cls_scores': torch.from_numpy(sc),
+        'objectness_scores': torch.from_numpy(ob.astype(np.float32)),
+    })
+    if device is not None:
+        out = {k: v.to(device) for k, v in out.items()}
+    return out

@@ -165,6 +165,44 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0):
 
 
 # ------------------------------------------------------------------ checkpoints
+EVAL_CONFIG_DICT = {'remove_empty_box': False, 'use_3d_nms': True, 'nms_iou': 0.25,
+                    'use_old_type_nms': False, 'cls_nms': True, 'per_class_proposal': True,
+                    'conf_thresh': 0.05}  # train_Votenet_FSB.py:204-207
+
+
+def evaluate_one_epoch(net, batches, cfg, config_dict=None, ap_iou_thresh=0.25,
+                       class2type_map=None):
+    """The evaluation pass of the training scripts (train_Votenet_FSB.py:246-293): eval-mode
+    forward, loss statistics, parse_predictions / parse_groundtruths, AP.  `batches`: an
+    iterable of label dicts on the model's device.  Returns (mean stats dict, metrics dict).
+    The statistics stay on the device until the end (one host read per key instead of the
+    reference's `.item()` per key per batch)."""
+    from . import ap_helper
+    config_dict = dict(config_dict or EVAL_CONFIG_DICT, dataset_config=cfg)
+    calc = ap_helper.APCalculator(ap_iou_thresh=ap_iou_thresh, class2type_map=class2type_map)
+    was_training = net.training
+    net.eval()
+    stat, nb = {}, 0
+    try:
+        for batch in batches:
+            with torch.no_grad():
+                end_points = net({'point_clouds': batch['point_clouds']})
+                for key in batch:
+                    assert key not in end_points
+                    end_points[key] = batch[key]
+                _, end_points = loss_helper.get_loss(end_points, cfg)
+            for key, v in end_points.items():
+                if ('loss' in key or 'acc' in key or 'ratio' in key) and torch.is_tensor(v):
+                    stat[key] = stat.get(key, 0) + v.detach()
+            calc.step(ap_helper.parse_predictions(end_points, config_dict),
+                      ap_helper.parse_groundtruths(end_points, config_dict))
+            nb += 1
+    finally:
+        net.train(was_training)
+    stats = {k: float(v) / max(nb, 1) for k, v in sorted(stat.items())}
+    return stats, calc.compute_metrics()
+
+
 def save_checkpoint(path, net, optimizer, epoch, loss=None):
     """`checkpoint.tar` in the reference's wire format (train_Votenet_FSB.py:310-318): keys
     'epoch' (the NEXT epoch to run), 'optimizer_state_dict', 'loss', 'model_state_dict' (of the

@@ -289,6 +289,32 @@ int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
                          float *dagg, float *dvote, const float *weights8, int vote_mode,
                          const int *i2v, btr_stream_t stream);
 
+/* ---- Evaluation-side box arithmetic (the caller after the forward at eval time).
+ * The reference runs these per box in numpy / scipy on the host, in float64; so do the kernels.
+ *
+ * btr_nms_boxes: greedy NMS, one scene per workgroup -- nms_2d_faster / nms_3d_faster /
+ *   nms_3d_faster_samecls (detection/Votenet/utils/nms.py:42-156).  boxes (b,k,2*dim) f64 =
+ *   [min_0..min_{dim-1}, max_0..max_{dim-1}], dim 2 or 3; score (b,k) f64; cls (b,k) i32 or
+ *   NULL (NULL = boxes of different classes suppress each other too); valid (b,k) u8 or NULL
+ *   (rows the reference filters out before the call, ap_helper.py:145,163,183); old_type: the
+ *   overlap is inter / area(candidate) instead of the IoU.  pick (b,k) u8 <- 1 for kept boxes.
+ *   k <= 1024.  Equal scores: the higher index is visited first (numpy leaves it unspecified).
+ * btr_points_in_boxes: count (b,k) i32 <- min(cap, number of points of the scene inside box j)
+ *   -- `remove_empty_box` (models/ap_helper.py:116-127, extract_pc_in_box3d :27-30) without the
+ *   Delaunay triangulation per box.  points (b,n,point_stride) f32 in upright-depth coordinates
+ *   (the network input); center (b,k,3), size (b,k,3) = (l,w,h), angle (b,k): the box in
+ *   upright-camera coordinates as get_3d_box takes it (utils/box_util.py:211-227).
+ * btr_box3d_iou: iou (s,p,g) f64 <- box3d_iou (utils/box_util.py:98-128) of corners1 (s,p,8,3)
+ *   with corners2 (s,g,8,3), corner order of get_3d_box, upright-camera coordinates. */
+int btr_nms_boxes(int b, int k, int dim, const double *boxes, const double *score,
+                  const int *cls, const unsigned char *valid, double threshold, int old_type,
+                  unsigned char *pick, btr_stream_t stream);
+int btr_points_in_boxes(int b, int n, int k, int point_stride, int cap, const float *points,
+                        const double *center, const double *size, const double *angle,
+                        int *count, btr_stream_t stream);
+int btr_box3d_iou(int nscene, int p, int g, const double *corners1, const double *corners2,
+                  double *iou, btr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
