@@ -198,6 +198,29 @@ class PointnetSAModuleCenters(_SingleScaleSA):
         return new_features
 
 
+class PointnetSAModuleOffset(_SingleScaleSA):
+    """Set abstraction around GIVEN points, GroupFree3D's detector_DA
+    (detection/GroupFree3D/pointnet2/pointnet2_modules.py:481-576):
+    forward(xyz, features, new_xyz (B,npoint,3)) -> new_features (B,mlp[-1],npoint)
+    [, unique_cnt when ret_unique_cnt]."""
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor, new_xyz: torch.Tensor):
+        new_features, unique_cnt = self._group_and_pool(xyz, new_xyz, features)
+        if not self.ret_unique_cnt:
+            return new_features
+        return new_features, unique_cnt
+
+
+def ThreeNNInterpolate(known_feats, known_xyz, unknown_xyz):
+    """Inverse-distance 3-NN interpolation of `known_feats (B,C,m)` at `unknown_xyz (B,n,3)`
+    (detection/GroupFree3D/pointnet2/pointnet2_modules.py:722-730)."""
+    dist, idx = pointnet2_utils.three_nn(unknown_xyz, known_xyz)
+    dist_recip = 1.0 / (dist + 1e-8)
+    norm = torch.sum(dist_recip, dim=2, keepdim=True)
+    weight = dist_recip / norm
+    return pointnet2_utils.three_interpolate(known_feats, idx, weight)
+
+
 class PointnetFPModule(nn.Module):
     """Feature propagation: inverse-distance 3-NN interpolation of `known_feats` onto the
     `unknown` points, concatenated with their skip features, then a SharedMLP (:454-514)."""

@@ -34,7 +34,8 @@ def test_modules_are_keyword_only_like_the_reference():
         M.PointnetFPModule([4, 4])
     for name in ("PointnetSAModuleVotes", "PointnetFPModule", "PointnetSAModuleCenters",
                  "PointnetSAModuleMSG", "PointnetSAModule", "PointnetSAModuleMSGVotes",
-                 "PointnetLFPModuleMSG", "_PointnetSAModuleBase"):
+                 "PointnetLFPModuleMSG", "_PointnetSAModuleBase", "PointnetSAModuleOffset",
+                 "ThreeNNInterpolate"):
         assert hasattr(M, name)
 
 
@@ -129,6 +130,16 @@ def test_sa_variants_run(oracle_ext):
         assert m(xyz, feats)[1].shape == (2, 8, 16)
     centers = M.PointnetSAModuleCenters(npoint=5, radius=0.8, nsample=16, mlp=[4, 8])
     assert centers(xyz, feats, xyz[:, :5].contiguous()).shape == (2, 8, 5)
+    # GroupFree3D's variants: same computation as ...Centers, and the bare interpolation
+    offset = M.PointnetSAModuleOffset(npoint=5, radius=0.8, nsample=16, mlp=[4, 8])
+    offset.load_state_dict(centers.state_dict())
+    assert torch.equal(offset(xyz, feats, xyz[:, :5].contiguous()),
+                       centers(xyz, feats, xyz[:, :5].contiguous()))
+    fp = M.PointnetFPModule(mlp=[4, 4])
+    up = M.ThreeNNInterpolate(feats[:, :, :16].contiguous(), xyz[:, :16].contiguous(), xyz)
+    assert up.shape == (2, 4, xyz.shape[1])
+    assert torch.allclose(up[:, :, :16], feats[:, :, :16], atol=1e-4)  # a known point: itself
+    del fp
     msg = M.PointnetSAModuleMSG(npoint=16, radii=[0.4, 0.8], nsamples=[4, 8],
                                 mlps=[[4, 8], [4, 16]])
     nx, nf = msg(xyz, feats)
