@@ -1,0 +1,146 @@
+"""GroupFreeDetector (detection/GroupFree3D/models/detector.py:15-232), same constructor,
+attribute names (state-dict keys) and end_points keys."""
+import torch
+import torch.nn as nn
+
+from ..votenet.backbone_module import Pointnet2Backbone
+from .modules import (FPSModule, GeneralSamplingModule, PointsObjClsModule,
+                      PositionEmbeddingLearned, PredictHead)
+from .transformer import TransformerDecoderLayer
+
+
+class GroupFreeDetector(nn.Module):
+    """Backbone -> seed objectness -> top-k (KPS) or FPS query points -> proposal head ->
+    `num_decoder_layers` x (decoder layer + prediction head), each head refining the previous
+    head's (detached) box as the next layer's query position."""
+
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr,
+                 input_feature_dim=0, width=1, bn_momentum=0.1, sync_bn=False, num_proposal=128,
+                 sampling='kps', dropout=0.1, activation="relu", nhead=8, num_decoder_layers=6,
+                 dim_feedforward=2048, self_position_embedding='xyz_learned',
+                 cross_position_embedding='xyz_learned'):
+        super().__init__()
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_size_cluster = num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        assert mean_size_arr.shape[0] == self.num_size_cluster
+        self.input_feature_dim = input_feature_dim
+        self.num_proposal = num_proposal
+        self.bn_momentum = bn_momentum
+        self.sync_bn = sync_bn
+        self.width = width
+        self.nhead = nhead
+        self.sampling = sampling
+        self.num_decoder_layers = num_decoder_layers
+        self.dim_feedforward = dim_feedforward
+        self.self_position_embedding = self_position_embedding
+        self.cross_position_embedding = cross_position_embedding
+        if width != 1:
+            raise NotImplementedError("backbone width %r (the reference default 1 only)" % width)
+
+        self.backbone_net = Pointnet2Backbone(input_feature_dim=self.input_feature_dim,
+                                              fp2_out=288)
+        if self.sampling == 'fps':
+            self.fps_module = FPSModule(num_proposal)
+        elif self.sampling == 'kps':
+            self.points_obj_cls = PointsObjClsModule(288)
+            self.gsample_module = GeneralSamplingModule()
+        else:
+            raise NotImplementedError
+        head = lambda: PredictHead(num_class, num_heading_bin, num_size_cluster, mean_size_arr,
+                                   num_proposal, 288)
+        self.proposal_head = head()
+        if self.num_decoder_layers <= 0:
+            return
+
+        self.decoder_key_proj = nn.Conv1d(288, 288, kernel_size=1)
+        self.decoder_query_proj = nn.Conv1d(288, 288, kernel_size=1)
+
+        n = self.num_decoder_layers
+        self_dim = {'none': None, 'xyz_learned': 3, 'loc_learned': 6}
+        cross_dim = {'none': None, 'xyz_learned': 3}
+        if self_position_embedding not in self_dim:
+            raise NotImplementedError(
+                "self_position_embedding not supported %s" % self_position_embedding)
+        if cross_position_embedding not in cross_dim:
+            raise NotImplementedError(
+                "cross_position_embedding not supported %s" % cross_position_embedding)
+        if self_dim[self_position_embedding] is None:
+            self.decoder_self_posembeds = [None] * n
+        else:
+            self.decoder_self_posembeds = nn.ModuleList(
+                PositionEmbeddingLearned(self_dim[self_position_embedding], 288) for _ in range(n))
+        if cross_dim[cross_position_embedding] is None:
+            self.decoder_cross_posembeds = [None] * n
+        else:
+            self.decoder_cross_posembeds = nn.ModuleList(
+                PositionEmbeddingLearned(3, 288) for _ in range(n))
+
+        self.decoder = nn.ModuleList(
+            TransformerDecoderLayer(288, nhead, dim_feedforward, dropout, activation,
+                                    self_posembed=self.decoder_self_posembeds[i],
+                                    cross_posembed=self.decoder_cross_posembeds[i])
+            for i in range(n))
+        self.prediction_heads = nn.ModuleList(head() for _ in range(n))
+
+        self.init_weights()
+        self.init_bn_momentum()
+        if self.sync_bn:
+            nn.SyncBatchNorm.convert_sync_batchnorm(self)
+
+    def forward(self, inputs):
+        """inputs {'point_clouds': (B, N, 3 + input_feature_dim)} -> end_points."""
+        end_points = self.backbone_net(inputs['point_clouds'], {})
+        points_xyz = end_points['fp2_xyz']
+        points_features = end_points['fp2_features']
+        end_points['seed_inds'] = end_points['fp2_inds']
+        end_points['seed_xyz'] = points_xyz
+        end_points['seed_features'] = points_features
+        if self.sampling == 'fps':
+            xyz, features, sample_inds = self.fps_module(points_xyz, points_features)
+        else:
+            logits = self.points_obj_cls(points_features)            # (B, 1, num_seed)
+            end_points['seeds_obj_cls_logits'] = logits
+            scores = torch.sigmoid(logits).squeeze(1)
+            sample_inds = torch.topk(scores, self.num_proposal)[1].int()
+            xyz, features, sample_inds = self.gsample_module(points_xyz, points_features,
+                                                             sample_inds)
+        cluster_feature, cluster_xyz = features, xyz
+        end_points['query_points_xyz'] = xyz
+        end_points['query_points_feature'] = features
+        end_points['query_points_sample_inds'] = sample_inds
+
+        center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz,
+                                          end_points=end_points, prefix='proposal_')
+        base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        if self.num_decoder_layers <= 0:
+            return end_points
+
+        query = self.decoder_query_proj(cluster_feature)
+        key = self.decoder_key_proj(points_features)
+        key_pos = None if self.cross_position_embedding == 'none' else points_xyz
+        for i in range(self.num_decoder_layers):
+            prefix = 'last_' if i == self.num_decoder_layers - 1 else '%dhead_' % i
+            if self.self_position_embedding == 'none':
+                query_pos = None
+            elif self.self_position_embedding == 'xyz_learned':
+                query_pos = base_xyz
+            else:
+                query_pos = torch.cat([base_xyz, base_size], -1)
+            query = self.decoder[i](query, key, query_pos, key_pos)
+            center, size = self.prediction_heads[i](query, base_xyz=cluster_xyz,
+                                                    end_points=end_points, prefix=prefix)
+            base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        return end_points
+
+    def init_weights(self):
+        # xavier on every decoder matrix, position-embedding convolutions included
+        for p in self.decoder.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def init_bn_momentum(self):
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.momentum = self.bn_momentum

@@ -1,0 +1,208 @@
+"""GroupFree3D training loss (detection/GroupFree3D/models/loss_helper.py:17-319,
+models/losses.py): query-point generation (sigmoid focal loss on the k seeds nearest to each
+box centre), and per prediction head (proposal + every decoder layer) the objectness focal
+loss, box losses and semantic cross-entropy with the labels of the object the query point
+lies in.  Labels beyond VoteNet's: 'size_gts' (B,K2,3), 'point_obj_mask' (B,N) i64,
+'point_instance_label' (B,N) i64 (-1 = background)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def smoothl1_loss(error, delta=1.0):
+    """0.5 x^2 / d for |x| < d, |x| - 0.5 d beyond (losses.py:5-13)."""
+    diff = torch.abs(error)
+    return torch.where(diff < delta, 0.5 * diff * diff / delta, diff - 0.5 * delta)
+
+
+def l1_loss(error):
+    return torch.abs(error)
+
+
+def sigmoid_focal_loss(logits, target, weights, gamma=2.0, alpha=0.25):
+    """SigmoidFocalClassificationLoss.forward (losses.py:21-81): logits / target (B,P,C),
+    weights (B,P) -> weighted focal loss (B,P,C)."""
+    p = torch.sigmoid(logits)
+    alpha_w = target * alpha + (1 - target) * (1 - alpha)
+    pt = target * (1.0 - p) + (1.0 - target) * p
+    bce = torch.clamp(logits, min=0) - logits * target + torch.log1p(torch.exp(-torch.abs(logits)))
+    return alpha_w * torch.pow(pt, gamma) * bce * weights.unsqueeze(-1)
+
+
+def head_prefixes(num_decoder_layers):
+    if num_decoder_layers > 0:
+        return ['proposal_', 'last_'] + ['%dhead_' % i for i in range(num_decoder_layers - 1)]
+    return ['proposal_']
+
+
+def compute_points_obj_cls_loss_hard_topk(end_points, topk):
+    """loss_helper.py:17-78: a seed is positive when it belongs to an object and is among the
+    `topk` seeds of that object closest (in box-size units) to the object's centre."""
+    box_label_mask = end_points['box_label_mask']
+    seed_inds = end_points['seed_inds'].long()
+    seed_xyz = end_points['seed_xyz']
+    logits = end_points['seeds_obj_cls_logits']
+    gt_center = end_points['center_label'][:, :, 0:3]
+    gt_size = end_points['size_gts'][:, :, 0:3]
+    B, K, K2 = gt_center.shape[0], seed_xyz.shape[1], gt_center.shape[1]
+    dev = seed_xyz.device
+
+    point_instance_label = end_points['point_instance_label']
+    seed_instance = torch.gather(point_instance_label, 1, seed_inds)              # (B,K)
+    assignment = torch.where(seed_instance < 0, torch.full_like(seed_instance, K2 - 1),
+                             seed_instance)
+    one_hot = torch.zeros((B, K, K2), device=dev)
+    one_hot.scatter_(2, assignment.unsqueeze(-1), 1)
+    delta = (seed_xyz.unsqueeze(2) - gt_center.unsqueeze(1)) / (gt_size.unsqueeze(1) + 1e-6)
+    dist = torch.sqrt(torch.sum(delta ** 2, dim=-1) + 1e-6)                         # (B,K,K2)
+    dist = (dist * one_hot + 100 * (1 - one_hot)).transpose(1, 2).contiguous()      # (B,K2,K)
+    topk_inds = torch.topk(dist, topk, largest=False)[1] * box_label_mask[:, :, None] + \
+        (box_label_mask[:, :, None] - 1)          # padded boxes -> index -1 (the spare column)
+    topk_inds = topk_inds.long().view(B, -1)
+
+    label = torch.zeros((B, K + 1), dtype=torch.long, device=dev)
+    label.scatter_(1, torch.where(topk_inds < 0, torch.full_like(topk_inds, K), topk_inds), 1)
+    label = label[:, :K]
+    label = torch.where(seed_instance < 0, torch.zeros_like(label), label)
+
+    total = B * K
+    end_points['points_hard_topk%d_pos_ratio' % topk] = torch.sum(label.float()) / float(total)
+    end_points['points_hard_topk%d_neg_ratio' % topk] = \
+        1 - end_points['points_hard_topk%d_pos_ratio' % topk]
+
+    weights = (label >= 0).float()
+    weights = weights / torch.clamp(weights.sum(dim=1, keepdim=True), min=1.0)
+    loss = sigmoid_focal_loss(logits.view(B, K, 1), label.unsqueeze(-1).float(), weights)
+    return loss.sum() / B
+
+
+def compute_objectness_loss_based_on_query_points(end_points, num_decoder_layers):
+    """loss_helper.py:81-137: objectness target of a query point = whether its seed point lies
+    in an object; its box target = that object (background -> the last ground-truth slot)."""
+    seed_inds = end_points['seed_inds'].long()
+    sample_inds = end_points['query_points_sample_inds'].long()
+    K2 = end_points['center_label'].shape[1]
+    B, K = sample_inds.shape
+    obj_gt = torch.gather(torch.gather(end_points['point_obj_mask'], 1, seed_inds), 1, sample_inds)
+    instance = torch.gather(torch.gather(end_points['point_instance_label'], 1, seed_inds), 1,
+                            sample_inds)
+    assignment = torch.where(instance < 0, torch.full_like(instance, K2 - 1), instance)
+    mask = torch.ones((B, K), device=seed_inds.device)
+    total = float(B * K)
+    weights = mask / torch.clamp(mask.sum(dim=1, keepdim=True), min=1.0)
+
+    loss_sum = 0.0
+    for prefix in head_prefixes(num_decoder_layers):
+        end_points[prefix + 'objectness_label'] = obj_gt
+        # (the reference normalises its all-ones mask IN PLACE after storing it, :114-128: what
+        # callers find under this key is 1/K per query point)
+        end_points[prefix + 'objectness_mask'] = weights
+        end_points[prefix + 'object_assignment'] = assignment
+        end_points[prefix + 'pos_ratio'] = torch.sum(obj_gt.float()) / total
+        end_points[prefix + 'neg_ratio'] = torch.sum(mask) / total - end_points[prefix + 'pos_ratio']
+        scores = end_points[prefix + 'objectness_scores']                 # (B, K, 1)
+        # the reference flattens the TRANSPOSED (B,1,K) tensor, which is the same memory order
+        loss = sigmoid_focal_loss(scores.transpose(2, 1).contiguous().view(B, K, 1),
+                                  obj_gt.unsqueeze(-1).float(), weights).sum() / B
+        end_points[prefix + 'objectness_loss'] = loss
+        loss_sum = loss_sum + loss
+    return loss_sum, end_points
+
+
+def compute_box_and_sem_cls_loss(end_points, config, num_decoder_layers,
+                                 center_loss_type='smoothl1', center_delta=1.0,
+                                 size_loss_type='smoothl1', size_delta=1.0,
+                                 heading_loss_type='smoothl1', heading_delta=1.0):
+    """loss_helper.py:140-275: per head, masked by the objectness label and normalised by the
+    number of positive query points."""
+    nh, ns = config.num_heading_bin, config.num_size_cluster
+    gt_center = end_points['center_label'][:, :, 0:3]
+    dev = gt_center.device
+    mean_size = torch.from_numpy(np.ascontiguousarray(config.mean_size_arr, np.float32)).to(dev)
+
+    def reg(err, kind, delta):
+        if kind == 'smoothl1':
+            return smoothl1_loss(err, delta=delta)
+        if kind == 'l1':
+            return l1_loss(err)
+        raise NotImplementedError
+
+    box_sum, sem_sum = 0.0, 0.0
+    for prefix in head_prefixes(num_decoder_layers):
+        assignment = end_points[prefix + 'object_assignment']
+        label = end_points[prefix + 'objectness_label'].float()
+        npos = torch.sum(label) + 1e-6
+        a3 = assignment.unsqueeze(2).expand(-1, -1, 3)
+
+        center_loss = reg(torch.gather(gt_center, 1, a3) - end_points[prefix + 'center'],
+                          center_loss_type, center_delta)
+        center_loss = torch.sum(center_loss * label.unsqueeze(2)) / npos
+
+        hcls = torch.gather(end_points['heading_class_label'], 1, assignment)
+        heading_class_loss = F.cross_entropy(end_points[prefix + 'heading_scores'].transpose(2, 1),
+                                             hcls, reduction='none')
+        heading_class_loss = torch.sum(heading_class_loss * label) / npos
+        hres = torch.gather(end_points['heading_residual_label'], 1, assignment) / (np.pi / nh)
+        h_one_hot = F.one_hot(hcls, nh).float()
+        h_err = torch.sum(end_points[prefix + 'heading_residuals_normalized'] * h_one_hot, -1) - hres
+        heading_reg = reg(h_err, heading_loss_type, heading_delta)
+        if heading_loss_type == 'smoothl1':
+            heading_reg = heading_delta * heading_reg
+        heading_reg = torch.sum(heading_reg * label) / npos
+
+        scls = torch.gather(end_points['size_class_label'], 1, assignment)
+        size_class_loss = F.cross_entropy(end_points[prefix + 'size_scores'].transpose(2, 1), scls,
+                                          reduction='none')
+        size_class_loss = torch.sum(size_class_loss * label) / npos
+        sres = torch.gather(end_points['size_residual_label'], 1, a3)
+        s_one_hot = F.one_hot(scls, ns).float().unsqueeze(-1).expand(-1, -1, -1, 3)
+        pred_res = torch.sum(end_points[prefix + 'size_residuals_normalized'] * s_one_hot, 2)
+        mean_label = torch.sum(s_one_hot * mean_size.unsqueeze(0).unsqueeze(0), 2)
+        size_reg = reg(pred_res - sres / mean_label, size_loss_type, size_delta)
+        if size_loss_type == 'smoothl1':
+            size_reg = size_delta * size_reg
+        size_reg = torch.sum(size_reg * label.unsqueeze(2)) / npos
+
+        sem_label = torch.gather(end_points['sem_cls_label'], 1, assignment)
+        sem_loss = F.cross_entropy(end_points[prefix + 'sem_cls_scores'].transpose(2, 1),
+                                   sem_label, reduction='none')
+        sem_loss = torch.sum(sem_loss * label) / npos
+
+        box_loss = center_loss + 0.1 * heading_class_loss + heading_reg + 0.1 * size_class_loss + \
+            size_reg
+        end_points[prefix + 'center_loss'] = center_loss
+        end_points[prefix + 'heading_cls_loss'] = heading_class_loss
+        end_points[prefix + 'heading_reg_loss'] = heading_reg
+        end_points[prefix + 'size_cls_loss'] = size_class_loss
+        end_points[prefix + 'size_reg_loss'] = size_reg
+        end_points[prefix + 'box_loss'] = box_loss
+        end_points[prefix + 'sem_cls_loss'] = sem_loss
+        box_sum = box_sum + box_loss
+        sem_sum = sem_sum + sem_loss
+    return box_sum, sem_sum, end_points
+
+
+def get_loss(end_points, config, num_decoder_layers, query_points_generator_loss_coef,
+             obj_loss_coef, box_loss_coef, sem_cls_loss_coef, query_points_obj_topk=5,
+             center_loss_type='smoothl1', center_delta=1.0, size_loss_type='smoothl1',
+             size_delta=1.0, heading_loss_type='smoothl1', heading_delta=1.0):
+    """loss_helper.py:278-319; returns (loss, end_points)."""
+    if 'seeds_obj_cls_logits' in end_points:
+        gen_loss = compute_points_obj_cls_loss_hard_topk(end_points, query_points_obj_topk)
+        end_points['query_points_generation_loss'] = gen_loss
+    else:
+        gen_loss = 0.0
+    obj_sum, end_points = compute_objectness_loss_based_on_query_points(end_points,
+                                                                        num_decoder_layers)
+    end_points['sum_heads_objectness_loss'] = obj_sum
+    box_sum, sem_sum, end_points = compute_box_and_sem_cls_loss(
+        end_points, config, num_decoder_layers, center_loss_type, center_delta=center_delta,
+        size_loss_type=size_loss_type, size_delta=size_delta,
+        heading_loss_type=heading_loss_type, heading_delta=heading_delta)
+    end_points['sum_heads_box_loss'] = box_sum
+    end_points['sum_heads_sem_cls_loss'] = sem_sum
+    loss = query_points_generator_loss_coef * gen_loss + 1.0 / (num_decoder_layers + 1) * (
+        obj_loss_coef * obj_sum + box_loss_coef * box_sum + sem_cls_loss_coef * sem_sum)
+    loss = loss * 10
+    end_points['loss'] = loss
+    return loss, end_points

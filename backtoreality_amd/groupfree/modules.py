@@ -1,0 +1,136 @@
+"""Sampling and head modules of GroupFree3D (detection/GroupFree3D/models/modules.py), same
+class / attribute names so reference checkpoints load."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..pointnet2 import pointnet2_utils
+
+
+class PointsObjClsModule(nn.Module):
+    """Per-seed objectness logit used to pick the query points (modules.py:17-47):
+    (B, C, num_seed) -> (B, 1, num_seed)."""
+
+    def __init__(self, seed_feature_dim):
+        super().__init__()
+        self.in_dim = seed_feature_dim
+        self.conv1 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.bn1 = nn.BatchNorm1d(self.in_dim)
+        self.conv2 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.bn2 = nn.BatchNorm1d(self.in_dim)
+        self.conv3 = nn.Conv1d(self.in_dim, 1, 1)
+
+    def forward(self, seed_features):
+        net = F.relu(self.bn1(self.conv1(seed_features)))
+        net = F.relu(self.bn2(self.conv2(net)))
+        return self.conv3(net)
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """Learned absolute position embedding: (B, P, 3|6) -> (B, 288, P) (modules.py:50-65)."""
+
+    def __init__(self, input_channel, num_pos_feats=288):
+        super().__init__()
+        self.position_embedding_head = nn.Sequential(
+            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1),
+            nn.BatchNorm1d(num_pos_feats),
+            nn.ReLU(inplace=True),
+            nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+
+    def forward(self, xyz):
+        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+
+
+def _take(xyz, features, sample_inds):
+    """Rows `sample_inds` of (B,K,3) coordinates and (B,C,K) features (gather_points kernel)."""
+    new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(),
+                                               sample_inds).transpose(1, 2).contiguous()
+    new_features = pointnet2_utils.gather_operation(features, sample_inds).contiguous()
+    return new_xyz, new_features, sample_inds
+
+
+class FPSModule(nn.Module):
+    """Query points by furthest point sampling of the seeds (modules.py:68-86)."""
+
+    def __init__(self, num_proposal):
+        super().__init__()
+        self.num_proposal = num_proposal
+
+    def forward(self, xyz, features):
+        return _take(xyz, features, pointnet2_utils.furthest_point_sample(xyz, self.num_proposal))
+
+
+class GeneralSamplingModule(nn.Module):
+    """Query points at given seed indices (modules.py:89-104)."""
+
+    def forward(self, xyz, features, sample_inds):
+        return _take(xyz, features, sample_inds)
+
+
+class PredictHead(nn.Module):
+    """Box head on (B, C, num_proposal) features (modules.py:107-193): objectness (1 logit),
+    centre residual w.r.t. `base_xyz`, heading / size class scores and normalised residuals,
+    semantic scores; fills end_points['<prefix>...'] and returns (center, pred_size)."""
+
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr, num_proposal,
+                 seed_feat_dim=256):
+        super().__init__()
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_size_cluster = num_size_cluster
+        self.mean_size_arr = mean_size_arr
+        self.num_proposal = num_proposal
+        self.seed_feat_dim = seed_feat_dim
+
+        self.conv1 = nn.Conv1d(seed_feat_dim, seed_feat_dim, 1)
+        self.bn1 = nn.BatchNorm1d(seed_feat_dim)
+        self.conv2 = nn.Conv1d(seed_feat_dim, seed_feat_dim, 1)
+        self.bn2 = nn.BatchNorm1d(seed_feat_dim)
+
+        self.objectness_scores_head = nn.Conv1d(seed_feat_dim, 1, 1)
+        self.center_residual_head = nn.Conv1d(seed_feat_dim, 3, 1)
+        self.heading_class_head = nn.Conv1d(seed_feat_dim, num_heading_bin, 1)
+        self.heading_residual_head = nn.Conv1d(seed_feat_dim, num_heading_bin, 1)
+        self.size_class_head = nn.Conv1d(seed_feat_dim, num_size_cluster, 1)
+        self.size_residual_head = nn.Conv1d(seed_feat_dim, num_size_cluster * 3, 1)
+        self.sem_cls_scores_head = nn.Conv1d(seed_feat_dim, self.num_class, 1)
+        self._mean_size = None
+
+    def _mean_size_on(self, device):
+        if self._mean_size is None or self._mean_size.device != device:
+            self._mean_size = torch.from_numpy(
+                np.ascontiguousarray(self.mean_size_arr, np.float32)).to(device)
+        return self._mean_size
+
+    def forward(self, features, base_xyz, end_points, prefix=''):
+        B, P = features.shape[0], features.shape[-1]
+        net = F.relu(self.bn1(self.conv1(features)))
+        net = F.relu(self.bn2(self.conv2(net)))
+        objectness_scores = self.objectness_scores_head(net).transpose(2, 1)
+        center = base_xyz + self.center_residual_head(net).transpose(2, 1)
+
+        heading_scores = self.heading_class_head(net).transpose(2, 1)
+        heading_residuals_normalized = self.heading_residual_head(net).transpose(2, 1)
+        heading_residuals = heading_residuals_normalized * (np.pi / self.num_heading_bin)
+
+        mean_size = self._mean_size_on(features.device).unsqueeze(0).unsqueeze(0)
+        size_scores = self.size_class_head(net).transpose(2, 1)
+        size_residuals_normalized = self.size_residual_head(net).transpose(2, 1).view(
+            [B, P, self.num_size_cluster, 3])
+        size_residuals = size_residuals_normalized * mean_size
+        size_recover = size_residuals + mean_size
+        pick = torch.argmax(size_scores, -1).unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 1, 3)
+        pred_size = torch.gather(size_recover, 2, pick).squeeze(2)
+        sem_cls_scores = self.sem_cls_scores_head(net).transpose(2, 1)
+
+        for key, value in (('base_xyz', base_xyz), ('objectness_scores', objectness_scores),
+                           ('center', center), ('heading_scores', heading_scores),
+                           ('heading_residuals_normalized', heading_residuals_normalized),
+                           ('heading_residuals', heading_residuals),
+                           ('size_scores', size_scores),
+                           ('size_residuals_normalized', size_residuals_normalized),
+                           ('size_residuals', size_residuals), ('pred_size', pred_size),
+                           ('sem_cls_scores', sem_cls_scores)):
+            end_points[prefix + key] = value
+        return center, pred_size

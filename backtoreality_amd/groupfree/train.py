@@ -1,0 +1,52 @@
+"""Training step of GroupFree3D (detection/GroupFree3D/train_GF_FSB.py:196-322): model,
+AdamW with the decoder's own learning rate, loss with the script's default coefficients,
+gradient clipping."""
+import torch
+
+from .detector import GroupFreeDetector
+from .loss_helper import get_loss
+
+# train_GF_FSB.py:42-52
+LOSS_ARGS = dict(num_decoder_layers=6, query_points_generator_loss_coef=0.8, obj_loss_coef=0.1,
+                 box_loss_coef=1, sem_cls_loss_coef=0.1, query_points_obj_topk=4,
+                 center_loss_type='smoothl1', center_delta=1.0, size_loss_type='smoothl1',
+                 size_delta=1.0, heading_loss_type='smoothl1', heading_delta=1.0)
+
+
+def build_model(cfg, device, input_feature_dim=0, num_proposal=256, seed=0, **kw):
+    """Random-init GroupFreeDetector with the script defaults (train_GF_FSB.py:26-34,196-217:
+    no height channel unless --use_height, 256 query points, KPS sampling, six decoder layers,
+    dropout 0.1)."""
+    torch.manual_seed(seed)
+    net = GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                            cfg.mean_size_arr, input_feature_dim=input_feature_dim,
+                            num_proposal=num_proposal, **kw)
+    return net.to(device)
+
+
+def make_optimizer(net, lr=0.004, decoder_lr=0.0004, weight_decay=0.0005):
+    """AdamW, decoder parameters at their own learning rate (train_GF_FSB.py:233-244); the
+    fused multi-tensor implementation on the GPU."""
+    named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    groups = [{"params": [p for n, p in named if "decoder" not in n]},
+              {"params": [p for n, p in named if "decoder" in n], "lr": decoder_lr}]
+    fused = all(p.is_cuda for _, p in named)
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=fused)
+
+
+def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1):
+    """One optimisation step (train_GF_FSB.py:287-322) on `batch` (label dict on the model's
+    device, GroupFree3D schema: VoteNet's keys + size_gts, point_obj_mask,
+    point_instance_label).  Returns (loss, end_points); no host synchronisation."""
+    loss_args = dict(LOSS_ARGS, **(loss_args or {}))
+    end_points = net({'point_clouds': batch['point_clouds']})
+    for key in batch:
+        assert key not in end_points
+        end_points[key] = batch[key]
+    loss, end_points = get_loss(end_points, cfg, **loss_args)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if clip_norm > 0:
+        torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
+    optimizer.step()
+    return loss, end_points

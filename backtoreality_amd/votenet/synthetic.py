@@ -51,6 +51,7 @@ def make_scene(index, num_points=40000, config=None, use_height=True, kind="surf
     N = int(num_points)
     votes = np.zeros((N, 3))
     vote_mask = np.zeros((N,), np.int64)
+    instance = np.full((N,), -1, np.int64)   # which box a point belongs to (GroupFree3D labels)
     if kind == "surface":
         n_floor = int(0.35 * N)
         n_wall = int(0.35 * N)
@@ -73,6 +74,7 @@ def make_scene(index, num_points=40000, config=None, use_height=True, kind="surf
         pts = np.concatenate([floor, wall, obj], 0)
         votes[n_floor + n_wall:] = np.concatenate(obj_vote, 0)
         vote_mask[n_floor + n_wall:] = 1
+        instance[n_floor + n_wall:] = np.repeat(np.arange(nbox), per)
         pts = pts + rng.normal(0.0, 0.005, size=pts.shape)
     elif kind == "uniform":
         pts = rng.uniform(0, 1, size=(N, 3)) * ext
@@ -80,12 +82,13 @@ def make_scene(index, num_points=40000, config=None, use_height=True, kind="surf
         for b in range(nbox):
             m = np.all(np.abs(pts - centers[b]) <= 0.5 * sizes[b], axis=1) & ~inside
             votes[m] = centers[b] - pts[m]
+            instance[m] = b
             inside |= m
         vote_mask[inside] = 1
     else:
         raise ValueError(kind)
     perm = rng.permutation(N)
-    pts, votes, vote_mask = pts[perm], votes[perm], vote_mask[perm]
+    pts, votes, vote_mask, instance = pts[perm], votes[perm], vote_mask[perm], instance[perm]
 
     pc = pts.astype(np.float32)
     if use_height:
@@ -105,7 +108,13 @@ def make_scene(index, num_points=40000, config=None, use_height=True, kind="surf
         'box_label_mask': np.zeros((K,), np.float32),
         'vote_label': np.tile(votes, (1, 3)).astype(np.float32),  # 3 identical GT votes
         'vote_label_mask': vote_mask,
+        # GroupFree3D's extra labels (GroupFree3D/scannet/scannet_detection_dataset.py:181,
+        # 220-258)
+        'size_gts': np.zeros((K, 3), np.float32),
+        'point_obj_mask': (instance >= 0).astype(np.int64),
+        'point_instance_label': instance,
     }
+    ret['size_gts'][:nbox] = sizes
     ret['center_label'][:nbox] = centers
     ret['size_class_label'][:nbox] = size_cls
     ret['size_residual_label'][:nbox] = sizes - config.mean_size_arr[size_cls]

@@ -1,0 +1,182 @@
+"""GroupFree3D (backtoreality_amd/groupfree: detector, decoder, loss -- SURVEY 8(f) #2) against
+tests/golden/groupfree_step.npz, generated from the REFERENCE's GroupFreeDetector + get_loss
+(detection/GroupFree3D/models/) by tests/golden/make_golden.py --groupfree.  The CPU run goes
+through the oracle `_ext`; the GPU twin through the HIP kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from backtoreality_amd import groupfree
+from backtoreality_amd.votenet import config, synthetic
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "groupfree_step.npz")
+LOSS_ARGS = dict(num_decoder_layers=6, query_points_generator_loss_coef=0.8, obj_loss_coef=0.1,
+                 box_loss_coef=1, sem_cls_loss_coef=0.1, query_points_obj_topk=4)
+PREFIXES = ['proposal_', 'last_'] + ['%dhead_' % i for i in range(5)]
+
+
+def run(device):
+    cfg = config.scannet_md40()
+    batch = synthetic.make_batch(0, 2, 4096, cfg, use_height=False, device=device)
+    torch.manual_seed(0)
+    net = groupfree.GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                      cfg.mean_size_arr, input_feature_dim=0, num_proposal=256,
+                                      dropout=0.0).to(device)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    names = sorted(sd)
+    sig = (names, np.array([float(sd[k].double().sum()) for k in names]),
+           [str(tuple(sd[k].shape)) for k in names])
+    end_points = net({'point_clouds': batch['point_clouds']})
+    end_points.update(batch)
+    loss, end_points = groupfree.get_loss(end_points, cfg, **LOSS_ARGS)
+    loss.backward()
+    return net, sig, end_points
+
+
+def _sub(t, sample, sums, rtol, stride):
+    a = t.detach().cpu().numpy().astype(np.float32).ravel()
+    scale = np.abs(sample).max() + 1e-12
+    np.testing.assert_allclose(a[::stride], sample, rtol=rtol, atol=rtol * scale)
+    np.testing.assert_allclose(np.abs(a.astype(np.float64)).sum(), sums[1], rtol=rtol)
+
+
+def check(res, rtol, grad_rtol):
+    g = np.load(GOLD)
+    net, (names, sums, shapes), ep = res
+    # reference checkpoints load: identical state-dict keys (the decoder layers' aliases of
+    # the position embeddings included), shapes and seeded initial values
+    assert names == list(g['state_names']) and shapes == list(g['state_shapes'])
+    np.testing.assert_allclose(sums, g['state_sums'], rtol=1e-6, atol=1e-6)
+    for k in ('sa1_inds', 'seed_inds'):
+        np.testing.assert_array_equal(ep[k].cpu().numpy(), g[k])
+    _sub(ep['fp2_features'], g['fp2_features_sample'], g['fp2_features_sums'], rtol, 37)
+    lg = g['seeds_obj_cls_logits']
+    np.testing.assert_allclose(ep['seeds_obj_cls_logits'].detach().cpu().numpy(), lg, rtol=rtol,
+                               atol=rtol * np.abs(lg).max())
+    # k-closest-point sampling: the same top-k seeds in the same order (a swap is only
+    # possible between scores closer than rounding)
+    inds = ep['query_points_sample_inds'].cpu().numpy()
+    assert inds.dtype == np.int32
+    assert np.array_equal(np.sort(inds, 1), np.sort(g['query_points_sample_inds'], 1))
+    same_order = np.array_equal(inds, g['query_points_sample_inds'])
+    for p in PREFIXES:
+        np.testing.assert_array_equal(ep[p + 'objectness_label'].cpu().numpy()[
+            np.arange(2)[:, None], np.argsort(inds, 1)],
+            g[p + 'objectness_label'][np.arange(2)[:, None],
+                                      np.argsort(g['query_points_sample_inds'], 1)])
+        if same_order:
+            for k in ('object_assignment', 'objectness_label'):
+                np.testing.assert_array_equal(ep[p + k].cpu().numpy(), g[p + k])
+            np.testing.assert_allclose(ep[p + 'objectness_mask'].cpu().numpy(),
+                                       g[p + 'objectness_mask'], rtol=1e-6)
+            for k in ('center', 'objectness_scores', 'sem_cls_scores', 'pred_size',
+                      'heading_residuals', 'size_scores'):
+                want = g[p + k]
+                np.testing.assert_allclose(ep[p + k].detach().cpu().numpy(), want,
+                                           rtol=10 * rtol, atol=10 * rtol * np.abs(want).max())
+            _sub(ep[p + 'size_residuals'], g[p + 'size_residuals_sample'],
+                 g[p + 'size_residuals_sums'], 10 * rtol, 37)
+        for k in ('objectness_loss', 'center_loss', 'heading_cls_loss', 'heading_reg_loss',
+                  'size_cls_loss', 'size_reg_loss', 'box_loss', 'sem_cls_loss', 'pos_ratio',
+                  'neg_ratio'):
+            a, b = float(ep[p + k]), float(g[p + k])
+            assert abs(a - b) <= 10 * rtol * max(1.0, abs(b)), (p + k, a, b)
+    for k in ('loss', 'query_points_generation_loss', 'sum_heads_objectness_loss',
+              'sum_heads_box_loss', 'sum_heads_sem_cls_loss', 'points_hard_topk4_pos_ratio',
+              'points_hard_topk4_neg_ratio'):
+        a, b = float(ep[k]), float(g[k])
+        assert abs(a - b) <= 10 * rtol * max(1.0, abs(b)), (k, a, b)
+    grads = {'grad_sa1_w0': net.backbone_net.sa1.mlp_module.layer0.conv.weight.grad,
+             'grad_obj_cls_conv3': net.points_obj_cls.conv3.weight.grad,
+             'grad_proposal_conv1': net.proposal_head.conv1.weight.grad,
+             'grad_dec0_self_in_proj': net.decoder[0].self_attn.in_proj_weight.grad,
+             'grad_dec5_linear2': net.decoder[5].linear2.weight.grad,
+             'grad_dec3_cross_pos0':
+                 net.decoder_cross_posembeds[3].position_embedding_head[0].weight.grad,
+             'grad_key_proj': net.decoder_key_proj.weight.grad,
+             'grad_head2_center': net.prediction_heads[2].center_residual_head.weight.grad}
+    for k, t in grads.items():
+        a = t.detach().cpu().numpy().astype(np.float32).ravel()[::53]
+        want = g[k + '_sample']
+        rel = np.linalg.norm(a - want) / (np.linalg.norm(want) + 1e-30)
+        assert rel <= grad_rtol, (k, rel)
+
+
+def test_groupfree_step_matches_reference_cpu(oracle_ext, monkeypatch):
+    monkeypatch.setenv("BTR_FUSED_SA", "0")
+    check(run(torch.device("cpu")), rtol=1e-4, grad_rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_groupfree_step_matches_reference_gpu(cuda):
+    check(run(cuda), rtol=1e-4, grad_rtol=2e-2)
+
+
+def test_groupfree_variants_build_and_name_their_heads():
+    cfg = config.scannet_md40()
+    net = groupfree.GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                      cfg.mean_size_arr, num_proposal=64, sampling='fps',
+                                      num_decoder_layers=2, self_position_embedding='loc_learned')
+    assert not hasattr(net, 'points_obj_cls') and len(net.decoder) == 2
+    assert net.decoder[0].self_posembed is net.decoder_self_posembeds[0]
+    assert net.decoder_self_posembeds[0].position_embedding_head[0].in_channels == 6
+    bare = groupfree.GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                       cfg.mean_size_arr, num_decoder_layers=0)
+    assert not hasattr(bare, 'decoder')
+    from backtoreality_amd.groupfree.loss_helper import head_prefixes
+    assert head_prefixes(0) == ['proposal_']
+    assert head_prefixes(3) == ['proposal_', 'last_', '0head_', '1head_']
+    with pytest.raises(NotImplementedError):
+        groupfree.GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                    cfg.mean_size_arr, sampling='random')
+
+
+@pytest.mark.gpu
+def test_groupfree_train_steps(cuda):
+    """Training-mode steps with the script defaults (dropout 0.1, clip 0.1, AdamW groups) on
+    the fused SA path: finite losses, every parameter receives a gradient, the decoder group
+    runs at its own learning rate."""
+    from backtoreality_amd.groupfree import train as gf_train
+    cfg = config.scannet_md40()
+    net = gf_train.build_model(cfg, cuda)
+    opt = gf_train.make_optimizer(net)
+    assert [g['lr'] for g in opt.param_groups] == [0.004, 0.0004]
+    n_dec = sum(p.numel() for n, p in net.named_parameters() if "decoder" in n)
+    assert sum(p.numel() for p in opt.param_groups[1]['params']) == n_dec > 10e6
+    batch = synthetic.make_batch(0, 2, 8192, cfg, use_height=False, device=cuda)
+    losses = []
+    for _ in range(3):
+        loss, end = gf_train.train_step(net, opt, batch, cfg)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)), losses
+    missing = [n for n, p in net.named_parameters() if p.grad is None]
+    assert not missing, missing
+    assert end['last_center'].shape == (2, 256, 3) and end['seeds_obj_cls_logits'].shape == (2, 1, 1024)
+
+
+@pytest.mark.gpu
+def test_groupfree_eval_through_ap_helper(cuda):
+    """The last decoder head's boxes through the evaluation path (the reference's GroupFree3D
+    ap_helper takes a prefix; the keys are copied to the un-prefixed names here)."""
+    from backtoreality_amd.groupfree import train as gf_train
+    from backtoreality_amd.votenet import ap_helper, train
+    cfg = config.scannet_md40()
+    net = gf_train.build_model(cfg, cuda).eval()
+    batch = synthetic.make_batch(0, 2, 8192, cfg, use_height=False, device=cuda)
+    with torch.no_grad():
+        end = net({'point_clouds': batch['point_clouds']})
+    end.update(batch)
+    for k in ('center', 'heading_scores', 'heading_residuals', 'size_scores', 'size_residuals',
+              'sem_cls_scores'):
+        end[k] = end['last_' + k]
+    # one sigmoid logit -> the two-class logits parse_predictions takes
+    obj = end['last_objectness_scores']
+    end['objectness_scores'] = torch.cat([torch.zeros_like(obj), obj], -1)
+    cd = dict(train.EVAL_CONFIG_DICT, dataset_config=cfg, conf_thresh=0.0)
+    pred = ap_helper.parse_predictions(end, cd)
+    gt = ap_helper.parse_groundtruths(end, cd)
+    calc = ap_helper.APCalculator(0.25)
+    calc.step(pred, gt)
+    assert 'mAP' in calc.compute_metrics()
