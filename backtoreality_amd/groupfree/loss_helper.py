@@ -9,6 +9,17 @@ import torch
 import torch.nn.functional as F
 
 
+def _mean_size(config, dev):
+    cache = getattr(config, "_mean_size_dev", None)
+    if cache is None or cache.device != dev:
+        cache = torch.from_numpy(np.ascontiguousarray(config.mean_size_arr, np.float32)).to(dev)
+        try:
+            config._mean_size_dev = cache
+        except AttributeError:
+            pass
+    return cache
+
+
 def smoothl1_loss(error, delta=1.0):
     """0.5 x^2 / d for |x| < d, |x| - 0.5 d beyond (losses.py:5-13)."""
     diff = torch.abs(error)
@@ -118,7 +129,7 @@ def compute_box_and_sem_cls_loss(end_points, config, num_decoder_layers,
     nh, ns = config.num_heading_bin, config.num_size_cluster
     gt_center = end_points['center_label'][:, :, 0:3]
     dev = gt_center.device
-    mean_size = torch.from_numpy(np.ascontiguousarray(config.mean_size_arr, np.float32)).to(dev)
+    mean_size = _mean_size(config, dev)   # cached on the device: no per-step H2D copy
 
     def reg(err, kind, delta):
         if kind == 'smoothl1':

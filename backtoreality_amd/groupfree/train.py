@@ -24,14 +24,15 @@ def build_model(cfg, device, input_feature_dim=0, num_proposal=256, seed=0, **kw
     return net.to(device)
 
 
-def make_optimizer(net, lr=0.004, decoder_lr=0.0004, weight_decay=0.0005):
+def make_optimizer(net, lr=0.004, decoder_lr=0.0004, weight_decay=0.0005, capturable=False):
     """AdamW, decoder parameters at their own learning rate (train_GF_FSB.py:233-244); the
-    fused multi-tensor implementation on the GPU."""
+    fused multi-tensor implementation on the GPU (`capturable`: for GraphedTrainStep)."""
     named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
     groups = [{"params": [p for n, p in named if "decoder" not in n]},
               {"params": [p for n, p in named if "decoder" in n], "lr": decoder_lr}]
     fused = all(p.is_cuda for _, p in named)
-    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=fused)
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=fused,
+                             capturable=bool(capturable and fused))
 
 
 def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1):
@@ -50,3 +51,38 @@ def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1):
         torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
     optimizer.step()
     return loss, end_points
+
+
+class GraphedTrainStep(object):
+    """The whole training step captured once into a HIP graph and replayed.
+
+    A GroupFree3D step is ~3 500 kernel launches (six decoder layers, seven prediction heads
+    with eight loss terms each); enqueueing them costs the host 44 ms while the GPU needs 25 ms
+    (tools/gf_times.py), so the eager loop is host-bound.  Replaying a captured graph removes
+    the enqueue cost.  Conditions: fixed batch shapes (labels are copied into static buffers
+    by `__call__`), AdamW with `capturable=True` (step counter on the device), no host reads
+    inside the step -- all true for `train_step`.  Learning-rate changes must go through
+    tensor-valued `lr`s; BatchNorm momentum changes need a new capture."""
+
+    def __init__(self, net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, warmup=3):
+        self.static = {k: v.clone() for k, v in batch.items()}
+        self.net, self.optimizer = net, optimizer
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                train_step(net, optimizer, self.static, cfg, loss_args, clip_norm)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.end_points = train_step(net, optimizer, self.static, cfg, loss_args,
+                                                    clip_norm)
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            for k, v in batch.items():
+                if v is not self.static[k]:
+                    self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.loss, self.end_points

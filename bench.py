@@ -47,6 +47,9 @@ def parse():
                         "cr: br + the CenterRefine centre head / jitter regressor; gf: "
                         "GroupFree3D (configs[3] shape: 50 000 points without the height "
                         "channel, batch 4 unless --points / --batch are given)")
+    p.add_argument("--no-graph", action="store_true",
+                   help="gf only: enqueue the step kernel by kernel instead of replaying the "
+                        "captured HIP graph (the eager GroupFree3D loop is host-bound)")
     p.add_argument("--cpu-points", type=int, default=40000)
     return p.parse_args()
 
@@ -115,7 +118,8 @@ def main():
         if args.points == 40000 and args.batch == 8:      # configs[3]: 4 x 50 000 points
             args.points, args.batch = 50000, 4
         net = gf_train.build_model(cfg, dev)
-        opt = gf_train.make_optimizer(net)
+        graphed = world == 1 and not args.no_graph
+        opt = gf_train.make_optimizer(net, capturable=graphed)
     else:
         net = train.build_model(cfg, dev, domain_adaptation=br, center_refine=cr)
         opt = train.make_optimizer(net)
@@ -124,8 +128,15 @@ def main():
     jit = 0.1 if cr else 0.0
     batch = synthetic.make_batch(rank * B, B, args.points, cfg, device=dev,
                                  center_jitter=jit, use_height=not gf)  # resident in HBM
+    eager_step = None
     if gf:
-        train_step = gf_train.train_step
+        train_step = eager_step = gf_train.train_step
+        if graphed:
+            # one capture of the whole step (forward, loss, backward, clip, AdamW); every
+            # timed step is one replay: ~3 500 launches whose enqueue costs more host time
+            # (41 ms) than the GPU needs to run them (21 ms)
+            gs = gf_train.GraphedTrainStep(net, opt, batch, cfg)
+            train_step = lambda n, o, b, c: gs(b)  # noqa: E731
     elif br:  # source + target branch: two forwards, one backward (train_Votenet_BR.py:267-289)
         batch_T = synthetic.make_batch(100000 + rank * B, B, args.points, cfg, device=dev,
                                        center_jitter=jit)
@@ -169,7 +180,7 @@ def main():
     detail_steps = 3
     _ext.timing_begin()
     for _ in range(detail_steps):
-        train_step(ddp, opt, batch, cfg)
+        (eager_step or train_step)(ddp, opt, batch, cfg)
     barrier()
     detail = _ext.timing_end()
     # Secondary figure (never `value`): the same K steps with the NEXT batch's sampling pyramid
@@ -220,7 +231,9 @@ def main():
                                    ((B, args.points) if (br or gf) else (args.points, B)),
                        "points": args.points, "batch_per_gpu": B, "parallelism": "dp%d" % world},
         }
-        out.update(roofline_objects(kernels, detail, detail_steps))
+        if gf:
+            out["hip_graph"] = bool(graphed)
+        out.update(roofline_objects(kernels or detail, detail, detail_steps))
         if pipelined is not None:
             out["pipelined"] = {
                 "value": world * B * args.steps / pipelined, "unit": "scenes/s",

@@ -180,3 +180,36 @@ def test_groupfree_eval_through_ap_helper(cuda):
     calc = ap_helper.APCalculator(0.25)
     calc.step(pred, gt)
     assert 'mAP' in calc.compute_metrics()
+
+
+@pytest.mark.gpu
+def test_groupfree_graphed_step_trains_like_the_eager_step(cuda):
+    """The captured HIP graph replays the same step: with dropout off, the parameters after
+    one eager warm-up step and two replays equal the parameters after three eager steps (up to atomics order)."""
+    from backtoreality_amd.groupfree import train as gf_train
+    cfg = config.scannet_md40()
+    batch = synthetic.make_batch(0, 2, 8192, cfg, use_height=False, device=cuda)
+    nets = []
+    for graphed in (False, True):
+        net = gf_train.build_model(cfg, cuda, dropout=0.0)
+        opt = gf_train.make_optimizer(net, capturable=graphed)
+        if graphed:   # one eager step inside the constructor (warm-up), then two replays
+            step = gf_train.GraphedTrainStep(net, opt, batch, cfg, warmup=1)
+            for _ in range(2):
+                loss, _ = step(batch)
+        else:
+            for _ in range(3):
+                loss, _ = gf_train.train_step(net, opt, batch, cfg)
+        nets.append((net, float(loss)))
+    (ne, le), (ng, lg) = nets
+    # (float atomics order differs between runs and top-k query sampling amplifies it: two
+    # eager runs differ by as much)
+    assert abs(le - lg) <= 3e-2 * abs(le), (le, lg)
+    # Adam moves a parameter by ~lr per step whatever the gradient's size, so parameters whose
+    # gradient is rounding noise differ by up to steps * lr; compare in aggregate
+    num = sum(float((a - b).double().pow(2).sum())
+              for a, b in zip(ne.parameters(), ng.parameters()))
+    den = sum(float(a.double().pow(2).sum()) for a in ne.parameters())
+    assert (num / den) ** 0.5 <= 1e-2, (num / den) ** 0.5   # a replay that did nothing: 0.15
+    for a, b in zip(ne.parameters(), ng.parameters()):
+        assert float((a - b).abs().max()) <= 3 * 0.004 + 1e-6
