@@ -87,6 +87,13 @@ def compute_points_obj_cls_loss_hard_topk(end_points, topk):
     return loss.sum() / B
 
 
+def _stack(end_points, prefixes, key):
+    """(H, ...) tensor of one head output over all prediction heads: the seven heads share
+    their targets, so every loss term is evaluated once on the stacked tensor instead of once
+    per head (7x fewer launches; the per-head scalars are views of one (H,) vector)."""
+    return torch.stack([end_points[p + key] for p in prefixes], 0)
+
+
 def compute_objectness_loss_based_on_query_points(end_points, num_decoder_layers):
     """loss_helper.py:81-137: objectness target of a query point = whether its seed point lies
     in an object; its box target = that object (background -> the last ground-truth slot)."""
@@ -101,23 +108,26 @@ def compute_objectness_loss_based_on_query_points(end_points, num_decoder_layers
     mask = torch.ones((B, K), device=seed_inds.device)
     total = float(B * K)
     weights = mask / torch.clamp(mask.sum(dim=1, keepdim=True), min=1.0)
+    pos_ratio = torch.sum(obj_gt.float()) / total
+    neg_ratio = torch.sum(mask) / total - pos_ratio
 
-    loss_sum = 0.0
-    for prefix in head_prefixes(num_decoder_layers):
+    prefixes = head_prefixes(num_decoder_layers)
+    scores = _stack(end_points, prefixes, 'objectness_scores')            # (H, B, K, 1)
+    # (the reference flattens the TRANSPOSED (B,1,K) tensor: the same memory order)
+    loss = sigmoid_focal_loss(scores.reshape(-1, K, 1),
+                              obj_gt.unsqueeze(-1).float().repeat(len(prefixes), 1, 1),
+                              weights.repeat(len(prefixes), 1))
+    loss = loss.view(len(prefixes), -1).sum(1) / B                         # (H,)
+    for h, prefix in enumerate(prefixes):
         end_points[prefix + 'objectness_label'] = obj_gt
         # (the reference normalises its all-ones mask IN PLACE after storing it, :114-128: what
         # callers find under this key is 1/K per query point)
         end_points[prefix + 'objectness_mask'] = weights
         end_points[prefix + 'object_assignment'] = assignment
-        end_points[prefix + 'pos_ratio'] = torch.sum(obj_gt.float()) / total
-        end_points[prefix + 'neg_ratio'] = torch.sum(mask) / total - end_points[prefix + 'pos_ratio']
-        scores = end_points[prefix + 'objectness_scores']                 # (B, K, 1)
-        # the reference flattens the TRANSPOSED (B,1,K) tensor, which is the same memory order
-        loss = sigmoid_focal_loss(scores.transpose(2, 1).contiguous().view(B, K, 1),
-                                  obj_gt.unsqueeze(-1).float(), weights).sum() / B
-        end_points[prefix + 'objectness_loss'] = loss
-        loss_sum = loss_sum + loss
-    return loss_sum, end_points
+        end_points[prefix + 'pos_ratio'] = pos_ratio
+        end_points[prefix + 'neg_ratio'] = neg_ratio
+        end_points[prefix + 'objectness_loss'] = loss[h]
+    return loss.sum(), end_points
 
 
 def compute_box_and_sem_cls_loss(end_points, config, num_decoder_layers,
@@ -130,67 +140,69 @@ def compute_box_and_sem_cls_loss(end_points, config, num_decoder_layers,
     gt_center = end_points['center_label'][:, :, 0:3]
     dev = gt_center.device
     mean_size = _mean_size(config, dev)   # cached on the device: no per-step H2D copy
+    prefixes = head_prefixes(num_decoder_layers)
+    H = len(prefixes)
 
-    def reg(err, kind, delta):
+    # targets: identical for every head (set by compute_objectness_loss_based_on_query_points)
+    assignment = end_points[prefixes[0] + 'object_assignment']
+    label = end_points[prefixes[0] + 'objectness_label'].float()           # (B, K)
+    npos = torch.sum(label) + 1e-6
+    B, K = label.shape
+    a3 = assignment.unsqueeze(2).expand(-1, -1, 3)
+    per_head = lambda t: t.reshape(H, -1).sum(1) / npos                    # noqa: E731
+
+    err = torch.gather(gt_center, 1, a3).unsqueeze(0) - _stack(end_points, prefixes, 'center')
+    if center_loss_type == 'smoothl1':
+        center_loss = smoothl1_loss(err, delta=center_delta)
+    elif center_loss_type == 'l1':
+        center_loss = l1_loss(err)
+    else:
+        raise NotImplementedError
+    center_loss = per_head(center_loss * label.unsqueeze(2))
+
+    def cls_loss(key, target, nclass):
+        scores = _stack(end_points, prefixes, key).reshape(-1, nclass)     # (H*B*K, C)
+        ce = F.cross_entropy(scores, target.reshape(-1).repeat(H), reduction='none')
+        return per_head(ce.view(H, B, K) * label)
+
+    def res_loss(err, kind, delta):
         if kind == 'smoothl1':
-            return smoothl1_loss(err, delta=delta)
+            return delta * smoothl1_loss(err, delta=delta)
         if kind == 'l1':
             return l1_loss(err)
         raise NotImplementedError
 
-    box_sum, sem_sum = 0.0, 0.0
-    for prefix in head_prefixes(num_decoder_layers):
-        assignment = end_points[prefix + 'object_assignment']
-        label = end_points[prefix + 'objectness_label'].float()
-        npos = torch.sum(label) + 1e-6
-        a3 = assignment.unsqueeze(2).expand(-1, -1, 3)
+    hcls = torch.gather(end_points['heading_class_label'], 1, assignment)
+    heading_class_loss = cls_loss('heading_scores', hcls, nh)
+    hres = torch.gather(end_points['heading_residual_label'], 1, assignment) / (np.pi / nh)
+    h_one_hot = F.one_hot(hcls, nh).float()
+    h_err = torch.sum(_stack(end_points, prefixes, 'heading_residuals_normalized') * h_one_hot,
+                      -1) - hres
+    heading_reg = per_head(res_loss(h_err, heading_loss_type, heading_delta) * label)
 
-        center_loss = reg(torch.gather(gt_center, 1, a3) - end_points[prefix + 'center'],
-                          center_loss_type, center_delta)
-        center_loss = torch.sum(center_loss * label.unsqueeze(2)) / npos
+    scls = torch.gather(end_points['size_class_label'], 1, assignment)
+    size_class_loss = cls_loss('size_scores', scls, ns)
+    sres = torch.gather(end_points['size_residual_label'], 1, a3)
+    s_one_hot = F.one_hot(scls, ns).float().unsqueeze(-1).expand(-1, -1, -1, 3)
+    pred_res = torch.sum(_stack(end_points, prefixes, 'size_residuals_normalized') * s_one_hot, 3)
+    mean_label = torch.sum(s_one_hot * mean_size.unsqueeze(0).unsqueeze(0), 2)
+    size_reg = per_head(res_loss(pred_res - sres / mean_label, size_loss_type, size_delta) *
+                        label.unsqueeze(2))
 
-        hcls = torch.gather(end_points['heading_class_label'], 1, assignment)
-        heading_class_loss = F.cross_entropy(end_points[prefix + 'heading_scores'].transpose(2, 1),
-                                             hcls, reduction='none')
-        heading_class_loss = torch.sum(heading_class_loss * label) / npos
-        hres = torch.gather(end_points['heading_residual_label'], 1, assignment) / (np.pi / nh)
-        h_one_hot = F.one_hot(hcls, nh).float()
-        h_err = torch.sum(end_points[prefix + 'heading_residuals_normalized'] * h_one_hot, -1) - hres
-        heading_reg = reg(h_err, heading_loss_type, heading_delta)
-        if heading_loss_type == 'smoothl1':
-            heading_reg = heading_delta * heading_reg
-        heading_reg = torch.sum(heading_reg * label) / npos
+    sem_label = torch.gather(end_points['sem_cls_label'], 1, assignment)
+    sem_loss = cls_loss('sem_cls_scores', sem_label, config.num_class)
 
-        scls = torch.gather(end_points['size_class_label'], 1, assignment)
-        size_class_loss = F.cross_entropy(end_points[prefix + 'size_scores'].transpose(2, 1), scls,
-                                          reduction='none')
-        size_class_loss = torch.sum(size_class_loss * label) / npos
-        sres = torch.gather(end_points['size_residual_label'], 1, a3)
-        s_one_hot = F.one_hot(scls, ns).float().unsqueeze(-1).expand(-1, -1, -1, 3)
-        pred_res = torch.sum(end_points[prefix + 'size_residuals_normalized'] * s_one_hot, 2)
-        mean_label = torch.sum(s_one_hot * mean_size.unsqueeze(0).unsqueeze(0), 2)
-        size_reg = reg(pred_res - sres / mean_label, size_loss_type, size_delta)
-        if size_loss_type == 'smoothl1':
-            size_reg = size_delta * size_reg
-        size_reg = torch.sum(size_reg * label.unsqueeze(2)) / npos
-
-        sem_label = torch.gather(end_points['sem_cls_label'], 1, assignment)
-        sem_loss = F.cross_entropy(end_points[prefix + 'sem_cls_scores'].transpose(2, 1),
-                                   sem_label, reduction='none')
-        sem_loss = torch.sum(sem_loss * label) / npos
-
-        box_loss = center_loss + 0.1 * heading_class_loss + heading_reg + 0.1 * size_class_loss + \
-            size_reg
-        end_points[prefix + 'center_loss'] = center_loss
-        end_points[prefix + 'heading_cls_loss'] = heading_class_loss
-        end_points[prefix + 'heading_reg_loss'] = heading_reg
-        end_points[prefix + 'size_cls_loss'] = size_class_loss
-        end_points[prefix + 'size_reg_loss'] = size_reg
-        end_points[prefix + 'box_loss'] = box_loss
-        end_points[prefix + 'sem_cls_loss'] = sem_loss
-        box_sum = box_sum + box_loss
-        sem_sum = sem_sum + sem_loss
-    return box_sum, sem_sum, end_points
+    box_loss = center_loss + 0.1 * heading_class_loss + heading_reg + 0.1 * size_class_loss + \
+        size_reg
+    for h, prefix in enumerate(prefixes):
+        end_points[prefix + 'center_loss'] = center_loss[h]
+        end_points[prefix + 'heading_cls_loss'] = heading_class_loss[h]
+        end_points[prefix + 'heading_reg_loss'] = heading_reg[h]
+        end_points[prefix + 'size_cls_loss'] = size_class_loss[h]
+        end_points[prefix + 'size_reg_loss'] = size_reg[h]
+        end_points[prefix + 'box_loss'] = box_loss[h]
+        end_points[prefix + 'sem_cls_loss'] = sem_loss[h]
+    return box_loss.sum(), sem_loss.sum(), end_points
 
 
 def get_loss(end_points, config, num_decoder_layers, query_points_generator_loss_coef,

@@ -107,22 +107,26 @@ class PredictHead(nn.Module):
         B, P = features.shape[0], features.shape[-1]
         net = F.relu(self.bn1(self.conv1(features)))
         net = F.relu(self.bn2(self.conv2(net)))
-        objectness_scores = self.objectness_scores_head(net).transpose(2, 1)
-        center = base_xyz + self.center_residual_head(net).transpose(2, 1)
-
-        heading_scores = self.heading_class_head(net).transpose(2, 1)
-        heading_residuals_normalized = self.heading_residual_head(net).transpose(2, 1)
+        # the seven output layers are 1x1 convolutions of the same `net`: one convolution with
+        # the concatenated weights (116 output channels at ScanNet sizes) instead of seven of
+        # 1..66 channels; the parameters stay separate (state-dict keys of the reference)
+        heads = (self.objectness_scores_head, self.center_residual_head, self.heading_class_head,
+                 self.heading_residual_head, self.size_class_head, self.size_residual_head,
+                 self.sem_cls_scores_head)
+        out = F.conv1d(net, torch.cat([h.weight for h in heads], 0),
+                       torch.cat([h.bias for h in heads], 0)).transpose(2, 1)   # (B, P, sum)
+        (objectness_scores, center_residual, heading_scores, heading_residuals_normalized,
+         size_scores, size_residuals_flat, sem_cls_scores) = torch.split(
+            out, [h.out_channels for h in heads], dim=2)
+        center = base_xyz + center_residual
         heading_residuals = heading_residuals_normalized * (np.pi / self.num_heading_bin)
 
         mean_size = self._mean_size_on(features.device).unsqueeze(0).unsqueeze(0)
-        size_scores = self.size_class_head(net).transpose(2, 1)
-        size_residuals_normalized = self.size_residual_head(net).transpose(2, 1).view(
-            [B, P, self.num_size_cluster, 3])
+        size_residuals_normalized = size_residuals_flat.reshape(B, P, self.num_size_cluster, 3)
         size_residuals = size_residuals_normalized * mean_size
         size_recover = size_residuals + mean_size
         pick = torch.argmax(size_scores, -1).unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 1, 3)
         pred_size = torch.gather(size_recover, 2, pick).squeeze(2)
-        sem_cls_scores = self.sem_cls_scores_head(net).transpose(2, 1)
 
         for key, value in (('base_xyz', base_xyz), ('objectness_scores', objectness_scores),
                            ('center', center), ('heading_scores', heading_scores),
