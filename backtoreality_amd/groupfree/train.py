@@ -3,6 +3,7 @@ AdamW with the decoder's own learning rate, loss with the script's default coeff
 gradient clipping."""
 import torch
 
+from ..votenet.train import _sync_grads
 from .detector import GroupFreeDetector
 from .loss_helper import get_loss
 
@@ -47,6 +48,7 @@ def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1):
     loss, end_points = get_loss(end_points, cfg, **loss_args)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
+    _sync_grads(net)          # data parallel: one all-reduce of the flat gradient buffer
     if clip_norm > 0:
         torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
     optimizer.step()

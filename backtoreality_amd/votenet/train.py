@@ -23,7 +23,10 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # BTR_FORCE_DDP=1: a one-rank process group, so that the DDP wrapper and RCCL run on a
+    # single GPU too (what a 1-GPU box can check of the N>1 path: tools/ddp_one_rank.sh)
+    force = os.environ.get("BTR_FORCE_DDP", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -47,17 +50,98 @@ def build_model(cfg, device, input_feature_dim=1, num_proposal=256, vote_factor=
     return net.to(device)
 
 
+class FlatGradParallel(torch.nn.Module):
+    """Data parallelism for this model without the DistributedDataParallel machinery: after the
+    backward the gradients are gathered into ONE flat f32 buffer by one multi-tensor copy, the
+    only collective of the path (the gradient mean, 3.8 MB) is ONE all-reduce of
+    that buffer, and every `.grad` is re-pointed at its slice of the buffer (no copy back).
+
+    Why not DDP: its per-iteration bookkeeping (an autograd hook and an accumulate / copy
+    kernel per parameter, two wrapped forwards per Back-to-Reality step) costs 0.25-1.2 ms of
+    a 9.6 / 18.2 ms step on ONE rank (tools/ddp_one_rank.sh); overlapping the all-reduce with
+    the backward, the thing that machinery buys, hides <0.1 ms here (3.8 MB over xGMI).
+    `BTR_DP=ddp` selects DistributedDataParallel instead.  Same interface where the step
+    functions touch it: `.module`, call = forward, `state_dict()` keys prefixed `module.`.
+    Parameters are broadcast from rank 0 at construction; buffers (BatchNorm statistics)
+    are per replica, like the reference (`broadcast_buffers=False`, train_GF_FSB.py:250).
+    A parameter without a gradient (the CenterRefine model's jitter_netD) contributes zeros and
+    keeps `.grad = None`, so the optimizer skips it on every rank alike."""
+
+    def __init__(self, module, process_group=None):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.world = dist.get_world_size(process_group)
+        params = [p for p in module.parameters() if p.requires_grad]
+        assert params and all(p.dtype == torch.float32 for p in params)
+        dev = params[0].device
+        assert all(p.device == dev for p in params)
+        with torch.no_grad():
+            for p in module.parameters():
+                dist.broadcast(p.data, 0, group=process_group)
+        total = sum(p.numel() for p in params)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._views = []
+        o = 0
+        for p in params:
+            self._views.append((p, self.flat_grad[o:o + p.numel()].view_as(p)))
+            o += p.numel()
+        self._avg = dist.get_backend(process_group) == "nccl"   # RCCL has AVG; gloo only sums
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def sync_gradients(self):
+        """Mean of the gradients over the ranks.  Enqueued behind the backward: the collective
+        runs on the backend's stream and the current stream waits for it -- no host
+        synchronisation."""
+        src, dst = [], []
+        for p, v in self._views:
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g is not v:
+                src.append(g)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        if self._avg:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=self.process_group)
+        else:
+            dist.all_reduce(self.flat_grad, group=self.process_group)
+            self.flat_grad.div_(self.world)
+        for p, v in self._views:
+            if p.grad is not None:
+                p.grad = v
+
+
 def wrap_ddp(net, device):
-    """DistributedDataParallel when a process group is up, else the bare module."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """The data-parallel wrapper when a process group is up (FlatGradParallel, or
+    DistributedDataParallel with BTR_DP=ddp), else the bare module."""
+    force = os.environ.get("BTR_FORCE_DDP", "0") == "1"
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
+        if os.environ.get("BTR_DP", "flat") != "ddp":
+            return FlatGradParallel(net)
         ids = [device.index] if device.type == "cuda" else None
         # the CenterRefine model's jitter_netD has no loss term (commented out in the
         # reference, loss_helper.py:776,787), so its parameters never receive a gradient
         unused = bool(getattr(net, "center_refine", False))
+        # gradient_as_bucket_view: the gradients ARE the all-reduce buffer (no per-parameter
+        # copy kernels into and out of the bucket)
         return torch.nn.parallel.DistributedDataParallel(net, device_ids=ids,
                                                          broadcast_buffers=False,
-                                                         find_unused_parameters=unused)
+                                                         find_unused_parameters=unused,
+                                                         gradient_as_bucket_view=True)
     return net
+
+
+def _zero_grad(net, optimizer):
+    optimizer.zero_grad(set_to_none=True)
+
+
+def _sync_grads(net):
+    if isinstance(net, FlatGradParallel):
+        net.sync_gradients()
 
 
 def make_optimizer(net, lr=1e-3, weight_decay=0.0):
@@ -101,7 +185,7 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None):
     (coordinates only, independent of the weights) is launched on the side stream under this
     step's backward; the returned end_points['next_sampling'] is then passed as `sampling` to
     the next call.  Results are identical to the unpipelined loop; bench.py does NOT use it."""
-    optimizer.zero_grad(set_to_none=True)
+    _zero_grad(net, optimizer)
     inputs = {'point_clouds': batch['point_clouds']}
     if sampling is not None:
         inputs['sampling'] = sampling
@@ -115,6 +199,7 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None):
         end_points['next_sampling'] = core.backbone_net.prefetch_sampling(
             next_batch['point_clouds'])
     loss.backward()
+    _sync_grads(net)
     optimizer.step()
     return loss, end_points
 
@@ -124,7 +209,7 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg):
     VoteNet_DA runs a source (virtual scenes) and a target (real scenes) forward -- BatchNorm
     running statistics are updated twice -- then one `get_loss_DA`, one backward, one Adam
     step.  Two scenes batches = 2 x batch scenes of hot-path work per step."""
-    optimizer.zero_grad(set_to_none=True)
+    _zero_grad(net, optimizer)
     # the target branch's sampling pyramid (coordinates only) runs on the side stream under
     # the source branch's forward
     core = net.module if hasattr(net, "module") else net
@@ -137,6 +222,7 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg):
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = loss_helper.get_loss_DA(end_points_S, end_points_T, cfg)
     loss.backward()
+    _sync_grads(net)
     optimizer.step()
     return loss, end_points_S, end_points_T
 
@@ -146,7 +232,7 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0):
     train_step_br, but both forwards also pool features around the (noisy) GT centres and
     regress their displacement; batches need 'center_jitter' (synthetic.make_batch(...,
     center_jitter=0.1))."""
-    optimizer.zero_grad(set_to_none=True)
+    _zero_grad(net, optimizer)
     core = net.module if hasattr(net, "module") else net
     sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
     end_points_S = net({'point_clouds': batch_S['point_clouds']}, batch_S['center_label'],
@@ -160,6 +246,7 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0):
     loss, end_points_S, end_points_T = loss_helper.get_loss_DA_jitter(
         end_points_S, end_points_T, epoch, cfg)
     loss.backward()
+    _sync_grads(net)
     optimizer.step()
     return loss, end_points_S, end_points_T
 

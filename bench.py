@@ -243,7 +243,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not gf:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_points)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
+        barrier()
         dist.destroy_process_group()
 
 

@@ -19,9 +19,9 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="flat"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BTR_DP=mode)
     torch.set_num_threads(2)
     import oracle
     from backtoreality_amd.pointnet2 import pointnet2_utils
@@ -35,10 +35,22 @@ def _worker(rank, world, port, q):
     net = train.build_model(cfg, dev, num_proposal=64)       # same seed on every rank
     solo = copy.deepcopy(net)
     ddp = train.wrap_ddp(net, dev)
-    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    if mode == "ddp":
+        assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    else:
+        assert isinstance(ddp, train.FlatGradParallel)
+        assert list(ddp.state_dict())[0].startswith("module.")
     opt = train.make_optimizer(net)
     batch = synthetic.make_batch(10 + rank, 1, 2304, cfg)     # a different scene per rank
     loss, _ = train.train_step(ddp, opt, batch, cfg)
+    if mode == "flat":   # a second step from the same weights gives the same mean gradient
+        g1 = [p.grad.clone() for p in net.parameters()]
+        net.load_state_dict(solo.state_dict())             # back to the initial weights
+        opt = train.make_optimizer(net)
+        loss, _ = train.train_step(ddp, opt, batch, cfg)
+        for p, g in zip(net.parameters(), g1):
+            assert p.grad.data_ptr() >= ddp.flat_grad.data_ptr()
+            assert torch.allclose(p.grad, g, rtol=1e-4, atol=1e-7)
 
     # reference: local gradient without DDP, averaged by hand
     solo_opt = train.make_optimizer(solo)
@@ -60,11 +72,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_step_matches_manual_average():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", ["flat", "ddp"])
+def test_two_rank_gloo_step_matches_manual_average(mode):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in range(world)]
