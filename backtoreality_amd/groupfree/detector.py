@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from ..votenet.backbone_module import Pointnet2Backbone
+from ..votenet.votenet_da import grad_reverse
 from .modules import (FPSModule, GeneralSamplingModule, PointsObjClsModule,
                       PositionEmbeddingLearned, PredictHead)
 from .transformer import TransformerDecoderLayer
@@ -115,7 +116,7 @@ class GroupFreeDetector(nn.Module):
                                           end_points=end_points, prefix='proposal_')
         base_xyz, base_size = center.detach().clone(), size.detach().clone()
         if self.num_decoder_layers <= 0:
-            return end_points
+            return self._finish(end_points)
 
         query = self.decoder_query_proj(cluster_feature)
         key = self.decoder_key_proj(points_features)
@@ -129,9 +130,16 @@ class GroupFreeDetector(nn.Module):
             else:
                 query_pos = torch.cat([base_xyz, base_size], -1)
             query = self.decoder[i](query, key, query_pos, key_pos)
+            self._after_decoder_layer(prefix, query, end_points)
             center, size = self.prediction_heads[i](query, base_xyz=cluster_xyz,
                                                     end_points=end_points, prefix=prefix)
             base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        return self._finish(end_points)
+
+    def _after_decoder_layer(self, prefix, query, end_points):
+        """Hook for the domain-adaptation variant."""
+
+    def _finish(self, end_points):
         return end_points
 
     def init_weights(self):
@@ -144,3 +152,32 @@ class GroupFreeDetector(nn.Module):
         for m in self.modules():
             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
                 m.momentum = self.bn_momentum
+
+
+class GroupFreeDetector_DA(GroupFreeDetector):
+    """GroupFreeDetector with the two domain classifiers of Back-to-Reality behind gradient
+    reversal (detection/GroupFree3D/models/detector_DA.py:56-302): a global one on the seed
+    features (`global_d_pred` (B,2)) and a local one on the last decoder layer's query
+    features (`last_local_d_pred` (B,1,num_proposal), after a sigmoid).  The classifiers are
+    created after the weight / BN-momentum initialisation, like the reference."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.global_netD1 = nn.Sequential(
+            nn.Conv1d(288, 256, 1), nn.BatchNorm1d(256), nn.ReLU(),
+            nn.Conv1d(256, 128, 1), nn.BatchNorm1d(128), nn.ReLU())
+        self.global_netD2 = nn.Linear(128, 2)
+        self.decoder_netD = nn.Sequential(
+            nn.Conv1d(288, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
+            nn.Conv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
+            nn.Conv1d(128, 1, 1))
+
+    def _after_decoder_layer(self, prefix, query, end_points):
+        if prefix == 'last_':
+            end_points[prefix + 'local_d_pred'] = torch.sigmoid(
+                self.decoder_netD(grad_reverse(query)))
+
+    def _finish(self, end_points):
+        g = self.global_netD1(grad_reverse(end_points['seed_features']))   # (B,128,num_seed)
+        end_points['global_d_pred'] = self.global_netD2(torch.mean(g, dim=2))
+        return end_points

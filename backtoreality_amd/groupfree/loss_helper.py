@@ -229,3 +229,160 @@ def get_loss(end_points, config, num_decoder_layers, query_points_generator_loss
     loss = loss * 10
     end_points['loss'] = loss
     return loss, end_points
+
+
+# ------------------------------------------------------------------ Back-to-Reality (weak labels)
+def compute_points_obj_cls_loss_hard_topk_weak(end_points, topk):
+    """loss_helper.py:322-384: like compute_points_obj_cls_loss_hard_topk, but with centre
+    labels only -- the `topk` seeds nearest (Euclidean) to each labelled centre are positive."""
+    box_label_mask = end_points['box_label_mask']
+    seed_xyz = end_points['seed_xyz']
+    logits = end_points['seeds_obj_cls_logits']
+    gt_center = end_points['center_label'][:, :, 0:3]
+    B, K, K2 = gt_center.shape[0], seed_xyz.shape[1], gt_center.shape[1]
+    delta = seed_xyz.unsqueeze(2) - gt_center.unsqueeze(1)
+    dist = torch.sqrt(torch.sum(delta ** 2, dim=-1) + 1e-6).transpose(1, 2).contiguous()
+    topk_inds = torch.topk(dist, topk, largest=False)[1] * box_label_mask[:, :, None] + \
+        (box_label_mask[:, :, None] - 1)
+    topk_inds = topk_inds.long().view(B, -1)
+    label = torch.zeros((B, K + 1), dtype=torch.long, device=seed_xyz.device)
+    label.scatter_(1, torch.where(topk_inds < 0, torch.full_like(topk_inds, K), topk_inds), 1)
+    label = label[:, :K]
+    total = B * K
+    end_points['points_hard_topk%d_pos_ratio' % topk] = torch.sum(label.float()) / float(total)
+    end_points['points_hard_topk%d_neg_ratio' % topk] = \
+        1 - end_points['points_hard_topk%d_pos_ratio' % topk]
+    weights = (label >= 0).float()
+    weights = weights / torch.clamp(weights.sum(dim=1, keepdim=True), min=1.0)
+    loss = sigmoid_focal_loss(logits.view(B, K, 1), label.unsqueeze(-1).float(), weights)
+    return loss.sum() / B
+
+
+def compute_objectness_loss_based_on_query_points_weak(end_points, num_decoder_layers):
+    """loss_helper.py:416-476: a query point is positive when it lies within 0.3 m of a
+    labelled centre; its target is the nearest centre."""
+    xyz = end_points['query_points_xyz']
+    gt_center = end_points['center_label'][:, :, 0:3]
+    B, K = xyz.shape[:2]
+    d = torch.sum((xyz.unsqueeze(2) - gt_center.unsqueeze(1)) ** 2, dim=-1)      # (B,K,K2)
+    dist1, assignment = torch.min(d, dim=2)
+    label = (torch.sqrt(dist1 + 1e-6) < 0.3).long()
+    mask = torch.ones((B, K), device=xyz.device)
+    weights = mask / torch.clamp(mask.sum(dim=1, keepdim=True), min=1.0)
+    prefixes = head_prefixes(num_decoder_layers)
+    scores = _stack(end_points, prefixes, 'objectness_scores')
+    loss = sigmoid_focal_loss(scores.reshape(-1, K, 1),
+                              label.unsqueeze(-1).float().repeat(len(prefixes), 1, 1),
+                              weights.repeat(len(prefixes), 1))
+    loss = loss.view(len(prefixes), -1).sum(1) / B
+    for h, prefix in enumerate(prefixes):
+        end_points[prefix + 'objectness_label'] = label
+        end_points[prefix + 'objectness_mask'] = weights   # (normalised in place upstream)
+        end_points[prefix + 'object_assignment'] = assignment
+        end_points[prefix + 'objectness_loss'] = loss[h]
+    return loss.sum(), end_points
+
+
+def compute_center_and_sem_cls_loss(end_points, config, num_decoder_layers,
+                                    center_loss_type='smoothl1', center_delta=1.0, **_unused):
+    """loss_helper.py:479-554: the weakly supervised box loss -- centre regression with a dead
+    zone of 5 % of the class's mean size, size-class and semantic cross-entropy."""
+    mean_size = _mean_size(config, end_points['center_label'].device)
+    gt_center = end_points['center_label'][:, :, 0:3]
+    prefixes = head_prefixes(num_decoder_layers)
+    H = len(prefixes)
+    assignment = end_points[prefixes[0] + 'object_assignment']
+    label = end_points[prefixes[0] + 'objectness_label'].float()
+    npos = torch.sum(label) + 1e-6
+    B, K = label.shape
+    per_head = lambda t: t.reshape(H, -1).sum(1) / npos                    # noqa: E731
+    scls = torch.gather(end_points['size_class_label'], 1, assignment)
+    margin = 0.05 * mean_size[scls]                                         # (B,K,3)
+    err = torch.gather(gt_center, 1, assignment.unsqueeze(2).expand(-1, -1, 3)).unsqueeze(0) - \
+        _stack(end_points, prefixes, 'center')
+    if center_loss_type == 'smoothl1':
+        center_loss = smoothl1_loss(err, delta=center_delta)
+    elif center_loss_type == 'l1':
+        center_loss = l1_loss(err)
+    else:
+        raise NotImplementedError
+    center_loss = per_head(torch.clamp(center_loss - margin, min=0) * label.unsqueeze(2))
+
+    def cls_loss(key, target, nclass):
+        scores = _stack(end_points, prefixes, key).reshape(-1, nclass)
+        ce = F.cross_entropy(scores, target.reshape(-1).repeat(H), reduction='none')
+        return per_head(ce.view(H, B, K) * label)
+
+    size_class_loss = cls_loss('size_scores', scls, config.num_size_cluster)
+    sem_label = torch.gather(end_points['sem_cls_label'], 1, assignment)
+    sem_loss = cls_loss('sem_cls_scores', sem_label, config.num_class)
+    box_loss = center_loss + 0.1 * size_class_loss
+    for h, prefix in enumerate(prefixes):
+        end_points[prefix + 'center_loss'] = center_loss[h]
+        end_points[prefix + 'size_cls_loss'] = size_class_loss[h]
+        end_points[prefix + 'box_loss'] = box_loss[h]
+        end_points[prefix + 'sem_cls_loss'] = sem_loss[h]
+    return box_loss.sum(), sem_loss.sum(), end_points
+
+
+def get_loss_weak(end_points, config, num_decoder_layers, query_points_generator_loss_coef,
+                  obj_loss_coef, box_loss_coef, sem_cls_loss_coef, query_points_obj_topk=5,
+                  center_loss_type='smoothl1', center_delta=1.0, size_loss_type='smoothl1',
+                  size_delta=1.0, heading_loss_type='smoothl1', heading_delta=1.0):
+    """loss_helper.py:557-606.  The reference also evaluates every fully supervised term here
+    and adds it with weight 0.000; those are not evaluated (same `loss`, same values under
+    every key the weak functions set; the zero-weighted strong-only statistics
+    `*heading_cls_loss`, `*heading_reg_loss`, `*size_reg_loss` are not filled)."""
+    if 'seeds_obj_cls_logits' in end_points:
+        gen_loss = compute_points_obj_cls_loss_hard_topk_weak(end_points, query_points_obj_topk)
+        end_points['query_points_generation_loss'] = gen_loss
+    else:
+        gen_loss = 0.0
+    obj_sum, end_points = compute_objectness_loss_based_on_query_points_weak(end_points,
+                                                                             num_decoder_layers)
+    end_points['sum_heads_objectness_loss'] = obj_sum
+    box_sum, sem_sum, end_points = compute_center_and_sem_cls_loss(
+        end_points, config, num_decoder_layers, center_loss_type, center_delta=center_delta)
+    end_points['sum_heads_box_loss'] = box_sum
+    end_points['sum_heads_sem_cls_loss'] = sem_sum
+    loss = query_points_generator_loss_coef * gen_loss + 1.0 / (num_decoder_layers + 1) * (
+        obj_loss_coef * obj_sum + box_loss_coef * box_sum + sem_cls_loss_coef * sem_sum)
+    loss = loss * 10
+    end_points['loss'] = loss
+    return loss, end_points
+
+
+def softmax_focal_loss(inputs, targets, gamma):
+    """FocalLoss(class_num=2, gamma) with alpha = 1 (loss_helper.py:609-670): mean over the
+    batch of -(1 - p_t)^gamma log p_t."""
+    probs = torch.gather(torch.softmax(inputs, dim=-1), 1, targets.view(-1, 1))
+    return (-torch.pow(1 - probs, gamma) * probs.log()).mean()
+
+
+def get_loss_DA(end_points_S, end_points_T, config, num_decoder_layers,
+                query_points_generator_loss_coef, obj_loss_coef, box_loss_coef,
+                sem_cls_loss_coef, query_points_obj_topk=5, center_loss_type='smoothl1',
+                center_delta=1.0, size_loss_type='smoothl1', size_delta=1.0,
+                heading_loss_type='smoothl1', heading_delta=1.0):
+    """The Back-to-Reality loss of GroupFree3D (loss_helper.py:673-712): half the fully
+    supervised loss on the source (virtual) scenes + the weakly supervised loss on the target
+    (real) scenes + 10 x the domain losses (global: focal, gamma 3; local: squared, weighted
+    by the objectness label of the last head)."""
+    args = (config, num_decoder_layers, query_points_generator_loss_coef, obj_loss_coef,
+            box_loss_coef, sem_cls_loss_coef, query_points_obj_topk, center_loss_type,
+            center_delta, size_loss_type, size_delta, heading_loss_type, heading_delta)
+    loss = 0.5 * get_loss(end_points_S, *args)[0] + get_loss_weak(end_points_T, *args)[0]
+    g_S, g_T = end_points_S['global_d_pred'], end_points_T['global_d_pred']
+    source_dloss = softmax_focal_loss(g_S, torch.zeros(g_S.size(0), dtype=torch.long,
+                                                       device=g_S.device), 3)
+    target_dloss = softmax_focal_loss(g_T, torch.ones(g_T.size(0), dtype=torch.long,
+                                                      device=g_T.device), 3)
+    l_S = end_points_S['last_local_d_pred'].transpose(1, 2).contiguous().squeeze(-1)
+    l_T = end_points_T['last_local_d_pred'].transpose(1, 2).contiguous().squeeze(-1)
+    source_dloss = source_dloss + torch.mean(l_S ** 2 * end_points_S['last_objectness_label'])
+    target_dloss = target_dloss + torch.mean((1 - l_T) ** 2 *
+                                             end_points_T['last_objectness_label'])
+    da_loss = source_dloss + target_dloss
+    end_points_S['DA_loss'] = da_loss
+    loss = loss + 10 * da_loss
+    return loss, end_points_S, end_points_T

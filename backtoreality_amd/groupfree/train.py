@@ -4,7 +4,7 @@ gradient clipping."""
 import torch
 
 from ..votenet.train import _sync_grads
-from .detector import GroupFreeDetector
+from .detector import GroupFreeDetector, GroupFreeDetector_DA
 from .loss_helper import get_loss
 
 # train_GF_FSB.py:42-52
@@ -14,12 +14,14 @@ LOSS_ARGS = dict(num_decoder_layers=6, query_points_generator_loss_coef=0.8, obj
                  size_delta=1.0, heading_loss_type='smoothl1', heading_delta=1.0)
 
 
-def build_model(cfg, device, input_feature_dim=0, num_proposal=256, seed=0, **kw):
+def build_model(cfg, device, input_feature_dim=0, num_proposal=256, seed=0,
+                domain_adaptation=False, **kw):
     """Random-init GroupFreeDetector with the script defaults (train_GF_FSB.py:26-34,196-217:
     no height channel unless --use_height, 256 query points, KPS sampling, six decoder layers,
     dropout 0.1)."""
     torch.manual_seed(seed)
-    net = GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+    cls = GroupFreeDetector_DA if domain_adaptation else GroupFreeDetector
+    net = cls(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
                             cfg.mean_size_arr, input_feature_dim=input_feature_dim,
                             num_proposal=num_proposal, **kw)
     return net.to(device)
@@ -66,25 +68,60 @@ class GraphedTrainStep(object):
     inside the step -- all true for `train_step`.  Learning-rate changes must go through
     tensor-valued `lr`s; BatchNorm momentum changes need a new capture."""
 
-    def __init__(self, net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, warmup=3):
+    def __init__(self, net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, warmup=3,
+                 batch_T=None):
+        """`batch_T`: capture the Back-to-Reality step (`train_step_br`, source = `batch`)."""
         self.static = {k: v.clone() for k, v in batch.items()}
+        self.static_T = None if batch_T is None else {k: v.clone() for k, v in batch_T.items()}
         self.net, self.optimizer = net, optimizer
+
+        def step():
+            if self.static_T is None:
+                return train_step(net, optimizer, self.static, cfg, loss_args, clip_norm)
+            out = train_step_br(net, optimizer, self.static, self.static_T, cfg, loss_args,
+                                clip_norm)
+            return out[0], out[1:]
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                train_step(net, optimizer, self.static, cfg, loss_args, clip_norm)
+                step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss, self.end_points = train_step(net, optimizer, self.static, cfg, loss_args,
-                                                    clip_norm)
+            self.loss, self.end_points = step()
 
-    def __call__(self, batch=None):
-        if batch is not None:
-            for k, v in batch.items():
-                if v is not self.static[k]:
-                    self.static[k].copy_(v, non_blocking=True)
+    def __call__(self, batch=None, batch_T=None):
+        for src, dst in ((batch, self.static), (batch_T, self.static_T)):
+            if src is not None:
+                for k, v in src.items():
+                    if v is not dst[k]:
+                        dst[k].copy_(v, non_blocking=True)
         self.graph.replay()
         return self.loss, self.end_points
+
+
+def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_norm=0.1):
+    """One Back-to-Reality step of GroupFree3D (train_GF_BR.py:322-365): the SAME
+    GroupFreeDetector_DA runs a source (virtual, fully labelled) and a target (real, centre
+    labels only) forward, then one `get_loss_DA`, one backward, clipping, one AdamW step."""
+    from .loss_helper import get_loss_DA
+    loss_args = dict(LOSS_ARGS, **(loss_args or {}))
+    end_points_S = net({'point_clouds': batch_S['point_clouds']})
+    end_points_T = net({'point_clouds': batch_T['point_clouds']})
+    for key in batch_S:
+        assert key not in end_points_S
+        end_points_S[key] = batch_S[key]
+    for key in batch_T:
+        assert key not in end_points_T
+        end_points_T[key] = batch_T[key]
+    loss, end_points_S, end_points_T = get_loss_DA(end_points_S, end_points_T, cfg, **loss_args)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    _sync_grads(net)
+    if clip_norm > 0:
+        torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
+    optimizer.step()
+    return loss, end_points_S, end_points_T

@@ -41,12 +41,13 @@ def parse():
                         "machine); measured 10.0 -> 9.76 ms/step")
     p.add_argument("--no-pipelined", action="store_true",
                    help="skip the secondary (informational) software-pipelined loop")
-    p.add_argument("--workload", choices=["fsb", "br", "cr", "gf"], default="fsb",
+    p.add_argument("--workload", choices=["fsb", "br", "cr", "gf", "gfbr"], default="fsb",
                    help="fsb: VoteNet FSB step (BASELINE configs[1], the headline); br: the "
                         "two-branch Back-to-Reality step (configs[2]), 2 x batch scenes per step; "
                         "cr: br + the CenterRefine centre head / jitter regressor; gf: "
                         "GroupFree3D (configs[3] shape: 50 000 points without the height "
-                        "channel, batch 4 unless --points / --batch are given)")
+                        "channel, batch 4 unless --points / --batch are given); gfbr: GroupFree3D "
+                        "Back-to-Reality step (source + target forward, get_loss_DA)")
     p.add_argument("--no-graph", action="store_true",
                    help="gf only: enqueue the step kernel by kernel instead of replaying the "
                         "captured HIP graph (the eager GroupFree3D loop is host-bound)")
@@ -112,12 +113,13 @@ def main():
     cfg = config.scannet_md40()
     br = args.workload in ("br", "cr")
     cr = args.workload == "cr"
-    gf = args.workload == "gf"
+    gf = args.workload in ("gf", "gfbr")
+    gfbr = args.workload == "gfbr"
     if gf:
         from backtoreality_amd.groupfree import train as gf_train
         if args.points == 40000 and args.batch == 8:      # configs[3]: 4 x 50 000 points
             args.points, args.batch = 50000, 4
-        net = gf_train.build_model(cfg, dev)
+        net = gf_train.build_model(cfg, dev, domain_adaptation=gfbr)
         graphed = world == 1 and not args.no_graph
         opt = gf_train.make_optimizer(net, capturable=graphed)
     else:
@@ -129,7 +131,15 @@ def main():
     batch = synthetic.make_batch(rank * B, B, args.points, cfg, device=dev,
                                  center_jitter=jit, use_height=not gf)  # resident in HBM
     eager_step = None
-    if gf:
+    if gfbr:
+        batch_T = synthetic.make_batch(100000 + rank * B, B, args.points, cfg, device=dev,
+                                       use_height=False)
+        train_step = eager_step = lambda n, o, b, c: gf_train.train_step_br(  # noqa: E731
+            n, o, b, batch_T, c)[:2]
+        if graphed:
+            gs = gf_train.GraphedTrainStep(net, opt, batch, cfg, batch_T=batch_T)
+            train_step = lambda n, o, b, c: gs(b)  # noqa: E731
+    elif gf:
         train_step = eager_step = gf_train.train_step
         if graphed:
             # one capture of the whole step (forward, loss, backward, clip, AdamW); every
@@ -202,7 +212,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        scenes = world * B * args.steps * (2 if br else 1)
+        scenes = world * B * args.steps * (2 if (br or gfbr) else 1)
         out = {
             "metric": ("scenes/sec (50k-pt GroupFree3D fwd+bwd)" if gf else
                        "scenes/sec (40k-pt VoteNet fwd+bwd)"),
@@ -223,6 +233,9 @@ def main():
                                     "2 x %%d scenes of %%d points per GPU" % ("_jitter" if cr
                                                                               else "")
                                     if br else
+                                    "GroupFree3D BR train step (GroupFreeDetector_DA, source+target "
+                                    "forward, get_loss_DA, one backward, clip, AdamW), 2 x %d scenes "
+                                    "of %d points (xyz only) per GPU" if gfbr else
                                     "GroupFree3D FSB train step (backbone fp2->288, KPS, 6 decoder "
                                     "layers, fwd+loss+bwd+clip+AdamW), %d scenes of %d points "
                                     "(xyz only) per GPU" if gf else

@@ -213,3 +213,97 @@ def test_groupfree_graphed_step_trains_like_the_eager_step(cuda):
     assert (num / den) ** 0.5 <= 1e-2, (num / den) ** 0.5   # a replay that did nothing: 0.15
     for a, b in zip(ne.parameters(), ng.parameters()):
         assert float((a - b).abs().max()) <= 3 * 0.004 + 1e-6
+
+
+# ------------------------------------------------------------ Back-to-Reality step (8f #2)
+GOLD_BR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                       "groupfree_br_step.npz")
+
+
+def run_br(device):
+    cfg = config.scannet_md40()
+    batch_S = synthetic.make_batch(0, 2, 4096, cfg, use_height=False, device=device)
+    batch_T = synthetic.make_batch(100, 2, 4096, cfg, use_height=False, device=device)
+    torch.manual_seed(0)
+    net = groupfree.GroupFreeDetector_DA(cfg.num_class, cfg.num_heading_bin,
+                                         cfg.num_size_cluster, cfg.mean_size_arr,
+                                         input_feature_dim=0, num_proposal=256,
+                                         dropout=0.0).to(device)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    names = sorted(sd)
+    sig = (names, np.array([float(sd[k].double().sum()) for k in names]),
+           [str(tuple(sd[k].shape)) for k in names])
+    eS = net({'point_clouds': batch_S['point_clouds']})
+    eT = net({'point_clouds': batch_T['point_clouds']})
+    eS.update(batch_S)
+    eT.update(batch_T)
+    loss, eS, eT = groupfree.get_loss_DA(eS, eT, cfg, **LOSS_ARGS)
+    loss.backward()
+    return net, sig, loss, eS, eT
+
+
+def check_br(res, rtol, grad_rtol):
+    g = np.load(GOLD_BR)
+    net, (names, sums, shapes), loss, eS, eT = res
+    assert names == list(g['state_names']) and shapes == list(g['state_shapes'])
+    np.testing.assert_allclose(sums, g['state_sums'], rtol=1e-6, atol=1e-6)
+    close = lambda a, b, k: abs(a - b) <= 10 * rtol * max(1.0, abs(b)) or \
+        pytest.fail("%s: %r vs %r" % (k, a, b))                            # noqa: E731
+    close(float(loss), float(g['loss']), 'loss')
+    close(float(eS['loss']), float(g['loss_S']), 'loss_S')
+    close(float(eT['loss']), float(g['loss_T']), 'loss_T')
+    for tag, e in (("S_", eS), ("T_", eT)):
+        inds = e['query_points_sample_inds'].cpu().numpy()
+        same = np.array_equal(inds, g[tag + 'query_points_sample_inds'])
+        assert np.array_equal(np.sort(inds, 1), np.sort(g[tag + 'query_points_sample_inds'], 1))
+        np.testing.assert_allclose(e['global_d_pred'].detach().cpu().numpy(),
+                                   g[tag + 'global_d_pred'], rtol=10 * rtol, atol=10 * rtol)
+        if same:
+            np.testing.assert_allclose(e['last_local_d_pred'].detach().cpu().numpy(),
+                                       g[tag + 'last_local_d_pred'], rtol=10 * rtol,
+                                       atol=10 * rtol)
+            for k in ('last_objectness_label', 'last_object_assignment'):
+                np.testing.assert_array_equal(e[k].cpu().numpy(), g[tag + k])
+        for k in ('query_points_generation_loss', 'sum_heads_objectness_loss',
+                  'sum_heads_box_loss', 'sum_heads_sem_cls_loss'):
+            close(float(e[k]), float(g[tag + k]), tag + k)
+        for p in ('proposal_', 'last_', '2head_'):
+            for k in ('objectness_loss', 'center_loss', 'size_cls_loss', 'box_loss',
+                      'sem_cls_loss'):
+                close(float(e[p + k]), float(g[tag + p + k]), tag + p + k)
+    grads = {'grad_global_netD2': net.global_netD2.weight.grad,
+             'grad_decoder_netD6': net.decoder_netD[6].weight.grad,
+             'grad_global_netD1_0': net.global_netD1[0].weight.grad,
+             'grad_sa1_w0': net.backbone_net.sa1.mlp_module.layer0.conv.weight.grad,
+             'grad_dec5_linear2': net.decoder[5].linear2.weight.grad,
+             'grad_proposal_conv1': net.proposal_head.conv1.weight.grad}
+    for k, t in grads.items():
+        a = t.detach().cpu().numpy().astype(np.float32).ravel()[::53]
+        want = g[k + '_sample']
+        rel = np.linalg.norm(a - want) / (np.linalg.norm(want) + 1e-30)
+        assert rel <= grad_rtol, (k, rel)
+
+
+def test_groupfree_br_step_matches_reference_cpu(oracle_ext, monkeypatch):
+    monkeypatch.setenv("BTR_FUSED_SA", "0")
+    check_br(run_br(torch.device("cpu")), rtol=1e-4, grad_rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_groupfree_br_step_matches_reference_gpu(cuda):
+    check_br(run_br(cuda), rtol=1e-4, grad_rtol=2e-2)
+
+
+@pytest.mark.gpu
+def test_groupfree_br_train_steps(cuda):
+    from backtoreality_amd.groupfree import train as gf_train
+    cfg = config.scannet_md40()
+    net = gf_train.build_model(cfg, cuda, domain_adaptation=True)
+    opt = gf_train.make_optimizer(net)
+    bS = synthetic.make_batch(0, 2, 8192, cfg, use_height=False, device=cuda)
+    bT = synthetic.make_batch(50, 2, 8192, cfg, use_height=False, device=cuda)
+    for _ in range(2):
+        loss, eS, eT = gf_train.train_step_br(net, opt, bS, bT, cfg)
+    assert np.isfinite(float(loss))
+    assert not [n for n, p in net.named_parameters() if p.grad is None]
+    assert eT['last_local_d_pred'].shape == (2, 1, 256) and eS['global_d_pred'].shape == (2, 2)
