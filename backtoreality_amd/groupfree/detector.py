@@ -15,6 +15,8 @@ class GroupFreeDetector(nn.Module):
     `num_decoder_layers` x (decoder layer + prediction head), each head refining the previous
     head's (detached) box as the next layer's query position."""
 
+    center_refine = False   # GroupFreeDetector_DA_jitter: backbone with the centre head
+
     def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr,
                  input_feature_dim=0, width=1, bn_momentum=0.1, sync_bn=False, num_proposal=128,
                  sampling='kps', dropout=0.1, activation="relu", nhead=8, num_decoder_layers=6,
@@ -41,7 +43,8 @@ class GroupFreeDetector(nn.Module):
             raise NotImplementedError("backbone width %r (the reference default 1 only)" % width)
 
         self.backbone_net = Pointnet2Backbone(input_feature_dim=self.input_feature_dim,
-                                              fp2_out=288)
+                                              fp2_out=288, center_refine=self.center_refine,
+                                              num_class=num_class)
         if self.sampling == 'fps':
             self.fps_module = FPSModule(num_proposal)
         elif self.sampling == 'kps':
@@ -90,9 +93,9 @@ class GroupFreeDetector(nn.Module):
         if self.sync_bn:
             nn.SyncBatchNorm.convert_sync_batchnorm(self)
 
-    def forward(self, inputs):
+    def forward(self, inputs, center_xyz=None, center_cls=None):
         """inputs {'point_clouds': (B, N, 3 + input_feature_dim)} -> end_points."""
-        end_points = self.backbone_net(inputs['point_clouds'], {})
+        end_points = self._backbone(inputs, center_xyz, center_cls)
         points_xyz = end_points['fp2_xyz']
         points_features = end_points['fp2_features']
         end_points['seed_inds'] = end_points['fp2_inds']
@@ -135,6 +138,9 @@ class GroupFreeDetector(nn.Module):
                                                     end_points=end_points, prefix=prefix)
             base_xyz, base_size = center.detach().clone(), size.detach().clone()
         return self._finish(end_points)
+
+    def _backbone(self, inputs, center_xyz, center_cls):
+        return self.backbone_net(inputs['point_clouds'], {})
 
     def _after_decoder_layer(self, prefix, query, end_points):
         """Hook for the domain-adaptation variant."""
@@ -180,4 +186,26 @@ class GroupFreeDetector_DA(GroupFreeDetector):
     def _finish(self, end_points):
         g = self.global_netD1(grad_reverse(end_points['seed_features']))   # (B,128,num_seed)
         end_points['global_d_pred'] = self.global_netD2(torch.mean(g, dim=2))
+        return end_points
+
+
+class GroupFreeDetector_DA_jitter(GroupFreeDetector_DA):
+    """CenterRefine variant (detector_DA.py:317-575): the backbone additionally pools seed
+    features around the 64 (noisy) ground-truth centres (`ctjt_head`), and `jitter_net`
+    regresses each centre's displacement from them: forward(inputs, center_xyz (B,64,3),
+    center_cls (B,64)) adds 'center_features' (B,128+num_class,64) and 'jitter_pred'
+    (B,3,64)."""
+    center_refine = True
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.jitter_net = nn.Sequential(
+            nn.Conv1d(128 + self.num_class, 64, 1), nn.BatchNorm1d(64), nn.ReLU(),
+            nn.Conv1d(64, 3, 1))
+
+    def _backbone(self, inputs, center_xyz, center_cls):
+        end_points = self.backbone_net(inputs['point_clouds'], {}, center_xyz=center_xyz,
+                                       center_cls=center_cls)
+        if center_xyz is not None:
+            end_points['jitter_pred'] = self.jitter_net(end_points['center_features'])
         return end_points

@@ -386,3 +386,35 @@ def get_loss_DA(end_points_S, end_points_T, config, num_decoder_layers,
     end_points_S['DA_loss'] = da_loss
     loss = loss + 10 * da_loss
     return loss, end_points_S, end_points_T
+
+
+def compute_jitter_loss(end_points):
+    """Mean squared error of the predicted centre displacement (loss_helper.py:715-720)."""
+    loss = ((end_points['center_jitter'] -
+             end_points['jitter_pred'].transpose(1, 2).contiguous()) ** 2).mean()
+    end_points['jitter_loss'] = loss
+    return loss
+
+
+def get_loss_DA_jitter(end_points_S, end_points_T, epoch, config, num_decoder_layers,
+                       query_points_generator_loss_coef, obj_loss_coef, box_loss_coef,
+                       sem_cls_loss_coef, query_points_obj_topk=5, **kw):
+    """CenterRefine loss of GroupFree3D (loss_helper.py:723-774): the centre labels are first
+    moved back by the known (source) / predicted (target, detached) displacement, ramped in
+    over 120 epochs; then get_loss_DA with 0.5 x the source jitter-regression loss inside the
+    domain term.  (The reference edits the batch tensors in place; here the corrected centres
+    replace the end_points entries.)"""
+    if epoch > -1:
+        ramp = min(epoch / 120.0, 1.0)
+        end_points_S['center_label'] = end_points_S['center_label'] - \
+            ramp * end_points_S['center_jitter']
+        corr_T = end_points_T['jitter_pred'].transpose(1, 2) * \
+            end_points_T['box_label_mask'].unsqueeze(-1)
+        end_points_T['center_label'] = (end_points_T['center_label'] - ramp * corr_T).detach()
+    jitter_loss_S = compute_jitter_loss(end_points_S)
+    loss, end_points_S, end_points_T = get_loss_DA(
+        end_points_S, end_points_T, config, num_decoder_layers,
+        query_points_generator_loss_coef, obj_loss_coef, box_loss_coef, sem_cls_loss_coef,
+        query_points_obj_topk, **kw)
+    loss = loss + 10 * (0.5 * jitter_loss_S)
+    return loss, end_points_S, end_points_T

@@ -4,7 +4,7 @@ gradient clipping."""
 import torch
 
 from ..votenet.train import _sync_grads
-from .detector import GroupFreeDetector, GroupFreeDetector_DA
+from .detector import GroupFreeDetector, GroupFreeDetector_DA, GroupFreeDetector_DA_jitter
 from .loss_helper import get_loss
 
 # train_GF_FSB.py:42-52
@@ -15,12 +15,13 @@ LOSS_ARGS = dict(num_decoder_layers=6, query_points_generator_loss_coef=0.8, obj
 
 
 def build_model(cfg, device, input_feature_dim=0, num_proposal=256, seed=0,
-                domain_adaptation=False, **kw):
+                domain_adaptation=False, center_refine=False, **kw):
     """Random-init GroupFreeDetector with the script defaults (train_GF_FSB.py:26-34,196-217:
     no height channel unless --use_height, 256 query points, KPS sampling, six decoder layers,
     dropout 0.1)."""
     torch.manual_seed(seed)
-    cls = GroupFreeDetector_DA if domain_adaptation else GroupFreeDetector
+    cls = GroupFreeDetector_DA_jitter if center_refine else (
+        GroupFreeDetector_DA if domain_adaptation else GroupFreeDetector)
     net = cls(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
                             cfg.mean_size_arr, input_feature_dim=input_feature_dim,
                             num_proposal=num_proposal, **kw)
@@ -118,6 +119,32 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_no
         assert key not in end_points_T
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = get_loss_DA(end_points_S, end_points_T, cfg, **loss_args)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    _sync_grads(net)
+    if clip_norm > 0:
+        torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
+    optimizer.step()
+    return loss, end_points_S, end_points_T
+
+
+def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, loss_args=None,
+                         clip_norm=0.1):
+    """One CenterRefine step of GroupFree3D (train_GF_BR_CenterRefine.py): like train_step_br,
+    both forwards also pool features around the (noisy) centre labels and regress their
+    displacement; batches need 'center_jitter' (synthetic.make_batch(..., center_jitter=))."""
+    from .loss_helper import get_loss_DA_jitter
+    loss_args = dict(LOSS_ARGS, **(loss_args or {}))
+    end_points_S = net({'point_clouds': batch_S['point_clouds']}, batch_S['center_label'],
+                       batch_S['sem_cls_label'])
+    end_points_T = net({'point_clouds': batch_T['point_clouds']}, batch_T['center_label'],
+                       batch_T['sem_cls_label'])
+    for key in batch_S:
+        end_points_S[key] = batch_S[key]
+    for key in batch_T:
+        end_points_T[key] = batch_T[key]
+    loss, end_points_S, end_points_T = get_loss_DA_jitter(end_points_S, end_points_T, epoch, cfg,
+                                                          **loss_args)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     _sync_grads(net)

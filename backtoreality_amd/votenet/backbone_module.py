@@ -40,7 +40,7 @@ class Pointnet2Backbone(nn.Module):
         self.num_class = num_class
         if center_refine:  # backbone_module.py:188-195
             self.ctjt_head = PointnetSAModuleCenters(npoint=64, radius=0.8, nsample=16,
-                                                     mlp=[256, 128], use_xyz=True,
+                                                     mlp=[fp2_out, 128], use_xyz=True,
                                                      normalize_xyz=False)
 
     @staticmethod

@@ -307,3 +307,76 @@ def test_groupfree_br_train_steps(cuda):
     assert np.isfinite(float(loss))
     assert not [n for n, p in net.named_parameters() if p.grad is None]
     assert eT['last_local_d_pred'].shape == (2, 1, 256) and eS['global_d_pred'].shape == (2, 2)
+
+
+# ------------------------------------------------------------------ CenterRefine step (8f #2/#3)
+GOLD_CR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                       "groupfree_cr_step.npz")
+
+
+def run_cr(device):
+    cfg = config.scannet_md40()
+    bS = synthetic.make_batch(0, 2, 4096, cfg, use_height=False, center_jitter=0.1, device=device)
+    bT = synthetic.make_batch(100, 2, 4096, cfg, use_height=False, center_jitter=0.1,
+                              device=device)
+    torch.manual_seed(0)
+    net = groupfree.GroupFreeDetector_DA_jitter(cfg.num_class, cfg.num_heading_bin,
+                                                cfg.num_size_cluster, cfg.mean_size_arr,
+                                                input_feature_dim=0, num_proposal=256,
+                                                dropout=0.0).to(device)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    names = sorted(sd)
+    sig = (names, np.array([float(sd[k].double().sum()) for k in names]),
+           [str(tuple(sd[k].shape)) for k in names])
+    eS = net({'point_clouds': bS['point_clouds']}, bS['center_label'], bS['sem_cls_label'])
+    eT = net({'point_clouds': bT['point_clouds']}, bT['center_label'], bT['sem_cls_label'])
+    eS.update(bS)
+    eT.update(bT)
+    before = bS['center_label'].clone()
+    loss, eS, eT = groupfree.get_loss_DA_jitter(eS, eT, 30, cfg, **LOSS_ARGS)
+    assert torch.equal(bS['center_label'], before)      # the caller's batch is not edited
+    loss.backward()
+    return net, sig, loss, eS, eT
+
+
+def check_cr(res, rtol, grad_rtol):
+    g = np.load(GOLD_CR)
+    net, (names, sums, shapes), loss, eS, eT = res
+    assert names == list(g['state_names']) and shapes == list(g['state_shapes'])
+    np.testing.assert_allclose(sums, g['state_sums'], rtol=1e-6, atol=1e-6)
+    for a, k in ((loss, 'loss'), (eS['loss'], 'loss_S'), (eT['loss'], 'loss_T'),
+                 (eS['jitter_loss'], 'jitter_loss')):
+        assert abs(float(a) - float(g[k])) <= 10 * rtol * max(1.0, abs(float(g[k]))), k
+    for tag, e in (("S_", eS), ("T_", eT)):
+        for k in ('jitter_pred', 'center_label'):
+            want = g[tag + k]
+            np.testing.assert_allclose(e[k].detach().cpu().numpy(), want, rtol=10 * rtol,
+                                       atol=10 * rtol * np.abs(want).max())
+    _sub(eS['center_features'], g['S_center_features_sample'], g['S_center_features_sums'],
+         10 * rtol, 37)
+    grads = {'grad_jitter_net3': net.jitter_net[3].weight.grad,
+             'grad_ctjt_w0': net.backbone_net.ctjt_head.mlp_module.layer0.conv.weight.grad,
+             'grad_sa1_w0': net.backbone_net.sa1.mlp_module.layer0.conv.weight.grad}
+    for k, t in grads.items():
+        a = t.detach().cpu().numpy().astype(np.float32).ravel()[::11]
+        want = g[k + '_sample']
+        rel = np.linalg.norm(a - want) / (np.linalg.norm(want) + 1e-30)
+        assert rel <= grad_rtol, (k, rel)
+
+
+def test_groupfree_cr_step_matches_reference_cpu(oracle_ext, monkeypatch):
+    monkeypatch.setenv("BTR_FUSED_SA", "0")
+    check_cr(run_cr(torch.device("cpu")), rtol=1e-4, grad_rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_groupfree_cr_step_matches_reference_gpu(cuda):
+    check_cr(run_cr(cuda), rtol=1e-4, grad_rtol=2e-2)
+    from backtoreality_amd.groupfree import train as gf_train
+    cfg = config.scannet_md40()
+    net = gf_train.build_model(cfg, cuda, center_refine=True)
+    opt = gf_train.make_optimizer(net)
+    bS = synthetic.make_batch(0, 2, 8192, cfg, use_height=False, center_jitter=0.1, device=cuda)
+    bT = synthetic.make_batch(9, 2, 8192, cfg, use_height=False, center_jitter=0.1, device=cuda)
+    loss, eS, eT = gf_train.train_step_br_jitter(net, opt, bS, bT, cfg, epoch=60)
+    assert np.isfinite(float(loss)) and eT['jitter_pred'].shape == (2, 3, 64)
