@@ -39,16 +39,17 @@ def make_optimizer(net, lr=0.004, decoder_lr=0.0004, weight_decay=0.0005, captur
                              capturable=bool(capturable and fused))
 
 
-def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1):
+def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, criterion=None):
     """One optimisation step (train_GF_FSB.py:287-322) on `batch` (label dict on the model's
     device, GroupFree3D schema: VoteNet's keys + size_gts, point_obj_mask,
-    point_instance_label).  Returns (loss, end_points); no host synchronisation."""
+    point_instance_label).  Returns (loss, end_points); no host synchronisation.
+    `criterion`: `get_loss` (default) or `get_loss_weak` (train_GF_WSB.py:217)."""
     loss_args = dict(LOSS_ARGS, **(loss_args or {}))
     end_points = net({'point_clouds': batch['point_clouds']})
     for key in batch:
         assert key not in end_points
         end_points[key] = batch[key]
-    loss, end_points = get_loss(end_points, cfg, **loss_args)
+    loss, end_points = (criterion or get_loss)(end_points, cfg, **loss_args)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     _sync_grads(net)          # data parallel: one all-reduce of the flat gradient buffer

@@ -353,6 +353,37 @@ def _get_loss_DA_fused(end_points_S, end_points_T, config, fused_loss):
     return loss, end_points_S, end_points_T
 
 
+def get_loss_weak(end_points, config):
+    """Loss of the weakly supervised baseline (train_Votenet_WSB.py:170; loss_helper.py:403-464):
+    centre labels only -- the weak vote loss, objectness, centre regression with its dead
+    zone, size-class and semantic cross-entropy; the target-branch terms of get_loss_DA on
+    their own.  Fused kernels on the GPU, torch composition otherwise."""
+    if end_points['seed_xyz'].is_cuda:
+        from . import fused_loss
+        if fused_loss.can_fuse(end_points, config):
+            keys = ('vote_loss', 'objectness_loss', 'center_loss', 'size_cls_loss',
+                    'sem_cls_loss', 'pos_ratio', 'neg_ratio', 'obj_acc')
+            loss = fused_loss.get_loss_branch(end_points, config, fused_loss.W_DA_TARGET, keys)
+            end_points['loss'] = loss
+            return loss, end_points
+    vote_loss = compute_weak_vote_loss(end_points)
+    end_points['vote_loss'] = vote_loss
+    _objectness_bookkeeping(end_points)
+    center_loss, size_cls_loss, sem_cls_loss = compute_center_and_sem_cls_loss(end_points, config)
+    end_points['center_loss'] = center_loss
+    end_points['size_cls_loss'] = size_cls_loss
+    end_points['sem_cls_loss'] = sem_cls_loss
+    box_loss = center_loss + 0.1 * size_cls_loss
+    loss = vote_loss + 0.5 * end_points['objectness_loss'] + box_loss + 0.1 * sem_cls_loss
+    loss = loss * 10
+    end_points['loss'] = loss
+    obj_pred_val = torch.argmax(end_points['objectness_scores'], 2)
+    label, mask = end_points['objectness_label'], end_points['objectness_mask']
+    end_points['obj_acc'] = torch.sum((obj_pred_val == label.long()).float() * mask) / \
+        (torch.sum(mask) + 1e-6)
+    return loss, end_points
+
+
 def compute_jitter_loss(end_points):
     """Mean squared error between the displacement applied to the GT centres and the
     regressed one (loss_helper.py:667-672)."""

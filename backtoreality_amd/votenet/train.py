@@ -175,7 +175,7 @@ def freeze_gc():
     gc.freeze()
 
 
-def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None):
+def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None, criterion=None):
     """One optimisation step on `batch` (dict of tensors already on the model's device).
     Returns (loss tensor, end_points).  No host synchronisation inside (the reference's
     `.item()` statistics, FSB:234-237, are left to the caller).
@@ -184,7 +184,10 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None):
     loader with prefetch gives): pass `next_batch` and the sampling pyramid of that batch
     (coordinates only, independent of the weights) is launched on the side stream under this
     step's backward; the returned end_points['next_sampling'] is then passed as `sampling` to
-    the next call.  Results are identical to the unpipelined loop; bench.py does NOT use it."""
+    the next call.  Results are identical to the unpipelined loop; bench.py does NOT use it.
+
+    `criterion`: `loss_helper.get_loss` (default, train_Votenet_FSB.py) or
+    `loss_helper.get_loss_weak` (the weakly supervised baseline, train_Votenet_WSB.py:170)."""
     _zero_grad(net, optimizer)
     inputs = {'point_clouds': batch['point_clouds']}
     if sampling is not None:
@@ -193,7 +196,7 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None):
     for key in batch:
         assert key not in end_points
         end_points[key] = batch[key]
-    loss, end_points = loss_helper.get_loss(end_points, cfg)
+    loss, end_points = (criterion or loss_helper.get_loss)(end_points, cfg)
     if next_batch is not None:
         core = net.module if hasattr(net, "module") else net
         end_points['next_sampling'] = core.backbone_net.prefetch_sampling(

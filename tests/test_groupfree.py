@@ -380,3 +380,55 @@ def test_groupfree_cr_step_matches_reference_gpu(cuda):
     bT = synthetic.make_batch(9, 2, 8192, cfg, use_height=False, center_jitter=0.1, device=cuda)
     loss, eS, eT = gf_train.train_step_br_jitter(net, opt, bS, bT, cfg, epoch=60)
     assert np.isfinite(float(loss)) and eT['jitter_pred'].shape == (2, 3, 64)
+
+
+# ------------------------------------------------------------ weakly supervised baseline (WSB)
+def run_wsb(device):
+    cfg = config.scannet_md40()
+    batch = synthetic.make_batch(0, 2, 4096, cfg, use_height=False, device=device)
+    torch.manual_seed(0)
+    net = groupfree.GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                      cfg.mean_size_arr, input_feature_dim=0, num_proposal=256,
+                                      dropout=0.0).to(device)
+    e = net({'point_clouds': batch['point_clouds']})
+    e.update(batch)
+    loss, e = groupfree.get_loss_weak(e, cfg, **LOSS_ARGS)
+    loss.backward()
+    return net, loss, e
+
+
+def check_wsb(res, rtol, grad_rtol):
+    g = np.load(os.path.join(os.path.dirname(GOLD), "groupfree_wsb_step.npz"))
+    net, loss, e = res
+    assert abs(float(loss) - float(g['loss'])) <= 10 * rtol * abs(float(g['loss']))
+    for k in ('query_points_generation_loss', 'sum_heads_objectness_loss', 'sum_heads_box_loss',
+              'sum_heads_sem_cls_loss'):
+        assert abs(float(e[k]) - float(g[k])) <= 10 * rtol * max(1.0, abs(float(g[k]))), k
+    for p in ('proposal_', 'last_', '3head_'):
+        for k in ('objectness_loss', 'center_loss', 'size_cls_loss', 'box_loss', 'sem_cls_loss'):
+            a, b = float(e[p + k]), float(g[p + k])
+            assert abs(a - b) <= 10 * rtol * max(1.0, abs(b)), (p + k, a, b)
+    for k, t, st in (('grad_sa1_w0', net.backbone_net.sa1.mlp_module.layer0.conv.weight.grad, 11),
+                     ('grad_dec5_linear2', net.decoder[5].linear2.weight.grad, 53)):
+        a = t.detach().cpu().numpy().astype(np.float32).ravel()[::st]
+        want = g[k + '_sample']
+        rel = np.linalg.norm(a - want) / (np.linalg.norm(want) + 1e-30)
+        assert rel <= grad_rtol, (k, rel)
+
+
+def test_groupfree_wsb_step_matches_reference_cpu(oracle_ext, monkeypatch):
+    """train_GF_WSB.py:217: GroupFreeDetector + get_loss_weak."""
+    monkeypatch.setenv("BTR_FUSED_SA", "0")
+    check_wsb(run_wsb(torch.device("cpu")), rtol=1e-4, grad_rtol=1e-3)
+
+
+@pytest.mark.gpu
+def test_groupfree_wsb_step_matches_reference_gpu(cuda):
+    check_wsb(run_wsb(cuda), rtol=1e-4, grad_rtol=2e-2)
+    from backtoreality_amd.groupfree import train as gf_train
+    cfg = config.scannet_md40()
+    net = gf_train.build_model(cfg, cuda)
+    opt = gf_train.make_optimizer(net)
+    batch = synthetic.make_batch(0, 2, 8192, cfg, use_height=False, device=cuda)
+    loss, _ = gf_train.train_step(net, opt, batch, cfg, criterion=groupfree.get_loss_weak)
+    assert np.isfinite(float(loss))
