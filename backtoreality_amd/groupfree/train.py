@@ -153,3 +153,46 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, loss_ar
         torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
     optimizer.step()
     return loss, end_points_S, end_points_T
+
+
+def evaluate_one_epoch(net, batches, cfg, config_dict=None, ap_iou_thresholds=(0.25, 0.5),
+                       loss_args=None, criterion=None):
+    """The evaluation pass of train_GF_FSB.py:354-445: eval-mode forward, loss statistics, and
+    for EVERY prediction head (last decoder layer, proposal stage, intermediate layers) the
+    boxes through parse_predictions -> AP at each IoU threshold.  Returns
+    (mean stats dict, {iou_threshold: {prefix: metrics dict}})."""
+    from ..votenet import ap_helper
+    from ..votenet.train import EVAL_CONFIG_DICT
+    from .loss_helper import head_prefixes
+    loss_args = dict(LOSS_ARGS, **(loss_args or {}))
+    config_dict = dict(config_dict or dict(EVAL_CONFIG_DICT, conf_thresh=0.0), dataset_config=cfg)
+    core = net.module if hasattr(net, "module") else net
+    n = core.num_decoder_layers
+    prefixes = (['last_', 'proposal_'] + ['%dhead_' % i for i in range(n - 1)]) if n > 0 \
+        else ['proposal_']
+    assert sorted(prefixes) == sorted(head_prefixes(n))
+    calcs = {thr: {p: ap_helper.APCalculator(ap_iou_thresh=thr) for p in prefixes}
+             for thr in ap_iou_thresholds}
+    was_training = net.training
+    net.eval()
+    stat, nb = {}, 0
+    try:
+        for batch in batches:
+            with torch.no_grad():
+                end_points = net({'point_clouds': batch['point_clouds']})
+                for key in batch:
+                    end_points[key] = batch[key]
+                _, end_points = (criterion or get_loss)(end_points, cfg, **loss_args)
+            for key, v in end_points.items():
+                if ('loss' in key or 'acc' in key or 'ratio' in key) and torch.is_tensor(v):
+                    stat[key] = stat.get(key, 0) + v.detach()
+            gt = ap_helper.parse_groundtruths(end_points, config_dict)
+            for p in prefixes:
+                pred = ap_helper.parse_predictions(end_points, config_dict, p)
+                for thr in ap_iou_thresholds:
+                    calcs[thr][p].step(pred, gt)
+            nb += 1
+    finally:
+        net.train(was_training)
+    stats = {k: float(v) / max(nb, 1) for k, v in sorted(stat.items())}
+    return stats, {thr: {p: c.compute_metrics() for p, c in d.items()} for thr, d in calcs.items()}

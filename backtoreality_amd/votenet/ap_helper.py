@@ -47,22 +47,27 @@ def get_3d_box_batch(box_size, heading_angle, center):
     return corners + center.unsqueeze(-2)
 
 
-def _decode(end_points, dc):
+def _decode(end_points, dc, prefix=""):
     """Argmax class + gathered residual of the heading / size heads -> angle (B,K), size
     (B,K,3), centre in camera coordinates (B,K,3), all float64 (ap_helper.py:80-110)."""
-    center = end_points['center']
-    hcls = torch.argmax(end_points['heading_scores'], -1)
-    hres = torch.gather(end_points['heading_residuals'], 2, hcls.unsqueeze(-1)).squeeze(2)
-    scls = torch.argmax(end_points['size_scores'], -1)
-    sres = torch.gather(end_points['size_residuals'], 2,
+    center = end_points[prefix + 'center']
+    hcls = torch.argmax(end_points[prefix + 'heading_scores'], -1)
+    hres = torch.gather(end_points[prefix + 'heading_residuals'], 2,
+                        hcls.unsqueeze(-1)).squeeze(2)
+    scls = torch.argmax(end_points[prefix + 'size_scores'], -1)
+    sres = torch.gather(end_points[prefix + 'size_residuals'], 2,
                         scls.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 1, 3)).squeeze(2)
     angle = dc.class2angle_batch(hcls, hres)
     size = dc.class2size_batch(scls, sres)
     return angle.contiguous(), size.contiguous(), flip_axis_to_camera(center.double()).contiguous()
 
 
-def parse_predictions(end_points, config_dict):
+def parse_predictions(end_points, config_dict, prefix=""):
     """Decode the head outputs to oriented boxes and suppress overlapping ones.
+
+    `prefix`: which prediction head of a GroupFree3D model ('last_', 'proposal_', '0head_',
+    ...; detection/GroupFree3D/models/ap_helper.py:69); its heads emit ONE objectness logit
+    (sigmoid) where VoteNet's emits two (softmax) -- told apart by the last dimension.
 
     end_points: {center, heading_scores, heading_residuals, size_scores, size_residuals,
     sem_cls_scores, objectness_scores[, point_clouds]} on the GPU; config_dict:
@@ -73,16 +78,18 @@ def parse_predictions(end_points, config_dict):
     upright-camera coordinates, score); also stored in end_points together with 'pred_mask'
     (B,K) -- ap_helper.py:63-199."""
     dc = config_dict['dataset_config']
-    center = end_points['center']
+    center = end_points[prefix + 'center']
     if not center.is_cuda:
         raise RuntimeError("CPU not supported")
     with torch.no_grad():
-        angle, size, center_cam = _decode(end_points, dc)
+        angle, size, center_cam = _decode(end_points, dc, prefix)
         corners = get_3d_box_batch(size, angle, center_cam)           # (B,K,8,3) f64
-        sem = end_points['sem_cls_scores'].detach().float()
+        sem = end_points[prefix + 'sem_cls_scores'].detach().float()
         pred_sem_cls = torch.argmax(sem, -1)
         sem_probs = torch.softmax(sem, -1)
-        obj_prob = torch.softmax(end_points['objectness_scores'].detach().float(), -1)[..., 1]
+        obj = end_points[prefix + 'objectness_scores'].detach().float()
+        obj_prob = torch.sigmoid(obj)[..., 0] if obj.shape[-1] == 1 else \
+            torch.softmax(obj, -1)[..., 1]
         B, K = obj_prob.shape
 
         valid = None

@@ -158,8 +158,8 @@ def test_groupfree_train_steps(cuda):
 
 @pytest.mark.gpu
 def test_groupfree_eval_through_ap_helper(cuda):
-    """The last decoder head's boxes through the evaluation path (the reference's GroupFree3D
-    ap_helper takes a prefix; the keys are copied to the un-prefixed names here)."""
+    """The last decoder head's boxes through the evaluation path
+    (detection/GroupFree3D/models/ap_helper.py: `prefix`, one sigmoid objectness logit)."""
     from backtoreality_amd.groupfree import train as gf_train
     from backtoreality_amd.votenet import ap_helper, train
     cfg = config.scannet_md40()
@@ -168,14 +168,18 @@ def test_groupfree_eval_through_ap_helper(cuda):
     with torch.no_grad():
         end = net({'point_clouds': batch['point_clouds']})
     end.update(batch)
+    cd = dict(train.EVAL_CONFIG_DICT, dataset_config=cfg, conf_thresh=0.0)
+    pred = ap_helper.parse_predictions(end, cd, prefix='last_')
+    # the same boxes through the un-prefixed two-logit form VoteNet's head emits
     for k in ('center', 'heading_scores', 'heading_residuals', 'size_scores', 'size_residuals',
               'sem_cls_scores'):
         end[k] = end['last_' + k]
-    # one sigmoid logit -> the two-class logits parse_predictions takes
     obj = end['last_objectness_scores']
     end['objectness_scores'] = torch.cat([torch.zeros_like(obj), obj], -1)
-    cd = dict(train.EVAL_CONFIG_DICT, dataset_config=cfg, conf_thresh=0.0)
-    pred = ap_helper.parse_predictions(end, cd)
+    pred2 = ap_helper.parse_predictions(end, cd)
+    assert [len(p) for p in pred] == [len(p) for p in pred2]
+    assert np.allclose([s for p in pred for _, _, s in p], [s for p in pred2 for _, _, s in p],
+                       rtol=1e-5, atol=1e-7)
     gt = ap_helper.parse_groundtruths(end, cd)
     calc = ap_helper.APCalculator(0.25)
     calc.step(pred, gt)
@@ -432,3 +436,18 @@ def test_groupfree_wsb_step_matches_reference_gpu(cuda):
     batch = synthetic.make_batch(0, 2, 8192, cfg, use_height=False, device=cuda)
     loss, _ = gf_train.train_step(net, opt, batch, cfg, criterion=groupfree.get_loss_weak)
     assert np.isfinite(float(loss))
+
+
+@pytest.mark.gpu
+def test_groupfree_evaluate_one_epoch(cuda):
+    from backtoreality_amd.groupfree import train as gf_train
+    cfg = config.scannet_md40()
+    net = gf_train.build_model(cfg, cuda, num_decoder_layers=2)
+    batches = [synthetic.make_batch(3 * i, 2, 4096, cfg, use_height=False, device=cuda)
+               for i in range(2)]
+    stats, metrics = gf_train.evaluate_one_epoch(net, batches, cfg,
+                                                 loss_args={'num_decoder_layers': 2})
+    assert net.training and np.isfinite(stats['loss'])
+    assert sorted(metrics) == [0.25, 0.5]
+    assert sorted(metrics[0.25]) == ['0head_', 'last_', 'proposal_']
+    assert 'mAP' in metrics[0.5]['last_']
