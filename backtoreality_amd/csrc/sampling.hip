@@ -40,6 +40,21 @@ __global__ __launch_bounds__(256) void gather_points_grad_kernel(
   }
 }
 
+// (b,n,c)[idx (b,m)] -> (b,m,c): the sampled rows of a channel-LAST tensor in one pass -- what
+// the SA layers need for new_xyz (the reference transposes to (b,3,n), calls gather_points and
+// transposes back, pointnet2_modules.py:238-240: three launches).
+__global__ __launch_bounds__(256) void gather_rows_kernel(int n, int m, int c, long long total,
+                                                          const float *__restrict__ src,
+                                                          const int *__restrict__ idx,
+                                                          float *__restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int ch = (int)(t % c);
+  const long long row = t / c;              // b * m + j
+  const long long bi = row / m;
+  out[t] = src[(bi * n + idx[row]) * c + ch];
+}
+
 // --------------------------------------------------------------------------------------- FPS
 // Selection rule (bit-exact with sampling_gpu.cu:74-178 for block size `bs`):
 //   next = argmax over non-skipped points of key(k) = (d2(k), -tk(k)),
@@ -489,6 +504,16 @@ int btr_gather_points(int b, int c, int n, int npoints, const float *points, con
   hipLaunchKernelGGL(gather_points_kernel, dim3(grid), dim3(256), 0, as_stream(stream), c, n,
                      npoints, total, points, idx, out);
   return check_launch("gather_points");
+}
+
+int btr_gather_rows(int b, int n, int m, int c, const float *src, const int *idx, float *out,
+                    btr_stream_t stream) {
+  if (b <= 0 || m <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(src && idx && out && n > 0, "gather_rows: null pointer or n=%d <= 0", n);
+  const long long total = (long long)b * m * c;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                     n, m, c, total, src, idx, out);
+  return check_launch("gather_rows");
 }
 
 int btr_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,

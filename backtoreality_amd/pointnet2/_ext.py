@@ -71,6 +71,7 @@ _SIGNATURES = {
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
+    "btr_gather_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     # evaluation-side box arithmetic (used by votenet/ap_helper.py)
     "btr_nms_boxes": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, ctypes.c_double, _ci, _vp, _vp]),
     "btr_points_in_boxes": (_ci, [_ci] * 5 + [_vp] * 6),
@@ -240,6 +241,21 @@ def gather_points(points, idx):
     out = torch.empty((B, C, M), dtype=torch.float32, device=points.device)
     with _on(points) as dev:
         _call(_lib.btr_gather_points, B, C, N, M, _p(points), _p(idx), _p(out), _stream(dev))
+    return out
+
+
+def gather_rows(src, idx):
+    """(B,N,C) f32, (B,M) i32 -> (B,M,C): the rows `idx` of a channel-last tensor."""
+    _check(src, "src", "float")
+    _check(idx, "idx", "int", like=src)
+    _gpu_only(src)
+    _require(src.dim() == 3 and idx.dim() == 2 and idx.size(0) == src.size(0),
+             "src must be (B, N, C) and idx (B, M)")
+    B, N, C = src.shape
+    M = idx.size(1)
+    out = torch.empty((B, M, C), dtype=torch.float32, device=src.device)
+    with _on(src) as dev:
+        _call(_lib.btr_gather_rows, B, N, M, C, _p(src), _p(idx), _p(out), _stream(dev))
     return out
 
 

@@ -32,9 +32,7 @@ def _sample_centres(xyz, npoint, inds=None):
         return None, inds
     if inds is None:
         inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
-    xyz_flipped = xyz.transpose(1, 2).contiguous()
-    new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
-    return new_xyz, inds
+    return pointnet2_utils.gather_rows(xyz, inds), inds
 
 
 def _pool(new_features, grouped_xyz, pooling, sigma, nsample):

@@ -85,6 +85,31 @@ class GatherOperation(Function):
 gather_operation = GatherOperation.apply
 
 
+class GatherRows(Function):
+    """rows `idx (B,M)` of a channel-last `(B,N,C)` tensor -> `(B,M,C)`; one launch on the GPU
+    instead of transpose + gather_operation + transpose, same values and gradient."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = src.size(1)
+        return _ext.gather_rows(src.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        g = _ext.gather_points_grad(grad_out.transpose(1, 2).contiguous(), idx, ctx.n)
+        return g.transpose(1, 2).contiguous(), None
+
+
+def gather_rows(src, idx):
+    """(B,N,C)[idx (B,M)] -> (B,M,C).  Extensions without `gather_rows` (the CPU oracle
+    adapter) take the reference's transpose + gather + transpose route."""
+    if hasattr(_ext, "gather_rows") and src.is_cuda:
+        return GatherRows.apply(src, idx)
+    return gather_operation(src.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+
+
 class ThreeNN(Function):
     """unknown (B,n,3), known (B,m,3) -> (l2 dist (B,n,3), idx (B,n,3)); no gradient (:120-146)."""
 

@@ -69,7 +69,7 @@ class Pointnet2Backbone(nn.Module):
             cur, inds = xyz, None
             for li, npoint in enumerate(npoints):
                 if li > 0:
-                    cur = torch.gather(cur, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+                    cur = pointnet2_utils.gather_rows(cur, inds)
                     cur.record_stream(side)
                 inds = pointnet2_utils.furthest_point_sample(cur, npoint)
                 inds.record_stream(main)
@@ -101,7 +101,7 @@ class Pointnet2Backbone(nn.Module):
         with torch.cuda.stream(side):
             cur, inds = xyz, inds1
             for npoint in npoints[1:]:
-                cur = torch.gather(cur, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+                cur = pointnet2_utils.gather_rows(cur, inds)
                 inds = pointnet2_utils.furthest_point_sample(cur, npoint)
                 inds.record_stream(main)
                 cur.record_stream(side)

@@ -289,6 +289,12 @@ int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
                          float *dagg, float *dvote, const float *weights8, int vote_mode,
                          const int *i2v, btr_stream_t stream);
 
+/* out (b,m,c) <- src (b,n,c)[idx (b,m)]: row gather of a channel-last tensor.  No counterpart of
+ * its own in the reference: it does transpose + gather_points + transpose for `new_xyz`
+ * (pointnet2/pointnet2_modules.py:238-240); same values. */
+int btr_gather_rows(int b, int n, int m, int c, const float *src, const int *idx, float *out,
+                    btr_stream_t stream);
+
 /* ---- Evaluation-side box arithmetic (the caller after the forward at eval time).
  * The reference runs these per box in numpy / scipy on the host, in float64; so do the kernels.
  *

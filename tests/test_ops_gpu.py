@@ -278,3 +278,22 @@ def test_errors_match_reference(cuda):
         e.gather_points(torch.zeros(1, 3, 10, device=cuda), torch.zeros(1, 4, device=cuda))
     with pytest.raises(RuntimeError, match="float tensor"):
         e.three_nn(xc.double(), xc)
+
+
+def test_gather_rows_matches_the_transpose_gather_route(cuda):
+    """pointnet2_utils.gather_rows (one launch) against the reference's transpose +
+    gather_operation + transpose for new_xyz (pointnet2_modules.py:238-240), values and
+    gradient, with repeated indices."""
+    from backtoreality_amd.pointnet2 import pointnet2_utils as U
+    g = torch.Generator().manual_seed(0)
+    for (B, N, M, C) in ((2, 1000, 300, 3), (3, 64, 64, 5), (1, 7, 20, 1)):
+        src = torch.randn(B, N, C, generator=g).to(cuda).requires_grad_(True)
+        idx = torch.randint(0, N, (B, M), generator=g).int().to(cuda)
+        w = torch.randn(B, M, C, generator=g).to(cuda)
+        out = U.gather_rows(src, idx)
+        (out * w).sum().backward()
+        g1, src.grad = src.grad.clone(), None
+        ref = U.gather_operation(src.transpose(1, 2).contiguous(), idx).transpose(1, 2)
+        (ref * w).sum().backward()
+        assert torch.equal(out, ref)
+        assert torch.allclose(g1, src.grad, rtol=1e-5, atol=1e-6)
