@@ -152,12 +152,23 @@ def make_optimizer(net, lr=1e-3, weight_decay=0.0):
     return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
 
 
-def enable_conv_autotune():
+MIOPEN_DB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                             "miopen_db")
+
+
+def enable_conv_autotune(use_shipped_db=True):
     """`torch.backends.cudnn.benchmark = True` like the reference's GroupFree3D scripts
-    (train_GF_FSB.py:454-455): on ROCm MIOpen then benchmarks its solvers for every new
-    convolution shape (the 1x1 convolutions of the FP / voting / proposal layers) the first time
-    it sees it -- tens of seconds in the first step, 0.2 ms per step afterwards (10.0 -> 9.8
-    ms).  The hand-written kernels are not affected."""
+    (train_GF_FSB.py:454-455): on ROCm MIOpen then times its solvers for every new convolution
+    shape (the 1x1 convolutions of the FP / voting / proposal layers) the first time it sees
+    it and uses the fastest from then on -- 0.15-0.9 ms per step here (FSB 9.44 -> 9.30 ms,
+    Back-to-Reality 18.0 -> 17.3 ms).  The search costs 20-60 s per process on a fresh machine;
+    `use_shipped_db` points MIOpen's user find-db (MIOPEN_USER_DB_PATH, unless already set) at
+    backtoreality_amd/miopen_db/, which holds the search results for the bench workloads on
+    gfx950 / this MIOpen build (tools/miopen_db.sh regenerates it), so that they are looked
+    up instead.  Call before the first convolution runs.  The hand-written kernels are not
+    affected."""
+    if use_shipped_db and "MIOPEN_USER_DB_PATH" not in os.environ and os.path.isdir(MIOPEN_DB_DIR):
+        os.environ["MIOPEN_USER_DB_PATH"] = MIOPEN_DB_DIR
     torch.backends.cudnn.enabled = True
     torch.backends.cudnn.benchmark = True
 
