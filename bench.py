@@ -122,6 +122,8 @@ def main():
     gfbr = args.workload == "gfbr"
     if gf:
         from backtoreality_amd.groupfree import train as gf_train
+        if not args.no_conv_autotune:     # shipped GEMM solution choices (TunableOp)
+            gf_train.enable_gemm_tuning()
         if args.points == 40000 and args.batch == 8:      # configs[3]: 4 x 50 000 points
             args.points, args.batch = 50000, 4
         net = gf_train.build_model(cfg, dev, domain_adaptation=gfbr)
