@@ -39,6 +39,34 @@ def make_optimizer(net, lr=0.004, decoder_lr=0.0004, weight_decay=0.0005, captur
                              capturable=bool(capturable and fused))
 
 
+def get_scheduler(optimizer, n_iter_per_epoch, lr_scheduler="step", max_epoch=400,
+                  lr_decay_epochs=(280, 340), lr_decay_rate=0.1, warmup_epoch=-1,
+                  warmup_multiplier=100):
+    """Per-ITERATION learning-rate schedule of train_GF_*.py (utils/lr_scheduler.py:65-87;
+    defaults train_GF_FSB.py:66-82): step decay at the given epochs or cosine annealing, with
+    an optional linear warm-up from lr / multiplier over `warmup_epoch` epochs; call `.step()`
+    after every optimizer step."""
+    from torch.optim.lr_scheduler import (CosineAnnealingLR, LinearLR, MultiStepLR,
+                                          SequentialLR)
+    if "cosine" in lr_scheduler:
+        sched = CosineAnnealingLR(optimizer, eta_min=0.000001,
+                                  T_max=(max_epoch - warmup_epoch) * n_iter_per_epoch)
+    elif "step" in lr_scheduler:
+        if isinstance(lr_decay_epochs, int):
+            lr_decay_epochs = [lr_decay_epochs]
+        sched = MultiStepLR(optimizer, gamma=lr_decay_rate,
+                            milestones=[(m - warmup_epoch) * n_iter_per_epoch
+                                        for m in lr_decay_epochs])
+    else:
+        raise NotImplementedError("scheduler %s not supported" % lr_scheduler)
+    if warmup_epoch > 0:
+        warm = LinearLR(optimizer, start_factor=1.0 / warmup_multiplier, end_factor=1.0,
+                        total_iters=warmup_epoch * n_iter_per_epoch)
+        sched = SequentialLR(optimizer, [warm, sched],
+                             milestones=[warmup_epoch * n_iter_per_epoch])
+    return sched
+
+
 def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, criterion=None):
     """One optimisation step (train_GF_FSB.py:287-322) on `batch` (label dict on the model's
     device, GroupFree3D schema: VoteNet's keys + size_gts, point_obj_mask,

@@ -156,6 +156,36 @@ MIOPEN_DB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__f
                              "miopen_db")
 
 
+# ------------------------------------------------ epoch-level schedules of the training scripts
+def get_current_lr(epoch, base_lr=0.001, decay_steps=(80, 120, 160), decay_rates=(0.1, 0.1, 0.1)):
+    """Step schedule of train_Votenet_*.py (:191-196; defaults :55-60)."""
+    lr = base_lr
+    for step, rate in zip(decay_steps, decay_rates):
+        if epoch >= step:
+            lr *= rate
+    return lr
+
+
+def adjust_learning_rate(optimizer, epoch, **schedule):
+    """train_Votenet_FSB.py:198-201."""
+    lr = get_current_lr(epoch, **schedule)
+    for group in optimizer.param_groups:
+        group['lr'] = lr
+    return lr
+
+
+def make_bn_momentum_scheduler(net, start_epoch=0, bn_decay_step=20, bn_decay_rate=0.5,
+                               momentum_init=0.5, momentum_max=0.001):
+    """The BatchNorm-momentum decay of train_Votenet_*.py (:186-189): 0.5 halved every 20
+    epochs, floor 0.001; `.step()` once per epoch.  The fused set-abstraction layers read
+    `bn.momentum` at every call, so they follow the scheduler like torch's own modules."""
+    from ..pointnet2.pytorch_utils import BNMomentumScheduler
+
+    def bn_lambda(it):
+        return max(momentum_init * bn_decay_rate ** (int(it / bn_decay_step)), momentum_max)
+    return BNMomentumScheduler(net, bn_lambda=bn_lambda, last_epoch=start_epoch - 1)
+
+
 def enable_conv_autotune(use_shipped_db=True):
     """`torch.backends.cudnn.benchmark = True` like the reference's GroupFree3D scripts
     (train_GF_FSB.py:454-455): on ROCm MIOpen then times its solvers for every new convolution

@@ -213,3 +213,36 @@ def test_shipped_library_tuning_files(monkeypatch):
         assert os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"
     finally:
         torch.backends.cudnn.benchmark = old
+
+
+def test_epoch_schedules_of_the_training_scripts():
+    from backtoreality_amd.groupfree import train as gf_train
+    from backtoreality_amd.votenet import train
+    assert train.get_current_lr(0) == 0.001 and train.get_current_lr(79) == 0.001
+    assert abs(train.get_current_lr(80) - 1e-4) < 1e-12
+    assert abs(train.get_current_lr(160) - 1e-6) < 1e-15
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+    opt = torch.optim.Adam(lin.parameters(), lr=1.0)
+    assert abs(train.adjust_learning_rate(opt, 120) - 1e-5) < 1e-15
+    assert abs(opt.param_groups[0]['lr'] - 1e-5) < 1e-15
+    sch = train.make_bn_momentum_scheduler(lin)
+    assert lin[1].momentum == 0.5
+    for _ in range(20):      # the scripts call step() at the START of epochs 0..19
+        sch.step()
+    assert lin[1].momentum == 0.5
+    sch.step()               # epoch 20
+    assert lin[1].momentum == 0.25
+    sch.step(400)
+    assert lin[1].momentum == 0.001
+    opt = torch.optim.AdamW([{"params": [lin[0].weight]}, {"params": [lin[0].bias], "lr": 0.0004}],
+                            lr=0.004)
+    s = gf_train.get_scheduler(opt, n_iter_per_epoch=2, lr_decay_epochs=(3, 5), warmup_epoch=-1)
+    lrs = []
+    for _ in range(13):
+        lrs.append(opt.param_groups[0]['lr'])
+        opt.step()
+        s.step()
+    # milestones at (3 + 1) * 2 = 8 and (5 + 1) * 2 = 12 iterations
+    assert abs(lrs[7] - 0.004) < 1e-12 and abs(lrs[8] - 0.0004) < 1e-12
+    assert abs(lrs[12] - 0.00004) < 1e-12
+    assert abs(opt.param_groups[1]['lr'] - 0.000004) < 1e-12
