@@ -13,6 +13,7 @@ import torch  # noqa: E402
 from backtoreality_amd.votenet import config, synthetic, train  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+train.enable_conv_autotune()
 dev = torch.device("cuda:0")
 cfg = config.scannet_md40()
 batch = synthetic.make_batch(0, 8, 40000, cfg, device=dev)
