@@ -311,7 +311,7 @@ def roofline_objects(kernels, detail, detail_steps):
                                       "traffic": pmc_traffic("bq_grid_query_kernel"),
                                       "algorithmic_bytes": nbytes,
                                       "shape": [b, n, m, s], "avg_ms": ms,
-                                      "note": "grid-culled query incl. grid build (5 launches)"}
+                                      "note": "grid-culled query incl. the one-launch grid build (2 launches)"}
     # grouped shared MLP: every f32-MFMA GEMM launch of the fused SA path (fwd NT with BN
     # prologue/epilogue, dgrad NT, wgrad TN); flops = 2*rows*n*k per launch
     gemm = [(k, t) for (o, k), t in detail.items() if o in ("sa_gemm_nt", "sa_gemm_tn", "sa_gemm_nt_pool", "sa_gemm_tn_pool", "sa_gemm_nt_rc", "sa_gemm_tn_rc")]
