@@ -89,14 +89,26 @@ __device__ __forceinline__ float4 rc_y4(const float4 x, const float *__restrict_
 //   dY[r][k] = pa[k]*Y[r][k] + pb[k] + (r % S == parg[r/S][k] ? pdcl[r/S][k] : 0)
 // (pa = alpha, pb = beta, pdcl = scale*dOut where the pooled output is > 0; see
 // btr_sa_pool_bwd_coef).
-template <int BN, int PRO, bool STATS>
+// PS > 0 ("pooling epilogue", BN == 128 only: a wave owns 64 consecutive rows): per group of PS
+// rows and column the epilogue also emits the extremum of C that the max-pool will select and
+// the row where it occurs first -- gext [R/PS][N] f32, aext [R/PS][N] u8.  BatchNorm + ReLU
+// are monotone per channel, non-decreasing for scale > 0 and non-increasing for scale < 0, and
+// sign(scale) = sign(gamma) (`gsign` = the layer's gamma) is known before the statistics are:
+// the maximum is tracked where gamma >= 0, the minimum elsewhere, and the max-pool of the
+// activated layer is relu(scale * gext + shift).  The pool kernel's pass over the whole pre-BN
+// tensor (537 MB for SA1) becomes a pass over 1/PS of it (sa_pool_fin_kernel).
+template <int BN, int PRO, bool STATS, int PS = 0>
 // (second launch bound: at least 2 waves per SIMD, i.e. <= 256 VGPRs -- two workgroups per
 // CU; without it the PRO == 2 / BN = 128 variant allocates 292 and runs alone on its CU)
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
     float *__restrict__ C, int ldc, int R, int N, int K, const float *__restrict__ pa,
     const float *__restrict__ pb, float *__restrict__ part,
-    const unsigned char *__restrict__ parg, const float *__restrict__ pdcl, int SSH) {
+    const unsigned char *__restrict__ parg, const float *__restrict__ pdcl, int SSH,
+    const float *__restrict__ gsign = nullptr, float *__restrict__ gext = nullptr,
+    unsigned char *__restrict__ aext = nullptr) {
+  static_assert(PS == 0 || (BN == 128 && (PS == 16 || PS == 32 || PS == 64)),
+                "pooling epilogue: 128-column tiles, groups of 16 / 32 / 64 rows");
   constexpr int WN = BN / 64;      // waves along N
   constexpr int WM = 4 / WN;       // waves along M
   constexpr int MI = kBM / WM / 32;  // 32-row MFMA tiles per wave
@@ -263,6 +275,51 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
           }
         }
       }
+    if constexpr (PS > 0) {
+      // this wave's 64 rows = 64 / PS whole groups; lanes l and l ^ 32 hold the same column
+      // (rows interleaved in blocks of 4), v ascending = rows ascending within a lane
+      constexpr int G = 64 / PS;
+      const int wrow0 = r0 + wm * (kBM / WM);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n_blk + wn * 64 + j * 32 + l31;
+        const float sg = (col < N && gsign[col] < 0.f) ? -1.f : 1.f;
+        float vmx[G];
+        int imx[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          vmx[g] = -3.0e38f;
+          imx[g] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int rw = i * 32 + (v & 3) + 8 * (v >> 2);   // + 4 * h (same group)
+            const int g = rw / PS;
+            const float c = acc[i][j][v] * sg;
+            if (c > vmx[g]) {
+              vmx[g] = c;
+              imx[g] = rw - g * PS;
+            }
+          }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int mine = imx[g] + 4 * h;
+          const float omx = __shfl_xor(vmx[g], 32);
+          const int oix = __shfl_xor(mine, 32);
+          const bool take = omx > vmx[g] || (omx == vmx[g] && oix < mine);
+          const float best = take ? omx : vmx[g];
+          const int bidx = take ? oix : mine;
+          const int grow = wrow0 + g * PS;
+          if (h == 0 && grow < R && col < N) {
+            const size_t o = (size_t)(grow / PS) * N + col;
+            gext[o] = best * sg;
+            aext[o] = (unsigned char)bidx;
+          }
+        }
+      }
+    }
   }
   if (STATS) {
 #pragma unroll
@@ -390,6 +447,28 @@ __global__ __launch_bounds__(256) void sa_pool_kernel(int M, int S, int C, int l
   out[((size_t)bi * C + c) * M + m] = best;
   if (out_cl) out_cl[(size_t)g * C + c] = best;
   arg[(size_t)g * C + c] = (unsigned char)bs;
+}
+
+// Max-pool of relu(bn(Y)) from the per-group extremum the pooling epilogue of the last layer's
+// GEMM emitted (see gemm_nt_kernel, PS): out / out_cl / arg as sa_pool4_kernel writes them.
+// relu(fma(a, y, b)) is monotone in y, so the pooled value is the one of the extremum; its row
+// (first occurrence) is the arg-max unless the pooled value is 0, where sa_pool4_kernel keeps
+// row 0 and no gradient flows anyway.
+__global__ __launch_bounds__(256) void sa_pool_fin_kernel(
+    int M, int C, const float *__restrict__ gext, const unsigned char *__restrict__ aext,
+    const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
+    float *__restrict__ out_cl, unsigned char *__restrict__ arg, long long groups) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= groups * C) return;
+  const long long g = t / C;
+  const int c = (int)(t - g * C);
+  const float a = scale[c], b = shift[c];
+  const float v = fmaxf(fmaf(a, gext[t], b), 0.f);
+  const long long bi = g / M;
+  const int m = (int)(g - bi * M);
+  out[((size_t)bi * C + c) * M + m] = v;
+  if (out_cl) out_cl[t] = v;
+  arg[t] = v > 0.f ? aext[t] : (unsigned char)0;
 }
 
 // Same with four channels per thread (C % 4 == 0, ldy % 4 == 0): 16-byte loads, four
@@ -1177,6 +1256,12 @@ static int ilog2(int v) {
 // Number of workgroups (= rows of the `part` buffer) btr_sa_gemm_nt uses along rows.
 int btr_sa_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, kBM), 512)); }
 
+// Whether the last layer's GEMM can emit the per-group extrema itself (pooling epilogue):
+// 128-column tiles (n > 64) and whole groups of 16 / 32 / 64 rows per wave.
+int btr_sa_gemm_nt_poolfwd_supported(int rows, int n, int s) {
+  return n > 64 && (s == 16 || s == 32 || s == 64) && rows > 0 && rows % s == 0;
+}
+
 // C[rows][n] = f(A)[rows][k] . W[n][k]^T;  pa/pb != NULL: f = relu(pa*y+pb) per k;
 // part != NULL: per-workgroup column sums / sums of squares -> part[grid][2][n].
 int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
@@ -1213,6 +1298,43 @@ int btr_sa_bn_finalize(int n, int nblk, double count, float eps, float momentum,
                      nblk, count, eps, momentum, part, gamma, beta, scale, shift, mean, invstd,
                      running_mean, running_var);
   return check_launch("sa_bn_finalize");
+}
+
+int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, const float *w,
+                           int ldw, float *c, int ldc, const float *pa, const float *pb,
+                           float *part, int s, const float *gamma, float *gext,
+                           unsigned char *aext, btr_stream_t stream) {
+  if (rows <= 0 || n <= 0) return BTR_OK;
+  BTR_REQUIRE(a && w && c && part && pa && pb && gamma && gext && aext && k > 0 &&
+                  k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
+              "sa_gemm_nt_poolfwd: null pointer or k=%d lda=%d ldw=%d not multiples of 4", k,
+              lda, ldw);
+  BTR_REQUIRE(btr_sa_gemm_nt_poolfwd_supported(rows, n, s),
+              "sa_gemm_nt_poolfwd: n=%d / nsample=%d not supported", n, s);
+  const int gx = btr_sa_gemm_grid(rows);
+  hipStream_t st = as_stream(stream);
+#define BTR_GEMM(PS)                                                                          \
+  hipLaunchKernelGGL((gemm_nt_kernel<128, 1, true, PS>), dim3(gx, cdiv(n, 128)), dim3(256), 0,  \
+                     st, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,                      \
+                     (const unsigned char *)nullptr, (const float *)nullptr, 0, gamma, gext,    \
+                     aext)
+  if (s == 16) BTR_GEMM(16);
+  else if (s == 32) BTR_GEMM(32);
+  else BTR_GEMM(64);
+#undef BTR_GEMM
+  return check_launch("sa_gemm_nt_poolfwd");
+}
+
+int btr_sa_pool_fin(int b, int m, int c, const float *gext, const unsigned char *aext,
+                    const float *scale, const float *shift, float *out, float *out_cl,
+                    unsigned char *arg, btr_stream_t stream) {
+  const long long groups = (long long)b * m;
+  if (groups <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(gext && aext && scale && shift && out && arg, "sa_pool_fin: null pointer");
+  hipLaunchKernelGGL(sa_pool_fin_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
+                     as_stream(stream), m, c, gext, aext, scale, shift, out, out_cl, arg,
+                     groups);
+  return check_launch("sa_pool_fin");
 }
 
 int btr_sa_pool(int b, int m, int s, int c, int ldy, const float *y, const float *scale,

@@ -72,6 +72,10 @@ _SIGNATURES = {
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
     "btr_gather_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
+    "btr_sa_gemm_nt_poolfwd_supported": (_ci, [_ci, _ci, _ci]),
+    "btr_sa_gemm_nt_poolfwd": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp,
+                                     _ci, _vp, _vp, _vp, _vp]),
+    "btr_sa_pool_fin": (_ci, [_ci, _ci, _ci] + [_vp] * 8),
     # evaluation-side box arithmetic (used by votenet/ap_helper.py)
     "btr_nms_boxes": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, ctypes.c_double, _ci, _vp, _vp]),
     "btr_points_in_boxes": (_ci, [_ci] * 5 + [_vp] * 6),

@@ -67,6 +67,7 @@ class FusedSAFunction(Function):
             _call(_lib.btr_sa_gather, B, N, M, S, C, K0p, use_xyz, rdiv, _p(xyz), _p(new_xyz),
                   _p(feats_cl), _p(idx), _p(X0), st)
             grid = _lib.btr_sa_gemm_grid(R)
+            ext = None
             Ys, stats, Ws, counters = [], [], [], []
             A, lda, K = X0, K0p, K0p
             pa = pb = None
@@ -92,6 +93,16 @@ class FusedSAFunction(Function):
                     Y = _f32((R, Nl), dev)
                     _call(_lib.btr_sa_gemm_nt_rc, R, Nl, K, _p(X0), _p(Ws[0]), _p(W2), K, _p(Y),
                           Nl, _p(pa), _p(pb), _p(part), st, key=(R, Nl, K))
+                elif (l == L - 1 and pa is not None and _pool_in_epilogue() and
+                      _lib.btr_sa_gemm_nt_poolfwd_supported(R, Nl, S)):
+                    # last layer: the GEMM epilogue also emits the per-group extrema, so the
+                    # max-pool below does not read Y again
+                    Y = _f32((R, Nl), dev)
+                    ext = (_f32((R // S, Nl), dev),
+                           torch.empty((R // S, Nl), dtype=torch.uint8, device=dev))
+                    _call(_lib.btr_sa_gemm_nt_poolfwd, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl,
+                          _p(pa), _p(pb), _p(part), S, _p(gamma), _p(ext[0]), _p(ext[1]), st,
+                          key=(R, Nl, K))
                 else:
                     Y = _f32((R, Nl), dev)
                     _call(_lib.btr_sa_gemm_nt, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl,
@@ -118,8 +129,12 @@ class FusedSAFunction(Function):
             out = _f32((B, CL, M), dev)
             out_cl = _f32((B, M, CL), dev)
             arg = torch.empty((B * M, CL), dtype=torch.uint8, device=dev)
-            _call(_lib.btr_sa_pool, B, M, S, CL, CL, _p(Ys[-1]), _p(stats[-1][0]),
-                  _p(stats[-1][1]), _p(out), _p(out_cl), _p(arg), st)
+            if ext is not None:
+                _call(_lib.btr_sa_pool_fin, B, M, CL, _p(ext[0]), _p(ext[1]), _p(stats[-1][0]),
+                      _p(stats[-1][1]), _p(out), _p(out_cl), _p(arg), st)
+            else:
+                _call(_lib.btr_sa_pool, B, M, S, CL, CL, _p(Ys[-1]), _p(stats[-1][0]),
+                      _p(stats[-1][1]), _p(out), _p(out_cl), _p(arg), st)
             if counters:  # one launch for the layer's num_batches_tracked += 1
                 torch._foreach_add_(counters, 1)
 
@@ -249,6 +264,12 @@ class FusedSAFunction(Function):
                         if dfeat_cl is not None:
                             dfeat = dfeat_cl.transpose(1, 2).contiguous()
         return (dxyz, dnew, dfeat, None, None) + tuple(grads)
+
+
+def _pool_in_epilogue():
+    """BTR_POOL_EPILOGUE=0: the max-pool reads the last layer's output again (btr_sa_pool)
+    instead of using the extrema the GEMM epilogue emits."""
+    return os.environ.get("BTR_POOL_EPILOGUE", "1") != "0"
 
 
 def _pool_grad_in_prologue(nsample):

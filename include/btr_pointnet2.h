@@ -233,6 +233,21 @@ int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, co
                          const float *invstd, const float *scale, const float *shift,
                          float *part, float *m1, float *m2, float *dgamma, float *dbeta,
                          float *dcl, float *alpha, float *beta, btr_stream_t stream);
+/* Pooling epilogue: the last MLP layer's GEMM (prologue = previous layer's BN + ReLU, epilogue =
+ * BN statistics) also emits, per group of `s` rows and column, the extremum of the pre-BN output
+ * that the max-pool will select (the maximum where gamma >= 0, the minimum elsewhere: BatchNorm +
+ * ReLU are monotone per channel and sign(scale) = sign(gamma)) and the row where it occurs first:
+ * gext [rows/s][n] f32, aext [rows/s][n] u8.  btr_sa_pool_fin turns them into what btr_sa_pool
+ * computes from the whole tensor.  btr_sa_gemm_nt_poolfwd_supported: n > 64, s in {16,32,64},
+ * rows % s == 0. */
+int btr_sa_gemm_nt_poolfwd_supported(int rows, int n, int s);
+int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, const float *w,
+                           int ldw, float *c, int ldc, const float *pa, const float *pb,
+                           float *part, int s, const float *gamma, float *gext,
+                           unsigned char *aext, btr_stream_t stream);
+int btr_sa_pool_fin(int b, int m, int c, const float *gext, const unsigned char *aext,
+                    const float *scale, const float *shift, float *out, float *out_cl,
+                    unsigned char *arg, btr_stream_t stream);
 int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const float *w, int ldw,
                         float *c, int ldc, int s, const unsigned char *arg, const float *dcl,
                         const float *alpha, const float *beta, btr_stream_t stream);

@@ -164,3 +164,34 @@ def test_first_layer_recompute(cuda, monkeypatch, recompute, C, mlp):
     for k in sorted(ref):
         tol = 1e-4 if k == "out" or "running" in k or "tracked" in k else 5e-4
         assert _rel(got[k], ref[k]) < tol, (k, _rel(got[k], ref[k]))
+
+
+@pytest.mark.parametrize("S", [16, 32, 64])
+def test_pooling_epilogue_equals_the_pool_pass(cuda, monkeypatch, S):
+    """The per-group extrema emitted by the last layer's GEMM (BTR_POOL_EPILOGUE, default)
+    give the same pooled features and gradients as the separate pool pass over the whole
+    pre-BN tensor -- including channels with a NEGATIVE BatchNorm weight (minimum tracked) and
+    balls padded with repeated points (ties)."""
+    from backtoreality_amd.pointnet2 import pointnet2_modules as M
+    g = torch.Generator().manual_seed(S)
+    xyz = torch.rand(2, 1500, 3, generator=g).to(cuda)
+    feats = torch.randn(2, 5, 1500, generator=g).to(cuda)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BTR_POOL_EPILOGUE", flag)
+        torch.manual_seed(0)
+        sa = M.PointnetSAModuleVotes(npoint=256, radius=0.15, nsample=S, mlp=[5, 32, 128],
+                                     use_xyz=True, normalize_xyz=True).to(cuda)
+        with torch.no_grad():   # half of the last layer's BN weights negative, one zero
+            w = sa.mlp_module.layer1.bn.bn.weight
+            w[::2] = -w[::2]
+            w[5] = 0.0
+        f = feats.clone().requires_grad_(True)
+        _, nf, _ = sa(xyz, f)
+        (nf * torch.linspace(0.5, 1.5, nf.shape[2], device=cuda)).sum().backward()
+        outs[flag] = (nf.detach(), f.grad, sa.mlp_module.layer0.conv.weight.grad,
+                      sa.mlp_module.layer1.bn.bn.weight.grad)
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()) + 1e-12), \
+            float((a - b).abs().max())
+    assert torch.equal(outs["1"][0], outs["0"][0])      # the pooled values are bit-identical
