@@ -92,3 +92,70 @@ def test_two_rank_gloo_step_matches_manual_average(mode):
     for _, _, worst, same in results:
         assert worst < 1e-5, worst
         assert same
+
+
+def _worker_unused(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BTR_DP="flat")
+    torch.set_num_threads(1)
+    from backtoreality_amd.votenet import train
+    train.init_distributed(backend="gloo")
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.used = torch.nn.Linear(4, 3)
+            self.unused = torch.nn.Linear(4, 2)      # no loss term: never gets a gradient
+            self.frozen = torch.nn.Parameter(torch.ones(2), requires_grad=False)
+
+        def forward(self, x):
+            return self.used(x) * self.frozen.sum()
+
+    torch.manual_seed(100 + rank)                    # different initial weights per rank ...
+    net = Net()
+    dp = train.wrap_ddp(net, torch.device("cpu"))    # ... broadcast from rank 0 here
+    w0 = net.used.weight.detach().clone()
+    unused0 = net.unused.weight.detach().clone()
+    gathered = [torch.empty_like(w0) for _ in range(world)]
+    dist.all_gather(gathered, w0)
+    replicated = all(torch.equal(g, w0) for g in gathered)
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=0.1)
+    x = torch.full((5, 4), float(rank + 1))
+    ok = True
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        dp(x).sum().backward()
+        local = net.used.weight.grad.clone()
+        train._sync_grads(dp)
+        want = local.clone()
+        dist.all_reduce(want)
+        want /= world
+        ok = ok and torch.allclose(net.used.weight.grad, want)
+        ok = ok and net.unused.weight.grad is None and net.frozen.grad is None
+        ok = ok and net.used.weight.grad.data_ptr() >= dp.flat_grad.data_ptr()
+        opt.step()
+    same_unused = torch.equal(net.unused.weight, unused0)        # skipped by the optimizer
+    flat = torch.cat([p.detach().flatten() for p in net.parameters()])
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    q.put((rank, replicated, bool(ok), same_unused, all(torch.equal(o, flat) for o in other)))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_parallel_with_unused_and_frozen_parameters():
+    """FlatGradParallel on a module with a parameter that never receives a gradient (the
+    CenterRefine model's jitter_netD) and a frozen one: parameters are broadcast from rank 0,
+    gradients averaged, the unused parameter keeps grad None on every rank (the optimizer
+    skips it alike), replicas stay identical."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_unused, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, replicated, ok, same_unused, same in results:
+        assert replicated and ok and same_unused and same
