@@ -1,68 +1,123 @@
-"""Builds libbtr_pointnet2.so (the C-ABI of include/btr_pointnet2.h) with hipcc for gfx950.
+"""Builds the C-ABI libraries of include/btr_pointnet2.h with hipcc for gfx950.
 
-In-tree build: the .so lands in backtoreality_amd/lib/ so that it travels with the repo
-snapshot to the GPU box (it is git-ignored, not gpurun-ignored).  hipcc cross-compiles without
-a GPU, so this also runs in the CPU-only build container.
+In-tree build: the .so files land in backtoreality_amd/lib/ so that they travel with the repo
+snapshot to the GPU box (git-ignored, not gpurun-ignored).  hipcc cross-compiles without a
+GPU, so this also runs in the CPU-only build container.
+
+One library per rounding mode of the squared distance (BTR_FMAD, csrc/common.hpp):
+    libbtr_pointnet2.so         BTR_FMAD=1  (default: what an nvcc --fmad=true build rounds to)
+    libbtr_pointnet2_fmad0.so   BTR_FMAD=0  (as written, no contraction)
+    libbtr_pointnet2_fmad2.so   BTR_FMAD=2  (left-to-right fma chain)
+Only the index-producing sources depend on the mode; the other objects are shared.  Every
+source is compiled to its own object (in parallel, cached by content hash) and linked.
 """
 import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libbtr_pointnet2.so")
-STAMP = os.path.join(LIB_DIR, "libbtr_pointnet2.stamp")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+LIB_NAMES = {1: "libbtr_pointnet2.so", 0: "libbtr_pointnet2_fmad0.so",
+             2: "libbtr_pointnet2_fmad2.so"}
+LIB_PATH = os.path.join(LIB_DIR, LIB_NAMES[1])
 
 ARCH = "gfx950"
-# -ffp-contract=off: index-producing kernels must round f32 expressions exactly as the
-# reference source writes them (bit-exact parity with the oracle).  Files that want FMA
+# -ffp-contract=off: index-producing kernels must round f32 expressions exactly as the mode
+# says (bit-exact parity with the oracle); nothing may fuse on its own.  Files that want FMA
 # contraction (MFMA GEMM tiles) opt back in with `#pragma clang fp contract(fast)`.
 HIPCC_FLAGS = [
     "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
-    "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+    "-fPIC", "-Wall", "-Wno-unused-function",
 ]
+# sources whose code depends on BTR_FMAD (they evaluate sq3() / dot3())
+MODE_SOURCES = ("ball_query.hip", "ball_query_grid.hip", "fps_bucket.hip", "interpolate.hip",
+                "sampling.hip")
+
+
+def lib_path(mode=1):
+    return os.path.join(LIB_DIR, LIB_NAMES[int(mode)])
 
 
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _digest():
+def _headers_digest():
     h = hashlib.sha256()
     h.update(" ".join(HIPCC_FLAGS).encode())
-    files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
-                               if f.endswith(".hpp"))
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
     files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "btr_pointnet2.h"))
     for f in files:
-        h.update(f.encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
-    return h.hexdigest()
+    return h
+
+
+def _object_plan():
+    """[(source, mode or None, object path)]: one object per source, three for MODE_SOURCES."""
+    base = _headers_digest()
+    plan = []
+    for src in sources():
+        name = os.path.basename(src)
+        with open(src, "rb") as fh:
+            body = fh.read()
+        for mode in ((0, 1, 2) if name in MODE_SOURCES else (None,)):
+            h = base.copy()
+            h.update(body)
+            h.update(str(mode).encode())
+            tag = "" if mode is None else ".fmad%d" % mode
+            plan.append((src, mode, os.path.join(
+                OBJ_DIR, "%s%s.%s.o" % (name[:-4], tag, h.hexdigest()[:16]))))
+    return plan
 
 
 def is_fresh():
-    if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP)):
+    plan = _object_plan()
+    if not all(os.path.exists(o) for _, _, o in plan):
         return False
-    with open(STAMP) as fh:
-        return fh.read().strip() == _digest()
+    newest = max(os.path.getmtime(o) for _, _, o in plan)
+    return all(os.path.exists(lib_path(m)) and os.path.getmtime(lib_path(m)) >= newest
+               for m in LIB_NAMES)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source into LIB_PATH; no-op when sources and flags are unchanged."""
+def build(force=False, verbose=False, jobs=None):
+    """Compile every HIP source and link the three libraries; no-op when nothing changed."""
     if not force and is_fresh():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + sources() + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    with open(STAMP, "w") as fh:
-        fh.write(_digest())
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    plan = _object_plan()
+    todo = [(s, m, o) for s, m, o in plan if force or not os.path.exists(o)]
+
+    def compile_one(item):
+        src, mode, obj = item
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", src, "-o", obj + ".tmp"]
+        if mode is not None:
+            cmd.insert(1, "-DBTR_FMAD=%d" % mode)
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        os.replace(obj + ".tmp", obj)
+
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(compile_one, todo))
+    keep = {o for _, _, o in plan}
+    for f in os.listdir(OBJ_DIR):                      # objects of older source versions
+        if os.path.join(OBJ_DIR, f) not in keep:
+            os.remove(os.path.join(OBJ_DIR, f))
+    for mode in LIB_NAMES:
+        objs = [o for _, m, o in plan if m is None or m == mode]
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", lib_path(mode)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     return LIB_PATH
 
 

@@ -47,8 +47,7 @@ __global__ __launch_bounds__(64) void bq_scan_kernel(int n, int m, int nsample, 
     const int ke = min(k1, kb + 64);
     for (int k = kb; k < ke; ++k) {
       const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-      const float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) +
-                       (new_z - z) * (new_z - z);
+      const float d2 = sq3(new_x - x, new_y - y, new_z - z);
       if (d2 < radius2 && cnt < nsample) {
         if (cnt == 0) first = k;
         out[cnt] = k;
@@ -115,8 +114,7 @@ __global__ __launch_bounds__(256) void bq_wave_kernel(int n, int m, int nsample,
       bool hit = false;
       if (k < n) {
         const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-        const float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) +
-                         (new_z - z) * (new_z - z);
+        const float d2 = sq3(new_x - x, new_y - y, new_z - z);
         hit = d2 < radius2;
       }
       const unsigned long long mask = __ballot(hit);

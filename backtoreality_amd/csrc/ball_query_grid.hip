@@ -356,8 +356,7 @@ __global__ __launch_bounds__(256) void bq_grid_query_kernel(
       const int len = __builtin_amdgcn_readlane(rlen, r);
       for (int t = lane; t < len; t += 64) {
         const float4 p = pts[b + t];
-        const float d2 = (new_x - p.x) * (new_x - p.x) + (new_y - p.y) * (new_y - p.y) +
-                         (new_z - p.z) * (new_z - p.z);
+        const float d2 = sq3(new_x - p.x, new_y - p.y, new_z - p.z);
         if (d2 < radius2) {
           const unsigned k = (unsigned)__float_as_int(p.w);
           atomicOr(&bm[k >> 5], 1u << (k & 31));

@@ -85,6 +85,44 @@ __device__ __forceinline__ void lds_barrier() {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// ------------------------------------------------------------- the one distance expression
+// Every index the path produces (FPS arg-max, ball-query membership, 3-NN order) is decided by
+// the f32 rounding of  a*a + b*b + c*c  with a = x2 - x1 ... (reference sampling_gpu.cu:108-109,
+// :105 for |p|^2; ball_query_gpu.cu:36-38; interpolate_gpu.cu:38).  The reference is built by
+// nvcc -O2 with the default --fmad=true (pointnet2/setup.py:22-25), which CONTRACTS the
+// expression; how is decided by the compiler, not the source, so the rounding is a build
+// mode here (BTR_FMAD, one library per mode, see build.py / DESIGN.md section 2):
+//   1 (default)  fma(c, c, fma(a, a, b*b))  -- the NVPTX/LLVM contraction of ((a*a + b*b) + c*c):
+//                an fadd whose FIRST operand is an fmul fuses that operand, else the second
+//   2            fma(c, c, fma(b, b, a*a))  -- the left-to-right chain
+//   0            ((a*a) + (b*b)) + (c*c)    -- as written, no contraction (--fmad=false)
+// All files are compiled with -ffp-contract=off, so nothing else fuses.  Each form is monotone
+// non-decreasing in |a|, |b|, |c| (products of equal factors and rounded sums / fmas of
+// non-negative terms are), which is what the FPS box-pruning argument needs (fps_bucket.hip).
+#ifndef BTR_FMAD
+#define BTR_FMAD 1
+#endif
+__device__ __forceinline__ float sq3(float a, float b, float c) {
+#if BTR_FMAD == 1
+  return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
+#elif BTR_FMAD == 2
+  return __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a));
+#else
+  return a * a + b * b + c * c;
+#endif
+}
+// p1*w1 + p2*w2 + p3*w3 (three_interpolate, interpolate_gpu.cu:103-104) under the same rule.
+__device__ __forceinline__ float dot3(float p1, float w1, float p2, float w2, float p3,
+                                      float w3) {
+#if BTR_FMAD == 1
+  return __builtin_fmaf(p3, w3, __builtin_fmaf(p1, w1, p2 * w2));
+#elif BTR_FMAD == 2
+  return __builtin_fmaf(p3, w3, __builtin_fmaf(p2, w2, p1 * w1));
+#else
+  return p1 * w1 + p2 * w2 + p3 * w3;
+#endif
+}
+
 }  // namespace btr
 
 #define BTR_REQUIRE(cond, ...)                                              \

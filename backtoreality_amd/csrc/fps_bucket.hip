@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void fps_sortm_scatter_kernel(
     const float x = dataset[k * 3], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
     const int c = morton_cell(x, y, z, bx.mnx, bx.mny, bx.mnz, bx.scale);
     const int pos = atomicAdd(&cells[(size_t)bi * kCells + c], 1);
-    const float mag = (x * x) + (y * y) + (z * z);
+    const float mag = sq3(x, y, z);
     sp[soa_at(pos, 0)] = x;
     sp[soa_at(pos, 1)] = y;
     sp[soa_at(pos, 2)] = z;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       const float cy = fminf(fmaxf(sy, by0[s]), by1[s]);
       const float cz = fminf(fmaxf(sz, bz0[s]), bz1[s]);
       const float ex = cx - sx, ey = cy - sy, ez = cz - sz;
-      const float dbox = ex * ex + ey * ey + ez * ez;
+      const float dbox = sq3(ex, ey, ez);
       const bool active = (__float_as_uint(dbox) + 1u) < mhi[s];  // mhi == 0: none competes
       unsigned long long todo = __ballot(active);
       if (PROF) {
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
         asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(p.x), "v"(sx));
         asm("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(p.y), "v"(sy));
         asm("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(p.z), "v"(sz));
-        const float d = dx * dx + dy * dy + dz * dz;
+        const float d = sq3(dx, dy, dz);
         const bool valid = t0 >= 0.f;
         const float t = valid ? fminf(d, t0) : t0;
         if (t != t0) tmin[co] = t;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
           const float cy = fminf(fmaxf(ay[a], by0[s]), by1[s]);
           const float cz = fminf(fmaxf(az[a], bz0[s]), bz1[s]);
           const float ex = cx - ax[a], ey = cy - ay[a], ez = cz - az[a];
-          const float dbox = ex * ex + ey * ey + ez * ez;
+          const float dbox = sq3(ex, ey, ez);
           active |= (__float_as_uint(dbox) + 1u) < mhi[s];
         }
       }
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
           for (int a = 0; a < KMAX; ++a) {
             if (a < nacc) {
               const float dx = p_[u].x - ax[a], dy = p_[u].y - ay[a], dz = p_[u].z - az[a];
-              const float d = dx * dx + dy * dy + dz * dz;
+              const float d = sq3(dx, dy, dz);
               t = valid ? fminf(d, t) : t;
             }
           }
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
           const float tt = __uint_as_float(ht - 1u);
           const float xt = rl_f(c.x, t), yt = rl_f(c.y, t), zt = rl_f(c.z, t);
           const float dx = xt - c.x, dy = yt - c.y, dz = zt - c.z;           // point c_t, sample c_r
-          const float d = dx * dx + dy * dy + dz * dz;
+          const float d = sq3(dx, dy, dz);
           const bool viol = lane < t && (fminf(d, tt) != tt || c.b2hi >= ht);  // (ii), (iii)
           if (__ballot(viol)) break;
           A = t + 1;

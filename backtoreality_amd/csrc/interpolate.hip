@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void three_nn_kernel(int n, int m,
   int besti1 = 0, besti2 = 0, besti3 = 0;
   for (int k = 0; k < m; ++k) {
     const float x = known[k * 3 + 0], y = known[k * 3 + 1], z = known[k * 3 + 2];
-    const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+    const float d = sq3(ux - x, uy - y, uz - z);
     // branch-free form of the reference's if / else-if / else-if insertion (:39-54):
     // strict `<` against the current 1st/2nd/3rd keeps the earliest index on ties
     const bool c1 = d < best1, c2 = d < best2, c3 = d < best3;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void three_nn_split_kernel(int n, int m,
   const int k1 = min(m, (part + 1) * per);
   for (int k = part * per; k < k1; ++k) {
     const float x = known[k * 3 + 0], y = known[k * 3 + 1], z = known[k * 3 + 2];
-    const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+    const float d = sq3(ux - x, uy - y, uz - z);
     const bool c1 = d < t.d1, c2 = d < t.d2, c3 = d < t.d3;  // indices ascend inside a slice
     t.d3 = c2 ? t.d2 : (c3 ? d : t.d3);
     t.i3 = c2 ? t.i2 : (c3 ? k : t.i3);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(
   const int lc = min(kInterpCh, c - l0);
   for (int l = 0; l < lc; ++l) {
     const float *p = points + ((size_t)bi * c + l0 + l) * m;
-    out[((size_t)bi * c + l0 + l) * n + j] = p[i1] * w1 + p[i2] * w2 + p[i3] * w3;
+    out[((size_t)bi * c + l0 + l) * n + j] = dot3(p[i1], w1, p[i2], w2, p[i3], w3);
   }
 }
 

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, int bs, int log2bs
         px[i] = dataset[k * 3 + 0];
         py[i] = dataset[k * 3 + 1];
         pz[i] = dataset[k * 3 + 2];
-        const float mag = (px[i] * px[i]) + (py[i] * py[i]) + (pz[i] * pz[i]);
+        const float mag = sq3(px[i], py[i], pz[i]);
         pt[i] = ((double)mag <= 1e-3) ? -1.f : 1e10f;  // sampling_gpu.cu:105-106
         plo[i] = 0xffffffffu - fps_tk(k, bs, log2bs, cpb);
       }
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, int bs, int log2bs
   } else {
     for (int k = tid; k < n; k += T) {
       const float x = dataset[k * 3 + 0], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
-      const float mag = (x * x) + (y * y) + (z * z);
+      const float mag = sq3(x, y, z);
       temp[k] = ((double)mag <= 1e-3) ? -1.f : 1e10f;
     }
   }
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, int bs, int log2bs
 #pragma unroll
       for (int i = 0; i < PPT; ++i) {
         const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-        const float d = dx * dx + dy * dy + dz * dz;
+        const float d = sq3(dx, dy, dz);
         const bool valid = pt[i] >= 0.f;
         const float d2 = valid ? fminf(d, pt[i]) : pt[i];
         pt[i] = d2;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, int bs, int log2bs
         if (t < 0.f) continue;
         const float x = dataset[k * 3 + 0], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
         const float dx = x - x1, dy = y - y1, dz = z - z1;
-        const float d = dx * dx + dy * dy + dz * dz;
+        const float d = sq3(dx, dy, dz);
         const float d2 = fminf(d, t);
         temp[k] = d2;
         const unsigned hi = __float_as_uint(d2) + 1u;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs,
       px[i] = dataset[k * 3 + 0];
       py[i] = dataset[k * 3 + 1];
       pz[i] = dataset[k * 3 + 2];
-      const float mag = (px[i] * px[i]) + (py[i] * py[i]) + (pz[i] * pz[i]);
+      const float mag = sq3(px[i], py[i], pz[i]);
       pt[i] = ((double)mag <= 1e-3) ? kSkip : __float_as_int(1e10f);  // sampling_gpu.cu:105-106
     }
     lx[k] = px[i];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs,
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-      const int d = __float_as_int(dx * dx + dy * dy + dz * dz);
+      const int d = __float_as_int(sq3(dx, dy, dz));
       pt[i] = d < pt[i] ? d : pt[i];
       mi = mi > pt[i] ? mi : pt[i];
     }
@@ -443,6 +443,8 @@ using namespace btr;
 extern "C" {
 
 int btr_abi_version(void) { return BTR_ABI_VERSION; }
+
+int btr_distance_mode(void) { return BTR_FMAD; }
 
 const char *btr_last_error(void) { return err_buf(); }
 

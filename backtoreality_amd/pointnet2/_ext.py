@@ -15,7 +15,11 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libbtr_pointnet2.so")
+# one library per rounding mode of the squared distance (include/btr_pointnet2.h,
+# btr_distance_mode): 1 = nvcc-style contraction (default), 0 = as written, 2 = left-to-right
+_LIB_NAMES = {1: "libbtr_pointnet2.so", 0: "libbtr_pointnet2_fmad0.so",
+              2: "libbtr_pointnet2_fmad2.so"}
+LIB_PATH = os.path.join(_PKG, "lib", _LIB_NAMES[1])
 
 _vp = ctypes.c_void_p
 _ci = ctypes.c_int
@@ -27,6 +31,7 @@ _sz = ctypes.c_size_t
 # name -> (restype, argtypes); mirrors include/btr_pointnet2.h one to one.
 _SIGNATURES = {
     "btr_abi_version": (_ci, []),
+    "btr_distance_mode": (_ci, []),
     "btr_last_error": (ctypes.c_char_p, []),
     "btr_opt_n_threads": (_ci, [_ci]),
     "btr_furthest_point_sampling": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp]),
@@ -83,23 +88,45 @@ _SIGNATURES = {
 }
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
+def _load(mode=1):
+    path = os.path.join(_PKG, "lib", _LIB_NAMES[mode])
+    if not os.path.exists(path):
         raise ImportError(
             "Could not import _ext: %s is missing.\n"
             "Build the HIP extension first: python -c 'import __graft_entry__ as g; g.build()' "
-            "(or python backtoreality_amd/build.py)." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "(or python backtoreality_amd/build.py)." % path)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = stale .so: fail loudly
         fn.restype = res
         fn.argtypes = args
     if lib.btr_abi_version() != 1:
-        raise ImportError("libbtr_pointnet2.so ABI %d != 1: rebuild" % lib.btr_abi_version())
+        raise ImportError("%s ABI %d != 1: rebuild" % (path, lib.btr_abi_version()))
+    if lib.btr_distance_mode() != mode:
+        raise ImportError("%s was built with BTR_FMAD=%d" % (path, lib.btr_distance_mode()))
     return lib
 
 
-_lib = _load()
+# `_lib`: the library behind everything that does not depend on the distance rounding (fused
+# MLP, loss, evaluation kernels; callers bind it once).  `_idx`: the library the
+# index-producing ops below call -- the same object unless BTR_FMAD / set_fmad() says otherwise.
+_lib = _load(1)
+_FMAD = int(os.environ.get("BTR_FMAD", "1"))
+_idx = _lib if _FMAD == 1 else _load(_FMAD)
+
+
+def fmad():
+    """Rounding mode of the squared distance the index-producing ops currently use."""
+    return _FMAD
+
+
+def set_fmad(mode):
+    """Select the library the index-producing ops (FPS, ball query, three_nn,
+    three_interpolate) run from: 1 (default) / 0 / 2, see btr_distance_mode in the header."""
+    global _FMAD, _idx
+    mode = int(mode)
+    _idx = _lib if mode == 1 else _load(mode)
+    _FMAD = mode
 
 
 # ------------------------------------------------------------------------------------ checks
@@ -169,9 +196,10 @@ def _call(fn, *args, key=None):
     if timed:
         e1.record()
         _TIMING.append((fn.__name__.replace("btr_", "").replace("_ws", ""), key, e0, e1))
-    if rc != 0:
+    if rc != 0:   # the error text is thread-local inside the library that owns `fn`
+        owner = _idx if getattr(_idx, fn.__name__, None) is fn else _lib
         raise RuntimeError("%s failed (%d): %s" %
-                           (fn.__name__, rc, _lib.btr_last_error().decode(errors="replace")))
+                           (fn.__name__, rc, owner.btr_last_error().decode(errors="replace")))
 
 
 class _on(object):
@@ -209,7 +237,7 @@ def furthest_point_sampling(points, nsamples):
 
 def _fps(points, nsamples, block_size, out):
     B, N, _ = points.shape
-    ws_bytes = _lib.btr_furthest_point_sampling_workspace_bytes(B, N, nsamples)
+    ws_bytes = _idx.btr_furthest_point_sampling_workspace_bytes(B, N, nsamples)
     if ws_bytes:   # bucketed kernel: scratch from torch's stream-ordered caching allocator
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device)
         temp = None
@@ -217,7 +245,7 @@ def _fps(points, nsamples, block_size, out):
         ws = None
         temp = torch.empty((B, N), dtype=torch.float32, device=points.device)
     with _on(points) as dev:
-        _call(_lib.btr_furthest_point_sampling_ws, B, N, nsamples, _p(points), _p(temp),
+        _call(_idx.btr_furthest_point_sampling_ws, B, N, nsamples, _p(points), _p(temp),
               _p(out), int(block_size), _p(ws), ws_bytes, _stream(dev),
               key=(B, N, nsamples))
     return out
@@ -285,11 +313,11 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.size(1)
     nsample = int(nsample)
     out = torch.empty((B, M, nsample), dtype=torch.int32, device=new_xyz.device)
-    ws_bytes = _lib.btr_ball_query_workspace_bytes(B, N, M, nsample)
+    ws_bytes = _idx.btr_ball_query_workspace_bytes(B, N, M, nsample)
     ws = (torch.empty((ws_bytes,), dtype=torch.uint8, device=new_xyz.device)
           if ws_bytes else None)
     with _on(new_xyz) as dev:
-        _call(_lib.btr_ball_query_ws, B, N, M, float(radius), nsample, _p(new_xyz), _p(xyz),
+        _call(_idx.btr_ball_query_ws, B, N, M, float(radius), nsample, _p(new_xyz), _p(xyz),
               _p(out), _p(ws), ws_bytes, _stream(dev), key=(B, N, M, nsample))
     return out
 
@@ -331,7 +359,7 @@ def three_nn(unknowns, knows):
     dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknowns.device)
     idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknowns.device)
     with _on(unknowns) as dev:
-        _call(_lib.btr_three_nn, B, n, m, _p(unknowns), _p(knows), _p(dist2), _p(idx),
+        _call(_idx.btr_three_nn, B, n, m, _p(unknowns), _p(knows), _p(dist2), _p(idx),
               _stream(dev))
     return [dist2, idx]
 
@@ -346,7 +374,7 @@ def three_interpolate(points, idx, weight):
     n = idx.size(1)
     out = torch.empty((B, C, n), dtype=torch.float32, device=points.device)
     with _on(points) as dev:
-        _call(_lib.btr_three_interpolate, B, C, m, n, _p(points), _p(idx), _p(weight), _p(out),
+        _call(_idx.btr_three_interpolate, B, C, m, n, _p(points), _p(idx), _p(weight), _p(out),
               _stream(dev))
     return out
 

@@ -55,6 +55,10 @@ def parse():
                    help="gf only: enqueue the step kernel by kernel instead of replaying the "
                         "captured HIP graph (the eager GroupFree3D loop is host-bound)")
     p.add_argument("--cpu-points", type=int, default=40000)
+    p.add_argument("--launch-check", action="store_true",
+                   help="only start the --gpus ranks, count them with one all-reduce (RCCL on a "
+                        "GPU box, gloo without GPUs) and print {\"launch_check\": ranks}: what "
+                        "tests/test_distributed_cpu.py runs to cover the self-launch path")
     return p.parse_args()
 
 
@@ -102,16 +106,60 @@ def cpu_baseline(cfg, points):
                       % (points, steps, ncpu)}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started plainly, i.e. not by torch.distributed.run:
+    start the N ranks OURSELVES -- one process per GPU, the recipe of the reference's
+    GroupFree3D scripts (detection/GroupFree3D/train_GF_FSB.py:450-453) -- as a CHILD process
+    and exit with its code.  Nothing in this process has touched the GPU yet (importing torch
+    does not), and it never execs."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                 # a free rendezvous port on the loopback
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))       # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     from backtoreality_amd.pointnet2 import _ext
     from backtoreality_amd.votenet import config, synthetic, train
 
     rank, world, local_rank = train.init_distributed()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus>1"
+    if args.launch_check:
+        assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+        n = 1
+        if world > 1:
+            one = torch.ones(1, device="cuda:%d" % local_rank if torch.cuda.is_available()
+                             else "cpu")
+            dist.all_reduce(one)
+            n = int(one.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": n, "backend":
+                              "nccl" if torch.cuda.is_available() else "gloo"}))
+        return
+    # never a silent 1-rank run: the job must have exactly --gpus ranks, over RCCL when > 1
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    rccl_ranks = 0
+    if world > 1:
+        assert dist.is_initialized() and dist.get_backend() == "nccl"
+        assert dist.get_world_size() == args.gpus
+        # every rank contributes 1 through the collective the gradients will use
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == args.gpus, "all-reduce saw %d ranks" % rccl_ranks
 
     if not args.no_conv_autotune:   # before the first convolution runs (train.enable_conv_autotune)
         train.enable_conv_autotune()
@@ -225,6 +273,7 @@ def main():
             "value": scenes / elapsed,
             "unit": "scenes/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,   # ranks counted by an RCCL all-reduce (0: single process)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -282,6 +331,12 @@ def pmc_traffic(substr):
     return max(cands)[0] if cands else None
 
 
+# every f32-MFMA GEMM entry point of the fused SA path (csrc/sa_mlp.hip): forward NT (plain,
+# recompute, pool-epilogue), dgrad NT (plain, pooled), wgrad TN (plain, pooled, recompute)
+GEMM_OPS = ("sa_gemm_nt", "sa_gemm_nt_rc", "sa_gemm_nt_poolfwd", "sa_gemm_nt_pool",
+            "sa_gemm_tn", "sa_gemm_tn_rc", "sa_gemm_tn_pool")
+
+
 def roofline_objects(kernels, detail, detail_steps):
     """kernels / detail: {(op, shape-key): [ms, ...]} from the HIP-event timer in `_ext`
     (`kernels`: inside the timed region; `detail`: the instrumented steps after it).
@@ -314,7 +369,7 @@ def roofline_objects(kernels, detail, detail_steps):
                                       "note": "grid-culled query incl. the one-launch grid build (2 launches)"}
     # grouped shared MLP: every f32-MFMA GEMM launch of the fused SA path (fwd NT with BN
     # prologue/epilogue, dgrad NT, wgrad TN); flops = 2*rows*n*k per launch
-    gemm = [(k, t) for (o, k), t in detail.items() if o in ("sa_gemm_nt", "sa_gemm_tn", "sa_gemm_nt_pool", "sa_gemm_tn_pool", "sa_gemm_nt_rc", "sa_gemm_tn_rc")]
+    gemm = [(k, t) for (o, k), t in detail.items() if o in GEMM_OPS]
     if gemm:
         steps = detail_steps
         flops = sum(2.0 * k[0] * k[1] * k[2] * len(t) for k, t in gemm) / steps
@@ -325,7 +380,8 @@ def roofline_objects(kernels, detail, detail_steps):
         hbm = gbytes / (ms * 1e-3) / 1e9
         res["mlp_roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
                                "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
-                               "traffic": None, "kernel": "gemm_nt_kernel + gemm_tn_kernel",
+                               "traffic": None,
+                               "kernel": "gemm_nt_kernel (incl. poolfwd / rc / pool) + gemm_tn_kernel",
                                "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_step": gbytes,
                                "gflop_per_step": flops / 1e9, "ms_per_step": ms,

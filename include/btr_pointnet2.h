@@ -38,6 +38,17 @@ typedef void *btr_stream_t; /* a hipStream_t; NULL = the null stream */
 #define BTR_ABI_VERSION 1
 int btr_abi_version(void);
 
+/* Rounding mode of the squared distance a*a + b*b + c*c this library was built with
+ * (BTR_FMAD, csrc/common.hpp): every index the path returns (FPS arg-max, ball-query
+ * membership, 3-NN order) is decided by it.  The reference's sources write the expression
+ * out (sampling_gpu.cu:108-109, ball_query_gpu.cu:36-38, interpolate_gpu.cu:38) and leave the
+ * contraction to nvcc (-O2, default --fmad=true, pointnet2/setup.py:22-25):
+ *   1  libbtr_pointnet2.so        fma(c,c, fma(a,a, b*b))   nvcc/NVPTX contraction (default)
+ *   0  libbtr_pointnet2_fmad0.so  ((a*a)+(b*b))+(c*c)       as written (--fmad=false build)
+ *   2  libbtr_pointnet2_fmad2.so  fma(c,c, fma(b,b, a*a))   left-to-right chain
+ * The three libraries export the same symbols and differ in nothing else. */
+int btr_distance_mode(void);
+
 /* Thread-local description of the last non-zero status returned on this thread ("" if none). */
 const char *btr_last_error(void);
 

@@ -17,26 +17,48 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
 
 _f = ctypes.POINTER(ctypes.c_float)
 _i = ctypes.POINTER(ctypes.c_int)
 _c = ctypes.c_int
 
 
+_NAMES = {1: "libbtr_oracle.so", 0: "libbtr_oracle_fmad0.so", 2: "libbtr_oracle_fmad2.so"}
+_LIBS = {}
+_MODE = int(os.environ.get("BTR_FMAD", "1"))
+
+
 def build(force=False):
-    """Compile libbtr_oracle.so with the committed Makefile (gcc, -ffp-contract=off)."""
-    so = os.path.join(_HERE, "libbtr_oracle.so")
+    """Compile the three libbtr_oracle*.so (one per BTR_FMAD rounding mode of the squared
+    distance) with the committed Makefile (gcc, -ffp-contract=off)."""
     src = os.path.join(_HERE, "pointnet2_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libbtr_oracle.so"])
-    return so
+    mk = os.path.join(_HERE, "Makefile")
+    newest = max(os.path.getmtime(src), os.path.getmtime(mk))
+    sos = [os.path.join(_HERE, n) for n in _NAMES.values()]
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < newest for so in sos):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "all"])
+    return os.path.join(_HERE, _NAMES[1])
+
+
+def fmad():
+    """The rounding mode the oracle currently restates (see pointnet2_oracle.c header)."""
+    return _MODE
+
+
+def set_fmad(mode):
+    """Select the rounding mode (0, 1 or 2); tests switch it together with the HIP library's
+    (backtoreality_amd.pointnet2._ext.set_fmad)."""
+    global _MODE
+    assert mode in _NAMES, mode
+    _MODE = int(mode)
 
 
 def lib():
-    global _LIB
-    if _LIB is None:
-        L = ctypes.CDLL(build())
+    if _MODE not in _LIBS:
+        build()
+        L = ctypes.CDLL(os.path.join(_HERE, _NAMES[_MODE]))
+        L.btr_oracle_fmad_mode.restype = _c
+        assert L.btr_oracle_fmad_mode() == _MODE
         L.btr_oracle_opt_n_threads.argtypes = [_c]
         L.btr_oracle_opt_n_threads.restype = _c
         L.btr_oracle_furthest_point_sampling_bs.argtypes = [_c, _c, _c, _f, _f, _i, _c]
@@ -49,8 +71,8 @@ def lib():
         L.btr_oracle_three_nn.argtypes = [_c, _c, _c, _f, _f, _f, _i]
         L.btr_oracle_three_interpolate.argtypes = [_c, _c, _c, _c, _f, _i, _f, _f]
         L.btr_oracle_three_interpolate_grad.argtypes = [_c, _c, _c, _c, _f, _i, _f, _f]
-        _LIB = L
-    return _LIB
+        _LIBS[_MODE] = L
+    return _LIBS[_MODE]
 
 
 def _fp(a):

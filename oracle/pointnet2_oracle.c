@@ -16,9 +16,17 @@
  *     the fixtures in tests/golden/ generated from the reference's own Python layers running
  *     over this oracle.
  *
- * Build: gcc -O2 -ffp-contract=off -fopenmp (see oracle/Makefile).  -ffp-contract=off is load
- * bearing: every float expression below must round exactly as written (no FMA fusion), the
- * HIP kernels are built the same way, and indices are compared bit-exactly.
+ * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp -DBTR_FMAD={0,1,2} (see oracle/Makefile).
+ * -ffp-contract=off is load bearing: the compiler must not fuse anything by itself; the ONE
+ * expression that decides indices -- a*a + b*b + c*c of the coordinate differences -- is
+ * rounded by btr_sq3() below according to BTR_FMAD, the same three modes the HIP kernels have
+ * (backtoreality_amd/csrc/common.hpp), and indices are compared bit-exactly per mode:
+ *   1 (default): fmaf(c,c, fmaf(a,a, b*b)) -- what nvcc -O2 (default --fmad=true, the reference's
+ *      setup.py:22-25) emits for ((a*a + b*b) + c*c): mul.f32 b,b; fma.rn a,a,.; fma.rn c,c,.
+ *      (NVPTX/LLVM contraction rule: an fadd fuses its FIRST fmul operand, else the second);
+ *   2: fmaf(c,c, fmaf(b,b, a*a)) -- the left-to-right chain;
+ *   0: as written, no contraction (an nvcc --fmad=false build).
+ * Which of 1/2 a given nvcc emits cannot be checked here (no nvcc): see DESIGN.md section 2.
  *
  * All citations are relative to /root/reference/detection/Votenet/pointnet2/_ext_src/.
  */
@@ -27,6 +35,33 @@
 #include <string.h>
 
 #define BTR_TOTAL_THREADS 512 /* include/cuda_utils.h:18 */
+
+#ifndef BTR_FMAD
+#define BTR_FMAD 1
+#endif
+int btr_oracle_fmad_mode(void) { return BTR_FMAD; }
+
+/* a*a + b*b + c*c as the reference's build rounds it (sampling_gpu.cu:105,108-109;
+ * ball_query_gpu.cu:36-38; interpolate_gpu.cu:38). */
+static inline float btr_sq3(float a, float b, float c) {
+#if BTR_FMAD == 1
+  return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
+#elif BTR_FMAD == 2
+  return __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a));
+#else
+  return (a * a) + (b * b) + (c * c);
+#endif
+}
+/* p1*w1 + p2*w2 + p3*w3 (interpolate_gpu.cu:103-104) under the same contraction rule. */
+static inline float btr_dot3(float p1, float w1, float p2, float w2, float p3, float w3) {
+#if BTR_FMAD == 1
+  return __builtin_fmaf(p3, w3, __builtin_fmaf(p1, w1, p2 * w2));
+#elif BTR_FMAD == 2
+  return __builtin_fmaf(p3, w3, __builtin_fmaf(p2, w2, p1 * w1));
+#else
+  return p1 * w1 + p2 * w2 + p3 * w3;
+#endif
+}
 
 /* include/cuda_utils.h:20-24 -- opt_n_threads: 2^floor(log2(work_size)) clamped to [1,512],
  * evaluated in double exactly as the reference does (the quotient of two logs). */
@@ -84,10 +119,9 @@ void btr_oracle_furthest_point_sampling_bs(int b, int n, int m, const float *dat
         float best = -1;
         for (int k = tid; k < n; k += bs) {
           const float x2 = ds[k * 3 + 0], y2 = ds[k * 3 + 1], z2 = ds[k * 3 + 2];
-          const float mag = (x2 * x2) + (y2 * y2) + (z2 * z2);
+          const float mag = btr_sq3(x2, y2, z2);
           if (mag <= 1e-3) continue;
-          const float d =
-              (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+          const float d = btr_sq3(x2 - x1, y2 - y1, z2 - z1);
           const float d2 = d < tp[k] ? d : tp[k]; /* min(d, temp[k]) */
           tp[k] = d2;
           besti = d2 > best ? k : besti;
@@ -147,10 +181,9 @@ void btr_oracle_furthest_point_sampling_closed_form(int b, int n, int m, const f
       unsigned long long bestkey = ~0ull;
       for (int k = 0; k < n; ++k) {
         const float x2 = ds[k * 3 + 0], y2 = ds[k * 3 + 1], z2 = ds[k * 3 + 2];
-        const float mag = (x2 * x2) + (y2 * y2) + (z2 * z2);
+        const float mag = btr_sq3(x2, y2, z2);
         if (mag <= 1e-3) continue;
-        const float d =
-            (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+        const float d = btr_sq3(x2 - x1, y2 - y1, z2 - z1);
         const float d2 = d < tp[k] ? d : tp[k];
         tp[k] = d2;
         const unsigned long long key =
@@ -216,8 +249,7 @@ void btr_oracle_ball_query(int b, int n, int m, float radius, int nsample, const
       const float new_x = pc[0], new_y = pc[1], new_z = pc[2];
       for (int k = 0, cnt = 0; k < n && cnt < nsample; ++k) {
         const float x = px[k * 3 + 0], y = px[k * 3 + 1], z = px[k * 3 + 2];
-        const float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) +
-                         (new_z - z) * (new_z - z);
+        const float d2 = btr_sq3(new_x - x, new_y - y, new_z - z);
         if (d2 < radius2) {
           if (cnt == 0)
             for (int l = 0; l < nsample; ++l) row[l] = k;
@@ -279,7 +311,7 @@ void btr_oracle_three_nn(int b, int n, int m, const float *unknown, const float 
       int besti1 = 0, besti2 = 0, besti3 = 0;
       for (int k = 0; k < m; ++k) {
         const float x = kn[k * 3 + 0], y = kn[k * 3 + 1], z = kn[k * 3 + 2];
-        const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+        const float d = btr_sq3(ux - x, uy - y, uz - z);
         if (d < best1) {
           best3 = best2; besti3 = besti2;
           best2 = best1; besti2 = besti1;
@@ -315,7 +347,7 @@ void btr_oracle_three_interpolate(int b, int c, int m, int n, const float *point
       for (int j = 0; j < n; ++j) {
         const float w1 = w[j * 3 + 0], w2 = w[j * 3 + 1], w3 = w[j * 3 + 2];
         const int i1 = id[j * 3 + 0], i2 = id[j * 3 + 1], i3 = id[j * 3 + 2];
-        o[j] = p[i1] * w1 + p[i2] * w2 + p[i3] * w3;
+        o[j] = btr_dot3(p[i1], w1, p[i2], w2, p[i3], w3);
       }
     }
 }

@@ -44,3 +44,18 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=[1, 0, 2], ids=["fmad1", "fmad0", "fmad2"])
+def distance_mode(request):
+    """Runs a test once per rounding mode of the squared distance (include/btr_pointnet2.h,
+    btr_distance_mode): the HIP library of that mode against the oracle of that mode."""
+    import oracle
+    from backtoreality_amd.pointnet2 import _ext
+    _ext.set_fmad(request.param)
+    oracle.set_fmad(request.param)
+    try:
+        yield request.param
+    finally:
+        _ext.set_fmad(1)
+        oracle.set_fmad(1)

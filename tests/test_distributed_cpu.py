@@ -159,3 +159,19 @@ def test_flat_grad_parallel_with_unused_and_frozen_parameters():
         assert p.exitcode == 0
     for _, replicated, ok, same_unused, same in results:
         assert replicated and ok and same_unused and same
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started plainly (no torchrun, WORLD_SIZE unset) must start two
+    ranks itself and never fall back to a silent one-rank run (gloo here; RCCL on a GPU box)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--launch-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line)["launch_check"] == 2

@@ -8,7 +8,8 @@ import torch
 
 import oracle
 
-pytestmark = pytest.mark.gpu
+# every test of this module runs once per rounding mode of the squared distance (conftest.py)
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("distance_mode")]
 
 
 def _ext():

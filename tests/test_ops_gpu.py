@@ -8,7 +8,8 @@ import torch
 import oracle
 from backtoreality_amd.votenet import synthetic
 
-pytestmark = pytest.mark.gpu
+# every test of this module runs once per rounding mode of the squared distance (conftest.py)
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("distance_mode")]
 
 
 def _ext():
@@ -23,6 +24,30 @@ def _scene_xyz(B, N, first=0, kind="surface"):
 
 def _t(a, cuda):
     return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+# ----------------------------------------------- inputs on which the rounding modes disagree
+@pytest.mark.parametrize("N,M", [(4096, 256), (20000, 128)])   # register / bucketed FPS kernel
+def test_fps_mode_sensitive_cloud(cuda, N, M):
+    from mode_cases import sphere_cloud
+    xyz = sphere_cloud(3, N)
+    ref = oracle.furthest_point_sampling(xyz, M)
+    got = _ext().furthest_point_sampling(_t(xyz, cuda), M).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_ball_query_and_three_nn_mode_sensitive(cuda, distance_mode):
+    from mode_cases import shell_ball_case
+    assert _ext()._idx.btr_distance_mode() == distance_mode == oracle.fmad()
+    for n in (4096, 12000):        # wave-per-centre kernel / grid kernel
+        centres, pts, radius = shell_ball_case(4, n=n)
+        ref = oracle.ball_query(centres, pts, radius, 64)
+        got = _ext().ball_query(_t(centres, cuda), _t(pts, cuda), float(radius), 64).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+    d_ref, i_ref = oracle.three_nn(centres, pts[:, :500])
+    d_got, i_got = _ext().three_nn(_t(centres, cuda), _t(pts[:, :500].copy(), cuda))
+    np.testing.assert_array_equal(i_got.cpu().numpy(), i_ref)
+    np.testing.assert_array_equal(d_got.cpu().numpy(), d_ref)
 
 
 # ----------------------------------------------------------------------------------- FPS

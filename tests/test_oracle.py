@@ -2,6 +2,7 @@
 reference's CUDA kernels (no golden vectors exist in the reference for these ops):
 each case cites the .cu lines it pins."""
 import numpy as np
+import pytest
 
 import oracle
 
@@ -132,3 +133,45 @@ def test_reference_interpolate_vector():
     w = np.array([[[1, 1, 1], [2, 2, 2]]], np.float32)
     out = oracle.three_interpolate(feats, idx, w)
     np.testing.assert_array_equal(out, [[[6, 18], [18, 42]]])
+
+
+# ------------------------------------------------- the three roundings of the squared distance
+@pytest.fixture
+def restore_mode():
+    yield
+    oracle.set_fmad(1)
+
+
+def test_distance_modes_follow_their_formula(restore_mode):
+    """three_nn returns the squared distance itself: each oracle mode must equal its formula
+    evaluated in exact rational arithmetic with one rounding per machine operation."""
+    from mode_cases import sq3_exact
+    rng = np.random.default_rng(11)
+    u = rng.uniform(-3, 3, (1, 300, 3)).astype(np.float32)
+    k = rng.uniform(-3, 3, (1, 1, 3)).astype(np.float32)
+    got = {}
+    for mode in (0, 1, 2):
+        oracle.set_fmad(mode)
+        assert oracle.lib().btr_oracle_fmad_mode() == mode
+        d2, idx = oracle.three_nn(u, k)
+        got[mode] = d2[0, :, 0].copy()
+        dx, dy, dz = (u[0, :, a] - k[0, 0, a] for a in range(3))   # float32 subtractions
+        want = np.array([sq3_exact(dx[i], dy[i], dz[i], mode) for i in range(300)], np.float32)
+        np.testing.assert_array_equal(got[mode], want)
+    assert (got[0] != got[1]).any() and (got[1] != got[2]).any() and (got[0] != got[2]).any()
+
+
+def test_distance_modes_change_indices_on_crafted_inputs(restore_mode):
+    """On ordinary scenes the modes agree; on these inputs they must not (otherwise the GPU
+    twins of this test could not tell the libraries apart)."""
+    from mode_cases import shell_ball_case, sphere_cloud
+    xyz = sphere_cloud(3, 4096)
+    centres, pts, radius = shell_ball_case(4)
+    fps, bq = {}, {}
+    for mode in (0, 1, 2):
+        oracle.set_fmad(mode)
+        fps[mode] = oracle.furthest_point_sampling(xyz, 256)
+        bq[mode] = oracle.ball_query(centres, pts, radius, 64)
+    for a, b in ((0, 1), (1, 2), (0, 2)):
+        assert (fps[a] != fps[b]).any(), ("fps", a, b)
+        assert (bq[a] != bq[b]).any(), ("ball_query", a, b)

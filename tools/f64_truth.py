@@ -1,0 +1,163 @@
+"""Float64 'truth' for the gradients the golden tests compare (CPU, build container or GPU box).
+
+The fixtures hold what the REFERENCE computes in float32 on CPU.  A gradient of this network
+is a sum over 1e5..1e6 rows gated by ReLU / arg-max selections, so two correct float32
+implementations differ by more than forward rounding.  This tool measures how far the float32
+fixture itself is from the same step evaluated in float64 (same indices: the index-producing
+ops run on the float32 casts, everything differentiable in float64), which is the scale any
+float32 implementation's gradient bound has to be read against.
+
+    python tools/f64_truth.py            # prints fixture-vs-f64 deviations, writes
+                                         # tests/golden/f64_truth.npz (the f64 gradients)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle  # noqa: E402
+import test_golden_cpu as T  # noqa: E402
+from backtoreality_amd.pointnet2 import pointnet2_utils  # noqa: E402
+from backtoreality_amd.votenet import config, loss_helper, synthetic, train, votenet  # noqa: E402
+
+
+class ExtF64(object):
+    """The nine `_ext` callables for float64 tensors: indices from the float32 oracle (on the
+    float32 casts of the coordinates), copies / blends / scatter-adds as float64 torch ops."""
+
+    def furthest_point_sampling(self, points, n):
+        return torch.from_numpy(oracle.furthest_point_sampling(points.detach().float().numpy(), int(n)))
+
+    def gather_points(self, points, idx):
+        return torch.gather(points, 2, idx.long().unsqueeze(1).expand(-1, points.size(1), -1))
+
+    def gather_points_grad(self, grad_out, idx, n):
+        out = grad_out.new_zeros(grad_out.size(0), grad_out.size(1), n)
+        return out.scatter_add_(2, idx.long().unsqueeze(1).expand(-1, grad_out.size(1), -1), grad_out)
+
+    def ball_query(self, new_xyz, xyz, radius, nsample):
+        return torch.from_numpy(oracle.ball_query(new_xyz.detach().float().numpy(),
+                                                  xyz.detach().float().numpy(), float(radius),
+                                                  int(nsample)))
+
+    def group_points(self, points, idx):
+        B, C, N = points.shape
+        _, M, S = idx.shape
+        flat = idx.long().reshape(B, 1, M * S).expand(-1, C, -1)
+        return torch.gather(points, 2, flat).reshape(B, C, M, S).clone()
+
+    def group_points_grad(self, grad_out, idx, n):
+        B, C, M, S = grad_out.shape
+        out = grad_out.new_zeros(B, C, n)
+        flat = idx.long().reshape(B, 1, M * S).expand(-1, C, -1)
+        return out.scatter_add_(2, flat, grad_out.reshape(B, C, M * S))
+
+    def three_nn(self, unknown, known):
+        _, idx = oracle.three_nn(unknown.detach().float().numpy(), known.detach().float().numpy())
+        idx = torch.from_numpy(idx)
+        B, n, _ = unknown.shape
+        nb = torch.gather(known.unsqueeze(1).expand(-1, n, -1, -1), 2,
+                          idx.long().unsqueeze(-1).expand(-1, -1, -1, 3))
+        return [((unknown.unsqueeze(2) - nb) ** 2).sum(-1), idx]
+
+    def three_interpolate(self, points, idx, weight):
+        B, C, m = points.shape
+        n = idx.size(1)
+        flat = idx.long().reshape(B, 1, n * 3).expand(-1, C, -1)
+        return (torch.gather(points, 2, flat).reshape(B, C, n, 3) * weight.unsqueeze(1)).sum(-1)
+
+    def three_interpolate_grad(self, grad_out, idx, weight, m):
+        B, C, n = grad_out.shape
+        out = grad_out.new_zeros(B, C, m)
+        flat = idx.long().reshape(B, 1, n * 3).expand(-1, C, -1)
+        return out.scatter_add_(2, flat, (grad_out.unsqueeze(-1) * weight.unsqueeze(1)).reshape(B, C, n * 3))
+
+
+def to64(batch):
+    return {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+
+
+def grads_of(net, names):
+    out = {}
+    for key, path in names.items():
+        obj = net
+        for part in path.split("."):
+            obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+        out[key] = obj.grad.detach().numpy().copy()
+    return out
+
+
+FSB = {'grad_sa1_w0': 'backbone_net.sa1.mlp_module.layer0.conv.weight',
+       'grad_vote_agg_w0': 'pnet.vote_aggregation.mlp_module.layer0.conv.weight',
+       'grad_vgen_conv3_b': 'vgen.conv3.bias'}
+BR = {'grad_sa1_w0': 'backbone_net.sa1.mlp_module.layer0.conv.weight',
+      'grad_global_netD2_w': 'global_netD2.weight', 'grad_local_netD_last_w': 'local_netD.6.weight'}
+CR = {'grad_sa1_w0': 'backbone_net.sa1.mlp_module.layer0.conv.weight',
+      'grad_ctjt_w0': 'backbone_net.ctjt_head.mlp_module.layer0.conv.weight',
+      'grad_jitter_net_last_w': 'jitter_net.3.weight'}
+
+
+def main():
+    dev = torch.device("cpu")
+    cfg = config.scannet_md40()
+    pointnet2_utils._ext = ExtF64()
+    os.environ["BTR_FUSED_LOSS"] = "0"
+    out = {}
+
+    def report(tag, g, got, loss):
+        print("== %s: loss f64 %.9f  fixture(f32) %.9f  rel %.1e" % (
+            tag, loss, float(g['loss']), abs(loss - float(g['loss'])) / abs(loss)))
+        for k, v in got.items():
+            want = g[k]
+            err = np.abs(want - v).max() / np.abs(v).max()
+            l2 = np.linalg.norm(want - v) / np.linalg.norm(v)
+            print("   %-26s fixture vs f64: max-norm %.2e  rel L2 %.2e" % (k, err, l2))
+            out[tag + "_" + k] = v
+
+    # FSB
+    g = np.load(os.path.join(T.GOLD, "votenet_fsb_step.npz"))
+    batch = to64(synthetic.make_batch(0, 2, 4096, cfg))
+    torch.manual_seed(0)
+    net = votenet.VoteNet(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                          cfg.mean_size_arr, input_feature_dim=1, num_proposal=256,
+                          vote_factor=1, sampling='vote_fps').double()
+    with T.pinned_vote_inds(net, g['aggregated_vote_inds'], idx_per_forward=[g['vote_agg_idx']]):
+        ep = net({'point_clouds': batch['point_clouds']})
+    ep.update(batch)
+    loss, ep = loss_helper.get_loss(ep, cfg)
+    loss.backward()
+    report("fsb", g, grads_of(net, FSB), float(loss))
+
+    # BR / CR
+    for tag, names, gname, kw, jit in (("br", BR, "votenet_br_step.npz", dict(domain_adaptation=True), 0.0),
+                                       ("cr", CR, "votenet_br_jitter_step.npz", dict(center_refine=True), 0.1)):
+        g = np.load(os.path.join(T.GOLD, gname))
+        mk = dict(center_jitter=jit) if jit else {}
+        bS = to64(synthetic.make_batch(0, 2, 4096, cfg, **mk))
+        bT = to64(synthetic.make_batch(100, 2, 4096, cfg, **mk))
+        net = train.build_model(cfg, dev, seed=0, **kw).double()
+        with T.pinned_vote_inds(net, g['S_aggregated_vote_inds'], g['T_aggregated_vote_inds'],
+                                idx_per_forward=[g['S_vote_agg_idx'], g['T_vote_agg_idx']]):
+            if jit:
+                eS = net({'point_clouds': bS['point_clouds']}, bS['center_label'], bS['sem_cls_label'])
+                eT = net({'point_clouds': bT['point_clouds']}, bT['center_label'], bT['sem_cls_label'])
+            else:
+                eS = net({'point_clouds': bS['point_clouds']})
+                eT = net({'point_clouds': bT['point_clouds']})
+        eS.update(bS)
+        eT.update(bT)
+        if jit:
+            loss, eS, eT = loss_helper.get_loss_DA_jitter(eS, eT, 30, cfg)
+        else:
+            loss, eS, eT = loss_helper.get_loss_DA(eS, eT, cfg)
+        loss.backward()
+        report(tag, g, grads_of(net, names), float(loss))
+    np.savez_compressed(os.path.join(T.GOLD, "f64_truth.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
