@@ -530,6 +530,314 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
 #undef BTR_PH
 }
 
+// ------------------------------------------- work-queue kernel (BTR_FPS_IMPL=queue, opt-in)
+// MEASURED AND NOT ADOPTED (MI355X, 8 x 40000 -> 2048): 2.71 ms against 2.22 ms for the
+// owner-wave kernel above; bit-exact in the whole index suite.  It removes the second trip of
+// the busiest wave (items/step per wave 1.17 max instead of 1.6 trips) but pays for it with a
+// second barrier, the queue exchange and a reduction over NW + Q candidates: s_memtime phase
+// counters (BTR_FPS_PROF=1 BTR_FPS_IMPL=queue), cycles per step on the busiest wave:
+// test+push 391, barrier A 669, pop+fetch+untouched-best 639, update 783, barrier B 235,
+// reduce+winner 762 = 3503, against 2600 for the owner-wave kernel.  Kept for A/B.
+// Same algorithm as fps_bucket_kernel above (bucket boxes, exact pruning, one sample per
+// step), other distribution of the per-step work.  There, bucket b is ALWAYS updated by its
+// owner wave b % NW: a late sample touches ~10 of 625 buckets, the busiest of the 16 waves makes
+// 1.6-2.0 dependent trips (L2 round trip + wave reduction each) while half of the waves make
+// none.  Here the owner lanes only run the box test; the touched buckets go through an LDS
+// queue and wave w updates queue items w, w + NW, ...: one trip per wave up to NW touched
+// buckets.  Per step:
+//   test (owner lanes, registers) -> push touched bucket ids (one LDS atomic per wave)
+//   -> barrier A -> pop -> load bucket (L2) | under that latency: best UNTOUCHED bucket of the
+//   wave's own lanes -> update min-dists, bucket arg-max -> record to LDS -> barrier B
+//   -> every wave reduces the NW untouched-bests + Q fresh records -> next sample.
+// The per-bucket winner records live in LDS (rec[]), so a record is written once by whoever
+// updated the bucket and read by the one wave-uniform broadcast read of the final winner;
+// owners keep only the box and the bucket's max key in registers.
+struct QRec {  // 32 B: two ds_write_b128 / ds_read_b128
+  unsigned hi, lo;
+  float x, y, z;
+  int k, pad0, pad1;
+};
+
+template <int NW, int SL, bool PROF = false>
+__global__ __launch_bounds__(NW * 64) void fps_queue_kernel(int n, int np, int m, int bs,
+                                                            int log2bs,
+                                                            const float *__restrict__ dataset,
+                                                            const float4 *__restrict__ spts,
+                                                            float *__restrict__ tmin,
+                                                            int *__restrict__ idxs,
+                                                            unsigned long long *dbg = nullptr) {
+  // PROF: s_memtime phase counters (tuning builds only; BTR_FPS_PROF=1)
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, nitem = 0;
+#define BTR_QPH(i)                                                 \
+  if (PROF) {                                                      \
+    const unsigned long long now = __builtin_amdgcn_s_memtime();   \
+    tph[i] += now - tlast;                                         \
+    tlast = now;                                                   \
+  }
+  constexpr int NB = NW * 64 * SL;  // bucket capacity of the workgroup
+  __shared__ QRec rec[NB];          // winner record of every bucket
+  __shared__ int queue[2][NB];      // touched bucket ids of this step (double-buffered)
+  __shared__ unsigned qhi[NB];      // max key of queue item i after its update
+  __shared__ uint2 slots[NW];       // (max key, bucket) of each wave's best untouched bucket
+  __shared__ int qcount[2];
+  constexpr int kOut = 2048;        // samples are collected in LDS and written out in chunks:
+  __shared__ int out_idx[kOut];     // no global store on the per-step chain
+
+  __builtin_amdgcn_s_setprio(3);  // latency chain: issue ahead of co-resident streaming waves
+  const int bi = blockIdx.x;
+  dataset += (size_t)bi * n * 3;
+  spts += (size_t)bi * np;
+  tmin += (size_t)bi * np;
+  idxs += (size_t)bi * m;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = np >> 6;
+  const TieParams tp{bs, log2bs, (n + bs - 1) >> log2bs};
+  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
+
+  // ---- owner state: bounding box + max key of the buckets this lane owns
+  float bx0[SL], by0[SL], bz0[SL], bx1[SL], by1[SL], bz1[SL];
+  unsigned mhi[SL];
+  int myb[SL];
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    myb[s] = (s * 64 + lane) * NW + wave;
+    bx0[s] = by0[s] = bz0[s] = bx1[s] = by1[s] = bz1[s] = 0.f;
+    mhi[s] = 0u;
+    if (myb[s] < nb) {
+      const float *bp = (const float *)spts + (size_t)myb[s] * 256;
+      const float *tm = tmin + (size_t)myb[s] * 64;
+      float ax0 = bp[0], ax1 = ax0, ay0 = bp[64], ay1 = ay0, az0 = bp[128], az1 = az0;
+      bool any = tm[0] >= 0.f;
+#pragma unroll 8
+      for (int i = 1; i < 64; ++i) {
+        if (__float_as_int(bp[192 + i]) < 0) continue;  // padding slot: not in the box
+        const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
+        ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
+        ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
+        az0 = fminf(az0, qz); az1 = fmaxf(az1, qz);
+        any |= tm[i] >= 0.f;
+      }
+      bx0[s] = ax0; bx1[s] = ax1; by0[s] = ay0; by1[s] = ay1; bz0[s] = az0; bz1[s] = az1;
+      mhi[s] = any ? __float_as_uint(1e10f) + 1u : 0u;  // competing points start at 1e10
+    }
+  }
+  if (tid == 0) {
+    out_idx[0] = 0;
+    qcount[0] = 0;
+    qcount[1] = 0;
+  }
+  float sx = x0, sy = y0, sz = z0;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  lds_barrier();
+  if (PROF) tlast = __builtin_amdgcn_s_memtime();
+
+  for (int j = 1; j < m; ++j) {
+    if ((j & (kOut - 1)) == 0) {  // flush a full chunk of samples
+      lds_barrier();
+      for (int i = tid; i < kOut; i += NW * 64) idxs[j - kOut + i] = out_idx[i];
+      lds_barrier();
+    }
+    const int par = j & 1;
+    int *q = queue[par];
+    // ---- A: box test on the owner lanes (lower bound of the distance from the sample to the
+    // bucket, rounded exactly like the point distance: see the header of this file)
+    bool act[SL];
+    int myslot[SL];
+    unsigned lane_hi = 0u;
+    int lane_b = 0;
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      const float ex = __builtin_amdgcn_fmed3f(sx, bx0[s], bx1[s]) - sx;
+      const float ey = __builtin_amdgcn_fmed3f(sy, by0[s], by1[s]) - sy;
+      const float ez = __builtin_amdgcn_fmed3f(sz, bz0[s], bz1[s]) - sz;
+      const float dbox = sq3(ex, ey, ez);
+      act[s] = (__float_as_uint(dbox) + 1u) < mhi[s];  // mhi == 0: none competes
+      // ---- B: push the touched buckets: one LDS atomic per wave and slot
+      const unsigned long long mask = __ballot(act[s]);
+      myslot[s] = 0;
+      if (mask) {
+        const int first = __builtin_ctzll(mask);
+        int base = 0;
+        if (lane == first) base = atomicAdd(&qcount[par], __builtin_popcountll(mask));
+        base = __builtin_amdgcn_readlane(base, first);
+        myslot[s] = base + __builtin_popcountll(mask & lt);
+        if (act[s]) q[myslot[s]] = myb[s];
+      }
+      // this lane's best UNTOUCHED bucket (its record in rec[] stays valid through the step)
+      const unsigned uh = act[s] ? 0u : mhi[s];
+      if (s == 0 || uh > lane_hi) {
+        lane_hi = uh;
+        lane_b = myb[s];
+      }
+    }
+    BTR_QPH(0)
+    // Min-dist stores of the previous step must have COMPLETED before another wave may load
+    // the same bucket (a bucket is updated by whichever wave pops it): they were issued a full
+    // reduction phase ago, so this wait is normally free.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BTR_QPH(1)
+    lds_barrier();  // ---- barrier A: the queue of this step is complete
+    BTR_QPH(2)
+    if (tid == 0) qcount[par ^ 1] = 0;  // next step's counter (everyone finished reading it
+                                        // before arriving here)
+    const int Q = __builtin_amdgcn_readfirstlane(qcount[par]);
+
+    // ---- C: pop + update.  Item `it` of the queue belongs to wave it % NW.  Software
+    // pipelined like the kernel above: the next item's loads are in flight while the current
+    // one is reduced; the untouched-best of the wave runs under the first load's latency.
+    auto fetch = [&](int it, int &b, float4 &p, float &t) {
+      b = __builtin_amdgcn_readfirstlane(q[it]);
+      const float *bp = (const float *)spts + (size_t)b * 256 + lane;
+      p.x = bp[0];
+      p.y = bp[64];
+      p.z = bp[128];
+      p.w = bp[192];
+      t = tmin[(size_t)b * 64 + lane];
+    };
+    auto process = [&](int it, int b, const float4 &p, float t0) {
+      float dx, dy, dz;  // plain v_sub_f32 through asm: see fps_bucket_kernel
+      asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(p.x), "v"(sx));
+      asm("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(p.y), "v"(sy));
+      asm("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(p.z), "v"(sz));
+      const float d = sq3(dx, dy, dz);
+      const bool valid = t0 >= 0.f;
+      const float t = valid ? fminf(d, t0) : t0;
+      if (t != t0) tmin[(size_t)b * 64 + lane] = t;
+      const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
+      const unsigned mh = wave_max_u32(hi);
+      const unsigned long long cand = __ballot(hi == mh);
+      const int kk = __float_as_int(p.w);
+      int w;
+      if (__builtin_popcountll(cand) == 1) {
+        w = __builtin_ctzll(cand);
+      } else {  // exact tie (duplicated points) or an all-skipped bucket
+        const unsigned lo = (hi == mh) ? 0xffffffffu - fps_tk2(kk, tp.bs, tp.log2bs, tp.cpb) : 0u;
+        const unsigned ml = wave_max_u32(lo);
+        w = __builtin_ctzll(__ballot(hi == mh && lo == ml));
+      }
+      if (lane == w) {  // the winner lane publishes its own point: no readlanes
+        rec[b] = QRec{mh, 0xffffffffu - fps_tk2(kk, tp.bs, tp.log2bs, tp.cpb), p.x, p.y, p.z,
+                      kk, 0, 0};
+        qhi[it] = mh;
+      }
+    };
+    auto untouched_best = [&]() {
+      const unsigned wh = wave_max_u32(lane_hi);
+      const unsigned long long c = __ballot(lane_hi == wh);
+      int wl;
+      if (__builtin_popcountll(c) == 1) {
+        wl = __builtin_ctzll(c);
+      } else {  // several buckets hold the same max key: the tie key decides
+        const unsigned lo = (lane_hi == wh && wh != 0u) ? rec[lane_b].lo : 0u;
+        const unsigned ml = wave_max_u32(lo);
+        wl = __builtin_ctzll(__ballot(lane_hi == wh && lo == ml));
+      }
+      if (lane == wl) slots[wave] = make_uint2(wh, (unsigned)lane_b);
+    };
+    if (PROF) nitem += (Q > wave) ? (unsigned)((Q - wave + NW - 1) / NW) : 0u;
+    {
+      int it = wave;
+      if (it >= Q) {
+        untouched_best();
+      } else {
+        int bA, bB = 0, itA = it, itB = 0;
+        float4 pA, pB = make_float4(0.f, 0.f, 0.f, 0.f);
+        float tA, tB = 0.f;
+        fetch(itA, bA, pA, tA);
+        untouched_best();
+        BTR_QPH(3)
+        if (PROF) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          BTR_QPH(4)
+        }
+        for (;;) {
+          itB = itA + NW;
+          if (itB >= Q) {
+            process(itA, bA, pA, tA);
+            break;
+          }
+          fetch(itB, bB, pB, tB);
+          process(itA, bA, pA, tA);
+          itA = itB + NW;
+          if (itA >= Q) {
+            process(itB, bB, pB, tB);
+            break;
+          }
+          fetch(itA, bA, pA, tA);
+          process(itB, bB, pB, tB);
+        }
+      }
+    }
+    BTR_QPH(5)
+    lds_barrier();  // ---- barrier B: every record of this step is in LDS
+    BTR_QPH(6)
+
+    // owners pick up the new max key of their touched buckets (used by the next box test;
+    // the read runs under the reduction below)
+    unsigned nh[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) nh[s] = act[s] ? qhi[myslot[s]] : mhi[s];
+
+    // ---- D: every wave reduces the NW untouched-bests + the Q fresh records
+    unsigned gh = 0u, glo = 0u;
+    int gb = 0;
+    const int C = NW + Q;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int ci = c0 + lane;
+      unsigned h = 0u;
+      int bkt = 0;
+      if (ci < NW) {
+        const uint2 v = slots[ci];
+        h = v.x;
+        bkt = (int)v.y;
+      } else if (ci < C) {
+        h = qhi[ci - NW];
+        bkt = q[ci - NW];
+      }
+      const unsigned ch = wave_max_u32(h);
+      const unsigned long long cand = __ballot(h == ch);
+      if (c0 == 0 && C <= 64 && __builtin_popcountll(cand) == 1) {  // the common case
+        gh = ch;
+        gb = __builtin_amdgcn_readlane(bkt, __builtin_ctzll(cand));
+        break;
+      }
+      if (ch == 0u) continue;
+      const unsigned lo = (h == ch) ? rec[bkt].lo : 0u;  // ties: the tie key decides
+      const unsigned cl = wave_max_u32(lo);
+      const int cw = __builtin_ctzll(__ballot(h == ch && lo == cl));
+      const int cb = __builtin_amdgcn_readlane(bkt, cw);
+      if (ch > gh || (ch == gh && cl > glo)) {
+        gh = ch;
+        glo = cl;
+        gb = cb;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < SL; ++s) mhi[s] = nh[s];
+    if (gh == 0u) {  // nothing competes: best=-1, besti=0 in the reference
+      sx = x0; sy = y0; sz = z0;
+      if (tid == 0) out_idx[j & (kOut - 1)] = 0;
+    } else {
+      const QRec win = rec[gb];  // wave-uniform address: broadcast read
+      sx = win.x; sy = win.y; sz = win.z;
+      if (tid == 0) out_idx[j & (kOut - 1)] = win.k;
+    }
+    BTR_QPH(7)
+  }
+  lds_barrier();
+  {
+    const int done = (m - 1) & ~(kOut - 1);  // first sample of the chunk still in LDS
+    for (int i = tid; done + i < m; i += NW * 64) idxs[done + i] = out_idx[i];
+  }
+  if (PROF && lane == 0 && dbg) {
+    unsigned long long *o = dbg + ((size_t)bi * NW + wave) * 16;
+    for (int i = 0; i < 8; ++i) o[i] = tph[i];
+    o[8] = nitem;
+  }
+#undef BTR_QPH
+}
+
 // ------------------------------------------------------------------- multi-sample rounds
 // Exact FPS emitting SEVERAL samples per synchronisation round.
 //
@@ -827,6 +1135,28 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   }
   int rc = check_launch("furthest_point_sampling(sort)");
   if (rc) return rc;
+  if (getenv("BTR_FPS_PROF") && getenv("BTR_FPS_IMPL") && getenv("BTR_FPS_IMPL")[0] == 'q') {
+    static unsigned long long *dbg = nullptr;
+    if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 64 * 16 * 16);
+    hipLaunchKernelGGL((fps_queue_kernel<16, 1, true>), dim3(b), dim3(1024), 0, s, n, p.np, m, bs,
+                       log2bs, dataset, spts, sk, idxs, dbg);
+    (void)hipStreamSynchronize(s);
+    unsigned long long h[16 * 16];
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    const char *names[8] = {"test+push", "store-wait", "barrierA", "pop+fetch+untouched",
+                            "load-wait", "process", "barrierB", "reduce+winner"};
+    for (int w = 0; w < 16; w += 5) {
+      fprintf(stderr, "[fps queue prof] scene 0 wave %2d:", w);
+      double tot = 0;
+      for (int i = 0; i < 8; ++i) {
+        fprintf(stderr, " %s %.0f", names[i], (double)h[w * 16 + i] / (m - 1));
+        tot += (double)h[w * 16 + i] / (m - 1);
+      }
+      fprintf(stderr, " | total %.0f cycles/step, items/step %.2f\n", tot,
+              (double)h[w * 16 + 8] / (m - 1));
+    }
+    return check_launch("furthest_point_sampling(queue,prof)");
+  }
   if (getenv("BTR_FPS_PROF")) {  // tuning only: phase counters -> first bytes of idxs' scratch
     static unsigned long long *dbg = nullptr;
     if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 64 * 16 * 8);
@@ -899,7 +1229,19 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
       return check_launch("furthest_point_sampling(bucket,multi)");
     }
   }
-  // one-sample-per-step kernel: 16 waves, one bucket per trip (measured best)
+  {  // BTR_FPS_IMPL=queue: the work-queue kernel (measured slower, see its header)
+    const char *e = getenv("BTR_FPS_IMPL");
+    if (e && e[0] == 'q') {
+      if (p.nb <= kBucketWaves * 64)
+        hipLaunchKernelGGL((fps_queue_kernel<kBucketWaves, 1>), dim3(b), dim3(kBucketWaves * 64),
+                           0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
+      else
+        hipLaunchKernelGGL((fps_queue_kernel<kBucketWaves, 2>), dim3(b), dim3(kBucketWaves * 64),
+                           0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
+      return check_launch("furthest_point_sampling(queue)");
+    }
+  }
+  // owner-wave kernel: 16 waves, one bucket per trip
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);

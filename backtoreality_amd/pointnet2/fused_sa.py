@@ -58,6 +58,8 @@ class FusedSAFunction(Function):
         feats_cl = None
         if C:
             feats_cl = getattr(features, "_btr_channel_last", None)
+            if os.environ.get("BTR_SA_CL_SHORTCUT", "1") == "0":
+                feats_cl = None
             if feats_cl is None or feats_cl.shape != (B, N, C):
                 feats_cl = features.transpose(1, 2).contiguous()
 

@@ -69,7 +69,8 @@ def test_c5_matterport_80k_points(cuda, monkeypatch):
     assert torch.equal(end_f['sa1_inds'], end_u['sa1_inds'])
     assert torch.equal(end_f['aggregated_vote_inds'], end_u['aggregated_vote_inds'])
     assert _rel(end_f['fp2_features'], end_u['fp2_features']) < 1e-4
-    assert _rel(end_f['aggregated_vote_features'], end_u['aggregated_vote_features']) < 1e-4
+    # two float32 paths, each within 1e-4 of the reference's result: 2e-4 between them
+    assert _rel(end_f['aggregated_vote_features'], end_u['aggregated_vote_features']) < 2e-4
     assert abs(float(loss_f) - float(loss_u)) / abs(float(loss_u)) < 1e-4
     worst = _worst_grad_dev(g_f, g_u)
     assert worst < 2e-2, worst

@@ -85,6 +85,9 @@ def test_fps_full_size_and_both_large_kernels(cuda, monkeypatch):
     monkeypatch.setenv("BTR_FPS_IMPL", "stream")
     got = _ext().furthest_point_sampling(x[:2], 600).cpu().numpy()
     np.testing.assert_array_equal(got, ref[:2, :600])
+    monkeypatch.setenv("BTR_FPS_IMPL", "queue")   # work-queue distribution of the bucket updates
+    got_q = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
+    np.testing.assert_array_equal(got_q, ref)
     monkeypatch.setenv("BTR_FPS_IMPL", "multi")   # several samples per round, still exact
     got = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
     np.testing.assert_array_equal(got, ref)

@@ -138,7 +138,7 @@ def main():
         g = np.load(os.path.join(T.GOLD, gname))
         mk = dict(center_jitter=jit) if jit else {}
         bS = to64(synthetic.make_batch(0, 2, 4096, cfg, **mk))
-        bT = to64(synthetic.make_batch(100, 2, 4096, cfg, **mk))
+        bT = to64(synthetic.make_batch(100 if jit else 300, 2, 4096, cfg, **mk))
         net = train.build_model(cfg, dev, seed=0, **kw).double()
         with T.pinned_vote_inds(net, g['S_aggregated_vote_inds'], g['T_aggregated_vote_inds'],
                                 idx_per_forward=[g['S_vote_agg_idx'], g['T_vote_agg_idx']]):
