@@ -122,4 +122,4 @@ def build(force=False, verbose=False, jobs=None):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

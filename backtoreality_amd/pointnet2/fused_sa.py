@@ -268,6 +268,61 @@ class FusedSAFunction(Function):
         return (dxyz, dnew, dfeat, None, None) + tuple(grads)
 
 
+def fused_eval_forward(module, xyz, new_xyz, features, idx):
+    """Inference-mode forward of a set-abstraction layer (module.eval(), under no_grad -- the
+    evaluation pass of the reference, train_Votenet_FSB.py:246-293): BatchNorm uses its RUNNING
+    statistics, so no batch reduction separates the layers and nothing is saved for a backward:
+    gather -> one GEMM per layer with the previous layer's BN + ReLU applied while its operand
+    is staged -> BN + ReLU + max-pool.  Same kernels as the training forward, minus the
+    statistics epilogues / finalize launches; the grouped tensor never exists."""
+    g = module.grouper
+    dev = xyz.device
+    B, N, _ = xyz.shape
+    M, S = idx.shape[1], idx.shape[2]
+    C = features.shape[1] if features is not None else 0
+    use_xyz = 1 if g.use_xyz else 0
+    rdiv = float(g.radius if g.normalize_xyz else 1.0)
+    R = B * M * S
+    K0p = _ceil4(3 * use_xyz + C)
+    xyz = xyz.contiguous()
+    new_xyz = new_xyz.contiguous()
+    feats_cl = None
+    if C:
+        feats_cl = getattr(features, "_btr_channel_last", None)
+        if feats_cl is None or feats_cl.shape != (B, N, C):
+            feats_cl = features.transpose(1, 2).contiguous()
+    with _on(xyz) as d:
+        st = _stream(d)
+        A = _f32((R, K0p), dev)
+        _call(_lib.btr_sa_gather, B, N, M, S, C, K0p, use_xyz, rdiv, _p(xyz), _p(new_xyz),
+              _p(feats_cl), _p(idx), _p(A), st)
+        lda, K, pa, pb = K0p, K0p, None, None
+        for layer in module.mlp_module:
+            W, bn = layer.conv.weight, layer.bn.bn
+            Nl = W.shape[0]
+            W2 = W.reshape(Nl, -1)
+            if W2.shape[1] != K:  # layer 0 with a padded input width
+                Wp = torch.zeros((Nl, K), dtype=torch.float32, device=dev)
+                Wp[:, :W2.shape[1]] = W2
+                W2 = Wp
+            W2 = W2.contiguous()
+            Y = _f32((R, Nl), dev)
+            _call(_lib.btr_sa_gemm_nt, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl, _p(pa), _p(pb),
+                  None, st, key=(R, Nl, K))
+            # y_bn = (y - running_mean) / sqrt(running_var + eps) * gamma + beta = pa * y + pb
+            pa = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            pb = bn.bias - bn.running_mean * pa
+            A, lda, K = Y, Nl, Nl
+        CL = K
+        out = _f32((B, CL, M), dev)
+        out_cl = _f32((B, M, CL), dev)
+        arg = torch.empty((B * M, CL), dtype=torch.uint8, device=dev)
+        _call(_lib.btr_sa_pool, B, M, S, CL, CL, _p(A), _p(pa.contiguous()), _p(pb.contiguous()),
+              _p(out), _p(out_cl), _p(arg), st)
+    out._btr_channel_last = out_cl
+    return out
+
+
 def _pool_in_epilogue():
     """BTR_POOL_EPILOGUE=0: the max-pool reads the last layer's output again (btr_sa_pool)
     instead of using the extrema the GEMM epilogue emits."""
@@ -283,10 +338,13 @@ def _pool_grad_in_prologue(nsample):
 def can_fuse(module, xyz, features):
     """True when `module` (a _SingleScaleSA) is in the configuration the fused kernels cover:
     ball-query grouping, max-pool, every MLP layer = bias-free 1x1 conv + BatchNorm2d + ReLU,
-    training mode (batch statistics), CUDA tensors."""
+    CUDA tensors; training mode (batch statistics, forward + backward) or inference mode under
+    no_grad (running statistics, forward only: fused_eval_forward)."""
     import torch.nn as nn
-    if not (enabled() and xyz.is_cuda and module.training and module.pooling == 'max'):
+    if not (enabled() and xyz.is_cuda and module.pooling == 'max'):
         return False
+    if not module.training and torch.is_grad_enabled():
+        return False   # eval-mode layers that still need a backward: op-by-op path
     g = module.grouper
     if not isinstance(g, pointnet2_utils.QueryAndGroup) or g.sample_uniformly:
         return False
@@ -302,6 +360,8 @@ def can_fuse(module, xyz, features):
             return False
         if layer.bn.bn.weight is None:
             return False
+        if not module.training and (layer.bn.bn.training or layer.bn.bn.running_mean is None):
+            return False
     return features is None or features.dtype == torch.float32
 
 
@@ -309,6 +369,10 @@ def fused_group_mlp_max(module, xyz, new_xyz, features):
     """Drop-in for grouper + mlp_module + max-pool of a _SingleScaleSA module."""
     g = module.grouper
     idx = pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz)
+    if features is None and not g.use_xyz:
+        raise AssertionError("Cannot have not features and not use xyz as a feature!")
+    if not module.training:
+        return fused_eval_forward(module, xyz, new_xyz, features, idx)
     params = []
     bns = []
     for layer in module.mlp_module:

@@ -197,16 +197,28 @@ class QueryAndGroup(nn.Module):
             assert self.sample_uniformly
 
     def _resample_uniformly(self, idx):
-        # :336-345 -- host-side loop; no model in the reference enables it.
-        unique_cnt = torch.zeros((idx.shape[0], idx.shape[1]))
-        for b in range(idx.shape[0]):
-            for r in range(idx.shape[1]):
-                uniq = torch.unique(idx[b, r, :])
-                k = uniq.shape[0]
-                unique_cnt[b, r] = k
-                pick = torch.randint(0, k, (self.nsample - k,), dtype=torch.long)
-                idx[b, r, :] = torch.cat((uniq, uniq[pick.to(uniq.device)]))
-        return unique_cnt
+        """:336-345 on the device, one pass of tensor ops instead of the reference's host
+        double loop (B * npoint iterations of torch.unique + torch.randint + a host sync each).
+        A ball-query row IS its distinct hits in ascending order followed by copies of the
+        first one (ball_query_gpu.cu:39-43), so `torch.unique(row)` = its first k entries with
+        k = 1 + #(entries != the first) -- no sort needed; the padding slots are then redrawn
+        uniformly from those k.  Same distribution as the reference; the draws come from the
+        device generator, so they are not the reference's CPU-generator draws (checked against
+        the reference loop with the draws injected: tests/test_host_logic.py).
+        Returns unique_cnt (B, npoint) float32 like the reference."""
+        B, M, S = idx.shape
+        first = idx[:, :, :1]
+        k = (idx != first).sum(-1, keepdim=True) + 1                     # (B, M, 1)
+        slot = torch.arange(S, device=idx.device).view(1, 1, S)
+        draw = self._uniform_draws((B, M, S), idx.device)                # in [0, 1)
+        src = torch.minimum((draw * k).long(), k - 1)                    # uniform in [0, k)
+        src = torch.where(slot < k, slot.expand(B, M, S), src)           # keep the k hits
+        idx.copy_(torch.gather(idx, 2, src))
+        return k.squeeze(-1).to(torch.float32)
+
+    @staticmethod
+    def _uniform_draws(shape, device):
+        return torch.rand(shape, device=device)
 
     def forward(self, xyz, new_xyz, features=None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)

@@ -110,6 +110,32 @@ def test_query_and_group_and_group_all(oracle_ext):
     assert nf.shape == (2, 8, 8, 6) and cnt.shape == (2, 8) and cnt.min() >= 1
 
 
+def test_sample_uniformly_equals_the_reference_loop(oracle_ext, monkeypatch):
+    """QueryAndGroup(sample_uniformly=True): the one-pass tensor form against the reference's
+    host double loop (pointnet2_utils.py:336-345) with the SAME uniform draws injected into
+    both: identical rows and unique counts."""
+    rng = np.random.default_rng(7)
+    xyz = torch.from_numpy(rng.uniform(0, 2, (2, 300, 3)).astype(np.float32))
+    new_xyz = torch.cat([xyz[:, :30], xyz[:, :2] + 50.0], 1).contiguous()   # two empty balls
+    S = 12
+    idx0 = U.ball_query(0.35, S, xyz, new_xyz)
+    u = torch.from_numpy(rng.uniform(0, 1, idx0.shape).astype(np.float32))
+    monkeypatch.setattr(U.QueryAndGroup, "_uniform_draws", staticmethod(lambda shape, device: u))
+    grouper = U.QueryAndGroup(0.35, S, use_xyz=True, sample_uniformly=True, ret_unique_cnt=True)
+    got = idx0.clone()
+    cnt = grouper._resample_uniformly(got)
+    want, want_cnt = idx0.clone(), torch.zeros(idx0.shape[:2])
+    for b in range(idx0.shape[0]):                       # the reference's loop
+        for r in range(idx0.shape[1]):
+            uniq = torch.unique(idx0[b, r, :])
+            k = uniq.shape[0]
+            want_cnt[b, r] = k
+            pick = torch.clamp((u[b, r, k:] * k).long(), max=k - 1)   # its randint(0, k, S - k)
+            want[b, r, :] = torch.cat((uniq, uniq[pick]))
+    assert torch.equal(got, want) and torch.equal(cnt, want_cnt)
+    assert cnt.min() == 1 and cnt.max() > 3
+
+
 def test_sa_variants_run(oracle_ext):
     rng = np.random.default_rng(1)
     xyz = torch.from_numpy(rng.uniform(0.3, 2, (2, 96, 3)).astype(np.float32))
