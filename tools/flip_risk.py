@@ -36,8 +36,16 @@ def risks(kind, seeds, center_jitter=0.0):
     dev = torch.device("cpu")
     mk = dict(center_jitter=center_jitter) if center_jitter else {}
     batches = [to64(synthetic.make_batch(s, 2, 4096, cfg, **mk)) for s in seeds]
+    sampling = kind.split(":")[1] if ":" in kind else "vote_fps"
+    kind = kind.split(":")[0]
     net = train.build_model(cfg, dev, seed=0, domain_adaptation=(kind == "br"),
-                            center_refine=(kind == "cr")).double()
+                            center_refine=(kind == "cr"), sampling=sampling).double()
+    if sampling == "random":    # the fixture's draws
+        import numpy as _np
+        gs = _np.load(os.path.join(ROOT, "tests", "golden", "votenet_sampling.npz"))
+        real = torch.randint
+        torch.randint = lambda *a, **k: torch.as_tensor(gs['random_aggregated_vote_inds'],
+                                                        dtype=k.get('dtype', torch.int64))
     cap = []
 
     def pre(name):
@@ -52,10 +60,19 @@ def risks(kind, seeds, center_jitter=0.0):
             out.retain_grad()
             cap[-1][2] = out
         return h
+    pools = []
+
+    def pool_hook(name):
+        def h(mod, inp, out):
+            out.retain_grad()
+            pools.append((name, out))
+        return h
     for n, m in net.named_modules():
         if isinstance(m, nn.ReLU):
             m.register_forward_pre_hook(pre(n))
             m.register_forward_hook(post(n))
+        if n.endswith("mlp_module"):      # (B, C, npoint, nsample) right before the max-pool
+            m.register_forward_hook(pool_hook(n))
     ends = []
     for b in batches:
         if kind == "cr":
@@ -85,6 +102,20 @@ def risks(kind, seeds, center_jitter=0.0):
         hit = near & (expo > EXPOSURE)
         for idx in hit.nonzero().tolist()[:5]:
             found.append((name, tuple(idx), float(z[tuple(idx)]), float(expo[tuple(idx)])))
+    # max-pool: two samples of a group within float32 noise of each other at the top, the
+    # pooled gradient then goes to the one or the other point
+    for name, z in pools:
+        if z.grad is None or z.dim() != 4 or z.size(3) < 2:
+            continue
+        top = torch.topk(z.detach(), 2, dim=3).values
+        gap = top[..., 0] - top[..., 1]
+        std = z.detach().std(dim=(0, 2, 3), keepdim=True).squeeze(-1) + 1e-30
+        g = z.grad.sum(dim=3)
+        expo = g.abs() / (g.norm() + 1e-300)
+        hit = (gap < REL_Z * std) & (gap > 0) & (expo > EXPOSURE)
+        for idx in hit.nonzero().tolist()[:5]:
+            found.append((name + " [max-pool top-2 gap]", tuple(idx), float(gap[tuple(idx)]),
+                          float(expo[tuple(idx)])))
     return found
 
 

@@ -36,7 +36,11 @@ for fused in ("1", "0"):
     for name, run, chk in (("fsb", T.run_votenet, T.check_votenet),
                            ("br", T.run_votenet_br, T.check_votenet_br),
                            ("cr", T.run_votenet_br_jitter, T.check_votenet_br_jitter),
-                           ("wsb", T.run_votenet_wsb, T.check_votenet_wsb)):
+                           ("wsb", T.run_votenet_wsb, T.check_votenet_wsb),
+                           ("seed_fps", lambda d, pin: T.run_votenet_sampling(d, "seed_fps", pin),
+                            lambda r, a, b: T.check_votenet_sampling(r, "seed_fps", a, b)),
+                           ("random", lambda d, pin: T.run_votenet_sampling(d, "random", pin),
+                            lambda r, a, b: T.check_votenet_sampling(r, "random", a, b))):
         print("== %s  BTR_FUSED_SA=%s" % (name, fused))
         rows.clear()
         rep = []
