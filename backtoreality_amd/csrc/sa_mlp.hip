@@ -24,6 +24,18 @@ namespace btr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// "Compact rows" (csrc comment block further down, btr_sac_plan): device-side description of
+// a row array in which every group keeps only ceil8(#distinct neighbours) rows.
+//   dims[0] = number of rows, dims[1] = number of 8-row blocks
+//   bw[block]   = weight of the block's FIRST row (1 + S - len for a group's first block, else 1)
+//   bgrp[block] = group (b * M + m) the block belongs to,  goff[g] = first row of group g
+struct Compact {
+  const int *dims = nullptr;
+  const float *bw = nullptr;
+  const int *bgrp = nullptr;
+  const int *goff = nullptr;
+};
+
 constexpr int kBM = 128;      // rows per workgroup tile
 constexpr int kBK = 32;       // reduction chunk staged in LDS
 constexpr int kLd = kBK + 4;  // padded LDS row (floats): conflict-free ds_read_b128
@@ -106,25 +118,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const float *__restrict__ pb, float *__restrict__ part,
     const unsigned char *__restrict__ parg, const float *__restrict__ pdcl, int SSH,
     const float *__restrict__ gsign = nullptr, float *__restrict__ gext = nullptr,
-    unsigned char *__restrict__ aext = nullptr) {
-  static_assert(PS == 0 || (BN == 128 && (PS == 16 || PS == 32 || PS == 64)),
-                "pooling epilogue: 128-column tiles, groups of 16 / 32 / 64 rows");
+    unsigned char *__restrict__ aext = nullptr, Compact cm = Compact{}) {
+  static_assert(PS == 0 || (BN == 128 && (PS == 8 || PS == 16 || PS == 32 || PS == 64)),
+                "pooling epilogue: 128-column tiles, groups of 8 / 16 / 32 / 64 rows");
+  if (cm.dims) R = cm.dims[0];  // compact rows: the row count lives on the device
   constexpr int WN = BN / 64;      // waves along N
   constexpr int WM = 4 / WN;       // waves along M
   constexpr int MI = kBM / WM / 32;  // 32-row MFMA tiles per wave
   constexpr int NJ = 2;            // 32-col MFMA tiles per wave
   __shared__ __attribute__((aligned(16))) float As[kBM * kLd];
   __shared__ __attribute__((aligned(16))) float Bs[BN * kLd];
-  __shared__ float red[STATS ? 2 * WM * BN : 1];
+  __shared__ double red[STATS ? 2 * WM * BN : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
   const int n_blk = blockIdx.y * BN;
 
+  // BatchNorm statistics: per tile a lane adds its 16 * MI values in f32, across the tiles of
+  // this workgroup the per-lane partials accumulate in f64 (a workgroup covers up to 2048
+  // rows: in f32 that chain alone put ~1e-6 of relative error into mean / variance)
   float s1[NJ], s2[NJ];
+  double d1[NJ], d2[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
+  for (int j = 0; j < NJ; ++j) {
+    s1[j] = s2[j] = 0.f;
+    d1[j] = d2[j] = 0.0;
+  }
 
   const int ntiles = (R + kBM - 1) / kBM;
   const int nkc = (K + kBK - 1) / kBK;
@@ -142,18 +162,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   unsigned sp_arg = 0;
   float sp_d = 0.f;
   bool sp_on = false;
+  // compact rows (cm.bgrp): groups are runs of 8-row blocks, a tile holds 16 blocks -> two
+  // block slots per thread; sp_lr = local row of the group's arg-max if it lies in that block
+  int sp_lr[2] = {-1, -1};
+  float sp_dv[2] = {0.f, 0.f};
+  float rwt[kBM / 32];  // PRO == 2: weight of the dense part for the rows this thread stages
   auto fetch = [&](int tile, int kc) {
     const int r0 = tile * kBM, kk = kc * kBK + kq;
 #pragma unroll
     for (int p = 0; p < kBM / 32; ++p) {
       const int row = srow + 32 * p;
       ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rwt[p] = 1.f;
       if (r0 + row < R && kk < K) {
         ra[p] = PRO == 3 ? *reinterpret_cast<const float4 *>(A + (size_t)(r0 + row) * 4)
                          : *reinterpret_cast<const float4 *>(A + (size_t)(r0 + row) * lda + kk);
+        if (PRO == 2 && cm.bw && (row & 7) == 0) rwt[p] = cm.bw[(r0 + row) >> 3];
       }
     }
-    if (PRO == 2) {
+    if (PRO == 2 && cm.bgrp) {
+      const int k1 = kc * kBK + sp_k;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int slot = sp_gi + 8 * q, blk = (r0 >> 3) + slot;
+        sp_lr[q] = -1;
+        if ((blk << 3) < R && k1 < K) {
+          const int g = cm.bgrp[blk];
+          const int lr = cm.goff[g] + (int)parg[(size_t)g * K + k1] - r0;
+          if (lr >= 0 && (lr >> 3) == slot) {
+            sp_lr[q] = lr;
+            sp_dv[q] = pdcl[(size_t)g * K + k1];
+          }
+        }
+      }
+    } else if (PRO == 2) {
       const int k1 = kc * kBK + sp_k;  // (group size S = 1 << SSH: shifts, no divisions)
       const int g = (r0 >> SSH) + sp_gi;
       sp_on = (sp_gi << SSH) < kBM && (g << SSH) < R && k1 < K;
@@ -194,11 +236,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         v.z = fmaxf(fmaf(fa.z, y.z, fb.z), 0.f);
         v.w = fmaxf(fmaf(fa.w, y.w, fb.w), 0.f);
       }
-      if (PRO == 2 && r0 + row < R && kk < K) {  // dense part: alpha*y + beta
-        v.x = fmaf(fa.x, v.x, fb.x);
-        v.y = fmaf(fa.y, v.y, fb.y);
-        v.z = fmaf(fa.z, v.z, fb.z);
-        v.w = fmaf(fa.w, v.w, fb.w);
+      if (PRO == 2 && r0 + row < R && kk < K) {  // dense part: w * (alpha*y + beta)
+        const float wr = rwt[p];                  // (w = 1 except a compact group's first row)
+        v.x = wr * fmaf(fa.x, v.x, fb.x);
+        v.y = wr * fmaf(fa.y, v.y, fb.y);
+        v.z = wr * fmaf(fa.z, v.z, fb.z);
+        v.w = wr * fmaf(fa.w, v.w, fb.w);
       }
       *reinterpret_cast<float4 *>(&As[row * kLd + kq]) = v;
     }
@@ -222,7 +265,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       stage(tile, kc);
       __syncthreads();
       if (PRO == 2) {  // sparse part: the arg-max row of every (group, channel) of this tile
-        if (sp_on) As[((sp_gi << SSH) + (int)sp_arg) * kLd + sp_k] += sp_d;
+        if (cm.bgrp) {
+          if (sp_lr[0] >= 0) As[sp_lr[0] * kLd + sp_k] += sp_dv[0];
+          if (sp_lr[1] >= 0) As[sp_lr[1] * kLd + sp_k] += sp_dv[1];
+        } else if (sp_on) {
+          As[((sp_gi << SSH) + (int)sp_arg) * kLd + sp_k] += sp_d;
+        }
         __syncthreads();
       }
       // issue the next step's global loads before the MFMAs of this one
@@ -272,9 +320,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
           if (STATS) {  // rows >= R hold exact zeros (A staged as 0): no masking needed
             s1[j] += c;
             s2[j] = fmaf(c, c, s2[j]);
+            // compact rows: the first row of a group stands for 1 + S - len copies of itself
+            if (cm.bw && h == 0 && (v & 3) == 0 && row < R) {
+              const float wx = cm.bw[row >> 3] - 1.f;
+              s1[j] = fmaf(wx, c, s1[j]);
+              s2[j] = fmaf(wx * c, c, s2[j]);
+            }
           }
         }
       }
+    if (STATS) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        d1[j] += (double)s1[j];
+        d2[j] += (double)s2[j];
+        s1[j] = s2[j] = 0.f;
+      }
+    }
     if constexpr (PS > 0) {
       // this wave's 64 rows = 64 / PS whole groups; lanes l and l ^ 32 hold the same column
       // (rows interleaved in blocks of 4), v ascending = rows ascending within a lane
@@ -324,21 +386,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   if (STATS) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      s1[j] += __shfl_xor(s1[j], 32);
-      s2[j] += __shfl_xor(s2[j], 32);
+      d1[j] += __shfl_xor(d1[j], 32);
+      d2[j] += __shfl_xor(d2[j], 32);
       if (h == 0) {
-        red[(0 * WM + wm) * BN + wn * 64 + j * 32 + l31] = s1[j];
-        red[(1 * WM + wm) * BN + wn * 64 + j * 32 + l31] = s2[j];
+        red[(0 * WM + wm) * BN + wn * 64 + j * 32 + l31] = d1[j];
+        red[(1 * WM + wm) * BN + wn * 64 + j * 32 + l31] = d2[j];
       }
     }
     __syncthreads();
     for (int c = tid; c < 2 * BN; c += 256) {
       const int which = c / BN, col = c % BN;
-      float s = 0.f;
+      double s = 0.0;
 #pragma unroll
       for (int w = 0; w < WM; ++w) s += red[(which * WM + w) * BN + col];
       if (n_blk + col < N)
-        part[((size_t)blockIdx.x * 2 + which) * N + n_blk + col] = s;
+        part[((size_t)blockIdx.x * 2 + which) * N + n_blk + col] = (float)s;
     }
   }
 }
@@ -598,7 +660,7 @@ __global__ __launch_bounds__(256) void sa_pool_bwd_tile_kernel(
     const float *__restrict__ out, const unsigned char *__restrict__ arg,
     const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ part,
-    float *__restrict__ dcl) {
+    float *__restrict__ dcl, const int *__restrict__ goff = nullptr) {
   __shared__ float tile[64][17];
   const int bi = blockIdx.z, c0 = blockIdx.y * 16, m0 = blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -619,7 +681,9 @@ __global__ __launch_bounds__(256) void sa_pool_bwd_tile_kernel(
           y = (ov - shift[c]) / a;
         } else {
           const size_t grp = (size_t)bi * M + m;
-          y = Y[(grp * S + arg[grp * C + c]) * ldy + c];
+          const size_t row = goff ? (size_t)goff[grp] + arg[grp * C + c]
+                                  : grp * S + arg[grp * C + c];
+          y = Y[row * ldy + c];
         }
         gx = g * ((y - mean[c]) * invstd[c]);
         dv = a * g;
@@ -700,8 +764,10 @@ constexpr int kBnBwdMaxC = 256;
 __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(
     long long R, int C, int ld, const float *__restrict__ G, const float *__restrict__ Y,
     const float *__restrict__ scale, const float *__restrict__ shift,
-    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ part) {
+    const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ part,
+    Compact cm = Compact{}) {
   __shared__ float red[2][256 * 4];
+  if (cm.dims) R = cm.dims[0];
   const int tpr = C >> 2;             // threads per row
   const int slots = 256 / tpr;        // rows per block iteration
   const int slot = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
@@ -742,8 +808,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_stats_rc_kernel(
     long long R, int C, int ld, const float *__restrict__ G, const float *__restrict__ X0,
     const float *__restrict__ W0, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ mean,
-    const float *__restrict__ invstd, float *__restrict__ part) {
+    const float *__restrict__ invstd, float *__restrict__ part, Compact cm = Compact{}) {
   __shared__ float red[2][256 * 4];
+  if (cm.dims) R = cm.dims[0];
   const int tpr = C >> 2;
   const int slots = 256 / tpr;
   const int slot = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
@@ -788,8 +855,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_wgrad0_rc_kernel(
     const float *__restrict__ W0, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ m1,
-    const float *__restrict__ m2, float *__restrict__ pw) {
+    const float *__restrict__ m2, float *__restrict__ pw, Compact cm = Compact{}) {
   __shared__ float red[256 * 16];
+  if (cm.dims) R = cm.dims[0];
   const int tpr = C >> 2;
   const int slots = 256 / tpr;
   const int slot = threadIdx.x / tpr, c4 = (threadIdx.x % tpr) * 4;
@@ -808,11 +876,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_wgrad0_rc_kernel(
       const float4 x = *reinterpret_cast<const float4 *>(X0 + (size_t)r * 4);
       const float4 y = rc_y4(x, W0, c4);
       const float4 g = *reinterpret_cast<const float4 *>(G + (size_t)r * ld + c4);
+      // compact rows: G is the gradient summed over the copies a row stands for, the
+      // statistics term counts once per copy (w copies)
+      const float cw = (cm.bw && (r & 7) == 0) ? cm.bw[r >> 3] : 1.f;
       float d[4];
-      d[0] = a.x * ((fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f) - c1.x - (y.x - mu.x) * is.x * c2.x);
-      d[1] = a.y * ((fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f) - c1.y - (y.y - mu.y) * is.y * c2.y);
-      d[2] = a.z * ((fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f) - c1.z - (y.z - mu.z) * is.z * c2.z);
-      d[3] = a.w * ((fmaf(a.w, y.w, b.w) > 0.f ? g.w : 0.f) - c1.w - (y.w - mu.w) * is.w * c2.w);
+      d[0] = a.x * ((fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f) - cw * (c1.x + (y.x - mu.x) * is.x * c2.x));
+      d[1] = a.y * ((fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f) - cw * (c1.y + (y.y - mu.y) * is.y * c2.y));
+      d[2] = a.z * ((fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f) - cw * (c1.z + (y.z - mu.z) * is.z * c2.z));
+      d[3] = a.w * ((fmaf(a.w, y.w, b.w) > 0.f ? g.w : 0.f) - cw * (c1.w + (y.w - mu.w) * is.w * c2.w));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         w[i].x = fmaf(d[i], x.x, w[i].x);
@@ -840,7 +911,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
     long long R, int C, int ld, float *__restrict__ G, const float *__restrict__ Y,
     const float *__restrict__ scale, const float *__restrict__ shift,
     const float *__restrict__ mean, const float *__restrict__ invstd,
-    const float *__restrict__ m1, const float *__restrict__ m2) {
+    const float *__restrict__ m1, const float *__restrict__ m2, Compact cm = Compact{}) {
+  if (cm.dims) R = cm.dims[0];
   const int cq = C >> 2;
   const long long total = R * (long long)cq;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total;
@@ -855,10 +927,11 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
     const float4 is = *reinterpret_cast<const float4 *>(invstd + c4);
     const float4 c1 = *reinterpret_cast<const float4 *>(m1 + c4);
     const float4 c2 = *reinterpret_cast<const float4 *>(m2 + c4);
-    g.x = a.x * ((fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f) - c1.x - (y.x - mu.x) * is.x * c2.x);
-    g.y = a.y * ((fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f) - c1.y - (y.y - mu.y) * is.y * c2.y);
-    g.z = a.z * ((fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f) - c1.z - (y.z - mu.z) * is.z * c2.z);
-    g.w = a.w * ((fmaf(a.w, y.w, b.w) > 0.f ? g.w : 0.f) - c1.w - (y.w - mu.w) * is.w * c2.w);
+    const float w = (cm.bw && (r & 7) == 0) ? cm.bw[r >> 3] : 1.f;  // see wgrad0_rc
+    g.x = a.x * ((fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f) - w * (c1.x + (y.x - mu.x) * is.x * c2.x));
+    g.y = a.y * ((fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f) - w * (c1.y + (y.y - mu.y) * is.y * c2.y));
+    g.z = a.z * ((fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f) - w * (c1.z + (y.z - mu.z) * is.z * c2.z));
+    g.w = a.w * ((fmaf(a.w, y.w, b.w) > 0.f ? g.w : 0.f) - w * (c1.w + (y.w - mu.w) * is.w * c2.w));
     *reinterpret_cast<float4 *>(G + (size_t)r * ld + c4) = g;
   }
 }
@@ -881,7 +954,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     float *__restrict__ pw, const unsigned char *__restrict__ garg = nullptr,
     const float *__restrict__ gdcl = nullptr, const float *__restrict__ galpha = nullptr,
     const float *__restrict__ gbeta = nullptr, int SSH = 0,
-    const float *__restrict__ xw0 = nullptr) {
+    const float *__restrict__ xw0 = nullptr, Compact cm = Compact{}) {
+  if (cm.dims) R = cm.dims[0];  // compact rows: the row count lives on the device
   constexpr int BR = 32;
   constexpr int TN = 32 * TNW;      // n columns of G staged per step
   constexpr int LG = TN + 4, LX = 68;
@@ -924,16 +998,37 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
   unsigned sp_arg = 0;
   float sp_d = 0.f;
   bool sp_on = false;
+  // compact rows: a 32-row step holds 4 blocks of 8 rows; 256 / TN block slots per pass
+  constexpr int SPQ = 4 * TN / 256;  // passes over the block slots (2 for TN = 128, 1 for 64)
+  int sp_lr[SPQ];
+  float sp_dv[SPQ];
+  float gwt[GPASS];  // weight of the dense part for the rows this thread stages
   auto fetch = [&](int r0) {
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       const int row = gr + GR * p;
       rg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      gwt[p] = 1.f;
       if (r0 + row < rend && n0 + gc4 < N) {
         rg[p] = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * ldg + n0 + gc4);
+        if (GPOOL && cm.bw && ((r0 + row) & 7) == 0) gwt[p] = cm.bw[(r0 + row) >> 3];
       }
     }
-    if (GPOOL) {
+    if (GPOOL && cm.bgrp) {
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q, blk = (r0 >> 3) + slot;
+        sp_lr[q] = -1;
+        if (slot < 4 && (blk << 3) < rend && n0 + sp_n < N) {
+          const int g = cm.bgrp[blk];
+          const int lr = cm.goff[g] + (int)garg[(size_t)g * N + n0 + sp_n] - r0;
+          if (lr >= 0 && (lr >> 3) == slot) {
+            sp_lr[q] = lr;
+            sp_dv[q] = gdcl[(size_t)g * N + n0 + sp_n];
+          }
+        }
+      }
+    } else if (GPOOL) {
       const int g = (r0 >> SSH) + sp_gi;  // group size S = 1 << SSH
       sp_on = (sp_gi << SSH) < BR && (g << SSH) < rend && n0 + sp_n < N;
       if (sp_on) {
@@ -958,11 +1053,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       float4 v = rg[p];
-      if (GPOOL && r0 + gr + GR * p < rend && n0 + gc4 < N) {  // dense part
-        v.x = fmaf(ga.x, v.x, gb.x);
-        v.y = fmaf(ga.y, v.y, gb.y);
-        v.z = fmaf(ga.z, v.z, gb.z);
-        v.w = fmaf(ga.w, v.w, gb.w);
+      if (GPOOL && r0 + gr + GR * p < rend && n0 + gc4 < N) {  // dense part, weighted
+        const float wr = gwt[p];
+        v.x = wr * fmaf(ga.x, v.x, gb.x);
+        v.y = wr * fmaf(ga.y, v.y, gb.y);
+        v.z = wr * fmaf(ga.z, v.z, gb.z);
+        v.w = wr * fmaf(ga.w, v.w, gb.w);
       }
       *reinterpret_cast<float4 *>(&Gs[(gr + GR * p) * LG + gc4]) = v;
     }
@@ -981,7 +1077,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     }
     __syncthreads();
     if (GPOOL) {
-      if (sp_on) Gs[(int)sp_arg * LG + sp_n] += sp_d;
+      if (cm.bgrp) {
+#pragma unroll
+        for (int q = 0; q < SPQ; ++q)
+          if (sp_lr[q] >= 0) Gs[sp_lr[q] * LG + sp_n] += sp_dv[q];
+      } else if (sp_on) {
+        Gs[(int)sp_arg * LG + sp_n] += sp_d;
+      }
       __syncthreads();
     }
     if (r0 + BR < rend) fetch(r0 + BR);  // next rows in flight during the MFMAs
@@ -1223,6 +1325,239 @@ __global__ __launch_bounds__(256) void centre_grad_kernel(long long groups, int 
   dnew_xyz[t] = -acc * inv_radius;
 }
 
+
+// =================================================================== compact rows ("sac")
+// The reference pads every ball-query row with copies of its first hit (ball_query_gpu.cu:39-43)
+// and then runs the shared MLP over all nsample rows of every group: at the benchmark shape
+// 37 % of SA1's and 69 % of SA2's rows are such copies.  A copy computes exactly what its
+// original computes, so the layer is evaluated on the DISTINCT rows only:
+//   * group g keeps len_g = ceil8(cnt_g) rows (cnt_g distinct neighbours; the len_g - cnt_g
+//     alignment rows are further copies of the first hit), laid out back to back: row r
+//     belongs to the 8-row block r >> 3, block b to group bgrp[b], group g starts at goff[g];
+//   * the first row of a group stands for w = 1 + nsample - len_g copies of itself, every other
+//     row for one: train-mode BatchNorm statistics weight the rows by w, the max-pool is
+//     unaffected (first occurrence wins ties, as in F.max_pool2d), and in the backward each
+//     compact row carries the gradient SUMMED over its copies, which only changes the
+//     statistics term of the BatchNorm backward (it counts once per copy): see
+//     bn_relu_bwd_apply_kernel and the PRO == 2 prologue.
+// The row count is data dependent and lives on the device (dims[0]); every kernel takes it
+// from there, grids and buffers are sized for the dense worst case, nothing synchronises.
+// Same results as the dense evaluation up to float32 summation order.
+__global__ __launch_bounds__(256) void sac_count_kernel(int groups, int S,
+                                                        const int *__restrict__ idx,
+                                                        int *__restrict__ len) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups) return;
+  const int *row = idx + (size_t)g * S;
+  const int first = row[0];
+  int cnt = 1;
+  for (int s2 = 1; s2 < S; ++s2) cnt += row[s2] != first ? 1 : 0;
+  len[g] = (cnt + 7) & ~7;
+}
+
+// exclusive scan of len[0..groups) -> goff[0..groups]; dims[0] = rows, dims[1] = blocks
+__global__ __launch_bounds__(1024) void sac_scan_kernel(int groups, const int *__restrict__ len,
+                                                        int *__restrict__ goff,
+                                                        int *__restrict__ dims) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < groups; base += 1024) {
+    const int i = base + tid;
+    const int v = i < groups ? len[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int pre = carry_s;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    const int excl = pre + incl - v;
+    if (i < groups) goff[i] = excl;
+    __syncthreads();
+    if (tid == 1023) carry_s = excl + v;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    goff[groups] = carry_s;
+    dims[0] = carry_s;
+    dims[1] = carry_s >> 3;
+  }
+}
+
+// per (group, slot): cidx[row] = neighbour index of the compact row; per block: group, weight
+__global__ __launch_bounds__(256) void sac_fill_kernel(int groups, int S,
+                                                       const int *__restrict__ idx,
+                                                       const int *__restrict__ goff,
+                                                       int *__restrict__ cidx,
+                                                       int *__restrict__ bgrp,
+                                                       float *__restrict__ bw) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)groups * S) return;
+  const int g = (int)(t / S), slot = (int)(t - (long long)g * S);
+  const int beg = goff[g], len = goff[g + 1] - beg;
+  if (slot >= len) return;
+  // a ball-query row is its distinct hits in ascending order, then copies of the first one:
+  // slot < cnt is the slot-th hit, cnt <= slot < len a copy of the first (= what idx holds)
+  cidx[beg + slot] = idx[(size_t)g * S + slot];
+  if ((slot & 7) == 0) {
+    bgrp[(beg + slot) >> 3] = g;
+    bw[(beg + slot) >> 3] = slot == 0 ? (float)(1 + S - len) : 1.f;
+  }
+}
+
+// X0 of the compact rows (as sa_gather_kernel, one group per bgrp entry)
+__global__ __launch_bounds__(256) void sac_gather_kernel(
+    int N, int M, int C, int ldx, int use_xyz, float inv_radius, const float *__restrict__ xyz,
+    const float *__restrict__ new_xyz, const float *__restrict__ feats_cl,
+    const int *__restrict__ cidx, const int *__restrict__ bgrp, const int *__restrict__ dims,
+    float *__restrict__ X) {
+  const int rows = dims[0];
+  const int tpr = min(64, ldx);
+  const int rows_per_block = 256 / tpr;
+  const int lr = threadIdx.x / tpr, lc = threadIdx.x % tpr;
+  if (lr >= rows_per_block) return;
+  const int xoff = use_xyz ? 3 : 0;
+  for (int r = blockIdx.x * rows_per_block + lr; r < rows; r += gridDim.x * rows_per_block) {
+    const int g = bgrp[r >> 3];
+    const int bi = g / M;
+    const int ii = cidx[r];
+    float *out = X + (size_t)r * ldx;
+    const float *f = feats_cl ? feats_cl + ((size_t)bi * N + ii) * C : nullptr;
+    for (int c = lc; c < ldx; c += tpr) {
+      float v = 0.f;
+      if (c < xoff) {
+        v = (xyz[((size_t)bi * N + ii) * 3 + c] - new_xyz[(size_t)g * 3 + c]) * inv_radius;
+      } else if (c - xoff < C) {
+        v = f[c - xoff];
+      }
+      out[c] = v;
+    }
+  }
+}
+
+// Max-pool of the compact rows from the per-BLOCK extrema the last GEMM's epilogue emits
+// (gemm_nt_kernel PS = 8): group g = blocks goff[g]/8 .. goff[g+1]/8.  out = relu(a*ext + b),
+// first occurrence wins (blocks ascending, strict >); arg = row within the group.
+__global__ __launch_bounds__(256) void sac_pool_kernel(
+    int M, int C, long long groups, const float *__restrict__ gext,
+    const unsigned char *__restrict__ aext, const int *__restrict__ goff,
+    const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
+    float *__restrict__ out_cl, unsigned char *__restrict__ arg) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= groups * C) return;
+  const long long g = t / C;
+  const int c = (int)(t - g * C);
+  const int b0 = goff[g] >> 3, b1 = goff[g + 1] >> 3;
+  const float a = scale[c], b = shift[c];
+  float best = -1.f;
+  int ba = 0;
+  for (int blk = b0; blk < b1; ++blk) {
+    const float v = fmaxf(fmaf(a, gext[(size_t)blk * C + c], b), 0.f);
+    if (v > best) {
+      best = v;
+      ba = ((blk - b0) << 3) + aext[(size_t)blk * C + c];
+    }
+  }
+  const long long bi = g / M;
+  const int m = (int)(g - bi * M);
+  out[((size_t)bi * C + c) * M + m] = best;
+  if (out_cl) out_cl[t] = best;
+  arg[t] = best > 0.f ? (unsigned char)ba : (unsigned char)0;
+}
+
+// Inverted neighbour lists of the compact rows of ONE batch element per workgroup (as
+// csr_small_kernel; rows goff[b*M] .. goff[(b+1)*M) of batch element b, N <= kCsrSmallN bins).
+__global__ __launch_bounds__(1024) void sac_csr_kernel(int M, int N, const int *__restrict__ cidx,
+                                                       const int *__restrict__ goff,
+                                                       int *__restrict__ off,
+                                                       int *__restrict__ refs) {
+  __shared__ int cnt[kCsrSmallN];
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = goff[(size_t)bi * M], r1 = goff[(size_t)(bi + 1) * M];
+  off += (size_t)bi * (N + 1);
+  for (int i = tid; i < N; i += 1024) cnt[i] = 0;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int r = r0 + tid; r < r1; r += 1024) atomicAdd(&cnt[cidx[r]], 1);
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + tid;
+    const int v = i < N ? cnt[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int pre = carry_s;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    const int excl = pre + incl - v;
+    if (i < N) {
+      cnt[i] = excl;
+      off[i] = r0 + excl;   // refs is indexed by global compact row position
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = excl + v;
+    __syncthreads();
+  }
+  if (tid == 0) off[N] = r0 + carry_s;
+  for (int r = r0 + tid; r < r1; r += 1024) {
+    const int pos = atomicAdd(&cnt[cidx[r]], 1);
+    refs[r0 + pos] = r;      // global compact row
+  }
+}
+
+// One wave per point: dfeat_cl[b][n][c] = sum over refs of dX0[row][xoff + c] (rows global)
+__global__ __launch_bounds__(256) void sac_reduce_kernel(int N, int C, int ldx, int xoff,
+                                                         const float *__restrict__ dX,
+                                                         const int *__restrict__ off,
+                                                         const int *__restrict__ refs,
+                                                         float *__restrict__ dfeat_cl) {
+  const int bi = blockIdx.y;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const int beg = off[(size_t)bi * (N + 1) + n], end = off[(size_t)bi * (N + 1) + n + 1];
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = beg; i < end; ++i) {
+      const float *r0 = dX + (size_t)refs[i] * ldx + xoff;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + q * 64 + lane;
+        if (c < C) acc[q] += r0[c];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + q * 64 + lane;
+      if (c < C) dfeat_cl[((size_t)bi * N + n) * C + c] = acc[q];
+    }
+  }
+}
+
+// The compact description bound on this host thread (btr_sac_bind); read by the launchers.
+struct HostCompact {
+  Compact dev;
+  double count = 0.0;  // number of rows of the DENSE evaluation (BatchNorm's N)
+  bool on = false;
+};
+inline HostCompact &host_compact() {
+  static thread_local HostCompact hc;
+  return hc;
+}
+inline Compact cur_compact() { return host_compact().on ? host_compact().dev : Compact{}; }
+
 }  // namespace btr
 
 using namespace btr;
@@ -1259,7 +1594,7 @@ int btr_sa_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, kBM), 51
 // Whether the last layer's GEMM can emit the per-group extrema itself (pooling epilogue):
 // 128-column tiles (n > 64) and whole groups of 16 / 32 / 64 rows per wave.
 int btr_sa_gemm_nt_poolfwd_supported(int rows, int n, int s) {
-  return n > 64 && (s == 16 || s == 32 || s == 64) && rows > 0 && rows % s == 0;
+  return n > 64 && (s == 8 || s == 16 || s == 32 || s == 64) && rows > 0 && rows % s == 0;
 }
 
 // C[rows][n] = f(A)[rows][k] . W[n][k]^T;  pa/pb != NULL: f = relu(pa*y+pb) per k;
@@ -1277,7 +1612,9 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
 #define BTR_GEMM(BN, P, S)                                                                   \
   hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S>), dim3(gx, cdiv(n, BN)), dim3(256), 0, s, a,  \
                      lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,                             \
-                     (const unsigned char *)nullptr, (const float *)nullptr, 0)
+                     (const unsigned char *)nullptr, (const float *)nullptr, 0,                 \
+                     (const float *)nullptr, (float *)nullptr, (unsigned char *)nullptr,        \
+                     cur_compact())
   if (n <= 64) {
     if (pro) { if (st) BTR_GEMM(64, 1, true); else BTR_GEMM(64, 1, false); }
     else     { if (st) BTR_GEMM(64, 0, true); else BTR_GEMM(64, 0, false); }
@@ -1317,8 +1654,9 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
   hipLaunchKernelGGL((gemm_nt_kernel<128, 1, true, PS>), dim3(gx, cdiv(n, 128)), dim3(256), 0,  \
                      st, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,                      \
                      (const unsigned char *)nullptr, (const float *)nullptr, 0, gamma, gext,    \
-                     aext)
-  if (s == 16) BTR_GEMM(16);
+                     aext, cur_compact())
+  if (s == 8) BTR_GEMM(8);
+  else if (s == 16) BTR_GEMM(16);
   else if (s == 32) BTR_GEMM(32);
   else BTR_GEMM(64);
 #undef BTR_GEMM
@@ -1386,7 +1724,8 @@ int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, co
   const long long tiles = (long long)b * cdiv(m, 64);
   if (shift != nullptr && tiles <= 1024 && c % 4 == 0 && b < 65536) {
     hipLaunchKernelGGL(sa_pool_bwd_tile_kernel, dim3(cdiv(m, 64), cdiv(c, 16), b), dim3(256), 0,
-                       st, m, s, c, ldy, y, dout, out, arg, mean, invstd, scale, shift, part, dcl);
+                       st, m, s, c, ldy, y, dout, out, arg, mean, invstd, scale, shift, part, dcl,
+                       cur_compact().goff);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c,
                        (int)tiles, (double)groups * s, part, m1, m2, dgamma, dbeta);
     hipLaunchKernelGGL(sa_pool_ab_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, c, scale, mean,
@@ -1412,18 +1751,21 @@ int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const f
   BTR_REQUIRE(y && w && c && arg && dcl && alpha && beta && s > 0 && k > 0 && k % 4 == 0 &&
                   ldy % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt_pool: bad arguments (k=%d ldy=%d ldw=%d s=%d)", k, ldy, ldw, s);
-  BTR_REQUIRE(s == 16 || s == 32 || s == 64 || s == 128,
+  BTR_REQUIRE(host_compact().on || s == 16 || s == 32 || s == 64 || s == 128,
               "sa_gemm_nt_pool: nsample %d must be 16, 32, 64 or 128", s);
   const int ssh = ilog2(s);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
   if (n <= 64)
     hipLaunchKernelGGL((gemm_nt_kernel<64, 2, false>), dim3(gx, cdiv(n, 64)), dim3(256), 0, st, y,
-                       ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl, ssh);
+                       ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl, ssh,
+                       (const float *)nullptr, (float *)nullptr, (unsigned char *)nullptr,
+                       cur_compact());
   else
     hipLaunchKernelGGL((gemm_nt_kernel<128, 2, false>), dim3(gx, cdiv(n, 128)), dim3(256), 0, st,
                        y, ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl,
-                       ssh);
+                       ssh, (const float *)nullptr, (float *)nullptr, (unsigned char *)nullptr,
+                       cur_compact());
   return check_launch("sa_gemm_nt_pool");
 }
 
@@ -1451,7 +1793,8 @@ int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, 
 #define BTR_NTRC(BN, S)                                                                       \
   hipLaunchKernelGGL((gemm_nt_kernel<BN, 3, S>), dim3(gx, cdiv(n, BN)), dim3(256), 0, st, x0, \
                      4, w, ldw, c, ldc, rows, n, k, pa, pb, part,                              \
-                     (const unsigned char *)nullptr, w0, 0)
+                     (const unsigned char *)nullptr, w0, 0, (const float *)nullptr,           \
+                     (float *)nullptr, (unsigned char *)nullptr, cur_compact())
   if (n <= 64) { if (part) BTR_NTRC(64, true); else BTR_NTRC(64, false); }
   else         { if (part) BTR_NTRC(128, true); else BTR_NTRC(128, false); }
 #undef BTR_NTRC
@@ -1474,12 +1817,12 @@ int btr_sa_gemm_tn_rc(int rows, int n, int k, const float *g, int ldg, const flo
     hipLaunchKernelGGL((gemm_tn_kernel<4, true, false, true>), grid, dim3(256), 0, st, g, ldg, x0,
                        4, rows, n, k, pa, pb, rpc, pw, (const unsigned char *)nullptr,
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
-                       w0);
+                       w0, cur_compact());
   else
     hipLaunchKernelGGL((gemm_tn_kernel<2, true, false, true>), grid, dim3(256), 0, st, g, ldg, x0,
                        4, rows, n, k, pa, pb, rpc, pw, (const unsigned char *)nullptr,
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
-                       w0);
+                       w0, cur_compact());
   if (n * k <= 1024 && chunks >= 64)
     hipLaunchKernelGGL((reduce_chunks_kernel<4, 64>), dim3(cdiv(n * k, 4)), dim3(256), 0, st,
                        n * k, chunks, pw, dw);
@@ -1507,12 +1850,13 @@ int btr_sa_bn_relu_bwd_rc(long long rows, int c, int ldg, const float *g, const 
               "sa_bn_relu_bwd_rc: %d channels must be a multiple of 4 and <= %d", c, kBnBwdMaxC);
   hipStream_t st = as_stream(stream);
   const int nblk = btr_sa_rc_wgrad_blocks(rows, c);
+  const double count = host_compact().on ? host_compact().count : (double)rows;
   hipLaunchKernelGGL(bn_relu_bwd_stats_rc_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ldg, g,
-                     x0, w0, scale, shift, mean, invstd, part);
+                     x0, w0, scale, shift, mean, invstd, part, cur_compact());
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c, nblk,
-                     (double)rows, part, m1, m2, dgamma, dbeta);
+                     count, part, m1, m2, dgamma, dbeta);
   hipLaunchKernelGGL(bn_relu_bwd_wgrad0_rc_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ldg, g,
-                     x0, w0, scale, shift, mean, invstd, m1, m2, pw);
+                     x0, w0, scale, shift, mean, invstd, m1, m2, pw, cur_compact());
   hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(c * 4, 16)), dim3(256), 0, st,
                      c * 4, nblk, pw, dw0);
   return check_launch("sa_bn_relu_bwd_rc");
@@ -1529,13 +1873,14 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
               "sa_bn_relu_bwd: %d channels must be a multiple of 4 and <= %d", c, kBnBwdMaxC);
   hipStream_t st = as_stream(stream);
   const int nblk = (int)std::min<long long>(cdiv(rows, 256 / (c / 4)), 512);
+  const double count = host_compact().on ? host_compact().count : (double)rows;
   hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ld, g, y,
-                     scale, shift, mean, invstd, part);
+                     scale, shift, mean, invstd, part, cur_compact());
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c, nblk,
-                     (double)rows, part, m1, m2, dgamma, dbeta);
+                     count, part, m1, m2, dgamma, dbeta);
   const int gx = (int)std::min<long long>(cdiv(rows * (c / 4), 256), 256 * 16);
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx), dim3(256), 0, st, rows, c, ld, g, y,
-                     scale, shift, mean, invstd, m1, m2);
+                     scale, shift, mean, invstd, m1, m2, cur_compact());
   return check_launch("sa_bn_relu_bwd");
 }
 
@@ -1553,7 +1898,9 @@ int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float 
   const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
 #define BTR_TN(W, P)                                                                          \
   hipLaunchKernelGGL((gemm_tn_kernel<W, P>), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n, \
-                     k, pa, pb, rpc, pw)
+                     k, pa, pb, rpc, pw, (const unsigned char *)nullptr, (const float *)nullptr, \
+                     (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr, \
+                     cur_compact())
   if (tn == 128) {
     if (pa) BTR_TN(4, true); else BTR_TN(4, false);
   } else {
@@ -1579,7 +1926,7 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
   BTR_REQUIRE(y && x && pw && dw && arg && dcl && alpha && beta && s > 0 && ldy % 4 == 0 &&
                   ldx % 4 == 0 && n % 4 == 0 && k % 4 == 0,
               "sa_gemm_tn_pool: sizes must be multiples of 4 (n=%d k=%d)", n, k);
-  BTR_REQUIRE(s == 16 || s == 32 || s == 64 || s == 128,
+  BTR_REQUIRE(host_compact().on || s == 16 || s == 32 || s == 64 || s == 128,
               "sa_gemm_tn_pool: nsample %d must be 16, 32, 64 or 128", s);
   const int ssh = ilog2(s);
   hipStream_t st = as_stream(stream);
@@ -1589,7 +1936,8 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
   const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
 #define BTR_TNP(W, P)                                                                         \
   hipLaunchKernelGGL((gemm_tn_kernel<W, P, true>), grid, dim3(256), 0, st, y, ldy, x, ldx,    \
-                     rows, n, k, pa, pb, rpc, pw, arg, dcl, alpha, beta, ssh)
+                     rows, n, k, pa, pb, rpc, pw, arg, dcl, alpha, beta, ssh,                 \
+                     (const float *)nullptr, cur_compact())
   if (tn == 128) {
     if (pa) BTR_TNP(4, true); else BTR_TNP(4, false);
   } else {
@@ -1649,6 +1997,87 @@ int btr_sa_scatter(int b, int n, int m, int s, int c, int ldx, int use_xyz, floa
                        s, ldx, inv, dx0, dnew_xyz);
   }
   return check_launch("sa_scatter");
+}
+
+// ------------------------------------------------------------------ compact rows (see above)
+void btr_sac_bind(const btr_compact_t *cm) {
+  HostCompact &hc = host_compact();
+  hc.on = cm != nullptr;
+  if (cm) {
+    hc.dev.dims = cm->dims;
+    hc.dev.bw = cm->bw;
+    hc.dev.bgrp = cm->bgrp;
+    hc.dev.goff = cm->goff;
+    hc.count = cm->dense_rows;
+  }
+}
+
+int btr_sac_plan(int groups, int s, const int *idx, int *len_tmp, int *goff, int *dims,
+                 int *cidx, int *bgrp, float *bw, btr_stream_t stream) {
+  if (groups <= 0 || s <= 0) return BTR_OK;
+  BTR_REQUIRE(idx && len_tmp && goff && dims && cidx && bgrp && bw && s % 8 == 0,
+              "sac_plan: null pointer or nsample %d not a multiple of 8", s);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(sac_count_kernel, dim3(cdiv(groups, 256)), dim3(256), 0, st, groups, s, idx,
+                     len_tmp);
+  hipLaunchKernelGGL(sac_scan_kernel, dim3(1), dim3(1024), 0, st, groups, len_tmp, goff, dims);
+  hipLaunchKernelGGL(sac_fill_kernel, dim3(cdiv((long long)groups * s, 256)), dim3(256), 0, st,
+                     groups, s, idx, goff, cidx, bgrp, bw);
+  return check_launch("sac_plan");
+}
+
+int btr_sac_gather(int b, int n, int m, int max_rows, int c, int ldx, int use_xyz,
+                   float radius_div, const float *xyz, const float *new_xyz,
+                   const float *feats_cl, const int *cidx, const int *bgrp, const int *dims,
+                   float *x0, btr_stream_t stream) {
+  if (b <= 0 || m <= 0 || max_rows <= 0) return BTR_OK;
+  BTR_REQUIRE(xyz && new_xyz && cidx && bgrp && dims && x0 &&
+                  ldx >= (use_xyz ? 3 : 0) + c && ldx % 4 == 0,
+              "sac_gather: bad arguments (ldx=%d, c=%d)", ldx, c);
+  BTR_REQUIRE(c == 0 || feats_cl, "sac_gather: features missing");
+  const int tpr = std::min(64, ldx);
+  const int rpb = 256 / tpr;
+  const int gx = (int)std::min<long long>(cdiv(max_rows, rpb), 8192);
+  const float inv = radius_div != 0.f ? 1.0f / radius_div : 1.0f;
+  hipLaunchKernelGGL(sac_gather_kernel, dim3(gx), dim3(256), 0, as_stream(stream), n, m, c, ldx,
+                     use_xyz, inv, xyz, new_xyz, feats_cl, cidx, bgrp, dims, x0);
+  return check_launch("sac_gather");
+}
+
+int btr_sac_pool(int b, int m, int c, const float *gext, const unsigned char *aext,
+                 const int *goff, const float *scale, const float *shift, float *out,
+                 float *out_cl, unsigned char *arg, btr_stream_t stream) {
+  const long long groups = (long long)b * m;
+  if (groups <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(gext && aext && goff && scale && shift && out && arg, "sac_pool: null pointer");
+  hipLaunchKernelGGL(sac_pool_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
+                     as_stream(stream), m, c, groups, gext, aext, goff, scale, shift, out, out_cl,
+                     arg);
+  return check_launch("sac_pool");
+}
+
+size_t btr_sac_scatter_workspace_bytes(int b, int n, int max_rows) {
+  if (b <= 0) return 0;
+  return sizeof(int) * ((size_t)b * (n + 1) + (size_t)max_rows);
+}
+
+// dfeat_cl[b][n][c] = sum over the compact rows that reference point n of dx0[row][xoff + c]
+// (n <= 8192 points per batch element: the layers behind SA1).
+int btr_sac_scatter(int b, int n, int m, int c, int ldx, int use_xyz, const float *dx0,
+                    const int *cidx, const int *goff, float *dfeat_cl, void *workspace,
+                    size_t workspace_bytes, int max_rows, btr_stream_t stream) {
+  if (b <= 0 || m <= 0 || n <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(dx0 && cidx && goff && dfeat_cl && workspace &&
+                  workspace_bytes >= btr_sac_scatter_workspace_bytes(b, n, max_rows),
+              "sac_scatter: null pointer or workspace too small");
+  BTR_REQUIRE(n <= kCsrSmallN, "sac_scatter: %d points per batch element > %d", n, kCsrSmallN);
+  hipStream_t st = as_stream(stream);
+  int *off = (int *)workspace;
+  int *refs = off + (size_t)b * (n + 1);
+  hipLaunchKernelGGL(sac_csr_kernel, dim3(b), dim3(1024), 0, st, m, n, cidx, goff, off, refs);
+  hipLaunchKernelGGL(sac_reduce_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, st, n, c, ldx,
+                     use_xyz ? 3 : 0, dx0, off, refs, dfeat_cl);
+  return check_launch("sac_scatter");
 }
 
 }  // extern "C"

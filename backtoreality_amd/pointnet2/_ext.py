@@ -73,6 +73,14 @@ _SIGNATURES = {
                                   _vp, _vp, _vp]),
     "btr_sa_gemm_tn_pool": (_ci, [_ci, _ci, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci,
                                   _vp, _vp, _vp, _vp, _vp]),
+    # compact rows of the fused set-abstraction path (used by fused_sa.py)
+    "btr_sac_bind": (None, [_vp]),
+    "btr_sac_plan": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "btr_sac_gather": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _cf] + [_vp] * 8),
+    "btr_sac_pool": (_ci, [_ci, _ci, _ci] + [_vp] * 9),
+    "btr_sac_scatter_workspace_bytes": (_sz, [_ci, _ci, _ci]),
+    "btr_sac_scatter": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _ci,
+                              _vp]),
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
@@ -127,6 +135,31 @@ def set_fmad(mode):
     mode = int(mode)
     _idx = _lib if mode == 1 else _load(mode)
     _FMAD = mode
+
+
+class CompactRows(ctypes.Structure):
+    """btr_compact_t of include/btr_pointnet2.h: device pointers describing the compact rows of
+    one set-abstraction call; keeps the tensors alive while bound."""
+    _fields_ = [("dims", _vp), ("bw", _vp), ("bgrp", _vp), ("goff", _vp),
+                ("dense_rows", ctypes.c_double)]
+
+
+class compact_bound(object):
+    """`with compact_bound(cm):` -- the btr_sa_* calls inside operate on compact rows
+    (btr_sac_bind is per host thread; autograd's backward thread binds its own)."""
+
+    def __init__(self, cm):
+        self.cm = cm
+
+    def __enter__(self):
+        if self.cm is not None:
+            _lib.btr_sac_bind(ctypes.addressof(self.cm))
+        return self.cm
+
+    def __exit__(self, *exc):
+        if self.cm is not None:
+            _lib.btr_sac_bind(None)
+        return False
 
 
 # ------------------------------------------------------------------------------------ checks

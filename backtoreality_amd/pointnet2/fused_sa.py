@@ -63,16 +63,46 @@ class FusedSAFunction(Function):
             if feats_cl is None or feats_cl.shape != (B, N, C):
                 feats_cl = features.transpose(1, 2).contiguous()
 
+        # Compact rows (csrc/sa_mlp.hip "compact rows"): layers whose groups are mostly padding
+        # (nsample >= 32: SA1 keeps 67 %, SA2 43 % of its rows at the benchmark shape) are
+        # evaluated on the distinct neighbours only.  Needs the pooling epilogue and the
+        # prologue form of the pooled gradient, and no coordinate gradients (only the vote
+        # aggregation, nsample = 16, asks for those).
+        L_ = len(params) // 3
+        compact = (_compact_enabled() and S >= 32 and S % 8 == 0 and L_ >= 2 and
+                   params[3 * (L_ - 1)].shape[0] > 64 and _pool_in_epilogue() and
+                   _pool_grad_in_prologue(S) and not ctx.needs_input_grad[0] and
+                   not ctx.needs_input_grad[1] and
+                   (not ctx.needs_input_grad[2] or N <= 8192) and
+                   B * ((M + 63) // 64) <= 1024)   # the tile form of btr_sa_pool_bwd_coef
+        _lib.btr_sac_bind(None)   # (a failed call must not leave this thread bound)
+        cm = cplan = None
         with _on(xyz) as d:
             st = _stream(d)
             X0 = _f32((R, K0p), dev)
-            _call(_lib.btr_sa_gather, B, N, M, S, C, K0p, use_xyz, rdiv, _p(xyz), _p(new_xyz),
-                  _p(feats_cl), _p(idx), _p(X0), st)
+            if compact:
+                groups = B * M
+                i32 = dict(dtype=torch.int32, device=dev)
+                cplan = dict(goff=torch.empty(groups + 1, **i32), dims=torch.empty(2, **i32),
+                             cidx=torch.empty(R, **i32), bgrp=torch.empty(R // 8, **i32),
+                             bw=_f32((R // 8,), dev))
+                len_tmp = torch.empty(groups, **i32)
+                _call(_lib.btr_sac_plan, groups, S, _p(idx), _p(len_tmp), _p(cplan["goff"]),
+                      _p(cplan["dims"]), _p(cplan["cidx"]), _p(cplan["bgrp"]), _p(cplan["bw"]), st)
+                cm = _make_cm(cplan, R)
+                _call(_lib.btr_sac_gather, B, N, M, R, C, K0p, use_xyz, rdiv, _p(xyz),
+                      _p(new_xyz), _p(feats_cl), _p(cplan["cidx"]), _p(cplan["bgrp"]),
+                      _p(cplan["dims"]), _p(X0), st)
+            else:
+                _call(_lib.btr_sa_gather, B, N, M, S, C, K0p, use_xyz, rdiv, _p(xyz),
+                      _p(new_xyz), _p(feats_cl), _p(idx), _p(X0), st)
             grid = _lib.btr_sa_gemm_grid(R)
             ext = None
             Ys, stats, Ws, counters = [], [], [], []
             A, lda, K = X0, K0p, K0p
             pa = pb = None
+            bound = _ext.compact_bound(cm)
+            bound.__enter__()
             # First-layer recompute (SA1: 4 input columns, nobody needs the input gradient):
             # the first pre-BN output is never stored; its consumers rebuild it from X0.
             rc = (K0p == 4 and L >= 3 and not any(ctx.needs_input_grad[0:3]) and
@@ -96,14 +126,15 @@ class FusedSAFunction(Function):
                     _call(_lib.btr_sa_gemm_nt_rc, R, Nl, K, _p(X0), _p(Ws[0]), _p(W2), K, _p(Y),
                           Nl, _p(pa), _p(pb), _p(part), st, key=(R, Nl, K))
                 elif (l == L - 1 and pa is not None and _pool_in_epilogue() and
-                      _lib.btr_sa_gemm_nt_poolfwd_supported(R, Nl, S)):
-                    # last layer: the GEMM epilogue also emits the per-group extrema, so the
-                    # max-pool below does not read Y again
+                      _lib.btr_sa_gemm_nt_poolfwd_supported(R, Nl, 8 if compact else S)):
+                    # last layer: the GEMM epilogue also emits the per-group extrema (compact
+                    # rows: per 8-row block), so the max-pool below does not read Y again
+                    PSz = 8 if compact else S
                     Y = _f32((R, Nl), dev)
-                    ext = (_f32((R // S, Nl), dev),
-                           torch.empty((R // S, Nl), dtype=torch.uint8, device=dev))
+                    ext = (_f32((R // PSz, Nl), dev),
+                           torch.empty((R // PSz, Nl), dtype=torch.uint8, device=dev))
                     _call(_lib.btr_sa_gemm_nt_poolfwd, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl,
-                          _p(pa), _p(pb), _p(part), S, _p(gamma), _p(ext[0]), _p(ext[1]), st,
+                          _p(pa), _p(pb), _p(part), PSz, _p(gamma), _p(ext[0]), _p(ext[1]), st,
                           key=(R, Nl, K))
                 else:
                     Y = _f32((R, Nl), dev)
@@ -127,11 +158,16 @@ class FusedSAFunction(Function):
                 stats.append((scale, shift, mean, invstd))
                 A, lda, K = Y, Nl, Nl
                 pa, pb = scale, shift
+            bound.__exit__()
             CL = Ys[-1].shape[1]
             out = _f32((B, CL, M), dev)
             out_cl = _f32((B, M, CL), dev)
             arg = torch.empty((B * M, CL), dtype=torch.uint8, device=dev)
-            if ext is not None:
+            if compact:
+                assert ext is not None
+                _call(_lib.btr_sac_pool, B, M, CL, _p(ext[0]), _p(ext[1]), _p(cplan["goff"]),
+                      _p(stats[-1][0]), _p(stats[-1][1]), _p(out), _p(out_cl), _p(arg), st)
+            elif ext is not None:
                 _call(_lib.btr_sa_pool_fin, B, M, CL, _p(ext[0]), _p(ext[1]), _p(stats[-1][0]),
                       _p(stats[-1][1]), _p(out), _p(out_cl), _p(arg), st)
             else:
@@ -143,11 +179,13 @@ class FusedSAFunction(Function):
         out._btr_channel_last = out_cl  # lets the next fused layer skip a transpose
         ctx.dims = (B, N, M, S, C, use_xyz, rdiv, K0, K0p, L)
         ctx.rc = rc
+        ctx.compact = compact
         ctx.pshapes = [p.shape for p in params]
         # save_for_backward (not attributes): saving the OUTPUT through an attribute would
         # create a ctx <-> out reference cycle that only the cyclic GC frees (GBs per step)
         flat_stats = [t for st4 in stats for t in st4]
-        ctx.save_for_backward(idx, X0, arg, out, *Ys, *Ws, *flat_stats)
+        cp = [cplan[k] for k in ("goff", "dims", "cidx", "bgrp", "bw")] if compact else []
+        ctx.save_for_backward(idx, X0, arg, out, *Ys, *Ws, *flat_stats, *cp)
         return out
 
     @staticmethod
@@ -160,6 +198,9 @@ class FusedSAFunction(Function):
         Ws = list(saved[4 + L:4 + 2 * L])
         flat = saved[4 + 2 * L:]
         stats = [tuple(flat[4 * l:4 * l + 4]) for l in range(L)]
+        cm = cplan = None
+        if ctx.compact:
+            cplan = dict(zip(("goff", "dims", "cidx", "bgrp", "bw"), flat[4 * L:4 * L + 5]))
         dev = dout.device
         R = B * M * S
         dout = dout.contiguous()
@@ -167,7 +208,10 @@ class FusedSAFunction(Function):
         grads = [None] * (3 * L)
         dxyz = dnew = dfeat = None
 
-        with _on(dout) as d:
+        _lib.btr_sac_bind(None)
+        if cplan is not None:
+            cm = _make_cm(cplan, R)
+        with _on(dout) as d, _ext.compact_bound(cm):
             st = _stream(d)
             # ---- last layer: max-pool + ReLU + BN backward.  Default: only the statistics
             # and the per-group coefficients are computed; the dense dY of the pooled layer
@@ -259,10 +303,18 @@ class FusedSAFunction(Function):
                             dxyz = _f32((B, N, 3), dev)
                         if need_new and use_xyz:
                             dnew = _f32((B, M, 3), dev)
-                        wsb = _lib.btr_sa_scatter_workspace_bytes(B, N, M, S)
-                        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-                        _call(_lib.btr_sa_scatter, B, N, M, S, C, K0p, use_xyz, rdiv, _p(G),
-                              _p(idx), _p(dfeat_cl), _p(dxyz), _p(dnew), _p(ws), wsb, st)
+                        if cplan is not None:   # compact rows: feature gradient only
+                            wsb = _lib.btr_sac_scatter_workspace_bytes(B, N, R)
+                            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+                            if dfeat_cl is not None:
+                                _call(_lib.btr_sac_scatter, B, N, M, C, K0p, use_xyz, _p(G),
+                                      _p(cplan["cidx"]), _p(cplan["goff"]), _p(dfeat_cl), _p(ws),
+                                      wsb, R, st)
+                        else:
+                            wsb = _lib.btr_sa_scatter_workspace_bytes(B, N, M, S)
+                            ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+                            _call(_lib.btr_sa_scatter, B, N, M, S, C, K0p, use_xyz, rdiv, _p(G),
+                                  _p(idx), _p(dfeat_cl), _p(dxyz), _p(dnew), _p(ws), wsb, st)
                         if dfeat_cl is not None:
                             dfeat = dfeat_cl.transpose(1, 2).contiguous()
         return (dxyz, dnew, dfeat, None, None) + tuple(grads)
@@ -321,6 +373,18 @@ def fused_eval_forward(module, xyz, new_xyz, features, idx):
               _p(out), _p(out_cl), _p(arg), st)
     out._btr_channel_last = out_cl
     return out
+
+
+def _compact_enabled():
+    """BTR_SA_COMPACT=0: evaluate every layer on all nsample rows per group (dense rows)."""
+    return os.environ.get("BTR_SA_COMPACT", "1") != "0"
+
+
+def _make_cm(cplan, dense_rows):
+    cm = _ext.CompactRows(_p(cplan["dims"]), _p(cplan["bw"]), _p(cplan["bgrp"]), _p(cplan["goff"]),
+                          float(dense_rows))
+    cm._keep = cplan   # the tensors stay alive as long as the description does
+    return cm
 
 
 def _pool_in_epilogue():

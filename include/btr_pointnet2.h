@@ -347,6 +347,41 @@ int btr_points_in_boxes(int b, int n, int k, int point_stride, int cap, const fl
 int btr_box3d_iou(int nscene, int p, int g, const double *corners1, const double *corners2,
                   double *iou, btr_stream_t stream);
 
+/* ---- compact rows of the fused set-abstraction path ------------------------------------------
+ * The reference runs its shared MLP over ALL nsample rows of every group although a ball-query
+ * row is its distinct hits followed by copies of the first one (ball_query_gpu.cu:39-43;
+ * grouping: pointnet2_utils.py:346-357; MLP: pointnet2_modules.py:243-252).  A copy computes
+ * what its original computes, so the btr_sa_* kernels can evaluate the layer on the distinct
+ * rows only -- every group keeps ceil8(#distinct) rows, its first row carries the weight of
+ * the copies it stands for in the BatchNorm statistics (sa_mlp.hip, "compact rows").
+ * btr_sac_plan builds the description on the device (the row count is data dependent and
+ * never read by the host); btr_sac_bind(&cm) makes every following btr_sa_gemm_* /
+ * btr_sa_bn_relu_bwd* / btr_sa_pool_bwd_coef call ON THIS HOST THREAD operate on compact rows
+ * (their `rows` argument then only sizes grids: pass the dense row count), btr_sac_bind(NULL)
+ * ends it.  max_rows = groups * nsample (dense worst case) sizes every buffer. */
+typedef struct btr_compact {
+  const int *dims;     /* [2] device: rows, rows / 8                                         */
+  const float *bw;     /* [max_rows / 8] device: weight of each 8-row block's first row      */
+  const int *bgrp;     /* [max_rows / 8] device: group of each block                         */
+  const int *goff;     /* [groups + 1] device: first row of each group                       */
+  double dense_rows;   /* groups * nsample: BatchNorm's element count                        */
+} btr_compact_t;
+void btr_sac_bind(const btr_compact_t *cm);
+int btr_sac_plan(int groups, int s, const int *idx, int *len_tmp /*[groups]*/, int *goff,
+                 int *dims, int *cidx /*[max_rows]*/, int *bgrp, float *bw, btr_stream_t stream);
+int btr_sac_gather(int b, int n, int m, int max_rows, int c, int ldx, int use_xyz,
+                   float radius_div, const float *xyz, const float *new_xyz,
+                   const float *feats_cl, const int *cidx, const int *bgrp, const int *dims,
+                   float *x0, btr_stream_t stream);
+/* max-pool from the per-8-row-block extrema of btr_sa_gemm_nt_poolfwd(..., s = 8, ...) */
+int btr_sac_pool(int b, int m, int c, const float *gext, const unsigned char *aext,
+                 const int *goff, const float *scale, const float *shift, float *out,
+                 float *out_cl, unsigned char *arg, btr_stream_t stream);
+size_t btr_sac_scatter_workspace_bytes(int b, int n, int max_rows);
+int btr_sac_scatter(int b, int n, int m, int c, int ldx, int use_xyz, const float *dx0,
+                    const int *cidx, const int *goff, float *dfeat_cl, void *workspace,
+                    size_t workspace_bytes, int max_rows, btr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -172,6 +172,7 @@ def test_pooling_epilogue_equals_the_pool_pass(cuda, monkeypatch, S):
     give the same pooled features and gradients as the separate pool pass over the whole
     pre-BN tensor -- including channels with a NEGATIVE BatchNorm weight (minimum tracked) and
     balls padded with repeated points (ties)."""
+    monkeypatch.setenv("BTR_SA_COMPACT", "0")   # like with like: dense rows on both sides
     from backtoreality_amd.pointnet2 import pointnet2_modules as M
     g = torch.Generator().manual_seed(S)
     xyz = torch.rand(2, 1500, 3, generator=g).to(cuda)
@@ -195,3 +196,47 @@ def test_pooling_epilogue_equals_the_pool_pass(cuda, monkeypatch, S):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()) + 1e-12), \
             float((a - b).abs().max())
     assert torch.equal(outs["1"][0], outs["0"][0])      # the pooled values are bit-identical
+
+
+@pytest.mark.parametrize("N,npoint,radius,S,mlp,C,feat_grad", [
+    (4096, 512, 0.2, 64, [1, 64, 64, 128], 1, False),        # SA1: first-layer recompute
+    (2048, 256, 0.4, 32, [128, 128, 128, 256], 128, True),   # SA2: feature gradient (scatter)
+    (4096, 300, 0.12, 64, [3, 32, 128], 3, True),            # mostly empty / tiny balls
+    (2048, 200, 2.0, 32, [4, 16, 128], 4, True),             # every ball full (nothing to drop)
+])
+def test_compact_rows_equal_dense_rows(cuda, monkeypatch, N, npoint, radius, S, mlp, C, feat_grad):
+    """Compact rows (distinct neighbours only, weighted BatchNorm statistics) against the dense
+    evaluation of the same fused kernels (BTR_SA_COMPACT=0): same features, arg-max routing,
+    running statistics and every gradient, with negative BatchNorm scales in the pooled layer."""
+    B = 2
+    xyz = torch.from_numpy(np.stack([synthetic.make_scene(60 + i, N, use_height=False)[
+        'point_clouds'] for i in range(B)], 0)).to(cuda)
+    torch.manual_seed(1)
+    feats = torch.randn(B, C, N, device=cuda)
+    sa = M.PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=S, mlp=list(mlp),
+                                 use_xyz=True, normalize_xyz=True).to(cuda)
+    with torch.no_grad():
+        for layer in sa.mlp_module:
+            layer.bn.bn.weight.uniform_(-1.5, 1.5)
+            layer.bn.bn.bias.uniform_(-0.3, 0.3)
+    from backtoreality_amd.pointnet2 import fused_sa, pointnet2_utils
+    inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("BTR_SA_COMPACT", mode)
+        mod = copy.deepcopy(sa)
+        f = feats.clone().requires_grad_(feat_grad)
+        new_xyz, out, _ = mod(xyz, f, inds)
+        w = torch.linspace(0.5, 1.5, out.numel(), device=cuda).view_as(out)
+        (out * w).sum().backward()
+        res[mode] = {"out": out.detach(), "dfeat": f.grad}
+        for n, p in mod.named_parameters():
+            res[mode]["d" + n] = p.grad
+        for n, b in mod.named_buffers():
+            res[mode][n] = b.detach().clone().float()
+    for k in res["0"]:
+        if res["0"][k] is None:
+            assert res["1"][k] is None, k
+            continue
+        tol = 2e-5 if k == "out" or "running" in k else 2e-4
+        assert _rel(res["1"][k], res["0"][k]) < tol, (k, _rel(res["1"][k], res["0"][k]))
