@@ -39,6 +39,7 @@ struct Compact {
 constexpr int kBM = 128;      // rows per workgroup tile
 constexpr int kBK = 32;       // reduction chunk staged in LDS
 constexpr int kLd = kBK + 4;  // padded LDS row (floats): conflict-free ds_read_b128
+constexpr int kMaxK = 512;    // largest reduction length of a GEMM with a prologue (LDS tables)
 
 // ----------------------------------------------------------------------------- group gather
 // X0[r][c], r = (b*M + m)*S + s:  c < 3: (xyz[b, idx, c] - new_xyz[b, m, c]) * inv_radius
@@ -129,6 +130,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   __shared__ __attribute__((aligned(16))) float As[kBM * kLd];
   __shared__ __attribute__((aligned(16))) float Bs[BN * kLd];
   __shared__ double red[STATS ? 2 * WM * BN : 1];
+  // per-k prologue coefficients (and, PRO == 3, the first layer's weight rows) live in LDS for
+  // the whole kernel: read from global memory inside stage() each of them was a cache round
+  // trip in front of the LDS writes of every chunk
+  __shared__ __attribute__((aligned(16))) float sPa[PRO ? kMaxK : 4], sPb[PRO ? kMaxK : 4];
+  __shared__ __attribute__((aligned(16))) float sW0[PRO == 3 ? kMaxK * 4 : 4];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -164,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   bool sp_on = false;
   // compact rows (cm.bgrp): groups are runs of 8-row blocks, a tile holds 16 blocks -> two
   // block slots per thread; sp_lr = local row of the group's arg-max if it lies in that block
-  int sp_lr[2] = {-1, -1};
+  int sp_g[2] = {0, 0}, sp_ng[2] = {0, 0}, sp_off[2] = {0, 0};
+  unsigned sp_a[2] = {0, 0};
+  bool sp_ok[2] = {false, false};
   float sp_dv[2] = {0.f, 0.f};
   float rwt[kBM / 32];  // PRO == 2: weight of the dense part for the rows this thread stages
   auto fetch = [&](int tile, int kc) {
@@ -181,18 +189,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       }
     }
     if (PRO == 2 && cm.bgrp) {
+      // group of each block slot: fixed per TILE, loaded one tile ahead (with the last chunk of
+      // the previous tile) so that the loads below depend on registers only -- a chain
+      // bgrp -> goff / arg inside this prefetch would stall the wave in front of its MFMAs
       const int k1 = kc * kBK + sp_k;
+      if (kc == 0 && tile != (int)blockIdx.x) {
+        sp_g[0] = sp_ng[0];
+        sp_g[1] = sp_ng[1];
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int slot = sp_gi + 8 * q, blk = (r0 >> 3) + slot;
-        sp_lr[q] = -1;
-        if ((blk << 3) < R && k1 < K) {
-          const int g = cm.bgrp[blk];
-          const int lr = cm.goff[g] + (int)parg[(size_t)g * K + k1] - r0;
-          if (lr >= 0 && (lr >> 3) == slot) {
-            sp_lr[q] = lr;
-            sp_dv[q] = pdcl[(size_t)g * K + k1];
-          }
+        sp_ok[q] = (blk << 3) < R && k1 < K;
+        if (sp_ok[q]) {
+          const int g = sp_g[q];
+          sp_off[q] = cm.goff[g] - r0;
+          sp_a[q] = parg[(size_t)g * K + k1];
+          sp_dv[q] = pdcl[(size_t)g * K + k1];
+        }
+      }
+      if (kc + 1 >= nkc) {  // last chunk of this tile: the next tile's groups
+        const int nr0 = (tile + (int)gridDim.x) * kBM;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int blk = (nr0 >> 3) + sp_gi + 8 * q;
+          sp_ng[q] = (blk << 3) < R ? cm.bgrp[blk] : 0;
         }
       }
     } else if (PRO == 2) {
@@ -216,8 +237,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const int r0 = tile * kBM, kk = kc * kBK + kq;
     float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PRO && kk < K) {  // K is padded to a multiple of 4 by the caller
-      fa = *reinterpret_cast<const float4 *>(pa + kk);
-      fb = *reinterpret_cast<const float4 *>(pb + kk);
+      fa = *reinterpret_cast<const float4 *>(&sPa[kk]);
+      fb = *reinterpret_cast<const float4 *>(&sPb[kk]);
     }
 #pragma unroll
     for (int p = 0; p < kBM / 32; ++p) {
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         v.w = fmaxf(fmaf(fa.w, v.w, fb.w), 0.f);
       }
       if (PRO == 3 && r0 + row < R && kk < K) {  // y0 rebuilt from the 4-column input row
-        const float4 y = rc_y4(v, pdcl, kk);      // (pdcl carries W0 [K][4] in this mode)
+        const float4 y = rc_y4(v, sW0, kk);       // (pdcl carries W0 [K][4] in this mode)
         v.x = fmaxf(fmaf(fa.x, y.x, fb.x), 0.f);
         v.y = fmaxf(fmaf(fa.y, y.y, fb.y), 0.f);
         v.z = fmaxf(fmaf(fa.z, y.z, fb.z), 0.f);
@@ -250,6 +271,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       *reinterpret_cast<float4 *>(&Bs[(srow + 32 * p) * kLd + kq]) = rb[p];
   };
 
+  if (PRO == 2 && cm.bgrp) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int blk = ((int)blockIdx.x * kBM >> 3) + sp_gi + 8 * q;
+      sp_g[q] = (blk << 3) < R ? cm.bgrp[blk] : 0;
+    }
+  }
+  if (PRO) {
+    for (int i = tid; i < K; i += 256) {
+      sPa[i] = pa[i];
+      sPb[i] = pb[i];
+    }
+    if (PRO == 3)
+      for (int i = tid; i < K * 4; i += 256) sW0[i] = pdcl[i];
+    __syncthreads();
+  }
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x, 0);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int r0 = tile * kBM;
@@ -260,14 +297,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    float bwx[MI][4];  // STATS on compact rows: (weight - 1) of the wave's 8-row blocks,
+    if (STATS && cm.bw) {  // fetched here so that the epilogue does not wait for them
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = r0 + wm * (kBM / WM) + i * 32 + 8 * q;
+          bwx[i][q] = row < R ? cm.bw[row >> 3] - 1.f : 0.f;
+        }
+    }
 
     for (int kc = 0; kc < nkc; ++kc) {
       stage(tile, kc);
       __syncthreads();
       if (PRO == 2) {  // sparse part: the arg-max row of every (group, channel) of this tile
         if (cm.bgrp) {
-          if (sp_lr[0] >= 0) As[sp_lr[0] * kLd + sp_k] += sp_dv[0];
-          if (sp_lr[1] >= 0) As[sp_lr[1] * kLd + sp_k] += sp_dv[1];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int lr = sp_off[q] + (int)sp_a[q];  // local row of the group's arg-max
+            if (sp_ok[q] && lr >= 0 && (lr >> 3) == sp_gi + 8 * q) As[lr * kLd + sp_k] += sp_dv[q];
+          }
         } else if (sp_on) {
           As[((sp_gi << SSH) + (int)sp_arg) * kLd + sp_k] += sp_d;
         }
@@ -321,8 +371,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
             s1[j] += c;
             s2[j] = fmaf(c, c, s2[j]);
             // compact rows: the first row of a group stands for 1 + S - len copies of itself
-            if (cm.bw && h == 0 && (v & 3) == 0 && row < R) {
-              const float wx = cm.bw[row >> 3] - 1.f;
+            // (bwx: block weights - 1, loaded at the top of the tile)
+            if (cm.bw && h == 0 && (v & 3) == 0) {
+              const float wx = bwx[i][v >> 2];
               s1[j] = fmaf(wx, c, s1[j]);
               s2[j] = fmaf(wx * c, c, s2[j]);
             }
@@ -962,6 +1013,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
   constexpr int KT = TNW == 4 ? 2 : 1;  // 32-wide k tiles per wave
   __shared__ __attribute__((aligned(16))) float Gs[BR * LG];
   __shared__ __attribute__((aligned(16))) float Xs[BR * LX];
+  __shared__ __attribute__((aligned(16))) float sXw[XRC ? 64 * 4 : 4];  // W0 rows k0 .. k0+63
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = TNW == 4 ? wave : (wave >> 1);
   const int wk = TNW == 4 ? 0 : (wave & 1);
@@ -1000,8 +1052,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
   bool sp_on = false;
   // compact rows: a 32-row step holds 4 blocks of 8 rows; 256 / TN block slots per pass
   constexpr int SPQ = 4 * TN / 256;  // passes over the block slots (2 for TN = 128, 1 for 64)
-  int sp_lr[SPQ];
+  int sp_g[SPQ], sp_ng[SPQ], sp_off[SPQ];
+  unsigned sp_a[SPQ];
+  bool sp_ok[SPQ];
   float sp_dv[SPQ];
+#pragma unroll
+  for (int q = 0; q < SPQ; ++q) {
+    sp_g[q] = sp_ng[q] = sp_off[q] = 0;
+    sp_a[q] = 0u;
+    sp_ok[q] = false;
+    sp_dv[q] = 0.f;
+  }
   float gwt[GPASS];  // weight of the dense part for the rows this thread stages
   auto fetch = [&](int r0) {
 #pragma unroll
@@ -1015,18 +1076,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
       }
     }
     if (GPOOL && cm.bgrp) {
+      // groups of this step's four blocks: loaded one step ahead (see gemm_nt_kernel)
 #pragma unroll
       for (int q = 0; q < SPQ; ++q) {
         const int slot = sp_gi + (256 / TN) * q, blk = (r0 >> 3) + slot;
-        sp_lr[q] = -1;
-        if (slot < 4 && (blk << 3) < rend && n0 + sp_n < N) {
-          const int g = cm.bgrp[blk];
-          const int lr = cm.goff[g] + (int)garg[(size_t)g * N + n0 + sp_n] - r0;
-          if (lr >= 0 && (lr >> 3) == slot) {
-            sp_lr[q] = lr;
-            sp_dv[q] = gdcl[(size_t)g * N + n0 + sp_n];
-          }
+        if (r0 != rbeg) sp_g[q] = sp_ng[q];
+        sp_ok[q] = slot < 4 && (blk << 3) < rend && n0 + sp_n < N;
+        if (sp_ok[q]) {
+          const int g = sp_g[q];
+          sp_off[q] = cm.goff[g] - r0;
+          sp_a[q] = garg[(size_t)g * N + n0 + sp_n];
+          sp_dv[q] = gdcl[(size_t)g * N + n0 + sp_n];
         }
+        const int nblk = ((r0 + BR) >> 3) + slot;
+        sp_ng[q] = (slot < 4 && (nblk << 3) < rend) ? cm.bgrp[nblk] : 0;
       }
     } else if (GPOOL) {
       const int g = (r0 >> SSH) + sp_gi;  // group size S = 1 << SSH
@@ -1048,6 +1111,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
                     : *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + xc4);
     }
   };
+  if (GPOOL && cm.bgrp && rbeg < rend) {
+#pragma unroll
+    for (int q = 0; q < SPQ; ++q) {
+      const int slot = sp_gi + (256 / TN) * q, blk = (rbeg >> 3) + slot;
+      sp_g[q] = (slot < 4 && (blk << 3) < rend) ? cm.bgrp[blk] : 0;
+    }
+  }
+  if (XRC) {  // 64 k rows x 4 input columns of the first layer's weight
+    if (k0 + (tid >> 2) < K) sXw[tid] = xw0[(size_t)k0 * 4 + tid];
+    __syncthreads();
+  }
   if (rbeg < rend) fetch(rbeg);
   for (int r0 = rbeg; r0 < rend; r0 += BR) {
 #pragma unroll
@@ -1066,7 +1140,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     for (int p = 0; p < 2; ++p) {
       const int row = xr + 16 * p;
       float4 x = rx[p];
-      if (XRC && r0 + row < rend && k0 + xc4 < K) x = rc_y4(x, xw0, k0 + xc4);
+      if (XRC && r0 + row < rend && k0 + xc4 < K) x = rc_y4(x, sXw, xc4);
       if (PRO && r0 + row < rend && k0 + xc4 < K) {
         x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
         x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
@@ -1079,8 +1153,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     if (GPOOL) {
       if (cm.bgrp) {
 #pragma unroll
-        for (int q = 0; q < SPQ; ++q)
-          if (sp_lr[q] >= 0) Gs[sp_lr[q] * LG + sp_n] += sp_dv[q];
+        for (int q = 0; q < SPQ; ++q) {
+          const int lr = sp_off[q] + (int)sp_a[q];
+          if (sp_ok[q] && lr >= 0 && (lr >> 3) == sp_gi + (256 / TN) * q)
+            Gs[lr * LG + sp_n] += sp_dv[q];
+        }
       } else if (sp_on) {
         Gs[(int)sp_arg * LG + sp_n] += sp_d;
       }
@@ -1606,6 +1683,7 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
   BTR_REQUIRE(a && w && (c || part) && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt: k=%d lda=%d ldw=%d must be multiples of 4", k, lda, ldw);
   BTR_REQUIRE((pa == nullptr) == (pb == nullptr), "sa_gemm_nt: pa/pb must come together");
+  BTR_REQUIRE(pa == nullptr || k <= kMaxK, "sa_gemm_nt: k=%d > %d with a prologue", k, kMaxK);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t s = as_stream(stream);
   const bool pro = pa != nullptr, st = part != nullptr;
@@ -1646,8 +1724,8 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
                   k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt_poolfwd: null pointer or k=%d lda=%d ldw=%d not multiples of 4", k,
               lda, ldw);
-  BTR_REQUIRE(btr_sa_gemm_nt_poolfwd_supported(rows, n, s),
-              "sa_gemm_nt_poolfwd: n=%d / nsample=%d not supported", n, s);
+  BTR_REQUIRE(btr_sa_gemm_nt_poolfwd_supported(rows, n, s) && k <= kMaxK,
+              "sa_gemm_nt_poolfwd: n=%d / nsample=%d / k=%d not supported", n, s, k);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
 #define BTR_GEMM(PS)                                                                          \
@@ -1753,6 +1831,7 @@ int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const f
               "sa_gemm_nt_pool: bad arguments (k=%d ldy=%d ldw=%d s=%d)", k, ldy, ldw, s);
   BTR_REQUIRE(host_compact().on || s == 16 || s == 32 || s == 64 || s == 128,
               "sa_gemm_nt_pool: nsample %d must be 16, 32, 64 or 128", s);
+  BTR_REQUIRE(k <= kMaxK, "sa_gemm_nt_pool: k=%d > %d", k, kMaxK);
   const int ssh = ilog2(s);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
@@ -1786,7 +1865,8 @@ int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, 
                       int ldw, float *c, int ldc, const float *pa, const float *pb, float *part,
                       btr_stream_t stream) {
   if (rows <= 0 || n <= 0) return BTR_OK;
-  BTR_REQUIRE(x0 && w0 && w && c && pa && pb && k > 0 && k % 4 == 0 && ldw % 4 == 0,
+  BTR_REQUIRE(x0 && w0 && w && c && pa && pb && k > 0 && k % 4 == 0 && ldw % 4 == 0 &&
+                  k <= kMaxK,
               "sa_gemm_nt_rc: null pointer or k=%d ldw=%d not multiples of 4", k, ldw);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
