@@ -225,7 +225,8 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None, crite
     loader with prefetch gives): pass `next_batch` and the sampling pyramid of that batch
     (coordinates only, independent of the weights) is launched on the side stream under this
     step's backward; the returned end_points['next_sampling'] is then passed as `sampling` to
-    the next call.  Results are identical to the unpipelined loop; bench.py does NOT use it.
+    the next call.  Results are identical to the unpipelined loop (bench.py times this loop and
+    reports the strictly sequential one beside it).
 
     `criterion`: `loss_helper.get_loss` (default, train_Votenet_FSB.py) or
     `loss_helper.get_loss_weak` (the weakly supervised baseline, train_Votenet_WSB.py:170)."""
