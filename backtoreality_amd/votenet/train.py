@@ -144,12 +144,14 @@ def _sync_grads(net):
         net.sync_gradients()
 
 
-def make_optimizer(net, lr=1e-3, weight_decay=0.0):
+def make_optimizer(net, lr=1e-3, weight_decay=0.0, capturable=False):
     """Adam, lr 1e-3 (train_Votenet_FSB.py:172).  On the GPU the fused multi-tensor
-    implementation (same update rule, two launches instead of ~10 per step)."""
+    implementation (same update rule, two launches instead of ~10 per step).  `capturable`:
+    step counter on the device, needed inside a HIP graph (GraphedPipelinedStep)."""
     params = list(net.parameters())
     fused = bool(params) and all(p.is_cuda for p in params)
-    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused)
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=fused,
+                            capturable=bool(capturable and fused))
 
 
 MIOPEN_DB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
@@ -247,6 +249,76 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None, crite
     _sync_grads(net)
     optimizer.step()
     return loss, end_points
+
+
+class GraphedPipelinedStep(object):
+    """The software-pipelined training step as ONE HIP graph, replayed per step.
+
+    Why: the eager step is ~400 launches whose enqueue costs the host 6.5 ms, as much as the
+    GPU needs for the pipelined step -- the loop is on the edge of being host-bound and every
+    further kernel gain would be invisible.  A replay costs the host ~20 us.
+
+    What is captured (main stream unless noted):
+        p_in <- p_out                 (the sampling pyramid the PREVIOUS replay produced)
+        zero_grad, forward(cur, sampling = p_in), get_loss
+        side stream: sampling pyramid of `nxt_pc` (FPS, 4 levels)  || backward, Adam
+        join; p_out <- that pyramid
+    `cur` (a whole batch dict) and `nxt_pc` (the NEXT batch's point clouds) are static buffers
+    filled by __call__ before each replay -- what a prefetching loader would fill.  Nothing
+    synchronises with the host; shapes are fixed; Adam is `capturable`.  `prime(batch)`
+    computes the pyramid of the first batch eagerly (the head of the loop).
+    Single-process only: under FlatGradParallel / DDP the eager pipelined loop is used."""
+
+    def __init__(self, net, optimizer, batch, next_batch, cfg, warmup=3, criterion=None):
+        assert not hasattr(net, "module"), "graph capture of the data-parallel step: not supported"
+        self.net, self.optimizer, self.cfg = net, optimizer, cfg
+        self.cur = {k: v.clone() for k, v in batch.items()}
+        self.nxt_pc = next_batch['point_clouds'].clone()
+        bb = net.backbone_net
+        pyr = bb.prefetch_sampling(self.cur['point_clouds'])
+        torch.cuda.synchronize()
+        self.p_out = [inds.clone() for inds, _ in pyr]
+        self.p_in = [t.clone() for t in self.p_out]
+
+        def step():
+            for dst, src in zip(self.p_in, self.p_out):
+                dst.copy_(src)
+            loss, end = train_step(net, optimizer, self.cur, cfg,
+                                   sampling=[(t, None) for t in self.p_in],
+                                   next_batch={'point_clouds': self.nxt_pc}, criterion=criterion)
+            torch.cuda.current_stream().wait_stream(bb._prefetch_stream)   # join the side stream
+            for dst, (inds, _) in zip(self.p_out, end['next_sampling']):
+                dst.copy_(inds)
+            return loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = step()
+
+    def prime(self, batch):
+        """Head of the loop: the sampling pyramid of the first batch (eager, current stream)."""
+        pyr = self.net.backbone_net.prefetch_sampling(batch['point_clouds'])
+        main = torch.cuda.current_stream()
+        for dst, (inds, ev) in zip(self.p_out, pyr):
+            if ev is not None:
+                main.wait_event(ev)
+            dst.copy_(inds)
+
+    def __call__(self, batch, next_batch):
+        for k, v in batch.items():
+            if v is not self.cur[k]:
+                self.cur[k].copy_(v, non_blocking=True)
+        if next_batch is not None:
+            self.nxt_pc.copy_(next_batch['point_clouds'], non_blocking=True)
+        self.graph.replay()
+        return self.loss
 
 
 def train_step_br(net, optimizer, batch_S, batch_T, cfg):
