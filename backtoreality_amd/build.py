@@ -34,8 +34,8 @@ HIPCC_FLAGS = [
     "-fPIC", "-Wall", "-Wno-unused-function",
 ]
 # sources whose code depends on BTR_FMAD (they evaluate sq3() / dot3())
-MODE_SOURCES = ("ball_query.hip", "ball_query_grid.hip", "fps_bucket.hip", "interpolate.hip",
-                "sampling.hip")
+MODE_SOURCES = ("ball_query.hip", "ball_query_bucket.hip", "ball_query_grid.hip",
+                "fps_bucket.hip", "interpolate.hip", "sampling.hip")
 
 
 def lib_path(mode=1):

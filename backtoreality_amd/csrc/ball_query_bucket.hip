@@ -1,0 +1,286 @@
+// ball_query_bucket.hip -- ball query over the Hilbert-sorted buckets the large-scene FPS has
+// already built for the same cloud (fps_bucket.hip): no spatial structure of its own.
+//
+// SA1 of the benchmark step samples 2048 centres of a 40 000-point scene with the bucketed
+// FPS and then ball-queries the SAME cloud around them.  ball_query_grid.hip counting-sorts the
+// cloud a second time (47 us for the build, 38 us for the query itself) although the FPS
+// workspace still holds the cloud sorted along a Hilbert curve in buckets of 64 points --
+// x[64] y[64] z[64] k[64] per bucket, k = original index.  Here:
+//   1. bqb_box_kernel / bqb_super_kernel: bounding box of every bucket (one wave per bucket:
+//      three coalesced 256-byte loads and a wave min/max) and of every SUPER-bucket of 16
+//      consecutive buckets (consecutive along the curve = spatially compact);
+//   2. bqb_query_kernel, one wave per centre: box test of the <= 64 super-buckets (one per
+//      lane, boxes in LDS), then of the 16 buckets of every touched one; the points of the
+//      surviving buckets (four coalesced loads per bucket) are tested with the reference's
+//      exact f32 expression and mark bit `index` in a per-wave LDS bitmap with a one-bit-per-
+//      word summary on top; the summary is walked in index order, so the FIRST nsample indices
+//      come out without a sort and without touching the empty 95 % of the bitmap.
+// A point can only pass d2 < r^2 if its bucket's box is within r of the centre: the box test
+// uses the exact squared distance to the box in f32 with a relative slack of 1e-5 on r^2
+// (conservative: it may only admit extra buckets), so the hit set is the reference's, bit for
+// bit (ball_query_gpu.cu:14-49).  Workgroups are mapped so that all centres of a scene run
+// on one XCD (blockIdx % B = scene): the scene's 640 KB sorted copy is fetched into that L2
+// once.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace btr {
+
+constexpr int kSuper = 16;          // buckets per super-bucket
+constexpr int kMaxSupers = 128;     // super-buckets per scene the query kernel can hold
+constexpr int kBqbWaves = 4;
+
+struct Box8 {  // two float4: lo.xyz, hi.xyz
+  float x0, y0, z0, p0, x1, y1, z1, p1;
+};
+
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+// boxes[scene][nb]: one wave per bucket
+__global__ __launch_bounds__(256) void bqb_box_kernel(int np, int nb,
+                                                      const float *__restrict__ spts,
+                                                      Box8 *__restrict__ boxes) {
+  const int bi = blockIdx.y, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nb) return;
+  const float *bp = spts + (size_t)bi * np * 4 + (size_t)b * 256 + lane;
+  const bool real = __float_as_int(bp[192]) >= 0;  // padding slots carry index -1
+  const float x = bp[0], y = bp[64], z = bp[128];
+  const float big = 3.0e38f;
+  // six reductions interleaved (independent chains)
+  float lo[3] = {real ? x : big, real ? y : big, real ? z : big};
+  float hi[3] = {real ? x : -big, real ? y : -big, real ? z : -big};
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+  if (lane == 0)
+    boxes[(size_t)bi * nb + b] = Box8{lo[0], lo[1], lo[2], 0.f, hi[0], hi[1], hi[2], 0.f};
+}
+
+// sboxes[scene][nsup]: union of the boxes of 16 consecutive buckets, one thread each
+__global__ __launch_bounds__(64) void bqb_super_kernel(int nb, int nsup,
+                                                       const Box8 *__restrict__ boxes,
+                                                       Box8 *__restrict__ sboxes) {
+  const int bi = blockIdx.y, s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= nsup) return;
+  const Box8 *bx = boxes + (size_t)bi * nb;
+  Box8 a = Box8{3.0e38f, 3.0e38f, 3.0e38f, 0.f, -3.0e38f, -3.0e38f, -3.0e38f, 0.f};
+  for (int b = s * kSuper; b < min(nb, (s + 1) * kSuper); ++b) {
+    const Box8 q = bx[b];
+    a.x0 = fminf(a.x0, q.x0); a.y0 = fminf(a.y0, q.y0); a.z0 = fminf(a.z0, q.z0);
+    a.x1 = fmaxf(a.x1, q.x1); a.y1 = fmaxf(a.y1, q.y1); a.z1 = fmaxf(a.z1, q.z1);
+  }
+  sboxes[(size_t)bi * nsup + s] = a;
+}
+
+// squared distance from p to the box (0 inside); plain f32, only used as a conservative cull
+__device__ __forceinline__ float box_d2(const Box8 &q, float x, float y, float z) {
+  const float ex = fmaxf(fmaxf(q.x0 - x, x - q.x1), 0.f);
+  const float ey = fmaxf(fmaxf(q.y0 - y, y - q.y1), 0.f);
+  const float ez = fmaxf(fmaxf(q.z0 - z, z - q.z1), 0.f);
+  return ex * ex + ey * ey + ez * ez;
+}
+
+// Dynamic LDS per workgroup: nsup Box8 (super boxes) + kBqbWaves * (words + twords) bitmap
+// words (zero on entry, restored to zero after every centre).
+__global__ __launch_bounds__(kBqbWaves * 64) void bqb_query_kernel(
+    int B, int n, int np, int nb, int nsup, int m, int nsample, int words, int twords,
+    float radius2, float cull2, const float *__restrict__ new_xyz,
+    const float *__restrict__ spts, const Box8 *__restrict__ boxes,
+    const Box8 *__restrict__ sboxes, int *__restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Box8 *sb = reinterpret_cast<Box8 *>(smem);
+  unsigned *maps = reinterpret_cast<unsigned *>(smem + sizeof(Box8) * nsup);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bi = blockIdx.x % B;            // all workgroups of a scene share blockIdx % B:
+  const int chunk = blockIdx.x / B;         // with B a multiple or divisor of 8 -> one XCD set
+  const int nchunks = gridDim.x / B;
+  unsigned *bm = maps + (size_t)wave * (words + twords);
+  unsigned *top = bm + words;
+  for (int w = lane; w < words + twords; w += 64) bm[w] = 0u;
+  for (int s = threadIdx.x; s < nsup; s += kBqbWaves * 64) sb[s] = sboxes[(size_t)bi * nsup + s];
+  __syncthreads();
+
+  const float *sp = spts + (size_t)bi * np * 4;
+  const Box8 *bx = boxes + (size_t)bi * nb;
+  for (int j = chunk * kBqbWaves + wave; j < m; j += nchunks * kBqbWaves) {
+    const float *c = new_xyz + ((size_t)bi * m + j) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    // ---- level 1: super-buckets (lane = super-bucket; up to two rounds of 64)
+    for (int s0 = 0; s0 < nsup; s0 += 64) {
+      const int s = s0 + lane;
+      const bool near = s < nsup && box_d2(sb[s], cx, cy, cz) < cull2;
+      unsigned long long smask = __ballot(near);
+      // ---- level 2: the 16 buckets of each touched super-bucket, four supers per round
+      while (smask) {
+        int sup[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sup[q] = smask ? s0 + __builtin_ctzll(smask) : -1;
+          smask &= smask - 1;
+        }
+        const int mys = sup[lane >> 4];
+        const int b = mys * kSuper + (lane & 15);
+        const bool cand = mys >= 0 && b < nb && box_d2(bx[b], cx, cy, cz) < cull2;
+        unsigned long long bmask = __ballot(cand);
+        // ---- candidates: 64 points per bucket, two buckets per trip (8 loads in flight)
+        while (bmask) {
+          const int s1 = __builtin_ctzll(bmask);
+          bmask &= bmask - 1;
+          const bool two = bmask != 0;
+          const int s2 = two ? __builtin_ctzll(bmask) : s1;
+          bmask &= bmask - 1;
+          const int b1 = __builtin_amdgcn_readlane(b, s1), b2 = __builtin_amdgcn_readlane(b, s2);
+          const float *p1 = sp + (size_t)b1 * 256 + lane, *p2 = sp + (size_t)b2 * 256 + lane;
+          const float x1 = p1[0], y1 = p1[64], z1 = p1[128];
+          const int k1 = __float_as_int(p1[192]);
+          const float x2 = p2[0], y2 = p2[64], z2 = p2[128];
+          const int k2 = __float_as_int(p2[192]);
+          if (k1 >= 0 && sq3(cx - x1, cy - y1, cz - z1) < radius2) {
+            atomicOr(&bm[k1 >> 5], 1u << (k1 & 31));
+            atomicOr(&top[k1 >> 10], 1u << ((k1 >> 5) & 31));
+          }
+          if (two && k2 >= 0 && sq3(cx - x2, cy - y2, cz - z2) < radius2) {
+            atomicOr(&bm[k2 >> 5], 1u << (k2 & 31));
+            atomicOr(&top[k2 >> 10], 1u << ((k2 >> 5) & 31));
+          }
+        }
+      }
+    }
+    // ---- first nsample set bits in index order: lane l owns summary words l, l + 64, ...
+    int *row = idx + ((size_t)bi * m + j) * nsample;
+    int base = 0;          // hits in the summary words of earlier rounds
+    int first = 0x7fffffff;
+    for (int t0 = 0; t0 < twords; t0 += 64) {
+      const int t = t0 + lane;
+      unsigned tw = t < twords ? top[t] : 0u;
+      int cnt = 0;
+      for (unsigned v = tw; v; v &= v - 1) cnt += __builtin_popcount(bm[(t << 5) + __builtin_ctz(v)]);
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+      }
+      int pos = base + incl - cnt;
+      base += __builtin_amdgcn_readlane(incl, 63);
+      if (tw) top[t] = 0u;
+      while (tw) {
+        const int w = (t << 5) + __builtin_ctz(tw);
+        tw &= tw - 1;
+        unsigned v = bm[w];
+        bm[w] = 0u;  // restore the bitmap for the next centre
+        while (v) {
+          const int k = (w << 5) + __builtin_ctz(v);
+          v &= v - 1;
+          first = min(first, k);
+          if (pos < nsample) row[pos] = k;
+          ++pos;
+        }
+      }
+    }
+    // padding: the smallest hit fills the rest; no hit -> zeros (ball_query_gpu.cu:39-43)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) first = min(first, __shfl_xor(first, o));
+    const int fill = base == 0 ? 0 : first;
+    for (int l = min(base, nsample) + lane; l < nsample; l += 64) row[l] = fill;
+  }
+}
+
+struct BqbPlan {
+  int nb, np, nsup, words, twords;
+  size_t box_bytes, sbox_bytes, lds;
+};
+
+static BqbPlan bqb_plan(int b, int n) {
+  BqbPlan p;
+  p.nb = cdiv(n, 64);
+  p.np = p.nb * 64;
+  p.nsup = cdiv(p.nb, kSuper);
+  p.words = cdiv(n, 32);
+  p.twords = cdiv(p.words, 32);
+  p.box_bytes = sizeof(Box8) * (size_t)b * p.nb;
+  p.sbox_bytes = sizeof(Box8) * (size_t)b * p.nsup;
+  p.lds = sizeof(Box8) * p.nsup + sizeof(unsigned) * (size_t)kBqbWaves * (p.words + p.twords);
+  return p;
+}
+
+bool bq_bucket_supported(int n, int m, int nsample) {
+  if (n <= 0 || m <= 0 || nsample <= 0) return false;
+  const BqbPlan p = bqb_plan(1, n);
+  return p.nsup <= kMaxSupers && p.lds <= 120 * 1024;
+}
+
+size_t bq_bucket_workspace_bytes(int b, int n) {
+  const BqbPlan p = bqb_plan(b, n);
+  return p.box_bytes + p.sbox_bytes;
+}
+
+// spts: the bucket-SoA copy at the start of the FPS workspace (fps_bucket.hip fps_plan)
+int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                     const void *fps_workspace, int *idx, void *ws, size_t ws_bytes,
+                     hipStream_t s) {
+  const BqbPlan p = bqb_plan(b, n);
+  BTR_REQUIRE(fps_workspace && ws && ws_bytes >= p.box_bytes + p.sbox_bytes,
+              "ball_query(buckets): workspace too small");
+  const float *spts = (const float *)fps_workspace;
+  Box8 *boxes = (Box8 *)ws;
+  Box8 *sboxes = (Box8 *)((char *)ws + p.box_bytes);
+  hipLaunchKernelGGL(bqb_box_kernel, dim3(cdiv(p.nb, 4), b), dim3(256), 0, s, p.np, p.nb, spts,
+                     boxes);
+  hipLaunchKernelGGL(bqb_super_kernel, dim3(cdiv(p.nsup, 64), b), dim3(64), 0, s, p.nb, p.nsup,
+                     boxes, sboxes);
+  static size_t lds_set = 0;
+  if (p.lds > lds_set && p.lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)bqb_query_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+    if (e != hipSuccess)
+      return fail((int)e, "ball_query(buckets) attr: %s", hipGetErrorString(e));
+    lds_set = p.lds;
+  }
+  const float radius2 = radius * radius;          // ball_query_gpu.cu:27
+  const float cull2 = radius2 * 1.00001f + 1e-30f;  // conservative box cull (see the header)
+  const int chunks = std::max(1, std::min(cdiv(m, kBqbWaves), 2048 / std::max(1, b)));
+  hipLaunchKernelGGL(bqb_query_kernel, dim3(chunks * b), dim3(kBqbWaves * 64), p.lds, s, b, n,
+                     p.np, p.nb, p.nsup, m, nsample, p.words, p.twords, radius2, cull2, new_xyz,
+                     spts, boxes, sboxes, idx);
+  return check_launch("ball_query(buckets)");
+}
+
+}  // namespace btr
+
+using namespace btr;
+
+extern "C" {
+
+size_t btr_ball_query_buckets_workspace_bytes(int b, int n, int m, int nsample) {
+  if (b <= 0 || !bq_bucket_supported(n, m, nsample)) return 0;
+  return bq_bucket_workspace_bytes(b, n);
+}
+
+int btr_ball_query_buckets(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                           const void *fps_workspace, int *idx, void *workspace,
+                           size_t workspace_bytes, btr_stream_t stream) {
+  if (b <= 0 || m <= 0 || nsample <= 0) return BTR_OK;
+  BTR_REQUIRE(idx && new_xyz, "ball_query(buckets): null pointer");
+  BTR_REQUIRE(bq_bucket_supported(n, m, nsample), "ball_query(buckets): n=%d not supported", n);
+  return bq_bucket_launch(b, n, m, radius, nsample, new_xyz, fps_workspace, idx, workspace,
+                          workspace_bytes, as_stream(stream));
+}
+
+}  // extern "C"

@@ -110,7 +110,7 @@ __device__ __forceinline__ float4 rc_y4(const float4 x, const float *__restrict_
 // the maximum is tracked where gamma >= 0, the minimum elsewhere, and the max-pool of the
 // activated layer is relu(scale * gext + shift).  The pool kernel's pass over the whole pre-BN
 // tensor (537 MB for SA1) becomes a pass over 1/PS of it (sa_pool_fin_kernel).
-template <int BN, int PRO, bool STATS, int PS = 0>
+template <int BN, int PRO, bool STATS, int PS = 0, int BM = kBM, bool BIAS = false>
 // (second launch bound: at least 2 waves per SIMD, i.e. <= 256 VGPRs -- two workgroups per
 // CU; without it the PRO == 2 / BN = 128 variant allocates 292 and runs alone on its CU)
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
@@ -125,9 +125,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   if (cm.dims) R = cm.dims[0];  // compact rows: the row count lives on the device
   constexpr int WN = BN / 64;      // waves along N
   constexpr int WM = 4 / WN;       // waves along M
-  constexpr int MI = kBM / WM / 32;  // 32-row MFMA tiles per wave
+  constexpr int MI = BM / WM / 32;  // 32-row MFMA tiles per wave
   constexpr int NJ = 2;            // 32-col MFMA tiles per wave
-  __shared__ __attribute__((aligned(16))) float As[kBM * kLd];
+  __shared__ __attribute__((aligned(16))) float As[BM * kLd];
   __shared__ __attribute__((aligned(16))) float Bs[BN * kLd];
   __shared__ double red[STATS ? 2 * WM * BN : 1];
   // per-k prologue coefficients (and, PRO == 3, the first layer's weight rows) live in LDS for
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     d1[j] = d2[j] = 0.0;
   }
 
-  const int ntiles = (R + kBM - 1) / kBM;
+  const int ntiles = (R + BM - 1) / BM;
   const int nkc = (K + kBK - 1) / kBK;
   const int kq = (tid & 7) * 4;  // this thread's 4 consecutive k inside a staged chunk
   const int srow = tid >> 3;     // ... and its row (+32*p)
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   // Register-staged software pipeline over the flattened (tile, k-chunk) sequence: the global
   // loads of step q+1 are in flight while the MFMAs of step q run (T14 "issue early, write
   // late"); the BN+ReLU prologue is applied when the registers are written to LDS.
-  float4 ra[kBM / 32], rb[BN / 32];
+  float4 ra[BM / 32], rb[BN / 32];
   // PRO == 2: the sparse part of dY (one entry per group and channel) is added to the staged
   // tile in LDS by one thread per (group of the tile, k column): 2 registers of prefetch
   // instead of an arg word + a float4 per staged row (which cost a wave of occupancy).
@@ -174,11 +174,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   unsigned sp_a[2] = {0, 0};
   bool sp_ok[2] = {false, false};
   float sp_dv[2] = {0.f, 0.f};
-  float rwt[kBM / 32];  // PRO == 2: weight of the dense part for the rows this thread stages
+  float rwt[BM / 32];  // PRO == 2: weight of the dense part for the rows this thread stages
   auto fetch = [&](int tile, int kc) {
-    const int r0 = tile * kBM, kk = kc * kBK + kq;
+    const int r0 = tile * BM, kk = kc * kBK + kq;
 #pragma unroll
-    for (int p = 0; p < kBM / 32; ++p) {
+    for (int p = 0; p < BM / 32; ++p) {
       const int row = srow + 32 * p;
       ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       rwt[p] = 1.f;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         }
       }
       if (kc + 1 >= nkc) {  // last chunk of this tile: the next tile's groups
-        const int nr0 = (tile + (int)gridDim.x) * kBM;
+        const int nr0 = (tile + (int)gridDim.x) * BM;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int blk = (nr0 >> 3) + sp_gi + 8 * q;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     } else if (PRO == 2) {
       const int k1 = kc * kBK + sp_k;  // (group size S = 1 << SSH: shifts, no divisions)
       const int g = (r0 >> SSH) + sp_gi;
-      sp_on = (sp_gi << SSH) < kBM && (g << SSH) < R && k1 < K;
+      sp_on = (sp_gi << SSH) < BM && (g << SSH) < R && k1 < K;
       if (sp_on) {
         sp_arg = parg[(size_t)g * K + k1];
         sp_d = pdcl[(size_t)g * K + k1];
@@ -234,14 +234,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     }
   };
   auto stage = [&](int tile, int kc) {
-    const int r0 = tile * kBM, kk = kc * kBK + kq;
+    const int r0 = tile * BM, kk = kc * kBK + kq;
     float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PRO && kk < K) {  // K is padded to a multiple of 4 by the caller
       fa = *reinterpret_cast<const float4 *>(&sPa[kk]);
       fb = *reinterpret_cast<const float4 *>(&sPb[kk]);
     }
 #pragma unroll
-    for (int p = 0; p < kBM / 32; ++p) {
+    for (int p = 0; p < BM / 32; ++p) {
       const int row = srow + 32 * p;
       float4 v = ra[p];
       if (PRO == 1 && r0 + row < R && kk < K) {  // padded rows / columns must stay exactly 0
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   if (PRO == 2 && cm.bgrp) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int blk = ((int)blockIdx.x * kBM >> 3) + sp_gi + 8 * q;
+      const int blk = ((int)blockIdx.x * BM >> 3) + sp_gi + 8 * q;
       sp_g[q] = (blk << 3) < R ? cm.bgrp[blk] : 0;
     }
   }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   }
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x, 0);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int r0 = tile * kBM;
+    const int r0 = tile * BM;
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int row = r0 + wm * (kBM / WM) + i * 32 + 8 * q;
+          const int row = r0 + wm * (BM / WM) + i * 32 + 8 * q;
           bwx[i][q] = row < R ? cm.bw[row >> 3] - 1.f : 0.f;
         }
     }
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           af[i] = *reinterpret_cast<const float4 *>(
-              &As[(wm * (kBM / WM) + i * 32 + l31) * kLd + h * (kBK / 2) + t4]);
+              &As[(wm * (BM / WM) + i * 32 + l31) * kLd + h * (kBK / 2) + t4]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           bf[j] = *reinterpret_cast<const float4 *>(
@@ -364,8 +364,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         const int col = n_blk + wn * 64 + j * 32 + l31;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const int row = r0 + wm * (kBM / WM) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-          const float c = acc[i][j][v];
+          const int row = r0 + wm * (BM / WM) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          float c = acc[i][j][v];
+          if (BIAS && col < N && row < R) c += gsign[col];  // (BIAS: gsign carries the bias row)
           if (C != nullptr && row < R && col < N) C[(size_t)row * ldc + col] = c;
           if (STATS) {  // rows >= R hold exact zeros (A staged as 0): no masking needed
             s1[j] += c;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       // this wave's 64 rows = 64 / PS whole groups; lanes l and l ^ 32 hold the same column
       // (rows interleaved in blocks of 4), v ascending = rows ascending within a lane
       constexpr int G = 64 / PS;
-      const int wrow0 = r0 + wm * (kBM / WM);
+      const int wrow0 = r0 + wm * (BM / WM);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int col = n_blk + wn * 64 + j * 32 + l31;
@@ -1623,6 +1624,62 @@ __global__ __launch_bounds__(256) void sac_reduce_kernel(int N, int C, int ldx, 
   }
 }
 
+
+// ======================================================== point-wise MLP chains ("pm")
+// The 1x1-convolution + BatchNorm + ReLU chains around the set-abstraction stack (feature
+// propagation MLPs, vote generator, proposal head: 2 048 - 16 384 rows) run on the same GEMM /
+// statistics / BN-backward kernels, with 64-row tiles so that these small problems still fill
+// the chip (btr_pm_gemm_nt).  pm_out_kernel turns the last pre-BN output into what the next torch
+// op reads: out[b][c][n] = f(a[c] * Y[b*N + n][c] + s[c]) in (B, C, N) and channel-last.
+__global__ __launch_bounds__(256) void pm_out_kernel(int N, int C, int ldy,
+                                                     const float *__restrict__ Y,
+                                                     const float *__restrict__ scale,
+                                                     const float *__restrict__ shift, int relu,
+                                                     float *__restrict__ out_bcn,
+                                                     float *__restrict__ out_cl) {
+  __shared__ float tile[64][65];
+  const int bi = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {   // read rows n0 + ty + 4i, channel c0 + tx (coalesced in c)
+    const int n = n0 + ty + 4 * i, c = c0 + tx;
+    float v = 0.f;
+    if (n < N && c < C) {
+      v = Y[((size_t)bi * N + n) * ldy + c];
+      if (scale) v = fmaf(scale[c], v, shift[c]);
+      if (relu) v = fmaxf(v, 0.f);
+      if (out_cl) out_cl[((size_t)bi * N + n) * C + c] = v;
+    }
+    tile[ty + 4 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {   // write channel c0 + ty + 4i, point n0 + tx (coalesced in n)
+    const int c = c0 + ty + 4 * i, n = n0 + tx;
+    if (n < N && c < C) out_bcn[((size_t)bi * C + c) * N + n] = tile[tx][ty + 4 * i];
+  }
+}
+
+// rows[b*N + n][c] = x[b][c][n] (c < C), zero for C <= c < ldr: (B, C, N) -> channel-last rows
+__global__ __launch_bounds__(256) void pm_rows_kernel(int N, int C, int ldr,
+                                                      const float *__restrict__ x,
+                                                      float *__restrict__ rows) {
+  __shared__ float tile[64][65];
+  const int bi = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, n = n0 + tx;
+    tile[ty + 4 * i][tx] = (c < C && n < N) ? x[((size_t)bi * C + c) * N + n] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + ty + 4 * i, c = c0 + tx;
+    if (n < N && c < ldr) rows[((size_t)bi * N + n) * ldr + c] = tile[tx][ty + 4 * i];
+  }
+}
+
 // The compact description bound on this host thread (btr_sac_bind); read by the launchers.
 struct HostCompact {
   Compact dev;
@@ -2158,6 +2215,60 @@ int btr_sac_scatter(int b, int n, int m, int c, int ldx, int use_xyz, const floa
   hipLaunchKernelGGL(sac_reduce_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, st, n, c, ldx,
                      use_xyz ? 3 : 0, dx0, off, refs, dfeat_cl);
   return check_launch("sac_scatter");
+}
+
+// ------------------------------------------------------------- point-wise MLP chains (pm)
+int btr_pm_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, 64), 512)); }
+
+// As btr_sa_gemm_nt on 64-row tiles (n > 64) with an optional bias row added to C (layers
+// without BatchNorm); part: [btr_pm_gemm_grid(rows)][2][n].
+int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
+                   float *c, int ldc, const float *pa, const float *pb, float *part,
+                   const float *bias, btr_stream_t stream) {
+  if (rows <= 0 || n <= 0) return BTR_OK;
+  BTR_REQUIRE(a && w && c && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
+              "pm_gemm_nt: k=%d lda=%d ldw=%d must be multiples of 4", k, lda, ldw);
+  BTR_REQUIRE((pa == nullptr) == (pb == nullptr), "pm_gemm_nt: pa/pb must come together");
+  BTR_REQUIRE(pa == nullptr || k <= kMaxK, "pm_gemm_nt: k=%d > %d with a prologue", k, kMaxK);
+  BTR_REQUIRE(!(bias && part), "pm_gemm_nt: bias and statistics are exclusive");
+  hipStream_t s = as_stream(stream);
+  const int gx = btr_pm_gemm_grid(rows);
+#define BTR_PM(BN, P, S, BIAS)                                                                 \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S, 0, 64, BIAS>), dim3(gx, cdiv(n, BN)), dim3(256), \
+                     0, s, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,                    \
+                     (const unsigned char *)nullptr, (const float *)nullptr, 0, bias,          \
+                     (float *)nullptr, (unsigned char *)nullptr, Compact{})
+  if (pa) {
+    if (part) BTR_PM(128, 1, true, false);
+    else if (bias) BTR_PM(128, 1, false, true);
+    else BTR_PM(128, 1, false, false);
+  } else {
+    if (part) BTR_PM(128, 0, true, false);
+    else if (bias) BTR_PM(128, 0, false, true);
+    else BTR_PM(128, 0, false, false);
+  }
+#undef BTR_PM
+  return check_launch("pm_gemm_nt");
+}
+
+// out_bcn (B, C, N) [and out_cl (B*N, C)] = f(scale * y + shift); scale/shift NULL: identity
+int btr_pm_out(int b, int n, int c, int ldy, const float *y, const float *scale,
+               const float *shift, int relu, float *out_bcn, float *out_cl,
+               btr_stream_t stream) {
+  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(y && out_bcn && (scale == nullptr) == (shift == nullptr), "pm_out: bad arguments");
+  hipLaunchKernelGGL(pm_out_kernel, dim3(cdiv(n, 64), cdiv(c, 64), b), dim3(256), 0,
+                     as_stream(stream), n, c, ldy, y, scale, shift, relu, out_bcn, out_cl);
+  return check_launch("pm_out");
+}
+
+// rows (B*N, ldr) = x (B, C, N) transposed, columns C .. ldr zero
+int btr_pm_rows(int b, int n, int c, int ldr, const float *x, float *rows, btr_stream_t stream) {
+  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(x && rows && ldr >= c, "pm_rows: bad arguments");
+  hipLaunchKernelGGL(pm_rows_kernel, dim3(cdiv(n, 64), cdiv(ldr, 64), b), dim3(256), 0,
+                     as_stream(stream), n, c, ldr, x, rows);
+  return check_launch("pm_rows");
 }
 
 }  // extern "C"

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "btr_ball_query": (_ci, [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp]),
     "btr_ball_query_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
     "btr_ball_query_ws": (_ci, [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "btr_ball_query_buckets_workspace_bytes": (_sz, [_ci, _ci, _ci, _ci]),
+    "btr_ball_query_buckets": (_ci, [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp, _sz, _vp]),
     "btr_group_points": (_ci, [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_group_points_grad": (_ci, [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_three_nn": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
@@ -81,6 +83,11 @@ _SIGNATURES = {
     "btr_sac_scatter_workspace_bytes": (_sz, [_ci, _ci, _ci]),
     "btr_sac_scatter": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _ci,
                               _vp]),
+    # point-wise MLP chains (used by fused_mlp.py)
+    "btr_pm_gemm_grid": (_ci, [_ci]),
+    "btr_pm_gemm_nt": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "btr_pm_out": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
+    "btr_pm_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp]),
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
@@ -281,6 +288,11 @@ def _fps(points, nsamples, block_size, out):
         _call(_idx.btr_furthest_point_sampling_ws, B, N, nsamples, _p(points), _p(temp),
               _p(out), int(block_size), _p(ws), ws_bytes, _stream(dev),
               key=(B, N, nsamples))
+        if ws is not None:
+            # the cloud, sorted into Hilbert buckets, stays with the tensor it was built from:
+            # a ball query of the SAME tensor (SA1 right after its FPS) searches it instead of
+            # building a grid of its own (ball_query below; csrc/ball_query_bucket.hip)
+            points._btr_fps_ws = (ws, points._version, torch.cuda.current_stream(dev), _idx)
     return out
 
 
@@ -337,6 +349,9 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
+BQ_CALLS = {"buckets": 0, "own": 0}   # which path ball_query took (tests / tools read it)
+
+
 def ball_query(new_xyz, xyz, radius, nsample):
     """(B,M,3), (B,N,3) f32 -> (B,M,nsample) i32.  C++ argument order, ball_query.cpp:13-37."""
     _check(new_xyz, "new_xyz", "float")
@@ -346,6 +361,26 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.size(1)
     nsample = int(nsample)
     out = torch.empty((B, M, nsample), dtype=torch.int32, device=new_xyz.device)
+    shared = getattr(xyz, "_btr_fps_ws", None)
+    # (not while a HIP graph is being captured: the tensor identity / version test that makes
+    # the reuse safe is evaluated once at capture time, the replays would keep reading a
+    # workspace that belongs to another batch)
+    if (shared is not None and shared[1] == xyz._version and shared[3] is _idx and
+            os.environ.get("BTR_BQ_BUCKETS", "1") != "0" and
+            not torch.cuda.is_current_stream_capturing()):
+        bws = _idx.btr_ball_query_buckets_workspace_bytes(B, N, M, nsample)
+        if bws:
+            fps_ws, _, fps_stream, _ = shared
+            with _on(new_xyz) as dev:
+                cur = torch.cuda.current_stream(dev)
+                if cur != fps_stream:        # built on another stream (prefetched pyramid):
+                    fps_ws.record_stream(cur)  # the caller has already waited for that FPS
+                box = torch.empty((bws,), dtype=torch.uint8, device=new_xyz.device)
+                _call(_idx.btr_ball_query_buckets, B, N, M, float(radius), nsample, _p(new_xyz),
+                      _p(fps_ws), _p(out), _p(box), bws, _stream(dev), key=(B, N, M, nsample))
+            BQ_CALLS["buckets"] += 1
+            return out
+    BQ_CALLS["own"] += 1
     ws_bytes = _idx.btr_ball_query_workspace_bytes(B, N, M, nsample)
     ws = (torch.empty((ws_bytes,), dtype=torch.uint8, device=new_xyz.device)
           if ws_bytes else None)

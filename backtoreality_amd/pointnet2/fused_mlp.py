@@ -1,0 +1,253 @@
+"""Fused point-wise MLP chains on MI355X: the 1x1-convolution (+bias) -> BatchNorm -> ReLU
+sequences around the set-abstraction stack -- the SharedMLP of the feature-propagation
+modules (reference pointnet2_modules.py:469-514, pytorch_utils.py:11-36), the vote generator
+(models/voting_module.py:37-56) and the proposal head (models/proposal_module.py:75-113).
+
+The reference runs them as stock conv / batch-norm / relu ops on (B, C, N) tensors: per layer a
+GEMM per batch sample, four BatchNorm launches, an activation, and twice that in the backward
+(~270 launches and ~1.1 ms of the benchmark step, as much host time as GPU time).  Here a
+chain runs on channel-last rows (B*N, C) through the kernels of the fused set-abstraction
+path (csrc/sa_mlp.hip): f32-MFMA GEMM on 64-row tiles with the BatchNorm statistics in its
+epilogue, BN + ReLU applied while the NEXT layer's operand is staged, BN backward as two
+streaming passes, weight gradient as a TN GEMM.  A conv bias in front of a train-mode
+BatchNorm cancels exactly (it only moves the running mean, which is corrected), so it is
+skipped and its gradient is the exact zero the mathematics gives.
+
+`PointwiseMLP.apply(x, meta, *params)`: x (B, C, N) f32 -> (B, C_out, N); the result carries
+its channel-last twin as `._btr_channel_last`.  `BTR_FUSED_MLP=0` disables the path.
+"""
+import os
+
+import torch
+from torch.autograd import Function
+
+if __package__:
+    from . import _ext
+else:
+    import pointnet2._ext as _ext
+_call, _lib, _on, _p, _stream = _ext._call, _ext._lib, _ext._on, _ext._p, _ext._stream
+
+
+def enabled():
+    return os.environ.get("BTR_FUSED_MLP", "1") != "0"
+
+
+def _ceil4(v):
+    return (v + 3) // 4 * 4
+
+
+def _f32(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+class PointwiseMLP(Function):
+    """meta: dict(layers=[dict(bn=nn.BatchNorm*|None, relu=bool)]); params: per layer
+    (W (C_out, C_in[,1[,1]]), bias|None, gamma|None, beta|None)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        layers = meta["layers"]
+        L = len(layers)
+        dev = x.device
+        B, K0, N = x.shape
+        rows = B * N
+        assert K0 % 4 == 0, "input width must be a multiple of 4"
+        with _on(x) as d:
+            st = _stream(d)
+            A = getattr(x, "_btr_channel_last", None)
+            if A is None or A.shape != (rows, K0):
+                A = _f32((rows, K0), dev)
+                _call(_lib.btr_pm_rows, B, N, K0, K0, _p(x.contiguous()), _p(A), st)
+            X0 = A
+            grid = _lib.btr_pm_gemm_grid(rows)
+            Ys, Ws, stats, widths = [], [], [], []
+            lda, K = K0, K0
+            pa = pb = None
+            counters = []
+            for l, spec in enumerate(layers):
+                W, bias, gamma, beta = params[4 * l:4 * l + 4]
+                Nl = W.shape[0]
+                Np = _ceil4(Nl)
+                W2 = W.reshape(Nl, -1)
+                assert W2.shape[1] == K
+                if Np != Nl:
+                    Wp = torch.zeros((Np, K), dtype=torch.float32, device=dev)
+                    Wp[:Nl] = W2
+                    W2 = Wp
+                W2 = W2.contiguous()
+                bn = spec["bn"]
+                Y = _f32((rows, Np), dev)
+                if bn is not None:
+                    part = _f32((grid, 2, Np), dev)
+                    _call(_lib.btr_pm_gemm_nt, rows, Np, K, _p(A), lda, _p(W2), K, _p(Y), Np,
+                          _p(pa), _p(pb), _p(part), None, st, key=(rows, Np, K))
+                    scale, shift, mean, invstd = (_f32((Np,), dev) for _ in range(4))
+                    mom = float(bn.momentum) if bn.momentum is not None else \
+                        1.0 / float(bn.num_batches_tracked.item() + 1)
+                    track = bn.track_running_stats and bn.running_mean is not None
+                    _call(_lib.btr_sa_bn_finalize, Np, grid, float(rows), float(bn.eps), mom,
+                          _p(part), _p(gamma), _p(beta), _p(scale), _p(shift), _p(mean),
+                          _p(invstd), _p(bn.running_mean if track else None),
+                          _p(bn.running_var if track else None), st)
+                    if track:
+                        if bias is not None:   # the skipped bias only moves the running mean
+                            bn.running_mean.add_(bias.detach(), alpha=mom)
+                        counters.append(bn.num_batches_tracked)
+                    stats.append((scale, shift, mean, invstd))
+                    assert spec["relu"], "BatchNorm without ReLU is not covered"
+                    pa, pb = scale, shift
+                else:
+                    assert l == L - 1 and not spec["relu"], "only the last layer may lack BN"
+                    bp = None
+                    if bias is not None:
+                        bp = bias if Np == Nl else torch.cat(
+                            [bias, torch.zeros(Np - Nl, device=dev)])
+                    _call(_lib.btr_pm_gemm_nt, rows, Np, K, _p(A), lda, _p(W2), K, _p(Y), Np,
+                          _p(pa), _p(pb), None, _p(bp), st, key=(rows, Np, K))
+                    stats.append(None)
+                    pa = pb = None
+                Ys.append(Y)
+                Ws.append(W2)
+                widths.append(Nl)
+                A, lda, K = Y, Np, Np
+            NL = widths[-1]
+            out = _f32((B, NL, N), dev)
+            out_cl = _f32((rows, NL), dev)
+            last = stats[-1]
+            _call(_lib.btr_pm_out, B, N, NL, Ys[-1].shape[1], _p(Ys[-1]),
+                  _p(last[0]) if last else None, _p(last[1]) if last else None,
+                  1 if last else 0, _p(out), _p(out_cl), st)
+            if counters:
+                torch._foreach_add_(counters, 1)
+        out._btr_channel_last = out_cl
+        ctx.dims = (B, N, K0, L)
+        ctx.widths = widths
+        ctx.pshapes = [None if p is None else p.shape for p in params]
+        ctx.has_bn = [s is not None for s in stats]
+        flat = [t for s4 in stats if s4 is not None for t in s4]
+        ctx.save_for_backward(X0, *Ys, *Ws, *flat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, N, K0, L = ctx.dims
+        rows = B * N
+        saved = ctx.saved_tensors
+        X0 = saved[0]
+        Ys = list(saved[1:1 + L])
+        Ws = list(saved[1 + L:1 + 2 * L])
+        flat = list(saved[1 + 2 * L:])
+        stats = []
+        for has in ctx.has_bn:
+            stats.append(tuple(flat[:4]) if has else None)
+            if has:
+                flat = flat[4:]
+        dev = dout.device
+        grads = [None] * (4 * L)
+        need_x = ctx.needs_input_grad[0]
+        dx = None
+        with _on(dout) as d:
+            st = _stream(d)
+            NL = ctx.widths[-1]
+            Np = Ys[-1].shape[1]
+            G = _f32((rows, Np), dev)
+            _call(_lib.btr_pm_rows, B, N, NL, Np, _p(dout.contiguous()), _p(G), st)
+            if stats[-1] is not None:
+                sc, sh, mu, isd = stats[-1]
+                part = _f32((1024, 2, Np), dev)
+                m1, m2, dg, db = (_f32((Np,), dev) for _ in range(4))
+                _call(_lib.btr_sa_bn_relu_bwd, rows, Np, Np, _p(G), _p(Ys[-1]), _p(sc), _p(sh),
+                      _p(mu), _p(isd), _p(part), _p(m1), _p(m2), _p(dg), _p(db), st)
+                grads[4 * (L - 1) + 2], grads[4 * (L - 1) + 3] = dg[:NL], db[:NL]
+                if ctx.pshapes[4 * (L - 1) + 1] is not None:
+                    grads[4 * (L - 1) + 1] = torch.zeros(NL, device=dev)
+            elif ctx.pshapes[4 * (L - 1) + 1] is not None:
+                grads[4 * (L - 1) + 1] = G.sum(0)[:NL]
+            dY = G
+            for l in range(L - 1, -1, -1):
+                W2 = Ws[l]
+                Np, K = W2.shape
+                Nl = ctx.widths[l]
+                if l == 0:
+                    Xsrc, ldx, pa, pb = X0, K0, None, None
+                else:
+                    Xsrc, ldx = Ys[l - 1], Ys[l - 1].shape[1]
+                    pa, pb = stats[l - 1][0], stats[l - 1][1]
+                chunks = _lib.btr_sa_gemm_tn_chunks(rows, Np, K)
+                pw = _f32((chunks, Np, K), dev)
+                dW = _f32((Np, K), dev)
+                _call(_lib.btr_sa_gemm_tn, rows, Np, K, _p(dY), Np, _p(Xsrc), ldx, _p(pa), _p(pb),
+                      _p(pw), _p(dW), st, key=(rows, Np, K))
+                grads[4 * l] = dW[:Nl].reshape(ctx.pshapes[4 * l])
+                if l > 0 or need_x:
+                    Wt = W2.t().contiguous()
+                    Gn = _f32((rows, K), dev)
+                    _call(_lib.btr_pm_gemm_nt, rows, K, Np, _p(dY), Np, _p(Wt), Np, _p(Gn), K,
+                          None, None, None, None, st, key=(rows, K, Np))
+                    if l > 0:
+                        sc, sh, mu, isd = stats[l - 1]
+                        part = _f32((1024, 2, K), dev)
+                        m1, m2, dg, db = (_f32((K,), dev) for _ in range(4))
+                        _call(_lib.btr_sa_bn_relu_bwd, rows, K, K, _p(Gn), _p(Ys[l - 1]), _p(sc),
+                              _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2), _p(dg), _p(db),
+                              st)
+                        wprev = ctx.widths[l - 1]
+                        grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3] = dg[:wprev], db[:wprev]
+                        if ctx.pshapes[4 * (l - 1) + 1] is not None:
+                            grads[4 * (l - 1) + 1] = torch.zeros(wprev, device=dev)
+                        dY = Gn
+                    else:
+                        dx = _f32((B, K0, N), dev)
+                        _call(_lib.btr_pm_out, B, N, K0, K0, _p(Gn), None, None, 0, _p(dx), None,
+                              st)
+        return (dx, None) + tuple(grads)
+
+
+def _layer_ok(conv, bn, K):
+    import torch.nn as nn
+    if conv.kernel_size not in ((1,), (1, 1)) or conv.stride not in ((1,), (1, 1)) or \
+            conv.groups != 1 or K % 4 != 0:
+        return False
+    if bn is not None:
+        if not isinstance(bn, (nn.BatchNorm1d, nn.BatchNorm2d)) or bn.weight is None or \
+                not bn.training or conv.out_channels % 4 != 0 or conv.out_channels > 256:
+            return False
+    return True
+
+
+def shared_mlp_chain(mlp):
+    """[(conv, bn, relu)] of a pytorch_utils.SharedMLP whose layers are conv -> bn -> ReLU
+    (the feature-propagation MLPs), else None."""
+    import torch.nn as nn
+    chain = []
+    for layer in mlp:
+        if [n for n, _ in layer.named_children()] != ["conv", "bn", "activation"]:
+            return None
+        if not isinstance(layer.activation, nn.ReLU):
+            return None
+        chain.append((layer.conv, layer.bn.bn, True))
+    return chain or None
+
+
+def run_chain(x, chain):
+    """chain: [(conv, bn | None, relu: bool)].  Returns None when the fused path does not
+    cover the configuration (CPU tensors, eval mode, disabled): the caller then runs the
+    stock ops."""
+    if not (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
+        return None
+    K = x.shape[1]
+    metas, params = [], []
+    for i, (conv, bn, relu) in enumerate(chain):
+        if not _layer_ok(conv, bn, K):
+            return None
+        if bn is None and (relu or i != len(chain) - 1):
+            return None
+        if bn is not None and not relu:
+            return None
+        metas.append({"bn": bn, "relu": relu})
+        params += [conv.weight, conv.bias, bn.weight if bn is not None else None,
+                   bn.bias if bn is not None else None]
+        K = conv.out_channels
+    if K > 256 and chain[-1][1] is not None:
+        return None
+    return PointwiseMLP.apply(x, {"layers": metas}, *params)

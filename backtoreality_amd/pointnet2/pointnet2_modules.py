@@ -16,6 +16,7 @@ if __package__:
     from . import pointnet2_utils
     from . import pytorch_utils as pt_utils
     from . import fused_sa
+    from . import fused_mlp
 else:
     import os
     import sys
@@ -23,6 +24,7 @@ else:
     import pointnet2_utils
     import pytorch_utils as pt_utils
     import fused_sa
+    import fused_mlp
 
 
 def _sample_centres(xyz, npoint, inds=None):
@@ -242,6 +244,10 @@ class PointnetFPModule(nn.Module):
             new_features = torch.cat([interpolated, unknow_feats], dim=1)
         else:
             new_features = interpolated
+        chain = fused_mlp.shared_mlp_chain(self.mlp)
+        out = fused_mlp.run_chain(new_features, chain) if chain is not None else None
+        if out is not None:   # MI355X fast path: the SharedMLP as fused GEMM + BN kernels
+            return out
         return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
 
 

@@ -45,7 +45,19 @@ class Pointnet2Backbone(nn.Module):
 
     @staticmethod
     def _break_up_pc(pc):
-        xyz = pc[..., 0:3].contiguous()
+        # the coordinate tensor is kept with the point cloud it was cut from: a prefetched
+        # sampling pyramid and the forward that consumes it then see the SAME xyz object, and
+        # with it the spatial sort the FPS attached to it (pointnet2/_ext.py _fps)
+        # (never while a HIP graph is captured: the version test would be evaluated once, at
+        # capture time, and every replay would read the coordinates of the capture batch)
+        cached = getattr(pc, "_btr_xyz", None)
+        capturing = pc.is_cuda and torch.cuda.is_current_stream_capturing()
+        if cached is not None and cached[1] == pc._version and not capturing:
+            xyz = cached[0]
+        else:
+            xyz = pc[..., 0:3].contiguous()
+            if not capturing:
+                pc._btr_xyz = (xyz, pc._version)
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..pointnet2 import pointnet2_utils
+from ..pointnet2 import fused_mlp, pointnet2_utils
 from ..pointnet2.pointnet2_modules import PointnetSAModuleVotes
 
 
@@ -98,9 +98,13 @@ class ProposalModule(nn.Module):
         end_points['aggregated_vote_features'] = features  # (B, 128, num_proposal)
         end_points['aggregated_vote_inds'] = sample_inds   # (B, num_proposal)
 
-        net = F.relu(self.bn1(self.conv1(features)))
-        net = F.relu(self.bn2(self.conv2(net)))
-        net = self.conv3(net)
+        net = fused_mlp.run_chain(features, [(self.conv1, self.bn1, True),
+                                             (self.conv2, self.bn2, True),
+                                             (self.conv3, None, False)])
+        if net is None:   # stock ops (CPU, eval mode, BTR_FUSED_MLP=0)
+            net = F.relu(self.bn1(self.conv1(features)))
+            net = F.relu(self.bn2(self.conv2(net)))
+            net = self.conv3(net)
         end_points['_head_output'] = net  # raw (B, Cout, K) scores for the fused loss
         return decode_scores(net, end_points, self.num_class, self.num_heading_bin,
                              self.num_size_cluster, self.mean_size_arr, self._mean_size_dev)

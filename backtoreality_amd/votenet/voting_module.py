@@ -4,6 +4,8 @@ votes = seed xyz + predicted offset, vote features = seed features + predicted r
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..pointnet2 import fused_mlp
+
 
 class VotingModule(nn.Module):
     def __init__(self, vote_factor, seed_feature_dim):
@@ -21,9 +23,14 @@ class VotingModule(nn.Module):
         """seed_xyz (B,S,3), seed_features (B,C,S) -> vote_xyz (B,S*vf,3), vote_features (B,C,S*vf)."""
         B, S = seed_xyz.shape[0], seed_xyz.shape[1]
         V = S * self.vote_factor
-        net = F.relu(self.bn1(self.conv1(seed_features)))
-        net = F.relu(self.bn2(self.conv2(net)))
-        net = self.conv3(net).transpose(2, 1).view(B, S, self.vote_factor, 3 + self.out_dim)
+        net = fused_mlp.run_chain(seed_features, [(self.conv1, self.bn1, True),
+                                                  (self.conv2, self.bn2, True),
+                                                  (self.conv3, None, False)])
+        if net is None:   # stock ops (CPU, eval mode, BTR_FUSED_MLP=0)
+            net = F.relu(self.bn1(self.conv1(seed_features)))
+            net = F.relu(self.bn2(self.conv2(net)))
+            net = self.conv3(net)
+        net = net.transpose(2, 1).view(B, S, self.vote_factor, 3 + self.out_dim)
         vote_xyz = (seed_xyz.unsqueeze(2) + net[:, :, :, 0:3]).contiguous().view(B, V, 3)
         vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[:, :, :, 3:]
         vote_features = vote_features.contiguous().view(B, V, self.out_dim)

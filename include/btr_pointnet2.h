@@ -347,6 +347,17 @@ int btr_points_in_boxes(int b, int n, int k, int point_stride, int cap, const fl
 int btr_box3d_iou(int nscene, int p, int g, const double *corners1, const double *corners2,
                   double *iou, btr_stream_t stream);
 
+/* ---- ball query over the FPS's spatial sort ---------------------------------------------------
+ * Same result as btr_ball_query (ball_query_gpu.cu:14-49).  `fps_workspace`: the workspace a
+ * preceding btr_furthest_point_sampling_ws call ON THE SAME xyz (n > 4096) was given; it still
+ * holds the cloud sorted along a Hilbert curve in 64-point buckets, which this call searches
+ * instead of counting-sorting the cloud again (csrc/ball_query_bucket.hip).  The workspace
+ * size is 0 when the shape is not supported (use btr_ball_query_ws then). */
+size_t btr_ball_query_buckets_workspace_bytes(int b, int n, int m, int nsample);
+int btr_ball_query_buckets(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                           const void *fps_workspace, int *idx, void *workspace,
+                           size_t workspace_bytes, btr_stream_t stream);
+
 /* ---- compact rows of the fused set-abstraction path ------------------------------------------
  * The reference runs its shared MLP over ALL nsample rows of every group although a ball-query
  * row is its distinct hits followed by copies of the first one (ball_query_gpu.cu:39-43;
@@ -381,6 +392,20 @@ size_t btr_sac_scatter_workspace_bytes(int b, int n, int max_rows);
 int btr_sac_scatter(int b, int n, int m, int c, int ldx, int use_xyz, const float *dx0,
                     const int *cidx, const int *goff, float *dfeat_cl, void *workspace,
                     size_t workspace_bytes, int max_rows, btr_stream_t stream);
+
+/* ---- point-wise MLP chains (feature propagation, vote generator, proposal head) --------------
+ * reference: pytorch_utils.SharedMLP / Conv1d + BatchNorm1d + ReLU sequences
+ * (pointnet2_modules.py:469-514, models/voting_module.py:37-56, models/proposal_module.py:75-113)
+ * on channel-last rows (B*N, C).  btr_pm_gemm_nt = btr_sa_gemm_nt on 64-row tiles (these
+ * problems have 2 048 - 16 384 rows) with an optional bias; the BatchNorm statistics /
+ * backward / weight-gradient entry points of the btr_sa_* family are shared. */
+int btr_pm_gemm_grid(int rows);
+int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
+                   float *c, int ldc, const float *pa, const float *pb, float *part,
+                   const float *bias, btr_stream_t stream);
+int btr_pm_out(int b, int n, int c, int ldy, const float *y, const float *scale,
+               const float *shift, int relu, float *out_bcn, float *out_cl, btr_stream_t stream);
+int btr_pm_rows(int b, int n, int c, int ldr, const float *x, float *rows, btr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,88 @@
+"""Fused point-wise MLP chains (backtoreality_amd/pointnet2/fused_mlp.py) against the stock
+torch ops they replace, on the GPU: same module, weights, inputs; outputs, every gradient and
+the BatchNorm running statistics."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from backtoreality_amd.pointnet2 import pointnet2_modules as M
+from backtoreality_amd.votenet import config, proposal_module, voting_module
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _compare(run, mod, monkeypatch, zero_ok=()):
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BTR_FUSED_MLP", flag)
+        m = copy.deepcopy(mod)
+        outs, ins = run(m)
+        loss = sum((o * torch.linspace(0.5, 1.5, o.numel(), device=o.device).view_as(o)).sum()
+                   for o in outs)
+        loss.backward()
+        res[flag] = {"out%d" % i: o.detach() for i, o in enumerate(outs)}
+        res[flag].update({"din%d" % i: t.grad for i, t in enumerate(ins)})
+        res[flag].update({"d" + n: p.grad for n, p in m.named_parameters()})
+        res[flag].update({n: b.detach().clone().float() for n, b in m.named_buffers()})
+    for k, want in res["0"].items():
+        got = res["1"][k]
+        if any(z in k for z in zero_ok):   # bias in front of a BatchNorm: true gradient 0
+            assert float(got.abs().max()) <= 1e-5 * (1 + float(want.abs().max())), k
+            continue
+        tol = 1e-4 if k.startswith("out") or "running" in k or "tracked" in k else 5e-4
+        assert got.shape == want.shape, k
+        assert _rel(got, want) < tol, (k, _rel(got, want))
+
+
+def test_fp_module_mlp(cuda, monkeypatch):
+    torch.manual_seed(0)
+    fp = M.PointnetFPModule(mlp=[256 + 256, 256, 256]).to(cuda)
+    with torch.no_grad():
+        for layer in fp.mlp:
+            layer.bn.bn.weight.uniform_(0.5, 1.5)
+            layer.bn.bn.bias.uniform_(-0.3, 0.3)
+    unknown = torch.rand(2, 1024, 3, device=cuda)
+    known = unknown[:, :512].contiguous()
+    uf = torch.randn(2, 256, 1024, device=cuda)
+    kf = torch.randn(2, 256, 512, device=cuda)
+
+    def run(m):
+        a, b = uf.clone().requires_grad_(True), kf.clone().requires_grad_(True)
+        return [m(unknown, known, a, b)], [a, b]
+    _compare(run, fp, monkeypatch)
+
+
+def test_voting_module(cuda, monkeypatch):
+    torch.manual_seed(1)
+    vg = voting_module.VotingModule(1, 256).to(cuda)
+    xyz = torch.rand(2, 1024, 3, device=cuda)
+    feats = torch.randn(2, 256, 1024, device=cuda)
+
+    def run(m):
+        f = feats.clone().requires_grad_(True)
+        vx, vf = m(xyz, f)
+        return [vx, vf], [f]
+    _compare(run, vg, monkeypatch, zero_ok=("dconv1.bias", "dconv2.bias"))
+
+
+def test_proposal_head(cuda, monkeypatch):
+    cfg = config.scannet_md40()
+    torch.manual_seed(2)
+    pm = proposal_module.ProposalModule(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                        cfg.mean_size_arr, 64, 'vote_fps').to(cuda)
+    xyz = torch.rand(2, 512, 3, device=cuda) * 2
+    feats = torch.randn(2, 256, 512, device=cuda) * 0.1
+    monkeypatch.setenv("BTR_FUSED_SA", "0")   # the head is what is compared here
+
+    def run(m):
+        x = xyz.clone().requires_grad_(True)
+        f = feats.clone().requires_grad_(True)
+        end = m(x, f, {'seed_xyz': xyz})
+        return [end['_head_output'], end['center']], [x, f]
+    _compare(run, pm, monkeypatch, zero_ok=("dconv1.bias", "dconv2.bias"))

@@ -194,6 +194,31 @@ def test_ball_query_grid_matches_oracle_and_brute_force(cuda, monkeypatch, kind,
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("kind,B,N,M,r,S,scale", [("surface", 8, 40000, 2048, 0.2, 64, 1.0),
+                                                  ("surface", 2, 80000, 2048, 0.2, 64, 1.7),
+                                                  ("uniform", 2, 30000, 1024, 0.3, 32, 1.0),
+                                                  ("surface", 3, 5000, 700, 0.25, 16, 1.0),
+                                                  ("surface", 2, 131000, 512, 0.1, 64, 2.0)])
+def test_ball_query_over_the_fps_buckets(cuda, monkeypatch, kind, B, N, M, r, S, scale):
+    """A ball query of the tensor the large-scene FPS has just sorted searches that sort
+    (csrc/ball_query_bucket.hip) instead of building a grid: oracle-exact, identical to the
+    grid path, including centres that are NOT points of the cloud."""
+    xyz = _scene_xyz(B, N, first=20, kind=kind) * np.array([scale, scale, 1.0], np.float32)
+    x = _t(xyz, cuda)
+    inds = _ext().furthest_point_sampling(x, M)
+    assert getattr(x, "_btr_fps_ws", None) is not None
+    new = torch.gather(x, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    new[:, ::7] += 0.03                      # off-cloud centres
+    new[:, 5] = 100.0                        # one centre far outside: empty ball -> zeros
+    ref = oracle.ball_query(new.cpu().numpy(), xyz, r, S)
+    before = dict(_ext().BQ_CALLS)
+    got = _ext().ball_query(new, x, r, S).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    assert _ext().BQ_CALLS["buckets"] == before["buckets"] + 1, "the bucket path was not taken"
+    monkeypatch.setenv("BTR_BQ_BUCKETS", "0")
+    np.testing.assert_array_equal(_ext().ball_query(new, x, r, S).cpu().numpy(), ref)
+
+
 def test_ball_query_grid_duplicates_and_dense(cuda):
     rng = np.random.default_rng(21)
     xyz = rng.uniform(0, 2, size=(1, 12000, 3)).astype(np.float32)

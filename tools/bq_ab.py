@@ -22,4 +22,4 @@ for (B, N, M, r, S, scale) in ((8, 40000, 2048, 0.2, 64, 1.0), (4, 50000, 2048, 
     med, mn = timeit(lambda: _ext.ball_query(new_xyz, xyz, r, S), iters=20)
     print("B=%d N=%d scale %.1f build=%s: median %.1f us min %.1f us  checksum %d" % (
         B, N, scale, os.environ.get("BTR_BQ_BUILD", "fused"), med * 1e3, mn * 1e3,
-        int(idx.long().sum())), flush=True)
+        int(idx.long().sum())), _ext.BQ_CALLS, flush=True)
