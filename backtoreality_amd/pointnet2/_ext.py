@@ -224,6 +224,11 @@ def timing_end():
     return out
 
 
+def timing_detail():
+    """True inside a fully instrumented region (timing_begin() without a filter)."""
+    return _TIMING is not None and _TIMING_FILTER is None
+
+
 def _call(fn, *args, key=None):
     timed = _TIMING is not None and key is not None
     if timed and _TIMING_FILTER is not None:

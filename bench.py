@@ -45,7 +45,7 @@ def parse():
     p.add_argument("--sequential", action="store_true",
                    help="time the strictly sequential loop (every step computes its own sampling "
                         "pyramid first) instead of the software-pipelined one")
-    p.add_argument("--no-sequential", "--no-pipelined", dest="no_sequential", action="store_true",
+    p.add_argument("--no-sequential", dest="no_sequential", action="store_true",
                    help="skip the secondary (informational) sequential loop")
     p.add_argument("--workload", choices=["fsb", "br", "cr", "gf", "gfbr"], default="fsb",
                    help="fsb: VoteNet FSB step (BASELINE configs[1], the headline); br: the "
@@ -282,10 +282,11 @@ def main():
     train.freeze_gc()  # host runtime hygiene (see train.freeze_gc); no effect on the GPU work
     # Timed region: HIP event pairs only around the two kernels the metric names (the
     # large-scene FPS = dominant hand-written kernel, and the SA1 ball query): 2 pairs/step.
-    _ext.timing_begin(lambda op, key: op in ("furthest_point_sampling", "ball_query")
-                      and key[1] > 4096)
+    _ext.timing_begin(lambda op, key: op in ("furthest_point_sampling", "ball_query",
+                                             "ball_query_buckets") and key[1] > 4096)
     t0 = time.perf_counter()
     run_steps(args.steps)
+    enqueue = time.perf_counter() - t0   # host side done (launches queued), GPU still running
     barrier()
     elapsed = time.perf_counter() - t0
     kernels = _ext.timing_end()
@@ -324,6 +325,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            # how long the host needed to queue the K steps (== ms_per_step: host-bound)
+            "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -387,7 +390,7 @@ def pmc_traffic(substr):
 # every f32-MFMA GEMM entry point of the fused SA path (csrc/sa_mlp.hip): forward NT (plain,
 # recompute, pool-epilogue), dgrad NT (plain, pooled), wgrad TN (plain, pooled, recompute)
 GEMM_OPS = ("sa_gemm_nt", "sa_gemm_nt_rc", "sa_gemm_nt_poolfwd", "sa_gemm_nt_pool",
-            "sa_gemm_tn", "sa_gemm_tn_rc", "sa_gemm_tn_pool")
+            "sa_gemm_tn", "sa_gemm_tn_rc", "sa_gemm_tn_pool", "pm_gemm_nt")
 
 
 def roofline_objects(kernels, detail, detail_steps):
@@ -409,17 +412,27 @@ def roofline_objects(kernels, detail, detail_steps):
         _, key, times = max(cands)
         return key, sum(times) / len(times)
 
-    bq = pick("ball_query")
+    bq_buckets = pick("ball_query_buckets")   # over the FPS's spatial sort (the default)
+    bq = bq_buckets or pick("ball_query")      # own grid build (no FPS workspace to reuse)
     if bq:
         (b, n, m, s), ms = bq
         nbytes = b * (12 * n + 12 * m + 4 * m * s)
         ach = nbytes / (ms * 1e-3) / 1e9
         res["ball_query_roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                      "traffic": pmc_traffic("bq_grid_query_kernel"),
+                                      "traffic": pmc_traffic("bqb_query_kernel" if bq_buckets
+                                                             else "bq_grid_query_kernel"),
                                       "algorithmic_bytes": nbytes,
                                       "shape": [b, n, m, s], "avg_ms": ms,
-                                      "note": "grid-culled query incl. the one-launch grid build (2 launches)"}
+                                      "kernel": ("bqb_query_kernel (+bqb_box_kernel, "
+                                                 "bqb_super_kernel)" if bq_buckets else
+                                                 "bq_grid_query_kernel (+grid build)"),
+                                      "note": ("query over the Hilbert buckets the FPS of the "
+                                               "same scene built (3 launches: bucket boxes, "
+                                               "super-bucket boxes, query); `traffic` is the "
+                                               "query kernel's" if bq_buckets else
+                                               "grid-culled query incl. the one-launch grid "
+                                               "build (2 launches)")}
     # grouped shared MLP: every f32-MFMA GEMM launch of the fused SA path (fwd NT with BN
     # prologue/epilogue, dgrad NT, wgrad TN); flops = 2*rows*n*k per launch
     gemm = [(k, t) for (o, k), t in detail.items() if o in GEMM_OPS]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""cProfile of the host side of the training step (where does enqueue time go?)."""
-import cProfile, os, pstats, sys, io
+"""cProfile of the host side of the software-pipelined training step (where does the enqueue
+time go?).  A small batch, so that the GPU never holds the host back."""
+import cProfile, os, pstats, sys, io, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -9,16 +10,33 @@ dev = torch.device("cuda:0")
 cfg = config.scannet_md40()
 net = train.build_model(cfg, dev)
 opt = train.make_optimizer(net)
-batch = synthetic.make_batch(0, 1, 4096, cfg, device=dev)
-for _ in range(4):
-    train.train_step(net, opt, batch, cfg)
+B, N = int(os.environ.get("HP_B", 2)), int(os.environ.get("HP_N", 20000))
+batches = [synthetic.make_batch(s, B, N, cfg, device=dev) for s in (0, 1)]
+
+
+def loop(n):
+    sampling = net.backbone_net.prefetch_sampling(batches[0]['point_clouds'])
+    for i in range(n):
+        out = train.train_step(net, opt, batches[i % 2], cfg, sampling=sampling,
+                               next_batch=batches[(i + 1) % 2])
+        sampling = out[1].get('next_sampling')
+
+
+loop(5)
 torch.cuda.synchronize()
+train.freeze_gc()
+t0 = time.perf_counter()
+loop(20)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host enqueue %.2f ms/step, to GPU idle %.2f ms/step" % ((t1 - t0) * 50, (t2 - t0) * 50))
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(10):
-    train.train_step(net, opt, batch, cfg)
-torch.cuda.synchronize()
+loop(20)
 pr.disable()
-st = io.StringIO()
-pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45)
-print(st.getvalue()[:9000])
+torch.cuda.synchronize()
+for key in ("tottime", "cumulative"):
+    st = io.StringIO()
+    pstats.Stats(pr, stream=st).sort_stats(key).print_stats(38)
+    print(st.getvalue()[:7500])

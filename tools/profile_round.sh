@@ -7,12 +7,12 @@
 # travel); copy what should be judged into profiles/.
 set -e
 TAG=${1:-round}
-ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-pipelined"
+ARGS="--steps 3 --warmup 2 --no-cpu-baseline --sequential"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/$TAG.*
-rocprofv3 --kernel-trace --stats -d /tmp/$TAG.kt -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-pipelined > $OUT/bench_under_profiler.json 2>/tmp/$TAG.kt.err
+rocprofv3 --kernel-trace --stats -d /tmp/$TAG.kt -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --sequential > $OUT/bench_under_profiler.json 2>/tmp/$TAG.kt.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/$TAG.fetch -o r -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > /dev/null 2>/tmp/$TAG.fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/$TAG.write -o r -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > /dev/null 2>/tmp/$TAG.write.err
 cd $GRAFT_REPO_ROOT
@@ -24,4 +24,7 @@ python tools/rocpd_stats.py $KT $OUT/kernel_stats.md
 python tools/rocpd_pmc.py $FE $OUT/pmc_FETCH_SIZE.md
 python tools/rocpd_pmc.py $WR $OUT/pmc_WRITE_SIZE.md
 python tools/pmc_traffic.py $FE $WR $OUT/pmc_traffic.json
-head -3 $OUT/one_step.md
+python tools/recompute_roofline.py $OUT/bench_under_profiler.json $OUT/one_step.md > $OUT/roofline_check.md
+# the headline loop (software-pipelined) and the sequential loop beside it, no profiler attached
+python bench.py > $OUT/bench.json 2>/dev/null
+head -3 $OUT/one_step.md; cat $OUT/roofline_check.md; tail -c 600 $OUT/bench.json

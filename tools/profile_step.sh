@@ -6,7 +6,7 @@ set -e
 TAG=${1:-prof}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/$TAG
-rocprofv3 --kernel-trace -d /tmp/$TAG -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-pipelined > /tmp/$TAG.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/$TAG -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --sequential > /tmp/$TAG.log 2>&1
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 DB=$(find /tmp/$TAG -name "*.db" | head -1)

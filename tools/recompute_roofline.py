@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Rebuild the three roofline fractions of a bench.py line from the rocprofv3 one-step table
+of the same command, so the live HIP-event figures can be checked against the profiler's:
+
+    tools/recompute_roofline.py profiles/r02_x_bench.json profiles/r02_x_one_step.md
+
+Taken from the JSON line: only the ALGORITHMIC work (bytes per launch of the FPS and the ball
+query, flops per step of the MFMA GEMM family) -- functions of the shapes, not measurements.
+Taken from the profile: the kernel durations (tools/rocpd_step.py: per kernel name the calls,
+the summed and the longest duration inside one steady-state step).
+
+  FPS         fps_bucket_kernel's longest call + the fps_sortm_* launches of that scene batch
+  ball query  the longest bqb_query_kernel (or bq_grid_query_kernel) call + its set-up
+              launches (bqb_box / bqb_super, or the grid build), longest call of each
+  grouped MLP every gemm_nt_kernel / gemm_tn_kernel launch of the step (+ reduce_chunks, the
+              second half of the TN GEMM's split-K) against the f32 MFMA peak
+
+Prints a table: live figure (JSON), profile figure, ratio."""
+import json
+import re
+import sys
+
+HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TF = 157.3
+
+
+def read_table(path):
+    rows = []
+    for line in open(path):
+        m = re.match(r"\| `(.*)` \| (\d+) \| ([\d.]+) \| ([\d.]+) \|(?: ([\d.]+) \|)?", line)
+        if m:
+            name, calls, tot, _, longest = m.groups()
+            rows.append((name, int(calls), float(tot),
+                         float(longest) if longest else float(tot) / int(calls)))
+    return rows
+
+
+def main():
+    line = [l for l in open(sys.argv[1]) if l.lstrip().startswith("{")][-1]
+    js = json.loads(line)
+    rows = read_table(sys.argv[2])
+
+    def longest(sub):
+        c = [r[3] for r in rows if sub in r[0]]
+        return max(c) if c else 0.0
+
+    def total(sub):
+        return sum(r[2] for r in rows if sub in r[0])
+
+    out = []
+    fps = js.get("roofline")
+    if fps:
+        us = longest("fps_bucket_kernel") + sum(r[3] for r in rows if "fps_sortm_" in r[0])
+        ach = fps["algorithmic_bytes"] / (us * 1e-6) / 1e9
+        out.append(("roofline (FPS)", fps["avg_ms"] * 1e3, us, fps["frac"], ach / HBM_PEAK_GBS))
+    bq = js.get("ball_query_roofline")
+    if bq:
+        if longest("bqb_query_kernel"):
+            us = longest("bqb_query_kernel") + longest("bqb_box_kernel") + \
+                longest("bqb_super_kernel")
+        else:
+            us = longest("bq_grid_query_kernel") + longest("bq_grid_build")
+        ach = bq["algorithmic_bytes"] / (us * 1e-6) / 1e9
+        out.append(("ball_query_roofline", bq["avg_ms"] * 1e3, us, bq["frac"],
+                    ach / HBM_PEAK_GBS))
+    mlp = js.get("mlp_roofline")
+    if mlp:
+        us = total("gemm_nt_kernel") + total("gemm_tn_kernel") + total("reduce_chunks_kernel")
+        ach = mlp["gflop_per_step"] * 1e9 / (us * 1e-6) / 1e12
+        out.append(("mlp_roofline", mlp["ms_per_step"] * 1e3, us, mlp["frac"],
+                    ach / MFMA_F32_PEAK_TF))
+    print("| object | live us | profile us | live frac | profile frac | profile/live time |")
+    print("|---|---|---|---|---|---|")
+    for name, live_us, prof_us, lf, pf in out:
+        print("| %s | %.1f | %.1f | %.5f | %.5f | %.3f |" % (name, live_us, prof_us, lf, pf,
+                                                             prof_us / live_us))
+
+
+if __name__ == "__main__":
+    main()

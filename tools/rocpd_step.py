@@ -26,16 +26,18 @@ def main():
     agg = {}
     for n, s, e in rows:
         if t0 <= s < t1:
-            a = agg.setdefault(n, [0, 0])
+            a = agg.setdefault(n, [0, 0, 0])
             a[0] += 1
             a[1] += e - s
+            a[2] = max(a[2], e - s)
     busy = sum(v[1] for v in agg.values())
     lines = ["step window: %.3f ms wall, %.3f ms kernel-busy, %d dispatches" % (
         (t1 - t0) / 1e6, busy / 1e6, sum(v[0] for v in agg.values())), "",
-        "| kernel | calls | total us | % of busy |", "|---|---|---|---|"]
-    for n, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        "| kernel | calls | total us | % of busy | longest call us |", "|---|---|---|---|---|"]
+    for n, (cnt, tot, longest) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         short = n if len(n) <= 100 else n[:97] + "..."
-        lines.append("| `%s` | %d | %.1f | %.2f |" % (short, cnt, tot / 1e3, 100.0 * tot / busy))
+        lines.append("| `%s` | %d | %.1f | %.2f | %.1f |" % (short, cnt, tot / 1e3,
+                                                            100.0 * tot / busy, longest / 1e3))
     text = "\n".join(lines) + "\n"
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(text)
