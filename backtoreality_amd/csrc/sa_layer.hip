@@ -1,0 +1,678 @@
+// sa_layer.hip -- whole-layer entry points: one set-abstraction layer (grouping + shared MLP +
+// max-pool) or one point-wise MLP chain per call, forward and backward.
+//
+// Nothing here computes: these functions SEQUENCE the btr_sa_* / btr_sac_* / btr_pm_* launches
+// of sa_mlp.hip, exactly as a caller of those entry points would (the Python orchestration in
+// pointnet2/fused_sa.py / fused_mlp.py is kept as the readable statement of the same sequence
+// and as the test oracle for this file: both must give bit-identical results).  Why it exists:
+// the VoteNet step is ~400 launches; issued one binding call at a time (argument marshalling,
+// one allocator call per intermediate) the host needs ~6.5 ms per step, more than the GPU needs
+// to run them.  Here a layer costs the host one call, and its intermediates live at fixed
+// offsets of three caller-provided buffers (saved for backward / scratch / flat gradients).
+//
+// reference: PointnetSAModuleVotes.forward (pointnet2/pointnet2_modules.py:243-267), SharedMLP
+// (pointnet2/pytorch_utils.py:11-36), the Conv1d+BatchNorm1d+ReLU chains of
+// models/voting_module.py:37-56 and models/proposal_module.py:75-113, and their autograd
+// backward.
+#include <algorithm>
+#include <cstring>
+
+#include "common.hpp"
+
+namespace btr {
+namespace {
+
+constexpr int kMaxL = BTR_MAX_LAYERS;
+constexpr size_t kAlign = 256;
+
+inline int ceil4(int v) { return (v + 3) / 4 * 4; }
+inline size_t up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+// Bump allocator over a byte range the caller owns (offsets only: usable for planning too).
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t at = off;
+    off = up(off + bytes);
+    return at;
+  }
+  size_t floats(size_t n) { return take(n * sizeof(float)); }
+};
+
+// ---------------------------------------------------------------- weight preparation kernel
+// One launch per layer stack: W2[l] = W[l] zero-padded to (np[l], kin[l]) and Wt[l] = W2[l]^T
+// (the operands of the forward / input-gradient GEMMs), and num_batches_tracked += 1.
+struct PrepArgs {
+  const float *w[kMaxL];
+  float *w2[kMaxL];
+  float *wt[kMaxL];
+  int n[kMaxL];      // rows of W
+  int np[kMaxL];     // rows of W2 (zero rows beyond n)
+  int kraw[kMaxL];   // columns of W
+  int kin[kMaxL];    // columns of W2 (zero columns beyond kraw)
+  int first[kMaxL + 1];  // first block of layer l
+  long long *nbt[kMaxL];
+  float *rmean[kMaxL];      // running_mean += mom * bias (NULL: nothing)
+  const float *rbias[kMaxL];
+  float mom[kMaxL];
+  int layers;
+};
+
+__global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
+  // the layer of this block: a fully unrolled scan with STATIC indices (a run-time index into
+  // the by-value argument arrays would make the compiler spill the whole struct to scratch)
+  const float *w = a.w[0];
+  float *w2 = a.w2[0], *wt = a.wt[0];
+  long long *nbt = a.nbt[0];
+  int n = a.n[0], np = a.np[0], kraw = a.kraw[0], kin = a.kin[0], first = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxL; ++i)
+    if (i < a.layers && (int)blockIdx.x >= a.first[i]) {
+      w = a.w[i]; w2 = a.w2[i]; wt = a.wt[i]; nbt = a.nbt[i];
+      n = a.n[i]; np = a.np[i]; kraw = a.kraw[i]; kin = a.kin[i]; first = a.first[i];
+    }
+  const int total = np * kin;
+  const int e = ((int)blockIdx.x - first) * 256 + (int)threadIdx.x;
+  if (e < total) {
+    const int r = e / kin, c = e - r * kin;
+    const float v = (r < n && c < kraw) ? w[(size_t)r * kraw + c] : 0.f;
+    w2[e] = v;
+    wt[(size_t)c * np + r] = v;
+  }
+  if ((int)blockIdx.x == first && threadIdx.x == 0 && nbt) *nbt += 1;
+}
+
+// running_mean[l] += momentum * bias[l] for the conv biases skipped in front of a BatchNorm
+// (AFTER bn_finalize has blended the batch mean in); one block per layer
+__global__ __launch_bounds__(256) void bias_running_mean_kernel(PrepArgs a) {
+#pragma unroll
+  for (int i = 0; i < kMaxL; ++i)   // static indices, see prep_weights_kernel
+    if (i == (int)blockIdx.x && a.rmean[i])
+      for (int c = threadIdx.x; c < a.n[i]; c += 256) a.rmean[i][c] += a.mom[i] * a.rbias[i][c];
+}
+
+// out[c] = sum_r g[r][c]  (bias gradient of a bare last layer), two deterministic stages:
+// part[chunk][c] = sum over the chunk's rows (grid: column tiles x chunks), then the chunks.
+constexpr int kColsumRows = 128;   // rows per chunk
+__global__ __launch_bounds__(256) void colsum_part_kernel(int rows, int c, int ld,
+                                                          const float *__restrict__ g,
+                                                          float *__restrict__ part) {
+  __shared__ float red[4][64];
+  const int col = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);
+  const int sub = (int)(threadIdx.x >> 6);
+  const int r0 = (int)blockIdx.y * kColsumRows;
+  const int r1 = min(rows, r0 + kColsumRows);
+  float acc = 0.f;
+  if (col < c)
+    for (int r = r0 + sub; r < r1; r += 4) acc += g[(size_t)r * ld + col];
+  red[sub][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sub == 0 && col < c)
+    part[(size_t)blockIdx.y * c + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                                         (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(int chunks, int c,
+                                                           const float *__restrict__ part,
+                                                           float *__restrict__ out) {
+  const int col = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (col >= c) return;
+  float acc = 0.f;
+  for (int k = 0; k < chunks; ++k) acc += part[(size_t)k * c + col];
+  out[col] = acc;
+}
+
+struct Unbind {
+  ~Unbind() { btr_sac_bind(nullptr); }
+};
+
+#define BTR_TRY(call)            \
+  do {                           \
+    const int rc_ = (call);      \
+    if (rc_ != BTR_OK) return rc_; \
+  } while (0)
+
+inline float *at_f(void *base, size_t off) { return (float *)((char *)base + off); }
+inline int *at_i(void *base, size_t off) { return (int *)((char *)base + off); }
+inline unsigned char *at_b(void *base, size_t off) { return (unsigned char *)base + off; }
+
+inline bool pool_grad_ok(int s) { return s == 16 || s == 32 || s == 64 || s == 128; }
+
+// scratch layouts (recomputed identically by plan / forward / backward)
+struct SaFwdScratch {
+  size_t part, len_tmp, extg, exta, bytes;
+};
+struct SaBwdScratch {
+  size_t part, m1, m2, dcl, alpha, beta, pw, g[2], scat, dfeat_cl, bytes;
+  size_t scat_bytes;
+};
+
+SaFwdScratch sa_fwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
+  SaFwdScratch s{};
+  Bump b;
+  int maxn = 0;
+  for (int l = 0; l < d.layers; ++l) maxn = std::max(maxn, d.width[l]);
+  s.part = b.floats((size_t)btr_sa_gemm_grid(p.rows) * 2 * maxn);
+  s.len_tmp = b.take(sizeof(int) * (size_t)d.b * d.m);
+  const int cl = d.width[d.layers - 1];
+  const int ps = p.compact ? 8 : d.s;
+  const size_t ext = p.pool_epilogue ? (size_t)(p.rows / ps) * cl : 0;
+  s.extg = b.floats(ext);
+  s.exta = b.take(ext);
+  s.bytes = b.off;
+  return s;
+}
+
+SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
+  SaBwdScratch s{};
+  Bump b;
+  int maxc = 0, maxk = 0;
+  size_t pw = 0;
+  for (int l = 0; l < d.layers; ++l) {
+    maxc = std::max(maxc, d.width[l]);
+    maxk = std::max(maxk, p.kin[l]);
+    pw = std::max(pw, (size_t)btr_sa_gemm_tn_chunks(p.rows, d.width[l], p.kin[l]) * d.width[l] *
+                          p.kin[l]);
+  }
+  if (p.recompute) pw = std::max(pw, (size_t)btr_sa_rc_wgrad_blocks(p.rows, d.width[0]) * d.width[0] * 4);
+  const int cl = d.width[d.layers - 1];
+  s.part = b.floats((size_t)1024 * 2 * maxc);
+  s.m1 = b.floats(maxc);
+  s.m2 = b.floats(maxc);
+  s.dcl = b.floats((size_t)d.b * d.m * cl);
+  s.alpha = b.floats(cl);
+  s.beta = b.floats(cl);
+  s.pw = b.floats(pw);
+  s.g[0] = b.floats((size_t)p.rows * maxk);
+  s.g[1] = b.floats((size_t)p.rows * maxk);
+  s.scat_bytes = p.compact ? btr_sac_scatter_workspace_bytes(d.b, d.n, p.rows)
+                           : btr_sa_scatter_workspace_bytes(d.b, d.n, d.m, d.s);
+  s.scat = b.take(s.scat_bytes);
+  s.dfeat_cl = b.floats((size_t)d.b * d.n * std::max(d.c, 1));
+  s.bytes = b.off;
+  return s;
+}
+
+}  // namespace
+}  // namespace btr
+
+using namespace btr;
+
+extern "C" {
+
+int btr_sa_layer_plan(const btr_sa_layer_t *dp, btr_sa_plan_t *p) {
+  BTR_REQUIRE(dp && p, "sa_layer_plan: null pointer");
+  const btr_sa_layer_t &d = *dp;
+  BTR_REQUIRE(d.layers >= 1 && d.layers <= kMaxL, "sa_layer_plan: %d layers", d.layers);
+  BTR_REQUIRE(d.b > 0 && d.n > 0 && d.m > 0 && d.s > 0 && d.s <= 255 && d.c >= 0,
+              "sa_layer_plan: bad sizes (b=%d n=%d m=%d s=%d c=%d)", d.b, d.n, d.m, d.s, d.c);
+  BTR_REQUIRE((long long)d.b * d.m * d.s < (1ll << 31), "sa_layer_plan: too many rows");
+  std::memset(p, 0, sizeof(*p));
+  const int L = d.layers;
+  p->rows = d.b * d.m * d.s;
+  p->k0 = (d.use_xyz ? 3 : 0) + d.c;
+  BTR_REQUIRE(p->k0 > 0, "sa_layer_plan: neither coordinates nor features");
+  p->k0p = ceil4(p->k0);
+  for (int l = 0; l < L; ++l) {
+    BTR_REQUIRE(d.width[l] > 0 && d.width[l] % 4 == 0, "sa_layer_plan: width %d", d.width[l]);
+    p->kin[l] = l == 0 ? p->k0p : d.width[l - 1];
+  }
+  const bool any_in = d.need_dxyz || d.need_dnew_xyz || d.need_dfeat;
+  p->pool_grad = (d.options & BTR_SA_OPT_POOL_GRAD) && pool_grad_ok(d.s);
+  const bool epi_allowed = (d.options & BTR_SA_OPT_POOL_EPILOGUE) != 0;
+  p->compact = (d.options & BTR_SA_OPT_COMPACT) && d.s >= 32 && d.s % 8 == 0 && L >= 2 &&
+               d.width[L - 1] > 64 && epi_allowed && p->pool_grad && !d.need_dxyz &&
+               !d.need_dnew_xyz && (!d.need_dfeat || d.n <= 8192) &&
+               (long long)d.b * ((d.m + 63) / 64) <= 1024;
+  p->recompute = (d.options & BTR_SA_OPT_RECOMPUTE) && p->k0p == 4 && L >= 3 && !any_in;
+  p->pool_epilogue = epi_allowed && L >= 2 &&
+                     btr_sa_gemm_nt_poolfwd_supported(p->rows, d.width[L - 1],
+                                                      p->compact ? 8 : d.s);
+  BTR_REQUIRE(!p->compact || p->pool_epilogue, "sa_layer_plan: compact rows without epilogue");
+  Bump sv;
+  p->x0 = sv.floats((size_t)p->rows * p->k0p);
+  for (int l = 0; l < L; ++l) {
+    p->y[l] = sv.floats((p->recompute && l == 0) ? 0 : (size_t)p->rows * d.width[l]);
+    p->w2[l] = sv.floats((size_t)d.width[l] * p->kin[l]);
+    p->wt[l] = sv.floats((size_t)d.width[l] * p->kin[l]);
+    p->stats[l] = sv.floats((size_t)4 * d.width[l]);
+  }
+  p->arg = sv.take((size_t)d.b * d.m * d.width[L - 1]);
+  if (p->compact) {
+    p->goff = sv.take(sizeof(int) * ((size_t)d.b * d.m + 1));
+    p->dims = sv.take(sizeof(int) * 2);
+    p->cidx = sv.take(sizeof(int) * (size_t)p->rows);
+    p->bgrp = sv.take(sizeof(int) * (size_t)(p->rows / 8));
+    p->bw = sv.take(sizeof(float) * (size_t)(p->rows / 8));
+  }
+  p->saved_bytes = sv.off;
+  p->fwd_scratch_bytes = sa_fwd_scratch(d, *p).bytes;
+  p->bwd_scratch_bytes = sa_bwd_scratch(d, *p).bytes;
+  size_t g = 0;
+  for (int l = 0; l < L; ++l) {
+    p->dw[l] = g;
+    g += (size_t)d.width[l] * p->kin[l];
+    p->dgamma[l] = g;
+    g += d.width[l];
+    p->dbeta[l] = g;
+    g += d.width[l];
+  }
+  p->grads_floats = g;
+  return BTR_OK;
+}
+
+int btr_sa_layer_forward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, const float *xyz,
+                         const float *new_xyz, const float *feats_cl, const int *idx, float *out,
+                         float *out_cl, void *saved, void *scratch, btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && xyz && new_xyz && idx && out && saved && scratch,
+              "sa_layer_forward: null pointer");
+  const btr_sa_layer_t &d = *dp;
+  const btr_sa_plan_t &p = *pp;
+  const int L = d.layers, R = p.rows;
+  const SaFwdScratch sc = sa_fwd_scratch(d, p);
+  btr_sac_bind(nullptr);
+  Unbind unbind;
+
+  PrepArgs pa{};
+  pa.layers = L;
+  int blocks = 0;
+  for (int l = 0; l < L; ++l) {
+    BTR_REQUIRE(d.w[l] && d.gamma[l] && d.beta[l], "sa_layer_forward: layer %d parameters", l);
+    pa.w[l] = d.w[l];
+    pa.w2[l] = at_f(saved, p.w2[l]);
+    pa.wt[l] = at_f(saved, p.wt[l]);
+    pa.n[l] = pa.np[l] = d.width[l];
+    pa.kraw[l] = l == 0 ? p.k0 : d.width[l - 1];
+    pa.kin[l] = p.kin[l];
+    pa.first[l] = blocks;
+    blocks += cdiv((long long)d.width[l] * p.kin[l], 256);
+    pa.nbt[l] = d.running_mean[l] ? d.num_batches_tracked[l] : nullptr;
+  }
+  pa.first[L] = blocks;
+  hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), pa);
+
+  float *x0 = at_f(saved, p.x0);
+  btr_compact_t cm{};
+  if (p.compact) {
+    cm.dims = at_i(saved, p.dims);
+    cm.bw = at_f(saved, p.bw);
+    cm.bgrp = at_i(saved, p.bgrp);
+    cm.goff = at_i(saved, p.goff);
+    cm.dense_rows = (double)R;
+    BTR_TRY(btr_sac_plan(d.b * d.m, d.s, idx, at_i(scratch, sc.len_tmp), at_i(saved, p.goff),
+                         at_i(saved, p.dims), at_i(saved, p.cidx), at_i(saved, p.bgrp),
+                         at_f(saved, p.bw), stream));
+    BTR_TRY(btr_sac_gather(d.b, d.n, d.m, R, d.c, p.k0p, d.use_xyz, d.radius_div, xyz, new_xyz,
+                           feats_cl, at_i(saved, p.cidx), at_i(saved, p.bgrp),
+                           at_i(saved, p.dims), x0, stream));
+    btr_sac_bind(&cm);
+  } else {
+    BTR_TRY(btr_sa_gather(d.b, d.n, d.m, d.s, d.c, p.k0p, d.use_xyz, d.radius_div, xyz, new_xyz,
+                          feats_cl, idx, x0, stream));
+  }
+  const int grid = btr_sa_gemm_grid(R);
+  float *part = at_f(scratch, sc.part);
+  float *extg = at_f(scratch, sc.extg);
+  unsigned char *exta = at_b(scratch, sc.exta);
+  const float *A = x0;
+  int lda = p.k0p;
+  const float *pscale = nullptr, *pshift = nullptr;
+  for (int l = 0; l < L; ++l) {
+    const int nl = d.width[l], k = p.kin[l];
+    const float *w2 = at_f(saved, p.w2[l]);
+    float *y = at_f(saved, p.y[l]);
+    if (p.recompute && l == 0) {  // statistics only
+      BTR_TRY(btr_sa_gemm_nt(R, nl, k, A, lda, w2, k, nullptr, nl, nullptr, nullptr, part, stream));
+    } else if (p.recompute && l == 1) {
+      BTR_TRY(btr_sa_gemm_nt_rc(R, nl, k, x0, at_f(saved, p.w2[0]), w2, k, y, nl, pscale, pshift,
+                                part, stream));
+    } else if (l == L - 1 && p.pool_epilogue) {
+      BTR_TRY(btr_sa_gemm_nt_poolfwd(R, nl, k, A, lda, w2, k, y, nl, pscale, pshift, part,
+                                     p.compact ? 8 : d.s, d.gamma[l], extg, exta, stream));
+    } else {
+      BTR_TRY(btr_sa_gemm_nt(R, nl, k, A, lda, w2, k, y, nl, pscale, pshift, part, stream));
+    }
+    float *st = at_f(saved, p.stats[l]);
+    BTR_TRY(btr_sa_bn_finalize(nl, grid, (double)R, d.eps[l], d.momentum[l], part, d.gamma[l],
+                               d.beta[l], st, st + nl, st + 2 * nl, st + 3 * nl,
+                               d.running_mean[l], d.running_var[l], stream));
+    A = y;
+    lda = nl;
+    pscale = st;
+    pshift = st + nl;
+  }
+  btr_sac_bind(nullptr);
+  const int cl = d.width[L - 1];
+  unsigned char *arg = at_b(saved, p.arg);
+  if (p.compact)
+    BTR_TRY(btr_sac_pool(d.b, d.m, cl, extg, exta, at_i(saved, p.goff), pscale, pshift, out,
+                         out_cl, arg, stream));
+  else if (p.pool_epilogue)
+    BTR_TRY(btr_sa_pool_fin(d.b, d.m, cl, extg, exta, pscale, pshift, out, out_cl, arg, stream));
+  else
+    BTR_TRY(btr_sa_pool(d.b, d.m, d.s, cl, cl, A, pscale, pshift, out, out_cl, arg, stream));
+  return check_launch("sa_layer_forward");
+}
+
+int btr_sa_layer_backward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, const int *idx,
+                          const float *out, const float *dout, void *saved, float *grads,
+                          float *dfeat, float *dxyz, float *dnew_xyz, void *scratch,
+                          btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && idx && out && dout && saved && grads && scratch,
+              "sa_layer_backward: null pointer");
+  const btr_sa_layer_t &d = *dp;
+  const btr_sa_plan_t &p = *pp;
+  const int L = d.layers, R = p.rows;
+  const SaBwdScratch sc = sa_bwd_scratch(d, p);
+  btr_sac_bind(nullptr);
+  Unbind unbind;
+  btr_compact_t cm{};
+  if (p.compact) {
+    cm.dims = at_i(saved, p.dims);
+    cm.bw = at_f(saved, p.bw);
+    cm.bgrp = at_i(saved, p.bgrp);
+    cm.goff = at_i(saved, p.goff);
+    cm.dense_rows = (double)R;
+    btr_sac_bind(&cm);
+  }
+  float *part = at_f(scratch, sc.part), *m1 = at_f(scratch, sc.m1), *m2 = at_f(scratch, sc.m2);
+  float *dcl = at_f(scratch, sc.dcl), *alpha = at_f(scratch, sc.alpha);
+  float *beta = at_f(scratch, sc.beta), *pw = at_f(scratch, sc.pw);
+  float *x0 = at_f(saved, p.x0);
+  const unsigned char *arg = at_b(saved, p.arg);
+  auto stat = [&](int l, int which) { return at_f(saved, p.stats[l]) + which * d.width[l]; };
+
+  const int cl = d.width[L - 1];
+  float *ylast = at_f(saved, p.y[L - 1]);
+  if (p.pool_grad)
+    BTR_TRY(btr_sa_pool_bwd_coef(d.b, d.m, d.s, cl, cl, ylast, dout, out, arg, stat(L - 1, 2),
+                                 stat(L - 1, 3), stat(L - 1, 0), stat(L - 1, 1), part, m1, m2,
+                                 grads + p.dgamma[L - 1], grads + p.dbeta[L - 1], dcl, alpha, beta,
+                                 stream));
+  else
+    BTR_TRY(btr_sa_pool_bwd(d.b, d.m, d.s, cl, cl, ylast, dout, out, arg, stat(L - 1, 2),
+                            stat(L - 1, 3), stat(L - 1, 0), part, m1, m2,
+                            grads + p.dgamma[L - 1], grads + p.dbeta[L - 1], stream));
+  const bool any_in = d.need_dxyz || d.need_dnew_xyz || d.need_dfeat;
+  float *dy = ylast;
+  int flip = 0;
+  for (int l = L - 1; l >= 0; --l) {
+    const int nl = d.width[l], k = p.kin[l];
+    const float *xsrc = l == 0 ? x0 : at_f(saved, p.y[l - 1]);
+    const int ldx = l == 0 ? p.k0p : d.width[l - 1];
+    const float *pa = l == 0 ? nullptr : stat(l - 1, 0);
+    const float *pb = l == 0 ? nullptr : stat(l - 1, 1);
+    const bool pooled = p.pool_grad && l == L - 1;
+    if (p.recompute && l == 0) break;  // finished by btr_sa_bn_relu_bwd_rc below
+    float *dw = grads + p.dw[l];
+    if (p.recompute && l == 1)
+      BTR_TRY(btr_sa_gemm_tn_rc(R, nl, k, dy, nl, x0, at_f(saved, p.w2[0]), pa, pb, pw, dw,
+                                stream));
+    else if (pooled)
+      BTR_TRY(btr_sa_gemm_tn_pool(R, nl, k, dy, nl, d.s, arg, dcl, alpha, beta, xsrc, ldx, pa, pb,
+                                  pw, dw, stream));
+    else
+      BTR_TRY(btr_sa_gemm_tn(R, nl, k, dy, nl, xsrc, ldx, pa, pb, pw, dw, stream));
+    if (l > 0 || any_in) {
+      const float *wt = at_f(saved, p.wt[l]);
+      float *g = at_f(scratch, sc.g[flip]);
+      flip ^= 1;
+      if (pooled)
+        BTR_TRY(btr_sa_gemm_nt_pool(R, k, nl, dy, nl, wt, nl, g, k, d.s, arg, dcl, alpha, beta,
+                                    stream));
+      else
+        BTR_TRY(btr_sa_gemm_nt(R, k, nl, dy, nl, wt, nl, g, k, nullptr, nullptr, nullptr,
+                               stream));
+      if (l > 0) {
+        float *dg = grads + p.dgamma[l - 1], *db = grads + p.dbeta[l - 1];
+        if (p.recompute && l == 1)
+          BTR_TRY(btr_sa_bn_relu_bwd_rc(R, k, k, g, x0, at_f(saved, p.w2[0]), stat(0, 0),
+                                        stat(0, 1), stat(0, 2), stat(0, 3), part, m1, m2, dg, db,
+                                        pw, grads + p.dw[0], stream));
+        else
+          BTR_TRY(btr_sa_bn_relu_bwd(R, k, k, g, at_f(saved, p.y[l - 1]), stat(l - 1, 0),
+                                     stat(l - 1, 1), stat(l - 1, 2), stat(l - 1, 3), part, m1, m2,
+                                     dg, db, stream));
+        dy = g;
+      } else {
+        float *dfeat_cl = (d.need_dfeat && d.c > 0 && dfeat) ? at_f(scratch, sc.dfeat_cl) : nullptr;
+        void *ws = (char *)scratch + sc.scat;
+        if (p.compact) {
+          if (dfeat_cl)
+            BTR_TRY(btr_sac_scatter(d.b, d.n, d.m, d.c, p.k0p, d.use_xyz, g, at_i(saved, p.cidx),
+                                    at_i(saved, p.goff), dfeat_cl, ws, sc.scat_bytes, R, stream));
+        } else {
+          BTR_TRY(btr_sa_scatter(d.b, d.n, d.m, d.s, d.c, p.k0p, d.use_xyz, d.radius_div, g, idx,
+                                 dfeat_cl, d.need_dxyz ? dxyz : nullptr,
+                                 d.need_dnew_xyz ? dnew_xyz : nullptr, ws, sc.scat_bytes, stream));
+        }
+        if (dfeat_cl)
+          BTR_TRY(btr_pm_out(d.b, d.n, d.c, d.c, dfeat_cl, nullptr, nullptr, 0, dfeat, nullptr,
+                             stream));
+      }
+    }
+  }
+  return check_launch("sa_layer_backward");
+}
+
+// ================================================================== point-wise MLP chains
+namespace {
+struct PmBwdScratch {
+  size_t g[2], part, m1, m2, pw, bytes;
+};
+PmBwdScratch pm_bwd_scratch(const btr_pm_chain_t &d, const btr_pm_plan_t &p) {
+  PmBwdScratch s{};
+  Bump b;
+  int maxc = 0;
+  size_t pw = 0;
+  for (int l = 0; l < d.layers; ++l) {
+    maxc = std::max(maxc, std::max(p.np[l], p.kin[l]));
+    pw = std::max(pw, (size_t)btr_sa_gemm_tn_chunks(p.rows, p.np[l], p.kin[l]) * p.np[l] *
+                          p.kin[l]);
+  }
+  pw = std::max(pw, (size_t)cdiv(p.rows, kColsumRows) * p.np[d.layers - 1]);  // colsum partials
+  s.g[0] = b.floats((size_t)p.rows * maxc);
+  s.g[1] = b.floats((size_t)p.rows * maxc);
+  s.part = b.floats((size_t)1024 * 2 * maxc);
+  s.m1 = b.floats(maxc);
+  s.m2 = b.floats(maxc);
+  s.pw = b.floats(pw);
+  s.bytes = b.off;
+  return s;
+}
+}  // namespace
+
+int btr_pm_chain_plan(const btr_pm_chain_t *dp, btr_pm_plan_t *p) {
+  BTR_REQUIRE(dp && p, "pm_chain_plan: null pointer");
+  const btr_pm_chain_t &d = *dp;
+  BTR_REQUIRE(d.layers >= 1 && d.layers <= kMaxL, "pm_chain_plan: %d layers", d.layers);
+  BTR_REQUIRE(d.b > 0 && d.n > 0 && d.c > 0 && d.c % 4 == 0, "pm_chain_plan: bad sizes");
+  BTR_REQUIRE((long long)d.b * d.n < (1ll << 31), "pm_chain_plan: too many rows");
+  std::memset(p, 0, sizeof(*p));
+  const int L = d.layers;
+  p->rows = d.b * d.n;
+  int maxn = 0;
+  for (int l = 0; l < L; ++l) {
+    BTR_REQUIRE(d.width[l] > 0, "pm_chain_plan: width");
+    p->np[l] = ceil4(d.width[l]);
+    p->kin[l] = l == 0 ? d.c : p->np[l - 1];
+    BTR_REQUIRE(!d.has_bn[l] || (d.width[l] % 4 == 0 && d.width[l] <= 256),
+                "pm_chain_plan: BatchNorm layer of width %d", d.width[l]);
+    BTR_REQUIRE(d.has_bn[l] || l == L - 1, "pm_chain_plan: only the last layer may lack BN");
+    maxn = std::max(maxn, p->np[l]);
+  }
+  Bump sv;
+  p->x0 = sv.floats((size_t)p->rows * d.c);
+  for (int l = 0; l < L; ++l) {
+    p->y[l] = sv.floats((size_t)p->rows * p->np[l]);
+    p->w2[l] = sv.floats((size_t)p->np[l] * p->kin[l]);
+    p->wt[l] = sv.floats((size_t)p->np[l] * p->kin[l]);
+    p->stats[l] = sv.floats((size_t)4 * p->np[l]);
+  }
+  p->saved_bytes = sv.off;
+  p->fwd_scratch_bytes = up(sizeof(float) * ((size_t)btr_pm_gemm_grid(p->rows) * 2 * maxn + maxn));
+  p->bwd_scratch_bytes = pm_bwd_scratch(d, *p).bytes;
+  size_t g = 0;
+  for (int l = 0; l < L; ++l) {
+    p->dw[l] = g;
+    g += (size_t)p->np[l] * p->kin[l];
+    p->dgamma[l] = g;
+    g += p->np[l];
+    p->dbeta[l] = g;
+    g += p->np[l];
+  }
+  // bias gradients last: the ones in front of a BatchNorm are exact zeros (one memset)
+  for (int l = 0; l < L; ++l) {
+    p->dbias[l] = g;
+    g += p->np[l];
+  }
+  p->grads_floats = g;
+  return BTR_OK;
+}
+
+int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, const float *x_bcn,
+                         const float *x_cl, float *out, float *out_cl, void *saved,
+                         void *scratch, btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && (x_bcn || x_cl) && out && saved && scratch,
+              "pm_chain_forward: null pointer");
+  const btr_pm_chain_t &d = *dp;
+  const btr_pm_plan_t &p = *pp;
+  const int L = d.layers, rows = p.rows;
+  hipStream_t hs = as_stream(stream);
+
+  PrepArgs pa{};
+  pa.layers = L;
+  int blocks = 0;
+  bool bias_fix = false;
+  for (int l = 0; l < L; ++l) {
+    BTR_REQUIRE(d.w[l] && (!d.has_bn[l] || (d.gamma[l] && d.beta[l])),
+                "pm_chain_forward: layer %d parameters", l);
+    pa.w[l] = d.w[l];
+    pa.w2[l] = at_f(saved, p.w2[l]);
+    pa.wt[l] = at_f(saved, p.wt[l]);
+    pa.n[l] = d.width[l];
+    pa.np[l] = p.np[l];
+    pa.kraw[l] = l == 0 ? d.c : d.width[l - 1];
+    pa.kin[l] = p.kin[l];
+    pa.first[l] = blocks;
+    blocks += cdiv((long long)p.np[l] * p.kin[l], 256);
+    const bool track = d.has_bn[l] && d.running_mean[l];
+    pa.nbt[l] = track ? d.num_batches_tracked[l] : nullptr;
+    if (track && d.bias[l]) {  // the skipped bias only moves the running mean
+      pa.rmean[l] = d.running_mean[l];
+      pa.rbias[l] = d.bias[l];
+      pa.mom[l] = d.momentum[l];
+      bias_fix = true;
+    }
+  }
+  pa.first[L] = blocks;
+  hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, hs, pa);
+
+  const float *A = x_cl;
+  if (!A) {
+    float *x0 = at_f(saved, p.x0);
+    BTR_TRY(btr_pm_rows(d.b, d.n, d.c, d.c, x_bcn, x0, stream));
+    A = x0;
+  }  // else: the caller keeps x_cl alive and hands it to the backward again
+  const int grid = btr_pm_gemm_grid(rows);
+  int maxn = 0;
+  for (int l = 0; l < L; ++l) maxn = std::max(maxn, p.np[l]);
+  float *part = (float *)scratch;
+  float *bias_pad = part + (size_t)grid * 2 * maxn;
+  int lda = d.c;
+  const float *pscale = nullptr, *pshift = nullptr;
+  for (int l = 0; l < L; ++l) {
+    const int np = p.np[l], k = p.kin[l];
+    const float *w2 = at_f(saved, p.w2[l]);
+    float *y = at_f(saved, p.y[l]);
+    if (d.has_bn[l]) {
+      BTR_TRY(btr_pm_gemm_nt(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, part, nullptr,
+                             stream));
+      float *st = at_f(saved, p.stats[l]);
+      BTR_TRY(btr_sa_bn_finalize(np, grid, (double)rows, d.eps[l], d.momentum[l], part,
+                                 d.gamma[l], d.beta[l], st, st + np, st + 2 * np, st + 3 * np,
+                                 d.running_mean[l], d.running_var[l], stream));
+      pscale = st;
+      pshift = st + np;
+    } else {
+      const float *bp = d.bias[l];
+      if (bp && np != d.width[l]) {  // pad the bias row to the padded width
+        hipError_t e = hipMemsetAsync(bias_pad, 0, sizeof(float) * np, hs);
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(bias_pad, bp, sizeof(float) * d.width[l], hipMemcpyDeviceToDevice, hs);
+        if (e != hipSuccess) return fail((int)e, "pm_chain_forward bias: %s", hipGetErrorString(e));
+        bp = bias_pad;
+      }
+      BTR_TRY(btr_pm_gemm_nt(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, nullptr, bp,
+                             stream));
+      pscale = pshift = nullptr;
+    }
+    A = y;
+    lda = np;
+  }
+  BTR_TRY(btr_pm_out(d.b, d.n, d.width[L - 1], p.np[L - 1], A, pscale, pshift, pscale ? 1 : 0,
+                     out, out_cl, stream));
+  if (bias_fix) hipLaunchKernelGGL(bias_running_mean_kernel, dim3(L), dim3(256), 0, hs, pa);
+  return check_launch("pm_chain_forward");
+}
+
+int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, const float *x_cl,
+                          const float *dout, void *saved, float *grads, float *dx,
+                          void *scratch, btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && dout && saved && grads && scratch, "pm_chain_backward: null pointer");
+  const btr_pm_chain_t &d = *dp;
+  const btr_pm_plan_t &p = *pp;
+  const int L = d.layers, rows = p.rows;
+  hipStream_t hs = as_stream(stream);
+  const PmBwdScratch sc = pm_bwd_scratch(d, p);
+  float *part = at_f(scratch, sc.part), *m1 = at_f(scratch, sc.m1), *m2 = at_f(scratch, sc.m2);
+  float *pw = at_f(scratch, sc.pw);
+  auto stat = [&](int l, int which) { return at_f(saved, p.stats[l]) + which * p.np[l]; };
+  {  // bias gradients: zero in front of a BatchNorm (and the padding of the others)
+    hipError_t e = hipMemsetAsync(grads + p.dbias[0], 0,
+                                  sizeof(float) * (p.grads_floats - p.dbias[0]), hs);
+    if (e != hipSuccess) return fail((int)e, "pm_chain_backward memset: %s", hipGetErrorString(e));
+  }
+  const int nl = d.width[L - 1], npl = p.np[L - 1];
+  int flip = 0;
+  float *g = at_f(scratch, sc.g[flip]);
+  flip ^= 1;
+  BTR_TRY(btr_pm_rows(d.b, d.n, nl, npl, dout, g, stream));
+  if (d.has_bn[L - 1]) {
+    BTR_TRY(btr_sa_bn_relu_bwd(rows, npl, npl, g, at_f(saved, p.y[L - 1]), stat(L - 1, 0),
+                               stat(L - 1, 1), stat(L - 1, 2), stat(L - 1, 3), part, m1, m2,
+                               grads + p.dgamma[L - 1], grads + p.dbeta[L - 1], stream));
+  } else if (d.bias[L - 1]) {
+    const int chunks = cdiv(rows, kColsumRows);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(npl, 64), chunks), dim3(256), 0, hs, rows,
+                       npl, npl, g, pw);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(npl, 256)), dim3(256), 0, hs, chunks, npl,
+                       pw, grads + p.dbias[L - 1]);
+  }
+  float *dy = g;
+  for (int l = L - 1; l >= 0; --l) {
+    const int np = p.np[l], k = p.kin[l];
+    const float *xsrc = l == 0 ? (x_cl ? x_cl : at_f(saved, p.x0)) : at_f(saved, p.y[l - 1]);
+    const int ldx = l == 0 ? d.c : p.np[l - 1];
+    const float *pa = l == 0 ? nullptr : stat(l - 1, 0);
+    const float *pb = l == 0 ? nullptr : stat(l - 1, 1);
+    BTR_TRY(btr_sa_gemm_tn(rows, np, k, dy, np, xsrc, ldx, pa, pb, pw, grads + p.dw[l], stream));
+    if (l > 0 || d.need_dx) {
+      float *gn = at_f(scratch, sc.g[flip]);
+      flip ^= 1;
+      BTR_TRY(btr_pm_gemm_nt(rows, k, np, dy, np, at_f(saved, p.wt[l]), np, gn, k, nullptr,
+                             nullptr, nullptr, nullptr, stream));
+      if (l > 0) {
+        BTR_TRY(btr_sa_bn_relu_bwd(rows, k, k, gn, at_f(saved, p.y[l - 1]), stat(l - 1, 0),
+                                   stat(l - 1, 1), stat(l - 1, 2), stat(l - 1, 3), part, m1, m2,
+                                   grads + p.dgamma[l - 1], grads + p.dbeta[l - 1], stream));
+        dy = gn;
+      } else {
+        BTR_REQUIRE(dx, "pm_chain_backward: dx missing");
+        BTR_TRY(btr_pm_out(d.b, d.n, d.c, d.c, gn, nullptr, nullptr, 0, dx, nullptr, stream));
+      }
+    }
+  }
+  return check_launch("pm_chain_backward");
+}
+
+}  // extern "C"

@@ -88,6 +88,13 @@ _SIGNATURES = {
     "btr_pm_gemm_nt": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
     "btr_pm_out": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "btr_pm_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp]),
+    # whole-layer entry points (csrc/sa_layer.hip): description + plan by address
+    "btr_sa_layer_plan": (_ci, [_vp, _vp]),
+    "btr_sa_layer_forward": (_ci, [_vp] * 11),
+    "btr_sa_layer_backward": (_ci, [_vp] * 12),
+    "btr_pm_chain_plan": (_ci, [_vp, _vp]),
+    "btr_pm_chain_forward": (_ci, [_vp] * 9),
+    "btr_pm_chain_backward": (_ci, [_vp] * 9),
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
@@ -149,6 +156,47 @@ class CompactRows(ctypes.Structure):
     one set-abstraction call; keeps the tensors alive while bound."""
     _fields_ = [("dims", _vp), ("bw", _vp), ("bgrp", _vp), ("goff", _vp),
                 ("dense_rows", ctypes.c_double)]
+
+
+MAX_LAYERS = 8   # BTR_MAX_LAYERS
+_vp8, _ci8, _cf8, _sz8 = _vp * 8, _ci * 8, _cf * 8, _sz * 8
+SA_OPT_COMPACT, SA_OPT_RECOMPUTE, SA_OPT_POOL_EPILOGUE, SA_OPT_POOL_GRAD = 1, 2, 4, 8
+
+
+class SaLayer(ctypes.Structure):
+    """btr_sa_layer_t: one set-abstraction layer (sizes, parameter pointers, options)."""
+    _fields_ = [("b", _ci), ("n", _ci), ("m", _ci), ("s", _ci), ("c", _ci), ("use_xyz", _ci),
+                ("radius_div", _cf), ("layers", _ci), ("width", _ci8), ("w", _vp8),
+                ("gamma", _vp8), ("beta", _vp8), ("running_mean", _vp8), ("running_var", _vp8),
+                ("num_batches_tracked", _vp8), ("eps", _cf8), ("momentum", _cf8),
+                ("need_dxyz", _ci), ("need_dnew_xyz", _ci), ("need_dfeat", _ci),
+                ("options", _ci)]
+
+
+class SaPlan(ctypes.Structure):
+    """btr_sa_plan_t: the variant that runs + the offsets of every tensor in the buffers."""
+    _fields_ = [("compact", _ci), ("recompute", _ci), ("pool_epilogue", _ci), ("pool_grad", _ci),
+                ("rows", _ci), ("k0", _ci), ("k0p", _ci), ("kin", _ci8),
+                ("x0", _sz), ("y", _sz8), ("w2", _sz8), ("wt", _sz8), ("stats", _sz8),
+                ("arg", _sz), ("goff", _sz), ("dims", _sz), ("cidx", _sz), ("bgrp", _sz),
+                ("bw", _sz), ("saved_bytes", _sz), ("fwd_scratch_bytes", _sz),
+                ("bwd_scratch_bytes", _sz), ("dw", _sz8), ("dgamma", _sz8), ("dbeta", _sz8),
+                ("grads_floats", _sz)]
+
+
+class PmChain(ctypes.Structure):
+    """btr_pm_chain_t: one conv1x1 (+bias) -> BatchNorm -> ReLU chain."""
+    _fields_ = [("b", _ci), ("n", _ci), ("c", _ci), ("layers", _ci), ("width", _ci8),
+                ("has_bn", _ci8), ("w", _vp8), ("bias", _vp8), ("gamma", _vp8), ("beta", _vp8),
+                ("running_mean", _vp8), ("running_var", _vp8), ("num_batches_tracked", _vp8),
+                ("eps", _cf8), ("momentum", _cf8), ("need_dx", _ci)]
+
+
+class PmPlan(ctypes.Structure):
+    _fields_ = [("rows", _ci), ("np", _ci8), ("kin", _ci8), ("x0", _sz), ("y", _sz8),
+                ("w2", _sz8), ("wt", _sz8), ("stats", _sz8), ("saved_bytes", _sz),
+                ("fwd_scratch_bytes", _sz), ("bwd_scratch_bytes", _sz), ("dw", _sz8),
+                ("dbias", _sz8), ("dgamma", _sz8), ("dbeta", _sz8), ("grads_floats", _sz)]
 
 
 class compact_bound(object):

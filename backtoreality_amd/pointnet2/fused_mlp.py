@@ -16,7 +16,9 @@ skipped and its gradient is the exact zero the mathematics gives.
 `PointwiseMLP.apply(x, meta, *params)`: x (B, C, N) f32 -> (B, C_out, N); the result carries
 its channel-last twin as `._btr_channel_last`.  `BTR_FUSED_MLP=0` disables the path.
 """
+import ctypes
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -203,6 +205,114 @@ class PointwiseMLP(Function):
         return (dx, None) + tuple(grads)
 
 
+def native_enabled():
+    """BTR_NATIVE_LAYERS=0 (or inside bench.py's instrumented steps): the Python sequence
+    (PointwiseMLP) instead of one btr_pm_chain_forward / _backward call per chain."""
+    return os.environ.get("BTR_NATIVE_LAYERS", "1") != "0" and not _ext.timing_detail()
+
+
+_CHAIN_CACHE = weakref.WeakKeyDictionary()   # first conv of a chain -> {shape: (desc, plan, ..)}
+
+
+def _u8(nbytes, dev):
+    return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
+
+
+class PointwiseChain(Function):
+    """PointwiseMLP with the launch sequence in C++ (btr_pm_chain_forward / _backward,
+    csrc/sa_layer.hip).  Same kernels; the bias gradient of a bare last layer is summed by
+    a kernel of the library instead of torch.sum (rounding-level difference)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        layers = meta["layers"]
+        L = len(layers)
+        dev = x.device
+        B, K0, N = x.shape
+        rows = B * N
+        need_dx = bool(ctx.needs_input_grad[0])
+        key = (B, K0, N, need_dx)
+        cache = meta["cache"]
+        ent = cache.get(key)
+        if ent is None:
+            d = _ext.PmChain()
+            d.b, d.n, d.c, d.layers, d.need_dx = B, N, K0, L, int(need_dx)
+            for l, spec in enumerate(layers):
+                d.width[l] = params[4 * l].shape[0]
+                d.has_bn[l] = 1 if spec["bn"] is not None else 0
+                d.eps[l] = float(spec["bn"].eps) if spec["bn"] is not None else 0.0
+            plan = _ext.PmPlan()
+            _call(_lib.btr_pm_chain_plan, ctypes.addressof(d), ctypes.addressof(plan))
+            sizes = []
+            for l in range(L):
+                sizes += [plan.np[l] * plan.kin[l], plan.np[l], plan.np[l]]
+            sizes += [plan.np[l] for l in range(L)]
+            ent = cache[key] = (d, plan, sizes)
+        d, plan, sizes = ent
+        for l, spec in enumerate(layers):
+            W, bias, gamma, beta = params[4 * l:4 * l + 4]
+            bn = spec["bn"]
+            assert W.is_contiguous()
+            d.w[l] = W.data_ptr()
+            d.bias[l] = _p(bias)
+            d.gamma[l], d.beta[l] = _p(gamma), _p(beta)
+            track = bn is not None and bn.track_running_stats and bn.running_mean is not None
+            d.running_mean[l] = bn.running_mean.data_ptr() if track else None
+            d.running_var[l] = bn.running_var.data_ptr() if track else None
+            d.num_batches_tracked[l] = bn.num_batches_tracked.data_ptr() if track else None
+            if bn is not None:
+                d.momentum[l] = float(bn.momentum) if bn.momentum is not None else \
+                    1.0 / float(bn.num_batches_tracked.item() + 1)
+        x_cl = getattr(x, "_btr_channel_last", None)
+        if x_cl is not None and (x_cl.shape != (rows, K0) or not x_cl.is_contiguous()):
+            x_cl = None
+        xb = x.contiguous() if x_cl is None else None
+        NL = d.width[L - 1]
+        out = _f32((B, NL, N), dev)
+        out_cl = _f32((rows, NL), dev)
+        saved = _u8(plan.saved_bytes, dev)
+        scratch = _u8(plan.fwd_scratch_bytes, dev)
+        with _on(x) as dv:
+            _call(_lib.btr_pm_chain_forward, ctypes.addressof(d), ctypes.addressof(plan), _p(xb),
+                  _p(x_cl), _p(out), _p(out_cl), _p(saved), _p(scratch), _stream(dv))
+        out._btr_channel_last = out_cl
+        ctx.plan = ent
+        ctx.has_x_cl = x_cl is not None
+        ctx.pshapes = [None if p is None else p.shape for p in params]
+        if x_cl is not None:
+            ctx.save_for_backward(saved, x_cl)
+        else:
+            ctx.save_for_backward(saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d, plan, sizes = ctx.plan
+        saved = ctx.saved_tensors[0]
+        x_cl = ctx.saved_tensors[1] if ctx.has_x_cl else None
+        dev = dout.device
+        L = d.layers
+        dout = dout.contiguous()
+        grads = _f32((plan.grads_floats,), dev)
+        scratch = _u8(plan.bwd_scratch_bytes, dev)
+        dx = _f32((d.b, d.c, d.n), dev) if d.need_dx else None
+        with _on(dout) as dv:
+            _call(_lib.btr_pm_chain_backward, ctypes.addressof(d), ctypes.addressof(plan),
+                  _p(x_cl), _p(dout), _p(saved), _p(grads), _p(dx), _p(scratch), _stream(dv))
+        parts = grads.split(sizes)
+        res = []
+        for l in range(L):
+            Nl = d.width[l]
+            wshape, bshape = ctx.pshapes[4 * l], ctx.pshapes[4 * l + 1]
+            dW = parts[3 * l].view(plan.np[l], plan.kin[l])[:Nl].reshape(wshape)
+            dbias = parts[3 * L + l][:Nl] if bshape is not None else None
+            if d.has_bn[l]:
+                res += [dW, dbias, parts[3 * l + 1][:Nl], parts[3 * l + 2][:Nl]]
+            else:
+                res += [dW, dbias, None, None]
+        return (dx, None) + tuple(res)
+
+
 def _layer_ok(conv, bn, K):
     import torch.nn as nn
     if conv.kernel_size not in ((1,), (1, 1)) or conv.stride not in ((1,), (1, 1)) or \
@@ -250,4 +360,9 @@ def run_chain(x, chain):
         K = conv.out_channels
     if K > 256 and chain[-1][1] is not None:
         return None
+    if native_enabled() and len(chain) <= _ext.MAX_LAYERS:
+        cache = _CHAIN_CACHE.get(chain[0][0])
+        if cache is None:
+            cache = _CHAIN_CACHE[chain[0][0]] = {}
+        return PointwiseChain.apply(x, {"layers": metas, "cache": cache}, *params)
     return PointwiseMLP.apply(x, {"layers": metas}, *params)

@@ -9,7 +9,9 @@ into the epilogue; the (B, 3+C, npoint, nsample) tensor and the post-activation 
 exist in HBM.  Used by `PointnetSAModuleVotes` when its configuration allows (see
 `can_fuse`); `BTR_FUSED_SA=0` disables it (the unfused path runs the nine `_ext` ops + torch).
 """
+import ctypes
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -325,6 +327,134 @@ class FusedSAFunction(Function):
         return (dxyz, dnew, dfeat, None, None) + tuple(grads)
 
 
+# per module: {(shape, flags): (description, plan, gradient split sizes)}; weak, so that modules
+# stay picklable / deep-copyable (ctypes structures with pointers are not)
+_LAYER_CACHE = weakref.WeakKeyDictionary()
+
+
+def native_enabled():
+    """BTR_NATIVE_LAYERS=0: sequence the btr_sa_* launches from Python (FusedSAFunction, the
+    readable statement of the sequence and the test oracle of csrc/sa_layer.hip) instead of
+    one btr_sa_layer_forward / _backward call per layer.  The fully instrumented steps of
+    bench.py (an event pair around every launch) also run the Python sequence."""
+    return os.environ.get("BTR_NATIVE_LAYERS", "1") != "0" and not _ext.timing_detail()
+
+
+def _sa_options():
+    o = 0
+    if _compact_enabled():
+        o |= _ext.SA_OPT_COMPACT
+    if os.environ.get("BTR_SA_RECOMPUTE", "1") != "0":
+        o |= _ext.SA_OPT_RECOMPUTE
+    if _pool_in_epilogue():
+        o |= _ext.SA_OPT_POOL_EPILOGUE
+    if os.environ.get("BTR_POOLGRAD", "1") != "0":
+        o |= _ext.SA_OPT_POOL_GRAD
+    return o
+
+
+def _u8(nbytes, dev):
+    return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
+
+
+class FusedSALayer(Function):
+    """FusedSAFunction with the launch sequence in C++ (btr_sa_layer_forward / _backward,
+    csrc/sa_layer.hip): per layer one description, one plan (cached per shape), three buffers
+    (saved / scratch / flat gradients) and one call each way.  Same kernels, same results."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, idx, meta, *params):
+        dev = xyz.device
+        B, N, _ = xyz.shape
+        M, S = idx.shape[1], idx.shape[2]
+        C = features.shape[1] if features is not None else 0
+        bns = meta["bns"]
+        L = len(params) // 3
+        xyz = xyz.contiguous()
+        new_xyz = new_xyz.contiguous()
+        feats_cl = None
+        if C:
+            feats_cl = getattr(features, "_btr_channel_last", None)
+            if os.environ.get("BTR_SA_CL_SHORTCUT", "1") == "0":
+                feats_cl = None
+            if feats_cl is None or feats_cl.shape != (B, N, C):
+                feats_cl = features.transpose(1, 2).contiguous()
+        need = ctx.needs_input_grad
+        key = (B, N, M, S, C, bool(need[0]), bool(need[1]), bool(need[2]), _sa_options())
+        cache = meta["cache"]
+        ent = cache.get(key)
+        if ent is None:
+            d = _ext.SaLayer()
+            d.b, d.n, d.m, d.s, d.c = B, N, M, S, C
+            d.use_xyz = 1 if meta["use_xyz"] else 0
+            d.radius_div = float(meta["radius_div"])
+            d.layers = L
+            for l in range(L):
+                d.width[l] = params[3 * l].shape[0]
+                d.eps[l] = float(bns[l].eps)
+            d.need_dxyz, d.need_dnew_xyz, d.need_dfeat = int(need[0]), int(need[1]), int(need[2])
+            d.options = key[-1]
+            plan = _ext.SaPlan()
+            _call(_lib.btr_sa_layer_plan, ctypes.addressof(d), ctypes.addressof(plan))
+            sizes = []
+            for l in range(L):
+                sizes += [d.width[l] * plan.kin[l], d.width[l], d.width[l]]
+            ent = cache[key] = (d, plan, sizes)
+        d, plan, sizes = ent
+        for l in range(L):
+            W, gamma, beta = params[3 * l:3 * l + 3]
+            bn = bns[l]
+            assert W.is_contiguous()
+            d.w[l], d.gamma[l], d.beta[l] = W.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+            track = bn.track_running_stats and bn.running_mean is not None
+            d.running_mean[l] = bn.running_mean.data_ptr() if track else None
+            d.running_var[l] = bn.running_var.data_ptr() if track else None
+            d.num_batches_tracked[l] = bn.num_batches_tracked.data_ptr() if track else None
+            d.momentum[l] = float(bn.momentum) if bn.momentum is not None else \
+                1.0 / float(bn.num_batches_tracked.item() + 1)
+        CL = d.width[L - 1]
+        out = _f32((B, CL, M), dev)
+        out_cl = _f32((B, M, CL), dev)
+        saved = _u8(plan.saved_bytes, dev)
+        scratch = _u8(plan.fwd_scratch_bytes, dev)
+        with _on(xyz) as dv:
+            _call(_lib.btr_sa_layer_forward, ctypes.addressof(d), ctypes.addressof(plan),
+                  _p(xyz), _p(new_xyz), _p(feats_cl), _p(idx), _p(out), _p(out_cl), _p(saved),
+                  _p(scratch), _stream(dv))
+        out._btr_channel_last = out_cl
+        ctx.plan = ent
+        ctx.dims = (B, N, M, C)
+        ctx.pshapes = [p.shape for p in params]
+        ctx.save_for_backward(idx, saved, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d, plan, sizes = ctx.plan
+        B, N, M, C = ctx.dims
+        idx, saved, out = ctx.saved_tensors
+        dev = dout.device
+        dout = dout.contiguous()
+        grads = _f32((plan.grads_floats,), dev)
+        scratch = _u8(plan.bwd_scratch_bytes, dev)
+        dfeat = _f32((B, C, N), dev) if d.need_dfeat and C else None
+        dxyz = _f32((B, N, 3), dev) if d.need_dxyz and d.use_xyz else None
+        dnew = _f32((B, M, 3), dev) if d.need_dnew_xyz and d.use_xyz else None
+        with _on(dout) as dv:
+            _call(_lib.btr_sa_layer_backward, ctypes.addressof(d), ctypes.addressof(plan),
+                  _p(idx), _p(out), _p(dout), _p(saved), _p(grads), _p(dfeat), _p(dxyz),
+                  _p(dnew), _p(scratch), _stream(dv))
+        parts = grads.split(sizes)
+        res = []
+        for l in range(d.layers):
+            shape = ctx.pshapes[3 * l]
+            dW = parts[3 * l].view(d.width[l], plan.kin[l])
+            if plan.kin[l] != shape[1]:
+                dW = dW[:, :shape[1]]
+            res += [dW.reshape(shape), parts[3 * l + 1], parts[3 * l + 2]]
+        return (dxyz, dnew, dfeat, None, None) + tuple(res)
+
+
 def fused_eval_forward(module, xyz, new_xyz, features, idx):
     """Inference-mode forward of a set-abstraction layer (module.eval(), under no_grad -- the
     evaluation pass of the reference, train_Votenet_FSB.py:246-293): BatchNorm uses its RUNNING
@@ -447,7 +577,11 @@ def fused_group_mlp_max(module, xyz, new_xyz, features):
     for layer in module.mlp_module:
         params += [layer.conv.weight, layer.bn.bn.weight, layer.bn.bn.bias]
         bns.append(layer.bn.bn)
-    meta = {"radius_div": g.radius if g.normalize_xyz else 1.0, "use_xyz": g.use_xyz, "bns": bns}
-    if features is None and not g.use_xyz:
-        raise AssertionError("Cannot have not features and not use xyz as a feature!")
+    cache = _LAYER_CACHE.get(module)
+    if cache is None:
+        cache = _LAYER_CACHE[module] = {}
+    meta = {"radius_div": g.radius if g.normalize_xyz else 1.0, "use_xyz": g.use_xyz, "bns": bns,
+            "cache": cache}
+    if native_enabled() and len(bns) <= _ext.MAX_LAYERS:
+        return FusedSALayer.apply(xyz, new_xyz, features, idx, meta, *params)
     return FusedSAFunction.apply(xyz, new_xyz, features, idx, meta, *params)

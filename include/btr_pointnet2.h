@@ -407,6 +407,105 @@ int btr_pm_out(int b, int n, int c, int ldy, const float *y, const float *scale,
                const float *shift, int relu, float *out_bcn, float *out_cl, btr_stream_t stream);
 int btr_pm_rows(int b, int n, int c, int ldr, const float *x, float *rows, btr_stream_t stream);
 
+/* ---- whole-layer entry points: one call per set-abstraction layer / per MLP chain ------------
+ * The btr_sa_* / btr_pm_* launches above, sequenced in C++ (csrc/sa_layer.hip) instead of by
+ * the caller: a training step is ~400 kernel launches, and a host that issues them one binding
+ * call at a time needs longer than the GPU needs to run them.  One description (btr_*_t, filled
+ * by the caller), one plan (btr_*_plan_t: which variant runs + where every tensor lives inside
+ * ONE saved buffer, ONE scratch buffer and ONE flat gradient buffer), one call forward, one
+ * call backward.  Results are bit-identical to issuing the individual calls.
+ *
+ * reference: PointnetSAModuleVotes.forward (pointnet2_modules.py:243-267) = QueryAndGroup
+ * (pointnet2_utils.py:317-376) + SharedMLP (pytorch_utils.py:11-36) + max_pool2d, and its
+ * autograd backward; SharedMLP / Conv1d+BatchNorm1d+ReLU chains for btr_pm_chain_*. */
+#define BTR_MAX_LAYERS 8
+enum {
+  BTR_SA_OPT_COMPACT = 1,       /* distinct-neighbour rows for nsample >= 32                     */
+  BTR_SA_OPT_RECOMPUTE = 2,     /* never store the first layer's output of a 4-column input      */
+  BTR_SA_OPT_POOL_EPILOGUE = 4, /* group extrema from the last GEMM's epilogue                    */
+  BTR_SA_OPT_POOL_GRAD = 8      /* pooled gradient formed inside the GEMM operand staging        */
+};
+typedef struct {
+  int b, n, m, s, c;            /* batch, points, centres, nsample, feature channels (may be 0)  */
+  int use_xyz;
+  float radius_div;             /* radius when normalize_xyz, else 1                             */
+  int layers;
+  int width[BTR_MAX_LAYERS];    /* output channels per layer (multiples of 4)                    */
+  const float *w[BTR_MAX_LAYERS];     /* (width[l], in_l) row-major, in_0 = 3*use_xyz + c        */
+  const float *gamma[BTR_MAX_LAYERS];
+  const float *beta[BTR_MAX_LAYERS];
+  float *running_mean[BTR_MAX_LAYERS];  /* NULL: not tracked                                     */
+  float *running_var[BTR_MAX_LAYERS];
+  long long *num_batches_tracked[BTR_MAX_LAYERS];  /* NULL or device int64, += 1                 */
+  float eps[BTR_MAX_LAYERS];
+  float momentum[BTR_MAX_LAYERS];
+  int need_dxyz, need_dnew_xyz, need_dfeat;  /* which input gradients the backward must produce  */
+  int options;                  /* BTR_SA_OPT_* the caller allows                                */
+} btr_sa_layer_t;
+
+typedef struct {
+  int compact, recompute, pool_epilogue, pool_grad;  /* what will run                            */
+  int rows, k0, k0p;            /* b*m*s, 3*use_xyz + c, the same rounded up to 4                */
+  int kin[BTR_MAX_LAYERS];      /* padded input width per layer                                  */
+  /* byte offsets into `saved` */
+  size_t x0, y[BTR_MAX_LAYERS], w2[BTR_MAX_LAYERS], wt[BTR_MAX_LAYERS], stats[BTR_MAX_LAYERS];
+  size_t arg, goff, dims, cidx, bgrp, bw;
+  size_t saved_bytes, fwd_scratch_bytes, bwd_scratch_bytes;
+  /* float offsets into `grads`: dW (width[l], kin[l]) padded, dgamma, dbeta */
+  size_t dw[BTR_MAX_LAYERS], dgamma[BTR_MAX_LAYERS], dbeta[BTR_MAX_LAYERS];
+  size_t grads_floats;
+} btr_sa_plan_t;
+
+int btr_sa_layer_plan(const btr_sa_layer_t *d, btr_sa_plan_t *plan);
+/* out (b, width[L-1], m); out_cl (b, m, width[L-1]); feats_cl (b, n, c) channel-last or NULL */
+int btr_sa_layer_forward(const btr_sa_layer_t *d, const btr_sa_plan_t *plan, const float *xyz,
+                         const float *new_xyz, const float *feats_cl, const int *idx, float *out,
+                         float *out_cl, void *saved, void *scratch, btr_stream_t stream);
+/* dfeat (b, c, n), dxyz (b, n, 3), dnew_xyz (b, m, 3): NULL when not needed.  `saved` is
+ * consumed (the pooled layer's output may be overwritten): one backward per forward. */
+int btr_sa_layer_backward(const btr_sa_layer_t *d, const btr_sa_plan_t *plan, const int *idx,
+                          const float *out, const float *dout, void *saved, float *grads,
+                          float *dfeat, float *dxyz, float *dnew_xyz, void *scratch,
+                          btr_stream_t stream);
+
+typedef struct {
+  int b, n, c;                  /* x: (b, c, n); c a multiple of 4                               */
+  int layers;
+  int width[BTR_MAX_LAYERS];
+  int has_bn[BTR_MAX_LAYERS];   /* conv -> BatchNorm -> ReLU; the last layer may be a bare conv  */
+  const float *w[BTR_MAX_LAYERS];     /* (width[l], in_l) row-major                              */
+  const float *bias[BTR_MAX_LAYERS];  /* NULL or (width[l]); skipped in front of a BatchNorm     */
+  const float *gamma[BTR_MAX_LAYERS];
+  const float *beta[BTR_MAX_LAYERS];
+  float *running_mean[BTR_MAX_LAYERS];
+  float *running_var[BTR_MAX_LAYERS];
+  long long *num_batches_tracked[BTR_MAX_LAYERS];
+  float eps[BTR_MAX_LAYERS];
+  float momentum[BTR_MAX_LAYERS];
+  int need_dx;
+} btr_pm_chain_t;
+
+typedef struct {
+  int rows;
+  int np[BTR_MAX_LAYERS];       /* width rounded up to 4                                         */
+  int kin[BTR_MAX_LAYERS];
+  size_t x0, y[BTR_MAX_LAYERS], w2[BTR_MAX_LAYERS], wt[BTR_MAX_LAYERS], stats[BTR_MAX_LAYERS];
+  size_t saved_bytes, fwd_scratch_bytes, bwd_scratch_bytes;
+  size_t dw[BTR_MAX_LAYERS], dbias[BTR_MAX_LAYERS], dgamma[BTR_MAX_LAYERS], dbeta[BTR_MAX_LAYERS];
+  size_t grads_floats;
+} btr_pm_plan_t;
+
+int btr_pm_chain_plan(const btr_pm_chain_t *d, btr_pm_plan_t *plan);
+/* x_bcn (b, c, n) or, when the producer kept it, x_cl (b*n, c) (then x_bcn may be NULL);
+ * out (b, width[L-1], n), out_cl (b*n, width[L-1]) */
+int btr_pm_chain_forward(const btr_pm_chain_t *d, const btr_pm_plan_t *plan, const float *x_bcn,
+                         const float *x_cl, float *out, float *out_cl, void *saved,
+                         void *scratch, btr_stream_t stream);
+/* x_cl: the rows the forward was given (NULL when it was given x_bcn: they are in `saved`) */
+int btr_pm_chain_backward(const btr_pm_chain_t *d, const btr_pm_plan_t *plan, const float *x_cl,
+                          const float *dout, void *saved, float *grads, float *dx,
+                          void *scratch, btr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,166 @@
+"""Whole-layer entry points (csrc/sa_layer.hip: btr_sa_layer_* / btr_pm_chain_*, one call per
+layer) against the same launches sequenced from Python (fused_sa.FusedSAFunction /
+fused_mlp.PointwiseMLP, BTR_NATIVE_LAYERS=0): same kernels in the same order, so every output,
+gradient and BatchNorm buffer must be BIT-identical -- except the bias gradient of a bare last
+layer, which the library sums itself (torch.sum in the Python sequence), and the scattered
+input gradients, whose summation order is the order atomics filled the per-point lists in
+(not reproducible between two runs of the SAME path either): 1e-5 relative."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from backtoreality_amd.pointnet2 import fused_mlp, fused_sa
+from backtoreality_amd.pointnet2 import pointnet2_modules as M
+from backtoreality_amd.pointnet2 import pointnet2_utils
+from backtoreality_amd.votenet import config, proposal_module, synthetic, voting_module
+
+pytestmark = pytest.mark.gpu
+
+
+def _sa_run(sa, xyz, feats, inds, xyz_grad, feat_grad=True):
+    xyz = xyz.clone().requires_grad_(xyz_grad)
+    feats = feats.clone().requires_grad_(feat_grad) if feats is not None else None
+    new_xyz, out, _ = sa(xyz, feats, inds)
+    torch.manual_seed(3)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    g = {"out": out.detach(), "out_cl": out._btr_channel_last.detach()}
+    if feats is not None and feat_grad:
+        g["dfeat"] = feats.grad
+    if xyz_grad:
+        g["dxyz"] = xyz.grad
+    for n, p in sa.named_parameters():
+        g["d" + n] = p.grad
+    for n, b in sa.named_buffers():
+        g[n] = b.detach().clone()
+    return g
+
+
+@pytest.mark.parametrize("N,npoint,radius,S,mlp,C,xyz_grad,feat_grad", [
+    (4096, 512, 0.2, 64, [1, 64, 64, 128], 1, False, False),      # SA1: compact + recompute
+    (4096, 512, 0.2, 64, [1, 64, 64, 128], 1, False, True),       # SA1-shaped, feature gradient
+    (2048, 256, 0.4, 32, [128, 128, 128, 256], 128, False, True),  # SA2: compact, scatter
+    (1024, 256, 0.3, 16, [256, 128, 128, 128], 256, True, True),   # vote aggregation
+    (1024, 128, 0.8, 16, [0, 32, 48], 0, True, True),              # no features, 2 layers
+    (700, 100, 0.5, 7, [5, 20], 5, True, True),                    # ragged, single layer
+    (3000, 64, 1.0, 128, [3, 32, 64], 3, True, True),              # nsample 128
+    (9000, 256, 0.3, 16, [8, 32, 64], 8, True, True),              # N > 8192
+    (2048, 256, 0.4, 32, [128, 128, 128, 256], 128, True, True),   # xyz gradient: dense rows
+])
+@pytest.mark.parametrize("options", ["default", "plain"])
+def test_sa_layer_call_equals_python_sequence(cuda, monkeypatch, N, npoint, radius, S, mlp, C,
+                                              xyz_grad, feat_grad, options):
+    if options == "plain":   # no compact rows / recompute / pooling epilogue / prologue gradient
+        for k in ("BTR_SA_COMPACT", "BTR_SA_RECOMPUTE", "BTR_POOL_EPILOGUE", "BTR_POOLGRAD"):
+            monkeypatch.setenv(k, "0")
+    B = 2
+    xyz = torch.from_numpy(np.stack([synthetic.make_scene(60 + i, N, use_height=False)[
+        'point_clouds'] for i in range(B)], 0)).to(cuda)
+    torch.manual_seed(0)
+    feats = torch.randn(B, C, N, device=cuda) if C else None
+    sa = M.PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=S, mlp=list(mlp),
+                                 use_xyz=True, normalize_xyz=True).to(cuda)
+    with torch.no_grad():
+        for layer in sa.mlp_module:
+            layer.bn.bn.weight.uniform_(0.5, 1.5)
+            layer.bn.bn.bias.uniform_(-0.3, 0.3)
+    inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BTR_NATIVE_LAYERS", flag)
+        assert fused_sa.native_enabled() == (flag == "1")
+        res[flag] = _sa_run(copy.deepcopy(sa), xyz, feats, inds, xyz_grad, feat_grad)
+    assert set(res["0"]) == set(res["1"])
+    for k, want in res["0"].items():
+        got = res["1"][k]
+        assert (want is None) == (got is None), k
+        if want is not None:
+            assert got.shape == want.shape and got.dtype == want.dtype, k
+            if k in ("dfeat", "dxyz"):   # summed in the order atomics built the point lists
+                rel = float((got - want).abs().max() / want.abs().max())
+                assert rel < 1e-5, (k, rel)
+            else:
+                assert torch.equal(got, want), (k, float((got.float() - want.float()).abs().max()))
+
+
+def _chain_compare(run, mod, monkeypatch, summed=()):
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BTR_NATIVE_LAYERS", flag)
+        assert fused_mlp.native_enabled() == (flag == "1")
+        m = copy.deepcopy(mod)
+        outs, ins = run(m)
+        loss = sum((o * torch.linspace(0.5, 1.5, o.numel(), device=o.device).view_as(o)).sum()
+                   for o in outs)
+        loss.backward()
+        res[flag] = {"out%d" % i: o.detach() for i, o in enumerate(outs)}
+        res[flag].update({"din%d" % i: t.grad for i, t in enumerate(ins)})
+        res[flag].update({"d" + n: p.grad for n, p in m.named_parameters()})
+        res[flag].update({n: b.detach().clone() for n, b in m.named_buffers()})
+    for k, want in res["0"].items():
+        got = res["1"][k]
+        assert got.shape == want.shape, k
+        if k in summed or k.startswith("din") or k.endswith("running_mean"):
+            # din*: behind atomically built lists (three_interpolate / scatter backward);
+            # running_mean: momentum * bias added by the library (no fma) vs torch.add_(alpha=)
+            rel = float((got - want).abs().max() / want.abs().max())
+            assert rel < (1e-6 if k.endswith("running_mean") else 1e-5), (k, rel)
+        else:
+            assert torch.equal(got, want), (k, float((got.float() - want.float()).abs().max()))
+
+
+def test_fp_chain_call_equals_python_sequence(cuda, monkeypatch):
+    torch.manual_seed(0)
+    fp = M.PointnetFPModule(mlp=[256 + 256, 256, 256]).to(cuda)
+    unknown = torch.rand(2, 1024, 3, device=cuda)
+    known = unknown[:, :512].contiguous()
+    uf = torch.randn(2, 256, 1024, device=cuda)
+    kf = torch.randn(2, 256, 512, device=cuda)
+
+    def run(m):
+        a, b = uf.clone().requires_grad_(True), kf.clone().requires_grad_(True)
+        return [m(unknown, known, a, b)], [a, b]
+    _chain_compare(run, fp, monkeypatch)
+
+
+def test_voting_chain_call_equals_python_sequence(cuda, monkeypatch):
+    torch.manual_seed(1)
+    vg = voting_module.VotingModule(1, 256).to(cuda)
+    xyz = torch.rand(2, 1024, 3, device=cuda)
+    feats = torch.randn(2, 256, 1024, device=cuda)
+
+    def run(m):   # 259 output channels: the padded (260) last layer
+        f = feats.clone().requires_grad_(True)
+        vx, vf = m(xyz, f)
+        return [vx, vf], [f]
+    _chain_compare(run, vg, monkeypatch, summed=("dconv3.bias",))
+
+
+def test_proposal_chain_call_equals_python_sequence(cuda, monkeypatch):
+    cfg = config.scannet_md40()
+    torch.manual_seed(2)
+    pm = proposal_module.ProposalModule(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                        cfg.mean_size_arr, 64, 'vote_fps').to(cuda)
+    xyz = torch.rand(2, 512, 3, device=cuda) * 2
+    feats = torch.randn(2, 256, 512, device=cuda) * 0.1
+
+    def run(m):   # vote aggregation (SA layer with coordinate gradients) + the head chain
+        x = xyz.clone().requires_grad_(True)
+        f = feats.clone().requires_grad_(True)
+        end = m(x, f, {'seed_xyz': xyz})
+        return [end['_head_output'], end['center']], [x, f]
+    _chain_compare(run, pm, monkeypatch, summed=("dconv3.bias",))
+
+
+def test_descriptions_are_cached_per_shape_and_modules_stay_copyable(cuda):
+    sa = M.PointnetSAModuleVotes(npoint=64, radius=0.5, nsample=16, mlp=[0, 16, 32],
+                                 use_xyz=True, normalize_xyz=True).to(cuda)
+    for n in (512, 512, 700):
+        xyz = torch.rand(2, n, 3, device=cuda)
+        sa(xyz, None)
+    assert len(fused_sa._LAYER_CACHE[sa]) == 2
+    clone = copy.deepcopy(sa)            # ctypes descriptions are not part of the module
+    assert clone not in fused_sa._LAYER_CACHE
+    clone(torch.rand(2, 512, 3, device=cuda), None)
