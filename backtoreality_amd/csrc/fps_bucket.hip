@@ -25,6 +25,13 @@
 
 namespace btr {
 
+// Measurement hook (btr_fps_time_next_kernel): an event pair recorded immediately around the
+// next launch of the sampling kernel itself (not its sort launches) by this host thread.
+hipEvent_t *fps_kernel_events() {
+  static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+  return ev;
+}
+
 constexpr int kSortThreads = 1024;
 constexpr int kGridBits = 5;                 // 32^3 cells (64^3 was measured: 9.4 vs 9.6 touched
 constexpr int kCells = 1 << (3 * kGridBits);  // buckets per sample, but +0.3 ms of sort)
@@ -1242,13 +1249,22 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
     }
   }
   // owner-wave kernel: 16 waves, one bucket per trip
+  hipEvent_t *ev = fps_kernel_events();   // bench.py: event pair around THIS kernel only
+  if (ev[0]) (void)hipEventRecord(ev[0], s);
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
   else
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
+  if (ev[1]) (void)hipEventRecord(ev[1], s);
+  ev[0] = ev[1] = nullptr;
   return check_launch("furthest_point_sampling(bucket)");
 }
 
 }  // namespace btr
+
+extern "C" void btr_fps_time_next_kernel(void *start_event, void *stop_event) {
+  btr::fps_kernel_events()[0] = (hipEvent_t)start_event;
+  btr::fps_kernel_events()[1] = (hipEvent_t)stop_event;
+}

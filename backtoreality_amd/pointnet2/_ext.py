@@ -88,6 +88,7 @@ _SIGNATURES = {
     "btr_pm_gemm_nt": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
     "btr_pm_out": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "btr_pm_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp]),
+    "btr_fps_time_next_kernel": (None, [_vp, _vp]),
     # whole-layer entry points (csrc/sa_layer.hip): description + plan by address
     "btr_sa_layer_plan": (_ci, [_vp, _vp]),
     "btr_sa_layer_forward": (_ci, [_vp] * 11),
@@ -338,6 +339,15 @@ def _fps(points, nsamples, block_size, out):
         ws = None
         temp = torch.empty((B, N), dtype=torch.float32, device=points.device)
     with _on(points) as dev:
+        kernel_only = ws is not None and _TIMING is not None and (
+            _TIMING_FILTER is None or _TIMING_FILTER("fps_kernel", (B, N, nsamples)))
+        if kernel_only:   # event pair around the sampling kernel alone (not its sort launches)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()   # (creates the handles; the library records them again in place)
+            e1.record()
+            _idx.btr_fps_time_next_kernel(e0.cuda_event, e1.cuda_event)
+            _TIMING.append(("fps_kernel", (B, N, nsamples), e0, e1))
         _call(_idx.btr_furthest_point_sampling_ws, B, N, nsamples, _p(points), _p(temp),
               _p(out), int(block_size), _p(ws), ws_bytes, _stream(dev),
               key=(B, N, nsamples))

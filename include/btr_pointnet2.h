@@ -85,6 +85,11 @@ int btr_furthest_point_sampling_ws(int b, int n, int m, const float *dataset, fl
                                    int *idxs, int block_size, void *workspace,
                                    size_t workspace_bytes, btr_stream_t stream);
 
+/* Measurement only (bench.py): the next large-scene btr_furthest_point_sampling* call of this
+ * host thread records the two hipEvent_t around its sampling kernel alone (the spatial-sort
+ * launches in front of it stay outside), on the call's stream.  NULL, NULL cancels. */
+void btr_fps_time_next_kernel(void *start_event, void *stop_event);
+
 /* Replaces gather_points_kernel_wrapper(b, c, n, npoints, points, idx, out)
  *   decl src/sampling.cpp:9-11, def src/sampling_gpu.cu:27-36, kernel :13-25.
  * out[b,c,j] = points[b,c,idx[b,j]];  points (b,c,n) f32, idx (b,npoints) i32. */

@@ -9,7 +9,8 @@ query, flops per step of the MFMA GEMM family) -- functions of the shapes, not m
 Taken from the profile: the kernel durations (tools/rocpd_step.py: per kernel name the calls,
 the summed and the longest duration inside one steady-state step).
 
-  FPS         fps_bucket_kernel's longest call + the fps_sortm_* launches of that scene batch
+  FPS         fps_bucket_kernel's longest call (the live figure is an event pair around that
+              kernel alone)
   ball query  the longest bqb_query_kernel (or bq_grid_query_kernel) call + its set-up
               launches (bqb_box / bqb_super, or the grid build), longest call of each
   grouped MLP every gemm_nt_kernel / gemm_tn_kernel launch of the step (+ reduce_chunks, the
@@ -50,7 +51,9 @@ def main():
     out = []
     fps = js.get("roofline")
     if fps:
-        us = longest("fps_bucket_kernel") + sum(r[3] for r in rows if "fps_sortm_" in r[0])
+        us = longest("fps_bucket_kernel")
+        if "fps_sortm" in fps.get("kernel", ""):   # older lines timed the whole call
+            us += sum(r[3] for r in rows if "fps_sortm_" in r[0])
         ach = fps["algorithmic_bytes"] / (us * 1e-6) / 1e9
         out.append(("roofline (FPS)", fps["avg_ms"] * 1e3, us, fps["frac"], ach / HBM_PEAK_GBS))
     bq = js.get("ball_query_roofline")

@@ -4,6 +4,7 @@ two consecutive launches of a marker kernel (default: the large-scene FPS kernel
 step) -- the one with the MEDIAN wall time among the windows shorter than 1.5x the shortest
 (warm-up and bench.py's fully instrumented detail steps are longer).
 Usage: rocpd_step.py results.db [marker-substring] [out.md] [markers-per-step]"""
+import os
 import sqlite3
 import sys
 
@@ -21,7 +22,8 @@ def main():
     if len(marks) < 2:
         raise SystemExit("marker %r seen %d times" % (marker, len(marks)))
     wins = sorted((b - a, a, b) for a, b in zip(marks[:-1], marks[1:]))
-    wins = [w for w in wins if w[0] <= 1.5 * wins[0][0]]
+    if os.environ.get("ROCPD_WINDOW") != "median":   # (median of ALL windows: pipelined loop,
+        wins = [w for w in wins if w[0] <= 1.5 * wins[0][0]]   # whose shortest window is the prologue)
     _, t0, t1 = wins[len(wins) // 2]
     agg = {}
     for n, s, e in rows:

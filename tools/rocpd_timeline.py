@@ -3,6 +3,7 @@
 window choice as rocpd_step.py): start offset, duration, gap to the previous end on any queue,
 queue id, kernel.  Usage: rocpd_timeline.py results.db [marker-substring] [out.txt]"""
 import re
+import os
 import sqlite3
 import sys
 
@@ -19,7 +20,8 @@ def main():
     rows = c.execute(sel).fetchall()
     marks = [r[1] for r in rows if marker in r[0]]
     wins = sorted((b - a, a, b) for a, b in zip(marks[:-1], marks[1:]))
-    wins = [w for w in wins if w[0] <= 1.5 * wins[0][0]]
+    if os.environ.get("ROCPD_WINDOW") != "median":   # (median of ALL windows: pipelined loop,
+        wins = [w for w in wins if w[0] <= 1.5 * wins[0][0]]   # whose shortest window is the prologue)
     _, t0, t1 = wins[len(wins) // 2]
     out = ["step window %.3f ms" % ((t1 - t0) / 1e6), "start_us   dur_us   idle_us  queue  kernel"]
     last_end = t0
