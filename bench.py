@@ -168,7 +168,11 @@ def main():
         rccl_ranks = int(ones.item())
         assert rccl_ranks == args.gpus, "all-reduce saw %d ranks" % rccl_ranks
 
-    if not args.no_conv_autotune:   # before the first convolution runs (train.enable_conv_autotune)
+    # MIOpen solver look-up for the stock convolutions that are left: none in the FSB step (its
+    # 1x1 conv chains run on this package's kernels), the domain classifiers of the BR / CR
+    # steps and GroupFree3D's decoder / heads
+    autotune = not args.no_conv_autotune and args.workload != "fsb"
+    if autotune:   # before the first convolution runs (train.enable_conv_autotune)
         train.enable_conv_autotune()
     cfg = config.scannet_md40()
     br = args.workload in ("br", "cr")
@@ -177,7 +181,7 @@ def main():
     gfbr = args.workload == "gfbr"
     if gf:
         from backtoreality_amd.groupfree import train as gf_train
-        if not args.no_conv_autotune:     # shipped GEMM solution choices (TunableOp)
+        if autotune:     # shipped GEMM solution choices (TunableOp)
             gf_train.enable_gemm_tuning()
         if args.points == 40000 and args.batch == 8:      # configs[3]: 4 x 50 000 points
             args.points, args.batch = 50000, 4
@@ -267,7 +271,7 @@ def main():
         return out
 
     graphed_step = None
-    if not args.no_conv_autotune:
+    if autotune:
         # One-time set-up, never timed: MIOpen's solver look-up (or search, for a shape that is
         # not in the shipped find-db) for the stock convolution layers happens in this priming
         # step, whatever --warmup is.
