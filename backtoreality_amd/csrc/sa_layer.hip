@@ -485,7 +485,7 @@ int btr_pm_chain_plan(const btr_pm_chain_t *dp, btr_pm_plan_t *p) {
   BTR_REQUIRE(dp && p, "pm_chain_plan: null pointer");
   const btr_pm_chain_t &d = *dp;
   BTR_REQUIRE(d.layers >= 1 && d.layers <= kMaxL, "pm_chain_plan: %d layers", d.layers);
-  BTR_REQUIRE(d.b > 0 && d.n > 0 && d.c > 0 && d.c % 4 == 0, "pm_chain_plan: bad sizes");
+  BTR_REQUIRE(d.b > 0 && d.n > 0 && d.c > 0, "pm_chain_plan: bad sizes");
   BTR_REQUIRE((long long)d.b * d.n < (1ll << 31), "pm_chain_plan: too many rows");
   std::memset(p, 0, sizeof(*p));
   const int L = d.layers;
@@ -494,14 +494,14 @@ int btr_pm_chain_plan(const btr_pm_chain_t *dp, btr_pm_plan_t *p) {
   for (int l = 0; l < L; ++l) {
     BTR_REQUIRE(d.width[l] > 0, "pm_chain_plan: width");
     p->np[l] = ceil4(d.width[l]);
-    p->kin[l] = l == 0 ? d.c : p->np[l - 1];
-    BTR_REQUIRE(!d.has_bn[l] || (d.width[l] % 4 == 0 && d.width[l] <= 256),
+    p->kin[l] = l == 0 ? ceil4(d.c) : p->np[l - 1];   // input rows zero-padded to 4 columns
+    BTR_REQUIRE(!d.has_bn[l] || (d.width[l] % 4 == 0 && d.width[l] <= 512),
                 "pm_chain_plan: BatchNorm layer of width %d", d.width[l]);
     BTR_REQUIRE(d.has_bn[l] || l == L - 1, "pm_chain_plan: only the last layer may lack BN");
     maxn = std::max(maxn, p->np[l]);
   }
   Bump sv;
-  p->x0 = sv.floats((size_t)p->rows * d.c);
+  p->x0 = sv.floats((size_t)p->rows * p->kin[0]);
   for (int l = 0; l < L; ++l) {
     p->y[l] = sv.floats((size_t)p->rows * p->np[l]);
     p->w2[l] = sv.floats((size_t)p->np[l] * p->kin[l]);
@@ -567,10 +567,12 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
   pa.first[L] = blocks;
   hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, hs, pa);
 
+  const int k0 = p.kin[0];
+  BTR_REQUIRE(!x_cl || k0 == d.c, "pm_chain_forward: x_cl needs a channel count that is a multiple of 4");
   const float *A = x_cl;
   if (!A) {
     float *x0 = at_f(saved, p.x0);
-    BTR_TRY(btr_pm_rows(d.b, d.n, d.c, d.c, x_bcn, x0, stream));
+    BTR_TRY(btr_pm_rows(d.b, d.n, d.c, k0, x_bcn, x0, stream));
     A = x0;
   }  // else: the caller keeps x_cl alive and hands it to the backward again
   const int grid = btr_pm_gemm_grid(rows);
@@ -578,7 +580,7 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
   for (int l = 0; l < L; ++l) maxn = std::max(maxn, p.np[l]);
   float *part = (float *)scratch;
   float *bias_pad = part + (size_t)grid * 2 * maxn;
-  int lda = d.c;
+  int lda = k0;
   const float *pscale = nullptr, *pshift = nullptr;
   for (int l = 0; l < L; ++l) {
     const int np = p.np[l], k = p.kin[l];
@@ -652,7 +654,7 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
   for (int l = L - 1; l >= 0; --l) {
     const int np = p.np[l], k = p.kin[l];
     const float *xsrc = l == 0 ? (x_cl ? x_cl : at_f(saved, p.x0)) : at_f(saved, p.y[l - 1]);
-    const int ldx = l == 0 ? d.c : p.np[l - 1];
+    const int ldx = l == 0 ? p.kin[0] : p.np[l - 1];
     const float *pa = l == 0 ? nullptr : stat(l - 1, 0);
     const float *pb = l == 0 ? nullptr : stat(l - 1, 1);
     BTR_TRY(btr_sa_gemm_tn(rows, np, k, dy, np, xsrc, ldx, pa, pb, pw, grads + p.dw[l], stream));
@@ -668,7 +670,7 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
         dy = gn;
       } else {
         BTR_REQUIRE(dx, "pm_chain_backward: dx missing");
-        BTR_TRY(btr_pm_out(d.b, d.n, d.c, d.c, gn, nullptr, nullptr, 0, dx, nullptr, stream));
+        BTR_TRY(btr_pm_out(d.b, d.n, d.c, p.kin[0], gn, nullptr, nullptr, 0, dx, nullptr, stream));
       }
     }
   }

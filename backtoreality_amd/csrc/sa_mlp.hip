@@ -808,11 +808,12 @@ __global__ __launch_bounds__(256) void sa_pool_bwd_apply_kernel(
 // Hidden layers: G holds dX (gradient w.r.t. the post-ReLU activation).  Pass 1 (stats):
 // g = G * (a*Y + b > 0);  part <- sum(g), sum(g*xhat).   Pass 2 (apply, in place on G):
 // G <- a * (g - m1 - xhat*m2).  Rows x channels elementwise, lanes along c.
-constexpr int kBnBwdMaxC = 256;
+constexpr int kBnBwdMaxC = 512;
 
 // Statistics pass: every thread owns 4 consecutive channels (one float4 per row) and walks
-// the rows assigned to its row slot; C % 4 == 0, C <= 256, so a row is covered by C/4 <= 64
-// lanes and a 256-thread block streams 256/(C/4) rows per iteration with 16-byte loads.
+// the rows assigned to its row slot; C % 4 == 0, C <= 512, so a row is covered by C/4 <= 128
+// lanes and a 256-thread block streams 256/(C/4) rows per iteration with 16-byte loads
+// (threads beyond the last whole row slot idle: C = 288 uses 216 of 256).
 __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(
     long long R, int C, int ld, const float *__restrict__ G, const float *__restrict__ Y,
     const float *__restrict__ scale, const float *__restrict__ shift,

@@ -140,7 +140,9 @@ class GroupFreeDetector(nn.Module):
         return self._finish(end_points)
 
     def _backbone(self, inputs, center_xyz, center_cls):
-        return self.backbone_net(inputs['point_clouds'], {})
+        # inputs['sampling']: optional handle of backbone_net.prefetch_sampling (the pyramid of
+        # this cloud computed ahead, e.g. under the previous step's backward)
+        return self.backbone_net(inputs['point_clouds'], {}, sampling=inputs.get('sampling'))
 
     def _after_decoder_layer(self, prefix, query, end_points):
         """Hook for the domain-adaptation variant."""

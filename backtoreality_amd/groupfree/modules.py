@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..pointnet2 import pointnet2_utils
+from ..pointnet2 import fused_mlp, pointnet2_utils
 
 
 class PointsObjClsModule(nn.Module):
@@ -22,6 +22,11 @@ class PointsObjClsModule(nn.Module):
         self.conv3 = nn.Conv1d(self.in_dim, 1, 1)
 
     def forward(self, seed_features):
+        net = fused_mlp.run_chain(seed_features, [(self.conv1, self.bn1, True),
+                                                  (self.conv2, self.bn2, True),
+                                                  (self.conv3, None, False)])
+        if net is not None:   # the chain on this package's GEMM / BatchNorm kernels
+            return net
         net = F.relu(self.bn1(self.conv1(seed_features)))
         net = F.relu(self.bn2(self.conv2(net)))
         return self.conv3(net)
@@ -39,7 +44,10 @@ class PositionEmbeddingLearned(nn.Module):
             nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
 
     def forward(self, xyz):
-        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+        x = xyz.transpose(1, 2).contiguous()
+        head = self.position_embedding_head
+        out = fused_mlp.run_chain(x, [(head[0], head[1], True), (head[3], None, False)])
+        return out if out is not None else head(x)
 
 
 def _take(xyz, features, sample_inds):
@@ -66,6 +74,18 @@ class GeneralSamplingModule(nn.Module):
 
     def forward(self, xyz, features, sample_inds):
         return _take(xyz, features, sample_inds)
+
+
+class _CatConv(object):
+    """Several 1x1 Conv1d layers of the same input seen as ONE layer (weights / biases
+    concatenated along the output channels): what fused_mlp.run_chain needs of a conv."""
+    kernel_size, stride, groups = (1,), (1,), 1
+
+    def __init__(self, convs):
+        self.weight = torch.cat([c.weight for c in convs], 0)
+        self.bias = torch.cat([c.bias for c in convs], 0)
+        self.in_channels = convs[0].in_channels
+        self.out_channels = self.weight.shape[0]
 
 
 class PredictHead(nn.Module):
@@ -105,16 +125,20 @@ class PredictHead(nn.Module):
 
     def forward(self, features, base_xyz, end_points, prefix=''):
         B, P = features.shape[0], features.shape[-1]
-        net = F.relu(self.bn1(self.conv1(features)))
-        net = F.relu(self.bn2(self.conv2(net)))
         # the seven output layers are 1x1 convolutions of the same `net`: one convolution with
         # the concatenated weights (116 output channels at ScanNet sizes) instead of seven of
         # 1..66 channels; the parameters stay separate (state-dict keys of the reference)
         heads = (self.objectness_scores_head, self.center_residual_head, self.heading_class_head,
                  self.heading_residual_head, self.size_class_head, self.size_residual_head,
                  self.sem_cls_scores_head)
-        out = F.conv1d(net, torch.cat([h.weight for h in heads], 0),
-                       torch.cat([h.bias for h in heads], 0)).transpose(2, 1)   # (B, P, sum)
+        last = _CatConv(heads)
+        out = fused_mlp.run_chain(features, [(self.conv1, self.bn1, True),
+                                             (self.conv2, self.bn2, True), (last, None, False)])
+        if out is None:   # stock ops (CPU, eval mode, BTR_FUSED_MLP=0)
+            net = F.relu(self.bn1(self.conv1(features)))
+            net = F.relu(self.bn2(self.conv2(net)))
+            out = F.conv1d(net, last.weight, last.bias)
+        out = out.transpose(2, 1)   # (B, P, sum)
         (objectness_scores, center_residual, heading_scores, heading_residuals_normalized,
          size_scores, size_residuals_flat, sem_cls_scores) = torch.split(
             out, [h.out_channels for h in heads], dim=2)

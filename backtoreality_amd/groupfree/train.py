@@ -67,18 +67,29 @@ def get_scheduler(optimizer, n_iter_per_epoch, lr_scheduler="step", max_epoch=40
     return sched
 
 
-def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, criterion=None):
+def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, criterion=None,
+               sampling=None, next_batch=None):
     """One optimisation step (train_GF_FSB.py:287-322) on `batch` (label dict on the model's
     device, GroupFree3D schema: VoteNet's keys + size_gts, point_obj_mask,
     point_instance_label).  Returns (loss, end_points); no host synchronisation.
-    `criterion`: `get_loss` (default) or `get_loss_weak` (train_GF_WSB.py:217)."""
+    `criterion`: `get_loss` (default) or `get_loss_weak` (train_GF_WSB.py:217).
+    `sampling` / `next_batch`: software pipelining as in votenet.train.train_step -- the
+    sampling pyramid of the NEXT batch (coordinates only) runs on the side stream under this
+    step's backward and comes back as end_points['next_sampling']."""
     loss_args = dict(LOSS_ARGS, **(loss_args or {}))
-    end_points = net({'point_clouds': batch['point_clouds']})
+    inputs = {'point_clouds': batch['point_clouds']}
+    if sampling is not None:
+        inputs['sampling'] = sampling
+    end_points = net(inputs)
     for key in batch:
         assert key not in end_points
         end_points[key] = batch[key]
     loss, end_points = (criterion or get_loss)(end_points, cfg, **loss_args)
     optimizer.zero_grad(set_to_none=True)
+    if next_batch is not None:
+        core = net.module if hasattr(net, "module") else net
+        end_points['next_sampling'] = core.backbone_net.prefetch_sampling(
+            next_batch['point_clouds'])
     loss.backward()
     _sync_grads(net)          # data parallel: one all-reduce of the flat gradient buffer
     if clip_norm > 0:
@@ -129,6 +140,64 @@ class GraphedTrainStep(object):
                 for k, v in src.items():
                     if v is not dst[k]:
                         dst[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.loss, self.end_points
+
+
+class GraphedPipelinedStep(object):
+    """GraphedTrainStep with the NEXT batch's sampling pyramid inside the same graph, on a side
+    stream under the backward (votenet.train.GraphedPipelinedStep has the scheme): the four FPS
+    levels of a 4 x 50 000-point batch occupy 4 of 256 CUs for 3.3 ms, which this hides.
+    `cur` (whole batch) and `nxt_pc` are static buffers filled by __call__; `prime(batch)`
+    computes the pyramid of the first batch eagerly."""
+
+    def __init__(self, net, optimizer, batch, next_batch, cfg, loss_args=None, clip_norm=0.1,
+                 warmup=3):
+        self.net, self.optimizer = net, optimizer
+        self.cur = {k: v.clone() for k, v in batch.items()}
+        self.nxt_pc = next_batch['point_clouds'].clone()
+        bb = net.backbone_net
+        pyr = bb.prefetch_sampling(self.cur['point_clouds'])
+        torch.cuda.synchronize()
+        self.p_out = [inds.clone() for inds, _ in pyr]
+        self.p_in = [t.clone() for t in self.p_out]
+
+        def step():
+            for dst, src in zip(self.p_in, self.p_out):
+                dst.copy_(src)
+            loss, end = train_step(net, optimizer, self.cur, cfg, loss_args, clip_norm,
+                                   sampling=[(t, None) for t in self.p_in],
+                                   next_batch={'point_clouds': self.nxt_pc})
+            torch.cuda.current_stream().wait_stream(bb._prefetch_stream)
+            for dst, (inds, _) in zip(self.p_out, end['next_sampling']):
+                dst.copy_(inds)
+            return loss, end
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.end_points = step()
+
+    def prime(self, batch):
+        pyr = self.net.backbone_net.prefetch_sampling(batch['point_clouds'])
+        main = torch.cuda.current_stream()
+        for dst, (inds, ev) in zip(self.p_out, pyr):
+            if ev is not None:
+                main.wait_event(ev)
+            dst.copy_(inds)
+
+    def __call__(self, batch, next_batch):
+        for k, v in batch.items():
+            if v is not self.cur[k]:
+                self.cur[k].copy_(v, non_blocking=True)
+        if next_batch is not None:
+            self.nxt_pc.copy_(next_batch['point_clouds'], non_blocking=True)
         self.graph.replay()
         return self.loss, self.end_points
 

@@ -237,10 +237,11 @@ def main():
 
     # two distinct resident batches, alternated: nothing a step computes can be reused by the next
     batches = [batch]
-    if not br and not gf:
+    if not br and not gfbr:
         batches.append(synthetic.make_batch(500000 + rank * B, B, args.points, cfg, device=dev,
                                             center_jitter=jit, use_height=not gf))
-    pipelined_loop = not br and not gf and not args.sequential
+    pipelined_loop = not br and not gfbr and not args.sequential
+    pipe_step = gf_train.train_step if gf else train.train_step
 
     def run_steps(n, record=None):
         """n training steps over the alternating batches.  pipelined_loop: the loop of a
@@ -265,8 +266,8 @@ def main():
         sampling = core.backbone_net.prefetch_sampling(batches[0]['point_clouds'])
         for i in range(n):
             nxt = batches[(i + 1) % len(batches)] if i + 1 < n else None
-            out = train.train_step(ddp, opt, batches[i % len(batches)], cfg, sampling=sampling,
-                                   next_batch=nxt)
+            out = pipe_step(ddp, opt, batches[i % len(batches)], cfg, sampling=sampling,
+                            next_batch=nxt)
             sampling = out[1].get('next_sampling')
         return out
 
@@ -280,6 +281,11 @@ def main():
     if pipelined_loop and not gf and not br and fsb_graph:
         # one-time capture (untimed, like the priming step above)
         graphed_step = train.GraphedPipelinedStep(net, opt, batches[0], batches[1], cfg)
+        barrier()
+    if pipelined_loop and gf and graphed:
+        # GroupFree3D: the eager loop is host-bound (~3 500 launches), so the pipelined step is
+        # replayed as one HIP graph (next batch's pyramid on a side stream inside the graph)
+        graphed_step = gf_train.GraphedPipelinedStep(net, opt, batches[0], batches[1], cfg)
         barrier()
     run_steps(args.warmup)
     barrier()

@@ -474,7 +474,7 @@ int btr_sa_layer_backward(const btr_sa_layer_t *d, const btr_sa_plan_t *plan, co
                           btr_stream_t stream);
 
 typedef struct {
-  int b, n, c;                  /* x: (b, c, n); c a multiple of 4                               */
+  int b, n, c;                  /* x: (b, c, n); rows are zero-padded to a multiple of 4 columns */
   int layers;
   int width[BTR_MAX_LAYERS];
   int has_bn[BTR_MAX_LAYERS];   /* conv -> BatchNorm -> ReLU; the last layer may be a bare conv  */
