@@ -5,6 +5,7 @@ import torch
 
 from ..votenet.train import _sync_grads
 from .detector import GroupFreeDetector, GroupFreeDetector_DA, GroupFreeDetector_DA_jitter
+from . import fused_attention
 from .loss_helper import get_loss
 
 # train_GF_FSB.py:42-52
@@ -80,6 +81,8 @@ def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, criter
     inputs = {'point_clouds': batch['point_clouds']}
     if sampling is not None:
         inputs['sampling'] = sampling
+    if inputs['point_clouds'].is_cuda:   # new attention-dropout masks every step (also when
+        fused_attention.bump_step(inputs['point_clouds'].device)   # the step is a replayed graph)
     end_points = net(inputs)
     for key in batch:
         assert key not in end_points
@@ -208,6 +211,8 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_no
     labels only) forward, then one `get_loss_DA`, one backward, clipping, one AdamW step."""
     from .loss_helper import get_loss_DA
     loss_args = dict(LOSS_ARGS, **(loss_args or {}))
+    if batch_S['point_clouds'].is_cuda:
+        fused_attention.bump_step(batch_S['point_clouds'].device)
     end_points_S = net({'point_clouds': batch_S['point_clouds']})
     end_points_T = net({'point_clouds': batch_T['point_clouds']})
     for key in batch_S:

@@ -2,9 +2,12 @@
 post-norm self-attention over the query points, cross-attention onto the seed points, FFN;
 position embeddings are added to queries and keys AND to the values (the reference passes
 the position-augmented tensors as `value`).  `torch.nn.MultiheadAttention` is the module the
-reference vendors a copy of (models/multi_head_attention.py), same parameter names."""
+reference vendors a copy of (models/multi_head_attention.py), same parameter names; on the
+GPU its forward runs through groupfree/fused_attention.py (hand-written attention core)."""
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import fused_attention
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -37,13 +40,20 @@ class TransformerDecoderLayer(nn.Module):
         query = query.permute(2, 0, 1)
         key = key.permute(2, 0, 1)
 
+        # attention core: the fused kernels (csrc/attention.hip) when they cover the call, else
+        # the stock module (CPU, BTR_FUSED_ATTENTION=0)
         qp = query if q_pos is None else query + q_pos
-        query = self.norm1(query + self.dropout1(self.self_attn(qp, qp, value=qp)[0]))
+        att = fused_attention.mha_forward(self.self_attn, qp, qp)
+        if att is None:
+            att = self.self_attn(qp, qp, value=qp)[0]
+        query = self.norm1(query + self.dropout1(att))
 
         qp = query if q_pos is None else query + q_pos
         kp = key if k_pos is None else key + k_pos
-        query = self.norm2(query + self.dropout2(self.multihead_attn(query=qp, key=kp,
-                                                                     value=kp)[0]))
+        att = fused_attention.mha_forward(self.multihead_attn, qp, kp)
+        if att is None:
+            att = self.multihead_attn(query=qp, key=kp, value=kp)[0]
+        query = self.norm2(query + self.dropout2(att))
 
         ffn = self.linear2(self.dropout(self.activation(self.linear1(query))))
         query = self.norm3(query + self.dropout3(ffn))

@@ -511,6 +511,27 @@ int btr_pm_chain_backward(const btr_pm_chain_t *d, const btr_pm_plan_t *plan, co
                           const float *dout, void *saved, float *grads, float *dx,
                           void *scratch, btr_stream_t stream);
 
+/* ---- fused multi-head attention core (GroupFree3D decoder) -----------------------
+ * reference: detection/GroupFree3D/models/transformer.py:36-76 -> models/multi_head_attention.py
+ * (softmax(q k^T / sqrt(d)) -> dropout -> . v per head, and its autograd backward).
+ * q[l][b][h*d + c] is read at q + l*q_sl + b*q_sb (element strides), k / v likewise with
+ * kv_sl / kv_sb: the projection outputs are used in place.  out, dout: (lq, b, h*d) contiguous;
+ * lse, dsum: (b*h, lq) floats (saved log-sum-exp / backward scratch).  dq / dk / dv are written
+ * with their own strides (e.g. into one packed (L, B, 3E) gradient).  dropout_p in [0, 1):
+ * keep-mask = hash(seed, *step, element), identical in forward and backward for equal
+ * (seed, *step); step may be NULL.  Head width d <= 64. */
+int btr_attention_supported(int d);
+int btr_attention_fwd(int lq, int lk, int b, int h, int d, const float *q, long long q_sl,
+                      long long q_sb, const float *k, const float *v, long long kv_sl,
+                      long long kv_sb, float *out, float *lse, float scale, float dropout_p,
+                      unsigned long long seed, const long long *step, btr_stream_t stream);
+int btr_attention_bwd(int lq, int lk, int b, int h, int d, const float *q, long long q_sl,
+                      long long q_sb, const float *k, const float *v, long long kv_sl,
+                      long long kv_sb, const float *out, const float *dout, const float *lse,
+                      float *dsum, float *dq, long long dq_sl, long long dq_sb, float *dk,
+                      float *dv, long long dkv_sl, long long dkv_sb, float scale, float dropout_p,
+                      unsigned long long seed, const long long *step, btr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

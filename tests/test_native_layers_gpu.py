@@ -86,6 +86,7 @@ def test_sa_layer_call_equals_python_sequence(cuda, monkeypatch, N, npoint, radi
 
 
 def _chain_compare(run, mod, monkeypatch, summed=()):
+    monkeypatch.setenv("BTR_CHAIN_MIN_ROWS", "0")   # (small test shapes: below the default gate)
     res = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("BTR_NATIVE_LAYERS", flag)
