@@ -1081,6 +1081,281 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
   if (dbg && tid == 0) dbg[bi] = rounds;
 }
 
+
+// ------------------------------------ multi-sample rounds, pipelined (BTR_FPS_IMPL=pm, opt-in)
+// MEASURED AND NOT ADOPTED (MI355X, 8 x 40000 -> 2048): 2.26 ms against 2.23 ms for the
+// one-sample-per-step kernel; bit-exact in the whole index suite.  The multi-sample scheme above
+// (same invariant, same acceptance rule (i)-(iii), hence the same exactness argument) on the
+// owner-wave kernel's machinery: touched buckets are updated with the software-pipelined
+// two-register-set loop (all accepted samples applied in one pass: t = min over the samples);
+// after the first barrier every wave RANKS its own candidate among the NW (one compare per
+// lane), the KMAX best go to sorted[rank], and after a second barrier the chain is validated
+// with one (earlier, later) pair per lane.  One bucket per lane (n <= NW * 64 * 64 points).
+// KMAX = 4: 3.0 samples per round, 681 rounds -- but 7 500 cycles per round (s_memtime,
+// BTR_FPS_PROF=1 BTR_FPS_IMPL=pm): box tests against 4 samples 520-840, bucket trips
+// 1 800-2 200 (1.9 per wave and round), wave arg-max 380, barrier 1 1 200-2 900 (the wave with
+// the most trips), rank 440-640, barrier 2 150-330, chain 1 200-2 100 = 2 500 cycles per SAMPLE
+// against 2 600 for one sample per step.  The number of bucket trips per sample is the same
+// either way (9.6; each an L2 round trip + three wave reductions), better balanced here (the
+// busiest wave makes ~1.2 trips per sample instead of 1.6), and that gain is spent on the second
+// barrier and on 16 waves sharing 4 SIMDs for the rank / chain arithmetic (an earlier form
+// where every wave extracted and validated the candidates itself, no second barrier, needed
+// 9 200 cycles per round: ~280 instructions x 16 waves is issue-bound).  What bounds FPS on
+// this machine is the trip: ~1 000 cycles of L2 latency + reductions per touched bucket.
+template <int NW, int KMAX, bool PROF = false>
+__global__ __launch_bounds__(NW * 64) void fps_bucket_pm_kernel(
+    int n, int np, int m, int bs, int log2bs, const float *__restrict__ dataset,
+    const float4 *__restrict__ spts, float *__restrict__ tmin, int *__restrict__ idxs,
+    unsigned long long *dbg) {
+  static_assert(NW <= 16 && KMAX <= NW && KMAX <= 8, "slots are reduced by one 16-lane row");
+  __shared__ MSlot slots[NW];      // one slot per wave: its winner this round
+  __shared__ MSlot sorted[KMAX];   // the KMAX best of them, in order
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, ntrip = 0;
+#define BTR_PMH(i)                                                 \
+  if (PROF) {                                                      \
+    const unsigned long long now = __builtin_amdgcn_s_memtime();   \
+    tph[i] += now - tlast;                                         \
+    tlast = now;                                                   \
+  }
+
+  __builtin_amdgcn_s_setprio(3);
+  const int bi = blockIdx.x;
+  dataset += (size_t)bi * n * 3;
+  spts += (size_t)bi * np;
+  tmin += (size_t)bi * np;
+  idxs += (size_t)bi * m;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = np >> 6;
+  const TieParams tp{bs, log2bs, (n + bs - 1) >> log2bs};
+  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
+
+  float bx0 = 0.f, by0 = 0.f, bz0 = 0.f, bx1 = 0.f, by1 = 0.f, bz1 = 0.f;
+  unsigned mhi = 0u, mlo = 0u, mb2 = 0u;
+  int mk = 0;
+  float mx = 0.f, my = 0.f, mz = 0.f;
+  {
+    const int myb = lane * NW + wave;
+    if (myb < nb) {
+      const float *bp = (const float *)spts + (size_t)myb * 256;
+      const float *tm = tmin + (size_t)myb * 64;
+      float ax0 = bp[0], ax1 = ax0, ay0 = bp[64], ay1 = ay0, az0 = bp[128], az1 = az0;
+      bool any = tm[0] >= 0.f;
+#pragma unroll 8
+      for (int i = 1; i < 64; ++i) {
+        if (__float_as_int(bp[192 + i]) < 0) continue;
+        const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
+        ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
+        ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
+        az0 = fminf(az0, qz); az1 = fmaxf(az1, qz);
+        any |= tm[i] >= 0.f;
+      }
+      bx0 = ax0; bx1 = ax1; by0 = ay0; by1 = ay1; bz0 = az0; bz1 = az1;
+      mhi = mb2 = any ? __float_as_uint(1e10f) + 1u : 0u;   // (b2 = best: no chain until the
+    }                                                         // bucket has been through a pass)
+  }
+  if (tid == 0) idxs[0] = 0;
+  float ax[KMAX], ay[KMAX], az[KMAX];   // samples accepted in the previous round (wave-uniform)
+#pragma unroll
+  for (int a = 0; a < KMAX; ++a) { ax[a] = x0; ay[a] = y0; az[a] = z0; }
+  int nacc = 1;
+  unsigned long long rounds = 0;
+  int wl = 0;
+  unsigned wh = 0u, w2 = 0u;
+  bool fresh = false;
+
+  if (PROF) tlast = __builtin_amdgcn_s_memtime();
+  for (int j = 1; j < m;) {
+    // ---- box test against every accepted sample
+    bool active = false;
+#pragma unroll
+    for (int a = 0; a < KMAX; ++a) {
+      if (a < nacc) {
+        const float cx = fminf(fmaxf(ax[a], bx0), bx1);
+        const float cy = fminf(fmaxf(ay[a], by0), by1);
+        const float cz = fminf(fmaxf(az[a], bz0), bz1);
+        const float ex = cx - ax[a], ey = cy - ay[a], ez = cz - az[a];
+        active |= (__float_as_uint(sq3(ex, ey, ez)) + 1u) < mhi;
+      }
+    }
+    unsigned long long todo = __ballot(active);
+    const bool touched = todo != 0;
+    if (PROF) ntrip += __builtin_popcountll(todo);
+    BTR_PMH(0)
+    if (touched) {
+      auto fetch = [&](int b, size_t &o, float4 &p, float &t) {
+        const size_t bkt = (size_t)(b * NW + wave);
+        const float *bp = (const float *)spts + bkt * 256 + lane;
+        o = bkt * 64 + lane;
+        p.x = bp[0];
+        p.y = bp[64];
+        p.z = bp[128];
+        p.w = bp[192];
+        t = tmin[o];
+      };
+      auto process = [&](int cb, size_t co, const float4 &p, float t0) {
+        float dx, dy, dz;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(p.x), "v"(ax[0]));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(p.y), "v"(ay[0]));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(p.z), "v"(az[0]));
+        float d = sq3(dx, dy, dz);
+#pragma unroll
+        for (int a = 1; a < KMAX; ++a) {
+          if (a < nacc) {
+            const float ex = p.x - ax[a], ey = p.y - ay[a], ez = p.z - az[a];
+            d = fminf(d, sq3(ex, ey, ez));
+          }
+        }
+        const bool valid = t0 >= 0.f;
+        const float t = valid ? fminf(d, t0) : t0;
+        if (t != t0) tmin[co] = t;
+        const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
+        const unsigned mh = wave_max_u32(hi);
+        const unsigned long long cand = __ballot(hi == mh);
+        const int kk = __float_as_int(p.w);
+        int w;
+        if (__builtin_popcountll(cand) == 1) {
+          w = __builtin_ctzll(cand);
+        } else {
+          const unsigned lo = (hi == mh) ? 0xffffffffu - fps_tk2(kk, tp.bs, tp.log2bs, tp.cpb)
+                                         : 0u;
+          const unsigned ml = wave_max_u32(lo);
+          w = __builtin_ctzll(__ballot(hi == mh && lo == ml));
+        }
+        const unsigned b2 = wave_max_u32(lane == w ? 0u : hi);   // second-best hi of the bucket
+        const int wk = __builtin_amdgcn_readlane(kk, w);
+        const unsigned wlo = 0xffffffffu - fps_tk2(wk, tp.bs, tp.log2bs, tp.cpb);
+        const float wx = rl_f(p.x, w), wy = rl_f(p.y, w), wz = rl_f(p.z, w);
+        const bool mine = lane == cb;
+        mhi = mine ? mh : mhi;
+        mlo = mine ? wlo : mlo;
+        mb2 = mine ? b2 : mb2;
+        mk = mine ? wk : mk;
+        mx = mine ? wx : mx;
+        my = mine ? wy : my;
+        mz = mine ? wz : mz;
+      };
+      int bA = __builtin_ctzll(todo), bB = 0;
+      todo &= todo - 1;
+      size_t oA, oB = 0;
+      float4 pA, pB = make_float4(0.f, 0.f, 0.f, 0.f);
+      float tA, tB = 0.f;
+      fetch(bA, oA, pA, tA);
+      for (;;) {
+        if (todo == 0) {
+          process(bA, oA, pA, tA);
+          break;
+        }
+        bB = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        fetch(bB, oB, pB, tB);
+        process(bA, oA, pA, tA);
+        if (todo == 0) {
+          process(bB, oB, pB, tB);
+          break;
+        }
+        bA = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        fetch(bA, oA, pA, tA);
+        process(bB, oB, pB, tB);
+      }
+    }
+    BTR_PMH(1)
+    // ---- wave winner and the bound for everything else in this wave
+    if (touched || !fresh) {
+      wl = wave_argmax(mhi, [&]() { return mlo; }, wh);
+      w2 = wave_max_u32(lane == wl ? 0u : mhi);
+    }
+    fresh = true;
+    // (single-buffered: a slot is rewritten after the NEXT round's second barrier at the
+    // earliest, `sorted` after the next round's first)
+    MSlot *sl = slots;
+    if (lane == wl) sl[wave] = MSlot{wh, mlo, mk, mx, my, mz, mb2, w2};
+    BTR_PMH(2)
+    lds_barrier();
+    BTR_PMH(3)
+
+    // ---- phase A: every wave ranks ITS candidate among the NW (one compare per lane); the
+    // KMAX best are copied to sorted[rank].  (Doing the whole extraction + validation in every
+    // wave was measured first: 16 waves x ~280 scalar-ish instructions on 4 SIMDs is issue-
+    // bound, 2 200-5 000 cycles per round; ranking is 10 instructions.)
+    const int r = lane & 15;
+    unsigned ehi = 0u, elo = 0u, ew2 = 0u;
+    if (r < NW) {
+      ehi = sl[r].hi;
+      elo = sl[r].lo;
+      ew2 = sl[r].w2hi;
+    }
+    const unsigned U = row16_max_u32(ew2);   // bounds every point hidden behind a wave winner
+    const unsigned mylo = (unsigned)__builtin_amdgcn_readlane((int)mlo, wl);
+    const bool gt = r != wave && r < NW &&
+                    (ehi > wh || (ehi == wh && (elo > mylo || (elo == mylo && r < wave))));
+    const int rank = __builtin_popcountll(__ballot(gt) & 0xFFFFull);
+    if (rank < KMAX && lane == wl) sorted[rank] = MSlot{wh, mlo, mk, mx, my, mz, mb2, w2};
+    BTR_PMH(4)
+    lds_barrier();
+    BTR_PMH(5)
+    // ---- phase B: chain validation, one (earlier, later) candidate pair per lane
+    const int limit = min(KMAX, m - j);
+    // lane p < KMAX*(KMAX-1)/2: pair (q, t), q < t, enumerated by t: (0,1) (0,2) (1,2) (0,3) ...
+    int pt = 1, pq = lane;
+#pragma unroll
+    for (int t = 1; t < KMAX; ++t)
+      if (pq >= pt && pt == t) { pq -= t; pt = t + 1; }
+    bool okp = true;
+    if (pt < KMAX) {
+      const MSlot cq = sorted[pq], ct = sorted[pt];
+      const float tt = __uint_as_float(ct.hi - 1u);
+      const float dx = ct.x - cq.x, dy = ct.y - cq.y, dz = ct.z - cq.z;   // point c_t, sample c_q
+      okp = (fminf(sq3(dx, dy, dz), tt) == tt) && (cq.b2hi < ct.hi);       // (ii), (iii)
+    }
+    // lane 32 + t: condition (i) of candidate t (and a strict drop from candidate t - 1: a tie on
+    // hi ends the chain)
+    bool oki = true;
+    if (lane >= 32 && lane < 32 + KMAX) {
+      const int t = lane - 32;
+      const unsigned ht = sorted[t].hi;
+      const unsigned hp = sorted[t > 0 ? t - 1 : 0].hi;
+      oki = t < limit && (t == 0 || (ht > U && ht > 1u && ht < hp));
+    }
+    const unsigned long long badp = __ballot(!okp), badi = __ballot(!oki) >> 32;
+    int A = 1;
+#pragma unroll
+    for (int t = 1; t < KMAX; ++t) {
+      const unsigned long long pairs = ((1ull << t) - 1ull) << (t * (t - 1) / 2);  // (q, t), q < t
+      if (A == t && !((badi >> t) & 1ull) && !(badp & pairs)) A = t + 1;
+    }
+    const MSlot c0 = sorted[0];
+    if (c0.hi == 0u) {   // nothing competes: best = -1, besti = 0 in the reference
+      A = 1;
+      ax[0] = x0; ay[0] = y0; az[0] = z0;
+      if (tid == 0) idxs[j] = 0;
+    } else {
+#pragma unroll
+      for (int a = 0; a < KMAX; ++a) {
+        const MSlot c = sorted[a < A ? a : 0];
+        ax[a] = c.x; ay[a] = c.y; az[a] = c.z;
+      }
+      if (tid < A) idxs[j + tid] = sorted[tid].k;
+    }
+    nacc = A;
+    j += nacc;
+    ++rounds;
+    BTR_PMH(6)
+  }
+  if (PROF) {
+    if (lane == 0 && dbg) {
+      unsigned long long *o = dbg + 8 + ((size_t)bi * NW + wave) * 16;
+      for (int i = 0; i < 7; ++i) o[i] = tph[i];
+      o[7] = ntrip;
+      o[8] = rounds;
+    }
+  } else if (dbg && tid == 0) {
+    dbg[bi] = rounds;
+  }
+#undef BTR_PMH
+}
+
 struct FpsPlan {
   int nb, np;
   size_t pts_bytes, k_bytes, sort_bytes;  // sort_bytes: cells[b][32768] + meta[b][8]
@@ -1164,7 +1439,8 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
     }
     return check_launch("furthest_point_sampling(queue,prof)");
   }
-  if (getenv("BTR_FPS_PROF")) {  // tuning only: phase counters -> first bytes of idxs' scratch
+  if (getenv("BTR_FPS_PROF") && !(getenv("BTR_FPS_IMPL") && getenv("BTR_FPS_IMPL")[0] == 'p')) {
+    // tuning only: s_memtime phase counters of the default kernel
     static unsigned long long *dbg = nullptr;
     if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 64 * 16 * 8);
     hipLaunchKernelGGL((fps_bucket_kernel<16, 1, 1, true>), dim3(b), dim3(1024), 0, s, n, p.np, m,
@@ -1246,6 +1522,59 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
         hipLaunchKernelGGL((fps_queue_kernel<kBucketWaves, 2>), dim3(b), dim3(kBucketWaves * 64),
                            0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
       return check_launch("furthest_point_sampling(queue)");
+    }
+  }
+  {  // BTR_FPS_IMPL=pm: multi-sample rounds on the pipelined machinery (n <= 65 536; measured
+     // equal to the one-sample-per-step kernel below, see fps_bucket_pm_kernel)
+    const char *e = getenv("BTR_FPS_IMPL");
+    const bool pm = e && e[0] == 'p' && e[1] == 'm' && p.nb <= kBucketWaves * 64;
+    if (pm && getenv("BTR_FPS_PROF")) {   // tuning: s_memtime phase counters of scene 0
+      static unsigned long long *dbgp = nullptr;
+      if (!dbgp) (void)hipMalloc(&dbgp, sizeof(unsigned long long) * (8 + 64 * 16 * 16));
+      hipLaunchKernelGGL((fps_bucket_pm_kernel<kBucketWaves, 4, true>), dim3(b),
+                         dim3(kBucketWaves * 64), 0, s, n, p.np, m, bs, log2bs, dataset, spts, sk,
+                         idxs, dbgp);
+      (void)hipStreamSynchronize(s);
+      unsigned long long h[8 + 16 * 16];
+      (void)hipMemcpy(h, dbgp, sizeof(h), hipMemcpyDeviceToHost);
+      const char *names[7] = {"box-test", "bucket-trips", "wave-argmax+slot", "barrier-1",
+                              "rank", "barrier-2", "chain"};
+      for (int w = 0; w < 16; w += 5) {
+        const unsigned long long *o = h + 8 + w * 16;
+        const double rnd = (double)std::max<unsigned long long>(1, o[8]);
+        fprintf(stderr, "[fps pm prof] scene 0 wave %2d:", w);
+        double tot = 0;
+        for (int i = 0; i < 7; ++i) {
+          fprintf(stderr, " %s %.0f", names[i], (double)o[i] / rnd);
+          tot += (double)o[i] / rnd;
+        }
+        fprintf(stderr, " | %.0f cycles/round, %.0f rounds, %.2f trips/round\n", tot, rnd,
+                (double)o[7] / rnd);
+      }
+      return check_launch("furthest_point_sampling(bucket,pm,prof)");
+    }
+    if (pm) {
+      unsigned long long *rd = nullptr;
+      if (getenv("BTR_FPS_ROUNDS")) {
+        static unsigned long long *dbg3 = nullptr;
+        if (!dbg3) (void)hipMalloc(&dbg3, sizeof(unsigned long long) * 4096);
+        rd = dbg3;
+      }
+      hipEvent_t *ev = fps_kernel_events();
+      if (ev[0]) (void)hipEventRecord(ev[0], s);
+      hipLaunchKernelGGL((fps_bucket_pm_kernel<kBucketWaves, 4>), dim3(b),
+                         dim3(kBucketWaves * 64), 0, s, n, p.np, m, bs, log2bs, dataset, spts, sk,
+                         idxs, rd);
+      if (ev[1]) (void)hipEventRecord(ev[1], s);
+      ev[0] = ev[1] = nullptr;
+      if (rd) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long h = 0;
+        (void)hipMemcpy(&h, rd, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[fps] scene 0: %llu rounds for %d samples (%.2f samples/round)\n", h,
+                m - 1, (double)(m - 1) / (double)h);
+      }
+      return check_launch("furthest_point_sampling(bucket,pm)");
     }
   }
   // owner-wave kernel: 16 waves, one bucket per trip

@@ -88,13 +88,15 @@ def test_fps_full_size_and_both_large_kernels(cuda, monkeypatch):
     monkeypatch.setenv("BTR_FPS_IMPL", "queue")   # work-queue distribution of the bucket updates
     got_q = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
     np.testing.assert_array_equal(got_q, ref)
-    monkeypatch.setenv("BTR_FPS_IMPL", "multi")   # several samples per round, still exact
-    got = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
-    np.testing.assert_array_equal(got, ref)
+    for impl in ("multi", "pm"):   # several samples per round (two implementations), still exact
+        monkeypatch.setenv("BTR_FPS_IMPL", impl)
+        got = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
 
 
-def test_fps_multi_sample_rounds_ties_and_skips(cuda, monkeypatch):
-    monkeypatch.setenv("BTR_FPS_IMPL", "multi")
+@pytest.mark.parametrize("impl", ["multi", "pm"])
+def test_fps_multi_sample_rounds_ties_and_skips(cuda, monkeypatch, impl):
+    monkeypatch.setenv("BTR_FPS_IMPL", impl)
     rng = np.random.default_rng(12)
     xyz = rng.uniform(-3, 3, size=(2, 12000, 3)).astype(np.float32)
     xyz[:, 500:900] *= 0.004
