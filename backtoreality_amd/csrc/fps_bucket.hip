@@ -845,7 +845,7 @@ __global__ __launch_bounds__(NW * 64) void fps_queue_kernel(int n, int np, int m
 #undef BTR_QPH
 }
 
-// ------------------------------------------------------------------- multi-sample rounds
+// ------------------------------------- multi-sample rounds (BTR_FPS_IMPL=pm, opt-in)
 // Exact FPS emitting SEVERAL samples per synchronisation round.
 //
 // Round-start invariant: every min-dist is exact for the samples chosen so far and each bucket
@@ -869,223 +869,8 @@ struct MSlot {
   unsigned b2hi, w2hi;
 };
 
-template <int NW, int SL, int UB, int KMAX>
-__global__ __launch_bounds__(NW * 64) void fps_bucket_multi_kernel(
-    int n, int np, int m, int bs, int log2bs, const float *__restrict__ dataset,
-    const float4 *__restrict__ spts, float *__restrict__ tmin, int *__restrict__ idxs,
-    unsigned long long *dbg) {
-  static_assert(NW <= 16 && KMAX <= NW, "slots are reduced by one 16-lane row");
-  __shared__ MSlot wslot[NW];
-  __shared__ MSlot sorted[NW];
-  __shared__ int acc_n;
-
-  const int bi = blockIdx.x;
-  dataset += (size_t)bi * n * 3;
-  spts += (size_t)bi * np;
-  tmin += (size_t)bi * np;
-  idxs += (size_t)bi * m;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nb = np >> 6;
-  const TieParams tp{bs, log2bs, (n + bs - 1) >> log2bs};
-  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
-
-  float bx0[SL], by0[SL], bz0[SL], bx1[SL], by1[SL], bz1[SL];
-  unsigned mhi[SL], mlo[SL], mb2[SL];
-  int mk[SL];
-  float mx[SL], my[SL], mz[SL];
-#pragma unroll
-  for (int s = 0; s < SL; ++s) {
-    const int myb = (s * 64 + lane) * NW + wave;
-    bx0[s] = by0[s] = bz0[s] = bx1[s] = by1[s] = bz1[s] = 0.f;
-    mhi[s] = mlo[s] = mb2[s] = 0u;
-    mk[s] = 0;
-    mx[s] = my[s] = mz[s] = 0.f;
-    if (myb < nb) {
-      const float *bp = (const float *)spts + (size_t)myb * 256;
-      const float *tm = tmin + (size_t)myb * 64;
-      float ax0 = bp[0], ax1 = ax0, ay0 = bp[64], ay1 = ay0, az0 = bp[128], az1 = az0;
-      bool any = tm[0] >= 0.f;
-#pragma unroll 8
-      for (int i = 1; i < 64; ++i) {
-        if (__float_as_int(bp[192 + i]) < 0) continue;  // padding slot: not in the box
-        const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
-        ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
-        ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
-        az0 = fminf(az0, qz); az1 = fmaxf(az1, qz);
-        any |= tm[i] >= 0.f;
-      }
-      bx0[s] = ax0; bx1[s] = ax1; by0[s] = ay0; by1[s] = ay1; bz0[s] = az0; bz1[s] = az1;
-      mhi[s] = any ? __float_as_uint(1e10f) + 1u : 0u;  // placeholder until the first pass
-    }
-  }
-
-  if (tid == 0) idxs[0] = 0;
-  // samples accepted in the previous round (to be applied now); round 0: the start point
-  float ax[KMAX], ay[KMAX], az[KMAX];
-#pragma unroll
-  for (int a = 0; a < KMAX; ++a) { ax[a] = x0; ay[a] = y0; az[a] = z0; }
-  int nacc = 1;
-  unsigned long long rounds = 0;
-
-  for (int j = 1; j < m;) {
-    // ---------------- apply the accepted samples to every bucket they can change
-#pragma unroll
-    for (int s = 0; s < SL; ++s) {
-      bool active = false;
-#pragma unroll
-      for (int a = 0; a < KMAX; ++a) {
-        if (a < nacc) {
-          const float cx = fminf(fmaxf(ax[a], bx0[s]), bx1[s]);
-          const float cy = fminf(fmaxf(ay[a], by0[s]), by1[s]);
-          const float cz = fminf(fmaxf(az[a], bz0[s]), bz1[s]);
-          const float ex = cx - ax[a], ey = cy - ay[a], ez = cz - az[a];
-          const float dbox = sq3(ex, ey, ez);
-          active |= (__float_as_uint(dbox) + 1u) < mhi[s];
-        }
-      }
-      unsigned long long todo = __ballot(active);
-      while (todo) {
-        int bi_[UB];
-        float4 p_[UB];
-        int k_[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          bi_[u] = todo ? __builtin_ctzll(todo) : -1;
-          todo &= todo - 1;
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int b = (s * 64 + max(bi_[u], 0)) * NW + wave;
-          if (bi_[u] >= 0) {
-            p_[u] = soa_point((const float *)spts, (size_t)b * 64 + lane);
-            k_[u] = __float_as_int(p_[u].w);
-            p_[u].w = tmin[(size_t)b * 64 + lane];
-          } else {
-            p_[u] = make_float4(0.f, 0.f, 0.f, -1.f);
-            k_[u] = 0;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          if (bi_[u] < 0) continue;  // wave-uniform
-          const bool valid = p_[u].w >= 0.f;
-          float t = p_[u].w;
-#pragma unroll
-          for (int a = 0; a < KMAX; ++a) {
-            if (a < nacc) {
-              const float dx = p_[u].x - ax[a], dy = p_[u].y - ay[a], dz = p_[u].z - az[a];
-              const float d = sq3(dx, dy, dz);
-              t = valid ? fminf(d, t) : t;
-            }
-          }
-          if (t != p_[u].w) {
-            const int b = (s * 64 + bi_[u]) * NW + wave;
-            tmin[(size_t)b * 64 + lane] = t;
-          }
-          const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
-          unsigned mh;
-          const int kk = k_[u];
-          const int w = wave_argmax(
-              hi, [&]() { return 0xffffffffu - fps_tk2(kk, tp.bs, tp.log2bs, tp.cpb); }, mh);
-          const unsigned b2 = wave_max_u32(lane == w ? 0u : hi);
-          const int wk = __builtin_amdgcn_readlane(kk, w);
-          const unsigned wlo = 0xffffffffu - fps_tk2(wk, tp.bs, tp.log2bs, tp.cpb);
-          const bool mine = lane == bi_[u];
-          mhi[s] = mine ? mh : mhi[s];
-          mlo[s] = mine ? wlo : mlo[s];
-          mb2[s] = mine ? b2 : mb2[s];
-          mk[s] = mine ? wk : mk[s];
-          mx[s] = mine ? rl_f(p_[u].x, w) : mx[s];
-          my[s] = mine ? rl_f(p_[u].y, w) : my[s];
-          mz[s] = mine ? rl_f(p_[u].z, w) : mz[s];
-        }
-      }
-    }
-
-    // ---------------- wave winner (+ bounds for everything else in this wave)
-    unsigned lh = mhi[0], ll = mlo[0], lb2 = mb2[0], lsec = 0u;
-    int lk = mk[0];
-    float lx = mx[0], ly = my[0], lz = mz[0];
-#pragma unroll
-    for (int s = 1; s < SL; ++s) {
-      const bool better = mhi[s] > lh || (mhi[s] == lh && mlo[s] > ll);
-      lsec = max(lsec, better ? lh : mhi[s]);
-      lh = better ? mhi[s] : lh;
-      ll = better ? mlo[s] : ll;
-      lb2 = better ? mb2[s] : lb2;
-      lk = better ? mk[s] : lk;
-      lx = better ? mx[s] : lx;
-      ly = better ? my[s] : ly;
-      lz = better ? mz[s] : lz;
-    }
-    unsigned wh;
-    const int wl = wave_argmax(lh, [&]() { return ll; }, wh);
-    const unsigned w2 = wave_max_u32(lane == wl ? lsec : lh);
-    if (lane == wl) wslot[wave] = MSlot{wh, ll, lk, lx, ly, lz, lb2, w2};
-    lds_barrier();
-
-    // ---------------- leader: sort the NW winners, validate the chain
-    if (wave == 0) {
-      MSlot e = MSlot{0u, 0u, 0, 0.f, 0.f, 0.f, 0u, 0u};
-      if (lane < NW) e = wslot[lane];
-      const unsigned U = wave_max_u32(e.w2hi);
-      int rank = 0;
-#pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        const unsigned hq = (unsigned)__builtin_amdgcn_readlane((int)e.hi, q);
-        const unsigned lq = (unsigned)__builtin_amdgcn_readlane((int)e.lo, q);
-        const bool gt = hq > e.hi || (hq == e.hi && (lq > e.lo || (lq == e.lo && q < lane)));
-        rank += (gt && q != lane) ? 1 : 0;
-      }
-      if (lane < NW) sorted[rank] = e;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      MSlot c = MSlot{0u, 0u, 0, 0.f, 0.f, 0.f, 0u, 0u};
-      if (lane < NW) c = sorted[lane];  // lane r now holds the r-th best candidate
-      int A = 1;
-      const unsigned h0 = (unsigned)__builtin_amdgcn_readlane((int)c.hi, 0);
-      if (h0 == 0u) {  // nothing competes: best=-1, besti=0 in the reference
-        if (lane == 0) sorted[0] = MSlot{0u, 0u, 0, x0, y0, z0, 0u, 0u};
-      } else {
-        const int limit = min(KMAX, m - j);
-        for (int t = 1; t < limit; ++t) {
-          const unsigned ht = (unsigned)__builtin_amdgcn_readlane((int)c.hi, t);
-          if (!(ht > U && ht > 1u)) break;                                   // (i)
-          const float tt = __uint_as_float(ht - 1u);
-          const float xt = rl_f(c.x, t), yt = rl_f(c.y, t), zt = rl_f(c.z, t);
-          const float dx = xt - c.x, dy = yt - c.y, dz = zt - c.z;           // point c_t, sample c_r
-          const float d = sq3(dx, dy, dz);
-          const bool viol = lane < t && (fminf(d, tt) != tt || c.b2hi >= ht);  // (ii), (iii)
-          if (__ballot(viol)) break;
-          A = t + 1;
-        }
-      }
-      if (lane == 0) acc_n = A;
-    }
-    lds_barrier();
-
-    // ---------------- everyone: pick up the accepted samples
-    nacc = __builtin_amdgcn_readfirstlane(acc_n);
-#pragma unroll
-    for (int a = 0; a < KMAX; ++a) {
-      const MSlot v = sorted[a < nacc ? a : 0];
-      ax[a] = v.x; ay[a] = v.y; az[a] = v.z;
-    }
-    if (tid < nacc) idxs[j + tid] = sorted[tid].k;
-    j += nacc;
-    ++rounds;
-    // the leader reads wslot/sorted of THIS round before anyone can overwrite them: the next
-    // write to wslot happens after the next apply phase, and `sorted` is only written by the
-    // leader itself after the next barrier.
-  }
-  if (dbg && tid == 0) dbg[bi] = rounds;
-}
-
-
-// ------------------------------------ multi-sample rounds, pipelined (BTR_FPS_IMPL=pm, opt-in)
 // MEASURED AND NOT ADOPTED (MI355X, 8 x 40000 -> 2048): 2.26 ms against 2.23 ms for the
-// one-sample-per-step kernel; bit-exact in the whole index suite.  The multi-sample scheme above
-// (same invariant, same acceptance rule (i)-(iii), hence the same exactness argument) on the
+// one-sample-per-step kernel; bit-exact in the whole index suite.  The scheme above on the
 // owner-wave kernel's machinery: touched buckets are updated with the software-pipelined
 // two-register-set loop (all accepted samples applied in one pass: t = min over the samples);
 // after the first barrier every wave RANKS its own candidate among the NW (one compare per
@@ -1484,34 +1269,6 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
     }
     return check_launch("furthest_point_sampling(bucket,prof)");
   }
-  {  // BTR_FPS_IMPL=multi: the multi-sample-round kernel (exact, 3.7 samples per round on
-     // 40k-point rooms, but 6.7 us per round vs 1.5 us per one-sample step: 3.7 vs 3.1 ms, so
-     // it is opt-in until its per-round overhead comes down)
-    const char *e = getenv("BTR_FPS_IMPL");
-    const bool single = !(e && e[0] == 'm');
-    unsigned long long *rd = nullptr;
-    if (getenv("BTR_FPS_ROUNDS")) {  // tuning: print the number of rounds of scene 0
-      static unsigned long long *dbg2 = nullptr;
-      if (!dbg2) (void)hipMalloc(&dbg2, sizeof(unsigned long long) * 4096);
-      rd = dbg2;
-    }
-    if (!single) {
-      if (p.nb <= 16 * 64)
-        hipLaunchKernelGGL((fps_bucket_multi_kernel<16, 1, 2, 8>), dim3(b), dim3(1024), 0, s, n,
-                           p.np, m, bs, log2bs, dataset, spts, sk, idxs, rd);
-      else
-        hipLaunchKernelGGL((fps_bucket_multi_kernel<16, 2, 2, 8>), dim3(b), dim3(1024), 0, s, n,
-                           p.np, m, bs, log2bs, dataset, spts, sk, idxs, rd);
-      if (rd) {
-        (void)hipStreamSynchronize(s);
-        unsigned long long h = 0;
-        (void)hipMemcpy(&h, rd, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[fps] scene 0: %llu rounds for %d samples (%.2f samples/round)\n", h,
-                m - 1, (double)(m - 1) / (double)h);
-      }
-      return check_launch("furthest_point_sampling(bucket,multi)");
-    }
-  }
   {  // BTR_FPS_IMPL=queue: the work-queue kernel (measured slower, see its header)
     const char *e = getenv("BTR_FPS_IMPL");
     if (e && e[0] == 'q') {
@@ -1527,7 +1284,8 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   {  // BTR_FPS_IMPL=pm: multi-sample rounds on the pipelined machinery (n <= 65 536; measured
      // equal to the one-sample-per-step kernel below, see fps_bucket_pm_kernel)
     const char *e = getenv("BTR_FPS_IMPL");
-    const bool pm = e && e[0] == 'p' && e[1] == 'm' && p.nb <= kBucketWaves * 64;
+    const bool pm = e && ((e[0] == 'p' && e[1] == 'm') || e[0] == 'm') &&   // "pm" / "multi"
+                    p.nb <= kBucketWaves * 64;
     if (pm && getenv("BTR_FPS_PROF")) {   // tuning: s_memtime phase counters of scene 0
       static unsigned long long *dbgp = nullptr;
       if (!dbgp) (void)hipMalloc(&dbgp, sizeof(unsigned long long) * (8 + 64 * 16 * 16));
