@@ -377,10 +377,22 @@ def main():
                         "step waits for its own FPS first); informational"}
         if world == 1 and not args.no_cpu_baseline and not gf:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_points)
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if dist.is_available() and dist.is_initialized():
         barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # the JSON line is the LAST thing on stdout: RCCL writes its version banner through C
+        # stdio, which a pipe buffers until exit -- flush that first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 def pmc_traffic(substr):
