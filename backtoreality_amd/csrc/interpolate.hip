@@ -14,11 +14,23 @@ namespace btr {
 // (interpolate_gpu.cu:32,39-54); with finite or infinite f32 distances that is the same
 // ordering as f32 comparisons against +inf, and (float)1e40 == +inf is what it stores when
 // fewer than three known points exist.
+// the inverse-distance blend weights of the feature-propagation module
+// (pointnet2_modules.py:493-496: 1 / (sqrt(d2) + 1e-8), normalised over the three neighbours)
+__device__ __forceinline__ void nn_weights(float d1, float d2, float d3, float *w) {
+  const float r1 = 1.0f / (sqrtf(d1) + 1e-8f), r2 = 1.0f / (sqrtf(d2) + 1e-8f),
+              r3 = 1.0f / (sqrtf(d3) + 1e-8f);
+  const float norm = (r1 + r2) + r3;
+  w[0] = r1 / norm;
+  w[1] = r2 / norm;
+  w[2] = r3 / norm;
+}
+
 __global__ __launch_bounds__(64) void three_nn_kernel(int n, int m,
                                                       const float *__restrict__ unknown,
                                                       const float *__restrict__ known,
                                                       float *__restrict__ dist2,
-                                                      int *__restrict__ idx) {
+                                                      int *__restrict__ idx,
+                                                      float *__restrict__ weight = nullptr) {
   const int bi = blockIdx.y;
   const int j = blockIdx.x * 64 + threadIdx.x;
   if (j >= n) return;
@@ -45,6 +57,7 @@ __global__ __launch_bounds__(64) void three_nn_kernel(int n, int m,
   int *id = idx + ((size_t)bi * n + j) * 3;
   d2[0] = best1; d2[1] = best2; d2[2] = best3;
   id[0] = besti1; id[1] = besti2; id[2] = besti3;
+  if (weight) nn_weights(best1, best2, best3, weight + ((size_t)bi * n + j) * 3);
 }
 
 // Same result with 8 lanes per query: each lane scans a contiguous slice of the known points
@@ -74,7 +87,8 @@ __global__ __launch_bounds__(64) void three_nn_split_kernel(int n, int m,
                                                             const float *__restrict__ unknown,
                                                             const float *__restrict__ known,
                                                             float *__restrict__ dist2,
-                                                            int *__restrict__ idx) {
+                                                            int *__restrict__ idx,
+                                                            float *__restrict__ weight = nullptr) {
   const int bi = blockIdx.y;
   const int part = threadIdx.x & 7;
   const int j = blockIdx.x * 8 + (threadIdx.x >> 3);
@@ -113,6 +127,7 @@ __global__ __launch_bounds__(64) void three_nn_split_kernel(int n, int m,
     int *id = idx + ((size_t)bi * n + j) * 3;
     d2[0] = t.d1; d2[1] = t.d2; d2[2] = t.d3;
     id[0] = t.i1; id[1] = t.i2; id[2] = t.i3;
+    if (weight) nn_weights(t.d1, t.d2, t.d3, weight + ((size_t)bi * n + j) * 3);
   }
 }
 
@@ -251,18 +266,31 @@ using namespace btr;
 
 extern "C" {
 
-int btr_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
-                 int *idx, btr_stream_t stream) {
+static int three_nn_launch(int b, int n, int m, const float *unknown, const float *known,
+                           float *dist2, int *idx, float *weight, btr_stream_t stream) {
   if (b <= 0 || n <= 0) return BTR_OK;
   BTR_REQUIRE(unknown && dist2 && idx && (m <= 0 || known), "three_nn: null pointer");
   BTR_REQUIRE(b < 65536, "three_nn: batch too large");
   if (m >= 64)
     hipLaunchKernelGGL(three_nn_split_kernel, dim3(cdiv(n, 8), b), dim3(64), 0,
-                       as_stream(stream), n, m, unknown, known, dist2, idx);
+                       as_stream(stream), n, m, unknown, known, dist2, idx, weight);
   else
     hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 64), b), dim3(64), 0, as_stream(stream), n,
-                       std::max(m, 0), unknown, known, dist2, idx);
+                       std::max(m, 0), unknown, known, dist2, idx, weight);
   return check_launch("three_nn");
+}
+
+int btr_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                 int *idx, btr_stream_t stream) {
+  return three_nn_launch(b, n, m, unknown, known, dist2, idx, nullptr, stream);
+}
+
+// three_nn + the feature-propagation module's blend weights in the same launch:
+// weight (b, n, 3) = normalised 1 / (sqrt(dist2) + 1e-8)  (pointnet2_modules.py:492-496)
+int btr_three_nn_weights(int b, int n, int m, const float *unknown, const float *known,
+                         float *dist2, int *idx, float *weight, btr_stream_t stream) {
+  BTR_REQUIRE(weight || b <= 0 || n <= 0, "three_nn_weights: null pointer");
+  return three_nn_launch(b, n, m, unknown, known, dist2, idx, weight, stream);
 }
 
 int btr_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,

@@ -121,6 +121,59 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int chunks, int c,
   out[col] = acc;
 }
 
+
+// ------------------------------------------------------------------- vote assembly
+// votes from the vote generator's last layer (models/voting_module.py:57-64, vote_factor 1):
+//   vote_xyz[b][i][0..2]  = seed_xyz[b][i] + net[b][i][0..2]
+//   vote_feat[b][i][c]    = seed_feat[b][i][c] + net[b][i][3 + c]
+// on channel-last rows; the features are written channel-last and as (B, C, N) in one pass
+// (the reference: transpose, two adds, two contiguous copies, a transpose back).
+__global__ __launch_bounds__(256) void vote_assemble_kernel(
+    int N, int C, int ldn, const float *__restrict__ net_cl, const float *__restrict__ seed_xyz,
+    const float *__restrict__ seed_cl, float *__restrict__ vote_xyz,
+    float *__restrict__ feat_bcn, float *__restrict__ feat_cl) {
+  __shared__ float tile[64][65];
+  const int bi = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + ty + 4 * i, c = c0 + tx;
+    float v = 0.f;
+    if (n < N && c < C) {
+      const size_t r = (size_t)bi * N + n;
+      v = seed_cl[r * C + c] + net_cl[r * ldn + 3 + c];
+      feat_cl[r * C + c] = v;
+    }
+    tile[ty + 4 * i][tx] = v;
+  }
+  if (blockIdx.y == 0 && threadIdx.x < 192) {   // the three coordinates of this tile's 64 points
+    const int n = n0 + (int)threadIdx.x / 3, k = (int)threadIdx.x % 3;
+    if (n < N) {
+      const size_t r = (size_t)bi * N + n;
+      vote_xyz[r * 3 + k] = seed_xyz[r * 3 + k] + net_cl[r * ldn + k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, n = n0 + tx;
+    if (n < N && c < C) feat_bcn[((size_t)bi * C + c) * N + n] = tile[tx][ty + 4 * i];
+  }
+}
+
+// gradient w.r.t. the generator's output (B, 3 + C, N): rows 0..2 = d vote_xyz transposed,
+// rows 3.. = d vote_feat (the seed features' gradient is d vote_feat itself)
+__global__ __launch_bounds__(256) void vote_assemble_bwd_kernel(
+    int N, int C, const float *__restrict__ dxyz, const float *__restrict__ dfeat,
+    float *__restrict__ dnet) {
+  const int bi = blockIdx.z, ch = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float v = ch < 3 ? dxyz[((size_t)bi * N + n) * 3 + ch]
+                         : dfeat[((size_t)bi * C + (ch - 3)) * N + n];
+  dnet[((size_t)bi * (C + 3) + ch) * N + n] = v;
+}
+
 struct Unbind {
   ~Unbind() { btr_sac_bind(nullptr); }
 };
@@ -675,6 +728,29 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
     }
   }
   return check_launch("pm_chain_backward");
+}
+
+int btr_vote_assemble(int b, int n, int c, const float *net_cl, int ld_net,
+                      const float *seed_xyz, const float *seed_cl, float *vote_xyz,
+                      float *vote_feat_bcn, float *vote_feat_cl, btr_stream_t stream) {
+  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(net_cl && seed_xyz && seed_cl && vote_xyz && vote_feat_bcn && vote_feat_cl &&
+                  ld_net >= c + 3 && b < 65536,
+              "vote_assemble: bad arguments");
+  hipLaunchKernelGGL(vote_assemble_kernel, dim3(cdiv(n, 64), cdiv(c, 64), b), dim3(256), 0,
+                     as_stream(stream), n, c, ld_net, net_cl, seed_xyz, seed_cl, vote_xyz,
+                     vote_feat_bcn, vote_feat_cl);
+  return check_launch("vote_assemble");
+}
+
+int btr_vote_assemble_bwd(int b, int n, int c, const float *dvote_xyz, const float *dvote_feat_bcn,
+                          float *dnet_bcn, btr_stream_t stream) {
+  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(dvote_xyz && dvote_feat_bcn && dnet_bcn && b < 65536 && c + 3 < 65536,
+              "vote_assemble_bwd: bad arguments");
+  hipLaunchKernelGGL(vote_assemble_bwd_kernel, dim3(cdiv(n, 256), c + 3, b), dim3(256), 0,
+                     as_stream(stream), n, c, dvote_xyz, dvote_feat_bcn, dnet_bcn);
+  return check_launch("vote_assemble_bwd");
 }
 
 }  // extern "C"

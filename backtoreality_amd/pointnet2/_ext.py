@@ -48,6 +48,7 @@ _SIGNATURES = {
     "btr_group_points": (_ci, [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_group_points_grad": (_ci, [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_three_nn": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "btr_three_nn_weights": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "btr_three_interpolate": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
     "btr_three_interpolate_grad": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]),
     # fused set-abstraction MLP (used by fused_sa.py)
@@ -89,6 +90,8 @@ _SIGNATURES = {
     "btr_pm_out": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "btr_pm_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp]),
     "btr_fps_time_next_kernel": (None, [_vp, _vp]),
+    "btr_vote_assemble": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "btr_vote_assemble_bwd": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     # fused attention core (groupfree/fused_attention.py)
     "btr_attention_supported": (_ci, [_ci]),
     "btr_attention_fwd": (_ci, [_ci] * 5 + [_vp, _ll, _ll, _vp, _vp, _ll, _ll, _vp, _vp, _cf, _cf,
@@ -500,6 +503,23 @@ def three_nn(unknowns, knows):
         _call(_idx.btr_three_nn, B, n, m, _p(unknowns), _p(knows), _p(dist2), _p(idx),
               _stream(dev))
     return [dist2, idx]
+
+
+def three_nn_weights(unknowns, knows):
+    """three_nn + the FP module's normalised inverse-distance weights in one launch:
+    -> [dist2 (B,n,3), idx (B,n,3) i32, weight (B,n,3)]."""
+    _check(unknowns, "unknowns", "float")
+    _check(knows, "knows", "float", like=unknowns)
+    _gpu_only(unknowns)
+    B, n, _ = unknowns.shape
+    m = knows.size(1)
+    dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknowns.device)
+    idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknowns.device)
+    weight = torch.empty((B, n, 3), dtype=torch.float32, device=unknowns.device)
+    with _on(unknowns) as dev:
+        _call(_idx.btr_three_nn_weights, B, n, m, _p(unknowns), _p(knows), _p(dist2), _p(idx),
+              _p(weight), _stream(dev))
+    return [dist2, idx, weight]
 
 
 def three_interpolate(points, idx, weight):

@@ -232,10 +232,13 @@ class PointnetFPModule(nn.Module):
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            norm = torch.sum(dist_recip, dim=2, keepdim=True)
-            weight = dist_recip / norm
+            if unknown.is_cuda and hasattr(pointnet2_utils._ext, "three_nn_weights"):
+                idx, weight = pointnet2_utils.three_nn_weights(unknown, known)   # one launch
+            else:
+                dist, idx = pointnet2_utils.three_nn(unknown, known)
+                dist_recip = 1.0 / (dist + 1e-8)
+                norm = torch.sum(dist_recip, dim=2, keepdim=True)
+                weight = dist_recip / norm
             interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

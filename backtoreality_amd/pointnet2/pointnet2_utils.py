@@ -128,6 +128,26 @@ class ThreeNN(Function):
 three_nn = ThreeNN.apply
 
 
+class ThreeNNWeights(Function):
+    """three_nn + the blend weights PointnetFPModule derives from it
+    (pointnet2_modules.py:492-496: 1 / (dist + 1e-8), normalised over the three neighbours) in
+    one launch: unknown (B,n,3), known (B,m,3) -> (idx (B,n,3), weight (B,n,3)); no gradient,
+    like three_nn."""
+
+    @staticmethod
+    def forward(ctx, unknown, known):
+        _, idx, weight = _ext.three_nn_weights(unknown, known)
+        ctx.mark_non_differentiable(idx, weight)
+        return idx, weight
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn_weights = ThreeNNWeights.apply
+
+
 class ThreeInterpolate(Function):
     """features (B,c,m), idx/weight (B,n,3) -> (B,c,n) weighted blend (:152-203)."""
 

@@ -5,6 +5,8 @@
 requires grad, so backward reaches group_points_grad AND gather_points_grad.  The head
 (3x Conv1d) and `decode_scores` (:18-50) are stock torch ops.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -48,6 +50,67 @@ def decode_scores(net, end_points, num_class, num_heading_bin, num_size_cluster,
 
     end_points['sem_cls_scores'] = t[:, :, o + 4 * NS:]
     return end_points
+
+
+DECODED_KEYS = frozenset([
+    'objectness_scores', 'center', 'heading_scores', 'heading_residuals_normalized',
+    'heading_residuals', 'size_scores', 'size_residuals_normalized', 'size_residuals',
+    'pred_size', 'sem_cls_scores'])
+
+
+class DecodedEndPoints(dict):
+    """`end_points` whose decode_scores entries are computed on first use.
+
+    A training step through the fused loss (votenet/fused_loss.py) reads the raw head output
+    and never touches the decoded predictions: decoding them eagerly, as the reference does
+    (proposal_module.py:108-113), is ten launches per step for nothing.  Any access -- a decoded
+    key, `in`, `get`, iteration, `len`, `keys/items/values`, `copy` -- decodes first, so the
+    dict always LOOKS like the reference's; only plain reads / writes of other keys do not."""
+
+    def __init__(self, base, decode):
+        super().__init__(base)
+        self._decode = decode
+
+    def _force(self):
+        decode, self._decode = self._decode, None
+        if decode is not None:
+            decode(self)
+
+    def __missing__(self, key):
+        if self._decode is not None and key in DECODED_KEYS:
+            self._force()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (self._decode is not None and key in DECODED_KEYS)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __iter__(self):
+        self._force()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._force()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._force()
+        return dict.keys(self)
+
+    def items(self):
+        self._force()
+        return dict.items(self)
+
+    def values(self):
+        self._force()
+        return dict.values(self)
+
+    def copy(self):
+        self._force()
+        return dict(self)
 
 
 class ProposalModule(nn.Module):
@@ -106,5 +169,12 @@ class ProposalModule(nn.Module):
             net = F.relu(self.bn2(self.conv2(net)))
             net = self.conv3(net)
         end_points['_head_output'] = net  # raw (B, Cout, K) scores for the fused loss
-        return decode_scores(net, end_points, self.num_class, self.num_heading_bin,
-                             self.num_size_cluster, self.mean_size_arr, self._mean_size_dev)
+
+        def decode(ep):
+            decode_scores(net, ep, self.num_class, self.num_heading_bin, self.num_size_cluster,
+                          self.mean_size_arr, self._mean_size_dev)
+        if self.training and torch.is_grad_enabled() and net.is_cuda and \
+                os.environ.get("BTR_LAZY_DECODE", "1") != "0":
+            return DecodedEndPoints(end_points, decode)   # decoded when somebody looks
+        decode(end_points)
+        return end_points

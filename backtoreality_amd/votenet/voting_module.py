@@ -1,10 +1,49 @@
 """Vote generation from seed features (detection/Votenet/models/voting_module.py:16-65):
 three 1x1 Conv1d (256 -> 256 -> 256 -> (3+256)*vote_factor) with BN+ReLU on the first two;
 votes = seed xyz + predicted offset, vote features = seed features + predicted residual."""
+import os
+
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.autograd import Function
 
-from ..pointnet2 import fused_mlp
+from ..pointnet2 import _ext, fused_mlp
+
+
+class _VoteAssemble(Function):
+    """votes = seeds + the generator's output (forward :57-64), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, net, seed_xyz, seed_features):
+        B, C, N = seed_features.shape
+        net_cl = net._btr_channel_last                       # (B*N, 3 + C)
+        seed_cl = getattr(seed_features, "_btr_channel_last", None)
+        if seed_cl is None or seed_cl.shape != (B * N, C) or not seed_cl.is_contiguous():
+            seed_cl = seed_features.transpose(1, 2).contiguous().view(B * N, C)
+        dev = net.device
+        vote_xyz = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        feat = torch.empty((B, C, N), dtype=torch.float32, device=dev)
+        feat_cl = torch.empty((B * N, C), dtype=torch.float32, device=dev)
+        with _ext._on(net) as d:
+            _ext._call(_ext._lib.btr_vote_assemble, B, N, C, _ext._p(net_cl), net_cl.shape[1],
+                       _ext._p(seed_xyz.contiguous()), _ext._p(seed_cl), _ext._p(vote_xyz),
+                       _ext._p(feat), _ext._p(feat_cl), _ext._stream(d))
+        feat._btr_channel_last = feat_cl.view(B, N, C)      # what the vote aggregation gathers
+        ctx.dims = (B, C, N)
+        return vote_xyz, feat
+
+    @staticmethod
+    def backward(ctx, dxyz, dfeat):
+        B, C, N = ctx.dims
+        dev = (dxyz if dxyz is not None else dfeat).device
+        dxyz = dxyz.contiguous() if dxyz is not None else torch.zeros((B, N, 3), device=dev)
+        dfeat = dfeat.contiguous() if dfeat is not None else torch.zeros((B, C, N), device=dev)
+        dnet = torch.empty((B, 3 + C, N), dtype=torch.float32, device=dxyz.device)
+        with _ext._on(dxyz) as d:
+            _ext._call(_ext._lib.btr_vote_assemble_bwd, B, N, C, _ext._p(dxyz), _ext._p(dfeat),
+                       _ext._p(dnet), _ext._stream(d))
+        return dnet, None, dfeat
 
 
 class VotingModule(nn.Module):
@@ -30,6 +69,10 @@ class VotingModule(nn.Module):
             net = F.relu(self.bn1(self.conv1(seed_features)))
             net = F.relu(self.bn2(self.conv2(net)))
             net = self.conv3(net)
+        if (self.vote_factor == 1 and net.is_cuda and seed_xyz.dtype == torch.float32 and
+                getattr(net, "_btr_channel_last", None) is not None and
+                os.environ.get("BTR_FUSED_VOTES", "1") != "0"):
+            return _VoteAssemble.apply(net, seed_xyz, seed_features)
         net = net.transpose(2, 1).view(B, S, self.vote_factor, 3 + self.out_dim)
         vote_xyz = (seed_xyz.unsqueeze(2) + net[:, :, :, 0:3]).contiguous().view(B, V, 3)
         vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[:, :, :, 3:]

@@ -134,6 +134,11 @@ int btr_group_points_grad(int b, int c, int n, int npoints, int nsample, const f
  * earliest index wins ties; m < 3 leaves +inf / index 0 in the unused slots. */
 int btr_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
                  int *idx, btr_stream_t stream);
+/* The same launch also writing the feature-propagation blend weights the reference computes with
+ * four torch ops on the result (pointnet2/pointnet2_modules.py:492-496):
+ * weight (b, n, 3) = r / sum(r), r = 1 / (sqrt(dist2) + 1e-8). */
+int btr_three_nn_weights(int b, int n, int m, const float *unknown, const float *known,
+                         float *dist2, int *idx, float *weight, btr_stream_t stream);
 
 /* Replaces three_interpolate_kernel_wrapper(b, c, m, n, points, idx, weight, out)
  *   decl src/interpolate.cpp:11-13, def src/interpolate_gpu.cu:108-117, kernel :77-106.
@@ -510,6 +515,17 @@ int btr_pm_chain_forward(const btr_pm_chain_t *d, const btr_pm_plan_t *plan, con
 int btr_pm_chain_backward(const btr_pm_chain_t *d, const btr_pm_plan_t *plan, const float *x_cl,
                           const float *dout, void *saved, float *grads, float *dx,
                           void *scratch, btr_stream_t stream);
+
+/* ---- vote assembly (models/voting_module.py:57-64, vote_factor 1) -----------------------------
+ * from the generator's last layer on channel-last rows net_cl (b*n, ld_net >= 3 + c):
+ * vote_xyz (b, n, 3) = seed_xyz + net[..., 0:3]; vote features = seed features + net[..., 3:],
+ * written as (b, c, n) and channel-last (b*n, c).  The backward assembles the gradient w.r.t. the
+ * generator's (b, 3 + c, n) output; the seed features' gradient is d vote_feat itself. */
+int btr_vote_assemble(int b, int n, int c, const float *net_cl, int ld_net,
+                      const float *seed_xyz, const float *seed_cl, float *vote_xyz,
+                      float *vote_feat_bcn, float *vote_feat_cl, btr_stream_t stream);
+int btr_vote_assemble_bwd(int b, int n, int c, const float *dvote_xyz, const float *dvote_feat_bcn,
+                          float *dnet_bcn, btr_stream_t stream);
 
 /* ---- fused multi-head attention core (GroupFree3D decoder) -----------------------
  * reference: detection/GroupFree3D/models/transformer.py:36-76 -> models/multi_head_attention.py

@@ -96,3 +96,43 @@ def test_small_problems_stay_on_the_stock_ops(cuda, monkeypatch):
     chain = [(vg.conv1, vg.bn1, True), (vg.conv2, vg.bn2, True), (vg.conv3, None, False)]
     assert fused_mlp.run_chain(torch.randn(2, 256, 512, device=cuda), chain) is None
     assert fused_mlp.run_chain(torch.randn(2, 256, 1024, device=cuda), chain) is not None
+
+
+def test_vote_assembly_and_fp_weights_match_the_torch_composition(cuda, monkeypatch):
+    """The one-launch vote assembly (btr_vote_assemble) and the FP module's in-kernel blend
+    weights (btr_three_nn_weights) against the reference's torch op strings: outputs and
+    gradients."""
+    from backtoreality_amd.pointnet2 import pointnet2_utils
+    monkeypatch.setenv("BTR_CHAIN_MIN_ROWS", "0")
+    torch.manual_seed(5)
+    vg = voting_module.VotingModule(1, 256).to(cuda)
+    xyz = torch.rand(2, 700, 3, device=cuda)
+    feats = torch.randn(2, 256, 700, device=cuda)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BTR_FUSED_VOTES", flag)
+        m = copy.deepcopy(vg)
+        f = feats.clone().requires_grad_(True)
+        vx, vf = m(xyz, f)
+        if flag == "1":
+            assert torch.equal(vf._btr_channel_last, vf.transpose(1, 2))
+        ((vx * torch.linspace(-1, 1, vx.numel(), device=cuda).view_as(vx)).sum() +
+         (vf * torch.linspace(0.5, 1.5, vf.numel(), device=cuda).view_as(vf)).sum()).backward()
+        res[flag] = {"vx": vx.detach(), "vf": vf.detach(), "df": f.grad,
+                     "dw3": m.conv3.weight.grad, "db3": m.conv3.bias.grad,
+                     "dw1": m.conv1.weight.grad}
+    for k, want in res["0"].items():
+        assert _rel(res["1"][k], want) < 1e-5, (k, _rel(res["1"][k], want))
+
+    unknown = torch.rand(2, 1024, 3, device=cuda)
+    known = unknown[:, ::2].contiguous() + 0.01
+    idx, weight = pointnet2_utils.three_nn_weights(unknown, known)
+    dist, idx0 = pointnet2_utils.three_nn(unknown, known)
+    r = 1.0 / (dist + 1e-8)
+    assert torch.equal(idx, idx0)
+    assert _rel(weight, r / r.sum(2, keepdim=True)) < 1e-6
+    few = known[:, :2].contiguous()                       # fewer than three known points
+    _, w2 = pointnet2_utils.three_nn_weights(unknown, few)
+    d2, _ = pointnet2_utils.three_nn(unknown, few)
+    r2 = 1.0 / (d2 + 1e-8)
+    assert torch.allclose(w2, r2 / r2.sum(2, keepdim=True), rtol=1e-6, atol=1e-12)

@@ -272,3 +272,31 @@ def test_epoch_schedules_of_the_training_scripts():
     assert abs(lrs[7] - 0.004) < 1e-12 and abs(lrs[8] - 0.0004) < 1e-12
     assert abs(lrs[12] - 0.00004) < 1e-12
     assert abs(opt.param_groups[1]['lr'] - 0.000004) < 1e-12
+
+
+def test_decoded_end_points_are_lazy_but_look_complete():
+    """proposal_module.DecodedEndPoints: decode_scores runs on first use, and every way of
+    looking at the dict sees the decoded keys."""
+    from backtoreality_amd.votenet.proposal_module import DECODED_KEYS, DecodedEndPoints
+    calls = []
+
+    def decode(ep):
+        calls.append(1)
+        for k in DECODED_KEYS:
+            ep[k] = k.upper()
+    ep = DecodedEndPoints({'seed_xyz': 1}, decode)
+    ep['loss'] = 2.0                       # plain reads / writes do not decode
+    assert ep['seed_xyz'] == 1 and 'loss' in ep and not calls
+    assert 'center' in ep and 'nonsense' not in ep and not calls
+    assert ep['center'] == 'CENTER' and calls == [1]
+    assert ep.get('pred_size') == 'PRED_SIZE' and ep.get('nonsense', 7) == 7
+    for make in (lambda e: list(e.keys()), lambda e: dict(e), lambda e: len(e),
+                 lambda e: list(e.items()), lambda e: e.copy(), lambda e: [k for k in e]):
+        e2 = DecodedEndPoints({'a': 1}, decode)
+        got = make(e2)
+        assert dict.__contains__(e2, 'center'), make
+        if isinstance(got, (list, dict)):
+            assert len(got) == 1 + len(DECODED_KEYS)
+    with __import__('pytest').raises(KeyError):
+        DecodedEndPoints({}, decode)['nonsense']
+    assert calls.count(1) == 7
