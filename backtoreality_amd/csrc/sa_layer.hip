@@ -174,6 +174,92 @@ __global__ __launch_bounds__(256) void vote_assemble_bwd_kernel(
   dnet[((size_t)bi * (C + 3) + ch) * N + n] = v;
 }
 
+// The same with the L2 normalisation VoteNet applies to the vote features right after
+// (models/votenet.py:98-99: features / ||features||_2 over the channels) folded in: a block owns
+// 32 points and ALL channels (CJ * 8 of them: 8 threads per point, CJ values per thread in
+// registers), so the norm is a reduction inside the block.  nrm (b*n): saved for the backward.
+template <int CJ>
+__global__ __launch_bounds__(256) void vote_assemble_norm_kernel(
+    int N, int C, int ldn, const float *__restrict__ net_cl, const float *__restrict__ seed_xyz,
+    const float *__restrict__ seed_cl, float *__restrict__ vote_xyz,
+    float *__restrict__ feat_bcn, float *__restrict__ feat_cl, float *__restrict__ nrm) {
+  __shared__ float tile[CJ * 8][33];
+  const int bi = blockIdx.y, n0 = blockIdx.x * 32;
+  const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  const int n = n0 + row;
+  const size_t r = (size_t)bi * N + min(n, N - 1);
+  float v[CJ];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) {
+    const int c = sub + 8 * j;
+    v[j] = c < C ? seed_cl[r * C + c] + net_cl[r * ldn + 3 + c] : 0.f;
+    ss = fmaf(v[j], v[j], ss);
+  }
+  ss += __shfl_xor(ss, 1);
+  ss += __shfl_xor(ss, 2);
+  ss += __shfl_xor(ss, 4);
+  const float nr = sqrtf(ss);
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) {
+    const int c = sub + 8 * j;
+    const float y = v[j] / nr;
+    if (c < C && n < N) feat_cl[r * C + c] = y;
+    tile[c][row] = y;
+  }
+  if (n < N && sub == 0) nrm[r] = nr;
+  if (n < N && sub < 3) vote_xyz[r * 3 + sub] = seed_xyz[r * 3 + sub] + net_cl[r * ldn + sub];
+  __syncthreads();
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 points x 8 channel rows
+  for (int c = ty; c < C; c += 8)
+    if (n0 + tx < N) feat_bcn[((size_t)bi * C + c) * N + n0 + tx] = tile[c][tx];
+}
+
+// backward of the normalised assembly: y = v / ||v||,  dv = (dy - y (y . dy)) / ||v||;
+// dnet rows 3.. and the seed features' gradient both receive dv, rows 0..2 = d vote_xyz^T
+template <int CJ>
+__global__ __launch_bounds__(256) void vote_assemble_norm_bwd_kernel(
+    int N, int C, const float *__restrict__ dxyz, const float *__restrict__ dfeat,
+    const float *__restrict__ y_cl, const float *__restrict__ nrm, float *__restrict__ dnet,
+    float *__restrict__ dseed) {
+  __shared__ float tile[CJ * 8][33];
+  const int bi = blockIdx.y, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int c = ty; c < CJ * 8; c += 8)
+    tile[c][tx] = (c < C && n0 + tx < N) ? dfeat[((size_t)bi * C + c) * N + n0 + tx] : 0.f;
+  __syncthreads();
+  const int row = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  const int n = n0 + row;
+  const size_t r = (size_t)bi * N + min(n, N - 1);
+  float y[CJ], dy[CJ];
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) {
+    const int c = sub + 8 * j;
+    y[j] = c < C ? y_cl[r * C + c] : 0.f;
+    dy[j] = tile[c][row];
+    dot = fmaf(y[j], dy[j], dot);
+  }
+  dot += __shfl_xor(dot, 1);
+  dot += __shfl_xor(dot, 2);
+  dot += __shfl_xor(dot, 4);
+  const float nr = nrm[r];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CJ; ++j) tile[sub + 8 * j][row] = (dy[j] - y[j] * dot) / nr;
+  __syncthreads();
+  for (int c = ty; c < C; c += 8)
+    if (n0 + tx < N) {
+      const float g = tile[c][tx];
+      dnet[((size_t)bi * (C + 3) + 3 + c) * N + n0 + tx] = g;
+      dseed[((size_t)bi * C + c) * N + n0 + tx] = g;
+    }
+  if (threadIdx.x < 96) {
+    const int k = threadIdx.x >> 5, i = n0 + (threadIdx.x & 31);
+    if (i < N) dnet[((size_t)bi * (C + 3) + k) * N + i] = dxyz[((size_t)bi * N + i) * 3 + k];
+  }
+}
+
 struct Unbind {
   ~Unbind() { btr_sac_bind(nullptr); }
 };
@@ -732,11 +818,25 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
 
 int btr_vote_assemble(int b, int n, int c, const float *net_cl, int ld_net,
                       const float *seed_xyz, const float *seed_cl, float *vote_xyz,
-                      float *vote_feat_bcn, float *vote_feat_cl, btr_stream_t stream) {
+                      float *vote_feat_bcn, float *vote_feat_cl, float *nrm,
+                      btr_stream_t stream) {
   if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(net_cl && seed_xyz && seed_cl && vote_xyz && vote_feat_bcn && vote_feat_cl &&
                   ld_net >= c + 3 && b < 65536,
               "vote_assemble: bad arguments");
+  if (nrm) {   // with the L2 normalisation of the features
+    BTR_REQUIRE(c <= 256, "vote_assemble: normalised form covers <= 256 channels, got %d", c);
+    const dim3 grid(cdiv(n, 32), b);
+#define BTR_VA(CJ)                                                                          \
+  hipLaunchKernelGGL((vote_assemble_norm_kernel<CJ>), grid, dim3(256), 0, as_stream(stream), \
+                     n, c, ld_net, net_cl, seed_xyz, seed_cl, vote_xyz, vote_feat_bcn,      \
+                     vote_feat_cl, nrm)
+    if (c <= 64) BTR_VA(8);
+    else if (c <= 128) BTR_VA(16);
+    else BTR_VA(32);
+#undef BTR_VA
+    return check_launch("vote_assemble(norm)");
+  }
   hipLaunchKernelGGL(vote_assemble_kernel, dim3(cdiv(n, 64), cdiv(c, 64), b), dim3(256), 0,
                      as_stream(stream), n, c, ld_net, net_cl, seed_xyz, seed_cl, vote_xyz,
                      vote_feat_bcn, vote_feat_cl);
@@ -744,10 +844,23 @@ int btr_vote_assemble(int b, int n, int c, const float *net_cl, int ld_net,
 }
 
 int btr_vote_assemble_bwd(int b, int n, int c, const float *dvote_xyz, const float *dvote_feat_bcn,
-                          float *dnet_bcn, btr_stream_t stream) {
+                          const float *vote_feat_cl, const float *nrm, float *dnet_bcn,
+                          float *dseed_bcn, btr_stream_t stream) {
   if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(dvote_xyz && dvote_feat_bcn && dnet_bcn && b < 65536 && c + 3 < 65536,
               "vote_assemble_bwd: bad arguments");
+  if (nrm) {
+    BTR_REQUIRE(vote_feat_cl && dseed_bcn && c <= 256, "vote_assemble_bwd: normalised form");
+    const dim3 grid(cdiv(n, 32), b);
+#define BTR_VA(CJ)                                                                              \
+  hipLaunchKernelGGL((vote_assemble_norm_bwd_kernel<CJ>), grid, dim3(256), 0, as_stream(stream), \
+                     n, c, dvote_xyz, dvote_feat_bcn, vote_feat_cl, nrm, dnet_bcn, dseed_bcn)
+    if (c <= 64) BTR_VA(8);
+    else if (c <= 128) BTR_VA(16);
+    else BTR_VA(32);
+#undef BTR_VA
+    return check_launch("vote_assemble_bwd(norm)");
+  }
   hipLaunchKernelGGL(vote_assemble_bwd_kernel, dim3(cdiv(n, 256), c + 3, b), dim3(256), 0,
                      as_stream(stream), n, c, dvote_xyz, dvote_feat_bcn, dnet_bcn);
   return check_launch("vote_assemble_bwd");

@@ -90,8 +90,8 @@ _SIGNATURES = {
     "btr_pm_out": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "btr_pm_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp]),
     "btr_fps_time_next_kernel": (None, [_vp, _vp]),
-    "btr_vote_assemble": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "btr_vote_assemble_bwd": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp]),
+    "btr_vote_assemble": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "btr_vote_assemble_bwd": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     # fused attention core (groupfree/fused_attention.py)
     "btr_attention_supported": (_ci, [_ci]),
     "btr_attention_fwd": (_ci, [_ci] * 5 + [_vp, _ll, _ll, _vp, _vp, _ll, _ll, _vp, _vp, _cf, _cf,

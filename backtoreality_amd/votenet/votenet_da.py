@@ -70,8 +70,8 @@ class VoteNet_DA(nn.Module):
         end_points['seed_xyz'] = xyz
         end_points['seed_features'] = features
 
-        xyz, features = self.vgen(xyz, features)
-        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))
+        # (votes + the L2 normalisation of their features, models/votenet.py:97-99, in one call)
+        xyz, features = self.vgen(xyz, features, normalize=True)
         end_points['vote_xyz'] = xyz
         end_points['vote_features'] = features
         end_points = self.pnet(xyz, features, end_points)

@@ -520,12 +520,17 @@ int btr_pm_chain_backward(const btr_pm_chain_t *d, const btr_pm_plan_t *plan, co
  * from the generator's last layer on channel-last rows net_cl (b*n, ld_net >= 3 + c):
  * vote_xyz (b, n, 3) = seed_xyz + net[..., 0:3]; vote features = seed features + net[..., 3:],
  * written as (b, c, n) and channel-last (b*n, c).  The backward assembles the gradient w.r.t. the
- * generator's (b, 3 + c, n) output; the seed features' gradient is d vote_feat itself. */
+ * generator's (b, 3 + c, n) output; the seed features' gradient is d vote_feat itself.
+ * nrm != NULL (b*n floats, c <= 256): the features are also L2-normalised over the channels, what
+ * VoteNet.forward does next (models/votenet.py:98-99); the backward then needs the normalised
+ * features (channel-last) and nrm back and also writes the seed features' gradient. */
 int btr_vote_assemble(int b, int n, int c, const float *net_cl, int ld_net,
                       const float *seed_xyz, const float *seed_cl, float *vote_xyz,
-                      float *vote_feat_bcn, float *vote_feat_cl, btr_stream_t stream);
+                      float *vote_feat_bcn, float *vote_feat_cl, float *nrm,
+                      btr_stream_t stream);
 int btr_vote_assemble_bwd(int b, int n, int c, const float *dvote_xyz, const float *dvote_feat_bcn,
-                          float *dnet_bcn, btr_stream_t stream);
+                          const float *vote_feat_cl, const float *nrm, float *dnet_bcn,
+                          float *dseed_bcn, btr_stream_t stream);
 
 /* ---- fused multi-head attention core (GroupFree3D decoder) -----------------------
  * reference: detection/GroupFree3D/models/transformer.py:36-76 -> models/multi_head_attention.py

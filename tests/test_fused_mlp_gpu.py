@@ -108,21 +108,22 @@ def test_vote_assembly_and_fp_weights_match_the_torch_composition(cuda, monkeypa
     vg = voting_module.VotingModule(1, 256).to(cuda)
     xyz = torch.rand(2, 700, 3, device=cuda)
     feats = torch.randn(2, 256, 700, device=cuda)
-    res = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("BTR_FUSED_VOTES", flag)
-        m = copy.deepcopy(vg)
-        f = feats.clone().requires_grad_(True)
-        vx, vf = m(xyz, f)
-        if flag == "1":
-            assert torch.equal(vf._btr_channel_last, vf.transpose(1, 2))
-        ((vx * torch.linspace(-1, 1, vx.numel(), device=cuda).view_as(vx)).sum() +
-         (vf * torch.linspace(0.5, 1.5, vf.numel(), device=cuda).view_as(vf)).sum()).backward()
-        res[flag] = {"vx": vx.detach(), "vf": vf.detach(), "df": f.grad,
-                     "dw3": m.conv3.weight.grad, "db3": m.conv3.bias.grad,
-                     "dw1": m.conv1.weight.grad}
-    for k, want in res["0"].items():
-        assert _rel(res["1"][k], want) < 1e-5, (k, _rel(res["1"][k], want))
+    for normalize in (False, True):   # True: + the L2 normalisation VoteNet.forward applies next
+        res = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("BTR_FUSED_VOTES", flag)
+            m = copy.deepcopy(vg)
+            f = feats.clone().requires_grad_(True)
+            vx, vf = m(xyz, f, normalize=normalize)
+            if flag == "1":
+                assert torch.equal(vf._btr_channel_last, vf.transpose(1, 2))
+            ((vx * torch.linspace(-1, 1, vx.numel(), device=cuda).view_as(vx)).sum() +
+             (vf * torch.linspace(0.5, 1.5, vf.numel(), device=cuda).view_as(vf)).sum()).backward()
+            res[flag] = {"vx": vx.detach(), "vf": vf.detach(), "df": f.grad,
+                         "dw3": m.conv3.weight.grad, "db3": m.conv3.bias.grad,
+                         "dw1": m.conv1.weight.grad}
+        for k, want in res["0"].items():
+            assert _rel(res["1"][k], want) < 2e-5, (normalize, k, _rel(res["1"][k], want))
 
     unknown = torch.rand(2, 1024, 3, device=cuda)
     known = unknown[:, ::2].contiguous() + 0.01
