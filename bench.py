@@ -312,13 +312,16 @@ def main():
     # Secondary figure (never `value`): the same K steps strictly one after the other -- every
     # step waits for its own sampling pyramid (8 of 256 CUs for ~2.2 ms) before anything else.
     sequential = None
+    seq_kernels = None
     if pipelined_loop and not args.no_sequential:
         barrier()
+        _ext.timing_begin(lambda op, key: op == "fps_kernel" and key[1] > 4096)
         t1 = time.perf_counter()
         for i in range(args.steps):
             train_step(ddp, opt, batches[i % len(batches)], cfg)
         barrier()
         sequential = time.perf_counter() - t1
+        seq_kernels = _ext.timing_end()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -365,6 +368,14 @@ def main():
         else:
             out["hip_graph"] = graphed_step is not None
         out.update(roofline_objects(kernels or detail, detail, detail_steps))
+        if seq_kernels and "roofline" in out:
+            # the same kernel when nothing shares the chip with it (the sequential loop below)
+            ts = [t for (op, key), v in seq_kernels.items() if op == "fps_kernel" for t in v]
+            if ts:
+                ms = sum(ts) / len(ts)
+                rf = out["roofline"]
+                rf["avg_ms_running_alone"] = ms
+                rf["frac_running_alone"] = rf["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out["loop"] = ("software-pipelined: step i issues the sampling pyramid (FPS) of batch i+1 "
                        "on a side stream under its own backward; the first batch's pyramid is "
                        "computed inside the timed region; two distinct batches alternate"
