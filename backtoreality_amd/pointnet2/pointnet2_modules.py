@@ -34,6 +34,9 @@ def _sample_centres(xyz, npoint, inds=None):
         return None, inds
     if inds is None:
         inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    pre = getattr(inds, "_btr_new_xyz", None)   # gathered by whoever sampled (prefetched pyramid)
+    if pre is not None and pre[1] is xyz and pre[0].shape == (xyz.shape[0], inds.shape[1], 3):
+        return pre[0], inds
     return pointnet2_utils.gather_rows(xyz, inds), inds
 
 

@@ -78,16 +78,20 @@ class Pointnet2Backbone(nn.Module):
         npoints = [getattr(self, "sa%d" % i).npoint for i in (1, 2, 3, 4)]
         out = []
         with torch.cuda.stream(side):
-            cur, inds = xyz, None
-            for li, npoint in enumerate(npoints):
-                if li > 0:
-                    cur = pointnet2_utils.gather_rows(cur, inds)
-                    cur.record_stream(side)
+            cur = xyz
+            for npoint in npoints:
                 inds = pointnet2_utils.furthest_point_sample(cur, npoint)
                 inds.record_stream(main)
+                # the sampled coordinates are needed here anyway (next level's input); the SA
+                # layer that consumes `inds` takes them from the handle instead of gathering
+                # them again on the main stream (pointnet2_modules._sample_centres)
+                new_xyz = pointnet2_utils.gather_rows(cur, inds)
+                new_xyz.record_stream(main)
+                inds._btr_new_xyz = (new_xyz, cur)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 out.append((inds, ev))
+                cur = new_xyz
         xyz.record_stream(side)
         return out
 
