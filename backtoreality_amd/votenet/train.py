@@ -321,38 +321,63 @@ class GraphedPipelinedStep(object):
         return self.loss
 
 
-def train_step_br(net, optimizer, batch_S, batch_T, cfg):
+def _source_inputs(batch_S, sampling_S):
+    inputs = {'point_clouds': batch_S['point_clouds']}
+    if sampling_S is not None:
+        inputs['sampling'] = sampling_S
+    return inputs
+
+
+def _prefetch_next(core, end_points_S, end_points_T, next_batch_S, next_batch_T):
+    """next step's pyramids on the side stream, source first (its forward runs first)"""
+    if next_batch_S is not None:
+        end_points_S['next_sampling'] = core.backbone_net.prefetch_sampling(
+            next_batch_S['point_clouds'])
+    if next_batch_T is not None:
+        end_points_T['next_sampling'] = core.backbone_net.prefetch_sampling(
+            next_batch_T['point_clouds'])
+
+
+def train_step_br(net, optimizer, batch_S, batch_T, cfg, sampling_S=None, next_batch_S=None,
+                  sampling_T=None, next_batch_T=None):
     """One Back-to-Reality step (detection/Votenet/train_Votenet_BR.py:267-289): the SAME
     VoteNet_DA runs a source (virtual scenes) and a target (real scenes) forward -- BatchNorm
     running statistics are updated twice -- then one `get_loss_DA`, one backward, one Adam
-    step.  Two scenes batches = 2 x batch scenes of hot-path work per step."""
+    step.  Two scenes batches = 2 x batch scenes of hot-path work per step.
+    `sampling_S/_T`, `next_batch_S/_T`: software pipelining across steps as in train_step --
+    the NEXT step's pyramids run under this step's backward and come back as
+    end_points_S/_T['next_sampling']."""
     _zero_grad(net, optimizer)
-    # the target branch's sampling pyramid (coordinates only) runs on the side stream under
-    # the source branch's forward
+    # (unpipelined:) the target branch's sampling pyramid (coordinates only) runs on the side
+    # stream under the source branch's forward
     core = net.module if hasattr(net, "module") else net
-    sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
-    end_points_S = net({'point_clouds': batch_S['point_clouds']})
+    if sampling_T is None:
+        sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
+    end_points_S = net(_source_inputs(batch_S, sampling_S))
     end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T})
     for key in batch_S:
         end_points_S[key] = batch_S[key]
     for key in batch_T:
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = loss_helper.get_loss_DA(end_points_S, end_points_T, cfg)
+    _prefetch_next(core, end_points_S, end_points_T, next_batch_S, next_batch_T)
     loss.backward()
     _sync_grads(net)
     optimizer.step()
     return loss, end_points_S, end_points_T
 
 
-def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0):
+def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, sampling_S=None,
+                         next_batch_S=None, sampling_T=None, next_batch_T=None):
     """One CenterRefine step (detection/Votenet/train_Votenet_BR_CenterRefine.py:254-276): like
     train_step_br, but both forwards also pool features around the (noisy) GT centres and
     regress their displacement; batches need 'center_jitter' (synthetic.make_batch(...,
     center_jitter=0.1))."""
     _zero_grad(net, optimizer)
     core = net.module if hasattr(net, "module") else net
-    sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
-    end_points_S = net({'point_clouds': batch_S['point_clouds']}, batch_S['center_label'],
+    if sampling_T is None:
+        sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
+    end_points_S = net(_source_inputs(batch_S, sampling_S), batch_S['center_label'],
                        batch_S['sem_cls_label'])
     end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T},
                        batch_T['center_label'], batch_T['sem_cls_label'])
@@ -362,6 +387,7 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0):
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = loss_helper.get_loss_DA_jitter(
         end_points_S, end_points_T, epoch, cfg)
+    _prefetch_next(core, end_points_S, end_points_T, next_batch_S, next_batch_T)
     loss.backward()
     _sync_grads(net)
     optimizer.step()

@@ -219,13 +219,16 @@ def main():
             gs = gf_train.GraphedTrainStep(net, opt, batch, cfg)
             train_step = lambda n, o, b, c: gs(b)  # noqa: E731
     elif br:  # source + target branch: two forwards, one backward (train_Votenet_BR.py:267-289)
-        batch_T = synthetic.make_batch(100000 + rank * B, B, args.points, cfg, device=dev,
-                                       center_jitter=jit)
+        # two (source, target) batch pairs, alternated like the FSB batches
+        batches_T = [synthetic.make_batch(100000 + 7000 * i + rank * B, B, args.points, cfg,
+                                          device=dev, center_jitter=jit) for i in range(2)]
+        batch_T = batches_T[0]
         if cr:
-            train_step = lambda n, o, b, c: train.train_step_br_jitter(  # noqa: E731
-                n, o, b, batch_T, c, epoch=30)[:2]
+            br_step = lambda n, o, bs, bt, c, **kw: train.train_step_br_jitter(  # noqa: E731
+                n, o, bs, bt, c, epoch=30, **kw)
         else:
-            train_step = lambda n, o, b, c: train.train_step_br(n, o, b, batch_T, c)[:2]  # noqa: E731
+            br_step = train.train_step_br
+        train_step = lambda n, o, b, c: br_step(n, o, b, batch_T, c)[:2]  # noqa: E731
     else:
         train_step = train.train_step
 
@@ -237,10 +240,10 @@ def main():
 
     # two distinct resident batches, alternated: nothing a step computes can be reused by the next
     batches = [batch]
-    if not br and not gfbr:
+    if not gfbr:
         batches.append(synthetic.make_batch(500000 + rank * B, B, args.points, cfg, device=dev,
                                             center_jitter=jit, use_height=not gf))
-    pipelined_loop = not br and not gfbr and not args.sequential
+    pipelined_loop = not gfbr and not args.sequential
     pipe_step = gf_train.train_step if gf else train.train_step
 
     def run_steps(n, record=None):
@@ -252,9 +255,25 @@ def main():
         out = None
         if not pipelined_loop:
             for i in range(n):
-                out = train_step(ddp, opt, batches[i % len(batches)], cfg)
+                if br:
+                    out = br_step(ddp, opt, batches[i % 2], batches_T[i % 2], cfg)
+                else:
+                    out = train_step(ddp, opt, batches[i % len(batches)], cfg)
             return out
         if n <= 0:
+            return out
+        if br:   # the next step's SOURCE pyramid under this step's backward (the target's
+            core = net.module if hasattr(net, "module") else net   # runs under the source forward)
+            sampling = core.backbone_net.prefetch_sampling(batches[0]['point_clouds'])
+            sampling_t = None   # first step: under the source forward, as in the plain step
+            for i in range(n):
+                last = i + 1 >= n
+                out = br_step(ddp, opt, batches[i % 2], batches_T[i % 2], cfg,
+                              sampling_S=sampling, sampling_T=sampling_t,
+                              next_batch_S=None if last else batches[(i + 1) % 2],
+                              next_batch_T=None if last else batches_T[(i + 1) % 2])
+                sampling = out[1].get('next_sampling')
+                sampling_t = out[2].get('next_sampling')
             return out
         if graphed_step is not None:
             graphed_step.prime(batches[0])
@@ -318,7 +337,10 @@ def main():
         _ext.timing_begin(lambda op, key: op == "fps_kernel" and key[1] > 4096)
         t1 = time.perf_counter()
         for i in range(args.steps):
-            train_step(ddp, opt, batches[i % len(batches)], cfg)
+            if br:
+                br_step(ddp, opt, batches[i % 2], batches_T[i % 2], cfg)
+            else:
+                train_step(ddp, opt, batches[i % len(batches)], cfg)
         barrier()
         sequential = time.perf_counter() - t1
         seq_kernels = _ext.timing_end()
@@ -377,12 +399,14 @@ def main():
                 rf["avg_ms_running_alone"] = ms
                 rf["frac_running_alone"] = rf["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out["loop"] = ("software-pipelined: step i issues the sampling pyramid (FPS) of batch i+1 "
-                       "on a side stream under its own backward; the first batch's pyramid is "
-                       "computed inside the timed region; two distinct batches alternate"
-                       if pipelined_loop else "sequential")
+                       "(BR / CR: of the next SOURCE batch; the target's runs under the source "
+                       "forward) on a side stream under its own backward; the first batch's "
+                       "pyramid is computed inside the timed region; two distinct batches "
+                       "(batch pairs) alternate" if pipelined_loop else "sequential")
         if sequential is not None:
             out["sequential"] = {
-                "value": world * B * args.steps / sequential, "unit": "scenes/s",
+                "value": world * B * args.steps * (2 if br else 1) / sequential,
+                "unit": "scenes/s",
                 "ms_per_step": 1e3 * sequential / args.steps,
                 "note": "rank-0 clock; the same K steps without the cross-step overlap (every "
                         "step waits for its own FPS first); informational"}

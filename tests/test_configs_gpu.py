@@ -154,6 +154,42 @@ def test_sampling_prefetch_gives_identical_training(cuda):
     np.testing.assert_allclose(l1[1], l0[1], rtol=1e-2)
 
 
+@pytest.mark.parametrize("jitter", [False, True])
+def test_back_to_reality_prefetch_gives_identical_training(cuda, jitter):
+    """The same for the two-branch steps (train_step_br / train_step_br_jitter): both pyramids
+    of the NEXT step under this step's backward; the indices both branches consume and the
+    first loss are bit-identical to the plain loop's."""
+    cfg = config.scannet_md40()
+    jit = 0.1 if jitter else 0.0
+    bs = [synthetic.make_batch(10 * i, 2, 12000, cfg, device=cuda, center_jitter=jit)
+          for i in range(2)]
+    bt = [synthetic.make_batch(500 + 10 * i, 2, 12000, cfg, device=cuda, center_jitter=jit)
+          for i in range(2)]
+    step = (lambda *a, **k: train.train_step_br_jitter(*a, epoch=30, **k)) if jitter \
+        else train.train_step_br
+
+    def run(pipelined):
+        net = train.build_model(cfg, cuda, seed=0, domain_adaptation=True, center_refine=jitter)
+        opt = train.make_optimizer(net)
+        losses, inds, ss, st = [], [], None, None
+        for i in range(2):
+            more = pipelined and i + 1 < 2
+            loss, es, et = step(net, opt, bs[i], bt[i], cfg, sampling_S=ss, sampling_T=st,
+                                next_batch_S=bs[i + 1] if more else None,
+                                next_batch_T=bt[i + 1] if more else None)
+            ss, st = es.get('next_sampling'), et.get('next_sampling')
+            losses.append(float(loss))
+            inds.append((es['sa1_inds'].clone(), et['sa1_inds'].clone(), et['sa2_inds'].clone()))
+        return losses, inds
+
+    l0, i0 = run(False)
+    l1, i1 = run(True)
+    for a, b in zip(i0, i1):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert l0[0] == l1[0], (l0, l1)
+    np.testing.assert_allclose(l1[1], l0[1], rtol=1e-2)
+
+
 def test_graphed_pipelined_step_replays_the_eager_loop(cuda):
     """train.GraphedPipelinedStep (the software-pipelined step as one HIP graph, what bench.py
     times on one GPU) against the eager pipelined loop: same sampling indices consumed, first
