@@ -236,15 +236,23 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None, crite
     inputs = {'point_clouds': batch['point_clouds']}
     if sampling is not None:
         inputs['sampling'] = sampling
+    early = next_batch is not None and os.environ.get("BTR_PREFETCH_AT", "forward") == "forward"
+    nxt_sampling = None
+    if early:   # the next pyramid is issued before this step's forward: 4 ms of dependent FPS
+        # steps on 8 CUs then have the whole step to hide under (issued at the backward it ended
+        # 0.2 ms before the next forward needed it; BTR_PREFETCH_AT=backward: 6.05 vs 6.00 ms)
+        core = net.module if hasattr(net, "module") else net
+        nxt_sampling = core.backbone_net.prefetch_sampling(next_batch['point_clouds'])
     end_points = net(inputs)
     for key in batch:
         assert key not in end_points
         end_points[key] = batch[key]
     loss, end_points = (criterion or loss_helper.get_loss)(end_points, cfg)
-    if next_batch is not None:
+    if next_batch is not None and not early:
         core = net.module if hasattr(net, "module") else net
-        end_points['next_sampling'] = core.backbone_net.prefetch_sampling(
-            next_batch['point_clouds'])
+        nxt_sampling = core.backbone_net.prefetch_sampling(next_batch['point_clouds'])
+    if nxt_sampling is not None:
+        end_points['next_sampling'] = nxt_sampling
     loss.backward()
     _sync_grads(net)
     optimizer.step()
@@ -353,6 +361,10 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, sampling_S=None, next_b
     core = net.module if hasattr(net, "module") else net
     if sampling_T is None:
         sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
+    early = os.environ.get("BTR_PREFETCH_AT", "forward") == "forward"
+    nxt = ({}, {})
+    if early:
+        _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
     end_points_S = net(_source_inputs(batch_S, sampling_S))
     end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T})
     for key in batch_S:
@@ -360,7 +372,10 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, sampling_S=None, next_b
     for key in batch_T:
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = loss_helper.get_loss_DA(end_points_S, end_points_T, cfg)
-    _prefetch_next(core, end_points_S, end_points_T, next_batch_S, next_batch_T)
+    if not early:
+        _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
+    end_points_S.update(nxt[0])
+    end_points_T.update(nxt[1])
     loss.backward()
     _sync_grads(net)
     optimizer.step()
@@ -377,6 +392,10 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, samplin
     core = net.module if hasattr(net, "module") else net
     if sampling_T is None:
         sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
+    early = os.environ.get("BTR_PREFETCH_AT", "forward") == "forward"
+    nxt = ({}, {})
+    if early:
+        _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
     end_points_S = net(_source_inputs(batch_S, sampling_S), batch_S['center_label'],
                        batch_S['sem_cls_label'])
     end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T},
@@ -387,7 +406,10 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, samplin
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = loss_helper.get_loss_DA_jitter(
         end_points_S, end_points_T, epoch, cfg)
-    _prefetch_next(core, end_points_S, end_points_T, next_batch_S, next_batch_T)
+    if not early:
+        _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
+    end_points_S.update(nxt[0])
+    end_points_T.update(nxt[1])
     loss.backward()
     _sync_grads(net)
     optimizer.step()
