@@ -400,9 +400,10 @@ def main():
                 rf["frac_running_alone"] = rf["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out["loop"] = ("software-pipelined: step i issues the sampling pyramid (FPS) of batch i+1 "
                        "(BR / CR: of the next SOURCE batch; the target's runs under the source "
-                       "forward) on a side stream under its own backward; the first batch's "
-                       "pyramid is computed inside the timed region; two distinct batches "
-                       "(batch pairs) alternate" if pipelined_loop else "sequential")
+                       "forward) on a side stream while it runs itself (issued before its "
+                       "forward); the first batch's pyramid is computed inside the timed "
+                       "region; two distinct batches (batch pairs) alternate"
+                       if pipelined_loop else "sequential")
         if sequential is not None:
             out["sequential"] = {
                 "value": world * B * args.steps * (2 if br else 1) / sequential,
