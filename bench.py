@@ -399,8 +399,7 @@ def main():
                 rf["avg_ms_running_alone"] = ms
                 rf["frac_running_alone"] = rf["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out["loop"] = ("software-pipelined: step i issues the sampling pyramid (FPS) of batch i+1 "
-                       "(BR / CR: of the next SOURCE batch; the target's runs under the source "
-                       "forward) on a side stream while it runs itself (issued before its "
+                       "(BR / CR: of both branches of step i+1) on a side stream while it runs itself (issued before its "
                        "forward); the first batch's pyramid is computed inside the timed "
                        "region; two distinct batches (batch pairs) alternate"
                        if pipelined_loop else "sequential")
