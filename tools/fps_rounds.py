@@ -6,7 +6,7 @@ from backtoreality_amd.pointnet2 import _ext
 from tools.bench_ops import scenes, timeit
 xyz = scenes(8, 40000)
 ref = None
-for impl in ("single", "multi"):
+for impl in ("single", "pm"):
     if impl == "single": os.environ["BTR_FPS_IMPL"] = "single"
     else: os.environ.pop("BTR_FPS_IMPL", None)
     out = _ext.furthest_point_sampling(xyz, 2048)

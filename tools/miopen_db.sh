@@ -8,7 +8,7 @@ cd $GRAFT_REPO_ROOT
 export MIOPEN_USER_DB_PATH=$PWD/backtoreality_amd/miopen_db
 for w in fsb br cr gf gfbr; do
   s=$(date +%s)
-  python bench.py --workload $w --no-cpu-baseline --no-pipelined 2>gpurun_out/at_$w.err | python -c "
+  python bench.py --workload $w --no-cpu-baseline --sequential 2>gpurun_out/at_$w.err | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print('$w', d['value'], d['ms_per_step'])"
   echo "$w took $(( $(date +%s) - s )) s"
