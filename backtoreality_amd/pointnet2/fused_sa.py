@@ -126,11 +126,11 @@ class FusedSAFunction(Function):
                 if rc and l == 0:    # statistics only
                     Y = _f32((0, Nl), dev)
                     _call(_lib.btr_sa_gemm_nt, R, Nl, K, _p(A), lda, _p(W2), K, None, Nl, None,
-                          None, _p(part), st, key=(Rk, Nl, K))
+                          None, _p(part), st, key=(Rk, Nl, K, R))
                 elif rc and l == 1:  # A = relu(bn(X0 . W0^T)) rebuilt while staging
                     Y = _f32((R, Nl), dev)
                     _call(_lib.btr_sa_gemm_nt_rc, R, Nl, K, _p(X0), _p(Ws[0]), _p(W2), K, _p(Y),
-                          Nl, _p(pa), _p(pb), _p(part), st, key=(Rk, Nl, K))
+                          Nl, _p(pa), _p(pb), _p(part), st, key=(Rk, Nl, K, R))
                 elif (l == L - 1 and pa is not None and _pool_in_epilogue() and
                       _lib.btr_sa_gemm_nt_poolfwd_supported(R, Nl, 8 if compact else S)):
                     # last layer: the GEMM epilogue also emits the per-group extrema (compact
@@ -141,11 +141,11 @@ class FusedSAFunction(Function):
                            torch.empty((R // PSz, Nl), dtype=torch.uint8, device=dev))
                     _call(_lib.btr_sa_gemm_nt_poolfwd, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl,
                           _p(pa), _p(pb), _p(part), PSz, _p(gamma), _p(ext[0]), _p(ext[1]), st,
-                          key=(Rk, Nl, K))
+                          key=(Rk, Nl, K, R))
                 else:
                     Y = _f32((R, Nl), dev)
                     _call(_lib.btr_sa_gemm_nt, R, Nl, K, _p(A), lda, _p(W2), K, _p(Y), Nl,
-                          _p(pa), _p(pb), _p(part), st, key=(Rk, Nl, K))
+                          _p(pa), _p(pb), _p(part), st, key=(Rk, Nl, K, R))
                 scale, shift, mean, invstd = (_f32((Nl,), dev) for _ in range(4))
                 bn = bns[l]
                 if bn.momentum is None:
@@ -260,14 +260,14 @@ class FusedSAFunction(Function):
                 dW = _f32((Nl, K), dev)
                 if ctx.rc and l == 1:  # X = relu(bn(X0 . W0^T)) rebuilt while staging
                     _call(_lib.btr_sa_gemm_tn_rc, R, Nl, K, _p(dY), Nl, _p(X0), _p(Ws[0]),
-                          _p(pa), _p(pb), _p(pw), _p(dW), st, key=(Rk, Nl, K))
+                          _p(pa), _p(pb), _p(pw), _p(dW), st, key=(Rk, Nl, K, R))
                 elif pooled:
                     _call(_lib.btr_sa_gemm_tn_pool, R, Nl, K, _p(dY), Nl, S, _p(arg),
                           _p(pool[0]), _p(pool[1]), _p(pool[2]), _p(Xsrc), ldx, _p(pa), _p(pb),
-                          _p(pw), _p(dW), st, key=(Rk, Nl, K))
+                          _p(pw), _p(dW), st, key=(Rk, Nl, K, R))
                 else:
                     _call(_lib.btr_sa_gemm_tn, R, Nl, K, _p(dY), Nl, _p(Xsrc), ldx, _p(pa),
-                          _p(pb), _p(pw), _p(dW), st, key=(Rk, Nl, K))
+                          _p(pb), _p(pw), _p(dW), st, key=(Rk, Nl, K, R))
                 kin = pshapes[3 * l][1]
                 grads[3 * l] = dW[:, :kin].reshape(pshapes[3 * l])
                 # input gradient: dX_l[r][k] = sum_n dY[r][n] * W[n][k]
@@ -277,10 +277,10 @@ class FusedSAFunction(Function):
                     if pooled:
                         _call(_lib.btr_sa_gemm_nt_pool, R, K, Nl, _p(dY), Nl, _p(Wt), Nl, _p(G),
                               K, S, _p(arg), _p(pool[0]), _p(pool[1]), _p(pool[2]), st,
-                              key=(Rk, K, Nl))
+                              key=(Rk, K, Nl, R))
                     else:
                         _call(_lib.btr_sa_gemm_nt, R, K, Nl, _p(dY), Nl, _p(Wt), Nl, _p(G), K,
-                              None, None, None, st, key=(Rk, K, Nl))
+                              None, None, None, st, key=(Rk, K, Nl, R))
                     if l > 0:
                         sc, sh, mu, isd = stats[l - 1]
                         part = _f32((1024, 2, K), dev)

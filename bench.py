@@ -497,6 +497,10 @@ def roofline_objects(kernels, detail, detail_steps):
     if gemm:
         steps = detail_steps
         flops = sum(2.0 * k[0] * k[1] * k[2] * len(t) for k, t in gemm) / steps
+        # the same launches priced at the rows the REFERENCE's formulation has (every padded
+        # copy of a neighbour is a row there; compact rows evaluate distinct neighbours only)
+        dense = sum(2.0 * (k[3] if len(k) > 3 else k[0]) * k[1] * k[2] * len(t)
+                    for k, t in gemm) / steps
         ms = sum(sum(t) for _, t in gemm) / steps
         ach = flops / (ms * 1e-3) / 1e12
         # the same launches against the HBM roof: f32 operands + result moved once
@@ -509,6 +513,9 @@ def roofline_objects(kernels, detail, detail_steps):
                                "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_step": gbytes,
                                "gflop_per_step": flops / 1e9, "ms_per_step": ms,
+                               "dense_rows_gflop_per_step": dense / 1e9,
+                               "dense_rows_equivalent_frac": dense / (ms * 1e-3) / 1e12 /
+                               MFMA_F32_PEAK_TF,
                                "launches_per_step": sum(len(t) for _, t in gemm) / steps}
     fps_op = pick("furthest_point_sampling")   # spatial sort (4 launches) + sampling kernel
     fps = pick("fps_kernel") or fps_op          # the sampling kernel alone (event pair recorded
