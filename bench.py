@@ -534,7 +534,7 @@ def roofline_objects(kernels, detail, detail_steps):
                                    "scene), not by bytes: see iterations_per_s.  avg_ms: the "
                                    "kernel alone, in the loop that was timed (software-"
                                    "pipelined: on the side stream, sharing the chip with the "
-                                   "backward pass); op_avg_ms: the whole FPS call incl. its "
+                                   "step that runs meanwhile); op_avg_ms: the whole FPS call incl. its "
                                    "spatial-sort launches and their queueing",
                            "streaming_GBs": b * (m - 1) * n * 20 / (ms * 1e-3) / 1e9,
                            "iterations_per_s": b * (m - 1) / (ms * 1e-3)}
