@@ -1,7 +1,6 @@
 """VoteNet assembly (detection/Votenet/models/votenet.py:25-100): backbone -> voting ->
 L2-normalised vote features -> proposal module.  Sub-module names (`backbone_net`, `vgen`,
 `pnet`) match the reference so its checkpoints' `model_state_dict` loads."""
-import torch
 import torch.nn as nn
 
 from .backbone_module import Pointnet2Backbone

@@ -6,7 +6,6 @@ sizes and at ragged ones; dropout: keep fraction, scaling, and a backward that m
 forward's mask (finite differences through the same seed)."""
 import copy
 
-import numpy as np
 import pytest
 import torch
 import torch.nn as nn

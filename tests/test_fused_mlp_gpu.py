@@ -3,7 +3,6 @@ torch ops they replace, on the GPU: same module, weights, inputs; outputs, every
 the BatchNorm running statistics."""
 import copy
 
-import numpy as np
 import pytest
 import torch
 
