@@ -135,6 +135,10 @@ class Pointnet2Backbone(nn.Module):
         'center_features' (B, 128 + num_class, 64) (backbone_module.py:257-260)."""
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
+        # the coordinate slice is shared between a prefetch and the ONE forward that consumes it,
+        # never across steps: a later step on the same resident tensor cuts it again
+        if hasattr(pointcloud, "_btr_xyz"):
+            del pointcloud._btr_xyz
         pyramid = sampling if sampling is not None else self._fps_pyramid(xyz)
         for i in (1, 2, 3, 4):
             inds, ready = pyramid[i - 1]
