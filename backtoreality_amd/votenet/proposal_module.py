@@ -67,8 +67,8 @@ class DecodedEndPoints(dict):
     key, `in`, `get`, iteration, `len`, `keys/items/values`, `copy` -- decodes first, so the
     dict always LOOKS like the reference's; only plain reads / writes of other keys do not."""
 
-    def __init__(self, base, decode):
-        super().__init__(base)
+    def __init__(self, base=(), decode=None):   # (dict-like construction: nn.DataParallel's
+        super().__init__(base)                  # gather rebuilds type(out)(pairs))
         self._decode = decode
 
     def _force(self):

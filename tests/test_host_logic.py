@@ -297,6 +297,8 @@ def test_decoded_end_points_are_lazy_but_look_complete():
         assert dict.__contains__(e2, 'center'), make
         if isinstance(got, (list, dict)):
             assert len(got) == 1 + len(DECODED_KEYS)
+    rebuilt = type(ep)((k, v) for k, v in ep.items())     # what DataParallel's gather does
+    assert rebuilt['center'] == 'CENTER' and len(rebuilt) == len(ep)
     with __import__('pytest').raises(KeyError):
         DecodedEndPoints({}, decode)['nonsense']
     assert calls.count(1) == 7
