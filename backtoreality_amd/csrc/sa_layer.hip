@@ -15,6 +15,7 @@
 // models/voting_module.py:37-56 and models/proposal_module.py:75-113, and their autograd
 // backward.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -260,6 +261,47 @@ __global__ __launch_bounds__(256) void vote_assemble_norm_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------- weight gradients on a side stream
+// In a layer's backward the weight-gradient GEMM of layer l (dW_l = dY_l^T X_l) and the chain that
+// continues to layer l - 1 (dX = dY_l W_l, BatchNorm backward, ...) only share their input dY_l.
+// On the small layers (SA3 / SA4 / vote aggregation / the MLP chains: 2 000 - 65 000 rows) neither
+// fills the chip, so the wgrad launches go to a second stream: fork after dY_l is final, join at
+// the end of the call (the caller sees one stream).  Not while a HIP graph is being captured;
+// BTR_WGRAD_STREAM=0 turns it off.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t ready[kMaxL + 1] = {}, done[kMaxL + 1] = {};
+  int device = -1;
+};
+SideStream *side_stream() {
+  static thread_local SideStream ctx[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream &c = ctx[dev];
+  if (!c.s) {
+    if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (int i = 0; i <= kMaxL; ++i) {
+      (void)hipEventCreateWithFlags(&c.ready[i], hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&c.done[i], hipEventDisableTiming);
+    }
+    c.device = dev;
+  }
+  return &c;
+}
+// the side stream to use for this call, or NULL (disabled / capturing / creation failed)
+SideStream *wgrad_side(hipStream_t main) {
+  static const bool off = getenv("BTR_WGRAD_STREAM") && getenv("BTR_WGRAD_STREAM")[0] == '0';
+  if (off) return nullptr;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  // (inside a captured GroupFree3D step the fork / join nodes cost more than the overlap buys:
+  // 15.3 vs 14.3 ms per replay)
+  if (hipStreamIsCapturing(main, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return side_stream();
+}
+
 struct Unbind {
   ~Unbind() { btr_sac_bind(nullptr); }
 };
@@ -281,7 +323,7 @@ struct SaFwdScratch {
   size_t part, len_tmp, extg, exta, bytes;
 };
 struct SaBwdScratch {
-  size_t part, m1, m2, dcl, alpha, beta, pw, g[2], scat, dfeat_cl, bytes;
+  size_t part, m1, m2, dcl, alpha, beta, pw, pw0, g[2], scat, dfeat_cl, bytes;
   size_t scat_bytes;
 };
 
@@ -312,7 +354,7 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
     pw = std::max(pw, (size_t)btr_sa_gemm_tn_chunks(p.rows, d.width[l], p.kin[l]) * d.width[l] *
                           p.kin[l]);
   }
-  if (p.recompute) pw = std::max(pw, (size_t)btr_sa_rc_wgrad_blocks(p.rows, d.width[0]) * d.width[0] * 4);
+  const size_t pw0 = p.recompute ? (size_t)btr_sa_rc_wgrad_blocks(p.rows, d.width[0]) * d.width[0] * 4 : 0;
   const int cl = d.width[d.layers - 1];
   s.part = b.floats((size_t)1024 * 2 * maxc);
   s.m1 = b.floats(maxc);
@@ -321,6 +363,7 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   s.alpha = b.floats(cl);
   s.beta = b.floats(cl);
   s.pw = b.floats(pw);
+  s.pw0 = b.floats(pw0);   // (first-layer recompute: its partials, written on the main stream)
   s.g[0] = b.floats((size_t)p.rows * maxk);
   s.g[1] = b.floats((size_t)p.rows * maxk);
   s.scat_bytes = p.compact ? btr_sac_scatter_workspace_bytes(d.b, d.n, p.rows)
@@ -534,6 +577,9 @@ int btr_sa_layer_backward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, con
   const bool any_in = d.need_dxyz || d.need_dnew_xyz || d.need_dfeat;
   float *dy = ylast;
   int flip = 0;
+  hipStream_t hmain = as_stream(stream);
+  SideStream *side = wgrad_side(hmain);
+  int last_done = -1;
   for (int l = L - 1; l >= 0; --l) {
     const int nl = d.width[l], k = p.kin[l];
     const float *xsrc = l == 0 ? x0 : at_f(saved, p.y[l - 1]);
@@ -543,18 +589,30 @@ int btr_sa_layer_backward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, con
     const bool pooled = p.pool_grad && l == L - 1;
     if (p.recompute && l == 0) break;  // finished by btr_sa_bn_relu_bwd_rc below
     float *dw = grads + p.dw[l];
+    // weight gradient of layer l: dY_l is final here -> fork
+    btr_stream_t ws = stream;
+    if (side) {
+      (void)hipEventRecord(side->ready[l], hmain);
+      (void)hipStreamWaitEvent(side->s, side->ready[l], 0);
+      ws = (btr_stream_t)side->s;
+    }
     if (p.recompute && l == 1)
-      BTR_TRY(btr_sa_gemm_tn_rc(R, nl, k, dy, nl, x0, at_f(saved, p.w2[0]), pa, pb, pw, dw,
-                                stream));
+      BTR_TRY(btr_sa_gemm_tn_rc(R, nl, k, dy, nl, x0, at_f(saved, p.w2[0]), pa, pb, pw, dw, ws));
     else if (pooled)
       BTR_TRY(btr_sa_gemm_tn_pool(R, nl, k, dy, nl, d.s, arg, dcl, alpha, beta, xsrc, ldx, pa, pb,
-                                  pw, dw, stream));
+                                  pw, dw, ws));
     else
-      BTR_TRY(btr_sa_gemm_tn(R, nl, k, dy, nl, xsrc, ldx, pa, pb, pw, dw, stream));
+      BTR_TRY(btr_sa_gemm_tn(R, nl, k, dy, nl, xsrc, ldx, pa, pb, pw, dw, ws));
+    if (side) {
+      (void)hipEventRecord(side->done[l], side->s);
+      last_done = l;
+    }
     if (l > 0 || any_in) {
       const float *wt = at_f(saved, p.wt[l]);
       float *g = at_f(scratch, sc.g[flip]);
       flip ^= 1;
+      // g is the buffer dY_{l+1} lived in: its weight gradient must be through with it
+      if (side && l + 1 <= L - 2) (void)hipStreamWaitEvent(hmain, side->done[l + 1], 0);
       if (pooled)
         BTR_TRY(btr_sa_gemm_nt_pool(R, k, nl, dy, nl, wt, nl, g, k, d.s, arg, dcl, alpha, beta,
                                     stream));
@@ -566,7 +624,7 @@ int btr_sa_layer_backward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, con
         if (p.recompute && l == 1)
           BTR_TRY(btr_sa_bn_relu_bwd_rc(R, k, k, g, x0, at_f(saved, p.w2[0]), stat(0, 0),
                                         stat(0, 1), stat(0, 2), stat(0, 3), part, m1, m2, dg, db,
-                                        pw, grads + p.dw[0], stream));
+                                        at_f(scratch, sc.pw0), grads + p.dw[0], stream));
         else
           BTR_TRY(btr_sa_bn_relu_bwd(R, k, k, g, at_f(saved, p.y[l - 1]), stat(l - 1, 0),
                                      stat(l - 1, 1), stat(l - 1, 2), stat(l - 1, 3), part, m1, m2,
@@ -574,15 +632,15 @@ int btr_sa_layer_backward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, con
         dy = g;
       } else {
         float *dfeat_cl = (d.need_dfeat && d.c > 0 && dfeat) ? at_f(scratch, sc.dfeat_cl) : nullptr;
-        void *ws = (char *)scratch + sc.scat;
+        void *ws2 = (char *)scratch + sc.scat;
         if (p.compact) {
           if (dfeat_cl)
             BTR_TRY(btr_sac_scatter(d.b, d.n, d.m, d.c, p.k0p, d.use_xyz, g, at_i(saved, p.cidx),
-                                    at_i(saved, p.goff), dfeat_cl, ws, sc.scat_bytes, R, stream));
+                                    at_i(saved, p.goff), dfeat_cl, ws2, sc.scat_bytes, R, stream));
         } else {
           BTR_TRY(btr_sa_scatter(d.b, d.n, d.m, d.s, d.c, p.k0p, d.use_xyz, d.radius_div, g, idx,
                                  dfeat_cl, d.need_dxyz ? dxyz : nullptr,
-                                 d.need_dnew_xyz ? dnew_xyz : nullptr, ws, sc.scat_bytes, stream));
+                                 d.need_dnew_xyz ? dnew_xyz : nullptr, ws2, sc.scat_bytes, stream));
         }
         if (dfeat_cl)
           BTR_TRY(btr_pm_out(d.b, d.n, d.c, d.c, dfeat_cl, nullptr, nullptr, 0, dfeat, nullptr,
@@ -590,6 +648,7 @@ int btr_sa_layer_backward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, con
       }
     }
   }
+  if (side && last_done >= 0) (void)hipStreamWaitEvent(hmain, side->done[last_done], 0);   // join
   return check_launch("sa_layer_backward");
 }
 
@@ -790,16 +849,30 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
                        pw, grads + p.dbias[L - 1]);
   }
   float *dy = g;
+  SideStream *side = wgrad_side(hs);
+  int last_done = -1;
   for (int l = L - 1; l >= 0; --l) {
     const int np = p.np[l], k = p.kin[l];
     const float *xsrc = l == 0 ? (x_cl ? x_cl : at_f(saved, p.x0)) : at_f(saved, p.y[l - 1]);
     const int ldx = l == 0 ? p.kin[0] : p.np[l - 1];
     const float *pa = l == 0 ? nullptr : stat(l - 1, 0);
     const float *pb = l == 0 ? nullptr : stat(l - 1, 1);
-    BTR_TRY(btr_sa_gemm_tn(rows, np, k, dy, np, xsrc, ldx, pa, pb, pw, grads + p.dw[l], stream));
+    btr_stream_t ws = stream;   // weight gradient on the side stream (see SideStream)
+    if (side) {
+      (void)hipEventRecord(side->ready[l], hs);
+      (void)hipStreamWaitEvent(side->s, side->ready[l], 0);
+      ws = (btr_stream_t)side->s;
+    }
+    BTR_TRY(btr_sa_gemm_tn(rows, np, k, dy, np, xsrc, ldx, pa, pb, pw, grads + p.dw[l], ws));
+    if (side) {
+      (void)hipEventRecord(side->done[l], side->s);
+      last_done = l;
+    }
     if (l > 0 || d.need_dx) {
       float *gn = at_f(scratch, sc.g[flip]);
       flip ^= 1;
+      // gn is the buffer dY_{l+1} lived in: its weight gradient must be through with it
+      if (side && l + 1 <= L - 1) (void)hipStreamWaitEvent(hs, side->done[l + 1], 0);
       BTR_TRY(btr_pm_gemm_nt(rows, k, np, dy, np, at_f(saved, p.wt[l]), np, gn, k, nullptr,
                              nullptr, nullptr, nullptr, stream));
       if (l > 0) {
@@ -813,6 +886,7 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
       }
     }
   }
+  if (side && last_done >= 0) (void)hipStreamWaitEvent(hs, side->done[last_done], 0);   // join
   return check_launch("pm_chain_backward");
 }
 
