@@ -567,7 +567,11 @@ def can_fuse(module, xyz, features):
 def fused_group_mlp_max(module, xyz, new_xyz, features):
     """Drop-in for grouper + mlp_module + max-pool of a _SingleScaleSA module."""
     g = module.grouper
-    idx = pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz)
+    pre = getattr(new_xyz, "_btr_ball_query", None)   # computed with the prefetched pyramid
+    if pre is not None and pre[1] is xyz and pre[2] == g.radius and pre[3] == g.nsample:
+        idx = pre[0]
+    else:
+        idx = pointnet2_utils.ball_query(g.radius, g.nsample, xyz, new_xyz)
     if features is None and not g.use_xyz:
         raise AssertionError("Cannot have not features and not use xyz as a feature!")
     if not module.training:

@@ -235,7 +235,10 @@ class PointnetFPModule(nn.Module):
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
         if known is not None:
-            if unknown.is_cuda and hasattr(pointnet2_utils._ext, "three_nn_weights"):
+            pre = getattr(unknown, "_btr_three_nn", None)   # computed with a prefetched pyramid
+            if pre is not None and pre[0] is known:
+                idx, weight = pre[1], pre[2]
+            elif unknown.is_cuda and hasattr(pointnet2_utils._ext, "three_nn_weights"):
                 idx, weight = pointnet2_utils.three_nn_weights(unknown, known)   # one launch
             else:
                 dist, idx = pointnet2_utils.three_nn(unknown, known)

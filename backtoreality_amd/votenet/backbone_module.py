@@ -77,9 +77,11 @@ class Pointnet2Backbone(nn.Module):
         side.wait_stream(main)
         npoints = [getattr(self, "sa%d" % i).npoint for i in (1, 2, 3, 4)]
         out = []
+        geometry = os.environ.get("BTR_PREFETCH_GEOMETRY", "1") != "0"
         with torch.cuda.stream(side):
             cur = xyz
-            for npoint in npoints:
+            centres = []
+            for li, npoint in enumerate(npoints):
                 inds = pointnet2_utils.furthest_point_sample(cur, npoint)
                 inds.record_stream(main)
                 # the sampled coordinates are needed here anyway (next level's input); the SA
@@ -88,10 +90,29 @@ class Pointnet2Backbone(nn.Module):
                 new_xyz = pointnet2_utils.gather_rows(cur, inds)
                 new_xyz.record_stream(main)
                 inds._btr_new_xyz = (new_xyz, cur)
+                if geometry:
+                    # everything else that depends on coordinates only goes the same way: the
+                    # layer's ball query ...
+                    g = getattr(self, "sa%d" % (li + 1)).grouper
+                    idx = pointnet2_utils.ball_query(g.radius, g.nsample, cur, new_xyz)
+                    idx.record_stream(main)
+                    new_xyz._btr_ball_query = (idx, cur, g.radius, g.nsample)
+                centres.append(new_xyz)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 out.append((inds, ev))
                 cur = new_xyz
+            if geometry:
+                # ... and the 3-NN blend weights of the two feature-propagation modules
+                # (fp1: sa3 <- sa4, fp2: sa2 <- sa3; forward() below)
+                for unknown, known in ((centres[2], centres[3]), (centres[1], centres[2])):
+                    idx, weight = pointnet2_utils.three_nn_weights(unknown, known)
+                    idx.record_stream(main)
+                    weight.record_stream(main)
+                    unknown._btr_three_nn = (known, idx, weight)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                out[-1] = (out[-1][0], ev)   # (the last level's event also covers these)
         xyz.record_stream(side)
         return out
 
