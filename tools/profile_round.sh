@@ -6,6 +6,9 @@
 # Everything is summarised on the box into gpurun_out/<tag>/ (the databases are too large to
 # travel); copy what should be judged into profiles/.
 set -e
+# every kernel alone on the chip: sequential loop, and the library's second (weight-gradient)
+# stream off -- overlapped kernels stretch each other's durations
+export BTR_WGRAD_STREAM=0
 TAG=${1:-round}
 ARGS="--steps 3 --warmup 2 --no-cpu-baseline --sequential"
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -26,5 +29,6 @@ python tools/rocpd_pmc.py $WR $OUT/pmc_WRITE_SIZE.md
 python tools/pmc_traffic.py $FE $WR $OUT/pmc_traffic.json
 python tools/recompute_roofline.py $OUT/bench_under_profiler.json $OUT/one_step.md > $OUT/roofline_check.md
 # the headline loop (software-pipelined) and the sequential loop beside it, no profiler attached
+unset BTR_WGRAD_STREAM
 python bench.py > $OUT/bench.json 2>/dev/null
 head -3 $OUT/one_step.md; cat $OUT/roofline_check.md; tail -c 600 $OUT/bench.json
