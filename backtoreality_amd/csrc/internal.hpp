@@ -1,0 +1,31 @@
+// internal.hpp -- functions one translation unit of libbtr_pointnet2.so offers the others
+// (not part of the C ABI).  The whole-backbone entry points (backbone.hip) sequence the
+// whole-layer ones (sa_layer.hip) and need a few of their pieces with extra operands.
+#pragma once
+#include "common.hpp"
+
+namespace btr {
+
+// sa_mlp.hip: out_bcn (B, C, N) [and out_cl (B*N, C)] = f(scale * y + shift) [+ add];
+// add (optional): a (B, C, N)-shaped operand whose batch elements are add_bstride floats apart
+// (a channel slab of a wider (B, C', N) tensor), added to out_bcn only.
+int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
+               const float *shift, int relu, float *out_bcn, float *out_cl, const float *add,
+               long long add_bstride, hipStream_t stream);
+
+// interpolate.hip: three_interpolate_grad through inverted index lists with caller-provided
+// scratch; grad_out's batch elements are go_bstride floats apart (>= c * n).
+size_t ti_grad_workspace_bytes(int b, int n, int m);
+int ti_grad_lists(int b, int c, int n, int m, const float *grad_out, long long go_bstride,
+                  const int *idx, const float *weight, float *grad_points, void *workspace,
+                  size_t workspace_bytes, hipStream_t stream);
+
+// sa_layer.hip: btr_sa_layer_backward with an operand added to the feature gradient it writes
+// (dfeat (b, c, n) = layer's own gradient + dfeat_add; dfeat_add's batch stride in floats).
+int sa_layer_backward_add(const btr_sa_layer_t *d, const btr_sa_plan_t *plan, const int *idx,
+                          const float *out, const float *dout, void *saved, float *grads,
+                          float *dfeat, float *dxyz, float *dnew_xyz, void *scratch,
+                          const float *dfeat_add, long long dfeat_add_bstride,
+                          btr_stream_t stream);
+
+}  // namespace btr

@@ -5,7 +5,7 @@
 
 #include <cstdlib>
 
-#include "common.hpp"
+#include "internal.hpp"
 
 namespace btr {
 
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void ti_fill_kernel(int n3, int m, const int *
 constexpr int kTiCpt = 8;  // channels per thread in the list reduction
 __global__ __launch_bounds__(256) void ti_reduce_kernel(
     int c, int n, int m, const float *__restrict__ grad_out, const float *__restrict__ weight,
-    const int *__restrict__ off, const int *__restrict__ refs, float *__restrict__ grad_points) {
+    const int *__restrict__ off, const int *__restrict__ refs, float *__restrict__ grad_points,
+    long long go_bs) {
   const int bi = blockIdx.z;
   const int j = blockIdx.x * 64 + (threadIdx.x & 63);
   const int c0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kTiCpt;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void ti_reduce_kernel(
   for (int e = beg; e < end; ++e) {
     const int ref = r[e];
     const float wt = w[ref];
-    const float *g = grad_out + ((size_t)bi * c + c0) * n + ref / 3;
+    const float *g = grad_out + (size_t)bi * go_bs + (size_t)c0 * n + ref / 3;
 #pragma unroll
     for (int l = 0; l < kTiCpt; ++l)
       if (c0 + l < c) acc[l] += g[(size_t)l * n] * wt;
@@ -259,6 +260,38 @@ __global__ __launch_bounds__(256) void ti_reduce_kernel(
 bool csr_small_supported(int n_bins);
 void csr_small_launch(int b, long long entries, int n_bins, const int *idx, int *off, int *refs,
                       hipStream_t st);
+
+size_t ti_grad_workspace_bytes(int b, int n, int m) {
+  if (b <= 0 || n <= 0 || m <= 0) return 0;
+  return sizeof(int) * ((size_t)b * (m + 1) + (size_t)b * m + (size_t)b * n * 3);
+}
+
+// grad_points (b, c, m) = scatter-add of grad_out (b, c, n) [batch stride go_bstride floats]
+// through the 3-NN lists, without float atomics (see ti_reduce_kernel)
+int ti_grad_lists(int b, int c, int n, int m, const float *grad_out, long long go_bstride,
+                  const int *idx, const float *weight, float *grad_points, void *workspace,
+                  size_t workspace_bytes, hipStream_t st) {
+  BTR_REQUIRE(grad_out && idx && weight && grad_points && workspace &&
+                  workspace_bytes >= ti_grad_workspace_bytes(b, n, m),
+              "three_interpolate_grad: null pointer or workspace too small");
+  BTR_REQUIRE(b < 65536 && (long long)n * 3 < 0x7fffffffLL, "three_interpolate_grad: too large");
+  const int n3 = n * 3;
+  const size_t off_b = sizeof(int) * (size_t)b * (m + 1), cur_b = sizeof(int) * (size_t)b * m;
+  char *ws = (char *)workspace;
+  int *off = (int *)ws, *cursor = (int *)(ws + off_b), *refs = (int *)(ws + off_b + cur_b);
+  if (csr_small_supported(m)) {
+    csr_small_launch(b, n3, m, idx, off, refs, st);
+  } else {
+    (void)hipMemsetAsync(off, 0, off_b, st);
+    hipLaunchKernelGGL(ti_count_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx, off);
+    hipLaunchKernelGGL(ti_scan_kernel, dim3(b), dim3(256), 0, st, m, off, cursor);
+    hipLaunchKernelGGL(ti_fill_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx,
+                       cursor, refs);
+  }
+  hipLaunchKernelGGL(ti_reduce_kernel, dim3(cdiv(m, 64), cdiv(c, 4 * kTiCpt), b), dim3(256), 0,
+                     st, c, n, m, grad_out, weight, off, refs, grad_points, go_bstride);
+  return check_launch("three_interpolate_grad(lists)");
+}
 
 }  // namespace btr
 
@@ -313,31 +346,16 @@ int btr_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out
   // default: inverted lists (no float atomics); BTR_TI_GRAD=atomic keeps the reference's form
   static const bool atomic_path = getenv("BTR_TI_GRAD") && getenv("BTR_TI_GRAD")[0] == 'a';
   if (!atomic_path && n > 0 && (long long)n * 3 < 0x7fffffffLL) {
-    BTR_REQUIRE(grad_out && idx && weight, "three_interpolate_grad: null pointer");
-    BTR_REQUIRE(b < 65536, "three_interpolate_grad: batch too large");
     hipStream_t st = as_stream(stream);
-    const int n3 = n * 3;
-    const size_t off_b = sizeof(int) * (size_t)b * (m + 1), cur_b = sizeof(int) * (size_t)b * m;
-    const size_t ref_b = sizeof(int) * (size_t)b * n3;
+    const size_t wsb = ti_grad_workspace_bytes(b, n, m);
     char *ws = nullptr;
-    hipError_t e = hipMallocAsync((void **)&ws, off_b + cur_b + ref_b, st);
+    hipError_t e = hipMallocAsync((void **)&ws, wsb, st);
     if (e != hipSuccess)
       return fail((int)e, "three_interpolate_grad workspace: %s", hipGetErrorString(e));
-    int *off = (int *)ws, *cursor = (int *)(ws + off_b), *refs = (int *)(ws + off_b + cur_b);
-    if (csr_small_supported(m)) {
-      csr_small_launch(b, n3, m, idx, off, refs, st);
-    } else {
-      (void)hipMemsetAsync(off, 0, off_b, st);
-      hipLaunchKernelGGL(ti_count_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx,
-                         off);
-      hipLaunchKernelGGL(ti_scan_kernel, dim3(b), dim3(256), 0, st, m, off, cursor);
-      hipLaunchKernelGGL(ti_fill_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx,
-                         cursor, refs);
-    }
-    hipLaunchKernelGGL(ti_reduce_kernel, dim3(cdiv(m, 64), cdiv(c, 4 * kTiCpt), b), dim3(256), 0,
-                       st, c, n, m, grad_out, weight, off, refs, grad_points);
+    const int rc = ti_grad_lists(b, c, n, m, grad_out, (long long)c * n, idx, weight, grad_points,
+                                 ws, wsb, st);
     (void)hipFreeAsync(ws, st);
-    return check_launch("three_interpolate_grad(lists)");
+    return rc;
   }
   hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * nout, as_stream(stream));
   if (e != hipSuccess)

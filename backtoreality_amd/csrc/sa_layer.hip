@@ -18,7 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "common.hpp"
+#include "internal.hpp"
 
 namespace btr {
 namespace {
@@ -539,6 +539,17 @@ int btr_sa_layer_backward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, con
                           const float *out, const float *dout, void *saved, float *grads,
                           float *dfeat, float *dxyz, float *dnew_xyz, void *scratch,
                           btr_stream_t stream) {
+  return sa_layer_backward_add(dp, pp, idx, out, dout, saved, grads, dfeat, dxyz, dnew_xyz,
+                               scratch, nullptr, 0, stream);
+}
+
+}  // extern "C"
+
+int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, const int *idx,
+                               const float *out, const float *dout, void *saved, float *grads,
+                               float *dfeat, float *dxyz, float *dnew_xyz, void *scratch,
+                               const float *dfeat_add, long long dfeat_add_bstride,
+                               btr_stream_t stream) {
   BTR_REQUIRE(dp && pp && idx && out && dout && saved && grads && scratch,
               "sa_layer_backward: null pointer");
   const btr_sa_layer_t &d = *dp;
@@ -643,14 +654,16 @@ int btr_sa_layer_backward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, con
                                  d.need_dnew_xyz ? dnew_xyz : nullptr, ws2, sc.scat_bytes, stream));
         }
         if (dfeat_cl)
-          BTR_TRY(btr_pm_out(d.b, d.n, d.c, d.c, dfeat_cl, nullptr, nullptr, 0, dfeat, nullptr,
-                             stream));
+          BTR_TRY(pm_out_add(d.b, d.n, d.c, d.c, dfeat_cl, nullptr, nullptr, 0, dfeat, nullptr,
+                             dfeat_add, dfeat_add_bstride, hmain));
       }
     }
   }
   if (side && last_done >= 0) (void)hipStreamWaitEvent(hmain, side->done[last_done], 0);   // join
   return check_launch("sa_layer_backward");
 }
+
+extern "C" {
 
 // ================================================================== point-wise MLP chains
 namespace {

@@ -18,7 +18,7 @@
 #include <algorithm>
 #include <cmath>
 
-#include "common.hpp"
+#include "internal.hpp"
 
 namespace btr {
 
@@ -1637,7 +1637,9 @@ __global__ __launch_bounds__(256) void pm_out_kernel(int N, int C, int ldy,
                                                      const float *__restrict__ scale,
                                                      const float *__restrict__ shift, int relu,
                                                      float *__restrict__ out_bcn,
-                                                     float *__restrict__ out_cl) {
+                                                     float *__restrict__ out_cl,
+                                                     const float *__restrict__ add = nullptr,
+                                                     long long add_bs = 0) {
   __shared__ float tile[64][65];
   const int bi = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
@@ -1657,7 +1659,11 @@ __global__ __launch_bounds__(256) void pm_out_kernel(int N, int C, int ldy,
 #pragma unroll
   for (int i = 0; i < 16; ++i) {   // write channel c0 + ty + 4i, point n0 + tx (coalesced in n)
     const int c = c0 + ty + 4 * i, n = n0 + tx;
-    if (n < N && c < C) out_bcn[((size_t)bi * C + c) * N + n] = tile[tx][ty + 4 * i];
+    if (n < N && c < C) {
+      float v = tile[tx][ty + 4 * i];
+      if (add) v += add[(size_t)bi * add_bs + (size_t)c * N + n];
+      out_bcn[((size_t)bi * C + c) * N + n] = v;
+    }
   }
 }
 
@@ -1679,6 +1685,17 @@ __global__ __launch_bounds__(256) void pm_rows_kernel(int N, int C, int ldr,
     const int n = n0 + ty + 4 * i, c = c0 + tx;
     if (n < N && c < ldr) rows[((size_t)bi * N + n) * ldr + c] = tile[tx][ty + 4 * i];
   }
+}
+
+// (internal.hpp) pm_out with an operand added to the (B, C, N) output
+int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
+               const float *shift, int relu, float *out_bcn, float *out_cl, const float *add,
+               long long add_bstride, hipStream_t stream) {
+  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(y && out_bcn && (scale == nullptr) == (shift == nullptr), "pm_out: bad arguments");
+  hipLaunchKernelGGL(pm_out_kernel, dim3(cdiv(n, 64), cdiv(c, 64), b), dim3(256), 0, stream, n, c,
+                     ldy, y, scale, shift, relu, out_bcn, out_cl, add, add_bstride);
+  return check_launch("pm_out");
 }
 
 // The compact description bound on this host thread (btr_sac_bind); read by the launchers.
@@ -2256,11 +2273,8 @@ int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
 int btr_pm_out(int b, int n, int c, int ldy, const float *y, const float *scale,
                const float *shift, int relu, float *out_bcn, float *out_cl,
                btr_stream_t stream) {
-  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
-  BTR_REQUIRE(y && out_bcn && (scale == nullptr) == (shift == nullptr), "pm_out: bad arguments");
-  hipLaunchKernelGGL(pm_out_kernel, dim3(cdiv(n, 64), cdiv(c, 64), b), dim3(256), 0,
-                     as_stream(stream), n, c, ldy, y, scale, shift, relu, out_bcn, out_cl);
-  return check_launch("pm_out");
+  return pm_out_add(b, n, c, ldy, y, scale, shift, relu, out_bcn, out_cl, nullptr, 0,
+                    as_stream(stream));
 }
 
 // rows (B*N, ldr) = x (B, C, N) transposed, columns C .. ldr zero

@@ -106,6 +106,11 @@ _SIGNATURES = {
     "btr_pm_chain_plan": (_ci, [_vp, _vp]),
     "btr_pm_chain_forward": (_ci, [_vp] * 9),
     "btr_pm_chain_backward": (_ci, [_vp] * 9),
+    # whole-backbone entry points (csrc/backbone.hip): description + plan by address
+    "btr_backbone_plan": (_ci, [_vp, _vp]),
+    "btr_backbone_sampling": (_ci, [_vp] * 6),
+    "btr_backbone_forward": (_ci, [_vp] * 7 + [_ci, _vp]),
+    "btr_backbone_backward": (_ci, [_vp] * 10),
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
@@ -208,6 +213,28 @@ class PmPlan(ctypes.Structure):
                 ("w2", _sz8), ("wt", _sz8), ("stats", _sz8), ("saved_bytes", _sz),
                 ("fwd_scratch_bytes", _sz), ("bwd_scratch_bytes", _sz), ("dw", _sz8),
                 ("dbias", _sz8), ("dgamma", _sz8), ("dbeta", _sz8), ("grads_floats", _sz)]
+
+
+MAX_LEVELS = 4   # BTR_MAX_LEVELS
+_sz4, _ci4, _cf4 = _sz * 4, _ci * 4, _cf * 4
+
+
+class Backbone(ctypes.Structure):
+    """btr_backbone_t: L set-abstraction levels + F feature-propagation modules."""
+    _fields_ = [("b", _ci), ("n", _ci), ("c", _ci), ("levels", _ci), ("fps", _ci),
+                ("radius", _cf4), ("sa", SaLayer * 4), ("fp", PmChain * 4)]
+
+
+class BackbonePlan(ctypes.Structure):
+    _fields_ = [("sa", SaPlan * 4), ("fp", PmPlan * 4), ("g_xyz", _sz), ("g_feat", _sz),
+                ("g_inds", _sz4), ("g_new_xyz", _sz4), ("g_idx", _sz4), ("g_fps_ws", _sz4),
+                ("g_fps_ws_bytes", _sz4), ("g_fps_temp", _sz4), ("bq_buckets", _ci4),
+                ("g_nn_idx", _sz4), ("g_nn_w", _sz4), ("g_ws", _sz), ("g_ws_bytes", _sz),
+                ("geom_bytes", _sz), ("o_sa", _sz4), ("o_sa_cl", _sz4), ("o_fp", _sz4),
+                ("o_fp_cl", _sz4), ("out_bytes", _sz), ("s_sa", _sz4), ("s_fp", _sz4),
+                ("s_fpx", _sz4), ("saved_bytes", _sz), ("fwd_scratch_bytes", _sz),
+                ("bwd_scratch_bytes", _sz), ("gr_sa", _sz4), ("gr_fp", _sz4),
+                ("grads_floats", _sz)]
 
 
 class compact_bound(object):

@@ -4,13 +4,19 @@ layers with the hyper-parameters hard-coded in the reference
 (`sa1..sa4`, `fp1`, `fp2`), so the state-dict keys are `backbone_net.sa1.mlp_module.layer0...`.
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
 
-from ..pointnet2 import pointnet2_utils
+from ..pointnet2 import fused_backbone, pointnet2_utils
 from ..pointnet2.pointnet2_modules import (PointnetFPModule, PointnetSAModuleCenters,
                                            PointnetSAModuleVotes)
+
+# backbone module -> {input shape: fused_backbone.Entry}; weak, so that modules stay picklable /
+# deep-copyable (an Entry holds ctypes structures with pointers)
+_NATIVE_ENTRIES = weakref.WeakKeyDictionary()
+_SIDE_STREAMS = weakref.WeakKeyDictionary()   # backbone module -> {(name, device): stream}
 
 # (npoint, radius, nsample, mlp-after-input) per SA layer -- backbone_module.py:35-69
 SA_SPECS = (
@@ -61,15 +67,48 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
+    # ------------------------------------------------------------ whole-backbone library calls
+    def _sa_fp(self):
+        return ([self.sa1, self.sa2, self.sa3, self.sa4], [self.fp1, self.fp2])
+
+    def _native_entry(self, pointcloud):
+        """Description + plan of the whole-backbone calls (pointnet2/fused_backbone.py) for this
+        input shape, or None when the configuration is not covered (then: layer by layer)."""
+        sa, fp = self._sa_fp()
+        if not fused_backbone.supported(sa, fp, pointcloud):
+            return None
+        cache = _NATIVE_ENTRIES.get(self)
+        if cache is None:
+            cache = _NATIVE_ENTRIES[self] = {}
+        key = (tuple(pointcloud.shape), pointcloud.device, fused_backbone.fused_sa._sa_options(),
+               fused_backbone._ext.fmad())
+        ent = cache.get(key)
+        if ent is None:
+            B, N, W = pointcloud.shape
+            ent = cache[key] = fused_backbone.Entry(sa, fp, B, N, W - 3)
+        return ent
+
     def prefetch_sampling(self, pointcloud):
         """Start the sampling pyramid of `pointcloud` on the side stream NOW and return a
         handle to pass to forward(..., sampling=handle).  Sampling depends on coordinates
         only, so a caller that runs several forwards per step (the Back-to-Reality step runs a
         source and a target branch, train_Votenet_BR.py:277-278) can overlap the second
         branch's FPS with the first branch's forward.  Same indices as computing them inline."""
-        xyz, _ = self._break_up_pc(pointcloud)
-        if not xyz.is_cuda or os.environ.get("BTR_OVERLAP_FPS", "1") == "0":
+        if not pointcloud.is_cuda or os.environ.get("BTR_OVERLAP_FPS", "1") == "0":
             return None
+        entry = self._native_entry(pointcloud)
+        if entry is not None:   # one library call for the whole pyramid
+            main = torch.cuda.current_stream(pointcloud.device)
+            side = self._get_side_stream(pointcloud.device, "_prefetch_stream")
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                handle = fused_backbone.sample(entry, pointcloud)
+                handle.event = torch.cuda.Event()
+                handle.event.record(side)
+            handle.geom.record_stream(main)
+            pointcloud.record_stream(side)
+            return handle
+        xyz, _ = self._break_up_pc(pointcloud)
         main = torch.cuda.current_stream(xyz.device)
         # its own stream: on the stream forward() uses for levels 2-4 the prefetched pyramid
         # would queue in front of them and stall the forward it is supposed to hide under
@@ -77,7 +116,10 @@ class Pointnet2Backbone(nn.Module):
         side.wait_stream(main)
         npoints = [getattr(self, "sa%d" % i).npoint for i in (1, 2, 3, 4)]
         out = []
-        geometry = os.environ.get("BTR_PREFETCH_GEOMETRY", "1") != "0"
+        # (the geometry extras ride on tensor attributes; a captured step only carries the index
+        # tensors through its static buffers, so under capture they would be computed twice)
+        geometry = (os.environ.get("BTR_PREFETCH_GEOMETRY", "1") != "0" and
+                    not torch.cuda.is_current_stream_capturing())
         with torch.cuda.stream(side):
             cur = xyz
             centres = []
@@ -117,9 +159,15 @@ class Pointnet2Backbone(nn.Module):
         return out
 
     def _get_side_stream(self, device, name="_side_stream"):
-        if getattr(self, name, None) is None or getattr(self, name).device != device:
-            setattr(self, name, torch.cuda.Stream(device=device))
-        return getattr(self, name)
+        # (kept outside the module's attributes: a HIP stream can be neither pickled nor
+        # deep-copied, a module that has run once must still be)
+        streams = _SIDE_STREAMS.get(self)
+        if streams is None:
+            streams = _SIDE_STREAMS[self] = {}
+        key = (name, device)
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]
 
     def _fps_pyramid(self, xyz):
         """Sampling indices of all four SA levels.  They depend on coordinates only, so levels
@@ -155,6 +203,11 @@ class Pointnet2Backbone(nn.Module):
         center_xyz (B,64,3) / center_cls (B,64) i64 (center_refine backbones only): adds
         'center_features' (B, 128 + num_class, 64) (backbone_module.py:257-260)."""
         end_points = end_points if end_points else {}
+        if sampling is None or isinstance(sampling, fused_backbone.Sampling):
+            entry = self._native_entry(pointcloud)
+            if entry is not None:
+                return self._forward_native(entry, pointcloud, end_points, sampling, center_xyz,
+                                            center_cls)
         xyz, features = self._break_up_pc(pointcloud)
         # the coordinate slice is shared between a prefetch and the ONE forward that consumes it,
         # never across steps: a later step on the same resident tensor cuts it again
@@ -181,6 +234,45 @@ class Pointnet2Backbone(nn.Module):
         # FPS over an FPS-ordered prefix returns 0..k-1, so the seeds' indices into the input
         # cloud are the first num_seed entries of sa1_inds (backbone_module.py:113-132)
         end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:num_seed]
+        return self._center_head(end_points, features, center_xyz, center_cls)
+
+    def _forward_native(self, entry, pointcloud, end_points, sampling, center_xyz, center_cls):
+        """forward() through btr_backbone_sampling / _forward (one autograd node)."""
+        dev = pointcloud.device
+        if hasattr(pointcloud, "_btr_xyz"):
+            del pointcloud._btr_xyz
+        if sampling is not None and not sampling.valid_for(entry, pointcloud):
+            # computed for another tensor / shape, or the cloud was written to since: the indices
+            # would describe other coordinates
+            raise RuntimeError("sampling handle does not belong to this point cloud (another "
+                               "tensor, another shape, or modified in place since "
+                               "prefetch_sampling)")
+        if sampling is None:
+            # levels 2.. and the 3-NN weights on the side stream, under SA1's MLP
+            side = None
+            if os.environ.get("BTR_OVERLAP_FPS", "1") != "0":
+                side = self._get_side_stream(dev)
+            sampling = fused_backbone.sample(entry, pointcloud, side=side)
+        elif sampling.event is not None:
+            torch.cuda.current_stream(dev).wait_event(sampling.event)
+        outs = fused_backbone.FusedBackboneFn.apply(pointcloud, sampling, entry, *entry.params)
+        twins, entry.last_twins = entry.last_twins, None
+        for o, t in zip(outs, twins):
+            o._btr_channel_last = t
+        L = len(sampling.inds)
+        for i in range(L):
+            if i < 2:
+                end_points["sa%d_inds" % (i + 1)] = sampling.inds[i]
+            end_points["sa%d_xyz" % (i + 1)] = sampling.xyz[i]
+            end_points["sa%d_features" % (i + 1)] = outs[i]
+        features = outs[-1]
+        end_points["fp2_features"] = features
+        end_points["fp2_xyz"] = end_points["sa2_xyz"]
+        num_seed = end_points["fp2_xyz"].shape[1]
+        end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:num_seed]
+        return self._center_head(end_points, features, center_xyz, center_cls)
+
+    def _center_head(self, end_points, features, center_xyz, center_cls):
         if center_xyz is not None:
             center_features = self.ctjt_head(end_points["sa2_xyz"], features,
                                              center_xyz.contiguous())

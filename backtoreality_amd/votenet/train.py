@@ -294,7 +294,8 @@ class GraphedPipelinedStep(object):
             loss, end = train_step(net, optimizer, self.cur, cfg,
                                    sampling=[(t, None) for t in self.p_in],
                                    next_batch={'point_clouds': self.nxt_pc}, criterion=criterion)
-            torch.cuda.current_stream().wait_stream(bb._prefetch_stream)   # join the side stream
+            torch.cuda.current_stream().wait_stream(
+                bb._get_side_stream(self.cur['point_clouds'].device, "_prefetch_stream"))   # join the side stream
             for dst, (inds, _) in zip(self.p_out, end['next_sampling']):
                 dst.copy_(inds)
             return loss

@@ -516,6 +516,71 @@ int btr_pm_chain_backward(const btr_pm_chain_t *d, const btr_pm_plan_t *plan, co
                           const float *dout, void *saved, float *grads, float *dx,
                           void *scratch, btr_stream_t stream);
 
+/* ---- whole-backbone entry points (csrc/backbone.hip) ------------------------------------------
+ * reference: Pointnet2Backbone.forward (models/backbone_module.py:83-133): L set-abstraction
+ * levels (PointnetSAModuleVotes, pointnet2_modules.py:210-272) and F < L feature-propagation
+ * modules (PointnetFPModule, :469-514), and the autograd backward of that graph.  Module j
+ * (0-based) interpolates the features living on level L - j (SA_L's output for j = 0, module
+ * j-1's output otherwise) onto the points of level L - j - 1 and concatenates that level's SA
+ * output (the skip connection) in front of its SharedMLP.
+ * Five caller-provided arenas, laid out by btr_backbone_plan (byte offsets in the plan):
+ *   geom     what depends on coordinates only: per level the FPS indices (b, m) i32, the
+ *            sampled coordinates (b, m, 3), the ball-query lists (b, m, s) i32; per module
+ *            the 3-NN indices / blend weights (b, n, 3); the (b, n, 3) / (b, n, c) split of the
+ *            cloud when it carries features; scratch of the index kernels
+ *   out      per level and module the output as (b, c, m) and channel-last (b, m, c)
+ *   saved    what the backward reads (per layer as btr_sa_layer_* / btr_pm_chain_* lay it out)
+ *   scratch  forward / backward scratch (plan->fwd_scratch_bytes / bwd_scratch_bytes)
+ *   grads    ONE flat f32 buffer: the layers' gradient blocks back to back (plan->gr_sa / gr_fp
+ *            give each layer's first float; inside a block the layer plan's dw/dgamma/dbeta)
+ * btr_backbone_sampling fills `geom` from the cloud (b, n, 3 + c).  It may run on any stream,
+ * e.g. a whole step ahead of the forward that consumes it (the caller orders the two).
+ * `side` != NULL and != stream: level 1 runs on `stream`, the deeper levels and the 3-NN weights
+ * on `side` (forked behind level 1), and btr_backbone_forward(..., wait_side = 1, ...) CALLED
+ * NEXT ON THE SAME HOST THREAD waits for each of them right before the layer that needs it --
+ * SA1's MLP then overlaps the remaining FPS levels.
+ * btr_backbone_backward: dout_sa[l] (b, c_l, m_l) / dout_fp[j] (b, c, n) are the gradients of
+ * the corresponding outputs, NULL entries (or NULL arrays) = no gradient. */
+#define BTR_MAX_LEVELS 4
+typedef struct {
+  int b, n, c;                         /* the cloud: (b, n, 3 + c) f32                          */
+  int levels, fps;                     /* L set-abstraction levels, F < L propagation modules   */
+  float radius[BTR_MAX_LEVELS];        /* ball-query radius per level                           */
+  btr_sa_layer_t sa[BTR_MAX_LEVELS];   /* sa[l].n / .c continue level l's m / last width        */
+  btr_pm_chain_t fp[BTR_MAX_LEVELS];   /* fp[j].n = points of level L-j-1, .c = c_known + c_skip */
+} btr_backbone_t;
+
+typedef struct {
+  btr_sa_plan_t sa[BTR_MAX_LEVELS];
+  btr_pm_plan_t fp[BTR_MAX_LEVELS];
+  /* geometry arena */
+  size_t g_xyz, g_feat;
+  size_t g_inds[BTR_MAX_LEVELS], g_new_xyz[BTR_MAX_LEVELS], g_idx[BTR_MAX_LEVELS];
+  size_t g_fps_ws[BTR_MAX_LEVELS], g_fps_ws_bytes[BTR_MAX_LEVELS], g_fps_temp[BTR_MAX_LEVELS];
+  int bq_buckets[BTR_MAX_LEVELS];      /* ball query over the FPS's spatial sort                */
+  size_t g_nn_idx[BTR_MAX_LEVELS], g_nn_w[BTR_MAX_LEVELS];
+  size_t g_ws, g_ws_bytes, geom_bytes;
+  /* output arena */
+  size_t o_sa[BTR_MAX_LEVELS], o_sa_cl[BTR_MAX_LEVELS], o_fp[BTR_MAX_LEVELS],
+      o_fp_cl[BTR_MAX_LEVELS], out_bytes;
+  /* saved arena: per layer its own `saved` block; s_fpx = the modules' input rows */
+  size_t s_sa[BTR_MAX_LEVELS], s_fp[BTR_MAX_LEVELS], s_fpx[BTR_MAX_LEVELS], saved_bytes;
+  size_t fwd_scratch_bytes, bwd_scratch_bytes;
+  size_t gr_sa[BTR_MAX_LEVELS], gr_fp[BTR_MAX_LEVELS], grads_floats;
+} btr_backbone_plan_t;
+
+int btr_backbone_plan(const btr_backbone_t *d, btr_backbone_plan_t *plan);
+int btr_backbone_sampling(const btr_backbone_t *d, const btr_backbone_plan_t *plan,
+                          const float *cloud, void *geom, btr_stream_t stream,
+                          btr_stream_t side);
+int btr_backbone_forward(const btr_backbone_t *d, const btr_backbone_plan_t *plan,
+                         const float *cloud, const void *geom, void *out, void *saved,
+                         void *scratch, int wait_side, btr_stream_t stream);
+int btr_backbone_backward(const btr_backbone_t *d, const btr_backbone_plan_t *plan,
+                          const void *geom, const void *out, const float *const *dout_sa,
+                          const float *const *dout_fp, void *saved, float *grads, void *scratch,
+                          btr_stream_t stream);
+
 /* ---- vote assembly (models/voting_module.py:57-64, vote_factor 1) -----------------------------
  * from the generator's last layer on channel-last rows net_cl (b*n, ld_net >= 3 + c):
  * vote_xyz (b, n, 3) = seed_xyz + net[..., 0:3]; vote features = seed features + net[..., 3:],

@@ -228,7 +228,10 @@ def test_graphed_pipelined_step_replays_the_eager_loop(cuda):
         return losses
 
     le, lg = eager(), graphed()
-    assert le[0] == lg[0], (le, lg)
+    # (the eager loop runs the backbone through the whole-backbone library calls, whose
+    # feature-propagation MLPs are always the fused kernels; the captured step goes layer by
+    # layer and leaves the 1 024-row fp1 chain of this small batch to the stock ops)
+    np.testing.assert_allclose(lg[0], le[0], rtol=1e-5)
     # from the third step on even two eager runs drift apart by percents (f32 atomics in the
     # nine-op backward, then the vote FPS picks other proposals: tools/diag_nondeterminism.py)
     np.testing.assert_allclose(lg[1], le[1], rtol=1e-3)
