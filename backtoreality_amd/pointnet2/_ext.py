@@ -255,6 +255,12 @@ class compact_bound(object):
         return False
 
 
+if __package__:
+    from ._twin import attach_derived, attach_twin, derived, twin_of  # noqa: E402,F401
+else:
+    from _twin import attach_derived, attach_twin, derived, twin_of  # noqa: E402,F401
+
+
 # ------------------------------------------------------------------------------------ checks
 def _require(cond, msg):
     if not cond:

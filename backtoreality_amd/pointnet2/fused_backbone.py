@@ -16,6 +16,7 @@ Python per 4.5 ms of GPU work (profiles/r02_h_bench_steps20.json: host_enqueue 5
 """
 import ctypes
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -146,40 +147,68 @@ class Entry(object):
                 f.momentum[i] = _momentum(bn)
 
 
+_STATIC_OK = weakref.WeakKeyDictionary()   # first SA module -> {training flags: bool}
+
+
+def _bns(sa_modules, fp_modules):
+    for m in sa_modules:
+        for layer in m.mlp_module:
+            yield layer.bn.bn
+    for m in fp_modules:
+        for layer in m.mlp:
+            yield layer.bn.bn
+
+
+def _static_ok(sa_modules, fp_modules, probe):
+    """The part of supported() that only depends on the modules: evaluated once per
+    combination of training flags (it walks every layer: ~0.2 ms per call otherwise)."""
+    import torch.nn as nn
+    if not 1 <= len(sa_modules) <= _ext.MAX_LEVELS or len(fp_modules) >= len(sa_modules):
+        return False
+    try:
+        key = tuple(m.training for m in sa_modules) + \
+            tuple(bn.training for bn in _bns(sa_modules, fp_modules))
+    except AttributeError:   # a layer without conv / bn children: not a covered configuration
+        return False
+    cache = _STATIC_OK.get(sa_modules[0])
+    if cache is None:
+        cache = _STATIC_OK[sa_modules[0]] = {}
+    ok = cache.get(key)
+    if ok is not None:
+        return ok
+    ok = True
+    for l, m in enumerate(sa_modules):
+        if not m.training or m.npoint is None or getattr(m, "ret_unique_cnt", False) or \
+                not fused_sa.can_fuse(m, probe, None) or len(m.mlp_module) > _ext.MAX_LAYERS or \
+                any(layer.conv.weight.shape[0] % 4 for layer in m.mlp_module):
+            ok = False
+    for m in fp_modules:
+        chain = fused_mlp.shared_mlp_chain(m.mlp)
+        if chain is None or len(chain) > _ext.MAX_LAYERS:
+            ok = False
+            continue
+        for conv, bn, _ in chain:
+            if not isinstance(bn, (nn.BatchNorm1d, nn.BatchNorm2d)) or bn.weight is None or \
+                    not bn.training or conv.out_channels % 4 or conv.out_channels > 512 or \
+                    conv.kernel_size not in ((1,), (1, 1)) or conv.groups != 1:
+                ok = False
+    cache[key] = ok
+    return ok
+
+
 def supported(sa_modules, fp_modules, pointcloud):
     """True when every layer is in the configuration the fused kernels cover (training mode,
     ball-query grouping + max-pool, conv -> BatchNorm -> ReLU MLPs) and the cloud is a
     contiguous CUDA f32 tensor that needs no gradient."""
-    import torch.nn as nn
     pc = pointcloud
     if not (enabled() and pc.is_cuda and pc.dtype == torch.float32 and pc.dim() == 3 and
             pc.is_contiguous() and pc.size(-1) >= 3 and not pc.requires_grad):
         return False
     if not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
         return False
-    if not 1 <= len(sa_modules) <= _ext.MAX_LEVELS or len(fp_modules) >= len(sa_modules):
+    if not sa_modules[0].grouper.use_xyz and pc.size(-1) == 3:
         return False
-    probe = pc[:, :1, :3]
-    for l, m in enumerate(sa_modules):
-        if not m.training or m.npoint is None or getattr(m, "ret_unique_cnt", False):
-            return False
-        if not fused_sa.can_fuse(m, probe, None) or len(m.mlp_module) > _ext.MAX_LAYERS:
-            return False
-        if not m.grouper.use_xyz and l == 0 and pc.size(-1) == 3:
-            return False
-        for layer in m.mlp_module:
-            if layer.conv.weight.shape[0] % 4:
-                return False
-    for m in fp_modules:
-        chain = fused_mlp.shared_mlp_chain(m.mlp)
-        if chain is None or len(chain) > _ext.MAX_LAYERS:
-            return False
-        for conv, bn, _ in chain:
-            if not isinstance(bn, (nn.BatchNorm1d, nn.BatchNorm2d)) or bn.weight is None or \
-                    not bn.training or conv.out_channels % 4 or conv.out_channels > 512 or \
-                    conv.kernel_size not in ((1,), (1, 1)) or conv.groups != 1:
-                return False
-    return True
+    return _static_ok(sa_modules, fp_modules, pc[:, :1, :3])
 
 
 class Sampling(object):
@@ -198,6 +227,20 @@ class Sampling(object):
             self.inds.append(geom.as_strided((B, m), (m, 1), p.g_inds[l] // 4))
             self.xyz.append(geom.as_strided((B, m, 3), (3 * m, 3, 1),
                                             p.g_new_xyz[l] // 4).view(torch.float32))
+
+    def idx(self, level):
+        """Ball-query lists (B, m, nsample) i32 of SA level `level` (0-based)."""
+        s = self.entry.d.sa[level]
+        return self.geom.as_strided((self.entry.B, s.m, s.s), (s.m * s.s, s.s, 1),
+                                    self.entry.plan.g_idx[level] // 4)
+
+    def three_nn(self, module):
+        """(idx (B, n, 3) i32, weight (B, n, 3) f32) of feature-propagation module `module`."""
+        n = self.entry.d.fp[module].n
+        shape, stride = (self.entry.B, n, 3), (3 * n, 3, 1)
+        p = self.entry.plan
+        return (self.geom.as_strided(shape, stride, p.g_nn_idx[module] // 4),
+                self.geom.as_strided(shape, stride, p.g_nn_w[module] // 4).view(torch.float32))
 
     def valid_for(self, entry, pointcloud):
         return (self.entry is entry and self.cloud is pointcloud and

@@ -56,7 +56,7 @@ class PointwiseMLP(Function):
         assert K0 % 4 == 0, "input width must be a multiple of 4"
         with _on(x) as d:
             st = _stream(d)
-            A = getattr(x, "_btr_channel_last", None)
+            A = _ext.twin_of(x)
             if A is None or A.shape != (rows, K0):
                 A = _f32((rows, K0), dev)
                 _call(_lib.btr_pm_rows, B, N, K0, K0, _p(x.contiguous()), _p(A), st)
@@ -121,7 +121,7 @@ class PointwiseMLP(Function):
                   1 if last else 0, _p(out), _p(out_cl), st)
             if counters:
                 torch._foreach_add_(counters, 1)
-        out._btr_channel_last = out_cl
+        _ext.attach_twin(out, out_cl)
         ctx.dims = (B, N, K0, L)
         ctx.widths = widths
         ctx.pshapes = [None if p is None else p.shape for p in params]
@@ -263,7 +263,7 @@ class PointwiseChain(Function):
             if bn is not None:
                 d.momentum[l] = float(bn.momentum) if bn.momentum is not None else \
                     1.0 / float(bn.num_batches_tracked.item() + 1)
-        x_cl = getattr(x, "_btr_channel_last", None)
+        x_cl = _ext.twin_of(x)
         if x_cl is not None and (x_cl.shape != (rows, K0) or not x_cl.is_contiguous() or K0 % 4):
             x_cl = None
         xb = x.contiguous() if x_cl is None else None
@@ -275,7 +275,7 @@ class PointwiseChain(Function):
         with _on(x) as dv:
             _call(_lib.btr_pm_chain_forward, ctypes.addressof(d), ctypes.addressof(plan), _p(xb),
                   _p(x_cl), _p(out), _p(out_cl), _p(saved), _p(scratch), _stream(dv))
-        out._btr_channel_last = out_cl
+        _ext.attach_twin(out, out_cl)
         ctx.plan = ent
         ctx.has_x_cl = x_cl is not None
         ctx.pshapes = [None if p is None else p.shape for p in params]

@@ -59,7 +59,7 @@ class FusedSAFunction(Function):
         new_xyz = new_xyz.contiguous()
         feats_cl = None
         if C:
-            feats_cl = getattr(features, "_btr_channel_last", None)
+            feats_cl = _ext.twin_of(features)
             if os.environ.get("BTR_SA_CL_SHORTCUT", "1") == "0":
                 feats_cl = None
             if feats_cl is None or feats_cl.shape != (B, N, C):
@@ -182,7 +182,7 @@ class FusedSAFunction(Function):
             if counters:  # one launch for the layer's num_batches_tracked += 1
                 torch._foreach_add_(counters, 1)
 
-        out._btr_channel_last = out_cl  # lets the next fused layer skip a transpose
+        _ext.attach_twin(out, out_cl)  # lets the next fused layer skip a transpose
         ctx.dims = (B, N, M, S, C, use_xyz, rdiv, K0, K0p, L)
         ctx.rc = rc
         ctx.compact = compact
@@ -374,7 +374,7 @@ class FusedSALayer(Function):
         new_xyz = new_xyz.contiguous()
         feats_cl = None
         if C:
-            feats_cl = getattr(features, "_btr_channel_last", None)
+            feats_cl = _ext.twin_of(features)
             if os.environ.get("BTR_SA_CL_SHORTCUT", "1") == "0":
                 feats_cl = None
             if feats_cl is None or feats_cl.shape != (B, N, C):
@@ -421,7 +421,7 @@ class FusedSALayer(Function):
             _call(_lib.btr_sa_layer_forward, ctypes.addressof(d), ctypes.addressof(plan),
                   _p(xyz), _p(new_xyz), _p(feats_cl), _p(idx), _p(out), _p(out_cl), _p(saved),
                   _p(scratch), _stream(dv))
-        out._btr_channel_last = out_cl
+        _ext.attach_twin(out, out_cl)
         ctx.plan = ent
         ctx.dims = (B, N, M, C)
         ctx.pshapes = [p.shape for p in params]
@@ -475,7 +475,7 @@ def fused_eval_forward(module, xyz, new_xyz, features, idx):
     new_xyz = new_xyz.contiguous()
     feats_cl = None
     if C:
-        feats_cl = getattr(features, "_btr_channel_last", None)
+        feats_cl = _ext.twin_of(features)
         if feats_cl is None or feats_cl.shape != (B, N, C):
             feats_cl = features.transpose(1, 2).contiguous()
     with _on(xyz) as d:
@@ -506,7 +506,7 @@ def fused_eval_forward(module, xyz, new_xyz, features, idx):
         arg = torch.empty((B * M, CL), dtype=torch.uint8, device=dev)
         _call(_lib.btr_sa_pool, B, M, S, CL, CL, _p(A), _p(pa.contiguous()), _p(pb.contiguous()),
               _p(out), _p(out_cl), _p(arg), st)
-    out._btr_channel_last = out_cl
+    _ext.attach_twin(out, out_cl)
     return out
 
 
@@ -567,7 +567,8 @@ def can_fuse(module, xyz, features):
 def fused_group_mlp_max(module, xyz, new_xyz, features):
     """Drop-in for grouper + mlp_module + max-pool of a _SingleScaleSA module."""
     g = module.grouper
-    pre = getattr(new_xyz, "_btr_ball_query", None)   # computed with the prefetched pyramid
+    # (computed with the prefetched pyramid; void once xyz / new_xyz were written to in place)
+    pre = _ext.derived(new_xyz, "_btr_ball_query", xyz)
     if pre is not None and pre[1] is xyz and pre[2] == g.radius and pre[3] == g.nsample:
         idx = pre[0]
     else:

@@ -17,6 +17,7 @@ if __package__:
     from . import pytorch_utils as pt_utils
     from . import fused_sa
     from . import fused_mlp
+    from . import _twin
 else:
     import os
     import sys
@@ -25,6 +26,7 @@ else:
     import pytorch_utils as pt_utils
     import fused_sa
     import fused_mlp
+    import _twin
 
 
 def _sample_centres(xyz, npoint, inds=None):
@@ -34,7 +36,8 @@ def _sample_centres(xyz, npoint, inds=None):
         return None, inds
     if inds is None:
         inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
-    pre = getattr(inds, "_btr_new_xyz", None)   # gathered by whoever sampled (prefetched pyramid)
+    # gathered by whoever sampled (prefetched pyramid); void once inds / xyz were modified
+    pre = _twin.derived(inds, "_btr_new_xyz", xyz)
     if pre is not None and pre[1] is xyz and pre[0].shape == (xyz.shape[0], inds.shape[1], 3):
         return pre[0], inds
     return pointnet2_utils.gather_rows(xyz, inds), inds
@@ -235,7 +238,8 @@ class PointnetFPModule(nn.Module):
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
                 known_feats: torch.Tensor) -> torch.Tensor:
         if known is not None:
-            pre = getattr(unknown, "_btr_three_nn", None)   # computed with a prefetched pyramid
+            # computed with a prefetched pyramid; void once unknown / known were modified
+            pre = _twin.derived(unknown, "_btr_three_nn", known)
             if pre is not None and pre[0] is known:
                 idx, weight = pre[1], pre[2]
             elif unknown.is_cuda and hasattr(pointnet2_utils._ext, "three_nn_weights"):

@@ -9,7 +9,7 @@ import weakref
 import torch
 import torch.nn as nn
 
-from ..pointnet2 import fused_backbone, pointnet2_utils
+from ..pointnet2 import _ext, fused_backbone, pointnet2_utils
 from ..pointnet2.pointnet2_modules import (PointnetFPModule, PointnetSAModuleCenters,
                                            PointnetSAModuleVotes)
 
@@ -131,14 +131,15 @@ class Pointnet2Backbone(nn.Module):
                 # them again on the main stream (pointnet2_modules._sample_centres)
                 new_xyz = pointnet2_utils.gather_rows(cur, inds)
                 new_xyz.record_stream(main)
-                inds._btr_new_xyz = (new_xyz, cur)
+                _ext.attach_derived(inds, "_btr_new_xyz", (new_xyz, cur), cur)
                 if geometry:
                     # everything else that depends on coordinates only goes the same way: the
                     # layer's ball query ...
                     g = getattr(self, "sa%d" % (li + 1)).grouper
                     idx = pointnet2_utils.ball_query(g.radius, g.nsample, cur, new_xyz)
                     idx.record_stream(main)
-                    new_xyz._btr_ball_query = (idx, cur, g.radius, g.nsample)
+                    _ext.attach_derived(new_xyz, "_btr_ball_query",
+                                        (idx, cur, g.radius, g.nsample), cur)
                 centres.append(new_xyz)
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -151,7 +152,8 @@ class Pointnet2Backbone(nn.Module):
                     idx, weight = pointnet2_utils.three_nn_weights(unknown, known)
                     idx.record_stream(main)
                     weight.record_stream(main)
-                    unknown._btr_three_nn = (known, idx, weight)
+                    _ext.attach_derived(unknown, "_btr_three_nn", (known, idx, weight),
+                                        known)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 out[-1] = (out[-1][0], ev)   # (the last level's event also covers these)
@@ -258,7 +260,7 @@ class Pointnet2Backbone(nn.Module):
         outs = fused_backbone.FusedBackboneFn.apply(pointcloud, sampling, entry, *entry.params)
         twins, entry.last_twins = entry.last_twins, None
         for o, t in zip(outs, twins):
-            o._btr_channel_last = t
+            _ext.attach_twin(o, t)
         L = len(sampling.inds)
         for i in range(L):
             if i < 2:

@@ -18,8 +18,8 @@ class _VoteAssemble(Function):
     @staticmethod
     def forward(ctx, net, seed_xyz, seed_features, normalize):
         B, C, N = seed_features.shape
-        net_cl = net._btr_channel_last                       # (B*N, 3 + C)
-        seed_cl = getattr(seed_features, "_btr_channel_last", None)
+        net_cl = _ext.twin_of(net)                           # (B*N, 3 + C)
+        seed_cl = _ext.twin_of(seed_features)
         if seed_cl is None or seed_cl.shape != (B * N, C) or not seed_cl.is_contiguous():
             seed_cl = seed_features.transpose(1, 2).contiguous().view(B * N, C)
         dev = net.device
@@ -31,7 +31,7 @@ class _VoteAssemble(Function):
             _ext._call(_ext._lib.btr_vote_assemble, B, N, C, _ext._p(net_cl), net_cl.shape[1],
                        _ext._p(seed_xyz.contiguous()), _ext._p(seed_cl), _ext._p(vote_xyz),
                        _ext._p(feat), _ext._p(feat_cl), _ext._p(nrm), _ext._stream(d))
-        feat._btr_channel_last = feat_cl.view(B, N, C)      # what the vote aggregation gathers
+        _ext.attach_twin(feat, feat_cl.view(B, N, C))       # what the vote aggregation gathers
         ctx.dims = (B, C, N)
         if normalize:
             ctx.save_for_backward(feat_cl, nrm)
@@ -79,7 +79,7 @@ class VotingModule(nn.Module):
             net = F.relu(self.bn2(self.conv2(net)))
             net = self.conv3(net)
         if (self.vote_factor == 1 and net.is_cuda and seed_xyz.dtype == torch.float32 and
-                getattr(net, "_btr_channel_last", None) is not None and
+                _ext.twin_of(net) is not None and
                 os.environ.get("BTR_FUSED_VOTES", "1") != "0" and
                 (not normalize or self.out_dim <= 256)):
             return _VoteAssemble.apply(net, seed_xyz, seed_features, bool(normalize))

@@ -344,8 +344,12 @@ def main():
         barrier()
         sequential = time.perf_counter() - t1
         seq_kernels = _ext.timing_end()
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = [1e3 * float(x.item()) / args.steps for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -385,6 +389,9 @@ def main():
                                    ((B, args.points) if (br or gf) else (args.points, B)),
                        "points": args.points, "batch_per_gpu": B, "parallelism": "dp%d" % world},
         }
+        if per_rank is not None:   # every rank's own clock over the same K steps
+            out["per_rank_ms_per_step"] = {"min": min(per_rank), "max": max(per_rank),
+                                           "ranks": per_rank}
         if gf:
             out["hip_graph"] = bool(graphed)
         else:

@@ -23,7 +23,8 @@ def _worst_grad_dev(g_f, g_u):
     noise (conv biases in front of a BatchNorm have an exactly-zero true gradient).
     Gradients flow through arg-max / ReLU selections, so two valid f32 implementations may
     differ by more than rounding on individual entries (max-norm deviations of 1e-2 were
-    observed between the fused and the op-by-op path); the bound is 2e-2 in relative L2
+    observed between the fused and the op-by-op path); the bound is 1e-2 in relative L2
+    (measured: 2e-3 .. 5e-3 on inputs without a near-tie element, tools/diag_c5_grads.py)
     while features and losses are held to 1e-4."""
     gmax = max(float(g.abs().max()) for g in g_u.values())
 
@@ -52,8 +53,11 @@ def _votenet_step(cfg, batch, dev, fused, monkeypatch, num_proposal=256, vote_in
 def test_c5_matterport_80k_points(cuda, monkeypatch):
     """C5: 80 000-point scenes (12 x 12 x 3 m), 13 classes / 12 heading bins, batch 4."""
     cfg = config.matterport_md40()
-    B = 2
-    batch = synthetic.make_batch(0, B, 80000, cfg, extent_scale=1.7, device=cuda)
+    B = 4   # BASELINE configs[4]: batch 4 per GPU
+    # (scenes 8..11: scenes 0..3 hold a max-pool element of SA4 within float32 noise of a tie
+    # whose flip moves one row of one weight gradient by 0.3 and everything upstream by 4 %:
+    # tools/diag_c5_grads.py)
+    batch = synthetic.make_batch(8, B, 80000, cfg, extent_scale=1.7, device=cuda)
     # op-by-op path first; the fused path then aggregates around the SAME proposals (the vote
     # FPS samples computed floats, so it may legitimately differ between two f32 paths), which
     # makes the loss and every gradient comparable unconditionally
@@ -73,13 +77,13 @@ def test_c5_matterport_80k_points(cuda, monkeypatch):
     assert _rel(end_f['aggregated_vote_features'], end_u['aggregated_vote_features']) < 2e-4
     assert abs(float(loss_f) - float(loss_u)) / abs(float(loss_u)) < 1e-4
     worst = _worst_grad_dev(g_f, g_u)
-    assert worst < 2e-2, worst
+    assert worst < 1e-2, worst
 
 
 def test_c4_groupfree_backbone_50k_no_features(cuda, monkeypatch):
     """C4: GroupFree3D-style backbone: xyz only (no height channel), 50 000 points, fp2 -> 288
-    channels (detection/GroupFree3D/models/backbone_module.py:33-75)."""
-    B = 2
+    channels (detection/GroupFree3D/models/backbone_module.py:33-75); configs[3]: batch 4."""
+    B = 4
     pc = torch.from_numpy(np.stack([synthetic.make_scene(70 + i, 50000, use_height=False)[
         'point_clouds'] for i in range(B)], 0)).to(cuda)
 
@@ -99,7 +103,7 @@ def test_c4_groupfree_backbone_50k_no_features(cuda, monkeypatch):
     for k in ('sa1_features', 'sa2_features', 'sa4_features', 'fp2_features'):
         assert _rel(end_f[k], end_u[k]) < 1e-4, k
     worst = _worst_grad_dev(g_f, g_u)
-    assert worst < 2e-2, worst
+    assert worst < 1e-2, worst
 
 
 def test_ddp_wrapper_on_the_gpu_path(cuda, monkeypatch):
