@@ -6,6 +6,7 @@ import copy
 import pytest
 import torch
 
+from backtoreality_amd.pointnet2 import _ext
 from backtoreality_amd.pointnet2 import pointnet2_modules as M
 from backtoreality_amd.votenet import config, proposal_module, voting_module
 
@@ -115,7 +116,7 @@ def test_vote_assembly_and_fp_weights_match_the_torch_composition(cuda, monkeypa
             f = feats.clone().requires_grad_(True)
             vx, vf = m(xyz, f, normalize=normalize)
             if flag == "1":
-                assert torch.equal(vf._btr_channel_last, vf.transpose(1, 2))
+                assert torch.equal(_ext.twin_of(vf), vf.transpose(1, 2))
             ((vx * torch.linspace(-1, 1, vx.numel(), device=cuda).view_as(vx)).sum() +
              (vf * torch.linspace(0.5, 1.5, vf.numel(), device=cuda).view_as(vf)).sum()).backward()
             res[flag] = {"vx": vx.detach(), "vf": vf.detach(), "df": f.grad,

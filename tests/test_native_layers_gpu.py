@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from backtoreality_amd.pointnet2 import fused_mlp, fused_sa
+from backtoreality_amd.pointnet2 import _ext
 from backtoreality_amd.pointnet2 import pointnet2_modules as M
 from backtoreality_amd.pointnet2 import pointnet2_utils
 from backtoreality_amd.votenet import config, proposal_module, synthetic, voting_module
@@ -26,7 +27,7 @@ def _sa_run(sa, xyz, feats, inds, xyz_grad, feat_grad=True):
     torch.manual_seed(3)
     w = torch.randn_like(out)
     (out * w).sum().backward()
-    g = {"out": out.detach(), "out_cl": out._btr_channel_last.detach()}
+    g = {"out": out.detach(), "out_cl": _ext.twin_of(out).detach()}
     if feats is not None and feat_grad:
         g["dfeat"] = feats.grad
     if xyz_grad:
