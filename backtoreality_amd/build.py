@@ -75,9 +75,25 @@ def _object_plan():
     return plan
 
 
+def build_id(plan=None):
+    """Digest of every source, header and flag the libraries are built from: what
+    btr_build_id() returns.  profiles/pmc_traffic.json records it, so that bench.py can tell
+    whether the counters it quotes were measured on the kernels it is running."""
+    plan = plan or _object_plan()
+    h = hashlib.sha256()
+    for _, _, obj in plan:
+        h.update(os.path.basename(obj).encode())
+    return h.hexdigest()[:16]
+
+
+def _build_id_object(plan):
+    return os.path.join(OBJ_DIR, "build_id.%s.o" % build_id(plan))
+
+
 def is_fresh():
     plan = _object_plan()
-    if not all(os.path.exists(o) for _, _, o in plan):
+    if not all(os.path.exists(o) for _, _, o in plan) or \
+            not os.path.exists(_build_id_object(plan)):
         return False
     newest = max(os.path.getmtime(o) for _, _, o in plan)
     return all(os.path.exists(lib_path(m)) and os.path.getmtime(lib_path(m)) >= newest
@@ -108,12 +124,20 @@ def build(force=False, verbose=False, jobs=None):
     jobs = jobs or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         list(pool.map(compile_one, todo))
-    keep = {o for _, _, o in plan}
+    bid_obj = _build_id_object(plan)
+    if not os.path.exists(bid_obj):   # (host-only: a second to compile)
+        src = bid_obj[:-2] + ".cpp"
+        with open(src, "w") as fh:
+            fh.write('extern "C" const char *btr_build_id(void) { return "%s"; }\n' % build_id(plan))
+        subprocess.check_call([hipcc, "-O1", "-fPIC", "-c", src, "-o", bid_obj + ".tmp"])
+        os.replace(bid_obj + ".tmp", bid_obj)
+        os.remove(src)
+    keep = {o for _, _, o in plan} | {bid_obj}
     for f in os.listdir(OBJ_DIR):                      # objects of older source versions
         if os.path.join(OBJ_DIR, f) not in keep:
             os.remove(os.path.join(OBJ_DIR, f))
     for mode in LIB_NAMES:
-        objs = [o for _, m, o in plan if m is None or m == mode]
+        objs = [o for _, m, o in plan if m is None or m == mode] + [bid_obj]
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", lib_path(mode)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

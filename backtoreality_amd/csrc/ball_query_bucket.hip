@@ -24,7 +24,7 @@
 #include <algorithm>
 #include <cmath>
 
-#include "common.hpp"
+#include "internal.hpp"
 
 namespace btr {
 
@@ -279,8 +279,16 @@ int btr_ball_query_buckets(int b, int n, int m, float radius, int nsample, const
   if (b <= 0 || m <= 0 || nsample <= 0) return BTR_OK;
   BTR_REQUIRE(idx && new_xyz, "ball_query(buckets): null pointer");
   BTR_REQUIRE(bq_bucket_supported(n, m, nsample), "ball_query(buckets): n=%d not supported", n);
-  return bq_bucket_launch(b, n, m, radius, nsample, new_xyz, fps_workspace, idx, workspace,
-                          workspace_bytes, as_stream(stream));
+  hipEvent_t *ev = bq_call_events();   // (btr_ball_query_time_next)
+  const bool timed = ev[0] != nullptr;
+  if (timed) (void)hipEventRecord(ev[0], as_stream(stream));
+  const int rc = bq_bucket_launch(b, n, m, radius, nsample, new_xyz, fps_workspace, idx,
+                                  workspace, workspace_bytes, as_stream(stream));
+  if (timed) {
+    (void)hipEventRecord(ev[1], as_stream(stream));
+    ev[0] = ev[1] = nullptr;
+  }
+  return rc;
 }
 
 }  // extern "C"

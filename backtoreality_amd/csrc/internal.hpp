@@ -20,6 +20,10 @@ int ti_grad_lists(int b, int c, int n, int m, const float *grad_out, long long g
                   const int *idx, const float *weight, float *grad_points, void *workspace,
                   size_t workspace_bytes, hipStream_t stream);
 
+// ball_query.hip: measurement hook (btr_ball_query_time_next): the event pair the next ball
+// query call of this host thread records around its launches
+hipEvent_t *bq_call_events();
+
 // sa_layer.hip: btr_sa_layer_backward with an operand added to the feature gradient it writes
 // (dfeat (b, c, n) = layer's own gradient + dfeat_add; dfeat_add's batch stride in floats).
 int sa_layer_backward_add(const btr_sa_layer_t *d, const btr_sa_plan_t *plan, const int *idx,

@@ -31,6 +31,7 @@ _sz = ctypes.c_size_t
 # name -> (restype, argtypes); mirrors include/btr_pointnet2.h one to one.
 _SIGNATURES = {
     "btr_abi_version": (_ci, []),
+    "btr_build_id": (ctypes.c_char_p, []),
     "btr_distance_mode": (_ci, []),
     "btr_last_error": (ctypes.c_char_p, []),
     "btr_opt_n_threads": (_ci, [_ci]),
@@ -90,6 +91,7 @@ _SIGNATURES = {
     "btr_pm_out": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "btr_pm_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp]),
     "btr_fps_time_next_kernel": (None, [_vp, _vp]),
+    "btr_ball_query_time_next": (None, [_vp, _vp]),
     "btr_vote_assemble": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "btr_vote_assemble_bwd": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     # fused attention core (groupfree/fused_attention.py)
@@ -649,6 +651,11 @@ def box3d_iou(corners1, corners2):
             _call(_lib.btr_box3d_iou, s1 - s0, P, G, _p(corners1[s0:s1]), _p(corners2[s0:s1]),
                   _p(iou[s0:s1]), _stream(dev))
     return iou
+
+
+def build_id():
+    """Digest of the sources the loaded library was built from (btr_build_id)."""
+    return _lib.btr_build_id().decode()
 
 
 def opt_n_threads(work_size):

@@ -263,6 +263,20 @@ def sample(entry, pointcloud, stream=None, side=None):
     geom = torch.empty((entry.plan.geom_bytes // 4,), dtype=torch.int32, device=dev)
     with _ext._on(pointcloud) as dv:
         cur = stream if stream is not None else torch.cuda.current_stream(dv)
+        if _ext._TIMING is not None:   # bench.py: event pairs around the large-scene FPS kernel
+            s0 = entry.d.sa[0]         # and the first level's ball query, recorded by the library
+            for op, key, hook in (
+                    ("fps_kernel", (entry.B, s0.n, s0.m), entry.lib.btr_fps_time_next_kernel),
+                    ("ball_query_buckets" if entry.plan.bq_buckets[0] else "ball_query",
+                     (entry.B, s0.n, s0.m, s0.s), entry.lib.btr_ball_query_time_next)):
+                if s0.n > 4096 and (_ext._TIMING_FILTER is None or _ext._TIMING_FILTER(op, key)):
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    with torch.cuda.stream(cur):
+                        e0.record()   # (creates the handles; the library records them in place)
+                        e1.record()
+                    hook(e0.cuda_event, e1.cuda_event)
+                    _ext._TIMING.append((op, key, e0, e1))
         _ext._call(entry.lib.btr_backbone_sampling, ctypes.addressof(entry.d),
                    ctypes.addressof(entry.plan), _p(pointcloud), _p(geom), cur.cuda_stream,
                    side.cuda_stream if side is not None else None)

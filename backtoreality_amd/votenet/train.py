@@ -259,6 +259,34 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None, crite
     return loss, end_points
 
 
+def train_one_epoch(net, optimizer, batches, cfg, criterion=None, on_step=None):
+    """The training loop of train_Votenet_FSB.py:211-244 over `batches` (an iterable of batch
+    dicts resident on the model's device), software-pipelined: while step i runs, the sampling
+    pyramid of batch i+1 -- coordinates only, independent of the weights -- is computed on a
+    side stream (train_step(sampling=, next_batch=)); the first batch's pyramid is computed at
+    the head of the loop.  Same results as calling train_step batch by batch.  This is the
+    loop bench.py times.  `on_step(i, loss, end_points)`: the caller's statistics hook (the
+    reference's `.item()` logging, FSB:234-237); nothing here synchronises with the device.
+    Returns the last (loss, end_points)."""
+    it = iter(batches)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return None
+    core = net.module if hasattr(net, "module") else net
+    sampling = core.backbone_net.prefetch_sampling(cur['point_clouds'])
+    out, i = None, 0
+    while cur is not None:
+        nxt = next(it, None)
+        out = train_step(net, optimizer, cur, cfg, sampling=sampling, next_batch=nxt,
+                         criterion=criterion)
+        sampling = out[1].get('next_sampling')
+        if on_step is not None:
+            on_step(i, out[0], out[1])
+        cur, i = nxt, i + 1
+    return out
+
+
 class GraphedPipelinedStep(object):
     """The software-pipelined training step as ONE HIP graph, replayed per step.
 
@@ -275,7 +303,15 @@ class GraphedPipelinedStep(object):
     filled by __call__ before each replay -- what a prefetching loader would fill.  Nothing
     synchronises with the host; shapes are fixed; Adam is `capturable`.  `prime(batch)`
     computes the pyramid of the first batch eagerly (the head of the loop).
-    Single-process only: under FlatGradParallel / DDP the eager pipelined loop is used."""
+    Single-process only: under FlatGradParallel / DDP the eager pipelined loop is used.
+
+    Frozen at capture (a replay runs the kernels with the arguments they were recorded with):
+    python-float hyper-parameters -- the learning rate `adjust_learning_rate` sets and the
+    BatchNorm momentum (a kernel argument of the fused layers): the reference's per-epoch
+    decays (train_Votenet_FSB.py:186-201) need a re-capture (a new object) at each change.
+    Constructing the object runs `warmup` + 1 REAL optimisation steps on `batch` (weights, Adam
+    state and BatchNorm running statistics move): a caller that needs the initial state back
+    must restore it (tests/test_configs_gpu.py does)."""
 
     def __init__(self, net, optimizer, batch, next_batch, cfg, warmup=3, criterion=None):
         assert not hasattr(net, "module"), "graph capture of the data-parallel step: not supported"

@@ -23,6 +23,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+BQ_LAUNCHES = 3         # bucket boxes, super-bucket boxes, query (csrc/ball_query_bucket.hip)
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
 
 
@@ -281,6 +282,9 @@ def main():
                 nxt = batches[(i + 1) % len(batches)] if i + 1 < n else None
                 out = graphed_step(batches[i % len(batches)], nxt)
             return out
+        if not gf:   # the product's own loop (votenet/train.py train_one_epoch)
+            return train.train_one_epoch(ddp, opt, (batches[i % len(batches)] for i in range(n)),
+                                         cfg)
         core = net.module if hasattr(net, "module") else net
         sampling = core.backbone_net.prefetch_sampling(batches[0]['point_clouds'])
         for i in range(n):
@@ -410,7 +414,12 @@ def main():
                        "forward); the first batch's pyramid is computed inside the timed "
                        "region; two distinct batches (batch pairs) alternate"
                        if pipelined_loop else "sequential")
+        # stable keys across rounds: which loop `value` timed, and the strictly sequential
+        # figure (round 1's `value`) always at top level when it was measured
+        out["value_loop"] = "software-pipelined" if pipelined_loop else "sequential"
         if sequential is not None:
+            out["sequential_value"] = world * B * args.steps * (2 if br else 1) / sequential
+            out["sequential_ms_per_step"] = 1e3 * sequential / args.steps
             out["sequential"] = {
                 "value": world * B * args.steps * (2 if br else 1) / sequential,
                 "unit": "scenes/s",
@@ -446,7 +455,13 @@ def pmc_traffic(substr):
     if not os.path.exists(path):
         return None
     with open(path) as fh:
-        ks = json.load(fh)["kernels"]
+        doc = json.load(fh)
+    # counters are only quoted for the kernels they were measured on: the profile records the
+    # digest of the sources it ran (btr_build_id); a library built from anything else -> null
+    from backtoreality_amd.pointnet2 import _ext
+    if doc.get("build_id") != _ext.build_id():
+        return None
+    ks = doc["kernels"]
     cands = [(v["read_bytes_corrected"] + v["write_bytes"], k) for k, v in ks.items()
              if substr in k]
     return max(cands)[0] if cands else None
@@ -488,6 +503,13 @@ def roofline_objects(kernels, detail, detail_steps):
                                       "traffic": pmc_traffic("bqb_query_kernel" if bq_buckets
                                                              else "bq_grid_query_kernel"),
                                       "algorithmic_bytes": nbytes,
+                                      # what a launch sequence of this size can reach at all: one
+                                      # dependent-kernel boundary per launch (1.45 us,
+                                      # MI355X_MICROARCH.md price list) + the bytes at the HBM
+                                      # rate a streaming kernel achieves (6.3 TB/s)
+                                      "floor_us": BQ_LAUNCHES * 1.45 + nbytes / 6.3e12 * 1e6,
+                                      "frac_of_floor": (BQ_LAUNCHES * 1.45 + nbytes / 6.3e12 * 1e6)
+                                      / (ms * 1e3),
                                       "shape": [b, n, m, s], "avg_ms": ms,
                                       "kernel": ("bqb_query_kernel (+bqb_box_kernel, "
                                                  "bqb_super_kernel)" if bq_buckets else

@@ -37,6 +37,9 @@ typedef void *btr_stream_t; /* a hipStream_t; NULL = the null stream */
 /* Library identification: returns BTR_ABI_VERSION the .so was built with. */
 #define BTR_ABI_VERSION 1
 int btr_abi_version(void);
+/* Digest of the sources this library was built from (build.py build_id): measurements that are
+ * quoted from committed profiles carry it, so a reader can tell whether they belong to it. */
+const char *btr_build_id(void);
 
 /* Rounding mode of the squared distance a*a + b*b + c*c this library was built with
  * (BTR_FMAD, csrc/common.hpp): every index the path returns (FPS arg-max, ball-query
@@ -115,6 +118,11 @@ size_t btr_ball_query_workspace_bytes(int b, int n, int m, int nsample);
 int btr_ball_query_ws(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                       const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
                       btr_stream_t stream);
+
+/* Measurement only (bench.py): the next btr_ball_query_buckets call -- or btr_ball_query_ws call
+ * on a scene of more than 4096 points -- of this host thread records the two hipEvent_t around
+ * its launches, on the call's stream.  NULL, NULL cancels. */
+void btr_ball_query_time_next(void *start_event, void *stop_event);
 
 /* Replaces group_points_kernel_wrapper(b, c, n, npoints, nsample, points, idx, out)
  *   decl src/group_points.cpp:9-11, def src/group_points_gpu.cu:35-44, kernel :13-33.

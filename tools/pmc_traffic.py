@@ -7,8 +7,11 @@ so `read_bytes_corrected` = 2 x FETCH_SIZE x 1024 is the upper estimate and
 `read_bytes_raw` the lower one.
 Usage: pmc_traffic.py fetch.db write.db out.json"""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(path):
@@ -34,7 +37,9 @@ def main():
             "read_bytes_corrected": 2.0 * f[1] * 1024.0,
             "write_bytes": w[1] * 1024.0,
         }
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate "
+    from backtoreality_amd import build
+    json.dump({"build_id": build.build_id(),
+               "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate "
                          "passes) -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline",
                "kernels": res}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
