@@ -17,12 +17,45 @@
 // per-chunk partials (deterministic).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "internal.hpp"
 
 namespace btr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ---- "bf16x6": an f32 product on the bf16 matrix pipe ----------------------------------------
+// v_mfma_f32_32x32x2_f32 retires 2 k per 64 cycles, v_mfma_f32_32x32x16_bf16 16 k per 32: the
+// bf16 pipe is 16x the f32-input one.  Every f32 operand is split into three bf16 pieces,
+// a = ah + am + al, each the round-to-nearest of what the previous ones left -- 3 x 8 significant
+// bits carry the 24 of an f32, the split is exact.  A bf16 x bf16 product is exact in f32, so
+//   a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm) + [am*bl + al*bm + al*bl]
+// where the bracket is <= 2^-23 |a*b| (the size of one f32 rounding) and is dropped; the six
+// kept terms are accumulated in f32 by the MFMA, smallest first.  Six bf16 instructions per
+// 16 k = 2.67x the f32-input rate at the same accuracy: against a float64 evaluation both
+// forms sit at 2e-7 (max) / 2e-8 (mean) of max|C| on the layer shapes of the benchmark step
+// (tools/probe/gemm_lab.hip).  BTR_GEMM=f32 selects the f32-input MFMA kernels instead.
+struct Split4 {
+  bf16x4 h, m, l;
+};
+__device__ __forceinline__ Split4 split4(const float4 v) {
+  Split4 s;
+  const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 h = (__bf16)f[i];
+    const float r1 = f[i] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    s.h[i] = h;
+    s.m[i] = m;
+    s.l[i] = (__bf16)(r1 - (float)m);
+  }
+  return s;
+}
+constexpr int kLp = 40;   // row pitch of a bf16 plane (80 B: conflict-free ds_read_b128)
 
 // "Compact rows" (csrc comment block further down, btr_sac_plan): device-side description of
 // a row array in which every group keeps only ceil8(#distinct neighbours) rows.
@@ -110,7 +143,10 @@ __device__ __forceinline__ float4 rc_y4(const float4 x, const float *__restrict_
 // the maximum is tracked where gamma >= 0, the minimum elsewhere, and the max-pool of the
 // activated layer is relu(scale * gext + shift).  The pool kernel's pass over the whole pre-BN
 // tensor (537 MB for SA1) becomes a pass over 1/PS of it (sa_pool_fin_kernel).
-template <int BN, int PRO, bool STATS, int PS = 0, int BM = kBM, bool BIAS = false>
+// MM == 1: the products run as bf16x6 (see split4); LDS then holds three bf16 planes per operand
+// and the C tile leaves through a per-wave LDS transpose as 16-byte row stores (with the matrix
+// pipe 2.67x faster the 4-byte-per-lane stores of the accumulator layout were the bound).
+template <int BN, int PRO, bool STATS, int PS = 0, int BM = kBM, bool BIAS = false, int MM = 0>
 // (second launch bound: at least 2 waves per SIMD, i.e. <= 256 VGPRs -- two workgroups per
 // CU; without it the PRO == 2 / BN = 128 variant allocates 292 and runs alone on its CU)
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
@@ -127,8 +163,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   constexpr int WM = 4 / WN;       // waves along M
   constexpr int MI = BM / WM / 32;  // 32-row MFMA tiles per wave
   constexpr int NJ = 2;            // 32-col MFMA tiles per wave
-  __shared__ __attribute__((aligned(16))) float As[BM * kLd];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * kLd];
+  static_assert(MM == 0 || PRO != 2, "the pooled-gradient prologue adds to the f32 tile in LDS");
+  __shared__ __attribute__((aligned(16))) float As[MM ? 4 : BM * kLd];
+  __shared__ __attribute__((aligned(16))) float Bs[MM ? 4 : BN * kLd];
+  __shared__ __attribute__((aligned(16))) __bf16 Pl[MM ? 3 * (BM + BN) * kLp : 8];
+  static_assert(!MM || 3 * (BM + BN) * kLp * 2 >= 4 * 32 * 68 * 4, "transpose regions");
   __shared__ double red[STATS ? 2 * WM * BN : 1];
   // per-k prologue coefficients (and, PRO == 3, the first layer's weight rows) live in LDS for
   // the whole kernel: read from global memory inside stage() each of them was a cache round
@@ -264,11 +303,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         v.z = wr * fmaf(fa.z, v.z, fb.z);
         v.w = wr * fmaf(fa.w, v.w, fb.w);
       }
-      *reinterpret_cast<float4 *>(&As[row * kLd + kq]) = v;
+      if constexpr (MM) {
+        const Split4 sp = split4(v);
+        *reinterpret_cast<bf16x4 *>(&Pl[(0 * BM + row) * kLp + kq]) = sp.h;
+        *reinterpret_cast<bf16x4 *>(&Pl[(1 * BM + row) * kLp + kq]) = sp.m;
+        *reinterpret_cast<bf16x4 *>(&Pl[(2 * BM + row) * kLp + kq]) = sp.l;
+      } else {
+        *reinterpret_cast<float4 *>(&As[row * kLd + kq]) = v;
+      }
     }
 #pragma unroll
-    for (int p = 0; p < BN / 32; ++p)
-      *reinterpret_cast<float4 *>(&Bs[(srow + 32 * p) * kLd + kq]) = rb[p];
+    for (int p = 0; p < BN / 32; ++p) {
+      if constexpr (MM) {
+        const Split4 sp = split4(rb[p]);
+        const int row = srow + 32 * p;
+        *reinterpret_cast<bf16x4 *>(&Pl[(3 * BM + 0 * BN + row) * kLp + kq]) = sp.h;
+        *reinterpret_cast<bf16x4 *>(&Pl[(3 * BM + 1 * BN + row) * kLp + kq]) = sp.m;
+        *reinterpret_cast<bf16x4 *>(&Pl[(3 * BM + 2 * BN + row) * kLp + kq]) = sp.l;
+      } else {
+        *reinterpret_cast<float4 *>(&Bs[(srow + 32 * p) * kLd + kq]) = rb[p];
+      }
+    }
   };
 
   if (PRO == 2 && cm.bgrp) {
@@ -332,6 +387,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       // and 16+t4.. in lanes 32-63: a chunk with <= t4 valid columns has nothing left -- the
       // K = 4 first layer runs one group instead of four)
       const int kleft = K - kc * kBK;
+      if constexpr (MM) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (ks * 16 >= kleft) break;
+          bf16x8 af[3][MI], bf[3][NJ];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+              af[q][i] = *reinterpret_cast<const bf16x8 *>(
+                  &Pl[(q * BM + wm * (BM / WM) + i * 32 + l31) * kLp + ks * 16 + h * 8]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              bf[q][j] = *reinterpret_cast<const bf16x8 *>(
+                  &Pl[(3 * BM + q * BN + wn * 64 + j * 32 + l31) * kLp + ks * 16 + h * 8]);
+          }
+          // smallest terms first: (l,h) (h,l) (m,m) | (m,h) (h,m) | (h,h)
+#define BTR_X6(QA, QB)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA][i], bf[QB][j], acc[i][j], 0, 0, 0);
+          BTR_X6(2, 0)
+          BTR_X6(0, 2)
+          BTR_X6(1, 1)
+          BTR_X6(1, 0)
+          BTR_X6(0, 1)
+          BTR_X6(0, 0)
+#undef BTR_X6
+        }
+      } else {
 #pragma unroll
       for (int t4 = 0; t4 < kBK / 2; t4 += 4) {
         if (t4 >= kleft) break;
@@ -354,11 +438,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         BTR_MFMA_STEP(w)
 #undef BTR_MFMA_STEP
       }
+      }
       __syncthreads();
     }
     // ---- epilogue: D layout col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+    constexpr bool kWide = MM != 0;   // C through the per-wave LDS transpose, 16-byte stores
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int col = n_blk + wn * 64 + j * 32 + l31;
@@ -367,7 +453,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
           const int row = r0 + wm * (BM / WM) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
           float c = acc[i][j][v];
           if (BIAS && col < N && row < R) c += gsign[col];  // (BIAS: gsign carries the bias row)
-          if (C != nullptr && row < R && col < N) C[(size_t)row * ldc + col] = c;
+          if (BIAS && kWide) acc[i][j][v] = c;
+          if (!kWide && C != nullptr && row < R && col < N) C[(size_t)row * ldc + col] = c;
           if (STATS) {  // rows >= R hold exact zeros (A staged as 0): no masking needed
             s1[j] += c;
             s2[j] = fmaf(c, c, s2[j]);
@@ -381,6 +468,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
           }
         }
       }
+      if (kWide && C != nullptr) {
+        // the wave's 32 x 64 block: written to its own LDS region in the accumulator layout
+        // (lanes along the columns), read back as rows: each store instruction puts 4 rows x
+        // 256 B.  The regions overlay the staging planes: every wave is past its last MFMA
+        // (the barrier that ended the chunk loop), and the barrier below ends the overlay.
+        float *T = reinterpret_cast<float *>(Pl) + wave * (32 * 68);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            T[((v & 3) + 8 * (v >> 2) + 4 * h) * 68 + j * 32 + l31] = acc[i][j][v];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the region is private to the wave)
+        __builtin_amdgcn_wave_barrier();
+        const int rl = lane >> 4, c4 = (lane & 15) * 4;
+        const int colw = n_blk + wn * 64 + c4;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const float4 q4 = *reinterpret_cast<const float4 *>(&T[(it * 4 + rl) * 68 + c4]);
+          const int row = r0 + wm * (BM / WM) + i * 32 + it * 4 + rl;
+          if (row < R && colw < N) *reinterpret_cast<float4 *>(C + (size_t)row * ldc + colw) = q4;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (kWide && C != nullptr) __syncthreads();
     if (STATS) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -1710,6 +1822,12 @@ inline HostCompact &host_compact() {
 }
 inline Compact cur_compact() { return host_compact().on ? host_compact().dev : Compact{}; }
 
+// BTR_GEMM=f32: the f32-input MFMA kernels (v_mfma_f32_32x32x2_f32) instead of bf16x6
+inline bool gemm_x6() {
+  static const bool on = !(getenv("BTR_GEMM") && getenv("BTR_GEMM")[0] == 'f');
+  return on;
+}
+
 }  // namespace btr
 
 using namespace btr;
@@ -1762,12 +1880,17 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t s = as_stream(stream);
   const bool pro = pa != nullptr, st = part != nullptr;
-#define BTR_GEMM(BN, P, S)                                                                   \
-  hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S>), dim3(gx, cdiv(n, BN)), dim3(256), 0, s, a,  \
-                     lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,                             \
+#define BTR_GEMM_MM(BN, P, S, MM)                                                            \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S, 0, kBM, false, MM>), dim3(gx, cdiv(n, BN)),    \
+                     dim3(256), 0, s, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,       \
                      (const unsigned char *)nullptr, (const float *)nullptr, 0,                 \
                      (const float *)nullptr, (float *)nullptr, (unsigned char *)nullptr,        \
                      cur_compact())
+#define BTR_GEMM(BN, P, S)            \
+  do {                                \
+    if (gemm_x6()) BTR_GEMM_MM(BN, P, S, 1); \
+    else BTR_GEMM_MM(BN, P, S, 0);    \
+  } while (0)
   if (n <= 64) {
     if (pro) { if (st) BTR_GEMM(64, 1, true); else BTR_GEMM(64, 1, false); }
     else     { if (st) BTR_GEMM(64, 0, true); else BTR_GEMM(64, 0, false); }
@@ -1776,6 +1899,7 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
     else     { if (st) BTR_GEMM(128, 0, true); else BTR_GEMM(128, 0, false); }
   }
 #undef BTR_GEMM
+#undef BTR_GEMM_MM
   return check_launch("sa_gemm_nt");
 }
 
@@ -1803,16 +1927,22 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
               "sa_gemm_nt_poolfwd: n=%d / nsample=%d / k=%d not supported", n, s, k);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
-#define BTR_GEMM(PS)                                                                          \
-  hipLaunchKernelGGL((gemm_nt_kernel<128, 1, true, PS>), dim3(gx, cdiv(n, 128)), dim3(256), 0,  \
-                     st, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,                      \
+#define BTR_GEMM_MM(PS, MM)                                                                   \
+  hipLaunchKernelGGL((gemm_nt_kernel<128, 1, true, PS, kBM, false, MM>), dim3(gx, cdiv(n, 128)), \
+                     dim3(256), 0, st, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,        \
                      (const unsigned char *)nullptr, (const float *)nullptr, 0, gamma, gext,    \
                      aext, cur_compact())
+#define BTR_GEMM(PS)                  \
+  do {                                \
+    if (gemm_x6()) BTR_GEMM_MM(PS, 1); \
+    else BTR_GEMM_MM(PS, 0);          \
+  } while (0)
   if (s == 8) BTR_GEMM(8);
   else if (s == 16) BTR_GEMM(16);
   else if (s == 32) BTR_GEMM(32);
   else BTR_GEMM(64);
 #undef BTR_GEMM
+#undef BTR_GEMM_MM
   return check_launch("sa_gemm_nt_poolfwd");
 }
 
@@ -1945,14 +2075,20 @@ int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, 
               "sa_gemm_nt_rc: null pointer or k=%d ldw=%d not multiples of 4", k, ldw);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
-#define BTR_NTRC(BN, S)                                                                       \
-  hipLaunchKernelGGL((gemm_nt_kernel<BN, 3, S>), dim3(gx, cdiv(n, BN)), dim3(256), 0, st, x0, \
-                     4, w, ldw, c, ldc, rows, n, k, pa, pb, part,                              \
+#define BTR_NTRC_MM(BN, S, MM)                                                                \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, 3, S, 0, kBM, false, MM>), dim3(gx, cdiv(n, BN)),     \
+                     dim3(256), 0, st, x0, 4, w, ldw, c, ldc, rows, n, k, pa, pb, part,        \
                      (const unsigned char *)nullptr, w0, 0, (const float *)nullptr,           \
                      (float *)nullptr, (unsigned char *)nullptr, cur_compact())
+#define BTR_NTRC(BN, S)                \
+  do {                                 \
+    if (gemm_x6()) BTR_NTRC_MM(BN, S, 1); \
+    else BTR_NTRC_MM(BN, S, 0);        \
+  } while (0)
   if (n <= 64) { if (part) BTR_NTRC(64, true); else BTR_NTRC(64, false); }
   else         { if (part) BTR_NTRC(128, true); else BTR_NTRC(128, false); }
 #undef BTR_NTRC
+#undef BTR_NTRC_MM
   return check_launch("sa_gemm_nt_rc");
 }
 
@@ -2251,11 +2387,16 @@ int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
   BTR_REQUIRE(!(bias && part), "pm_gemm_nt: bias and statistics are exclusive");
   hipStream_t s = as_stream(stream);
   const int gx = btr_pm_gemm_grid(rows);
-#define BTR_PM(BN, P, S, BIAS)                                                                 \
-  hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S, 0, 64, BIAS>), dim3(gx, cdiv(n, BN)), dim3(256), \
-                     0, s, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,                    \
+#define BTR_PM_MM(BN, P, S, BIAS, MM)                                                          \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S, 0, 64, BIAS, MM>), dim3(gx, cdiv(n, BN)),         \
+                     dim3(256), 0, s, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,         \
                      (const unsigned char *)nullptr, (const float *)nullptr, 0, bias,          \
                      (float *)nullptr, (unsigned char *)nullptr, Compact{})
+#define BTR_PM(BN, P, S, BIAS)              \
+  do {                                      \
+    if (gemm_x6()) BTR_PM_MM(BN, P, S, BIAS, 1); \
+    else BTR_PM_MM(BN, P, S, BIAS, 0);      \
+  } while (0)
   if (pa) {
     if (part) BTR_PM(128, 1, true, false);
     else if (bias) BTR_PM(128, 1, false, true);
@@ -2266,6 +2407,7 @@ int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
     else BTR_PM(128, 0, false, false);
   }
 #undef BTR_PM
+#undef BTR_PM_MM
   return check_launch("pm_gemm_nt");
 }
 
