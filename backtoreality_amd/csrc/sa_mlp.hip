@@ -163,7 +163,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   constexpr int WM = 4 / WN;       // waves along M
   constexpr int MI = BM / WM / 32;  // 32-row MFMA tiles per wave
   constexpr int NJ = 2;            // 32-col MFMA tiles per wave
-  static_assert(MM == 0 || PRO != 2, "the pooled-gradient prologue adds to the f32 tile in LDS");
+  // PRO == 2 with bf16x6: the sparse part is added by the thread that stages the element, BEFORE
+  // the split, from a per-chunk table (slot = group / 8-row block of the tile, k): local row of
+  // the arg-max (-1: none in this tile) and the value to add
+  __shared__ int sLr[(MM && PRO == 2) ? 16 * 32 : 4];
+  __shared__ float sDv[(MM && PRO == 2) ? 16 * 32 : 4];
   __shared__ __attribute__((aligned(16))) float As[MM ? 4 : BM * kLd];
   __shared__ __attribute__((aligned(16))) float Bs[MM ? 4 : BN * kLd];
   __shared__ __attribute__((aligned(16))) __bf16 Pl[MM ? 3 * (BM + BN) * kLp : 8];
@@ -302,6 +306,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
         v.y = wr * fmaf(fa.y, v.y, fb.y);
         v.z = wr * fmaf(fa.z, v.z, fb.z);
         v.w = wr * fmaf(fa.w, v.w, fb.w);
+        if constexpr (MM != 0) {   // + the sparse part (tables written right before this stage)
+          const int slot = cm.bgrp ? (row >> 3) : (row >> SSH);
+          const int4 lr = *reinterpret_cast<const int4 *>(&sLr[slot * 32 + kq]);
+          const float4 dv = *reinterpret_cast<const float4 *>(&sDv[slot * 32 + kq]);
+          v.x += lr.x == row ? dv.x : 0.f;
+          v.y += lr.y == row ? dv.y : 0.f;
+          v.z += lr.z == row ? dv.z : 0.f;
+          v.w += lr.w == row ? dv.w : 0.f;
+        }
       }
       if constexpr (MM) {
         const Split4 sp = split4(v);
@@ -364,9 +377,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     }
 
     for (int kc = 0; kc < nkc; ++kc) {
+      if constexpr (PRO == 2 && MM != 0) {   // the chunk's sparse table (see sLr)
+        if (cm.bgrp) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int slot = sp_gi + 8 * q;
+            const int lr = sp_off[q] + (int)sp_a[q];
+            sLr[slot * 32 + sp_k] = (sp_ok[q] && lr >= 0 && (lr >> 3) == slot) ? lr : -1;
+            sDv[slot * 32 + sp_k] = sp_dv[q];
+          }
+        } else {
+          sLr[sp_gi * 32 + sp_k] = sp_on ? (sp_gi << SSH) + (int)sp_arg : -1;
+          sDv[sp_gi * 32 + sp_k] = sp_d;
+          sLr[(sp_gi + 8) * 32 + sp_k] = -1;
+        }
+        __syncthreads();
+      }
       stage(tile, kc);
       __syncthreads();
-      if (PRO == 2) {  // sparse part: the arg-max row of every (group, channel) of this tile
+      if (PRO == 2 && MM == 0) {  // sparse part: the arg-max row of every (group, channel) of this tile
         if (cm.bgrp) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
@@ -942,10 +971,11 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(
     const float4 b = *reinterpret_cast<const float4 *>(shift + c4);
     const float4 mu = *reinterpret_cast<const float4 *>(mean + c4);
     const float4 is = *reinterpret_cast<const float4 *>(invstd + c4);
-    for (long long r = (long long)blockIdx.x * slots + slot; r < R;
-         r += (long long)gridDim.x * slots) {
-      const float4 y = *reinterpret_cast<const float4 *>(Y + (size_t)r * ld + c4);
-      float4 g = *reinterpret_cast<const float4 *>(G + (size_t)r * ld + c4);
+    // four rows in flight per thread (a streaming pass: the loads of a row must not wait for
+    // the arithmetic of the previous one)
+    const long long stride = (long long)gridDim.x * slots;
+    long long r = (long long)blockIdx.x * slots + slot;
+    auto one = [&](const float4 y, float4 g) {
       g.x = fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f;
       g.y = fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f;
       g.z = fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f;
@@ -955,7 +985,20 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(
       s2.y = fmaf(g.y, (y.y - mu.y) * is.y, s2.y);
       s2.z = fmaf(g.z, (y.z - mu.z) * is.z, s2.z);
       s2.w = fmaf(g.w, (y.w - mu.w) * is.w, s2.w);
+    };
+    for (; r + 3 * stride < R; r += 4 * stride) {
+      float4 y[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        y[u] = *reinterpret_cast<const float4 *>(Y + (size_t)(r + u * stride) * ld + c4);
+        g[u] = *reinterpret_cast<const float4 *>(G + (size_t)(r + u * stride) * ld + c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(y[u], g[u]);
     }
+    for (; r < R; r += stride)
+      one(*reinterpret_cast<const float4 *>(Y + (size_t)r * ld + c4),
+          *reinterpret_cast<const float4 *>(G + (size_t)r * ld + c4));
   }
   *reinterpret_cast<float4 *>(&red[0][threadIdx.x * 4]) = s1;
   *reinterpret_cast<float4 *>(&red[1][threadIdx.x * 4]) = s2;
@@ -985,10 +1028,10 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_stats_rc_kernel(
     const float4 b = *reinterpret_cast<const float4 *>(shift + c4);
     const float4 mu = *reinterpret_cast<const float4 *>(mean + c4);
     const float4 is = *reinterpret_cast<const float4 *>(invstd + c4);
-    for (long long r = (long long)blockIdx.x * slots + slot; r < R;
-         r += (long long)gridDim.x * slots) {
-      const float4 y = rc_y4(*reinterpret_cast<const float4 *>(X0 + (size_t)r * 4), W0, c4);
-      float4 g = *reinterpret_cast<const float4 *>(G + (size_t)r * ld + c4);
+    const long long stride = (long long)gridDim.x * slots;
+    long long r = (long long)blockIdx.x * slots + slot;
+    auto one = [&](const float4 x, float4 g) {
+      const float4 y = rc_y4(x, W0, c4);
       g.x = fmaf(a.x, y.x, b.x) > 0.f ? g.x : 0.f;
       g.y = fmaf(a.y, y.y, b.y) > 0.f ? g.y : 0.f;
       g.z = fmaf(a.z, y.z, b.z) > 0.f ? g.z : 0.f;
@@ -998,7 +1041,20 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_stats_rc_kernel(
       s2.y = fmaf(g.y, (y.y - mu.y) * is.y, s2.y);
       s2.z = fmaf(g.z, (y.z - mu.z) * is.z, s2.z);
       s2.w = fmaf(g.w, (y.w - mu.w) * is.w, s2.w);
+    };
+    for (; r + 3 * stride < R; r += 4 * stride) {   // four rows in flight per thread
+      float4 x[4], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = *reinterpret_cast<const float4 *>(X0 + (size_t)(r + u * stride) * 4);
+        g[u] = *reinterpret_cast<const float4 *>(G + (size_t)(r + u * stride) * ld + c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(x[u], g[u]);
     }
+    for (; r < R; r += stride)
+      one(*reinterpret_cast<const float4 *>(X0 + (size_t)r * 4),
+          *reinterpret_cast<const float4 *>(G + (size_t)r * ld + c4));
   }
   *reinterpret_cast<float4 *>(&red[0][threadIdx.x * 4]) = s1;
   *reinterpret_cast<float4 *>(&red[1][threadIdx.x * 4]) = s2;
@@ -2040,16 +2096,17 @@ int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const f
   const int ssh = ilog2(s);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
-  if (n <= 64)
-    hipLaunchKernelGGL((gemm_nt_kernel<64, 2, false>), dim3(gx, cdiv(n, 64)), dim3(256), 0, st, y,
-                       ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl, ssh,
-                       (const float *)nullptr, (float *)nullptr, (unsigned char *)nullptr,
-                       cur_compact());
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 2, false>), dim3(gx, cdiv(n, 128)), dim3(256), 0, st,
-                       y, ldy, w, ldw, c, ldc, rows, n, k, alpha, beta, (float *)nullptr, arg, dcl,
-                       ssh, (const float *)nullptr, (float *)nullptr, (unsigned char *)nullptr,
-                       cur_compact());
+#define BTR_NTP(BN, MM)                                                                       \
+  hipLaunchKernelGGL((gemm_nt_kernel<BN, 2, false, 0, kBM, false, MM>), dim3(gx, cdiv(n, BN)), \
+                     dim3(256), 0, st, y, ldy, w, ldw, c, ldc, rows, n, k, alpha, beta,        \
+                     (float *)nullptr, arg, dcl, ssh, (const float *)nullptr, (float *)nullptr, \
+                     (unsigned char *)nullptr, cur_compact())
+  if (n <= 64) {
+    if (gemm_x6()) BTR_NTP(64, 1); else BTR_NTP(64, 0);
+  } else {
+    if (gemm_x6()) BTR_NTP(128, 1); else BTR_NTP(128, 0);
+  }
+#undef BTR_NTP
   return check_launch("sa_gemm_nt_pool");
 }
 
@@ -2154,7 +2211,7 @@ int btr_sa_bn_relu_bwd_rc(long long rows, int c, int ldg, const float *g, const 
 }
 
 // In place: g (gradient w.r.t. the post-ReLU activation of a hidden layer) -> gradient w.r.t.
-// the layer's pre-BN output y; also dgamma/dbeta.  part: [256][2][c] floats.
+// the layer's pre-BN output y; also dgamma/dbeta.  part: [1024][2][c] floats.
 int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
                        const float *scale, const float *shift, const float *mean,
                        const float *invstd, float *part, float *m1, float *m2, float *dgamma,
@@ -2163,7 +2220,7 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
   BTR_REQUIRE(c <= kBnBwdMaxC && c % 4 == 0 && ld % 4 == 0,
               "sa_bn_relu_bwd: %d channels must be a multiple of 4 and <= %d", c, kBnBwdMaxC);
   hipStream_t st = as_stream(stream);
-  const int nblk = (int)std::min<long long>(cdiv(rows, 256 / (c / 4)), 512);
+  const int nblk = (int)std::min<long long>(cdiv(rows, 256 / (c / 4)), 1024);
   const double count = host_compact().on ? host_compact().count : (double)rows;
   hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ld, g, y,
                      scale, shift, mean, invstd, part, cur_compact());
