@@ -160,6 +160,21 @@ inline int fp_known_c(const btr_backbone_t &d, const Dims &s, int j) {
   return j == 0 ? s.c[d.levels] : d.fp[j - 1].width[d.fp[j - 1].layers - 1];
 }
 
+// the prepared compact plan / scatter lists of level l inside the geometry arena
+SaGeom level_geom(const btr_backbone_plan_t &p, const void *geom, int l) {
+  SaGeom g;
+  char *base = (char *)const_cast<void *>(geom);
+  if (p.sa[l].compact) {
+    g.goff = (int *)(base + p.g_goff[l]);
+    g.dims = (int *)(base + p.g_dims[l]);
+    g.cidx = (int *)(base + p.g_cidx[l]);
+    g.bgrp = (int *)(base + p.g_bgrp[l]);
+    g.bw = (float *)(base + p.g_bw[l]);
+  }
+  if (p.g_scat_bytes[l]) g.scatter_ws = base + p.g_scat[l];
+  return g;
+}
+
 struct BwdScratch {
   size_t dx[kMaxLv], dk[kMaxLv], df[kMaxLv + 1], ti, layer, bytes;
   size_t ti_bytes;
@@ -245,11 +260,28 @@ int btr_backbone_plan(const btr_backbone_t *dp, btr_backbone_plan_t *p) {
                             ? btr_ball_query_buckets_workspace_bytes(d.b, s.n, s.m, s.s) : 0;
       p->bq_buckets[l] = bk > 0;
       bq = std::max(bq, bk ? bk : btr_ball_query_workspace_bytes(d.b, s.n, s.m, s.s));
+      if (p->sa[l].compact) {   // the compact-row plan (csrc/sa_mlp.hip "compact rows")
+        const size_t groups = (size_t)d.b * s.m, rows = (size_t)p->sa[l].rows;
+        p->g_goff[l] = g.ints(groups + 1);
+        p->g_dims[l] = g.ints(2);
+        p->g_cidx[l] = g.ints(rows);
+        p->g_bgrp[l] = g.ints(rows / 8);
+        p->g_bw[l] = g.floats(rows / 8);
+        p->g_len[l] = g.ints(groups);
+      }
+      if (s.need_dfeat && s.c > 0) {   // the backward's inverted neighbour lists
+        p->g_scat_bytes[l] = p->sa[l].compact
+                                 ? btr_sac_scatter_workspace_bytes(d.b, s.n, p->sa[l].rows)
+                                 : btr_sa_scatter_workspace_bytes(d.b, s.n, s.m, s.s);
+        p->g_scat[l] = g.take(p->g_scat_bytes[l]);
+      }
     }
     for (int j = 0; j < d.fps; ++j) {
       const size_t e = (size_t)d.b * dm.n[fp_unknown(d, j)] * 3;
       p->g_nn_idx[j] = g.ints(e);
       p->g_nn_w[j] = g.floats(e);
+      p->g_ti_bytes[j] = ti_grad_workspace_bytes(d.b, dm.n[fp_unknown(d, j)], dm.n[fp_known(d, j)]);
+      p->g_ti[j] = g.take(p->g_ti_bytes[j]);
       bq = std::max(bq, e * sizeof(float));   // dist2 of three_nn (not kept)
     }
     p->g_ws_bytes = bq;
@@ -331,6 +363,23 @@ int btr_backbone_sampling(const btr_backbone_t *dp, const btr_backbone_plan_t *p
     else
       BTR_TRY(btr_ball_query_ws(d.b, s.n, s.m, d.radius[l], s.s, new_xyz, xyz,
                                 at_i(geom, p.g_idx[l]), ws, p.g_ws_bytes, cur));
+    // what forward / backward derive from the ball query alone, while nobody waits for it
+    if (p.sa[l].compact)
+      BTR_TRY(btr_sac_plan(d.b * s.m, s.s, at_i(geom, p.g_idx[l]), at_i(geom, p.g_len[l]),
+                           at_i(geom, p.g_goff[l]), at_i(geom, p.g_dims[l]),
+                           at_i(geom, p.g_cidx[l]), at_i(geom, p.g_bgrp[l]),
+                           at_f(geom, p.g_bw[l]), cur));
+    if (p.g_scat_bytes[l]) {
+      void *sw = (char *)geom + p.g_scat[l];
+      if (p.sa[l].compact)
+        BTR_TRY(sac_scatter_ex(d.b, s.n, s.m, s.c, p.sa[l].k0p, s.use_xyz, nullptr,
+                               at_i(geom, p.g_cidx[l]), at_i(geom, p.g_goff[l]), nullptr, sw,
+                               p.g_scat_bytes[l], p.sa[l].rows, kScatterBuild, as_stream(cur)));
+      else
+        BTR_TRY(sa_scatter_ex(d.b, s.n, s.m, s.s, s.c, p.sa[l].k0p, s.use_xyz, s.radius_div,
+                              nullptr, at_i(geom, p.g_idx[l]), nullptr, nullptr, nullptr, sw,
+                              p.g_scat_bytes[l], kScatterBuild, as_stream(cur)));
+    }
     if (ev) {
       if (l == 0) {   // level 1 stays on the caller's stream; the rest forks to the side stream
         (void)hipEventRecord(ev->fork, as_stream(stream));
@@ -347,6 +396,9 @@ int btr_backbone_sampling(const btr_backbone_t *dp, const btr_backbone_plan_t *p
     BTR_TRY(btr_three_nn_weights(d.b, dm.n[u], dm.n[k], at_f(geom, p.g_new_xyz[u - 1]),
                                  at_f(geom, p.g_new_xyz[k - 1]), (float *)ws,
                                  at_i(geom, p.g_nn_idx[j]), at_f(geom, p.g_nn_w[j]), cur));
+    BTR_TRY(ti_grad_lists(d.b, 0, dm.n[u], dm.n[k], nullptr, 0, at_i(geom, p.g_nn_idx[j]),
+                          nullptr, nullptr, (char *)geom + p.g_ti[j], p.g_ti_bytes[j],
+                          as_stream(cur), kScatterBuild));
   }
   if (ev) (void)hipEventRecord(ev->level[d.levels], as_stream(side));   // the 3-NN weights
   return check_launch("backbone_sampling");
@@ -371,9 +423,11 @@ int btr_backbone_forward(const btr_backbone_t *dp, const btr_backbone_plan_t *pp
   for (int l = 0; l < d.levels; ++l) {
     if (ev && l > 0) (void)hipStreamWaitEvent(st, ev->level[l], 0);
     const float *new_xyz = at_f(geom, p.g_new_xyz[l]);
-    BTR_TRY(btr_sa_layer_forward(&d.sa[l], &p.sa[l], xyz, new_xyz, feats, at_i(geom, p.g_idx[l]),
-                                 at_f(out, p.o_sa[l]), at_f(out, p.o_sa_cl[l]),
-                                 (char *)saved + p.s_sa[l], scratch, stream));
+    const SaGeom sg = level_geom(p, geom, l);
+    BTR_TRY(sa_layer_forward_geom(&d.sa[l], &p.sa[l], xyz, new_xyz, feats,
+                                  at_i(geom, p.g_idx[l]), at_f(out, p.o_sa[l]),
+                                  at_f(out, p.o_sa_cl[l]), (char *)saved + p.s_sa[l], scratch,
+                                  &sg, stream));
     xyz = new_xyz;
     feats = at_f(out, p.o_sa_cl[l]);
   }
@@ -447,7 +501,8 @@ int btr_backbone_backward(const btr_backbone_t *dp, const btr_backbone_plan_t *p
     // known level's share: scatter the interpolated channels back through the 3-NN lists
     BTR_TRY(ti_grad_lists(d.b, c1, dm.n[u], dm.n[k], dx, (long long)d.fp[j].c * dm.n[u],
                           at_i(geom, p.g_nn_idx[j]), at_f(geom, p.g_nn_w[j]),
-                          at_f(scratch, sc.dk[j]), (char *)scratch + sc.ti, sc.ti_bytes, st));
+                          at_f(scratch, sc.dk[j]), (char *)const_cast<void *>(geom) + p.g_ti[j],
+                          p.g_ti_bytes[j], st, kScatterReduce));
   }
   // ---- set-abstraction levels, last first
   for (int l = L; l >= 1; --l) {
@@ -502,10 +557,11 @@ int btr_backbone_backward(const btr_backbone_t *dp, const btr_backbone_plan_t *p
         add_bs = (long long)d.fp[j].c * dm.n[l - 1];
       }
     }
+    const SaGeom sg = level_geom(p, geom, l - 1);
     BTR_TRY(sa_layer_backward_add(&s, &p.sa[l - 1], at_i(geom, p.g_idx[l - 1]),
                                   at_f(out, p.o_sa[l - 1]), dout, (char *)saved + p.s_sa[l - 1],
                                   grads + p.gr_sa[l - 1], dfeat, nullptr, nullptr, layer_scratch,
-                                  add, add_bs, stream));
+                                  add, add_bs, &sg, stream));
   }
   return check_launch("backbone_backward");
 }

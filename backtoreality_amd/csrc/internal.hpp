@@ -18,11 +18,36 @@ int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
 size_t ti_grad_workspace_bytes(int b, int n, int m);
 int ti_grad_lists(int b, int c, int n, int m, const float *grad_out, long long go_bstride,
                   const int *idx, const float *weight, float *grad_points, void *workspace,
-                  size_t workspace_bytes, hipStream_t stream);
+                  size_t workspace_bytes, hipStream_t stream, int mode = 0 /* kScatter* */);
 
 // ball_query.hip: measurement hook (btr_ball_query_time_next): the event pair the next ball
 // query call of this host thread records around its launches
 hipEvent_t *bq_call_events();
+
+// sa_mlp.hip: btr_sa_scatter / btr_sac_scatter split in two: the inverted neighbour lists only
+// depend on the ball-query result, so a caller that has it early (btr_backbone_sampling) builds
+// them ahead (mode 1) and the backward only reduces (mode 2); mode 0 = both, as the C entry points.
+enum { kScatterBoth = 0, kScatterBuild = 1, kScatterReduce = 2 };
+int sa_scatter_ex(int b, int n, int m, int s, int c, int ldx, int use_xyz, float radius_div,
+                  const float *dx0, const int *idx, float *dfeat_cl, float *dxyz,
+                  float *dnew_xyz, void *workspace, size_t workspace_bytes, int mode,
+                  hipStream_t stream);
+int sac_scatter_ex(int b, int n, int m, int c, int ldx, int use_xyz, const float *dx0,
+                   const int *cidx, const int *goff, float *dfeat_cl, void *workspace,
+                   size_t workspace_bytes, int max_rows, int mode, hipStream_t stream);
+
+// What btr_backbone_sampling prepares for one set-abstraction layer besides the ball query:
+// the compact-row plan (NULL pointers: the layer is not compact / builds its own) and the
+// filled scatter workspace of the backward (NULL: built in the backward).
+struct SaGeom {
+  int *goff = nullptr, *dims = nullptr, *cidx = nullptr, *bgrp = nullptr;
+  float *bw = nullptr;
+  void *scatter_ws = nullptr;
+};
+int sa_layer_forward_geom(const btr_sa_layer_t *d, const btr_sa_plan_t *plan, const float *xyz,
+                          const float *new_xyz, const float *feats_cl, const int *idx,
+                          float *out, float *out_cl, void *saved, void *scratch,
+                          const SaGeom *geom, btr_stream_t stream);
 
 // sa_layer.hip: btr_sa_layer_backward with an operand added to the feature gradient it writes
 // (dfeat (b, c, n) = layer's own gradient + dfeat_add; dfeat_add's batch stride in floats).
@@ -30,6 +55,6 @@ int sa_layer_backward_add(const btr_sa_layer_t *d, const btr_sa_plan_t *plan, co
                           const float *out, const float *dout, void *saved, float *grads,
                           float *dfeat, float *dxyz, float *dnew_xyz, void *scratch,
                           const float *dfeat_add, long long dfeat_add_bstride,
-                          btr_stream_t stream);
+                          const SaGeom *geom, btr_stream_t stream);
 
 }  // namespace btr

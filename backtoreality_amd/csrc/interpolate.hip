@@ -270,8 +270,8 @@ size_t ti_grad_workspace_bytes(int b, int n, int m) {
 // through the 3-NN lists, without float atomics (see ti_reduce_kernel)
 int ti_grad_lists(int b, int c, int n, int m, const float *grad_out, long long go_bstride,
                   const int *idx, const float *weight, float *grad_points, void *workspace,
-                  size_t workspace_bytes, hipStream_t st) {
-  BTR_REQUIRE(grad_out && idx && weight && grad_points && workspace &&
+                  size_t workspace_bytes, hipStream_t st, int mode) {
+  BTR_REQUIRE(idx && workspace && (mode == kScatterBuild || (grad_out && weight && grad_points)) &&
                   workspace_bytes >= ti_grad_workspace_bytes(b, n, m),
               "three_interpolate_grad: null pointer or workspace too small");
   BTR_REQUIRE(b < 65536 && (long long)n * 3 < 0x7fffffffLL, "three_interpolate_grad: too large");
@@ -279,17 +279,21 @@ int ti_grad_lists(int b, int c, int n, int m, const float *grad_out, long long g
   const size_t off_b = sizeof(int) * (size_t)b * (m + 1), cur_b = sizeof(int) * (size_t)b * m;
   char *ws = (char *)workspace;
   int *off = (int *)ws, *cursor = (int *)(ws + off_b), *refs = (int *)(ws + off_b + cur_b);
-  if (csr_small_supported(m)) {
-    csr_small_launch(b, n3, m, idx, off, refs, st);
-  } else {
-    (void)hipMemsetAsync(off, 0, off_b, st);
-    hipLaunchKernelGGL(ti_count_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx, off);
-    hipLaunchKernelGGL(ti_scan_kernel, dim3(b), dim3(256), 0, st, m, off, cursor);
-    hipLaunchKernelGGL(ti_fill_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx,
-                       cursor, refs);
+  if (mode != kScatterReduce) {
+    if (csr_small_supported(m)) {
+      csr_small_launch(b, n3, m, idx, off, refs, st);
+    } else {
+      (void)hipMemsetAsync(off, 0, off_b, st);
+      hipLaunchKernelGGL(ti_count_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx,
+                         off);
+      hipLaunchKernelGGL(ti_scan_kernel, dim3(b), dim3(256), 0, st, m, off, cursor);
+      hipLaunchKernelGGL(ti_fill_kernel, dim3(cdiv(n3, 256), b), dim3(256), 0, st, n3, m, idx,
+                         cursor, refs);
+    }
   }
-  hipLaunchKernelGGL(ti_reduce_kernel, dim3(cdiv(m, 64), cdiv(c, 4 * kTiCpt), b), dim3(256), 0,
-                     st, c, n, m, grad_out, weight, off, refs, grad_points, go_bstride);
+  if (mode != kScatterBuild)
+    hipLaunchKernelGGL(ti_reduce_kernel, dim3(cdiv(m, 64), cdiv(c, 4 * kTiCpt), b), dim3(256), 0,
+                       st, c, n, m, grad_out, weight, off, refs, grad_points, go_bstride);
   return check_launch("three_interpolate_grad(lists)");
 }
 

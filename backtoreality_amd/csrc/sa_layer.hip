@@ -445,6 +445,29 @@ int btr_sa_layer_plan(const btr_sa_layer_t *dp, btr_sa_plan_t *p) {
 int btr_sa_layer_forward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, const float *xyz,
                          const float *new_xyz, const float *feats_cl, const int *idx, float *out,
                          float *out_cl, void *saved, void *scratch, btr_stream_t stream) {
+  return sa_layer_forward_geom(dp, pp, xyz, new_xyz, feats_cl, idx, out, out_cl, saved, scratch,
+                               nullptr, stream);
+}
+
+}  // extern "C"
+
+// (the compact-row plan of a layer: in its `saved` block unless the caller prepared it)
+namespace {
+struct CompactPtrs {
+  int *goff, *dims, *cidx, *bgrp;
+  float *bw;
+};
+inline CompactPtrs compact_ptrs(const btr_sa_plan_t &p, void *saved, const btr::SaGeom *g) {
+  if (g && g->goff) return CompactPtrs{g->goff, g->dims, g->cidx, g->bgrp, g->bw};
+  return CompactPtrs{at_i(saved, p.goff), at_i(saved, p.dims), at_i(saved, p.cidx),
+                     at_i(saved, p.bgrp), at_f(saved, p.bw)};
+}
+}  // namespace
+
+int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp,
+                               const float *xyz, const float *new_xyz, const float *feats_cl,
+                               const int *idx, float *out, float *out_cl, void *saved,
+                               void *scratch, const SaGeom *geom, btr_stream_t stream) {
   BTR_REQUIRE(dp && pp && xyz && new_xyz && idx && out && saved && scratch,
               "sa_layer_forward: null pointer");
   const btr_sa_layer_t &d = *dp;
@@ -474,18 +497,18 @@ int btr_sa_layer_forward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, cons
 
   float *x0 = at_f(saved, p.x0);
   btr_compact_t cm{};
+  const CompactPtrs cp = compact_ptrs(p, saved, geom);
   if (p.compact) {
-    cm.dims = at_i(saved, p.dims);
-    cm.bw = at_f(saved, p.bw);
-    cm.bgrp = at_i(saved, p.bgrp);
-    cm.goff = at_i(saved, p.goff);
+    cm.dims = cp.dims;
+    cm.bw = cp.bw;
+    cm.bgrp = cp.bgrp;
+    cm.goff = cp.goff;
     cm.dense_rows = (double)R;
-    BTR_TRY(btr_sac_plan(d.b * d.m, d.s, idx, at_i(scratch, sc.len_tmp), at_i(saved, p.goff),
-                         at_i(saved, p.dims), at_i(saved, p.cidx), at_i(saved, p.bgrp),
-                         at_f(saved, p.bw), stream));
+    if (!(geom && geom->goff))   // (else: planned by btr_backbone_sampling)
+      BTR_TRY(btr_sac_plan(d.b * d.m, d.s, idx, at_i(scratch, sc.len_tmp), cp.goff, cp.dims,
+                           cp.cidx, cp.bgrp, cp.bw, stream));
     BTR_TRY(btr_sac_gather(d.b, d.n, d.m, R, d.c, p.k0p, d.use_xyz, d.radius_div, xyz, new_xyz,
-                           feats_cl, at_i(saved, p.cidx), at_i(saved, p.bgrp),
-                           at_i(saved, p.dims), x0, stream));
+                           feats_cl, cp.cidx, cp.bgrp, cp.dims, x0, stream));
     btr_sac_bind(&cm);
   } else {
     BTR_TRY(btr_sa_gather(d.b, d.n, d.m, d.s, d.c, p.k0p, d.use_xyz, d.radius_div, xyz, new_xyz,
@@ -526,7 +549,7 @@ int btr_sa_layer_forward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, cons
   const int cl = d.width[L - 1];
   unsigned char *arg = at_b(saved, p.arg);
   if (p.compact)
-    BTR_TRY(btr_sac_pool(d.b, d.m, cl, extg, exta, at_i(saved, p.goff), pscale, pshift, out,
+    BTR_TRY(btr_sac_pool(d.b, d.m, cl, extg, exta, cp.goff, pscale, pshift, out,
                          out_cl, arg, stream));
   else if (p.pool_epilogue)
     BTR_TRY(btr_sa_pool_fin(d.b, d.m, cl, extg, exta, pscale, pshift, out, out_cl, arg, stream));
@@ -535,12 +558,14 @@ int btr_sa_layer_forward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, cons
   return check_launch("sa_layer_forward");
 }
 
+extern "C" {
+
 int btr_sa_layer_backward(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp, const int *idx,
                           const float *out, const float *dout, void *saved, float *grads,
                           float *dfeat, float *dxyz, float *dnew_xyz, void *scratch,
                           btr_stream_t stream) {
   return sa_layer_backward_add(dp, pp, idx, out, dout, saved, grads, dfeat, dxyz, dnew_xyz,
-                               scratch, nullptr, 0, stream);
+                               scratch, nullptr, 0, nullptr, stream);
 }
 
 }  // extern "C"
@@ -549,7 +574,7 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
                                const float *out, const float *dout, void *saved, float *grads,
                                float *dfeat, float *dxyz, float *dnew_xyz, void *scratch,
                                const float *dfeat_add, long long dfeat_add_bstride,
-                               btr_stream_t stream) {
+                               const SaGeom *geom, btr_stream_t stream) {
   BTR_REQUIRE(dp && pp && idx && out && dout && saved && grads && scratch,
               "sa_layer_backward: null pointer");
   const btr_sa_layer_t &d = *dp;
@@ -559,11 +584,12 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   btr_sac_bind(nullptr);
   Unbind unbind;
   btr_compact_t cm{};
+  const CompactPtrs cp = compact_ptrs(p, saved, geom);
   if (p.compact) {
-    cm.dims = at_i(saved, p.dims);
-    cm.bw = at_f(saved, p.bw);
-    cm.bgrp = at_i(saved, p.bgrp);
-    cm.goff = at_i(saved, p.goff);
+    cm.dims = cp.dims;
+    cm.bw = cp.bw;
+    cm.bgrp = cp.bgrp;
+    cm.goff = cp.goff;
     cm.dense_rows = (double)R;
     btr_sac_bind(&cm);
   }
@@ -643,15 +669,19 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
         dy = g;
       } else {
         float *dfeat_cl = (d.need_dfeat && d.c > 0 && dfeat) ? at_f(scratch, sc.dfeat_cl) : nullptr;
-        void *ws2 = (char *)scratch + sc.scat;
+        // the inverted neighbour lists: prepared with the sampling, or built here
+        const bool pre = geom && geom->scatter_ws;
+        void *ws2 = pre ? geom->scatter_ws : (char *)scratch + sc.scat;
+        const int mode = pre ? kScatterReduce : kScatterBoth;
         if (p.compact) {
           if (dfeat_cl)
-            BTR_TRY(btr_sac_scatter(d.b, d.n, d.m, d.c, p.k0p, d.use_xyz, g, at_i(saved, p.cidx),
-                                    at_i(saved, p.goff), dfeat_cl, ws2, sc.scat_bytes, R, stream));
+            BTR_TRY(sac_scatter_ex(d.b, d.n, d.m, d.c, p.k0p, d.use_xyz, g, cp.cidx, cp.goff,
+                                   dfeat_cl, ws2, sc.scat_bytes, R, mode, hmain));
         } else {
-          BTR_TRY(btr_sa_scatter(d.b, d.n, d.m, d.s, d.c, p.k0p, d.use_xyz, d.radius_div, g, idx,
-                                 dfeat_cl, d.need_dxyz ? dxyz : nullptr,
-                                 d.need_dnew_xyz ? dnew_xyz : nullptr, ws2, sc.scat_bytes, stream));
+          BTR_TRY(sa_scatter_ex(d.b, d.n, d.m, d.s, d.c, p.k0p, d.use_xyz, d.radius_div, g, idx,
+                                dfeat_cl, d.need_dxyz ? dxyz : nullptr,
+                                d.need_dnew_xyz ? dnew_xyz : nullptr, ws2, sc.scat_bytes, mode,
+                                hmain));
         }
         if (dfeat_cl)
           BTR_TRY(pm_out_add(d.b, d.n, d.c, d.c, dfeat_cl, nullptr, nullptr, 0, dfeat, nullptr,

@@ -2312,40 +2312,54 @@ int btr_sa_scatter(int b, int n, int m, int s, int c, int ldx, int use_xyz, floa
                    const float *dx0, const int *idx, float *dfeat_cl, float *dxyz,
                    float *dnew_xyz, void *workspace, size_t workspace_bytes,
                    btr_stream_t stream) {
+  return sa_scatter_ex(b, n, m, s, c, ldx, use_xyz, radius_div, dx0, idx, dfeat_cl, dxyz,
+                       dnew_xyz, workspace, workspace_bytes, kScatterBoth, as_stream(stream));
+}
+
+}  // extern "C"
+
+int btr::sa_scatter_ex(int b, int n, int m, int s, int c, int ldx, int use_xyz, float radius_div,
+                       const float *dx0, const int *idx, float *dfeat_cl, float *dxyz,
+                       float *dnew_xyz, void *workspace, size_t workspace_bytes, int mode,
+                       hipStream_t st) {
   if (b <= 0 || m <= 0 || s <= 0 || n <= 0) return BTR_OK;
-  hipStream_t st = as_stream(stream);
   const long long ms = (long long)m * s;
   const float inv = radius_div != 0.f ? 1.0f / radius_div : 1.0f;
   const int xoff = use_xyz ? 3 : 0;
   if (!use_xyz) dxyz = dnew_xyz = nullptr;
   if (c <= 0) dfeat_cl = nullptr;
-  if (dfeat_cl || dxyz) {
+  if (dfeat_cl || dxyz || mode == kScatterBuild) {
     BTR_REQUIRE(workspace && workspace_bytes >= btr_sa_scatter_workspace_bytes(b, n, m, s),
                 "sa_scatter: workspace too small");
     int *cnt_off = (int *)workspace;
     int *cursor = cnt_off + (size_t)b * (n + 1);
     int *refs = cursor + (size_t)b * n;
-    if (n <= kCsrSmallN) {
-      hipLaunchKernelGGL(csr_small_kernel, dim3(b), dim3(1024), 0, st, ms, n, idx, cnt_off, refs);
-    } else {
-      hipError_t e = hipMemsetAsync(cnt_off, 0, sizeof(int) * (size_t)b * (n + 1), st);
-      if (e != hipSuccess) return fail((int)e, "sa_scatter memset: %s", hipGetErrorString(e));
-      const int gx = (int)std::min<long long>(cdiv(ms, 256), 1024);
-      hipLaunchKernelGGL(csr_count_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cnt_off);
-      hipLaunchKernelGGL(csr_scan_kernel, dim3(b), dim3(1024), 0, st, n, cnt_off, cursor);
-      hipLaunchKernelGGL(csr_fill_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cursor,
-                         refs);
+    if (mode != kScatterReduce) {
+      if (n <= kCsrSmallN) {
+        hipLaunchKernelGGL(csr_small_kernel, dim3(b), dim3(1024), 0, st, ms, n, idx, cnt_off, refs);
+      } else {
+        hipError_t e = hipMemsetAsync(cnt_off, 0, sizeof(int) * (size_t)b * (n + 1), st);
+        if (e != hipSuccess) return fail((int)e, "sa_scatter memset: %s", hipGetErrorString(e));
+        const int gx = (int)std::min<long long>(cdiv(ms, 256), 1024);
+        hipLaunchKernelGGL(csr_count_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cnt_off);
+        hipLaunchKernelGGL(csr_scan_kernel, dim3(b), dim3(1024), 0, st, n, cnt_off, cursor);
+        hipLaunchKernelGGL(csr_fill_kernel, dim3(gx, b), dim3(256), 0, st, ms, n, idx, cursor,
+                           refs);
+      }
     }
-    hipLaunchKernelGGL(csr_reduce_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, st, n, ms, c, ldx,
-                       xoff, inv, dx0, cnt_off, refs, dfeat_cl, dxyz);
+    if (mode != kScatterBuild)
+      hipLaunchKernelGGL(csr_reduce_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, st, n, ms, c, ldx,
+                         xoff, inv, dx0, cnt_off, refs, dfeat_cl, dxyz);
   }
-  if (dnew_xyz) {
+  if (dnew_xyz && mode != kScatterBuild) {
     const long long groups = (long long)b * m;
     hipLaunchKernelGGL(centre_grad_kernel, dim3(cdiv(groups * 3, 256)), dim3(256), 0, st, groups,
                        s, ldx, inv, dx0, dnew_xyz);
   }
   return check_launch("sa_scatter");
 }
+
+extern "C" {
 
 // ------------------------------------------------------------------ compact rows (see above)
 void btr_sac_bind(const btr_compact_t *cm) {
@@ -2414,19 +2428,31 @@ size_t btr_sac_scatter_workspace_bytes(int b, int n, int max_rows) {
 int btr_sac_scatter(int b, int n, int m, int c, int ldx, int use_xyz, const float *dx0,
                     const int *cidx, const int *goff, float *dfeat_cl, void *workspace,
                     size_t workspace_bytes, int max_rows, btr_stream_t stream) {
+  return sac_scatter_ex(b, n, m, c, ldx, use_xyz, dx0, cidx, goff, dfeat_cl, workspace,
+                        workspace_bytes, max_rows, kScatterBoth, as_stream(stream));
+}
+
+}  // extern "C"
+
+int btr::sac_scatter_ex(int b, int n, int m, int c, int ldx, int use_xyz, const float *dx0,
+                        const int *cidx, const int *goff, float *dfeat_cl, void *workspace,
+                        size_t workspace_bytes, int max_rows, int mode, hipStream_t st) {
   if (b <= 0 || m <= 0 || n <= 0 || c <= 0) return BTR_OK;
-  BTR_REQUIRE(dx0 && cidx && goff && dfeat_cl && workspace &&
+  BTR_REQUIRE(cidx && goff && workspace && (mode == kScatterBuild || (dx0 && dfeat_cl)) &&
                   workspace_bytes >= btr_sac_scatter_workspace_bytes(b, n, max_rows),
               "sac_scatter: null pointer or workspace too small");
   BTR_REQUIRE(n <= kCsrSmallN, "sac_scatter: %d points per batch element > %d", n, kCsrSmallN);
-  hipStream_t st = as_stream(stream);
   int *off = (int *)workspace;
   int *refs = off + (size_t)b * (n + 1);
-  hipLaunchKernelGGL(sac_csr_kernel, dim3(b), dim3(1024), 0, st, m, n, cidx, goff, off, refs);
-  hipLaunchKernelGGL(sac_reduce_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, st, n, c, ldx,
-                     use_xyz ? 3 : 0, dx0, off, refs, dfeat_cl);
+  if (mode != kScatterReduce)
+    hipLaunchKernelGGL(sac_csr_kernel, dim3(b), dim3(1024), 0, st, m, n, cidx, goff, off, refs);
+  if (mode != kScatterBuild)
+    hipLaunchKernelGGL(sac_reduce_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, st, n, c, ldx,
+                       use_xyz ? 3 : 0, dx0, off, refs, dfeat_cl);
   return check_launch("sac_scatter");
 }
+
+extern "C" {
 
 // ------------------------------------------------------------- point-wise MLP chains (pm)
 int btr_pm_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, 64), 512)); }

@@ -231,7 +231,10 @@ class BackbonePlan(ctypes.Structure):
     _fields_ = [("sa", SaPlan * 4), ("fp", PmPlan * 4), ("g_xyz", _sz), ("g_feat", _sz),
                 ("g_inds", _sz4), ("g_new_xyz", _sz4), ("g_idx", _sz4), ("g_fps_ws", _sz4),
                 ("g_fps_ws_bytes", _sz4), ("g_fps_temp", _sz4), ("bq_buckets", _ci4),
-                ("g_nn_idx", _sz4), ("g_nn_w", _sz4), ("g_ws", _sz), ("g_ws_bytes", _sz),
+                ("g_nn_idx", _sz4), ("g_nn_w", _sz4), ("g_goff", _sz4), ("g_dims", _sz4),
+                ("g_cidx", _sz4), ("g_bgrp", _sz4), ("g_bw", _sz4), ("g_len", _sz4),
+                ("g_scat", _sz4), ("g_scat_bytes", _sz4), ("g_ti", _sz4), ("g_ti_bytes", _sz4),
+                ("g_ws", _sz), ("g_ws_bytes", _sz),
                 ("geom_bytes", _sz), ("o_sa", _sz4), ("o_sa_cl", _sz4), ("o_fp", _sz4),
                 ("o_fp_cl", _sz4), ("out_bytes", _sz), ("s_sa", _sz4), ("s_fp", _sz4),
                 ("s_fpx", _sz4), ("saved_bytes", _sz), ("fwd_scratch_bytes", _sz),

@@ -567,6 +567,13 @@ typedef struct {
   size_t g_fps_ws[BTR_MAX_LEVELS], g_fps_ws_bytes[BTR_MAX_LEVELS], g_fps_temp[BTR_MAX_LEVELS];
   int bq_buckets[BTR_MAX_LEVELS];      /* ball query over the FPS's spatial sort                */
   size_t g_nn_idx[BTR_MAX_LEVELS], g_nn_w[BTR_MAX_LEVELS];
+  /* prepared with the sampling for forward / backward: the compact-row plans (compact levels)
+   * and the filled inverted neighbour lists of the input-gradient scatters / of the 3-NN
+   * gradient (0 bytes: not needed) */
+  size_t g_goff[BTR_MAX_LEVELS], g_dims[BTR_MAX_LEVELS], g_cidx[BTR_MAX_LEVELS],
+      g_bgrp[BTR_MAX_LEVELS], g_bw[BTR_MAX_LEVELS], g_len[BTR_MAX_LEVELS];
+  size_t g_scat[BTR_MAX_LEVELS], g_scat_bytes[BTR_MAX_LEVELS];
+  size_t g_ti[BTR_MAX_LEVELS], g_ti_bytes[BTR_MAX_LEVELS];
   size_t g_ws, g_ws_bytes, geom_bytes;
   /* output arena */
   size_t o_sa[BTR_MAX_LEVELS], o_sa_cl[BTR_MAX_LEVELS], o_fp[BTR_MAX_LEVELS],
