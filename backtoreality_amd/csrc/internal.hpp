@@ -24,6 +24,12 @@ int ti_grad_lists(int b, int c, int n, int m, const float *grad_out, long long g
 // query call of this host thread records around its launches
 hipEvent_t *bq_call_events();
 
+// sa_mlp.hip: between begin and flush the split-K reductions of the btr_sa_gemm_tn* calls of
+// this host thread are collected and issued as ONE launch by the flush, on `stream` (all of
+// them must have been issued on that stream, each with its own partials buffer)
+void reduce_batch_begin();
+void reduce_batch_flush(hipStream_t stream);
+
 // sa_mlp.hip: btr_sa_scatter / btr_sac_scatter split in two: the inverted neighbour lists only
 // depend on the ball-query result, so a caller that has it early (btr_backbone_sampling) builds
 // them ahead (mode 1) and the backward only reduces (mode 2); mode 0 = both, as the C entry points.

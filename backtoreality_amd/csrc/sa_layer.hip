@@ -305,6 +305,18 @@ SideStream *wgrad_side(hipStream_t main) {
 struct Unbind {
   ~Unbind() { btr_sac_bind(nullptr); }
 };
+// collects the split-K reductions of the TN GEMMs issued in its scope (see reduce_batch_begin);
+// flushes on every exit path
+struct ReduceBatchScope {
+  hipStream_t st;
+  bool open = true;
+  explicit ReduceBatchScope(hipStream_t s) : st(s) { reduce_batch_begin(); }
+  void flush() {
+    if (open) reduce_batch_flush(st);
+    open = false;
+  }
+  ~ReduceBatchScope() { flush(); }
+};
 
 #define BTR_TRY(call)            \
   do {                           \
@@ -323,7 +335,7 @@ struct SaFwdScratch {
   size_t part, len_tmp, extg, exta, bytes;
 };
 struct SaBwdScratch {
-  size_t part, m1, m2, dcl, alpha, beta, pw, pw0, g[2], scat, dfeat_cl, bytes;
+  size_t part, m1, m2, dcl, alpha, beta, pw[kMaxL], pw0, g[2], scat, dfeat_cl, bytes;
   size_t scat_bytes;
 };
 
@@ -347,12 +359,9 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   SaBwdScratch s{};
   Bump b;
   int maxc = 0, maxk = 0;
-  size_t pw = 0;
   for (int l = 0; l < d.layers; ++l) {
     maxc = std::max(maxc, d.width[l]);
     maxk = std::max(maxk, p.kin[l]);
-    pw = std::max(pw, (size_t)btr_sa_gemm_tn_chunks(p.rows, d.width[l], p.kin[l]) * d.width[l] *
-                          p.kin[l]);
   }
   const size_t pw0 = p.recompute ? (size_t)btr_sa_rc_wgrad_blocks(p.rows, d.width[0]) * d.width[0] * 4 : 0;
   const int cl = d.width[d.layers - 1];
@@ -362,7 +371,10 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   s.dcl = b.floats((size_t)d.b * d.m * cl);
   s.alpha = b.floats(cl);
   s.beta = b.floats(cl);
-  s.pw = b.floats(pw);
+  // split-K partials: one region per layer (their reductions are issued together at the end)
+  for (int l = 0; l < d.layers; ++l)
+    s.pw[l] = b.floats((size_t)btr_sa_gemm_tn_chunks(p.rows, d.width[l], p.kin[l]) * d.width[l] *
+                       p.kin[l]);
   s.pw0 = b.floats(pw0);   // (first-layer recompute: its partials, written on the main stream)
   s.g[0] = b.floats((size_t)p.rows * maxk);
   s.g[1] = b.floats((size_t)p.rows * maxk);
@@ -595,7 +607,7 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   }
   float *part = at_f(scratch, sc.part), *m1 = at_f(scratch, sc.m1), *m2 = at_f(scratch, sc.m2);
   float *dcl = at_f(scratch, sc.dcl), *alpha = at_f(scratch, sc.alpha);
-  float *beta = at_f(scratch, sc.beta), *pw = at_f(scratch, sc.pw);
+  float *beta = at_f(scratch, sc.beta);
   float *x0 = at_f(saved, p.x0);
   const unsigned char *arg = at_b(saved, p.arg);
   auto stat = [&](int l, int which) { return at_f(saved, p.stats[l]) + which * d.width[l]; };
@@ -617,6 +629,8 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   hipStream_t hmain = as_stream(stream);
   SideStream *side = wgrad_side(hmain);
   int last_done = -1;
+  // the layers' split-K reductions: ONE launch behind the last TN GEMM, on the stream they ran on
+  ReduceBatchScope batch(side ? side->s : hmain);
   for (int l = L - 1; l >= 0; --l) {
     const int nl = d.width[l], k = p.kin[l];
     const float *xsrc = l == 0 ? x0 : at_f(saved, p.y[l - 1]);
@@ -626,6 +640,7 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     const bool pooled = p.pool_grad && l == L - 1;
     if (p.recompute && l == 0) break;  // finished by btr_sa_bn_relu_bwd_rc below
     float *dw = grads + p.dw[l];
+    float *pw = at_f(scratch, sc.pw[l]);
     // weight gradient of layer l: dY_l is final here -> fork
     btr_stream_t ws = stream;
     if (side) {
@@ -689,7 +704,11 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       }
     }
   }
-  if (side && last_done >= 0) (void)hipStreamWaitEvent(hmain, side->done[last_done], 0);   // join
+  batch.flush();
+  if (side && last_done >= 0) {   // join
+    (void)hipEventRecord(side->done[kMaxL], side->s);
+    (void)hipStreamWaitEvent(hmain, side->done[kMaxL], 0);
+  }
   return check_launch("sa_layer_backward");
 }
 
@@ -698,25 +717,22 @@ extern "C" {
 // ================================================================== point-wise MLP chains
 namespace {
 struct PmBwdScratch {
-  size_t g[2], part, m1, m2, pw, bytes;
+  size_t g[2], part, m1, m2, pw[kMaxL], colsum, bytes;
 };
 PmBwdScratch pm_bwd_scratch(const btr_pm_chain_t &d, const btr_pm_plan_t &p) {
   PmBwdScratch s{};
   Bump b;
   int maxc = 0;
-  size_t pw = 0;
-  for (int l = 0; l < d.layers; ++l) {
-    maxc = std::max(maxc, std::max(p.np[l], p.kin[l]));
-    pw = std::max(pw, (size_t)btr_sa_gemm_tn_chunks(p.rows, p.np[l], p.kin[l]) * p.np[l] *
-                          p.kin[l]);
-  }
-  pw = std::max(pw, (size_t)cdiv(p.rows, kColsumRows) * p.np[d.layers - 1]);  // colsum partials
+  for (int l = 0; l < d.layers; ++l) maxc = std::max(maxc, std::max(p.np[l], p.kin[l]));
   s.g[0] = b.floats((size_t)p.rows * maxc);
   s.g[1] = b.floats((size_t)p.rows * maxc);
   s.part = b.floats((size_t)1024 * 2 * maxc);
   s.m1 = b.floats(maxc);
   s.m2 = b.floats(maxc);
-  s.pw = b.floats(pw);
+  for (int l = 0; l < d.layers; ++l)   // split-K partials, one region per layer
+    s.pw[l] = b.floats((size_t)btr_sa_gemm_tn_chunks(p.rows, p.np[l], p.kin[l]) * p.np[l] *
+                       p.kin[l]);
+  s.colsum = b.floats((size_t)cdiv(p.rows, kColsumRows) * p.np[d.layers - 1]);
   s.bytes = b.off;
   return s;
 }
@@ -868,7 +884,7 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
   hipStream_t hs = as_stream(stream);
   const PmBwdScratch sc = pm_bwd_scratch(d, p);
   float *part = at_f(scratch, sc.part), *m1 = at_f(scratch, sc.m1), *m2 = at_f(scratch, sc.m2);
-  float *pw = at_f(scratch, sc.pw);
+  float *colsum = at_f(scratch, sc.colsum);
   auto stat = [&](int l, int which) { return at_f(saved, p.stats[l]) + which * p.np[l]; };
   {  // bias gradients: zero in front of a BatchNorm (and the padding of the others)
     hipError_t e = hipMemsetAsync(grads + p.dbias[0], 0,
@@ -887,13 +903,14 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
   } else if (d.bias[L - 1]) {
     const int chunks = cdiv(rows, kColsumRows);
     hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(npl, 64), chunks), dim3(256), 0, hs, rows,
-                       npl, npl, g, pw);
+                       npl, npl, g, colsum);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(npl, 256)), dim3(256), 0, hs, chunks, npl,
-                       pw, grads + p.dbias[L - 1]);
+                       colsum, grads + p.dbias[L - 1]);
   }
   float *dy = g;
   SideStream *side = wgrad_side(hs);
   int last_done = -1;
+  ReduceBatchScope batch(side ? side->s : hs);   // (see btr_sa_layer_backward)
   for (int l = L - 1; l >= 0; --l) {
     const int np = p.np[l], k = p.kin[l];
     const float *xsrc = l == 0 ? (x_cl ? x_cl : at_f(saved, p.x0)) : at_f(saved, p.y[l - 1]);
@@ -906,7 +923,8 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
       (void)hipStreamWaitEvent(side->s, side->ready[l], 0);
       ws = (btr_stream_t)side->s;
     }
-    BTR_TRY(btr_sa_gemm_tn(rows, np, k, dy, np, xsrc, ldx, pa, pb, pw, grads + p.dw[l], ws));
+    BTR_TRY(btr_sa_gemm_tn(rows, np, k, dy, np, xsrc, ldx, pa, pb, at_f(scratch, sc.pw[l]),
+                           grads + p.dw[l], ws));
     if (side) {
       (void)hipEventRecord(side->done[l], side->s);
       last_done = l;
@@ -929,7 +947,11 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
       }
     }
   }
-  if (side && last_done >= 0) (void)hipStreamWaitEvent(hs, side->done[last_done], 0);   // join
+  batch.flush();
+  if (side && last_done >= 0) {   // join
+    (void)hipEventRecord(side->done[kMaxL], side->s);
+    (void)hipStreamWaitEvent(hs, side->done[kMaxL], 0);
+  }
   return check_launch("pm_chain_backward");
 }
 

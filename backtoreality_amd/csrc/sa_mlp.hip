@@ -1386,6 +1386,94 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(int total, int chunk
   }
 }
 
+// The same reduction for SEVERAL weight gradients in one launch: a layer call's TN GEMMs all
+// run on the weight-gradient stream and nothing reads a dW before the call returns, so their
+// split-K reductions are collected (reduce_batch) and issued once, behind the last GEMM -- one
+// launch per call instead of one per layer (25 -> 9 per training step).  Same summation order
+// per element as reduce_chunks_kernel<16, 16>.
+constexpr int kMaxReduceSeg = 12;
+struct ReduceArgs {
+  const float *pw[kMaxReduceSeg];
+  float *dw[kMaxReduceSeg];
+  int total[kMaxReduceSeg], chunks[kMaxReduceSeg], first[kMaxReduceSeg + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) {
+  __shared__ double red[16][17];
+  // the segment of this block: unrolled scan with STATIC indices (see prep_weights_kernel)
+  const float *pw = a.pw[0];
+  float *dw = a.dw[0];
+  int total = a.total[0], chunks = a.chunks[0], first = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxReduceSeg; ++i)
+    if (i < a.n && (int)blockIdx.x >= a.first[i]) {
+      pw = a.pw[i]; dw = a.dw[i]; total = a.total[i]; chunks = a.chunks[i]; first = a.first[i];
+    }
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  const int i = ((int)blockIdx.x - first) * 16 + tx;
+  double s = 0.0;
+  if (i < total)
+#pragma unroll 8
+    for (int c = ty; c < chunks; c += 16) s += (double)pw[(size_t)c * total + i];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < total) {
+    s = 0.0;
+    for (int y0 = 0; y0 < 16; y0 += 8) {
+      double acc = 0.0;
+#pragma unroll
+      for (int y = 0; y < 8; ++y) acc += red[y0 + y][tx];
+      s += acc;
+    }
+    dw[i] = (float)s;
+  }
+}
+
+struct ReduceBatch {
+  ReduceArgs args;
+  bool on = false;
+};
+inline ReduceBatch &reduce_batch() {
+  static thread_local ReduceBatch b;
+  return b;
+}
+// dw = sum over chunks of pw: now, or with the batch of the running layer call
+inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *dw,
+                                 hipStream_t st) {
+  ReduceBatch &b = reduce_batch();
+  if (b.on && b.args.n < kMaxReduceSeg) {
+    ReduceArgs &a = b.args;
+    a.pw[a.n] = pw;
+    a.dw[a.n] = dw;
+    a.total[a.n] = total;
+    a.chunks[a.n] = chunks;
+    a.first[a.n + 1] = a.first[a.n] + cdiv(total, 16);
+    ++a.n;
+    return;
+  }
+  if (total <= 1024 && chunks >= 64)
+    hipLaunchKernelGGL((reduce_chunks_kernel<4, 64>), dim3(cdiv(total, 4)), dim3(256), 0, st,
+                       total, chunks, pw, dw);
+  else
+    hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(total, 16)), dim3(256), 0, st,
+                       total, chunks, pw, dw);
+}
+// (internal.hpp) collect the split-K reductions issued on this host thread until the flush
+void reduce_batch_begin() {
+  ReduceBatch &b = reduce_batch();
+  b.on = true;
+  b.args.n = 0;
+  b.args.first[0] = 0;
+}
+void reduce_batch_flush(hipStream_t st) {
+  ReduceBatch &b = reduce_batch();
+  b.on = false;
+  if (b.args.n > 0)
+    hipLaunchKernelGGL(reduce_chunks_multi_kernel, dim3(b.args.first[b.args.n]), dim3(256), 0, st,
+                       b.args);
+  b.args.n = 0;
+}
+
 // ------------------------------------------------------------- scatter of dX0 (layer-0 dgrad)
 // dX0[r][c] -> c < 3: d xyz[b, idx, c] += v/radius, d new_xyz[b, m, c] -= v/radius;
 // c >= 3: d features[b, idx, c-3] += v.  Instead of float atomics on (B,C,N) (what
@@ -2171,12 +2259,7 @@ int btr_sa_gemm_tn_rc(int rows, int n, int k, const float *g, int ldg, const flo
                        4, rows, n, k, pa, pb, rpc, pw, (const unsigned char *)nullptr,
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
                        w0, cur_compact());
-  if (n * k <= 1024 && chunks >= 64)
-    hipLaunchKernelGGL((reduce_chunks_kernel<4, 64>), dim3(cdiv(n * k, 4)), dim3(256), 0, st,
-                       n * k, chunks, pw, dw);
-  else
-    hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(n * k, 16)), dim3(256), 0, st,
-                       n * k, chunks, pw, dw);
+  reduce_chunks_launch(n * k, chunks, pw, dw, st);
   return check_launch("sa_gemm_tn_rc");
 }
 
@@ -2255,12 +2338,7 @@ int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float 
     if (pa) BTR_TN(2, true); else BTR_TN(2, false);
   }
 #undef BTR_TN
-  if (n * k <= 1024 && chunks >= 64)
-    hipLaunchKernelGGL((reduce_chunks_kernel<4, 64>), dim3(cdiv(n * k, 4)), dim3(256), 0, st,
-                       n * k, chunks, pw, dw);
-  else
-    hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(n * k, 16)), dim3(256), 0, st,
-                       n * k, chunks, pw, dw);
+  reduce_chunks_launch(n * k, chunks, pw, dw, st);
   return check_launch("sa_gemm_tn");
 }
 
@@ -2292,12 +2370,7 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
     if (pa) BTR_TNP(2, true); else BTR_TNP(2, false);
   }
 #undef BTR_TNP
-  if (n * k <= 1024 && chunks >= 64)
-    hipLaunchKernelGGL((reduce_chunks_kernel<4, 64>), dim3(cdiv(n * k, 4)), dim3(256), 0, st,
-                       n * k, chunks, pw, dw);
-  else
-    hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(n * k, 16)), dim3(256), 0, st,
-                       n * k, chunks, pw, dw);
+  reduce_chunks_launch(n * k, chunks, pw, dw, st);
   return check_launch("sa_gemm_tn_pool");
 }
 

@@ -302,3 +302,37 @@ def test_decoded_end_points_are_lazy_but_look_complete():
     with __import__('pytest').raises(KeyError):
         DecodedEndPoints({}, decode)['nonsense']
     assert calls.count(1) == 7
+
+
+@pytest.mark.gpu
+def test_fast_adam_equals_torch_adam(cuda):
+    """train.FastAdam = torch.optim.Adam(fused=True) minus the per-step Python bookkeeping:
+    identical parameters / state after several steps (one parameter without a gradient, a
+    learning-rate change, a state_dict round trip)."""
+    import copy
+    from backtoreality_amd.votenet import train
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4),
+                              torch.nn.Linear(4, 4)).to(cuda)      # [3] never used: no gradient
+    ref = copy.deepcopy(net)
+    fast = train.make_optimizer(net, lr=1e-3)
+    assert isinstance(fast, train.FastAdam)
+    slow = torch.optim.Adam(ref.parameters(), lr=1e-3, fused=True)
+    x = torch.randn(8, 16, device=cuda)
+    for i in range(6):
+        if i == 3:
+            train.adjust_learning_rate(fast, 90)
+            train.adjust_learning_rate(slow, 90)
+            sd = copy.deepcopy(fast.state_dict())
+            assert all('_btr_fast' not in g for g in sd['param_groups'])
+            fast.load_state_dict(sd)
+        for m, o in ((net, fast), (ref, slow)):
+            o.zero_grad(set_to_none=True)
+            m[2](m[1](m[0](x))).square().sum().backward()
+            o.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(a, b)
+    for a, b in zip(net.parameters(), ref.parameters()):
+        if a in fast.state and fast.state[a]:
+            assert torch.equal(fast.state[a]['exp_avg_sq'], slow.state[b]['exp_avg_sq'])
+            assert float(fast.state[a]['step']) == float(slow.state[b]['step']) == 6
