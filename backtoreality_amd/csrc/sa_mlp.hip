@@ -1357,6 +1357,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
   }
 }
 
+// (A bf16x6 form of this kernel was built and measured: the reduction runs over ROWS, so the
+// MFMA operands want 8 consecutive rows of one column.  Staging the tiles transposed with one
+// column per thread makes the LDS side plain 16-byte stores but turns the global side into
+// 4-byte loads -- 96 instead of 24 vector-memory instructions per workgroup and 32-row step,
+// and the CU's address unit, not the matrix pipe, set the pace: 78 -> 136 us on
+// 114 624 x 128 x 132, 75 -> 127 us on 65 536 x 128 x 260.  The f32-input kernel stays.)
 // dw[i] = sum over chunks of pw[chunk][i], fixed order; EL elements x SL chunk slices per block
 // (4 x 64 for the small weight matrices, whose launches are latency-bound; 16 x 16 keeps the
 // reads of the large ones coalesced).
@@ -1966,6 +1972,8 @@ inline HostCompact &host_compact() {
 }
 inline Compact cur_compact() { return host_compact().on ? host_compact().dev : Compact{}; }
 
+#define BTR_TN_KERNEL(W, P, GP, XR) (gemm_tn_kernel<W, P, GP, XR>)
+
 // BTR_GEMM=f32: the f32-input MFMA kernels (v_mfma_f32_32x32x2_f32) instead of bf16x6
 inline bool gemm_x6() {
   static const bool on = !(getenv("BTR_GEMM") && getenv("BTR_GEMM")[0] == 'f');
@@ -2250,12 +2258,12 @@ int btr_sa_gemm_tn_rc(int rows, int n, int k, const float *g, int ldg, const flo
   const int tn = tn_tile_n(n);
   const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
   if (tn == 128)
-    hipLaunchKernelGGL((gemm_tn_kernel<4, true, false, true>), grid, dim3(256), 0, st, g, ldg, x0,
+    hipLaunchKernelGGL(BTR_TN_KERNEL(4, true, false, true), grid, dim3(256), 0, st, g, ldg, x0,
                        4, rows, n, k, pa, pb, rpc, pw, (const unsigned char *)nullptr,
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
                        w0, cur_compact());
   else
-    hipLaunchKernelGGL((gemm_tn_kernel<2, true, false, true>), grid, dim3(256), 0, st, g, ldg, x0,
+    hipLaunchKernelGGL(BTR_TN_KERNEL(2, true, false, true), grid, dim3(256), 0, st, g, ldg, x0,
                        4, rows, n, k, pa, pb, rpc, pw, (const unsigned char *)nullptr,
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
                        w0, cur_compact());
@@ -2328,7 +2336,7 @@ int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float 
   const int tn = tn_tile_n(n);
   const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
 #define BTR_TN(W, P)                                                                          \
-  hipLaunchKernelGGL((gemm_tn_kernel<W, P>), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n, \
+  hipLaunchKernelGGL(BTR_TN_KERNEL(W, P, false, false), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n, \
                      k, pa, pb, rpc, pw, (const unsigned char *)nullptr, (const float *)nullptr, \
                      (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr, \
                      cur_compact())
@@ -2361,7 +2369,7 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
   const int tn = tn_tile_n(n);
   const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
 #define BTR_TNP(W, P)                                                                         \
-  hipLaunchKernelGGL((gemm_tn_kernel<W, P, true>), grid, dim3(256), 0, st, y, ldy, x, ldx,    \
+  hipLaunchKernelGGL(BTR_TN_KERNEL(W, P, true, false), grid, dim3(256), 0, st, y, ldy, x, ldx,    \
                      rows, n, k, pa, pb, rpc, pw, arg, dcl, alpha, beta, ssh,                 \
                      (const float *)nullptr, cur_compact())
   if (tn == 128) {
