@@ -26,6 +26,7 @@
 // the three kernels; `seed` is a host value unique per call, `step` an optional device counter
 // (so a replayed HIP graph draws new masks every replay).
 #include "common.hpp"
+#include "internal.hpp"
 
 namespace btr {
 namespace {
@@ -36,7 +37,8 @@ struct AttnArgs {
   long long q_sl, q_sb;
   const float *k, *v;
   long long kv_sl, kv_sb;
-  float *out;          // (lq, b, h*d)
+  float *out;          // out[l][b][h*d + c] at out + l*o_sl + b*o_sb (dout alike)
+  long long o_sl, o_sb;
   float *lse;          // (b*h, lq)
   const float *dout;   // (lq, b, h*d)
   float *dsum;         // (b*h, lq): rowsum(dO * O)
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
   }
   if (i < a.lq) {
     const float inv = 1.f / L;
-    float *op = a.out + ((long long)i * a.b + b) * ((long long)a.h * a.d) + (long long)h * a.d;
+    float *op = a.out + (long long)i * a.o_sl + (long long)b * a.o_sb + (long long)h * a.d;
     for (int c = sub; c < a.d; c += 8) {
       float acc = 0.f;
 #pragma unroll
@@ -324,7 +326,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.h, h = bh - b * a.h;
   const int q0 = blockIdx.x * kMT;
-  const long long e = (long long)a.h * a.d;
   const float *qp = a.q + (long long)b * a.q_sb + (long long)h * a.d;
   const float *kp = a.k + (long long)b * a.kv_sb + (long long)h * a.d;
   const float *vp = a.v + (long long)b * a.kv_sb + (long long)h * a.d;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   for (int kk = 0; kk < KS; ++kk) {
     const int c = 2 * kk + hh;
     const bool ok = live && c < a.d;
-    const long long o_at = ((long long)qi * a.b + b) * e + (long long)h * a.d + c;
+    const long long o_at = (long long)qi * a.o_sl + (long long)b * a.o_sb + (long long)h * a.d + c;
     qf[kk] = ok ? qp[(long long)qi * a.q_sl + c] : 0.f;
     dof[kk] = ok ? a.dout[o_at] : 0.f;
     dsum = fmaf(dof[kk], ok ? a.out[o_at] : 0.f, dsum);
@@ -432,11 +433,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.h, h = bh - b * a.h;
   const int j0 = blockIdx.x * kMT;
-  const long long e = (long long)a.h * a.d;
   const float *qp = a.q + (long long)b * a.q_sb + (long long)h * a.d;
   const float *kp = a.k + (long long)b * a.kv_sb + (long long)h * a.d;
   const float *vp = a.v + (long long)b * a.kv_sb + (long long)h * a.d;
-  const float *dop = a.dout + (long long)b * e + (long long)h * a.d;   // row stride b * e
+  const float *dop = a.dout + (long long)b * a.o_sb + (long long)h * a.d;   // row stride o_sl
   const unsigned long long key = drop_key(a);
   float *Qt = smem + w * WAVE_F, *Ot = Qt + kMT * LDT, *Ls = Ot + kMT * LDT, *Ds = Ls + 32;
   for (int i = lane; i < 2 * kMT * LDT; i += 64) Qt[i] = 0.f;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   const TileMap tm = tile_map(a.d, lane);
   if (w < ntiles) {
     tile_fetch<VEC>(qt, tm, qp, a.q_sl, w * kMT, a.lq, a.d, lane);
-    tile_fetch<VEC>(ot, tm, dop, (long long)a.b * e, w * kMT, a.lq, a.d, lane);
+    tile_fetch<VEC>(ot, tm, dop, a.o_sl, w * kMT, a.lq, a.d, lane);
   }
   for (int tile = w; tile < ntiles; tile += 4) {
     const int q0 = tile * kMT;
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
     }
     if (tile + 4 < ntiles) {
       tile_fetch<VEC>(qt, tm, qp, a.q_sl, q0 + 4 * kMT, a.lq, a.d, lane);
-      tile_fetch<VEC>(ot, tm, dop, (long long)a.b * e, q0 + 4 * kMT, a.lq, a.d, lane);
+      tile_fetch<VEC>(ot, tm, dop, a.o_sl, q0 + 4 * kMT, a.lq, a.d, lane);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -545,7 +545,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
 bool vec_ok(const AttnArgs &a) {
   auto al = [](const void *p) { return p == nullptr || ((size_t)p & 15) == 0; };
   return a.d % 4 == 0 && a.q_sl % 4 == 0 && a.q_sb % 4 == 0 && a.kv_sl % 4 == 0 &&
-         a.kv_sb % 4 == 0 && al(a.q) && al(a.k) && al(a.v) && al(a.dout) && al(a.out);
+         a.kv_sb % 4 == 0 && a.o_sl % 4 == 0 && a.o_sb % 4 == 0 && al(a.q) && al(a.k) &&
+         al(a.v) && al(a.dout) && al(a.out);
 }
 
 int fill_dropout(AttnArgs &a, float p) {
@@ -574,6 +575,18 @@ int btr_attention_fwd(int lq, int lk, int b, int h, int d, const float *q, long 
                       long long q_sb, const float *k, const float *v, long long kv_sl,
                       long long kv_sb, float *out, float *lse, float scale, float dropout_p,
                       unsigned long long seed, const long long *step, btr_stream_t stream) {
+  return attention_fwd_strided(lq, lk, b, h, d, q, q_sl, q_sb, k, v, kv_sl, kv_sb, out,
+                               (long long)b * h * d, (long long)h * d, lse, scale, dropout_p,
+                               seed, step, stream);
+}
+}  // extern "C"
+
+int btr::attention_fwd_strided(int lq, int lk, int b, int h, int d, const float *q,
+                               long long q_sl, long long q_sb, const float *k, const float *v,
+                               long long kv_sl, long long kv_sb, float *out, long long o_sl,
+                               long long o_sb, float *lse, float scale, float dropout_p,
+                               unsigned long long seed, const long long *step,
+                               btr_stream_t stream) {
   if (lq <= 0 || b <= 0 || h <= 0) return BTR_OK;
   BTR_REQUIRE(q && k && v && out && lse && lk > 0 && btr_attention_supported(d),
               "attention_fwd: null pointer, no keys or head width %d not in 1..64", d);
@@ -582,7 +595,7 @@ int btr_attention_fwd(int lq, int lk, int b, int h, int d, const float *q, long 
   a.lq = lq; a.lk = lk; a.b = b; a.h = h; a.d = d;
   a.q = q; a.q_sl = q_sl; a.q_sb = q_sb;
   a.k = k; a.v = v; a.kv_sl = kv_sl; a.kv_sb = kv_sb;
-  a.out = out; a.lse = lse; a.scale = scale; a.seed = seed; a.step = step;
+  a.out = out; a.o_sl = o_sl; a.o_sb = o_sb; a.lse = lse; a.scale = scale; a.seed = seed; a.step = step;
   if (int rc = fill_dropout(a, dropout_p)) return rc;
   const dim3 grid(cdiv(lq, kMT), b * h);
   hipStream_t s = as_stream(stream);
@@ -603,12 +616,30 @@ int btr_attention_fwd(int lq, int lk, int b, int h, int d, const float *q, long 
   }
 }
 
+extern "C" {
+
 int btr_attention_bwd(int lq, int lk, int b, int h, int d, const float *q, long long q_sl,
                       long long q_sb, const float *k, const float *v, long long kv_sl,
                       long long kv_sb, const float *out, const float *dout, const float *lse,
                       float *dsum, float *dq, long long dq_sl, long long dq_sb, float *dk,
                       float *dv, long long dkv_sl, long long dkv_sb, float scale, float dropout_p,
                       unsigned long long seed, const long long *step, btr_stream_t stream) {
+  return attention_bwd_strided(lq, lk, b, h, d, q, q_sl, q_sb, k, v, kv_sl, kv_sb, out, dout,
+                               (long long)b * h * d, (long long)h * d, lse, dsum, dq, dq_sl,
+                               dq_sb, dk, dv, dkv_sl, dkv_sb, scale, dropout_p, seed, step,
+                               stream);
+}
+}  // extern "C"
+
+int btr::attention_bwd_strided(int lq, int lk, int b, int h, int d, const float *q,
+                               long long q_sl, long long q_sb, const float *k, const float *v,
+                               long long kv_sl, long long kv_sb, const float *out,
+                               const float *dout, long long o_sl, long long o_sb,
+                               const float *lse, float *dsum, float *dq, long long dq_sl,
+                               long long dq_sb, float *dk, float *dv, long long dkv_sl,
+                               long long dkv_sb, float scale, float dropout_p,
+                               unsigned long long seed, const long long *step,
+                               btr_stream_t stream) {
   if (lq <= 0 || b <= 0 || h <= 0) return BTR_OK;
   BTR_REQUIRE(q && k && v && out && dout && lse && dsum && dq && dk && dv && lk > 0 &&
                   btr_attention_supported(d),
@@ -618,7 +649,7 @@ int btr_attention_bwd(int lq, int lk, int b, int h, int d, const float *q, long 
   a.lq = lq; a.lk = lk; a.b = b; a.h = h; a.d = d;
   a.q = q; a.q_sl = q_sl; a.q_sb = q_sb;
   a.k = k; a.v = v; a.kv_sl = kv_sl; a.kv_sb = kv_sb;
-  a.out = const_cast<float *>(out); a.lse = const_cast<float *>(lse); a.dout = dout;
+  a.out = const_cast<float *>(out); a.o_sl = o_sl; a.o_sb = o_sb; a.lse = const_cast<float *>(lse); a.dout = dout;
   a.dsum = dsum; a.dq = dq; a.dq_sl = dq_sl; a.dq_sb = dq_sb;
   a.dk = dk; a.dv = dv; a.dkv_sl = dkv_sl; a.dkv_sb = dkv_sb;
   a.scale = scale; a.seed = seed; a.step = step;
@@ -646,5 +677,3 @@ int btr_attention_bwd(int lq, int lk, int b, int h, int d, const float *q, long 
     return check_launch("attention_bwd");
   }
 }
-
-}  // extern "C"

@@ -63,4 +63,20 @@ int sa_layer_backward_add(const btr_sa_layer_t *d, const btr_sa_plan_t *plan, co
                           const float *dfeat_add, long long dfeat_add_bstride,
                           const SaGeom *geom, btr_stream_t stream);
 
+
+// attention.hip: btr_attention_fwd / _bwd with out / dout strided like q (out[l][b][.] at
+// out + l*o_sl + b*o_sb): the decoder layer keeps its rows batch-major
+int attention_fwd_strided(int lq, int lk, int b, int h, int d, const float *q, long long q_sl,
+                          long long q_sb, const float *k, const float *v, long long kv_sl,
+                          long long kv_sb, float *out, long long o_sl, long long o_sb,
+                          float *lse, float scale, float dropout_p, unsigned long long seed,
+                          const long long *step, btr_stream_t stream);
+int attention_bwd_strided(int lq, int lk, int b, int h, int d, const float *q, long long q_sl,
+                          long long q_sb, const float *k, const float *v, long long kv_sl,
+                          long long kv_sb, const float *out, const float *dout, long long o_sl,
+                          long long o_sb, const float *lse, float *dsum, float *dq,
+                          long long dq_sl, long long dq_sb, float *dk, float *dv,
+                          long long dkv_sl, long long dkv_sb, float scale, float dropout_p,
+                          unsigned long long seed, const long long *step, btr_stream_t stream);
+
 }  // namespace btr

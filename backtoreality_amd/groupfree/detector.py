@@ -3,11 +3,19 @@ attribute names (state-dict keys) and end_points keys."""
 import torch
 import torch.nn as nn
 
+from ..pointnet2 import fused_mlp
 from ..votenet.backbone_module import Pointnet2Backbone
 from ..votenet.votenet_da import grad_reverse
 from .modules import (FPSModule, GeneralSamplingModule, PointsObjClsModule,
                       PositionEmbeddingLearned, PredictHead)
 from .transformer import TransformerDecoderLayer
+
+
+def _project(conv, x):
+    """A bare 1x1 Conv1d; on the GPU through the point-wise chain kernels, whose result carries
+    the channel-last rows the decoder layers read."""
+    out = fused_mlp.run_chain(x, [(conv, None, False)])
+    return out if out is not None else conv(x)
 
 
 class GroupFreeDetector(nn.Module):
@@ -121,8 +129,8 @@ class GroupFreeDetector(nn.Module):
         if self.num_decoder_layers <= 0:
             return self._finish(end_points)
 
-        query = self.decoder_query_proj(cluster_feature)
-        key = self.decoder_key_proj(points_features)
+        query = _project(self.decoder_query_proj, cluster_feature)
+        key = _project(self.decoder_key_proj, points_features)
         key_pos = None if self.cross_position_embedding == 'none' else points_xyz
         for i in range(self.num_decoder_layers):
             prefix = 'last_' if i == self.num_decoder_layers - 1 else '%dhead_' % i

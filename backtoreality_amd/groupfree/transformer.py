@@ -3,11 +3,13 @@ post-norm self-attention over the query points, cross-attention onto the seed po
 position embeddings are added to queries and keys AND to the values (the reference passes
 the position-augmented tensors as `value`).  `torch.nn.MultiheadAttention` is the module the
 reference vendors a copy of (models/multi_head_attention.py), same parameter names; on the
-GPU its forward runs through groupfree/fused_attention.py (hand-written attention core)."""
+GPU the whole layer is one library call (groupfree/fused_decoder.py -> csrc/decoder.hip); the
+op-by-op form below (attention core through groupfree/fused_attention.py) is the CPU path and
+what `BTR_FUSED_DECODER=0` selects."""
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import fused_attention
+from . import fused_attention, fused_decoder
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -33,10 +35,14 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, query, key, query_pos, key_pos):
         """query (B,C,Pq), key (B,C,Pk), query_pos (B,Pq,3|6), key_pos (B,Pk,3) -> (B,C,Pq)."""
-        q_pos = self.self_posembed(query_pos).permute(2, 0, 1) if self.self_posembed is not None \
-            else None
-        k_pos = self.cross_posembed(key_pos).permute(2, 0, 1) if self.cross_posembed is not None \
-            else None
+        q_pos = self.self_posembed(query_pos) if self.self_posembed is not None else None
+        k_pos = self.cross_posembed(key_pos) if self.cross_posembed is not None else None
+        # the whole layer as one library call (csrc/decoder.hip) when it covers the configuration
+        out = fused_decoder.layer_forward(self, query, key, q_pos, k_pos)
+        if out is not None:
+            return out
+        q_pos = q_pos.permute(2, 0, 1) if q_pos is not None else None
+        k_pos = k_pos.permute(2, 0, 1) if k_pos is not None else None
         query = query.permute(2, 0, 1)
         key = key.permute(2, 0, 1)
 

@@ -113,6 +113,10 @@ _SIGNATURES = {
     "btr_backbone_sampling": (_ci, [_vp] * 6),
     "btr_backbone_forward": (_ci, [_vp] * 7 + [_ci, _vp]),
     "btr_backbone_backward": (_ci, [_vp] * 10),
+    # whole decoder layer (csrc/decoder.hip, used by groupfree/fused_decoder.py)
+    "btr_decoder_layer_plan": (_ci, [_vp, _vp]),
+    "btr_decoder_layer_forward": (_ci, [_vp] * 11),
+    "btr_decoder_layer_backward": (_ci, [_vp] * 14),
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
@@ -240,6 +244,28 @@ class BackbonePlan(ctypes.Structure):
                 ("s_fpx", _sz4), ("saved_bytes", _sz), ("fwd_scratch_bytes", _sz),
                 ("bwd_scratch_bytes", _sz), ("gr_sa", _sz4), ("gr_fp", _sz4),
                 ("grads_floats", _sz)]
+
+
+_vp3, _cf3, _sz3 = _vp * 3, _cf * 3, _sz * 3
+
+
+class DecoderLayer(ctypes.Structure):
+    """btr_decoder_layer_t: one GroupFree3D TransformerDecoderLayer."""
+    _fields_ = [("b", _ci), ("pq", _ci), ("pk", _ci), ("e", _ci), ("heads", _ci), ("ff", _ci),
+                ("dropout", _cf), ("seed", ctypes.c_ulonglong), ("step", _vp),
+                ("sa_in_w", _vp), ("sa_in_b", _vp), ("sa_out_w", _vp), ("sa_out_b", _vp),
+                ("ca_in_w", _vp), ("ca_in_b", _vp), ("ca_out_w", _vp), ("ca_out_b", _vp),
+                ("lin1_w", _vp), ("lin1_b", _vp), ("lin2_w", _vp), ("lin2_b", _vp),
+                ("ln_w", _vp3), ("ln_b", _vp3), ("ln_eps", _cf3)]
+
+
+class DecoderPlan(ctypes.Structure):
+    _fields_ = [("rq", _ci), ("rk", _ci)] + [(n, _sz) for n in (
+        "qp0", "qkv", "a1", "lse1", "xh1", "rs1", "x1", "qp1", "q2", "kp", "kv", "a2", "lse2",
+        "xh2", "rs2", "x2", "h", "xh3", "rs3", "saved_bytes", "fwd_scratch_bytes",
+        "bwd_scratch_bytes", "g_sa_in_w", "g_sa_in_b", "g_sa_out_w", "g_sa_out_b", "g_ca_in_w",
+        "g_ca_in_b", "g_ca_out_w", "g_ca_out_b", "g_lin1_w", "g_lin1_b", "g_lin2_w",
+        "g_lin2_b")] + [("g_ln", _sz3), ("grads_floats", _sz)]
 
 
 class compact_bound(object):

@@ -633,6 +633,54 @@ int btr_attention_bwd(int lq, int lk, int b, int h, int d, const float *q, long 
                       float *dv, long long dkv_sl, long long dkv_sb, float scale, float dropout_p,
                       unsigned long long seed, const long long *step, btr_stream_t stream);
 
+/* ---- whole decoder layer (csrc/decoder.hip) ---------------------------------------
+ * reference: detection/GroupFree3D/models/transformer.py:11-76 (TransformerDecoderLayer.forward:
+ * self-attention over the query points, cross-attention onto the seed points, FFN, post-norm;
+ * position embeddings added to queries, keys and values) and its autograd backward, one call
+ * each.  Parameters in torch's layouts (nn.MultiheadAttention in_proj_weight (3E, E) /
+ * in_proj_bias / out_proj, nn.Linear, nn.LayerNorm).  Rows are batch-major channel-last:
+ * x_cl / qpos_cl / out_cl (b*pq, e), key_cl / kpos_cl (b*pk, e) -- the layout the point-wise MLP
+ * chains keep as their second output; qpos_cl / kpos_cl may be NULL (no position embedding).
+ * Tensors at the module boundary are (b, e, p) like the reference's.  dropout in [0, 1): the
+ * four nn.Dropout of the layer and the two attention dropouts draw their keep-masks from
+ * hash(seed, *step, element); backward must see the (seed, *step) of its forward. */
+typedef struct {
+  int b, pq, pk, e, heads, ff;
+  float dropout;
+  unsigned long long seed;
+  const long long *step;          /* device pointer or NULL                                      */
+  const float *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b;   /* self_attn                          */
+  const float *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b;   /* multihead_attn                     */
+  const float *lin1_w, *lin1_b, *lin2_w, *lin2_b;         /* linear1 (ff, e), linear2 (e, ff)   */
+  const float *ln_w[3], *ln_b[3];                         /* norm1, norm2, norm3                */
+  float ln_eps[3];
+} btr_decoder_layer_t;
+
+typedef struct {
+  int rq, rk;                     /* b*pq, b*pk                                                  */
+  /* byte offsets into `saved` */
+  size_t qp0, qkv, a1, lse1, xh1, rs1, x1, qp1, q2, kp, kv, a2, lse2, xh2, rs2, x2, h, xh3, rs3;
+  size_t saved_bytes, fwd_scratch_bytes, bwd_scratch_bytes;
+  /* float offsets into `grads`; g_ln[i]: weight gradient then bias gradient (2e floats) */
+  size_t g_sa_in_w, g_sa_in_b, g_sa_out_w, g_sa_out_b, g_ca_in_w, g_ca_in_b, g_ca_out_w,
+      g_ca_out_b, g_lin1_w, g_lin1_b, g_lin2_w, g_lin2_b, g_ln[3];
+  size_t grads_floats;
+} btr_decoder_plan_t;
+
+int btr_decoder_layer_plan(const btr_decoder_layer_t *d, btr_decoder_plan_t *plan);
+/* out_cl (b*pq, e) and, when non-NULL, out_bcp (b, e, pq) */
+int btr_decoder_layer_forward(const btr_decoder_layer_t *d, const btr_decoder_plan_t *plan,
+                              const float *x_cl, const float *key_cl, const float *qpos_cl,
+                              const float *kpos_cl, float *out_bcp, float *out_cl, void *saved,
+                              void *scratch, btr_stream_t stream);
+/* dout_bcp (b, e, pq); grads: plan->grads_floats floats, fully written; dx_bcp (b, e, pq),
+ * dqpos_bcp (b, e, pq), dkey_bcp (b, e, pk) [= the gradient of kpos as well]: each may be NULL */
+int btr_decoder_layer_backward(const btr_decoder_layer_t *d, const btr_decoder_plan_t *plan,
+                               const float *x_cl, const float *key_cl, const float *qpos_cl,
+                               const float *kpos_cl, const float *dout_bcp, void *saved,
+                               float *grads, float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
+                               void *scratch, btr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,7 @@ def test_decoder_layer_uses_the_fused_core(cuda, monkeypatch):
     layer = TransformerDecoderLayer(288, 8, 512, dropout=0.0).to(cuda)
     q = torch.randn(2, 288, 64, device=cuda)
     k = torch.randn(2, 288, 200, device=cuda)
+    monkeypatch.setenv("BTR_FUSED_DECODER", "0")   # the op-by-op form of the layer
     calls = []
     real = fused_attention._AttentionCore.apply
     monkeypatch.setattr(fused_attention._AttentionCore, "apply",
