@@ -1,9 +1,12 @@
 """Training step of GroupFree3D (detection/GroupFree3D/train_GF_FSB.py:196-322): model,
 AdamW with the decoder's own learning rate, loss with the script's default coefficients,
 gradient clipping."""
+import os
+
 import torch
 
-from ..votenet.train import _sync_grads
+from ..pointnet2 import fused_backbone
+from ..votenet.train import FastAdamW, _sync_grads
 from .detector import GroupFreeDetector, GroupFreeDetector_DA, GroupFreeDetector_DA_jitter
 from . import fused_attention
 from .loss_helper import get_loss
@@ -36,8 +39,23 @@ def make_optimizer(net, lr=0.004, decoder_lr=0.0004, weight_decay=0.0005, captur
     groups = [{"params": [p for n, p in named if "decoder" not in n]},
               {"params": [p for n, p in named if "decoder" in n], "lr": decoder_lr}]
     fused = all(p.is_cuda for _, p in named)
-    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=fused,
-                             capturable=bool(capturable and fused))
+    # (capturable: the step counters live on the device and the learning rates may be tensors;
+    # the stock step() handles that)
+    fast = fused and not capturable and os.environ.get("BTR_FAST_ADAM", "1") != "0"
+    cls = FastAdamW if fast else torch.optim.AdamW
+    return cls(groups, lr=lr, weight_decay=weight_decay, fused=fused,
+               capturable=bool(capturable and fused))
+
+
+def clip_and_step(net, optimizer, clip_norm):
+    """Gradient clipping + optimizer step (train_GF_FSB.py:316-319); FastAdamW does both in its
+    update kernels."""
+    if clip_norm > 0 and isinstance(optimizer, FastAdamW):
+        optimizer.step(clip_norm=clip_norm)
+        return
+    if clip_norm > 0:
+        torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
+    optimizer.step()
 
 
 def get_scheduler(optimizer, n_iter_per_epoch, lr_scheduler="step", max_epoch=400,
@@ -95,9 +113,7 @@ def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, criter
             next_batch['point_clouds'])
     loss.backward()
     _sync_grads(net)          # data parallel: one all-reduce of the flat gradient buffer
-    if clip_norm > 0:
-        torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
-    optimizer.step()
+    clip_and_step(net, optimizer, clip_norm)
     return loss, end_points
 
 
@@ -128,7 +144,7 @@ class GraphedTrainStep(object):
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), fused_backbone.layerwise():
             for _ in range(warmup):
                 step()
         torch.cuda.current_stream().wait_stream(side)
@@ -179,7 +195,7 @@ class GraphedPipelinedStep(object):
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), fused_backbone.layerwise():
             for _ in range(warmup):
                 step()
         torch.cuda.current_stream().wait_stream(side)
@@ -226,9 +242,7 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_no
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     _sync_grads(net)
-    if clip_norm > 0:
-        torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
-    optimizer.step()
+    clip_and_step(net, optimizer, clip_norm)
     return loss, end_points_S, end_points_T
 
 
@@ -252,9 +266,7 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, loss_ar
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     _sync_grads(net)
-    if clip_norm > 0:
-        torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm, foreach=True)
-    optimizer.step()
+    clip_and_step(net, optimizer, clip_norm)
     return loss, end_points_S, end_points_T
 
 

@@ -30,9 +30,29 @@ else:
 _p = _ext._p
 
 
+_LAYERWISE = [0]
+
+
+class layerwise(object):
+    """`with layerwise():` -- the whole-backbone calls are off inside (the layer-by-layer path
+    runs, as it does while a HIP graph is captured).  The warm-up steps in front of a capture
+    run under it, so that every stock op of the captured path (MIOpen / hipBLASLt solution
+    searches, allocator pools) has been seen before the capture begins."""
+
+    def __enter__(self):
+        _LAYERWISE[0] += 1
+        fused_mlp._CAPTURE_PATH[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _LAYERWISE[0] -= 1
+        fused_mlp._CAPTURE_PATH[0] -= 1
+        return False
+
+
 def enabled():
-    return (os.environ.get("BTR_NATIVE_BACKBONE", "1") != "0" and fused_sa.enabled() and
-            fused_mlp.enabled() and fused_sa.native_enabled())
+    return (os.environ.get("BTR_NATIVE_BACKBONE", "1") != "0" and not _LAYERWISE[0] and
+            fused_sa.enabled() and fused_mlp.enabled() and fused_sa.native_enabled())
 
 
 def _momentum(bn):

@@ -344,16 +344,30 @@ def shared_mlp_chain(mlp):
     return chain or None
 
 
+_CAPTURE_PATH = [0]   # > 0: take the decisions a HIP-graph capture takes (fused_backbone.layerwise)
+
+
+def _min_rows():
+    """Chains of fewer rows stay on the stock ops.  Below ~2 000 rows a chain is a string of
+    5-15 us launches either way: issued as one library call it costs the host less than the
+    stock ops (GroupFree3D's 256-query heads and position embeddings, eager step: 20.5 ->
+    16.2 ms with them on this path); as nodes of a replayed HIP graph the stock ones are
+    fewer (15.5 vs 16.2 ms per replay)."""
+    v = os.environ.get("BTR_CHAIN_MIN_ROWS")
+    if v is not None:
+        return int(v)
+    if native_enabled() and not _CAPTURE_PATH[0] and not torch.cuda.is_current_stream_capturing():
+        return 0
+    return 2048
+
+
 def run_chain(x, chain):
     """chain: [(conv, bn | None, relu: bool)].  Returns None when the fused path does not
     cover the configuration (CPU tensors, eval mode, disabled): the caller then runs the
     stock ops."""
     if not (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
         return None
-    # small problems stay on the stock ops: below ~2 000 rows a chain is a string of 5-15 us
-    # launches either way and the stock ones are fewer (GroupFree3D's 256-query heads and
-    # position embeddings: measured 16.9 vs 16.1 ms per step with them on this path)
-    if x.shape[0] * x.shape[2] < int(os.environ.get("BTR_CHAIN_MIN_ROWS", "2048")):
+    if x.shape[0] * x.shape[2] < _min_rows():
         return None
     K = x.shape[1]
     metas, params = [], []

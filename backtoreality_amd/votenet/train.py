@@ -12,6 +12,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from ..pointnet2 import fused_backbone
 from . import loss_helper
 from .votenet import VoteNet
 from .votenet_da import VoteNet_DA, VoteNet_DA_jitter
@@ -144,44 +145,67 @@ def _sync_grads(net):
         net.sync_gradients()
 
 
-class FastAdam(torch.optim.Adam):
-    """torch.optim.Adam (same state, same state_dict, same fused update kernels) whose step()
-    skips the Python bookkeeping of the stock optimizer once the state exists: the per-step
-    `_init_group` walk, the device / dtype grouping and the profiler hooks cost 0.45 ms of
-    host time per step for ~100 parameter tensors (tools/host_profile.py) -- a tenth of the
-    whole step.  Covers what the training scripts use (fused kernels on one device, no
-    amsgrad / maximize / closure / grad scaler); anything else goes through Adam.step()."""
+class _FastStep(object):
+    """step() of torch.optim.Adam / AdamW (same state, same state_dict, same fused update
+    kernels) without the Python bookkeeping of the stock optimizer once the state exists: the
+    per-step `_init_group` walk, the device / dtype grouping and the profiler hooks cost
+    0.45 ms of host time per step for ~100 parameter tensors (tools/host_profile.py) -- a tenth
+    of the whole VoteNet step, 1.2 ms for GroupFree3D's ~400.  Covers what the training scripts
+    use (fused kernels on one device, no amsgrad / maximize / closure / grad scaler); anything
+    else goes through the stock step().
+
+    `step(clip_norm=c)`: torch.nn.utils.clip_grad_norm_(parameters, c) folded into the update
+    (train_GF_FSB.py:316-318 clips, then steps): one multi-tensor norm, and the fused kernel
+    divides every gradient by max(1, (total_norm + 1e-6) / c) on its way in (its `grad_scale`
+    operand) -- no Python loop over the parameters, no second pass over the gradients.
+    Returns the total norm (a tensor) in that case."""
+    _decoupled = False
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, clip_norm=None):
         if closure is not None or not self._fast_ok():
-            return super().step(closure)
+            return self._stock_step(closure, clip_norm)
+        work = []
         for group in self.param_groups:
             cache = group.get('_btr_fast')
             params = [p for p in group['params'] if p.grad is not None]
             if cache is None or len(cache[0]) != len(params) or \
                     any(a is not b for a, b in zip(cache[0], params)):
                 if any(len(self.state[p]) == 0 for p in params):
-                    return super().step()            # first step: the stock path builds the state
+                    return self._stock_step(None, clip_norm)   # first step: builds the state
                 cache = group['_btr_fast'] = (
                     params, [self.state[p]['exp_avg'] for p in params],
                     [self.state[p]['exp_avg_sq'] for p in params],
                     [self.state[p]['step'] for p in params])
-            params, exp_avgs, exp_avg_sqs, steps = cache
-            if not params:
-                continue
+            if cache[0]:
+                work.append((group, cache, [p.grad for p in cache[0]]))
+        total = scale = None
+        if clip_norm is not None and work:
+            norms = torch._foreach_norm([g for _, _, grads in work for g in grads])
+            total = torch.linalg.vector_norm(torch.stack(norms))
+            scale = ((total + 1e-6) / float(clip_norm)).clamp_(min=1.0)
+        kernel = torch._fused_adamw_ if self._decoupled else torch._fused_adam_
+        for group, (params, exp_avgs, exp_avg_sqs, steps), grads in work:
             beta1, beta2 = group['betas']
             torch._foreach_add_(steps, 1)
-            torch._fused_adam_(params, [p.grad for p in params], exp_avgs, exp_avg_sqs, [], steps,
-                               amsgrad=False, lr=group['lr'], beta1=beta1, beta2=beta2,
-                               weight_decay=group['weight_decay'], eps=group['eps'],
-                               maximize=False, grad_scale=None, found_inf=None)
-        return None
+            kernel(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False,
+                   lr=group['lr'], beta1=beta1, beta2=beta2, weight_decay=group['weight_decay'],
+                   eps=group['eps'], maximize=False, grad_scale=scale, found_inf=None)
+        return total
+
+    def _stock_step(self, closure, clip_norm):
+        total = None
+        if clip_norm is not None:
+            total = torch.nn.utils.clip_grad_norm_(
+                [p for g in self.param_groups for p in g['params']], clip_norm, foreach=True)
+        out = super().step(closure)
+        return total if clip_norm is not None else out
 
     def _fast_ok(self):
         for g in self.param_groups:
             if not g.get('fused') or g.get('amsgrad') or g.get('maximize') or \
-                    g.get('differentiable') or g.get('decoupled_weight_decay') or \
+                    g.get('differentiable') or \
+                    bool(g.get('decoupled_weight_decay')) != self._decoupled or \
                     isinstance(g['lr'], torch.Tensor) or isinstance(g['betas'][0], torch.Tensor):
                 return False
         return getattr(self, 'grad_scale', None) is None and getattr(self, 'found_inf', None) is None
@@ -201,6 +225,15 @@ class FastAdam(torch.optim.Adam):
         super().load_state_dict(state_dict)
         for g in self.param_groups:     # the loaded state tensors are new objects
             g.pop('_btr_fast', None)
+
+
+class FastAdam(_FastStep, torch.optim.Adam):
+    """torch.optim.Adam with the lean step() of _FastStep."""
+
+
+class FastAdamW(_FastStep, torch.optim.AdamW):
+    """torch.optim.AdamW (decoupled weight decay) with the lean step() of _FastStep."""
+    _decoupled = True
 
 
 def make_optimizer(net, lr=1e-3, weight_decay=0.0, capturable=False):
@@ -398,7 +431,7 @@ class GraphedPipelinedStep(object):
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), fused_backbone.layerwise():
             for _ in range(warmup):
                 step()
         torch.cuda.current_stream().wait_stream(side)

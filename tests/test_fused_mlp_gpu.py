@@ -90,12 +90,21 @@ def test_proposal_head(cuda, monkeypatch):
 
 
 def test_small_problems_stay_on_the_stock_ops(cuda, monkeypatch):
-    """Below BTR_CHAIN_MIN_ROWS (2048) rows run_chain declines: the caller runs torch's ops."""
-    from backtoreality_amd.pointnet2 import fused_mlp
+    """The row gate of run_chain (fused_mlp._min_rows): one library call per chain takes every
+    size; the Python-sequenced form and the path a HIP-graph capture takes leave chains below
+    2048 rows to torch's ops; BTR_CHAIN_MIN_ROWS overrides."""
+    from backtoreality_amd.pointnet2 import fused_backbone, fused_mlp
     vg = voting_module.VotingModule(1, 256).to(cuda)
     chain = [(vg.conv1, vg.bn1, True), (vg.conv2, vg.bn2, True), (vg.conv3, None, False)]
-    assert fused_mlp.run_chain(torch.randn(2, 256, 512, device=cuda), chain) is None
-    assert fused_mlp.run_chain(torch.randn(2, 256, 1024, device=cuda), chain) is not None
+    small, large = torch.randn(2, 256, 512, device=cuda), torch.randn(2, 256, 1024, device=cuda)
+    assert fused_mlp.run_chain(small, chain) is not None
+    with fused_backbone.layerwise():
+        assert fused_mlp.run_chain(small, chain) is None
+        assert fused_mlp.run_chain(large, chain) is not None
+    monkeypatch.setenv("BTR_NATIVE_LAYERS", "0")
+    assert fused_mlp.run_chain(small, chain) is None
+    monkeypatch.setenv("BTR_CHAIN_MIN_ROWS", "0")
+    assert fused_mlp.run_chain(small, chain) is not None
 
 
 def test_vote_assembly_and_fp_weights_match_the_torch_composition(cuda, monkeypatch):

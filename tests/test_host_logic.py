@@ -336,3 +336,27 @@ def test_fast_adam_equals_torch_adam(cuda):
         if a in fast.state and fast.state[a]:
             assert torch.equal(fast.state[a]['exp_avg_sq'], slow.state[b]['exp_avg_sq'])
             assert float(fast.state[a]['step']) == float(slow.state[b]['step']) == 6
+
+
+def test_fast_adamw_with_folded_clipping_equals_clip_then_adamw():
+    """FastAdamW.step(clip_norm=c) == clip_grad_norm_(c) followed by torch.optim.AdamW.step()
+    (train_GF_FSB.py:316-319), on the stock fallback here (CPU: not fused)."""
+    import copy
+    import torch
+    from backtoreality_amd.votenet.train import FastAdamW
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    net_b = copy.deepcopy(net_a)
+    opt_a = FastAdamW(net_a.parameters(), lr=0.01, weight_decay=0.05)
+    opt_b = torch.optim.AdamW(net_b.parameters(), lr=0.01, weight_decay=0.05)
+    x = torch.randn(16, 5)
+    for _ in range(3):
+        for net, opt in ((net_a, opt_a), (net_b, opt_b)):
+            opt.zero_grad()
+            (net(x) ** 2).sum().backward()
+        total = opt_a.step(clip_norm=0.1)
+        ref = torch.nn.utils.clip_grad_norm_(net_b.parameters(), 0.1)
+        opt_b.step()
+        assert torch.allclose(total, ref)
+    for a, b in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.equal(a, b)

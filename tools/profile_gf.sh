@@ -9,7 +9,7 @@ rocprofv3 --kernel-trace -d /tmp/$TAG -o r -- python3 $GRAFT_REPO_ROOT/bench.py 
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 DB=$(find /tmp/$TAG -name "*.db" | head -1)
-python tools/rocpd_step.py $DB fps_bucket_kernel gpurun_out/$TAG/one_step.md
+ROCPD_WINDOW=median python tools/rocpd_step.py $DB fps_bucket_kernel gpurun_out/$TAG/one_step.md
 grep "^{" /tmp/$TAG.json | tail -1 > gpurun_out/$TAG/bench.json
 head -1 gpurun_out/$TAG/one_step.md
 ROCPD_WINDOW=median python tools/rocpd_timeline.py $DB fps_bucket_kernel gpurun_out/$TAG/timeline.txt
