@@ -150,6 +150,9 @@ __global__ __launch_bounds__(256) void rows_to_bcp_kernel(int P, int C,
 struct LnFwd {
   int rows, e;
   const float *res, *o;
+  int on;               // o = obias + sum of `on` planes, `ostride` floats apart (split-K GEMM)
+  long long ostride;
+  const float *obias;   // optional
   Drop drop;
   const float *gamma, *beta;
   float eps;
@@ -175,6 +178,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd a) {
     if (j < q) {
       const float4 r = res4[j];
       float4 o = o4[j];
+      for (int z = 1; z < a.on; ++z) {
+        const float4 t = ((const float4 *)(a.o + (size_t)z * a.ostride))[base + j];
+        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+      }
+      if (a.obias) {
+        const float4 t = ((const float4 *)a.obias)[j];
+        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+      }
       if (a.drop.thr) {
         const unsigned long long e = ((unsigned long long)row * q + j) * 4;
         o.x = drop1(key, e, a.drop, o.x); o.y = drop1(key, e + 1, a.drop, o.y);
@@ -220,6 +231,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwd a) {
 struct LnBwd {
   int rows, e;
   const float *g0, *g1, *g2;
+  int g1n;              // g1 = sum of `g1n` planes, `g1stride` floats apart (split-K GEMM)
+  long long g1stride;
   const float *xhat, *rstd, *gamma;
   Drop drop;
   float *dres, *dout;
@@ -249,8 +262,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwd a) {
       dy[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j < q) {
         dy[i] = ((const float4 *)a.g0)[base + j];
-        if (a.g1) {
-          const float4 t = ((const float4 *)a.g1)[base + j];
+        for (int z = 0; z < a.g1n; ++z) {
+          const float4 t = ((const float4 *)(a.g1 + (size_t)z * a.g1stride))[base + j];
           dy[i].x += t.x; dy[i].y += t.y; dy[i].z += t.z; dy[i].w += t.w;
         }
         if (a.g2) {
@@ -478,7 +491,9 @@ BwdScratch bwd_scratch(const btr_decoder_layer_t &d) {
   Bump b;
   const size_t rq = (size_t)d.b * d.pq, rk = (size_t)d.b * d.pk, e = d.e, f = d.ff;
   s.dx3 = b.floats(rq * e); s.dres3 = b.floats(rq * e); s.df = b.floats(rq * e);
-  s.dh = b.floats(rq * f); s.dx2f = b.floats(rq * e); s.dres2 = b.floats(rq * e);
+  s.dh = b.floats(rq * f);
+  s.dx2f = b.floats(rq * e * (size_t)pm_splitk_slices((int)rq, d.e, d.ff));
+  s.dres2 = b.floats(rq * e);
   s.do2 = b.floats(rq * e); s.da2 = b.floats(rq * e); s.dq2 = b.floats(rq * e);
   s.dkv = b.floats(rk * 2 * e); s.dqp1 = b.floats(rq * e); s.dkp = b.floats(rk * e);
   s.dres1 = b.floats(rq * e); s.do1 = b.floats(rq * e); s.da1 = b.floats(rq * e);
@@ -532,8 +547,8 @@ int btr_decoder_layer_plan(const btr_decoder_layer_t *dp, btr_decoder_plan_t *p)
   p->xh2 = sv.floats(rq * e); p->rs2 = sv.floats(rq); p->x2 = sv.floats(rq * e);
   p->h = sv.floats(rq * f); p->xh3 = sv.floats(rq * e); p->rs3 = sv.floats(rq);
   p->saved_bytes = sv.off;
-  Bump fs;   // forward scratch: the three branch outputs that are normalised in
-  fs.floats(rq * e);
+  Bump fs;   // forward scratch: the branch output that is normalised in (split-K: its planes)
+  fs.floats(rq * e * (size_t)pm_splitk_slices((int)rq, d.e, d.ff));
   p->fwd_scratch_bytes = fs.off;
   p->bwd_scratch_bytes = bwd_scratch(d).bytes;
   size_t g = 0;   // flat gradients, floats
@@ -581,7 +596,7 @@ int btr_decoder_layer_forward(const btr_decoder_layer_t *dp, const btr_decoder_p
   BTR_TRY(btr_pm_gemm_nt(rq, e, e, a1, e, d.sa_out_w, e, o, e, nullptr, nullptr, nullptr,
                          d.sa_out_b, stream));
   {
-    LnFwd a{rq, e, x_cl, o, make_drop(d, 0), d.ln_w[0], d.ln_b[0], d.ln_eps[0], x1,
+    LnFwd a{rq, e, x_cl, o, 1, 0, nullptr, make_drop(d, 0), d.ln_w[0], d.ln_b[0], d.ln_eps[0], x1,
             at_f(saved, p.xh1), at_f(saved, p.rs1), qpos_cl, qpos_cl ? qp1 : nullptr};
     BTR_TRY(ln_forward(hs, a));
   }
@@ -603,7 +618,7 @@ int btr_decoder_layer_forward(const btr_decoder_layer_t *dp, const btr_decoder_p
   BTR_TRY(btr_pm_gemm_nt(rq, e, e, a2, e, d.ca_out_w, e, o, e, nullptr, nullptr, nullptr,
                          d.ca_out_b, stream));
   {
-    LnFwd a{rq, e, x1, o, make_drop(d, 1), d.ln_w[1], d.ln_b[1], d.ln_eps[1], x2,
+    LnFwd a{rq, e, x1, o, 1, 0, nullptr, make_drop(d, 1), d.ln_w[1], d.ln_b[1], d.ln_eps[1], x2,
             at_f(saved, p.xh2), at_f(saved, p.rs2), nullptr, nullptr};
     BTR_TRY(ln_forward(hs, a));
   }
@@ -612,10 +627,15 @@ int btr_decoder_layer_forward(const btr_decoder_layer_t *dp, const btr_decoder_p
                          stream));
   hipLaunchKernelGGL(relu_drop_kernel, dim3(cdiv((long long)rq * f / 4, 256)), dim3(256), 0, hs,
                      (long long)rq * f / 4, (float4 *)h, make_drop(d, 2));
-  BTR_TRY(btr_pm_gemm_nt(rq, e, f, h, f, d.lin2_w, f, o, e, nullptr, nullptr, nullptr, d.lin2_b,
-                         stream));
+  const int sk = pm_splitk_slices(rq, e, f);   // linear2: 288 columns, reduction over ff
+  if (sk > 1)
+    BTR_TRY(pm_gemm_nt_splitk(rq, e, f, h, f, d.lin2_w, f, o, (long long)rq * e, sk, hs));
+  else
+    BTR_TRY(btr_pm_gemm_nt(rq, e, f, h, f, d.lin2_w, f, o, e, nullptr, nullptr, nullptr,
+                           d.lin2_b, stream));
   {
-    LnFwd a{rq, e, x2, o, make_drop(d, 3), d.ln_w[2], d.ln_b[2], d.ln_eps[2], out_cl,
+    LnFwd a{rq, e, x2, o, sk, (long long)rq * e, sk > 1 ? d.lin2_b : nullptr, make_drop(d, 3),
+            d.ln_w[2], d.ln_b[2], d.ln_eps[2], out_cl,
             at_f(saved, p.xh3), at_f(saved, p.rs3), nullptr, nullptr};
     BTR_TRY(ln_forward(hs, a));
   }
@@ -680,7 +700,7 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
   // ---- LayerNorm 3, feed-forward
   BTR_TRY(btr_pm_rows(d.b, d.pq, e, e, dout_bcp, S(sc.dx3), stream));
   {
-    LnBwd a{rq, e, S(sc.dx3), nullptr, nullptr, at_f(saved, p.xh3), at_f(saved, p.rs3),
+    LnBwd a{rq, e, S(sc.dx3), nullptr, nullptr, 0, 0, at_f(saved, p.xh3), at_f(saved, p.rs3),
             d.ln_w[2], make_drop(d, 3), S(sc.dres3), S(sc.df), S(sc.lnp[2])};
     BTR_TRY(ln_backward(hs, a));
   }
@@ -690,10 +710,15 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
                      hs, (long long)rq * f / 4, (float4 *)S(sc.dh), (const float4 *)h,
                      make_drop(d, 2).keep_inv);
   BTR_TRY(wgrad(5, S(sc.dh), x2, grads + p.g_lin1_w));
-  BTR_TRY(dgrad(rq, f, e, S(sc.dh), S(sc.t_l1), f, S(sc.dx2f)));
+  const int sk = pm_splitk_slices(rq, e, f);   // dX2 = dH W1: 288 columns, reduction over ff
+  if (sk > 1)
+    BTR_TRY(pm_gemm_nt_splitk(rq, e, f, S(sc.dh), f, S(sc.t_l1), f, S(sc.dx2f),
+                              (long long)rq * e, sk, hs));
+  else
+    BTR_TRY(dgrad(rq, f, e, S(sc.dh), S(sc.t_l1), f, S(sc.dx2f)));
   // ---- LayerNorm 2, cross-attention
   {
-    LnBwd a{rq, e, S(sc.dres3), S(sc.dx2f), nullptr, at_f(saved, p.xh2), at_f(saved, p.rs2),
+    LnBwd a{rq, e, S(sc.dres3), S(sc.dx2f), nullptr, sk, (long long)rq * e, at_f(saved, p.xh2), at_f(saved, p.rs2),
             d.ln_w[1], make_drop(d, 1), S(sc.dres2), S(sc.do2), S(sc.lnp[1])};
     BTR_TRY(ln_backward(hs, a));
   }
@@ -711,7 +736,7 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
     BTR_TRY(dgrad(rk, 2 * e, e, S(sc.dkv), S(sc.t_ca_in) + e, 3 * e, S(sc.dkp)));
   // ---- LayerNorm 1, self-attention
   {
-    LnBwd a{rq, e, S(sc.dres2), S(sc.dqp1), nullptr, at_f(saved, p.xh1), at_f(saved, p.rs1),
+    LnBwd a{rq, e, S(sc.dres2), S(sc.dqp1), nullptr, 1, 0, at_f(saved, p.xh1), at_f(saved, p.rs1),
             d.ln_w[0], make_drop(d, 0), S(sc.dres1), S(sc.do1), S(sc.lnp[0])};
     BTR_TRY(ln_backward(hs, a));
   }

@@ -13,6 +13,12 @@ int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
                const float *shift, int relu, float *out_bcn, float *out_cl, const float *add,
                long long add_bstride, hipStream_t stream);
 
+// sa_mlp.hip: btr_pm_gemm_nt (no prologue / bias / statistics) with the reduction split over
+// `slices` workgroups per C tile; plane z of the partial products at parts + z * part_stride
+int pm_splitk_slices(int rows, int n, int k);
+int pm_gemm_nt_splitk(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
+                      float *parts, long long part_stride, int slices, hipStream_t stream);
+
 // interpolate.hip: three_interpolate_grad through inverted index lists with caller-provided
 // scratch; grad_out's batch elements are go_bstride floats apart (>= c * n).
 size_t ti_grad_workspace_bytes(int b, int n, int m);

@@ -67,6 +67,10 @@ struct Compact {
   const float *bw = nullptr;
   const int *bgrp = nullptr;
   const int *goff = nullptr;
+  // split-K (pm_gemm_nt_splitk): workgroups of blockIdx.z = z reduce k in [z*kz, (z+1)*kz) and
+  // write the plane C + z*czs; kz == 0: off
+  int kz = 0;
+  long long czs = 0;
 };
 
 constexpr int kBM = 128;      // rows per workgroup tile
@@ -159,6 +163,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   static_assert(PS == 0 || (BN == 128 && (PS == 8 || PS == 16 || PS == 32 || PS == 64)),
                 "pooling epilogue: 128-column tiles, groups of 8 / 16 / 32 / 64 rows");
   if (cm.dims) R = cm.dims[0];  // compact rows: the row count lives on the device
+  if (cm.kz) {
+    const int k0 = (int)blockIdx.z * cm.kz;
+    A += k0;
+    W += k0;
+    C += (size_t)blockIdx.z * cm.czs;
+    K = min(cm.kz, K - k0);
+  }
   constexpr int WN = BN / 64;      // waves along N
   constexpr int WM = 4 / WN;       // waves along M
   constexpr int MI = BM / WM / 32;  // 32-row MFMA tiles per wave
@@ -1435,6 +1446,24 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) 
   }
 }
 
+// Few chunks of a LARGE gradient (the decoder's 288 x 2048 FFN weights: 4 - 16 partials of
+// 590 000 elements): one thread per 4 consecutive elements streams the partials with 16-byte
+// loads (the 16-element blocks above read 64-byte pieces and leave 3/4 of their threads idle
+// when there are only 4 chunks: 64 us for a reduction that moves 12 MB).
+__global__ __launch_bounds__(256) void reduce_chunks_wide_kernel(int total4, int chunks,
+                                                                 const float4 *__restrict__ pw,
+                                                                 float4 *__restrict__ dw) {
+  const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (i >= total4) return;
+  double x = 0.0, y = 0.0, z = 0.0, w = 0.0;
+#pragma unroll 4
+  for (int c = 0; c < chunks; ++c) {
+    const float4 v = pw[(size_t)c * total4 + i];
+    x += (double)v.x; y += (double)v.y; z += (double)v.z; w += (double)v.w;
+  }
+  dw[i] = make_float4((float)x, (float)y, (float)z, (float)w);
+}
+
 struct ReduceBatch {
   ReduceArgs args;
   bool on = false;
@@ -1446,6 +1475,11 @@ inline ReduceBatch &reduce_batch() {
 // dw = sum over chunks of pw: now, or with the batch of the running layer call
 inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *dw,
                                  hipStream_t st) {
+  if (chunks <= 16 && total >= 65536 && total % 4 == 0) {
+    hipLaunchKernelGGL(reduce_chunks_wide_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, st,
+                       total / 4, chunks, (const float4 *)pw, (float4 *)dw);
+    return;
+  }
   ReduceBatch &b = reduce_batch();
   if (b.on && b.args.n < kMaxReduceSeg) {
     ReduceArgs &a = b.args;
@@ -2574,6 +2608,45 @@ int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
 #undef BTR_PM_MM
   return check_launch("pm_gemm_nt");
 }
+
+}  // extern "C"
+
+// Skinny products with a long reduction (the decoder's 1024 x 288 x 2048 FFN GEMMs: 48
+// workgroups on 256 CUs, each looping over all of k): `slices` workgroups share one C tile's
+// reduction and write their partial products to parts + z * part_stride ((rows, n), leading
+// dimension n); the consumer adds the planes.  pm_splitk_slices: 1 = not worth it.
+int btr::pm_splitk_slices(int rows, int n, int k) {
+  const int wg = btr_pm_gemm_grid(rows) * cdiv(n, 128);
+  if (wg >= 128 || k < 1024) return 1;
+  return std::max(1, std::min(std::min(8, 256 / wg), k / 256));
+}
+int btr::pm_gemm_nt_splitk(int rows, int n, int k, const float *a, int lda, const float *w,
+                           int ldw, float *parts, long long part_stride, int slices,
+                           hipStream_t s) {
+  if (rows <= 0 || n <= 0) return BTR_OK;
+  BTR_REQUIRE(a && w && parts && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 &&
+                  slices >= 1 && slices <= 64,
+              "pm_gemm_nt_splitk: bad arguments (k=%d lda=%d ldw=%d slices=%d)", k, lda, ldw,
+              slices);
+  Compact cm{};
+  cm.kz = cdiv(cdiv(k, slices), kBK) * kBK;
+  cm.czs = part_stride;
+  const dim3 grid(btr_pm_gemm_grid(rows), cdiv(n, 128), cdiv(k, cm.kz));
+  BTR_REQUIRE((int)grid.z == slices, "pm_gemm_nt_splitk: %d slices of %d do not tile k=%d",
+              slices, cm.kz, k);
+#define BTR_SK(MM)                                                                               \
+  hipLaunchKernelGGL((gemm_nt_kernel<128, 0, false, 0, 64, false, MM>), grid, dim3(256), 0, s, a, \
+                     lda, w, ldw, parts, n, rows, n, k, (const float *)nullptr,                  \
+                     (const float *)nullptr, (float *)nullptr, (const unsigned char *)nullptr,   \
+                     (const float *)nullptr, 0, (const float *)nullptr, (float *)nullptr,        \
+                     (unsigned char *)nullptr, cm)
+  if (gemm_x6()) BTR_SK(1);
+  else BTR_SK(0);
+#undef BTR_SK
+  return check_launch("pm_gemm_nt_splitk");
+}
+
+extern "C" {
 
 // out_bcn (B, C, N) [and out_cl (B*N, C)] = f(scale * y + shift); scale/shift NULL: identity
 int btr_pm_out(int b, int n, int c, int ldy, const float *y, const float *scale,

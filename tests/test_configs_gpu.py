@@ -231,12 +231,20 @@ def test_graphed_pipelined_step_replays_the_eager_loop(cuda):
             losses.append(float(gs(batches[i % 2], batches[(i + 1) % 2])))
         return losses
 
-    le, lg = eager(), graphed()
-    # (the eager loop runs the backbone through the whole-backbone library calls, whose
-    # feature-propagation MLPs are always the fused kernels; the captured step goes layer by
-    # layer and leaves the 1 024-row fp1 chain of this small batch to the stock ops)
-    np.testing.assert_allclose(lg[0], le[0], rtol=1e-5)
+    from backtoreality_amd.pointnet2 import fused_backbone
+    lg = graphed()
+    # the eager loop on the path a capture takes (backbone layer by layer, chains below 2 048
+    # rows on the stock ops): the replay is that loop
+    with fused_backbone.layerwise():
+        le = eager()
+    np.testing.assert_allclose(lg[0], le[0], rtol=1e-6)
     # from the third step on even two eager runs drift apart by percents (f32 atomics in the
     # nine-op backward, then the vote FPS picks other proposals: tools/diag_nondeterminism.py)
     np.testing.assert_allclose(lg[1], le[1], rtol=1e-3)
     assert all(np.isfinite(lg))
+    # the default eager loop (whole-backbone library calls, every chain on the fused kernels)
+    # computes the same function with other kernels: its first loss agrees to rounding; after
+    # one Adam step (sign-like for noise-level gradients) the vote FPS may pick other proposals
+    ld = eager()
+    np.testing.assert_allclose(ld[0], lg[0], rtol=1e-5)
+    np.testing.assert_allclose(ld[1], lg[1], rtol=6e-2)

@@ -260,7 +260,10 @@ def test_groupfree_pipelined_steps_equal_the_sequential_ones(cuda):
         return losses
 
     seq, pipe, graph = run("sequential"), run("pipelined"), run("graphed")
-    assert seq[0] == pipe[0] == graph[0], (seq, pipe, graph)
+    assert seq[0] == pipe[0], (seq, pipe)
+    # (the capture takes the layer-by-layer backbone and leaves small chains to stock ops: same
+    # function, other kernels)
+    np.testing.assert_allclose(graph[0], seq[0], rtol=1e-5)
     # later steps: float atomics order + top-k query sampling (two eager runs differ as much)
     np.testing.assert_allclose(pipe[1:], seq[1:], rtol=3e-2)
     np.testing.assert_allclose(graph[1:], seq[1:], rtol=3e-2)
