@@ -238,9 +238,10 @@ def test_graphed_pipelined_step_replays_the_eager_loop(cuda):
     with fused_backbone.layerwise():
         le = eager()
     np.testing.assert_allclose(lg[0], le[0], rtol=1e-6)
-    # from the third step on even two eager runs drift apart by percents (f32 atomics in the
-    # nine-op backward, then the vote FPS picks other proposals: tools/diag_nondeterminism.py)
-    np.testing.assert_allclose(lg[1], le[1], rtol=1e-3)
+    # from the second step on even two eager runs drift apart by percents (run-dependent
+    # summation order in the input-gradient scatter, then the vote FPS picks other proposals:
+    # tools/diag_nondeterminism.py, tools/diag_step1b.py)
+    np.testing.assert_allclose(lg[1], le[1], rtol=6e-2)
     assert all(np.isfinite(lg))
     # the default eager loop (whole-backbone library calls, every chain on the fused kernels)
     # computes the same function with other kernels: its first loss agrees to rounding; after

