@@ -8,6 +8,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import fused_loss
+
 
 def _mean_size(config, dev):
     cache = getattr(config, "_mean_size_dev", None)
@@ -215,6 +217,17 @@ def get_loss(end_points, config, num_decoder_layers, query_points_generator_loss
         end_points['query_points_generation_loss'] = gen_loss
     else:
         gen_loss = 0.0
+    prefixes = head_prefixes(num_decoder_layers)
+    if fused_loss.can_fuse(end_points, config, prefixes,
+                           (center_loss_type, size_loss_type, heading_loss_type)):
+        # every head's objectness / box / semantic terms and their gradient: csrc/gf_loss.hip
+        heads = fused_loss.heads_loss(
+            end_points, config, prefixes, (obj_loss_coef, box_loss_coef, sem_cls_loss_coef),
+            (center_delta, heading_delta, size_delta),
+            _mean_size(config, end_points['center_label'].device))
+        loss = 10 * (query_points_generator_loss_coef * gen_loss) + heads
+        end_points['loss'] = loss
+        return loss, end_points
     obj_sum, end_points = compute_objectness_loss_based_on_query_points(end_points,
                                                                         num_decoder_layers)
     end_points['sum_heads_objectness_loss'] = obj_sum

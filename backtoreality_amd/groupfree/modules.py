@@ -138,6 +138,7 @@ class PredictHead(nn.Module):
             net = F.relu(self.bn1(self.conv1(features)))
             net = F.relu(self.bn2(self.conv2(net)))
             out = F.conv1d(net, last.weight, last.bias)
+        end_points[prefix + '_head_output'] = out   # (B, sum, P): what groupfree/fused_loss.py reads
         out = out.transpose(2, 1)   # (B, P, sum)
         (objectness_scores, center_residual, heading_scores, heading_residuals_normalized,
          size_scores, size_residuals_flat, sem_cls_scores) = torch.split(

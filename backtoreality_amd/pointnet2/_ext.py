@@ -117,6 +117,9 @@ _SIGNATURES = {
     "btr_decoder_layer_plan": (_ci, [_vp, _vp]),
     "btr_decoder_layer_forward": (_ci, [_vp] * 11),
     "btr_decoder_layer_backward": (_ci, [_vp] * 14),
+    # GroupFree3D per-head loss (csrc/gf_loss.hip, used by groupfree/fused_loss.py)
+    "btr_gf_loss_part_floats": (_ci, [_ci, _ci, _ci]),
+    "btr_gf_loss_fwd": (_ci, [_vp] * 21),
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
@@ -266,6 +269,13 @@ class DecoderPlan(ctypes.Structure):
         "bwd_scratch_bytes", "g_sa_in_w", "g_sa_in_b", "g_sa_out_w", "g_sa_out_b", "g_ca_in_w",
         "g_ca_in_b", "g_ca_out_w", "g_ca_out_b", "g_lin1_w", "g_lin1_b", "g_lin2_w",
         "g_lin2_b")] + [("g_ln", _sz3), ("grads_floats", _sz)]
+
+
+class GfLoss(ctypes.Structure):
+    """btr_gf_loss_t"""
+    _fields_ = [(n, _ci) for n in ("b", "p", "k2", "nh", "ns", "nc", "heads", "c", "s1", "n")] + \
+               [(n, _cf) for n in ("w_obj", "w_box", "w_sem", "center_delta", "heading_delta",
+                                   "size_delta")]
 
 
 class compact_bound(object):

@@ -681,6 +681,36 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *d, const btr_decoder_p
                                float *grads, float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
                                void *scratch, btr_stream_t stream);
 
+/* ---- GroupFree3D: per-head loss and its gradient (csrc/gf_loss.hip) --------------
+ * reference: detection/GroupFree3D/models/loss_helper.py:81-275
+ * (compute_objectness_loss_based_on_query_points + compute_box_and_sem_cls_loss, smooth-L1 forms)
+ * over all `heads` prediction heads at once.  heads[h]: the raw output of PredictHead h, (b, c, p)
+ * with c = 4 + 2 nh + 4 ns + nc channels in the reference's order (objectness, centre residual,
+ * heading scores, heading residuals, size scores, size residuals, semantic scores);
+ * base_xyz (b, p, 3); seed_inds (b, s1) / sample_inds (b, p) int32; labels as the GroupFree3D
+ * loader provides them (i64 class labels, f32 residuals); mean_size (ns, 3).
+ * w_obj / w_box / w_sem: 10 * coefficient / (num_decoder_layers + 1) (loss_helper.py:312-316).
+ * Outputs: objectness_label / object_assignment (b, p) i64; stats[8 heads + 6]: per head
+ * (objectness, centre, heading cls, heading reg, size cls, size reg, box, semantic) then (sum
+ * objectness, sum box, sum semantic, weighted total, pos_ratio, neg_ratio);
+ * grads (heads, b, c, p): d(weighted total) / d heads[h].  npos_part: b floats,
+ * part: btr_gf_loss_part_floats(b, p, heads) floats of scratch. */
+typedef struct {
+  int b, p, k2, nh, ns, nc, heads, c, s1, n;
+  float w_obj, w_box, w_sem;
+  float center_delta, heading_delta, size_delta;
+} btr_gf_loss_t;
+int btr_gf_loss_part_floats(int b, int p, int heads);
+int btr_gf_loss_fwd(const btr_gf_loss_t *d, const float *const *heads, const float *base_xyz,
+                    const int *seed_inds, const int *sample_inds,
+                    const long long *point_obj_mask, const long long *point_instance_label,
+                    const float *center_label, const long long *heading_class_label,
+                    const float *heading_residual_label, const long long *size_class_label,
+                    const float *size_residual_label, const long long *sem_cls_label,
+                    const float *mean_size, long long *objectness_label,
+                    long long *object_assignment, float *npos_part, float *part, float *stats,
+                    float *grads, btr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,79 @@
+"""csrc/gf_loss.hip (per-head GroupFree3D loss + gradient in one launch) against the op-by-op
+torch composition of groupfree/loss_helper.py, which restates the reference's
+compute_objectness_loss_based_on_query_points / compute_box_and_sem_cls_loss
+(detection/GroupFree3D/models/loss_helper.py:81-275) and is pinned by the reference golden."""
+import numpy as np
+import pytest
+import torch
+
+from backtoreality_amd.groupfree import fused_loss, loss_helper
+from backtoreality_amd.groupfree.modules import PredictHead
+from backtoreality_amd.votenet import config, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _end_points(dev, B, P, layers, seed):
+    cfg = config.scannet_md40()
+    torch.manual_seed(seed)
+    batch = synthetic.make_batch(seed, B, 4096, cfg, use_height=False, device=dev)
+    end = dict(batch)
+    end['seed_inds'] = torch.randint(0, 4096, (B, 1024), device=dev, dtype=torch.int32)
+    end['query_points_sample_inds'] = torch.randint(0, 1024, (B, P), device=dev,
+                                                    dtype=torch.int32)
+    base = torch.rand(B, P, 3, device=dev) * 4 - 2
+    heads = []
+    for prefix in loss_helper.head_prefixes(layers):
+        head = PredictHead(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                           cfg.mean_size_arr, P, 288).to(dev)
+        feats = torch.randn(B, 288, P, device=dev)
+        head(feats, base_xyz=base, end_points=end, prefix=prefix)
+        raw = end[prefix + '_head_output']
+        raw.retain_grad()
+        heads.append(raw)
+    return cfg, end, heads
+
+
+def _loss(cfg, end, layers):
+    return loss_helper.get_loss(end, cfg, num_decoder_layers=layers,
+                                query_points_generator_loss_coef=0.8, obj_loss_coef=0.1,
+                                box_loss_coef=1, sem_cls_loss_coef=0.1, query_points_obj_topk=4)
+
+
+@pytest.mark.parametrize("B,P,layers", [(4, 256, 6), (2, 100, 2), (3, 64, 0)])
+def test_heads_loss_and_gradient_match_the_torch_composition(B, P, layers, monkeypatch):
+    dev = torch.device("cuda:0")
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setenv("BTR_FUSED_GF_LOSS", "1" if fused else "0")
+        cfg, end, heads = _end_points(dev, B, P, layers, seed=3)
+        prefixes = loss_helper.head_prefixes(layers)
+        assert fused_loss.can_fuse(end, cfg, prefixes, ('smoothl1',) * 3) == fused
+        loss, end = _loss(cfg, end, layers)
+        loss.backward()
+        out[fused] = (float(loss), end, [h.grad.clone() for h in heads])
+    (lf, ef, gf), (lt, et, gt) = out[True], out[False]
+    assert abs(lf - lt) <= 1e-5 * abs(lt), (lf, lt)
+    for prefix in loss_helper.head_prefixes(layers):
+        assert torch.equal(ef[prefix + 'objectness_label'], et[prefix + 'objectness_label'])
+        assert torch.equal(ef[prefix + 'object_assignment'], et[prefix + 'object_assignment'])
+        assert torch.allclose(ef[prefix + 'objectness_mask'], et[prefix + 'objectness_mask'])
+        for key in fused_loss.TERMS + ('pos_ratio', 'neg_ratio'):
+            a, b = float(ef[prefix + key]), float(et[prefix + key])
+            assert abs(a - b) <= 2e-5 * abs(b) + 1e-7, (prefix, key, a, b)
+    for key in ('sum_heads_objectness_loss', 'sum_heads_box_loss', 'sum_heads_sem_cls_loss'):
+        np.testing.assert_allclose(float(ef[key]), float(et[key]), rtol=2e-5)
+    for a, b in zip(gf, gt):
+        scale = float(b.abs().max())
+        assert scale > 0
+        assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+
+
+def test_the_other_loss_forms_stay_on_the_torch_composition():
+    dev = torch.device("cuda:0")
+    cfg, end, _ = _end_points(dev, 2, 64, 1, seed=1)
+    prefixes = loss_helper.head_prefixes(1)
+    assert fused_loss.can_fuse(end, cfg, prefixes, ('smoothl1',) * 3)
+    assert not fused_loss.can_fuse(end, cfg, prefixes, ('l1', 'smoothl1', 'smoothl1'))
+    del end['last_' + fused_loss.HEAD_KEY]
+    assert not fused_loss.can_fuse(end, cfg, prefixes, ('smoothl1',) * 3)
