@@ -50,3 +50,33 @@ def test_no_oracle_in_product():
                 src = open(os.path.join(d, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "libbtr_oracle" not in src, f
+
+
+def test_plan_functions_lay_out_their_arenas_without_a_gpu():
+    """btr_decoder_layer_plan / btr_backbone_plan / btr_pm_chain_plan are host-only: offsets are
+    aligned and disjoint, the flat-gradient size is the parameter count, bad descriptions are
+    reported through the status code."""
+    from backtoreality_amd.pointnet2 import _ext
+    lib = _ext._lib
+    d, plan = _ext.DecoderLayer(), _ext.DecoderPlan()
+    d.b, d.pq, d.pk, d.e, d.heads, d.ff, d.dropout = 4, 256, 1024, 288, 8, 2048, 0.1
+    assert lib.btr_decoder_layer_plan(ctypes.addressof(d), ctypes.addressof(plan)) == 0
+    assert (plan.rq, plan.rk) == (1024, 4096)
+    E, F = 288, 2048
+    assert plan.grads_floats == 2 * (3 * E * E + 3 * E + E * E + E) + 2 * E * F + F + E + 6 * E
+    offs = [getattr(plan, n) for n in ("qp0", "qkv", "a1", "lse1", "xh1", "rs1", "x1", "qp1", "q2",
+                                       "kp", "kv", "a2", "lse2", "xh2", "rs2", "x2", "h", "xh3",
+                                       "rs3")]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and offs[-1] < plan.saved_bytes
+    assert plan.fwd_scratch_bytes > 0 and plan.bwd_scratch_bytes > plan.saved_bytes // 4
+    for field, bad in (("heads", 7), ("e", 290), ("dropout", 1.0), ("ff", 0)):
+        d2 = _ext.DecoderLayer.from_buffer_copy(d)
+        setattr(d2, field, bad)
+        assert lib.btr_decoder_layer_plan(ctypes.addressof(d2), ctypes.addressof(plan)) == -1
+        assert b"decoder_layer_plan" in lib.btr_last_error()
+    assert lib.btr_decoder_layer_plan(None, ctypes.addressof(plan)) == -1
+    assert lib.btr_gf_loss_part_floats(4, 256, 7) == 7 * 4 * 4 * 7
+    # the entry points refuse null operands before touching the device
+    assert lib.btr_decoder_layer_forward(ctypes.addressof(d), ctypes.addressof(plan), None, None,
+                                         None, None, None, None, None, None, None) == -1
+    assert lib.btr_gf_loss_fwd(*([None] * 21)) == -1
