@@ -1368,12 +1368,152 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
   }
 }
 
-// (A bf16x6 form of this kernel was built and measured: the reduction runs over ROWS, so the
-// MFMA operands want 8 consecutive rows of one column.  Staging the tiles transposed with one
-// column per thread makes the LDS side plain 16-byte stores but turns the global side into
-// 4-byte loads -- 96 instead of 24 vector-memory instructions per workgroup and 32-row step,
-// and the CU's address unit, not the matrix pipe, set the pace: 78 -> 136 us on
-// 114 624 x 128 x 132, 75 -> 127 us on 65 536 x 128 x 260.  The f32-input kernel stays.)
+// ---- the plain TN GEMM (no pooled gradient, no first-layer recompute) in bf16x6 ---------------
+// The reduction runs over ROWS, so an MFMA operand fragment is 8 consecutive rows of ONE column
+// of a row-major tile.  gfx950's LDS transpose read delivers exactly that: within a 16-lane
+// group the lanes address a [4 rows][16 columns] block of bf16 (lane p: row p/4, columns
+// 4*(p%4)..+3, 8 bytes) and ds_read_b64_tr_b16 hands lane i column i of the block, rows 0..3
+// (tools/probe/tr_probe.hip prints the mapping).  So the tiles are staged exactly like the NT
+// kernel's -- coalesced float4 loads, exact 3-way bf16 split, 8-byte plane stores, row-major --
+// and two transpose reads per plane give the 8-row fragment.  Row pitches of 320 B / 192 B put
+// the four rows of a block 16 / 48 banks apart: the 32 lanes of a read cycle hit 64 distinct banks.
+// (A first bf16x6 form staged the tiles transposed with one column per thread: plain 16-byte
+// LDS traffic but 4-byte global loads, 96 instead of 24 vector-memory instructions per 32-row
+// step, address-unit bound and slower than the f32-input kernel: 78 -> 136 us on
+// 114 624 x 128 x 132.)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_read8(const __bf16 *p, int pitch) {
+  typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * pitch));
+  union {
+    s16x4 s[2];
+    bf16x8 b;
+  } u;
+  u.s[0] = lo;
+  u.s[1] = hi;
+  return u.b;
+}
+
+template <int TNW, bool PRO>
+__global__ __launch_bounds__(256) void gemm_tn_x6_kernel(
+    const float *__restrict__ G, int ldg, const float *__restrict__ X, int ldx, int R, int N,
+    int K, const float *__restrict__ pa, const float *__restrict__ pb, int rows_per_chunk,
+    float *__restrict__ pw, Compact cm) {
+  if (cm.dims) R = cm.dims[0];  // compact rows: the row count lives on the device
+  constexpr int BR = 32;
+  constexpr int TN = 32 * TNW;
+  constexpr int LG = TN == 128 ? 160 : 96, LX = 96;   // bf16 row pitches: 320 B / 192 B
+  constexpr int KT = TNW == 4 ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) __bf16 Gp[3 * BR * LG];
+  __shared__ __attribute__((aligned(16))) __bf16 Xp[3 * BR * LX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = TNW == 4 ? wave : (wave >> 1);
+  const int wk = TNW == 4 ? 0 : (wave & 1);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * 64;
+  const int chunk = blockIdx.z;
+  const int rbeg = chunk * rows_per_chunk;
+  const int rend = min(R, rbeg + rows_per_chunk);
+
+  f32x16 acc[KT];
+#pragma unroll
+  for (int q = 0; q < KT; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+
+  const int xc4 = (tid & 15) * 4, xr = tid >> 4;
+  constexpr int GT = TN / 4, GR = 256 / GT, GPASS = BR / GR;
+  const int gc4 = (tid % GT) * 4, gr = tid / GT;
+  float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (PRO && k0 + xc4 < K) {
+    fa = *reinterpret_cast<const float4 *>(pa + k0 + xc4);
+    fb = *reinterpret_cast<const float4 *>(pb + k0 + xc4);
+  }
+  float4 rg[GPASS], rx[2];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < GPASS; ++p) {
+      const int row = gr + GR * p;
+      rg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < rend && n0 + gc4 < N)
+        rg[p] = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * ldg + n0 + gc4);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = xr + 16 * p;
+      rx[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < rend && k0 + xc4 < K)
+        rx[p] = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + xc4);
+    }
+  };
+  // fragment addressing of the transpose reads: lane -> (row, column) of its 8-byte piece
+  const int p16 = lane & 15, grp = lane >> 4;
+  const int frow = 8 * (grp >> 1) + (p16 >> 2), fcol = 16 * (grp & 1) + 4 * (p16 & 3);
+  if (rbeg < rend) fetch(rbeg);
+  for (int r0 = rbeg; r0 < rend; r0 += BR) {
+#pragma unroll
+    for (int p = 0; p < GPASS; ++p) {
+      const Split4 sp = split4(rg[p]);
+      const int at = (gr + GR * p) * LG + gc4;
+      *reinterpret_cast<bf16x4 *>(&Gp[0 * BR * LG + at]) = sp.h;
+      *reinterpret_cast<bf16x4 *>(&Gp[1 * BR * LG + at]) = sp.m;
+      *reinterpret_cast<bf16x4 *>(&Gp[2 * BR * LG + at]) = sp.l;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = xr + 16 * p;
+      float4 x = rx[p];
+      if (PRO && r0 + row < rend && k0 + xc4 < K) {
+        x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
+        x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
+        x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
+        x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
+      }
+      const Split4 sp = split4(x);
+      const int at = row * LX + xc4;
+      *reinterpret_cast<bf16x4 *>(&Xp[0 * BR * LX + at]) = sp.h;
+      *reinterpret_cast<bf16x4 *>(&Xp[1 * BR * LX + at]) = sp.m;
+      *reinterpret_cast<bf16x4 *>(&Xp[2 * BR * LX + at]) = sp.l;
+    }
+    __syncthreads();
+    if (r0 + BR < rend) fetch(r0 + BR);  // next rows in flight during the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[3], bf[3][KT];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        af[q] = tr_read8(&Gp[(q * BR + ks * 16 + frow) * LG + wn * 32 + fcol], LG);
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+          bf[q][t] = tr_read8(&Xp[(q * BR + ks * 16 + frow) * LX + (wk + t) * 32 + fcol], LX);
+      }
+      // smallest terms first (see gemm_nt_kernel)
+#define BTR_X6(QA, QB)                       \
+  _Pragma("unroll") for (int t = 0; t < KT; ++t) acc[t] = \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA], bf[QB][t], acc[t], 0, 0, 0);
+      BTR_X6(2, 0)
+      BTR_X6(0, 2)
+      BTR_X6(1, 1)
+      BTR_X6(1, 0)
+      BTR_X6(0, 1)
+      BTR_X6(0, 0)
+#undef BTR_X6
+    }
+    __syncthreads();
+  }
+  float *out = pw + (size_t)chunk * N * K;
+#pragma unroll
+  for (int q = 0; q < KT; ++q) {
+    const int col = k0 + (wk + q) * 32 + l31;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = n0 + wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+      if (row < N && col < K) out[(size_t)row * K + col] = acc[q][v];
+    }
+  }
+}
+
 // dw[i] = sum over chunks of pw[chunk][i], fixed order; EL elements x SL chunk slices per block
 // (4 x 64 for the small weight matrices, whose launches are latency-bound; 16 x 16 keeps the
 // reads of the large ones coalesced).
@@ -2013,6 +2153,11 @@ inline bool gemm_x6() {
   static const bool on = !(getenv("BTR_GEMM") && getenv("BTR_GEMM")[0] == 'f');
   return on;
 }
+// BTR_GEMM_TN=f32: the f32-input kernel for the plain weight-gradient GEMM only
+inline bool tn_x6() {
+  static const bool on = !(getenv("BTR_GEMM_TN") && getenv("BTR_GEMM_TN")[0] == 'f');
+  return on && gemm_x6();
+}
 
 }  // namespace btr
 
@@ -2374,11 +2519,21 @@ int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float 
                      k, pa, pb, rpc, pw, (const unsigned char *)nullptr, (const float *)nullptr, \
                      (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr, \
                      cur_compact())
-  if (tn == 128) {
+#define BTR_TN6(W, P)                                                                          \
+  hipLaunchKernelGGL((gemm_tn_x6_kernel<W, P>), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n, \
+                     k, pa, pb, rpc, pw, cur_compact())
+  if (tn_x6()) {
+    if (tn == 128) {
+      if (pa) BTR_TN6(4, true); else BTR_TN6(4, false);
+    } else {
+      if (pa) BTR_TN6(2, true); else BTR_TN6(2, false);
+    }
+  } else if (tn == 128) {
     if (pa) BTR_TN(4, true); else BTR_TN(4, false);
   } else {
     if (pa) BTR_TN(2, true); else BTR_TN(2, false);
   }
+#undef BTR_TN6
 #undef BTR_TN
   reduce_chunks_launch(n * k, chunks, pw, dw, st);
   return check_launch("sa_gemm_tn");
