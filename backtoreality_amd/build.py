@@ -32,7 +32,14 @@ ARCH = "gfx950"
 HIPCC_FLAGS = [
     "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
     "-fPIC", "-Wall", "-Wno-unused-function",
+    # No SLP vectorisation: it turns neighbouring scalar f32 ops into packed v_pk_{add,mul,fma}_f32
+    # with op_sel operands.  With such code the register-resident FPS kernel returned a wrong
+    # sequence in 1-3 % of its launches whenever another stream's kernels shared the chip
+    # (never alone; identical inputs, tools/diag_pipeline_inds.py) and not once in 10 000
+    # launches without it; the guide lists packed f32 as an anti-lever beside MFMAs anyway.
+    "-fno-slp-vectorize",
 ]
+EXTRA_FLAGS = {}   # per-file additions to HIPCC_FLAGS (none at present)
 # sources whose code depends on BTR_FMAD (they evaluate sq3() / dot3())
 MODE_SOURCES = ("ball_query.hip", "ball_query_bucket.hip", "ball_query_grid.hip",
                 "fps_bucket.hip", "interpolate.hip", "sampling.hip")
@@ -49,6 +56,7 @@ def sources():
 def _headers_digest():
     h = hashlib.sha256()
     h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
     files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "btr_pointnet2.h"))
     for f in files:
@@ -113,7 +121,8 @@ def build(force=False, verbose=False, jobs=None):
 
     def compile_one(item):
         src, mode, obj = item
-        cmd = [hipcc] + HIPCC_FLAGS + ["-c", src, "-o", obj + ".tmp"]
+        cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + \
+            ["-c", src, "-o", obj + ".tmp"]
         if mode is not None:
             cmd.insert(1, "-DBTR_FMAD=%d" % mode)
         if verbose:
