@@ -297,7 +297,11 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs,
     int mi = kSkip;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+      float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+      // keep the three differences scalar: with them SLP-packed (v_pk_add/mul/fma_f32 on register
+      // pairs) this kernel returned wrong sequences in 1-3 % of its launches beside other
+      // streams' kernels; the library is built with -fno-slp-vectorize as well
+      asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));
       const int d = __float_as_int(sq3(dx, dy, dz));
       pt[i] = d < pt[i] ? d : pt[i];
       mi = mi > pt[i] ? mi : pt[i];
