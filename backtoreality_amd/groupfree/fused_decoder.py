@@ -53,8 +53,9 @@ def _mha_ok(m, E):
 
 
 def covered(layer, query, key, q_pos, k_pos):
-    if not (enabled() and fused_attention.enabled() and query.is_cuda and query.dtype == torch.float32 and query.dim() == 3 and
-            key.dim() == 3 and key.dtype == torch.float32):
+    if not (enabled() and fused_attention.enabled() and query.is_cuda and
+            query.dtype == torch.float32 and query.dim() == 3 and key.dim() == 3 and
+            key.dtype == torch.float32):
         return False
     B, E, Pq = query.shape
     if key.shape[0] != B or key.shape[1] != E or E % 4 or E > 1024:
