@@ -120,6 +120,10 @@ _SIGNATURES = {
     # GroupFree3D per-head loss (csrc/gf_loss.hip, used by groupfree/fused_loss.py)
     "btr_gf_loss_part_floats": (_ci, [_ci, _ci, _ci]),
     "btr_gf_loss_fwd": (_ci, [_vp] * 21),
+    # multi-tensor Adam / AdamW (csrc/optimizer.hip, used by votenet/train.py)
+    "btr_adam_chunk": (_ci, []),
+    "btr_adam_multi": (_ci, [_ci, _ci, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double,
+                             ctypes.c_double, _ci, _ci, _vp, _vp]),
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
@@ -269,6 +273,20 @@ class DecoderPlan(ctypes.Structure):
         "bwd_scratch_bytes", "g_sa_in_w", "g_sa_in_b", "g_sa_out_w", "g_sa_out_b", "g_ca_in_w",
         "g_ca_in_b", "g_ca_out_w", "g_ca_out_b", "g_lin1_w", "g_lin1_b", "g_lin2_w",
         "g_lin2_b")] + [("g_ln", _sz3), ("grads_floats", _sz)]
+
+
+class AdamItem(ctypes.Structure):
+    """btr_adam_item_t"""
+    _fields_ = [("p", _vp), ("m", _vp), ("v", _vp), ("n", ctypes.c_longlong), ("lr", _cf),
+                ("wd", _cf), ("vec", _ci), ("pad_", _ci)]
+
+
+ADAM_MAX_TENSORS = 448   # BTR_ADAM_MAX_TENSORS
+
+
+class AdamGrads(ctypes.Structure):
+    """btr_adam_grads_t"""
+    _fields_ = [("g", _vp * ADAM_MAX_TENSORS)]
 
 
 class GfLoss(ctypes.Structure):

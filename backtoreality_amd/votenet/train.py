@@ -184,6 +184,8 @@ class _FastStep(object):
             norms = torch._foreach_norm([g for _, _, grads in work for g in grads])
             total = torch.linalg.vector_norm(torch.stack(norms))
             scale = ((total + 1e-6) / float(clip_norm)).clamp_(min=1.0)
+        if work and self._library_step(work, scale):
+            return total
         kernel = torch._fused_adamw_ if self._decoupled else torch._fused_adam_
         for group, (params, exp_avgs, exp_avg_sqs, steps), grads in work:
             beta1, beta2 = group['betas']
@@ -192,6 +194,89 @@ class _FastStep(object):
                    lr=group['lr'], beta1=beta1, beta2=beta2, weight_decay=group['weight_decay'],
                    eps=group['eps'], maximize=False, grad_scale=scale, found_inf=None)
         return total
+
+    # ---- the update of ALL groups as one launch of the library (csrc/optimizer.hip)
+    def _library_step(self, work, scale):
+        """True when btr_adam_multi did the update: CUDA f32 contiguous parameters / gradients on
+        one device, equal betas / eps in all groups, not while a HIP graph is captured
+        (`BTR_ADAM_KERNEL=0`: torch's fused kernels).  The per-tensor table (parameter, moments,
+        size, the group's lr / weight decay) and the chunk map live on the device and are rebuilt
+        when the parameter set or a learning rate changes; the gradient pointers ride in the
+        kernel arguments (448 tensors per launch)."""
+        import ctypes
+        import numpy as np
+        from ..pointnet2 import _ext
+        if os.environ.get("BTR_ADAM_KERNEL", "1") == "0":
+            return False
+        g0 = work[0][0]
+        first = work[0][1][0][0]
+        if not first.is_cuda or torch.cuda.is_current_stream_capturing():
+            return False
+        dev = first.device
+        key = tuple((id(cache[0]), float(group['lr']), float(group['weight_decay']),
+                     group['betas'], group['eps']) for group, cache, _ in work)
+        st = getattr(self, '_btr_lib', None)
+        if st is None or st['key'] != key:
+            for group, (params, exp_avgs, exp_avg_sqs, _), _ in work:   # checked once per table
+                if group['betas'] != g0['betas'] or group['eps'] != g0['eps']:
+                    return False
+                for t in list(params) + list(exp_avgs) + list(exp_avg_sqs):
+                    if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+                        return False
+            n_t = sum(len(cache[0]) for _, cache, _ in work)
+            items = (_ext.AdamItem * n_t)()
+            chunk = _ext._lib.btr_adam_chunk()
+            cmap, steps, i = [], [], 0
+            for group, (params, exp_avgs, exp_avg_sqs, stp), _ in work:
+                for p, m, v in zip(params, exp_avgs, exp_avg_sqs):
+                    it = items[i]
+                    it.p, it.m, it.v, it.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                    it.lr, it.wd = float(group['lr']), float(group['weight_decay'])
+                    # (the gradient's alignment is checked per step: see below)
+                    it.vec = int(p.numel() % 4 == 0 and all(
+                        t.data_ptr() % 16 == 0 for t in (p, m, v)))
+                    cmap += [(i, e) for e in range(0, p.numel(), chunk)]
+                    i += 1
+                steps += stp
+            raw = np.frombuffer(items, dtype=np.uint8).copy()
+            # launches: blocks of ADAM_MAX_TENSORS tensors = contiguous runs of the chunk map
+            blocks, c0 = [], 0
+            for t0 in range(0, n_t, _ext.ADAM_MAX_TENSORS):
+                t1 = min(n_t, t0 + _ext.ADAM_MAX_TENSORS)
+                c1 = c0
+                while c1 < len(cmap) and cmap[c1][0] < t1:
+                    c1 += 1
+                blocks.append((t0, t1, c0, c1 - c0, _ext.AdamGrads()))
+                c0 = c1
+            st = self._btr_lib = {
+                'key': key, 'n': n_t, 'steps': steps, 'blocks': blocks,
+                'items': torch.from_numpy(raw).to(dev),
+                'cmap': torch.tensor(cmap, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev),
+                'vec': [bool(items[j].vec) for j in range(n_t)],
+                'count': int(round(float(steps[0].item()))) if steps else 0}
+        ptrs = []
+        for _, _, grads in work:
+            for g in grads:
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.device != dev:
+                    self._btr_lib = None   # torch's kernels take this step (and its step count)
+                    return False
+                ptrs.append(g.data_ptr())
+        if any(v and (q & 15) for v, q in zip(st['vec'], ptrs)):
+            self._btr_lib = None       # a gradient the 16-byte loads cannot take
+            return False
+        torch._foreach_add_(st['steps'], 1)     # the state's step tensors stay what torch keeps
+        st['count'] += 1
+        beta1, beta2 = g0['betas']
+        cmap_ptr = st['cmap'].data_ptr()
+        with _ext._on(first) as dv:
+            stream = _ext._stream(dv)
+            for t0, t1, c0, nchunks, gp in st['blocks']:
+                gp.g[0:t1 - t0] = ptrs[t0:t1]
+                _ext._call(_ext._lib.btr_adam_multi, nchunks, t0, _ext._p(st['items']),
+                           ctypes.addressof(gp), cmap_ptr + 8 * c0, float(beta1), float(beta2),
+                           float(g0['eps']), st['count'], int(self._decoupled), _ext._p(scale),
+                           stream)
+        return True
 
     def _stock_step(self, closure, clip_norm):
         total = None
@@ -212,6 +297,7 @@ class _FastStep(object):
 
     def __setstate__(self, state):
         super().__setstate__(state)
+        self._btr_lib = None
         for g in self.param_groups:
             g.pop('_btr_fast', None)
 
@@ -223,6 +309,7 @@ class _FastStep(object):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._btr_lib = None
         for g in self.param_groups:     # the loaded state tensors are new objects
             g.pop('_btr_fast', None)
 

@@ -711,6 +711,33 @@ int btr_gf_loss_fwd(const btr_gf_loss_t *d, const float *const *heads, const flo
                     long long *object_assignment, float *npos_part, float *part, float *stats,
                     float *grads, btr_stream_t stream);
 
+/* ---- Adam / AdamW over many tensors in one launch (csrc/optimizer.hip) -----------------------
+ * reference: optimizer.step() of train_Votenet_FSB.py:231 (Adam) and train_GF_FSB.py:319 (AdamW,
+ * two parameter groups); update rule of torch's fused implementation (header of the source).
+ * items (device): per tensor its parameter, both moments, element count, learning rate and weight
+ * decay of its group, vec = 1 when all four pointers are 16-byte aligned and n % 4 == 0;
+ * grads (HOST struct, copied into the kernel arguments): the gradient pointers of tensors
+ * tensor0 .. tensor0 + BTR_ADAM_MAX_TENSORS - 1; chunk_map (device, already offset to the first
+ * chunk of tensor0): per workgroup (tensor index, first element), chunks of btr_adam_chunk()
+ * elements; step: the 1-based step count (1 - beta and the bias corrections are evaluated in double
+ * on the host, like torch's kernel does);
+ * grad_scale: NULL or a device scalar every gradient is divided by (folded gradient clipping). */
+typedef struct {
+  float *p, *m, *v;
+  long long n;
+  float lr, wd;
+  int vec, pad_;
+} btr_adam_item_t;
+#define BTR_ADAM_MAX_TENSORS 448
+typedef struct {
+  const float *g[BTR_ADAM_MAX_TENSORS];
+} btr_adam_grads_t;
+int btr_adam_chunk(void);
+int btr_adam_multi(int chunks, int tensor0, const btr_adam_item_t *items,
+                   const btr_adam_grads_t *grads, const int *chunk_map, double beta1,
+                   double beta2, double eps, int step, int decoupled, const float *grad_scale,
+                   btr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,72 @@
+"""train.FastAdam / FastAdamW on the library's one-launch update (csrc/optimizer.hip) against
+torch.optim.Adam / AdamW (fused): parameters and both moments after several steps, with two
+parameter groups, ragged tensor sizes (scalar-path tensors beside 16-byte-path ones), the folded
+gradient clipping, a learning-rate change between steps, and the state_dict round trip."""
+import copy
+
+import pytest
+import torch
+
+from backtoreality_amd.votenet.train import FastAdam, FastAdamW
+
+pytestmark = pytest.mark.gpu
+
+
+SHAPES = [(290, 37), (290,), (3, 290), (3,), (1,), (700, 512), (700,)]
+
+
+def _params(dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in SHAPES]
+
+
+@pytest.mark.parametrize("decoupled", [False, True])
+@pytest.mark.parametrize("clip", [None, 0.5])
+def test_library_step_equals_torch_fused(cuda, decoupled, clip, monkeypatch):
+    pa, pb = _params(cuda, 0), _params(cuda, 0)
+    groups = lambda ps: [{"params": ps[:2] + ps[4:5]}, {"params": ps[2:4] + ps[5:], "lr": 3e-4}]
+    fast_cls, ref_cls = (FastAdamW, torch.optim.AdamW) if decoupled else (FastAdam, torch.optim.Adam)
+    opt_a = fast_cls(groups(pa), lr=2e-3, weight_decay=0.01, fused=True)
+    opt_b = ref_cls(groups(pb), lr=2e-3, weight_decay=0.01, fused=True)
+    used = []
+    real = opt_a._library_step
+    monkeypatch.setattr(opt_a, "_library_step", lambda *a: used.append(real(*a)) or used[-1])
+    g = torch.Generator(device="cpu").manual_seed(7)
+
+    def give_grads():
+        # the SAME gradients to both (the comparison is of the update arithmetic, not of two
+        # trajectories that amplify its rounding)
+        for a, b in zip(pa, pb):
+            gr = (torch.randn(*a.shape, generator=g) * 3).to(cuda)
+            a.grad, b.grad = gr.clone(), gr.clone()
+
+    for i in range(6):
+        if i == 4:     # a scheduler changes the learning rate: the device table follows
+            for opt in (opt_a, opt_b):
+                opt.param_groups[0]['lr'] = 1e-3
+        give_grads()
+        if clip is None:
+            opt_a.step()
+        else:
+            total = opt_a.step(clip_norm=clip)
+            ref = torch.nn.utils.clip_grad_norm_(pb, clip)
+            assert torch.allclose(total, ref, rtol=1e-6)
+        opt_b.step()
+    assert used and all(used), used       # steps 2.. ran on btr_adam_multi (step 1 builds the state)
+    for n, (a, b) in enumerate(zip(pa, pb)):
+        # (a few ulps of the parameter: the two kernels round p - update in their own order)
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-6), (n, float((a - b).abs().max()))
+        sa, sb = opt_a.state[a], opt_b.state[b]
+        assert torch.allclose(sa['exp_avg'], sb['exp_avg'], rtol=2e-6, atol=1e-6), n
+        assert torch.allclose(sa['exp_avg_sq'], sb['exp_avg_sq'], rtol=2e-6, atol=1e-6), n
+        assert float(sa['step']) == float(sb['step']) == 6.0
+    # state_dict round trip: the reloaded optimizer continues identically
+    sd = copy.deepcopy(opt_a.state_dict())
+    opt_c = fast_cls(groups(pa), lr=2e-3, weight_decay=0.01, fused=True)
+    opt_c.load_state_dict(sd)
+    opt_c.param_groups[0]['lr'] = 1e-3
+    give_grads()
+    opt_c.step()
+    opt_b.step()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=3e-6, atol=1.5e-6)
