@@ -80,13 +80,16 @@ class FlatGradParallel(torch.nn.Module):
         with torch.no_grad():
             for p in module.parameters():
                 dist.broadcast(p.data, 0, group=process_group)
-        total = sum(p.numel() for p in params)
+        # every slice starts on a 16-byte boundary (the optimizer kernel's vector loads; the
+        # padding floats stay zero and ride along in the all-reduce)
+        pad4 = lambda n: (n + 3) // 4 * 4
+        total = sum(pad4(p.numel()) for p in params)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self._views = []
         o = 0
         for p in params:
             self._views.append((p, self.flat_grad[o:o + p.numel()].view_as(p)))
-            o += p.numel()
+            o += pad4(p.numel())
         self._avg = dist.get_backend(process_group) == "nccl"   # RCCL has AVG; gloo only sums
 
     def forward(self, *args, **kwargs):
@@ -258,11 +261,11 @@ class _FastStep(object):
         for _, _, grads in work:
             for g in grads:
                 if g.dtype != torch.float32 or not g.is_contiguous() or g.device != dev:
-                    self._btr_lib = None   # torch's kernels take this step (and its step count)
+                    st['count'] += 1       # torch's kernels take this step (and count it)
                     return False
                 ptrs.append(g.data_ptr())
         if any(v and (q & 15) for v, q in zip(st['vec'], ptrs)):
-            self._btr_lib = None       # a gradient the 16-byte loads cannot take
+            st['count'] += 1           # a gradient the 16-byte loads cannot take
             return False
         torch._foreach_add_(st['steps'], 1)     # the state's step tensors stay what torch keeps
         st['count'] += 1

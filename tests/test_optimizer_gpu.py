@@ -70,3 +70,32 @@ def test_library_step_equals_torch_fused(cuda, decoupled, clip, monkeypatch):
     opt_b.step()
     for a, b in zip(pa, pb):
         assert torch.allclose(a, b, rtol=3e-6, atol=1.5e-6)
+
+
+def test_misaligned_gradients_fall_back_for_that_step_only(cuda, monkeypatch):
+    """A gradient the 16-byte loads cannot take (a view at an odd offset) sends ONE step through
+    torch's kernels; the device table and the step count survive, the next step is the
+    library's again and the trajectory stays that of torch.optim.Adam."""
+    pa, pb = _params(cuda, 1), _params(cuda, 1)
+    opt_a = FastAdam(pa, lr=1e-3, fused=True)
+    opt_b = torch.optim.Adam(pb, lr=1e-3, fused=True)
+    used = []
+    real = opt_a._library_step
+    monkeypatch.setattr(opt_a, "_library_step", lambda *a: used.append(real(*a)) or used[-1])
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for i in range(5):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(*a.shape, generator=g).to(cuda)
+            if i == 2:    # an odd-offset view for every tensor
+                buf = torch.empty(gr.numel() + 1, device=cuda)
+                buf[1:] = gr.flatten()
+                a.grad = buf[1:].view_as(gr)
+            else:
+                a.grad = gr.clone()
+            b.grad = gr.clone()
+        opt_a.step()
+        opt_b.step()
+    assert used == [True, False, True, True], used     # (step 1 never reaches the library path)
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-6)
+        assert float(opt_a.state[a]['step']) == 5.0
