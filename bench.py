@@ -332,6 +332,7 @@ def main():
         (eager_step or train_step)(ddp, opt, batch, cfg)
     barrier()
     detail = _ext.timing_end()
+    pair_overhead_ms = _ext.PAIR_OVERHEAD_MS   # empty event pair, subtracted per launch above
     # Secondary figure (never `value`): the same K steps strictly one after the other -- every
     # step waits for its own sampling pyramid (8 of 256 CUs for ~2.2 ms) before anything else.
     sequential = None
@@ -400,7 +401,7 @@ def main():
             out["hip_graph"] = bool(graphed)
         else:
             out["hip_graph"] = graphed_step is not None
-        out.update(roofline_objects(kernels or detail, detail, detail_steps))
+        out.update(roofline_objects(kernels or detail, detail, detail_steps, pair_overhead_ms))
         if seq_kernels and "roofline" in out:
             # the same kernel when nothing shares the chip with it (the sequential loop below)
             ts = [t for (op, key), v in seq_kernels.items() if op == "fps_kernel" for t in v]
@@ -473,7 +474,7 @@ GEMM_OPS = ("sa_gemm_nt", "sa_gemm_nt_rc", "sa_gemm_nt_poolfwd", "sa_gemm_nt_poo
             "sa_gemm_tn", "sa_gemm_tn_rc", "sa_gemm_tn_pool", "pm_gemm_nt")
 
 
-def roofline_objects(kernels, detail, detail_steps):
+def roofline_objects(kernels, detail, detail_steps, pair_overhead_ms=0.0):
     """kernels / detail: {(op, shape-key): [ms, ...]} from the HIP-event timer in `_ext`
     (`kernels`: inside the timed region; `detail`: the instrumented steps after it).
     Algorithmic bytes per launch (SURVEY 8d): ball_query B*(12N + 12M + 4MS);
@@ -545,7 +546,9 @@ def roofline_objects(kernels, detail, detail_steps):
                                "dense_rows_gflop_per_step": dense / 1e9,
                                "dense_rows_equivalent_frac": dense / (ms * 1e-3) / 1e12 /
                                MFMA_F32_PEAK_TF,
-                               "launches_per_step": sum(len(t) for _, t in gemm) / steps}
+                               "launches_per_step": sum(len(t) for _, t in gemm) / steps,
+                               "event_pair_overhead_us_subtracted_per_launch":
+                                   1e3 * pair_overhead_ms}
     fps_op = pick("furthest_point_sampling")   # spatial sort (4 launches) + sampling kernel
     fps = pick("fps_kernel") or fps_op          # the sampling kernel alone (event pair recorded
     if fps:                                     # by the library right around its launch)
