@@ -88,11 +88,15 @@ class FusedHeadsLoss(Function):
         ctx.n_static = 5 + len(_LABELS)
         ctx.save_for_backward(grads)
         ctx.mark_non_differentiable(stats, label, assign)
+        # (no zero-filled gradients for the statistics / label outputs: four fill launches)
+        ctx.set_materialize_grads(False)
         return stats[8 * H + 3].clone(), stats, label, assign
 
     @staticmethod
     def backward(ctx, gtotal, *_unused):
         grads, = ctx.saved_tensors
+        if gtotal is None:
+            return (None,) * (ctx.n_static + grads.shape[0])
         g = grads * gtotal.to(torch.float32)
         return (None,) * ctx.n_static + tuple(g.unbind(0))
 

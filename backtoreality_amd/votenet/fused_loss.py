@@ -94,6 +94,8 @@ class FusedVoteNetLoss(Function):
                               vote_arg, *labels)
         loss = stats[0].clone()
         ctx.mark_non_differentiable(stats, objectness_label, objectness_mask, object_assignment)
+        # (no zero-filled gradients for the statistics / label outputs: four fill launches)
+        ctx.set_materialize_grads(False)
         return loss, stats, objectness_label, objectness_mask, object_assignment
 
     @staticmethod
@@ -101,6 +103,8 @@ class FusedVoteNetLoss(Function):
         (net, agg_xyz, vote_xyz, seed_xyz, seed_inds, mean_size, norm, objectness_label,
          objectness_mask, object_assignment, j1c, k2c, vote_arg, *labels) = ctx.saved_tensors
         B, K, K2, nh, ns, nc, S1, N, cout = ctx.dims
+        if gloss is None:
+            return (None,) * (7 + len(labels))
         gout = gloss.reshape(1).to(torch.float32).contiguous()
         dnet = torch.empty_like(net)
         dagg = torch.empty_like(agg_xyz)
