@@ -222,6 +222,70 @@ __global__ __launch_bounds__(64) void gf_final_kernel(GfDims d, int blocks_per_s
   }
 }
 
+// ------------------------------------------------------------------ decode of a PredictHead
+// reference: detection/GroupFree3D/models/modules.py:233-262 -- from the head's raw output the
+// box centre (base_xyz + residual), the heading / size residuals in metres and the size of the
+// arg-max size class; six elementwise / arg-max / gather launches per head there (seven heads per
+// step), plus the clones and the concatenation that build the next decoder layer's query position
+// (detector.py:204-230).  One wave per proposal here; element (b, p, ch) of the head output lives
+// at out[b * sb + p * sp + ch * sc] (the channel-last twin or the (b, c, p) tensor).
+struct DecodeArgs {
+  int rows, p, nh, ns;
+  const float *out;
+  long long sb, sp, sc;
+  const float *base_xyz, *mean_size;
+  float *center, *hres, *sres, *pred_size, *qpos, *qpos_t;
+  float hscale;
+};
+__global__ __launch_bounds__(256) void gf_head_decode_kernel(DecodeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int b = row / a.p, pp = row - b * a.p;
+  const float *o = a.out + b * a.sb + pp * a.sp;
+  const int o_hres = 4 + a.nh, o_ss = 4 + 2 * a.nh, o_sr = o_ss + a.ns;
+  // arg-max of the size scores: first index of the maximum (what torch.argmax returns here)
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int s = lane; s < a.ns; s += 64) {
+    const float v = o[(o_ss + s) * a.sc];
+    if (v > best || (v == best && s < bi) || (v != v && !(best != best))) {
+      best = v;
+      bi = s;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const float ov = __shfl_xor(best, m);
+    const int oi = __shfl_xor(bi, m);
+    const bool take = (ov != ov) ? (!(best != best) || oi < bi)
+                                 : (!(best != best) && (ov > best || (ov == best && oi < bi)));
+    if (take) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (bi == 0x7fffffff) bi = 0;
+  for (int h = lane; h < a.nh; h += 64)
+    a.hres[(size_t)row * a.nh + h] = __fmul_rn(o[(o_hres + h) * a.sc], a.hscale);
+  for (int i = lane; i < 3 * a.ns; i += 64)
+    a.sres[(size_t)row * 3 * a.ns + i] = __fmul_rn(o[(o_sr + i) * a.sc], a.mean_size[i]);
+  if (lane < 6) {
+    float v;
+    if (lane < 3) {
+      v = __fadd_rn(a.base_xyz[(size_t)row * 3 + lane], o[(1 + lane) * a.sc]);
+      a.center[(size_t)row * 3 + lane] = v;
+    } else {
+      const int c = lane - 3, i = bi * 3 + c;
+      const float ms = a.mean_size[i];
+      v = __fadd_rn(__fmul_rn(o[(o_sr + i) * a.sc], ms), ms);
+      a.pred_size[(size_t)row * 3 + c] = v;
+    }
+    a.qpos[(size_t)row * 6 + lane] = v;
+    a.qpos_t[((size_t)b * 6 + lane) * a.p + pp] = v;
+  }
+}
+
 }  // namespace
 }  // namespace btr
 
@@ -272,5 +336,20 @@ int btr_gf_loss_fwd(const btr_gf_loss_t *dp, const float *const *heads, const fl
 }
 
 int btr_gf_loss_part_floats(int b, int p, int heads) { return heads * b * cdiv(p, 64) * kTerms; }
+
+int btr_gf_head_decode(int b, int p, int nh, int ns, const float *out, long long sb, long long sp,
+                       long long sc, const float *base_xyz, const float *mean_size, float *center,
+                       float *heading_residuals, float *size_residuals, float *pred_size,
+                       float *query_pos, float *query_pos_t, btr_stream_t stream) {
+  if (b <= 0 || p <= 0) return BTR_OK;
+  BTR_REQUIRE(out && base_xyz && mean_size && center && heading_residuals && size_residuals &&
+                  pred_size && query_pos && query_pos_t && nh > 0 && ns > 0,
+              "gf_head_decode: null pointer or nh=%d ns=%d", nh, ns);
+  DecodeArgs a{b * p, p, nh, ns, out, sb, sp, sc, base_xyz, mean_size, center, heading_residuals,
+               size_residuals, pred_size, query_pos, query_pos_t, (float)(M_PI / nh)};
+  hipLaunchKernelGGL(gf_head_decode_kernel, dim3(cdiv(b * p, 4)), dim3(256), 0, as_stream(stream),
+                     a);
+  return check_launch("gf_head_decode");
+}
 
 }  // extern "C"

@@ -13,6 +13,10 @@ int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
                const float *shift, int relu, float *out_bcn, float *out_cl, const float *add,
                long long add_bstride, hipStream_t stream);
 
+// sa_mlp.hip: btr_pm_rows that also clears `nzero` floats at `zero` (first workgroup)
+int pm_rows_zero(int b, int n, int c, int ldr, const float *x, float *rows, float *zero,
+                 int nzero, hipStream_t stream);
+
 // sa_mlp.hip: btr_pm_gemm_nt (no prologue / bias / statistics) with the reduction split over
 // `slices` workgroups per C tile; plane z of the partial products at parts + z * part_stride
 int pm_splitk_slices(int rows, int n, int k);

@@ -83,6 +83,54 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(
   }
 }
 
+// ---- total gradient norm over the same table (clip_grad_norm_ folded into the step)
+// pass 1: one workgroup per chunk of the chunk map -> that chunk's sum of squares
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(
+    const btr_adam_item_t *__restrict__ items, btr_adam_grads_t grads, int tensor0,
+    const int2 *__restrict__ chunk_map, float *__restrict__ partial) {
+  const int2 cm = chunk_map[blockIdx.x];
+  const btr_adam_item_t it = items[cm.x];
+  const float *__restrict__ g = grads.g[cm.x - tensor0];
+  const long long e0 = cm.y, e1 = min((long long)cm.y + kChunk, it.n);
+  float s = 0.f;
+  if (it.vec) {
+    for (long long e = e0 + 4 * threadIdx.x; e < e1; e += 4 * 256) {
+      const float4 gg = *reinterpret_cast<const float4 *>(g + e);
+      s += gg.x * gg.x + gg.y * gg.y + gg.z * gg.z + gg.w * gg.w;
+    }
+  } else {
+    for (long long e = e0 + threadIdx.x; e < e1; e += 256) s += g[e] * g[e];
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// pass 2 (one workgroup, fixed order): out[0] = total norm, out[1] = max(1, (norm + 1e-6) / clip)
+__global__ __launch_bounds__(256) void grad_norm_final_kernel(const float *__restrict__ partial,
+                                                              int chunks, float clip,
+                                                              float *__restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < chunks; i += 256) s += (double)partial[i];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float total = (float)sqrt(red[0]);
+    out[0] = total;
+    out[1] = fmaxf(1.f, (total + 1e-6f) / clip);
+  }
+}
+
 }  // namespace
 }  // namespace btr
 
@@ -111,6 +159,25 @@ int btr_adam_multi(int chunks, int tensor0, const btr_adam_item_t *items,
   hipLaunchKernelGGL(adam_multi_kernel, dim3(chunks), dim3(256), 0, as_stream(stream), items,
                      *grads, tensor0, reinterpret_cast<const int2 *>(chunk_map), h, grad_scale);
   return check_launch("adam_multi");
+}
+
+int btr_grad_sumsq_multi(int chunks, int tensor0, const btr_adam_item_t *items,
+                         const btr_adam_grads_t *grads, const int *chunk_map, float *partial,
+                         btr_stream_t stream) {
+  if (chunks <= 0) return BTR_OK;
+  BTR_REQUIRE(items && grads && chunk_map && partial && tensor0 >= 0,
+              "grad_sumsq_multi: bad arguments");
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(chunks), dim3(256), 0, as_stream(stream), items,
+                     *grads, tensor0, reinterpret_cast<const int2 *>(chunk_map), partial);
+  return check_launch("grad_sumsq_multi");
+}
+
+int btr_grad_norm_final(int chunks, const float *partial, float clip, float *out,
+                        btr_stream_t stream) {
+  BTR_REQUIRE(chunks > 0 && partial && out && clip > 0.f, "grad_norm_final: bad arguments");
+  hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial,
+                     chunks, clip, out);
+  return check_launch("grad_norm_final");
 }
 
 }  // extern "C"

@@ -57,6 +57,10 @@ struct PrepArgs {
   const float *rbias[kMaxL];
   float mom[kMaxL];
   int layers;
+  // bias row of a bare last layer whose width is not a multiple of 4, zero-padded to np
+  const float *pbias_src;
+  float *pbias_dst;
+  int pbias_n, pbias_np;
 };
 
 __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
@@ -81,6 +85,9 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
     wt[(size_t)c * np + r] = v;
   }
   if ((int)blockIdx.x == first && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (blockIdx.x == 0 && a.pbias_dst)
+    for (int c = threadIdx.x; c < a.pbias_np; c += 256)
+      a.pbias_dst[c] = c < a.pbias_n ? a.pbias_src[c] : 0.f;
 }
 
 // running_mean[l] += momentum * bias[l] for the conv biases skipped in front of a BatchNorm
@@ -822,6 +829,17 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
     }
   }
   pa.first[L] = blocks;
+  const int grid = btr_pm_gemm_grid(rows);
+  int maxn = 0;
+  for (int l = 0; l < L; ++l) maxn = std::max(maxn, p.np[l]);
+  float *part = (float *)scratch;
+  float *bias_pad = part + (size_t)grid * 2 * maxn;
+  if (!d.has_bn[L - 1] && d.bias[L - 1] && p.np[L - 1] != d.width[L - 1]) {
+    pa.pbias_src = d.bias[L - 1];   // padded by the same launch (was a memset + a copy)
+    pa.pbias_dst = bias_pad;
+    pa.pbias_n = d.width[L - 1];
+    pa.pbias_np = p.np[L - 1];
+  }
   hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, hs, pa);
 
   const int k0 = p.kin[0];
@@ -832,11 +850,6 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
     BTR_TRY(btr_pm_rows(d.b, d.n, d.c, k0, x_bcn, x0, stream));
     A = x0;
   }  // else: the caller keeps x_cl alive and hands it to the backward again
-  const int grid = btr_pm_gemm_grid(rows);
-  int maxn = 0;
-  for (int l = 0; l < L; ++l) maxn = std::max(maxn, p.np[l]);
-  float *part = (float *)scratch;
-  float *bias_pad = part + (size_t)grid * 2 * maxn;
   int lda = k0;
   const float *pscale = nullptr, *pshift = nullptr;
   for (int l = 0; l < L; ++l) {
@@ -854,13 +867,7 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
       pshift = st + np;
     } else {
       const float *bp = d.bias[l];
-      if (bp && np != d.width[l]) {  // pad the bias row to the padded width
-        hipError_t e = hipMemsetAsync(bias_pad, 0, sizeof(float) * np, hs);
-        if (e == hipSuccess)
-          e = hipMemcpyAsync(bias_pad, bp, sizeof(float) * d.width[l], hipMemcpyDeviceToDevice, hs);
-        if (e != hipSuccess) return fail((int)e, "pm_chain_forward bias: %s", hipGetErrorString(e));
-        bp = bias_pad;
-      }
+      if (bp && np != d.width[l]) bp = bias_pad;   // (padded by prep_weights_kernel)
       BTR_TRY(btr_pm_gemm_nt(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, nullptr, bp,
                              stream));
       pscale = pshift = nullptr;
@@ -886,16 +893,13 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
   float *part = at_f(scratch, sc.part), *m1 = at_f(scratch, sc.m1), *m2 = at_f(scratch, sc.m2);
   float *colsum = at_f(scratch, sc.colsum);
   auto stat = [&](int l, int which) { return at_f(saved, p.stats[l]) + which * p.np[l]; };
-  {  // bias gradients: zero in front of a BatchNorm (and the padding of the others)
-    hipError_t e = hipMemsetAsync(grads + p.dbias[0], 0,
-                                  sizeof(float) * (p.grads_floats - p.dbias[0]), hs);
-    if (e != hipSuccess) return fail((int)e, "pm_chain_backward memset: %s", hipGetErrorString(e));
-  }
   const int nl = d.width[L - 1], npl = p.np[L - 1];
   int flip = 0;
   float *g = at_f(scratch, sc.g[flip]);
   flip ^= 1;
-  BTR_TRY(btr_pm_rows(d.b, d.n, nl, npl, dout, g, stream));
+  // (+ the bias gradients: zero in front of a BatchNorm, and the padding of the others)
+  BTR_TRY(pm_rows_zero(d.b, d.n, nl, npl, dout, g, grads + p.dbias[0],
+                       (int)(p.grads_floats - p.dbias[0]), hs));
   if (d.has_bn[L - 1]) {
     BTR_TRY(btr_sa_bn_relu_bwd(rows, npl, npl, g, at_f(saved, p.y[L - 1]), stat(L - 1, 0),
                                stat(L - 1, 1), stat(L - 1, 2), stat(L - 1, 3), part, m1, m2,

@@ -1395,11 +1395,17 @@ __device__ __forceinline__ bf16x8 tr_read8(const __bf16 *p, int pitch) {
   return u.b;
 }
 
-template <int TNW, bool PRO>
+// GPOOL / XRC as in gemm_tn_kernel.  GPOOL's sparse part cannot be added to the planes after the
+// split, so -- as in gemm_nt_kernel's PRO == 2 -- the threads that hold the (slot, n) entries of
+// the step write a small table (local row of the arg-max or -1, value) and the staging thread adds
+// its entries before splitting.
+template <int TNW, bool PRO, bool GPOOL = false, bool XRC = false>
 __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(
     const float *__restrict__ G, int ldg, const float *__restrict__ X, int ldx, int R, int N,
     int K, const float *__restrict__ pa, const float *__restrict__ pb, int rows_per_chunk,
-    float *__restrict__ pw, Compact cm) {
+    float *__restrict__ pw, const unsigned char *__restrict__ garg,
+    const float *__restrict__ gdcl, const float *__restrict__ galpha,
+    const float *__restrict__ gbeta, int SSH, const float *__restrict__ xw0, Compact cm) {
   if (cm.dims) R = cm.dims[0];  // compact rows: the row count lives on the device
   constexpr int BR = 32;
   constexpr int TN = 32 * TNW;
@@ -1407,6 +1413,10 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(
   constexpr int KT = TNW == 4 ? 2 : 1;
   __shared__ __attribute__((aligned(16))) __bf16 Gp[3 * BR * LG];
   __shared__ __attribute__((aligned(16))) __bf16 Xp[3 * BR * LX];
+  __shared__ __attribute__((aligned(16))) float sXw[XRC ? 64 * 4 : 4];  // W0 rows k0 .. k0+63
+  // GPOOL: per step, slot = group (plain rows) / 8-row block (compact rows) of the 32 rows
+  __shared__ __attribute__((aligned(16))) int sLr[GPOOL ? 4 * TN : 4];
+  __shared__ __attribute__((aligned(16))) float sDv[GPOOL ? 4 * TN : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = TNW == 4 ? wave : (wave >> 1);
   const int wk = TNW == 4 ? 0 : (wave & 1);
@@ -1430,32 +1440,119 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(
     fa = *reinterpret_cast<const float4 *>(pa + k0 + xc4);
     fb = *reinterpret_cast<const float4 *>(pb + k0 + xc4);
   }
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (GPOOL && n0 + gc4 < N) {
+    ga = *reinterpret_cast<const float4 *>(galpha + n0 + gc4);
+    gb = *reinterpret_cast<const float4 *>(gbeta + n0 + gc4);
+  }
   float4 rg[GPASS], rx[2];
+  // GPOOL: this thread's (slot, n column) entries of the step's sparse table
+  const int sp_gi = tid / TN, sp_n = tid % TN;
+  constexpr int SPQ = 4 * TN / 256;  // passes over the 4 slots (2 for TN = 128, 1 for 64)
+  int sp_g[SPQ], sp_ng[SPQ], sp_lr[SPQ];
+  float sp_dv[SPQ];
+#pragma unroll
+  for (int q = 0; q < SPQ; ++q) {
+    sp_g[q] = sp_ng[q] = 0;
+    sp_lr[q] = -1;
+    sp_dv[q] = 0.f;
+  }
+  float gwt[GPASS];  // weight of the dense part for the rows this thread stages
   auto fetch = [&](int r0) {
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       const int row = gr + GR * p;
       rg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r0 + row < rend && n0 + gc4 < N)
+      gwt[p] = 1.f;
+      if (r0 + row < rend && n0 + gc4 < N) {
         rg[p] = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * ldg + n0 + gc4);
+        if (GPOOL && cm.bw && ((r0 + row) & 7) == 0) gwt[p] = cm.bw[(r0 + row) >> 3];
+      }
+    }
+    if (GPOOL && cm.bgrp) {
+      // groups of this step's four blocks: loaded one step ahead (see gemm_nt_kernel)
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q, blk = (r0 >> 3) + slot;
+        if (r0 != rbeg) sp_g[q] = sp_ng[q];
+        sp_lr[q] = -1;
+        if (slot < 4 && (blk << 3) < rend && n0 + sp_n < N) {
+          const int g = sp_g[q];
+          const int lr = cm.goff[g] - r0 + (int)garg[(size_t)g * N + n0 + sp_n];
+          sp_dv[q] = gdcl[(size_t)g * N + n0 + sp_n];
+          sp_lr[q] = (lr >= 0 && (lr >> 3) == slot) ? lr : -1;
+        }
+        const int nblk = ((r0 + BR) >> 3) + slot;
+        sp_ng[q] = (slot < 4 && (nblk << 3) < rend) ? cm.bgrp[nblk] : 0;
+      }
+    } else if (GPOOL) {
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q;
+        const int g = (r0 >> SSH) + slot;  // group size S = 1 << SSH
+        sp_lr[q] = -1;
+        if ((slot << SSH) < BR && (g << SSH) < rend && n0 + sp_n < N) {
+          const int arow = (g << SSH) + (int)garg[(size_t)g * N + n0 + sp_n];
+          sp_dv[q] = gdcl[(size_t)g * N + n0 + sp_n];
+          const int lr = arow - r0;  // local row of the arg-max in this step
+          sp_lr[q] = (lr >= 0 && lr < BR && arow < rend) ? lr : -1;
+        }
+      }
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int row = xr + 16 * p;
       rx[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r0 + row < rend && k0 + xc4 < K)
-        rx[p] = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + xc4);
+        rx[p] = XRC ? *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * 4)
+                    : *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * ldx + k0 + xc4);
     }
   };
+  if (GPOOL && cm.bgrp && rbeg < rend) {
+#pragma unroll
+    for (int q = 0; q < SPQ; ++q) {
+      const int slot = sp_gi + (256 / TN) * q, blk = (rbeg >> 3) + slot;
+      sp_g[q] = (slot < 4 && (blk << 3) < rend) ? cm.bgrp[blk] : 0;
+    }
+  }
+  if (XRC) {  // 64 k rows x 4 input columns of the first layer's weight
+    if (k0 + (tid >> 2) < K) sXw[tid] = xw0[(size_t)k0 * 4 + tid];
+    __syncthreads();
+  }
   // fragment addressing of the transpose reads: lane -> (row, column) of its 8-byte piece
   const int p16 = lane & 15, grp = lane >> 4;
   const int frow = 8 * (grp >> 1) + (p16 >> 2), fcol = 16 * (grp & 1) + 4 * (p16 & 3);
   if (rbeg < rend) fetch(rbeg);
   for (int r0 = rbeg; r0 < rend; r0 += BR) {
+    if constexpr (GPOOL) {   // the step's sparse table
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q;
+        sLr[slot * TN + sp_n] = sp_lr[q];
+        sDv[slot * TN + sp_n] = sp_dv[q];
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
-      const Split4 sp = split4(rg[p]);
-      const int at = (gr + GR * p) * LG + gc4;
+      float4 v = rg[p];
+      const int row = gr + GR * p;
+      if (GPOOL && r0 + row < rend && n0 + gc4 < N) {  // dense part, weighted, + sparse part
+        const float wr = gwt[p];
+        v.x = wr * fmaf(ga.x, v.x, gb.x);
+        v.y = wr * fmaf(ga.y, v.y, gb.y);
+        v.z = wr * fmaf(ga.z, v.z, gb.z);
+        v.w = wr * fmaf(ga.w, v.w, gb.w);
+        const int slot = cm.bgrp ? (row >> 3) : (row >> SSH);
+        const int4 lr = *reinterpret_cast<const int4 *>(&sLr[slot * TN + gc4]);
+        const float4 dv = *reinterpret_cast<const float4 *>(&sDv[slot * TN + gc4]);
+        v.x += lr.x == row ? dv.x : 0.f;
+        v.y += lr.y == row ? dv.y : 0.f;
+        v.z += lr.z == row ? dv.z : 0.f;
+        v.w += lr.w == row ? dv.w : 0.f;
+      }
+      const Split4 sp = split4(v);
+      const int at = row * LG + gc4;
       *reinterpret_cast<bf16x4 *>(&Gp[0 * BR * LG + at]) = sp.h;
       *reinterpret_cast<bf16x4 *>(&Gp[1 * BR * LG + at]) = sp.m;
       *reinterpret_cast<bf16x4 *>(&Gp[2 * BR * LG + at]) = sp.l;
@@ -1464,6 +1561,7 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(
     for (int p = 0; p < 2; ++p) {
       const int row = xr + 16 * p;
       float4 x = rx[p];
+      if (XRC && r0 + row < rend && k0 + xc4 < K) x = rc_y4(x, sXw, xc4);
       if (PRO && r0 + row < rend && k0 + xc4 < K) {
         x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
         x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
@@ -1604,8 +1702,31 @@ __global__ __launch_bounds__(256) void reduce_chunks_wide_kernel(int total4, int
   dw[i] = make_float4((float)x, (float)y, (float)z, (float)w);
 }
 
+// ... and of several such gradients in one launch (a decoder layer's seven, a point-wise chain's
+// two or three): same per-element order as reduce_chunks_wide_kernel.
+__global__ __launch_bounds__(256) void reduce_chunks_wide_multi_kernel(ReduceArgs a) {
+  const float *pw = a.pw[0];
+  float *dw = a.dw[0];
+  int total4 = a.total[0], chunks = a.chunks[0], first = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxReduceSeg; ++i)   // static indices (see prep_weights_kernel)
+    if (i < a.n && (int)blockIdx.x >= a.first[i]) {
+      pw = a.pw[i]; dw = a.dw[i]; total4 = a.total[i]; chunks = a.chunks[i]; first = a.first[i];
+    }
+  const int i = ((int)blockIdx.x - first) * 256 + (int)threadIdx.x;
+  if (i >= total4) return;
+  double x = 0.0, y = 0.0, z = 0.0, w = 0.0;
+#pragma unroll 4
+  for (int c = 0; c < chunks; ++c) {
+    const float4 v = reinterpret_cast<const float4 *>(pw)[(size_t)c * total4 + i];
+    x += (double)v.x; y += (double)v.y; z += (double)v.z; w += (double)v.w;
+  }
+  reinterpret_cast<float4 *>(dw)[i] = make_float4((float)x, (float)y, (float)z, (float)w);
+}
+
 struct ReduceBatch {
   ReduceArgs args;
+  ReduceArgs wide;   // (total = number of float4, first = 256-thread blocks)
   bool on = false;
 };
 inline ReduceBatch &reduce_batch() {
@@ -1615,12 +1736,22 @@ inline ReduceBatch &reduce_batch() {
 // dw = sum over chunks of pw: now, or with the batch of the running layer call
 inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *dw,
                                  hipStream_t st) {
+  ReduceBatch &b = reduce_batch();
   if (chunks <= 16 && total >= 65536 && total % 4 == 0) {
+    if (b.on && b.wide.n < kMaxReduceSeg) {
+      ReduceArgs &a = b.wide;
+      a.pw[a.n] = pw;
+      a.dw[a.n] = dw;
+      a.total[a.n] = total / 4;
+      a.chunks[a.n] = chunks;
+      a.first[a.n + 1] = a.first[a.n] + cdiv(total / 4, 256);
+      ++a.n;
+      return;
+    }
     hipLaunchKernelGGL(reduce_chunks_wide_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, st,
                        total / 4, chunks, (const float4 *)pw, (float4 *)dw);
     return;
   }
-  ReduceBatch &b = reduce_batch();
   if (b.on && b.args.n < kMaxReduceSeg) {
     ReduceArgs &a = b.args;
     a.pw[a.n] = pw;
@@ -1642,8 +1773,8 @@ inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *
 void reduce_batch_begin() {
   ReduceBatch &b = reduce_batch();
   b.on = true;
-  b.args.n = 0;
-  b.args.first[0] = 0;
+  b.args.n = b.wide.n = 0;
+  b.args.first[0] = b.wide.first[0] = 0;
 }
 void reduce_batch_flush(hipStream_t st) {
   ReduceBatch &b = reduce_batch();
@@ -1651,7 +1782,10 @@ void reduce_batch_flush(hipStream_t st) {
   if (b.args.n > 0)
     hipLaunchKernelGGL(reduce_chunks_multi_kernel, dim3(b.args.first[b.args.n]), dim3(256), 0, st,
                        b.args);
-  b.args.n = 0;
+  if (b.wide.n > 0)
+    hipLaunchKernelGGL(reduce_chunks_wide_multi_kernel, dim3(b.wide.first[b.wide.n]), dim3(256), 0,
+                       st, b.wide);
+  b.args.n = b.wide.n = 0;
 }
 
 // ------------------------------------------------------------- scatter of dX0 (layer-0 dgrad)
@@ -2104,10 +2238,15 @@ __global__ __launch_bounds__(256) void pm_out_kernel(int N, int C, int ldy,
 }
 
 // rows[b*N + n][c] = x[b][c][n] (c < C), zero for C <= c < ldr: (B, C, N) -> channel-last rows
+// zero / nzero: a run of floats the first workgroup clears on the way (the chain backward's bias
+// gradients -- was a memset of its own in front of this kernel)
 __global__ __launch_bounds__(256) void pm_rows_kernel(int N, int C, int ldr,
                                                       const float *__restrict__ x,
-                                                      float *__restrict__ rows) {
+                                                      float *__restrict__ rows,
+                                                      float *__restrict__ zero, int nzero) {
   __shared__ float tile[64][65];
+  if (zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0.f;
   const int bi = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
@@ -2121,6 +2260,16 @@ __global__ __launch_bounds__(256) void pm_rows_kernel(int N, int C, int ldr,
     const int n = n0 + ty + 4 * i, c = c0 + tx;
     if (n < N && c < ldr) rows[((size_t)bi * N + n) * ldr + c] = tile[tx][ty + 4 * i];
   }
+}
+
+// (internal.hpp) btr_pm_rows that also clears `nzero` floats at `zero`
+int pm_rows_zero(int b, int n, int c, int ldr, const float *x, float *rows, float *zero,
+                 int nzero, hipStream_t stream) {
+  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(x && rows && ldr >= c, "pm_rows: bad arguments");
+  hipLaunchKernelGGL(pm_rows_kernel, dim3(cdiv(n, 64), cdiv(ldr, 64), b), dim3(256), 0, stream, n,
+                     c, ldr, x, rows, zero, nzero);
+  return check_launch("pm_rows");
 }
 
 // (internal.hpp) pm_out with an operand added to the (B, C, N) output
@@ -2146,7 +2295,6 @@ inline HostCompact &host_compact() {
 }
 inline Compact cur_compact() { return host_compact().on ? host_compact().dev : Compact{}; }
 
-#define BTR_TN_KERNEL(W, P, GP, XR) (gemm_tn_kernel<W, P, GP, XR>)
 
 // BTR_GEMM=f32: the f32-input MFMA kernels (v_mfma_f32_32x32x2_f32) instead of bf16x6
 inline bool gemm_x6() {
@@ -2157,6 +2305,27 @@ inline bool gemm_x6() {
 inline bool tn_x6() {
   static const bool on = !(getenv("BTR_GEMM_TN") && getenv("BTR_GEMM_TN")[0] == 'f');
   return on && gemm_x6();
+}
+// BTR_GEMM_TN_POOL=f32: the f32-input kernel for the pooled-gradient / first-layer-recompute
+// weight-gradient GEMMs only
+inline bool tn_pool_x6() {
+  static const bool on = !(getenv("BTR_GEMM_TN_POOL") && getenv("BTR_GEMM_TN_POOL")[0] == 'f');
+  return on && tn_x6();
+}
+
+template <int W, bool P, bool GP, bool XR>
+inline void launch_tn(bool x6, dim3 grid, hipStream_t st, const float *g, int ldg, const float *x,
+                      int ldx, int rows, int n, int k, const float *pa, const float *pb, int rpc,
+                      float *pw, const unsigned char *garg, const float *gdcl,
+                      const float *galpha, const float *gbeta, int ssh, const float *xw0) {
+  if (x6)
+    hipLaunchKernelGGL((gemm_tn_x6_kernel<W, P, GP, XR>), grid, dim3(256), 0, st, g, ldg, x, ldx,
+                       rows, n, k, pa, pb, rpc, pw, garg, gdcl, galpha, gbeta, ssh, xw0,
+                       cur_compact());
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<W, P, GP, XR>), grid, dim3(256), 0, st, g, ldg, x, ldx,
+                       rows, n, k, pa, pb, rpc, pw, garg, gdcl, galpha, gbeta, ssh, xw0,
+                       cur_compact());
 }
 
 }  // namespace btr
@@ -2437,15 +2606,11 @@ int btr_sa_gemm_tn_rc(int rows, int n, int k, const float *g, int ldg, const flo
   const int tn = tn_tile_n(n);
   const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
   if (tn == 128)
-    hipLaunchKernelGGL(BTR_TN_KERNEL(4, true, false, true), grid, dim3(256), 0, st, g, ldg, x0,
-                       4, rows, n, k, pa, pb, rpc, pw, (const unsigned char *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
-                       w0, cur_compact());
+    launch_tn<4, true, false, true>(tn_pool_x6(), grid, st, g, ldg, x0, 4, rows, n, k, pa, pb, rpc,
+                                    pw, nullptr, nullptr, nullptr, nullptr, 0, w0);
   else
-    hipLaunchKernelGGL(BTR_TN_KERNEL(2, true, false, true), grid, dim3(256), 0, st, g, ldg, x0,
-                       4, rows, n, k, pa, pb, rpc, pw, (const unsigned char *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0,
-                       w0, cur_compact());
+    launch_tn<2, true, false, true>(tn_pool_x6(), grid, st, g, ldg, x0, 4, rows, n, k, pa, pb, rpc,
+                                    pw, nullptr, nullptr, nullptr, nullptr, 0, w0);
   reduce_chunks_launch(n * k, chunks, pw, dw, st);
   return check_launch("sa_gemm_tn_rc");
 }
@@ -2514,26 +2679,14 @@ int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float 
   const int rpc = cdiv(cdiv(rows, chunks), 32) * 32;
   const int tn = tn_tile_n(n);
   const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
-#define BTR_TN(W, P)                                                                          \
-  hipLaunchKernelGGL(BTR_TN_KERNEL(W, P, false, false), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n, \
-                     k, pa, pb, rpc, pw, (const unsigned char *)nullptr, (const float *)nullptr, \
-                     (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr, \
-                     cur_compact())
-#define BTR_TN6(W, P)                                                                          \
-  hipLaunchKernelGGL((gemm_tn_x6_kernel<W, P>), grid, dim3(256), 0, st, g, ldg, x, ldx, rows, n, \
-                     k, pa, pb, rpc, pw, cur_compact())
-  if (tn_x6()) {
-    if (tn == 128) {
-      if (pa) BTR_TN6(4, true); else BTR_TN6(4, false);
-    } else {
-      if (pa) BTR_TN6(2, true); else BTR_TN6(2, false);
-    }
-  } else if (tn == 128) {
+#define BTR_TN(W, P)                                                                       \
+  launch_tn<W, P, false, false>(tn_x6(), grid, st, g, ldg, x, ldx, rows, n, k, pa, pb, rpc, pw, \
+                                nullptr, nullptr, nullptr, nullptr, 0, nullptr)
+  if (tn == 128) {
     if (pa) BTR_TN(4, true); else BTR_TN(4, false);
   } else {
     if (pa) BTR_TN(2, true); else BTR_TN(2, false);
   }
-#undef BTR_TN6
 #undef BTR_TN
   reduce_chunks_launch(n * k, chunks, pw, dw, st);
   return check_launch("sa_gemm_tn");
@@ -2557,10 +2710,9 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
   const int rpc = cdiv(cdiv(rows, chunks), 32) * 32;
   const int tn = tn_tile_n(n);
   const dim3 grid(cdiv(n, tn), cdiv(k, 64), chunks);
-#define BTR_TNP(W, P)                                                                         \
-  hipLaunchKernelGGL(BTR_TN_KERNEL(W, P, true, false), grid, dim3(256), 0, st, y, ldy, x, ldx,    \
-                     rows, n, k, pa, pb, rpc, pw, arg, dcl, alpha, beta, ssh,                 \
-                     (const float *)nullptr, cur_compact())
+#define BTR_TNP(W, P)                                                                      \
+  launch_tn<W, P, true, false>(tn_pool_x6(), grid, st, y, ldy, x, ldx, rows, n, k, pa, pb, rpc, \
+                               pw, arg, dcl, alpha, beta, ssh, nullptr)
   if (tn == 128) {
     if (pa) BTR_TNP(4, true); else BTR_TNP(4, false);
   } else {
@@ -2813,11 +2965,7 @@ int btr_pm_out(int b, int n, int c, int ldy, const float *y, const float *scale,
 
 // rows (B*N, ldr) = x (B, C, N) transposed, columns C .. ldr zero
 int btr_pm_rows(int b, int n, int c, int ldr, const float *x, float *rows, btr_stream_t stream) {
-  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
-  BTR_REQUIRE(x && rows && ldr >= c, "pm_rows: bad arguments");
-  hipLaunchKernelGGL(pm_rows_kernel, dim3(cdiv(n, 64), cdiv(ldr, 64), b), dim3(256), 0,
-                     as_stream(stream), n, c, ldr, x, rows);
-  return check_launch("pm_rows");
+  return pm_rows_zero(b, n, c, ldr, x, rows, nullptr, 0, as_stream(stream));
 }
 
 }  // extern "C"

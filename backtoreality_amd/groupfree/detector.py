@@ -125,7 +125,7 @@ class GroupFreeDetector(nn.Module):
 
         center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz,
                                           end_points=end_points, prefix='proposal_')
-        base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        query_pos = self._query_pos(center, size)
         if self.num_decoder_layers <= 0:
             return self._finish(end_points)
 
@@ -134,18 +134,24 @@ class GroupFreeDetector(nn.Module):
         key_pos = None if self.cross_position_embedding == 'none' else points_xyz
         for i in range(self.num_decoder_layers):
             prefix = 'last_' if i == self.num_decoder_layers - 1 else '%dhead_' % i
-            if self.self_position_embedding == 'none':
-                query_pos = None
-            elif self.self_position_embedding == 'xyz_learned':
-                query_pos = base_xyz
-            else:
-                query_pos = torch.cat([base_xyz, base_size], -1)
             query = self.decoder[i](query, key, query_pos, key_pos)
             self._after_decoder_layer(prefix, query, end_points)
             center, size = self.prediction_heads[i](query, base_xyz=cluster_xyz,
                                                     end_points=end_points, prefix=prefix)
-            base_xyz, base_size = center.detach().clone(), size.detach().clone()
+            query_pos = self._query_pos(center, size)
         return self._finish(end_points)
+
+    def _query_pos(self, center, size):
+        """The next decoder layer's query position from a head's (center, pred_size): detached
+        copies, concatenated for the 'loc_learned' embedding (detector.py:204-230)."""
+        if self.self_position_embedding == 'none':
+            return None
+        if self.self_position_embedding == 'xyz_learned':
+            return center.detach().clone()
+        fused = getattr(center, '_btr_query_pos', None)   # written by the head decode kernel
+        if fused is not None:
+            return fused
+        return torch.cat([center.detach().clone(), size.detach().clone()], -1)
 
     def _backbone(self, inputs, center_xyz, center_cls):
         # inputs['sampling']: optional handle of backbone_net.prefetch_sampling (the pyramid of

@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..pointnet2 import fused_mlp, pointnet2_utils
+from . import fused_decode
 
 
 class PointsObjClsModule(nn.Module):
@@ -44,7 +45,13 @@ class PositionEmbeddingLearned(nn.Module):
             nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
 
     def forward(self, xyz):
-        x = xyz.transpose(1, 2).contiguous()
+        # (B, C, P) form: made once per coordinate tensor (the key positions feed every decoder
+        # layer's embedding; the head decode kernel writes the query positions in both forms)
+        x = getattr(xyz, '_btr_t', None)
+        if x is None:
+            x = xyz.transpose(1, 2).contiguous()
+            if not xyz.requires_grad:
+                xyz._btr_t = x
         head = self.position_embedding_head
         out = fused_mlp.run_chain(x, [(head[0], head[1], True), (head[3], None, False)])
         return out if out is not None else head(x)
@@ -143,15 +150,22 @@ class PredictHead(nn.Module):
         (objectness_scores, center_residual, heading_scores, heading_residuals_normalized,
          size_scores, size_residuals_flat, sem_cls_scores) = torch.split(
             out, [h.out_channels for h in heads], dim=2)
-        center = base_xyz + center_residual
-        heading_residuals = heading_residuals_normalized * (np.pi / self.num_heading_bin)
-
-        mean_size = self._mean_size_on(features.device).unsqueeze(0).unsqueeze(0)
+        mean_size_2d = self._mean_size_on(features.device)
         size_residuals_normalized = size_residuals_flat.reshape(B, P, self.num_size_cluster, 3)
-        size_residuals = size_residuals_normalized * mean_size
-        size_recover = size_residuals + mean_size
-        pick = torch.argmax(size_scores, -1).unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 1, 3)
-        pred_size = torch.gather(size_recover, 2, pick).squeeze(2)
+        dec = fused_decode.decode(end_points[prefix + '_head_output'], base_xyz, mean_size_2d,
+                                  self.num_heading_bin, self.num_size_cluster)
+        if dec is not None:   # one launch (csrc/gf_loss.hip); also the next layer's query position
+            center, heading_residuals, size_residuals, pred_size, qpos, qpos_t = dec
+            qpos._btr_t = qpos_t
+            center._btr_query_pos = qpos
+        else:
+            center = base_xyz + center_residual
+            heading_residuals = heading_residuals_normalized * (np.pi / self.num_heading_bin)
+            mean_size = mean_size_2d.unsqueeze(0).unsqueeze(0)
+            size_residuals = size_residuals_normalized * mean_size
+            size_recover = size_residuals + mean_size
+            pick = torch.argmax(size_scores, -1).unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 1, 3)
+            pred_size = torch.gather(size_recover, 2, pick).squeeze(2)
 
         for key, value in (('base_xyz', base_xyz), ('objectness_scores', objectness_scores),
                            ('center', center), ('heading_scores', heading_scores),

@@ -120,10 +120,13 @@ _SIGNATURES = {
     # GroupFree3D per-head loss (csrc/gf_loss.hip, used by groupfree/fused_loss.py)
     "btr_gf_loss_part_floats": (_ci, [_ci, _ci, _ci]),
     "btr_gf_loss_fwd": (_ci, [_vp] * 21),
+    "btr_gf_head_decode": (_ci, [_ci] * 4 + [_vp] + [ctypes.c_longlong] * 3 + [_vp] * 9),
     # multi-tensor Adam / AdamW (csrc/optimizer.hip, used by votenet/train.py)
     "btr_adam_chunk": (_ci, []),
     "btr_adam_multi": (_ci, [_ci, _ci, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double,
                              ctypes.c_double, _ci, _ci, _vp, _vp]),
+    "btr_grad_sumsq_multi": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "btr_grad_norm_final": (_ci, [_ci, _vp, ctypes.c_float, _vp, _vp]),
     # fused VoteNet loss (used by votenet/fused_loss.py)
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),

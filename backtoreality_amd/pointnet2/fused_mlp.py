@@ -361,13 +361,24 @@ def _min_rows():
     return 2048
 
 
+PATHS = {"library": 0, "python": 0, "stock": 0, "stock_small": 0}   # run_chain decisions (bench.py reports them)
+
+
 def run_chain(x, chain):
     """chain: [(conv, bn | None, relu: bool)].  Returns None when the fused path does not
     cover the configuration (CPU tensors, eval mode, disabled): the caller then runs the
     stock ops."""
+    out = _run_chain(x, chain)
+    if out is None:
+        PATHS["stock"] += 1
+    return out
+
+
+def _run_chain(x, chain):
     if not (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
         return None
     if x.shape[0] * x.shape[2] < _min_rows():
+        PATHS["stock_small"] += 1
         return None
     K = x.shape[1]
     metas, params = [], []
@@ -388,5 +399,7 @@ def run_chain(x, chain):
         cache = _CHAIN_CACHE.get(chain[0][0])
         if cache is None:
             cache = _CHAIN_CACHE[chain[0][0]] = {}
+        PATHS["library"] += 1
         return PointwiseChain.apply(x, {"layers": metas, "cache": cache}, *params)
+    PATHS["python"] += 1
     return PointwiseMLP.apply(x, {"layers": metas}, *params)

@@ -182,13 +182,15 @@ class _FastStep(object):
                     [self.state[p]['step'] for p in params])
             if cache[0]:
                 work.append((group, cache, [p.grad for p in cache[0]]))
+        if work:
+            done = self._library_step(work, clip_norm)
+            if done is not None:
+                return done[0]
         total = scale = None
         if clip_norm is not None and work:
             norms = torch._foreach_norm([g for _, _, grads in work for g in grads])
             total = torch.linalg.vector_norm(torch.stack(norms))
             scale = ((total + 1e-6) / float(clip_norm)).clamp_(min=1.0)
-        if work and self._library_step(work, scale):
-            return total
         kernel = torch._fused_adamw_ if self._decoupled else torch._fused_adam_
         for group, (params, exp_avgs, exp_avg_sqs, steps), grads in work:
             beta1, beta2 = group['betas']
@@ -199,10 +201,13 @@ class _FastStep(object):
         return total
 
     # ---- the update of ALL groups as one launch of the library (csrc/optimizer.hip)
-    def _library_step(self, work, scale):
-        """True when btr_adam_multi did the update: CUDA f32 contiguous parameters / gradients on
-        one device, equal betas / eps in all groups, not while a HIP graph is captured
-        (`BTR_ADAM_KERNEL=0`: torch's fused kernels).  The per-tensor table (parameter, moments,
+    def _library_step(self, work, clip_norm):
+        """(total norm | None,) when btr_adam_multi did the update, None when it cannot: CUDA f32
+        contiguous parameters / gradients on one device, equal betas / eps in all groups, not
+        while a HIP graph is captured (`BTR_ADAM_KERNEL=0`: torch's fused kernels).  With
+        `clip_norm` the total gradient norm comes from two more launches over the same table
+        (btr_grad_sumsq_multi / btr_grad_norm_final) and its clip factor is the update's
+        grad_scale operand.  The per-tensor table (parameter, moments,
         size, the group's lr / weight decay) and the chunk map live on the device and are rebuilt
         when the parameter set or a learning rate changes; the gradient pointers ride in the
         kernel arguments (448 tensors per launch)."""
@@ -210,11 +215,11 @@ class _FastStep(object):
         import numpy as np
         from ..pointnet2 import _ext
         if os.environ.get("BTR_ADAM_KERNEL", "1") == "0":
-            return False
+            return None
         g0 = work[0][0]
         first = work[0][1][0][0]
         if not first.is_cuda or torch.cuda.is_current_stream_capturing():
-            return False
+            return None
         dev = first.device
         key = tuple((id(cache[0]), float(group['lr']), float(group['weight_decay']),
                      group['betas'], group['eps']) for group, cache, _ in work)
@@ -222,10 +227,10 @@ class _FastStep(object):
         if st is None or st['key'] != key:
             for group, (params, exp_avgs, exp_avg_sqs, _), _ in work:   # checked once per table
                 if group['betas'] != g0['betas'] or group['eps'] != g0['eps']:
-                    return False
+                    return None
                 for t in list(params) + list(exp_avgs) + list(exp_avg_sqs):
                     if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
-                        return False
+                        return None
             n_t = sum(len(cache[0]) for _, cache, _ in work)
             items = (_ext.AdamItem * n_t)()
             chunk = _ext._lib.btr_adam_chunk()
@@ -256,30 +261,41 @@ class _FastStep(object):
                 'items': torch.from_numpy(raw).to(dev),
                 'cmap': torch.tensor(cmap, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev),
                 'vec': [bool(items[j].vec) for j in range(n_t)],
+                'partial': torch.empty((max(len(cmap), 1),), dtype=torch.float32, device=dev),
                 'count': int(round(float(steps[0].item()))) if steps else 0}
         ptrs = []
         for _, _, grads in work:
             for g in grads:
                 if g.dtype != torch.float32 or not g.is_contiguous() or g.device != dev:
                     st['count'] += 1       # torch's kernels take this step (and count it)
-                    return False
+                    return None
                 ptrs.append(g.data_ptr())
         if any(v and (q & 15) for v, q in zip(st['vec'], ptrs)):
             st['count'] += 1           # a gradient the 16-byte loads cannot take
-            return False
+            return None
         torch._foreach_add_(st['steps'], 1)     # the state's step tensors stay what torch keeps
         st['count'] += 1
         beta1, beta2 = g0['betas']
         cmap_ptr = st['cmap'].data_ptr()
+        norm = None
         with _ext._on(first) as dv:
             stream = _ext._stream(dv)
             for t0, t1, c0, nchunks, gp in st['blocks']:
                 gp.g[0:t1 - t0] = ptrs[t0:t1]
+            if clip_norm is not None:
+                norm = torch.empty((2,), dtype=torch.float32, device=dev)   # (total, clip factor)
+                part = st['partial'].data_ptr()
+                for t0, t1, c0, nchunks, gp in st['blocks']:
+                    _ext._call(_ext._lib.btr_grad_sumsq_multi, nchunks, t0, _ext._p(st['items']),
+                               ctypes.addressof(gp), cmap_ptr + 8 * c0, part + 4 * c0, stream)
+                _ext._call(_ext._lib.btr_grad_norm_final, st['cmap'].shape[0], part,
+                           float(clip_norm), _ext._p(norm), stream)
+            scale = norm.data_ptr() + 4 if norm is not None else None
+            for t0, t1, c0, nchunks, gp in st['blocks']:
                 _ext._call(_ext._lib.btr_adam_multi, nchunks, t0, _ext._p(st['items']),
                            ctypes.addressof(gp), cmap_ptr + 8 * c0, float(beta1), float(beta2),
-                           float(g0['eps']), st['count'], int(self._decoupled), _ext._p(scale),
-                           stream)
-        return True
+                           float(g0['eps']), st['count'], int(self._decoupled), scale, stream)
+        return (norm[0] if norm is not None else None,)
 
     def _stock_step(self, closure, clip_norm):
         total = None

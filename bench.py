@@ -318,9 +318,13 @@ def main():
     _ext.timing_begin(lambda op, key: op in ("furthest_point_sampling", "fps_kernel",
                                              "ball_query", "ball_query_buckets")
                       and key[1] > 4096)
+    from backtoreality_amd.pointnet2 import fused_mlp as _fm
+    for k in _fm.PATHS:
+        _fm.PATHS[k] = 0
     t0 = time.perf_counter()
     run_steps(args.steps)
     enqueue = time.perf_counter() - t0   # host side done (launches queued), GPU still running
+    chain_paths = dict(_fm.PATHS)        # point-wise chains of the timed steps, by path taken
     barrier()
     elapsed = time.perf_counter() - t0
     kernels = _ext.timing_end()
@@ -401,6 +405,10 @@ def main():
             out["hip_graph"] = bool(graphed)
         else:
             out["hip_graph"] = graphed_step is not None
+        # which form the point-wise MLP chains of the timed steps took (library = one C call per
+        # chain and direction; stock_small = torch ops for chains of < 2048 rows, the choice made
+        # while a HIP graph is captured)
+        out["chain_paths"] = chain_paths
         out.update(roofline_objects(kernels or detail, detail, detail_steps, pair_overhead_ms))
         if seq_kernels and "roofline" in out:
             # the same kernel when nothing shares the chip with it (the sequential loop below)

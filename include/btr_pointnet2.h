@@ -711,6 +711,19 @@ int btr_gf_loss_fwd(const btr_gf_loss_t *d, const float *const *heads, const flo
                     long long *object_assignment, float *npos_part, float *part, float *stats,
                     float *grads, btr_stream_t stream);
 
+/* ---- GroupFree3D: decode of one PredictHead's raw output (csrc/gf_loss.hip) --------------------
+ * reference: detection/GroupFree3D/models/modules.py:233-262 and the query-position bookkeeping of
+ * detector.py:204-230.  Element (b, p, ch) of the head output is out[b*sb + p*sp + ch*sc]
+ * (channel order as in btr_gf_loss_fwd); base_xyz (b, p, 3); mean_size (ns, 3).
+ * center (b, p, 3) = base_xyz + centre residual; heading_residuals (b, p, nh) = normalized * pi/nh;
+ * size_residuals (b, p, ns, 3) = normalized * mean_size; pred_size (b, p, 3) = (size_residuals +
+ * mean_size)[arg-max size class]; query_pos (b, p, 6) = (center, pred_size) and query_pos_t
+ * (b, 6, p) its transpose -- the next decoder layer's position-embedding input. */
+int btr_gf_head_decode(int b, int p, int nh, int ns, const float *out, long long sb, long long sp,
+                       long long sc, const float *base_xyz, const float *mean_size, float *center,
+                       float *heading_residuals, float *size_residuals, float *pred_size,
+                       float *query_pos, float *query_pos_t, btr_stream_t stream);
+
 /* ---- Adam / AdamW over many tensors in one launch (csrc/optimizer.hip) -----------------------
  * reference: optimizer.step() of train_Votenet_FSB.py:231 (Adam) and train_GF_FSB.py:319 (AdamW,
  * two parameter groups); update rule of torch's fused implementation (header of the source).
@@ -737,6 +750,16 @@ int btr_adam_multi(int chunks, int tensor0, const btr_adam_item_t *items,
                    const btr_adam_grads_t *grads, const int *chunk_map, double beta1,
                    double beta2, double eps, int step, int decoupled, const float *grad_scale,
                    btr_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_(parameters, clip) (train_GF_FSB.py:316-318) over the same table,
+ * folded into the step: btr_grad_sumsq_multi writes one sum of squares per chunk of the chunk map
+ * (partial, already offset like chunk_map); btr_grad_norm_final adds all `chunks` of them in a
+ * fixed order and writes out[0] = total 2-norm, out[1] = max(1, (norm + 1e-6) / clip) -- the
+ * grad_scale operand of btr_adam_multi. */
+int btr_grad_sumsq_multi(int chunks, int tensor0, const btr_adam_item_t *items,
+                         const btr_adam_grads_t *grads, const int *chunk_map, float *partial,
+                         btr_stream_t stream);
+int btr_grad_norm_final(int chunks, const float *partial, float clip, float *out,
+                        btr_stream_t stream);
 
 #ifdef __cplusplus
 }

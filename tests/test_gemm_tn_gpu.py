@@ -40,3 +40,61 @@ def test_weight_gradient_matches_float64(cuda, rows, n, k, pro):
     dw2 = torch.empty_like(dw)
     rc = lib.btr_sa_gemm_tn(rows, n, k, p(gy), n, p(x), k, p(pa), p(pb), p(pw), p(dw2), st)
     assert rc == 0 and torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("groups,s,n,k", [(700, 16, 128, 64), (333, 32, 132, 68), (129, 64, 256, 128),
+                                          (50, 128, 64, 36), (2000, 16, 64, 64)])
+@pytest.mark.parametrize("pro", [False, True])
+def test_pooled_gradient_form_matches_float64(cuda, groups, s, n, k, pro):
+    """btr_sa_gemm_tn_pool: the gradient operand is formed while staging,
+    dY[r][c] = alpha[c] * y[r][c] + beta[c]  (+ dcl[g][c] on the group's arg-max row)."""
+    lib = _ext._lib
+    rows = groups * s
+    g = torch.Generator(device="cpu").manual_seed(groups + n)
+    y = torch.randn(rows, n, generator=g).to(cuda)
+    x = torch.randn(rows, k, generator=g).to(cuda)
+    arg = torch.randint(0, s, (groups, n), generator=g, dtype=torch.uint8).to(cuda)
+    dcl = torch.randn(groups, n, generator=g).to(cuda) * 5
+    alpha = (torch.randn(n, generator=g) * 0.1).to(cuda)
+    beta = (torch.randn(n, generator=g) * 0.1).to(cuda)
+    pa = (torch.rand(k, generator=g) + 0.5).to(cuda) if pro else None
+    pb = (torch.rand(k, generator=g) - 0.5).to(cuda) if pro else None
+    chunks = lib.btr_sa_gemm_tn_chunks(rows, n, k)
+    pw = torch.full((chunks, n, k), float("nan"), device=cuda)
+    dw = torch.full((n, k), float("nan"), device=cuda)
+    p = _ext._p
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.btr_sa_gemm_tn_pool(rows, n, k, p(y), n, s, p(arg), p(dcl), p(alpha), p(beta), p(x), k,
+                                 p(pa), p(pb), p(pw), p(dw), st)
+    assert rc == 0, lib.btr_last_error()
+    dy = alpha.double() * y.double() + beta.double()
+    dy = dy.view(groups, s, n).scatter_add(1, arg.long().unsqueeze(1), dcl.double().unsqueeze(1))
+    xe = torch.relu(x.double() * pa.double() + pb.double()) if pro else x.double()
+    ref = dy.view(rows, n).t() @ xe
+    assert torch.isfinite(dw).all()
+    err = float((dw.double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("rows,n,k", [(5000, 64, 64), (70001, 128, 64), (999, 64, 32)])
+def test_first_layer_recompute_form_matches_float64(cuda, rows, n, k):
+    """btr_sa_gemm_tn_rc: X = relu(pa * (x0 . w0^T) + pb) rebuilt from the 4-column input rows."""
+    lib = _ext._lib
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    gy = torch.randn(rows, n, generator=g).to(cuda)
+    x0 = torch.randn(rows, 4, generator=g).to(cuda)
+    w0 = torch.randn(k, 4, generator=g).to(cuda)
+    pa = (torch.rand(k, generator=g) + 0.5).to(cuda)
+    pb = (torch.rand(k, generator=g) - 0.5).to(cuda)
+    chunks = lib.btr_sa_gemm_tn_chunks(rows, n, k)
+    pw = torch.full((chunks, n, k), float("nan"), device=cuda)
+    dw = torch.full((n, k), float("nan"), device=cuda)
+    p = _ext._p
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.btr_sa_gemm_tn_rc(rows, n, k, p(gy), n, p(x0), p(w0), p(pa), p(pb), p(pw), p(dw), st)
+    assert rc == 0, lib.btr_last_error()
+    # (the kernel evaluates x0 . w0^T in f32 with its own fma order: compare against the same y0)
+    y0 = (x0.double() @ w0.double().t())
+    ref = gy.double().t() @ torch.relu(y0 * pa.double() + pb.double())
+    err = float((dw.double() - ref).abs().max() / ref.abs().max())
+    assert err < 5e-6, err
