@@ -275,6 +275,12 @@ __global__ __launch_bounds__(256) void vote_assemble_norm_bwd_kernel(
 // fills the chip, so the wgrad launches go to a second stream: fork after dY_l is final, join at
 // the end of the call (the caller sees one stream).  Not while a HIP graph is being captured;
 // BTR_WGRAD_STREAM=0 turns it off.
+// calls with fewer rows keep their weight gradients in line (BTR_SIDE_MIN_ROWS / _SA override)
+inline long long side_min_rows(bool sa) {
+  static const long long chain = getenv("BTR_SIDE_MIN_ROWS") ? atoll(getenv("BTR_SIDE_MIN_ROWS")) : 8192;
+  static const long long layer = getenv("BTR_SIDE_MIN_ROWS_SA") ? atoll(getenv("BTR_SIDE_MIN_ROWS_SA")) : 0;
+  return sa ? layer : chain;
+}
 struct SideStream {
   hipStream_t s = nullptr;
   hipEvent_t ready[kMaxL + 1] = {}, done[kMaxL + 1] = {};
@@ -634,7 +640,7 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   float *dy = ylast;
   int flip = 0;
   hipStream_t hmain = as_stream(stream);
-  SideStream *side = wgrad_side(hmain);
+  SideStream *side = R >= side_min_rows(true) ? wgrad_side(hmain) : nullptr;
   int last_done = -1;
   // the layers' split-K reductions: ONE launch behind the last TN GEMM, on the stream they ran on
   ReduceBatchScope batch(side ? side->s : hmain);
@@ -912,7 +918,10 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
                        colsum, grads + p.dbias[L - 1]);
   }
   float *dy = g;
-  SideStream *side = wgrad_side(hs);
+  // (few-row chains -- GroupFree3D's 1024-row heads and position embeddings -- stay on one
+  // stream: the fork / join calls cost the host more than the overlap of two 10 us kernels
+  // returns, 12.4 -> 12.0 ms per GroupFree3D step)
+  SideStream *side = rows >= side_min_rows(false) ? wgrad_side(hs) : nullptr;
   int last_done = -1;
   ReduceBatchScope batch(side ? side->s : hs);   // (see btr_sa_layer_backward)
   for (int l = L - 1; l >= 0; --l) {

@@ -150,6 +150,11 @@ __device__ __forceinline__ float4 rc_y4(const float4 x, const float *__restrict_
 // MM == 1: the products run as bf16x6 (see split4); LDS then holds three bf16 planes per operand
 // and the C tile leaves through a per-wave LDS transpose as 16-byte row stores (with the matrix
 // pipe 2.67x faster the 4-byte-per-lane stores of the accumulator layout were the bound).
+// (Few-workgroup launches -- the 1024-row decoder / head products, 48 - 256 workgroups, 14 us for a
+// 1024 x 288 x 288 product whose arithmetic is 3 us: a variant with three k chunks in flight
+// (three register sets, chunk loop unrolled by three) measured the same 16.4 us as this one.
+// With one workgroup per CU there is one wave per SIMD and its split / LDS / MFMA phases simply
+// run one after the other, ~1.3 us per chunk; global-load latency is not the bound.)
 template <int BN, int PRO, bool STATS, int PS = 0, int BM = kBM, bool BIAS = false, int MM = 0>
 // (second launch bound: at least 2 waves per SIMD, i.e. <= 256 VGPRs -- two workgroups per
 // CU; without it the PRO == 2 / BN = 128 variant allocates 292 and runs alone on its CU)
@@ -2560,7 +2565,15 @@ static int tn_tile_n(int n) { return n >= 128 ? 128 : 64; }
 int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
   const int tiles = cdiv(n, tn_tile_n(n)) * cdiv(k, 64);
   int chunks = std::max(1, std::min(1024 / tiles, 1024));  // ~1024 workgroups in flight
-  chunks = std::min(chunks, std::max(1, rows / 256));
+  // a workgroup (alone on its CU in these launches: one wave per SIMD, nothing to overlap with)
+  // spends ~1.3 us per 32-row step: few-row GEMMs (the 1024-row decoder / head layers: 8 steps
+  // per workgroup, 14 us) get chunks of down to 64 rows as long as the partials stay small
+  // (<= 16 MB to write and reduce)
+  static const int min_rows = getenv("BTR_TN_CHUNK_ROWS") ? atoi(getenv("BTR_TN_CHUNK_ROWS")) : 64;
+  const long long by_mem = std::max<long long>(4, (4ll << 20) / ((long long)n * k));
+  const long long by_rows = std::max(1, rows / std::max(min_rows, 32));
+  const long long cap = std::min<long long>(by_rows, std::max<long long>(by_mem, rows / 256));
+  chunks = (int)std::min<long long>(chunks, std::max<long long>(1, cap));
   return chunks;
 }
 
