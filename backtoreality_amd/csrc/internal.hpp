@@ -13,9 +13,16 @@ int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
                const float *shift, int relu, float *out_bcn, float *out_cl, const float *add,
                long long add_bstride, hipStream_t stream);
 
-// sa_mlp.hip: btr_pm_rows that also clears `nzero` floats at `zero` (first workgroup)
+// sa_mlp.hip: btr_sa_bn_finalize; rbias (nbias entries, may be NULL): running_mean += momentum * rbias
+int bn_finalize_bias(int n, int nblk, double count, float eps, float momentum, const float *part,
+                     const float *gamma, const float *beta, float *scale, float *shift,
+                     float *mean, float *invstd, float *running_mean, float *running_var,
+                     const float *rbias, int nbias, hipStream_t stream);
+
+// sa_mlp.hip: btr_pm_rows that also clears `nzero` floats at `zero` (first workgroup) and, with
+// colpart [b * cdiv(n, 64)][ldr], writes the column sums of every 64-row tile
 int pm_rows_zero(int b, int n, int c, int ldr, const float *x, float *rows, float *zero,
-                 int nzero, hipStream_t stream);
+                 int nzero, float *colpart, hipStream_t stream);
 
 // sa_mlp.hip: btr_pm_gemm_nt (no prologue / bias / statistics) with the reduction split over
 // `slices` workgroups per C tile; plane z of the partial products at parts + z * part_stride

@@ -53,9 +53,6 @@ struct PrepArgs {
   int kin[kMaxL];    // columns of W2 (zero columns beyond kraw)
   int first[kMaxL + 1];  // first block of layer l
   long long *nbt[kMaxL];
-  float *rmean[kMaxL];      // running_mean += mom * bias (NULL: nothing)
-  const float *rbias[kMaxL];
-  float mom[kMaxL];
   int layers;
   // bias row of a bare last layer whose width is not a multiple of 4, zero-padded to np
   const float *pbias_src;
@@ -90,35 +87,8 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
       a.pbias_dst[c] = c < a.pbias_n ? a.pbias_src[c] : 0.f;
 }
 
-// running_mean[l] += momentum * bias[l] for the conv biases skipped in front of a BatchNorm
-// (AFTER bn_finalize has blended the batch mean in); one block per layer
-__global__ __launch_bounds__(256) void bias_running_mean_kernel(PrepArgs a) {
-#pragma unroll
-  for (int i = 0; i < kMaxL; ++i)   // static indices, see prep_weights_kernel
-    if (i == (int)blockIdx.x && a.rmean[i])
-      for (int c = threadIdx.x; c < a.n[i]; c += 256) a.rmean[i][c] += a.mom[i] * a.rbias[i][c];
-}
-
 // out[c] = sum_r g[r][c]  (bias gradient of a bare last layer), two deterministic stages:
-// part[chunk][c] = sum over the chunk's rows (grid: column tiles x chunks), then the chunks.
-constexpr int kColsumRows = 128;   // rows per chunk
-__global__ __launch_bounds__(256) void colsum_part_kernel(int rows, int c, int ld,
-                                                          const float *__restrict__ g,
-                                                          float *__restrict__ part) {
-  __shared__ float red[4][64];
-  const int col = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);
-  const int sub = (int)(threadIdx.x >> 6);
-  const int r0 = (int)blockIdx.y * kColsumRows;
-  const int r1 = min(rows, r0 + kColsumRows);
-  float acc = 0.f;
-  if (col < c)
-    for (int r = r0 + sub; r < r1; r += 4) acc += g[(size_t)r * ld + col];
-  red[sub][threadIdx.x & 63] = acc;
-  __syncthreads();
-  if (sub == 0 && col < c)
-    part[(size_t)blockIdx.y * c + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
-                                         (red[2][threadIdx.x] + red[3][threadIdx.x]);
-}
+// part[tile][c] = sum over a 64-row tile (written by pm_rows_kernel on its way), then the tiles.
 __global__ __launch_bounds__(256) void colsum_final_kernel(int chunks, int c,
                                                            const float *__restrict__ part,
                                                            float *__restrict__ out) {
@@ -745,7 +715,7 @@ PmBwdScratch pm_bwd_scratch(const btr_pm_chain_t &d, const btr_pm_plan_t &p) {
   for (int l = 0; l < d.layers; ++l)   // split-K partials, one region per layer
     s.pw[l] = b.floats((size_t)btr_sa_gemm_tn_chunks(p.rows, p.np[l], p.kin[l]) * p.np[l] *
                        p.kin[l]);
-  s.colsum = b.floats((size_t)cdiv(p.rows, kColsumRows) * p.np[d.layers - 1]);
+  s.colsum = b.floats((size_t)d.b * cdiv(d.n, 64) * p.np[d.layers - 1]);   // per 64-row tile
   s.bytes = b.off;
   return s;
 }
@@ -812,7 +782,6 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
   PrepArgs pa{};
   pa.layers = L;
   int blocks = 0;
-  bool bias_fix = false;
   for (int l = 0; l < L; ++l) {
     BTR_REQUIRE(d.w[l] && (!d.has_bn[l] || (d.gamma[l] && d.beta[l])),
                 "pm_chain_forward: layer %d parameters", l);
@@ -827,12 +796,6 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
     blocks += cdiv((long long)p.np[l] * p.kin[l], 256);
     const bool track = d.has_bn[l] && d.running_mean[l];
     pa.nbt[l] = track ? d.num_batches_tracked[l] : nullptr;
-    if (track && d.bias[l]) {  // the skipped bias only moves the running mean
-      pa.rmean[l] = d.running_mean[l];
-      pa.rbias[l] = d.bias[l];
-      pa.mom[l] = d.momentum[l];
-      bias_fix = true;
-    }
   }
   pa.first[L] = blocks;
   const int grid = btr_pm_gemm_grid(rows);
@@ -866,9 +829,11 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
       BTR_TRY(btr_pm_gemm_nt(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, part, nullptr,
                              stream));
       float *st = at_f(saved, p.stats[l]);
-      BTR_TRY(btr_sa_bn_finalize(np, grid, (double)rows, d.eps[l], d.momentum[l], part,
-                                 d.gamma[l], d.beta[l], st, st + np, st + 2 * np, st + 3 * np,
-                                 d.running_mean[l], d.running_var[l], stream));
+      // (a convolution bias in front of the BatchNorm is skipped: it only moves the running mean)
+      BTR_TRY(bn_finalize_bias(np, grid, (double)rows, d.eps[l], d.momentum[l], part, d.gamma[l],
+                               d.beta[l], st, st + np, st + 2 * np, st + 3 * np,
+                               d.running_mean[l], d.running_var[l],
+                               d.running_mean[l] ? d.bias[l] : nullptr, d.width[l], hs));
       pscale = st;
       pshift = st + np;
     } else {
@@ -883,7 +848,6 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
   }
   BTR_TRY(btr_pm_out(d.b, d.n, d.width[L - 1], p.np[L - 1], A, pscale, pshift, pscale ? 1 : 0,
                      out, out_cl, stream));
-  if (bias_fix) hipLaunchKernelGGL(bias_running_mean_kernel, dim3(L), dim3(256), 0, hs, pa);
   return check_launch("pm_chain_forward");
 }
 
@@ -903,19 +867,19 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
   int flip = 0;
   float *g = at_f(scratch, sc.g[flip]);
   flip ^= 1;
-  // (+ the bias gradients: zero in front of a BatchNorm, and the padding of the others)
+  // (+ the bias gradients: zero in front of a BatchNorm, and the padding of the others.)  The
+  // bias gradient of a bare last layer = column sums of dout: per-tile partials from the same
+  // launch, then one small reduction
+  const bool bare_bias = !d.has_bn[L - 1] && d.bias[L - 1];
   BTR_TRY(pm_rows_zero(d.b, d.n, nl, npl, dout, g, grads + p.dbias[0],
-                       (int)(p.grads_floats - p.dbias[0]), hs));
+                       (int)(p.grads_floats - p.dbias[0]), bare_bias ? colsum : nullptr, hs));
   if (d.has_bn[L - 1]) {
     BTR_TRY(btr_sa_bn_relu_bwd(rows, npl, npl, g, at_f(saved, p.y[L - 1]), stat(L - 1, 0),
                                stat(L - 1, 1), stat(L - 1, 2), stat(L - 1, 3), part, m1, m2,
                                grads + p.dgamma[L - 1], grads + p.dbeta[L - 1], stream));
-  } else if (d.bias[L - 1]) {
-    const int chunks = cdiv(rows, kColsumRows);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(npl, 64), chunks), dim3(256), 0, hs, rows,
-                       npl, npl, g, colsum);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(npl, 256)), dim3(256), 0, hs, chunks, npl,
-                       colsum, grads + p.dbias[L - 1]);
+  } else if (bare_bias) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(npl, 256)), dim3(256), 0, hs,
+                       d.b * cdiv(d.n, 64), npl, colsum, grads + p.dbias[L - 1]);
   }
   float *dy = g;
   // (few-row chains -- GroupFree3D's 1024-row heads and position embeddings -- stay on one

@@ -664,7 +664,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     int N, int nblk, double count, float eps, float momentum, const float *__restrict__ part,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ scale,
     float *__restrict__ shift, float *__restrict__ mean_out, float *__restrict__ invstd_out,
-    float *__restrict__ running_mean, float *__restrict__ running_var) {
+    float *__restrict__ running_mean, float *__restrict__ running_var,
+    const float *__restrict__ rbias = nullptr, int nbias = 0) {
   const int tx = threadIdx.x & (kRedCh - 1), ty = threadIdx.x / kRedCh;
   const int n = blockIdx.x * kRedCh + tx;
   double s1, s2;
@@ -681,7 +682,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
   invstd_out[n] = invstd;
   if (running_mean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+    float rm = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+    // rbias: the convolution bias skipped in front of this BatchNorm only moves the running mean
+    // (was a launch of its own behind the chain: bias_running_mean_kernel)
+    if (rbias && n < nbias) rm += momentum * rbias[n];
+    running_mean[n] = rm;
     running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
   }
 }
@@ -2248,8 +2253,10 @@ __global__ __launch_bounds__(256) void pm_out_kernel(int N, int C, int ldy,
 __global__ __launch_bounds__(256) void pm_rows_kernel(int N, int C, int ldr,
                                                       const float *__restrict__ x,
                                                       float *__restrict__ rows,
-                                                      float *__restrict__ zero, int nzero) {
+                                                      float *__restrict__ zero, int nzero,
+                                                      float *__restrict__ colpart) {
   __shared__ float tile[64][65];
+  __shared__ float red[4][64];
   if (zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
     for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0.f;
   const int bi = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -2260,20 +2267,43 @@ __global__ __launch_bounds__(256) void pm_rows_kernel(int N, int C, int ldr,
     tile[ty + 4 * i][tx] = (c < C && n < N) ? x[((size_t)bi * C + c) * N + n] : 0.f;
   }
   __syncthreads();
+  float cs = 0.f;   // colpart: this tile's column sums (rows n >= N and columns c >= C hold zeros)
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int n = n0 + ty + 4 * i, c = c0 + tx;
-    if (n < N && c < ldr) rows[((size_t)bi * N + n) * ldr + c] = tile[tx][ty + 4 * i];
+    const float v = tile[tx][ty + 4 * i];
+    if (n < N && c < ldr) rows[((size_t)bi * N + n) * ldr + c] = v;
+    cs += v;
+  }
+  if (colpart) {   // colpart[(b * gridDim.x + tile)][ldr]: reduced by colsum_final_kernel
+    red[ty][tx] = cs;
+    __syncthreads();
+    if (ty == 0 && c0 + tx < ldr)
+      colpart[((size_t)bi * gridDim.x + blockIdx.x) * ldr + c0 + tx] =
+          (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
   }
 }
 
-// (internal.hpp) btr_pm_rows that also clears `nzero` floats at `zero`
+// (internal.hpp) btr_sa_bn_finalize with the skipped convolution bias added to the running mean
+int bn_finalize_bias(int n, int nblk, double count, float eps, float momentum, const float *part,
+                     const float *gamma, const float *beta, float *scale, float *shift,
+                     float *mean, float *invstd, float *running_mean, float *running_var,
+                     const float *rbias, int nbias, hipStream_t stream) {
+  if (n <= 0) return BTR_OK;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(n, kRedCh)), dim3(256), 0, stream, n, nblk,
+                     count, eps, momentum, part, gamma, beta, scale, shift, mean, invstd,
+                     running_mean, running_var, rbias, nbias);
+  return check_launch("sa_bn_finalize");
+}
+
+// (internal.hpp) btr_pm_rows that also clears `nzero` floats at `zero` and, with colpart
+// [b * cdiv(n, 64)][ldr], leaves the column sums of every 64-row tile there
 int pm_rows_zero(int b, int n, int c, int ldr, const float *x, float *rows, float *zero,
-                 int nzero, hipStream_t stream) {
+                 int nzero, float *colpart, hipStream_t stream) {
   if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(x && rows && ldr >= c, "pm_rows: bad arguments");
   hipLaunchKernelGGL(pm_rows_kernel, dim3(cdiv(n, 64), cdiv(ldr, 64), b), dim3(256), 0, stream, n,
-                     c, ldr, x, rows, zero, nzero);
+                     c, ldr, x, rows, zero, nzero, colpart);
   return check_launch("pm_rows");
 }
 
@@ -2412,11 +2442,8 @@ int btr_sa_bn_finalize(int n, int nblk, double count, float eps, float momentum,
                        const float *part, const float *gamma, const float *beta, float *scale,
                        float *shift, float *mean, float *invstd, float *running_mean,
                        float *running_var, btr_stream_t stream) {
-  if (n <= 0) return BTR_OK;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(n, kRedCh)), dim3(256), 0, as_stream(stream), n,
-                     nblk, count, eps, momentum, part, gamma, beta, scale, shift, mean, invstd,
-                     running_mean, running_var);
-  return check_launch("sa_bn_finalize");
+  return bn_finalize_bias(n, nblk, count, eps, momentum, part, gamma, beta, scale, shift, mean,
+                          invstd, running_mean, running_var, nullptr, 0, as_stream(stream));
 }
 
 int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, const float *w,
@@ -2978,7 +3005,7 @@ int btr_pm_out(int b, int n, int c, int ldy, const float *y, const float *scale,
 
 // rows (B*N, ldr) = x (B, C, N) transposed, columns C .. ldr zero
 int btr_pm_rows(int b, int n, int c, int ldr, const float *x, float *rows, btr_stream_t stream) {
-  return pm_rows_zero(b, n, c, ldr, x, rows, nullptr, 0, as_stream(stream));
+  return pm_rows_zero(b, n, c, ldr, x, rows, nullptr, 0, nullptr, as_stream(stream));
 }
 
 }  // extern "C"

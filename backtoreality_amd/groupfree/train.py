@@ -6,7 +6,7 @@ import os
 import torch
 
 from ..pointnet2 import fused_backbone
-from ..votenet.train import FastAdamW, _sync_grads
+from ..votenet.train import FastAdamW, _sync_grads, _zero_grad
 from .detector import GroupFreeDetector, GroupFreeDetector_DA, GroupFreeDetector_DA_jitter
 from . import fused_attention
 from .loss_helper import get_loss
@@ -106,7 +106,7 @@ def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, criter
         assert key not in end_points
         end_points[key] = batch[key]
     loss, end_points = (criterion or get_loss)(end_points, cfg, **loss_args)
-    optimizer.zero_grad(set_to_none=True)
+    _zero_grad(net, optimizer)
     if next_batch is not None:
         core = net.module if hasattr(net, "module") else net
         end_points['next_sampling'] = core.backbone_net.prefetch_sampling(
@@ -239,7 +239,7 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_no
         assert key not in end_points_T
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = get_loss_DA(end_points_S, end_points_T, cfg, **loss_args)
-    optimizer.zero_grad(set_to_none=True)
+    _zero_grad(net, optimizer)
     loss.backward()
     _sync_grads(net)
     clip_and_step(net, optimizer, clip_norm)
@@ -263,7 +263,7 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, loss_ar
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = get_loss_DA_jitter(end_points_S, end_points_T, epoch, cfg,
                                                           **loss_args)
-    optimizer.zero_grad(set_to_none=True)
+    _zero_grad(net, optimizer)
     loss.backward()
     _sync_grads(net)
     clip_and_step(net, optimizer, clip_norm)

@@ -140,7 +140,11 @@ def wrap_ddp(net, device):
 
 
 def _zero_grad(net, optimizer):
-    optimizer.zero_grad(set_to_none=True)
+    """optimizer.zero_grad(set_to_none=True) without its per-parameter bookkeeping (0.2 ms of
+    host time per step for GroupFree3D's ~400 tensors)."""
+    for group in optimizer.param_groups:
+        for p in group['params']:
+            p.grad = None
 
 
 def _sync_grads(net):
@@ -171,17 +175,26 @@ class _FastStep(object):
         work = []
         for group in self.param_groups:
             cache = group.get('_btr_fast')
-            params = [p for p in group['params'] if p.grad is not None]
+            # one walk over the parameters per step: their gradients; the cached lists stand when
+            # the same parameters (by identity) have one
+            every = group['params']
+            grads = [p.grad for p in every]
+            if None in grads:
+                params = [p for p, g in zip(every, grads) if g is not None]
+                grads = [g for g in grads if g is not None]
+            else:
+                params = every
             if cache is None or len(cache[0]) != len(params) or \
                     any(a is not b for a, b in zip(cache[0], params)):
                 if any(len(self.state[p]) == 0 for p in params):
                     return self._stock_step(None, clip_norm)   # first step: builds the state
+                params = list(params)
                 cache = group['_btr_fast'] = (
                     params, [self.state[p]['exp_avg'] for p in params],
                     [self.state[p]['exp_avg_sq'] for p in params],
                     [self.state[p]['step'] for p in params])
             if cache[0]:
-                work.append((group, cache, [p.grad for p in cache[0]]))
+                work.append((group, cache, grads))
         if work:
             done = self._library_step(work, clip_norm)
             if done is not None:
