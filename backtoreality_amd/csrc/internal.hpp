@@ -13,6 +13,30 @@ int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
                const float *shift, int relu, float *out_bcn, float *out_cl, const float *add,
                long long add_bstride, hipStream_t stream);
 
+// sa_mlp.hip: BatchNorm finalisation inside the statistics GEMM (the last workgroup of a column
+// block to arrive -- a ticket per 128 / 64-column block, zeroed by the call's first kernel -- turns
+// the per-workgroup partial sums into scale / shift / mean / invstd and updates the running
+// statistics: what btr_sa_bn_finalize does, in its summation order).  bnfin_arm() hands the
+// description to the NEXT statistics GEMM launched on this host thread (btr_sa_gemm_nt, _rc,
+// _poolfwd, btr_pm_gemm_nt); it returns false when the fused form is off (BTR_BN_TICKET=0, the
+// f32-input GEMMs, more than BTR_BN_TICKET_MAX_ROWS = 2048 rows) and the caller launches the
+// finalize kernel itself.  Measured on the FSB step (20 steps, same box): off 5.02 ms, <= 2048 rows
+// 5.01, <= 8192 rows 5.20, <= 16384 rows 5.19, <= 70000 rows 5.67, all 6.16: the one workgroup
+// that is left adds the 2 x (workgroups) x 128 partials of its column block alone (the finalize
+// kernel spreads them over channels x 64 slices), and every workgroup pays a device-scope release
+// behind a C tile it has just written -- a 5 us launch is cheaper from 128 workgroups up.
+struct BnFin {
+  unsigned *ticket;            // [column blocks] zeroed before the launch
+  const float *gamma, *beta;
+  float *scale, *shift, *mean, *invstd, *running_mean, *running_var;
+  const float *rbias;          // see bn_finalize_bias
+  int nbias;
+  double count;
+  float eps, momentum;
+};
+constexpr int kBnTickets = 8;  // tickets per statistics GEMM (column blocks of >= 64 channels, n <= 512)
+bool bnfin_arm(const BnFin &fin, long long rows);
+
 // sa_mlp.hip: btr_sa_bn_finalize; rbias (nbias entries, may be NULL): running_mean += momentum * rbias
 int bn_finalize_bias(int n, int nblk, double count, float eps, float momentum, const float *part,
                      const float *gamma, const float *beta, float *scale, float *shift,

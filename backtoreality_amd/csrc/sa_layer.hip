@@ -54,6 +54,8 @@ struct PrepArgs {
   int first[kMaxL + 1];  // first block of layer l
   long long *nbt[kMaxL];
   int layers;
+  unsigned *tickets;   // BatchNorm-finalisation tickets of this call (see BnFin): cleared here
+  int ntickets;
   // bias row of a bare last layer whose width is not a multiple of 4, zero-padded to np
   const float *pbias_src;
   float *pbias_dst;
@@ -85,6 +87,8 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
   if (blockIdx.x == 0 && a.pbias_dst)
     for (int c = threadIdx.x; c < a.pbias_np; c += 256)
       a.pbias_dst[c] = c < a.pbias_n ? a.pbias_src[c] : 0.f;
+  if (blockIdx.x == 0 && a.tickets)
+    for (int c = threadIdx.x; c < a.ntickets; c += 256) a.tickets[c] = 0u;
 }
 
 // out[c] = sum_r g[r][c]  (bias gradient of a bare last layer), two deterministic stages:
@@ -315,7 +319,7 @@ inline bool pool_grad_ok(int s) { return s == 16 || s == 32 || s == 64 || s == 1
 
 // scratch layouts (recomputed identically by plan / forward / backward)
 struct SaFwdScratch {
-  size_t part, len_tmp, extg, exta, bytes;
+  size_t part, len_tmp, extg, exta, tickets, bytes;
 };
 struct SaBwdScratch {
   size_t part, m1, m2, dcl, alpha, beta, pw[kMaxL], pw0, g[2], scat, dfeat_cl, bytes;
@@ -334,6 +338,7 @@ SaFwdScratch sa_fwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   const size_t ext = p.pool_epilogue ? (size_t)(p.rows / ps) * cl : 0;
   s.extg = b.floats(ext);
   s.exta = b.take(ext);
+  s.tickets = b.take(sizeof(unsigned) * kBnTickets * kMaxL);
   s.bytes = b.off;
   return s;
 }
@@ -488,6 +493,9 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     pa.nbt[l] = d.running_mean[l] ? d.num_batches_tracked[l] : nullptr;
   }
   pa.first[L] = blocks;
+  unsigned *tickets = reinterpret_cast<unsigned *>(at_b(scratch, sc.tickets));
+  pa.tickets = tickets;
+  pa.ntickets = kBnTickets * kMaxL;
   hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), pa);
 
   float *x0 = at_f(saved, p.x0);
@@ -520,6 +528,11 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     const int nl = d.width[l], k = p.kin[l];
     const float *w2 = at_f(saved, p.w2[l]);
     float *y = at_f(saved, p.y[l]);
+    float *st = at_f(saved, p.stats[l]);
+    // BatchNorm finalisation by the statistics GEMM's last workgroup (false: a launch of its own)
+    const bool fin_fused = bnfin_arm(BnFin{
+        tickets + kBnTickets * l, d.gamma[l], d.beta[l], st, st + nl, st + 2 * nl, st + 3 * nl,
+        d.running_mean[l], d.running_var[l], nullptr, 0, (double)R, d.eps[l], d.momentum[l]}, R);
     if (p.recompute && l == 0) {  // statistics only
       BTR_TRY(btr_sa_gemm_nt(R, nl, k, A, lda, w2, k, nullptr, nl, nullptr, nullptr, part, stream));
     } else if (p.recompute && l == 1) {
@@ -531,10 +544,10 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     } else {
       BTR_TRY(btr_sa_gemm_nt(R, nl, k, A, lda, w2, k, y, nl, pscale, pshift, part, stream));
     }
-    float *st = at_f(saved, p.stats[l]);
-    BTR_TRY(btr_sa_bn_finalize(nl, grid, (double)R, d.eps[l], d.momentum[l], part, d.gamma[l],
-                               d.beta[l], st, st + nl, st + 2 * nl, st + 3 * nl,
-                               d.running_mean[l], d.running_var[l], stream));
+    if (!fin_fused)
+      BTR_TRY(btr_sa_bn_finalize(nl, grid, (double)R, d.eps[l], d.momentum[l], part, d.gamma[l],
+                                 d.beta[l], st, st + nl, st + 2 * nl, st + 3 * nl,
+                                 d.running_mean[l], d.running_var[l], stream));
     A = y;
     lda = nl;
     pscale = st;
@@ -749,7 +762,8 @@ int btr_pm_chain_plan(const btr_pm_chain_t *dp, btr_pm_plan_t *p) {
     p->stats[l] = sv.floats((size_t)4 * p->np[l]);
   }
   p->saved_bytes = sv.off;
-  p->fwd_scratch_bytes = up(sizeof(float) * ((size_t)btr_pm_gemm_grid(p->rows) * 2 * maxn + maxn));
+  p->fwd_scratch_bytes = up(sizeof(float) * ((size_t)btr_pm_gemm_grid(p->rows) * 2 * maxn + maxn) +
+                            sizeof(unsigned) * kBnTickets * kMaxL);   // part, bias_pad, tickets
   p->bwd_scratch_bytes = pm_bwd_scratch(d, *p).bytes;
   size_t g = 0;
   for (int l = 0; l < L; ++l) {
@@ -803,6 +817,9 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
   for (int l = 0; l < L; ++l) maxn = std::max(maxn, p.np[l]);
   float *part = (float *)scratch;
   float *bias_pad = part + (size_t)grid * 2 * maxn;
+  unsigned *tickets = reinterpret_cast<unsigned *>(bias_pad + maxn);
+  pa.tickets = tickets;
+  pa.ntickets = kBnTickets * kMaxL;
   if (!d.has_bn[L - 1] && d.bias[L - 1] && p.np[L - 1] != d.width[L - 1]) {
     pa.pbias_src = d.bias[L - 1];   // padded by the same launch (was a memset + a copy)
     pa.pbias_dst = bias_pad;
@@ -826,14 +843,19 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
     const float *w2 = at_f(saved, p.w2[l]);
     float *y = at_f(saved, p.y[l]);
     if (d.has_bn[l]) {
-      BTR_TRY(btr_pm_gemm_nt(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, part, nullptr,
-                             stream));
       float *st = at_f(saved, p.stats[l]);
       // (a convolution bias in front of the BatchNorm is skipped: it only moves the running mean)
-      BTR_TRY(bn_finalize_bias(np, grid, (double)rows, d.eps[l], d.momentum[l], part, d.gamma[l],
-                               d.beta[l], st, st + np, st + 2 * np, st + 3 * np,
-                               d.running_mean[l], d.running_var[l],
-                               d.running_mean[l] ? d.bias[l] : nullptr, d.width[l], hs));
+      const float *rbias = d.running_mean[l] ? d.bias[l] : nullptr;
+      const bool fin_fused = bnfin_arm(BnFin{
+          tickets + kBnTickets * l, d.gamma[l], d.beta[l], st, st + np, st + 2 * np, st + 3 * np,
+          d.running_mean[l], d.running_var[l], rbias, d.width[l], (double)rows, d.eps[l],
+          d.momentum[l]}, rows);
+      BTR_TRY(btr_pm_gemm_nt(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, part, nullptr,
+                             stream));
+      if (!fin_fused)
+        BTR_TRY(bn_finalize_bias(np, grid, (double)rows, d.eps[l], d.momentum[l], part,
+                                 d.gamma[l], d.beta[l], st, st + np, st + 2 * np, st + 3 * np,
+                                 d.running_mean[l], d.running_var[l], rbias, d.width[l], hs));
       pscale = st;
       pshift = st + np;
     } else {

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const float *__restrict__ pb, float *__restrict__ part,
     const unsigned char *__restrict__ parg, const float *__restrict__ pdcl, int SSH,
     const float *__restrict__ gsign = nullptr, float *__restrict__ gext = nullptr,
-    unsigned char *__restrict__ aext = nullptr, Compact cm = Compact{}) {
+    unsigned char *__restrict__ aext = nullptr, Compact cm = Compact{}, BnFin fin = BnFin{}) {
   static_assert(PS == 0 || (BN == 128 && (PS == 8 || PS == 16 || PS == 32 || PS == 64)),
                 "pooling epilogue: 128-column tiles, groups of 8 / 16 / 32 / 64 rows");
   if (cm.dims) R = cm.dims[0];  // compact rows: the row count lives on the device
@@ -610,6 +610,68 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       for (int w = 0; w < WM; ++w) s += red[(which * WM + w) * BN + col];
       if (n_blk + col < N)
         part[((size_t)blockIdx.x * 2 + which) * N + n_blk + col] = (float)s;
+    }
+    if constexpr (MM != 0) {
+      if (fin.ticket) {
+        // ---- the last workgroup of this column block finalises the BatchNorm (see BnFin)
+        __shared__ int s_last;
+        __threadfence();   // this workgroup's partial sums are visible device-wide ...
+        __syncthreads();
+        if (tid == 0)      // ... before its ticket is
+          s_last = atomicAdd(&fin.ticket[blockIdx.y], 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();   // (acquire: the other workgroups' partial sums)
+        // reduce_partials' order: 64 slices of the workgroup axis, 8 groups of 8, the 8 groups;
+        // thread (col, q) adds the groups q, q + G, ... on its own, thread (col, 0) the 8 groups
+        constexpr int G = 256 / BN;   // threads per column
+        double *fr = reinterpret_cast<double *>(Pl);   // [2][8][BN], over the staging planes
+        static_assert(3 * (BM + BN) * kLp * 2 >= 2 * 8 * BN * 8, "finalize scratch");
+        const int col = tid % BN, q = tid / BN, n = n_blk + col;
+        const int nblk = gridDim.x;
+        for (int g = q; g < 8; g += G) {
+          double a1 = 0.0, a2 = 0.0;
+          if (n < N)
+            for (int y = 0; y < 8; ++y) {
+              double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+              for (int b = g * 8 + y; b < nblk; b += 64) {
+                s1 += (double)__builtin_nontemporal_load(&part[((size_t)b * 2 + 0) * N + n]);
+                s2 += (double)__builtin_nontemporal_load(&part[((size_t)b * 2 + 1) * N + n]);
+              }
+              a1 += s1;
+              a2 += s2;
+            }
+          fr[(0 * 8 + g) * BN + col] = a1;
+          fr[(1 * 8 + g) * BN + col] = a2;
+        }
+        __syncthreads();
+        if (q == 0 && n < N) {
+          double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            s1 += fr[(0 * 8 + g) * BN + col];
+            s2 += fr[(1 * 8 + g) * BN + col];
+          }
+          const double mean = s1 / fin.count;
+          double var = s2 / fin.count - mean * mean;
+          if (var < 0.0) var = 0.0;
+          const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+          const float a = fin.gamma[n] * invstd;
+          fin.scale[n] = a;
+          fin.shift[n] = fin.beta[n] - (float)mean * a;
+          fin.mean[n] = (float)mean;
+          fin.invstd[n] = invstd;
+          if (fin.running_mean) {
+            const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+            float rm = (1.f - fin.momentum) * fin.running_mean[n] + fin.momentum * (float)mean;
+            if (fin.rbias && n < fin.nbias) rm += fin.momentum * fin.rbias[n];
+            fin.running_mean[n] = rm;
+            fin.running_var[n] = (1.f - fin.momentum) * fin.running_var[n] +
+                                 fin.momentum * (float)unbiased;
+          }
+        }
+      }
     }
   }
 }
@@ -2331,6 +2393,22 @@ inline HostCompact &host_compact() {
 inline Compact cur_compact() { return host_compact().on ? host_compact().dev : Compact{}; }
 
 
+// the BatchNorm finalisation armed for the next statistics GEMM of this host thread (internal.hpp)
+struct HostBnFin {
+  BnFin fin{};
+  bool on = false;
+};
+inline HostBnFin &host_bnfin() {
+  static thread_local HostBnFin h;
+  return h;
+}
+inline BnFin take_bnfin() {
+  HostBnFin &h = host_bnfin();
+  if (!h.on) return BnFin{};
+  h.on = false;
+  return h.fin;
+}
+
 // BTR_GEMM=f32: the f32-input MFMA kernels (v_mfma_f32_32x32x2_f32) instead of bf16x6
 inline bool gemm_x6() {
   static const bool on = !(getenv("BTR_GEMM") && getenv("BTR_GEMM")[0] == 'f');
@@ -2361,6 +2439,17 @@ inline void launch_tn(bool x6, dim3 grid, hipStream_t st, const float *g, int ld
     hipLaunchKernelGGL((gemm_tn_kernel<W, P, GP, XR>), grid, dim3(256), 0, st, g, ldg, x, ldx,
                        rows, n, k, pa, pb, rpc, pw, garg, gdcl, galpha, gbeta, ssh, xw0,
                        cur_compact());
+}
+
+bool bnfin_arm(const BnFin &fin, long long rows) {
+  static const bool off = getenv("BTR_BN_TICKET") && getenv("BTR_BN_TICKET")[0] == '0';
+  static const long long max_rows =
+      getenv("BTR_BN_TICKET_MAX_ROWS") ? atoll(getenv("BTR_BN_TICKET_MAX_ROWS")) : 2048;
+  if (off || !gemm_x6() || !fin.ticket || rows > max_rows) return false;
+  HostBnFin &h = host_bnfin();
+  h.fin = fin;
+  h.on = true;
+  return true;
 }
 
 }  // namespace btr
@@ -2415,12 +2504,13 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t s = as_stream(stream);
   const bool pro = pa != nullptr, st = part != nullptr;
+  const BnFin fin = take_bnfin();   // (armed by the caller: finalisation inside this launch)
 #define BTR_GEMM_MM(BN, P, S, MM)                                                            \
   hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S, 0, kBM, false, MM>), dim3(gx, cdiv(n, BN)),    \
                      dim3(256), 0, s, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,       \
                      (const unsigned char *)nullptr, (const float *)nullptr, 0,                 \
                      (const float *)nullptr, (float *)nullptr, (unsigned char *)nullptr,        \
-                     cur_compact())
+                     cur_compact(), fin)
 #define BTR_GEMM(BN, P, S)            \
   do {                                \
     if (gemm_x6()) BTR_GEMM_MM(BN, P, S, 1); \
@@ -2459,11 +2549,12 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
               "sa_gemm_nt_poolfwd: n=%d / nsample=%d / k=%d not supported", n, s, k);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
+  const BnFin fin = take_bnfin();
 #define BTR_GEMM_MM(PS, MM)                                                                   \
   hipLaunchKernelGGL((gemm_nt_kernel<128, 1, true, PS, kBM, false, MM>), dim3(gx, cdiv(n, 128)), \
                      dim3(256), 0, st, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,        \
                      (const unsigned char *)nullptr, (const float *)nullptr, 0, gamma, gext,    \
-                     aext, cur_compact())
+                     aext, cur_compact(), fin)
 #define BTR_GEMM(PS)                  \
   do {                                \
     if (gemm_x6()) BTR_GEMM_MM(PS, 1); \
@@ -2616,11 +2707,12 @@ int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, 
               "sa_gemm_nt_rc: null pointer or k=%d ldw=%d not multiples of 4", k, ldw);
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
+  const BnFin fin = take_bnfin();
 #define BTR_NTRC_MM(BN, S, MM)                                                                \
   hipLaunchKernelGGL((gemm_nt_kernel<BN, 3, S, 0, kBM, false, MM>), dim3(gx, cdiv(n, BN)),     \
                      dim3(256), 0, st, x0, 4, w, ldw, c, ldc, rows, n, k, pa, pb, part,        \
                      (const unsigned char *)nullptr, w0, 0, (const float *)nullptr,           \
-                     (float *)nullptr, (unsigned char *)nullptr, cur_compact())
+                     (float *)nullptr, (unsigned char *)nullptr, cur_compact(), fin)
 #define BTR_NTRC(BN, S)                \
   do {                                 \
     if (gemm_x6()) BTR_NTRC_MM(BN, S, 1); \
@@ -2932,11 +3024,12 @@ int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
   BTR_REQUIRE(!(bias && part), "pm_gemm_nt: bias and statistics are exclusive");
   hipStream_t s = as_stream(stream);
   const int gx = btr_pm_gemm_grid(rows);
+  const BnFin fin = take_bnfin();
 #define BTR_PM_MM(BN, P, S, BIAS, MM)                                                          \
   hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S, 0, 64, BIAS, MM>), dim3(gx, cdiv(n, BN)),         \
                      dim3(256), 0, s, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,         \
                      (const unsigned char *)nullptr, (const float *)nullptr, 0, bias,          \
-                     (float *)nullptr, (unsigned char *)nullptr, Compact{})
+                     (float *)nullptr, (unsigned char *)nullptr, Compact{}, fin)
 #define BTR_PM(BN, P, S, BIAS)              \
   do {                                      \
     if (gemm_x6()) BTR_PM_MM(BN, P, S, BIAS, 1); \
