@@ -179,7 +179,7 @@ class _FastStep(object):
             # the same parameters (by identity) have one
             every = group['params']
             grads = [p.grad for p in every]
-            if None in grads:
+            if any(g is None for g in grads):   # (`None in grads` would call Tensor.__eq__ per entry)
                 params = [p for p, g in zip(every, grads) if g is not None]
                 grads = [g for g in grads if g is not None]
             else:

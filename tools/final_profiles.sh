@@ -1,0 +1,30 @@
+#!/bin/bash
+# The whole judged set of one build, on the GPU box:  tools/final_profiles.sh <tag>
+# (then, here: tools/collect_profiles.sh <tag>).  ~10 GPU-minutes.
+TAG=${1:-final}
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/$TAG
+mkdir -p $O
+bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
+bash tools/profile_pipelined.sh ${TAG}_pipe > $O/profile_pipelined.log 2>&1
+bash tools/probe/gemm_pmc.sh > $O/gemm_sq_counters.txt 2>&1
+bash tools/profile_gf.sh ${TAG}_gf_eager GF_ARGS=--no-graph > $O/profile_gf_eager.log 2>&1
+bash tools/profile_gf.sh ${TAG}_gf_graph > $O/profile_gf_graph.log 2>&1
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_steps20.json
+for wl in br cr gf gfbr; do
+  python bench.py --workload $wl 2>/dev/null | tail -1 > $O/bench_$wl.json
+done
+python bench.py --workload gf --no-graph 2>/dev/null | tail -1 > $O/bench_gf_eager.json
+python tools/gemm_tn_ab.py > $O/gemm_tn_ab.txt 2>&1
+python tools/gemm_nt_small_ab.py > $O/gemm_nt_small_ab.txt 2>&1
+python -c "
+import json
+for f in ('bench','bench_steps20','bench_br','bench_cr','bench_gf','bench_gf_eager','bench_gfbr'):
+    try:
+        d = json.load(open('$O/%s.json' % f))
+        print(f, round(d['value'], 1), d['unit'], round(d['ms_per_step'], 3), 'ms host', round(d['host_enqueue_ms_per_step'], 2), d.get('chain_paths'))
+    except Exception as e:
+        print(f, 'ERR', e)
+"
+head -1 $O/one_step.md gpurun_out/${TAG}_pipe/one_step.md gpurun_out/${TAG}_gf_eager/one_step.md gpurun_out/${TAG}_gf_graph/one_step.md
+cat $O/roofline_check.md | tail -5
