@@ -166,3 +166,22 @@ def test_descriptions_are_cached_per_shape_and_modules_stay_copyable(cuda):
     clone = copy.deepcopy(sa)            # ctypes descriptions are not part of the module
     assert clone not in fused_sa._LAYER_CACHE
     clone(torch.rand(2, 512, 3, device=cuda), None)
+
+
+def test_in_kernel_batchnorm_finalisation_at_every_size():
+    """The statistics GEMM's last workgroup finalises the BatchNorm for layers of <= 2 048 rows
+    by default (csrc/internal.hpp BnFin; larger layers measured slower that way).  The comparisons
+    of this file with the limit lifted -- 512-workgroup grids, two column blocks -- in a child
+    process (the switch is read once per process): still bit-identical to the finalize kernel."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BTR_BN_TICKET_MAX_ROWS="1000000000")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x",
+                        "-k", "equals_python_sequence", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=900)
+    tail = r.stdout.decode(errors="replace")[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
