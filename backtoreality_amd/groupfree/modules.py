@@ -47,11 +47,13 @@ class PositionEmbeddingLearned(nn.Module):
     def forward(self, xyz):
         # (B, C, P) form: made once per coordinate tensor (the key positions feed every decoder
         # layer's embedding; the head decode kernel writes the query positions in both forms)
-        x = getattr(xyz, '_btr_t', None)
-        if x is None:
+        cached = getattr(xyz, '_btr_t', None)   # (transpose, version of xyz it was made from)
+        if cached is not None and cached[1] == xyz._version:
+            x = cached[0]
+        else:
             x = xyz.transpose(1, 2).contiguous()
             if not xyz.requires_grad:
-                xyz._btr_t = x
+                xyz._btr_t = (x, xyz._version)
         head = self.position_embedding_head
         out = fused_mlp.run_chain(x, [(head[0], head[1], True), (head[3], None, False)])
         return out if out is not None else head(x)
@@ -156,7 +158,7 @@ class PredictHead(nn.Module):
                                   self.num_heading_bin, self.num_size_cluster)
         if dec is not None:   # one launch (csrc/gf_loss.hip); also the next layer's query position
             center, heading_residuals, size_residuals, pred_size, qpos, qpos_t = dec
-            qpos._btr_t = qpos_t
+            qpos._btr_t = (qpos_t, qpos._version)
             center._btr_query_pos = qpos
         else:
             center = base_xyz + center_residual

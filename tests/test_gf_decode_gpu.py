@@ -82,3 +82,20 @@ def test_head_and_detector_use_it(cuda, monkeypatch):
         # (two train-mode evaluations of the same BatchNorm chain: identical inputs, same bits)
         assert torch.equal(ep_a[k], ep_b[k]), k
     assert torch.equal(ca._btr_query_pos, torch.cat([cb, sb], -1))
+
+
+def test_cached_transpose_follows_in_place_edits(cuda):
+    """PositionEmbeddingLearned keeps the (B, C, P) form of a coordinate tensor on the tensor; an
+    in-place edit of the coordinates (its `_version` moves) must not be served the old copy."""
+    from backtoreality_amd.groupfree.modules import PositionEmbeddingLearned
+    torch.manual_seed(0)
+    pe = PositionEmbeddingLearned(3, 288).to(cuda).eval()
+    xyz = torch.rand(2, 256, 3, device=cuda)
+    with torch.no_grad():
+        a = pe(xyz)
+        assert getattr(xyz, '_btr_t', None) is not None
+        assert torch.equal(pe(xyz), a)
+        xyz.mul_(2.0)
+        b = pe(xyz)
+        assert torch.equal(b, pe(xyz.clone()))
+        assert not torch.equal(a, b)
