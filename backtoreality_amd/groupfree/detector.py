@@ -149,8 +149,9 @@ class GroupFreeDetector(nn.Module):
         if self.self_position_embedding == 'xyz_learned':
             return center.detach().clone()
         fused = getattr(center, '_btr_query_pos', None)   # written by the head decode kernel
-        if fused is not None:
-            return fused
+        if fused is not None and fused[1] == center._version and fused[2] is size and \
+                fused[3] == size._version:   # (neither tensor edited in place since)
+            return fused[0]
         return torch.cat([center.detach().clone(), size.detach().clone()], -1)
 
     def _backbone(self, inputs, center_xyz, center_cls):

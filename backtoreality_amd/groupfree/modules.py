@@ -159,7 +159,7 @@ class PredictHead(nn.Module):
         if dec is not None:   # one launch (csrc/gf_loss.hip); also the next layer's query position
             center, heading_residuals, size_residuals, pred_size, qpos, qpos_t = dec
             qpos._btr_t = (qpos_t, qpos._version)
-            center._btr_query_pos = qpos
+            center._btr_query_pos = (qpos, center._version, pred_size, pred_size._version)
         else:
             center = base_xyz + center_residual
             heading_residuals = heading_residuals_normalized * (np.pi / self.num_heading_bin)

@@ -81,7 +81,7 @@ def test_head_and_detector_use_it(cuda, monkeypatch):
             continue
         # (two train-mode evaluations of the same BatchNorm chain: identical inputs, same bits)
         assert torch.equal(ep_a[k], ep_b[k]), k
-    assert torch.equal(ca._btr_query_pos, torch.cat([cb, sb], -1))
+    assert torch.equal(ca._btr_query_pos[0], torch.cat([cb, sb], -1))
 
 
 def test_cached_transpose_follows_in_place_edits(cuda):
