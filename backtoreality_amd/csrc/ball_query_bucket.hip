@@ -6,9 +6,11 @@
 // cloud a second time (47 us for the build, 38 us for the query itself) although the FPS
 // workspace still holds the cloud sorted along a Hilbert curve in buckets of 64 points --
 // x[64] y[64] z[64] k[64] per bucket, k = original index.  Here:
-//   1. bqb_box_kernel / bqb_super_kernel: bounding box of every bucket (one wave per bucket:
-//      three coalesced 256-byte loads and a wave min/max) and of every SUPER-bucket of 16
-//      consecutive buckets (consecutive along the curve = spatially compact);
+//   1. the bounding box of every bucket: left in the FPS workspace by the FPS kernel, which
+//      needs them for its own pruning (internal.hpp fps_boxes_lookup; bqb_box_kernel -- one wave
+//      per bucket: three coalesced 256-byte loads and a wave min/max -- when another FPS kernel
+//      ran), and of every SUPER-bucket of 16 consecutive buckets (consecutive along the curve =
+//      spatially compact), built by every query workgroup in its prologue;
 //   2. bqb_query_kernel, one wave per centre: box test of the <= 64 super-buckets (one per
 //      lane, boxes in LDS), then of the 16 buckets of every touched one; the points of the
 //      surviving buckets (four coalesced loads per bucket) are tested with the reference's
@@ -31,10 +33,6 @@ namespace btr {
 constexpr int kSuper = 16;          // buckets per super-bucket
 constexpr int kMaxSupers = 128;     // super-buckets per scene the query kernel can hold
 constexpr int kBqbWaves = 4;
-
-struct Box8 {  // two float4: lo.xyz, hi.xyz
-  float x0, y0, z0, p0, x1, y1, z1, p1;
-};
 
 __device__ __forceinline__ float wave_min_f32(float v) {
 #pragma unroll
@@ -72,22 +70,6 @@ __global__ __launch_bounds__(256) void bqb_box_kernel(int np, int nb,
     boxes[(size_t)bi * nb + b] = Box8{lo[0], lo[1], lo[2], 0.f, hi[0], hi[1], hi[2], 0.f};
 }
 
-// sboxes[scene][nsup]: union of the boxes of 16 consecutive buckets, one thread each
-__global__ __launch_bounds__(64) void bqb_super_kernel(int nb, int nsup,
-                                                       const Box8 *__restrict__ boxes,
-                                                       Box8 *__restrict__ sboxes) {
-  const int bi = blockIdx.y, s = blockIdx.x * 64 + threadIdx.x;
-  if (s >= nsup) return;
-  const Box8 *bx = boxes + (size_t)bi * nb;
-  Box8 a = Box8{3.0e38f, 3.0e38f, 3.0e38f, 0.f, -3.0e38f, -3.0e38f, -3.0e38f, 0.f};
-  for (int b = s * kSuper; b < min(nb, (s + 1) * kSuper); ++b) {
-    const Box8 q = bx[b];
-    a.x0 = fminf(a.x0, q.x0); a.y0 = fminf(a.y0, q.y0); a.z0 = fminf(a.z0, q.z0);
-    a.x1 = fmaxf(a.x1, q.x1); a.y1 = fmaxf(a.y1, q.y1); a.z1 = fmaxf(a.z1, q.z1);
-  }
-  sboxes[(size_t)bi * nsup + s] = a;
-}
-
 // squared distance from p to the box (0 inside); plain f32, only used as a conservative cull
 __device__ __forceinline__ float box_d2(const Box8 &q, float x, float y, float z) {
   const float ex = fmaxf(fmaxf(q.x0 - x, x - q.x1), 0.f);
@@ -101,8 +83,7 @@ __device__ __forceinline__ float box_d2(const Box8 &q, float x, float y, float z
 __global__ __launch_bounds__(kBqbWaves * 64) void bqb_query_kernel(
     int B, int n, int np, int nb, int nsup, int m, int nsample, int words, int twords,
     float radius2, float cull2, const float *__restrict__ new_xyz,
-    const float *__restrict__ spts, const Box8 *__restrict__ boxes,
-    const Box8 *__restrict__ sboxes, int *__restrict__ idx) {
+    const float *__restrict__ spts, const Box8 *__restrict__ boxes, int *__restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Box8 *sb = reinterpret_cast<Box8 *>(smem);
   unsigned *maps = reinterpret_cast<unsigned *>(smem + sizeof(Box8) * nsup);
@@ -113,7 +94,17 @@ __global__ __launch_bounds__(kBqbWaves * 64) void bqb_query_kernel(
   unsigned *bm = maps + (size_t)wave * (words + twords);
   unsigned *top = bm + words;
   for (int w = lane; w < words + twords; w += 64) bm[w] = 0u;
-  for (int s = threadIdx.x; s < nsup; s += kBqbWaves * 64) sb[s] = sboxes[(size_t)bi * nsup + s];
+  // super-bucket boxes: the union of 16 consecutive bucket boxes, built here (640 B of L2 reads
+  // per super-bucket and workgroup; was a launch of its own)
+  for (int s = threadIdx.x; s < nsup; s += kBqbWaves * 64) {
+    const Box8 *q = boxes + (size_t)bi * nb + (size_t)s * kSuper;
+    Box8 a = Box8{3.0e38f, 3.0e38f, 3.0e38f, 0.f, -3.0e38f, -3.0e38f, -3.0e38f, 0.f};
+    for (int t = 0; t < min(kSuper, nb - s * kSuper); ++t) {
+      a.x0 = fminf(a.x0, q[t].x0); a.y0 = fminf(a.y0, q[t].y0); a.z0 = fminf(a.z0, q[t].z0);
+      a.x1 = fmaxf(a.x1, q[t].x1); a.y1 = fmaxf(a.y1, q[t].y1); a.z1 = fmaxf(a.z1, q[t].z1);
+    }
+    sb[s] = a;
+  }
   __syncthreads();
 
   const float *sp = spts + (size_t)bi * np * 4;
@@ -239,12 +230,15 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   BTR_REQUIRE(fps_workspace && ws && ws_bytes >= p.box_bytes + p.sbox_bytes,
               "ball_query(buckets): workspace too small");
   const float *spts = (const float *)fps_workspace;
-  Box8 *boxes = (Box8 *)ws;
-  Box8 *sboxes = (Box8 *)((char *)ws + p.box_bytes);
-  hipLaunchKernelGGL(bqb_box_kernel, dim3(cdiv(p.nb, 4), b), dim3(256), 0, s, p.np, p.nb, spts,
-                     boxes);
-  hipLaunchKernelGGL(bqb_super_kernel, dim3(cdiv(p.nsup, 64), b), dim3(64), 0, s, p.nb, p.nsup,
-                     boxes, sboxes);
+  // bucket boxes: left behind by the FPS kernel that sorted this cloud (internal.hpp), else one
+  // wave per bucket here
+  const Box8 *boxes = fps_boxes_lookup(fps_workspace, b, n);
+  if (!boxes) {
+    Box8 *own = (Box8 *)ws;
+    hipLaunchKernelGGL(bqb_box_kernel, dim3(cdiv(p.nb, 4), b), dim3(256), 0, s, p.np, p.nb, spts,
+                       own);
+    boxes = own;
+  }
   static size_t lds_set = 0;
   if (p.lds > lds_set && p.lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)bqb_query_kernel,
@@ -258,7 +252,7 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   const int chunks = std::max(1, std::min(cdiv(m, kBqbWaves), 2048 / std::max(1, b)));
   hipLaunchKernelGGL(bqb_query_kernel, dim3(chunks * b), dim3(kBqbWaves * 64), p.lds, s, b, n,
                      p.np, p.nb, p.nsup, m, nsample, p.words, p.twords, radius2, cull2, new_xyz,
-                     spts, boxes, sboxes, idx);
+                     spts, boxes, idx);
   return check_launch("ball_query(buckets)");
 }
 

@@ -21,7 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "common.hpp"
+#include "internal.hpp"
 
 namespace btr {
 
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
                                                              const float4 *__restrict__ spts,
                                                              float *__restrict__ tmin,
                                                              int *__restrict__ idxs,
-                                                             unsigned long long *dbg = nullptr) {
+                                                             unsigned long long *dbg = nullptr,
+                                                             Box8 *__restrict__ boxes = nullptr) {
   // PROF: s_memtime phase counters (tuning builds only; BTR_FPS_PROF=1 in tools/)
   unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, nact = 0, nuse = 0, nchg = 0;
 #define BTR_PH(i)                                                  \
@@ -335,6 +336,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       }
       bx0[s] = ax0; bx1[s] = ax1; by0[s] = ay0; by1[s] = ay1; bz0[s] = az0; bz1[s] = az1;
       mhi[s] = any ? __float_as_uint(1e10f) + 1u : 0u;  // competing points start at 1e10
+      // for the ball query over the same buckets (internal.hpp Box8)
+      if (boxes) boxes[(size_t)bi * nb + myb] = Box8{ax0, ay0, az0, 0.f, ax1, ay1, az1, 0.f};
     }
   }
 
@@ -1176,6 +1179,7 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
               p.pts_bytes + p.k_bytes + p.sort_bytes, workspace_bytes);
   float4 *spts = (float4 *)workspace;
   float *sk = (float *)((char *)workspace + p.pts_bytes);  // the min-dist array
+  fps_boxes_note(workspace, b, n, nullptr);   // (set again below by the kernel that writes them)
   {
     static int curve_set = -1;
     const char *cv = getenv("BTR_FPS_CURVE");
@@ -1338,15 +1342,55 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   // owner-wave kernel: 16 waves, one bucket per trip
   hipEvent_t *ev = fps_kernel_events();   // bench.py: event pair around THIS kernel only
   if (ev[0]) (void)hipEventRecord(ev[0], s);
+  // the bucket boxes go where the counting sort kept its cells (dead by now): b * nb * 32 bytes
+  // of the b * 131 072 there
+  Box8 *boxes = reinterpret_cast<Box8 *>((char *)workspace + p.pts_bytes + p.k_bytes);
+  static_assert(sizeof(Box8) * (kBucketMaxN / 64) <= sizeof(int) * kCells, "boxes fit the cells");
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
+                       0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
+                       (unsigned long long *)nullptr, boxes);
   else
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
+                       0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
+                       (unsigned long long *)nullptr, boxes);
   if (ev[1]) (void)hipEventRecord(ev[1], s);
   ev[0] = ev[1] = nullptr;
+  fps_boxes_note(workspace, b, n, boxes);
   return check_launch("furthest_point_sampling(bucket)");
+}
+
+// ---- which workspaces hold bucket boxes (internal.hpp): the last few launches of this thread
+namespace {
+struct BoxNote {
+  const void *ws = nullptr;
+  int b = 0, n = 0;
+  const Box8 *boxes = nullptr;
+};
+constexpr int kBoxNotes = 16;
+inline BoxNote *box_notes() {
+  static thread_local BoxNote notes[kBoxNotes];
+  return notes;
+}
+}  // namespace
+void fps_boxes_note(const void *workspace, int b, int n, const Box8 *boxes) {
+  BoxNote *t = box_notes();
+  static thread_local int next = 0;
+  for (int i = 0; i < kBoxNotes; ++i)
+    if (t[i].ws == workspace) {
+      t[i] = BoxNote{workspace, b, n, boxes};
+      return;
+    }
+  t[next] = BoxNote{workspace, b, n, boxes};
+  next = (next + 1) % kBoxNotes;
+}
+const Box8 *fps_boxes_lookup(const void *workspace, int b, int n) {
+  static const bool off = getenv("BTR_BQ_FPS_BOXES") && getenv("BTR_BQ_FPS_BOXES")[0] == '0';
+  if (off) return nullptr;
+  const BoxNote *t = box_notes();
+  for (int i = 0; i < kBoxNotes; ++i)
+    if (t[i].ws == workspace && t[i].b == b && t[i].n == n) return t[i].boxes;
+  return nullptr;
 }
 
 }  // namespace btr

@@ -13,6 +13,17 @@ int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
                const float *shift, int relu, float *out_bcn, float *out_cl, const float *add,
                long long add_bstride, hipStream_t stream);
 
+// Bounding box of a 64-point bucket of the FPS's spatial sort (two float4: lo.xyz, hi.xyz).  The
+// large-scene FPS kernel knows every bucket's box (its pruning test) and leaves them in the dead
+// counting-sort area of its workspace; the ball query over the same buckets
+// (ball_query_bucket.hip) then skips its own box pass.  fps_boxes_note / _lookup: which FPS
+// workspace (this host thread's most recent launches) holds boxes for (b, n), and where.
+struct Box8 {
+  float x0, y0, z0, p0, x1, y1, z1, p1;
+};
+void fps_boxes_note(const void *workspace, int b, int n, const Box8 *boxes);   // boxes NULL: none
+const Box8 *fps_boxes_lookup(const void *workspace, int b, int n);
+
 // sa_mlp.hip: BatchNorm finalisation inside the statistics GEMM (the last workgroup of a column
 // block to arrive -- a ticket per 128 / 64-column block, zeroed by the call's first kernel -- turns
 // the per-workgroup partial sums into scale / shift / mean / invstd and updates the running

@@ -23,7 +23,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-BQ_LAUNCHES = 3         # bucket boxes, super-bucket boxes, query (csrc/ball_query_bucket.hip)
+BQ_LAUNCHES = 1         # the query (its bucket boxes come from the FPS kernel: csrc/ball_query_bucket.hip)
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA peak
 
 
@@ -520,13 +520,13 @@ def roofline_objects(kernels, detail, detail_steps, pair_overhead_ms=0.0):
                                       "frac_of_floor": (BQ_LAUNCHES * 1.45 + nbytes / 6.3e12 * 1e6)
                                       / (ms * 1e3),
                                       "shape": [b, n, m, s], "avg_ms": ms,
-                                      "kernel": ("bqb_query_kernel (+bqb_box_kernel, "
-                                                 "bqb_super_kernel)" if bq_buckets else
+                                      "kernel": ("bqb_query_kernel" if bq_buckets else
                                                  "bq_grid_query_kernel (+grid build)"),
                                       "note": ("query over the Hilbert buckets the FPS of the "
-                                               "same scene built (3 launches: bucket boxes, "
-                                               "super-bucket boxes, query); `traffic` is the "
-                                               "query kernel's" if bq_buckets else
+                                               "same scene built: one launch (the bucket boxes "
+                                               "are left behind by the FPS kernel, the "
+                                               "super-bucket boxes are built in the query's "
+                                               "prologue)" if bq_buckets else
                                                "grid-culled query incl. the one-launch grid "
                                                "build (2 launches)")}
     # grouped shared MLP: every f32-MFMA GEMM launch of the fused SA path (fwd NT with BN

@@ -221,6 +221,25 @@ def test_ball_query_over_the_fps_buckets(cuda, monkeypatch, kind, B, N, M, r, S,
     np.testing.assert_array_equal(_ext().ball_query(new, x, r, S).cpu().numpy(), ref)
 
 
+def test_ball_query_over_the_fps_buckets_with_its_own_box_pass():
+    """The bucket boxes normally come from the FPS kernel (csrc/internal.hpp fps_boxes_lookup);
+    `BTR_BQ_FPS_BOXES=0` (read once per process: a child process) makes the query compute them
+    itself, as it does behind any other FPS kernel: same oracle-exact indices."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BTR_BQ_FPS_BOXES="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x",
+                        "-k", "test_ball_query_over_the_fps_buckets and surface",
+                        "-p", "no:cacheprovider"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=900)
+    tail = r.stdout.decode(errors="replace")[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "failed" not in tail, tail
+
+
 def test_ball_query_grid_duplicates_and_dense(cuda):
     rng = np.random.default_rng(21)
     xyz = rng.uniform(0, 2, size=(1, 12000, 3)).astype(np.float32)

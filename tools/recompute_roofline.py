@@ -12,7 +12,7 @@ the summed and the longest duration inside one steady-state step).
   FPS         fps_bucket_kernel's longest call (the live figure is an event pair around that
               kernel alone)
   ball query  the longest bqb_query_kernel (or bq_grid_query_kernel) call + its set-up
-              launches (bqb_box / bqb_super, or the grid build), longest call of each
+              launches (bqb_box / bqb_super in builds that had them, or the grid build), longest call of each
   grouped MLP every gemm_nt_kernel / gemm_tn_kernel launch of the step (+ reduce_chunks, the
               second half of the TN GEMM's split-K) against the f32 MFMA peak
 
