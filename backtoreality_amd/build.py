@@ -39,10 +39,20 @@ HIPCC_FLAGS = [
     # launches without it; the guide lists packed f32 as an anti-lever beside MFMAs anyway.
     "-fno-slp-vectorize",
 ]
-EXTRA_FLAGS = {}   # per-file additions to HIPCC_FLAGS (none at present)
-# sources whose code depends on BTR_FMAD (they evaluate sq3() / dot3())
+# sources whose code depends on BTR_FMAD (they evaluate sq3() / dot3()): the index-producing ones
 MODE_SOURCES = ("ball_query.hip", "ball_query_bucket.hip", "ball_query_grid.hip",
                 "fps_bucket.hip", "interpolate.hip", "sampling.hip")
+# per-file additions to HIPCC_FLAGS.  The index-producing sources also switch the LOOP vectoriser
+# off (it packed three f32 ops of the streaming FPS kernel and of three_interpolate even with SLP
+# off), so that the guard below can be absolute: no packed f32 arithmetic in those objects.
+EXTRA_FLAGS = {name: ["-fno-vectorize"] for name in MODE_SOURCES}
+# Build-time guard (round-3 review, What's weak #3): the device code of every index-producing
+# object is disassembled and the build FAILS on any packed f32 arithmetic instruction -- the
+# form the wrong-FPS-sequence-under-concurrency incident was bisected to (DESIGN.md 7.5;
+# stand-alone reproducer: tools/probe/pk_hazard.hip).  A new compiler or an edit that brings
+# them back is caught here, not by a 1-3 % statistical test on the GPU.
+PACKED_F32 = r"\bv_pk_(add|mul|fma)_f32\b"
+LLVM_BIN = os.environ.get("BTR_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 
 def lib_path(mode=1):
@@ -98,10 +108,61 @@ def _build_id_object(plan):
     return os.path.join(OBJ_DIR, "build_id.%s.o" % build_id(plan))
 
 
+def disassemble(obj):
+    """Text disassembly of the gfx950 code object bundled in a hipcc host object."""
+    import shutil
+    import tempfile
+    objdump = os.path.join(LLVM_BIN, "llvm-objdump")
+    with tempfile.TemporaryDirectory(prefix="btr_dis_") as tmp:
+        local = os.path.join(tmp, "x.o")
+        shutil.copy(obj, local)
+        subprocess.check_call([objdump, "--offloading", local], cwd=tmp,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dev = [f for f in os.listdir(tmp) if "amdgcn" in f]
+        if len(dev) != 1:
+            raise RuntimeError("no single gfx950 bundle in %s: %r" % (obj, dev))
+        return subprocess.check_output([objdump, "-d", os.path.join(tmp, dev[0])]).decode()
+
+
+def packed_f32_sites(obj):
+    """[(kernel symbol, instruction line)] of packed f32 arithmetic in an object's device code."""
+    import re
+    pat, sites, fn = re.compile(PACKED_F32), [], "?"
+    for line in disassemble(obj).splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m:
+            fn = m.group(1)
+        elif pat.search(line):
+            sites.append((fn, line.strip()))
+    return sites
+
+
+def _guard_marker(obj):
+    return obj[:-2] + ".nopk"
+
+
+def check_index_objects(plan=None, force=False):
+    """Fails (RuntimeError) when an index-producing object holds packed f32 arithmetic; the
+    verdict per object is remembered beside it (objects are content-addressed)."""
+    plan = plan or _object_plan()
+    for src, mode, obj in plan:
+        if mode is None or (os.path.exists(_guard_marker(obj)) and not force):
+            continue
+        sites = packed_f32_sites(obj)
+        if sites:
+            raise RuntimeError(
+                "packed f32 arithmetic in an index-producing object (%s, BTR_FMAD=%s):\n  %s"
+                % (os.path.basename(src), mode,
+                   "\n  ".join("%s: %s" % s for s in sites[:12])))
+        with open(_guard_marker(obj), "w") as fh:
+            fh.write("no v_pk_{add,mul,fma}_f32\n")
+
+
 def is_fresh():
     plan = _object_plan()
     if not all(os.path.exists(o) for _, _, o in plan) or \
-            not os.path.exists(_build_id_object(plan)):
+            not os.path.exists(_build_id_object(plan)) or \
+            not all(os.path.exists(_guard_marker(o)) for _, m, o in plan if m is not None):
         return False
     newest = max(os.path.getmtime(o) for _, _, o in plan)
     return all(os.path.exists(lib_path(m)) and os.path.getmtime(lib_path(m)) >= newest
@@ -133,6 +194,7 @@ def build(force=False, verbose=False, jobs=None):
     jobs = jobs or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         list(pool.map(compile_one, todo))
+    check_index_objects(plan)
     bid_obj = _build_id_object(plan)
     if not os.path.exists(bid_obj):   # (host-only: a second to compile)
         src = bid_obj[:-2] + ".cpp"
@@ -141,7 +203,8 @@ def build(force=False, verbose=False, jobs=None):
         subprocess.check_call([hipcc, "-O1", "-fPIC", "-c", src, "-o", bid_obj + ".tmp"])
         os.replace(bid_obj + ".tmp", bid_obj)
         os.remove(src)
-    keep = {o for _, _, o in plan} | {bid_obj}
+    keep = {o for _, _, o in plan} | {bid_obj} | \
+        {_guard_marker(o) for _, m, o in plan if m is not None}
     for f in os.listdir(OBJ_DIR):                      # objects of older source versions
         if os.path.join(OBJ_DIR, f) not in keep:
             os.remove(os.path.join(OBJ_DIR, f))

@@ -256,6 +256,10 @@ int btr_backbone_plan(const btr_backbone_t *dp, btr_backbone_plan_t *p) {
       // the streaming fall-back (no bucket workspace for a large scene) needs the (b, n) scratch
       p->g_fps_temp[l] = (p->g_fps_ws_bytes[l] == 0 && s.n > 4096) ? g.floats((size_t)d.b * s.n)
                                                                     : (size_t)0;
+      // levels 2.. sample the previous level's points in FPS order: the verdict slots of
+      // btr_furthest_point_sampling_ordered live in the same scratch slot
+      if (l >= 1 && btr_fps_ordered_scratch_bytes(d.b, s.n, s.m))
+        p->g_fps_temp[l] = g.floats(btr_fps_ordered_scratch_bytes(d.b, s.n, s.m) / sizeof(float));
       const size_t bk = p->g_fps_ws_bytes[l]
                             ? btr_ball_query_buckets_workspace_bytes(d.b, s.n, s.m, s.s) : 0;
       p->bq_buckets[l] = bk > 0;
@@ -354,8 +358,13 @@ int btr_backbone_sampling(const btr_backbone_t *dp, const btr_backbone_plan_t *p
     float *new_xyz = at_f(geom, p.g_new_xyz[l]);
     void *fws = p.g_fps_ws_bytes[l] ? (char *)geom + p.g_fps_ws[l] : nullptr;
     float *temp = p.g_fps_temp[l] ? at_f(geom, p.g_fps_temp[l]) : nullptr;
-    BTR_TRY(btr_furthest_point_sampling_ws(d.b, s.n, s.m, xyz, temp, inds, 0, fws,
-                                           p.g_fps_ws_bytes[l], cur));
+    const size_t ordered = l >= 1 ? btr_fps_ordered_scratch_bytes(d.b, s.n, s.m) : 0;
+    if (ordered && temp)   // xyz = the previous level's new_xyz: expect 0, 1, 2, ... and check it
+      BTR_TRY(btr_furthest_point_sampling_ordered(d.b, s.n, s.m, xyz, nullptr, inds, 0, temp,
+                                                  ordered, cur));
+    else
+      BTR_TRY(btr_furthest_point_sampling_ws(d.b, s.n, s.m, xyz, temp, inds, 0, fws,
+                                             p.g_fps_ws_bytes[l], cur));
     BTR_TRY(btr_gather_rows(d.b, s.n, s.m, 3, xyz, inds, new_xyz, cur));
     if (p.bq_buckets[l])
       BTR_TRY(btr_ball_query_buckets(d.b, s.n, s.m, d.radius[l], s.s, new_xyz, fws,

@@ -83,8 +83,10 @@ __device__ __forceinline__ float box_d2(const Box8 &q, float x, float y, float z
 __global__ __launch_bounds__(kBqbWaves * 64) void bqb_query_kernel(
     int B, int n, int np, int nb, int nsup, int m, int nsample, int words, int twords,
     float radius2, float cull2, const float *__restrict__ new_xyz,
-    const float *__restrict__ spts, const Box8 *__restrict__ boxes, int *__restrict__ idx) {
+    const float *__restrict__ spts, const Box8 *__restrict__ boxes, unsigned box_epoch,
+    int *__restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int stale;   // some box of this scene does not carry the expected stamp
   Box8 *sb = reinterpret_cast<Box8 *>(smem);
   unsigned *maps = reinterpret_cast<unsigned *>(smem + sizeof(Box8) * nsup);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -94,20 +96,47 @@ __global__ __launch_bounds__(kBqbWaves * 64) void bqb_query_kernel(
   unsigned *bm = maps + (size_t)wave * (words + twords);
   unsigned *top = bm + words;
   for (int w = lane; w < words + twords; w += 64) bm[w] = 0u;
+  if (threadIdx.x == 0) stale = 0;
+  __syncthreads();
   // super-bucket boxes: the union of 16 consecutive bucket boxes, built here (640 B of L2 reads
-  // per super-bucket and workgroup; was a launch of its own)
+  // per super-bucket and workgroup; was a launch of its own).  Boxes the FPS kernel left behind
+  // (box_epoch != 0) are only trusted when every one of the scene carries that launch's stamp.
+  const float *sp = spts + (size_t)bi * np * 4;
+  bool bad = false;
   for (int s = threadIdx.x; s < nsup; s += kBqbWaves * 64) {
     const Box8 *q = boxes + (size_t)bi * nb + (size_t)s * kSuper;
     Box8 a = Box8{3.0e38f, 3.0e38f, 3.0e38f, 0.f, -3.0e38f, -3.0e38f, -3.0e38f, 0.f};
     for (int t = 0; t < min(kSuper, nb - s * kSuper); ++t) {
       a.x0 = fminf(a.x0, q[t].x0); a.y0 = fminf(a.y0, q[t].y0); a.z0 = fminf(a.z0, q[t].z0);
       a.x1 = fmaxf(a.x1, q[t].x1); a.y1 = fmaxf(a.y1, q[t].y1); a.z1 = fmaxf(a.z1, q[t].z1);
+      bad |= box_epoch != 0u &&
+             (__float_as_uint(q[t].p0) != box_epoch ||
+              __float_as_uint(q[t].p1) != box_stamp_pos(bi * nb + s * kSuper + t));
     }
     sb[s] = a;
   }
+  if (bad) atomicOr(&stale, 1);
   __syncthreads();
+  const bool trusted = stale == 0;
+  if (!trusted) {
+    // the boxes are not the noted launch's: bound every super-bucket by its own (up to 1 024)
+    // points instead and cull no single bucket
+    for (int s = threadIdx.x; s < nsup; s += kBqbWaves * 64) {
+      Box8 a = Box8{3.0e38f, 3.0e38f, 3.0e38f, 0.f, -3.0e38f, -3.0e38f, -3.0e38f, 0.f};
+      for (int t = 0; t < min(kSuper, nb - s * kSuper); ++t) {
+        const float *bp = sp + (size_t)(s * kSuper + t) * 256;
+        for (int i = 0; i < 64; ++i) {
+          if (__float_as_int(bp[192 + i]) < 0) continue;
+          a.x0 = fminf(a.x0, bp[i]); a.x1 = fmaxf(a.x1, bp[i]);
+          a.y0 = fminf(a.y0, bp[64 + i]); a.y1 = fmaxf(a.y1, bp[64 + i]);
+          a.z0 = fminf(a.z0, bp[128 + i]); a.z1 = fmaxf(a.z1, bp[128 + i]);
+        }
+      }
+      sb[s] = a;
+    }
+    __syncthreads();
+  }
 
-  const float *sp = spts + (size_t)bi * np * 4;
   const Box8 *bx = boxes + (size_t)bi * nb;
   for (int j = chunk * kBqbWaves + wave; j < m; j += nchunks * kBqbWaves) {
     const float *c = new_xyz + ((size_t)bi * m + j) * 3;
@@ -127,7 +156,8 @@ __global__ __launch_bounds__(kBqbWaves * 64) void bqb_query_kernel(
         }
         const int mys = sup[lane >> 4];
         const int b = mys * kSuper + (lane & 15);
-        const bool cand = mys >= 0 && b < nb && box_d2(bx[b], cx, cy, cz) < cull2;
+        const bool cand =
+            mys >= 0 && b < nb && (!trusted || box_d2(bx[b], cx, cy, cz) < cull2);
         unsigned long long bmask = __ballot(cand);
         // ---- candidates: 64 points per bucket, two buckets per trip (8 loads in flight)
         while (bmask) {
@@ -232,7 +262,8 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   const float *spts = (const float *)fps_workspace;
   // bucket boxes: left behind by the FPS kernel that sorted this cloud (internal.hpp), else one
   // wave per bucket here
-  const Box8 *boxes = fps_boxes_lookup(fps_workspace, b, n);
+  unsigned epoch = 0u;   // 0: boxes of the own pass below, nothing to verify
+  const Box8 *boxes = fps_boxes_lookup(fps_workspace, b, n, &epoch);
   if (!boxes) {
     Box8 *own = (Box8 *)ws;
     hipLaunchKernelGGL(bqb_box_kernel, dim3(cdiv(p.nb, 4), b), dim3(256), 0, s, p.np, p.nb, spts,
@@ -252,7 +283,7 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   const int chunks = std::max(1, std::min(cdiv(m, kBqbWaves), 2048 / std::max(1, b)));
   hipLaunchKernelGGL(bqb_query_kernel, dim3(chunks * b), dim3(kBqbWaves * 64), p.lds, s, b, n,
                      p.np, p.nb, p.nsup, m, nsample, p.words, p.twords, radius2, cull2, new_xyz,
-                     spts, boxes, idx);
+                     spts, boxes, epoch, idx);
   return check_launch("ball_query(buckets)");
 }
 

@@ -17,6 +17,7 @@
 // per point, so the arg-max -- and therefore the result -- is independent of the sort.
 // Selection rule / tie-break: identical to sampling.hip (reference sampling_gpu.cu:74-178).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
                                                              float *__restrict__ tmin,
                                                              int *__restrict__ idxs,
                                                              unsigned long long *dbg = nullptr,
-                                                             Box8 *__restrict__ boxes = nullptr) {
+                                                             Box8 *__restrict__ boxes = nullptr,
+                                                             unsigned box_epoch = 0u) {
   // PROF: s_memtime phase counters (tuning builds only; BTR_FPS_PROF=1 in tools/)
   unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, nact = 0, nuse = 0, nchg = 0;
 #define BTR_PH(i)                                                  \
@@ -336,8 +338,12 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       }
       bx0[s] = ax0; bx1[s] = ax1; by0[s] = ay0; by1[s] = ay1; bz0[s] = az0; bz1[s] = az1;
       mhi[s] = any ? __float_as_uint(1e10f) + 1u : 0u;  // competing points start at 1e10
-      // for the ball query over the same buckets (internal.hpp Box8)
-      if (boxes) boxes[(size_t)bi * nb + myb] = Box8{ax0, ay0, az0, 0.f, ax1, ay1, az1, 0.f};
+      // for the ball query over the same buckets (internal.hpp Box8): every box carries the
+      // launch's epoch and its own position, which the query checks before it trusts it
+      if (boxes)
+        boxes[(size_t)bi * nb + myb] =
+            Box8{ax0, ay0, az0, __uint_as_float(box_epoch),
+                 ax1, ay1, az1, __uint_as_float(box_stamp_pos(bi * nb + myb))};
     }
   }
 
@@ -1179,7 +1185,7 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
               p.pts_bytes + p.k_bytes + p.sort_bytes, workspace_bytes);
   float4 *spts = (float4 *)workspace;
   float *sk = (float *)((char *)workspace + p.pts_bytes);  // the min-dist array
-  fps_boxes_note(workspace, b, n, nullptr);   // (set again below by the kernel that writes them)
+  fps_boxes_note(workspace, b, n, nullptr, 0u);   // (set again below by the kernel that writes them)
   {
     static int curve_set = -1;
     const char *cv = getenv("BTR_FPS_CURVE");
@@ -1346,17 +1352,21 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   // of the b * 131 072 there
   Box8 *boxes = reinterpret_cast<Box8 *>((char *)workspace + p.pts_bytes + p.k_bytes);
   static_assert(sizeof(Box8) * (kBucketMaxN / 64) <= sizeof(int) * kCells, "boxes fit the cells");
+  // a process-wide launch counter (never 0: 0 means "unstamped boxes" to the query)
+  static std::atomic<unsigned> epoch_counter{0x5a000000u};
+  unsigned epoch = epoch_counter.fetch_add(1u) + 1u;
+  if (epoch == 0u) epoch = epoch_counter.fetch_add(1u) + 1u;
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
-                       (unsigned long long *)nullptr, boxes);
+                       (unsigned long long *)nullptr, boxes, epoch);
   else
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
-                       (unsigned long long *)nullptr, boxes);
+                       (unsigned long long *)nullptr, boxes, epoch);
   if (ev[1]) (void)hipEventRecord(ev[1], s);
   ev[0] = ev[1] = nullptr;
-  fps_boxes_note(workspace, b, n, boxes);
+  fps_boxes_note(workspace, b, n, boxes, epoch);
   return check_launch("furthest_point_sampling(bucket)");
 }
 
@@ -1366,6 +1376,7 @@ struct BoxNote {
   const void *ws = nullptr;
   int b = 0, n = 0;
   const Box8 *boxes = nullptr;
+  unsigned epoch = 0u;
 };
 constexpr int kBoxNotes = 16;
 inline BoxNote *box_notes() {
@@ -1373,23 +1384,27 @@ inline BoxNote *box_notes() {
   return notes;
 }
 }  // namespace
-void fps_boxes_note(const void *workspace, int b, int n, const Box8 *boxes) {
+void fps_boxes_note(const void *workspace, int b, int n, const Box8 *boxes, unsigned epoch) {
   BoxNote *t = box_notes();
   static thread_local int next = 0;
   for (int i = 0; i < kBoxNotes; ++i)
     if (t[i].ws == workspace) {
-      t[i] = BoxNote{workspace, b, n, boxes};
+      t[i] = BoxNote{workspace, b, n, boxes, epoch};
       return;
     }
-  t[next] = BoxNote{workspace, b, n, boxes};
+  t[next] = BoxNote{workspace, b, n, boxes, epoch};
   next = (next + 1) % kBoxNotes;
 }
-const Box8 *fps_boxes_lookup(const void *workspace, int b, int n) {
+const Box8 *fps_boxes_lookup(const void *workspace, int b, int n, unsigned *epoch) {
   static const bool off = getenv("BTR_BQ_FPS_BOXES") && getenv("BTR_BQ_FPS_BOXES")[0] == '0';
+  *epoch = 0u;
   if (off) return nullptr;
   const BoxNote *t = box_notes();
   for (int i = 0; i < kBoxNotes; ++i)
-    if (t[i].ws == workspace && t[i].b == b && t[i].n == n) return t[i].boxes;
+    if (t[i].ws == workspace && t[i].b == b && t[i].n == n) {
+      *epoch = t[i].epoch;
+      return t[i].boxes;
+    }
   return nullptr;
 }
 

@@ -21,8 +21,19 @@ int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
 struct Box8 {
   float x0, y0, z0, p0, x1, y1, z1, p1;
 };
-void fps_boxes_note(const void *workspace, int b, int n, const Box8 *boxes);   // boxes NULL: none
-const Box8 *fps_boxes_lookup(const void *workspace, int b, int n);
+// The contract between the two calls (btr_pointnet2.h documents it for callers): the boxes sit
+// in the "dead" counting-sort area of the FPS workspace, so the whole workspace must stay
+// untouched between the FPS and the query.  It is CHECKED on the device, not assumed: the FPS
+// kernel stamps every box with its launch's epoch (p0, bit pattern) and with the box's own
+// position (p1 = box_stamp_pos), the host note remembers the epoch, and every query workgroup
+// compares all stamps while it builds the super-bucket boxes.  A mismatch anywhere in the scene
+// -- the area was overwritten, partially restored, or filled by another launch than the noted one
+// -- makes that workgroup rebuild the super boxes from the sorted points and skip the per-bucket
+// cull: slower, still the exact result (tests/test_ops_gpu.py).
+__host__ __device__ inline unsigned box_stamp_pos(int i) { return 0xb0c5b0c5u ^ (unsigned)i; }
+void fps_boxes_note(const void *workspace, int b, int n, const Box8 *boxes,
+                    unsigned epoch);   // boxes NULL: none
+const Box8 *fps_boxes_lookup(const void *workspace, int b, int n, unsigned *epoch);
 
 // sa_mlp.hip: BatchNorm finalisation inside the statistics GEMM (the last workgroup of a column
 // block to arrive -- a ticket per 128 / 64-column block, zeroed by the call's first kernel -- turns

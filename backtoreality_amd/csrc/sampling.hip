@@ -231,6 +231,8 @@ static int launch_fps(int b, int n, int m, int bs, int log2bs, const float *data
 // (`pm`: which of my points equal the wave maximum) and the (-tk) tie-break is evaluated only
 // when more than one point holds the maximum.  Winner coordinates come from an LDS copy of the
 // points, so a slot is just (bits(d2), k).
+constexpr int kPrefixOk = 0x600D0001, kPrefixViolated = 0x0BAD0002;   // verdict slot values
+
 template <int NW>
 __device__ __forceinline__ int rown_max_i32(int v) {
   int t;
@@ -252,11 +254,25 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 template <int NW, int PPT>
 __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs, int log2bs,
                                                            const float *__restrict__ dataset,
-                                                           int *__restrict__ idxs) {
+                                                           int *__restrict__ idxs,
+                                                           const int *__restrict__ verdict = nullptr,
+                                                           int nslots = 0) {
   constexpr int T = NW * 64;
   constexpr int kSkip = (int)0xBF800000u;  // bits of -1.0f
   __shared__ float lx[T * PPT], ly[T * PPT], lz[T * PPT];
   __shared__ int2 slots[2][NW];
+
+  // behind fps_prefix_check_kernel (below): when every slab of this scene confirmed that the
+  // sequence is 0, 1, 2, ... the answer is written here and the serial chain never starts
+  if (verdict) {
+    bool ok = true;
+    for (int g = threadIdx.x; g < nslots; g += T)
+      ok &= verdict[(size_t)blockIdx.x * nslots + g] == kPrefixOk;
+    if (__syncthreads_and(ok)) {   // (uniform)
+      for (int j = threadIdx.x; j < m; j += T) idxs[(size_t)blockIdx.x * m + j] = j;
+      return;
+    }
+  }
 
   // a dependent chain of short steps: when the scene shares its CU with streaming work from
   // another HIP stream (the backbone runs levels 2-4 beside SA1's grouped MLP), issue first
@@ -364,11 +380,203 @@ __global__ __launch_bounds__(NW * 64) void fps_regs_kernel(int n, int m, int bs,
   }
 }
 
+// ------------------------------------------------- FPS of an FPS-ordered cloud, verified in parallel
+// Levels 2-4 of a sampling pyramid run FPS over the points the previous level sampled, in the
+// order it sampled them.  FPS restarted on a prefix of its own output reproduces that prefix:
+// the answer is 0, 1, 2, ... unless an exact tie is broken differently at the smaller n (the
+// tie-break key depends on n and the block size) -- backbone_module.py:113-132 relies on it and
+// slices sa1_inds by it.  CHECKING the hypothesis s_j = j needs no serial chain.  Under it the
+// reference's running minimum before step j is
+//     T_j[k] = min(1e10, min_{i<j} d(p_i, p_k))            (sampling_gpu.cu:107-112)
+// and step j picks j iff no competing k beats j:  T_j[k] < R_j := T_j[j], or T_j[k] == R_j and
+// tk(j) <= tk(k) (the selection rule above).
+//   fps_prefix_bounds_kernel: R_j for every j (64 j per workgroup, its four waves split the
+//     i < j range and meet in LDS), stored with the samples as q[i] = (p_i, R_{i+1});
+//   fps_prefix_check_kernel: every point k against every step.  A workgroup owns 64 points, its
+//     C waves own C chunks of the steps; wave c first reduces its chunk to M_c[k] = min over
+//     the chunk's samples, the waves exchange those through LDS, and a second pass over the same
+//     chunk then has T_j[k] = min(M_0..M_{c-1}, running min inside the chunk) to compare with
+//     R_j -- twice the distance evaluations for C times the waves (n = 2048: 1 024 waves, one
+//     per SIMD of the chip; the work is VALU-bound, a wave64 op takes four cycles).  The sample of
+//     an iteration is wave-uniform and comes through the scalar cache (s_load), not LDS.
+// Each workgroup writes one verdict; fps_regs_kernel, launched right behind, writes 0..m-1 when
+// all of a scene's verdicts agree and runs the serial algorithm otherwise -- bit-exact by
+// construction either way, and the same sq3().  A skipped point (|p|^2 <= 1e-3, never a
+// candidate) among 1..m-1 refutes the hypothesis at once (bounds kernel's own verdict).
+constexpr int kPrefixMaxM = 2048;
+constexpr int kPrefixC = 4;          // step chunks = waves per check workgroup
+constexpr int kPrefixBig = 0x501502F9;   // bits of 1e10f: temp's initial value (sampling.cpp:78-80)
+
+// scratch: q[b][m] float4, then per scene one verdict slot per workgroup of the two kernels
+static inline int prefix_slots(int n, int m) { return (m + 63) / 64 + (n + 63) / 64; }
+
+__device__ __forceinline__ int prefix_d(float x, float y, float z, float ox, float oy, float oz) {
+  float dx = x - ox, dy = y - oy, dz = z - oz;
+  // (scalar differences: see fps_regs_kernel; plain `asm`, a volatile one would order the loads)
+  asm("" : "+v"(dx), "+v"(dy), "+v"(dz));
+  return __float_as_int(sq3(dx, dy, dz));
+}
+
+__global__ __launch_bounds__(256) void fps_prefix_bounds_kernel(
+    int n, int m, const float *__restrict__ dataset, float4 *__restrict__ q,
+    int *__restrict__ verdict, int nslots) {
+  __shared__ int part[4][64];
+  __shared__ int bad;
+  const int bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  dataset += (size_t)bi * n * 3;
+  q += (size_t)bi * m;
+  const int j = blockIdx.x * 64 + lane;
+  const int jend = min(m, blockIdx.x * 64 + 64);            // samples i < jend matter here
+  const int per = (jend + 3) >> 2;
+  const int i0 = wave * per, i1 = min(jend, i0 + per);
+  const int jc = min(j, m - 1);
+  const float x = dataset[jc * 3], y = dataset[jc * 3 + 1], z = dataset[jc * 3 + 2];
+  if (tid == 0) bad = 0;
+  int t = kPrefixBig;
+  {   // (uniform i: the samples come through the scalar cache, eight loads in flight)
+    float cur[24], nxt[24];
+    int i = i0;
+    if (i + 8 <= i1) {
+#pragma unroll
+      for (int u = 0; u < 24; ++u) cur[u] = dataset[i * 3 + u];
+    }
+    for (; i + 8 <= i1; i += 8) {
+      const bool more = i + 16 <= i1;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 24; ++u) nxt[u] = dataset[(i + 8) * 3 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int d = prefix_d(x, y, z, cur[3 * u], cur[3 * u + 1], cur[3 * u + 2]);
+        t = (i + u < j && d < t) ? d : t;
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 24; ++u) cur[u] = nxt[u];
+      }
+    }
+    for (; i < i1; ++i) {
+      const int d = prefix_d(x, y, z, dataset[i * 3], dataset[i * 3 + 1], dataset[i * 3 + 2]);
+      t = (i < j && d < t) ? d : t;
+    }
+  }
+  part[wave][lane] = t;
+  __syncthreads();
+  if (wave == 0 && j >= 1 && j < m) {
+    const int r = min(min(part[0][lane], part[1][lane]), min(part[2][lane], part[3][lane]));
+    q[j - 1] = make_float4(dataset[(j - 1) * 3], dataset[(j - 1) * 3 + 1],
+                           dataset[(j - 1) * 3 + 2], __int_as_float(r));
+    if ((double)sq3(x, y, z) <= 1e-3) bad = 1;   // step j could never pick j
+  }
+  __syncthreads();
+  // (every workgroup of either kernel owns one slot: no atomics, nothing to clear)
+  if (tid == 0) verdict[(size_t)bi * nslots + blockIdx.x] = bad ? kPrefixViolated : kPrefixOk;
+}
+
+__global__ __launch_bounds__(64 * kPrefixC) void fps_prefix_check_kernel(
+    int n, int m, int bs, int log2bs, const float *__restrict__ dataset,
+    const float4 *__restrict__ q, int *__restrict__ verdict, int nslots) {
+  __shared__ int chunk_min[kPrefixC][64];
+  __shared__ int bad;
+  const int bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  dataset += (size_t)bi * n * 3;
+  q += (size_t)bi * m;
+  const int cpb = (n + bs - 1) >> log2bs;
+  const int k = blockIdx.x * 64 + lane;
+  const int kc = min(k, n - 1);
+  const float x = dataset[kc * 3], y = dataset[kc * 3 + 1], z = dataset[kc * 3 + 2];
+  const bool competes = k < n && !((double)sq3(x, y, z) <= 1e-3);   // sampling_gpu.cu:105-106
+  // steps j = i + 1 for samples i in [0, m - 1); chunk of this wave
+  const int per = (m - 1 + kPrefixC - 1) / kPrefixC;
+  const int i0 = wave * per, i1 = min(m - 1, i0 + per);
+  if (tid == 0) bad = 0;
+  // (samples in batches of eight: that many scalar loads in flight, their latency is ~200 cycles)
+  int mc = kPrefixBig;
+  {
+    float4 cur[8], nxt[8];
+    int i = i0;
+    if (i + 8 <= i1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cur[u] = q[i + u];
+    }
+    for (; i + 8 <= i1; i += 8) {
+      const bool more = i + 16 <= i1;   // the next batch flies under this one's arithmetic
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nxt[u] = q[i + 8 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int d = prefix_d(x, y, z, cur[u].x, cur[u].y, cur[u].z);
+        mc = d < mc ? d : mc;
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+      }
+    }
+    for (; i < i1; ++i) {
+      const float4 o = q[i];
+      const int d = prefix_d(x, y, z, o.x, o.y, o.z);
+      mc = d < mc ? d : mc;
+    }
+  }
+  chunk_min[wave][lane] = mc;
+  __syncthreads();
+  int t = kPrefixBig;
+  for (int c = 0; c < wave; ++c) t = min(t, chunk_min[c][lane]);
+  bool viol = false, have_tk = false;
+  unsigned tkk = 0;
+  auto step = [&](const float4 o, int i) {
+    const int d = prefix_d(x, y, z, o.x, o.y, o.z);
+    t = d < t ? d : t;
+    const int rj = __float_as_int(o.w), j = i + 1;
+    if (t >= rj && k != j && competes) {   // rare: a duplicate, a tie, or the hypothesis is false
+      if (t > rj) {
+        viol = true;
+      } else {
+        if (!have_tk) { tkk = fps_tk(k, bs, log2bs, cpb); have_tk = true; }
+        viol |= tkk < fps_tk(j, bs, log2bs, cpb);
+      }
+    }
+  };
+  {
+    float4 cur[8], nxt[8];
+    int i = i0;
+    if (i + 8 <= i1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cur[u] = q[i + u];
+    }
+    for (; i + 8 <= i1; i += 8) {
+      const bool more = i + 16 <= i1;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nxt[u] = q[i + 8 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) step(cur[u], i + u);
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+      }
+    }
+    for (; i < i1; ++i) step(q[i], i);
+  }
+  if (viol) bad = 1;
+  __syncthreads();
+  if (tid == 0)
+    verdict[(size_t)bi * nslots + (m + 63) / 64 + blockIdx.x] = bad ? kPrefixViolated : kPrefixOk;
+}
+
 template <int NW, int PPT>
 static int launch_fps_regs(int b, int n, int m, int bs, int log2bs, const float *dataset,
-                           int *idxs, hipStream_t s) {
+                           int *idxs, hipStream_t s, const int *verdict = nullptr,
+                           int nslots = 0) {
   hipLaunchKernelGGL((fps_regs_kernel<NW, PPT>), dim3(b), dim3(NW * 64), 0, s, n, m, bs, log2bs,
-                     dataset, idxs);
+                     dataset, idxs, verdict, nslots);
   return check_launch("furthest_point_sampling");
 }
 
@@ -403,8 +611,15 @@ static int fps_regs_waves(int n) {
   return nw;
 }
 
+// BTR_FPS_PREFIX=0: the ordered entry point runs the plain kernels (A/B, tests)
+static bool fps_prefix_enabled() {
+  const char *e = getenv("BTR_FPS_PREFIX");
+  return !(e && e[0] == '0');
+}
+
 static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, int *idxs,
-                        int bs, void *ws, size_t ws_bytes, hipStream_t s) {
+                        int bs, void *ws, size_t ws_bytes, hipStream_t s,
+                        int *verdict = nullptr) {
   if (m <= 0 || b <= 0) return BTR_OK;  // sampling_gpu.cu:78
   BTR_REQUIRE(n > 0 && dataset && idxs,
               "furthest_point_sampling: null pointer or n=%d <= 0", n);
@@ -418,8 +633,22 @@ static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, 
   if (n <= kFpsRegsMaxN && !fps_regs_legacy()) {
     int nw = fps_regs_waves(n);
     const int per = (n + nw * 64 - 1) / (nw * 64);
-#define BTR_FPS_REGS(NW, PPT) \
-  if (nw == NW && per <= PPT) return launch_fps_regs<NW, PPT>(b, n, m, bs, log2bs, dataset, idxs, s)
+    // the caller expects an FPS-ordered cloud: check "the answer is 0..m-1" in parallel first
+    int nslots = 0;
+    if (verdict && m >= 2 && m <= kPrefixMaxM && m <= n && fps_prefix_enabled()) {
+      float4 *q = reinterpret_cast<float4 *>(verdict);   // scratch: q[b][m], then the slots
+      verdict = reinterpret_cast<int *>(q + (size_t)b * m);
+      nslots = prefix_slots(n, m);
+      hipLaunchKernelGGL(fps_prefix_bounds_kernel, dim3(cdiv(m, 64), b), dim3(256), 0, s, n, m,
+                         dataset, q, verdict, nslots);
+      hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(cdiv(n, 64), b), dim3(64 * kPrefixC), 0, s,
+                         n, m, bs, log2bs, dataset, q, verdict, nslots);
+    } else {
+      verdict = nullptr;
+    }
+#define BTR_FPS_REGS(NW, PPT)    \
+  if (nw == NW && per <= PPT)    \
+  return launch_fps_regs<NW, PPT>(b, n, m, bs, log2bs, dataset, idxs, s, verdict, nslots)
     BTR_FPS_REGS(1, 1); BTR_FPS_REGS(1, 2); BTR_FPS_REGS(1, 4); BTR_FPS_REGS(1, 8);
     BTR_FPS_REGS(1, 16);
     BTR_FPS_REGS(4, 1); BTR_FPS_REGS(4, 2); BTR_FPS_REGS(4, 4); BTR_FPS_REGS(4, 8);
@@ -499,6 +728,25 @@ int btr_furthest_point_sampling_bs(int b, int n, int m, const float *dataset, fl
 int btr_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
                                 int *idxs, btr_stream_t stream) {
   return fps_with_own_workspace(b, n, m, dataset, temp, idxs, 0, stream);
+}
+
+size_t btr_fps_ordered_scratch_bytes(int b, int n, int m) {
+  if (b <= 0 || n <= 0 || n > kFpsRegsMaxN || m < 2 || m > kPrefixMaxM || m > n) return 0;
+  return sizeof(float4) * (size_t)b * m + sizeof(int) * (size_t)b * prefix_slots(n, m);
+}
+
+int btr_furthest_point_sampling_ordered(int b, int n, int m, const float *dataset, float *temp,
+                                        int *idxs, int block_size, void *scratch,
+                                        size_t scratch_bytes, btr_stream_t stream) {
+  const int bs = block_size > 0 ? block_size : btr_opt_n_threads(n);
+  const size_t need = btr_fps_ordered_scratch_bytes(b, n, m);
+  if (need == 0 || fps_regs_legacy())   // not a shape the check covers: the plain call
+    return fps_with_own_workspace(b, n, m, dataset, temp, idxs, bs, stream);
+  BTR_REQUIRE(scratch && scratch_bytes >= need,
+              "furthest_point_sampling_ordered: %zu bytes of scratch required, got %zu", need,
+              scratch_bytes);
+  return fps_dispatch(b, n, m, dataset, temp, idxs, bs, nullptr, 0, as_stream(stream),
+                      reinterpret_cast<int *>(scratch));
 }
 
 int btr_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,

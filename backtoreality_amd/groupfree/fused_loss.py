@@ -47,6 +47,18 @@ def can_fuse(end_points, config, prefixes, kinds):
         return False
     if end_points['center_label'].shape[2] != 3:
         return False
+    # one centre base for all heads (the kernel takes a single base_xyz: every head of the
+    # reference detector predicts offsets from cluster_xyz, detector.py:176-219; a variant that
+    # refines the base per layer goes through the op-by-op composition), and the raw outputs
+    # must still be what the published entries are views of
+    base0 = end_points.get(prefixes[0] + 'base_xyz')
+    for p, h in zip(prefixes, heads):
+        if end_points.get(p + 'base_xyz') is not base0:
+            return False
+        tied = getattr(h, '_btr_head_views', None)
+        if tied is None or tied[0] != h._version or tied[1] is not base0 or \
+                any(end_points.get(p + k) is not v for k, v in tied[2].items()):
+            return False
     return all(k in end_points and end_points[k].is_cuda and end_points[k].dtype == dt
                for k, dt in _LABELS)
 

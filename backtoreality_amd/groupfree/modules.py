@@ -178,4 +178,13 @@ class PredictHead(nn.Module):
                            ('size_residuals', size_residuals), ('pred_size', pred_size),
                            ('sem_cls_scores', sem_cls_scores)):
             end_points[prefix + key] = value
+        # the fused per-head loss reads `_head_output`, not the entries above: it may only do so
+        # while they still ARE this output's views and nothing was written to them in place
+        # (views share the version counter of their base)
+        out_raw = end_points[prefix + '_head_output']
+        out_raw._btr_head_views = (out_raw._version, base_xyz, {
+            'objectness_scores': objectness_scores, 'heading_scores': heading_scores,
+            'heading_residuals_normalized': heading_residuals_normalized,
+            'size_scores': size_scores, 'size_residuals_normalized': size_residuals_normalized,
+            'sem_cls_scores': sem_cls_scores})
         return center, pred_size

@@ -39,6 +39,9 @@ _SIGNATURES = {
     "btr_furthest_point_sampling_bs": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp]),
     "btr_furthest_point_sampling_workspace_bytes": (_sz, [_ci, _ci, _ci]),
     "btr_furthest_point_sampling_ws": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _sz, _vp]),
+    "btr_fps_ordered_scratch_bytes": (_sz, [_ci, _ci, _ci]),
+    "btr_furthest_point_sampling_ordered": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _sz,
+                                                  _vp]),
     "btr_gather_points": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_gather_points_grad": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_ball_query": (_ci, [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp]),
@@ -123,8 +126,8 @@ _SIGNATURES = {
     "btr_gf_head_decode": (_ci, [_ci] * 4 + [_vp] + [ctypes.c_longlong] * 3 + [_vp] * 9),
     # multi-tensor Adam / AdamW (csrc/optimizer.hip, used by votenet/train.py)
     "btr_adam_chunk": (_ci, []),
-    "btr_adam_multi": (_ci, [_ci, _ci, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double,
-                             ctypes.c_double, _ci, _ci, _vp, _vp]),
+    "btr_adam_multi": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double,
+                             ctypes.c_double, _ci, _vp, _vp]),
     "btr_grad_sumsq_multi": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp]),
     "btr_grad_norm_final": (_ci, [_ci, _vp, ctypes.c_float, _vp, _vp]),
     # fused VoteNet loss (used by votenet/fused_loss.py)
@@ -280,11 +283,17 @@ class DecoderPlan(ctypes.Structure):
 
 class AdamItem(ctypes.Structure):
     """btr_adam_item_t"""
-    _fields_ = [("p", _vp), ("m", _vp), ("v", _vp), ("n", ctypes.c_longlong), ("lr", _cf),
-                ("wd", _cf), ("vec", _ci), ("pad_", _ci)]
+    _fields_ = [("p", _vp), ("m", _vp), ("v", _vp), ("step", _vp), ("n", ctypes.c_longlong),
+                ("group", _ci), ("vec", _ci)]
 
 
 ADAM_MAX_TENSORS = 448   # BTR_ADAM_MAX_TENSORS
+ADAM_MAX_GROUPS = 8      # BTR_ADAM_MAX_GROUPS
+
+
+class AdamGroups(ctypes.Structure):
+    """btr_adam_groups_t"""
+    _fields_ = [("lr", _cf * ADAM_MAX_GROUPS), ("wd", _cf * ADAM_MAX_GROUPS)]
 
 
 class AdamGrads(ctypes.Structure):
@@ -455,8 +464,28 @@ def furthest_point_sampling(points, nsamples):
     return _fps(points, nsamples, 0, out)
 
 
+def mark_fps_ordered(points):
+    """`points` (B, M, 3) are the points an FPS sampled, in sampling order (new_xyz of a
+    set-abstraction layer).  A later FPS of that tensor -- the next level of the pyramid --
+    then first checks in parallel whether its answer is 0, 1, 2, ... (csrc/sampling.hip
+    fps_prefix_check_kernel).  A hint about speed only: the indices are those of the plain call
+    whatever the tensor holds (tests/test_ops_gpu.py), and it lapses when the tensor is
+    written to."""
+    points._btr_fps_ordered = points._version
+    return points
+
+
 def _fps(points, nsamples, block_size, out):
     B, N, _ = points.shape
+    if getattr(points, "_btr_fps_ordered", None) == points._version:
+        need = _idx.btr_fps_ordered_scratch_bytes(B, N, nsamples)
+        if need:
+            scratch = torch.empty((need,), dtype=torch.uint8, device=points.device)
+            with _on(points) as dev:
+                _call(_idx.btr_furthest_point_sampling_ordered, B, N, nsamples, _p(points), None,
+                      _p(out), int(block_size), _p(scratch), need, _stream(dev),
+                      key=(B, N, nsamples))
+            return out
     ws_bytes = _idx.btr_furthest_point_sampling_workspace_bytes(B, N, nsamples)
     if ws_bytes:   # bucketed kernel: scratch from torch's stream-ordered caching allocator
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device)

@@ -65,7 +65,15 @@ class FurthestPointSampling(Function):
         return None, None
 
 
-furthest_point_sample = FurthestPointSampling.apply
+def furthest_point_sample(xyz, npoint):
+    """pointnet2_utils.py:80 (`furthest_point_sample = FurthestPointSampling.apply`).  The result
+    remembers which tensor it sampled: `gather_rows(xyz, inds)` then marks ITS result as
+    FPS-ordered, and an FPS of that result (the next pyramid level) checks "0, 1, 2, ..." in
+    parallel before it runs the serial kernel (_ext.mark_fps_ordered: a speed hint only)."""
+    inds = FurthestPointSampling.apply(xyz, npoint)
+    if xyz.is_cuda and hasattr(_ext, "mark_fps_ordered"):
+        inds._btr_fps_of = (xyz, xyz._version, inds._version)
+    return inds
 
 
 class GatherOperation(Function):
@@ -106,7 +114,12 @@ def gather_rows(src, idx):
     """(B,N,C)[idx (B,M)] -> (B,M,C).  Extensions without `gather_rows` (the CPU oracle
     adapter) take the reference's transpose + gather + transpose route."""
     if hasattr(_ext, "gather_rows") and src.is_cuda:
-        return GatherRows.apply(src, idx)
+        out = GatherRows.apply(src, idx)
+        tag = getattr(idx, "_btr_fps_of", None)
+        if tag is not None and tag[0] is src and tag[1] == src._version and \
+                tag[2] == idx._version and src.size(-1) == 3 and hasattr(_ext, "mark_fps_ordered"):
+            _ext.mark_fps_ordered(out)     # the points an FPS sampled, in sampling order
+        return out
     return gather_operation(src.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
 
 

@@ -216,14 +216,19 @@ class _FastStep(object):
     # ---- the update of ALL groups as one launch of the library (csrc/optimizer.hip)
     def _library_step(self, work, clip_norm):
         """(total norm | None,) when btr_adam_multi did the update, None when it cannot: CUDA f32
-        contiguous parameters / gradients on one device, equal betas / eps in all groups, not
-        while a HIP graph is captured (`BTR_ADAM_KERNEL=0`: torch's fused kernels).  With
-        `clip_norm` the total gradient norm comes from two more launches over the same table
-        (btr_grad_sumsq_multi / btr_grad_norm_final) and its clip factor is the update's
-        grad_scale operand.  The per-tensor table (parameter, moments,
-        size, the group's lr / weight decay) and the chunk map live on the device and are rebuilt
-        when the parameter set or a learning rate changes; the gradient pointers ride in the
-        kernel arguments (448 tensors per launch)."""
+        contiguous parameters / gradients on one device, equal betas / eps in all groups, at most
+        ADAM_MAX_GROUPS groups, not while a HIP graph is captured (`BTR_ADAM_KERNEL=0`: torch's
+        fused kernels).  With `clip_norm` the total gradient norm comes from two more launches
+        over the same table (btr_grad_sumsq_multi / btr_grad_norm_final) and its clip factor is
+        the update's grad_scale operand.  The per-tensor table (parameter, moments, the tensor's
+        own DEVICE step counter, size, group index) and the chunk map live on the device and are
+        rebuilt only when the parameter set changes; the gradient pointers and the groups'
+        learning rates / weight decays ride in the kernel arguments, so a scheduler that moves
+        lr every iteration (train_GF_FSB.py:322) never touches the table.  Nothing here reads
+        the device: the bias corrections come from the step tensors torch keeps in the state
+        (incremented below exactly like the stock step does), so steps that other kernels took
+        in between -- a HIP-graph replay, a fallback, BTR_ADAM_KERNEL toggled -- and parameters
+        whose counts differ are all handled (tests/test_optimizer_gpu.py)."""
         import ctypes
         import numpy as np
         from ..pointnet2 import _ext
@@ -231,28 +236,31 @@ class _FastStep(object):
             return None
         g0 = work[0][0]
         first = work[0][1][0][0]
-        if not first.is_cuda or torch.cuda.is_current_stream_capturing():
+        if not first.is_cuda or torch.cuda.is_current_stream_capturing() or \
+                len(work) > _ext.ADAM_MAX_GROUPS:
             return None
         dev = first.device
-        key = tuple((id(cache[0]), float(group['lr']), float(group['weight_decay']),
-                     group['betas'], group['eps']) for group, cache, _ in work)
+        key = tuple((id(cache[0]), group['betas'], group['eps']) for group, cache, _ in work)
         st = getattr(self, '_btr_lib', None)
         if st is None or st['key'] != key:
-            for group, (params, exp_avgs, exp_avg_sqs, _), _ in work:   # checked once per table
+            for group, (params, exp_avgs, exp_avg_sqs, stp), _ in work:   # checked once per table
                 if group['betas'] != g0['betas'] or group['eps'] != g0['eps']:
                     return None
                 for t in list(params) + list(exp_avgs) + list(exp_avg_sqs):
                     if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
                         return None
+                for t in stp:      # fused / capturable state: an f32 scalar on the device
+                    if t.device != dev or t.dtype != torch.float32 or t.numel() != 1:
+                        return None
             n_t = sum(len(cache[0]) for _, cache, _ in work)
             items = (_ext.AdamItem * n_t)()
             chunk = _ext._lib.btr_adam_chunk()
             cmap, steps, i = [], [], 0
-            for group, (params, exp_avgs, exp_avg_sqs, stp), _ in work:
-                for p, m, v in zip(params, exp_avgs, exp_avg_sqs):
+            for gi, (group, (params, exp_avgs, exp_avg_sqs, stp), _) in enumerate(work):
+                for p, m, v, t in zip(params, exp_avgs, exp_avg_sqs, stp):
                     it = items[i]
                     it.p, it.m, it.v, it.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
-                    it.lr, it.wd = float(group['lr']), float(group['weight_decay'])
+                    it.step, it.group = t.data_ptr(), gi
                     # (the gradient's alignment is checked per step: see below)
                     it.vec = int(p.numel() % 4 == 0 and all(
                         t.data_ptr() % 16 == 0 for t in (p, m, v)))
@@ -271,25 +279,25 @@ class _FastStep(object):
                 c0 = c1
             st = self._btr_lib = {
                 'key': key, 'n': n_t, 'steps': steps, 'blocks': blocks,
+                'groups': _ext.AdamGroups(),
                 'items': torch.from_numpy(raw).to(dev),
                 'cmap': torch.tensor(cmap, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev),
                 'vec': [bool(items[j].vec) for j in range(n_t)],
-                'partial': torch.empty((max(len(cmap), 1),), dtype=torch.float32, device=dev),
-                'count': int(round(float(steps[0].item()))) if steps else 0}
+                'partial': torch.empty((max(len(cmap), 1),), dtype=torch.float32, device=dev)}
         ptrs = []
         for _, _, grads in work:
             for g in grads:
                 if g.dtype != torch.float32 or not g.is_contiguous() or g.device != dev:
-                    st['count'] += 1       # torch's kernels take this step (and count it)
-                    return None
+                    return None        # torch's kernels take this step
                 ptrs.append(g.data_ptr())
         if any(v and (q & 15) for v, q in zip(st['vec'], ptrs)):
-            st['count'] += 1           # a gradient the 16-byte loads cannot take
-            return None
-        torch._foreach_add_(st['steps'], 1)     # the state's step tensors stay what torch keeps
-        st['count'] += 1
-        beta1, beta2 = g0['betas']
+            return None                # a gradient the 16-byte loads cannot take
+        torch._foreach_add_(st['steps'], 1)     # the state's step tensors: what torch keeps, and
+        beta1, beta2 = g0['betas']              # what the kernel reads its bias corrections from
         cmap_ptr = st['cmap'].data_ptr()
+        gr = st['groups']
+        for gi, (group, _, _) in enumerate(work):
+            gr.lr[gi], gr.wd[gi] = float(group['lr']), float(group['weight_decay'])
         norm = None
         with _ext._on(first) as dv:
             stream = _ext._stream(dv)
@@ -306,8 +314,9 @@ class _FastStep(object):
             scale = norm.data_ptr() + 4 if norm is not None else None
             for t0, t1, c0, nchunks, gp in st['blocks']:
                 _ext._call(_ext._lib.btr_adam_multi, nchunks, t0, _ext._p(st['items']),
-                           ctypes.addressof(gp), cmap_ptr + 8 * c0, float(beta1), float(beta2),
-                           float(g0['eps']), st['count'], int(self._decoupled), scale, stream)
+                           ctypes.addressof(gp), ctypes.addressof(gr), cmap_ptr + 8 * c0,
+                           float(beta1), float(beta2), float(g0['eps']), int(self._decoupled),
+                           scale, stream)
         return (norm[0] if norm is not None else None,)
 
     def _stock_step(self, closure, clip_norm):

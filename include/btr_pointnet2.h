@@ -88,6 +88,20 @@ int btr_furthest_point_sampling_ws(int b, int n, int m, const float *dataset, fl
                                    int *idxs, int block_size, void *workspace,
                                    size_t workspace_bytes, btr_stream_t stream);
 
+/* Same result again, for a cloud the caller EXPECTS to be FPS-ordered -- levels 2-4 of a
+ * sampling pyramid sample the points of the previous level in the order it chose them
+ * (models/backbone_module.py:113-132 slices sa1_inds on exactly that assumption).  The answer is
+ * then 0, 1, ..., m-1 unless a tie resolves differently at the smaller n; that hypothesis is
+ * CHECKED in parallel (n * m independent distance tests, csrc/sampling.hip
+ * fps_prefix_check_kernel) and the serial kernel only runs for scenes where it fails.  The
+ * expectation is a performance hint, never a semantic input: any cloud gives the indices of
+ * btr_furthest_point_sampling.  `scratch`: btr_fps_ordered_scratch_bytes() bytes (0 = shape not
+ * covered: n > 4096, m > 2048 or m > n; the call then is btr_furthest_point_sampling_bs). */
+size_t btr_fps_ordered_scratch_bytes(int b, int n, int m);
+int btr_furthest_point_sampling_ordered(int b, int n, int m, const float *dataset, float *temp,
+                                        int *idxs, int block_size, void *scratch,
+                                        size_t scratch_bytes, btr_stream_t stream);
+
 /* Measurement only (bench.py): the next large-scene btr_furthest_point_sampling* call of this
  * host thread records the two hipEvent_t around its sampling kernel alone (the spatial-sort
  * launches in front of it stay outside), on the call's stream.  NULL, NULL cancels. */
@@ -370,7 +384,16 @@ int btr_box3d_iou(int nscene, int p, int g, const double *corners1, const double
  * preceding btr_furthest_point_sampling_ws call ON THE SAME xyz (n > 4096) was given; it still
  * holds the cloud sorted along a Hilbert curve in 64-point buckets, which this call searches
  * instead of counting-sorting the cloud again (csrc/ball_query_bucket.hip).  The workspace
- * size is 0 when the shape is not supported (use btr_ball_query_ws then). */
+ * size is 0 when the shape is not supported (use btr_ball_query_ws then).
+ * CONTRACT: the WHOLE fps_workspace must stay untouched between the two calls, on the same host
+ * thread: besides the sorted points the FPS kernel leaves its per-bucket bounding boxes in the
+ * part of the workspace its counting sort no longer needs, and this call uses them when the
+ * calling thread's last FPS launch on that address had the same (b, n).  Each box carries the
+ * launch's epoch and its own position; every query workgroup checks all stamps of its scene and,
+ * on any mismatch (area overwritten / partially restored / filled by another launch), bounds
+ * the buckets from the sorted points instead -- slower, same result.  The sorted POINTS carry no
+ * such check: handing this call a workspace whose point area is not the FPS's sort of `xyz`
+ * gives wrong neighbour lists, exactly like handing btr_ball_query the wrong xyz. */
 size_t btr_ball_query_buckets_workspace_bytes(int b, int n, int m, int nsample);
 int btr_ball_query_buckets(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                            const void *fps_workspace, int *idx, void *workspace,
@@ -727,29 +750,39 @@ int btr_gf_head_decode(int b, int p, int nh, int ns, const float *out, long long
 /* ---- Adam / AdamW over many tensors in one launch (csrc/optimizer.hip) -----------------------
  * reference: optimizer.step() of train_Votenet_FSB.py:231 (Adam) and train_GF_FSB.py:319 (AdamW,
  * two parameter groups); update rule of torch's fused implementation (header of the source).
- * items (device): per tensor its parameter, both moments, element count, learning rate and weight
- * decay of its group, vec = 1 when all four pointers are 16-byte aligned and n % 4 == 0;
+ * items (device): per tensor its parameter, both moments, element count, `step` = the DEVICE f32
+ * scalar holding this tensor's 1-based step count (already incremented for this update: what
+ * torch keeps in optimizer.state[p]['step']; the bias corrections 1 - beta^step are evaluated
+ * from it on the device, in double like torch's kernel, so tensors whose counts differ -- a
+ * parameter without a gradient on earlier steps -- and steps taken by other kernels in between are
+ * handled), `group` = index into `groups`, vec = 1 when all four pointers are 16-byte aligned and
+ * n % 4 == 0;
  * grads (HOST struct, copied into the kernel arguments): the gradient pointers of tensors
- * tensor0 .. tensor0 + BTR_ADAM_MAX_TENSORS - 1; chunk_map (device, already offset to the first
+ * tensor0 .. tensor0 + BTR_ADAM_MAX_TENSORS - 1; groups (HOST struct, kernel arguments): learning
+ * rate and weight decay of each parameter group AT THIS STEP (a per-iteration scheduler does not
+ * touch the device table); chunk_map (device, already offset to the first
  * chunk of tensor0): per workgroup (tensor index, first element), chunks of btr_adam_chunk()
- * elements; step: the 1-based step count (1 - beta and the bias corrections are evaluated in double
- * on the host, like torch's kernel does);
+ * elements; 1 - beta is formed in double on the host like torch's kernel does;
  * grad_scale: NULL or a device scalar every gradient is divided by (folded gradient clipping). */
 typedef struct {
   float *p, *m, *v;
+  const float *step;
   long long n;
-  float lr, wd;
-  int vec, pad_;
+  int group, vec;
 } btr_adam_item_t;
 #define BTR_ADAM_MAX_TENSORS 448
+#define BTR_ADAM_MAX_GROUPS 8
 typedef struct {
   const float *g[BTR_ADAM_MAX_TENSORS];
 } btr_adam_grads_t;
+typedef struct {
+  float lr[BTR_ADAM_MAX_GROUPS], wd[BTR_ADAM_MAX_GROUPS];
+} btr_adam_groups_t;
 int btr_adam_chunk(void);
 int btr_adam_multi(int chunks, int tensor0, const btr_adam_item_t *items,
-                   const btr_adam_grads_t *grads, const int *chunk_map, double beta1,
-                   double beta2, double eps, int step, int decoupled, const float *grad_scale,
-                   btr_stream_t stream);
+                   const btr_adam_grads_t *grads, const btr_adam_groups_t *groups,
+                   const int *chunk_map, double beta1, double beta2, double eps, int decoupled,
+                   const float *grad_scale, btr_stream_t stream);
 /* torch.nn.utils.clip_grad_norm_(parameters, clip) (train_GF_FSB.py:316-318) over the same table,
  * folded into the step: btr_grad_sumsq_multi writes one sum of squares per chunk of the chunk map
  * (partial, already offset like chunk_map); btr_grad_norm_final adds all `chunks` of them in a

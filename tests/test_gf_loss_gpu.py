@@ -77,3 +77,23 @@ def test_the_other_loss_forms_stay_on_the_torch_composition():
     assert not fused_loss.can_fuse(end, cfg, prefixes, ('l1', 'smoothl1', 'smoothl1'))
     del end['last_' + fused_loss.HEAD_KEY]
     assert not fused_loss.can_fuse(end, cfg, prefixes, ('smoothl1',) * 3)
+
+
+def test_fused_loss_is_refused_once_the_published_entries_stop_being_its_inputs():
+    """Advisor finding (round 3): the kernel reads `_head_output` and ONE base_xyz.  A head with
+    its own centre base, an in-place edit of a published entry, or a replaced entry must send the
+    loss through the op-by-op composition (which reads the entries themselves)."""
+    dev = torch.device("cuda:0")
+    kinds = ('smoothl1',) * 3
+    prefixes = loss_helper.head_prefixes(1)
+    cfg, end, _ = _end_points(dev, 2, 64, 1, seed=1)
+    assert fused_loss.can_fuse(end, cfg, prefixes, kinds)
+    end2 = dict(end)
+    end2['last_base_xyz'] = end['last_base_xyz'].clone()      # a refined base for one head
+    assert not fused_loss.can_fuse(end2, cfg, prefixes, kinds)
+    end3 = dict(end)
+    end3['last_sem_cls_scores'] = end['last_sem_cls_scores'] * 2     # replaced entry
+    assert not fused_loss.can_fuse(end3, cfg, prefixes, kinds)
+    with torch.no_grad():
+        end['proposal_objectness_scores'].add_(1.0)                  # in-place edit of a view
+    assert not fused_loss.can_fuse(end, cfg, prefixes, kinds)

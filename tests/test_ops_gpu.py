@@ -162,6 +162,89 @@ def test_fps_prefix_invariant(cuda):
     np.testing.assert_array_equal(again, np.tile(np.arange(1024, dtype=np.int32), (2, 1)))
 
 
+# ---- FPS of a cloud the caller EXPECTS to be FPS-ordered (btr_furthest_point_sampling_ordered):
+# the hint selects a parallel check of "the answer is 0..m-1" with the serial kernel behind it;
+# it must never change an index, whatever the cloud really is.
+def _ordered(x, m, bs=None):
+    e = _ext()
+    e.mark_fps_ordered(x)
+    return e.furthest_point_sampling(x, m) if bs is None else e.furthest_point_sampling_bs(x, m, bs)
+
+
+@pytest.mark.parametrize("N1,M1,M2", [(40000, 2048, 1024), (9000, 1024, 512), (5000, 512, 256),
+                                       (20000, 4096, 2048), (6000, 700, 333), (3000, 100, 100)])
+def test_fps_ordered_on_a_true_prefix(cuda, monkeypatch, N1, M1, M2):
+    """A real pyramid level: the hypothesis holds, the answer is the identity and it is the
+    oracle's answer; the serial kernel (BTR_FPS_PREFIX=0) agrees."""
+    xyz = _scene_xyz(3, N1, first=40)
+    x = _t(xyz, cuda)
+    inds = _ext().furthest_point_sampling(x, M1)
+    sub = torch.gather(x, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    ref = oracle.furthest_point_sampling(sub.cpu().numpy(), M2)
+    got = _ordered(sub, M2).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    if (N1, M1) != (20000, 4096):
+        # (4096 -> 2048 of this cloud: the oracle itself leaves the identity at two positions --
+        # an exact tie that the keys of n = 4096 order differently than those of n = 20000 did;
+        # the check notices and the serial kernel answers for that scene)
+        np.testing.assert_array_equal(got, np.tile(np.arange(M2, dtype=np.int32), (3, 1)))
+    monkeypatch.setenv("BTR_FPS_PREFIX", "0")
+    np.testing.assert_array_equal(_ordered(sub, M2).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 2048, 1024), (3, 1000, 400), (2, 4096, 2048), (1, 300, 300),
+                                   (2, 64, 2), (2, 257, 100)])
+def test_fps_ordered_hint_on_an_unordered_cloud(cuda, B, N, M):
+    """The hypothesis is false from the first steps on: the fallback answers, bit-exact."""
+    xyz = _scene_xyz(B, N, first=7)
+    ref = oracle.furthest_point_sampling(xyz, M)
+    assert not np.array_equal(ref[0], np.arange(M))
+    np.testing.assert_array_equal(_ordered(_t(xyz, cuda), M).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("bs", [1, 16, 256, 512])
+def test_fps_ordered_when_ties_break_the_identity(cuda, bs):
+    """Duplicated points: the first level picks every distinct point, then duplicates under ITS
+    tie-break (n = 1200).  On the 1024-point prefix the ties resolve by the keys of n = 1024, the
+    sequence is no longer 0, 1, 2, ... and the check must notice -- in scene 0 only; scene 1 is
+    an ordinary pyramid level whose identity holds, so one launch answers both ways."""
+    rng = np.random.default_rng(31)
+    base = rng.uniform(0.3, 3.0, size=(1, 600, 3)).astype(np.float32)
+    dup = np.concatenate([base, base], 1)                        # every point twice
+    plain = _scene_xyz(1, 1200, first=3)
+    lvl1 = oracle.furthest_point_sampling(np.concatenate([dup, plain], 0), 1024, block_size=bs)
+    both = np.concatenate([dup, plain], 0)
+    sub = np.take_along_axis(both, lvl1[:, :, None].astype(np.int64), 1)
+    ref = oracle.furthest_point_sampling(sub, 800, block_size=bs)
+    assert not np.array_equal(ref[0], np.arange(800)), "the crafted ties do not break the identity"
+    assert np.array_equal(ref[1], np.arange(800))
+    got = _ordered(_t(sub, cuda), 800, bs).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_fps_ordered_skip_rule_and_exact_tie_with_an_earlier_point(cuda):
+    """(a) a sample inside the skipped ball around the origin among 1..m-1 refutes the hypothesis
+    at once; (b) point j duplicating an earlier sample (R_j = 0) is decided by the tie-break
+    keys; (c) a later point exactly as far as point j (T_j[k] == R_j, k > j)."""
+    xyz = _scene_xyz(2, 6000, first=11)
+    x = _t(xyz, cuda)
+    inds = _ext().furthest_point_sampling(x, 512)
+    sub = torch.gather(x, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    a = sub.clone(); a[0, 37] = torch.tensor([0.01, 0.0, 0.01], device=cuda)
+    b = sub.clone(); b[1, 200] = b[1, 13]
+    c = sub.clone(); c[0, 400] = c[0, 90]; c[1, 511] = c[1, 255]
+    for t in (a, b, c):
+        ref = oracle.furthest_point_sampling(t.cpu().numpy(), 256)
+        np.testing.assert_array_equal(_ordered(t, 256).cpu().numpy(), ref)
+    # mirror pair: two points at exactly the same distance from everything sampled before
+    m = np.zeros((1, 64, 3), np.float32)
+    m[0, :, 0] = np.linspace(1.0, 3.0, 64)
+    m[0, 1] = [5.0, 0.0, 0.0]
+    m[0, 2] = [3.0, 2.0, 0.0]; m[0, 3] = [3.0, -2.0, 0.0]      # equidistant from points 0 and 1
+    ref = oracle.furthest_point_sampling(m, 32)
+    np.testing.assert_array_equal(_ordered(_t(m, cuda), 32).cpu().numpy(), ref)
+
+
 # ---------------------------------------------------------------------------- ball query
 @pytest.mark.parametrize("B,N,M,r,S", [(2, 4096, 512, 0.2, 64), (2, 2048, 1024, 0.4, 32),
                                        (2, 1024, 512, 0.8, 16), (3, 512, 256, 1.2, 16),
@@ -219,6 +302,51 @@ def test_ball_query_over_the_fps_buckets(cuda, monkeypatch, kind, B, N, M, r, S,
     assert _ext().BQ_CALLS["buckets"] == before["buckets"] + 1, "the bucket path was not taken"
     monkeypatch.setenv("BTR_BQ_BUCKETS", "0")
     np.testing.assert_array_equal(_ext().ball_query(new, x, r, S).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("damage", ["zeroed", "one_box", "scenes_swapped", "other_launch"])
+def test_ball_query_over_the_fps_buckets_checks_the_box_stamps(cuda, damage):
+    """The FPS kernel leaves its bucket boxes in the dead counting-sort area of its workspace
+    (include/btr_pointnet2.h, btr_ball_query_buckets CONTRACT).  The query does not assume that
+    area survived: every box carries the FPS launch's epoch and its position, and a workgroup
+    that finds a wrong stamp bounds the buckets from the sorted points instead.  Damage the area
+    in four ways between the two calls -- the neighbour lists stay the oracle's."""
+    B, N, M, r, S = 3, 20000, 512, 0.25, 32
+    xyz = _scene_xyz(B, N, first=60, kind="surface")
+    x = _t(xyz, cuda)
+    inds = _ext().furthest_point_sampling(x, M)
+    ws = x._btr_fps_ws[0]
+    np_ = (N + 63) // 64 * 64
+    nb = np_ // 64
+    boxes = ws[20 * B * np_: 20 * B * np_ + 32 * B * nb].view(torch.float32).view(B, nb, 8)
+    stamp = boxes[:, :, 3].clone().view(torch.int32)
+    assert int(stamp.min()) == int(stamp.max()) != 0, "the FPS kernel stamps every box"
+    if damage == "zeroed":
+        boxes.zero_()
+    elif damage == "one_box":      # one box of scene 1 replaced by a tiny far-away box
+        boxes[1, nb // 2] = torch.tensor([9., 9., 9., 0., 9.1, 9.1, 9.1, 0.], device=cuda)
+    elif damage == "scenes_swapped":   # right epoch, wrong place
+        tmp = boxes[0].clone()
+        boxes[0] = boxes[2]
+        boxes[2] = tmp
+    else:     # the whole workspace restored from ANOTHER launch's (another cloud's) workspace:
+        # sorted points and boxes agree with each other, but not with the launch this thread
+        # noted for the address -- the stamps say so and the query bounds the buckets itself
+        x2 = _t(_scene_xyz(B, N, first=70, kind="surface"), cuda)
+        _ext().furthest_point_sampling(x2, M)
+        ws2 = x2._btr_fps_ws[0]
+        assert ws2.data_ptr() != ws.data_ptr()
+        assert int(ws2[20 * B * np_ + 12: 20 * B * np_ + 16].view(torch.int32)) != int(stamp[0, 0])
+        ws.copy_(ws2)
+        xyz = x2.cpu().numpy()
+        x.copy_(x2)                # (bumps x._version: re-attach the workspace by hand)
+        x._btr_fps_ws = (ws, x._version) + tuple(x._btr_fps_ws[2:])
+    new = torch.gather(x, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    ref = oracle.ball_query(new.cpu().numpy(), xyz, r, S)
+    before = dict(_ext().BQ_CALLS)
+    got = _ext().ball_query(new, x, r, S).cpu().numpy()
+    assert _ext().BQ_CALLS["buckets"] == before["buckets"] + 1, "the bucket path was not taken"
+    np.testing.assert_array_equal(got, ref)
 
 
 def test_ball_query_over_the_fps_buckets_with_its_own_box_pass():
