@@ -48,8 +48,11 @@ def parse():
                         "pyramid first) instead of the software-pipelined one")
     p.add_argument("--no-sequential", dest="no_sequential", action="store_true",
                    help="skip the secondary (informational) sequential loop")
-    p.add_argument("--workload", choices=["fsb", "br", "cr", "gf", "gfbr"], default="fsb",
-                   help="fsb: VoteNet FSB step (BASELINE configs[1], the headline); br: the "
+    p.add_argument("--workload", choices=["fsb", "c5", "br", "cr", "gf", "gfbr"], default="fsb",
+                   help="fsb: VoteNet FSB step (BASELINE configs[1], the headline); c5: the same "
+                        "step on BASELINE configs[4] -- Matterport3D-md40 heads (13 classes, 12 "
+                        "heading bins, model_util_matterport.py:16-30), 80 000-point scenes of "
+                        "12 x 12 x 3 m, batch 4 per GPU: the ball-query stress shape; br: the "
                         "two-branch Back-to-Reality step (configs[2]), 2 x batch scenes per step; "
                         "cr: br + the CenterRefine centre head / jitter regressor; gf: "
                         "GroupFree3D (configs[3] shape: 50 000 points without the height "
@@ -70,10 +73,13 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(cfg, points):
+def cpu_baseline(cfg, points, extent=1.0):
     """The same training step over the CPU oracle (kind "port": the reference has no CPU path
-    for the nine ops).  Bounded sample: ONE 40k-point scene, per probed thread count one untimed
-    and three timed steps (about 15-25 s of CPU work in total)."""
+    for the nine ops).  Bounded samples (B = 1 - 8): ONE scene -- per probed thread
+    count one untimed and three timed steps -- and, at the fastest thread count, a batch of
+    EIGHT scenes (one untimed, two timed steps; the C oracle's OpenMP loops run over batch x
+    centres, so the batch is what gives the host cores their parallelism).  About 25-40 s of CPU
+    work in total; `value` is the better of the two rates, both are reported."""
     import oracle
     from backtoreality_amd.pointnet2 import pointnet2_utils
     from backtoreality_amd.votenet import synthetic, train
@@ -87,7 +93,7 @@ def cpu_baseline(cfg, points):
     try:
         net = train.build_model(cfg, torch.device("cpu"))
         opt = train.make_optimizer(net)
-        batch = synthetic.make_batch(0, 1, points, cfg)
+        batch = synthetic.make_batch(0, 1, points, cfg, extent_scale=extent)
         # torch's CPU kernels do not scale to hundreds of threads on these small layers
         # (256 threads: 87 s/step on the GPU box), so probe a few thread counts and keep the
         # fastest; `cores` reports the count actually used.
@@ -104,14 +110,28 @@ def cpu_baseline(cfg, points):
             if time.time() - t_begin > 60:
                 break
         dt, cores = best
+        # the B = 8 sample at the fastest thread count (bounded: skipped when the B = 1 probes
+        # already took a minute)
+        b8 = None
+        if time.time() - t_begin < 60:
+            torch.set_num_threads(cores)
+            batch8 = synthetic.make_batch(0, 8, points, cfg, extent_scale=extent)
+            train.train_step(net, opt, batch8, cfg)
+            t0 = time.time()
+            for _ in range(2):
+                train.train_step(net, opt, batch8, cfg)
+            b8 = 8.0 / ((time.time() - t0) / 2)
     finally:
         pointnet2_utils._ext = saved
         torch.set_num_threads(saved_threads)
-    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": "VoteNet FSB step (fwd+loss+bwd+Adam), batch 1 x %d points, mean of %d "
-                      "timed steps after 1 warm-up at the fastest of {8,16,32,64} torch threads, C "
-                      "oracle kernels (OpenMP) + torch CPU conv/BN; host has %d logical CPUs"
-                      % (points, steps, ncpu)}
+    res = {"value": max(1.0 / dt, b8 or 0.0), "unit": "scenes/s", "cores": cores, "kind": "port",
+           "batch1_scenes_per_s": 1.0 / dt, "batch8_scenes_per_s": b8,
+           "sample": "VoteNet FSB step (fwd+loss+bwd+Adam) on %d-point scenes: batch 1, mean of %d "
+                     "timed steps after 1 warm-up at the fastest of {8,16,32,64} torch threads; "
+                     "batch 8, mean of 2 timed steps after 1 warm-up at that thread count; C "
+                     "oracle kernels (OpenMP) + torch CPU conv/BN; host has %d logical CPUs; "
+                     "value = the better of the two rates" % (points, steps, ncpu)}
+    return res
 
 
 def self_launch(args):
@@ -175,7 +195,13 @@ def main():
     autotune = not args.no_conv_autotune and args.workload != "fsb"
     if autotune:   # before the first convolution runs (train.enable_conv_autotune)
         train.enable_conv_autotune()
-    cfg = config.scannet_md40()
+    c5 = args.workload == "c5"
+    if c5 and args.points == 40000 and args.batch == 8:      # configs[4]: 4 x 80 000 points
+        args.points, args.batch = 80000, 4
+    if c5 and args.cpu_points == 40000:
+        args.cpu_points = args.points
+    cfg = config.matterport_md40() if c5 else config.scannet_md40()
+    extent = 1.7 if c5 else 1.0     # surface-room scaled to 12 x 12 x 3 m
     br = args.workload in ("br", "cr")
     cr = args.workload == "cr"
     gf = args.workload in ("gf", "gfbr")
@@ -200,7 +226,8 @@ def main():
     ddp = train.wrap_ddp(net, dev)
     B = args.batch
     jit = 0.1 if cr else 0.0
-    batch = synthetic.make_batch(rank * B, B, args.points, cfg, device=dev,
+    RUN_SHAPE.update(workload=args.workload, points=args.points, batch=B)
+    batch = synthetic.make_batch(rank * B, B, args.points, cfg, device=dev, extent_scale=extent,
                                  center_jitter=jit, use_height=not gf)  # resident in HBM
     eager_step = None
     if gfbr:
@@ -243,7 +270,8 @@ def main():
     batches = [batch]
     if not gfbr:
         batches.append(synthetic.make_batch(500000 + rank * B, B, args.points, cfg, device=dev,
-                                            center_jitter=jit, use_height=not gf))
+                                            extent_scale=extent, center_jitter=jit,
+                                            use_height=not gf))
     pipelined_loop = not gfbr and not args.sequential
     pipe_step = gf_train.train_step if gf else train.train_step
 
@@ -321,12 +349,19 @@ def main():
     from backtoreality_amd.pointnet2 import fused_mlp as _fm
     for k in _fm.PATHS:
         _fm.PATHS[k] = 0
+    # the step clock: wall time between the barriers (what `value` is), and beside it a hipEvent
+    # pair on the stream the steps are issued on (it closes after the joins of the
+    # side streams, so both clocks see the same work)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     run_steps(args.steps)
+    ev1.record()
     enqueue = time.perf_counter() - t0   # host side done (launches queued), GPU still running
     chain_paths = dict(_fm.PATHS)        # point-wise chains of the timed steps, by path taken
     barrier()
     elapsed = time.perf_counter() - t0
+    gpu_elapsed_ms = ev0.elapsed_time(ev1)
     kernels = _ext.timing_end()
     # Outside the timed region: 3 fully instrumented steps (an event pair around every
     # hand-written launch) for the per-kernel table and the grouped-MLP MFMA figure.
@@ -374,6 +409,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            # the same K steps between a hipEvent pair on the issuing stream (rank 0)
+            "gpu_ms_per_step": gpu_elapsed_ms / args.steps,
+            "clock": "value / ms_per_step: time.perf_counter between barrier + synchronize pairs, "
+                     "max over ranks; gpu_ms_per_step: hipEvent pair around the same loop",
             # how long the host needed to queue the K steps (== ms_per_step: host-bound)
             "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
             "higher_is_better": True,
@@ -393,6 +432,9 @@ def main():
                                     "GroupFree3D FSB train step (backbone fp2->288, KPS, 6 decoder "
                                     "layers, fwd+loss+bwd+clip+AdamW), %d scenes of %d points "
                                     "(xyz only) per GPU" if gf else
+                                    "VoteNet FSB train step (fwd+loss+bwd+Adam), %d points, "
+                                    "batch %d per GPU, matterport-md40 heads (13 classes, 12 "
+                                    "heading bins), 12 x 12 x 3 m scenes" if c5 else
                                     "VoteNet FSB train step (fwd+loss+bwd+Adam), %d points, "
                                     "batch %d per GPU, scannet-md40 heads") %
                                    ((B, args.points) if (br or gf) else (args.points, B)),
@@ -436,7 +478,7 @@ def main():
                 "note": "rank-0 clock; the same K steps without the cross-step overlap (every "
                         "step waits for its own FPS first); informational"}
         if world == 1 and not args.no_cpu_baseline and not gf:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_points)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_points, extent)
         line = json.dumps(out)
     else:
         line = None
@@ -455,24 +497,30 @@ def main():
         print(line, flush=True)
 
 
-def pmc_traffic(substr):
-    """HBM bytes per launch of the kernel whose name contains `substr`, from the committed
-    rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py from
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH_SIZE doubled per
-    the gfx950 correction in MI355X_MICROARCH.md).  None when no profile is committed."""
+RUN_SHAPE = {"workload": "fsb", "points": 40000, "batch": 8}   # set by main()
+
+
+def pmc_traffic(substr, grid=None):
+    """HBM bytes per launch of the kernel whose name contains `substr`, launched with `grid`
+    threads, from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, produced by
+    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command;
+    FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md).  A counter is only
+    quoted for the launch it was measured on: None when no profile is committed, when the
+    profile ran another build (btr_build_id), another workload / cloud size / batch than this
+    run, or holds no launch of that kernel with exactly this grid."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     with open(path) as fh:
         doc = json.load(fh)
-    # counters are only quoted for the kernels they were measured on: the profile records the
-    # digest of the sources it ran (btr_build_id); a library built from anything else -> null
     from backtoreality_amd.pointnet2 import _ext
     if doc.get("build_id") != _ext.build_id():
         return None
+    if doc.get("workload", {"workload": "fsb", "points": 40000, "batch": 8}) != RUN_SHAPE:
+        return None
     ks = doc["kernels"]
     cands = [(v["read_bytes_corrected"] + v["write_bytes"], k) for k, v in ks.items()
-             if substr in k]
+             if substr in k and (grid is None or k.endswith("@grid%d" % grid))]
     return max(cands)[0] if cands else None
 
 
@@ -509,8 +557,12 @@ def roofline_objects(kernels, detail, detail_steps, pair_overhead_ms=0.0):
         ach = nbytes / (ms * 1e-3) / 1e9
         res["ball_query_roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                      "traffic": pmc_traffic("bqb_query_kernel" if bq_buckets
-                                                             else "bq_grid_query_kernel"),
+                                      # (bqb_query_kernel's grid: csrc/ball_query_bucket.hip
+                                      # bq_bucket_launch; the grid kernel is not keyed)
+                                      "traffic": (pmc_traffic(
+                                          "bqb_query_kernel",
+                                          max(1, min((m + 3) // 4, 2048 // max(1, b))) * b * 256)
+                                          if bq_buckets else None),
                                       "algorithmic_bytes": nbytes,
                                       # what a launch sequence of this size can reach at all: one
                                       # dependent-kernel boundary per launch (1.45 us,
@@ -565,7 +617,8 @@ def roofline_objects(kernels, detail, detail_steps, pair_overhead_ms=0.0):
         ach = nbytes / (ms * 1e-3) / 1e9
         res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic("fps_bucket_kernel"),
+                           # (one 1024-thread workgroup per scene: csrc/fps_bucket.hip)
+                           "traffic": pmc_traffic("fps_bucket_kernel", b * 1024),
                            "algorithmic_bytes": nbytes,
                            "kernel": "fps_bucket_kernel",
                            "shape": [b, n, m], "avg_ms": ms,

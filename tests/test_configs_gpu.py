@@ -80,6 +80,53 @@ def test_c5_matterport_80k_points(cuda, monkeypatch):
     assert worst < 1e-2, worst
 
 
+def test_c5_scenes_with_a_near_tie_state_the_bound_per_flip(cuda, monkeypatch):
+    """The C5 test above uses scenes 8..11 because scenes 0..3 hold ONE max-pool element of SA4
+    (layer 2, channel 83) within float32 noise of a tie between two different neighbours
+    (tools/diag_c5_grads.py).  Instead of only stepping around it, state what such a flip may
+    do, on those very scenes -- two correct f32 implementations may pick either neighbour:
+      * nothing in the forward moves (the two candidates hold the same value to rounding): loss
+        and features stay at 1e-4;
+      * the gradients of every layer the backward reaches BEFORE the flipped pool (proposal
+        head, vote aggregation, voting module, fp1 / fp2) do not depend on the choice: they keep
+        the normal bound;
+      * in the flipped layer's weight gradient exactly the flipped channel's row moves: all but
+        <= 2 rows keep the normal bound row by row;
+      * everything upstream of it (SA4's first layers, SA3..SA1) receives that one element's
+        gradient through another neighbour: 4 % relative L2 was measured, 0.1 is the bound.
+    On a box / build where the element does not flip every bound holds trivially."""
+    cfg = config.matterport_md40()
+    B = 4
+    batch = synthetic.make_batch(0, B, 80000, cfg, extent_scale=1.7, device=cuda)
+    loss_u, end_u, g_u = _votenet_step(cfg, batch, cuda, False, monkeypatch)
+    loss_f, end_f, g_f = _votenet_step(cfg, batch, cuda, True, monkeypatch,
+                                       vote_inds=end_u['aggregated_vote_inds'])
+    assert torch.equal(end_f['sa1_inds'], end_u['sa1_inds'])
+    assert _rel(end_f['fp2_features'], end_u['fp2_features']) < 1e-4
+    assert _rel(end_f['aggregated_vote_features'], end_u['aggregated_vote_features']) < 2e-4
+    assert abs(float(loss_f) - float(loss_u)) / abs(float(loss_u)) < 1e-4
+    gmax = max(float(g.abs().max()) for g in g_u.values())
+
+    def l2(n):
+        return float((g_f[n] - g_u[n]).norm() / (g_u[n].norm() + 1e-20))
+    live = [n for n in g_u if float(g_u[n].abs().max()) > 1e-4 * gmax]
+    upstream = ('backbone_net.sa1.', 'backbone_net.sa2.', 'backbone_net.sa3.', 'backbone_net.sa4.')
+    flipped = 'backbone_net.sa4.mlp_module.layer2.conv.weight'
+    assert flipped in g_u
+    for n in live:
+        if not n.startswith(upstream):
+            assert l2(n) < 1e-2, (n, l2(n))       # reached before the pool: unaffected
+        elif n != flipped:
+            assert l2(n) < 0.1, (n, l2(n))        # reached through the flipped element
+    wf, wu = g_f[flipped].flatten(1), g_u[flipped].flatten(1)
+    # (row deviations relative to the tensor's largest row: a row whose own norm is small is not
+    # "moved" by ordinary rounding of the others' scale)
+    row_dev = (wf - wu).norm(dim=1) / float(wu.norm(dim=1).max())
+    moved = int((row_dev > 1e-2).sum())
+    own = (wf - wu).norm(dim=1) / (wu.norm(dim=1) + 1e-20)
+    assert moved <= 2, (moved, row_dev.topk(8), own.topk(8), {n: l2(n) for n in live})
+
+
 def test_c4_groupfree_backbone_50k_no_features(cuda, monkeypatch):
     """C4: GroupFree3D-style backbone: xyz only (no height channel), 50 000 points, fp2 -> 288
     channels (detection/GroupFree3D/models/backbone_module.py:33-75); configs[3]: batch 4."""

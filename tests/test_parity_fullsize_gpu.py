@@ -25,13 +25,10 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def test_c2_full_size_every_index_vs_oracle(cuda):
-    cfg = config.scannet_md40()
-    B, N = 8, 40000
-    batch = synthetic.make_batch(0, B, N, cfg, device=cuda)
-    pc = batch['point_clouds']
-    net = train.build_model(cfg, cuda, seed=0).train()
-    bb = net.backbone_net
+def _check_pyramid(bb, pc):
+    """Every index of the backbone's sampling pyramid for the clouds `pc` against the oracle:
+    FPS indices, sampled coordinates and ball-query lists of all four levels, the 3-NN lists of
+    both feature-propagation modules.  Returns (handle, centres)."""
     handle = bb.prefetch_sampling(pc)
     torch.cuda.synchronize()
     assert type(handle).__name__ == "Sampling", "the whole-backbone library calls must be on"
@@ -53,6 +50,41 @@ def test_c2_full_size_every_index_vs_oracle(cuda):
         _, nn_idx = oracle.three_nn(centres[u], centres[k])
         np.testing.assert_array_equal(handle.three_nn(j)[0].cpu().numpy(), nn_idx,
                                       err_msg="3-NN of feature-propagation module %d" % (j + 1))
+    return handle, centres
+
+
+@pytest.mark.parametrize("case", ["c3_source", "c3_target", "c4", "c5"])
+def test_full_size_every_pyramid_index_vs_oracle(cuda, case):
+    """The full-size check of configs[1] below for the other BASELINE configs: both branches of
+    C3 (Back-to-Reality: source and target batch, 8 x 40 000 each), C4 (GroupFree3D's backbone,
+    4 x 50 000, xyz only, fp2 -> 288) and C5 (Matterport heads, 4 x 80 000 points on
+    12 x 12 x 3 m: two bucket slots per lane in the large-scene FPS, 1 250 buckets per scene in
+    the ball query) -- every level's FPS, ball-query and 3-NN list, not only SA1's."""
+    from backtoreality_amd.votenet import backbone_module
+    if case == "c4":
+        pc = torch.from_numpy(np.stack([synthetic.make_scene(70 + i, 50000, use_height=False)[
+            'point_clouds'] for i in range(4)], 0)).to(cuda)
+        torch.manual_seed(0)
+        bb = backbone_module.Pointnet2Backbone(input_feature_dim=0, fp2_out=288).to(cuda).train()
+    elif case == "c5":
+        cfg = config.matterport_md40()
+        pc = synthetic.make_batch(0, 4, 80000, cfg, extent_scale=1.7, device=cuda)['point_clouds']
+        bb = train.build_model(cfg, cuda, seed=0).train().backbone_net
+    else:
+        cfg = config.scannet_md40()
+        first = 0 if case == "c3_source" else 100000    # bench.py's source / target batches
+        pc = synthetic.make_batch(first, 8, 40000, cfg, device=cuda)['point_clouds']
+        bb = train.build_model(cfg, cuda, seed=0, domain_adaptation=True).train().backbone_net
+    _check_pyramid(bb, pc)
+
+
+def test_c2_full_size_every_index_vs_oracle(cuda):
+    cfg = config.scannet_md40()
+    B, N = 8, 40000
+    batch = synthetic.make_batch(0, B, N, cfg, device=cuda)
+    pc = batch['point_clouds']
+    net = train.build_model(cfg, cuda, seed=0).train()
+    handle, centres = _check_pyramid(net.backbone_net, pc)
 
     # the forward consumes exactly these, and the vote aggregation then samples / queries the
     # votes it computed: compare its choices with the oracle's ON THE SAME VOTES

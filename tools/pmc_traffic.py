@@ -5,7 +5,9 @@ SA1-sized launches can be told apart.  FETCH_SIZE / WRITE_SIZE are KiB per dispa
 FETCH_SIZE counts a wide coalesced read stream at half its bytes (MI355X_MICROARCH.md, HBM),
 so `read_bytes_corrected` = 2 x FETCH_SIZE x 1024 is the upper estimate and
 `read_bytes_raw` the lower one.
-Usage: pmc_traffic.py fetch.db write.db out.json"""
+The workload the passes ran (bench.py --workload / --points / --batch) is recorded too: bench.py
+quotes a counter only on the launch shape it was measured on.
+Usage: pmc_traffic.py fetch.db write.db out.json [workload points batch]"""
 import json
 import os
 import sqlite3
@@ -38,7 +40,11 @@ def main():
             "write_bytes": w[1] * 1024.0,
         }
     from backtoreality_amd import build
+    wl = sys.argv[4] if len(sys.argv) > 4 else "fsb"
+    points = int(sys.argv[5]) if len(sys.argv) > 5 else 40000
+    batch = int(sys.argv[6]) if len(sys.argv) > 6 else 8
     json.dump({"build_id": build.build_id(),
+               "workload": {"workload": wl, "points": points, "batch": batch},
                "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate "
                          "passes) -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline",
                "kernels": res}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
