@@ -1684,6 +1684,401 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(
   }
 }
 
+// ---- one pass over a layer's backward operands: dgrad + wgrad + the next BatchNorm's sums ------
+// The backward of a hidden layer l used to be five passes over its big tensors: the weight
+// gradient dW_l = dY_l^T . X_{l-1} and the input gradient dZ_{l-1} = dY_l . W_l each read dY_l,
+// then BatchNorm_{l-1}'s backward read (dZ_{l-1}, Y_{l-1}) once for its sums and once more to
+// apply them (writing dY_{l-1}), which the next two GEMMs read again: 9 row passes per layer (16
+// over SA1's backward: 2.9 GB at the benchmark shape).  All of them walk the same rows.  This
+// kernel is gemm_tn_x6_kernel's streaming loop (32 rows per step, operands split into bf16
+// planes in LDS, the next rows prefetched into registers) with everything else hung onto it:
+//   * dY_l is FORMED while staging -- GM == 1: from the pooled layer's pre-BN output and the
+//     (alpha, beta, arg-max) coefficients, exactly as GPOOL; GM == 2: BatchNorm_l's backward
+//     applied on the fly, dY = a (m G - w (c1 + xhat c2)) from (G = dZ_l, Y_l) and the finalised
+//     sums of layer l (what bn_relu_bwd_apply_kernel wrote in place);
+//   * the weight gradient accumulates over the workgroup's row chunk as before (transpose reads);
+//   * the SAME dY planes are the A operand of the input gradient: 32 rows x 64 columns per step
+//     against W_l^T, whose three planes stay in LDS for the whole kernel.  Rows of a plane are
+//     read as rows here and as columns by the transpose reads: with the tr-friendly pitches
+//     (320 / 192 B) sixteen row reads would share four bank groups, so the 16-byte units of a
+//     row are XOR-swizzled by (row / 4) % 4 -- constant over the four rows of a transpose block,
+//     a permutation inside its 64-byte segment, so both access patterns stay conflict-free;
+//   * the four waves split the input gradient's reduction in halves, the halves meet in LDS in
+//     row layout, and the thread that staged X_{l-1}[row][4 k] (and still holds the raw
+//     Y_{l-1} values) adds them, stores dZ_{l-1} as a 16-byte row store and accumulates
+//     BatchNorm_{l-1}'s backward sums  s1 += m dz,  s2 += m dz xhat  -- per-workgroup partials,
+//     reduced in a fixed order by bn_bwd_finalize_kernel like the stand-alone statistics pass.
+// Per layer: read dZ_l (or Y_l), Y_l, Y_{l-1}; write dZ_{l-1}: 4 passes.
+// XRC: X_{l-1} = relu(bn(y0)), y0 rebuilt from the 4-column input rows (first-layer recompute).
+constexpr int kFusedMaxChunks = 512;
+__device__ __forceinline__ int swz(int row, int byte_off) { return byte_off ^ (((row >> 2) & 3) << 4); }
+
+struct FusedArgs {
+  const float *G;      // GM 1: pooled layer's pre-BN output Y_l;  GM 2: dZ_l
+  const float *Yl;     // GM 2: Y_l (same leading dimension as G)
+  int ldg;
+  const float *X;      // Y_{l-1} [R][ldx], or X0 [R][4] (XRC)
+  int ldx;
+  int R, N, K, rows_per_chunk;
+  const float *pa, *pb, *mu_p, *is_p;    // layer l-1: scale, shift, mean, invstd
+  const float *xw0;                      // XRC: first-layer weight [K][4]
+  const float *Wt;     // W_l^T [K][ldw]
+  int ldw;
+  float *Z;            // out: dZ_{l-1} [R][ldz]
+  int ldz;
+  float *pw;           // out: weight-gradient partials [chunk][N][K]
+  float *spart;        // out: [chunk][2][K] sums for BatchNorm_{l-1}'s backward
+  // GM 1
+  const unsigned char *garg;
+  const float *gdcl, *galpha, *gbeta;
+  int SSH;
+  // GM 2: layer l's scale, shift, mean, invstd and finalised m1, m2
+  const float *sc, *sh, *mu, *is, *m1, *m2;
+};
+
+template <int TNW, int GM, bool XRC>
+__global__ __launch_bounds__(256) void sa_bwd_fused_kernel(FusedArgs a, Compact cm) {
+  constexpr int BR = 32;
+  constexpr int TN = 32 * TNW;
+  constexpr int LG = TN == 128 ? 160 : 96, LX = 96;   // bf16 row pitches: 320 B / 192 B
+  constexpr int LW = TN + 8;                          // W^T planes: 272 / 144 B (row reads only)
+  constexpr int LC = 68;                              // f32 pitch of the dgrad exchange tile
+  constexpr int KT = TNW == 4 ? 2 : 1;
+  constexpr bool GPOOL = GM == 1;
+  int R = a.R;
+  if (cm.dims) R = cm.dims[0];
+  const int N = a.N, K = a.K;
+  __shared__ __attribute__((aligned(16))) __bf16 Gp[3 * BR * LG];
+  __shared__ __attribute__((aligned(16))) __bf16 Xp[3 * BR * LX];
+  __shared__ __attribute__((aligned(16))) __bf16 Wp[3 * 64 * LW];
+  __shared__ __attribute__((aligned(16))) float Cs[2 * BR * LC];
+  __shared__ __attribute__((aligned(16))) float sXw[XRC ? 64 * 4 : 4];
+  __shared__ __attribute__((aligned(16))) int sLr[GPOOL ? 4 * TN : 4];
+  __shared__ __attribute__((aligned(16))) float sDv[GPOOL ? 4 * TN : 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = TNW == 4 ? wave : (wave >> 1);
+  const int wk = TNW == 4 ? 0 : (wave & 1);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int k0 = blockIdx.y * 64;
+  const int chunk = blockIdx.z;
+  const int rbeg = chunk * a.rows_per_chunk;
+  const int rend = min(R, rbeg + a.rows_per_chunk);
+  const float *__restrict__ G = a.G;
+  const float *__restrict__ X = a.X;
+
+  // ---- W_l^T rows k0 .. k0+63 -> three bf16 planes, once
+  for (int t = tid; t < 64 * (TN / 4); t += 256) {
+    const int kr = t / (TN / 4), c4 = (t % (TN / 4)) * 4;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k0 + kr < K && c4 < N)
+      w = *reinterpret_cast<const float4 *>(a.Wt + (size_t)(k0 + kr) * a.ldw + c4);
+    const Split4 sp = split4(w);
+    *reinterpret_cast<bf16x4 *>(&Wp[(0 * 64 + kr) * LW + c4]) = sp.h;
+    *reinterpret_cast<bf16x4 *>(&Wp[(1 * 64 + kr) * LW + c4]) = sp.m;
+    *reinterpret_cast<bf16x4 *>(&Wp[(2 * 64 + kr) * LW + c4]) = sp.l;
+  }
+  if (XRC) {
+    if (k0 + (tid >> 2) < K) sXw[tid] = a.xw0[(size_t)k0 * 4 + tid];
+  }
+
+  f32x16 acc[KT];
+#pragma unroll
+  for (int q = 0; q < KT; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+
+  const int xc4 = (tid & 15) * 4, xr = tid >> 4;
+  constexpr int GT = TN / 4, GR = 256 / GT, GPASS = BR / GR;
+  const int gc4 = (tid % GT) * 4, gr = tid / GT;
+  // layer l-1 per-column coefficients of this thread's four k columns
+  float4 fa = make_float4(0.f, 0.f, 0.f, 0.f), fb = fa, fmu = fa, fis = fa;
+  if (k0 + xc4 < K) {
+    fa = *reinterpret_cast<const float4 *>(a.pa + k0 + xc4);
+    fb = *reinterpret_cast<const float4 *>(a.pb + k0 + xc4);
+    fmu = *reinterpret_cast<const float4 *>(a.mu_p + k0 + xc4);
+    fis = *reinterpret_cast<const float4 *>(a.is_p + k0 + xc4);
+  }
+  // layer l per-column coefficients of this thread's four n columns
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga, gA1 = ga, gA2 = ga;
+  if (gc4 < N) {
+    if (GPOOL) {
+      ga = *reinterpret_cast<const float4 *>(a.galpha + gc4);
+      gb = *reinterpret_cast<const float4 *>(a.gbeta + gc4);
+    } else {
+      // dY = a (m G - w (c1 + xhat c2)) = m (a G) - w (A1 + A2 y),  A2 = a c2 invstd,
+      // A1 = a c1 - A2 mean;  m = (a y + shift > 0)
+      ga = *reinterpret_cast<const float4 *>(a.sc + gc4);
+      gb = *reinterpret_cast<const float4 *>(a.sh + gc4);
+      const float4 mu = *reinterpret_cast<const float4 *>(a.mu + gc4);
+      const float4 is = *reinterpret_cast<const float4 *>(a.is + gc4);
+      const float4 c1 = *reinterpret_cast<const float4 *>(a.m1 + gc4);
+      const float4 c2 = *reinterpret_cast<const float4 *>(a.m2 + gc4);
+      gA2 = make_float4(ga.x * c2.x * is.x, ga.y * c2.y * is.y, ga.z * c2.z * is.z,
+                        ga.w * c2.w * is.w);
+      gA1 = make_float4(ga.x * c1.x - gA2.x * mu.x, ga.y * c1.y - gA2.y * mu.y,
+                        ga.z * c1.z - gA2.z * mu.z, ga.w * c1.w - gA2.w * mu.w);
+    }
+  }
+  float4 rg[GPASS], ry[GM == 2 ? GPASS : 1], rx[2], ykeep[2];
+  const int sp_gi = tid / TN, sp_n = tid % TN;
+  constexpr int SPQ = 4 * TN / 256;
+  int sp_g[SPQ], sp_ng[SPQ], sp_lr[SPQ];
+  float sp_dv[SPQ];
+#pragma unroll
+  for (int q = 0; q < SPQ; ++q) {
+    sp_g[q] = sp_ng[q] = 0;
+    sp_lr[q] = -1;
+    sp_dv[q] = 0.f;
+  }
+  float gwt[GPASS];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < GPASS; ++p) {
+      const int row = gr + GR * p;
+      rg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (GM == 2) ry[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      gwt[p] = 1.f;
+      if (r0 + row < rend && gc4 < N) {
+        rg[p] = *reinterpret_cast<const float4 *>(G + (size_t)(r0 + row) * a.ldg + gc4);
+        if constexpr (GM == 2)
+          ry[p] = *reinterpret_cast<const float4 *>(a.Yl + (size_t)(r0 + row) * a.ldg + gc4);
+        if (cm.bw && ((r0 + row) & 7) == 0) gwt[p] = cm.bw[(r0 + row) >> 3];
+      }
+    }
+    if (GPOOL && cm.bgrp) {
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q, blk = (r0 >> 3) + slot;
+        if (r0 != rbeg) sp_g[q] = sp_ng[q];
+        sp_lr[q] = -1;
+        if (slot < 4 && (blk << 3) < rend && sp_n < N) {
+          const int g = sp_g[q];
+          const int lr = cm.goff[g] - r0 + (int)a.garg[(size_t)g * N + sp_n];
+          sp_dv[q] = a.gdcl[(size_t)g * N + sp_n];
+          sp_lr[q] = (lr >= 0 && (lr >> 3) == slot) ? lr : -1;
+        }
+        const int nblk = ((r0 + BR) >> 3) + slot;
+        sp_ng[q] = (slot < 4 && (nblk << 3) < rend) ? cm.bgrp[nblk] : 0;
+      }
+    } else if (GPOOL) {
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q;
+        const int g = (r0 >> a.SSH) + slot;
+        sp_lr[q] = -1;
+        if ((slot << a.SSH) < BR && (g << a.SSH) < rend && sp_n < N) {
+          const int arow = (g << a.SSH) + (int)a.garg[(size_t)g * N + sp_n];
+          sp_dv[q] = a.gdcl[(size_t)g * N + sp_n];
+          const int lr = arow - r0;
+          sp_lr[q] = (lr >= 0 && lr < BR && arow < rend) ? lr : -1;
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = xr + 16 * p;
+      rx[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < rend && k0 + xc4 < K)
+        rx[p] = XRC ? *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * 4)
+                    : *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * a.ldx + k0 + xc4);
+    }
+  };
+  if (GPOOL && cm.bgrp && rbeg < rend) {
+#pragma unroll
+    for (int q = 0; q < SPQ; ++q) {
+      const int slot = sp_gi + (256 / TN) * q, blk = (rbeg >> 3) + slot;
+      sp_g[q] = (slot < 4 && (blk << 3) < rend) ? cm.bgrp[blk] : 0;
+    }
+  }
+  __syncthreads();   // Wp, sXw
+  const int p16 = lane & 15, grp = lane >> 4;
+  const int frow = 8 * (grp >> 1) + (p16 >> 2), fcol = 16 * (grp & 1) + 4 * (p16 & 3);
+  // input gradient: wave -> (k half j, n half nh) of the 32 x 64 tile
+  const int dj = wave & 1, dnh = wave >> 1;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (rbeg < rend) fetch(rbeg);
+  for (int r0 = rbeg; r0 < rend; r0 += BR) {
+    if constexpr (GPOOL) {
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q;
+        sLr[slot * TN + sp_n] = sp_lr[q];
+        sDv[slot * TN + sp_n] = sp_dv[q];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < GPASS; ++p) {
+      float4 v = rg[p];
+      const int row = gr + GR * p;
+      if (r0 + row < rend && gc4 < N) {
+        const float wr = gwt[p];
+        if constexpr (GPOOL) {
+          v.x = wr * fmaf(ga.x, v.x, gb.x);
+          v.y = wr * fmaf(ga.y, v.y, gb.y);
+          v.z = wr * fmaf(ga.z, v.z, gb.z);
+          v.w = wr * fmaf(ga.w, v.w, gb.w);
+          const int slot = cm.bgrp ? (row >> 3) : (row >> a.SSH);
+          const int4 lr = *reinterpret_cast<const int4 *>(&sLr[slot * TN + gc4]);
+          const float4 dv = *reinterpret_cast<const float4 *>(&sDv[slot * TN + gc4]);
+          v.x += lr.x == row ? dv.x : 0.f;
+          v.y += lr.y == row ? dv.y : 0.f;
+          v.z += lr.z == row ? dv.z : 0.f;
+          v.w += lr.w == row ? dv.w : 0.f;
+        } else if constexpr (GM == 2) {
+          const float4 y = ry[p];
+          v.x = fmaf(-wr, fmaf(gA2.x, y.x, gA1.x), fmaf(ga.x, y.x, gb.x) > 0.f ? ga.x * v.x : 0.f);
+          v.y = fmaf(-wr, fmaf(gA2.y, y.y, gA1.y), fmaf(ga.y, y.y, gb.y) > 0.f ? ga.y * v.y : 0.f);
+          v.z = fmaf(-wr, fmaf(gA2.z, y.z, gA1.z), fmaf(ga.z, y.z, gb.z) > 0.f ? ga.z * v.z : 0.f);
+          v.w = fmaf(-wr, fmaf(gA2.w, y.w, gA1.w), fmaf(ga.w, y.w, gb.w) > 0.f ? ga.w * v.w : 0.f);
+        }
+      } else {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const Split4 sp = split4(v);
+      const int at = row * LG + (swz(row, gc4 * 2) >> 1);
+      *reinterpret_cast<bf16x4 *>(&Gp[0 * BR * LG + at]) = sp.h;
+      *reinterpret_cast<bf16x4 *>(&Gp[1 * BR * LG + at]) = sp.m;
+      *reinterpret_cast<bf16x4 *>(&Gp[2 * BR * LG + at]) = sp.l;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = xr + 16 * p;
+      float4 x = rx[p];
+      const bool live = r0 + row < rend && k0 + xc4 < K;
+      if (XRC && live) x = rc_y4(x, sXw, xc4);
+      ykeep[p] = x;   // the raw pre-BN values of layer l-1: the epilogue's mask and xhat
+      if (live) {
+        x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
+        x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
+        x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
+        x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
+      } else {
+        x = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const Split4 sp = split4(x);
+      const int at = row * LX + xc4;
+      *reinterpret_cast<bf16x4 *>(&Xp[0 * BR * LX + at]) = sp.h;
+      *reinterpret_cast<bf16x4 *>(&Xp[1 * BR * LX + at]) = sp.m;
+      *reinterpret_cast<bf16x4 *>(&Xp[2 * BR * LX + at]) = sp.l;
+    }
+    __syncthreads();
+    if (r0 + BR < rend) fetch(r0 + BR);  // next rows in flight during the MFMAs
+    // ---- weight gradient: reduction over the 32 rows (transpose reads of both operands)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[3], bf[3][KT];
+      const int trow = ks * 16 + frow;   // (+4 for the second half: same swizzle class + 1)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        {
+          typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+          const int c2 = (wn * 32 + fcol) * 2;
+          const __bf16 *b0 = &Gp[(q * BR + trow) * LG + (swz(trow, c2) >> 1)];
+          const __bf16 *b1 = &Gp[(q * BR + trow + 4) * LG + (swz(trow + 4, c2) >> 1)];
+          union {
+            s16x4 s[2];
+            bf16x8 b;
+          } u;
+          u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b0));
+          u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b1));
+          af[q] = u.b;
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+          bf[q][t] = tr_read8(&Xp[(q * BR + trow) * LX + (wk + t) * 32 + fcol], LX);
+      }
+#define BTR_X6(QA, QB)                       \
+  _Pragma("unroll") for (int t = 0; t < KT; ++t) acc[t] = \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA], bf[QB][t], acc[t], 0, 0, 0);
+      BTR_X6(2, 0)
+      BTR_X6(0, 2)
+      BTR_X6(1, 1)
+      BTR_X6(1, 0)
+      BTR_X6(0, 1)
+      BTR_X6(0, 0)
+#undef BTR_X6
+    }
+    // ---- input gradient: C[32 rows][32 k of half dj] over the n half dnh (row reads)
+    {
+      f32x16 cd;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) cd[v] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < TN / 32; ++kk) {
+        const int nb = (dnh * (TN / 32) + kk) * 16 + h * 8;   // first of this lane's 8 n
+        bf16x8 ad[3], bd[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          ad[q] = *reinterpret_cast<const bf16x8 *>(
+              &Gp[(q * BR + l31) * LG + (swz(l31, nb * 2) >> 1)]);
+          bd[q] = *reinterpret_cast<const bf16x8 *>(&Wp[(q * 64 + dj * 32 + l31) * LW + nb]);
+        }
+#define BTR_X6D(QA, QB) cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[QA], bd[QB], cd, 0, 0, 0);
+        BTR_X6D(2, 0)
+        BTR_X6D(0, 2)
+        BTR_X6D(1, 1)
+        BTR_X6D(1, 0)
+        BTR_X6D(0, 1)
+        BTR_X6D(0, 0)
+#undef BTR_X6D
+      }
+      float *T = Cs + dnh * (BR * LC);
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+        T[((v & 3) + 8 * (v >> 2) + 4 * h) * LC + dj * 32 + l31] = cd[v];
+    }
+    __syncthreads();
+    // ---- epilogue: the thread that staged X[row][xc4..] owns dZ[row][k0 + xc4..]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = xr + 16 * p;
+      if (r0 + row < rend && k0 + xc4 < K) {
+        const float4 c0 = *reinterpret_cast<const float4 *>(&Cs[row * LC + xc4]);
+        const float4 c1 = *reinterpret_cast<const float4 *>(&Cs[BR * LC + row * LC + xc4]);
+        const float4 c = make_float4(c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w);
+        *reinterpret_cast<float4 *>(a.Z + (size_t)(r0 + row) * a.ldz + k0 + xc4) = c;
+        const float4 y = ykeep[p];
+        const float gx = fmaf(fa.x, y.x, fb.x) > 0.f ? c.x : 0.f;
+        const float gy = fmaf(fa.y, y.y, fb.y) > 0.f ? c.y : 0.f;
+        const float gz = fmaf(fa.z, y.z, fb.z) > 0.f ? c.z : 0.f;
+        const float gw = fmaf(fa.w, y.w, fb.w) > 0.f ? c.w : 0.f;
+        s1.x += gx; s1.y += gy; s1.z += gz; s1.w += gw;
+        s2.x = fmaf(gx, (y.x - fmu.x) * fis.x, s2.x);
+        s2.y = fmaf(gy, (y.y - fmu.y) * fis.y, s2.y);
+        s2.z = fmaf(gz, (y.z - fmu.z) * fis.z, s2.z);
+        s2.w = fmaf(gw, (y.w - fmu.w) * fis.w, s2.w);
+      }
+    }
+    // (the next step's staging writes Gp / Xp: every wave is past its MFMA reads -- the barrier
+    // above -- and Cs is rewritten only after the next staging barrier)
+  }
+  // ---- weight-gradient partial of this chunk
+  float *out = a.pw + (size_t)chunk * N * K;
+#pragma unroll
+  for (int q = 0; q < KT; ++q) {
+    const int col = k0 + (wk + q) * 32 + l31;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+      if (row < N && col < K) out[(size_t)row * K + col] = acc[q][v];
+    }
+  }
+  // ---- BatchNorm_{l-1} sums of this chunk: 16 row-threads per k column group, fixed order
+  __syncthreads();
+  float *red = Cs;   // [2][16 row threads][64 k]
+  *reinterpret_cast<float4 *>(&red[(0 * 16 + xr) * 64 + xc4]) = s1;
+  *reinterpret_cast<float4 *>(&red[(1 * 16 + xr) * 64 + xc4]) = s2;
+  __syncthreads();
+  if (tid < 128) {
+    const int which = tid >> 6, c = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[(which * 16 + q) * 64 + c];
+    if (k0 + c < K) a.spart[((size_t)chunk * 2 + which) * K + k0 + c] = t;
+  }
+}
+
 // dw[i] = sum over chunks of pw[chunk][i], fixed order; EL elements x SL chunk slices per block
 // (4 x 64 for the small weight matrices, whose launches are latency-bound; 16 x 16 keeps the
 // reads of the large ones coalesced).
@@ -2777,6 +3172,24 @@ int btr_sa_bn_relu_bwd_rc(long long rows, int c, int ldg, const float *g, const 
   return check_launch("sa_bn_relu_bwd_rc");
 }
 
+// btr_sa_bn_relu_bwd_rc minus its statistics pass: the sums come from btr_sa_bwd_fused.
+int btr_sa_bn_relu_bwd_rc_apply(long long rows, int c, int ldg, const float *g, const float *x0,
+                                const float *w0, const float *scale, const float *shift,
+                                const float *mean, const float *invstd, const float *m1,
+                                const float *m2, float *pw, float *dw0, btr_stream_t stream) {
+  if (rows <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(c <= kBnBwdMaxC && c % 4 == 0 && ldg % 4 == 0,
+              "sa_bn_relu_bwd_rc_apply: %d channels must be a multiple of 4 and <= %d", c,
+              kBnBwdMaxC);
+  hipStream_t st = as_stream(stream);
+  const int nblk = btr_sa_rc_wgrad_blocks(rows, c);
+  hipLaunchKernelGGL(bn_relu_bwd_wgrad0_rc_kernel, dim3(nblk), dim3(256), 0, st, rows, c, ldg, g,
+                     x0, w0, scale, shift, mean, invstd, m1, m2, pw, cur_compact());
+  hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(c * 4, 16)), dim3(256), 0, st,
+                     c * 4, nblk, pw, dw0);
+  return check_launch("sa_bn_relu_bwd_rc_apply");
+}
+
 // In place: g (gradient w.r.t. the post-ReLU activation of a hidden layer) -> gradient w.r.t.
 // the layer's pre-BN output y; also dgamma/dbeta.  part: [1024][2][c] floats.
 int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
@@ -2797,6 +3210,70 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx), dim3(256), 0, st, rows, c, ld, g, y,
                      scale, shift, mean, invstd, m1, m2, cur_compact());
   return check_launch("sa_bn_relu_bwd");
+}
+
+// ---- a hidden layer's whole backward as ONE pass (sa_bwd_fused_kernel) ------------------------
+// dY_l formed while staging (pooled: arg != NULL, g = the pooled layer's pre-BN output; else
+// BatchNorm_l's backward from g = dZ_l, yl = Y_l and the finalised sums of layer l), then
+//   dw [n][k]    = dY_l^T . X_{l-1}          (pw: [btr_sa_bwd_fused_chunks][n][k] partials)
+//   dz [rows][k] = dY_l . W_l                (wt = W_l^T [k][ldw])
+//   m1, m2, dgamma, dbeta of BatchNorm_{l-1} from (dz, Y_{l-1})   (spart: [chunks][2][k])
+// X_{l-1} = relu(pa * y + pb) with y = x [rows][ldx], or y rebuilt from the 4-column input rows
+// x [rows][4] and w0 [k][4] when w0 != NULL (first-layer recompute).
+int btr_sa_bwd_fused_supported(int rows, int n, int k) {
+  static const bool off = getenv("BTR_BWD_FUSED") && getenv("BTR_BWD_FUSED")[0] == '0';
+  return !off && gemm_x6() && tn_pool_x6() && rows > 0 && n >= 32 && n <= 128 && n % 4 == 0 &&
+         k >= 4 && k <= 256 && k % 4 == 0;
+}
+
+int btr_sa_bwd_fused_chunks(int rows, int n, int k) {
+  return std::min(kFusedMaxChunks, btr_sa_gemm_tn_chunks(rows, n, k));
+}
+
+int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const float *yl,
+                     const float *sc, const float *sh, const float *mu, const float *is,
+                     const float *m1l, const float *m2l, int s, const unsigned char *arg,
+                     const float *dcl, const float *alpha, const float *beta, const float *x,
+                     int ldx, const float *w0, const float *pa, const float *pb,
+                     const float *mu_p, const float *is_p, const float *wt, int ldw, float *dz,
+                     int ldz, float *pw, float *dw, float *spart, float *m1, float *m2,
+                     float *dgamma, float *dbeta, btr_stream_t stream) {
+  BTR_REQUIRE(btr_sa_bwd_fused_supported(rows, n, k), "sa_bwd_fused: shape %d x %d x %d", rows, n,
+              k);
+  const bool pooled = arg != nullptr;
+  BTR_REQUIRE(g && x && pa && pb && mu_p && is_p && wt && dz && pw && dw && spart && m1 && m2 &&
+                  dgamma && dbeta && ldg % 4 == 0 && ldw % 4 == 0 && ldz % 4 == 0 &&
+                  (w0 || ldx % 4 == 0),
+              "sa_bwd_fused: null pointer or unaligned leading dimension");
+  BTR_REQUIRE(pooled ? (dcl && alpha && beta && s > 0) : (yl && sc && sh && mu && is && m1l && m2l),
+              "sa_bwd_fused: incomplete %s operands", pooled ? "pooled-gradient" : "BatchNorm");
+  BTR_REQUIRE(!pooled || host_compact().on || s == 16 || s == 32 || s == 64 || s == 128,
+              "sa_bwd_fused: nsample %d must be 16, 32, 64 or 128", s);
+  hipStream_t st = as_stream(stream);
+  const int chunks = btr_sa_bwd_fused_chunks(rows, n, k);
+  FusedArgs a{};
+  a.G = g; a.Yl = yl; a.ldg = ldg; a.X = x; a.ldx = ldx; a.R = rows; a.N = n; a.K = k;
+  a.rows_per_chunk = cdiv(cdiv(rows, chunks), 32) * 32;
+  a.pa = pa; a.pb = pb; a.mu_p = mu_p; a.is_p = is_p; a.xw0 = w0; a.Wt = wt; a.ldw = ldw;
+  a.Z = dz; a.ldz = ldz; a.pw = pw; a.spart = spart;
+  a.garg = arg; a.gdcl = dcl; a.galpha = alpha; a.gbeta = beta; a.SSH = pooled ? ilog2(s) : 0;
+  a.sc = sc; a.sh = sh; a.mu = mu; a.is = is; a.m1 = m1l; a.m2 = m2l;
+  const dim3 grid(1, cdiv(k, 64), chunks);
+#define BTR_FUSED(W, GM, XR) \
+  hipLaunchKernelGGL((sa_bwd_fused_kernel<W, GM, XR>), grid, dim3(256), 0, st, a, cur_compact())
+  if (n > 64) {
+    if (pooled) { if (w0) BTR_FUSED(4, 1, true); else BTR_FUSED(4, 1, false); }
+    else        { if (w0) BTR_FUSED(4, 2, true); else BTR_FUSED(4, 2, false); }
+  } else {
+    if (pooled) { if (w0) BTR_FUSED(2, 1, true); else BTR_FUSED(2, 1, false); }
+    else        { if (w0) BTR_FUSED(2, 2, true); else BTR_FUSED(2, 2, false); }
+  }
+#undef BTR_FUSED
+  const double count = host_compact().on ? host_compact().count : (double)rows;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(k, kRedCh)), dim3(256), 0, st, k, chunks,
+                     count, spart, m1, m2, dgamma, dbeta);
+  reduce_chunks_launch(n * k, chunks, pw, dw, st);
+  return check_launch("sa_bwd_fused");
 }
 
 // dW[n][k] = sum_r G[r][n] * f(X[r][k]).

@@ -76,6 +76,11 @@ _SIGNATURES = {
     "btr_sa_rc_wgrad_blocks": (_ci, [_ll, _ci]),
     "btr_sa_bn_relu_bwd_rc": (_ci, [_ll, _ci, _ci] + [_vp] * 15),
     "btr_sa_pool_bwd_coef": (_ci, [_ci, _ci, _ci, _ci, _ci] + [_vp] * 17),
+    "btr_sa_bwd_fused_supported": (_ci, [_ci, _ci, _ci]),
+    "btr_sa_bwd_fused_chunks": (_ci, [_ci, _ci, _ci]),
+    "btr_sa_bwd_fused": (_ci, [_ci, _ci, _ci, _vp, _ci] + [_vp] * 7 + [_ci] + [_vp] * 5 +
+                         [_ci] + [_vp] * 6 + [_ci, _vp, _ci] + [_vp] * 8),
+    "btr_sa_bn_relu_bwd_rc_apply": (_ci, [_ll, _ci, _ci] + [_vp] * 12),
     "btr_sa_gemm_nt_pool": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _vp, _vp,
                                   _vp, _vp, _vp]),
     "btr_sa_gemm_tn_pool": (_ci, [_ci, _ci, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci,

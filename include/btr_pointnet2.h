@@ -299,6 +299,41 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
                         const float *beta, const float *x, int ldx, const float *pa,
                         const float *pb, float *pw, float *dw, btr_stream_t stream);
 
+/* A hidden layer's whole backward as ONE pass over its rows (csrc/sa_mlp.hip
+ * sa_bwd_fused_kernel; round 4).  What the calls above do in five passes for layer l -- weight
+ * gradient and input gradient each reading dY_l, then BatchNorm_{l-1}'s statistics pass and its
+ * in-place apply pass over (dZ_{l-1}, Y_{l-1}) -- is one streaming kernel: dY_l is formed while
+ * its rows are staged (arg != NULL: the pooled layer's gradient from y, arg, dcl, alpha, beta as
+ * in btr_sa_gemm_*_pool with g = the pooled layer's pre-BN output; arg == NULL: BatchNorm_l's
+ * backward dY = scale (m g - w (m1 + xhat m2)) from g = dZ_l, yl = Y_l and layer l's scale,
+ * shift, mean, invstd, m1, m2), the same staged planes feed
+ *   dw [n][k]    = dY_l^T . X_{l-1}   (pw: [btr_sa_bwd_fused_chunks()][n][k] partials)
+ *   dz [rows][k] = dY_l . W_l         (wt = W_l^T [k][ldw]),
+ * and the thread that stores a piece of dz also holds the matching raw Y_{l-1} values, so the
+ * sums of BatchNorm_{l-1}'s backward (spart [chunks][2][k] -> m1, m2, dgamma, dbeta) come out of
+ * the same pass.  X_{l-1} = relu(pa * y + pb), y = x [rows][ldx], or y rebuilt from the
+ * 4-column input rows x [rows][4] and w0 [k][4] when w0 != NULL (first-layer recompute);
+ * mu_p / is_p: mean and invstd of layer l-1.  The caller then feeds (dz, Y_{l-1}, m1, m2) to
+ * the next call, or to btr_sa_bn_relu_bwd_rc_apply for a recomputed first layer.
+ * Supported: n <= 128, k <= 256, multiples of 4, bf16x6 GEMMs on (BTR_BWD_FUSED=0: never).
+ * Reference: the autograd backward of SharedMLP's Conv2d + BatchNorm2d + ReLU stack,
+ * pointnet2/pytorch_utils.py:11-36, 157-188. */
+int btr_sa_bwd_fused_supported(int rows, int n, int k);
+int btr_sa_bwd_fused_chunks(int rows, int n, int k);
+int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const float *yl,
+                     const float *sc, const float *sh, const float *mu, const float *is,
+                     const float *m1l, const float *m2l, int s, const unsigned char *arg,
+                     const float *dcl, const float *alpha, const float *beta, const float *x,
+                     int ldx, const float *w0, const float *pa, const float *pb,
+                     const float *mu_p, const float *is_p, const float *wt, int ldw, float *dz,
+                     int ldz, float *pw, float *dw, float *spart, float *m1, float *m2,
+                     float *dgamma, float *dbeta, btr_stream_t stream);
+/* btr_sa_bn_relu_bwd_rc without its statistics pass: m1, m2 are given (btr_sa_bwd_fused). */
+int btr_sa_bn_relu_bwd_rc_apply(long long rows, int c, int ldg, const float *g, const float *x0,
+                                const float *w0, const float *scale, const float *shift,
+                                const float *mean, const float *invstd, const float *m1,
+                                const float *m2, float *pw, float *dw0, btr_stream_t stream);
+
 /* ---- VoteNet loss, forward + backward (the caller right after the hot path).
  * Replaces the ~250 torch launches of detection/Votenet/models/loss_helper.py:336-400
  * (compute_vote_loss :24-69, compute_objectness_loss :111-152, compute_box_and_sem_cls_loss
