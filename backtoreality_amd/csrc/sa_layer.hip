@@ -627,6 +627,13 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   int last_done = -1;
   // the layers' split-K reductions: ONE launch behind the last TN GEMM, on the stream they ran on
   ReduceBatchScope batch(side ? side->s : hmain);
+  // `lazy`: dy holds dZ_l, the gradient w.r.t. layer l's ACTIVATION, with BatchNorm_l's backward
+  // sums finalised in (m1, m2) -- not yet dY_l.  btr_sa_bwd_fused applies them while it stages
+  // its operand; any other consumer gets them applied in place first.
+  bool lazy = false, fused_any = false;
+  auto fusable = [&](int l) {
+    return l >= 1 && btr_sa_bwd_fused_supported(R, d.width[l], p.kin[l]) != 0;
+  };
   for (int l = L - 1; l >= 0; --l) {
     const int nl = d.width[l], k = p.kin[l];
     const float *xsrc = l == 0 ? x0 : at_f(saved, p.y[l - 1]);
@@ -634,7 +641,38 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     const float *pa = l == 0 ? nullptr : stat(l - 1, 0);
     const float *pb = l == 0 ? nullptr : stat(l - 1, 1);
     const bool pooled = p.pool_grad && l == L - 1;
-    if (p.recompute && l == 0) break;  // finished by btr_sa_bn_relu_bwd_rc below
+    if (p.recompute && l == 0) {
+      // the recomputed first layer behind a fused call: its sums exist, one pass left
+      if (lazy)
+        BTR_TRY(btr_sa_bn_relu_bwd_rc_apply(R, d.width[0], d.width[0], dy, x0,
+                                            at_f(saved, p.w2[0]), stat(0, 0), stat(0, 1),
+                                            stat(0, 2), stat(0, 3), m1, m2,
+                                            at_f(scratch, sc.pw0), grads + p.dw[0], stream));
+      break;  // (otherwise finished by btr_sa_bn_relu_bwd_rc below)
+    }
+    if (fusable(l) && (pooled || lazy)) {
+      // ---- the whole backward of layer l in one pass (csrc/sa_mlp.hip sa_bwd_fused_kernel):
+      // dW_l, dZ_{l-1} and BatchNorm_{l-1}'s sums; dY_l is formed while its rows are staged
+      float *g = at_f(scratch, sc.g[flip]);
+      flip ^= 1;
+      const bool rc1 = p.recompute && l == 1;
+      BTR_TRY(btr_sa_bwd_fused(
+          R, nl, k, pooled ? ylast : dy, nl, pooled ? nullptr : at_f(saved, p.y[l]), stat(l, 0),
+          stat(l, 1), stat(l, 2), stat(l, 3), m1, m2, d.s, pooled ? arg : nullptr,
+          pooled ? dcl : nullptr, pooled ? alpha : nullptr, pooled ? beta : nullptr,
+          rc1 ? x0 : xsrc, rc1 ? 4 : ldx, rc1 ? at_f(saved, p.w2[0]) : nullptr, pa, pb,
+          stat(l - 1, 2), stat(l - 1, 3), at_f(saved, p.wt[l]), nl, g, k,
+          at_f(scratch, sc.pw[l]), grads + p.dw[l], part, m1, m2, grads + p.dgamma[l - 1],
+          grads + p.dbeta[l - 1], stream));
+      dy = g;
+      lazy = fused_any = true;
+      continue;
+    }
+    if (lazy) {   // a consumer that wants dY_l itself
+      BTR_TRY(btr_sa_bn_relu_bwd_apply(R, nl, nl, dy, at_f(saved, p.y[l]), stat(l, 0), stat(l, 1),
+                                       stat(l, 2), stat(l, 3), m1, m2, stream));
+      lazy = false;
+    }
     float *dw = grads + p.dw[l];
     float *pw = at_f(scratch, sc.pw[l]);
     // weight gradient of layer l: dY_l is final here -> fork
@@ -673,7 +711,12 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
           BTR_TRY(btr_sa_bn_relu_bwd_rc(R, k, k, g, x0, at_f(saved, p.w2[0]), stat(0, 0),
                                         stat(0, 1), stat(0, 2), stat(0, 3), part, m1, m2, dg, db,
                                         at_f(scratch, sc.pw0), grads + p.dw[0], stream));
-        else
+        else if (fusable(l - 1)) {   // the next layer applies the sums while it stages g
+          BTR_TRY(btr_sa_bn_relu_bwd_sums(R, k, k, g, at_f(saved, p.y[l - 1]), stat(l - 1, 0),
+                                          stat(l - 1, 1), stat(l - 1, 2), stat(l - 1, 3), part,
+                                          m1, m2, dg, db, stream));
+          lazy = true;
+        } else
           BTR_TRY(btr_sa_bn_relu_bwd(R, k, k, g, at_f(saved, p.y[l - 1]), stat(l - 1, 0),
                                      stat(l - 1, 1), stat(l - 1, 2), stat(l - 1, 3), part, m1, m2,
                                      dg, db, stream));
@@ -700,8 +743,12 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       }
     }
   }
+  if (side && fused_any) {   // the fused calls' partials were written on the main stream
+    (void)hipEventRecord(side->ready[kMaxL], hmain);
+    (void)hipStreamWaitEvent(side->s, side->ready[kMaxL], 0);
+  }
   batch.flush();
-  if (side && last_done >= 0) {   // join
+  if (side && (last_done >= 0 || fused_any)) {   // join
     (void)hipEventRecord(side->done[kMaxL], side->s);
     (void)hipStreamWaitEvent(hmain, side->done[kMaxL], 0);
   }

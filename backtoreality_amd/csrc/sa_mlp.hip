@@ -1737,22 +1737,25 @@ struct FusedArgs {
 };
 
 template <int TNW, int GM, bool XRC>
-__global__ __launch_bounds__(256) void sa_bwd_fused_kernel(FusedArgs a, Compact cm) {
+__global__ __launch_bounds__(256, 2) void sa_bwd_fused_kernel(FusedArgs a, Compact cm) {
   constexpr int BR = 32;
   constexpr int TN = 32 * TNW;
   constexpr int LG = TN == 128 ? 160 : 96, LX = 96;   // bf16 row pitches: 320 B / 192 B
-  constexpr int LW = TN + 8;                          // W^T planes: 272 / 144 B (row reads only)
   constexpr int LC = 68;                              // f32 pitch of the dgrad exchange tile
   constexpr int KT = TNW == 4 ? 2 : 1;
   constexpr bool GPOOL = GM == 1;
-  int R = a.R;
-  if (cm.dims) R = cm.dims[0];
+  // compact rows: the row count lives on the device, and so does the split of the rows over
+  // the workgroups -- sized by the host's dense bound, a third of the grid would find no rows and
+  // the rest would run 1.5x as long (SA1 keeps 67 % of its rows, SA2 44 %)
+  int R = a.R, rows_per_chunk = a.rows_per_chunk;
+  if (cm.dims) {
+    R = cm.dims[0];
+    rows_per_chunk = ((R + (int)gridDim.z - 1) / (int)gridDim.z + 31) / 32 * 32;
+  }
   const int N = a.N, K = a.K;
   __shared__ __attribute__((aligned(16))) __bf16 Gp[3 * BR * LG];
   __shared__ __attribute__((aligned(16))) __bf16 Xp[3 * BR * LX];
-  __shared__ __attribute__((aligned(16))) __bf16 Wp[3 * 64 * LW];
   __shared__ __attribute__((aligned(16))) float Cs[2 * BR * LC];
-  __shared__ __attribute__((aligned(16))) float sXw[XRC ? 64 * 4 : 4];
   __shared__ __attribute__((aligned(16))) int sLr[GPOOL ? 4 * TN : 4];
   __shared__ __attribute__((aligned(16))) float sDv[GPOOL ? 4 * TN : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1761,24 +1764,46 @@ __global__ __launch_bounds__(256) void sa_bwd_fused_kernel(FusedArgs a, Compact 
   const int l31 = lane & 31, h = lane >> 5;
   const int k0 = blockIdx.y * 64;
   const int chunk = blockIdx.z;
-  const int rbeg = chunk * a.rows_per_chunk;
-  const int rend = min(R, rbeg + a.rows_per_chunk);
+  const int rbeg = chunk * rows_per_chunk;
+  const int rend = min(R, rbeg + rows_per_chunk);
   const float *__restrict__ G = a.G;
   const float *__restrict__ X = a.X;
 
-  // ---- W_l^T rows k0 .. k0+63 -> three bf16 planes, once
-  for (int t = tid; t < 64 * (TN / 4); t += 256) {
-    const int kr = t / (TN / 4), c4 = (t % (TN / 4)) * 4;
-    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k0 + kr < K && c4 < N)
-      w = *reinterpret_cast<const float4 *>(a.Wt + (size_t)(k0 + kr) * a.ldw + c4);
-    const Split4 sp = split4(w);
-    *reinterpret_cast<bf16x4 *>(&Wp[(0 * 64 + kr) * LW + c4]) = sp.h;
-    *reinterpret_cast<bf16x4 *>(&Wp[(1 * 64 + kr) * LW + c4]) = sp.m;
-    *reinterpret_cast<bf16x4 *>(&Wp[(2 * 64 + kr) * LW + c4]) = sp.l;
+  // ---- input gradient: wave -> (k half dj, n half dnh) of the step's 32 x 64 tile.  Its B
+  // operand -- W_l^T rows k0 + 32 dj + (lane % 32), this lane's 8 n of each 16-wide reduction
+  // step of the wave's n half -- never changes: split once, kept in registers for the whole
+  // kernel (TN / 32 steps x 3 planes x 4 VGPRs; as LDS planes they cost 52 KB and the second
+  // workgroup per CU that hides the load latency of this streaming loop)
+  const int dj = wave & 1, dnh = wave >> 1;
+  bf16x8 bdr[TN / 32][3];
+  {
+    const int kr = k0 + dj * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < TN / 32; ++kk) {
+      const int nb = (dnh * (TN / 32) + kk) * 16 + (lane >> 5) * 8;
+      float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+      if (kr < K && nb < N) w0 = *reinterpret_cast<const float4 *>(a.Wt + (size_t)kr * a.ldw + nb);
+      if (kr < K && nb + 4 < N)
+        w1 = *reinterpret_cast<const float4 *>(a.Wt + (size_t)kr * a.ldw + nb + 4);
+      const Split4 s0 = split4(w0), s1 = split4(w1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bdr[kk][0][e] = s0.h[e]; bdr[kk][0][4 + e] = s1.h[e];
+        bdr[kk][1][e] = s0.m[e]; bdr[kk][1][4 + e] = s1.m[e];
+        bdr[kk][2][e] = s0.l[e]; bdr[kk][2][4 + e] = s1.l[e];
+      }
+    }
   }
-  if (XRC) {
-    if (k0 + (tid >> 2) < K) sXw[tid] = a.xw0[(size_t)k0 * 4 + tid];
+  // XRC: the first layer's weight rows of this thread's four k columns, in registers (read
+  // from an LDS table [k][4] the sixteen lanes of a row group hit four banks: 36 % of the LDS
+  // cycles of this variant were conflicts)
+  float4 w0r[XRC ? 4 : 1];
+  if constexpr (XRC) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      w0r[e] = (k0 + (tid & 15) * 4 + e < K)
+                   ? *reinterpret_cast<const float4 *>(a.xw0 + (size_t)(k0 + (tid & 15) * 4 + e) * 4)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
   f32x16 acc[KT];
@@ -1890,14 +1915,15 @@ __global__ __launch_bounds__(256) void sa_bwd_fused_kernel(FusedArgs a, Compact 
       sp_g[q] = (slot < 4 && (blk << 3) < rend) ? cm.bgrp[blk] : 0;
     }
   }
-  __syncthreads();   // Wp, sXw
   const int p16 = lane & 15, grp = lane >> 4;
   const int frow = 8 * (grp >> 1) + (p16 >> 2), fcol = 16 * (grp & 1) + 4 * (p16 & 3);
-  // input gradient: wave -> (k half j, n half nh) of the 32 x 64 tile
-  const int dj = wave & 1, dnh = wave >> 1;
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (rbeg < rend) fetch(rbeg);
-  for (int r0 = rbeg; r0 < rend; r0 += BR) {
+  // GPOOL: the step's sparse table.  Written for the FIRST step here; for every later step
+  // right behind the fetch that loaded its entries, i.e. between the staging barrier and the
+  // exchange barrier of the step before (every wave is past its table reads, none has started
+  // the next staging) -- no barrier of its own.
+  auto put_table = [&]() {
     if constexpr (GPOOL) {
 #pragma unroll
       for (int q = 0; q < SPQ; ++q) {
@@ -1905,8 +1931,13 @@ __global__ __launch_bounds__(256) void sa_bwd_fused_kernel(FusedArgs a, Compact 
         sLr[slot * TN + sp_n] = sp_lr[q];
         sDv[slot * TN + sp_n] = sp_dv[q];
       }
-      __syncthreads();
     }
+  };
+  if constexpr (GPOOL) {
+    put_table();
+    __syncthreads();
+  }
+  for (int r0 = rbeg; r0 < rend; r0 += BR) {
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       float4 v = rg[p];
@@ -1946,7 +1977,11 @@ __global__ __launch_bounds__(256) void sa_bwd_fused_kernel(FusedArgs a, Compact 
       const int row = xr + 16 * p;
       float4 x = rx[p];
       const bool live = r0 + row < rend && k0 + xc4 < K;
-      if (XRC && live) x = rc_y4(x, sXw, xc4);
+      if constexpr (XRC) {
+        if (live)
+          x = make_float4(rc_dot4(x, w0r[0]), rc_dot4(x, w0r[1]), rc_dot4(x, w0r[2]),
+                          rc_dot4(x, w0r[3]));
+      }
       ykeep[p] = x;   // the raw pre-BN values of layer l-1: the epilogue's mask and xhat
       if (live) {
         x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
@@ -2007,13 +2042,12 @@ __global__ __launch_bounds__(256) void sa_bwd_fused_kernel(FusedArgs a, Compact 
 #pragma unroll
       for (int kk = 0; kk < TN / 32; ++kk) {
         const int nb = (dnh * (TN / 32) + kk) * 16 + h * 8;   // first of this lane's 8 n
-        bf16x8 ad[3], bd[3];
+        bf16x8 ad[3];
+        const bf16x8 *bd = bdr[kk];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 3; ++q)
           ad[q] = *reinterpret_cast<const bf16x8 *>(
               &Gp[(q * BR + l31) * LG + (swz(l31, nb * 2) >> 1)]);
-          bd[q] = *reinterpret_cast<const bf16x8 *>(&Wp[(q * 64 + dj * 32 + l31) * LW + nb]);
-        }
 #define BTR_X6D(QA, QB) cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[QA], bd[QB], cd, 0, 0, 0);
         BTR_X6D(2, 0)
         BTR_X6D(0, 2)
@@ -2028,6 +2062,7 @@ __global__ __launch_bounds__(256) void sa_bwd_fused_kernel(FusedArgs a, Compact 
       for (int v = 0; v < 16; ++v)
         T[((v & 3) + 8 * (v >> 2) + 4 * h) * LC + dj * 32 + l31] = cd[v];
     }
+    if (r0 + BR < rend) put_table();   // (the entries the fetch above loaded)
     __syncthreads();
     // ---- epilogue: the thread that staged X[row][xc4..] owns dZ[row][k0 + xc4..]
 #pragma unroll
@@ -3196,6 +3231,19 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
                        const float *scale, const float *shift, const float *mean,
                        const float *invstd, float *part, float *m1, float *m2, float *dgamma,
                        float *dbeta, btr_stream_t stream) {
+  const int rc = btr_sa_bn_relu_bwd_sums(rows, c, ld, g, y, scale, shift, mean, invstd, part, m1,
+                                         m2, dgamma, dbeta, stream);
+  if (rc != BTR_OK) return rc;
+  return btr_sa_bn_relu_bwd_apply(rows, c, ld, g, y, scale, shift, mean, invstd, m1, m2, stream);
+}
+
+// The two halves of btr_sa_bn_relu_bwd: the statistics pass + finalisation (g is only read), and
+// the in-place apply pass.  A caller that hands (g, y, m1, m2) to btr_sa_bwd_fused -- which
+// applies BatchNorm's backward while it stages its operand -- only needs the first.
+int btr_sa_bn_relu_bwd_sums(long long rows, int c, int ld, const float *g, const float *y,
+                            const float *scale, const float *shift, const float *mean,
+                            const float *invstd, float *part, float *m1, float *m2,
+                            float *dgamma, float *dbeta, btr_stream_t stream) {
   if (rows <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(c <= kBnBwdMaxC && c % 4 == 0 && ld % 4 == 0,
               "sa_bn_relu_bwd: %d channels must be a multiple of 4 and <= %d", c, kBnBwdMaxC);
@@ -3206,10 +3254,21 @@ int btr_sa_bn_relu_bwd(long long rows, int c, int ld, float *g, const float *y,
                      scale, shift, mean, invstd, part, cur_compact());
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c, nblk,
                      count, part, m1, m2, dgamma, dbeta);
+  return check_launch("sa_bn_relu_bwd_sums");
+}
+
+int btr_sa_bn_relu_bwd_apply(long long rows, int c, int ld, float *g, const float *y,
+                             const float *scale, const float *shift, const float *mean,
+                             const float *invstd, const float *m1, const float *m2,
+                             btr_stream_t stream) {
+  if (rows <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(c <= kBnBwdMaxC && c % 4 == 0 && ld % 4 == 0,
+              "sa_bn_relu_bwd: %d channels must be a multiple of 4 and <= %d", c, kBnBwdMaxC);
+  hipStream_t st = as_stream(stream);
   const int gx = (int)std::min<long long>(cdiv(rows * (c / 4), 256), 256 * 16);
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx), dim3(256), 0, st, rows, c, ld, g, y,
                      scale, shift, mean, invstd, m1, m2, cur_compact());
-  return check_launch("sa_bn_relu_bwd");
+  return check_launch("sa_bn_relu_bwd_apply");
 }
 
 // ---- a hidden layer's whole backward as ONE pass (sa_bwd_fused_kernel) ------------------------

@@ -81,6 +81,8 @@ _SIGNATURES = {
     "btr_sa_bwd_fused": (_ci, [_ci, _ci, _ci, _vp, _ci] + [_vp] * 7 + [_ci] + [_vp] * 5 +
                          [_ci] + [_vp] * 6 + [_ci, _vp, _ci] + [_vp] * 8),
     "btr_sa_bn_relu_bwd_rc_apply": (_ci, [_ll, _ci, _ci] + [_vp] * 12),
+    "btr_sa_bn_relu_bwd_sums": (_ci, [_ll, _ci, _ci] + [_vp] * 12),
+    "btr_sa_bn_relu_bwd_apply": (_ci, [_ll, _ci, _ci] + [_vp] * 9),
     "btr_sa_gemm_nt_pool": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _ci, _vp, _vp,
                                   _vp, _vp, _vp]),
     "btr_sa_gemm_tn_pool": (_ci, [_ci, _ci, _ci, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci,

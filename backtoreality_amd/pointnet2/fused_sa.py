@@ -242,6 +242,15 @@ class FusedSAFunction(Function):
                       _p(dg), _p(db), st)
             grads[3 * (L - 1) + 1], grads[3 * (L - 1) + 2] = dg, db
             dY = Ys[-1]
+            # `lazy`: dY holds dZ_l (gradient w.r.t. layer l's activation) with BatchNorm_l's
+            # backward sums in lazy = (m1, m2); btr_sa_bwd_fused applies them while it stages
+            # its operand, any other consumer gets them applied in place first (the same
+            # sequence as csrc/sa_layer.hip sa_layer_backward_add)
+            lazy = None
+
+            def fusable(j):
+                return j >= 1 and bool(_lib.btr_sa_bwd_fused_supported(
+                    R, Ws[j].shape[0], Ws[j].shape[1]))
             for l in range(L - 1, -1, -1):
                 Nl = dY.shape[1]
                 W2 = Ws[l]
@@ -253,7 +262,50 @@ class FusedSAFunction(Function):
                     pa, pb = stats[l - 1][0], stats[l - 1][1]
                 pooled = pool is not None and l == L - 1  # dY is still Y_last + coefficients
                 if ctx.rc and l == 0:
-                    break  # layer 0 was finished by btr_sa_bn_relu_bwd_rc below
+                    if lazy is not None:   # the recomputed first layer behind a fused call
+                        sc, sh, mu, isd = stats[0]
+                        C0 = Ws[0].shape[0]
+                        nb = _lib.btr_sa_rc_wgrad_blocks(R, C0)
+                        pw0 = _f32((nb, C0, 4), dev)
+                        dW0 = _f32((C0, 4), dev)
+                        _call(_lib.btr_sa_bn_relu_bwd_rc_apply, R, C0, C0, _p(dY), _p(X0),
+                              _p(Ws[0]), _p(sc), _p(sh), _p(mu), _p(isd), _p(lazy[0]),
+                              _p(lazy[1]), _p(pw0), _p(dW0), st)
+                        grads[0] = dW0[:, :pshapes[0][1]].reshape(pshapes[0])
+                    break  # (otherwise finished by btr_sa_bn_relu_bwd_rc below)
+                if fusable(l) and (pooled or lazy is not None):
+                    # the whole backward of layer l in one pass: dW_l, dZ_{l-1}, BatchNorm_{l-1}'s
+                    # sums (csrc/sa_mlp.hip sa_bwd_fused_kernel)
+                    chunks = _lib.btr_sa_bwd_fused_chunks(R, Nl, K)
+                    pw = _f32((chunks, Nl, K), dev)
+                    dW = _f32((Nl, K), dev)
+                    Wt = W2.t().contiguous()  # (K, Nl)
+                    G = _f32((R, K), dev)
+                    part = _f32((chunks, 2, K), dev)
+                    m1, m2, dg, db = (_f32((K,), dev) for _ in range(4))
+                    scl, shl, mul, isl = stats[l]
+                    scp, shp, mup, isp = stats[l - 1]
+                    rc1 = ctx.rc and l == 1
+                    _call(_lib.btr_sa_bwd_fused, R, Nl, K, _p(dY), Nl,
+                          None if pooled else _p(Ys[l]), _p(scl), _p(shl), _p(mul), _p(isl),
+                          None if pooled else _p(lazy[0]), None if pooled else _p(lazy[1]), S,
+                          _p(arg) if pooled else None, _p(pool[0]) if pooled else None,
+                          _p(pool[1]) if pooled else None, _p(pool[2]) if pooled else None,
+                          _p(X0) if rc1 else _p(Xsrc), 4 if rc1 else ldx,
+                          _p(Ws[0]) if rc1 else None, _p(pa), _p(pb), _p(mup), _p(isp), _p(Wt),
+                          Nl, _p(G), K, _p(pw), _p(dW), _p(part), _p(m1), _p(m2), _p(dg), _p(db),
+                          st, key=(Rk, Nl, K, R))
+                    kin = pshapes[3 * l][1]
+                    grads[3 * l] = dW[:, :kin].reshape(pshapes[3 * l])
+                    grads[3 * (l - 1) + 1], grads[3 * (l - 1) + 2] = dg, db
+                    dY = G
+                    lazy = (m1, m2)
+                    continue
+                if lazy is not None:   # a consumer that wants dY_l itself
+                    scl, shl, mul, isl = stats[l]
+                    _call(_lib.btr_sa_bn_relu_bwd_apply, R, Nl, Nl, _p(dY), _p(Ys[l]), _p(scl),
+                          _p(shl), _p(mul), _p(isl), _p(lazy[0]), _p(lazy[1]), st)
+                    lazy = None
                 # weight gradient: dW[n][k] = sum_r dY[r][n] * X_l[r][k]
                 chunks = _lib.btr_sa_gemm_tn_chunks(R, Nl, K)
                 pw = _f32((chunks, Nl, K), dev)
@@ -296,6 +348,11 @@ class FusedSAFunction(Function):
                                   _p(m2), _p(dg), _p(db), _p(pw0), _p(dW0), st)
                             kin0 = pshapes[0][1]
                             grads[0] = dW0[:, :kin0].reshape(pshapes[0])
+                        elif fusable(l - 1):   # the next layer applies the sums itself
+                            _call(_lib.btr_sa_bn_relu_bwd_sums, R, K, K, _p(G), _p(Ys[l - 1]),
+                                  _p(sc), _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2),
+                                  _p(dg), _p(db), st)
+                            lazy = (m1, m2)
                         else:
                             _call(_lib.btr_sa_bn_relu_bwd, R, K, K, _p(G), _p(Ys[l - 1]),
                                   _p(sc), _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2),

@@ -328,6 +328,16 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
                      const float *mu_p, const float *is_p, const float *wt, int ldw, float *dz,
                      int ldz, float *pw, float *dw, float *spart, float *m1, float *m2,
                      float *dgamma, float *dbeta, btr_stream_t stream);
+/* The two halves of btr_sa_bn_relu_bwd (statistics + finalisation; in-place apply): a caller
+ * that hands (g, y, m1, m2) to btr_sa_bwd_fused only needs the first. */
+int btr_sa_bn_relu_bwd_sums(long long rows, int c, int ld, const float *g, const float *y,
+                            const float *scale, const float *shift, const float *mean,
+                            const float *invstd, float *part, float *m1, float *m2,
+                            float *dgamma, float *dbeta, btr_stream_t stream);
+int btr_sa_bn_relu_bwd_apply(long long rows, int c, int ld, float *g, const float *y,
+                             const float *scale, const float *shift, const float *mean,
+                             const float *invstd, const float *m1, const float *m2,
+                             btr_stream_t stream);
 /* btr_sa_bn_relu_bwd_rc without its statistics pass: m1, m2 are given (btr_sa_bwd_fused). */
 int btr_sa_bn_relu_bwd_rc_apply(long long rows, int c, int ldg, const float *g, const float *x0,
                                 const float *w0, const float *scale, const float *shift,
