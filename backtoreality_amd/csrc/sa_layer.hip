@@ -699,9 +699,20 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       flip ^= 1;
       // g is the buffer dY_{l+1} lived in: its weight gradient must be through with it
       if (side && l + 1 <= L - 2) (void)hipStreamWaitEvent(hmain, side->done[l + 1], 0);
+      // the first layer's input gradient when nobody asks for the coordinate part (a backbone
+      // level: xyz carries no gradient): only the feature columns 3 .. 3 + c of dX0 are computed,
+      // as a dense (rows, c) tile -- with k0p = 3 + c (132, 260) the xyz columns cost a whole
+      // extra column block whose 124 other columns are padding
+      static const bool feat_off = getenv("BTR_DGRAD0_FEAT") && getenv("BTR_DGRAD0_FEAT")[0] == '0';
+      const bool feat_only = !feat_off && l == 0 && !pooled && d.use_xyz && d.c > 0 &&
+                             d.c % 4 == 0 && !d.need_dxyz && !d.need_dnew_xyz;
+      const int gld = feat_only ? d.c : k;
       if (pooled)
         BTR_TRY(btr_sa_gemm_nt_pool(R, k, nl, dy, nl, wt, nl, g, k, d.s, arg, dcl, alpha, beta,
                                     stream));
+      else if (feat_only)
+        BTR_TRY(btr_sa_gemm_nt(R, d.c, nl, dy, nl, wt + (size_t)3 * nl, nl, g, d.c, nullptr,
+                               nullptr, nullptr, stream));
       else
         BTR_TRY(btr_sa_gemm_nt(R, k, nl, dy, nl, wt, nl, g, k, nullptr, nullptr, nullptr,
                                stream));
@@ -729,11 +740,11 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
         const int mode = pre ? kScatterReduce : kScatterBoth;
         if (p.compact) {
           if (dfeat_cl)
-            BTR_TRY(sac_scatter_ex(d.b, d.n, d.m, d.c, p.k0p, d.use_xyz, g, cp.cidx, cp.goff,
-                                   dfeat_cl, ws2, sc.scat_bytes, R, mode, hmain));
+            BTR_TRY(sac_scatter_ex(d.b, d.n, d.m, d.c, gld, feat_only ? 0 : d.use_xyz, g, cp.cidx,
+                                   cp.goff, dfeat_cl, ws2, sc.scat_bytes, R, mode, hmain));
         } else {
-          BTR_TRY(sa_scatter_ex(d.b, d.n, d.m, d.s, d.c, p.k0p, d.use_xyz, d.radius_div, g, idx,
-                                dfeat_cl, d.need_dxyz ? dxyz : nullptr,
+          BTR_TRY(sa_scatter_ex(d.b, d.n, d.m, d.s, d.c, gld, feat_only ? 0 : d.use_xyz,
+                                d.radius_div, g, idx, dfeat_cl, d.need_dxyz ? dxyz : nullptr,
                                 d.need_dnew_xyz ? dnew_xyz : nullptr, ws2, sc.scat_bytes, mode,
                                 hmain));
         }

@@ -1478,7 +1478,10 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(
     float *__restrict__ pw, const unsigned char *__restrict__ garg,
     const float *__restrict__ gdcl, const float *__restrict__ galpha,
     const float *__restrict__ gbeta, int SSH, const float *__restrict__ xw0, Compact cm) {
-  if (cm.dims) R = cm.dims[0];  // compact rows: the row count lives on the device
+  if (cm.dims) {  // compact rows: the row count lives on the device, and so does the split of
+    R = cm.dims[0];  // the rows over the chunks (by the host's dense bound half the grid idles)
+    rows_per_chunk = ((R + (int)gridDim.z - 1) / (int)gridDim.z + 31) / 32 * 32;
+  }
   constexpr int BR = 32;
   constexpr int TN = 32 * TNW;
   constexpr int LG = TN == 128 ? 160 : 96, LX = 96;   // bf16 row pitches: 320 B / 192 B

@@ -325,11 +325,20 @@ class FusedSAFunction(Function):
                 # input gradient: dX_l[r][k] = sum_n dY[r][n] * W[n][k]
                 if l > 0 or need_xyz or need_new or need_feat:
                     Wt = W2.t().contiguous()  # (K, Nl)
-                    G = _f32((R, K), dev)
+                    # first layer, nobody asks for the coordinate part: only the feature columns
+                    # of dX0, as a dense (R, C) tile (see csrc/sa_layer.hip feat_only)
+                    feat_only = (os.environ.get("BTR_DGRAD0_FEAT", "1") != "0" and
+                                 l == 0 and not pooled and use_xyz and C > 0 and C % 4 == 0 and
+                                 not (need_xyz and use_xyz) and not (need_new and use_xyz))
+                    gld = C if feat_only else K
+                    G = _f32((R, gld), dev)
                     if pooled:
                         _call(_lib.btr_sa_gemm_nt_pool, R, K, Nl, _p(dY), Nl, _p(Wt), Nl, _p(G),
                               K, S, _p(arg), _p(pool[0]), _p(pool[1]), _p(pool[2]), st,
                               key=(Rk, K, Nl, R))
+                    elif feat_only:
+                        _call(_lib.btr_sa_gemm_nt, R, C, Nl, _p(dY), Nl, Wt.data_ptr() + 12 * Nl,
+                              Nl, _p(G), C, None, None, None, st, key=(Rk, C, Nl, R))
                     else:
                         _call(_lib.btr_sa_gemm_nt, R, K, Nl, _p(dY), Nl, _p(Wt), Nl, _p(G), K,
                               None, None, None, st, key=(Rk, K, Nl, R))
@@ -371,13 +380,15 @@ class FusedSAFunction(Function):
                             wsb = _lib.btr_sac_scatter_workspace_bytes(B, N, R)
                             ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
                             if dfeat_cl is not None:
-                                _call(_lib.btr_sac_scatter, B, N, M, C, K0p, use_xyz, _p(G),
+                                _call(_lib.btr_sac_scatter, B, N, M, C, gld,
+                                      0 if feat_only else use_xyz, _p(G),
                                       _p(cplan["cidx"]), _p(cplan["goff"]), _p(dfeat_cl), _p(ws),
                                       wsb, R, st)
                         else:
                             wsb = _lib.btr_sa_scatter_workspace_bytes(B, N, M, S)
                             ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
-                            _call(_lib.btr_sa_scatter, B, N, M, S, C, K0p, use_xyz, rdiv, _p(G),
+                            _call(_lib.btr_sa_scatter, B, N, M, S, C, gld,
+                                  0 if feat_only else use_xyz, rdiv, _p(G),
                                   _p(idx), _p(dfeat_cl), _p(dxyz), _p(dnew), _p(ws), wsb, st)
                         if dfeat_cl is not None:
                             dfeat = dfeat_cl.transpose(1, 2).contiguous()

@@ -527,7 +527,11 @@ def pmc_traffic(substr, grid=None):
 # every f32-MFMA GEMM entry point of the fused SA path (csrc/sa_mlp.hip): forward NT (plain,
 # recompute, pool-epilogue), dgrad NT (plain, pooled), wgrad TN (plain, pooled, recompute)
 GEMM_OPS = ("sa_gemm_nt", "sa_gemm_nt_rc", "sa_gemm_nt_poolfwd", "sa_gemm_nt_pool",
-            "sa_gemm_tn", "sa_gemm_tn_rc", "sa_gemm_tn_pool", "pm_gemm_nt")
+            "sa_gemm_tn", "sa_gemm_tn_rc", "sa_gemm_tn_pool", "pm_gemm_nt", "sa_bwd_fused")
+# sa_bwd_fused (csrc/sa_mlp.hip sa_bwd_fused_kernel) is TWO products per launch -- the weight
+# gradient and the input gradient of a layer over one pass of its rows -- and moves
+# dZ_l / Y_l (one of them twice: BatchNorm's backward needs both), Y_{l-1} and dZ_{l-1}
+FLOP_FACTOR = {"sa_bwd_fused": 2.0}
 
 
 def roofline_objects(kernels, detail, detail_steps, pair_overhead_ms=0.0):
@@ -583,30 +587,33 @@ def roofline_objects(kernels, detail, detail_steps, pair_overhead_ms=0.0):
                                                "build (2 launches)")}
     # grouped shared MLP: every f32-MFMA GEMM launch of the fused SA path (fwd NT with BN
     # prologue/epilogue, dgrad NT, wgrad TN); flops = 2*rows*n*k per launch
-    gemm = [(k, t) for (o, k), t in detail.items() if o in GEMM_OPS]
+    gemm = [(k, t, FLOP_FACTOR.get(o, 1.0)) for (o, k), t in detail.items() if o in GEMM_OPS]
     if gemm:
         steps = detail_steps
-        flops = sum(2.0 * k[0] * k[1] * k[2] * len(t) for k, t in gemm) / steps
+        flops = sum(2.0 * f * k[0] * k[1] * k[2] * len(t) for k, t, f in gemm) / steps
         # the same launches priced at the rows the REFERENCE's formulation has (every padded
         # copy of a neighbour is a row there; compact rows evaluate distinct neighbours only)
-        dense = sum(2.0 * (k[3] if len(k) > 3 else k[0]) * k[1] * k[2] * len(t)
-                    for k, t in gemm) / steps
-        ms = sum(sum(t) for _, t in gemm) / steps
+        dense = sum(2.0 * f * (k[3] if len(k) > 3 else k[0]) * k[1] * k[2] * len(t)
+                    for k, t, f in gemm) / steps
+        ms = sum(sum(t) for _, t, _f in gemm) / steps
         ach = flops / (ms * 1e-3) / 1e12
-        # the same launches against the HBM roof: f32 operands + result moved once
-        gbytes = sum(4.0 * (k[0] * (k[1] + k[2]) + k[1] * k[2]) * len(t) for k, t in gemm) / steps
+        # the same launches against the HBM roof: f32 operands + result moved once (the fused
+        # backward: its dY source of n columns, Y_{l-1} and dZ_{l-1} of k columns each)
+        gbytes = sum(4.0 * (k[0] * (k[1] + k[2] * f) + k[1] * k[2]) * len(t)
+                     for k, t, f in gemm) / steps
         hbm = gbytes / (ms * 1e-3) / 1e9
         res["mlp_roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF,
                                "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF,
                                "traffic": None,
-                               "kernel": "gemm_nt_kernel (incl. poolfwd / rc / pool) + gemm_tn_kernel",
+                               "kernel": "gemm_nt_kernel (incl. poolfwd / rc / pool) + gemm_tn_kernel + "
+                                         "sa_bwd_fused_kernel (two products per launch)",
                                "hbm_achieved_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_step": gbytes,
                                "gflop_per_step": flops / 1e9, "ms_per_step": ms,
                                "dense_rows_gflop_per_step": dense / 1e9,
                                "dense_rows_equivalent_frac": dense / (ms * 1e-3) / 1e12 /
                                MFMA_F32_PEAK_TF,
-                               "launches_per_step": sum(len(t) for _, t in gemm) / steps,
+                               "launches_per_step": sum(len(t) for _, t, _f in gemm) / steps,
                                "event_pair_overhead_us_subtracted_per_launch":
                                    1e3 * pair_overhead_ms}
     fps_op = pick("furthest_point_sampling")   # spatial sort (4 launches) + sampling kernel

@@ -2,12 +2,12 @@
 # SQ counters of the kernels whose name contains $2, run by `python3 $1`: where do the
 # wave-cycles go?  Two --pmc passes (8 SQ slots each).  Output: markdown on stdout.
 #   bash tools/pmc_kernels.sh tools/bwd_fused_ab.py sa_bwd_fused > gpurun_out/x.md
-TOOL=$1; PAT=$2
+TOOL=$1; PAT=$2; TOOLARGS=${3:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kpmc1 /tmp/kpmc2
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES -d /tmp/kpmc1 -o r -- python3 $ROOT/$TOOL > /tmp/kpmc1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU -d /tmp/kpmc2 -o r -- python3 $ROOT/$TOOL > /tmp/kpmc2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES -d /tmp/kpmc1 -o r -- python3 $ROOT/$TOOL $TOOLARGS > /tmp/kpmc1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU -d /tmp/kpmc2 -o r -- python3 $ROOT/$TOOL $TOOLARGS > /tmp/kpmc2.log 2>&1
 cd $ROOT
 python3 - "$PAT" $(find /tmp/kpmc1 -name "*.db" | head -1) $(find /tmp/kpmc2 -name "*.db" | head -1) <<'PY'
 import sqlite3, sys
