@@ -33,6 +33,8 @@ namespace btr {
 constexpr int kSuper = 16;          // buckets per super-bucket
 constexpr int kMaxSupers = 128;     // super-buckets per scene the query kernel can hold
 constexpr int kBqbWaves = 4;
+// candidate buckets loaded per dependent round trip: template parameter kTrip (BTR_BQ_TRIP = 2 |
+// 4 | 8 for A/B; default 4)
 
 __device__ __forceinline__ float wave_min_f32(float v) {
 #pragma unroll
@@ -80,6 +82,7 @@ __device__ __forceinline__ float box_d2(const Box8 &q, float x, float y, float z
 
 // Dynamic LDS per workgroup: nsup Box8 (super boxes) + kBqbWaves * (words + twords) bitmap
 // words (zero on entry, restored to zero after every centre).
+template <int kTrip>
 __global__ __launch_bounds__(kBqbWaves * 64) void bqb_query_kernel(
     int B, int n, int np, int nb, int nsup, int m, int nsample, int words, int twords,
     float radius2, float cull2, const float *__restrict__ new_xyz,
@@ -159,26 +162,36 @@ __global__ __launch_bounds__(kBqbWaves * 64) void bqb_query_kernel(
         const bool cand =
             mys >= 0 && b < nb && (!trusted || box_d2(bx[b], cx, cy, cz) < cull2);
         unsigned long long bmask = __ballot(cand);
-        // ---- candidates: 64 points per bucket, two buckets per trip (8 loads in flight)
+        // ---- candidates: 64 points per bucket, kTrip buckets per trip.  The kernel is bound by
+        // its dependent L2 round trips (SQ counters, profiles/r04_bq_counters.md: 74 % of the
+        // wave-cycles parked in s_waitcnt, 18 % issuing): a centre has 10-14 candidate buckets,
+        // two per trip were 5-7 round trips in a row, four are 3 (16 loads in flight per lane)
         while (bmask) {
-          const int s1 = __builtin_ctzll(bmask);
-          bmask &= bmask - 1;
-          const bool two = bmask != 0;
-          const int s2 = two ? __builtin_ctzll(bmask) : s1;
-          bmask &= bmask - 1;
-          const int b1 = __builtin_amdgcn_readlane(b, s1), b2 = __builtin_amdgcn_readlane(b, s2);
-          const float *p1 = sp + (size_t)b1 * 256 + lane, *p2 = sp + (size_t)b2 * 256 + lane;
-          const float x1 = p1[0], y1 = p1[64], z1 = p1[128];
-          const int k1 = __float_as_int(p1[192]);
-          const float x2 = p2[0], y2 = p2[64], z2 = p2[128];
-          const int k2 = __float_as_int(p2[192]);
-          if (k1 >= 0 && sq3(cx - x1, cy - y1, cz - z1) < radius2) {
-            atomicOr(&bm[k1 >> 5], 1u << (k1 & 31));
-            atomicOr(&top[k1 >> 10], 1u << ((k1 >> 5) & 31));
+          int bb[kTrip];
+          bool on[kTrip];
+#pragma unroll
+          for (int t = 0; t < kTrip; ++t) {
+            on[t] = bmask != 0;
+            const int sl = on[t] ? __builtin_ctzll(bmask) : 0;
+            bb[t] = on[t] ? __builtin_amdgcn_readlane(b, sl) : bb[0];   // (a valid bucket to read)
+            bmask &= bmask - 1;   // (0 stays 0)
           }
-          if (two && k2 >= 0 && sq3(cx - x2, cy - y2, cz - z2) < radius2) {
-            atomicOr(&bm[k2 >> 5], 1u << (k2 & 31));
-            atomicOr(&top[k2 >> 10], 1u << ((k2 >> 5) & 31));
+          float px[kTrip], py[kTrip], pz[kTrip];
+          int pk[kTrip];
+#pragma unroll
+          for (int t = 0; t < kTrip; ++t) {
+            const float *pp = sp + (size_t)bb[t] * 256 + lane;
+            px[t] = pp[0];
+            py[t] = pp[64];
+            pz[t] = pp[128];
+            pk[t] = __float_as_int(pp[192]);
+          }
+#pragma unroll
+          for (int t = 0; t < kTrip; ++t) {
+            if (on[t] && pk[t] >= 0 && sq3(cx - px[t], cy - py[t], cz - pz[t]) < radius2) {
+              atomicOr(&bm[pk[t] >> 5], 1u << (pk[t] & 31));
+              atomicOr(&top[pk[t] >> 10], 1u << ((pk[t] >> 5) & 31));
+            }
           }
         }
       }
@@ -270,10 +283,17 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
                        own);
     boxes = own;
   }
+  static const int trip = [] {
+    const char *e = getenv("BTR_BQ_TRIP");
+    const int v = e ? atoi(e) : 4;
+    return (v == 2 || v == 8) ? v : 4;
+  }();
+  const void *fn = trip == 2   ? (const void *)bqb_query_kernel<2>
+                   : trip == 8 ? (const void *)bqb_query_kernel<8>
+                               : (const void *)bqb_query_kernel<4>;
   static size_t lds_set = 0;
   if (p.lds > lds_set && p.lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)bqb_query_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
     if (e != hipSuccess)
       return fail((int)e, "ball_query(buckets) attr: %s", hipGetErrorString(e));
     lds_set = p.lds;
@@ -281,9 +301,12 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   const float radius2 = radius * radius;          // ball_query_gpu.cu:27
   const float cull2 = radius2 * 1.00001f + 1e-30f;  // conservative box cull (see the header)
   const int chunks = std::max(1, std::min(cdiv(m, kBqbWaves), 2048 / std::max(1, b)));
-  hipLaunchKernelGGL(bqb_query_kernel, dim3(chunks * b), dim3(kBqbWaves * 64), p.lds, s, b, n,
-                     p.np, p.nb, p.nsup, m, nsample, p.words, p.twords, radius2, cull2, new_xyz,
-                     spts, boxes, epoch, idx);
+#define BTR_BQB(T)                                                                              \
+  hipLaunchKernelGGL(bqb_query_kernel<T>, dim3(chunks * b), dim3(kBqbWaves * 64), p.lds, s, b, n, \
+                     p.np, p.nb, p.nsup, m, nsample, p.words, p.twords, radius2, cull2, new_xyz, \
+                     spts, boxes, epoch, idx)
+  if (trip == 2) BTR_BQB(2); else if (trip == 8) BTR_BQB(8); else BTR_BQB(4);
+#undef BTR_BQB
   return check_launch("ball_query(buckets)");
 }
 

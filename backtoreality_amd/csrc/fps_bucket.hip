@@ -18,6 +18,8 @@
 // Selection rule / tie-break: identical to sampling.hip (reference sampling_gpu.cu:74-178).
 #include <algorithm>
 #include <atomic>
+#include <cstdint>
+#include <vector>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1356,18 +1358,83 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   static std::atomic<unsigned> epoch_counter{0x5a000000u};
   unsigned epoch = epoch_counter.fetch_add(1u) + 1u;
   if (epoch == 0u) epoch = epoch_counter.fetch_add(1u) + 1u;
+  // BTR_CU_MASK: the sampling kernel alone moves to the stream that owns the reserved CUs (its
+  // sort launches and everything behind it stay where they are); fork / join with two events.
+  // Not while a HIP graph is captured (the events are not part of the capture's streams).
+  hipStream_t ks = s;
+  static thread_local hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  if (hipStream_t fs = cu_mask_fps_stream()) {
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cst) == hipSuccess && cst == hipStreamCaptureStatusNone) {
+      if (!fork_ev) {
+        (void)hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&join_ev, hipEventDisableTiming);
+      }
+      (void)hipEventRecord(fork_ev, s);
+      (void)hipStreamWaitEvent(fs, fork_ev, 0);
+      ks = fs;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  if (ev[0] && ks != s) (void)hipEventRecord(ev[0], ks);   // (time the kernel on ITS stream)
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
+                       0, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
                        (unsigned long long *)nullptr, boxes, epoch);
   else
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
+                       0, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
                        (unsigned long long *)nullptr, boxes, epoch);
-  if (ev[1]) (void)hipEventRecord(ev[1], s);
+  if (ev[1]) (void)hipEventRecord(ev[1], ks);
   ev[0] = ev[1] = nullptr;
+  if (ks != s) {
+    (void)hipEventRecord(join_ev, ks);
+    (void)hipStreamWaitEvent(s, join_ev, 0);
+  }
   fps_boxes_note(workspace, b, n, boxes, epoch);
   return check_launch("furthest_point_sampling(bucket)");
+}
+
+// ---- CU partitioning (internal.hpp)
+int cu_mask_reserved() {
+  static const int c = [] {
+    const char *e = getenv("BTR_CU_MASK");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 && v <= 8 ? v : 0;
+  }();
+  return c;
+}
+hipStream_t cu_mask_create_stream(bool reserved) {
+  const int c = cu_mask_reserved();
+  hipStream_t st = nullptr;
+  if (c == 0) {
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return st;
+  }
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    return nullptr;
+  const int words = (cus + 31) / 32;
+  std::vector<uint32_t> mask(words, 0u);
+  for (int i = 0; i < cus; ++i) {
+    const bool low = i < 8 * c;   // bits 0 .. 8c-1: CUs 0 .. c-1 of each of the 8 XCDs
+    if (low == reserved) mask[i >> 5] |= 1u << (i & 31);
+  }
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return st;
+}
+hipStream_t cu_mask_fps_stream() {
+  if (cu_mask_reserved() == 0) return nullptr;
+  static thread_local hipStream_t per_dev[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!per_dev[dev]) per_dev[dev] = cu_mask_create_stream(true);
+  return per_dev[dev];
 }
 
 // ---- which workspaces hold bucket boxes (internal.hpp): the last few launches of this thread
@@ -1409,6 +1476,11 @@ const Box8 *fps_boxes_lookup(const void *workspace, int b, int n, unsigned *epoc
 }
 
 }  // namespace btr
+
+extern "C" int btr_cu_mask_reserved(void) { return btr::cu_mask_reserved(); }
+extern "C" void *btr_cu_mask_create_stream(int reserved) {
+  return (void *)btr::cu_mask_create_stream(reserved != 0);
+}
 
 extern "C" void btr_fps_time_next_kernel(void *start_event, void *stop_event) {
   btr::fps_kernel_events()[0] = (hipEvent_t)start_event;

@@ -6,6 +6,17 @@
 
 namespace btr {
 
+// fps_bucket.hip: CU partitioning between the sampling kernel and everything else
+// (BTR_CU_MASK = c > 0: the large-scene FPS kernel -- one 1024-thread workgroup per scene, a
+// dependent chain of ~2 000 steps -- runs on a stream restricted to the first c CUs of every XCD,
+// every other stream the library or the training loop creates on the complement.  Without it
+// the eight FPS workgroups share their CUs with whatever the other streams put there, both slow
+// down, and a streaming kernel waits for the few workgroups that landed beside an FPS scene).
+// Mask bit i = CU (i / 8) of XCD (i % 8): tools/probe/cu_mask_probe.hip.
+int cu_mask_reserved();                       // c (0: off)
+hipStream_t cu_mask_fps_stream();             // the reserved CUs (one per device and host thread)
+hipStream_t cu_mask_create_stream(bool reserved);   // a NEW stream on the reserved / other CUs
+
 // sa_mlp.hip: out_bcn (B, C, N) [and out_cl (B*N, C)] = f(scale * y + shift) [+ add];
 // add (optional): a (B, C, N)-shaped operand whose batch elements are add_bstride floats apart
 // (a channel slab of a wider (B, C', N) tensor), added to out_bcn only.

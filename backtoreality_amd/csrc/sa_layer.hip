@@ -266,7 +266,8 @@ SideStream *side_stream() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   SideStream &c = ctx[dev];
   if (!c.s) {
-    if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    c.s = cu_mask_create_stream(false);   // (BTR_CU_MASK: not on the sampling kernel's CUs)
+    if (!c.s) return nullptr;
     for (int i = 0; i <= kMaxL; ++i) {
       (void)hipEventCreateWithFlags(&c.ready[i], hipEventDisableTiming);
       (void)hipEventCreateWithFlags(&c.done[i], hipEventDisableTiming);

@@ -1739,13 +1739,20 @@ struct FusedArgs {
   const float *sc, *sh, *mu, *is, *m1, *m2;
 };
 
+// TNW = 2 / 4: n <= 64 / 128, two workgroups per CU.  TNW = 8: n <= 256 (the pooled layers of
+// SA2-SA4, the 256-wide point-wise chains) -- every wave owns two n tiles of the weight gradient
+// and eight reduction steps of W^T fragments, ~380 VGPRs and 91 KB of LDS: one workgroup per CU.
+// Those layers have 8 000 - 115 000 rows; what they gain is the passes and launches they lose.
 template <int TNW, int GM, bool XRC>
-__global__ __launch_bounds__(256, 2) void sa_bwd_fused_kernel(FusedArgs a, Compact cm) {
+__global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(FusedArgs a,
+                                                                             Compact cm) {
   constexpr int BR = 32;
   constexpr int TN = 32 * TNW;
-  constexpr int LG = TN == 128 ? 160 : 96, LX = 96;   // bf16 row pitches: 320 B / 192 B
+  // bf16 row pitches: 576 / 320 / 192 B -- (pitch / 4) % 64 in {16, 48}: transpose-read friendly
+  constexpr int LG = TN == 256 ? 288 : (TN == 128 ? 160 : 96), LX = 96;
   constexpr int LC = 68;                              // f32 pitch of the dgrad exchange tile
-  constexpr int KT = TNW == 4 ? 2 : 1;
+  constexpr int KT = TNW >= 4 ? 2 : 1;                // 32-wide k tiles per wave (weight gradient)
+  constexpr int NTW = TNW >= 4 ? TNW / 4 : 1;         // 32-wide n tiles per wave
   constexpr bool GPOOL = GM == 1;
   // compact rows: the row count lives on the device, and so does the split of the rows over
   // the workgroups -- sized by the host's dense bound, a third of the grid would find no rows and
@@ -1762,8 +1769,8 @@ __global__ __launch_bounds__(256, 2) void sa_bwd_fused_kernel(FusedArgs a, Compa
   __shared__ __attribute__((aligned(16))) int sLr[GPOOL ? 4 * TN : 4];
   __shared__ __attribute__((aligned(16))) float sDv[GPOOL ? 4 * TN : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = TNW == 4 ? wave : (wave >> 1);
-  const int wk = TNW == 4 ? 0 : (wave & 1);
+  const int wn = TNW >= 4 ? wave * NTW : (wave >> 1);   // first n tile of this wave
+  const int wk = TNW >= 4 ? 0 : (wave & 1);
   const int l31 = lane & 31, h = lane >> 5;
   const int k0 = blockIdx.y * 64;
   const int chunk = blockIdx.z;
@@ -1809,11 +1816,13 @@ __global__ __launch_bounds__(256, 2) void sa_bwd_fused_kernel(FusedArgs a, Compa
                    : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  f32x16 acc[KT];
+  f32x16 acc[NTW][KT];
 #pragma unroll
-  for (int q = 0; q < KT; ++q)
+  for (int t = 0; t < NTW; ++t)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+    for (int q = 0; q < KT; ++q)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[t][q][v] = 0.f;
 
   const int xc4 = (tid & 15) * 4, xr = tid >> 4;
   constexpr int GT = TN / 4, GR = 256 / GT, GPASS = BR / GR;
@@ -2005,13 +2014,14 @@ __global__ __launch_bounds__(256, 2) void sa_bwd_fused_kernel(FusedArgs a, Compa
     // ---- weight gradient: reduction over the 32 rows (transpose reads of both operands)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[3], bf[3][KT];
+      bf16x8 af[3][NTW], bf[3][KT];
       const int trow = ks * 16 + frow;   // (+4 for the second half: same swizzle class + 1)
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
           typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
-          const int c2 = (wn * 32 + fcol) * 2;
+          const int c2 = ((wn + t) * 32 + fcol) * 2;
           const __bf16 *b0 = &Gp[(q * BR + trow) * LG + (swz(trow, c2) >> 1)];
           const __bf16 *b1 = &Gp[(q * BR + trow + 4) * LG + (swz(trow + 4, c2) >> 1)];
           union {
@@ -2020,15 +2030,15 @@ __global__ __launch_bounds__(256, 2) void sa_bwd_fused_kernel(FusedArgs a, Compa
           } u;
           u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b0));
           u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b1));
-          af[q] = u.b;
+          af[q][t] = u.b;
         }
 #pragma unroll
         for (int t = 0; t < KT; ++t)
           bf[q][t] = tr_read8(&Xp[(q * BR + trow) * LX + (wk + t) * 32 + fcol], LX);
       }
-#define BTR_X6(QA, QB)                       \
-  _Pragma("unroll") for (int t = 0; t < KT; ++t) acc[t] = \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA], bf[QB][t], acc[t], 0, 0, 0);
+#define BTR_X6(QA, QB)                                                                       \
+  _Pragma("unroll") for (int u = 0; u < NTW; ++u) _Pragma("unroll") for (int t = 0; t < KT; ++t) \
+      acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA][u], bf[QB][t], acc[u][t], 0, 0, 0);
       BTR_X6(2, 0)
       BTR_X6(0, 2)
       BTR_X6(1, 1)
@@ -2094,14 +2104,16 @@ __global__ __launch_bounds__(256, 2) void sa_bwd_fused_kernel(FusedArgs a, Compa
   // ---- weight-gradient partial of this chunk
   float *out = a.pw + (size_t)chunk * N * K;
 #pragma unroll
-  for (int q = 0; q < KT; ++q) {
-    const int col = k0 + (wk + q) * 32 + l31;
+  for (int t = 0; t < NTW; ++t)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int row = wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-      if (row < N && col < K) out[(size_t)row * K + col] = acc[q][v];
+    for (int q = 0; q < KT; ++q) {
+      const int col = k0 + (wk + q) * 32 + l31;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = (wn + t) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (row < N && col < K) out[(size_t)row * K + col] = acc[t][q][v];
+      }
     }
-  }
   // ---- BatchNorm_{l-1} sums of this chunk: 16 row-threads per k column group, fixed order
   __syncthreads();
   float *red = Cs;   // [2][16 row threads][64 k]
@@ -3284,12 +3296,17 @@ int btr_sa_bn_relu_bwd_apply(long long rows, int c, int ld, float *g, const floa
 // x [rows][4] and w0 [k][4] when w0 != NULL (first-layer recompute).
 int btr_sa_bwd_fused_supported(int rows, int n, int k) {
   static const bool off = getenv("BTR_BWD_FUSED") && getenv("BTR_BWD_FUSED")[0] == '0';
-  return !off && gemm_x6() && tn_pool_x6() && rows > 0 && n >= 32 && n <= 128 && n % 4 == 0 &&
-         k >= 4 && k <= 256 && k % 4 == 0;
+  // (n > 128: the one-workgroup-per-CU variant; BTR_BWD_FUSED_WIDE=0 keeps those layers on the
+  // separate calls)
+  static const bool wide_off =
+      getenv("BTR_BWD_FUSED_WIDE") && getenv("BTR_BWD_FUSED_WIDE")[0] == '0';
+  return !off && gemm_x6() && tn_pool_x6() && rows > 0 && n >= 32 && n <= (wide_off ? 128 : 256) &&
+         n % 4 == 0 && k >= 4 && k <= 512 && k % 4 == 0;
 }
 
 int btr_sa_bwd_fused_chunks(int rows, int n, int k) {
-  return std::min(kFusedMaxChunks, btr_sa_gemm_tn_chunks(rows, n, k));
+  // n > 128: one workgroup per CU, so 256 (x k blocks) fill the chip
+  return std::min(n > 128 ? 256 : kFusedMaxChunks, btr_sa_gemm_tn_chunks(rows, n, k));
 }
 
 int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const float *yl,
@@ -3311,6 +3328,7 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
               "sa_bwd_fused: incomplete %s operands", pooled ? "pooled-gradient" : "BatchNorm");
   BTR_REQUIRE(!pooled || host_compact().on || s == 16 || s == 32 || s == 64 || s == 128,
               "sa_bwd_fused: nsample %d must be 16, 32, 64 or 128", s);
+  BTR_REQUIRE(n <= 128 || !w0, "sa_bwd_fused: first-layer recompute behind %d > 128 columns", n);
   hipStream_t st = as_stream(stream);
   const int chunks = btr_sa_bwd_fused_chunks(rows, n, k);
   FusedArgs a{};
@@ -3323,7 +3341,9 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
   const dim3 grid(1, cdiv(k, 64), chunks);
 #define BTR_FUSED(W, GM, XR) \
   hipLaunchKernelGGL((sa_bwd_fused_kernel<W, GM, XR>), grid, dim3(256), 0, st, a, cur_compact())
-  if (n > 64) {
+  if (n > 128) {   // (no first-layer recompute behind a 256-wide layer: w0 is refused below)
+    if (pooled) BTR_FUSED(8, 1, false); else BTR_FUSED(8, 2, false);
+  } else if (n > 64) {
     if (pooled) { if (w0) BTR_FUSED(4, 1, true); else BTR_FUSED(4, 1, false); }
     else        { if (w0) BTR_FUSED(4, 2, true); else BTR_FUSED(4, 2, false); }
   } else {

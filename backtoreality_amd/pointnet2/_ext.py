@@ -39,6 +39,8 @@ _SIGNATURES = {
     "btr_furthest_point_sampling_bs": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp]),
     "btr_furthest_point_sampling_workspace_bytes": (_sz, [_ci, _ci, _ci]),
     "btr_furthest_point_sampling_ws": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _sz, _vp]),
+    "btr_cu_mask_reserved": (_ci, []),
+    "btr_cu_mask_create_stream": (_vp, [_ci]),
     "btr_fps_ordered_scratch_bytes": (_sz, [_ci, _ci, _ci]),
     "btr_furthest_point_sampling_ordered": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _sz,
                                                   _vp]),
@@ -469,6 +471,24 @@ def furthest_point_sampling(points, nsamples):
     if nsamples <= 0 or B == 0:
         return out
     return _fps(points, nsamples, 0, out)
+
+
+def cu_mask_reserved():
+    """c of BTR_CU_MASK (0: off): the large-scene FPS kernel owns the first c CUs of every XCD."""
+    return int(_lib.btr_cu_mask_reserved())
+
+
+def new_stream(device):
+    """A new torch stream for work that must stay off the sampling kernel's CUs: a plain
+    torch.cuda.Stream unless BTR_CU_MASK is set, then an ExternalStream around a HIP stream
+    created with the complement CU mask (include/btr_pointnet2.h btr_cu_mask_create_stream)."""
+    if not cu_mask_reserved():
+        return torch.cuda.Stream(device=device)
+    with torch.cuda.device(device):
+        ptr = _lib.btr_cu_mask_create_stream(0)
+    if not ptr:
+        raise RuntimeError("btr_cu_mask_create_stream failed")
+    return torch.cuda.ExternalStream(ptr, device=device)
 
 
 def mark_fps_ordered(points):

@@ -168,7 +168,8 @@ class Pointnet2Backbone(nn.Module):
             streams = _SIDE_STREAMS[self] = {}
         key = (name, device)
         if key not in streams:
-            streams[key] = torch.cuda.Stream(device=device)
+            # (BTR_CU_MASK: a stream that stays off the large-scene FPS kernel's CUs)
+            streams[key] = _ext.new_stream(device)
         return streams[key]
 
     def _fps_pyramid(self, xyz):

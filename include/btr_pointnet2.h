@@ -133,6 +133,16 @@ int btr_ball_query_ws(int b, int n, int m, float radius, int nsample, const floa
                       const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
                       btr_stream_t stream);
 
+/* CU partitioning (csrc/fps_bucket.hip; environment BTR_CU_MASK = c in 1..8, default off): the
+ * large-scene FPS kernel -- one workgroup per scene, ~2 000 dependent steps -- runs on the first
+ * c CUs of every XCD, alone; every stream the library creates for itself excludes them.  A
+ * caller that wants the partition to hold for its own work creates its streams with
+ * btr_cu_mask_create_stream(0) (a new HIP stream on the other CUs; reserved = 1: on the
+ * reserved ones) and issues its work there -- torch: torch.cuda.ExternalStream(ptr).
+ * btr_cu_mask_reserved() returns c (0: off; the create call then returns a plain stream). */
+int btr_cu_mask_reserved(void);
+void *btr_cu_mask_create_stream(int reserved);
+
 /* Measurement only (bench.py): the next btr_ball_query_buckets call -- or btr_ball_query_ws call
  * on a scene of more than 4096 points -- of this host thread records the two hipEvent_t around
  * its launches, on the call's stream.  NULL, NULL cancels. */

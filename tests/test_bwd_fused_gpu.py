@@ -91,6 +91,10 @@ def _check(got, ref):
     (736, 100, 36, False, False, 16),      # n, k not multiples of 32
     (20000, 128, 64, True, True, 32),      # many chunks, pooled over a recomputed layer
     (3000, 48, 132, False, False, 16),     # three k blocks, the last one of 4 columns
+    (4096, 256, 128, True, False, 32),     # SA2's pooled layer: the 256-wide variant
+    (3008, 256, 128, False, False, 16),    # 256-wide, BatchNorm source, ragged rows
+    (1024, 200, 260, False, False, 16),    # 256-wide variant on n = 200, five k blocks
+    (8192, 256, 256, False, False, 16),    # a feature-propagation chain layer
 ])
 def test_fused_backward_matches_float64(cuda, rows, n, k, pooled, rc, s):
     got, ref = _run(cuda, rows, n, k, pooled, rc, s=s, ldx_pad=4 if (k % 8 and not rc) else 0)
@@ -105,6 +109,6 @@ def test_fused_backward_is_bit_reproducible(cuda):
 
 
 def test_unsupported_shapes_are_refused(cuda):
-    assert not _lib.btr_sa_bwd_fused_supported(1024, 256, 128)    # n > 128
+    assert not _lib.btr_sa_bwd_fused_supported(1024, 260, 128)    # n > 256
     assert not _lib.btr_sa_bwd_fused_supported(1024, 128, 130)    # k not a multiple of 4
     assert not _lib.btr_sa_bwd_fused_supported(0, 128, 64)

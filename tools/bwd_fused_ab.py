@@ -97,3 +97,7 @@ if __name__ == "__main__":
     case(114688, 128, 128, False, False, 32)   # SA2 hidden layer
     case(65536, 128, 128, False, False, 16)    # SA3 hidden layer
     case(32768, 128, 128, False, False, 16)    # SA4 / vote aggregation hidden layer
+    case(114688, 256, 128, True, False, 32)    # SA2 pooled layer (256-wide variant)
+    case(65536, 256, 128, True, False, 16)     # SA3 pooled layer
+    case(32768, 256, 128, True, False, 16)     # SA4 pooled layer
+    case(8192, 256, 256, False, False, 16)     # feature-propagation chain layer
