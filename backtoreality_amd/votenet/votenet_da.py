@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
+from ..pointnet2 import fused_mlp
 from .backbone_module import Pointnet2Backbone
 from .proposal_module import ProposalModule
 from .voting_module import VotingModule
@@ -29,6 +30,31 @@ def grad_reverse(x):
 
 def _conv_bn_relu(cin, cout):
     return [nn.Conv1d(cin, cout, 1), nn.BatchNorm1d(cout), nn.ReLU()]
+
+
+def _run_head(seq, x):
+    """A domain classifier / regressor head -- nn.Sequential of (Conv1d k=1, BatchNorm1d, ReLU)
+    groups with an optional bare Conv1d at the end (votenet_DA.py:91-99, 113-121, 250-262) --
+    as ONE library call per direction on the point-wise chain kernels (csrc/sa_layer.hip
+    btr_pm_chain_*) instead of 3 stock ops per layer and MIOpen's per-sample convolution
+    kernels in the backward; the parameters stay the Sequential's own (state-dict keys of the
+    reference).  Falls back to the stock modules when the chain path does not apply (CPU, eval
+    mode, BTR_FUSED_MLP=0)."""
+    mods = list(seq)
+    chain, i = [], 0
+    while i < len(mods):
+        if i + 2 < len(mods) and isinstance(mods[i], nn.Conv1d) and \
+                isinstance(mods[i + 1], nn.BatchNorm1d) and isinstance(mods[i + 2], nn.ReLU):
+            chain.append((mods[i], mods[i + 1], True))
+            i += 3
+        elif i == len(mods) - 1 and isinstance(mods[i], nn.Conv1d):
+            chain.append((mods[i], None, False))
+            i += 1
+        else:
+            chain = None
+            break
+    out = fused_mlp.run_chain(x, chain) if chain else None
+    return out if out is not None else seq(x)
 
 
 class VoteNet_DA(nn.Module):
@@ -76,9 +102,9 @@ class VoteNet_DA(nn.Module):
         end_points['vote_features'] = features
         end_points = self.pnet(xyz, features, end_points)
 
-        g = self.global_netD1(grad_reverse(end_points['seed_features']))  # (B,128,1024)
+        g = _run_head(self.global_netD1, grad_reverse(end_points['seed_features']))  # (B,128,1024)
         end_points['global_d_pred'] = self.global_netD2(torch.mean(g, dim=2))  # (B,2)
-        local = self.local_netD(grad_reverse(end_points['aggregated_vote_features']))
+        local = _run_head(self.local_netD, grad_reverse(end_points['aggregated_vote_features']))
         end_points['local_d_pred'] = torch.sigmoid(local)  # (B,1,num_proposal)
         self._center_heads(end_points, center_xyz, before_voting=False)
         return end_points
@@ -106,7 +132,8 @@ class VoteNet_DA_jitter(VoteNet_DA):
         if center_xyz is None:
             return
         if before_voting:  # votenet_DA.py:291-292
-            end_points['jitter_pred'] = self.jitter_net(end_points['center_features'])  # B,3,64
+            end_points['jitter_pred'] = _run_head(self.jitter_net,
+                                                  end_points['center_features'])  # B,3,64
         else:              # :324-327
-            d = self.jitter_netD(grad_reverse(end_points['center_features']))
+            d = _run_head(self.jitter_netD, grad_reverse(end_points['center_features']))
             end_points['jitter_d_pred'] = torch.sigmoid(d)  # B,1,64
