@@ -41,17 +41,40 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 struct Split4 {
   bf16x4 h, m, l;
 };
+// Two elements at a time: gfx950 converts a PAIR of f32 to packed bf16 in one instruction
+// (v_cvt_pk_bf16_f32, round to nearest even -- what the scalar conversions compile to as well,
+// one pair slot wasted each), and a packed pair widens back to two f32 with a shift and a mask.
+// 11 VALU ops per pair instead of ~17, results bit-identical to the element-wise form, and the
+// planes come out packed (no v_or to assemble the 8-byte LDS stores).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 widen2(const bf16x2 b) {
+  const unsigned u = __builtin_bit_cast(unsigned, b);
+  f32x2 r;
+  r.x = __uint_as_float(u << 16);
+  r.y = __uint_as_float(u & 0xffff0000u);
+  return r;
+}
 __device__ __forceinline__ Split4 split4(const float4 v) {
   Split4 s;
-  const float f[4] = {v.x, v.y, v.z, v.w};
+  const f32x2 f[2] = {{v.x, v.y}, {v.z, v.w}};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const __bf16 h = (__bf16)f[i];
-    const float r1 = f[i] - (float)h;
-    const __bf16 m = (__bf16)r1;
-    s.h[i] = h;
-    s.m[i] = m;
-    s.l[i] = (__bf16)(r1 - (float)m);
+  for (int p = 0; p < 2; ++p) {
+    // (the differences element by element: packed f32 arithmetic beside MFMAs is an anti-lever)
+    const bf16x2 h = __builtin_convertvector(f[p], bf16x2);
+    const f32x2 wh = widen2(h);
+    f32x2 r1;
+    r1.x = f[p].x - wh.x;
+    r1.y = f[p].y - wh.y;
+    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+    const f32x2 wm = widen2(m);
+    f32x2 r2;
+    r2.x = r1.x - wm.x;
+    r2.y = r1.y - wm.y;
+    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+    s.h[2 * p] = h.x; s.h[2 * p + 1] = h.y;
+    s.m[2 * p] = m.x; s.m[2 * p + 1] = m.y;
+    s.l[2 * p] = l.x; s.l[2 * p + 1] = l.y;
   }
   return s;
 }
