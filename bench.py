@@ -397,12 +397,18 @@ def main():
         barrier()
         sequential = time.perf_counter() - t1
         seq_kernels = _ext.timing_end()
-    per_rank = None
+    per_rank = per_rank_host = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         every = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         per_rank = [1e3 * float(x.item()) / args.steps for x in every]
+        # every rank's host-enqueue time: N Python processes share one host, and the workloads
+        # other than FSB are paced by it -- a scaling line shows here whether they contend
+        h = torch.tensor([enqueue], device=dev, dtype=torch.float64)
+        every_h = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(every_h, h)
+        per_rank_host = [1e3 * float(x.item()) / args.steps for x in every_h]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -453,6 +459,8 @@ def main():
         if per_rank is not None:   # every rank's own clock over the same K steps
             out["per_rank_ms_per_step"] = {"min": min(per_rank), "max": max(per_rank),
                                            "ranks": per_rank}
+            out["per_rank_host_enqueue_ms_per_step"] = {
+                "min": min(per_rank_host), "max": max(per_rank_host), "ranks": per_rank_host}
         if gf:
             out["hip_graph"] = bool(graphed)
         else:

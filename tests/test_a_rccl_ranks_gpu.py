@@ -26,7 +26,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(world):
+def _launch(world, mode=None):
     if torch.cuda.is_initialized():
         pytest.skip("this process already initialised the GPU: it must not start programs")
     n = torch.cuda.device_count()          # (counting devices does not initialise them)
@@ -38,7 +38,8 @@ def _launch(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BTR_DP="flat",
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py")],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py")] +
+                                      ([mode] if mode else []),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True))
     results = []
@@ -72,3 +73,17 @@ def test_two_rank_rccl_pipelined_steps():
 
 def test_one_rank_rccl_worker():
     _check(_launch(1), 1)
+
+
+@pytest.mark.parametrize("mode", ["br", "gf"])
+@pytest.mark.parametrize("world", [2, 1])
+def test_rccl_back_to_reality_and_groupfree_steps(world, mode):
+    """The two-forward Back-to-Reality step and the GroupFree3D step under FlatGradParallel over
+    RCCL (train_GF_BR.py:330-331, 356: two forwards per backward with broadcast_buffers=False;
+    train_GF_FSB.py:250, 316-319): replicas bit-identical after three pipelined steps.  Two ranks
+    need two GPUs; the one-rank variant runs wherever a GPU exists."""
+    results = _launch(world, mode)
+    assert [r["rank"] for r in results] == list(range(world))
+    for r in results:
+        assert r["mode"] == mode and r["rccl_ranks"] == world
+        assert r["replicas_identical"] and r["finite"], r

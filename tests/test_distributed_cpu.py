@@ -175,3 +175,72 @@ def test_bench_launches_its_own_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     assert json.loads(line)["launch_check"] == 2
+
+
+def _worker_small(rank, world, port, q):
+    """Two data-parallel steps on a tiny scene (the whole path: rendezvous, broadcast at
+    construction, one flat all-reduce per step) at the node's REAL rank count."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BTR_DP="flat")
+    torch.set_num_threads(1)
+    import oracle
+    from backtoreality_amd.pointnet2 import pointnet2_utils
+    from backtoreality_amd.votenet import config, synthetic, train
+    pointnet2_utils._ext = oracle.ext_cpu
+    r, w, _ = train.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg = config.scannet_md40()
+    torch.manual_seed(1000 + rank)     # different initial weights: rank 0's must win
+    net = train.build_model(cfg, torch.device("cpu"), num_proposal=16, seed=1000 + rank)
+    dp = train.wrap_ddp(net, torch.device("cpu"))
+    opt = train.make_optimizer(net)
+    losses = []
+    for step in range(2):
+        batch = synthetic.make_batch(50 * rank + step, 1, 1024, cfg)
+        loss, _ = train.train_step(dp, opt, batch, cfg)
+        losses.append(float(loss))
+    flat = torch.cat([p.detach().flatten() for p in net.parameters()])
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    ones = torch.ones(1)
+    dist.all_reduce(ones)
+    q.put((rank, int(ones.item()), all(torch.equal(o, flat) for o in other),
+           all(l == l for l in losses)))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_two_steps_tiny_scene():
+    """BASELINE configs[2] / [4] run on 8 GPUs of one node: the rendezvous + FlatGradParallel
+    path at world_size 8 (gloo, CPU oracle `_ext`, one 1 024-point scene per rank and step).
+    Replicas must stay bit-identical although every rank starts from its own weights (rank 0's
+    are broadcast) and sees its own shard."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_small, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == list(range(world))
+    for _, ranks, same, finite in results:
+        assert ranks == world and same and finite
+
+
+def test_bench_launches_eight_ranks():
+    """`python bench.py --gpus 8 --launch-check`: the self-launch path at the rank count of the
+    driver's scaling run (torch.distributed.run, 127.0.0.1 rendezvous, one all-reduce)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8",
+                          "--launch-check"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line)["launch_check"] == 8
