@@ -1710,6 +1710,249 @@ __global__ __launch_bounds__(256) void gemm_tn_x6_kernel(
   }
 }
 
+// ---- streaming forward / input-gradient GEMM for the narrow layers ----------------------------
+// gemm_nt_kernel re-stages and re-splits its weight tile for every 128-row tile -- for SA1's
+// 128 x 64 last layer that is as much staging work as the activations themselves -- and its
+// epilogue (statistics, pooling extrema, transposed store) runs with nothing in flight.  For
+// n <= 128, k <= 128 the sa_bwd_fused_kernel layout does better: 32 (n <= 128) or 64 (n <= 64)
+// rows per step, the whole k extent staged once per step as bf16 planes (double-buffered: one
+// barrier per step), every wave owns one 32 x 32 output tile whose B fragments -- its 32 weight
+// rows, split once -- stay in registers for the whole kernel, the next step's rows are in flight
+// during the MFMAs, and the epilogue works on the accumulators: BatchNorm statistics (compact-row
+// weights as in gemm_nt_kernel), the pooling extrema of 8-row blocks, the C tile through a
+// per-wave LDS transpose as 16-byte row stores.  Same arithmetic as gemm_nt_kernel<.., MM = 1>
+// (bf16x6, smallest terms first); the statistics partials keep its layout (one row of `part`
+// per workgroup, gridDim.x = btr_sa_gemm_grid(rows)), so bn_finalize_kernel does not change.
+// PRO: 0 plain, 1 relu(pa * a + pb), 3 first-layer recompute (a = x0 rows of 4, w0 [k][4]).
+struct StreamArgs {
+  const float *A;
+  int lda;
+  const float *W;   // [N][ldw]
+  int ldw;
+  float *C;
+  int ldc;
+  int R, N, K, rows_per_chunk;
+  const float *pa, *pb, *w0;
+  float *part;
+  const float *gsign;   // PS > 0: the layer's gamma
+  float *gext;
+  unsigned char *aext;
+};
+
+template <int BR, int KMAX, int PRO, bool STATS, int PS>
+__global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Compact cm) {
+  static_assert((BR == 32 || BR == 64) && (KMAX == 64 || KMAX == 128), "tile shapes");
+  static_assert(PS == 0 || PS == 8, "pooling epilogue: 8-row blocks (compact rows)");
+  constexpr int WR = BR / 32;           // row tiles (waves along the rows)
+  constexpr int WC = 4 / WR;            // column tiles: n <= 32 * WC
+  constexpr int LX = KMAX + 8;          // bf16 pitch: 144 / 272 B (conflict-free 16-byte row reads)
+  constexpr int KS = KMAX / 16;         // reduction steps of 16
+  constexpr int TPR = KMAX / 4;         // staging threads per row
+  constexpr int RP = 256 / TPR;         // rows per staging pass
+  constexpr int NP = BR / RP;           // staging passes
+  constexpr int LT = 36;                // f32 pitch of the per-wave transpose tile
+  int R = a.R, rows_per_chunk = a.rows_per_chunk;
+  if (cm.dims) {   // compact rows: count and split on the device (see sa_bwd_fused_kernel)
+    R = cm.dims[0];
+    rows_per_chunk = ((R + (int)gridDim.x - 1) / (int)gridDim.x + BR - 1) / BR * BR;
+  }
+  const int N = a.N, K = a.K;
+  __shared__ __attribute__((aligned(16))) __bf16 Xp[2][3 * BR * LX];
+  __shared__ __attribute__((aligned(16))) float Ts[4][32 * LT];
+  __shared__ double red[STATS ? 2 * WR * 32 * WC : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int rbeg = blockIdx.x * rows_per_chunk;
+  const int rend = min(R, rbeg + rows_per_chunk);
+
+  // ---- this wave's 32 weight rows, split once
+  bf16x8 bdr[KS][3];
+  {
+    const int nr = wc * 32 + l31;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kb = ks * 16 + h * 8;
+      float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+      if (nr < N && kb < K) w0 = *reinterpret_cast<const float4 *>(a.W + (size_t)nr * a.ldw + kb);
+      if (nr < N && kb + 4 < K)
+        w1 = *reinterpret_cast<const float4 *>(a.W + (size_t)nr * a.ldw + kb + 4);
+      const Split4 s0 = split4(w0), s1 = split4(w1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bdr[ks][0][e] = s0.h[e]; bdr[ks][0][4 + e] = s1.h[e];
+        bdr[ks][1][e] = s0.m[e]; bdr[ks][1][4 + e] = s1.m[e];
+        bdr[ks][2][e] = s0.l[e]; bdr[ks][2][4 + e] = s1.l[e];
+      }
+    }
+  }
+  const int xc4 = (tid % TPR) * 4, xr = tid / TPR;
+  float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (PRO && xc4 < K) {
+    fa = *reinterpret_cast<const float4 *>(a.pa + xc4);
+    fb = *reinterpret_cast<const float4 *>(a.pb + xc4);
+  }
+  float4 w0r[PRO == 3 ? 4 : 1];
+  if constexpr (PRO == 3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      w0r[e] = (xc4 + e < K) ? *reinterpret_cast<const float4 *>(a.w0 + (size_t)(xc4 + e) * 4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 rx[NP];
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int row = xr + RP * p;
+      rx[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < rend && xc4 < K)
+        rx[p] = PRO == 3 ? *reinterpret_cast<const float4 *>(a.A + (size_t)(r0 + row) * 4)
+                         : *reinterpret_cast<const float4 *>(a.A + (size_t)(r0 + row) * a.lda + xc4);
+    }
+  };
+  const float sg = (PS > 0 && wc * 32 + l31 < N && a.gsign[wc * 32 + l31] < 0.f) ? -1.f : 1.f;
+  double d1 = 0.0, d2 = 0.0;
+  if (rbeg < rend) fetch(rbeg);
+  int buf = 0;
+  for (int r0 = rbeg; r0 < rend; r0 += BR, buf ^= 1) {
+    __bf16 *xp = Xp[buf];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int row = xr + RP * p;
+      float4 x = rx[p];
+      const bool live = r0 + row < rend && xc4 < K;
+      if constexpr (PRO == 3) {
+        if (live)
+          x = make_float4(rc_dot4(x, w0r[0]), rc_dot4(x, w0r[1]), rc_dot4(x, w0r[2]),
+                          rc_dot4(x, w0r[3]));
+      }
+      if (PRO != 0 && live) {
+        x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
+        x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
+        x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
+        x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
+      }
+      if (!live) x = make_float4(0.f, 0.f, 0.f, 0.f);   // padded rows / columns stay exactly 0
+      const Split4 sp = split4(x);
+      const int at = row * LX + xc4;
+      *reinterpret_cast<bf16x4 *>(&xp[0 * BR * LX + at]) = sp.h;
+      *reinterpret_cast<bf16x4 *>(&xp[1 * BR * LX + at]) = sp.m;
+      *reinterpret_cast<bf16x4 *>(&xp[2 * BR * LX + at]) = sp.l;
+    }
+    float bwx[4];   // STATS on compact rows: (weight - 1) of this wave's four 8-row blocks
+    if (STATS && cm.bw) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = r0 + wr * 32 + 8 * q;
+        bwx[q] = row < rend ? cm.bw[row >> 3] - 1.f : 0.f;
+      }
+    }
+    __syncthreads();   // (the other buffer is free: every wave finished its MFMAs of the step
+                       // before last when it arrived here)
+    if (r0 + BR < rend) fetch(r0 + BR);
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks * 16 >= K) break;
+      bf16x8 af[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        af[q] = *reinterpret_cast<const bf16x8 *>(
+            &xp[(q * BR + wr * 32 + l31) * LX + ks * 16 + h * 8]);
+      const bf16x8 *bd = bdr[ks];
+#define BTR_X6S(QA, QB) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA], bd[QB], acc, 0, 0, 0);
+      BTR_X6S(2, 0)
+      BTR_X6S(0, 2)
+      BTR_X6S(1, 1)
+      BTR_X6S(1, 0)
+      BTR_X6S(0, 1)
+      BTR_X6S(0, 0)
+#undef BTR_X6S
+    }
+    // ---- epilogue on the accumulators: D layout col = lane & 31, row = (v&3) + 8*(v>>2) + 4*h
+    const int col = wc * 32 + l31;
+    const int wrow0 = r0 + wr * 32;
+    if constexpr (STATS) {   // rows >= rend hold exact zeros
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const float c = acc[v];
+        s1 += c;
+        s2 = fmaf(c, c, s2);
+        if (cm.bw && h == 0 && (v & 3) == 0) {
+          const float wx = bwx[v >> 2];
+          s1 = fmaf(wx, c, s1);
+          s2 = fmaf(wx * c, c, s2);
+        }
+      }
+      d1 += (double)s1;
+      d2 += (double)s2;
+    }
+    if constexpr (PS == 8) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        float vmx = -3.0e38f;
+        int imx = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float c = acc[4 * b + q] * sg;
+          if (c > vmx) {
+            vmx = c;
+            imx = q;
+          }
+        }
+        const int mine = imx + 4 * h;
+        const float omx = __shfl_xor(vmx, 32);
+        const int oix = __shfl_xor(mine, 32);
+        const bool take = omx > vmx || (omx == vmx && oix < mine);
+        const float best = take ? omx : vmx;
+        const int bidx = take ? oix : mine;
+        const int grow = wrow0 + b * 8;
+        if (h == 0 && grow < rend && col < N) {
+          const size_t o = (size_t)(grow >> 3) * N + col;
+          a.gext[o] = best * sg;
+          a.aext[o] = (unsigned char)bidx;
+        }
+      }
+    }
+    if (a.C != nullptr) {
+      float *T = Ts[wave];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) T[((v & 3) + 8 * (v >> 2) + 4 * h) * LT + l31] = acc[v];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the tile is private to the wave)
+      __builtin_amdgcn_wave_barrier();
+      const int rl = lane >> 3, c4 = (lane & 7) * 4;   // 8 rows x 8 float4 per pass
+      const int colw = wc * 32 + c4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const float4 q4 = *reinterpret_cast<const float4 *>(&T[(it * 8 + rl) * LT + c4]);
+        const int row = wrow0 + it * 8 + rl;
+        if (row < rend && colw < N)
+          *reinterpret_cast<float4 *>(a.C + (size_t)row * a.ldc + colw) = q4;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if constexpr (STATS) {
+    d1 += __shfl_xor(d1, 32);
+    d2 += __shfl_xor(d2, 32);
+    if (h == 0) {
+      red[(0 * WR + wr) * 32 * WC + wc * 32 + l31] = d1;
+      red[(1 * WR + wr) * 32 * WC + wc * 32 + l31] = d2;
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * 32 * WC; c += 256) {
+      const int which = c / (32 * WC), col = c % (32 * WC);
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < WR; ++w) sum += red[(which * WR + w) * 32 * WC + col];
+      if (col < N) a.part[((size_t)blockIdx.x * 2 + which) * N + col] = (float)sum;
+    }
+  }
+}
+
 // ---- one pass over a layer's backward operands: dgrad + wgrad + the next BatchNorm's sums ------
 // The backward of a hidden layer l used to be five passes over its big tensors: the weight
 // gradient dW_l = dY_l^T . X_{l-1} and the input gradient dZ_{l-1} = dY_l . W_l each read dY_l,
@@ -2922,6 +3165,59 @@ bool bnfin_arm(const BnFin &fin, long long rows) {
 
 }  // namespace btr
 
+// sa_fwd_stream_kernel for the NT entry points below: true when it took the launch.
+// BTR_FWD_STREAM=0: never.  Rows below kStreamMinRows stay on gemm_nt_kernel (its BatchNorm
+// ticket path covers the tiny layers, and a streaming grid of few steps gains nothing).
+namespace btr {
+constexpr int kStreamMinRows = 16384;
+static bool stream_ok(int rows, int n, int k, int lda_ok, bool fin_armed) {
+  const char *e = getenv("BTR_FWD_STREAM");   // (read per call: tests and A/B runs toggle it)
+  const bool off = e && e[0] == '0';
+  return !off && gemm_x6() && !fin_armed && lda_ok && rows >= kStreamMinRows && n % 4 == 0 &&
+         k % 4 == 0 && n <= 128 && k <= 128 && !host_compact().dev.kz;
+}
+template <int BR, int KMAX, int PRO, bool STATS, int PS>
+static void launch_stream(int gx, hipStream_t st, StreamArgs &a) {
+  a.rows_per_chunk = cdiv(cdiv(a.R, gx), BR) * BR;
+  hipLaunchKernelGGL((sa_fwd_stream_kernel<BR, KMAX, PRO, STATS, PS>), dim3(gx), dim3(256), 0, st,
+                     a, cur_compact());
+}
+// pro: 0 / 1 / 3;  ps: 0 / 8.  The instantiated combinations are the layers' (see the kernel).
+static bool try_stream(int rows, int n, int k, const float *A, int lda, const float *W, int ldw,
+                       float *C, int ldc, const float *pa, const float *pb, const float *w0,
+                       float *part, int ps, const float *gamma, float *gext, unsigned char *aext,
+                       int pro, hipStream_t st) {
+  StreamArgs a{};
+  a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.R = rows; a.N = n; a.K = k;
+  a.pa = pa; a.pb = pb; a.w0 = w0; a.part = part; a.gsign = gamma; a.gext = gext; a.aext = aext;
+  const int gx = btr_sa_gemm_grid(rows);
+  const bool stats = part != nullptr;
+  if (ps == 8) {
+    if (pro == 1 && stats && n > 64 && k <= 64) { launch_stream<32, 64, 1, true, 8>(gx, st, a); return true; }
+    if (pro == 1 && stats && n > 64) { launch_stream<32, 128, 1, true, 8>(gx, st, a); return true; }
+    return false;
+  }
+  if (ps != 0) return false;
+  if (pro == 3) {
+    if (stats && n <= 64 && k <= 64) { launch_stream<64, 64, 3, true, 0>(gx, st, a); return true; }
+    return false;
+  }
+  if (pro == 1 && stats) {
+    if (n <= 64 && k <= 64) { launch_stream<64, 64, 1, true, 0>(gx, st, a); return true; }
+    if (n > 64 && k <= 64) { launch_stream<32, 64, 1, true, 0>(gx, st, a); return true; }
+    if (n > 64) { launch_stream<32, 128, 1, true, 0>(gx, st, a); return true; }
+    return false;
+  }
+  if (pro == 0 && !stats) {   // input gradients
+    if (n <= 64 && k <= 64) { launch_stream<64, 64, 0, false, 0>(gx, st, a); return true; }
+    if (n > 64 && k <= 64) { launch_stream<32, 64, 0, false, 0>(gx, st, a); return true; }
+    if (n > 64) { launch_stream<32, 128, 0, false, 0>(gx, st, a); return true; }
+    return false;
+  }
+  return false;
+}
+}  // namespace btr
+
 using namespace btr;
 
 extern "C" {
@@ -2973,6 +3269,10 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
   hipStream_t s = as_stream(stream);
   const bool pro = pa != nullptr, st = part != nullptr;
   const BnFin fin = take_bnfin();   // (armed by the caller: finalisation inside this launch)
+  if (c && stream_ok(rows, n, k, lda % 4 == 0, fin.ticket != nullptr) &&
+      try_stream(rows, n, k, a, lda, w, ldw, c, ldc, pa, pb, nullptr, part, 0, nullptr, nullptr,
+                 nullptr, pro ? 1 : 0, s))
+    return check_launch("sa_gemm_nt(stream)");
 #define BTR_GEMM_MM(BN, P, S, MM)                                                            \
   hipLaunchKernelGGL((gemm_nt_kernel<BN, P, S, 0, kBM, false, MM>), dim3(gx, cdiv(n, BN)),    \
                      dim3(256), 0, s, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,       \
@@ -3018,6 +3318,10 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
   const BnFin fin = take_bnfin();
+  if (s == 8 && stream_ok(rows, n, k, lda % 4 == 0, fin.ticket != nullptr) &&
+      try_stream(rows, n, k, a, lda, w, ldw, c, ldc, pa, pb, nullptr, part, 8, gamma, gext, aext, 1,
+                 st))
+    return check_launch("sa_gemm_nt_poolfwd(stream)");
 #define BTR_GEMM_MM(PS, MM)                                                                   \
   hipLaunchKernelGGL((gemm_nt_kernel<128, 1, true, PS, kBM, false, MM>), dim3(gx, cdiv(n, 128)), \
                      dim3(256), 0, st, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,        \
@@ -3176,6 +3480,10 @@ int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, 
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
   const BnFin fin = take_bnfin();
+  if (stream_ok(rows, n, k, true, fin.ticket != nullptr) &&
+      try_stream(rows, n, k, x0, 4, w, ldw, c, ldc, pa, pb, w0, part, 0, nullptr, nullptr, nullptr,
+                 3, st))
+    return check_launch("sa_gemm_nt_rc(stream)");
 #define BTR_NTRC_MM(BN, S, MM)                                                                \
   hipLaunchKernelGGL((gemm_nt_kernel<BN, 3, S, 0, kBM, false, MM>), dim3(gx, cdiv(n, BN)),     \
                      dim3(256), 0, st, x0, 4, w, ldw, c, ldc, rows, n, k, pa, pb, part,        \
@@ -3328,8 +3636,12 @@ int btr_sa_bwd_fused_supported(int rows, int n, int k) {
 }
 
 int btr_sa_bwd_fused_chunks(int rows, int n, int k) {
-  // n > 128: one workgroup per CU, so 256 (x k blocks) fill the chip
-  return std::min(n > 128 ? 256 : kFusedMaxChunks, btr_sa_gemm_tn_chunks(rows, n, k));
+  // one round of resident workgroups: 256 CUs x (2 workgroups per CU; n > 128: one) over the
+  // 64-wide k blocks -- more chunks only add partials to write and reduce (SA2's 256-wide layer:
+  // 33 MB at 256 chunks) and a second, half-empty round
+  const int resident = 256 * (n > 128 ? 1 : 2), kblocks = (k + 63) / 64;
+  const int want = std::max(32, resident / kblocks);
+  return std::max(1, std::min(std::min(want, kFusedMaxChunks), btr_sa_gemm_tn_chunks(rows, n, k)));
 }
 
 int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const float *yl,

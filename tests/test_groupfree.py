@@ -214,7 +214,10 @@ def test_groupfree_graphed_step_trains_like_the_eager_step(cuda):
     num = sum(float((a - b).double().pow(2).sum())
               for a, b in zip(ne.parameters(), ng.parameters()))
     den = sum(float(a.double().pow(2).sum()) for a in ne.parameters())
-    assert (num / den) ** 0.5 <= 1e-2, (num / den) ** 0.5   # a replay that did nothing: 0.15
+    # (two eager runs of one build: 0.0024; eager against replay 0.0098-0.0105; the same eager
+    # step on two GEMM kernels whose BatchNorm sums are added in another order 0.013 --
+    # tools/diag_gf_eager_vs_graph.py; a replay that did nothing: 0.15)
+    assert (num / den) ** 0.5 <= 2e-2, (num / den) ** 0.5
     for a, b in zip(ne.parameters(), ng.parameters()):
         # (each run moves a parameter by at most ~lr per step; opposite signs on a noise-level
         # gradient put two runs 2 * lr apart per step)
