@@ -413,6 +413,24 @@ int btr_backbone_sampling(const btr_backbone_t *dp, const btr_backbone_plan_t *p
   return check_launch("backbone_sampling");
 }
 
+// btr_backbone_fork_event (header): the event the NEXT btr_backbone_forward of this host thread
+// records on its stream once set-abstraction level `level` (1-based) has been issued
+namespace {
+struct ForkEvent {
+  hipEvent_t ev = nullptr;
+  int level = 0;
+};
+inline ForkEvent &fork_event() {
+  static thread_local ForkEvent f;
+  return f;
+}
+}  // namespace
+
+void btr_backbone_fork_event(void *event, int level) {
+  fork_event().ev = (hipEvent_t)event;
+  fork_event().level = level;
+}
+
 int btr_backbone_forward(const btr_backbone_t *dp, const btr_backbone_plan_t *pp,
                          const float *cloud, const void *geom, void *out, void *saved,
                          void *scratch, int wait_side, btr_stream_t stream) {
@@ -439,6 +457,10 @@ int btr_backbone_forward(const btr_backbone_t *dp, const btr_backbone_plan_t *pp
                                   &sg, stream));
     xyz = new_xyz;
     feats = at_f(out, p.o_sa_cl[l]);
+    if (fork_event().ev && (l + 1 == fork_event().level || l + 1 == d.levels)) {
+      (void)hipEventRecord(fork_event().ev, st);   // (at the last level at the latest)
+      fork_event().ev = nullptr;
+    }
   }
   if (ev && d.fps > 0) (void)hipStreamWaitEvent(st, ev->level[d.levels], 0);
   for (int j = 0; j < d.fps; ++j) {

@@ -299,7 +299,10 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
   }
   __shared__ BSlot slots[2][NW];
 
-  __builtin_amdgcn_s_setprio(3);  // latency chain: issue ahead of co-resident streaming waves
+  // latency chain: issue ahead of co-resident streaming waves -- unless the caller hides this
+  // kernel under other work anyway (box_epoch's top bit: see fps_bucket_launch, BTR_FPS_PRIO)
+  if (!(box_epoch & 0x80000000u)) __builtin_amdgcn_s_setprio(3);
+  box_epoch &= 0x7fffffffu;
   const int bi = blockIdx.x;
   dataset += (size_t)bi * n * 3;
   spts += (size_t)bi * np;
@@ -1356,8 +1359,14 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   static_assert(sizeof(Box8) * (kBucketMaxN / 64) <= sizeof(int) * kCells, "boxes fit the cells");
   // a process-wide launch counter (never 0: 0 means "unstamped boxes" to the query)
   static std::atomic<unsigned> epoch_counter{0x5a000000u};
-  unsigned epoch = epoch_counter.fetch_add(1u) + 1u;
-  if (epoch == 0u) epoch = epoch_counter.fetch_add(1u) + 1u;
+  unsigned epoch = (epoch_counter.fetch_add(1u) + 1u) & 0x7fffffffu;
+  if (epoch == 0u) epoch = (epoch_counter.fetch_add(1u) + 1u) & 0x7fffffffu;
+  // BTR_FPS_PRIO=0: no raised wave priority (rides in the epoch's top bit, stripped in the kernel
+  // before the boxes are stamped).  With priority 3 the eight FPS workgroups starve whatever
+  // shares their CUs; when the pyramid is hidden under a training step anyway, the step's own
+  // kernels are what should not wait.
+  const char *pe = getenv("BTR_FPS_PRIO");
+  const unsigned kflag = (pe && pe[0] == '0') ? 0x80000000u : 0u;
   // BTR_CU_MASK: the sampling kernel alone moves to the stream that owns the reserved CUs (its
   // sort launches and everything behind it stay where they are); fork / join with two events.
   // Not while a HIP graph is captured (the events are not part of the capture's streams).
@@ -1381,11 +1390,11 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
-                       (unsigned long long *)nullptr, boxes, epoch);
+                       (unsigned long long *)nullptr, boxes, epoch | kflag);
   else
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2, 1>), dim3(b), dim3(kBucketWaves * 64),
                        0, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
-                       (unsigned long long *)nullptr, boxes, epoch);
+                       (unsigned long long *)nullptr, boxes, epoch | kflag);
   if (ev[1]) (void)hipEventRecord(ev[1], ks);
   ev[0] = ev[1] = nullptr;
   if (ks != s) {

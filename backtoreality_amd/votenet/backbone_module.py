@@ -88,19 +88,41 @@ class Pointnet2Backbone(nn.Module):
             ent = cache[key] = fused_backbone.Entry(sa, fp, B, N, W - 3)
         return ent
 
-    def prefetch_sampling(self, pointcloud):
+    def arm_fork_event(self, pointcloud):
+        """Software pipelining: returns an event that the NEXT native forward of this backbone
+        records behind SA level 2 (btr_backbone_fork_event), or None when the native whole-
+        backbone path does not apply.  `prefetch_sampling(next_cloud, after=event)` then starts
+        the next pyramid's ~2 000-step FPS chain beside SA3 .. loss .. backward -- strings of
+        short latency-bound kernels -- instead of beside SA1 / SA2, whose forward is HBM-bound
+        and loses most to a co-runner (votenet/train.py train_step)."""
+        if not pointcloud.is_cuda or os.environ.get("BTR_OVERLAP_FPS", "1") == "0":
+            return None
+        entry = self._native_entry(pointcloud)
+        if entry is None or torch.cuda.is_current_stream_capturing():
+            return None
+        ev = torch.cuda.Event()
+        ev.record()      # (creates the handle; the library records it again in place)
+        entry.lib.btr_backbone_fork_event(ev.cuda_event, int(os.environ.get("BTR_FORK_LEVEL", "2")))
+        return ev
+
+    def prefetch_sampling(self, pointcloud, after=None):
         """Start the sampling pyramid of `pointcloud` on the side stream NOW and return a
         handle to pass to forward(..., sampling=handle).  Sampling depends on coordinates
         only, so a caller that runs several forwards per step (the Back-to-Reality step runs a
         source and a target branch, train_Votenet_BR.py:277-278) can overlap the second
-        branch's FPS with the first branch's forward.  Same indices as computing them inline."""
+        branch's FPS with the first branch's forward.  Same indices as computing them inline.
+        `after`: an event of the current stream the side stream waits for instead of the
+        stream's whole queue (arm_fork_event)."""
         if not pointcloud.is_cuda or os.environ.get("BTR_OVERLAP_FPS", "1") == "0":
             return None
         entry = self._native_entry(pointcloud)
         if entry is not None:   # one library call for the whole pyramid
             main = torch.cuda.current_stream(pointcloud.device)
             side = self._get_side_stream(pointcloud.device, "_prefetch_stream")
-            side.wait_stream(main)
+            if after is not None:
+                side.wait_event(after)
+            else:
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 handle = fused_backbone.sample(entry, pointcloud)
                 handle.event = torch.cuda.Event()

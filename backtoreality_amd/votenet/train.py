@@ -457,20 +457,34 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None, crite
     inputs = {'point_clouds': batch['point_clouds']}
     if sampling is not None:
         inputs['sampling'] = sampling
-    early = next_batch is not None and os.environ.get("BTR_PREFETCH_AT", "forward") == "forward"
+    where = os.environ.get("BTR_PREFETCH_AT", "forward")
+    early = next_batch is not None and where == "forward"
     nxt_sampling = None
+    core = net.module if hasattr(net, "module") else net
     if early:   # the next pyramid is issued before this step's forward: 4 ms of dependent FPS
         # steps on 8 CUs then have the whole step to hide under (issued at the backward it ended
         # 0.2 ms before the next forward needed it; BTR_PREFETCH_AT=backward: 6.05 vs 6.00 ms)
-        core = net.module if hasattr(net, "module") else net
         nxt_sampling = core.backbone_net.prefetch_sampling(next_batch['point_clouds'])
+    fork = None
+    if next_batch is not None and where == "sa2" and sampling is not None:
+        # BTR_PREFETCH_AT=sa2 (round 4, measured, NOT the default): the next pyramid starts once
+        # THIS forward is past SA level BTR_FORK_LEVEL (2) -- the idea: its FPS chain wants L2
+        # latency, SA1 / SA2 want HBM bandwidth, and beside each other both lose (FPS 2.1 ->
+        # 2.8 ms, the GEMMs +19 %).  Same box, 20 steps: before the forward 4.69 ms, behind SA1
+        # 4.68, SA2 4.72, SA3 4.75, SA4 4.80, before the backward 5.00 (tools/ab_prefetch.sh):
+        # the FPS runs 0.13 ms faster the later it starts, the step does not -- what the two
+        # streams cost each other is paid wherever they overlap
+        fork = core.backbone_net.arm_fork_event(batch['point_clouds'])
+        if fork is None:
+            nxt_sampling = core.backbone_net.prefetch_sampling(next_batch['point_clouds'])
     end_points = net(inputs)
+    if fork is not None:
+        nxt_sampling = core.backbone_net.prefetch_sampling(next_batch['point_clouds'], after=fork)
     for key in batch:
         assert key not in end_points
         end_points[key] = batch[key]
     loss, end_points = (criterion or loss_helper.get_loss)(end_points, cfg)
-    if next_batch is not None and not early:
-        core = net.module if hasattr(net, "module") else net
+    if next_batch is not None and nxt_sampling is None:   # (BTR_PREFETCH_AT=backward)
         nxt_sampling = core.backbone_net.prefetch_sampling(next_batch['point_clouds'])
     if nxt_sampling is not None:
         end_points['next_sampling'] = nxt_sampling

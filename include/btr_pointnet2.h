@@ -669,6 +669,13 @@ int btr_backbone_sampling(const btr_backbone_t *d, const btr_backbone_plan_t *pl
 int btr_backbone_forward(const btr_backbone_t *d, const btr_backbone_plan_t *plan,
                          const float *cloud, const void *geom, void *out, void *saved,
                          void *scratch, int wait_side, btr_stream_t stream);
+/* Software pipelining hook: `event` (a hipEvent_t) is recorded by the NEXT btr_backbone_forward
+ * of the calling host thread, on its stream, right behind set-abstraction level `level`
+ * (1-based; at the last level at the latest).  A trainer that computes the next batch's sampling
+ * pyramid on a side stream makes that stream wait for the event: the ~2 000-step FPS chain then
+ * runs beside the latency-bound middle of the step (SA3 .. loss .. their backward) instead of
+ * beside the two bandwidth-bound levels (votenet/train.py train_step). */
+void btr_backbone_fork_event(void *event, int level);
 int btr_backbone_backward(const btr_backbone_t *d, const btr_backbone_plan_t *plan,
                           const void *geom, const void *out, const float *const *dout_sa,
                           const float *const *dout_fp, void *saved, float *grads, void *scratch,
