@@ -1953,6 +1953,228 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
   }
 }
 
+// ---- single-launch inference set-abstraction layer ---------------------------------------------
+// eval mode (module.eval(), pointnet2_modules.py:210-272 under the evaluation pass of
+// train_Votenet_FSB.py:246-293): BatchNorm uses its RUNNING statistics, so no batch reduction
+// separates the layers -- gather -> conv -> BN -> ReLU -> conv -> BN -> ReLU -> conv -> BN -> ReLU ->
+// max over the group can run per 64 rows without anything of size rows x channels touching HBM
+// (the three-launch eval path writes and re-reads 268 + 268 + 537 MB for SA1 at the benchmark
+// shape).  For the layer shape that carries those bytes: input of <= 4 columns (xyz + one
+// feature), widths <= 64, <= 64, <= 128, nsample 16 / 32 / 64.
+//   stage 0  a thread gathers its row's 4 input values (neighbour index -> coordinates relative to
+//            the centre, scaled; the feature) -- loaded one step ahead -- and evaluates 16 of the
+//            64 first-layer outputs (k = 4: plain FMAs), BN + ReLU, bf16 split -> planes X1
+//   stage 1  64 x 64 x 64 on the matrix pipe (2 x 2 waves; W1 fragments resident in registers),
+//            BN + ReLU on the accumulators, split -> planes X2 (2-byte LDS stores in row layout)
+//   stage 2  64 x 128 x 64 (a wave owns 32 columns of all 64 rows; W2 fragments resident),
+//            BN + ReLU, max over the rows of each group -- all of a group's rows of a column sit
+//            in one wave -- and the pooled values are the only thing written.
+// Same arithmetic as the multi-launch path (bf16x6 products, relu(fma(a, y, b))), so the results
+// agree to rounding; tests/test_eval_fused_gpu.py and the votenet_eval golden.
+struct EvalArgs {
+  const float *xyz, *new_xyz, *feat_cl;   // (B, N, 3), (B, M, 3), (B, N, C) or NULL
+  const int *idx;                          // (B, M, S)
+  const float *w0, *w1, *w2;               // [c1][4], [c2][ld1], [c3][ld2]
+  int ld1, ld2;
+  const float *a0, *b0, *a1, *b1, *a2, *b2;   // eval-mode BatchNorm as scale / shift per layer
+  float *out, *out_cl;                     // (B, c3, M), (B, M, c3)
+  int B, N, M, S, C, use_xyz, c1, c2, c3, steps_per_wg;
+  float inv_radius;
+};
+
+__global__ __launch_bounds__(256, 2) void sa_eval_fused_kernel(EvalArgs a) {
+  constexpr int BR = 64, LX = 72;   // rows per step; bf16 pitch (144 B: conflict-free row reads)
+  __shared__ __attribute__((aligned(16))) __bf16 X1[3 * BR * LX];
+  __shared__ __attribute__((aligned(16))) __bf16 X2[3 * BR * LX];
+  __shared__ __attribute__((aligned(16))) float sW0[64 * 4], sA0[64], sB0[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const long long rows = (long long)a.B * a.M * a.S;
+  const long long nsteps = (rows + BR - 1) / BR;
+  const long long s_beg = (long long)blockIdx.x * a.steps_per_wg;
+  const long long s_end = min(nsteps, s_beg + a.steps_per_wg);
+  for (int i = tid; i < 64 * 4; i += 256) sW0[i] = (i >> 2) < a.c1 ? a.w0[i] : 0.f;
+  if (tid < 64) {
+    sA0[tid] = tid < a.c1 ? a.a0[tid] : 0.f;
+    sB0[tid] = tid < a.c1 ? a.b0[tid] : 0.f;
+  }
+  // weight fragments: stage 1 tile (wr1, wc1) of 32 x 32, stage 2 columns 32 * wave
+  const int wr1 = wave >> 1, wc1 = wave & 1;
+  bf16x8 f1[4][3], f2[4][3];
+  float a1c = 0.f, b1c = 0.f, a2c = 0.f, b2c = 0.f;
+  {
+    const int n1 = wc1 * 32 + l31, n2 = wave * 32 + l31;
+    if (n1 < a.c2) { a1c = a.a1[n1]; b1c = a.b1[n1]; }
+    if (n2 < a.c3) { a2c = a.a2[n2]; b2c = a.b2[n2]; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kb = ks * 16 + h * 8;
+      float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), u1 = u0, v0 = u0, v1 = u0;
+      if (n1 < a.c2 && kb < a.c1) u0 = *reinterpret_cast<const float4 *>(a.w1 + (size_t)n1 * a.ld1 + kb);
+      if (n1 < a.c2 && kb + 4 < a.c1) u1 = *reinterpret_cast<const float4 *>(a.w1 + (size_t)n1 * a.ld1 + kb + 4);
+      if (n2 < a.c3 && kb < a.c2) v0 = *reinterpret_cast<const float4 *>(a.w2 + (size_t)n2 * a.ld2 + kb);
+      if (n2 < a.c3 && kb + 4 < a.c2) v1 = *reinterpret_cast<const float4 *>(a.w2 + (size_t)n2 * a.ld2 + kb + 4);
+      const Split4 su0 = split4(u0), su1 = split4(u1), sv0 = split4(v0), sv1 = split4(v1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f1[ks][0][e] = su0.h[e]; f1[ks][0][4 + e] = su1.h[e];
+        f1[ks][1][e] = su0.m[e]; f1[ks][1][4 + e] = su1.m[e];
+        f1[ks][2][e] = su0.l[e]; f1[ks][2][4 + e] = su1.l[e];
+        f2[ks][0][e] = sv0.h[e]; f2[ks][0][4 + e] = sv1.h[e];
+        f2[ks][1][e] = sv0.m[e]; f2[ks][1][4 + e] = sv1.m[e];
+        f2[ks][2][e] = sv0.l[e]; f2[ks][2][4 + e] = sv1.l[e];
+      }
+    }
+  }
+  __syncthreads();
+  // stage 0 mapping: thread -> (row = tid / 4, columns 16 * (tid % 4) .. + 15)
+  const int grow = tid >> 2, gq = tid & 3;
+  const long long ms = (long long)a.M * a.S;
+  float4 x0n = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto gather = [&](long long step) {
+    const long long r = step * BR + grow;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+      const long long bi = r / ms;
+      const long long g = r / a.S;   // b * M + m
+      const int ii = a.idx[r];
+      int c = 0;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.use_xyz) {
+        const float *p = a.xyz + ((size_t)bi * a.N + ii) * 3;
+        const float *q = a.new_xyz + (size_t)g * 3;
+        v[0] = (p[0] - q[0]) * a.inv_radius;
+        v[1] = (p[1] - q[1]) * a.inv_radius;
+        v[2] = (p[2] - q[2]) * a.inv_radius;
+        c = 3;
+      }
+      for (int j = 0; j < a.C && c < 4; ++j, ++c) v[c] = a.feat_cl[((size_t)bi * a.N + ii) * a.C + j];
+      x = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return x;
+  };
+  if (s_beg < s_end) x0n = gather(s_beg);
+  for (long long step = s_beg; step < s_end; ++step) {
+    const float4 x0 = x0n;
+    // ---- stage 0: first layer on the VALU, BN + ReLU, split
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int c4 = gq * 16 + p * 4;
+      const float4 *w = reinterpret_cast<const float4 *>(sW0) + c4;
+      const float4 fa = *reinterpret_cast<const float4 *>(&sA0[c4]);
+      const float4 fb = *reinterpret_cast<const float4 *>(&sB0[c4]);
+      float4 y = make_float4(rc_dot4(x0, w[0]), rc_dot4(x0, w[1]), rc_dot4(x0, w[2]),
+                             rc_dot4(x0, w[3]));
+      y.x = fmaxf(fmaf(fa.x, y.x, fb.x), 0.f);
+      y.y = fmaxf(fmaf(fa.y, y.y, fb.y), 0.f);
+      y.z = fmaxf(fmaf(fa.z, y.z, fb.z), 0.f);
+      y.w = fmaxf(fmaf(fa.w, y.w, fb.w), 0.f);
+      const Split4 sp = split4(y);
+      const int at = grow * LX + c4;
+      *reinterpret_cast<bf16x4 *>(&X1[0 * BR * LX + at]) = sp.h;
+      *reinterpret_cast<bf16x4 *>(&X1[1 * BR * LX + at]) = sp.m;
+      *reinterpret_cast<bf16x4 *>(&X1[2 * BR * LX + at]) = sp.l;
+    }
+    __syncthreads();   // X1 complete; every wave is past stage 2 of the step before (X2 free)
+    if (step + 1 < s_end) x0n = gather(step + 1);   // the next rows' loads fly under the MFMAs
+    // ---- stage 1: X1 (64 x c1) . W1^T -> 32 x 32 tile (wr1, wc1)
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks * 16 >= a.c1) break;
+        bf16x8 af[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          af[q] = *reinterpret_cast<const bf16x8 *>(
+              &X1[(q * BR + wr1 * 32 + l31) * LX + ks * 16 + h * 8]);
+#define BTR_X6E(F, QA, QB) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA], F[ks][QB], acc, 0, 0, 0);
+        BTR_X6E(f1, 2, 0)
+        BTR_X6E(f1, 0, 2)
+        BTR_X6E(f1, 1, 1)
+        BTR_X6E(f1, 1, 0)
+        BTR_X6E(f1, 0, 1)
+        BTR_X6E(f1, 0, 0)
+      }
+      // BN + ReLU, split, row-layout planes: element (row, col = wc1 * 32 + l31)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = wr1 * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        const float y = fmaxf(fmaf(a1c, acc[v], b1c), 0.f);
+        const __bf16 bh = (__bf16)y;
+        const float r1 = y - (float)bh;
+        const __bf16 bm = (__bf16)r1;
+        const __bf16 bl = (__bf16)(r1 - (float)bm);
+        const int at = row * LX + wc1 * 32 + l31;
+        X2[0 * BR * LX + at] = bh;
+        X2[1 * BR * LX + at] = bm;
+        X2[2 * BR * LX + at] = bl;
+      }
+    }
+    __syncthreads();   // X2 complete (and every wave is done reading X1)
+    // ---- stage 2: X2 (64 x c2) . W2^T -> columns 32 * wave, both row tiles; BN + ReLU + max
+    {
+      f32x16 acc2[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc2[t][v] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks * 16 >= a.c2) break;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          bf16x8 af[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            af[q] = *reinterpret_cast<const bf16x8 *>(
+                &X2[(q * BR + t * 32 + l31) * LX + ks * 16 + h * 8]);
+          f32x16 acc = acc2[t];
+          BTR_X6E(f2, 2, 0)
+          BTR_X6E(f2, 0, 2)
+          BTR_X6E(f2, 1, 1)
+          BTR_X6E(f2, 1, 0)
+          BTR_X6E(f2, 0, 1)
+          BTR_X6E(f2, 0, 0)
+          acc2[t] = acc;
+        }
+      }
+#undef BTR_X6E
+      // max over the rows of each group: 8-row blocks first (v >> 2 = block of the tile, both h)
+      float bmax[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          float mx = 0.f;   // (relu output: >= 0)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mx = fmaxf(mx, fmaxf(fmaf(a2c, acc2[t][4 * b + q], b2c), 0.f));
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          bmax[t][b] = mx;
+        }
+      const int col = wave * 32 + l31;
+      const int gps = BR / a.S;   // groups per step: 1, 2, 4
+      if (h == 0 && col < a.c3) {
+        for (int g = 0; g < gps; ++g) {
+          const long long grp = step * gps + g;
+          if (grp * a.S >= rows) break;
+          float mx = 0.f;
+          const int b0 = g * (a.S / 8), b1 = b0 + a.S / 8;   // 8-row blocks [b0, b1) of the step
+#pragma unroll
+          for (int bb = 0; bb < 8; ++bb)
+            if (bb >= b0 && bb < b1) mx = fmaxf(mx, bmax[bb >> 2][bb & 3]);
+          const long long bi = grp / a.M;
+          const int m = (int)(grp - bi * a.M);
+          a.out[((size_t)bi * a.c3 + col) * a.M + m] = mx;
+          a.out_cl[(size_t)grp * a.c3 + col] = mx;
+        }
+      }
+    }
+  }
+}
+
 // ---- one pass over a layer's backward operands: dgrad + wgrad + the next BatchNorm's sums ------
 // The backward of a hidden layer l used to be five passes over its big tensors: the weight
 // gradient dW_l = dY_l^T . X_{l-1} and the input gradient dZ_{l-1} = dY_l . W_l each read dY_l,
@@ -3551,6 +3773,43 @@ int btr_sa_bn_relu_bwd_rc(long long rows, int c, int ldg, const float *g, const 
   hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(c * 4, 16)), dim3(256), 0, st,
                      c * 4, nblk, pw, dw0);
   return check_launch("sa_bn_relu_bwd_rc");
+}
+
+// ---- single-launch inference set-abstraction layer (sa_eval_fused_kernel)
+int btr_sa_eval_fused_supported(int s, int c, int use_xyz, int c1, int c2, int c3) {
+  static const bool off = getenv("BTR_EVAL_FUSED") && getenv("BTR_EVAL_FUSED")[0] == '0';
+  const int k0 = (use_xyz ? 3 : 0) + c;
+  return !off && gemm_x6() && (s == 16 || s == 32 || s == 64) && k0 >= 1 && k0 <= 4 && c1 >= 4 &&
+         c1 <= 64 && c2 >= 4 && c2 <= 64 && c3 >= 4 && c3 <= 128 && c1 % 4 == 0 && c2 % 4 == 0;
+}
+
+int btr_sa_eval_fused(int b, int n, int m, int s, int c, int use_xyz, float radius_div,
+                      const float *xyz, const float *new_xyz, const float *feats_cl,
+                      const int *idx, int c1, int c2, int c3, const float *w0, const float *w1,
+                      int ld1, const float *w2, int ld2, const float *a0, const float *b0,
+                      const float *a1, const float *b1, const float *a2, const float *b2,
+                      float *out, float *out_cl, btr_stream_t stream) {
+  if (b <= 0 || m <= 0) return BTR_OK;
+  BTR_REQUIRE(btr_sa_eval_fused_supported(s, c, use_xyz, c1, c2, c3),
+              "sa_eval_fused: nsample %d, %d + %d input columns, widths %d %d %d", s,
+              use_xyz ? 3 : 0, c, c1, c2, c3);
+  BTR_REQUIRE(xyz && new_xyz && idx && w0 && w1 && w2 && a0 && b0 && a1 && b1 && a2 && b2 && out &&
+                  out_cl && (c == 0 || feats_cl) && ld1 % 4 == 0 && ld2 % 4 == 0 && ld1 >= c1 &&
+                  ld2 >= c2,
+              "sa_eval_fused: null pointer or bad leading dimension");
+  EvalArgs a{};
+  a.xyz = xyz; a.new_xyz = new_xyz; a.feat_cl = feats_cl; a.idx = idx;
+  a.w0 = w0; a.w1 = w1; a.w2 = w2; a.ld1 = ld1; a.ld2 = ld2;
+  a.a0 = a0; a.b0 = b0; a.a1 = a1; a.b1 = b1; a.a2 = a2; a.b2 = b2;
+  a.out = out; a.out_cl = out_cl;
+  a.B = b; a.N = n; a.M = m; a.S = s; a.C = c; a.use_xyz = use_xyz; a.c1 = c1; a.c2 = c2; a.c3 = c3;
+  a.inv_radius = radius_div != 0.f ? 1.0f / radius_div : 1.0f;
+  const long long steps = ((long long)b * m * s + 63) / 64;
+  const int wgs = (int)std::min<long long>(steps, 1024);
+  a.steps_per_wg = (int)((steps + wgs - 1) / wgs);
+  hipLaunchKernelGGL(sa_eval_fused_kernel, dim3(cdiv((int)steps, a.steps_per_wg)), dim3(256), 0,
+                     as_stream(stream), a);
+  return check_launch("sa_eval_fused");
 }
 
 // btr_sa_bn_relu_bwd_rc minus its statistics pass: the sums come from btr_sa_bwd_fused.

@@ -79,6 +79,9 @@ _SIGNATURES = {
     "btr_sa_rc_wgrad_blocks": (_ci, [_ll, _ci]),
     "btr_sa_bn_relu_bwd_rc": (_ci, [_ll, _ci, _ci] + [_vp] * 15),
     "btr_sa_pool_bwd_coef": (_ci, [_ci, _ci, _ci, _ci, _ci] + [_vp] * 17),
+    "btr_sa_eval_fused_supported": (_ci, [_ci] * 6),
+    "btr_sa_eval_fused": (_ci, [_ci] * 6 + [_cf] + [_vp] * 4 + [_ci] * 3 + [_vp, _vp, _ci, _vp, _ci] +
+                          [_vp] * 9),
     "btr_sa_bwd_fused_supported": (_ci, [_ci, _ci, _ci]),
     "btr_sa_bwd_fused_chunks": (_ci, [_ci, _ci, _ci]),
     "btr_sa_bwd_fused": (_ci, [_ci, _ci, _ci, _vp, _ci] + [_vp] * 7 + [_ci] + [_vp] * 5 +

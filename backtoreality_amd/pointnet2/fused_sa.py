@@ -546,6 +546,33 @@ def fused_eval_forward(module, xyz, new_xyz, features, idx):
         feats_cl = _ext.twin_of(features)
         if feats_cl is None or feats_cl.shape != (B, N, C):
             feats_cl = features.transpose(1, 2).contiguous()
+    layers = list(module.mlp_module)
+    widths = [l.conv.weight.shape[0] for l in layers]
+    if len(layers) == 3 and _lib.btr_sa_eval_fused_supported(S, C, use_xyz, *widths):
+        # the whole layer as ONE launch (csrc/sa_mlp.hip sa_eval_fused_kernel): no rows x channels
+        # tensor reaches HBM
+        ws, ab = [], []
+        K = 4
+        for l in layers:
+            W, bn = l.conv.weight, l.bn.bn
+            W2 = W.reshape(W.shape[0], -1)
+            if W2.shape[1] != K:
+                Wp = torch.zeros((W.shape[0], K), dtype=torch.float32, device=dev)
+                Wp[:, :W2.shape[1]] = W2
+                W2 = Wp
+            ws.append(W2.contiguous())
+            pa = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+            ab += [pa, (bn.bias - bn.running_mean * pa).contiguous()]
+            K = W.shape[0]
+        out = _f32((B, widths[2], M), dev)
+        out_cl = _f32((B, M, widths[2]), dev)
+        with _on(xyz) as d:
+            _call(_lib.btr_sa_eval_fused, B, N, M, S, C, use_xyz, rdiv, _p(xyz), _p(new_xyz),
+                  _p(feats_cl), _p(idx.contiguous()), widths[0], widths[1], widths[2], _p(ws[0]),
+                  _p(ws[1]), widths[0], _p(ws[2]), widths[1], *[_p(t) for t in ab], _p(out),
+                  _p(out_cl), _stream(d))
+        _ext.attach_twin(out, out_cl)
+        return out
     with _on(xyz) as d:
         st = _stream(d)
         A = _f32((R, K0p), dev)

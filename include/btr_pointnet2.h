@@ -309,6 +309,22 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
                         const float *beta, const float *x, int ldx, const float *pa,
                         const float *pb, float *pw, float *dw, btr_stream_t stream);
 
+/* Single-launch INFERENCE set-abstraction layer (csrc/sa_mlp.hip sa_eval_fused_kernel): the eval
+ * mode of PointnetSAModuleVotes.forward (pointnet2_modules.py:210-272 with module.eval(): BatchNorm
+ * on its running statistics, given here as per-channel scale a_l / shift b_l) -- gather, three
+ * 1x1 convolutions with BN + ReLU, max over the nsample axis -- without any rows x channels tensor
+ * in HBM.  Covers the layer shape that carries the bytes: 3 * use_xyz + c <= 4 input columns,
+ * widths c1, c2 <= 64 and c3 <= 128, nsample 16 / 32 / 64 (SA1: 4 -> 64 -> 64 -> 128, 64
+ * samples); w0 [c1][4] (zero-padded input columns), w1 [c2][ld1], w2 [c3][ld2]; idx (b, m, s)
+ * from btr_ball_query; out (b, c3, m) and its channel-last twin out_cl (b, m, c3). */
+int btr_sa_eval_fused_supported(int s, int c, int use_xyz, int c1, int c2, int c3);
+int btr_sa_eval_fused(int b, int n, int m, int s, int c, int use_xyz, float radius_div,
+                      const float *xyz, const float *new_xyz, const float *feats_cl,
+                      const int *idx, int c1, int c2, int c3, const float *w0, const float *w1,
+                      int ld1, const float *w2, int ld2, const float *a0, const float *b0,
+                      const float *a1, const float *b1, const float *a2, const float *b2,
+                      float *out, float *out_cl, btr_stream_t stream);
+
 /* A hidden layer's whole backward as ONE pass over its rows (csrc/sa_mlp.hip
  * sa_bwd_fused_kernel; round 4).  What the calls above do in five passes for layer l -- weight
  * gradient and input gradient each reading dY_l, then BatchNorm_{l-1}'s statistics pass and its
