@@ -954,10 +954,26 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
   const bool bare_bias = !d.has_bn[L - 1] && d.bias[L - 1];
   BTR_TRY(pm_rows_zero(d.b, d.n, nl, npl, dout, g, grads + p.dbias[0],
                        (int)(p.grads_floats - p.dbias[0]), bare_bias ? colsum : nullptr, hs));
+  // `lazy` / `fusable`: as in btr_sa_layer_backward -- a hidden layer behind a BatchNorm runs its
+  // whole backward (dW_l, dZ_{l-1}, BatchNorm_{l-1}'s sums) as one btr_sa_bwd_fused call, which
+  // applies BatchNorm_l's backward from the finalised sums (m1, m2) while it stages dZ_l
+  const char *cf_env = getenv("BTR_CHAIN_FUSED");   // (read per call: the tests toggle it)
+  const bool chain_fused_off = cf_env && cf_env[0] == '0';
+  auto fusable = [&](int l) {
+    return !chain_fused_off && l >= 1 && d.has_bn[l] &&
+           btr_sa_bwd_fused_supported(rows, p.np[l], p.kin[l]) != 0;
+  };
+  bool lazy = false, fused_any = false;
   if (d.has_bn[L - 1]) {
-    BTR_TRY(btr_sa_bn_relu_bwd(rows, npl, npl, g, at_f(saved, p.y[L - 1]), stat(L - 1, 0),
-                               stat(L - 1, 1), stat(L - 1, 2), stat(L - 1, 3), part, m1, m2,
-                               grads + p.dgamma[L - 1], grads + p.dbeta[L - 1], stream));
+    if (fusable(L - 1)) {
+      BTR_TRY(btr_sa_bn_relu_bwd_sums(rows, npl, npl, g, at_f(saved, p.y[L - 1]), stat(L - 1, 0),
+                                      stat(L - 1, 1), stat(L - 1, 2), stat(L - 1, 3), part, m1, m2,
+                                      grads + p.dgamma[L - 1], grads + p.dbeta[L - 1], stream));
+      lazy = true;
+    } else
+      BTR_TRY(btr_sa_bn_relu_bwd(rows, npl, npl, g, at_f(saved, p.y[L - 1]), stat(L - 1, 0),
+                                 stat(L - 1, 1), stat(L - 1, 2), stat(L - 1, 3), part, m1, m2,
+                                 grads + p.dgamma[L - 1], grads + p.dbeta[L - 1], stream));
   } else if (bare_bias) {
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(npl, 256)), dim3(256), 0, hs,
                        d.b * cdiv(d.n, 64), npl, colsum, grads + p.dbias[L - 1]);
@@ -975,6 +991,27 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
     const int ldx = l == 0 ? p.kin[0] : p.np[l - 1];
     const float *pa = l == 0 ? nullptr : stat(l - 1, 0);
     const float *pb = l == 0 ? nullptr : stat(l - 1, 1);
+    if (lazy && fusable(l)) {
+      float *gn = at_f(scratch, sc.g[flip]);
+      flip ^= 1;
+      // gn is the buffer dY_{l+1} lived in: its weight gradient must be through with it
+      if (side && l + 1 <= L - 1 && last_done == l + 1)
+        (void)hipStreamWaitEvent(hs, side->done[l + 1], 0);
+      BTR_TRY(btr_sa_bwd_fused(rows, np, k, dy, np, at_f(saved, p.y[l]), stat(l, 0), stat(l, 1),
+                               stat(l, 2), stat(l, 3), m1, m2, 0, nullptr, nullptr, nullptr,
+                               nullptr, xsrc, ldx, nullptr, pa, pb, stat(l - 1, 2), stat(l - 1, 3),
+                               at_f(saved, p.wt[l]), np, gn, k, at_f(scratch, sc.pw[l]),
+                               grads + p.dw[l], part, m1, m2, grads + p.dgamma[l - 1],
+                               grads + p.dbeta[l - 1], stream));
+      dy = gn;
+      fused_any = true;   // (and still lazy: dy = dZ_{l-1} with BatchNorm_{l-1}'s sums in m1, m2)
+      continue;
+    }
+    if (lazy) {   // a consumer that wants dY_l itself
+      BTR_TRY(btr_sa_bn_relu_bwd_apply(rows, np, np, dy, at_f(saved, p.y[l]), stat(l, 0),
+                                       stat(l, 1), stat(l, 2), stat(l, 3), m1, m2, stream));
+      lazy = false;
+    }
     btr_stream_t ws = stream;   // weight gradient on the side stream (see SideStream)
     if (side) {
       (void)hipEventRecord(side->ready[l], hs);
@@ -991,13 +1028,21 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
       float *gn = at_f(scratch, sc.g[flip]);
       flip ^= 1;
       // gn is the buffer dY_{l+1} lived in: its weight gradient must be through with it
-      if (side && l + 1 <= L - 1) (void)hipStreamWaitEvent(hs, side->done[l + 1], 0);
+      if (side && l + 1 <= L - 1 && last_done == l + 1)
+        (void)hipStreamWaitEvent(hs, side->done[l + 1], 0);
       BTR_TRY(btr_pm_gemm_nt(rows, k, np, dy, np, at_f(saved, p.wt[l]), np, gn, k, nullptr,
                              nullptr, nullptr, nullptr, stream));
       if (l > 0) {
-        BTR_TRY(btr_sa_bn_relu_bwd(rows, k, k, gn, at_f(saved, p.y[l - 1]), stat(l - 1, 0),
-                                   stat(l - 1, 1), stat(l - 1, 2), stat(l - 1, 3), part, m1, m2,
-                                   grads + p.dgamma[l - 1], grads + p.dbeta[l - 1], stream));
+        if (fusable(l - 1)) {   // the next layer applies the sums while it stages gn
+          BTR_TRY(btr_sa_bn_relu_bwd_sums(rows, k, k, gn, at_f(saved, p.y[l - 1]),
+                                          stat(l - 1, 0), stat(l - 1, 1), stat(l - 1, 2),
+                                          stat(l - 1, 3), part, m1, m2, grads + p.dgamma[l - 1],
+                                          grads + p.dbeta[l - 1], stream));
+          lazy = true;
+        } else
+          BTR_TRY(btr_sa_bn_relu_bwd(rows, k, k, gn, at_f(saved, p.y[l - 1]), stat(l - 1, 0),
+                                     stat(l - 1, 1), stat(l - 1, 2), stat(l - 1, 3), part, m1, m2,
+                                     grads + p.dgamma[l - 1], grads + p.dbeta[l - 1], stream));
         dy = gn;
       } else {
         BTR_REQUIRE(dx, "pm_chain_backward: dx missing");
@@ -1005,8 +1050,12 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
       }
     }
   }
+  if (side && fused_any) {   // the fused calls' partials were written on the main stream
+    (void)hipEventRecord(side->ready[kMaxL], hs);
+    (void)hipStreamWaitEvent(side->s, side->ready[kMaxL], 0);
+  }
   batch.flush();
-  if (side && last_done >= 0) {   // join
+  if (side && (last_done >= 0 || fused_any)) {   // join
     (void)hipEventRecord(side->done[kMaxL], side->s);
     (void)hipStreamWaitEvent(hs, side->done[kMaxL], 0);
   }

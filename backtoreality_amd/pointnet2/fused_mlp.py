@@ -154,12 +154,25 @@ class PointwiseMLP(Function):
             Np = Ys[-1].shape[1]
             G = _f32((rows, Np), dev)
             _call(_lib.btr_pm_rows, B, N, NL, Np, _p(dout.contiguous()), _p(G), st)
+            # `lazy` / `fusable`: the same sequence as csrc/sa_layer.hip btr_pm_chain_backward -- a
+            # hidden layer behind a BatchNorm runs its whole backward as one btr_sa_bwd_fused call
+            fused_on = os.environ.get("BTR_CHAIN_FUSED", "1") != "0"
+
+            def fusable(j):
+                return fused_on and j >= 1 and stats[j] is not None and bool(
+                    _lib.btr_sa_bwd_fused_supported(rows, Ws[j].shape[0], Ws[j].shape[1]))
+            lazy = None
             if stats[-1] is not None:
                 sc, sh, mu, isd = stats[-1]
                 part = _f32((1024, 2, Np), dev)
                 m1, m2, dg, db = (_f32((Np,), dev) for _ in range(4))
-                _call(_lib.btr_sa_bn_relu_bwd, rows, Np, Np, _p(G), _p(Ys[-1]), _p(sc), _p(sh),
-                      _p(mu), _p(isd), _p(part), _p(m1), _p(m2), _p(dg), _p(db), st)
+                if fusable(L - 1):
+                    _call(_lib.btr_sa_bn_relu_bwd_sums, rows, Np, Np, _p(G), _p(Ys[-1]), _p(sc),
+                          _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2), _p(dg), _p(db), st)
+                    lazy = (m1, m2)
+                else:
+                    _call(_lib.btr_sa_bn_relu_bwd, rows, Np, Np, _p(G), _p(Ys[-1]), _p(sc),
+                          _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2), _p(dg), _p(db), st)
                 grads[4 * (L - 1) + 2], grads[4 * (L - 1) + 3] = dg[:NL], db[:NL]
                 if ctx.pshapes[4 * (L - 1) + 1] is not None:
                     grads[4 * (L - 1) + 1] = torch.zeros(NL, device=dev)
@@ -175,6 +188,34 @@ class PointwiseMLP(Function):
                 else:
                     Xsrc, ldx = Ys[l - 1], Ys[l - 1].shape[1]
                     pa, pb = stats[l - 1][0], stats[l - 1][1]
+                if lazy is not None and fusable(l):
+                    chunks = _lib.btr_sa_bwd_fused_chunks(rows, Np, K)
+                    pw = _f32((chunks, Np, K), dev)
+                    dW = _f32((Np, K), dev)
+                    Wt = W2.t().contiguous()
+                    Gn = _f32((rows, K), dev)
+                    part = _f32((chunks, 2, K), dev)
+                    m1, m2, dg, db = (_f32((K,), dev) for _ in range(4))
+                    scl, shl, mul, isl = stats[l]
+                    scp, shp, mup, isp = stats[l - 1]
+                    _call(_lib.btr_sa_bwd_fused, rows, Np, K, _p(dY), Np, _p(Ys[l]), _p(scl),
+                          _p(shl), _p(mul), _p(isl), _p(lazy[0]), _p(lazy[1]), 0, None, None, None,
+                          None, _p(Xsrc), ldx, None, _p(pa), _p(pb), _p(mup), _p(isp), _p(Wt), Np,
+                          _p(Gn), K, _p(pw), _p(dW), _p(part), _p(m1), _p(m2), _p(dg), _p(db), st,
+                          key=(rows, Np, K))
+                    grads[4 * l] = dW[:Nl].reshape(ctx.pshapes[4 * l])
+                    wprev = ctx.widths[l - 1]
+                    grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3] = dg[:wprev], db[:wprev]
+                    if ctx.pshapes[4 * (l - 1) + 1] is not None:
+                        grads[4 * (l - 1) + 1] = torch.zeros(wprev, device=dev)
+                    dY = Gn
+                    lazy = (m1, m2)
+                    continue
+                if lazy is not None:   # a consumer that wants dY_l itself
+                    scl, shl, mul, isl = stats[l]
+                    _call(_lib.btr_sa_bn_relu_bwd_apply, rows, Np, Np, _p(dY), _p(Ys[l]), _p(scl),
+                          _p(shl), _p(mul), _p(isl), _p(lazy[0]), _p(lazy[1]), st)
+                    lazy = None
                 chunks = _lib.btr_sa_gemm_tn_chunks(rows, Np, K)
                 pw = _f32((chunks, Np, K), dev)
                 dW = _f32((Np, K), dev)
@@ -190,9 +231,15 @@ class PointwiseMLP(Function):
                         sc, sh, mu, isd = stats[l - 1]
                         part = _f32((1024, 2, K), dev)
                         m1, m2, dg, db = (_f32((K,), dev) for _ in range(4))
-                        _call(_lib.btr_sa_bn_relu_bwd, rows, K, K, _p(Gn), _p(Ys[l - 1]), _p(sc),
-                              _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2), _p(dg), _p(db),
-                              st)
+                        if fusable(l - 1):   # the next layer applies the sums itself
+                            _call(_lib.btr_sa_bn_relu_bwd_sums, rows, K, K, _p(Gn), _p(Ys[l - 1]),
+                                  _p(sc), _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2),
+                                  _p(dg), _p(db), st)
+                            lazy = (m1, m2)
+                        else:
+                            _call(_lib.btr_sa_bn_relu_bwd, rows, K, K, _p(Gn), _p(Ys[l - 1]),
+                                  _p(sc), _p(sh), _p(mu), _p(isd), _p(part), _p(m1), _p(m2),
+                                  _p(dg), _p(db), st)
                         wprev = ctx.widths[l - 1]
                         grads[4 * (l - 1) + 2], grads[4 * (l - 1) + 3] = dg[:wprev], db[:wprev]
                         if ctx.pshapes[4 * (l - 1) + 1] is not None:

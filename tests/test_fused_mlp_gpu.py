@@ -89,6 +89,63 @@ def test_proposal_head(cuda, monkeypatch):
     _compare(run, pm, monkeypatch, zero_ok=("dconv1.bias", "dconv2.bias"))
 
 
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_chain_backward_through_the_fused_layer_kernel(cuda, monkeypatch, native):
+    """Round 4: a hidden chain layer behind a BatchNorm runs its backward as one
+    btr_sa_bwd_fused call (BTR_CHAIN_FUSED=0: weight-gradient + input-gradient GEMMs and the
+    BatchNorm-backward passes).  Both sequences against float64 torch ops on the same chain --
+    three BatchNorm layers + a bare last layer, padded last width -- and against each other."""
+    from backtoreality_amd.pointnet2 import fused_mlp
+    monkeypatch.setenv("BTR_CHAIN_MIN_ROWS", "0")
+    monkeypatch.setenv("BTR_NATIVE_LAYERS", native)
+    torch.manual_seed(5)
+    widths = [128, 256, 256, 128, 79]
+    convs = [torch.nn.Conv1d(a, b, 1).to(cuda) for a, b in zip(widths[:-1], widths[1:])]
+    bns = [torch.nn.BatchNorm1d(w).to(cuda) for w in widths[1:-1]]
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    chain = [(c, b, True) for c, b in zip(convs[:-1], bns)] + [(convs[-1], None, False)]
+    x = torch.randn(4, 128, 1024, device=cuda)
+    wgt = torch.randn(4, 79, 1024, device=cuda)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BTR_CHAIN_FUSED", flag)
+        for m in convs + bns:
+            m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        out = fused_mlp.run_chain(xi, chain)
+        assert out is not None
+        (out * wgt).sum().backward()
+        res[flag] = [xi.grad] + [p.grad.clone() for m in convs + bns for p in m.parameters()]
+    # float64 reference
+    c64 = [copy.deepcopy(c).double() for c in convs]
+    b64 = [copy.deepcopy(b).double() for b in bns]
+    for m in c64 + b64:
+        m.zero_grad(set_to_none=True)
+    xi = x.double().requires_grad_(True)
+    h = xi
+    for i, c in enumerate(c64):
+        h = c(h)
+        if i < len(b64):
+            h = torch.relu(b64[i](h))
+    (h * wgt.double()).sum().backward()
+    ref = [xi.grad] + [p.grad for m in c64 + b64 for p in m.parameters()]
+    names = ["dx"] + ["%s.%s" % (type(m).__name__, n) for m in convs + bns
+                     for n, _ in m.named_parameters()]
+    for name, a, b, r in zip(names, res["0"], res["1"], ref):
+        scale = float(r.abs().max()) + 1e-12
+        if "Conv1d.bias" in name and scale < 1e-6:
+            continue
+        ea, eb = float((a - r).abs().max()) / scale, float((b - r).abs().max()) / scale
+        # (a convolution bias in front of a BatchNorm: true gradient 0, rounding noise in float64)
+        if "Conv1d.bias" in name and float(b.abs().max()) == 0.0:
+            continue
+        assert eb <= 2 * ea + 1e-5, (name, ea, eb)
+        assert eb < 2e-4, (name, eb)
+
+
 def test_small_problems_stay_on_the_stock_ops(cuda, monkeypatch):
     """The row gate of run_chain (fused_mlp._min_rows): one library call per chain takes every
     size; the Python-sequenced form and the path a HIP-graph capture takes leave chains below
