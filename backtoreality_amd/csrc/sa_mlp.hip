@@ -1737,12 +1737,14 @@ struct StreamArgs {
   const float *gsign;   // PS > 0: the layer's gamma
   float *gext;
   unsigned char *aext;
+  int hs;               // log2 of the 128-column slabs of n (n > 128: two workgroups per row chunk)
 };
 
 template <int BR, int KMAX, int PRO, bool STATS, int PS>
 __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Compact cm) {
   static_assert((BR == 32 || BR == 64) && (KMAX == 64 || KMAX == 128), "tile shapes");
-  static_assert(PS == 0 || PS == 8, "pooling epilogue: 8-row blocks (compact rows)");
+  static_assert(PS == 0 || PS == 8 || PS == 16,
+                "pooling epilogue: 8-row blocks (compact rows) or groups of 16 rows");
   constexpr int WR = BR / 32;           // row tiles (waves along the rows)
   constexpr int WC = 4 / WR;            // column tiles: n <= 32 * WC
   constexpr int LX = KMAX + 8;          // bf16 pitch: 144 / 272 B (conflict-free 16-byte row reads)
@@ -1754,22 +1756,25 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
   int R = a.R, rows_per_chunk = a.rows_per_chunk;
   if (cm.dims) {   // compact rows: count and split on the device (see sa_bwd_fused_kernel)
     R = cm.dims[0];
-    rows_per_chunk = ((R + (int)gridDim.x - 1) / (int)gridDim.x + BR - 1) / BR * BR;
+    const int nchunks = (int)gridDim.x >> a.hs;
+    rows_per_chunk = ((R + nchunks - 1) / nchunks + BR - 1) / BR * BR;
   }
   const int N = a.N, K = a.K;
+  // n > 128: neighbouring workgroups share a row chunk and take one 128-column slab each
+  const int chunk = (int)blockIdx.x >> a.hs, cb = ((int)blockIdx.x & ((1 << a.hs) - 1)) * 128;
   __shared__ __attribute__((aligned(16))) __bf16 Xp[2][3 * BR * LX];
   __shared__ __attribute__((aligned(16))) float Ts[4][32 * LT];
   __shared__ double red[STATS ? 2 * WR * 32 * WC : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int l31 = lane & 31, h = lane >> 5;
-  const int rbeg = blockIdx.x * rows_per_chunk;
+  const int rbeg = chunk * rows_per_chunk;
   const int rend = min(R, rbeg + rows_per_chunk);
 
   // ---- this wave's 32 weight rows, split once
   bf16x8 bdr[KS][3];
   {
-    const int nr = wc * 32 + l31;
+    const int nr = cb + wc * 32 + l31;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int kb = ks * 16 + h * 8;
@@ -1810,7 +1815,8 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
                          : *reinterpret_cast<const float4 *>(a.A + (size_t)(r0 + row) * a.lda + xc4);
     }
   };
-  const float sg = (PS > 0 && wc * 32 + l31 < N && a.gsign[wc * 32 + l31] < 0.f) ? -1.f : 1.f;
+  const float sg =
+      (PS > 0 && cb + wc * 32 + l31 < N && a.gsign[cb + wc * 32 + l31] < 0.f) ? -1.f : 1.f;
   double d1 = 0.0, d2 = 0.0;
   if (rbeg < rend) fetch(rbeg);
   int buf = 0;
@@ -1872,7 +1878,7 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
 #undef BTR_X6S
     }
     // ---- epilogue on the accumulators: D layout col = lane & 31, row = (v&3) + 8*(v>>2) + 4*h
-    const int col = wc * 32 + l31;
+    const int col = cb + wc * 32 + l31;
     const int wrow0 = r0 + wr * 32;
     if constexpr (STATS) {   // rows >= rend hold exact zeros
       float s1 = 0.f, s2 = 0.f;
@@ -1890,7 +1896,9 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
       d1 += (double)s1;
       d2 += (double)s2;
     }
-    if constexpr (PS == 8) {
+    if constexpr (PS > 0) {
+      float bestv[4];
+      int bestr[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         float vmx = -3.0e38f;
@@ -1907,13 +1915,29 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
         const float omx = __shfl_xor(vmx, 32);
         const int oix = __shfl_xor(mine, 32);
         const bool take = omx > vmx || (omx == vmx && oix < mine);
-        const float best = take ? omx : vmx;
-        const int bidx = take ? oix : mine;
-        const int grow = wrow0 + b * 8;
-        if (h == 0 && grow < rend && col < N) {
-          const size_t o = (size_t)(grow >> 3) * N + col;
-          a.gext[o] = best * sg;
-          a.aext[o] = (unsigned char)bidx;
+        bestv[b] = take ? omx : vmx;
+        bestr[b] = take ? oix : mine;
+      }
+      if constexpr (PS == 8) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int grow = wrow0 + b * 8;
+          if (h == 0 && grow < rend && col < N) {
+            const size_t o = (size_t)(grow >> 3) * N + col;
+            a.gext[o] = bestv[b] * sg;
+            a.aext[o] = (unsigned char)bestr[b];
+          }
+        }
+      } else {   // groups of 16 rows: two blocks, the first occurrence wins a tie
+#pragma unroll
+        for (int b = 0; b < 4; b += 2) {
+          const bool second = bestv[b + 1] > bestv[b];
+          const int grow = wrow0 + b * 8;
+          if (h == 0 && grow < rend && col < N) {
+            const size_t o = (size_t)(grow >> 4) * N + col;
+            a.gext[o] = (second ? bestv[b + 1] : bestv[b]) * sg;
+            a.aext[o] = (unsigned char)(second ? 8 + bestr[b + 1] : bestr[b]);
+          }
         }
       }
     }
@@ -1924,7 +1948,7 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the tile is private to the wave)
       __builtin_amdgcn_wave_barrier();
       const int rl = lane >> 3, c4 = (lane & 7) * 4;   // 8 rows x 8 float4 per pass
-      const int colw = wc * 32 + c4;
+      const int colw = cb + wc * 32 + c4;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const float4 q4 = *reinterpret_cast<const float4 *>(&T[(it * 8 + rl) * LT + c4]);
@@ -1948,7 +1972,7 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
       double sum = 0.0;
 #pragma unroll
       for (int w = 0; w < WR; ++w) sum += red[(which * WR + w) * 32 * WC + col];
-      if (col < N) a.part[((size_t)blockIdx.x * 2 + which) * N + col] = (float)sum;
+      if (cb + col < N) a.part[((size_t)chunk * 2 + which) * N + cb + col] = (float)sum;
     }
   }
 }
@@ -3125,6 +3149,57 @@ __global__ __launch_bounds__(256) void sac_pool_kernel(
   arg[t] = best > 0.f ? (unsigned char)ba : (unsigned char)0;
 }
 
+// The same two pools (goff != nullptr: per-block extrema of compact rows; nullptr: one extremum per
+// group) on a 32-group x 32-channel tile per workgroup: the (B, C, M) output is written through an
+// LDS transpose as 128-byte segments along m -- with a thread per (group, channel) the 4-byte
+// stores of consecutive channels are M floats apart, one write transaction each (SA1: 2 M of them,
+// 42 us for a kernel whose bytes take 18).  Needs M % 32 == 0 (a tile stays in one batch element).
+__global__ __launch_bounds__(256) void sa_pool_tile_kernel(
+    int M, int C, const float *__restrict__ gext, const unsigned char *__restrict__ aext,
+    const int *__restrict__ goff, const float *__restrict__ scale,
+    const float *__restrict__ shift, float *__restrict__ out, float *__restrict__ out_cl,
+    unsigned char *__restrict__ arg) {
+  __shared__ float T[32 * 33];
+  const int c = (int)blockIdx.y * 32 + (threadIdx.x & 31), jj = threadIdx.x >> 5;
+  const long long g0 = (long long)blockIdx.x * 32;
+  const bool live = c < C;
+  const float a = live ? scale[c] : 0.f, b = live ? shift[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = jj + 8 * i;
+    const long long g = g0 + j;
+    float best = -1.f;
+    int ba = 0;
+    if (live) {
+      if (goff) {
+        const int b0 = goff[g] >> 3, b1 = goff[g + 1] >> 3;
+        for (int blk = b0; blk < b1; ++blk) {
+          const float v = fmaxf(fmaf(a, gext[(size_t)blk * C + c], b), 0.f);
+          if (v > best) {
+            best = v;
+            ba = ((blk - b0) << 3) + aext[(size_t)blk * C + c];
+          }
+        }
+      } else {
+        best = fmaxf(fmaf(a, gext[(size_t)g * C + c], b), 0.f);
+        ba = aext[(size_t)g * C + c];
+      }
+      if (out_cl) out_cl[(size_t)g * C + c] = best;
+      arg[(size_t)g * C + c] = best > 0.f ? (unsigned char)ba : (unsigned char)0;
+    }
+    T[(threadIdx.x & 31) * 33 + j] = best;
+  }
+  __syncthreads();
+  const long long bi = g0 / M;
+  const int m0 = (int)(g0 - bi * M);
+  const int j = threadIdx.x & 31;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cl = jj + 8 * i, cc = (int)blockIdx.y * 32 + cl;
+    if (cc < C) out[((size_t)bi * C + cc) * M + m0 + j] = T[cl * 33 + j];
+  }
+}
+
 // Inverted neighbour lists of the compact rows of ONE batch element per workgroup (as
 // csr_small_kernel; rows goff[b*M] .. goff[(b+1)*M) of batch element b, N <= kCsrSmallN bins).
 __global__ __launch_bounds__(1024) void sac_csr_kernel(int M, int N, const int *__restrict__ cidx,
@@ -3392,17 +3467,22 @@ bool bnfin_arm(const BnFin &fin, long long rows) {
 // ticket path covers the tiny layers, and a streaming grid of few steps gains nothing).
 namespace btr {
 constexpr int kStreamMinRows = 16384;
+// BTR_FWD_STREAM_WIDE=0: only what the first form took (n <= 128, 8-row pooling blocks)
+static bool stream_wide() {
+  const char *e = getenv("BTR_FWD_STREAM_WIDE");
+  return !(e && e[0] == '0');
+}
 static bool stream_ok(int rows, int n, int k, int lda_ok, bool fin_armed) {
   const char *e = getenv("BTR_FWD_STREAM");   // (read per call: tests and A/B runs toggle it)
   const bool off = e && e[0] == '0';
   return !off && gemm_x6() && !fin_armed && lda_ok && rows >= kStreamMinRows && n % 4 == 0 &&
-         k % 4 == 0 && n <= 128 && k <= 128 && !host_compact().dev.kz;
+         k % 4 == 0 && n <= (stream_wide() ? 256 : 128) && k <= 128 && !host_compact().dev.kz;
 }
 template <int BR, int KMAX, int PRO, bool STATS, int PS>
 static void launch_stream(int gx, hipStream_t st, StreamArgs &a) {
   a.rows_per_chunk = cdiv(cdiv(a.R, gx), BR) * BR;
-  hipLaunchKernelGGL((sa_fwd_stream_kernel<BR, KMAX, PRO, STATS, PS>), dim3(gx), dim3(256), 0, st,
-                     a, cur_compact());
+  hipLaunchKernelGGL((sa_fwd_stream_kernel<BR, KMAX, PRO, STATS, PS>), dim3(gx << a.hs), dim3(256),
+                     0, st, a, cur_compact());
 }
 // pro: 0 / 1 / 3;  ps: 0 / 8.  The instantiated combinations are the layers' (see the kernel).
 static bool try_stream(int rows, int n, int k, const float *A, int lda, const float *W, int ldw,
@@ -3414,9 +3494,16 @@ static bool try_stream(int rows, int n, int k, const float *A, int lda, const fl
   a.pa = pa; a.pb = pb; a.w0 = w0; a.part = part; a.gsign = gamma; a.gext = gext; a.aext = aext;
   const int gx = btr_sa_gemm_grid(rows);
   const bool stats = part != nullptr;
+  // n > 128 (the 256-wide pooled layers): two 128-column slabs per row chunk -- with the
+  // 32-row steps only (four column tiles per workgroup)
+  a.hs = n > 128 ? 1 : 0;
   if (ps == 8) {
     if (pro == 1 && stats && n > 64 && k <= 64) { launch_stream<32, 64, 1, true, 8>(gx, st, a); return true; }
     if (pro == 1 && stats && n > 64) { launch_stream<32, 128, 1, true, 8>(gx, st, a); return true; }
+    return false;
+  }
+  if (ps == 16) {
+    if (pro == 1 && stats && n > 64 && k > 64) { launch_stream<32, 128, 1, true, 16>(gx, st, a); return true; }
     return false;
   }
   if (ps != 0) return false;
@@ -3540,8 +3627,8 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
   const BnFin fin = take_bnfin();
-  if (s == 8 && stream_ok(rows, n, k, lda % 4 == 0, fin.ticket != nullptr) &&
-      try_stream(rows, n, k, a, lda, w, ldw, c, ldc, pa, pb, nullptr, part, 8, gamma, gext, aext, 1,
+  if ((s == 8 || (s == 16 && stream_wide())) && stream_ok(rows, n, k, lda % 4 == 0, fin.ticket != nullptr) &&
+      try_stream(rows, n, k, a, lda, w, ldw, c, ldc, pa, pb, nullptr, part, s, gamma, gext, aext, 1,
                  st))
     return check_launch("sa_gemm_nt_poolfwd(stream)");
 #define BTR_GEMM_MM(PS, MM)                                                                   \
@@ -3563,15 +3650,27 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
   return check_launch("sa_gemm_nt_poolfwd");
 }
 
+// sa_pool_tile_kernel takes the pools whose groups tile by 32 (BTR_POOL_TILE=0: the
+// thread-per-element kernels; read per call, the tests compare the two)
+static bool pool_tiled(int m) {
+  const char *e = getenv("BTR_POOL_TILE");
+  return m % 32 == 0 && !(e && e[0] == '0');
+}
+
 int btr_sa_pool_fin(int b, int m, int c, const float *gext, const unsigned char *aext,
                     const float *scale, const float *shift, float *out, float *out_cl,
                     unsigned char *arg, btr_stream_t stream) {
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(gext && aext && scale && shift && out && arg, "sa_pool_fin: null pointer");
-  hipLaunchKernelGGL(sa_pool_fin_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
-                     as_stream(stream), m, c, gext, aext, scale, shift, out, out_cl, arg,
-                     groups);
+  if (pool_tiled(m))
+    hipLaunchKernelGGL(sa_pool_tile_kernel, dim3((unsigned)(groups / 32), cdiv(c, 32)), dim3(256),
+                       0, as_stream(stream), m, c, gext, aext, (const int *)nullptr, scale, shift,
+                       out, out_cl, arg);
+  else
+    hipLaunchKernelGGL(sa_pool_fin_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
+                       as_stream(stream), m, c, gext, aext, scale, shift, out, out_cl, arg,
+                       groups);
   return check_launch("sa_pool_fin");
 }
 
@@ -4119,9 +4218,14 @@ int btr_sac_pool(int b, int m, int c, const float *gext, const unsigned char *ae
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(gext && aext && goff && scale && shift && out && arg, "sac_pool: null pointer");
-  hipLaunchKernelGGL(sac_pool_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
-                     as_stream(stream), m, c, groups, gext, aext, goff, scale, shift, out, out_cl,
-                     arg);
+  if (pool_tiled(m))
+    hipLaunchKernelGGL(sa_pool_tile_kernel, dim3((unsigned)(groups / 32), cdiv(c, 32)), dim3(256),
+                       0, as_stream(stream), m, c, gext, aext, goff, scale, shift, out, out_cl,
+                       arg);
+  else
+    hipLaunchKernelGGL(sac_pool_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
+                       as_stream(stream), m, c, groups, gext, aext, goff, scale, shift, out,
+                       out_cl, arg);
   return check_launch("sac_pool");
 }
 

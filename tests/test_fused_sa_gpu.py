@@ -203,6 +203,39 @@ def test_pooling_epilogue_equals_the_pool_pass(cuda, monkeypatch, S):
     assert torch.equal(outs["1"][0], outs["0"][0])      # the pooled values are bit-identical
 
 
+@pytest.mark.parametrize("compact", ["1", "0"])
+@pytest.mark.parametrize("width", [128, 100])
+def test_tiled_pool_equals_the_per_element_pool(cuda, monkeypatch, compact, width):
+    """sa_pool_tile_kernel (32 groups x 32 channels per workgroup, (B, C, M) written through an LDS
+    transpose) against the thread-per-element kernels (BTR_POOL_TILE=0): pooled features, arg-max
+    routing (through the gradients) bit-identical, on compact rows and on dense rows, with a
+    channel count that does not fill the last tile."""
+    from backtoreality_amd.pointnet2 import pointnet2_modules as M
+    monkeypatch.setenv("BTR_SA_COMPACT", compact)
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.rand(2, 3000, 3, generator=g).to(cuda)
+    feats = torch.randn(2, 4, 3000, generator=g).to(cuda)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BTR_POOL_TILE", flag)
+        torch.manual_seed(0)
+        sa = M.PointnetSAModuleVotes(npoint=256, radius=0.2, nsample=32, mlp=[4, 32, width],
+                                     use_xyz=True, normalize_xyz=True).to(cuda)
+        with torch.no_grad():
+            w = sa.mlp_module.layer1.bn.bn.weight
+            w[::3] = -w[::3]
+        f = feats.clone().requires_grad_(True)
+        _, nf, _ = sa(xyz, f)
+        (nf * torch.linspace(0.5, 1.5, nf.shape[2], device=cuda)).sum().backward()
+        outs[flag] = (nf.detach(), f.grad, sa.mlp_module.layer0.conv.weight.grad,
+                      sa.mlp_module.layer1.conv.weight.grad)
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    # (same arg-max routing: the gradients agree to the rounding of their own reductions -- the
+    # compact rows' scatter adds with atomics)
+    for a, b in zip(outs["1"][1:], outs["0"][1:]):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), float((a - b).abs().max())
+
+
 @pytest.mark.parametrize("N,npoint,radius,S,mlp,C,feat_grad", [
     (4096, 512, 0.2, 64, [1, 64, 64, 128], 1, False),        # SA1: first-layer recompute
     (2048, 256, 0.4, 32, [128, 128, 128, 256], 128, True),   # SA2: feature gradient (scatter)

@@ -1,7 +1,7 @@
 """sa_fwd_stream_kernel (csrc/sa_mlp.hip): the streaming form of the narrow layers' NT GEMMs --
-taken by btr_sa_gemm_nt / _rc / _poolfwd for n <= 128, k <= 128 and >= 16 384 rows -- against a
+taken by btr_sa_gemm_nt / _rc / _poolfwd for n <= 256, k <= 128 and >= 16 384 rows -- against a
 float64 evaluation: the product (with the BatchNorm + ReLU / first-layer-recompute prologues),
-the BatchNorm statistics partials, and the pooling extrema of 8-row blocks with the arg-max row
+the BatchNorm statistics partials, and the pooling extrema of 8-row blocks / 16-row groups with the arg-max row
 (first maximum; the minimum where gamma < 0)."""
 import pytest
 import torch
@@ -25,6 +25,8 @@ def _sums(part, nblk, n):
     (17000, 64, 64, 0, False),
     (16390, 100, 36, 1, True),     # n, k not multiples of 32
     (20000, 128, 64, 0, False),
+    (18000, 256, 128, 1, True),    # two 128-column slabs per row chunk
+    (16400, 200, 64, 0, False),    # ... the second one not full
 ])
 def test_stream_nt_matches_float64(cuda, rows, n, k, pro, stats):
     g = torch.Generator(device="cpu").manual_seed(rows + n)
@@ -70,8 +72,14 @@ def test_stream_first_layer_recompute(cuda):
     assert float((s2 - (ref * ref).sum(0)).abs().max()) <= 1e-5 * float((ref * ref).sum(0).max())
 
 
-@pytest.mark.parametrize("rows,n,k", [(20000, 128, 64), (16392, 128, 128), (24000, 100, 64)])
-def test_stream_pooling_epilogue_of_8_row_blocks(cuda, rows, n, k):
+@pytest.mark.parametrize("rows,n,k,ps", [
+    (20000, 128, 64, 8), (16392, 128, 128, 8), (24000, 100, 64, 8),
+    (18008, 256, 128, 8),     # SA2's pooled layer: 256 wide
+    (32768, 128, 128, 16),    # the vote aggregation's pooled layer: groups of 16 dense rows
+    (65536, 256, 128, 16),    # SA3's
+    (16400, 200, 100, 16),
+])
+def test_stream_pooling_epilogue_of_8_row_blocks(cuda, rows, n, k, ps):
     g = torch.Generator(device="cpu").manual_seed(n + k)
     rnd = lambda *s: torch.randn(*s, generator=g).to(cuda)
     A, W = rnd(rows, k), rnd(n, k) * 0.3
@@ -79,19 +87,22 @@ def test_stream_pooling_epilogue_of_8_row_blocks(cuda, rows, n, k):
     C = torch.full((rows, n), float("nan"), device=cuda)
     nblk = _lib.btr_sa_gemm_grid(rows)
     part = torch.full((nblk, 2, n), float("nan"), device=cuda)
-    groups = rows // 8
+    groups = rows // ps
     gext = torch.full((groups, n), float("nan"), device=cuda)
     aext = torch.full((groups, n), 255, dtype=torch.uint8, device=cuda)
-    assert _lib.btr_sa_gemm_nt_poolfwd_supported(rows, n, 8)
+    assert _lib.btr_sa_gemm_nt_poolfwd_supported(rows, n, ps)
     with _ext._on(A) as d:
         _ext._call(_lib.btr_sa_gemm_nt_poolfwd, rows, n, k, _p(A), k, _p(W), k, _p(C), n, _p(pa),
-                   _p(pb), _p(part), 8, _p(gamma), _p(gext), _p(aext), _ext._stream(d))
+                   _p(pb), _p(part), ps, _p(gamma), _p(gext), _p(aext), _ext._stream(d))
     ref = torch.relu(pa.double() * A.double() + pb.double()) @ W.double().t()
     assert float((C.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
     # the extrema of the kernel's OWN C (the selection is exact on the values it stored)
-    blocks = C.view(groups, 8, n)
+    blocks = C.view(groups, ps, n)
     sign = torch.where(gamma < 0, -1.0, 1.0)
     best, arg = (blocks * sign).max(1)
     assert torch.equal(gext, best * sign)
     first = ((blocks * sign) == best.unsqueeze(1)).float().argmax(1)   # first maximum
     assert torch.equal(aext.long(), first)
+    s1, s2 = _sums(part, nblk, n)
+    r2 = (ref * ref).sum(0)
+    assert float((s2 - r2).abs().max()) <= 1e-5 * float(r2.abs().max())
