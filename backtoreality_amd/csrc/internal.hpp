@@ -102,6 +102,7 @@ hipEvent_t *bq_call_events();
 // this host thread are collected and issued as ONE launch by the flush, on `stream` (all of
 // them must have been issued on that stream, each with its own partials buffer)
 void reduce_batch_begin();
+void reduce_unpad_next(int kpad, int kout);
 void reduce_batch_flush(hipStream_t stream);
 
 // sa_mlp.hip: btr_sa_scatter / btr_sac_scatter split in two: the inverted neighbour lists only

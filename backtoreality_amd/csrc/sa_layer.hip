@@ -683,6 +683,11 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       (void)hipStreamWaitEvent(side->s, side->ready[l], 0);
       ws = (btr_stream_t)side->s;
     }
+    // the first layer's gradient leaves without the zero columns of its 4-aligned input width:
+    // dense [nl][3 + c] rows, what the parameter's gradient is (a strided view would be copied
+    // by autograd: one launch per level at the very end of the backward)
+    const int k_real = (d.use_xyz ? 3 : 0) + d.c;
+    if (l == 0 && !p.recompute && k_real != k) reduce_unpad_next(k, k_real);
     if (p.recompute && l == 1)
       BTR_TRY(btr_sa_gemm_tn_rc(R, nl, k, dy, nl, x0, at_f(saved, p.w2[0]), pa, pb, pw, dw, ws));
     else if (pooled)
@@ -690,6 +695,7 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
                                   pw, dw, ws));
     else
       BTR_TRY(btr_sa_gemm_tn(R, nl, k, dy, nl, xsrc, ldx, pa, pb, pw, dw, ws));
+    reduce_unpad_next(0, 0);
     if (side) {
       (void)hipEventRecord(side->done[l], side->s);
       last_done = l;

@@ -2680,6 +2680,10 @@ struct ReduceArgs {
   const float *pw[kMaxReduceSeg];
   float *dw[kMaxReduceSeg];
   int total[kMaxReduceSeg], chunks[kMaxReduceSeg], first[kMaxReduceSeg + 1];
+  // kpad != 0 (reduce_chunks_multi_kernel only): the partials are [.][kpad] rows whose first kout
+  // columns are written as dense [.][kout] rows -- a first layer's weight gradient without the
+  // zero columns its 4-aligned input width added (see reduce_unpad_next)
+  int kpad[kMaxReduceSeg], kout[kMaxReduceSeg];
   int n;
 };
 __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) {
@@ -2687,11 +2691,12 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) 
   // the segment of this block: unrolled scan with STATIC indices (see prep_weights_kernel)
   const float *pw = a.pw[0];
   float *dw = a.dw[0];
-  int total = a.total[0], chunks = a.chunks[0], first = 0;
+  int total = a.total[0], chunks = a.chunks[0], first = 0, kpad = a.kpad[0], kout = a.kout[0];
 #pragma unroll
   for (int i = 1; i < kMaxReduceSeg; ++i)
     if (i < a.n && (int)blockIdx.x >= a.first[i]) {
       pw = a.pw[i]; dw = a.dw[i]; total = a.total[i]; chunks = a.chunks[i]; first = a.first[i];
+      kpad = a.kpad[i]; kout = a.kout[i];
     }
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
   const int i = ((int)blockIdx.x - first) * 16 + tx;
@@ -2709,7 +2714,12 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) 
       for (int y = 0; y < 8; ++y) acc += red[y0 + y][tx];
       s += acc;
     }
-    dw[i] = (float)s;
+    if (kpad == 0) {
+      dw[i] = (float)s;
+    } else {
+      const int row = i / kpad, col = i - row * kpad;
+      if (col < kout) dw[(size_t)row * kout + col] = (float)s;
+    }
   }
 }
 
@@ -2757,6 +2767,7 @@ struct ReduceBatch {
   ReduceArgs args;
   ReduceArgs wide;   // (total = number of float4, first = 256-thread blocks)
   bool on = false;
+  int next_kpad = 0, next_kout = 0;   // reduce_unpad_next
 };
 inline ReduceBatch &reduce_batch() {
   static thread_local ReduceBatch b;
@@ -2766,7 +2777,16 @@ inline ReduceBatch &reduce_batch() {
 inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *dw,
                                  hipStream_t st) {
   ReduceBatch &b = reduce_batch();
-  if (chunks <= 16 && total >= 65536 && total % 4 == 0) {
+  const int kpad = b.next_kpad, kout = b.next_kout;
+  b.next_kpad = b.next_kout = 0;
+  if (kpad != 0 && !(b.on && b.args.n < kMaxReduceSeg)) {   // a launch of its own
+    ReduceArgs a{};
+    a.pw[0] = pw; a.dw[0] = dw; a.total[0] = total; a.chunks[0] = chunks;
+    a.kpad[0] = kpad; a.kout[0] = kout; a.first[1] = cdiv(total, 16); a.n = 1;
+    hipLaunchKernelGGL(reduce_chunks_multi_kernel, dim3(a.first[1]), dim3(256), 0, st, a);
+    return;
+  }
+  if (kpad == 0 && chunks <= 16 && total >= 65536 && total % 4 == 0) {
     if (b.on && b.wide.n < kMaxReduceSeg) {
       ReduceArgs &a = b.wide;
       a.pw[a.n] = pw;
@@ -2787,6 +2807,8 @@ inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *
     a.dw[a.n] = dw;
     a.total[a.n] = total;
     a.chunks[a.n] = chunks;
+    a.kpad[a.n] = kpad;
+    a.kout[a.n] = kout;
     a.first[a.n + 1] = a.first[a.n] + cdiv(total, 16);
     ++a.n;
     return;
@@ -2797,6 +2819,13 @@ inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *
   else
     hipLaunchKernelGGL((reduce_chunks_kernel<16, 16>), dim3(cdiv(total, 16)), dim3(256), 0, st,
                        total, chunks, pw, dw);
+}
+// (internal.hpp) the NEXT split-K reduction issued on this host thread writes dense [.][kout] rows
+// from its [.][kpad] partials
+void reduce_unpad_next(int kpad, int kout) {
+  ReduceBatch &b = reduce_batch();
+  b.next_kpad = kpad;
+  b.next_kout = kout;
 }
 // (internal.hpp) collect the split-K reductions issued on this host thread until the flush
 void reduce_batch_begin() {

@@ -55,6 +55,28 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int n, int m, int c, l
   out[t] = src[(bi * n + idx[row]) * c + ch];
 }
 
+// Its gradient: grad_src (b,n,c) = 0, then += grad_out (b,m,c) rows at idx -- one launch where the
+// transposing route takes four (transpose, fill, gather_points_grad, transpose).  A workgroup owns
+// `slab` consecutive points of one batch element: it clears them, then walks ALL m sampled rows
+// and adds the ones that fall into its slab (repeated indices -- FPS on fewer valid points than
+// samples -- add up through atomics, as in gather_points_grad).
+__global__ __launch_bounds__(256) void gather_rows_grad_kernel(int n, int m, int c, int slab,
+                                                               const float *__restrict__ grad_out,
+                                                               const int *__restrict__ idx,
+                                                               float *__restrict__ grad_src) {
+  const int bi = blockIdx.y, n0 = (int)blockIdx.x * slab, n1 = min(n, n0 + slab);
+  float *dst = grad_src + (size_t)bi * n * c;
+  for (int i = n0 * c + (int)threadIdx.x; i < n1 * c; i += 256) dst[i] = 0.f;
+  __syncthreads();
+  const float *g = grad_out + (size_t)bi * m * c;
+  const int *ix = idx + (size_t)bi * m;
+  for (int t = threadIdx.x; t < m * c; t += 256) {
+    const int j = t / c, ch = t - j * c;
+    const int p = ix[j];
+    if (p >= n0 && p < n1) atomicAdd(dst + (size_t)p * c + ch, g[t]);
+  }
+}
+
 // --------------------------------------------------------------------------------------- FPS
 // Selection rule (bit-exact with sampling_gpu.cu:74-178 for block size `bs`):
 //   next = argmax over non-skipped points of key(k) = (d2(k), -tk(k)),
@@ -770,6 +792,17 @@ int btr_gather_rows(int b, int n, int m, int c, const float *src, const int *idx
   hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
                      n, m, c, total, src, idx, out);
   return check_launch("gather_rows");
+}
+
+int btr_gather_rows_grad(int b, int n, int m, int c, const float *grad_out, const int *idx,
+                         float *grad_src, btr_stream_t stream) {
+  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(grad_src && (m <= 0 || (grad_out && idx)), "gather_rows_grad: null pointer");
+  // slabs of ~4096 floats to clear per workgroup, at most 256 per batch element
+  const int slab = std::max(1, std::max(cdiv(4096, c), cdiv(n, 256)));
+  hipLaunchKernelGGL(gather_rows_grad_kernel, dim3(cdiv(n, slab), b), dim3(256), 0,
+                     as_stream(stream), n, std::max(m, 0), c, slab, grad_out, idx, grad_src);
+  return check_launch("gather_rows_grad");
 }
 
 int btr_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,

@@ -6,7 +6,7 @@ import os
 import torch
 
 from ..pointnet2 import fused_backbone
-from ..votenet.train import FastAdamW, _sync_grads, _zero_grad
+from ..votenet.train import FastAdamW, _sync_grads, _zero_grad, backward
 from .detector import GroupFreeDetector, GroupFreeDetector_DA, GroupFreeDetector_DA_jitter
 from . import fused_attention
 from .loss_helper import get_loss
@@ -111,7 +111,7 @@ def train_step(net, optimizer, batch, cfg, loss_args=None, clip_norm=0.1, criter
         core = net.module if hasattr(net, "module") else net
         end_points['next_sampling'] = core.backbone_net.prefetch_sampling(
             next_batch['point_clouds'])
-    loss.backward()
+    backward(loss)
     _sync_grads(net)          # data parallel: one all-reduce of the flat gradient buffer
     clip_and_step(net, optimizer, clip_norm)
     return loss, end_points
@@ -240,7 +240,7 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_no
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = get_loss_DA(end_points_S, end_points_T, cfg, **loss_args)
     _zero_grad(net, optimizer)
-    loss.backward()
+    backward(loss)
     _sync_grads(net)
     clip_and_step(net, optimizer, clip_norm)
     return loss, end_points_S, end_points_T
@@ -264,7 +264,7 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, loss_ar
     loss, end_points_S, end_points_T = get_loss_DA_jitter(end_points_S, end_points_T, epoch, cfg,
                                                           **loss_args)
     _zero_grad(net, optimizer)
-    loss.backward()
+    backward(loss)
     _sync_grads(net)
     clip_and_step(net, optimizer, clip_norm)
     return loss, end_points_S, end_points_T

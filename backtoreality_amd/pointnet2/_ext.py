@@ -147,6 +147,7 @@ _SIGNATURES = {
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
     "btr_gather_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
+    "btr_gather_rows_grad": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),
     "btr_sa_gemm_nt_poolfwd_supported": (_ci, [_ci, _ci, _ci]),
     "btr_sa_gemm_nt_poolfwd": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp,
                                      _ci, _vp, _vp, _vp, _vp]),
@@ -582,6 +583,20 @@ def gather_rows(src, idx):
     out = torch.empty((B, M, C), dtype=torch.float32, device=src.device)
     with _on(src) as dev:
         _call(_lib.btr_gather_rows, B, N, M, C, _p(src), _p(idx), _p(out), _stream(dev))
+    return out
+
+
+def gather_rows_grad(grad_out, idx, n):
+    """(B,M,C) f32, (B,M) i32, n -> (B,n,C): gradient of gather_rows, one launch."""
+    _check(grad_out, "grad_out", "float")
+    _check(idx, "idx", "int", like=grad_out)
+    _gpu_only(grad_out)
+    _require(grad_out.dim() == 3 and idx.dim() == 2 and idx.shape == grad_out.shape[:2],
+             "grad_out must be (B, M, C) and idx (B, M)")
+    B, M, C = grad_out.shape
+    out = torch.empty((B, n, C), dtype=torch.float32, device=grad_out.device)
+    with _on(grad_out) as dev:
+        _call(_lib.btr_gather_rows_grad, B, n, M, C, _p(grad_out), _p(idx), _p(out), _stream(dev))
     return out
 
 

@@ -122,7 +122,10 @@ class Entry(object):
             for i in range(s.layers):
                 w = self.sa_params[l][3 * i]
                 base = plan.gr_sa[l]
-                self.grad_views += [(base + sp.dw[i], (s.width[i], sp.kin[i]), tuple(w.shape)),
+                # (a first layer's gradient is written as dense [n][3 + c] rows, without the
+                # columns its 4-aligned input width added: csrc/sa_layer.hip reduce_unpad_next)
+                kin = w.shape[1] if (i == 0 and not sp.recompute) else sp.kin[i]
+                self.grad_views += [(base + sp.dw[i], (s.width[i], kin), tuple(w.shape)),
                                     (base + sp.dgamma[i], (s.width[i],), None),
                                     (base + sp.dbeta[i], (s.width[i],), None)]
         for j in range(d.fps):
@@ -365,4 +368,6 @@ class FusedBackboneFn(Function):
                 continue
             n, k = (shape[0], shape[1]) if shape is not None else padded
             res.append(grads.as_strided((n, k), (padded[1], 1), off).reshape(shape))
+            # (a level's first layer arrives as dense [n][k] rows -- padded[1] == k in
+            # grad_views -- so no view here is copied by the reshape)
         return (None, None, None) + tuple(res)

@@ -516,9 +516,13 @@ class FusedSALayer(Function):
         res = []
         for l in range(d.layers):
             shape = ctx.pshapes[3 * l]
-            dW = parts[3 * l].view(d.width[l], plan.kin[l])
-            if plan.kin[l] != shape[1]:
-                dW = dW[:, :shape[1]]
+            if l == 0 and not plan.recompute:
+                # written without the padding columns (csrc/sa_layer.hip reduce_unpad_next)
+                dW = parts[0][:d.width[0] * shape[1]].view(d.width[0], shape[1])
+            else:
+                dW = parts[3 * l].view(d.width[l], plan.kin[l])
+                if plan.kin[l] != shape[1]:
+                    dW = dW[:, :shape[1]]
             res += [dW.reshape(shape), parts[3 * l + 1], parts[3 * l + 2]]
         return (dxyz, dnew, dfeat, None, None) + tuple(res)
 

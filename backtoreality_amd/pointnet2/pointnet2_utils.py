@@ -106,6 +106,8 @@ class GatherRows(Function):
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
+        if hasattr(_ext, "gather_rows_grad"):
+            return _ext.gather_rows_grad(grad_out.contiguous(), idx, ctx.n), None
         g = _ext.gather_points_grad(grad_out.transpose(1, 2).contiguous(), idx, ctx.n)
         return g.transpose(1, 2).contiguous(), None
 

@@ -125,8 +125,12 @@ class Pointnet2Backbone(nn.Module):
                 side.wait_stream(main)
             with torch.cuda.stream(side):
                 handle = fused_backbone.sample(entry, pointcloud)
+                # the seeds' indices (fp2_inds = the first sa2.npoint columns of sa1_inds) as a
+                # dense tensor, here instead of as a copy the loss makes on the main stream
+                handle.fp2_inds = handle.inds[0][:, :self.sa2.npoint].contiguous()
                 handle.event = torch.cuda.Event()
                 handle.event.record(side)
+            handle.fp2_inds.record_stream(main)
             handle.geom.record_stream(main)
             pointcloud.record_stream(side)
             return handle
@@ -294,7 +298,9 @@ class Pointnet2Backbone(nn.Module):
         end_points["fp2_features"] = features
         end_points["fp2_xyz"] = end_points["sa2_xyz"]
         num_seed = end_points["fp2_xyz"].shape[1]
-        end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:num_seed]
+        dense = getattr(sampling, "fp2_inds", None)   # (prefetch_sampling)
+        end_points["fp2_inds"] = dense if dense is not None and dense.shape[1] == num_seed \
+            else end_points["sa1_inds"][:, 0:num_seed]
         return self._center_head(end_points, features, center_xyz, center_cls)
 
     def _center_head(self, end_points, features, center_xyz, center_cls):

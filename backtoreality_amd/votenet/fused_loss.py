@@ -92,7 +92,9 @@ class FusedVoteNetLoss(Function):
         ctx.save_for_backward(net, agg_xyz, vote_xyz, seed_xyz, seed_inds, mean_size, norm,
                               objectness_label, objectness_mask, object_assignment, j1c, k2c,
                               vote_arg, *labels)
-        loss = stats[0].clone()
+        # (a view of the statistics vector, not a clone: one copy launch per step less; `stats`
+        # itself is returned non-differentiable below)
+        loss = stats[0]
         ctx.mark_non_differentiable(stats, objectness_label, objectness_mask, object_assignment)
         # (no zero-filled gradients for the statistics / label outputs: four fill launches)
         ctx.set_materialize_grads(False)

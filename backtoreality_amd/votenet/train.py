@@ -139,6 +139,19 @@ def wrap_ddp(net, device):
     return net
 
 
+_ONES = {}
+
+
+def backward(loss):
+    """loss.backward() with a cached unit gradient: autograd otherwise fills a fresh ones_like
+    (loss) -- one launch per step at the head of the backward's dependent chain."""
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    loss.backward(one if loss.dim() == 0 else None)
+
+
 def _zero_grad(net, optimizer):
     """optimizer.zero_grad(set_to_none=True) without its per-parameter bookkeeping (0.2 ms of
     host time per step for GroupFree3D's ~400 tensors)."""
@@ -488,7 +501,7 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None, crite
         nxt_sampling = core.backbone_net.prefetch_sampling(next_batch['point_clouds'])
     if nxt_sampling is not None:
         end_points['next_sampling'] = nxt_sampling
-    loss.backward()
+    backward(loss)
     _sync_grads(net)
     optimizer.step()
     return loss, end_points
@@ -648,7 +661,7 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, sampling_S=None, next_b
         _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
     end_points_S.update(nxt[0])
     end_points_T.update(nxt[1])
-    loss.backward()
+    backward(loss)
     _sync_grads(net)
     optimizer.step()
     return loss, end_points_S, end_points_T
@@ -682,7 +695,7 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, samplin
         _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
     end_points_S.update(nxt[0])
     end_points_T.update(nxt[1])
-    loss.backward()
+    backward(loss)
     _sync_grads(net)
     optimizer.step()
     return loss, end_points_S, end_points_T

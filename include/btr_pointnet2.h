@@ -424,6 +424,12 @@ int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
 int btr_gather_rows(int b, int n, int m, int c, const float *src, const int *idx, float *out,
                     btr_stream_t stream);
 
+/* Its gradient: grad_src (b,n,c) = 0, then grad_src[idx (b,m)] += grad_out (b,m,c) -- what the
+ * reference's route computes with gather_points_grad (sampling.cpp:46-69) between two transposes;
+ * one launch, grad_src need not be cleared by the caller.  Repeated indices add up. */
+int btr_gather_rows_grad(int b, int n, int m, int c, const float *grad_out, const int *idx,
+                         float *grad_src, btr_stream_t stream);
+
 /* ---- Evaluation-side box arithmetic (the caller after the forward at eval time).
  * The reference runs these per box in numpy / scipy on the host, in float64; so do the kernels.
  *

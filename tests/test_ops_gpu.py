@@ -488,7 +488,8 @@ def test_gather_rows_matches_the_transpose_gather_route(cuda):
     gradient, with repeated indices."""
     from backtoreality_amd.pointnet2 import pointnet2_utils as U
     g = torch.Generator().manual_seed(0)
-    for (B, N, M, C) in ((2, 1000, 300, 3), (3, 64, 64, 5), (1, 7, 20, 1)):
+    for (B, N, M, C) in ((2, 1000, 300, 3), (3, 64, 64, 5), (1, 7, 20, 1), (4, 1024, 256, 288),
+                         (2, 20000, 2048, 3)):
         src = torch.randn(B, N, C, generator=g).to(cuda).requires_grad_(True)
         idx = torch.randint(0, N, (B, M), generator=g).int().to(cuda)
         w = torch.randn(B, M, C, generator=g).to(cuda)
