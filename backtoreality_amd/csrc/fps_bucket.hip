@@ -1387,13 +1387,41 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
     }
   }
   if (ev[0] && ks != s) (void)hipEventRecord(ev[0], ks);   // (time the kernel on ITS stream)
+  // The launch asks for 128 KB (BTR_FPS_LDS_KB = k: k KB, 0: none) of dynamic LDS it never
+  // touches, on top of its own 1 KB.  A workgroup that holds most of its CU's 160 KB keeps every
+  // LDS-using workgroup of the other streams OFF that CU: a CU reservation by resource.  Why:
+  // the kernel sits on one CU per scene for 2 ms while the previous batch's training step runs
+  // on the other streams; whatever shares those CUs runs at a fraction of its speed (16
+  // high-priority waves beside it), and a launch of equal row chunks ends with its slowest
+  // workgroup.  Eight sleeping 1024-thread workgroups alone cost the backbone forward 8 %, VALU-
+  // busy ones more than double it (tools/probe/occupant.hip, tools/fps_interference.py).  A
+  // CU-masked queue does not do it: the dispatcher balances workgroups per shader engine, so
+  // taking one CU of 32 away slows every launch on that queue by 16 % (BTR_CU_MASK).
+  // Same box, 20 steps: 4.54 -> 4.37 ms per step; 64 KB: 4.49.
+  static const int lds_kb = [] {
+    const char *e = getenv("BTR_FPS_LDS_KB");
+    const int v = e ? atoi(e) : 128;
+    return v > 0 && v <= 156 ? v : 0;
+  }();
+  const size_t dyn = (size_t)lds_kb << 10;
+  if (dyn > 0) {
+    static bool attr_set = false;   // (per process; the attribute is a property of the function)
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      (void)hipGetLastError();
+      attr_set = true;
+    }
+  }
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       0, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
+                       dyn, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
                        (unsigned long long *)nullptr, boxes, epoch | kflag);
   else
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       0, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
+                       dyn, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
                        (unsigned long long *)nullptr, boxes, epoch | kflag);
   if (ev[1]) (void)hipEventRecord(ev[1], ks);
   ev[0] = ev[1] = nullptr;
@@ -1413,6 +1441,26 @@ int cu_mask_reserved() {
     return v > 0 && v <= 8 ? v : 0;
   }();
   return c;
+}
+int cu_mask_avail_cus() {
+  static const int avail = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+      cus = 256;   // (no device at hand: the build check, the CPU-side planning tests)
+    (void)hipGetLastError();
+    if (const char *e = getenv("BTR_GRID_CUS")) {   // sizing only, no partition
+      const int v = atoi(e);
+      if (v >= 8 && v <= cus) return v;
+    }
+    // default: the eight CUs the large-scene FPS of the NEXT batch sits on while a step runs (one
+    // workgroup per scene) are not counted -- a one-round grid sized for all 256 leaves its last
+    // workgroups waiting for a second round beside it (same box, 20 steps: 4.66 -> 4.59 ms
+    // pipelined, 6.42 -> 6.47 strictly sequential)
+    return std::max(8, cus - 8 * std::max(1, cu_mask_reserved()));
+  }();
+  return avail;
 }
 hipStream_t cu_mask_create_stream(bool reserved) {
   const int c = cu_mask_reserved();

@@ -14,6 +14,10 @@ namespace btr {
 // down, and a streaming kernel waits for the few workgroups that landed beside an FPS scene).
 // Mask bit i = CU (i / 8) of XCD (i % 8): tools/probe/cu_mask_probe.hip.
 int cu_mask_reserved();                       // c (0: off)
+// CUs a kernel of the step can land on (256 - 8c): grids sized as ONE round of resident workgroups
+// -- the row chunks of the streaming / fused / weight-gradient kernels -- count these, not the
+// device's, or the leftover workgroups wait for a second round on a partitioned chip
+int cu_mask_avail_cus();
 hipStream_t cu_mask_fps_stream();             // the reserved CUs (one per device and host thread)
 hipStream_t cu_mask_create_stream(bool reserved);   // a NEW stream on the reserved / other CUs
 

@@ -3585,7 +3585,21 @@ static int ilog2(int v) {
 }
 
 // Number of workgroups (= rows of the `part` buffer) btr_sa_gemm_nt uses along rows.
-int btr_sa_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, kBM), 512)); }
+// BTR_GRID_ROUNDS = r (default 1): the row-chunked kernels launch r rounds of resident workgroups
+// instead of one -- smaller chunks the dispatcher hands to whichever CU frees up first, against
+// workgroups that share their CU with another stream's waves (the large-scene FPS) holding up
+// the whole launch
+static int grid_rounds() {
+  static const int r = [] {
+    const char *e = getenv("BTR_GRID_ROUNDS");
+    const int v = e ? atoi(e) : 1;
+    return v >= 1 && v <= 4 ? v : 1;
+  }();
+  return r;
+}
+int btr_sa_gemm_grid(int rows) {
+  return std::max(1, std::min(cdiv(rows, kBM), 2 * cu_mask_avail_cus() * grid_rounds()));
+}
 
 // Whether the last layer's GEMM can emit the per-group extrema itself (pooling epilogue):
 // 128-column tiles (n > 64) and whole groups of 16 / 32 / 64 rows per wave.
@@ -3804,7 +3818,8 @@ static int tn_tile_n(int n) { return n >= 128 ? 128 : 64; }
 
 int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
   const int tiles = cdiv(n, tn_tile_n(n)) * cdiv(k, 64);
-  int chunks = std::max(1, std::min(1024 / tiles, 1024));  // ~1024 workgroups in flight
+  const int flight = 4 * cu_mask_avail_cus() * grid_rounds();   // ~1024 workgroups in flight
+  int chunks = std::max(1, std::min(flight / tiles, flight));
   // a workgroup (alone on its CU in these launches: one wave per SIMD, nothing to overlap with)
   // spends ~1.3 us per 32-row step: few-row GEMMs (the 1024-row decoder / head layers: 8 steps
   // per workgroup, 14 us) get chunks of down to 64 rows as long as the partials stay small
@@ -4026,9 +4041,11 @@ int btr_sa_bwd_fused_chunks(int rows, int n, int k) {
   // one round of resident workgroups: 256 CUs x (2 workgroups per CU; n > 128: one) over the
   // 64-wide k blocks -- more chunks only add partials to write and reduce (SA2's 256-wide layer:
   // 33 MB at 256 chunks) and a second, half-empty round
-  const int resident = 256 * (n > 128 ? 1 : 2), kblocks = (k + 63) / 64;
+  const int resident = cu_mask_avail_cus() * (n > 128 ? 1 : 2) * grid_rounds();
+  const int kblocks = (k + 63) / 64;
   const int want = std::max(32, resident / kblocks);
-  return std::max(1, std::min(std::min(want, kFusedMaxChunks), btr_sa_gemm_tn_chunks(rows, n, k)));
+  return std::max(1, std::min(std::min(want, kFusedMaxChunks * grid_rounds()),
+                              btr_sa_gemm_tn_chunks(rows, n, k)));
 }
 
 int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const float *yl,
@@ -4295,7 +4312,9 @@ int btr::sac_scatter_ex(int b, int n, int m, int c, int ldx, int use_xyz, const 
 extern "C" {
 
 // ------------------------------------------------------------- point-wise MLP chains (pm)
-int btr_pm_gemm_grid(int rows) { return std::max(1, std::min(cdiv(rows, 64), 512)); }
+int btr_pm_gemm_grid(int rows) {
+  return std::max(1, std::min(cdiv(rows, 64), 2 * cu_mask_avail_cus() * grid_rounds()));
+}
 
 // As btr_sa_gemm_nt on 64-row tiles (n > 64) with an optional bias row added to C (layers
 // without BatchNorm); part: [btr_pm_gemm_grid(rows)][2][n].

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""GPU time per phase of the software-pipelined FSB step, from hipEvents on the MAIN stream at
+the phase boundaries of the un-profiled loop (module forward hooks / gradient hooks): the
+sum of a phase's kernel durations (profiles/*_one_step.md) against this tells where the
+main stream waits or is slowed down -- a kernel trace slows the host too much to show it."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from backtoreality_amd.votenet import config, synthetic, train  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = config.scannet_md40()
+net = train.build_model(cfg, dev)
+opt = train.make_optimizer(net)
+batches = [synthetic.make_batch(s, 8, 40000, cfg, device=dev) for s in range(3)]
+marks = []
+
+
+def mark(name):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    marks.append((name, e))
+
+
+def fwd_hook(name):
+    def hook(mod, inp, out):
+        mark(name)
+    return hook
+
+
+core = net
+core.backbone_net.register_forward_hook(fwd_hook("backbone fwd"))
+core.vgen.register_forward_hook(fwd_hook("voting fwd"))
+core.pnet.register_forward_hook(fwd_hook("proposal fwd"))
+
+
+def grad_mark(t, name):
+    if t.requires_grad:
+        t.register_hook(lambda g: mark(name))
+
+
+orig_loss = train.loss_helper.get_loss
+
+
+def loss_with_marks(end_points, cfg_):
+    out = orig_loss(end_points, cfg_)
+    mark("loss fwd")
+    grad_mark(end_points['aggregated_vote_xyz'], "loss bwd + proposal bwd (to agg xyz)")
+    grad_mark(end_points['vote_features'], "vote aggregation bwd")
+    grad_mark(end_points['seed_features'], "voting bwd")
+    return out
+
+
+pipelined = "--sequential" not in sys.argv
+steps, warm = 30, 8
+sampling = core.backbone_net.prefetch_sampling(batches[0]['point_clouds']) if pipelined else None
+rows = {}
+order = []
+for it in range(warm + steps):
+    marks.clear()
+    b = batches[it % 3]
+    mark("start")
+    if pipelined:
+        loss, end = train.train_step(net, opt, b, cfg, sampling=sampling,
+                                     next_batch=batches[(it + 1) % 3], criterion=loss_with_marks)
+        sampling = end['next_sampling']
+    else:
+        loss, end = train.train_step(net, opt, b, cfg, criterion=loss_with_marks)
+    mark("backbone bwd + Adam")
+    if it >= warm:
+        torch.cuda.synchronize()
+        prev = marks[0][1]
+        for name, e in marks[1:]:
+            rows.setdefault(name, []).append(prev.elapsed_time(e) * 1e3)
+            if name not in order:
+                order.append(name)
+            prev = e
+tot = 0.0
+for name in order:
+    v = rows[name]
+    avg = sum(v) / len(v)
+    tot += avg
+    print("%-44s %8.1f us  (min %7.1f  max %7.1f)" % (name, avg, min(v), max(v)))
+print("%-44s %8.1f us   [per-step sync in this tool: the loop is not software-pipelined "
+      "across steps on the host]" % ("sum", tot))
