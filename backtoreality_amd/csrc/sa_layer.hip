@@ -247,8 +247,11 @@ __global__ __launch_bounds__(256) void vote_assemble_norm_bwd_kernel(
 // continues to layer l - 1 (dX = dY_l W_l, BatchNorm backward, ...) only share their input dY_l.
 // On the small layers (SA3 / SA4 / vote aggregation / the MLP chains: 2 000 - 65 000 rows) neither
 // fills the chip, so the wgrad launches go to a second stream: fork after dY_l is final, join at
-// the end of the call (the caller sees one stream).  Not while a HIP graph is being captured;
-// BTR_WGRAD_STREAM=0 turns it off.
+// the end of the call (the caller sees one stream).  Not while a HIP graph is being captured.
+// OFF by default since round 4 (BTR_WGRAD_STREAM=1 turns it on): with a hidden layer's whole
+// backward in one launch (sa_bwd_fused_kernel) few weight gradients are left to overlap, and a
+// launch of equal row chunks that shares CUs with another stream's waves ends with its slowest
+// workgroup -- same box, 20 steps: 4.39 -> 4.16 ms per VoteNet step, Back-to-Reality 10.43 -> 9.77.
 // calls with fewer rows keep their weight gradients in line (BTR_SIDE_MIN_ROWS / _SA override)
 inline long long side_min_rows(bool sa) {
   static const long long chain = getenv("BTR_SIDE_MIN_ROWS") ? atoll(getenv("BTR_SIDE_MIN_ROWS")) : 8192;
@@ -278,8 +281,8 @@ SideStream *side_stream() {
 }
 // the side stream to use for this call, or NULL (disabled / capturing / creation failed)
 SideStream *wgrad_side(hipStream_t main) {
-  static const bool off = getenv("BTR_WGRAD_STREAM") && getenv("BTR_WGRAD_STREAM")[0] == '0';
-  if (off) return nullptr;
+  static const bool on = getenv("BTR_WGRAD_STREAM") && getenv("BTR_WGRAD_STREAM")[0] == '1';
+  if (!on) return nullptr;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   // (inside a captured GroupFree3D step the fork / join nodes cost more than the overlap buys:
   // 15.3 vs 14.3 ms per replay)

@@ -17,13 +17,13 @@ cfg = config.scannet_md40()
 net = train.build_model(cfg, dev)
 opt = train.make_optimizer(net)
 batches = [synthetic.make_batch(s, 8, 40000, cfg, device=dev) for s in range(3)]
-marks = []
+all_marks = [[]]
 
 
 def mark(name):
     e = torch.cuda.Event(enable_timing=True)
     e.record()
-    marks.append((name, e))
+    all_marks[-1].append((name, e))
 
 
 def fwd_hook(name):
@@ -60,8 +60,11 @@ steps, warm = 30, 8
 sampling = core.backbone_net.prefetch_sampling(batches[0]['point_clouds']) if pipelined else None
 rows = {}
 order = []
+free_running = "--sync" not in sys.argv   # default: no host synchronisation between the steps
+all_marks = []
 for it in range(warm + steps):
-    marks.clear()
+    marks = []
+    all_marks.append(marks)
     b = batches[it % 3]
     mark("start")
     if pipelined:
@@ -71,19 +74,28 @@ for it in range(warm + steps):
     else:
         loss, end = train.train_step(net, opt, b, cfg, criterion=loss_with_marks)
     mark("backbone bwd + Adam")
-    if it >= warm:
+    if not free_running:
         torch.cuda.synchronize()
-        prev = marks[0][1]
-        for name, e in marks[1:]:
-            rows.setdefault(name, []).append(prev.elapsed_time(e) * 1e3)
-            if name not in order:
-                order.append(name)
-            prev = e
+torch.cuda.synchronize()
+for it, ms in enumerate(all_marks):
+    if it < warm:
+        continue
+    prev = ms[0][1]
+    for name, e in ms[1:]:
+        rows.setdefault(name, []).append(prev.elapsed_time(e) * 1e3)
+        if name not in order:
+            order.append(name)
+        prev = e
+    if it + 1 < len(all_marks):   # the distance to the next step's start mark
+        rows.setdefault("(to the next step's start)", []).append(
+            prev.elapsed_time(all_marks[it + 1][0][1]) * 1e3)
+if "(to the next step's start)" in rows:
+    order.append("(to the next step's start)")
 tot = 0.0
 for name in order:
     v = rows[name]
     avg = sum(v) / len(v)
     tot += avg
     print("%-44s %8.1f us  (min %7.1f  max %7.1f)" % (name, avg, min(v), max(v)))
-print("%-44s %8.1f us   [per-step sync in this tool: the loop is not software-pipelined "
-      "across steps on the host]" % ("sum", tot))
+print("%-44s %8.1f us   [%s]" % ("sum", tot, "free-running loop" if free_running else
+                                  "host synchronised after every step (--sync)"))
