@@ -488,6 +488,9 @@ def new_stream(device):
     torch.cuda.Stream unless BTR_CU_MASK is set, then an ExternalStream around a HIP stream
     created with the complement CU mask (include/btr_pointnet2.h btr_cu_mask_create_stream)."""
     if not cu_mask_reserved():
+        prio = os.environ.get("BTR_SIDE_PRIO")   # (experiment: DESIGN 7.6)
+        if prio:
+            return torch.cuda.Stream(device=device, priority=int(prio))
         return torch.cuda.Stream(device=device)
     with torch.cuda.device(device):
         ptr = _lib.btr_cu_mask_create_stream(0)

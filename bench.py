@@ -326,7 +326,12 @@ def main():
     # there, csrc/fps_bucket.hip); the training loop then has to stay off them as well -- every
     # step is issued on a stream created with the complement mask instead of torch's default one
     masked_main = None
-    if _ext.cu_mask_reserved():
+    if os.environ.get("BTR_MAIN_PRIO"):   # experiment: the step on a stream of its own priority
+        masked_main = torch.cuda.Stream(device=dev, priority=int(os.environ["BTR_MAIN_PRIO"]))
+        masked_main.wait_stream(torch.cuda.current_stream(dev))
+        _masked_ctx = torch.cuda.stream(masked_main)
+        _masked_ctx.__enter__()
+    elif _ext.cu_mask_reserved():
         masked_main = _ext.new_stream(dev)
         masked_main.wait_stream(torch.cuda.current_stream(dev))
         _masked_ctx = torch.cuda.stream(masked_main)

@@ -569,7 +569,10 @@ typedef struct {
   size_t x0, y[BTR_MAX_LAYERS], w2[BTR_MAX_LAYERS], wt[BTR_MAX_LAYERS], stats[BTR_MAX_LAYERS];
   size_t arg, goff, dims, cidx, bgrp, bw;
   size_t saved_bytes, fwd_scratch_bytes, bwd_scratch_bytes;
-  /* float offsets into `grads`: dW (width[l], kin[l]) padded, dgamma, dbeta */
+  /* float offsets into `grads`: dW (width[l], kin[l]) padded, dgamma, dbeta.  Layer 0 without the
+   * first-layer recompute: dW_0 is written as DENSE (width[0], 3 * use_xyz + c) rows at dw[0] --
+   * the parameter's own shape, without the columns the 4-aligned kin[0] added (the block keeps its
+   * padded size) */
   size_t dw[BTR_MAX_LAYERS], dgamma[BTR_MAX_LAYERS], dbeta[BTR_MAX_LAYERS];
   size_t grads_floats;
 } btr_sa_plan_t;

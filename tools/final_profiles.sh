@@ -20,6 +20,15 @@ python tools/gemm_nt_small_ab.py > $O/gemm_nt_small_ab.txt 2>&1
 python tools/bwd_fused_ab.py > $O/bwd_fused_ab.txt 2>&1
 python tools/fps_prefix_ab.py > $O/fps_prefix_ab.txt 2>&1
 bash tools/pmc_kernels.sh tools/bwd_fused_ab.py sa_bwd_fused > $O/fused_sq_counters.md 2>/dev/null
+# what the step's streams cost each other
+{ python tools/fps_interference.py 2>&1 | tail -2
+  for m in "8 0 2000" "8 1 2000" "8 2 2000"; do
+    echo "occupant (workgroups, mode 0 sleep / 1 VALU spin / 2 L2 pointer chase, us): $m"
+    python tools/fps_interference.py --occupant $m 2>&1 | tail -1
+  done
+  echo "BTR_FPS_LDS_KB=0:"; BTR_FPS_LDS_KB=0 python tools/fps_interference.py 2>&1 | tail -2; } > $O/fps_interference.txt
+{ python tools/phase_times.py 2>&1 | tail -11; echo; python tools/phase_times.py --sequential 2>&1 | tail -11; } > $O/phase_times.txt
+{ bash tools/ab_env2.sh "BTR_FPS_LDS_KB" 2; bash tools/ab_side.sh; BENCH_ARGS= bash tools/ab_gridcus.sh "256 248" | tail -6; } > $O/streams_ab.txt 2>&1
 python -c "
 import json
 for f in ('bench','bench_steps20','bench_c5','bench_br','bench_cr','bench_gf','bench_gf_eager','bench_gfbr'):
