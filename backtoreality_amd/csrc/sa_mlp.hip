@@ -2967,6 +2967,49 @@ void csr_small_launch(int b, long long entries, int n_bins, const int *idx, int 
                      refs);
 }
 
+// Sum of the rows base[rf[beg .. end)][0 .. C) by one wave, C in {128, 256} and 16-byte aligned rows:
+// a lane owns four channels (float4 loads: a row is 32 or 64 lanes), with C = 128 the two halves
+// of the wave take alternate rows; four rows per lane in flight.  The result (all rows) is valid
+// in the lanes < C / 4.  (The 4-byte-per-lane form -- one dependent index load and one or two
+// 256-byte loads per row -- moved SA2's 58 MB at 1.2 TB/s.)
+__device__ __forceinline__ float4 wave_sum_rows4(const float *__restrict__ base, int ldx, int C,
+                                                 const int *__restrict__ rf, int beg, int end,
+                                                 int lane) {
+  const int lpr = C >> 2;                 // lanes per row: 32 or 64
+  const int sub = lane / lpr, nsub = 64 / lpr;
+  const float *col = base + (lane % lpr) * 4;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  int i = beg + sub;
+  for (; i + 3 * nsub < end; i += 4 * nsub) {
+    const int r0 = rf[i], r1 = rf[i + nsub], r2 = rf[i + 2 * nsub], r3 = rf[i + 3 * nsub];
+    const float4 v0 = *reinterpret_cast<const float4 *>(col + (size_t)r0 * ldx);
+    const float4 v1 = *reinterpret_cast<const float4 *>(col + (size_t)r1 * ldx);
+    const float4 v2 = *reinterpret_cast<const float4 *>(col + (size_t)r2 * ldx);
+    const float4 v3 = *reinterpret_cast<const float4 *>(col + (size_t)r3 * ldx);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+    a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+  }
+  for (; i < end; i += nsub) {
+    const float4 v0 = *reinterpret_cast<const float4 *>(col + (size_t)rf[i] * ldx);
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+  }
+  float4 a = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                         (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+  if (nsub == 2) {
+    a.x += __shfl_xor(a.x, 32);
+    a.y += __shfl_xor(a.y, 32);
+    a.z += __shfl_xor(a.z, 32);
+    a.w += __shfl_xor(a.w, 32);
+  }
+  return a;
+}
+__device__ __forceinline__ bool wave_sum_rows4_ok(const float *p, int ldx, int xoff, int C) {
+  return (C == 128 || C == 256) && ldx % 4 == 0 && xoff % 4 == 0 &&
+         (reinterpret_cast<size_t>(p) & 15) == 0;
+}
+
 // One wave per point n: dfeat_cl[b][n][c] = sum over refs of dX0[ref][xoff + c];
 // dxyz[b][n][0..3) = (sum of dX0[ref][0..3)) * inv_radius.
 __global__ __launch_bounds__(256) void csr_reduce_kernel(
@@ -2980,7 +3023,11 @@ __global__ __launch_bounds__(256) void csr_reduce_kernel(
   const int beg = off[(size_t)bi * (N + 1) + n], end = off[(size_t)bi * (N + 1) + n + 1];
   const int *rf = refs + (size_t)bi * ms;
   const float *base = dX + (size_t)bi * ms * ldx;
-  if (dfeat_cl) {
+  if (dfeat_cl && wave_sum_rows4_ok(base, ldx, xoff, C)) {
+    const float4 a = wave_sum_rows4(base + xoff, ldx, C, rf, beg, end, lane);
+    if (lane < (C >> 2))
+      *reinterpret_cast<float4 *>(dfeat_cl + ((size_t)bi * N + n) * C + lane * 4) = a;
+  } else if (dfeat_cl) {
     // up to 4 channels per lane (C <= 256), 4 neighbour rows in flight per iteration
     for (int c0 = 0; c0 < C; c0 += 256) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -3286,6 +3333,12 @@ __global__ __launch_bounds__(256) void sac_reduce_kernel(int N, int C, int ldx, 
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
   const int beg = off[(size_t)bi * (N + 1) + n], end = off[(size_t)bi * (N + 1) + n + 1];
+  if (wave_sum_rows4_ok(dX, ldx, xoff, C)) {
+    const float4 a = wave_sum_rows4(dX + xoff, ldx, C, refs, beg, end, lane);
+    if (lane < (C >> 2))
+      *reinterpret_cast<float4 *>(dfeat_cl + ((size_t)bi * N + n) * C + lane * 4) = a;
+    return;
+  }
   for (int c0 = 0; c0 < C; c0 += 256) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = beg; i < end; ++i) {
