@@ -1403,17 +1403,21 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
     const int v = e ? atoi(e) : 128;
     return v > 0 && v <= 156 ? v : 0;
   }();
-  const size_t dyn = (size_t)lds_kb << 10;
+  size_t dyn = (size_t)lds_kb << 10;
   if (dyn > 0) {
-    static bool attr_set = false;   // (per process; the attribute is a property of the function)
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    // (per process; the attribute is a property of the function.  A runtime that refuses it
+    // leaves the launch as it was: the reservation is about speed only)
+    static const bool attr_ok = [&] {
+      const hipError_t e1 = hipFuncSetAttribute(
+          reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      const hipError_t e2 = hipFuncSetAttribute(
+          reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
       (void)hipGetLastError();
-      attr_set = true;
-    }
+      return e1 == hipSuccess && e2 == hipSuccess;
+    }();
+    if (!attr_ok) dyn = 0;
   }
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
