@@ -49,10 +49,68 @@ __device__ __forceinline__ float lse(const float *p, size_t cs, int n, float &mx
   return mx + logf(s);
 }
 
+// Cross-entropy of `n` logits against class `pick`: lse - p[pick].  Up to kLogitRegs classes the
+// logits are loaded ONCE, all loads in flight together, and the picked one is selected from the
+// registers (the two-pass loop above waits for every load before the next: ~110 dependent L2 round
+// trips per proposal over the three class blocks, 28 us for a kernel of one workgroup per scene).
+// Same operations in the same order as lse(): bit-identical.
+constexpr int kLogitRegs = 24;
+__device__ __forceinline__ float ce_pick(const float *p, size_t cs, int n, int pick) {
+  if (n > kLogitRegs) {
+    float mx;
+    return lse(p, cs, n, mx) - p[(size_t)pick * cs];
+  }
+  float v[kLogitRegs];
+#pragma unroll
+  for (int c = 0; c < kLogitRegs; ++c) v[c] = c < n ? p[c * cs] : -3.0e38f;
+  float mx = v[0], got = v[0];
+#pragma unroll
+  for (int c = 1; c < kLogitRegs; ++c) {
+    mx = fmaxf(mx, v[c]);
+    got = c == pick ? v[c] : got;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kLogitRegs; ++c) s += c < n ? expf(v[c] - mx) : 0.f;
+  return mx + logf(s) - got;
+}
+// ... and its gradient: g[c] = w * (softmax(p)[c] - (c == pick)) for c < n
+__device__ __forceinline__ void ce_grad(const float *p, float *g, size_t cs, int n, int pick,
+                                        float w) {
+  if (n > kLogitRegs) {
+    float mx;
+    const float l = lse(p, cs, n, mx);
+    for (int c = 0; c < n; ++c) g[c * cs] = w * (expf(p[c * cs] - l) - (c == pick ? 1.f : 0.f));
+    return;
+  }
+  float v[kLogitRegs];
+#pragma unroll
+  for (int c = 0; c < kLogitRegs; ++c) v[c] = c < n ? p[c * cs] : -3.0e38f;
+  float mx = v[0];
+#pragma unroll
+  for (int c = 1; c < kLogitRegs; ++c) mx = fmaxf(mx, v[c]);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kLogitRegs; ++c) s += c < n ? expf(v[c] - mx) : 0.f;
+  const float l = mx + logf(s);
+#pragma unroll
+  for (int c = 0; c < kLogitRegs; ++c)
+    if (c < n) g[c * cs] = w * (expf(v[c] - l) - (c == pick ? 1.f : 0.f));
+}
+
 enum {  // block / batch sums
   S_LABEL, S_MASK, S_BOXMASK, S_VOTEMASK, S_OBJ, S_D1C, S_D2C, S_HCLS, S_HREG, S_SCLS, S_SREG,
   S_SEM, S_VOTE, S_ACC, S_D2V
 };
+// The three independent parts of the loss run as three workgroups per scene (blockIdx.y): the
+// per-proposal terms, the centres' second chamfer direction, the vote loss -- one workgroup per
+// scene walked them one after the other, 41 us of dependent phases on 8 of 256 CUs.  Every sum
+// slot has ONE owner, so the partial sums are bit-identical to the single-workgroup form.
+enum { R_PROPOSALS, R_CENTRES, R_VOTES, kLossRoles };
+__device__ __forceinline__ int sum_owner(int slot) {
+  return (slot == S_D2C || slot == S_BOXMASK) ? R_CENTRES
+         : (slot == S_VOTE || slot == S_VOTEMASK || slot == S_D2V) ? R_VOTES : R_PROPOSALS;
+}
 
 __global__ __launch_bounds__(256) void loss_terms_kernel(
     LossDims d, const float *__restrict__ net, const float *__restrict__ agg_xyz,
@@ -70,6 +128,7 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
   __shared__ float cen[kMaxProp * 3];
   __shared__ float red[kNSums][4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int role = blockIdx.y;
   const size_t cs = (size_t)d.K;  // channel stride of net
   const float *nb = net + (size_t)b * d.Cout * d.K;
   float sums[kNSums];
@@ -80,11 +139,17 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
   __syncthreads();
 
   const int oH = 5, oHR = 5 + d.NH, oS = 5 + 2 * d.NH, oSR = oS + d.NS, oC = oS + 4 * d.NS;
-  for (int k = tid; k < d.K; k += 256) {
+  if (role == R_CENTRES)   // the predicted centres, for the scan below
+    for (int k = tid; k < d.K; k += 256) {
+      const float *a = agg_xyz + ((size_t)b * d.K + k) * 3;
+      cen[k * 3 + 0] = a[0] + nb[2 * cs + k];
+      cen[k * 3 + 1] = a[1] + nb[3 * cs + k];
+      cen[k * 3 + 2] = a[2] + nb[4 * cs + k];
+    }
+  for (int k = tid; role == R_PROPOSALS && k < d.K; k += 256) {
     const float *a = agg_xyz + ((size_t)b * d.K + k) * 3;
     const float ax = a[0], ay = a[1], az = a[2];
     const float cx = ax + nb[2 * cs + k], cy = ay + nb[3 * cs + k], cz = az + nb[4 * cs + k];
-    cen[k * 3 + 0] = cx; cen[k * 3 + 1] = cy; cen[k * 3 + 2] = cz;
     float d1 = 3.0e38f, d1c = 3.0e38f;
     int i1 = 0, i1c = 0;
     for (int j = 0; j < d.K2; ++j) {
@@ -120,10 +185,10 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
     const int hcl = (int)heading_class_label[jo];
     const int scl = (int)size_class_label[jo];
     const int sem = (int)sem_cls_label[jo];
-    sums[S_HCLS] += (lse(nb + oH * cs + k, cs, d.NH, mx) - nb[(oH + hcl) * cs + k]) * lab;
+    sums[S_HCLS] += ce_pick(nb + oH * cs + k, cs, d.NH, hcl) * lab;
     const float htar = heading_residual_label[jo] / (3.14159265358979323846f / (float)d.NH);
     sums[S_HREG] += huber1(nb[(oHR + hcl) * cs + k] - htar) * lab;
-    sums[S_SCLS] += (lse(nb + oS * cs + k, cs, d.NS, mx) - nb[(oS + scl) * cs + k]) * lab;
+    sums[S_SCLS] += ce_pick(nb + oS * cs + k, cs, d.NS, scl) * lab;
     float sreg = 0.f;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -131,11 +196,11 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
       sreg += huber1(nb[(oSR + scl * 3 + t) * cs + k] - tar);
     }
     sums[S_SREG] += (sreg / 3.f) * lab;
-    sums[S_SEM] += (lse(nb + oC * cs + k, cs, d.NC, mx) - nb[(oC + sem) * cs + k]) * lab;
+    sums[S_SEM] += ce_pick(nb + oC * cs + k, cs, d.NC, sem) * lab;
   }
   __syncthreads();
   // nearest predicted centre for every GT box (chamfer direction 2)
-  for (int j = tid; j < d.K2; j += 256) {
+  for (int j = tid; role == R_CENTRES && j < d.K2; j += 256) {
     const float gx = gt[j * 3], gy = gt[j * 3 + 1], gz = gt[j * 3 + 2];
     float best = 3.0e38f;
     int bi = 0;
@@ -149,7 +214,8 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
     sums[S_D2C] += best * bm;
     sums[S_BOXMASK] += bm;
   }
-  if (d.vote_mode == 0) {
+  if (role != R_VOTES) {
+  } else if (d.vote_mode == 0) {
     // vote loss (vote_factor 1): min over the 3 GT votes of the L1 distance
     for (int i = tid; i < d.S1; i += 256) {
       const size_t so = (size_t)b * d.S1 + i;
@@ -224,7 +290,7 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
     if (lane == 0) red[i][wave] = v;
   }
   __syncthreads();
-  if (tid < kNSums)
+  if (tid < kNSums && sum_owner(tid) == role)
     part[(size_t)b * kNSums + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
 }
 
@@ -281,6 +347,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
   __shared__ float bm[kMaxObj];
   __shared__ int kc[kMaxObj];
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int role = blockIdx.y;   // 0: the proposals' gradients, 1: the votes' (two workgroups)
   const size_t cs = (size_t)d.K;
   const float *nb = net + (size_t)b * d.Cout * d.K;
   float *gb = dnet + (size_t)b * d.Cout * d.K;
@@ -293,7 +360,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
   }
   __syncthreads();
   const int oH = 5, oHR = 5 + d.NH, oS = 5 + 2 * d.NH, oSR = oS + d.NS, oC = oS + 4 * d.NS;
-  for (int k = tid; k < d.K; k += 256) {
+  for (int k = tid; role == 0 && k < d.K; k += 256) {
     const size_t o = (size_t)b * d.K + k;
     const int label = (int)objectness_label[o];
     const float lab = (float)label, mask = objectness_mask[o];
@@ -328,19 +395,13 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
     const int sem = (int)sem_cls_label[jo];
     const float wl = lab * nl * g10;
     {
-      float mx;
-      const float l = lse(nb + oH * cs + k, cs, d.NH, mx);
-      for (int c = 0; c < d.NH; ++c)
-        gb[(oH + c) * cs + k] = d.w[3] * wl * (expf(nb[(oH + c) * cs + k] - l) - (c == hcl ? 1.f : 0.f));
+      ce_grad(nb + oH * cs + k, gb + oH * cs + k, cs, d.NH, hcl, d.w[3] * wl);
       const float htar = heading_residual_label[jo] / (3.14159265358979323846f / (float)d.NH);
       const float ge = huber1_grad(nb[(oHR + hcl) * cs + k] - htar) * wl * d.w[4];
       for (int c = 0; c < d.NH; ++c) gb[(oHR + c) * cs + k] = c == hcl ? ge : 0.f;
     }
     {
-      float mx;
-      const float l = lse(nb + oS * cs + k, cs, d.NS, mx);
-      for (int c = 0; c < d.NS; ++c)
-        gb[(oS + c) * cs + k] = d.w[5] * wl * (expf(nb[(oS + c) * cs + k] - l) - (c == scl ? 1.f : 0.f));
+      ce_grad(nb + oS * cs + k, gb + oS * cs + k, cs, d.NS, scl, d.w[5] * wl);
       for (int c = 0; c < d.NS; ++c)
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -352,15 +413,11 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
           gb[(oSR + c * 3 + t) * cs + k] = g;
         }
     }
-    {
-      float mx;
-      const float l = lse(nb + oC * cs + k, cs, d.NC, mx);
-      for (int c = 0; c < d.NC; ++c)
-        gb[(oC + c) * cs + k] = d.w[7] * wl * (expf(nb[(oC + c) * cs + k] - l) - (c == sem ? 1.f : 0.f));
-    }
+    ce_grad(nb + oC * cs + k, gb + oC * cs + k, cs, d.NC, sem, d.w[7] * wl);
   }
   // votes
-  if (d.vote_mode == 0) {
+  if (role != 1) {
+  } else if (d.vote_mode == 0) {
     for (int i = tid; i < d.S1; i += 256) {
       const size_t so = (size_t)b * d.S1 + i;
       const int pi = seed_inds[so];
@@ -426,7 +483,7 @@ int btr_votenet_loss_fwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
   LossDims d{b, k, k2, nh, ns, nc, s1, n, cout, {0, 0, 0, 0, 0, 0, 0, 0}, vote_mode};
   for (int i = 0; i < 8; ++i) d.w[i] = weights8[i];
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(loss_terms_kernel, dim3(b), dim3(256), 0, st, d, net, agg_xyz, vote_xyz,
+  hipLaunchKernelGGL(loss_terms_kernel, dim3(b, kLossRoles), dim3(256), 0, st, d, net, agg_xyz, vote_xyz,
                      seed_xyz, seed_inds, vote_label, vote_label_mask, center_label,
                      box_label_mask, heading_class_label, heading_residual_label,
                      size_class_label, size_residual_label, sem_cls_label, mean_size,
@@ -454,7 +511,7 @@ int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
   BTR_REQUIRE(weights8 && (vote_mode == 0 || i2v), "votenet_loss: weights / i2v missing");
   LossDims d{b, k, k2, nh, ns, nc, s1, n, cout, {0, 0, 0, 0, 0, 0, 0, 0}, vote_mode};
   for (int i = 0; i < 8; ++i) d.w[i] = weights8[i];
-  hipLaunchKernelGGL(loss_grad_kernel, dim3(b), dim3(256), 0, as_stream(stream), d, gout, norm,
+  hipLaunchKernelGGL(loss_grad_kernel, dim3(b, 2), dim3(256), 0, as_stream(stream), d, gout, norm,
                      net, agg_xyz, vote_xyz, seed_xyz, seed_inds, vote_label, vote_label_mask,
                      center_label, box_label_mask, heading_class_label, heading_residual_label,
                      size_class_label, size_residual_label, sem_cls_label, mean_size,
