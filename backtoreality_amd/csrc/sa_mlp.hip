@@ -2687,7 +2687,7 @@ struct ReduceArgs {
   int n;
 };
 __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) {
-  __shared__ double red[16][17];
+  __shared__ double red[16][65];
   // the segment of this block: unrolled scan with STATIC indices (see prep_weights_kernel)
   const float *pw = a.pw[0];
   float *dw = a.dw[0];
@@ -2698,26 +2698,35 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) 
       pw = a.pw[i]; dw = a.dw[i]; total = a.total[i]; chunks = a.chunks[i]; first = a.first[i];
       kpad = a.kpad[i]; kout = a.kout[i];
     }
+  // 16 slices of the chunk axis x 16 threads of four consecutive elements: a slice reads 256
+  // contiguous bytes per chunk (one element per thread read 64: SA2's 16 MB of partials took
+  // 22 us); every element's chunks are added in the order they always were
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
-  const int i = ((int)blockIdx.x - first) * 16 + tx;
-  double s = 0.0;
-  if (i < total)
-#pragma unroll 8
-    for (int c = ty; c < chunks; c += 16) s += (double)pw[(size_t)c * total + i];
-  red[ty][tx] = s;
+  const int i = (((int)blockIdx.x - first) * 16 + tx) * 4;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (i < total) {   // (total % 4 == 0)
+#pragma unroll 4
+    for (int c = ty; c < chunks; c += 16) {
+      const float4 v = *reinterpret_cast<const float4 *>(pw + (size_t)c * total + i);
+      s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+    }
+  }
+  red[ty][tx * 4 + 0] = s0; red[ty][tx * 4 + 1] = s1;
+  red[ty][tx * 4 + 2] = s2; red[ty][tx * 4 + 3] = s3;
   __syncthreads();
-  if (ty == 0 && i < total) {
-    s = 0.0;
+  if (threadIdx.x < 64 && ((int)blockIdx.x - first) * 64 + (int)threadIdx.x < total) {
+    const int e = threadIdx.x, at = ((int)blockIdx.x - first) * 64 + e;
+    double s = 0.0;
     for (int y0 = 0; y0 < 16; y0 += 8) {
       double acc = 0.0;
 #pragma unroll
-      for (int y = 0; y < 8; ++y) acc += red[y0 + y][tx];
+      for (int y = 0; y < 8; ++y) acc += red[y0 + y][e];
       s += acc;
     }
     if (kpad == 0) {
-      dw[i] = (float)s;
+      dw[at] = (float)s;
     } else {
-      const int row = i / kpad, col = i - row * kpad;
+      const int row = at / kpad, col = at - row * kpad;
       if (col < kout) dw[(size_t)row * kout + col] = (float)s;
     }
   }
@@ -2782,7 +2791,7 @@ inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *
   if (kpad != 0 && !(b.on && b.args.n < kMaxReduceSeg)) {   // a launch of its own
     ReduceArgs a{};
     a.pw[0] = pw; a.dw[0] = dw; a.total[0] = total; a.chunks[0] = chunks;
-    a.kpad[0] = kpad; a.kout[0] = kout; a.first[1] = cdiv(total, 16); a.n = 1;
+    a.kpad[0] = kpad; a.kout[0] = kout; a.first[1] = cdiv(total, 64); a.n = 1;
     hipLaunchKernelGGL(reduce_chunks_multi_kernel, dim3(a.first[1]), dim3(256), 0, st, a);
     return;
   }
@@ -2809,7 +2818,7 @@ inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *
     a.chunks[a.n] = chunks;
     a.kpad[a.n] = kpad;
     a.kout[a.n] = kout;
-    a.first[a.n + 1] = a.first[a.n] + cdiv(total, 16);
+    a.first[a.n + 1] = a.first[a.n] + cdiv(total, 64);
     ++a.n;
     return;
   }
