@@ -3659,8 +3659,17 @@ static int grid_rounds() {
   }();
   return r;
 }
+static int gemm_wgs_per_cu() {   // BTR_GEMM_WGS_PER_CU (default 2): row chunks per CU of the NT kernels
+  static const int v = [] {
+    const char *e = getenv("BTR_GEMM_WGS_PER_CU");
+    const int x = e ? atoi(e) : 2;
+    return x >= 1 && x <= 8 ? x : 2;
+  }();
+  return v;
+}
 int btr_sa_gemm_grid(int rows) {
-  return std::max(1, std::min(cdiv(rows, kBM), 2 * cu_mask_avail_cus() * grid_rounds()));
+  return std::max(1, std::min(cdiv(rows, kBM),
+                              gemm_wgs_per_cu() * cu_mask_avail_cus() * grid_rounds()));
 }
 
 // Whether the last layer's GEMM can emit the per-group extrema itself (pooling epilogue):
@@ -3880,7 +3889,15 @@ static int tn_tile_n(int n) { return n >= 128 ? 128 : 64; }
 
 int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
   const int tiles = cdiv(n, tn_tile_n(n)) * cdiv(k, 64);
-  const int flight = 4 * cu_mask_avail_cus() * grid_rounds();   // ~1024 workgroups in flight
+  // two workgroups per CU in flight (BTR_TN_WGS_PER_CU; four until the weight gradients moved to
+  // the caller's stream: half the partials to write and reduce, same box 4.10 -> 4.02 ms per step;
+  // three 4.00, one 4.54 -- the fused backward's chunk count is capped by this one)
+  static const int per_cu = [] {
+    const char *e = getenv("BTR_TN_WGS_PER_CU");
+    const int v = e ? atoi(e) : 2;
+    return v >= 1 && v <= 8 ? v : 2;
+  }();
+  const int flight = per_cu * cu_mask_avail_cus() * grid_rounds();
   int chunks = std::max(1, std::min(flight / tiles, flight));
   // a workgroup (alone on its CU in these launches: one wave per SIMD, nothing to overlap with)
   // spends ~1.3 us per 32-row step: few-row GEMMs (the 1024-row decoder / head layers: 8 steps
@@ -4375,7 +4392,8 @@ extern "C" {
 
 // ------------------------------------------------------------- point-wise MLP chains (pm)
 int btr_pm_gemm_grid(int rows) {
-  return std::max(1, std::min(cdiv(rows, 64), 2 * cu_mask_avail_cus() * grid_rounds()));
+  return std::max(1, std::min(cdiv(rows, 64),
+                              gemm_wgs_per_cu() * cu_mask_avail_cus() * grid_rounds()));
 }
 
 // As btr_sa_gemm_nt on 64-row tiles (n > 64) with an optional bias row added to C (layers
