@@ -347,11 +347,30 @@ def main():
         # one-time capture (untimed, like the priming step above)
         graphed_step = train.GraphedPipelinedStep(net, opt, batches[0], batches[1], cfg)
         barrier()
+    gf_calibration = None
     if pipelined_loop and gf and graphed:
-        # GroupFree3D: the eager loop is host-bound (~3 500 launches), so the pipelined step is
-        # replayed as one HIP graph (next batch's pyramid on a side stream inside the graph)
-        graphed_step = gf_train.GraphedPipelinedStep(net, opt, batches[0], batches[1], cfg)
+        # GroupFree3D: the eager loop is host-bound on a slow host (~1 000 launches per step),
+        # a HIP-graph replay is paced by its node count (~13 us each); which one is faster
+        # depends on the box.  The step is captured once, then -- unless --graph forces the
+        # replay (--no-graph: the eager loop) -- both loops run a few untimed steps and the
+        # faster one is what the timed region uses, as a trainer would choose at start-up
+        # (next batch's pyramid on a side stream inside the graph)
+        captured = gf_train.GraphedPipelinedStep(net, opt, batches[0], batches[1], cfg)
         barrier()
+        graphed_step = captured
+        if not args.graph:
+            ms = {}
+            for name, g in (("graph", captured), ("eager", None)):
+                graphed_step = g
+                run_steps(2)
+                barrier()
+                tc = time.perf_counter()
+                run_steps(5)
+                barrier()
+                ms[name] = 1e3 * (time.perf_counter() - tc) / 5
+            gf_calibration = ms
+            graphed_step = captured if ms["graph"] <= ms["eager"] else None
+            graphed = graphed_step is not None
     run_steps(args.warmup)
     barrier()
     train.freeze_gc()  # host runtime hygiene (see train.freeze_gc); no effect on the GPU work
@@ -468,6 +487,8 @@ def main():
                 "min": min(per_rank_host), "max": max(per_rank_host), "ranks": per_rank_host}
         if gf:
             out["hip_graph"] = bool(graphed)
+            if gf_calibration is not None:   # untimed 5-step samples the choice was made on
+                out["hip_graph_calibration_ms_per_step"] = gf_calibration
         else:
             out["hip_graph"] = graphed_step is not None
         # which form the point-wise MLP chains of the timed steps took (library = one C call per
