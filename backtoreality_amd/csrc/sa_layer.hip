@@ -321,6 +321,14 @@ inline unsigned char *at_b(void *base, size_t off) { return (unsigned char *)bas
 
 inline bool pool_grad_ok(int s) { return s == 16 || s == 32 || s == 64 || s == 128; }
 
+// chunks the split-K partials [.][n][k] of a layer's weight gradient are sized for: whichever of
+// the plain TN GEMM and the fused backward (csrc/sa_mlp.hip) splits the rows finer
+inline int wgrad_partial_chunks(int rows, int n, int k) {
+  int c = btr_sa_gemm_tn_chunks(rows, n, k);
+  if (btr_sa_bwd_fused_supported(rows, n, k)) c = std::max(c, btr_sa_bwd_fused_chunks(rows, n, k));
+  return c;
+}
+
 // scratch layouts (recomputed identically by plan / forward / backward)
 struct SaFwdScratch {
   size_t part, len_tmp, extg, exta, tickets, bytes;
@@ -365,7 +373,7 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   s.beta = b.floats(cl);
   // split-K partials: one region per layer (their reductions are issued together at the end)
   for (int l = 0; l < d.layers; ++l)
-    s.pw[l] = b.floats((size_t)btr_sa_gemm_tn_chunks(p.rows, d.width[l], p.kin[l]) * d.width[l] *
+    s.pw[l] = b.floats((size_t)wgrad_partial_chunks(p.rows, d.width[l], p.kin[l]) * d.width[l] *
                        p.kin[l]);
   s.pw0 = b.floats(pw0);   // (first-layer recompute: its partials, written on the main stream)
   s.g[0] = b.floats((size_t)p.rows * maxk);
@@ -794,7 +802,7 @@ PmBwdScratch pm_bwd_scratch(const btr_pm_chain_t &d, const btr_pm_plan_t &p) {
   s.m1 = b.floats(maxc);
   s.m2 = b.floats(maxc);
   for (int l = 0; l < d.layers; ++l)   // split-K partials, one region per layer
-    s.pw[l] = b.floats((size_t)btr_sa_gemm_tn_chunks(p.rows, p.np[l], p.kin[l]) * p.np[l] *
+    s.pw[l] = b.floats((size_t)wgrad_partial_chunks(p.rows, p.np[l], p.kin[l]) * p.np[l] *
                        p.kin[l]);
   s.colsum = b.floats((size_t)d.b * cdiv(d.n, 64) * p.np[d.layers - 1]);   // per 64-row tile
   s.bytes = b.off;

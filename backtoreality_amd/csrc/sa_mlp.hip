@@ -2243,10 +2243,13 @@ struct FusedArgs {
   int ldz;
   float *pw;           // out: weight-gradient partials [chunk][N][K]
   float *spart;        // out: [chunk][2][K] sums for BatchNorm_{l-1}'s backward
-  // GM 1
+  // GM 1 (garg / gdcl: [groups][ldt], this launch's columns from the pointer on)
   const unsigned char *garg;
   const float *gdcl, *galpha, *gbeta;
-  int SSH;
+  int SSH, ldt;
+  // acc != 0: dZ_{l-1} += this launch's product (the second 128-column slab of a 256-wide layer
+  // under BTR_BWD_FUSED_SPLIT=1)
+  int acc;
   // GM 2: layer l's scale, shift, mean, invstd and finalised m1, m2
   const float *sc, *sh, *mu, *is, *m1, *m2;
 };
@@ -2402,8 +2405,8 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
         sp_lr[q] = -1;
         if (slot < 4 && (blk << 3) < rend && sp_n < N) {
           const int g = sp_g[q];
-          const int lr = cm.goff[g] - r0 + (int)a.garg[(size_t)g * N + sp_n];
-          sp_dv[q] = a.gdcl[(size_t)g * N + sp_n];
+          const int lr = cm.goff[g] - r0 + (int)a.garg[(size_t)g * a.ldt + sp_n];
+          sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
           sp_lr[q] = (lr >= 0 && (lr >> 3) == slot) ? lr : -1;
         }
         const int nblk = ((r0 + BR) >> 3) + slot;
@@ -2416,8 +2419,8 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
         const int g = (r0 >> a.SSH) + slot;
         sp_lr[q] = -1;
         if ((slot << a.SSH) < BR && (g << a.SSH) < rend && sp_n < N) {
-          const int arow = (g << a.SSH) + (int)a.garg[(size_t)g * N + sp_n];
-          sp_dv[q] = a.gdcl[(size_t)g * N + sp_n];
+          const int arow = (g << a.SSH) + (int)a.garg[(size_t)g * a.ldt + sp_n];
+          sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
           const int lr = arow - r0;
           sp_lr[q] = (lr >= 0 && lr < BR && arow < rend) ? lr : -1;
         }
@@ -2597,7 +2600,13 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
         const float4 c0 = *reinterpret_cast<const float4 *>(&Cs[row * LC + xc4]);
         const float4 c1 = *reinterpret_cast<const float4 *>(&Cs[BR * LC + row * LC + xc4]);
         const float4 c = make_float4(c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w);
-        *reinterpret_cast<float4 *>(a.Z + (size_t)(r0 + row) * a.ldz + k0 + xc4) = c;
+        float *zp = a.Z + (size_t)(r0 + row) * a.ldz + k0 + xc4;
+        if (a.acc) {
+          const float4 o = *reinterpret_cast<const float4 *>(zp);
+          *reinterpret_cast<float4 *>(zp) = make_float4(o.x + c.x, o.y + c.y, o.z + c.z, o.w + c.w);
+        } else {
+          *reinterpret_cast<float4 *>(zp) = c;
+        }
         const float4 y = ykeep[p];
         const float gx = fmaf(fa.x, y.x, fb.x) > 0.f ? c.x : 0.f;
         const float gy = fmaf(fa.y, y.y, fb.y) > 0.f ? c.y : 0.f;
@@ -4116,15 +4125,33 @@ int btr_sa_bwd_fused_supported(int rows, int n, int k) {
          n % 4 == 0 && k >= 4 && k <= 512 && k % 4 == 0;
 }
 
-int btr_sa_bwd_fused_chunks(int rows, int n, int k) {
-  // one round of resident workgroups: 256 CUs x (2 workgroups per CU; n > 128: one) over the
-  // 64-wide k blocks -- more chunks only add partials to write and reduce (SA2's 256-wide layer:
-  // 33 MB at 256 chunks) and a second, half-empty round
-  const int resident = cu_mask_avail_cus() * (n > 128 ? 1 : 2) * grid_rounds();
+// BTR_BWD_FUSED_SPLIT=1 (measured, NOT the default): n > 128 as two launches of the 128-column
+// variant over the column slabs [0, 128) and [128, n) instead of one launch of the 256-column
+// variant (490 registers, one workgroup of four waves per CU: SA2's pooled layer moves its 233 MB
+// at 1.2 TB/s).  The weight gradient splits by rows of dW, the BatchNorm sums are linear in dZ
+// (each slab adds its own partial rows), and the second slab adds its product onto the first
+// one's dZ.  Same box, 20 steps: one launch 4.00 ms per step, two launches 4.05 (the second slab
+// re-reads X and dZ; with float atomics for the add instead of load + store: 4.31).
+static bool fused_split(int n) {
+  static const bool on =
+      getenv("BTR_BWD_FUSED_SPLIT") && getenv("BTR_BWD_FUSED_SPLIT")[0] == '1';
+  return n > 128 && on;
+}
+// row chunks of ONE launch
+static int fused_pass_chunks(int rows, int n, int k) {
+  // one round of resident workgroups: the CUs x (2 workgroups per CU; the 256-column variant: one)
+  // over the 64-wide k blocks -- more chunks only add partials to write and reduce and a second,
+  // half-empty round
+  const int np = fused_split(n) ? 128 : n;
+  const int resident = cu_mask_avail_cus() * (np > 128 ? 1 : 2) * grid_rounds();
   const int kblocks = (k + 63) / 64;
   const int want = std::max(32, resident / kblocks);
   return std::max(1, std::min(std::min(want, kFusedMaxChunks * grid_rounds()),
-                              btr_sa_gemm_tn_chunks(rows, n, k)));
+                              btr_sa_gemm_tn_chunks(rows, np, k)));
+}
+// Rows of `spart` ([.][2][k]) and chunk count `pw` ([.][n][k]) is sized for: both slabs' rows.
+int btr_sa_bwd_fused_chunks(int rows, int n, int k) {
+  return fused_pass_chunks(rows, n, k) * (fused_split(n) ? 2 : 1);
 }
 
 int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const float *yl,
@@ -4148,31 +4175,55 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
               "sa_bwd_fused: nsample %d must be 16, 32, 64 or 128", s);
   BTR_REQUIRE(n <= 128 || !w0, "sa_bwd_fused: first-layer recompute behind %d > 128 columns", n);
   hipStream_t st = as_stream(stream);
-  const int chunks = btr_sa_bwd_fused_chunks(rows, n, k);
+  const int chunks = fused_pass_chunks(rows, n, k);
+  const int passes = fused_split(n) ? 2 : 1;
   FusedArgs a{};
   a.G = g; a.Yl = yl; a.ldg = ldg; a.X = x; a.ldx = ldx; a.R = rows; a.N = n; a.K = k;
   a.rows_per_chunk = cdiv(cdiv(rows, chunks), 32) * 32;
   a.pa = pa; a.pb = pb; a.mu_p = mu_p; a.is_p = is_p; a.xw0 = w0; a.Wt = wt; a.ldw = ldw;
   a.Z = dz; a.ldz = ldz; a.pw = pw; a.spart = spart;
   a.garg = arg; a.gdcl = dcl; a.galpha = alpha; a.gbeta = beta; a.SSH = pooled ? ilog2(s) : 0;
+  a.ldt = n;
   a.sc = sc; a.sh = sh; a.mu = mu; a.is = is; a.m1 = m1l; a.m2 = m2l;
   const dim3 grid(1, cdiv(k, 64), chunks);
 #define BTR_FUSED(W, GM, XR) \
   hipLaunchKernelGGL((sa_bwd_fused_kernel<W, GM, XR>), grid, dim3(256), 0, st, a, cur_compact())
-  if (n > 128) {   // (no first-layer recompute behind a 256-wide layer: w0 is refused below)
-    if (pooled) BTR_FUSED(8, 1, false); else BTR_FUSED(8, 2, false);
-  } else if (n > 64) {
-    if (pooled) { if (w0) BTR_FUSED(4, 1, true); else BTR_FUSED(4, 1, false); }
-    else        { if (w0) BTR_FUSED(4, 2, true); else BTR_FUSED(4, 2, false); }
-  } else {
-    if (pooled) { if (w0) BTR_FUSED(2, 1, true); else BTR_FUSED(2, 1, false); }
-    else        { if (w0) BTR_FUSED(2, 2, true); else BTR_FUSED(2, 2, false); }
+  for (int pass = 0; pass < passes; ++pass) {
+    // the column slab of this launch: every per-column operand moves n0 columns on
+    const int n0 = pass * 128, np = passes == 1 ? n : std::min(128, n - n0);
+    a.N = np;
+    a.G = g + n0;
+    a.Yl = yl ? yl + n0 : nullptr;
+    a.Wt = wt + n0;
+    a.garg = arg ? arg + n0 : nullptr;
+    a.gdcl = dcl ? dcl + n0 : nullptr;
+    a.galpha = alpha ? alpha + n0 : nullptr;
+    a.gbeta = beta ? beta + n0 : nullptr;
+    a.sc = sc ? sc + n0 : nullptr; a.sh = sh ? sh + n0 : nullptr;
+    a.mu = mu ? mu + n0 : nullptr; a.is = is ? is + n0 : nullptr;
+    a.m1 = m1l ? m1l + n0 : nullptr; a.m2 = m2l ? m2l + n0 : nullptr;
+    a.pw = pw + (size_t)pass * chunks * 128 * k;            // [chunks][np][k]
+    a.spart = spart + (size_t)pass * chunks * 2 * k;        // rows pass * chunks ..
+    a.acc = pass;
+    if (np > 128) {   // (no first-layer recompute behind a 256-wide layer: w0 is refused above)
+      if (pooled) BTR_FUSED(8, 1, false); else BTR_FUSED(8, 2, false);
+    } else if (np > 64) {
+      if (pooled) { if (w0) BTR_FUSED(4, 1, true); else BTR_FUSED(4, 1, false); }
+      else        { if (w0) BTR_FUSED(4, 2, true); else BTR_FUSED(4, 2, false); }
+    } else {
+      if (pooled) { if (w0) BTR_FUSED(2, 1, true); else BTR_FUSED(2, 1, false); }
+      else        { if (w0) BTR_FUSED(2, 2, true); else BTR_FUSED(2, 2, false); }
+    }
   }
 #undef BTR_FUSED
   const double count = host_compact().on ? host_compact().count : (double)rows;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(k, kRedCh)), dim3(256), 0, st, k, chunks,
-                     count, spart, m1, m2, dgamma, dbeta);
-  reduce_chunks_launch(n * k, chunks, pw, dw, st);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(k, kRedCh)), dim3(256), 0, st, k,
+                     chunks * passes, count, spart, m1, m2, dgamma, dbeta);
+  for (int pass = 0; pass < passes; ++pass) {
+    const int n0 = pass * 128, np = passes == 1 ? n : std::min(128, n - n0);
+    reduce_chunks_launch(np * k, chunks, pw + (size_t)pass * chunks * 128 * k, dw + (size_t)n0 * k,
+                         st);
+  }
   return check_launch("sa_bwd_fused");
 }
 

@@ -341,7 +341,11 @@ int btr_sa_eval_fused(int b, int n, int m, int s, int c, int use_xyz, float radi
  * 4-column input rows x [rows][4] and w0 [k][4] when w0 != NULL (first-layer recompute);
  * mu_p / is_p: mean and invstd of layer l-1.  The caller then feeds (dz, Y_{l-1}, m1, m2) to
  * the next call, or to btr_sa_bn_relu_bwd_rc_apply for a recomputed first layer.
- * Supported: n <= 128, k <= 256, multiples of 4, bf16x6 GEMMs on (BTR_BWD_FUSED=0: never).
+ * Supported: n <= 256, k <= 512, multiples of 4, bf16x6 GEMMs on (BTR_BWD_FUSED=0: never).
+ * btr_sa_bwd_fused_chunks(): the rows spart and the chunk count pw must be sized for.  (With
+ * BTR_BWD_FUSED_SPLIT=1 -- measured slower, off -- n > 128 runs as two launches over the column
+ * slabs [0, 128) and [128, n): the second adds its product onto the first one's dz and writes
+ * its partial rows behind the first one's; the function then counts both.)
  * Reference: the autograd backward of SharedMLP's Conv2d + BatchNorm2d + ReLU stack,
  * pointnet2/pytorch_utils.py:11-36, 157-188. */
 int btr_sa_bwd_fused_supported(int rows, int n, int k);

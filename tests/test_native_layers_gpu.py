@@ -194,6 +194,7 @@ def test_in_kernel_batchnorm_finalisation_at_every_size():
     {"BTR_GRID_CUS": "256", "BTR_GRID_ROUNDS": "2"},    # more than one round of them
     {"BTR_TN_WGS_PER_CU": "4", "BTR_GEMM_WGS_PER_CU": "3"},
     {"BTR_FPS_LDS_KB": "0", "BTR_WGRAD_STREAM": "1"},   # the round-3 stream arrangement
+    {"BTR_BWD_FUSED_SPLIT": "1"},                       # 256-wide layers as two 128-column slabs
 ])
 def test_chunk_count_knobs_leave_the_results_alone(env):
     """The row-chunk counts of the streaming / fused / weight-gradient kernels are sized from the
