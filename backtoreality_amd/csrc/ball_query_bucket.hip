@@ -300,7 +300,18 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   }
   const float radius2 = radius * radius;          // ball_query_gpu.cu:27
   const float cull2 = radius2 * 1.00001f + 1e-30f;  // conservative box cull (see the header)
-  const int chunks = std::max(1, std::min(cdiv(m, kBqbWaves), 2048 / std::max(1, b)));
+  // one round of resident workgroups: a workgroup's time is its waves' chains of dependent L2
+  // round trips (~4.5 us per centre), so the 2 048 workgroups of the benchmark shape -- 1 792 fit
+  // the chip at once (LDS: seven per CU) -- spent a second round on the last 256 of them
+  // (BTR_BQ_WGS_PER_CU overrides the LDS-derived count; 0: the old fixed 2 048)
+  static const int wgs_env = getenv("BTR_BQ_WGS_PER_CU") ? atoi(getenv("BTR_BQ_WGS_PER_CU")) : -1;
+  const int by_lds = (int)std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(p.lds + 64, 1));
+  // (at most four per CU: inside the training loop the query shares the chip with the step's
+  // kernels and their LDS -- benchmark shape, in the loop: 87 us at seven per CU, 69 at four, 77 at
+  // three; alone 43 / 45 / 51.  The Matterport-shaped scenes fit three: 56 -> 37 us in the loop)
+  const int per_cu = wgs_env > 0 ? wgs_env : std::min(by_lds, 4);
+  const int budget = wgs_env == 0 ? 2048 : per_cu * cu_mask_avail_cus();
+  const int chunks = std::max(1, std::min(cdiv(m, kBqbWaves), budget / std::max(1, b)));
 #define BTR_BQB(T)                                                                              \
   hipLaunchKernelGGL(bqb_query_kernel<T>, dim3(chunks * b), dim3(kBqbWaves * 64), p.lds, s, b, n, \
                      p.np, p.nb, p.nsup, m, nsample, p.words, p.twords, radius2, cull2, new_xyz, \
