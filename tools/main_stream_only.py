@@ -23,6 +23,24 @@ h = net.backbone_net.prefetch_sampling(b['point_clouds'])
 torch.cuda.synchronize()
 
 
+occ = None
+if "--occupant" in sys.argv:   # a synthetic stand-in for the FPS beside the pyramid-less loop
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "liboccupant.so"))
+    i = sys.argv.index("--occupant")
+    o_mode, o_usec, o_lds = int(sys.argv[i + 1]), int(sys.argv[i + 2]), int(sys.argv[i + 3])
+    o_wgs = int(sys.argv[i + 4]) if len(sys.argv) > i + 4 else 8
+    perm = torch.randperm(160 * 1024, device=dev, dtype=torch.int32)
+    sink = torch.zeros(4, device=dev)
+    side = torch.cuda.Stream()
+
+    def occ():
+        side.wait_stream(torch.cuda.current_stream())
+        lib.occupant_launch_lds(o_wgs, o_mode, o_usec, ctypes.c_void_p(perm.data_ptr()), perm.numel(),
+                                ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream),
+                                o_lds)
+
+
 def loop(n, pipelined):
     global h
     t0 = time.perf_counter()
@@ -34,7 +52,11 @@ def loop(n, pipelined):
             s = out[1]['next_sampling']
     else:
         for _ in range(n):
+            if occ is not None:
+                occ()
             train.train_step(net, opt, b, cfg, sampling=h)
+            if occ is not None:
+                torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     return 1e3 * (time.perf_counter() - t0) / n
 

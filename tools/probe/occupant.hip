@@ -40,6 +40,20 @@ __global__ __launch_bounds__(1024) void occupant_kernel(int mode, long long tick
   if (acc == 12345.678f || p == -7) sink[0] = acc + (float)p;
 }
 
+// (lds_bytes of unused dynamic LDS, as the FPS launch holds: occupant_launch_lds)
+extern "C" int occupant_launch_lds(int wgs, int mode, int usec, const int *chain, int n,
+                                   float *sink, void *stream, int lds_bytes) {
+  static int set = 0;
+  if (lds_bytes > set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&occupant_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    set = lds_bytes;
+  }
+  hipLaunchKernelGGL(occupant_kernel, dim3(wgs), dim3(1024), lds_bytes, (hipStream_t)stream, mode,
+                     (long long)usec * 100, chain, n, sink);
+  return (int)hipGetLastError();
+}
+
 extern "C" int occupant_launch(int wgs, int mode, int usec, const int *chain, int n, float *sink,
                                void *stream) {
   hipLaunchKernelGGL(occupant_kernel, dim3(wgs), dim3(1024), 0, (hipStream_t)stream, mode,
