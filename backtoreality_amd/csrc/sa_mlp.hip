@@ -905,22 +905,30 @@ __global__ __launch_bounds__(256) void sa_pool_bwd_stats_kernel(
 }
 
 // part[nblk][2][C] -> m1 = sum(g)/count, m2 = sum(g*xhat)/count, dgamma = sum(g*xhat),
-// dbeta = sum(g).
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(int C, int nblk, double count,
-                                                              const float *__restrict__ part,
-                                                              float *__restrict__ m1,
-                                                              float *__restrict__ m2,
-                                                              float *__restrict__ dgamma,
-                                                              float *__restrict__ dbeta) {
+// dbeta = sum(g).  alpha != NULL (the pooled layer): also the coefficients of its dense gradient
+// part, what sa_pool_ab_kernel computes from the stored m1 / m2 (one launch less per level).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    int C, int nblk, double count, const float *__restrict__ part, float *__restrict__ m1,
+    float *__restrict__ m2, float *__restrict__ dgamma, float *__restrict__ dbeta,
+    const float *__restrict__ scale = nullptr, const float *__restrict__ mean = nullptr,
+    const float *__restrict__ invstd = nullptr, float *__restrict__ alpha = nullptr,
+    float *__restrict__ beta = nullptr) {
   const int tx = threadIdx.x & (kRedCh - 1), ty = threadIdx.x / kRedCh;
   const int c = blockIdx.x * kRedCh + tx;
   double s1, s2;
   reduce_partials(part, nblk, C, c, tx, ty, s1, s2);
   if (ty != 0 || c >= C) return;
-  m1[c] = (float)(s1 / count);
-  m2[c] = (float)(s2 / count);
+  const float f1 = (float)(s1 / count), f2 = (float)(s2 / count);
+  m1[c] = f1;
+  m2[c] = f2;
   dgamma[c] = (float)s2;
   dbeta[c] = (float)s1;
+  if (alpha) {
+    const float a = scale[c];
+    const float al = -a * invstd[c] * f2;
+    alpha[c] = al;
+    beta[c] = -a * f1 - al * mean[c];
+  }
 }
 
 // Coefficients of the pooled layer's gradient for the GEMM prologues (no dense dY pass):
@@ -3849,9 +3857,8 @@ int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, co
                        st, m, s, c, ldy, y, dout, out, arg, mean, invstd, scale, shift, part, dcl,
                        cur_compact().goff);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, kRedCh)), dim3(256), 0, st, c,
-                       (int)tiles, (double)groups * s, part, m1, m2, dgamma, dbeta);
-    hipLaunchKernelGGL(sa_pool_ab_kernel, dim3(cdiv(c, 256)), dim3(256), 0, st, c, scale, mean,
-                       invstd, m1, m2, alpha, beta);
+                       (int)tiles, (double)groups * s, part, m1, m2, dgamma, dbeta, scale, mean,
+                       invstd, alpha, beta);
     return check_launch("sa_pool_bwd_coef(tile)");
   }
   const int nblk = (int)std::min<long long>(groups, 1024);
