@@ -36,6 +36,9 @@ if "--occupant" in sys.argv:   # a synthetic stand-in for the FPS beside the pyr
 
     def occ():
         side.wait_stream(torch.cuda.current_stream())
+        if o_mode < 0:   # one sleeping WAVE per workgroup
+            lib.occupant_launch_small(o_wgs, o_usec, ctypes.c_void_p(side.cuda_stream))
+            return
         lib.occupant_launch_lds(o_wgs, o_mode, o_usec, ctypes.c_void_p(perm.data_ptr()), perm.numel(),
                                 ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream),
                                 o_lds)

@@ -55,7 +55,25 @@ def loss_with_marks(end_points, cfg_):
     return out
 
 
-pipelined = "--sequential" not in sys.argv
+pipelined = "--sequential" not in sys.argv and "--no-pyramid" not in sys.argv
+no_pyramid = "--no-pyramid" in sys.argv   # same batch every step, its pyramid computed once
+occ = None
+if "--occupant" in sys.argv:   # (with --no-pyramid) a sleeping stand-in for the FPS: wgs usec lds
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "liboccupant.so"))
+    i = sys.argv.index("--occupant")
+    o_wgs, o_usec, o_lds = int(sys.argv[i + 1]), int(sys.argv[i + 2]), int(sys.argv[i + 3])
+    perm = torch.randperm(1024, device=dev, dtype=torch.int32)
+    sink = torch.zeros(4, device=dev)
+    side = torch.cuda.Stream()
+
+    def occ():
+        side.wait_stream(torch.cuda.current_stream())
+        lib.occupant_launch_lds(o_wgs, 0, o_usec, ctypes.c_void_p(perm.data_ptr()), perm.numel(),
+                                ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream),
+                                o_lds)
+ready = core.backbone_net.prefetch_sampling(batches[0]['point_clouds']) if no_pyramid else None
+torch.cuda.synchronize()
 steps, warm = 30, 8
 sampling = core.backbone_net.prefetch_sampling(batches[0]['point_clouds']) if pipelined else None
 rows = {}
@@ -71,6 +89,11 @@ for it in range(warm + steps):
         loss, end = train.train_step(net, opt, b, cfg, sampling=sampling,
                                      next_batch=batches[(it + 1) % 3], criterion=loss_with_marks)
         sampling = end['next_sampling']
+    elif no_pyramid:
+        if occ is not None:
+            occ()
+        loss, end = train.train_step(net, opt, batches[0], cfg, sampling=ready,
+                                     criterion=loss_with_marks)
     else:
         loss, end = train.train_step(net, opt, b, cfg, criterion=loss_with_marks)
     mark("backbone bwd + Adam")

@@ -40,6 +40,17 @@ __global__ __launch_bounds__(1024) void occupant_kernel(int mode, long long tick
   if (acc == 12345.678f || p == -7) sink[0] = acc + (float)p;
 }
 
+// a single-wave variant (64 threads per workgroup): is it the resident KERNEL or its footprint?
+__global__ __launch_bounds__(64) void occupant_small_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int occupant_launch_small(int wgs, int usec, void *stream) {
+  hipLaunchKernelGGL(occupant_small_kernel, dim3(wgs), dim3(64), 0, (hipStream_t)stream,
+                     (long long)usec * 100);
+  return (int)hipGetLastError();
+}
+
 // (lds_bytes of unused dynamic LDS, as the FPS launch holds: occupant_launch_lds)
 extern "C" int occupant_launch_lds(int wgs, int mode, int usec, const int *chain, int n,
                                    float *sink, void *stream, int lds_bytes) {
