@@ -605,12 +605,13 @@ def roofline_objects(kernels, detail, detail_steps, pair_overhead_ms=0.0):
         ach = nbytes / (ms * 1e-3) / 1e9
         res["ball_query_roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                      # (bqb_query_kernel's grid: csrc/ball_query_bucket.hip
-                                      # bq_bucket_launch; the grid kernel is not keyed)
-                                      "traffic": (pmc_traffic(
-                                          "bqb_query_kernel",
-                                          max(1, min((m + 3) // 4, 2048 // max(1, b))) * b * 256)
-                                          if bq_buckets else None),
+                                      # (bqb_query_kernel runs once per step, for SA1: the
+                                      # profile's workload shape -- checked in pmc_traffic --
+                                      # identifies the launch; its grid follows the CUs and LDS
+                                      # of the device, csrc/ball_query_bucket.hip
+                                      # bq_bucket_launch.  The grid kernel is not keyed)
+                                      "traffic": (pmc_traffic("bqb_query_kernel")
+                                                  if bq_buckets else None),
                                       "algorithmic_bytes": nbytes,
                                       # what a launch sequence of this size can reach at all: one
                                       # dependent-kernel boundary per launch (1.45 us,
