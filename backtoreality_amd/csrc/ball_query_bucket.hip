@@ -291,12 +291,15 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   const void *fn = trip == 2   ? (const void *)bqb_query_kernel<2>
                    : trip == 8 ? (const void *)bqb_query_kernel<8>
                                : (const void *)bqb_query_kernel<4>;
-  static size_t lds_set = 0;
-  if (p.lds > lds_set && p.lds > 48 * 1024) {
+  static size_t lds_set[64] = {};   // (per device: the attribute belongs to the function on a device)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = dev >= 0 && dev < 64 ? dev : 0;
+  if (p.lds > lds_set[dev] && p.lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
     if (e != hipSuccess)
       return fail((int)e, "ball_query(buckets) attr: %s", hipGetErrorString(e));
-    lds_set = p.lds;
+    lds_set[dev] = p.lds;
   }
   const float radius2 = radius * radius;          // ball_query_gpu.cu:27
   const float cull2 = radius2 * 1.00001f + 1e-30f;  // conservative box cull (see the header)

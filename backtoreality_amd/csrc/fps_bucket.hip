@@ -1405,19 +1405,25 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   }();
   size_t dyn = (size_t)lds_kb << 10;
   if (dyn > 0) {
-    // (per process; the attribute is a property of the function.  A runtime that refuses it
-    // leaves the launch as it was: the reservation is about speed only)
-    static const bool attr_ok = [&] {
-      const hipError_t e1 = hipFuncSetAttribute(
-          reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      const hipError_t e2 = hipFuncSetAttribute(
-          reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      (void)hipGetLastError();
-      return e1 == hipSuccess && e2 == hipSuccess;
-    }();
-    if (!attr_ok) dyn = 0;
+    // (the attribute belongs to the function ON A DEVICE: set once per device.  A runtime that
+    // refuses it leaves the launch as it was: the reservation is about speed only)
+    static signed char attr_state[64] = {};   // 0 unknown, 1 set, -1 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      dyn = 0;
+    } else {
+      if (attr_state[dev] == 0) {
+        const hipError_t e1 = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        const hipError_t e2 = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        (void)hipGetLastError();
+        attr_state[dev] = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : -1;
+      }
+      if (attr_state[dev] != 1) dyn = 0;
+    }
   }
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
