@@ -13,8 +13,8 @@ the summed and the longest duration inside one steady-state step).
               kernel alone)
   ball query  the longest bqb_query_kernel (or bq_grid_query_kernel) call + its set-up
               launches (bqb_box / bqb_super in builds that had them, or the grid build), longest call of each
-  grouped MLP every gemm_nt_kernel / gemm_tn_kernel / gemm_tn_x6_kernel / sa_bwd_fused_kernel
-              launch of the step (+ every reduce_chunks* launch, the second half of the split-K)
+  grouped MLP every gemm_nt_kernel / sa_fwd_stream_kernel / gemm_tn_kernel / gemm_tn_x6_kernel /
+              sa_bwd_fused_kernel launch of the step (+ every reduce_chunks* launch, the second half of the split-K)
               against the f32 MFMA peak
 
 Prints a table: live figure (JSON), profile figure, ratio."""
@@ -73,8 +73,10 @@ def main():
         # rounds 3's tables matched "gemm_tn_kernel" only and so left it and the batched
         # reductions out -- the 0.63 "profile frac" of r03_k was really 0.40), the fused backward
         # (two products per launch) and all split-K reductions
+        # ... and the streaming forward / input-gradient kernel (round 4; the first r04_f / r04_h
+        # tables left it out: their 1.92 / 1.79 ms, 0.61 / 0.65 were 2.5 / 2.4 ms, 0.47 / 0.49)
         us = total("gemm_nt_kernel") + total("gemm_tn_") + total("sa_bwd_fused_kernel") + \
-            total("reduce_chunks")
+            total("sa_fwd_stream_kernel") + total("reduce_chunks")
         ach = mlp["gflop_per_step"] * 1e9 / (us * 1e-6) / 1e12
         out.append(("mlp_roofline", mlp["ms_per_step"] * 1e3, us, mlp["frac"],
                     ach / MFMA_F32_PEAK_TF))
