@@ -1398,11 +1398,7 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   // CU-masked queue does not do it: the dispatcher balances workgroups per shader engine, so
   // taking one CU of 32 away slows every launch on that queue by 16 % (BTR_CU_MASK).
   // Same box, 20 steps: 4.54 -> 4.37 ms per step; 64 KB: 4.49.
-  static const int lds_kb = [] {
-    const char *e = getenv("BTR_FPS_LDS_KB");
-    const int v = e ? atoi(e) : 128;
-    return v > 0 && v <= 156 ? v : 0;
-  }();
+  static const int lds_kb = fps_lds_reserve_kb();
   size_t dyn = (size_t)lds_kb << 10;
   if (dyn > 0) {
     // (the attribute belongs to the function ON A DEVICE: set once per device.  A runtime that
@@ -1443,6 +1439,23 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   return check_launch("furthest_point_sampling(bucket)");
 }
 
+// ---- the LDS reservation of the large-scene FPS launch (see btr_furthest_point_sampling's
+// bucket path): BTR_FPS_LDS_KB = k (0: none), default 128.  In a data-parallel run (WORLD_SIZE
+// > 1) the default drops to 96: RCCL's kernels need up to ~64 KB of LDS per workgroup, and the
+// all-reduce runs while the next batch's FPS holds its eight CUs -- with 96 KB taken a collective
+// workgroup still fits beside a scene (160 - 97 KB), so a ring of more channels than the 248 free
+// CUs' share never waits for the 2 ms sampling chain to end; the step's own LDS-heavy kernels (64
+// - 128 KB per workgroup pair) are still kept off those CUs.
+int fps_lds_reserve_kb() {
+  static const int kb = [] {
+    const char *e = getenv("BTR_FPS_LDS_KB");
+    const char *w = getenv("WORLD_SIZE");
+    const int v = e ? atoi(e) : (w && atoi(w) > 1 ? 96 : 128);
+    return v > 0 && v <= 156 ? v : 0;
+  }();
+  return kb;
+}
+
 // ---- CU partitioning (internal.hpp)
 int cu_mask_reserved() {
   static const int c = [] {
@@ -1451,6 +1464,18 @@ int cu_mask_reserved() {
     return v > 0 && v <= 8 ? v : 0;
   }();
   return c;
+}
+// CUs left to the collective's kernels when they overlap the step (see cu_mask_avail_cus):
+// BTR_COMM_CUS, default 16 under WORLD_SIZE > 1 with BTR_DP=ddp, else 0.
+static int comm_cus() {
+  if (const char *e = getenv("BTR_COMM_CUS")) {
+    const int v = atoi(e);
+    return v >= 0 && v <= 128 ? v : 0;
+  }
+  const char *w = getenv("WORLD_SIZE");
+  const char *dp = getenv("BTR_DP");
+  const bool overlapped = dp && dp[0] == 'd' && dp[1] == 'd' && dp[2] == 'p' && dp[3] == 0;
+  return (w && atoi(w) > 1 && overlapped) ? 16 : 0;
 }
 int cu_mask_avail_cus() {
   static const int avail = [] {
@@ -1467,8 +1492,13 @@ int cu_mask_avail_cus() {
     // default: the eight CUs the large-scene FPS of the NEXT batch sits on while a step runs (one
     // workgroup per scene) are not counted -- a one-round grid sized for all 256 leaves its last
     // workgroups waiting for a second round beside it (same box, 20 steps: 4.66 -> 4.59 ms
-    // pipelined, 6.42 -> 6.47 strictly sequential)
-    return std::max(8, cus - 8 * std::max(1, cu_mask_reserved()));
+    // pipelined, 6.42 -> 6.47 strictly sequential).  Data-parallel runs whose gradient
+    // collective overlaps the backward (BTR_DP=ddp: bucketed all-reduce kernels of RCCL beside
+    // the weight-gradient GEMMs) leave comm_cus() more out: RCCL's ring kernels are persistent
+    // workgroups (one per channel) that hold their CU's LDS staging buffers for the whole
+    // collective.  The flat all-reduce (the default wrapper) runs behind the backward, beside
+    // nothing of the step but the FPS: no CUs are set aside for it.
+    return std::max(8, cus - 8 * std::max(1, cu_mask_reserved()) - comm_cus());
   }();
   return avail;
 }
@@ -1545,6 +1575,8 @@ const Box8 *fps_boxes_lookup(const void *workspace, int b, int n, unsigned *epoc
 }  // namespace btr
 
 extern "C" int btr_cu_mask_reserved(void) { return btr::cu_mask_reserved(); }
+extern "C" int btr_grid_cus(void) { return btr::cu_mask_avail_cus(); }
+extern "C" int btr_fps_lds_reserve_kb(void) { return btr::fps_lds_reserve_kb(); }
 extern "C" void *btr_cu_mask_create_stream(int reserved) {
   return (void *)btr::cu_mask_create_stream(reserved != 0);
 }

@@ -18,6 +18,9 @@ int cu_mask_reserved();                       // c (0: off)
 // -- the row chunks of the streaming / fused / weight-gradient kernels -- count these, not the
 // device's, or the leftover workgroups wait for a second round on a partitioned chip
 int cu_mask_avail_cus();
+// KB of dynamic LDS the large-scene FPS launch asks for without using it (keeps the step's
+// LDS-using workgroups off its CUs); BTR_FPS_LDS_KB, default 128, 96 when WORLD_SIZE > 1
+int fps_lds_reserve_kb();
 hipStream_t cu_mask_fps_stream();             // the reserved CUs (one per device and host thread)
 hipStream_t cu_mask_create_stream(bool reserved);   // a NEW stream on the reserved / other CUs
 

@@ -365,7 +365,14 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   }
   const size_t pw0 = p.recompute ? (size_t)btr_sa_rc_wgrad_blocks(p.rows, d.width[0]) * d.width[0] * 4 : 0;
   const int cl = d.width[d.layers - 1];
-  s.part = b.floats((size_t)1024 * 2 * maxc);
+  // [rows of partial sums][2][maxc]: the BatchNorm-backward statistics passes write <= 1024 rows,
+  // btr_sa_bwd_fused writes one row per chunk and column slab (BTR_GRID_ROUNDS / _FUSED_SPLIT
+  // raise that count)
+  int part_rows = 1024;
+  for (int l = 1; l < d.layers; ++l)
+    if (btr_sa_bwd_fused_supported(p.rows, d.width[l], p.kin[l]))
+      part_rows = std::max(part_rows, btr_sa_bwd_fused_chunks(p.rows, d.width[l], p.kin[l]));
+  s.part = b.floats((size_t)part_rows * 2 * maxc);
   s.m1 = b.floats(maxc);
   s.m2 = b.floats(maxc);
   s.dcl = b.floats((size_t)d.b * d.m * cl);
@@ -643,8 +650,11 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   // sums finalised in (m1, m2) -- not yet dY_l.  btr_sa_bwd_fused applies them while it stages
   // its operand; any other consumer gets them applied in place first.
   bool lazy = false, fused_any = false;
+  // (the first-layer recompute rides in the fused call of layer 1 only behind <= 128 columns:
+  // a wider layer 1 takes the separate calls)
   auto fusable = [&](int l) {
-    return l >= 1 && btr_sa_bwd_fused_supported(R, d.width[l], p.kin[l]) != 0;
+    return l >= 1 && btr_sa_bwd_fused_supported(R, d.width[l], p.kin[l]) != 0 &&
+           !(p.recompute && l == 1 && d.width[l] > 128);
   };
   for (int l = L - 1; l >= 0; --l) {
     const int nl = d.width[l], k = p.kin[l];
@@ -667,6 +677,8 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       // dW_l, dZ_{l-1} and BatchNorm_{l-1}'s sums; dY_l is formed while its rows are staged
       float *g = at_f(scratch, sc.g[flip]);
       flip ^= 1;
+      // g is the buffer dY_{l+1} lived in: a side-stream weight gradient must be through with it
+      if (side && last_done == l + 1) (void)hipStreamWaitEvent(hmain, side->done[l + 1], 0);
       const bool rc1 = p.recompute && l == 1;
       BTR_TRY(btr_sa_bwd_fused(
           R, nl, k, pooled ? ylast : dy, nl, pooled ? nullptr : at_f(saved, p.y[l]), stat(l, 0),
@@ -798,7 +810,11 @@ PmBwdScratch pm_bwd_scratch(const btr_pm_chain_t &d, const btr_pm_plan_t &p) {
   for (int l = 0; l < d.layers; ++l) maxc = std::max(maxc, std::max(p.np[l], p.kin[l]));
   s.g[0] = b.floats((size_t)p.rows * maxc);
   s.g[1] = b.floats((size_t)p.rows * maxc);
-  s.part = b.floats((size_t)1024 * 2 * maxc);
+  int part_rows = 1024;   // (as in sa_bwd_scratch: one row per chunk of a fused call)
+  for (int l = 1; l < d.layers; ++l)
+    if (btr_sa_bwd_fused_supported(p.rows, p.np[l], p.kin[l]))
+      part_rows = std::max(part_rows, btr_sa_bwd_fused_chunks(p.rows, p.np[l], p.kin[l]));
+  s.part = b.floats((size_t)part_rows * 2 * maxc);
   s.m1 = b.floats(maxc);
   s.m2 = b.floats(maxc);
   for (int l = 0; l < d.layers; ++l)   // split-K partials, one region per layer

@@ -47,12 +47,12 @@ class GroupFreeDetector(nn.Module):
         self.dim_feedforward = dim_feedforward
         self.self_position_embedding = self_position_embedding
         self.cross_position_embedding = cross_position_embedding
-        if width != 1:
-            raise NotImplementedError("backbone width %r (the reference default 1 only)" % width)
 
+        # (the reference's detector passes `width` on and leaves the backbone's depth at its
+        # default 2, detector.py:57; both are accepted by the backbone here)
         self.backbone_net = Pointnet2Backbone(input_feature_dim=self.input_feature_dim,
                                               fp2_out=288, center_refine=self.center_refine,
-                                              num_class=num_class)
+                                              num_class=num_class, width=width)
         if self.sampling == 'fps':
             self.fps_module = FPSModule(num_proposal)
         elif self.sampling == 'kps':

@@ -102,7 +102,11 @@ class FusedHeadsLoss(Function):
         ctx.mark_non_differentiable(stats, label, assign)
         # (no zero-filled gradients for the statistics / label outputs: four fill launches)
         ctx.set_materialize_grads(False)
-        return stats[8 * H + 3].clone(), stats, label, assign
+        # the total: a 0-dim tensor on the statistics vector's storage -- no copy launch, and a
+        # base tensor (not an autograd view of `stats`), so `loss *= w` style code still works
+        loss = torch.empty((), dtype=torch.float32, device=stats.device).set_(
+            stats.untyped_storage(), stats.storage_offset() + 8 * H + 3, (), ())
+        return loss, stats, label, assign
 
     @staticmethod
     def backward(ctx, gtotal, *_unused):

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "btr_furthest_point_sampling_ws": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _sz, _vp]),
     "btr_backbone_fork_event": (None, [_vp, _ci]),
     "btr_cu_mask_reserved": (_ci, []),
+    "btr_grid_cus": (_ci, []),
+    "btr_fps_lds_reserve_kb": (_ci, []),
     "btr_cu_mask_create_stream": (_vp, [_ci]),
     "btr_fps_ordered_scratch_bytes": (_sz, [_ci, _ci, _ci]),
     "btr_furthest_point_sampling_ordered": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _sz,

@@ -249,8 +249,11 @@ class FusedSAFunction(Function):
             lazy = None
 
             def fusable(j):
+                # (the first-layer recompute rides in layer 1's fused call only behind <= 128
+                # columns, as in csrc/sa_layer.hip)
                 return j >= 1 and bool(_lib.btr_sa_bwd_fused_supported(
-                    R, Ws[j].shape[0], Ws[j].shape[1]))
+                    R, Ws[j].shape[0], Ws[j].shape[1])) and not (
+                        ctx.rc and j == 1 and Ws[j].shape[0] > 128)
             for l in range(L - 1, -1, -1):
                 Nl = dY.shape[1]
                 W2 = Ws[l]

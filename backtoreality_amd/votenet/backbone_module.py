@@ -33,16 +33,25 @@ class Pointnet2Backbone(nn.Module):
     centres (the noisy GT box centres) whose output, concatenated with the one-hot class of
     each centre, feeds the centre-jitter regressor of the CenterRefine recipe."""
 
-    def __init__(self, input_feature_dim=0, fp2_out=256, center_refine=False, num_class=22):
+    def __init__(self, input_feature_dim=0, fp2_out=256, center_refine=False, num_class=22,
+                 width=1, depth=2):
+        """width / depth: the channel multiplier and the number of hidden layers per
+        set-abstraction MLP of GroupFree3D's backbone (detection/GroupFree3D/models/
+        backbone_module.py:33-75: mlp = [in] + [h * width] * depth + [out * width], FP modules
+        [512 w, 256 w, 256 w] and [512 w, 256 w, fp2_out]); VoteNet's is width = 1, depth = 2."""
         super().__init__()
+        self.width, self.depth = int(width), int(depth)
+        assert self.width >= 1 and self.depth >= 1
+        w = self.width
         cin = input_feature_dim
         for i, (npoint, radius, nsample, widths) in enumerate(SA_SPECS, start=1):
+            hidden, out = widths[0] * w, widths[-1] * w
             setattr(self, "sa%d" % i, PointnetSAModuleVotes(
-                npoint=npoint, radius=radius, nsample=nsample, mlp=[cin] + list(widths),
-                use_xyz=True, normalize_xyz=True))
-            cin = widths[-1]
-        self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
-        self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, fp2_out])
+                npoint=npoint, radius=radius, nsample=nsample,
+                mlp=[cin] + [hidden] * self.depth + [out], use_xyz=True, normalize_xyz=True))
+            cin = out
+        self.fp1 = PointnetFPModule(mlp=[256 * w + 256 * w, 256 * w, 256 * w])
+        self.fp2 = PointnetFPModule(mlp=[256 * w + 256 * w, 256 * w, fp2_out])
         self.num_class = num_class
         if center_refine:  # backbone_module.py:188-195
             self.ctjt_head = PointnetSAModuleCenters(npoint=64, radius=0.8, nsample=16,
@@ -104,6 +113,12 @@ class Pointnet2Backbone(nn.Module):
         ev.record()      # (creates the handle; the library records it again in place)
         entry.lib.btr_backbone_fork_event(ev.cuda_event, int(os.environ.get("BTR_FORK_LEVEL", "2")))
         return ev
+
+    def disarm_fork_event(self, pointcloud):
+        """Drop an armed fork event (arm_fork_event) that no native forward consumed."""
+        entry = self._native_entry(pointcloud) if pointcloud.is_cuda else None
+        if entry is not None:
+            entry.lib.btr_backbone_fork_event(None, 0)
 
     def prefetch_sampling(self, pointcloud, after=None):
         """Start the sampling pyramid of `pointcloud` on the side stream NOW and return a

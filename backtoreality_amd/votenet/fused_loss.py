@@ -92,9 +92,13 @@ class FusedVoteNetLoss(Function):
         ctx.save_for_backward(net, agg_xyz, vote_xyz, seed_xyz, seed_inds, mean_size, norm,
                               objectness_label, objectness_mask, object_assignment, j1c, k2c,
                               vote_arg, *labels)
-        # (a view of the statistics vector, not a clone: one copy launch per step less; `stats`
-        # itself is returned non-differentiable below)
-        loss = stats[0]
+        # (the first word of the statistics vector, not a clone: one copy launch per step less.
+        # NOT an autograd view of `stats` either -- a view created inside a Function refuses
+        # every in-place op (`loss *= w`); a 0-dim tensor set on the same storage is a base
+        # tensor autograd treats like any other output.  `stats` itself is returned
+        # non-differentiable below)
+        loss = torch.empty((), dtype=torch.float32, device=dev).set_(
+            stats.untyped_storage(), stats.storage_offset(), (), ())
         ctx.mark_non_differentiable(stats, objectness_label, objectness_mask, object_assignment)
         # (no zero-filled gradients for the statistics / label outputs: four fill launches)
         ctx.set_materialize_grads(False)

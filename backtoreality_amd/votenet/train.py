@@ -490,7 +490,14 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None, crite
         fork = core.backbone_net.arm_fork_event(batch['point_clouds'])
         if fork is None:
             nxt_sampling = core.backbone_net.prefetch_sampling(next_batch['point_clouds'])
-    end_points = net(inputs)
+    try:
+        end_points = net(inputs)
+    finally:
+        # the library holds the event's raw handle until a native forward consumes it: never
+        # leave it armed past this forward (an exception / another path would leave a dangling
+        # handle for the thread's next forward to record)
+        if fork is not None:
+            core.backbone_net.disarm_fork_event(batch['point_clouds'])
     if fork is not None:
         nxt_sampling = core.backbone_net.prefetch_sampling(next_batch['point_clouds'], after=fork)
     for key in batch:

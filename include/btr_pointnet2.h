@@ -66,7 +66,10 @@ int btr_opt_n_threads(int work_size);
  * signature; it is overwritten (no pre-fill with 1e10 needed, src/sampling.cpp:78-80) and its
  * contents after the call are unspecified.
  * Bit-exact semantics: idxs[0]=0; points with x*x+y*y+z*z <= 1e-3 never compete; distances
- * in f32 exactly as written (no FMA contraction); ties between equal maxima resolve as the
+ * in f32 with the rounding of this library's btr_distance_mode() (default 1: the FMA
+ * contraction nvcc applies to the written expression; mode 0 = as written, no contraction);
+ * the differences x-x0, y-y0, z-z0 are plain f32 subtractions in every mode, and the skip test
+ * x*x+y*y+z*z uses the same mode; ties between equal maxima resolve as the
  * reference's 2^k-thread shared-memory tree does for block size opt_n_threads(n): smallest
  * (bitreverse(k mod bs), k).  m <= 0 is a no-op.
  * ------------------------------------------------------------------------------------------- */
@@ -142,6 +145,15 @@ int btr_ball_query_ws(int b, int n, int m, float radius, int nsample, const floa
  * btr_cu_mask_reserved() returns c (0: off; the create call then returns a plain stream). */
 int btr_cu_mask_reserved(void);
 void *btr_cu_mask_create_stream(int reserved);
+/* What the library's one-round grids are sized for, and what the large-scene FPS launch holds
+ * (both read once per process from the environment; no GPU needed to ask):
+ * btr_grid_cus(): CUs a kernel of the training step counts on = device CUs (256 without a
+ *   device) - 8 for the next batch's FPS scenes - BTR_COMM_CUS for a collective that overlaps
+ *   the backward (default 16 when WORLD_SIZE > 1 and BTR_DP=ddp, else 0); BTR_GRID_CUS overrides.
+ * btr_fps_lds_reserve_kb(): KB of LDS the FPS launch reserves on each of its CUs (BTR_FPS_LDS_KB;
+ *   default 128, 96 when WORLD_SIZE > 1 so that an RCCL workgroup still fits beside a scene). */
+int btr_grid_cus(void);
+int btr_fps_lds_reserve_kb(void);
 
 /* Measurement only (bench.py): the next btr_ball_query_buckets call -- or btr_ball_query_ws call
  * on a scene of more than 4096 points -- of this host thread records the two hipEvent_t around

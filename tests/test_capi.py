@@ -103,3 +103,39 @@ def test_build_guard_finds_packed_f32_in_index_objects(tmp_path):
                            "-o", str(obj)])
     sites = build.packed_f32_sites(str(obj))
     assert sites and all("pk_probe" in fn for fn, _ in sites), sites
+
+
+def _runtime_defaults(env):
+    """(btr_grid_cus, btr_fps_lds_reserve_kb) of a fresh process under `env` (both are read once
+    per process)."""
+    import subprocess
+    import sys
+    code = ("import ctypes; from backtoreality_amd import build; l = ctypes.CDLL(build.build()); "
+            "print(l.btr_grid_cus(), l.btr_fps_lds_reserve_kb())")
+    e = {k: v for k, v in os.environ.items()
+         if k not in ("WORLD_SIZE", "BTR_DP", "BTR_GRID_CUS", "BTR_FPS_LDS_KB", "BTR_COMM_CUS",
+                      "BTR_CU_MASK")}
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, check=True,
+                         capture_output=True, text=True).stdout.split()
+    return int(out[-2]), int(out[-1])
+
+
+def test_grid_and_lds_defaults_follow_the_world_size():
+    """One-round grids and the FPS's LDS reservation leave room for RCCL's kernels in a
+    data-parallel run (train_GF_FSB.py:450-474 launches one process per GPU): no GPU needed."""
+    import torch
+    cus = 256   # (no device here; on a GPU box the device's count)
+    if torch.cuda.is_available():
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert _runtime_defaults({}) == (cus - 8, 128)
+    assert _runtime_defaults({"WORLD_SIZE": "1"}) == (cus - 8, 128)
+    # the flat all-reduce runs behind the backward: only the LDS reservation moves
+    assert _runtime_defaults({"WORLD_SIZE": "8"}) == (cus - 8, 96)
+    # DistributedDataParallel overlaps its buckets with the backward: CUs set aside for them
+    assert _runtime_defaults({"WORLD_SIZE": "8", "BTR_DP": "ddp"}) == (cus - 24, 96)
+    assert _runtime_defaults({"WORLD_SIZE": "8", "BTR_DP": "ddp", "BTR_COMM_CUS": "32"}) == (
+        cus - 40, 96)
+    # explicit settings win
+    assert _runtime_defaults({"WORLD_SIZE": "8", "BTR_GRID_CUS": "200", "BTR_FPS_LDS_KB": "0"}) == (
+        200, 0)

@@ -127,6 +127,55 @@ def test_c5_scenes_with_a_near_tie_state_the_bound_per_flip(cuda, monkeypatch):
     assert moved <= 2, (moved, row_dev.topk(8), own.topk(8), {n: l2(n) for n in live})
 
 
+def _votenet_br_step(cfg, batch_S, batch_T, dev, fused, monkeypatch, vote_inds=None):
+    """One Back-to-Reality forward pair + get_loss_DA + backward (train_Votenet_BR.py:267-289).
+    `vote_inds`: (source, target) proposals for the two vote-aggregation calls, in call order."""
+    monkeypatch.setenv("BTR_FUSED_SA", "1" if fused else "0")
+    net = train.build_model(cfg, dev, seed=0, domain_adaptation=True)
+    if vote_inds is not None:
+        sa = net.pnet.vote_aggregation
+        own, queue = sa.forward, list(vote_inds)
+        sa.forward = lambda xyz, features=None, inds=None: own(xyz, features, queue.pop(0))
+    eS = net({'point_clouds': batch_S['point_clouds']})
+    eT = net({'point_clouds': batch_T['point_clouds']})
+    eS.update(batch_S)
+    eT.update(batch_T)
+    loss, eS, eT = loss_helper.get_loss_DA(eS, eT, cfg)
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    return loss.detach(), eS, eT, grads
+
+
+def test_c3_back_to_reality_full_size_step(cuda, monkeypatch):
+    """C3 (BASELINE configs[2]) at its full per-GPU size: source AND target batch of 8 x 40 000
+    points through the same VoteNet_DA (models/votenet_DA.py:123-176), get_loss_DA, one backward
+    -- the fused HIP path against the nine-op + torch composition with both branches' proposals
+    pinned to the op-by-op run's (as test_c5_matterport_80k_points): every sampling index equal,
+    features / discriminator outputs / every loss term 1e-4, gradients 1e-2 relative L2."""
+    cfg = config.scannet_md40()
+    batch_S = synthetic.make_batch(0, 8, 40000, cfg, device=cuda)         # bench.py's source
+    batch_T = synthetic.make_batch(100000, 8, 40000, cfg, device=cuda)    # ... and target batch
+    loss_u, uS, uT, g_u = _votenet_br_step(cfg, batch_S, batch_T, cuda, False, monkeypatch)
+    pins = (uS['aggregated_vote_inds'], uT['aggregated_vote_inds'])
+    loss_f, fS, fT, g_f = _votenet_br_step(cfg, batch_S, batch_T, cuda, True, monkeypatch,
+                                           vote_inds=pins)
+    for tag, f, u in (("S", fS, uS), ("T", fT, uT)):
+        for k in ('sa1_inds', 'sa2_inds', 'fp2_inds', 'aggregated_vote_inds', 'objectness_label'):
+            assert torch.equal(f[k], u[k]), (tag, k)
+        assert _rel(f['fp2_features'], u['fp2_features']) < 1e-4, tag
+        assert _rel(f['aggregated_vote_features'], u['aggregated_vote_features']) < 2e-4, tag
+        for k in ('global_d_pred', 'local_d_pred', 'center'):
+            assert _rel(f[k], u[k]) < 2e-4, (tag, k)
+        for k in ('vote_loss', 'objectness_loss', 'center_loss', 'size_cls_loss', 'sem_cls_loss'):
+            if k in u:
+                a, b = float(f[k]), float(u[k])
+                assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (tag, k, a, b)
+    assert abs(float(loss_f) - float(loss_u)) / abs(float(loss_u)) < 1e-4
+    assert set(g_f) == set(g_u)
+    worst = _worst_grad_dev(g_f, g_u)
+    assert worst < 1e-2, worst
+
+
 def test_c4_groupfree_backbone_50k_no_features(cuda, monkeypatch):
     """C4: GroupFree3D-style backbone: xyz only (no height channel), 50 000 points, fp2 -> 288
     channels (detection/GroupFree3D/models/backbone_module.py:33-75); configs[3]: batch 4."""

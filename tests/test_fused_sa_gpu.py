@@ -124,7 +124,8 @@ def test_pooled_gradient_paths_agree(cuda, monkeypatch, poolgrad):
 
 
 @pytest.mark.parametrize("recompute", ["1", "0"])
-@pytest.mark.parametrize("C,mlp", [(1, [1, 64, 64, 128]), (0, [0, 32, 48, 64])])
+@pytest.mark.parametrize("C,mlp", [(1, [1, 64, 64, 128]), (0, [0, 32, 48, 64]),
+                                   (1, [1, 64, 256, 256])])   # layer 1 wider than the fused rc
 def test_first_layer_recompute(cuda, monkeypatch, recompute, C, mlp):
     """SA1 configuration (<= 4 input columns, inputs without gradient): the first pre-BN output
     is not stored; the second layer's forward / weight gradient and the first layer's backward

@@ -133,6 +133,64 @@ def test_groupfree_variants_build_and_name_their_heads():
                                     cfg.mean_size_arr, sampling='random')
 
 
+def test_groupfree_backbone_width_and_depth():
+    """`width` / `depth` of GroupFree3D's backbone (models/backbone_module.py:33-75; train_GF_FSB.py
+    --width): mlp = [in] + [h * width] * depth + [out * width] per level, FP modules
+    [512 w, 256 w, 256 w] and [512 w, 256 w, 288]; the detector hands `width` on
+    (detector.py:61)."""
+    from backtoreality_amd.votenet.backbone_module import Pointnet2Backbone
+    bb = Pointnet2Backbone(input_feature_dim=0, fp2_out=288, width=2, depth=3)
+    shapes = {n: tuple(p.shape) for n, p in bb.state_dict().items() if n.endswith("conv.weight")}
+    want = {"sa1": [3, 128, 128, 128, 256], "sa2": [256 + 3, 256, 256, 256, 512],
+            "sa3": [512 + 3, 256, 256, 256, 512], "sa4": [512 + 3, 256, 256, 256, 512]}
+    for name, chain in want.items():
+        for i in range(len(chain) - 1):
+            assert shapes["%s.mlp_module.layer%d.conv.weight" % (name, i)] == (
+                chain[i + 1], chain[i], 1, 1), (name, i)
+    assert shapes["fp1.mlp.layer0.conv.weight"] == (512, 1024, 1, 1)
+    assert shapes["fp1.mlp.layer1.conv.weight"] == (512, 512, 1, 1)
+    assert shapes["fp2.mlp.layer0.conv.weight"] == (512, 1024, 1, 1)
+    assert shapes["fp2.mlp.layer1.conv.weight"] == (288, 512, 1, 1)
+    cfg = config.scannet_md40()
+    net = groupfree.GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                      cfg.mean_size_arr, width=2, num_decoder_layers=1)
+    assert net.backbone_net.width == 2 and net.backbone_net.depth == 2
+    assert net.backbone_net.sa2.mlp_module.layer2.conv.weight.shape == (512, 256, 1, 1)
+    # width 1 / depth 2 is the layout every golden fixture was generated with
+    base = Pointnet2Backbone(input_feature_dim=0, fp2_out=288)
+    assert base.sa1.mlp_module.layer2.conv.weight.shape == (128, 64, 1, 1)
+
+
+@pytest.mark.gpu
+def test_groupfree_wide_backbone_fused_equals_unfused(cuda, monkeypatch):
+    """width = 2 (train_GF_FSB.py --width 2): the 256 / 512-column layers leave the one-pass
+    backward's range (<= 256 columns) and the first-layer recompute sits behind a 128-column
+    layer: fused path against the nine-op + torch composition, features 1e-4, gradients 1e-2."""
+    from backtoreality_amd.votenet.backbone_module import Pointnet2Backbone
+    B = 2
+    pc = torch.from_numpy(np.stack([synthetic.make_scene(90 + i, 12000, use_height=False)[
+        'point_clouds'] for i in range(B)], 0)).to(cuda)
+
+    def run(fused):
+        monkeypatch.setenv("BTR_FUSED_SA", "1" if fused else "0")
+        torch.manual_seed(0)
+        net = Pointnet2Backbone(input_feature_dim=0, fp2_out=288, width=2).to(cuda)
+        end = net(pc)
+        end['fp2_features'].square().mean().backward()
+        return end, {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    end_f, g_f = run(True)
+    end_u, g_u = run(False)
+    assert end_f['fp2_features'].shape == (B, 288, 1024)
+    assert torch.equal(end_f['sa1_inds'], end_u['sa1_inds'])
+    for k in ('sa1_features', 'sa2_features', 'sa4_features', 'fp2_features'):
+        assert rel(end_f[k], end_u[k]) < 1e-4, k
+    for n in g_u:
+        d = float((g_f[n] - g_u[n]).norm() / (g_u[n].norm() + 1e-20))
+        assert d < 1e-2, (n, d)
+
+
 @pytest.mark.gpu
 def test_groupfree_train_steps(cuda):
     """Training-mode steps with the script defaults (dropout 0.1, clip 0.1, AdamW groups) on
