@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Full-size Back-to-Reality step (2 x 8 x 40 000), fused HIP path against the nine-op + torch
+composition with pinned proposals, for several scene seeds: which parameters' gradients deviate
+and by how much (tests/test_configs_gpu.py::test_c3_back_to_reality_full_size_step picks its
+scenes with this).  Usage: diag_c3_grads.py [first_seed ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from backtoreality_amd.votenet import config, loss_helper, synthetic, train  # noqa: E402
+
+
+def step(cfg, bS, bT, dev, fused, pins=None):
+    os.environ["BTR_FUSED_SA"] = "1" if fused else "0"
+    net = train.build_model(cfg, dev, seed=0, domain_adaptation=True)
+    if pins is not None:
+        sa = net.pnet.vote_aggregation
+        own, queue = sa.forward, list(pins)
+        sa.forward = lambda xyz, features=None, inds=None: own(xyz, features, queue.pop(0))
+    eS = net({'point_clouds': bS['point_clouds']})
+    eT = net({'point_clouds': bT['point_clouds']})
+    eS.update(bS)
+    eT.update(bT)
+    loss, eS, eT = loss_helper.get_loss_DA(eS, eT, cfg)
+    loss.backward()
+    return loss.detach(), eS, eT, {n: p.grad.detach().clone() for n, p in net.named_parameters()
+                                   if p.grad is not None}
+
+
+def main():
+    dev = torch.device("cuda:0")
+    cfg = config.scannet_md40()
+    seeds = [int(a) for a in sys.argv[1:]] or [0, 8, 16, 24]
+    for s in seeds:
+        bS = synthetic.make_batch(s, 8, 40000, cfg, device=dev)
+        bT = synthetic.make_batch(100000 + s, 8, 40000, cfg, device=dev)
+        lu, uS, uT, gu = step(cfg, bS, bT, dev, False)
+        lf, fS, fT, gf = step(cfg, bS, bT, dev, True,
+                              (uS['aggregated_vote_inds'], uT['aggregated_vote_inds']))
+        gmax = max(float(g.abs().max()) for g in gu.values())
+        devs = sorted(((float((gf[n] - gu[n]).norm() / (gu[n].norm() + 1e-20)), n) for n in gu
+                       if float(gu[n].abs().max()) > 1e-4 * gmax), reverse=True)
+        print("seed %d: loss rel %.2e; worst %.4f; first non-backbone %.4f" % (
+            s, abs(float(lf) - float(lu)) / abs(float(lu)), devs[0][0],
+            max(d for d, n in devs if not n.startswith("backbone_net.sa"))))
+        for d, n in devs[:6]:
+            print("   %.4f  %s" % (d, n))
+        sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()
