@@ -326,6 +326,7 @@ inline bool pool_grad_ok(int s) { return s == 16 || s == 32 || s == 64 || s == 1
 inline int wgrad_partial_chunks(int rows, int n, int k) {
   int c = btr_sa_gemm_tn_chunks(rows, n, k);
   if (btr_sa_bwd_fused_supported(rows, n, k)) c = std::max(c, btr_sa_bwd_fused_chunks(rows, n, k));
+  if (btr_sa_bwd_gram_supported(rows, n, k)) c = std::max(c, btr_sa_bwd_gram_chunks(rows, n, k));
   return c;
 }
 
@@ -334,9 +335,20 @@ struct SaFwdScratch {
   size_t part, len_tmp, extg, exta, tickets, bytes;
 };
 struct SaBwdScratch {
-  size_t part, m1, m2, dcl, alpha, beta, pw[kMaxL], pw0, g[2], scat, dfeat_cl, bytes;
+  size_t part, m1, m2, dcl, alpha, beta, pw[kMaxL], pw0, g[2], scat, dfeat_cl, gram, bytes;
   size_t scat_bytes;
 };
+
+// May the pooled (last) layer run without its stored output?  (see btr_sa_bwd_gram)
+inline bool sa_gram_ok(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
+  const int L = d.layers;
+  if (!(d.options & BTR_SA_OPT_POOL_GRAM) || !p.pool_grad || !p.pool_epilogue || L < 2) return false;
+  const int n = d.width[L - 1], k = p.kin[L - 1];
+  return btr_sa_bwd_gram_supported(p.rows, n, k) != 0 &&
+         btr_sa_gemm_nt_poolfwd_nostore_supported(p.rows, n, k, p.compact ? 8 : d.s) != 0 &&
+         // (the pooled BatchNorm's backward through its tile kernel: btr_sa_pool_bwd_coef, ldy == 0)
+         (long long)d.b * cdiv(d.m, 64) <= 1024 && n % 4 == 0 && d.b < 65536;
+}
 
 SaFwdScratch sa_fwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   SaFwdScratch s{};
@@ -372,6 +384,9 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   for (int l = 1; l < d.layers; ++l)
     if (btr_sa_bwd_fused_supported(p.rows, d.width[l], p.kin[l]))
       part_rows = std::max(part_rows, btr_sa_bwd_fused_chunks(p.rows, d.width[l], p.kin[l]));
+  if (p.pool_grad == 2)
+    part_rows = std::max(part_rows, btr_sa_bwd_gram_chunks(p.rows, d.width[d.layers - 1],
+                                                           p.kin[d.layers - 1]));
   s.part = b.floats((size_t)part_rows * 2 * maxc);
   s.m1 = b.floats(maxc);
   s.m2 = b.floats(maxc);
@@ -383,6 +398,9 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
     s.pw[l] = b.floats((size_t)wgrad_partial_chunks(p.rows, d.width[l], p.kin[l]) * d.width[l] *
                        p.kin[l]);
   s.pw0 = b.floats(pw0);   // (first-layer recompute: its partials, written on the main stream)
+  s.gram = b.floats(p.pool_grad == 2 ? btr_sa_bwd_gram_scratch_floats(
+                                           p.rows, d.width[d.layers - 1], p.kin[d.layers - 1])
+                                     : 0);
   s.g[0] = b.floats((size_t)p.rows * maxk);
   s.g[1] = b.floats((size_t)p.rows * maxk);
   s.scat_bytes = p.compact ? btr_sac_scatter_workspace_bytes(d.b, d.n, p.rows)
@@ -429,10 +447,15 @@ int btr_sa_layer_plan(const btr_sa_layer_t *dp, btr_sa_plan_t *p) {
                      btr_sa_gemm_nt_poolfwd_supported(p->rows, d.width[L - 1],
                                                       p->compact ? 8 : d.s);
   BTR_REQUIRE(!p->compact || p->pool_epilogue, "sa_layer_plan: compact rows without epilogue");
+  // pool_grad == 2: the pooled layer in Gram form (btr_sa_bwd_gram) -- its pre-BN output is
+  // neither stored nor read; y[L-1] then holds the arg-max rows' values only (b, m, width)
+  if (sa_gram_ok(d, *p)) p->pool_grad = 2;
   Bump sv;
   p->x0 = sv.floats((size_t)p->rows * p->k0p);
   for (int l = 0; l < L; ++l) {
-    p->y[l] = sv.floats((p->recompute && l == 0) ? 0 : (size_t)p->rows * d.width[l]);
+    p->y[l] = sv.floats((p->recompute && l == 0) ? 0
+                        : (p->pool_grad == 2 && l == L - 1) ? (size_t)d.b * d.m * d.width[l]
+                                                            : (size_t)p->rows * d.width[l]);
     p->w2[l] = sv.floats((size_t)d.width[l] * p->kin[l]);
     p->wt[l] = sv.floats((size_t)d.width[l] * p->kin[l]);
     p->stats[l] = sv.floats((size_t)4 * d.width[l]);
@@ -558,8 +581,10 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       BTR_TRY(btr_sa_gemm_nt_rc(R, nl, k, x0, at_f(saved, p.w2[0]), w2, k, y, nl, pscale, pshift,
                                 part, stream));
     } else if (l == L - 1 && p.pool_epilogue) {
-      BTR_TRY(btr_sa_gemm_nt_poolfwd(R, nl, k, A, lda, w2, k, y, nl, pscale, pshift, part,
-                                     p.compact ? 8 : d.s, d.gamma[l], extg, exta, stream));
+      // (Gram-form backward: no Y_l -- y then is the (b, m, nl) block of arg-max values below)
+      BTR_TRY(btr_sa_gemm_nt_poolfwd(R, nl, k, A, lda, w2, k, p.pool_grad == 2 ? nullptr : y, nl,
+                                     pscale, pshift, part, p.compact ? 8 : d.s, d.gamma[l], extg,
+                                     exta, stream));
     } else {
       BTR_TRY(btr_sa_gemm_nt(R, nl, k, A, lda, w2, k, y, nl, pscale, pshift, part, stream));
     }
@@ -575,11 +600,13 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   btr_sac_bind(nullptr);
   const int cl = d.width[L - 1];
   unsigned char *arg = at_b(saved, p.arg);
+  float *ywin = p.pool_grad == 2 ? at_f(saved, p.y[L - 1]) : nullptr;
   if (p.compact)
-    BTR_TRY(btr_sac_pool(d.b, d.m, cl, extg, exta, cp.goff, pscale, pshift, out,
-                         out_cl, arg, stream));
+    BTR_TRY(btr_sac_pool_y(d.b, d.m, cl, extg, exta, cp.goff, pscale, pshift, out,
+                           out_cl, arg, ywin, stream));
   else if (p.pool_epilogue)
-    BTR_TRY(btr_sa_pool_fin(d.b, d.m, cl, extg, exta, pscale, pshift, out, out_cl, arg, stream));
+    BTR_TRY(btr_sa_pool_fin_y(d.b, d.m, cl, extg, exta, pscale, pshift, out, out_cl, arg, ywin,
+                              stream));
   else
     BTR_TRY(btr_sa_pool(d.b, d.m, d.s, cl, cl, A, pscale, pshift, out, out_cl, arg, stream));
   return check_launch("sa_layer_forward");
@@ -629,8 +656,9 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
 
   const int cl = d.width[L - 1];
   float *ylast = at_f(saved, p.y[L - 1]);
+  const bool gram = p.pool_grad == 2;   // ylast = the arg-max rows' values (b, m, cl): ldy = 0
   if (p.pool_grad)
-    BTR_TRY(btr_sa_pool_bwd_coef(d.b, d.m, d.s, cl, cl, ylast, dout, out, arg, stat(L - 1, 2),
+    BTR_TRY(btr_sa_pool_bwd_coef(d.b, d.m, d.s, cl, gram ? 0 : cl, ylast, dout, out, arg, stat(L - 1, 2),
                                  stat(L - 1, 3), stat(L - 1, 0), stat(L - 1, 1), part, m1, m2,
                                  grads + p.dgamma[L - 1], grads + p.dbeta[L - 1], dcl, alpha, beta,
                                  stream));
@@ -671,6 +699,20 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
                                             stat(0, 2), stat(0, 3), m1, m2,
                                             at_f(scratch, sc.pw0), grads + p.dw[0], stream));
       break;  // (otherwise finished by btr_sa_bn_relu_bwd_rc below)
+    }
+    if (pooled && gram) {
+      // ---- the pooled layer in Gram form (csrc/sa_mlp.hip sa_bwd_gram_kernel): dW_l, dZ_{l-1}
+      // and BatchNorm_{l-1}'s sums from X_{l-1} alone
+      float *g = at_f(scratch, sc.g[flip]);
+      flip ^= 1;
+      BTR_TRY(btr_sa_bwd_gram(R, nl, k, xsrc, ldx, pa, pb, stat(l - 1, 2), stat(l - 1, 3),
+                              at_f(saved, p.w2[l]), at_f(saved, p.wt[l]), nl, d.s, arg, dcl,
+                              alpha, beta, g, k, at_f(scratch, sc.pw[l]), grads + p.dw[l],
+                              at_f(scratch, sc.gram), part, m1, m2, grads + p.dgamma[l - 1],
+                              grads + p.dbeta[l - 1], stream));
+      dy = g;
+      lazy = true;   // (no split-K reduction left for the join below: the call finished dW_l)
+      continue;
     }
     if (fusable(l) && (pooled || lazy)) {
       // ---- the whole backward of layer l in one pass (csrc/sa_mlp.hip sa_bwd_fused_kernel):

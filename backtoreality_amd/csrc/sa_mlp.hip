@@ -818,7 +818,8 @@ __global__ __launch_bounds__(256) void sa_pool_kernel(int M, int S, int C, int l
 __global__ __launch_bounds__(256) void sa_pool_fin_kernel(
     int M, int C, const float *__restrict__ gext, const unsigned char *__restrict__ aext,
     const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
-    float *__restrict__ out_cl, unsigned char *__restrict__ arg, long long groups) {
+    float *__restrict__ out_cl, unsigned char *__restrict__ arg, long long groups,
+    float *__restrict__ ywin = nullptr) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= groups * C) return;
   const long long g = t / C;
@@ -830,6 +831,7 @@ __global__ __launch_bounds__(256) void sa_pool_fin_kernel(
   out[((size_t)bi * C + c) * M + m] = v;
   if (out_cl) out_cl[t] = v;
   arg[t] = v > 0.f ? aext[t] : (unsigned char)0;
+  if (ywin) ywin[t] = gext[t];   // the pre-BN value behind `out` (only read where out > 0)
 }
 
 // Same with four channels per thread (C % 4 == 0, ldy % 4 == 0): 16-byte loads, four
@@ -986,6 +988,8 @@ __global__ __launch_bounds__(256) void sa_pool_bwd_tile_kernel(
         float y;
         if (fabsf(a) > 1e-20f) {
           y = (ov - shift[c]) / a;
+        } else if (ldy == 0) {   // Y = the arg-max rows' values (btr_sa_pool_fin_y / _sac_pool_y)
+          y = Y[((size_t)bi * M + m) * C + c];
         } else {
           const size_t grp = (size_t)bi * M + m;
           const size_t row = goff ? (size_t)goff[grp] + arg[grp * C + c]
@@ -2658,6 +2662,576 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
   }
 }
 
+// ---- the pooled layer's backward in Gram form --------------------------------------------------
+// sa_bwd_fused_kernel<., 1, .> reads the pooled layer's whole pre-BN output Y_l [rows][n] -- the
+// largest tensor of a set-abstraction level, twice as wide as its input -- to form
+//   dY[r][n] = w_r (alpha[n] Y[r][n] + beta[n]) + sparse[r][n]
+// (sparse: dcl[g][n] on the arg-max row of (group g, channel n); w_r: copies a compact row stands
+// for).  The dense part is AFFINE in Y_l = X W^T, X = relu(bn(Y_{l-1})) [rows][k], so it never
+// has to be formed per element:
+//   dZ_{l-1}[r] = dY[r] W        = w_r (x_r M + c) + sparse[r] W,   M = W^T diag(alpha) W [k][k],
+//                                                                   c = beta^T W [k]
+//   dW_l        = dY^T X         = diag(alpha) W G + beta (x) sx + sparse^T X,
+//                                  G = sum_r w_r x_r x_r^T [k][k],  sx = sum_r w_r x_r [k]
+// Y_l is not read -- and therefore not written by the forward either (sa_fwd_stream_kernel with
+// C == NULL: its pooling epilogue keeps the group extrema; the arg-max row's pre-BN value, the
+// one thing the pooled BatchNorm backward needs of Y_l, is left by the pool kernel: `ywin`).
+// Per row the kernel reads X (k floats) and writes dZ (k floats): 512 B at SA1's 128 x 64 layer
+// instead of 1 024 B here plus 512 B of Y_l written by the forward; the dense products shrink
+// from n x k to k x k per row.  One streaming pass of 32-row steps, laid out like
+// sa_bwd_fused_kernel (bf16x6 planes in LDS, the next rows in flight during the MFMAs):
+//   * X planes hold the layer's WHOLE k extent (k <= 128), swizzled for row and transpose reads;
+//     the first row of a compact group (the only row with w != 1) has a second, weighted copy in
+//     four side rows that the B operand of G and the A operand of x M select per lane;
+//   * the sparse operand is a plane tile that stays zero: the thread that fetched entry (slot,
+//     n) of the step writes its three bf16 pieces, and clears them again behind the MFMAs;
+//   * a wave accumulates  sparse^T X  (its n tiles x the workgroup's 64 k),  G  (its share of the
+//     k x 64 block) and, in ONE accumulator, its half of  sparse W  and of  (w x) M;
+//   * epilogue as in sa_bwd_fused_kernel: the halves meet in LDS, + w_r c, dZ_{l-1} leaves as
+//     16-byte row stores and BatchNorm_{l-1}'s backward sums accumulate on the way.
+// gram_reduce_kernel / gram_finish_kernel turn the per-chunk partials into dW_l (float64 for the
+// dense part: G and sx are sums of ~10^5..10^6 terms whose combination with alpha / beta cancels).
+struct GramArgs {
+  const float *X;      // Y_{l-1} [R][ldx]
+  int ldx;
+  int R, N, K, rows_per_chunk;
+  const float *pa, *pb, *mu_p, *is_p;    // layer l-1: scale, shift, mean, invstd
+  const float *Wt;     // W_l^T [K][ldw]
+  int ldw;
+  const float *M;      // [K][K] = W^T diag(alpha) W (symmetric)
+  const float *cvec;   // [K] = beta^T W
+  float *Z;            // out: dZ_{l-1} [R][ldz]
+  int ldz;
+  float *pw;           // out: [chunk][N][K]  sparse^T X
+  float *gp;           // out: [chunk][K][K]  G partial
+  float *sxp;          // out: [chunk][K]     sx partial
+  float *spart;        // out: [chunk][2][K]  sums for BatchNorm_{l-1}'s backward
+  const unsigned char *garg;
+  const float *gdcl;
+  int SSH, ldt;
+};
+
+__device__ __forceinline__ void split1(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
+  const f32x2 f = {v, 0.f};
+  const bf16x2 bh = __builtin_convertvector(f, bf16x2);
+  const f32x2 r1 = {v - widen2(bh).x, 0.f};
+  const bf16x2 bm = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = {r1.x - widen2(bm).x, 0.f};
+  const bf16x2 bl = __builtin_convertvector(r2, bf16x2);
+  h = bh.x; m = bm.x; l = bl.x;
+}
+
+// 8 consecutive reduction indices of one column out of a swizzled row-major plane (transpose
+// read; lane -> (row trow (+4), 4-column chunk at col), see sa_bwd_fused_kernel)
+__device__ __forceinline__ bf16x8 tr_read8_swz(const __bf16 *plane, int pitch, int trow, int col) {
+  typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+  const __bf16 *b0 = &plane[trow * pitch + (swz(trow, col * 2) >> 1)];
+  const __bf16 *b1 = &plane[(trow + 4) * pitch + (swz(trow + 4, col * 2) >> 1)];
+  union {
+    s16x4 s[2];
+    bf16x8 b;
+  } u;
+  u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b0));
+  u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b1));
+  return u.b;
+}
+
+// TNW = 2 / 4 / 8: n <= 64 / 128 / 256.  KF = 64 / 128: the layer's k extent (one or two 64-wide
+// k blocks; every workgroup stages all of X's columns and owns one block of dZ / G / sparse^T X).
+template <int TNW, int KF>
+__global__ __launch_bounds__(256, (TNW == 8 || KF == 128) ? 1 : 2) void sa_bwd_gram_kernel(
+    GramArgs a, Compact cm) {
+  constexpr int BR = 32;
+  constexpr int TN = 32 * TNW;
+  constexpr int LG = TN == 256 ? 288 : (TN == 128 ? 160 : 96);   // sparse planes (bf16 pitch)
+  constexpr int LXF = KF == 128 ? 160 : 96;                       // X planes
+  constexpr int LXW = KF + 8;                                     // weighted side rows
+  constexpr int LC = 68;
+  constexpr int KT = TNW >= 4 ? 2 : 1;
+  constexpr int NTW = TNW >= 4 ? TNW / 4 : 1;
+  constexpr int KB = KF / 64;          // k blocks staged
+  constexpr int GT = KF / 64;          // G tiles (32 x 32) per wave
+  int R = a.R, rows_per_chunk = a.rows_per_chunk;
+  if (cm.dims) {
+    R = cm.dims[0];
+    rows_per_chunk = ((R + (int)gridDim.z - 1) / (int)gridDim.z + 31) / 32 * 32;
+  }
+  const int N = a.N, K = a.K;
+  __shared__ __attribute__((aligned(16))) __bf16 Sp[3 * BR * LG];
+  __shared__ __attribute__((aligned(16))) __bf16 Xp[3 * BR * LXF];
+  __shared__ __attribute__((aligned(16))) __bf16 Xw[3 * 4 * LXW];
+  __shared__ __attribute__((aligned(16))) float Cs[2 * BR * LC];
+  // per-column coefficients of layer l-1 (scale, shift of every staged column; mean, invstd and c
+  // of the workgroup's own block): read back 16 bytes at a time where they are used -- as
+  // registers they cost the 128 x 64 variant its second workgroup per CU
+  __shared__ __attribute__((aligned(16))) float Cf[2 * KF + 3 * 64];
+  // (the raw pre-BN values of the own block, from the staging to the epilogue of a step)
+  __shared__ __attribute__((aligned(16))) float Yk[2 * 256 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = TNW >= 4 ? wave * NTW : (wave >> 1);
+  const int wk = TNW >= 4 ? 0 : (wave & 1);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int k0 = blockIdx.y * 64;
+  const int chunk = blockIdx.z;
+  const int rbeg = chunk * rows_per_chunk;
+  const int rend = min(R, rbeg + rows_per_chunk);
+  const float *__restrict__ X = a.X;
+  const bool cmw = cm.bw != nullptr;   // compact rows: rows = 0 (mod 8) carry a weight
+  for (int i = tid; i < 2 * KF + 3 * 64; i += 256) {
+    float v = 0.f;
+    if (i < 2 * KF) {
+      const int c = i % KF;
+      if (c < K) v = (i < KF ? a.pa : a.pb)[c];
+    } else {
+      const int j = i - 2 * KF, c = k0 + (j & 63);
+      if (c < K) v = (j < 64 ? a.mu_p : (j < 128 ? a.is_p : a.cvec))[c];
+    }
+    Cf[i] = v;
+  }
+
+  // ---- zero the sparse planes once (entries are written and cleared step by step)
+  for (int i = tid; i < 3 * BR * LG / 8; i += 256)
+    reinterpret_cast<float4 *>(Sp)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- resident B operands of the two input-gradient products of this wave: (k half dj of the
+  // block, reduction half dnh): W_l^T rows for the sparse part, M rows for the dense part
+  const int dj = wave & 1, dnh = wave >> 1;
+  bf16x8 bdr[TN / 32][3], mdr[KF / 32][3];
+  {
+    const int kr = k0 + dj * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < TN / 32; ++kk) {
+      const int nb = (dnh * (TN / 32) + kk) * 16 + (lane >> 5) * 8;
+      float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+      if (kr < K && nb < N) w0 = *reinterpret_cast<const float4 *>(a.Wt + (size_t)kr * a.ldw + nb);
+      if (kr < K && nb + 4 < N)
+        w1 = *reinterpret_cast<const float4 *>(a.Wt + (size_t)kr * a.ldw + nb + 4);
+      const Split4 s0 = split4(w0), s1 = split4(w1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bdr[kk][0][e] = s0.h[e]; bdr[kk][0][4 + e] = s1.h[e];
+        bdr[kk][1][e] = s0.m[e]; bdr[kk][1][4 + e] = s1.m[e];
+        bdr[kk][2][e] = s0.l[e]; bdr[kk][2][4 + e] = s1.l[e];
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KF / 32; ++kk) {
+      const int xb = (dnh * (KF / 32) + kk) * 16 + (lane >> 5) * 8;   // reduction index: x column
+      float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+      if (kr < K && xb < K) w0 = *reinterpret_cast<const float4 *>(a.M + (size_t)kr * K + xb);
+      if (kr < K && xb + 4 < K) w1 = *reinterpret_cast<const float4 *>(a.M + (size_t)kr * K + xb + 4);
+      const Split4 s0 = split4(w0), s1 = split4(w1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mdr[kk][0][e] = s0.h[e]; mdr[kk][0][4 + e] = s1.h[e];
+        mdr[kk][1][e] = s0.m[e]; mdr[kk][1][4 + e] = s1.m[e];
+        mdr[kk][2][e] = s0.l[e]; mdr[kk][2][4 + e] = s1.l[e];
+      }
+    }
+  }
+
+  f32x16 acc[NTW][KT], gacc[GT];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int q = 0; q < KT; ++q)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[t][q][v] = 0.f;
+#pragma unroll
+  for (int t = 0; t < GT; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) gacc[t][v] = 0.f;
+
+  // ---- staging: thread -> rows xr, xr + 16, columns kcol(b) .. + 3 of every k block b (b = 0: the
+  // workgroup's own block, whose dZ columns the thread owns in the epilogue)
+  const int xc4 = (tid & 15) * 4, xr = tid >> 4;
+  auto kcol = [&](int b) { return (b == 0 ? k0 : (k0 ^ 64)) + xc4; };
+  auto cf4 = [&](int at) { return *reinterpret_cast<const float4 *>(&Cf[at]); };
+  float4 rx[KB][2];
+  float wx[2] = {1.f, 1.f};
+  const int sp_gi = tid / TN, sp_n = tid % TN;
+  constexpr int SPQ = 4 * TN / 256;
+  int sp_g[SPQ], sp_ng[SPQ], sp_lr[SPQ], cl_lr[SPQ];
+  float sp_dv[SPQ];
+#pragma unroll
+  for (int q = 0; q < SPQ; ++q) {
+    sp_g[q] = sp_ng[q] = 0;
+    sp_lr[q] = cl_lr[q] = -1;
+    sp_dv[q] = 0.f;
+  }
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = xr + 16 * p;
+      wx[p] = 1.f;
+      if (cmw && (row & 7) == 0 && r0 + row < rend) wx[p] = cm.bw[(r0 + row) >> 3];
+#pragma unroll
+      for (int b = 0; b < KB; ++b) {
+        rx[b][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + row < rend && kcol(b) < K)
+          rx[b][p] = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * a.ldx + kcol(b));
+      }
+    }
+    if (cm.bgrp) {
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q, blk = (r0 >> 3) + slot;
+        if (r0 != rbeg) sp_g[q] = sp_ng[q];
+        sp_lr[q] = -1;
+        if (slot < 4 && (blk << 3) < rend && sp_n < N) {
+          const int g = sp_g[q];
+          const int lr = cm.goff[g] - r0 + (int)a.garg[(size_t)g * a.ldt + sp_n];
+          sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
+          sp_lr[q] = (lr >= 0 && (lr >> 3) == slot) ? lr : -1;
+        }
+        const int nblk = ((r0 + BR) >> 3) + slot;
+        sp_ng[q] = (slot < 4 && (nblk << 3) < rend) ? cm.bgrp[nblk] : 0;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q;
+        const int g = (r0 >> a.SSH) + slot;
+        sp_lr[q] = -1;
+        if ((slot << a.SSH) < BR && (g << a.SSH) < rend && sp_n < N) {
+          const int arow = (g << a.SSH) + (int)a.garg[(size_t)g * a.ldt + sp_n];
+          sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
+          const int lr = arow - r0;
+          sp_lr[q] = (lr >= 0 && lr < BR && arow < rend) ? lr : -1;
+        }
+      }
+    }
+  };
+  if (cm.bgrp && rbeg < rend) {
+#pragma unroll
+    for (int q = 0; q < SPQ; ++q) {
+      const int slot = sp_gi + (256 / TN) * q, blk = (rbeg >> 3) + slot;
+      sp_g[q] = (slot < 4 && (blk << 3) < rend) ? cm.bgrp[blk] : 0;
+    }
+  }
+  const int p16 = lane & 15, grp = lane >> 4;
+  const int frow = 8 * (grp >> 1) + (p16 >> 2), fcol = 16 * (grp & 1) + 4 * (p16 & 3);
+  const bool wlane_tr = cmw && (p16 >> 2) == 0;   // transpose reads: this lane's first row is 0 (mod 8)
+  const bool wlane_row = cmw && (l31 & 7) == 0;   // row reads: this lane's row
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, sxa = s1;
+  if (rbeg < rend) fetch(rbeg);
+  __syncthreads();   // (the zeroed sparse planes)
+  for (int r0 = rbeg; r0 < rend; r0 += BR) {
+    // ---- sparse entries of this step: the three pieces of dcl at [local row][n]
+#pragma unroll
+    for (int q = 0; q < SPQ; ++q) {
+      cl_lr[q] = sp_lr[q];
+      if (sp_lr[q] >= 0) {
+        __bf16 eh, em, el;
+        split1(sp_dv[q], eh, em, el);
+        const int at = sp_lr[q] * LG + (swz(sp_lr[q], sp_n * 2) >> 1);
+        Sp[0 * BR * LG + at] = eh;
+        Sp[1 * BR * LG + at] = em;
+        Sp[2 * BR * LG + at] = el;
+      }
+    }
+    // ---- X = relu(bn(Y_{l-1})): planes, weighted side rows, column sums
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = xr + 16 * p;
+#pragma unroll
+      for (int b = 0; b < KB; ++b) {
+        float4 x = rx[b][p];
+        const bool live = r0 + row < rend && kcol(b) < K;
+        // the raw pre-BN values of layer l-1: the epilogue's mask / xhat
+        if (b == 0) *reinterpret_cast<float4 *>(&Yk[(p * 256 + tid) * 4]) = x;
+        if (live) {
+          const float4 fab = cf4(kcol(b)), fbb = cf4(KF + kcol(b));
+          x.x = fmaxf(fmaf(fab.x, x.x, fbb.x), 0.f);
+          x.y = fmaxf(fmaf(fab.y, x.y, fbb.y), 0.f);
+          x.z = fmaxf(fmaf(fab.z, x.z, fbb.z), 0.f);
+          x.w = fmaxf(fmaf(fab.w, x.w, fbb.w), 0.f);
+        } else {
+          x = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const Split4 sp = split4(x);
+        const int at = row * LXF + (swz(row, kcol(b) * 2) >> 1);
+        *reinterpret_cast<bf16x4 *>(&Xp[0 * BR * LXF + at]) = sp.h;
+        *reinterpret_cast<bf16x4 *>(&Xp[1 * BR * LXF + at]) = sp.m;
+        *reinterpret_cast<bf16x4 *>(&Xp[2 * BR * LXF + at]) = sp.l;
+        const float w = wx[p];
+        if (b == 0) {
+          sxa.x = fmaf(w, x.x, sxa.x); sxa.y = fmaf(w, x.y, sxa.y);
+          sxa.z = fmaf(w, x.z, sxa.z); sxa.w = fmaf(w, x.w, sxa.w);
+        }
+        if (cmw && (row & 7) == 0) {
+          const Split4 sw = split4(make_float4(w * x.x, w * x.y, w * x.z, w * x.w));
+          const int aw = (row >> 3) * LXW + kcol(b);
+          *reinterpret_cast<bf16x4 *>(&Xw[0 * 4 * LXW + aw]) = sw.h;
+          *reinterpret_cast<bf16x4 *>(&Xw[1 * 4 * LXW + aw]) = sw.m;
+          *reinterpret_cast<bf16x4 *>(&Xw[2 * 4 * LXW + aw]) = sw.l;
+        }
+      }
+    }
+    const float wrow0 = wx[0], wrow1 = wx[1];   // (the fetch below overwrites wx)
+    __syncthreads();
+    if (r0 + BR < rend) fetch(r0 + BR);  // next rows in flight during the MFMAs
+    // ---- sparse^T X and G: reductions over the 32 rows (transpose reads).  Two passes, so that
+    // the fragments of one product are dead before the other's are loaded (register budget)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int trow = ks * 16 + frow;
+      {
+        bf16x8 af[3][NTW];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t)
+            af[q][t] = tr_read8_swz(&Sp[q * BR * LG], LG, trow, (wn + t) * 32 + fcol);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {   // (one k tile's fragments at a time)
+          bf16x8 bf[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            bf[q] = tr_read8_swz(&Xp[q * BR * LXF], LXF, trow, k0 + (wk + t) * 32 + fcol);
+#define BTR_X6(QA, QB)                            \
+  _Pragma("unroll") for (int u = 0; u < NTW; ++u) \
+      acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA][u], bf[QB], acc[u][t], 0, 0, 0);
+          BTR_X6(2, 0)
+          BTR_X6(0, 2)
+          BTR_X6(1, 1)
+          BTR_X6(1, 0)
+          BTR_X6(0, 1)
+          BTR_X6(0, 0)
+#undef BTR_X6
+        }
+      }
+      {
+        bf16x8 ga[3][GT], gb[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+          for (int t = 0; t < GT; ++t)
+            ga[q][t] =
+                tr_read8_swz(&Xp[q * BR * LXF], LXF, trow, ((wave >> 1) * GT + t) * 32 + fcol);
+          // B operand of G: weighted rows from the side planes
+          typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+          const int col = k0 + (wave & 1) * 32 + fcol;
+          const __bf16 *b0 = wlane_tr ? &Xw[(q * 4 + (trow >> 3)) * LXW + col]
+                                      : &Xp[(q * BR + trow) * LXF + (swz(trow, col * 2) >> 1)];
+          const __bf16 *b1 = &Xp[(q * BR + trow + 4) * LXF + (swz(trow + 4, col * 2) >> 1)];
+          union {
+            s16x4 s[2];
+            bf16x8 b;
+          } u;
+          u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b0));
+          u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b1));
+          gb[q] = u.b;
+        }
+#define BTR_X6(QA, QB)                           \
+  _Pragma("unroll") for (int t = 0; t < GT; ++t) \
+      gacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[QA][t], gb[QB], gacc[t], 0, 0, 0);
+        BTR_X6(2, 0)
+        BTR_X6(0, 2)
+        BTR_X6(1, 1)
+        BTR_X6(1, 0)
+        BTR_X6(0, 1)
+        BTR_X6(0, 0)
+#undef BTR_X6
+      }
+    }
+    // ---- input gradient: C[32 rows][32 k of half dj] = sparse W (n half dnh) + (w x) M (x half dnh)
+    {
+      f32x16 cd;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) cd[v] = 0.f;
+#define BTR_X6D(B) \
+      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[2], (B)[0], cd, 0, 0, 0); \
+      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[0], (B)[2], cd, 0, 0, 0); \
+      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[1], (B)[1], cd, 0, 0, 0); \
+      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[1], (B)[0], cd, 0, 0, 0); \
+      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[0], (B)[1], cd, 0, 0, 0); \
+      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[0], (B)[0], cd, 0, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < TN / 32; ++kk) {
+        const int nb = (dnh * (TN / 32) + kk) * 16 + h * 8;   // first of this lane's 8 n
+        bf16x8 ad[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          ad[q] = *reinterpret_cast<const bf16x8 *>(
+              &Sp[(q * BR + l31) * LG + (swz(l31, nb * 2) >> 1)]);
+        BTR_X6D(bdr[kk])
+      }
+#pragma unroll
+      for (int kk = 0; kk < KF / 32; ++kk) {
+        const int xb = (dnh * (KF / 32) + kk) * 16 + h * 8;   // first of this lane's 8 x columns
+        bf16x8 ad[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          ad[q] = *reinterpret_cast<const bf16x8 *>(
+              wlane_row ? &Xw[(q * 4 + (l31 >> 3)) * LXW + xb]
+                        : &Xp[(q * BR + l31) * LXF + (swz(l31, xb * 2) >> 1)]);
+        BTR_X6D(mdr[kk])
+      }
+#undef BTR_X6D
+      float *T = Cs + dnh * (BR * LC);
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+        T[((v & 3) + 8 * (v >> 2) + 4 * h) * LC + dj * 32 + l31] = cd[v];
+    }
+    __syncthreads();
+    // ---- epilogue: the thread that staged X[row][k0 + xc4..] owns dZ[row][k0 + xc4..]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = xr + 16 * p;
+      if (r0 + row < rend && k0 + xc4 < K) {
+        const float wr = p == 0 ? wrow0 : wrow1;
+        const float4 c0 = *reinterpret_cast<const float4 *>(&Cs[row * LC + xc4]);
+        const float4 c1 = *reinterpret_cast<const float4 *>(&Cs[BR * LC + row * LC + xc4]);
+        const float4 cv = cf4(2 * KF + 128 + xc4), fmu = cf4(2 * KF + xc4);
+        const float4 fis = cf4(2 * KF + 64 + xc4);
+        const float4 fa0 = cf4(k0 + xc4), fb0 = cf4(KF + k0 + xc4);
+        const float4 c = make_float4(fmaf(wr, cv.x, c0.x + c1.x), fmaf(wr, cv.y, c0.y + c1.y),
+                                     fmaf(wr, cv.z, c0.z + c1.z), fmaf(wr, cv.w, c0.w + c1.w));
+        *reinterpret_cast<float4 *>(a.Z + (size_t)(r0 + row) * a.ldz + k0 + xc4) = c;
+        const float4 y = *reinterpret_cast<const float4 *>(&Yk[(p * 256 + tid) * 4]);
+        const float gx = fmaf(fa0.x, y.x, fb0.x) > 0.f ? c.x : 0.f;
+        const float gy = fmaf(fa0.y, y.y, fb0.y) > 0.f ? c.y : 0.f;
+        const float gz = fmaf(fa0.z, y.z, fb0.z) > 0.f ? c.z : 0.f;
+        const float gw = fmaf(fa0.w, y.w, fb0.w) > 0.f ? c.w : 0.f;
+        s1.x += gx; s1.y += gy; s1.z += gz; s1.w += gw;
+        s2.x = fmaf(gx, (y.x - fmu.x) * fis.x, s2.x);
+        s2.y = fmaf(gy, (y.y - fmu.y) * fis.y, s2.y);
+        s2.z = fmaf(gz, (y.z - fmu.z) * fis.z, s2.z);
+        s2.w = fmaf(gw, (y.w - fmu.w) * fis.w, s2.w);
+      }
+    }
+    // ---- the sparse planes go back to zero (every wave is past its MFMA reads: the barrier above)
+#pragma unroll
+    for (int q = 0; q < SPQ; ++q)
+      if (cl_lr[q] >= 0) {
+        const int at = cl_lr[q] * LG + (swz(cl_lr[q], sp_n * 2) >> 1);
+        const __bf16 z = (__bf16)0.f;
+        Sp[0 * BR * LG + at] = z;
+        Sp[1 * BR * LG + at] = z;
+        Sp[2 * BR * LG + at] = z;
+      }
+  }
+  // ---- partials of this chunk: sparse^T X
+  {
+    float *out = a.pw + (size_t)chunk * N * K;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int q = 0; q < KT; ++q) {
+        const int col = k0 + (wk + q) * 32 + l31;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = (wn + t) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          if (row < N && col < K) out[(size_t)row * K + col] = acc[t][q][v];
+        }
+      }
+  }
+  // ---- ... G block [K][64 of this workgroup]
+  {
+    float *out = a.gp + (size_t)chunk * K * K;
+    const int col = k0 + (wave & 1) * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < GT; ++t)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = ((wave >> 1) * GT + t) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (row < K && col < K) out[(size_t)row * K + col] = gacc[t][v];
+      }
+  }
+  // ---- ... and the column sums: 16 row-threads per k column group, fixed order
+  __syncthreads();
+  float *red = Cs;   // [3][16 row threads][64 k]
+  *reinterpret_cast<float4 *>(&red[(0 * 16 + xr) * 64 + xc4]) = s1;
+  *reinterpret_cast<float4 *>(&red[(1 * 16 + xr) * 64 + xc4]) = s2;
+  *reinterpret_cast<float4 *>(&red[(2 * 16 + xr) * 64 + xc4]) = sxa;
+  __syncthreads();
+  if (tid < 192) {
+    const int which = tid >> 6, c = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[(which * 16 + q) * 64 + c];
+    if (k0 + c < K) {
+      if (which < 2) a.spart[((size_t)chunk * 2 + which) * K + k0 + c] = t;
+      else a.sxp[(size_t)chunk * K + k0 + c] = t;
+    }
+  }
+}
+
+// M = W^T diag(alpha) W and c = beta^T W of the Gram-form backward, from Wt = W^T [K][ldw]:
+// thread (i, j) of a 16 x 16 tile; float64 accumulation (alpha changes sign across channels).
+__global__ __launch_bounds__(256) void gram_prep_kernel(int N, int K, const float *__restrict__ Wt,
+                                                        int ldw, const float *__restrict__ alpha,
+                                                        const float *__restrict__ beta,
+                                                        float *__restrict__ M,
+                                                        float *__restrict__ cvec) {
+  __shared__ float Wi[16][65], Wj[16][65], Al[64], Be[64];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  double m = 0.0, c = 0.0;
+  for (int n0 = 0; n0 < N; n0 += 64) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int r = e >> 6, n = n0 + (e & 63);
+      Wi[r][e & 63] = (i0 + r < K && n < N) ? Wt[(size_t)(i0 + r) * ldw + n] : 0.f;
+      Wj[r][e & 63] = (j0 + r < K && n < N) ? Wt[(size_t)(j0 + r) * ldw + n] : 0.f;
+    }
+    if (threadIdx.x < 64) {
+      const int n = n0 + threadIdx.x;
+      Al[threadIdx.x] = n < N ? alpha[n] : 0.f;
+      Be[threadIdx.x] = n < N ? beta[n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int n = 0; n < 64; ++n) {
+      m += (double)Al[n] * (double)Wi[ty][n] * (double)Wj[tx][n];
+      if (blockIdx.x == 0 && tx == 0) c += (double)Be[n] * (double)Wi[ty][n];
+    }
+    __syncthreads();
+  }
+  if (i0 + ty < K && j0 + tx < K) M[(size_t)(i0 + ty) * K + j0 + tx] = (float)m;
+  if (blockIdx.x == 0 && tx == 0 && i0 + ty < K) cvec[i0 + ty] = (float)c;
+}
+
+// G64[i][j] = sum over chunks of gp[chunk][i][j]; sx64[k] likewise (float64, fixed order)
+__global__ __launch_bounds__(256) void gram_reduce_kernel(int K, int chunks,
+                                                          const float *__restrict__ gp,
+                                                          const float *__restrict__ sxp,
+                                                          double *__restrict__ G64,
+                                                          double *__restrict__ sx64) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int total = K * K;
+  if (i < total) {
+    double s = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < chunks; ++c) s += (double)gp[(size_t)c * total + i];
+    G64[i] = s;
+  } else if (i < total + K) {
+    const int k = i - total;
+    double s = 0.0;
+    for (int c = 0; c < chunks; ++c) s += (double)sxp[(size_t)c * K + k];
+    sx64[k] = s;
+  }
+}
+
+// dW[n][k] = sum over chunks of pw[chunk][n][k]  +  alpha[n] sum_j W[n][j] G[j][k]  +  beta[n] sx[k]
+// (w = W_l [N][K] row-major).  Thread per (n, k), lanes along k.
+__global__ __launch_bounds__(256) void gram_finish_kernel(
+    int N, int K, int chunks, const float *__restrict__ pw, const float *__restrict__ w,
+    const float *__restrict__ alpha, const float *__restrict__ beta,
+    const double *__restrict__ G64, const double *__restrict__ sx64, float *__restrict__ dw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * K) return;
+  const int n = i / K, k = i - n * K;
+  double s = 0.0;
+#pragma unroll 8
+  for (int c = 0; c < chunks; ++c) s += (double)pw[(size_t)c * N * K + i];
+  double d = 0.0;
+  const float *wr = w + (size_t)n * K;
+#pragma unroll 8
+  for (int j = 0; j < K; ++j) d += (double)wr[j] * G64[(size_t)j * K + k];
+  dw[i] = (float)(s + (double)alpha[n] * d + (double)beta[n] * sx64[k]);
+}
+
 // dw[i] = sum over chunks of pw[chunk][i], fixed order; EL elements x SL chunk slices per block
 // (4 x 64 for the small weight matrices, whose launches are latency-bound; 16 x 16 keeps the
 // reads of the large ones coalesced).
@@ -3228,19 +3802,22 @@ __global__ __launch_bounds__(256) void sac_pool_kernel(
     int M, int C, long long groups, const float *__restrict__ gext,
     const unsigned char *__restrict__ aext, const int *__restrict__ goff,
     const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
-    float *__restrict__ out_cl, unsigned char *__restrict__ arg) {
+    float *__restrict__ out_cl, unsigned char *__restrict__ arg,
+    float *__restrict__ ywin = nullptr) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= groups * C) return;
   const long long g = t / C;
   const int c = (int)(t - g * C);
   const int b0 = goff[g] >> 3, b1 = goff[g + 1] >> 3;
   const float a = scale[c], b = shift[c];
-  float best = -1.f;
+  float best = -1.f, by = 0.f;
   int ba = 0;
   for (int blk = b0; blk < b1; ++blk) {
-    const float v = fmaxf(fmaf(a, gext[(size_t)blk * C + c], b), 0.f);
+    const float e = gext[(size_t)blk * C + c];
+    const float v = fmaxf(fmaf(a, e, b), 0.f);
     if (v > best) {
       best = v;
+      by = e;
       ba = ((blk - b0) << 3) + aext[(size_t)blk * C + c];
     }
   }
@@ -3249,6 +3826,7 @@ __global__ __launch_bounds__(256) void sac_pool_kernel(
   out[((size_t)bi * C + c) * M + m] = best;
   if (out_cl) out_cl[t] = best;
   arg[t] = best > 0.f ? (unsigned char)ba : (unsigned char)0;
+  if (ywin) ywin[t] = by;   // the pre-BN value behind `out` (only read where out > 0)
 }
 
 // The same two pools (goff != nullptr: per-block extrema of compact rows; nullptr: one extremum per
@@ -3260,7 +3838,7 @@ __global__ __launch_bounds__(256) void sa_pool_tile_kernel(
     int M, int C, const float *__restrict__ gext, const unsigned char *__restrict__ aext,
     const int *__restrict__ goff, const float *__restrict__ scale,
     const float *__restrict__ shift, float *__restrict__ out, float *__restrict__ out_cl,
-    unsigned char *__restrict__ arg) {
+    unsigned char *__restrict__ arg, float *__restrict__ ywin = nullptr) {
   __shared__ float T[32 * 33];
   const int c = (int)blockIdx.y * 32 + (threadIdx.x & 31), jj = threadIdx.x >> 5;
   const long long g0 = (long long)blockIdx.x * 32;
@@ -3270,24 +3848,28 @@ __global__ __launch_bounds__(256) void sa_pool_tile_kernel(
   for (int i = 0; i < 4; ++i) {
     const int j = jj + 8 * i;
     const long long g = g0 + j;
-    float best = -1.f;
+    float best = -1.f, by = 0.f;
     int ba = 0;
     if (live) {
       if (goff) {
         const int b0 = goff[g] >> 3, b1 = goff[g + 1] >> 3;
         for (int blk = b0; blk < b1; ++blk) {
-          const float v = fmaxf(fmaf(a, gext[(size_t)blk * C + c], b), 0.f);
+          const float e = gext[(size_t)blk * C + c];
+          const float v = fmaxf(fmaf(a, e, b), 0.f);
           if (v > best) {
             best = v;
+            by = e;
             ba = ((blk - b0) << 3) + aext[(size_t)blk * C + c];
           }
         }
       } else {
-        best = fmaxf(fmaf(a, gext[(size_t)g * C + c], b), 0.f);
+        by = gext[(size_t)g * C + c];
+        best = fmaxf(fmaf(a, by, b), 0.f);
         ba = aext[(size_t)g * C + c];
       }
       if (out_cl) out_cl[(size_t)g * C + c] = best;
       arg[(size_t)g * C + c] = best > 0.f ? (unsigned char)ba : (unsigned char)0;
+      if (ywin) ywin[(size_t)g * C + c] = by;   // the pre-BN value behind `out`
     }
     T[(threadIdx.x & 31) * 33 + j] = best;
   }
@@ -3744,12 +4326,20 @@ int btr_sa_bn_finalize(int n, int nblk, double count, float eps, float momentum,
                           invstd, running_mean, running_var, nullptr, 0, as_stream(stream));
 }
 
+// c == NULL is accepted by btr_sa_gemm_nt_poolfwd exactly when this returns 1 (s: 8 for compact
+// rows' block extrema, else the group size; no in-kernel BatchNorm finalisation armed)
+int btr_sa_gemm_nt_poolfwd_nostore_supported(int rows, int n, int k, int s) {
+  if (!(s == 8 || (s == 16 && stream_wide())) || !stream_ok(rows, n, k, true, false)) return 0;
+  if (n <= 64) return 0;            // (the instantiated streaming variants: try_stream)
+  return s == 8 ? 1 : (k > 64 ? 1 : 0);
+}
+
 int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, const float *w,
                            int ldw, float *c, int ldc, const float *pa, const float *pb,
                            float *part, int s, const float *gamma, float *gext,
                            unsigned char *aext, btr_stream_t stream) {
   if (rows <= 0 || n <= 0) return BTR_OK;
-  BTR_REQUIRE(a && w && c && part && pa && pb && gamma && gext && aext && k > 0 &&
+  BTR_REQUIRE(a && w && part && pa && pb && gamma && gext && aext && k > 0 &&
                   k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt_poolfwd: null pointer or k=%d lda=%d ldw=%d not multiples of 4", k,
               lda, ldw);
@@ -3762,6 +4352,9 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
       try_stream(rows, n, k, a, lda, w, ldw, c, ldc, pa, pb, nullptr, part, s, gamma, gext, aext, 1,
                  st))
     return check_launch("sa_gemm_nt_poolfwd(stream)");
+  // c == NULL (statistics + extrema only, the Gram-form backward needs no Y_l): the streaming
+  // kernel's option -- btr_sa_gemm_nt_poolfwd_nostore_supported() says when it runs
+  BTR_REQUIRE(c, "sa_gemm_nt_poolfwd: no output matrix outside the streaming kernel's shapes");
 #define BTR_GEMM_MM(PS, MM)                                                                   \
   hipLaunchKernelGGL((gemm_nt_kernel<128, 1, true, PS, kBM, false, MM>), dim3(gx, cdiv(n, 128)), \
                      dim3(256), 0, st, a, lda, w, ldw, c, ldc, rows, n, k, pa, pb, part,        \
@@ -3788,21 +4381,28 @@ static bool pool_tiled(int m) {
   return m % 32 == 0 && !(e && e[0] == '0');
 }
 
-int btr_sa_pool_fin(int b, int m, int c, const float *gext, const unsigned char *aext,
-                    const float *scale, const float *shift, float *out, float *out_cl,
-                    unsigned char *arg, btr_stream_t stream) {
+// ywin (b, m, c) or NULL: the pre-BN value of the arg-max row -- what the pooled BatchNorm's
+// backward needs of Y_l when the forward did not store it (btr_sa_pool_bwd_coef with ldy == 0)
+int btr_sa_pool_fin_y(int b, int m, int c, const float *gext, const unsigned char *aext,
+                      const float *scale, const float *shift, float *out, float *out_cl,
+                      unsigned char *arg, float *ywin, btr_stream_t stream) {
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(gext && aext && scale && shift && out && arg, "sa_pool_fin: null pointer");
   if (pool_tiled(m))
     hipLaunchKernelGGL(sa_pool_tile_kernel, dim3((unsigned)(groups / 32), cdiv(c, 32)), dim3(256),
                        0, as_stream(stream), m, c, gext, aext, (const int *)nullptr, scale, shift,
-                       out, out_cl, arg);
+                       out, out_cl, arg, ywin);
   else
     hipLaunchKernelGGL(sa_pool_fin_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
                        as_stream(stream), m, c, gext, aext, scale, shift, out, out_cl, arg,
-                       groups);
+                       groups, ywin);
   return check_launch("sa_pool_fin");
+}
+int btr_sa_pool_fin(int b, int m, int c, const float *gext, const unsigned char *aext,
+                    const float *scale, const float *shift, float *out, float *out_cl,
+                    unsigned char *arg, btr_stream_t stream) {
+  return btr_sa_pool_fin_y(b, m, c, gext, aext, scale, shift, out, out_cl, arg, nullptr, stream);
 }
 
 int btr_sa_pool(int b, int m, int s, int c, int ldy, const float *y, const float *scale,
@@ -3852,6 +4452,9 @@ int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, co
   if (groups <= 0 || c <= 0) return BTR_OK;
   hipStream_t st = as_stream(stream);
   const long long tiles = (long long)b * cdiv(m, 64);
+  // ldy == 0: y holds only the arg-max rows' values (b, m, c) -- the tile kernel's operand
+  BTR_REQUIRE(ldy != 0 || (shift != nullptr && tiles <= 1024 && c % 4 == 0 && b < 65536),
+              "sa_pool_bwd_coef: arg-max values instead of Y only for c %% 4 == 0, <= 1024 tiles");
   if (shift != nullptr && tiles <= 1024 && c % 4 == 0 && b < 65536) {
     hipLaunchKernelGGL(sa_pool_bwd_tile_kernel, dim3(cdiv(m, 64), cdiv(c, 16), b), dim3(256), 0,
                        st, m, s, c, ldy, y, dout, out, arg, mean, invstd, scale, shift, part, dcl,
@@ -4234,6 +4837,78 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
   return check_launch("sa_bwd_fused");
 }
 
+// ---- the pooled layer's backward in Gram form (sa_bwd_gram_kernel): Y_l is not an operand ----
+//   dz [rows][k] = w_r (x_r M + c) + sparse_r W_l,  dw [n][k] = diag(alpha) W_l G + beta (x) sx +
+//   sparse^T X,  m1 / m2 / dgamma / dbeta of BatchNorm_{l-1};  X = relu(pa * x + pb), x [rows][ldx].
+// w = W_l [n][k] (row-major, leading dimension k), wt = W_l^T [k][ldw]; arg / dcl / alpha / beta:
+// what btr_sa_pool_bwd_coef left.  pw: [btr_sa_bwd_gram_chunks()][n][k] floats, gscratch:
+// btr_sa_bwd_gram_scratch_floats() floats, spart: [chunks][2][k].
+int btr_sa_bwd_gram_supported(int rows, int n, int k) {
+  const char *e = getenv("BTR_POOL_GRAM");   // (read per call: the tests toggle it)
+  const bool off = e && e[0] == '0';
+  return !off && btr_sa_bwd_fused_supported(rows, n, k) && k <= 128 && !fused_split(n);
+}
+static int gram_chunks(int rows, int n, int k) {
+  const int per_cu = (n > 128 || k > 64) ? 1 : 2;
+  const int resident = cu_mask_avail_cus() * per_cu * grid_rounds();
+  const int kblocks = (k + 63) / 64;
+  const int want = std::max(32, resident / kblocks);
+  return std::max(1, std::min(std::min(want, kFusedMaxChunks * grid_rounds()), cdiv(rows, 32)));
+}
+int btr_sa_bwd_gram_chunks(int rows, int n, int k) { return gram_chunks(rows, n, k); }
+size_t btr_sa_bwd_gram_scratch_floats(int rows, int n, int k) {
+  const size_t kk = (size_t)k * k, ch = (size_t)gram_chunks(rows, n, k);
+  // M, c | G partials, sx partials | G, sx in float64
+  return kk + k + ch * (kk + k) + 2 * (kk + k) + 8;
+}
+
+int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float *pa,
+                    const float *pb, const float *mu_p, const float *is_p, const float *w,
+                    const float *wt, int ldw, int s, const unsigned char *arg, const float *dcl,
+                    const float *alpha, const float *beta, float *dz, int ldz, float *pw,
+                    float *dw, float *gscratch, float *spart, float *m1, float *m2,
+                    float *dgamma, float *dbeta, btr_stream_t stream) {
+  BTR_REQUIRE(btr_sa_bwd_gram_supported(rows, n, k), "sa_bwd_gram: shape %d x %d x %d", rows, n, k);
+  BTR_REQUIRE(x && pa && pb && mu_p && is_p && w && wt && arg && dcl && alpha && beta && dz &&
+                  pw && dw && gscratch && spart && m1 && m2 && dgamma && dbeta &&
+                  ldx % 4 == 0 && ldw % 4 == 0 && ldz % 4 == 0 && s > 0,
+              "sa_bwd_gram: null pointer or unaligned leading dimension");
+  BTR_REQUIRE(host_compact().on || s == 16 || s == 32 || s == 64 || s == 128,
+              "sa_bwd_gram: nsample %d must be 16, 32, 64 or 128", s);
+  hipStream_t st = as_stream(stream);
+  const int chunks = gram_chunks(rows, n, k);
+  const size_t kk = (size_t)k * k;
+  float *M = gscratch, *cvec = M + kk, *gp = cvec + k, *sxp = gp + (size_t)chunks * kk;
+  size_t off = (size_t)(sxp + (size_t)chunks * k - gscratch);
+  off = (off + 1) & ~(size_t)1;   // float64 from here on (gscratch itself is 256-byte aligned)
+  double *G64 = reinterpret_cast<double *>(gscratch + off), *sx64 = G64 + kk;
+  hipLaunchKernelGGL(gram_prep_kernel, dim3(cdiv(k, 16), cdiv(k, 16)), dim3(256), 0, st, n, k, wt,
+                     ldw, alpha, beta, M, cvec);
+  GramArgs a{};
+  a.X = x; a.ldx = ldx; a.R = rows; a.N = n; a.K = k;
+  a.rows_per_chunk = cdiv(cdiv(rows, chunks), 32) * 32;
+  a.pa = pa; a.pb = pb; a.mu_p = mu_p; a.is_p = is_p; a.Wt = wt; a.ldw = ldw; a.M = M;
+  a.cvec = cvec; a.Z = dz; a.ldz = ldz; a.pw = pw; a.gp = gp; a.sxp = sxp; a.spart = spart;
+  a.garg = arg; a.gdcl = dcl; a.SSH = ilog2(s); a.ldt = n;
+  const dim3 grid(1, cdiv(k, 64), chunks);
+#define BTR_GRAM(W, KF) \
+  hipLaunchKernelGGL((sa_bwd_gram_kernel<W, KF>), grid, dim3(256), 0, st, a, cur_compact())
+  if (k <= 64) {
+    if (n > 128) BTR_GRAM(8, 64); else if (n > 64) BTR_GRAM(4, 64); else BTR_GRAM(2, 64);
+  } else {
+    if (n > 128) BTR_GRAM(8, 128); else if (n > 64) BTR_GRAM(4, 128); else BTR_GRAM(2, 128);
+  }
+#undef BTR_GRAM
+  const double count = host_compact().on ? host_compact().count : (double)rows;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(k, kRedCh)), dim3(256), 0, st, k, chunks,
+                     count, spart, m1, m2, dgamma, dbeta);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((int)kk + k, 256)), dim3(256), 0, st, k, chunks,
+                     gp, sxp, G64, sx64);
+  hipLaunchKernelGGL(gram_finish_kernel, dim3(cdiv(n * k, 256)), dim3(256), 0, st, n, k, chunks,
+                     pw, w, alpha, beta, G64, sx64, dw);
+  return check_launch("sa_bwd_gram");
+}
+
 // dW[n][k] = sum_r G[r][n] * f(X[r][k]).
 int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float *x, int ldx,
                    const float *pa, const float *pb, float *pw, float *dw,
@@ -4395,21 +5070,26 @@ int btr_sac_gather(int b, int n, int m, int max_rows, int c, int ldx, int use_xy
   return check_launch("sac_gather");
 }
 
-int btr_sac_pool(int b, int m, int c, const float *gext, const unsigned char *aext,
-                 const int *goff, const float *scale, const float *shift, float *out,
-                 float *out_cl, unsigned char *arg, btr_stream_t stream) {
+int btr_sac_pool_y(int b, int m, int c, const float *gext, const unsigned char *aext,
+                   const int *goff, const float *scale, const float *shift, float *out,
+                   float *out_cl, unsigned char *arg, float *ywin, btr_stream_t stream) {
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(gext && aext && goff && scale && shift && out && arg, "sac_pool: null pointer");
   if (pool_tiled(m))
     hipLaunchKernelGGL(sa_pool_tile_kernel, dim3((unsigned)(groups / 32), cdiv(c, 32)), dim3(256),
                        0, as_stream(stream), m, c, gext, aext, goff, scale, shift, out, out_cl,
-                       arg);
+                       arg, ywin);
   else
     hipLaunchKernelGGL(sac_pool_kernel, dim3(cdiv(groups * c, 256)), dim3(256), 0,
                        as_stream(stream), m, c, groups, gext, aext, goff, scale, shift, out,
-                       out_cl, arg);
+                       out_cl, arg, ywin);
   return check_launch("sac_pool");
+}
+int btr_sac_pool(int b, int m, int c, const float *gext, const unsigned char *aext,
+                 const int *goff, const float *scale, const float *shift, float *out,
+                 float *out_cl, unsigned char *arg, btr_stream_t stream) {
+  return btr_sac_pool_y(b, m, c, gext, aext, goff, scale, shift, out, out_cl, arg, nullptr, stream);
 }
 
 size_t btr_sac_scatter_workspace_bytes(int b, int n, int max_rows) {

@@ -88,6 +88,11 @@ _SIGNATURES = {
     "btr_sa_bwd_fused_chunks": (_ci, [_ci, _ci, _ci]),
     "btr_sa_bwd_fused": (_ci, [_ci, _ci, _ci, _vp, _ci] + [_vp] * 7 + [_ci] + [_vp] * 5 +
                          [_ci] + [_vp] * 6 + [_ci, _vp, _ci] + [_vp] * 8),
+    "btr_sa_bwd_gram_supported": (_ci, [_ci, _ci, _ci]),
+    "btr_sa_bwd_gram_chunks": (_ci, [_ci, _ci, _ci]),
+    "btr_sa_bwd_gram_scratch_floats": (_sz, [_ci, _ci, _ci]),
+    "btr_sa_bwd_gram": (_ci, [_ci, _ci, _ci, _vp, _ci] + [_vp] * 6 + [_ci, _ci] + [_vp] * 5 +
+                        [_ci] + [_vp] * 9),
     "btr_sa_bn_relu_bwd_rc_apply": (_ci, [_ll, _ci, _ci] + [_vp] * 12),
     "btr_sa_bn_relu_bwd_sums": (_ci, [_ll, _ci, _ci] + [_vp] * 12),
     "btr_sa_bn_relu_bwd_apply": (_ci, [_ll, _ci, _ci] + [_vp] * 9),
@@ -100,6 +105,9 @@ _SIGNATURES = {
     "btr_sac_plan": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "btr_sac_gather": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _ci, _cf] + [_vp] * 8),
     "btr_sac_pool": (_ci, [_ci, _ci, _ci] + [_vp] * 9),
+    "btr_sac_pool_y": (_ci, [_ci, _ci, _ci] + [_vp] * 10),
+    "btr_sa_pool_fin_y": (_ci, [_ci, _ci, _ci] + [_vp] * 9),
+    "btr_sa_gemm_nt_poolfwd_nostore_supported": (_ci, [_ci, _ci, _ci, _ci]),
     "btr_sac_scatter_workspace_bytes": (_sz, [_ci, _ci, _ci]),
     "btr_sac_scatter": (_ci, [_ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _sz, _ci,
                               _vp]),
@@ -212,6 +220,7 @@ class CompactRows(ctypes.Structure):
 MAX_LAYERS = 8   # BTR_MAX_LAYERS
 _vp8, _ci8, _cf8, _sz8 = _vp * 8, _ci * 8, _cf * 8, _sz * 8
 SA_OPT_COMPACT, SA_OPT_RECOMPUTE, SA_OPT_POOL_EPILOGUE, SA_OPT_POOL_GRAD = 1, 2, 4, 8
+SA_OPT_POOL_GRAM = 16
 
 
 class SaLayer(ctypes.Structure):

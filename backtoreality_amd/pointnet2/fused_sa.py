@@ -421,6 +421,15 @@ def _sa_options():
         o |= _ext.SA_OPT_POOL_EPILOGUE
     if os.environ.get("BTR_POOLGRAD", "1") != "0":
         o |= _ext.SA_OPT_POOL_GRAD
+    # the pooled layer without its stored pre-BN output (btr_sa_bwd_gram; whole-layer / whole-
+    # backbone calls only: the Python-sequenced FusedSAFunction keeps the Y_l-reading form).
+    # The environment switches of the kernels it rests on are part of the option word, so that a
+    # plan cached under other settings is not reused
+    if (os.environ.get("BTR_POOL_GRAM", "1") != "0" and
+            os.environ.get("BTR_FWD_STREAM", "1") != "0" and
+            os.environ.get("BTR_BWD_FUSED", "1") != "0" and
+            os.environ.get("BTR_GEMM", "") != "f32"):
+        o |= _ext.SA_OPT_POOL_GRAM
     return o
 
 

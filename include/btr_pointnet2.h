@@ -313,6 +313,19 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
 int btr_sa_pool_fin(int b, int m, int c, const float *gext, const unsigned char *aext,
                     const float *scale, const float *shift, float *out, float *out_cl,
                     unsigned char *arg, btr_stream_t stream);
+/* Round 5: the pooled layer without its stored output.  btr_sa_gemm_nt_poolfwd accepts c == NULL
+ * (statistics and extrema only) when btr_sa_gemm_nt_poolfwd_nostore_supported() returns 1 (the
+ * streaming kernel's shapes; s = 8 for the block extrema of compact rows);  btr_sa_pool_fin_y /
+ * btr_sac_pool_y also leave ywin (b, m, c) = the pre-BN value of the arg-max row, which
+ * btr_sa_pool_bwd_coef takes in place of y with ldy == 0 (needs c % 4 == 0 and <= 1024 tiles of 64
+ * centres); btr_sa_bwd_gram is the backward that goes with it. */
+int btr_sa_gemm_nt_poolfwd_nostore_supported(int rows, int n, int k, int s);
+int btr_sa_pool_fin_y(int b, int m, int c, const float *gext, const unsigned char *aext,
+                      const float *scale, const float *shift, float *out, float *out_cl,
+                      unsigned char *arg, float *ywin, btr_stream_t stream);
+int btr_sac_pool_y(int b, int m, int c, const float *gext, const unsigned char *aext,
+                   const int *goff, const float *scale, const float *shift, float *out,
+                   float *out_cl, unsigned char *arg, float *ywin, btr_stream_t stream);
 int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const float *w, int ldw,
                         float *c, int ldc, int s, const unsigned char *arg, const float *dcl,
                         const float *alpha, const float *beta, btr_stream_t stream);
@@ -370,6 +383,32 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
                      const float *mu_p, const float *is_p, const float *wt, int ldw, float *dz,
                      int ldz, float *pw, float *dw, float *spart, float *m1, float *m2,
                      float *dgamma, float *dbeta, btr_stream_t stream);
+/* The POOLED layer's whole backward without its pre-BN output (csrc/sa_mlp.hip
+ * sa_bwd_gram_kernel; round 5).  The dense part of the pooled layer's gradient is affine in
+ * Y_l = X W_l^T -- dY[r][n] = w_r (alpha[n] Y_l[r][n] + beta[n]) + sparse[r][n], sparse = dcl on
+ * the arg-max row of (group, channel), w_r = copies a compact row stands for -- so
+ *   dz [rows][k] = w_r (x_r M + c) + sparse_r W_l,       M = W_l^T diag(alpha) W_l, c = beta^T W_l
+ *   dw [n][k]    = diag(alpha) W_l G + beta (x) sx + sparse^T X,   G = sum_r w_r x_r x_r^T,
+ *                                                                  sx = sum_r w_r x_r
+ * need X = relu(pa * x + pb) (x [rows][ldx] = Y_{l-1}) only: per row k floats read and k written
+ * instead of n + k read, the forward stores no Y_l (btr_sa_gemm_nt_poolfwd with c == NULL) and
+ * the dense products are k x k instead of n x k per row.  Operands as btr_sa_bwd_fused with
+ * arg != NULL, minus g; w = W_l [n][k] row-major (leading dimension k), wt = W_l^T [k][ldw];
+ * pw [btr_sa_bwd_gram_chunks()][n][k], spart [chunks][2][k], gscratch
+ * btr_sa_bwd_gram_scratch_floats() floats (256-byte aligned).  Outputs as btr_sa_bwd_fused.
+ * Supported: btr_sa_bwd_fused's shapes with k <= 128 (BTR_POOL_GRAM=0: never).  Same result as
+ * the Y_l-reading form up to float32 rounding (G and sx are combined in float64).
+ * Reference: the autograd backward of max_pool2d over the last Conv2d + BatchNorm2d + ReLU of
+ * SharedMLP, pointnet2_modules.py:262-267, pytorch_utils.py:11-36. */
+int btr_sa_bwd_gram_supported(int rows, int n, int k);
+int btr_sa_bwd_gram_chunks(int rows, int n, int k);
+size_t btr_sa_bwd_gram_scratch_floats(int rows, int n, int k);
+int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float *pa,
+                    const float *pb, const float *mu_p, const float *is_p, const float *w,
+                    const float *wt, int ldw, int s, const unsigned char *arg, const float *dcl,
+                    const float *alpha, const float *beta, float *dz, int ldz, float *pw,
+                    float *dw, float *gscratch, float *spart, float *m1, float *m2,
+                    float *dgamma, float *dbeta, btr_stream_t stream);
 /* The two halves of btr_sa_bn_relu_bwd (statistics + finalisation; in-place apply): a caller
  * that hands (g, y, m1, m2) to btr_sa_bwd_fused only needs the first. */
 int btr_sa_bn_relu_bwd_sums(long long rows, int c, int ld, const float *g, const float *y,
@@ -557,7 +596,9 @@ enum {
   BTR_SA_OPT_COMPACT = 1,       /* distinct-neighbour rows for nsample >= 32                     */
   BTR_SA_OPT_RECOMPUTE = 2,     /* never store the first layer's output of a 4-column input      */
   BTR_SA_OPT_POOL_EPILOGUE = 4, /* group extrema from the last GEMM's epilogue                    */
-  BTR_SA_OPT_POOL_GRAD = 8      /* pooled gradient formed inside the GEMM operand staging        */
+  BTR_SA_OPT_POOL_GRAD = 8,     /* pooled gradient formed inside the GEMM operand staging        */
+  BTR_SA_OPT_POOL_GRAM = 16     /* pooled layer without its stored output (btr_sa_bwd_gram); the
+                                   plan reports it as pool_grad == 2                              */
 };
 typedef struct {
   int b, n, m, s, c;            /* batch, points, centres, nsample, feature channels (may be 0)  */

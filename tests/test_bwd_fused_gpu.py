@@ -112,3 +112,79 @@ def test_unsupported_shapes_are_refused(cuda):
     assert not _lib.btr_sa_bwd_fused_supported(1024, 260, 128)    # n > 256
     assert not _lib.btr_sa_bwd_fused_supported(1024, 128, 130)    # k not a multiple of 4
     assert not _lib.btr_sa_bwd_fused_supported(0, 128, 64)
+
+
+# ---------------------------------------------------------------- the pooled layer in Gram form
+def _run_gram(dev, rows, n, k, s, seed=0, ldx_pad=0):
+    """btr_sa_bwd_gram against the float64 evaluation of what it replaces: the pooled layer's
+    dY = alpha * Y_l + beta + sparse with Y_l = X W_l^T (the affine structure the Gram form rests
+    on), then dW_l, dZ_{l-1} and BatchNorm_{l-1}'s backward sums."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(dev)
+    ldx = k + ldx_pad
+    x = rnd(rows, ldx)
+    yprev = x[:, :k].double()
+    pa, pb = rnd(k), rnd(k) * 0.3
+    mu_p, is_p = rnd(k) * 0.2, torch.rand(k, generator=g).to(dev) + 0.5
+    W = rnd(n, k) * 0.2
+    Wt = W.t().contiguous()
+    groups = rows // s
+    arg = torch.randint(0, s, (groups, n), generator=g, dtype=torch.uint8).to(dev)
+    dcl = rnd(groups, n)
+    # alpha * y + beta with a mean that does not vanish: the dense part cancels in dW
+    alpha, beta = rnd(n) * 0.1, rnd(n) * 0.1
+    X = torch.relu(pa.double() * yprev + pb.double())
+    Y = X @ W.double().t()
+    rr = torch.arange(rows, device=dev)
+    hit = (rr % s).unsqueeze(1) == arg.long()[rr // s]
+    dY = alpha.double() * Y + beta.double() + torch.where(
+        hit, dcl.double()[rr // s], torch.zeros((), dtype=torch.float64, device=dev))
+    dz_ref = dY @ W.double()
+    dw_ref = dY.t() @ X
+    mp = (pa.double() * yprev + pb.double()) > 0
+    gm = torch.where(mp, dz_ref, torch.zeros_like(dz_ref))
+    s1_ref = gm.sum(0)
+    s2_ref = (gm * (yprev - mu_p.double()) * is_p.double()).sum(0)
+
+    assert _lib.btr_sa_bwd_gram_supported(rows, n, k)
+    chunks = _lib.btr_sa_bwd_gram_chunks(rows, n, k)
+    f32 = lambda *shape: torch.full(shape, float("nan"), dtype=torch.float32, device=dev)
+    dz, pw, dw = f32(rows, k), f32(chunks, n, k), f32(n, k)
+    spart = f32(chunks, 2, k)
+    gs = f32(int(_lib.btr_sa_bwd_gram_scratch_floats(rows, n, k)))
+    m1, m2, dg, db = f32(k), f32(k), f32(k), f32(k)
+    with _ext._on(x) as d:
+        _ext._call(_lib.btr_sa_bwd_gram, rows, n, k, _p(x), ldx, _p(pa), _p(pb), _p(mu_p),
+                   _p(is_p), _p(W), _p(Wt), n, s, _p(arg), _p(dcl), _p(alpha), _p(beta), _p(dz),
+                   k, _p(pw), _p(dw), _p(gs), _p(spart), _p(m1), _p(m2), _p(dg), _p(db),
+                   _ext._stream(d))
+    torch.cuda.synchronize()
+    return (dz, dw, dg, db, m1, m2), (dz_ref, dw_ref, s2_ref, s1_ref, s1_ref / rows, s2_ref / rows)
+
+
+@pytest.mark.parametrize("rows,n,k,s", [
+    (4096, 128, 64, 64),       # SA1's pooled layer
+    (4096, 256, 128, 32),      # SA2's: the 256-wide variant, two k blocks
+    (4096, 256, 128, 16),      # SA3 / SA4
+    (2048, 128, 128, 16),      # vote aggregation
+    (1040, 128, 64, 16),       # ragged rows (last step of 16)
+    (1024, 100, 36, 16),       # n, k not multiples of 32
+    (20000, 128, 64, 32),      # many chunks
+    (2048, 64, 64, 16),        # the 64-column variant
+    (3008, 200, 100, 16),      # 256-wide variant on n = 200, k = 100
+])
+def test_gram_backward_matches_float64(cuda, rows, n, k, s):
+    got, ref = _run_gram(cuda, rows, n, k, s, ldx_pad=4 if k % 8 else 0)
+    _check(got, ref)
+
+
+def test_gram_backward_is_bit_reproducible(cuda):
+    a, _ = _run_gram(cuda, 8960, 128, 64, 64, seed=3)
+    b, _ = _run_gram(cuda, 8960, 128, 64, 64, seed=3)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_gram_backward_refuses_wide_inputs(cuda):
+    assert not _lib.btr_sa_bwd_gram_supported(4096, 256, 256)   # k > 128: the Y_l-reading form
+    assert _lib.btr_sa_bwd_gram_supported(4096, 256, 128)

@@ -56,6 +56,9 @@ def test_sa_layer_call_equals_python_sequence(cuda, monkeypatch, N, npoint, radi
     if options == "plain":   # no compact rows / recompute / pooling epilogue / prologue gradient
         for k in ("BTR_SA_COMPACT", "BTR_SA_RECOMPUTE", "BTR_POOL_EPILOGUE", "BTR_POOLGRAD"):
             monkeypatch.setenv(k, "0")
+    # (the pooled layer's Gram-form backward exists in the whole-layer call only: the Python
+    # sequence reads Y_l; test_gram_form_equals_the_y_reading_form below compares the two)
+    monkeypatch.setenv("BTR_POOL_GRAM", "0")
     B = 2
     xyz = torch.from_numpy(np.stack([synthetic.make_scene(60 + i, N, use_height=False)[
         'point_clouds'] for i in range(B)], 0)).to(cuda)
@@ -84,6 +87,50 @@ def test_sa_layer_call_equals_python_sequence(cuda, monkeypatch, N, npoint, radi
                 assert rel < 1e-5, (k, rel)
             else:
                 assert torch.equal(got, want), (k, float((got.float() - want.float()).abs().max()))
+
+
+@pytest.mark.parametrize("N,npoint,radius,S,mlp,C,feat_grad", [
+    (8192, 1024, 0.2, 64, [1, 64, 64, 128], 1, False),        # SA1: compact rows + recompute
+    (4096, 512, 0.4, 32, [128, 128, 128, 256], 128, True),    # SA2: compact, 256-wide, 2 k blocks
+    (2048, 1024, 0.8, 16, [256, 128, 128, 256], 256, True),   # SA3 / SA4: groups of 16
+    (2048, 1024, 0.3, 16, [256, 128, 128, 128], 256, True),   # vote aggregation's widths
+    (4096, 512, 0.4, 32, [16, 64, 100], 16, True),            # two layers, n = 100
+])
+def test_gram_form_equals_the_y_reading_form(cuda, monkeypatch, N, npoint, radius, S, mlp, C,
+                                             feat_grad):
+    """The pooled layer without its stored pre-BN output (BTR_SA_OPT_POOL_GRAM: forward keeps
+    the group extrema only, btr_sa_bwd_gram forms dW_l / dZ_{l-1} from X_{l-1}) against the
+    Y_l-reading whole-layer call: the forward is the same arithmetic (outputs and BatchNorm
+    buffers bit-identical), the gradients agree to float32 rounding of their largest entry."""
+    B = 2
+    xyz = torch.from_numpy(np.stack([synthetic.make_scene(60 + i, N, use_height=False)[
+        'point_clouds'] for i in range(B)], 0)).to(cuda)
+    torch.manual_seed(0)
+    feats = torch.randn(B, C, N, device=cuda) if C else None
+    sa = M.PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=S, mlp=list(mlp),
+                                 use_xyz=True, normalize_xyz=True).to(cuda)
+    with torch.no_grad():
+        for layer in sa.mlp_module:
+            layer.bn.bn.weight.uniform_(-1.5, 1.5)     # (negative scales: minima are pooled)
+            layer.bn.bn.bias.uniform_(-0.3, 0.3)
+    inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    res, plans = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BTR_POOL_GRAM", flag)
+        mod = copy.deepcopy(sa)
+        res[flag] = _sa_run(mod, xyz, feats, inds, False, feat_grad)
+        plans[flag] = [ent[1].pool_grad for ent in fused_sa._LAYER_CACHE.get(mod, {}).values()]
+    assert plans["0"] == [1] and plans["1"] == [2], plans   # (the variant that actually ran)
+    for k, want in res["0"].items():
+        got = res["1"][k]
+        assert (want is None) == (got is None), k
+        if want is None:
+            continue
+        if k in ("out", "out_cl") or "running" in k or "tracked" in k:
+            assert torch.equal(got, want), k
+        else:
+            rel = float((got - want).abs().max() / want.abs().max())
+            assert rel < 2e-5, (k, rel)
 
 
 def _chain_compare(run, mod, monkeypatch, summed=()):
