@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "internal.hpp"
 
@@ -2709,6 +2710,7 @@ struct GramArgs {
   const unsigned char *garg;
   const float *gdcl;
   int SSH, ldt;
+  int dbg;   // measurement only (BTR_GRAM_DBG): 1 = consumers idle, 2 = producers idle
 };
 
 __device__ __forceinline__ void split1(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
@@ -3158,78 +3160,561 @@ __global__ __launch_bounds__(256, (TNW == 8 || KF == 128) ? 1 : 2) void sa_bwd_g
   }
 }
 
-// M = W^T diag(alpha) W and c = beta^T W of the Gram-form backward, from Wt = W^T [K][ldw]:
-// thread (i, j) of a 16 x 16 tile; float64 accumulation (alpha changes sign across channels).
+// ---- ... with producer and consumer waves -------------------------------------------------------
+// sa_bwd_gram_kernel above, like sa_bwd_fused_kernel, runs its three phases -- staging (VALU),
+// products (LDS reads + MFMA), epilogue (VALU + stores) -- one after the other in every wave, two
+// barriers per 32-row step, and leaves it to the second workgroup of the CU to fill the gaps:
+// both forms need ~12 500 cycles per pair of steps for 4 600 cycles of MFMA issue, whatever the
+// bytes (SA1's pooled layer: 266 us in Gram form against 270 us reading twice as much).  Here the
+// phases run BESIDE each other: a 512-thread workgroup (one per CU) whose waves 0-3 only stage and
+// finish rows and whose waves 4-7 only multiply, one of each kind per SIMD, so that a SIMD's
+// VALU work and its matrix work come from different waves by construction.
+//   iteration i:  producers   epilogue of step i-1 (C tile of buffer (i-1) % 2: dZ rows out, the
+//                             BatchNorm sums), staging of step i+1 into plane buffer (i+1) % 2,
+//                             global loads of step i+3 (two steps ahead of their use)
+//                 consumers   products of step i out of plane buffer i % 2 into C tile i % 2
+//                 ONE barrier
+// The planes, the weighted side rows and the C tile are double-buffered (137 KB at n = 128); the
+// producers keep the raw rows of the two steps in flight in registers for the epilogue.
+// n <= 128, k <= 64 (SA1's pooled layer: a third of all set-abstraction rows of the step).
+constexpr int kGramWsMaxBlocks = 2560;   // 8-row blocks per chunk (20 KB LDS table): 20 480 rows
+template <int TNW>
+__global__ __launch_bounds__(512, 1) void sa_bwd_gram_ws_kernel(GramArgs a, Compact cm) {
+  constexpr int BR = 32, KF = 64;
+  constexpr int TN = 32 * TNW;
+  constexpr int LG = TN == 128 ? 160 : 96;
+  constexpr int LXF = 96, LC = 68;
+  constexpr int XR = BR + 4;   // X plane rows: 32 + the weighted copies of rows 0, 8, 16, 24
+  constexpr int KT = TNW >= 4 ? 2 : 1;
+  constexpr int SPB = 3 * BR * LG, XPB = 3 * XR * LXF, CSB = 2 * BR * LC;
+  int R = a.R, rows_per_chunk = a.rows_per_chunk;
+  if (cm.dims) {
+    R = cm.dims[0];
+    rows_per_chunk = ((R + (int)gridDim.z - 1) / (int)gridDim.z + 31) / 32 * 32;
+  }
+  const int N = a.N, K = a.K;
+  __shared__ __attribute__((aligned(16))) __bf16 Sp[2 * SPB];
+  __shared__ __attribute__((aligned(16))) __bf16 Xp[2 * XPB];
+  __shared__ __attribute__((aligned(16))) float Cs[2 * CSB];
+  __shared__ int2 Bg[kGramWsMaxBlocks];   // per 8-row block of the chunk: (group, its first row)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.z;
+  const int rbeg = chunk * rows_per_chunk;
+  const int rend = min(R, rbeg + rows_per_chunk);
+  const int nsteps = rbeg < rend ? (rend - rbeg + BR - 1) / BR : 0;
+  const int nsteps2 = (nsteps + 1) & ~1;   // (pairs: the buffers alternate with static indices)
+  const bool cmw = cm.bw != nullptr;
+
+  for (int i = tid; i < 2 * SPB / 8; i += 512)
+    reinterpret_cast<float4 *>(Sp)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // compact rows: group of every 8-row block of this chunk, first row of every group it touches
+  // (the chunk's blocks are consecutive, and so are their groups)
+  if (cm.bgrp && rbeg < rend) {
+    const int nblk = (rend - rbeg + 7) >> 3;
+    for (int i = tid; i < nblk; i += 512) {
+      const int g = cm.bgrp[(rbeg >> 3) + i];
+      Bg[i] = make_int2(g, cm.goff[g]);
+    }
+  }
+  __syncthreads();
+
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, sxa = s1;
+  const int xc4 = (tid & 15) * 4, xr = (tid & 255) >> 4;
+  const std::integral_constant<int, 0> P0{};
+  const std::integral_constant<int, 1> P1{};
+  if (wave < 4) {
+    // ================================================================== producers
+    const float *__restrict__ X = a.X;
+    float4 fa = make_float4(0.f, 0.f, 0.f, 0.f), fb = fa, fmu = fa, fis = fa, cv = fa;
+    if (xc4 < K) {
+      fa = *reinterpret_cast<const float4 *>(a.pa + xc4);
+      fb = *reinterpret_cast<const float4 *>(a.pb + xc4);
+      fmu = *reinterpret_cast<const float4 *>(a.mu_p + xc4);
+      fis = *reinterpret_cast<const float4 *>(a.is_p + xc4);
+      cv = *reinterpret_cast<const float4 *>(a.cvec + xc4);
+    }
+    const int sp_gi = tid / TN, sp_n = tid % TN;
+    constexpr int SPQ = 4 * TN / 256;
+    float4 rx[2][2], yk[2][2];
+    float wx[2][2], wk[2][2];
+    // sparse entries: what the loads return is kept RAW (arg-max byte, value, the group's first
+    // row) and turned into a local row only when the step is staged, two iterations later -- an
+    // address or a comparison formed from a load inside fetch() would park the wave on that load
+    // (and on every load in front of it) once per step
+    int sp_arg[2][SPQ], sp_base[2][SPQ], cl_lr[2][SPQ];
+    float sp_dv[2][SPQ];
+#pragma unroll
+    for (int q = 0; q < SPQ; ++q) {
+      sp_arg[0][q] = sp_arg[1][q] = 0;
+      sp_base[0][q] = sp_base[1][q] = -0x40000000;   // (no entry)
+      cl_lr[0][q] = cl_lr[1][q] = -1;
+      sp_dv[0][q] = sp_dv[1][q] = 0.f;
+    }
+    // loads of the step at r0 into register set P
+    auto fetch = [&](auto P, int r0) {
+      constexpr int p = decltype(P)::value;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = xr + 16 * j;
+        wx[p][j] = 1.f;
+        rx[p][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + row < rend) {
+          if (cmw && (row & 7) == 0) wx[p][j] = cm.bw[(r0 + row) >> 3];
+          if (xc4 < K)
+            rx[p][j] = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * a.ldx + xc4);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        const int slot = sp_gi + (256 / TN) * q;
+        sp_base[p][q] = -0x40000000;
+        if (cm.bgrp) {
+          // (group of the block and its first row: LDS tables of this chunk, filled at the start)
+          const int blk = (r0 >> 3) + slot;
+          if (slot < 4 && (blk << 3) < rend && sp_n < N) {
+            const int2 gg = Bg[blk - (rbeg >> 3)];
+            const int g = gg.x;
+            sp_base[p][q] = gg.y - r0;
+            sp_arg[p][q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
+            sp_dv[p][q] = a.gdcl[(size_t)g * a.ldt + sp_n];
+          }
+        } else {
+          const int g = (r0 >> a.SSH) + slot;
+          if ((slot << a.SSH) < BR && (g << a.SSH) < rend && sp_n < N) {
+            sp_base[p][q] = (g << a.SSH) - r0;
+            sp_arg[p][q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
+            sp_dv[p][q] = a.gdcl[(size_t)g * a.ldt + sp_n];
+          }
+        }
+      }
+    };
+    // local row of entry q of register set p (-1: none in this step)
+    auto entry_row = [&](int r0, int slot, int base, int arg) {
+      const int lr = base + arg;
+      if (cm.bgrp) return (lr >= 0 && (lr >> 3) == slot) ? lr : -1;
+      return (lr >= 0 && lr < BR && r0 + lr < rend) ? lr : -1;
+    };
+    // register set P -> plane buffer P (the step's sparse entries replace those of the step before
+    // last; X = relu(bn(.)) planes incl. the weighted copies of rows 0 (mod 8), column sums)
+    auto stage = [&](auto P, int r0) {
+      constexpr int p = decltype(P)::value;
+      __bf16 *sp = Sp + p * SPB, *xp = Xp + p * XPB;
+#pragma unroll
+      for (int q = 0; q < SPQ; ++q) {
+        if (cl_lr[p][q] >= 0) {
+          const int at = cl_lr[p][q] * LG + (swz(cl_lr[p][q], sp_n * 2) >> 1);
+          const __bf16 z = (__bf16)0.f;
+          sp[0 * BR * LG + at] = z;
+          sp[1 * BR * LG + at] = z;
+          sp[2 * BR * LG + at] = z;
+        }
+        const int lr = entry_row(r0, sp_gi + (256 / TN) * q, sp_base[p][q], sp_arg[p][q]);
+        cl_lr[p][q] = lr;
+        if (lr >= 0) {
+          __bf16 eh, em, el;
+          split1(sp_dv[p][q], eh, em, el);
+          const int at = lr * LG + (swz(lr, sp_n * 2) >> 1);
+          sp[0 * BR * LG + at] = eh;
+          sp[1 * BR * LG + at] = em;
+          sp[2 * BR * LG + at] = el;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = xr + 16 * j;
+        float4 x = rx[p][j];
+        const bool live = r0 + row < rend && xc4 < K;
+        yk[p][j] = x;
+        wk[p][j] = wx[p][j];
+        if (live) {
+          x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
+          x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
+          x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
+          x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
+        } else {
+          x = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const Split4 spl = split4(x);
+        const int at = row * LXF + (swz(row, xc4 * 2) >> 1);
+        *reinterpret_cast<bf16x4 *>(&xp[0 * XR * LXF + at]) = spl.h;
+        *reinterpret_cast<bf16x4 *>(&xp[1 * XR * LXF + at]) = spl.m;
+        *reinterpret_cast<bf16x4 *>(&xp[2 * XR * LXF + at]) = spl.l;
+        const float w = wx[p][j];
+        sxa.x = fmaf(w, x.x, sxa.x); sxa.y = fmaf(w, x.y, sxa.y);
+        sxa.z = fmaf(w, x.z, sxa.z); sxa.w = fmaf(w, x.w, sxa.w);
+        if ((row & 7) == 0) {   // (dense rows: the copy is the row itself -- w = 1)
+          const Split4 sw = split4(make_float4(w * x.x, w * x.y, w * x.z, w * x.w));
+          const int aw = (BR + (row >> 3)) * LXF + xc4;   // rows 32 .. 35: (row >> 2) & 3 == 0
+          *reinterpret_cast<bf16x4 *>(&xp[0 * XR * LXF + aw]) = sw.h;
+          *reinterpret_cast<bf16x4 *>(&xp[1 * XR * LXF + aw]) = sw.m;
+          *reinterpret_cast<bf16x4 *>(&xp[2 * XR * LXF + aw]) = sw.l;
+        }
+      }
+    };
+    // C tile P -> dZ rows of the step at r0, BatchNorm_{l-1}'s sums
+    auto epilogue = [&](auto P, int r0) {
+      constexpr int p = decltype(P)::value;
+      const float *cs = Cs + p * CSB;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = xr + 16 * j;
+        if (r0 + row < rend && xc4 < K) {
+          const float wr = wk[p][j];
+          const float4 c0 = *reinterpret_cast<const float4 *>(&cs[row * LC + xc4]);
+          const float4 c1 = *reinterpret_cast<const float4 *>(&cs[BR * LC + row * LC + xc4]);
+          const float4 c = make_float4(fmaf(wr, cv.x, c0.x + c1.x), fmaf(wr, cv.y, c0.y + c1.y),
+                                       fmaf(wr, cv.z, c0.z + c1.z), fmaf(wr, cv.w, c0.w + c1.w));
+          *reinterpret_cast<float4 *>(a.Z + (size_t)(r0 + row) * a.ldz + xc4) = c;
+          const float4 y = yk[p][j];
+          const float gx = fmaf(fa.x, y.x, fb.x) > 0.f ? c.x : 0.f;
+          const float gy = fmaf(fa.y, y.y, fb.y) > 0.f ? c.y : 0.f;
+          const float gz = fmaf(fa.z, y.z, fb.z) > 0.f ? c.z : 0.f;
+          const float gw = fmaf(fa.w, y.w, fb.w) > 0.f ? c.w : 0.f;
+          s1.x += gx; s1.y += gy; s1.z += gz; s1.w += gw;
+          s2.x = fmaf(gx, (y.x - fmu.x) * fis.x, s2.x);
+          s2.y = fmaf(gy, (y.y - fmu.y) * fis.y, s2.y);
+          s2.z = fmaf(gz, (y.z - fmu.z) * fis.z, s2.z);
+          s2.w = fmaf(gw, (y.w - fmu.w) * fis.w, s2.w);
+        }
+      }
+    };
+    fetch(P0, rbeg);
+    fetch(P1, rbeg + BR);
+    stage(P0, rbeg);
+    fetch(P0, rbeg + 2 * BR);
+    __syncthreads();
+    for (int i = 0; i < nsteps2; i += 2) {
+      const int r0 = rbeg + i * BR;
+      if (a.dbg == 2) {
+        __syncthreads();
+        __syncthreads();
+        continue;
+      }
+      // iteration i (even): consumers work on buffer 0
+      if (i >= 1) epilogue(P1, r0 - BR);
+      stage(P1, r0 + BR);
+      fetch(P1, r0 + 3 * BR);
+      __syncthreads();
+      // iteration i + 1: consumers work on buffer 1
+      epilogue(P0, r0);
+      stage(P0, r0 + 2 * BR);
+      fetch(P0, r0 + 4 * BR);
+      __syncthreads();
+    }
+    if (nsteps2 >= 1) epilogue(P1, rbeg + (nsteps2 - 1) * BR);
+  } else {
+    // ================================================================== consumers
+    const int mw = wave - 4;
+    const int wn = TNW >= 4 ? mw : (mw >> 1);
+    const int wk_ = TNW >= 4 ? 0 : (mw & 1);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int dj = mw & 1, dnh = mw >> 1;
+    bf16x8 bdr[TN / 32][3], mdr[KF / 32][3];
+    {
+      const int kr = dj * 32 + (lane & 31);
+#pragma unroll
+      for (int kk = 0; kk < TN / 32; ++kk) {
+        const int nb = (dnh * (TN / 32) + kk) * 16 + (lane >> 5) * 8;
+        float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+        if (kr < K && nb < N) w0 = *reinterpret_cast<const float4 *>(a.Wt + (size_t)kr * a.ldw + nb);
+        if (kr < K && nb + 4 < N)
+          w1 = *reinterpret_cast<const float4 *>(a.Wt + (size_t)kr * a.ldw + nb + 4);
+        const Split4 t0 = split4(w0), t1 = split4(w1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bdr[kk][0][e] = t0.h[e]; bdr[kk][0][4 + e] = t1.h[e];
+          bdr[kk][1][e] = t0.m[e]; bdr[kk][1][4 + e] = t1.m[e];
+          bdr[kk][2][e] = t0.l[e]; bdr[kk][2][4 + e] = t1.l[e];
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KF / 32; ++kk) {
+        const int xb = (dnh * (KF / 32) + kk) * 16 + (lane >> 5) * 8;
+        float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+        if (kr < K && xb < K) w0 = *reinterpret_cast<const float4 *>(a.M + (size_t)kr * K + xb);
+        if (kr < K && xb + 4 < K)
+          w1 = *reinterpret_cast<const float4 *>(a.M + (size_t)kr * K + xb + 4);
+        const Split4 t0 = split4(w0), t1 = split4(w1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          mdr[kk][0][e] = t0.h[e]; mdr[kk][0][4 + e] = t1.h[e];
+          mdr[kk][1][e] = t0.m[e]; mdr[kk][1][4 + e] = t1.m[e];
+          mdr[kk][2][e] = t0.l[e]; mdr[kk][2][4 + e] = t1.l[e];
+        }
+      }
+    }
+    f32x16 acc[KT], gacc;
+#pragma unroll
+    for (int q = 0; q < KT; ++q)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) gacc[v] = 0.f;
+    // ---- every LDS address of the loop = one of these lane constants + a compile-time offset
+    // (plane, buffer, ks, k tile: the swizzle only touches bits 4-5 of the byte offset and is the
+    // same for rows 16 apart).  Element (bf16) offsets inside buffer 0:
+    const int p16 = lane & 15, grp = lane >> 4;
+    const int frow = 8 * (grp >> 1) + (p16 >> 2), fcol = 16 * (grp & 1) + 4 * (p16 & 3);
+    const bool wl_tr = cmw && (p16 >> 2) == 0;   // this lane's first transpose row is 0 (mod 8)
+    const bool wl_row = cmw && (l31 & 7) == 0;
+    const int oS0 = frow * LG + (swz(frow, fcol * 2) >> 1) + wn * 32;        // Sp, rows frow ..
+    const int oS1 = (frow + 4) * LG + (swz(frow + 4, fcol * 2) >> 1) + wn * 32;
+    const int oX0 = frow * LXF + (swz(frow, fcol * 2) >> 1);                  // Xp, columns fcol ..
+    const int oX1 = (frow + 4) * LXF + (swz(frow + 4, fcol * 2) >> 1);
+    const int oB = wk_ * 32, oGa = (mw >> 1) * 32, oGb = (mw & 1) * 32;       // column tiles
+    // G's B operand: the weighted copy (rows 32 + trow / 8, unswizzled) where trow = 0 (mod 8)
+    const int oW0 = wl_tr ? (BR + (frow >> 3)) * LXF + fcol + oGb : oX0 + oGb;            // ks = 0
+    const int oW1 = wl_tr ? (BR + 2 + (frow >> 3)) * LXF + fcol + oGb : oX0 + 16 * LXF + oGb;
+    int oDs[TN / 32], oDx[KF / 32];   // row reads of the input-gradient products
+#pragma unroll
+    for (int kk = 0; kk < TN / 32; ++kk) {
+      const int nb = (dnh * (TN / 32) + kk) * 16 + h * 8;
+      oDs[kk] = l31 * LG + (swz(l31, nb * 2) >> 1);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KF / 32; ++kk) {
+      const int xb = (dnh * (KF / 32) + kk) * 16 + h * 8;
+      oDx[kk] = wl_row ? (BR + (l31 >> 3)) * LXF + xb : l31 * LXF + (swz(l31, xb * 2) >> 1);
+    }
+    const int oC = dnh * (BR * LC) + 4 * h * LC + dj * 32 + l31;
+    typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+    auto tr2 = [&](const __bf16 *p0, const __bf16 *p1) {
+      union {
+        s16x4 s[2];
+        bf16x8 b;
+      } u;
+      u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0));
+      u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p1));
+      return u.b;
+    };
+    // The step's products as a chain of groups -- fragments out of LDS, then six (twelve) MFMAs --
+    // with a group's fragments requested before the MFMAs of the group in front of it:
+    //   groups 0 .. 3: (ks, what) = (0, sparse^T X), (0, G), (1, sparse^T X), (1, G)
+    //   groups 4 .. 4 + TN/32 - 1: sparse W, one 16-wide n step each;  then KF/32 groups (w x) M
+    struct Frag {
+      bf16x8 a[3], b[KT][3];
+    };
+    constexpr int NG = 4 + TN / 32 + KF / 32;
+#define BTR_X6G(ACC, A, B)                                                    \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A)[2], (B)[0], ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A)[0], (B)[2], ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A)[1], (B)[1], ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A)[1], (B)[0], ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A)[0], (B)[1], ACC, 0, 0, 0); \
+  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A)[0], (B)[0], ACC, 0, 0, 0);
+    auto step = [&](auto PB) {
+      constexpr int pb = decltype(PB)::value;
+      const __bf16 *sp = Sp + pb * SPB, *xp = Xp + pb * XPB;
+      f32x16 cd;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) cd[v] = 0.f;
+      auto load = [&](int g, Frag &f) {
+        if (g < 4) {
+          const int ro = (g >> 1) * 16;   // ks * 16 rows
+          if ((g & 1) == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              f.a[q] = tr2(sp + q * BR * LG + ro * LG + oS0, sp + q * BR * LG + ro * LG + oS1);
+#pragma unroll
+              for (int t = 0; t < KT; ++t)
+                f.b[t][q] = tr2(xp + q * XR * LXF + ro * LXF + t * 32 + oB + oX0,
+                                xp + q * XR * LXF + ro * LXF + t * 32 + oB + oX1);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+              f.a[q] = tr2(xp + q * XR * LXF + ro * LXF + oGa + oX0,
+                           xp + q * XR * LXF + ro * LXF + oGa + oX1);
+              f.b[0][q] = tr2(xp + q * XR * LXF + ((g >> 1) ? oW1 : oW0),
+                              xp + q * XR * LXF + ro * LXF + oGb + oX1);
+            }
+          }
+        } else if (g < 4 + TN / 32) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            f.a[q] = *reinterpret_cast<const bf16x8 *>(sp + q * BR * LG + oDs[g - 4]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            f.a[q] = *reinterpret_cast<const bf16x8 *>(xp + q * XR * LXF + oDx[g - 4 - TN / 32]);
+        }
+      };
+      auto mma = [&](int g, const Frag &f) {
+        if (g < 4) {
+          if ((g & 1) == 0) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t) { BTR_X6G(acc[t], f.a, f.b[t]) }
+          } else {
+            BTR_X6G(gacc, f.a, f.b[0])
+          }
+        } else if (g < 4 + TN / 32) {
+          BTR_X6G(cd, f.a, bdr[g - 4])
+        } else {
+          BTR_X6G(cd, f.a, mdr[g - 4 - TN / 32])
+        }
+      };
+      Frag fr[2];
+      load(0, fr[0]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        // (scheduling fences: left alone, the compiler sinks a group's LDS reads down to the MFMAs
+        // that consume them and the wave waits out an LDS round trip per group)
+        if (g + 1 < NG) load(g + 1, fr[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(g, fr[g & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float *T = Cs + pb * CSB + oC;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) T[((v & 3) + 8 * (v >> 2)) * LC] = cd[v];
+    };
+    __syncthreads();   // (the producers' first planes)
+    for (int i = 0; i < nsteps2; i += 2) {
+      if (a.dbg == 1) {
+        __syncthreads();
+        __syncthreads();
+        continue;
+      }
+      step(P0);
+      __syncthreads();
+      step(P1);
+      __syncthreads();
+    }
+#undef BTR_X6G
+    // ---- partials of this chunk: sparse^T X, G
+    {
+      float *out = a.pw + (size_t)chunk * N * K;
+#pragma unroll
+      for (int q = 0; q < KT; ++q) {
+        const int col = (wk_ + q) * 32 + l31;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = wn * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          if (row < N && col < K) out[(size_t)row * K + col] = acc[q][v];
+        }
+      }
+      float *og = a.gp + (size_t)chunk * K * K;
+      const int col = (mw & 1) * 32 + l31;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = (mw >> 1) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (row < K && col < K) og[(size_t)row * K + col] = gacc[v];
+      }
+    }
+  }
+  // ---- the producers' column sums: 16 row-threads per k column group, fixed order
+  __syncthreads();
+  float *red = Cs;   // [3][16 row threads][64 k]
+  if (wave < 4) {
+    *reinterpret_cast<float4 *>(&red[(0 * 16 + xr) * 64 + xc4]) = s1;
+    *reinterpret_cast<float4 *>(&red[(1 * 16 + xr) * 64 + xc4]) = s2;
+    *reinterpret_cast<float4 *>(&red[(2 * 16 + xr) * 64 + xc4]) = sxa;
+  }
+  __syncthreads();
+  if (tid < 192) {
+    const int which = tid >> 6, c = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[(which * 16 + q) * 64 + c];
+    if (c < K) {
+      if (which < 2) a.spart[((size_t)chunk * 2 + which) * K + c] = t;
+      else a.sxp[(size_t)chunk * K + c] = t;
+    }
+  }
+}
+
+// M = W^T diag(alpha) W and c = beta^T W of the Gram-form backward, from Wt = W^T [K][ldw].
+// One workgroup per 4 x 16 block of M: thread (i, j, slice) adds every 4th n of its slice in
+// float64 (alpha changes sign across channels), the four slices meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void gram_prep_kernel(int N, int K, const float *__restrict__ Wt,
                                                         int ldw, const float *__restrict__ alpha,
                                                         const float *__restrict__ beta,
                                                         float *__restrict__ M,
                                                         float *__restrict__ cvec) {
-  __shared__ float Wi[16][65], Wj[16][65], Al[64], Be[64];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  __shared__ double red[2][4][64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.y * 4 + (e >> 4), j = blockIdx.x * 16 + (e & 15);
   double m = 0.0, c = 0.0;
-  for (int n0 = 0; n0 < N; n0 += 64) {
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-      const int r = e >> 6, n = n0 + (e & 63);
-      Wi[r][e & 63] = (i0 + r < K && n < N) ? Wt[(size_t)(i0 + r) * ldw + n] : 0.f;
-      Wj[r][e & 63] = (j0 + r < K && n < N) ? Wt[(size_t)(j0 + r) * ldw + n] : 0.f;
+  if (i < K && j < K) {
+    const float *wi = Wt + (size_t)i * ldw, *wj = Wt + (size_t)j * ldw;
+    const int n0 = (N + 3) / 4 * sl, n1 = min(N, n0 + (N + 3) / 4);
+    for (int n = n0; n < n1; ++n) {
+      m += (double)alpha[n] * (double)wi[n] * (double)wj[n];
+      if (j == 0) c += (double)beta[n] * (double)wi[n];
     }
-    if (threadIdx.x < 64) {
-      const int n = n0 + threadIdx.x;
-      Al[threadIdx.x] = n < N ? alpha[n] : 0.f;
-      Be[threadIdx.x] = n < N ? beta[n] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int n = 0; n < 64; ++n) {
-      m += (double)Al[n] * (double)Wi[ty][n] * (double)Wj[tx][n];
-      if (blockIdx.x == 0 && tx == 0) c += (double)Be[n] * (double)Wi[ty][n];
-    }
-    __syncthreads();
   }
-  if (i0 + ty < K && j0 + tx < K) M[(size_t)(i0 + ty) * K + j0 + tx] = (float)m;
-  if (blockIdx.x == 0 && tx == 0 && i0 + ty < K) cvec[i0 + ty] = (float)c;
+  red[0][sl][e] = m;
+  red[1][sl][e] = c;
+  __syncthreads();
+  if (sl == 0 && i < K && j < K) {
+    M[(size_t)i * K + j] = (float)(red[0][0][e] + red[0][1][e] + red[0][2][e] + red[0][3][e]);
+    if (j == 0) cvec[i] = (float)(red[1][0][e] + red[1][1][e] + red[1][2][e] + red[1][3][e]);
+  }
 }
 
-// G64[i][j] = sum over chunks of gp[chunk][i][j]; sx64[k] likewise (float64, fixed order)
+// G64[i][j] = sum over chunks of gp[chunk][i][j]; sx64[k] likewise (float64, fixed order): 16
+// elements x 16 chunk slices per workgroup
 __global__ __launch_bounds__(256) void gram_reduce_kernel(int K, int chunks,
                                                           const float *__restrict__ gp,
                                                           const float *__restrict__ sxp,
                                                           double *__restrict__ G64,
                                                           double *__restrict__ sx64) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ double red[16][17];
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + e;
   const int total = K * K;
+  double s = 0.0;
   if (i < total) {
-    double s = 0.0;
-#pragma unroll 8
-    for (int c = 0; c < chunks; ++c) s += (double)gp[(size_t)c * total + i];
-    G64[i] = s;
+#pragma unroll 4
+    for (int c = sl; c < chunks; c += 16) s += (double)gp[(size_t)c * total + i];
   } else if (i < total + K) {
     const int k = i - total;
-    double s = 0.0;
-    for (int c = 0; c < chunks; ++c) s += (double)sxp[(size_t)c * K + k];
-    sx64[k] = s;
+#pragma unroll 4
+    for (int c = sl; c < chunks; c += 16) s += (double)sxp[(size_t)c * K + k];
+  }
+  red[sl][e] = s;
+  __syncthreads();
+  if (sl == 0 && i < total + K) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][e];
+    if (i < total) G64[i] = t;
+    else sx64[i - total] = t;
   }
 }
 
 // dW[n][k] = sum over chunks of pw[chunk][n][k]  +  alpha[n] sum_j W[n][j] G[j][k]  +  beta[n] sx[k]
-// (w = W_l [N][K] row-major).  Thread per (n, k), lanes along k.
+// (w = W_l [N][K] row-major).  16 elements (lanes along k) x 16 slices per workgroup: a slice adds
+// every 16th chunk and every 16th j, the slices meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void gram_finish_kernel(
     int N, int K, int chunks, const float *__restrict__ pw, const float *__restrict__ w,
     const float *__restrict__ alpha, const float *__restrict__ beta,
     const double *__restrict__ G64, const double *__restrict__ sx64, float *__restrict__ dw) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * K) return;
-  const int n = i / K, k = i - n * K;
-  double s = 0.0;
-#pragma unroll 8
-  for (int c = 0; c < chunks; ++c) s += (double)pw[(size_t)c * N * K + i];
-  double d = 0.0;
-  const float *wr = w + (size_t)n * K;
-#pragma unroll 8
-  for (int j = 0; j < K; ++j) d += (double)wr[j] * G64[(size_t)j * K + k];
-  dw[i] = (float)(s + (double)alpha[n] * d + (double)beta[n] * sx64[k]);
+  __shared__ double red[2][16][17];
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + e;
+  double s = 0.0, d = 0.0;
+  int n = 0, k = 0;
+  if (i < N * K) {
+    n = i / K;
+    k = i - n * K;
+#pragma unroll 4
+    for (int c = sl; c < chunks; c += 16) s += (double)pw[(size_t)c * N * K + i];
+    const float *wr = w + (size_t)n * K;
+    for (int j = sl; j < K; j += 16) d += (double)wr[j] * G64[(size_t)j * K + k];
+  }
+  red[0][sl][e] = s;
+  red[1][sl][e] = d;
+  __syncthreads();
+  if (sl == 0 && i < N * K) {
+    double ts = 0.0, td = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      ts += red[0][q][e];
+      td += red[1][q][e];
+    }
+    dw[i] = (float)(ts + (double)alpha[n] * td + (double)beta[n] * sx64[k]);
+  }
 }
 
 // dw[i] = sum over chunks of pw[chunk][i], fixed order; EL elements x SL chunk slices per block
@@ -4843,16 +5328,28 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
 // w = W_l [n][k] (row-major, leading dimension k), wt = W_l^T [k][ldw]; arg / dcl / alpha / beta:
 // what btr_sa_pool_bwd_coef left.  pw: [btr_sa_bwd_gram_chunks()][n][k] floats, gscratch:
 // btr_sa_bwd_gram_scratch_floats() floats, spart: [chunks][2][k].
+// the producer / consumer form (sa_bwd_gram_ws_kernel): n <= 128, k <= 64; BTR_GRAM_WS=0: never
+static bool gram_ws(int n, int k) {
+  const char *e = getenv("BTR_GRAM_WS");
+  return n <= 128 && k <= 64 && !(e && e[0] == '0');
+}
 int btr_sa_bwd_gram_supported(int rows, int n, int k) {
   const char *e = getenv("BTR_POOL_GRAM");   // (read per call: the tests toggle it)
   const bool off = e && e[0] == '0';
-  return !off && btr_sa_bwd_fused_supported(rows, n, k) && k <= 128 && !fused_split(n);
+  // default: the shapes of the producer / consumer kernel (n <= 128, k <= 64: SA1's pooled layer);
+  // BTR_POOL_GRAM=2: every shape the single-role kernel covers as well (k <= 128) -- measured
+  // equal to the Y_l-reading form there (tools/bwd_gram_ab.py), so only the forward's store is won
+  const bool all = e && e[0] == '2';
+  return !off && btr_sa_bwd_fused_supported(rows, n, k) && k <= 128 && !fused_split(n) &&
+         (all || gram_ws(n, k));
 }
 static int gram_chunks(int rows, int n, int k) {
-  const int per_cu = (n > 128 || k > 64) ? 1 : 2;
+  const int per_cu = (n > 128 || k > 64 || gram_ws(n, k)) ? 1 : 2;
   const int resident = cu_mask_avail_cus() * per_cu * grid_rounds();
   const int kblocks = (k + 63) / 64;
-  const int want = std::max(32, resident / kblocks);
+  int want = std::max(32, resident / kblocks);
+  // (the producer / consumer form keeps a chunk's block -> group table in LDS)
+  if (gram_ws(n, k)) want = std::max(want, cdiv(rows, 8 * kGramWsMaxBlocks - 64));
   return std::max(1, std::min(std::min(want, kFusedMaxChunks * grid_rounds()), cdiv(rows, 32)));
 }
 int btr_sa_bwd_gram_chunks(int rows, int n, int k) { return gram_chunks(rows, n, k); }
@@ -4877,12 +5374,14 @@ int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float
               "sa_bwd_gram: nsample %d must be 16, 32, 64 or 128", s);
   hipStream_t st = as_stream(stream);
   const int chunks = gram_chunks(rows, n, k);
+  BTR_REQUIRE(!gram_ws(n, k) || cdiv(cdiv(rows, chunks), 32) * 32 <= 8 * kGramWsMaxBlocks,
+              "sa_bwd_gram: %d rows in %d chunks exceed the block table", rows, chunks);
   const size_t kk = (size_t)k * k;
   float *M = gscratch, *cvec = M + kk, *gp = cvec + k, *sxp = gp + (size_t)chunks * kk;
   size_t off = (size_t)(sxp + (size_t)chunks * k - gscratch);
   off = (off + 1) & ~(size_t)1;   // float64 from here on (gscratch itself is 256-byte aligned)
   double *G64 = reinterpret_cast<double *>(gscratch + off), *sx64 = G64 + kk;
-  hipLaunchKernelGGL(gram_prep_kernel, dim3(cdiv(k, 16), cdiv(k, 16)), dim3(256), 0, st, n, k, wt,
+  hipLaunchKernelGGL(gram_prep_kernel, dim3(cdiv(k, 16), cdiv(k, 4)), dim3(256), 0, st, n, k, wt,
                      ldw, alpha, beta, M, cvec);
   GramArgs a{};
   a.X = x; a.ldx = ldx; a.R = rows; a.N = n; a.K = k;
@@ -4890,10 +5389,19 @@ int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float
   a.pa = pa; a.pb = pb; a.mu_p = mu_p; a.is_p = is_p; a.Wt = wt; a.ldw = ldw; a.M = M;
   a.cvec = cvec; a.Z = dz; a.ldz = ldz; a.pw = pw; a.gp = gp; a.sxp = sxp; a.spart = spart;
   a.garg = arg; a.gdcl = dcl; a.SSH = ilog2(s); a.ldt = n;
+  {
+    const char *e = getenv("BTR_GRAM_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
   const dim3 grid(1, cdiv(k, 64), chunks);
 #define BTR_GRAM(W, KF) \
   hipLaunchKernelGGL((sa_bwd_gram_kernel<W, KF>), grid, dim3(256), 0, st, a, cur_compact())
-  if (k <= 64) {
+  if (gram_ws(n, k)) {
+    if (n > 64)
+      hipLaunchKernelGGL((sa_bwd_gram_ws_kernel<4>), grid, dim3(512), 0, st, a, cur_compact());
+    else
+      hipLaunchKernelGGL((sa_bwd_gram_ws_kernel<2>), grid, dim3(512), 0, st, a, cur_compact());
+  } else if (k <= 64) {
     if (n > 128) BTR_GRAM(8, 64); else if (n > 64) BTR_GRAM(4, 64); else BTR_GRAM(2, 64);
   } else {
     if (n > 128) BTR_GRAM(8, 128); else if (n > 64) BTR_GRAM(4, 128); else BTR_GRAM(2, 128);
@@ -4902,9 +5410,9 @@ int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float
   const double count = host_compact().on ? host_compact().count : (double)rows;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(k, kRedCh)), dim3(256), 0, st, k, chunks,
                      count, spart, m1, m2, dgamma, dbeta);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((int)kk + k, 256)), dim3(256), 0, st, k, chunks,
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv((int)kk + k, 16)), dim3(256), 0, st, k, chunks,
                      gp, sxp, G64, sx64);
-  hipLaunchKernelGGL(gram_finish_kernel, dim3(cdiv(n * k, 256)), dim3(256), 0, st, n, k, chunks,
+  hipLaunchKernelGGL(gram_finish_kernel, dim3(cdiv(n * k, 16)), dim3(256), 0, st, n, k, chunks,
                      pw, w, alpha, beta, G64, sx64, dw);
   return check_launch("sa_bwd_gram");
 }

@@ -430,6 +430,8 @@ def _sa_options():
             os.environ.get("BTR_BWD_FUSED", "1") != "0" and
             os.environ.get("BTR_GEMM", "") != "f32"):
         o |= _ext.SA_OPT_POOL_GRAM
+        if os.environ.get("BTR_POOL_GRAM", "1") == "2":   # (every covered shape: csrc/sa_mlp.hip
+            o |= 32                                        # reads it; here it only keys the caches)
     return o
 
 

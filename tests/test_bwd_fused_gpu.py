@@ -162,6 +162,12 @@ def _run_gram(dev, rows, n, k, s, seed=0, ldx_pad=0):
     return (dz, dw, dg, db, m1, m2), (dz_ref, dw_ref, s2_ref, s1_ref, s1_ref / rows, s2_ref / rows)
 
 
+@pytest.fixture(autouse=True)
+def _all_gram_shapes(monkeypatch):
+    # (the default policy takes the producer / consumer kernel's shapes only: n <= 128, k <= 64)
+    monkeypatch.setenv("BTR_POOL_GRAM", "2")
+
+
 @pytest.mark.parametrize("rows,n,k,s", [
     (4096, 128, 64, 64),       # SA1's pooled layer
     (4096, 256, 128, 32),      # SA2's: the 256-wide variant, two k blocks

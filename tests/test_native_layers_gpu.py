@@ -115,14 +115,14 @@ def test_gram_form_equals_the_y_reading_form(cuda, monkeypatch, N, npoint, radiu
             layer.bn.bn.bias.uniform_(-0.3, 0.3)
     inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
     res, plans = {}, {}
-    for flag in ("0", "1"):
+    for flag in ("0", "2"):   # (2: every shape the Gram form covers, not only the default policy's)
         monkeypatch.setenv("BTR_POOL_GRAM", flag)
         mod = copy.deepcopy(sa)
         res[flag] = _sa_run(mod, xyz, feats, inds, False, feat_grad)
         plans[flag] = [ent[1].pool_grad for ent in fused_sa._LAYER_CACHE.get(mod, {}).values()]
-    assert plans["0"] == [1] and plans["1"] == [2], plans   # (the variant that actually ran)
+    assert plans["0"] == [1] and plans["2"] == [2], plans   # (the variant that actually ran)
     for k, want in res["0"].items():
-        got = res["1"][k]
+        got = res["2"][k]
         assert (want is None) == (got is None), k
         if want is None:
             continue
