@@ -1751,6 +1751,8 @@ struct StreamArgs {
   float *gext;
   unsigned char *aext;
   int hs;               // log2 of the 128-column slabs of n (n > 128: two workgroups per row chunk)
+  int nchunks;          // sa_fwd_ws_kernel: row chunks of the single-role grid (`part` rows)
+  int cpw;              // ... and how many of them a workgroup takes (2, or 1)
 };
 
 template <int BR, int KMAX, int PRO, bool STATS, int PS>
@@ -1988,6 +1990,356 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
       if (cb + col < N) a.part[((size_t)chunk * 2 + which) * N + cb + col] = (float)sum;
     }
   }
+}
+
+// ---- ... with producer and consumer waves (see sa_bwd_gram_ws_kernel) ---------------------------
+// sa_fwd_stream_kernel runs staging (VALU), products (LDS reads + MFMA) and epilogue (VALU +
+// stores) one after the other in every wave, and needs ~3x its MFMA time per step (SA1's pooled
+// layer: 2.6 us per 32-row step and workgroup for 0.4 us of matrix issue).  Here a 512-thread
+// workgroup (one per CU) splits the roles: waves 0-3 load rows two steps ahead, apply the
+// prologue, split and write the bf16 planes of step i+1 (double-buffered); waves 4-7 own one
+// 32 x 32 output tile each, multiply step i out of the other plane buffer and run the epilogue of
+// step i-1 on a second accumulator set -- independent instruction streams the scheduler
+// interleaves, so the epilogue's VALU work issues in the shadow of the MFMAs.  One barrier per
+// step.  Same arithmetic, same summation order and the SAME statistics partials as
+// sa_fwd_stream_kernel: a workgroup takes two consecutive row chunks of that kernel's grid and
+// writes a `part` row for each, so bn_finalize_kernel and every caller stay as they are (results
+// bit-identical to the single-role kernel).  BTR_FWD_WS=0: the single-role kernel.
+template <int BR, int KMAX, int PRO, bool STATS, int PS>
+__global__ __launch_bounds__(512, (KMAX == 64 && PS == 0) ? 4 : 2) void sa_fwd_ws_kernel(StreamArgs a, Compact cm) {
+  static_assert((BR == 32 || BR == 64) && (KMAX == 64 || KMAX == 128), "tile shapes");
+  static_assert(PS == 0 || PS == 8 || PS == 16, "pooling epilogue: blocks of 8 / groups of 16");
+  constexpr int WR = BR / 32;           // row tiles (consumer waves along the rows)
+  constexpr int WC = 4 / WR;            // column tiles: n <= 32 * WC
+  constexpr int LX = KMAX + 8;          // bf16 pitch (conflict-free 16-byte row reads)
+  constexpr int KS = KMAX / 16;
+  constexpr int TPR = KMAX / 4;         // staging threads per row
+  constexpr int RP = 256 / TPR;         // rows per staging pass
+  constexpr int NP = BR / RP;           // staging passes
+  constexpr int LT = 36;
+  constexpr int XPB = 3 * BR * LX;
+  int R = a.R, rows_per_chunk = a.rows_per_chunk;   // (chunk = the single-role kernel's)
+  const int nchunks = a.nchunks;
+  if (cm.dims) {
+    R = cm.dims[0];
+    rows_per_chunk = ((R + nchunks - 1) / nchunks + BR - 1) / BR * BR;
+  }
+  const int N = a.N, K = a.K;
+  const int pair = (int)blockIdx.x >> a.hs, cb = ((int)blockIdx.x & ((1 << a.hs) - 1)) * 128;
+  __shared__ __attribute__((aligned(16))) __bf16 Xp[2 * XPB];
+  __shared__ __attribute__((aligned(16))) float Ts[4][32 * LT];
+  __shared__ double red[STATS ? 2 * WR * 32 * WC : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // rows of this workgroup: chunks 2 * pair and 2 * pair + 1 of the single-role grid
+  // (a.cpw == 1, BTR_FWD_WS=2: one chunk per workgroup -- two workgroups per CU where the
+  // registers allow it)
+  const int c0 = a.cpw * pair;
+  const int rbeg = min(R, c0 * rows_per_chunk);
+  const int rmid = min(R, rbeg + rows_per_chunk);       // first row of the second chunk
+  const int rend = min(R, rbeg + a.cpw * rows_per_chunk);
+  const int nsteps = (rend - rbeg + BR - 1) / BR;
+  const int nsteps2 = (nsteps + 1) & ~1;
+  const std::integral_constant<int, 0> P0{};
+  const std::integral_constant<int, 1> P1{};
+  if (wave < 4) {
+    // ================================================================== producers
+    const int xc4 = (tid % TPR) * 4, xr = tid / TPR;
+    float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PRO && xc4 < K) {
+      fa = *reinterpret_cast<const float4 *>(a.pa + xc4);
+      fb = *reinterpret_cast<const float4 *>(a.pb + xc4);
+    }
+    float4 w0r[PRO == 3 ? 4 : 1];
+    if constexpr (PRO == 3) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w0r[e] = (xc4 + e < K) ? *reinterpret_cast<const float4 *>(a.w0 + (size_t)(xc4 + e) * 4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 rx[2][NP];
+    auto fetch = [&](auto P, int r0) {
+      constexpr int p = decltype(P)::value;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int row = xr + RP * j;
+        rx[p][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + row < rend && xc4 < K)
+          rx[p][j] = PRO == 3
+                         ? *reinterpret_cast<const float4 *>(a.A + (size_t)(r0 + row) * 4)
+                         : *reinterpret_cast<const float4 *>(a.A + (size_t)(r0 + row) * a.lda + xc4);
+      }
+    };
+    auto stage = [&](auto P, int r0) {
+      constexpr int p = decltype(P)::value;
+      __bf16 *xp = Xp + p * XPB;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int row = xr + RP * j;
+        float4 x = rx[p][j];
+        const bool live = r0 + row < rend && xc4 < K;
+        if constexpr (PRO == 3) {
+          if (live)
+            x = make_float4(rc_dot4(x, w0r[0]), rc_dot4(x, w0r[1]), rc_dot4(x, w0r[2]),
+                            rc_dot4(x, w0r[3]));
+        }
+        if (PRO != 0 && live) {
+          x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
+          x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
+          x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
+          x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
+        }
+        if (!live) x = make_float4(0.f, 0.f, 0.f, 0.f);   // padded rows / columns stay exactly 0
+        const Split4 sp = split4(x);
+        const int at = row * LX + xc4;
+        *reinterpret_cast<bf16x4 *>(&xp[0 * BR * LX + at]) = sp.h;
+        *reinterpret_cast<bf16x4 *>(&xp[1 * BR * LX + at]) = sp.m;
+        *reinterpret_cast<bf16x4 *>(&xp[2 * BR * LX + at]) = sp.l;
+      }
+    };
+    fetch(P0, rbeg);
+    fetch(P1, rbeg + BR);
+    stage(P0, rbeg);
+    fetch(P0, rbeg + 2 * BR);
+    __syncthreads();
+    for (int i = 0; i < nsteps2; i += 2) {
+      const int r0 = rbeg + i * BR;
+      stage(P1, r0 + BR);
+      fetch(P1, r0 + 3 * BR);
+      __syncthreads();
+      stage(P0, r0 + 2 * BR);
+      fetch(P0, r0 + 4 * BR);
+      __syncthreads();
+    }
+  } else {
+    // ================================================================== consumers
+    const int cw = wave - 4;
+    const int wr = cw / WC, wc = cw % WC;
+    const int l31 = lane & 31, h = lane >> 5;
+    bf16x8 bdr[KS][3];
+    {
+      const int nr = cb + wc * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kb = ks * 16 + h * 8;
+        float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+        if (nr < N && kb < K) w0 = *reinterpret_cast<const float4 *>(a.W + (size_t)nr * a.ldw + kb);
+        if (nr < N && kb + 4 < K)
+          w1 = *reinterpret_cast<const float4 *>(a.W + (size_t)nr * a.ldw + kb + 4);
+        const Split4 s0 = split4(w0), s1 = split4(w1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bdr[ks][0][e] = s0.h[e]; bdr[ks][0][4 + e] = s1.h[e];
+          bdr[ks][1][e] = s0.m[e]; bdr[ks][1][4 + e] = s1.m[e];
+          bdr[ks][2][e] = s0.l[e]; bdr[ks][2][4 + e] = s1.l[e];
+        }
+      }
+    }
+    const int col = cb + wc * 32 + l31;
+    const float sg = (PS > 0 && col < N && a.gsign[col] < 0.f) ? -1.f : 1.f;
+    double d1 = 0.0, d2 = 0.0;
+    f32x16 acc[2];
+    float bwx[2][4];
+    const int oA = (wr * 32 + l31) * LX + h * 8;   // this lane's fragment row inside a plane
+    auto mma = [&](auto P) {
+      constexpr int p = decltype(P)::value;
+      const __bf16 *xp = Xp + p * XPB + oA;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks * 16 >= K) break;
+        bf16x8 af[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          af[q] = *reinterpret_cast<const bf16x8 *>(xp + q * BR * LX + ks * 16);
+        const bf16x8 *bd = bdr[ks];
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bd[0], acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bd[2], acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bd[1], acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bd[0], acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bd[1], acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bd[0], acc[p], 0, 0, 0);
+      }
+    };
+    // (weight - 1) of this wave's four 8-row blocks of the step at r0 (compact rows)
+    auto load_bw = [&](auto P, int r0) {
+      constexpr int p = decltype(P)::value;
+      if (STATS && cm.bw) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = r0 + wr * 32 + 8 * q;
+          bwx[p][q] = row < rend ? cm.bw[row >> 3] - 1.f : 0.f;
+        }
+      }
+    };
+    // epilogue of the step at r0 on accumulator set P: D layout col = lane & 31,
+    // row = (v & 3) + 8 * (v >> 2) + 4 * h
+    auto epilogue = [&](auto P, int r0) {
+      constexpr int p = decltype(P)::value;
+      const int wrow0 = r0 + wr * 32;
+      if constexpr (STATS) {   // rows >= rend hold exact zeros
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const float c = acc[p][v];
+          s1 += c;
+          s2 = fmaf(c, c, s2);
+          if (cm.bw && h == 0 && (v & 3) == 0) {
+            const float wx = bwx[p][v >> 2];
+            s1 = fmaf(wx, c, s1);
+            s2 = fmaf(wx * c, c, s2);
+          }
+        }
+        d1 += (double)s1;
+        d2 += (double)s2;
+      }
+      if constexpr (PS > 0) {
+        float bestv[4];
+        int bestr[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          float vmx = -3.0e38f;
+          int imx = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float c = acc[p][4 * b + q] * sg;
+            if (c > vmx) {
+              vmx = c;
+              imx = q;
+            }
+          }
+          const int mine = imx + 4 * h;
+          const float omx = __shfl_xor(vmx, 32);
+          const int oix = __shfl_xor(mine, 32);
+          const bool take = omx > vmx || (omx == vmx && oix < mine);
+          bestv[b] = take ? omx : vmx;
+          bestr[b] = take ? oix : mine;
+        }
+        if constexpr (PS == 8) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int grow = wrow0 + b * 8;
+            if (h == 0 && grow < rend && col < N) {
+              const size_t o = (size_t)(grow >> 3) * N + col;
+              a.gext[o] = bestv[b] * sg;
+              a.aext[o] = (unsigned char)bestr[b];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; b += 2) {
+            const bool second = bestv[b + 1] > bestv[b];
+            const int grow = wrow0 + b * 8;
+            if (h == 0 && grow < rend && col < N) {
+              const size_t o = (size_t)(grow >> 4) * N + col;
+              a.gext[o] = (second ? bestv[b + 1] : bestv[b]) * sg;
+              a.aext[o] = (unsigned char)(second ? 8 + bestr[b + 1] : bestr[b]);
+            }
+          }
+        }
+      }
+      if (a.C != nullptr) {
+        float *T = Ts[cw];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) T[((v & 3) + 8 * (v >> 2) + 4 * h) * LT + l31] = acc[p][v];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the tile is private to the wave)
+        __builtin_amdgcn_wave_barrier();
+        const int rl = lane >> 3, c4 = (lane & 7) * 4;
+        const int colw = cb + wc * 32 + c4;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const float4 q4 = *reinterpret_cast<const float4 *>(&T[(it * 8 + rl) * LT + c4]);
+          const int row = wrow0 + it * 8 + rl;
+          if (row < rend && colw < N)
+            *reinterpret_cast<float4 *>(a.C + (size_t)row * a.ldc + colw) = q4;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    };
+    // statistics of the first chunk leave when the steps cross rmid (a multiple of BR)
+    double keep1 = 0.0, keep2 = 0.0;
+    bool first_done = false;
+    auto after_step = [&](int r0_done) {   // the step at r0_done has been added to d1 / d2
+      if (STATS && !first_done && r0_done + BR >= rmid) {
+        keep1 = d1;
+        keep2 = d2;
+        d1 = d2 = 0.0;
+        first_done = true;
+      }
+    };
+    load_bw(P0, rbeg);
+    __syncthreads();   // (the producers' first planes)
+    for (int i = 0; i < nsteps2; i += 2) {
+      const int r0 = rbeg + i * BR;
+      mma(P0);
+      load_bw(P1, r0 + BR);
+      if (i >= 1) {
+        epilogue(P1, r0 - BR);
+        after_step(r0 - BR);
+      }
+      __syncthreads();
+      mma(P1);
+      load_bw(P0, r0 + 2 * BR);
+      epilogue(P0, r0);
+      after_step(r0);
+      __syncthreads();
+    }
+    if (nsteps2 >= 1) {
+      epilogue(P1, rbeg + (nsteps2 - 1) * BR);
+      after_step(rbeg + (nsteps2 - 1) * BR);
+    }
+    if constexpr (STATS) {
+      if (!first_done) {   // (no rows at all in the second chunk)
+        keep1 = d1;
+        keep2 = d2;
+        d1 = d2 = 0.0;
+      }
+      // lanes' sums of chunk 0 and chunk 1 -> LDS, row tiles added in the single-role kernel's order
+      keep1 += __shfl_xor(keep1, 32);
+      keep2 += __shfl_xor(keep2, 32);
+      d1 += __shfl_xor(d1, 32);
+      d2 += __shfl_xor(d2, 32);
+      if (h == 0) {
+        red[(0 * WR + wr) * 32 * WC + wc * 32 + l31] = keep1;
+        red[(1 * WR + wr) * 32 * WC + wc * 32 + l31] = keep2;
+      }
+    }
+    // ---- the two `part` rows (three barriers the producers attend as well)
+    __syncthreads();
+    if constexpr (STATS) {
+      for (int c = (tid - 256); c < 2 * 32 * WC; c += 256) {
+        const int which = c / (32 * WC), ccol = c % (32 * WC);
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < WR; ++w) sum += red[(which * WR + w) * 32 * WC + ccol];
+        if (cb + ccol < N && c0 < nchunks)
+          a.part[((size_t)c0 * 2 + which) * N + cb + ccol] = (float)sum;
+      }
+    }
+    __syncthreads();
+    if constexpr (STATS) {
+      if (h == 0) {
+        red[(0 * WR + wr) * 32 * WC + wc * 32 + l31] = d1;
+        red[(1 * WR + wr) * 32 * WC + wc * 32 + l31] = d2;
+      }
+    }
+    __syncthreads();
+    if constexpr (STATS) {
+      for (int c = (tid - 256); c < 2 * 32 * WC; c += 256) {
+        const int which = c / (32 * WC), ccol = c % (32 * WC);
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < WR; ++w) sum += red[(which * WR + w) * 32 * WC + ccol];
+        if (cb + ccol < N && a.cpw == 2 && c0 + 1 < nchunks)
+          a.part[((size_t)(c0 + 1) * 2 + which) * N + cb + ccol] = (float)sum;
+      }
+    }
+    return;
+  }
+  // (producers: the consumers' three closing barriers)
+  __syncthreads();
+  __syncthreads();
+  __syncthreads();
 }
 
 // ---- single-launch inference set-abstraction layer ---------------------------------------------
@@ -2265,6 +2617,7 @@ struct FusedArgs {
   int acc;
   // GM 2: layer l's scale, shift, mean, invstd and finalised m1, m2
   const float *sc, *sh, *mu, *is, *m1, *m2;
+  int eager;   // measurement only (BTR_FUSED_EAGER=1)
 };
 
 // TNW = 2 / 4: n <= 64 / 128, two workgroups per CU.  TNW = 8: n <= 256 (the pooled layers of
@@ -2387,14 +2740,20 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
   float4 rg[GPASS], ry[GM == 2 ? GPASS : 1], rx[2], ykeep[2];
   const int sp_gi = tid / TN, sp_n = tid % TN;
   constexpr int SPQ = 4 * TN / 256;
-  int sp_g[SPQ], sp_ng[SPQ], sp_lr[SPQ];
+  // (the entries' loads are kept RAW -- first row of the group relative to the step, arg-max
+  // byte, value -- and turned into local rows in put_table(), behind the MFMAs: a comparison
+  // formed from a load inside fetch() parks the wave on that load, one L2 round trip per entry
+  // and step with nothing in flight to hide it)
+  int sp_g[SPQ], sp_ng[SPQ], sp_base[SPQ], sp_arg[SPQ];
   float sp_dv[SPQ];
 #pragma unroll
   for (int q = 0; q < SPQ; ++q) {
     sp_g[q] = sp_ng[q] = 0;
-    sp_lr[q] = -1;
+    sp_base[q] = -0x40000000;   // (no entry)
+    sp_arg[q] = 0;
     sp_dv[q] = 0.f;
   }
+  int tb_r0 = 0;   // the step the raw entries belong to
   float gwt[GPASS];
   auto fetch = [&](int r0) {
 #pragma unroll
@@ -2411,31 +2770,42 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
       }
     }
     if (GPOOL && cm.bgrp) {
+      tb_r0 = r0;
 #pragma unroll
       for (int q = 0; q < SPQ; ++q) {
         const int slot = sp_gi + (256 / TN) * q, blk = (r0 >> 3) + slot;
         if (r0 != rbeg) sp_g[q] = sp_ng[q];
-        sp_lr[q] = -1;
+        sp_base[q] = -0x40000000;
         if (slot < 4 && (blk << 3) < rend && sp_n < N) {
           const int g = sp_g[q];
-          const int lr = cm.goff[g] - r0 + (int)a.garg[(size_t)g * a.ldt + sp_n];
+          sp_base[q] = cm.goff[g] - r0;
+          sp_arg[q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
           sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
-          sp_lr[q] = (lr >= 0 && (lr >> 3) == slot) ? lr : -1;
+          if (a.eager) {   // (A/B: BTR_FUSED_EAGER=1 forms the local row here, as before round 5)
+            const int lr = sp_base[q] + sp_arg[q];
+            sp_base[q] = (lr >= 0 && (lr >> 3) == slot) ? lr : -0x40000000;
+            sp_arg[q] = 0;
+          }
         }
         const int nblk = ((r0 + BR) >> 3) + slot;
         sp_ng[q] = (slot < 4 && (nblk << 3) < rend) ? cm.bgrp[nblk] : 0;
       }
     } else if (GPOOL) {
+      tb_r0 = r0;
 #pragma unroll
       for (int q = 0; q < SPQ; ++q) {
         const int slot = sp_gi + (256 / TN) * q;
         const int g = (r0 >> a.SSH) + slot;
-        sp_lr[q] = -1;
+        sp_base[q] = -0x40000000;
         if ((slot << a.SSH) < BR && (g << a.SSH) < rend && sp_n < N) {
-          const int arow = (g << a.SSH) + (int)a.garg[(size_t)g * a.ldt + sp_n];
+          sp_base[q] = (g << a.SSH) - r0;
+          sp_arg[q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
           sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
-          const int lr = arow - r0;
-          sp_lr[q] = (lr >= 0 && lr < BR && arow < rend) ? lr : -1;
+          if (a.eager) {
+            const int lr = sp_base[q] + sp_arg[q];
+            sp_base[q] = (lr >= 0 && lr < BR && r0 + lr < rend) ? lr : -0x40000000;
+            sp_arg[q] = 0;
+          }
         }
       }
     }
@@ -2468,7 +2838,10 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
 #pragma unroll
       for (int q = 0; q < SPQ; ++q) {
         const int slot = sp_gi + (256 / TN) * q;
-        sLr[slot * TN + sp_n] = sp_lr[q];
+        const int lr = sp_base[q] + sp_arg[q];
+        const bool hit = cm.bgrp ? (lr >= 0 && (lr >> 3) == slot)
+                                 : (lr >= 0 && lr < BR && tb_r0 + lr < rend);
+        sLr[slot * TN + sp_n] = hit ? lr : -1;
         sDv[slot * TN + sp_n] = sp_dv[q];
       }
     }
@@ -2853,12 +3226,15 @@ __global__ __launch_bounds__(256, (TNW == 8 || KF == 128) ? 1 : 2) void sa_bwd_g
   float wx[2] = {1.f, 1.f};
   const int sp_gi = tid / TN, sp_n = tid % TN;
   constexpr int SPQ = 4 * TN / 256;
-  int sp_g[SPQ], sp_ng[SPQ], sp_lr[SPQ], cl_lr[SPQ];
+  // (raw loads; the local row is formed when the step is staged: see sa_bwd_fused_kernel)
+  int sp_g[SPQ], sp_ng[SPQ], sp_base[SPQ], sp_arg[SPQ], cl_lr[SPQ];
   float sp_dv[SPQ];
 #pragma unroll
   for (int q = 0; q < SPQ; ++q) {
     sp_g[q] = sp_ng[q] = 0;
-    sp_lr[q] = cl_lr[q] = -1;
+    sp_base[q] = -0x40000000;
+    sp_arg[q] = 0;
+    cl_lr[q] = -1;
     sp_dv[q] = 0.f;
   }
   auto fetch = [&](int r0) {
@@ -2879,12 +3255,12 @@ __global__ __launch_bounds__(256, (TNW == 8 || KF == 128) ? 1 : 2) void sa_bwd_g
       for (int q = 0; q < SPQ; ++q) {
         const int slot = sp_gi + (256 / TN) * q, blk = (r0 >> 3) + slot;
         if (r0 != rbeg) sp_g[q] = sp_ng[q];
-        sp_lr[q] = -1;
+        sp_base[q] = -0x40000000;
         if (slot < 4 && (blk << 3) < rend && sp_n < N) {
           const int g = sp_g[q];
-          const int lr = cm.goff[g] - r0 + (int)a.garg[(size_t)g * a.ldt + sp_n];
+          sp_base[q] = cm.goff[g] - r0;
+          sp_arg[q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
           sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
-          sp_lr[q] = (lr >= 0 && (lr >> 3) == slot) ? lr : -1;
         }
         const int nblk = ((r0 + BR) >> 3) + slot;
         sp_ng[q] = (slot < 4 && (nblk << 3) < rend) ? cm.bgrp[nblk] : 0;
@@ -2894,12 +3270,11 @@ __global__ __launch_bounds__(256, (TNW == 8 || KF == 128) ? 1 : 2) void sa_bwd_g
       for (int q = 0; q < SPQ; ++q) {
         const int slot = sp_gi + (256 / TN) * q;
         const int g = (r0 >> a.SSH) + slot;
-        sp_lr[q] = -1;
+        sp_base[q] = -0x40000000;
         if ((slot << a.SSH) < BR && (g << a.SSH) < rend && sp_n < N) {
-          const int arow = (g << a.SSH) + (int)a.garg[(size_t)g * a.ldt + sp_n];
+          sp_base[q] = (g << a.SSH) - r0;
+          sp_arg[q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
           sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
-          const int lr = arow - r0;
-          sp_lr[q] = (lr >= 0 && lr < BR && arow < rend) ? lr : -1;
         }
       }
     }
@@ -2922,11 +3297,16 @@ __global__ __launch_bounds__(256, (TNW == 8 || KF == 128) ? 1 : 2) void sa_bwd_g
     // ---- sparse entries of this step: the three pieces of dcl at [local row][n]
 #pragma unroll
     for (int q = 0; q < SPQ; ++q) {
-      cl_lr[q] = sp_lr[q];
-      if (sp_lr[q] >= 0) {
+      const int slot = sp_gi + (256 / TN) * q;
+      const int lr0 = sp_base[q] + sp_arg[q];
+      const bool hit = cm.bgrp ? (lr0 >= 0 && (lr0 >> 3) == slot)
+                               : (lr0 >= 0 && lr0 < BR && r0 + lr0 < rend);
+      const int lr = hit ? lr0 : -1;
+      cl_lr[q] = lr;
+      if (lr >= 0) {
         __bf16 eh, em, el;
         split1(sp_dv[q], eh, em, el);
-        const int at = sp_lr[q] * LG + (swz(sp_lr[q], sp_n * 2) >> 1);
+        const int at = lr * LG + (swz(lr, sp_n * 2) >> 1);
         Sp[0 * BR * LG + at] = eh;
         Sp[1 * BR * LG + at] = em;
         Sp[2 * BR * LG + at] = el;
@@ -4369,6 +4749,68 @@ __global__ __launch_bounds__(256) void sa_pool_tile_kernel(
   }
 }
 
+// The same pool with four channels per thread (C % 4 == 0): a workgroup takes 32 groups x 128
+// channels, a thread one group's 16-byte channel quad -- 512-byte rows of gext and 128-byte rows
+// of aext per 32 lanes instead of 128-byte / 32-byte ones, and a quarter of the loop iterations
+// (SA1: 88 000 blocks x 128 channels, 59 us in the one-channel form for 56 MB).  Same selection
+// rule (blocks ascending, strict >), so the results are identical.
+__global__ __launch_bounds__(256) void sa_pool_tile4_kernel(
+    int M, int C, const float *__restrict__ gext, const unsigned char *__restrict__ aext,
+    const int *__restrict__ goff, const float *__restrict__ scale,
+    const float *__restrict__ shift, float *__restrict__ out, float *__restrict__ out_cl,
+    unsigned char *__restrict__ arg, float *__restrict__ ywin) {
+  __shared__ float T[128 * 33];
+  const int q = threadIdx.x & 31, gi = threadIdx.x >> 5;
+  const int c = (int)blockIdx.y * 128 + q * 4;
+  const long long g0 = (long long)blockIdx.x * 32;
+  const bool live = c < C;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (live) {
+    a = *reinterpret_cast<const float4 *>(scale + c);
+    b = *reinterpret_cast<const float4 *>(shift + c);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = gi + 8 * i;
+    const long long g = g0 + j;
+    float4 best = make_float4(-1.f, -1.f, -1.f, -1.f), by = make_float4(0.f, 0.f, 0.f, 0.f);
+    int ba[4] = {0, 0, 0, 0};
+    if (live) {
+      const int b0 = goff ? goff[g] >> 3 : (int)g, b1 = goff ? goff[g + 1] >> 3 : (int)g + 1;
+      for (int blk = b0; blk < b1; ++blk) {
+        const float4 e = *reinterpret_cast<const float4 *>(gext + (size_t)blk * C + c);
+        const uchar4 r = *reinterpret_cast<const uchar4 *>(aext + (size_t)blk * C + c);
+        const int off = goff ? (blk - b0) << 3 : 0;
+        const float vx = fmaxf(fmaf(a.x, e.x, b.x), 0.f), vy = fmaxf(fmaf(a.y, e.y, b.y), 0.f);
+        const float vz = fmaxf(fmaf(a.z, e.z, b.z), 0.f), vw = fmaxf(fmaf(a.w, e.w, b.w), 0.f);
+        if (vx > best.x) { best.x = vx; by.x = e.x; ba[0] = off + r.x; }
+        if (vy > best.y) { best.y = vy; by.y = e.y; ba[1] = off + r.y; }
+        if (vz > best.z) { best.z = vz; by.z = e.z; ba[2] = off + r.z; }
+        if (vw > best.w) { best.w = vw; by.w = e.w; ba[3] = off + r.w; }
+      }
+      const size_t o = (size_t)g * C + c;
+      if (out_cl) *reinterpret_cast<float4 *>(out_cl + o) = best;
+      *reinterpret_cast<uchar4 *>(arg + o) =
+          make_uchar4(best.x > 0.f ? (unsigned char)ba[0] : 0, best.y > 0.f ? (unsigned char)ba[1] : 0,
+                      best.z > 0.f ? (unsigned char)ba[2] : 0, best.w > 0.f ? (unsigned char)ba[3] : 0);
+      if (ywin) *reinterpret_cast<float4 *>(ywin + o) = by;
+    }
+    T[(q * 4 + 0) * 33 + j] = best.x;
+    T[(q * 4 + 1) * 33 + j] = best.y;
+    T[(q * 4 + 2) * 33 + j] = best.z;
+    T[(q * 4 + 3) * 33 + j] = best.w;
+  }
+  __syncthreads();
+  const long long bi = g0 / M;
+  const int m0 = (int)(g0 - bi * M);
+  const int j = threadIdx.x & 31;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int cl = gi + 8 * i, cc = (int)blockIdx.y * 128 + cl;
+    if (cc < C) out[((size_t)bi * C + cc) * M + m0 + j] = T[cl * 33 + j];
+  }
+}
+
 // Inverted neighbour lists of the compact rows of ONE batch element per workgroup (as
 // csr_small_kernel; rows goff[b*M] .. goff[(b+1)*M) of batch element b, N <= kCsrSmallN bins).
 __global__ __launch_bounds__(1024) void sac_csr_kernel(int M, int N, const int *__restrict__ cidx,
@@ -4653,9 +5095,31 @@ static bool stream_ok(int rows, int n, int k, int lda_ok, bool fin_armed) {
   return !off && gemm_x6() && !fin_armed && lda_ok && rows >= kStreamMinRows && n % 4 == 0 &&
          k % 4 == 0 && n <= (stream_wide() ? 256 : 128) && k <= 128 && !host_compact().dev.kz;
 }
+// BTR_FWD_WS=0: the single-role kernel for every layer (read per call: the tests compare the two)
+// MEASURED AND NOT ADOPTED (tools/fwd_ws_ab.py, same box, alone on the chip; single-role /
+// two chunks per workgroup / one chunk per workgroup): SA1's pooled layer 706 560 x 128 x 64 with
+// the Y store 160 / 258 / 182 us, without 100 / 172 / 118; SA1's 64-wide layer 72 / 73 / 74; SA2's
+// hidden layer 40 / 37 / 37; SA2's pooled layer 68 / 83 / 90; SA3's 46 / 53 / 71.  The forward
+// step carries 24 (k = 64) or 48 MFMAs per wave against ~250 VALU instructions of epilogue: it
+// is bound by issue latency with two waves per SIMD either way, and splitting the roles does not
+// add waves -- unlike the pooled layer's backward (72 MFMAs per step), where it does pay.
+// BTR_FWD_WS=1 / 2 select it; bit-identical results (tests/test_fwd_stream_gpu.py).
+static int fwd_ws() {
+  const char *e = getenv("BTR_FWD_WS");
+  return e ? atoi(e) : 0;
+}
 template <int BR, int KMAX, int PRO, bool STATS, int PS>
 static void launch_stream(int gx, hipStream_t st, StreamArgs &a) {
   a.rows_per_chunk = cdiv(cdiv(a.R, gx), BR) * BR;
+  a.nchunks = gx;
+  if constexpr (STATS) {   // (the producer / consumer form: the layers' forward GEMMs)
+    if (fwd_ws()) {
+      a.cpw = fwd_ws() == 2 ? 1 : 2;
+      hipLaunchKernelGGL((sa_fwd_ws_kernel<BR, KMAX, PRO, STATS, PS>),
+                         dim3(cdiv(gx, a.cpw) << a.hs), dim3(512), 0, st, a, cur_compact());
+      return;
+    }
+  }
   hipLaunchKernelGGL((sa_fwd_stream_kernel<BR, KMAX, PRO, STATS, PS>), dim3(gx << a.hs), dim3(256),
                      0, st, a, cur_compact());
 }
@@ -4861,6 +5325,11 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
 
 // sa_pool_tile_kernel takes the pools whose groups tile by 32 (BTR_POOL_TILE=0: the
 // thread-per-element kernels; read per call, the tests compare the two)
+// ... four channels per thread (c % 4 == 0; BTR_POOL_TILE4=0: the one-channel tile kernel)
+static bool pool_tile4(int c) {
+  const char *e = getenv("BTR_POOL_TILE4");
+  return c % 4 == 0 && !(e && e[0] == '0');
+}
 static bool pool_tiled(int m) {
   const char *e = getenv("BTR_POOL_TILE");
   return m % 32 == 0 && !(e && e[0] == '0');
@@ -4874,7 +5343,11 @@ int btr_sa_pool_fin_y(int b, int m, int c, const float *gext, const unsigned cha
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(gext && aext && scale && shift && out && arg, "sa_pool_fin: null pointer");
-  if (pool_tiled(m))
+  if (pool_tiled(m) && pool_tile4(c))
+    hipLaunchKernelGGL(sa_pool_tile4_kernel, dim3((unsigned)(groups / 32), cdiv(c, 128)), dim3(256),
+                       0, as_stream(stream), m, c, gext, aext, (const int *)nullptr, scale, shift,
+                       out, out_cl, arg, ywin);
+  else if (pool_tiled(m))
     hipLaunchKernelGGL(sa_pool_tile_kernel, dim3((unsigned)(groups / 32), cdiv(c, 32)), dim3(256),
                        0, as_stream(stream), m, c, gext, aext, (const int *)nullptr, scale, shift,
                        out, out_cl, arg, ywin);
@@ -5279,6 +5752,10 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
   a.Z = dz; a.ldz = ldz; a.pw = pw; a.spart = spart;
   a.garg = arg; a.gdcl = dcl; a.galpha = alpha; a.gbeta = beta; a.SSH = pooled ? ilog2(s) : 0;
   a.ldt = n;
+  {
+    const char *e = getenv("BTR_FUSED_EAGER");
+    a.eager = e && e[0] == '1';
+  }
   a.sc = sc; a.sh = sh; a.mu = mu; a.is = is; a.m1 = m1l; a.m2 = m2l;
   const dim3 grid(1, cdiv(k, 64), chunks);
 #define BTR_FUSED(W, GM, XR) \
@@ -5584,7 +6061,11 @@ int btr_sac_pool_y(int b, int m, int c, const float *gext, const unsigned char *
   const long long groups = (long long)b * m;
   if (groups <= 0 || c <= 0) return BTR_OK;
   BTR_REQUIRE(gext && aext && goff && scale && shift && out && arg, "sac_pool: null pointer");
-  if (pool_tiled(m))
+  if (pool_tiled(m) && pool_tile4(c))
+    hipLaunchKernelGGL(sa_pool_tile4_kernel, dim3((unsigned)(groups / 32), cdiv(c, 128)), dim3(256),
+                       0, as_stream(stream), m, c, gext, aext, goff, scale, shift, out, out_cl,
+                       arg, ywin);
+  else if (pool_tiled(m))
     hipLaunchKernelGGL(sa_pool_tile_kernel, dim3((unsigned)(groups / 32), cdiv(c, 32)), dim3(256),
                        0, as_stream(stream), m, c, gext, aext, goff, scale, shift, out, out_cl,
                        arg, ywin);

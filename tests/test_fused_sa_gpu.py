@@ -217,8 +217,11 @@ def test_tiled_pool_equals_the_per_element_pool(cuda, monkeypatch, compact, widt
     xyz = torch.rand(2, 3000, 3, generator=g).to(cuda)
     feats = torch.randn(2, 4, 3000, generator=g).to(cuda)
     outs = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("BTR_POOL_TILE", flag)
+    # "1": the four-channels-per-thread tile kernel where c % 4 == 0 (sa_pool_tile4_kernel),
+    # "t1": the one-channel tile kernel, "0": thread per element
+    for flag in ("1", "t1", "0"):
+        monkeypatch.setenv("BTR_POOL_TILE", flag[-1])
+        monkeypatch.setenv("BTR_POOL_TILE4", "0" if flag == "t1" else "1")
         torch.manual_seed(0)
         sa = M.PointnetSAModuleVotes(npoint=256, radius=0.2, nsample=32, mlp=[4, 32, width],
                                      use_xyz=True, normalize_xyz=True).to(cuda)
@@ -230,11 +233,13 @@ def test_tiled_pool_equals_the_per_element_pool(cuda, monkeypatch, compact, widt
         (nf * torch.linspace(0.5, 1.5, nf.shape[2], device=cuda)).sum().backward()
         outs[flag] = (nf.detach(), f.grad, sa.mlp_module.layer0.conv.weight.grad,
                       sa.mlp_module.layer1.conv.weight.grad)
-    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["t1"][0], outs["0"][0])
     # (same arg-max routing: the gradients agree to the rounding of their own reductions -- the
     # compact rows' scatter adds with atomics)
-    for a, b in zip(outs["1"][1:], outs["0"][1:]):
-        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), float((a - b).abs().max())
+    for k in ("1", "t1"):
+        for a, b in zip(outs[k][1:], outs["0"][1:]):
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), (
+                k, float((a - b).abs().max()))
 
 
 @pytest.mark.parametrize("N,npoint,radius,S,mlp,C,feat_grad", [
