@@ -447,6 +447,32 @@ int btr_backbone_forward(const btr_backbone_t *dp, const btr_backbone_plan_t *pp
   }
   const float *xyz = d.c > 0 ? at_f(geom, p.g_xyz) : cloud;
   const float *feats = d.c > 0 ? at_f(geom, p.g_feat) : nullptr;
+  // ---- the weight preparation of all levels and modules as ONE launch: a collecting pass over
+  // the same calls (they add their layers and return), then the launch, then the real pass
+  // (BTR_PREP_BATCH=0: every call preps itself, six launches)
+  static const bool prep_batched = !(getenv("BTR_PREP_BATCH") && getenv("BTR_PREP_BATCH")[0] == '0');
+  struct PrepScope {
+    bool on;
+    ~PrepScope() { if (on) prep_batch_end(); }
+  } prep_scope{prep_batched};
+  if (prep_batched) {
+    prep_batch_begin();
+    const float *cx = xyz, *cf = feats;
+    for (int l = 0; l < d.levels; ++l) {
+      const SaGeom sg = level_geom(p, geom, l);
+      BTR_TRY(sa_layer_forward_geom(&d.sa[l], &p.sa[l], cx, at_f(geom, p.g_new_xyz[l]), cf,
+                                    at_i(geom, p.g_idx[l]), at_f(out, p.o_sa[l]),
+                                    at_f(out, p.o_sa_cl[l]), (char *)saved + p.s_sa[l], scratch,
+                                    &sg, stream));
+      cx = at_f(geom, p.g_new_xyz[l]);
+      cf = at_f(out, p.o_sa_cl[l]);
+    }
+    for (int j = 0; j < d.fps; ++j)
+      BTR_TRY(btr_pm_chain_forward(&d.fp[j], &p.fp[j], nullptr, at_f(saved, p.s_fpx[j]),
+                                   at_f(out, p.o_fp[j]), at_f(out, p.o_fp_cl[j]),
+                                   (char *)saved + p.s_fp[j], scratch, stream));
+    prep_batch_launch(st);
+  }
   for (int l = 0; l < d.levels; ++l) {
     if (ev && l > 0) (void)hipStreamWaitEvent(st, ev->level[l], 0);
     const float *new_xyz = at_f(geom, p.g_new_xyz[l]);

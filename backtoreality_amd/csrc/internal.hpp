@@ -75,6 +75,12 @@ struct BnFin {
   float eps, momentum;
 };
 constexpr int kBnTickets = 8;  // tickets per statistics GEMM (column blocks of >= 64 channels, n <= 512)
+// sa_layer.hip: one weight-preparation launch for the layer calls between _begin and _end (issued
+// twice by the caller: a collecting pass before _launch, the real pass after it)
+void prep_batch_begin();
+void prep_batch_launch(hipStream_t st);
+void prep_batch_end();
+bool bnfin_rows_ok(long long rows);   // would bnfin_arm() accept a GEMM over this many rows?
 bool bnfin_arm(const BnFin &fin, long long rows);
 
 // sa_mlp.hip: btr_sa_bn_finalize; rbias (nbias entries, may be NULL): running_mean += momentum * rbias

@@ -43,16 +43,17 @@ struct Bump {
 // ---------------------------------------------------------------- weight preparation kernel
 // One launch per layer stack: W2[l] = W[l] zero-padded to (np[l], kin[l]) and Wt[l] = W2[l]^T
 // (the operands of the forward / input-gradient GEMMs), and num_batches_tracked += 1.
-struct PrepArgs {
-  const float *w[kMaxL];
-  float *w2[kMaxL];
-  float *wt[kMaxL];
-  int n[kMaxL];      // rows of W
-  int np[kMaxL];     // rows of W2 (zero rows beyond n)
-  int kraw[kMaxL];   // columns of W
-  int kin[kMaxL];    // columns of W2 (zero columns beyond kraw)
-  int first[kMaxL + 1];  // first block of layer l
-  long long *nbt[kMaxL];
+template <int ML>
+struct PrepArgsT {
+  const float *w[ML];
+  float *w2[ML];
+  float *wt[ML];
+  int n[ML];      // rows of W
+  int np[ML];     // rows of W2 (zero rows beyond n)
+  int kraw[ML];   // columns of W
+  int kin[ML];    // columns of W2 (zero columns beyond kraw)
+  int first[ML + 1];  // first block of layer l
+  long long *nbt[ML];
   int layers;
   unsigned *tickets;   // BatchNorm-finalisation tickets of this call (see BnFin): cleared here
   int ntickets;
@@ -61,8 +62,13 @@ struct PrepArgs {
   float *pbias_dst;
   int pbias_n, pbias_np;
 };
+typedef PrepArgsT<kMaxL> PrepArgs;
+// several layer stacks in one launch (the whole-backbone call: 4 levels x 3 + 2 modules x 2 layers)
+constexpr int kPrepBatchL = 24;
+typedef PrepArgsT<kPrepBatchL> PrepArgsBatch;
 
-__global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
+template <int ML>
+__global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgsT<ML> a) {
   // the layer of this block: a fully unrolled scan with STATIC indices (a run-time index into
   // the by-value argument arrays would make the compiler spill the whole struct to scratch)
   const float *w = a.w[0];
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
   long long *nbt = a.nbt[0];
   int n = a.n[0], np = a.np[0], kraw = a.kraw[0], kin = a.kin[0], first = 0;
 #pragma unroll
-  for (int i = 1; i < kMaxL; ++i)
+  for (int i = 1; i < ML; ++i)
     if (i < a.layers && (int)blockIdx.x >= a.first[i]) {
       w = a.w[i]; w2 = a.w2[i]; wt = a.wt[i]; nbt = a.nbt[i];
       n = a.n[i]; np = a.np[i]; kraw = a.kraw[i]; kin = a.kin[i]; first = a.first[i];
@@ -91,16 +97,86 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgs a) {
     for (int c = threadIdx.x; c < a.ntickets; c += 256) a.tickets[c] = 0u;
 }
 
+// ---- one weight-preparation launch for several layer calls (btr_backbone_forward) -------------
+// prep_batch_begin(): the layer calls that follow on this host thread only ADD their layers to
+// the batch and return; prep_batch_launch(): one prep_weights_kernel for all of them, after which
+// the same calls, issued again, skip their own launch; prep_batch_end(): back to normal.  A call
+// that clears BatchNorm tickets or pads a bias row in its prep (few-row layers, bare last layers)
+// does not take part: it reports `false` from prep_batch_take() in both passes and preps itself.
+struct PrepBatch {
+  PrepArgsBatch args;
+  int blocks = 0;
+  int mode = 0;   // 0 off, 1 collecting, 2 launched
+};
+inline PrepBatch &prep_batch() {
+  static thread_local PrepBatch b;
+  return b;
+}
+}  // namespace
+void prep_batch_begin() {
+  PrepBatch &b = prep_batch();
+  b.args = PrepArgsBatch{};
+  b.blocks = 0;
+  b.mode = 1;
+}
+void prep_batch_launch(hipStream_t st) {
+  PrepBatch &b = prep_batch();
+  if (b.mode == 1 && b.args.layers > 0) {
+    b.args.first[b.args.layers] = b.blocks;
+    hipLaunchKernelGGL(prep_weights_kernel<kPrepBatchL>, dim3(b.blocks), dim3(256), 0, st, b.args);
+  }
+  b.mode = 2;
+}
+void prep_batch_end() { prep_batch().mode = 0; }
+namespace {
+bool prep_batch_collecting() { return prep_batch().mode == 1; }
+// Collecting: adds the stack's layers (true), or refuses when the batch is full (false: the call
+// then preps itself in the second pass).  Launched: true when the stack was added before.
+template <int ML>
+inline bool prep_batch_take(const PrepArgsT<ML> &pa, bool eligible) {
+  PrepBatch &b = prep_batch();
+  if (b.mode == 0 || !eligible) return false;
+  if (b.mode == 2) {   // was this stack collected?  (its first W2 pointer identifies it)
+    for (int i = 0; i < b.args.layers; ++i)
+      if (b.args.w2[i] == pa.w2[0]) return true;
+    return false;
+  }
+  if (b.args.layers + pa.layers > kPrepBatchL) return false;
+  for (int l = 0; l < pa.layers; ++l) {
+    const int i = b.args.layers + l;
+    b.args.w[i] = pa.w[l]; b.args.w2[i] = pa.w2[l]; b.args.wt[i] = pa.wt[l];
+    b.args.n[i] = pa.n[l]; b.args.np[i] = pa.np[l]; b.args.kraw[i] = pa.kraw[l];
+    b.args.kin[i] = pa.kin[l]; b.args.nbt[i] = pa.nbt[l];
+    b.args.first[i] = b.blocks + pa.first[l];
+  }
+  b.blocks += pa.first[pa.layers];
+  b.args.layers += pa.layers;
+  return true;
+}
+
 // out[c] = sum_r g[r][c]  (bias gradient of a bare last layer), two deterministic stages:
 // part[tile][c] = sum over a 64-row tile (written by pm_rows_kernel on its way), then the tiles.
+// (16 columns x 16 tile slices per workgroup, the slices added in LDS in a fixed order: as one
+// thread per column -- a single workgroup walking all 128 tiles -- the voting module's call took
+// 30 us)
 __global__ __launch_bounds__(256) void colsum_final_kernel(int chunks, int c,
                                                            const float *__restrict__ part,
                                                            float *__restrict__ out) {
-  const int col = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  if (col >= c) return;
+  __shared__ float red[16][17];
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int col = (int)blockIdx.x * 16 + e;
   float acc = 0.f;
-  for (int k = 0; k < chunks; ++k) acc += part[(size_t)k * c + col];
-  out[col] = acc;
+  if (col < c)
+#pragma unroll 4
+    for (int k = sl; k < chunks; k += 16) acc += part[(size_t)k * c + col];
+  red[sl][e] = acc;
+  __syncthreads();
+  if (sl == 0 && col < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][e];
+    out[col] = t;
+  }
 }
 
 
@@ -538,7 +614,12 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   unsigned *tickets = reinterpret_cast<unsigned *>(at_b(scratch, sc.tickets));
   pa.tickets = tickets;
   pa.ntickets = kBnTickets * kMaxL;
-  hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), pa);
+  // (a whole-backbone call preps every stack with one launch: see prep_batch_begin)
+  const bool batched = prep_batch_take(pa, !bnfin_rows_ok(R));
+  if (prep_batch_collecting()) return BTR_OK;
+  if (!batched)
+    hipLaunchKernelGGL(prep_weights_kernel<kMaxL>, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       pa);
 
   float *x0 = at_f(saved, p.x0);
   btr_compact_t cm{};
@@ -960,7 +1041,9 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
     pa.pbias_n = d.width[L - 1];
     pa.pbias_np = p.np[L - 1];
   }
-  hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, hs, pa);
+  const bool batched = prep_batch_take(pa, !bnfin_rows_ok(rows) && !pa.pbias_dst);
+  if (prep_batch_collecting()) return BTR_OK;
+  if (!batched) hipLaunchKernelGGL(prep_weights_kernel<kMaxL>, dim3(blocks), dim3(256), 0, hs, pa);
 
   const int k0 = p.kin[0];
   BTR_REQUIRE(!x_cl || k0 == d.c, "pm_chain_forward: x_cl needs a channel count that is a multiple of 4");
@@ -1050,7 +1133,7 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
                                  stat(L - 1, 1), stat(L - 1, 2), stat(L - 1, 3), part, m1, m2,
                                  grads + p.dgamma[L - 1], grads + p.dbeta[L - 1], stream));
   } else if (bare_bias) {
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(npl, 256)), dim3(256), 0, hs,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(npl, 16)), dim3(256), 0, hs,
                        d.b * cdiv(d.n, 64), npl, colsum, grads + p.dbias[L - 1]);
   }
   float *dy = g;

@@ -5066,11 +5066,15 @@ inline void launch_tn(bool x6, dim3 grid, hipStream_t st, const float *g, int ld
                        cur_compact());
 }
 
-bool bnfin_arm(const BnFin &fin, long long rows) {
+// (internal.hpp) may a statistics GEMM over `rows` rows finalise its BatchNorm itself?
+bool bnfin_rows_ok(long long rows) {
   static const bool off = getenv("BTR_BN_TICKET") && getenv("BTR_BN_TICKET")[0] == '0';
   static const long long max_rows =
       getenv("BTR_BN_TICKET_MAX_ROWS") ? atoll(getenv("BTR_BN_TICKET_MAX_ROWS")) : 2048;
-  if (off || !gemm_x6() || !fin.ticket || rows > max_rows) return false;
+  return !off && gemm_x6() && rows <= max_rows;
+}
+bool bnfin_arm(const BnFin &fin, long long rows) {
+  if (!fin.ticket || !bnfin_rows_ok(rows)) return false;
   HostBnFin &h = host_bnfin();
   h.fin = fin;
   h.on = true;
