@@ -27,6 +27,16 @@ constexpr int kMaxL = BTR_MAX_LAYERS;
 constexpr size_t kAlign = 256;
 
 inline int ceil4(int v) { return (v + 3) / 4 * 4; }
+inline int ceil16(int v) { return (v + 15) / 16 * 16; }
+// point-wise chains: the saved blocks of W2 (np x kin) and W2^T (kin x np) are followed by the
+// matrix's three bf16 planes (see PrepArgsT::wp2); floats a block takes, and where its planes start
+inline size_t pm_w_floats(int np, int kin, bool transposed) {
+  const size_t planes = transposed ? (size_t)3 * kin * ceil16(np) : (size_t)3 * np * ceil16(kin);
+  return (size_t)np * kin + (planes + 1) / 2;
+}
+inline __bf16 *pm_planes(float *w, int np, int kin) {
+  return reinterpret_cast<__bf16 *>(w + (size_t)np * kin);
+}
 inline size_t up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 // Bump allocator over a byte range the caller owns (offsets only: usable for planning too).
@@ -43,6 +53,22 @@ struct Bump {
 // ---------------------------------------------------------------- weight preparation kernel
 // One launch per layer stack: W2[l] = W[l] zero-padded to (np[l], kin[l]) and Wt[l] = W2[l]^T
 // (the operands of the forward / input-gradient GEMMs), and num_batches_tracked += 1.
+// the three bf16 pieces of an f32 (round to nearest each: csrc/sa_mlp.hip split4 / split1)
+struct f32x2p {
+  __bf16 h, m, l;
+};
+__device__ __forceinline__ f32x2p split3(float v) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  auto widen = [](b2 b) { return __uint_as_float(__builtin_bit_cast(unsigned, b) << 16); };
+  const b2 bh = __builtin_convertvector(f2{v, 0.f}, b2);
+  const float r1 = v - widen(bh);
+  const b2 bm = __builtin_convertvector(f2{r1, 0.f}, b2);
+  const float r2 = r1 - widen(bm);
+  const b2 bl = __builtin_convertvector(f2{r2, 0.f}, b2);
+  return f32x2p{bh.x, bm.x, bl.x};
+}
+
 template <int ML>
 struct PrepArgsT {
   const float *w[ML];
@@ -54,6 +80,9 @@ struct PrepArgsT {
   int kin[ML];    // columns of W2 (zero columns beyond kraw)
   int first[ML + 1];  // first block of layer l
   long long *nbt[ML];
+  // point-wise chains: the bf16x6 planes of W2 ([3][np][ceil16(kin)]) and of W2^T
+  // ([3][kin][ceil16(np)]) for the small-M GEMM (csrc/sa_mlp.hip gemm_nt_sm_kernel); NULL: none
+  __bf16 *wp2[ML], *wpt[ML];
   int layers;
   unsigned *tickets;   // BatchNorm-finalisation tickets of this call (see BnFin): cleared here
   int ntickets;
@@ -73,21 +102,39 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgsT<ML> a) {
   // the by-value argument arrays would make the compiler spill the whole struct to scratch)
   const float *w = a.w[0];
   float *w2 = a.w2[0], *wt = a.wt[0];
+  __bf16 *wp2 = a.wp2[0], *wpt = a.wpt[0];
   long long *nbt = a.nbt[0];
   int n = a.n[0], np = a.np[0], kraw = a.kraw[0], kin = a.kin[0], first = 0;
 #pragma unroll
   for (int i = 1; i < ML; ++i)
     if (i < a.layers && (int)blockIdx.x >= a.first[i]) {
-      w = a.w[i]; w2 = a.w2[i]; wt = a.wt[i]; nbt = a.nbt[i];
+      w = a.w[i]; w2 = a.w2[i]; wt = a.wt[i]; nbt = a.nbt[i]; wp2 = a.wp2[i]; wpt = a.wpt[i];
       n = a.n[i]; np = a.np[i]; kraw = a.kraw[i]; kin = a.kin[i]; first = a.first[i];
     }
-  const int total = np * kin;
+  // (the element grid covers the 16-padded matrix: the planes' zero columns are written too)
+  const int np16 = (np + 15) / 16 * 16, kp16 = (kin + 15) / 16 * 16;
+  const int total = np16 * kp16;
   const int e = ((int)blockIdx.x - first) * 256 + (int)threadIdx.x;
   if (e < total) {
-    const int r = e / kin, c = e - r * kin;
+    const int r = e / kp16, c = e - r * kp16;
     const float v = (r < n && c < kraw) ? w[(size_t)r * kraw + c] : 0.f;
-    w2[e] = v;
-    wt[(size_t)c * np + r] = v;
+    if (r < np && c < kin) {
+      w2[(size_t)r * kin + c] = v;
+      wt[(size_t)c * np + r] = v;
+    }
+    if (wp2) {
+      const f32x2p f = split3(v);
+      if (r < np) {
+        wp2[((size_t)0 * np + r) * kp16 + c] = f.h;
+        wp2[((size_t)1 * np + r) * kp16 + c] = f.m;
+        wp2[((size_t)2 * np + r) * kp16 + c] = f.l;
+      }
+      if (c < kin) {
+        wpt[((size_t)0 * kin + c) * np16 + r] = f.h;
+        wpt[((size_t)1 * kin + c) * np16 + r] = f.m;
+        wpt[((size_t)2 * kin + c) * np16 + r] = f.l;
+      }
+    }
   }
   if ((int)blockIdx.x == first && threadIdx.x == 0 && nbt) *nbt += 1;
   if (blockIdx.x == 0 && a.pbias_dst)
@@ -147,6 +194,7 @@ inline bool prep_batch_take(const PrepArgsT<ML> &pa, bool eligible) {
     b.args.w[i] = pa.w[l]; b.args.w2[i] = pa.w2[l]; b.args.wt[i] = pa.wt[l];
     b.args.n[i] = pa.n[l]; b.args.np[i] = pa.np[l]; b.args.kraw[i] = pa.kraw[l];
     b.args.kin[i] = pa.kin[l]; b.args.nbt[i] = pa.nbt[l];
+    b.args.wp2[i] = pa.wp2[l]; b.args.wpt[i] = pa.wpt[l];
     b.args.first[i] = b.blocks + pa.first[l];
   }
   b.blocks += pa.first[pa.layers];
@@ -607,7 +655,7 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     pa.kraw[l] = l == 0 ? p.k0 : d.width[l - 1];
     pa.kin[l] = p.kin[l];
     pa.first[l] = blocks;
-    blocks += cdiv((long long)d.width[l] * p.kin[l], 256);
+    blocks += cdiv((long long)ceil16(d.width[l]) * ceil16(p.kin[l]), 256);
     pa.nbt[l] = d.running_mean[l] ? d.num_batches_tracked[l] : nullptr;
   }
   pa.first[L] = blocks;
@@ -949,6 +997,17 @@ PmBwdScratch pm_bwd_scratch(const btr_pm_chain_t &d, const btr_pm_plan_t &p) {
 }
 }  // namespace
 
+// C = f(A) . W^T for a chain layer whose saved weight block holds W [n][ldw = k] followed by its
+// bf16 planes (pm_w_floats): the small-M kernel where it applies, else gemm_nt_kernel
+static int pm_gemm_nt_auto(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
+                           float *c, int ldc, const float *pa, const float *pb, float *part,
+                           const float *bias, btr_stream_t stream) {
+  if (ldw == k && btr_pm_gemm_nt_sm_supported(rows, n, k))
+    return btr_pm_gemm_nt_sm(rows, n, k, a, lda, w + (size_t)n * k, c, ldc, pa, pb, part, bias,
+                             stream);
+  return btr_pm_gemm_nt(rows, n, k, a, lda, w, ldw, c, ldc, pa, pb, part, bias, stream);
+}
+
 int btr_pm_chain_plan(const btr_pm_chain_t *dp, btr_pm_plan_t *p) {
   BTR_REQUIRE(dp && p, "pm_chain_plan: null pointer");
   const btr_pm_chain_t &d = *dp;
@@ -972,8 +1031,8 @@ int btr_pm_chain_plan(const btr_pm_chain_t *dp, btr_pm_plan_t *p) {
   p->x0 = sv.floats((size_t)p->rows * p->kin[0]);
   for (int l = 0; l < L; ++l) {
     p->y[l] = sv.floats((size_t)p->rows * p->np[l]);
-    p->w2[l] = sv.floats((size_t)p->np[l] * p->kin[l]);
-    p->wt[l] = sv.floats((size_t)p->np[l] * p->kin[l]);
+    p->w2[l] = sv.floats(pm_w_floats(p->np[l], p->kin[l], false));   // + its bf16 planes
+    p->wt[l] = sv.floats(pm_w_floats(p->np[l], p->kin[l], true));
     p->stats[l] = sv.floats((size_t)4 * p->np[l]);
   }
   p->saved_bytes = sv.off;
@@ -1022,9 +1081,11 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
     pa.kraw[l] = l == 0 ? d.c : d.width[l - 1];
     pa.kin[l] = p.kin[l];
     pa.first[l] = blocks;
-    blocks += cdiv((long long)p.np[l] * p.kin[l], 256);
+    blocks += cdiv((long long)ceil16(p.np[l]) * ceil16(p.kin[l]), 256);
     const bool track = d.has_bn[l] && d.running_mean[l];
     pa.nbt[l] = track ? d.num_batches_tracked[l] : nullptr;
+    pa.wp2[l] = pm_planes(at_f(saved, p.w2[l]), p.np[l], p.kin[l]);
+    pa.wpt[l] = pm_planes(at_f(saved, p.wt[l]), p.np[l], p.kin[l]);
   }
   pa.first[L] = blocks;
   const int grid = btr_pm_gemm_grid(rows);
@@ -1067,7 +1128,7 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
           tickets + kBnTickets * l, d.gamma[l], d.beta[l], st, st + np, st + 2 * np, st + 3 * np,
           d.running_mean[l], d.running_var[l], rbias, d.width[l], (double)rows, d.eps[l],
           d.momentum[l]}, rows);
-      BTR_TRY(btr_pm_gemm_nt(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, part, nullptr,
+      BTR_TRY(pm_gemm_nt_auto(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, part, nullptr,
                              stream));
       if (!fin_fused)
         BTR_TRY(bn_finalize_bias(np, grid, (double)rows, d.eps[l], d.momentum[l], part,
@@ -1078,7 +1139,7 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
     } else {
       const float *bp = d.bias[l];
       if (bp && np != d.width[l]) bp = bias_pad;   // (padded by prep_weights_kernel)
-      BTR_TRY(btr_pm_gemm_nt(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, nullptr, bp,
+      BTR_TRY(pm_gemm_nt_auto(rows, np, k, A, lda, w2, k, y, np, pscale, pshift, nullptr, bp,
                              stream));
       pscale = pshift = nullptr;
     }
@@ -1188,7 +1249,7 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
       // gn is the buffer dY_{l+1} lived in: its weight gradient must be through with it
       if (side && l + 1 <= L - 1 && last_done == l + 1)
         (void)hipStreamWaitEvent(hs, side->done[l + 1], 0);
-      BTR_TRY(btr_pm_gemm_nt(rows, k, np, dy, np, at_f(saved, p.wt[l]), np, gn, k, nullptr,
+      BTR_TRY(pm_gemm_nt_auto(rows, k, np, dy, np, at_f(saved, p.wt[l]), np, gn, k, nullptr,
                              nullptr, nullptr, nullptr, stream));
       if (l > 0) {
         if (fusable(l - 1)) {   // the next layer applies the sums while it stages gn

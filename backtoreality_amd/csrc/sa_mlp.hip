@@ -79,6 +79,15 @@ __device__ __forceinline__ Split4 split4(const float4 v) {
   }
   return s;
 }
+__device__ __forceinline__ void split1(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
+  const f32x2 f = {v, 0.f};
+  const bf16x2 bh = __builtin_convertvector(f, bf16x2);
+  const f32x2 r1 = {v - widen2(bh).x, 0.f};
+  const bf16x2 bm = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = {r1.x - widen2(bm).x, 0.f};
+  const bf16x2 bl = __builtin_convertvector(r2, bf16x2);
+  h = bh.x; m = bm.x; l = bl.x;
+}
 constexpr int kLp = 40;   // row pitch of a bf16 plane (80 B: conflict-free ds_read_b128)
 
 // "Compact rows" (csrc comment block further down, btr_sac_plan): device-side description of
@@ -698,6 +707,249 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
       }
     }
   }
+}
+
+// ---- small-M NT GEMM: 32-row tiles, weight fragments straight from pre-split planes -------------
+// The point-wise chains (feature propagation, vote generator, proposal head: 2 048 - 16 384 rows x
+// 128 - 512 columns) and GroupFree3D's 1 024-row layers ran on gemm_nt_kernel's 64 x 128 tiles:
+// 48 - 256 workgroups that each walk k in 32-wide chunks, ~1.3 us per chunk whatever it holds
+// (stage -> barrier -> MFMA -> barrier with one wave per SIMD): 14 - 17 us for 3 us of
+// arithmetic.  Here
+//   * a workgroup takes a 32 x 64 tile (>= 4x as many workgroups), and up to 288 columns of k in ONE
+//     staged chunk: two barriers per chunk, not per 32 columns;
+//   * the weights are split into their three bf16 planes ONCE per training step (by the weight
+//     preparation kernel, [3][n][ceil16(k)] next to W2 / W^T) instead of by every row tile: a wave
+//     loads its B fragments for the whole chunk straight from L2 into registers, before the A rows
+//     are staged, so every global load of the tile is in flight at once;
+//   * the four waves are (column tile 0 / 1) x (k half 0 / 1); the halves meet in LDS.
+// Same products (bf16x6, smallest terms first per 16-wide step) as gemm_nt_kernel; the k halves
+// are added in another order, so the results differ from it in the last bits.  Statistics
+// partials: one `part` row per 32-row tile, which is what btr_pm_gemm_grid() counts for these row
+// counts; BnFin (the last workgroup of a column block finalises the BatchNorm) as there.
+struct SmArgs {
+  const float *A;
+  int lda;
+  const __bf16 *Wp;    // planes [3][N][kp], kp = ceil16(K); rows n < N, columns k >= K are zero
+  int kp;
+  float *C;
+  int ldc;
+  int R, N, K;
+  const float *pa, *pb;
+  float *part;
+  const float *bias;
+};
+constexpr int kSmKC = 288;   // columns of k per staged chunk
+constexpr int kSmLX = kSmKC + 8;
+
+template <int PRO, bool STATS, bool BIAS>
+__global__ __launch_bounds__(256, 2) void gemm_nt_sm_kernel(SmArgs a, BnFin fin) {
+  constexpr int BM = 32, KC = kSmKC, LX = kSmLX, KS = KC / 32;   // KS: 16-wide steps per k half
+  __shared__ __attribute__((aligned(16))) __bf16 Xp[3 * BM * LX];
+  __shared__ __attribute__((aligned(16))) float Cs[2 * 32 * 36];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = wave & 1, kh = wave >> 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int r0 = blockIdx.x * BM, n_blk = blockIdx.y * 64;
+  const int R = a.R, N = a.N, K = a.K;
+  const int ncol = n_blk + t * 32 + l31;   // this lane's weight row / output column
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  const int srow = tid >> 6;               // staging: rows srow + 4 p, columns skq + 256 j
+  const int skq = (tid & 63) * 4;
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kc = min(KC, K - k0);
+    // ---- B fragments of this wave's k half: [ks][plane], all in flight before anything waits
+    bf16x8 bfr[KS][3];
+    const int kb0 = k0 + kh * (KC / 2) + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kk = kb0 + ks * 16;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bfr[ks][q][e] = (__bf16)0.f;
+        if (ncol < N && kk < a.kp && kh * (KC / 2) + ks * 16 < kc)
+          bfr[ks][q] = *reinterpret_cast<const bf16x8 *>(
+              a.Wp + ((size_t)q * N + ncol) * a.kp + kk);
+      }
+    }
+    // ---- A rows of the chunk: registers -> prologue -> three bf16 planes in LDS
+    float4 ra[8][2];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = r0 + srow + 4 * p, kk = skq + 256 * j;
+        ra[p][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < R && kk < kc && (j == 0 || skq < KC - 256))
+          ra[p][j] = *reinterpret_cast<const float4 *>(a.A + (size_t)row * a.lda + k0 + kk);
+      }
+    if (k0 > 0) __syncthreads();   // (the previous chunk's fragment reads are done)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = skq + 256 * j;
+      if (j == 1 && skq >= KC - 256) break;
+      float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRO && kk < kc) {
+        fa = *reinterpret_cast<const float4 *>(a.pa + k0 + kk);
+        fb = *reinterpret_cast<const float4 *>(a.pb + k0 + kk);
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int row = srow + 4 * p;
+        float4 v = ra[p][j];
+        if (PRO && r0 + row < R && kk < kc) {   // padded rows / columns stay exactly 0
+          v.x = fmaxf(fmaf(fa.x, v.x, fb.x), 0.f);
+          v.y = fmaxf(fmaf(fa.y, v.y, fb.y), 0.f);
+          v.z = fmaxf(fmaf(fa.z, v.z, fb.z), 0.f);
+          v.w = fmaxf(fmaf(fa.w, v.w, fb.w), 0.f);
+        }
+        const Split4 sp = split4(v);
+        *reinterpret_cast<bf16x4 *>(&Xp[(0 * BM + row) * LX + kk]) = sp.h;
+        *reinterpret_cast<bf16x4 *>(&Xp[(1 * BM + row) * LX + kk]) = sp.m;
+        *reinterpret_cast<bf16x4 *>(&Xp[(2 * BM + row) * LX + kk]) = sp.l;
+      }
+    }
+    __syncthreads();
+    // ---- this wave's k half of the chunk
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (kh * (KC / 2) + ks * 16 >= kc) break;
+      bf16x8 af[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        af[q] = *reinterpret_cast<const bf16x8 *>(
+            &Xp[(q * BM + l31) * LX + kh * (KC / 2) + ks * 16 + h * 8]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bfr[ks][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[ks][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[ks][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[ks][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[ks][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[ks][0], acc, 0, 0, 0);
+    }
+  }
+  // ---- the k halves meet: waves 2, 3 hand their tiles to waves 0, 1 (D layout kept)
+  float *T = Cs + t * (32 * 36);
+  if (kh == 1) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) T[((v & 3) + 8 * (v >> 2) + 4 * h) * 36 + l31] = acc[v];
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const float bcol = (BIAS && ncol < N) ? a.bias[ncol] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int rl = (v & 3) + 8 * (v >> 2) + 4 * h;
+      float c = acc[v] + T[rl * 36 + l31];
+      if (BIAS && r0 + rl < R) c += bcol;
+      acc[v] = c;
+      if (STATS) {   // rows >= R hold exact zeros
+        s1 += c;
+        s2 = fmaf(c, c, s2);
+      }
+    }
+    if (STATS) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (h == 0 && ncol < N) {
+        a.part[((size_t)blockIdx.x * 2 + 0) * N + ncol] = s1;
+        a.part[((size_t)blockIdx.x * 2 + 1) * N + ncol] = s2;
+      }
+    }
+    if (a.C != nullptr) {
+      // the tile back through LDS in the accumulator layout, out as 16-byte row stores
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();   // (this wave's reads of T above are done)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) T[((v & 3) + 8 * (v >> 2) + 4 * h) * 36 + l31] = acc[v];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int rl = lane >> 3, c4 = (lane & 7) * 4;
+      const int colw = n_blk + t * 32 + c4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const float4 q4 = *reinterpret_cast<const float4 *>(&T[(it * 8 + rl) * 36 + c4]);
+        const int row = r0 + it * 8 + rl;
+        if (row < R && colw < N)
+          *reinterpret_cast<float4 *>(a.C + (size_t)row * a.ldc + colw) = q4;
+      }
+    }
+  }
+  if constexpr (STATS) {
+    if (fin.ticket) {
+      // ---- the last workgroup of this column block finalises the BatchNorm (see gemm_nt_kernel)
+      __shared__ int s_last;
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) s_last = atomicAdd(&fin.ticket[blockIdx.y], 1u) == gridDim.x - 1;
+      __syncthreads();
+      if (!s_last) return;
+      __threadfence();
+      constexpr int BN = 64, G = 256 / BN;
+      double *fr = reinterpret_cast<double *>(Xp);   // [2][8][BN]
+      const int col = tid % BN, q = tid / BN, n = n_blk + col;
+      const int nblk = gridDim.x;
+      for (int g = q; g < 8; g += G) {
+        double a1 = 0.0, a2 = 0.0;
+        if (n < N)
+          for (int y = 0; y < 8; ++y) {
+            double u1 = 0.0, u2 = 0.0;
+#pragma unroll 4
+            for (int b = g * 8 + y; b < nblk; b += 64) {
+              u1 += (double)__builtin_nontemporal_load(&a.part[((size_t)b * 2 + 0) * N + n]);
+              u2 += (double)__builtin_nontemporal_load(&a.part[((size_t)b * 2 + 1) * N + n]);
+            }
+            a1 += u1;
+            a2 += u2;
+          }
+        fr[(0 * 8 + g) * BN + col] = a1;
+        fr[(1 * 8 + g) * BN + col] = a2;
+      }
+      __syncthreads();
+      if (q == 0 && n < N) {
+        double u1 = 0.0, u2 = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          u1 += fr[(0 * 8 + g) * BN + col];
+          u2 += fr[(1 * 8 + g) * BN + col];
+        }
+        const double mean = u1 / fin.count;
+        double var = u2 / fin.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+        const float sc = fin.gamma[n] * invstd;
+        fin.scale[n] = sc;
+        fin.shift[n] = fin.beta[n] - (float)mean * sc;
+        fin.mean[n] = (float)mean;
+        fin.invstd[n] = invstd;
+        if (fin.running_mean) {
+          const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+          float rm = (1.f - fin.momentum) * fin.running_mean[n] + fin.momentum * (float)mean;
+          if (fin.rbias && n < fin.nbias) rm += fin.momentum * fin.rbias[n];
+          fin.running_mean[n] = rm;
+          fin.running_var[n] = (1.f - fin.momentum) * fin.running_var[n] +
+                               fin.momentum * (float)unbiased;
+        }
+      }
+    }
+  }
+}
+
+// planes[q][r][c] (q = 0..2, r < n, c < ceil16(k)): the three bf16 pieces of w[r][c] (zero for
+// c >= k) -- the stand-alone form of what the weight preparation kernel writes beside W2 / W^T
+__global__ __launch_bounds__(256) void pm_weight_planes_kernel(int n, int k, int kp,
+                                                               const float *__restrict__ w, int ldw,
+                                                               __bf16 *__restrict__ planes) {
+  const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (e >= n * kp) return;
+  const int r = e / kp, c = e - r * kp;
+  __bf16 ph, pm, pl;
+  split1(c < k ? w[(size_t)r * ldw + c] : 0.f, ph, pm, pl);
+  planes[((size_t)0 * n + r) * kp + c] = ph;
+  planes[((size_t)1 * n + r) * kp + c] = pm;
+  planes[((size_t)2 * n + r) * kp + c] = pl;
 }
 
 // ------------------------------------------------- parallel reduction of per-workgroup partials
@@ -3086,15 +3338,6 @@ struct GramArgs {
   int dbg;   // measurement only (BTR_GRAM_DBG): 1 = consumers idle, 2 = producers idle
 };
 
-__device__ __forceinline__ void split1(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
-  const f32x2 f = {v, 0.f};
-  const bf16x2 bh = __builtin_convertvector(f, bf16x2);
-  const f32x2 r1 = {v - widen2(bh).x, 0.f};
-  const bf16x2 bm = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = {r1.x - widen2(bm).x, 0.f};
-  const bf16x2 bl = __builtin_convertvector(r2, bf16x2);
-  h = bh.x; m = bm.x; l = bl.x;
-}
 
 // 8 consecutive reduction indices of one column out of a swizzled row-major plane (transpose
 // read; lane -> (row trow (+4), 4-column chunk at col), see sa_bwd_fused_kernel)
@@ -6122,9 +6365,77 @@ int btr::sac_scatter_ex(int b, int n, int m, int c, int ldx, int use_xyz, const 
 extern "C" {
 
 // ------------------------------------------------------------- point-wise MLP chains (pm)
-int btr_pm_gemm_grid(int rows) {
+// gemm_nt_kernel's row-tile workgroups (64-row tiles, grid-stride)
+static int pm_tiles64_grid(int rows) {
   return std::max(1, std::min(cdiv(rows, 64),
                               gemm_wgs_per_cu() * cu_mask_avail_cus() * grid_rounds()));
+}
+// the small-M kernel (gemm_nt_sm_kernel): few rows, k in at most two staged chunks;
+// BTR_PM_SM=0: never (read per call: the tests compare the two kernels)
+// Measured (tools/gemm_sm_ab.py, alone on the chip, BatchNorm prologue + statistics; small-M /
+// 64-row tiles): 1 024 x 288 x 288 8.2 / 15.3 us, 2 048 x 128 x 128 7.2 / 8.7, 4 096 x 256 x 256
+// 12.4 / 14.5, 4 096 x 256 x 512 21.1 / 24.3 -- and 8 192 x 256 x 256 23.0 / 19.4, 16 384 x 256 x
+// 256 40.4 / 21.8: with four and more tiles per CU each tile's own load -> split -> MFMA latency
+// chain and its private copy of the weight fragments cost more than gemm_nt_kernel's 256
+// fully parallel workgroups.  Hence <= 4 096 rows (BTR_PM_SM_ROWS overrides).
+static bool pm_sm_rows(int rows) {
+  const char *e = getenv("BTR_PM_SM");
+  static const int max_rows = getenv("BTR_PM_SM_ROWS") ? atoi(getenv("BTR_PM_SM_ROWS")) : 4096;
+  return rows > 0 && rows <= max_rows && gemm_x6() && !(e && e[0] == '0');
+}
+// Rows of `part` a statistics GEMM of the chains writes (and bn_finalize reads): one per 32-row
+// tile where the small-M kernel may run, else one per workgroup of gemm_nt_kernel -- which writes
+// zero rows for workgroups without a tile, so both kernels serve either count.
+int btr_pm_gemm_grid(int rows) {
+  return pm_sm_rows(rows) ? cdiv(rows, 32) : pm_tiles64_grid(rows);
+}
+static int ceil16i(int v) { return (v + 15) / 16 * 16; }
+size_t btr_pm_weight_planes_bytes(int n, int k) { return (size_t)3 * n * ceil16i(k) * 2; }
+int btr_pm_weight_planes(int n, int k, const float *w, int ldw, void *planes,
+                         btr_stream_t stream) {
+  BTR_REQUIRE(w && planes && n > 0 && k > 0, "pm_weight_planes: bad arguments");
+  const int kp = ceil16i(k);
+  hipLaunchKernelGGL(pm_weight_planes_kernel, dim3(cdiv((long long)n * kp, 256)), dim3(256), 0,
+                     as_stream(stream), n, k, kp, w, ldw, (__bf16 *)planes);
+  return check_launch("pm_weight_planes");
+}
+int btr_pm_gemm_nt_sm_supported(int rows, int n, int k) {
+  return pm_sm_rows(rows) && n > 0 && k > 0 && k % 4 == 0 && k <= 2 * kSmKC && k <= kMaxK;
+}
+// C = f(A) . W^T with W given as its three bf16 planes (btr_pm_weight_planes); otherwise as
+// btr_pm_gemm_nt (part: [btr_pm_gemm_grid(rows)][2][n])
+int btr_pm_gemm_nt_sm(int rows, int n, int k, const float *a, int lda, const void *planes,
+                      float *c, int ldc, const float *pa, const float *pb, float *part,
+                      const float *bias, btr_stream_t stream) {
+  if (rows <= 0 || n <= 0) return BTR_OK;
+  BTR_REQUIRE(btr_pm_gemm_nt_sm_supported(rows, n, k), "pm_gemm_nt_sm: shape %d x %d x %d", rows,
+              n, k);
+  BTR_REQUIRE(a && planes && c && lda % 4 == 0 && ldc % 4 == 0,
+              "pm_gemm_nt_sm: null pointer or unaligned leading dimension");
+  BTR_REQUIRE((pa == nullptr) == (pb == nullptr), "pm_gemm_nt_sm: pa/pb must come together");
+  BTR_REQUIRE(!(bias && part), "pm_gemm_nt_sm: bias and statistics are exclusive");
+  hipStream_t s = as_stream(stream);
+  const BnFin fin = take_bnfin();
+  SmArgs sa{};
+  sa.A = a; sa.lda = lda; sa.Wp = (const __bf16 *)planes; sa.kp = ceil16i(k); sa.C = c; sa.ldc = ldc;
+  sa.R = rows; sa.N = n; sa.K = k; sa.pa = pa; sa.pb = pb; sa.part = part; sa.bias = bias;
+  // (one 32-row tile per workgroup.  A persistent form -- ~2 workgroups per CU walking several row
+  // tiles with the weight fragments kept in registers and the next tile's rows prefetched -- was
+  // measured slower: 8 192 x 256 x 256 27.4 vs 23.0 us, 4 096 x 256 x 256 20.0 vs 12.4 us)
+  const dim3 grid(cdiv(rows, 32), cdiv(n, 64));
+#define BTR_SM(P, S, B) \
+  hipLaunchKernelGGL((gemm_nt_sm_kernel<P, S, B>), grid, dim3(256), 0, s, sa, fin)
+  if (pa) {
+    if (part) BTR_SM(1, true, false);
+    else if (bias) BTR_SM(1, false, true);
+    else BTR_SM(1, false, false);
+  } else {
+    if (part) BTR_SM(0, true, false);
+    else if (bias) BTR_SM(0, false, true);
+    else BTR_SM(0, false, false);
+  }
+#undef BTR_SM
+  return check_launch("pm_gemm_nt_sm");
 }
 
 // As btr_sa_gemm_nt on 64-row tiles (n > 64) with an optional bias row added to C (layers
@@ -6172,7 +6483,7 @@ int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
 // reduction and write their partial products to parts + z * part_stride ((rows, n), leading
 // dimension n); the consumer adds the planes.  pm_splitk_slices: 1 = not worth it.
 int btr::pm_splitk_slices(int rows, int n, int k) {
-  const int wg = btr_pm_gemm_grid(rows) * cdiv(n, 128);
+  const int wg = pm_tiles64_grid(rows) * cdiv(n, 128);
   if (wg >= 128 || k < 1024) return 1;
   return std::max(1, std::min(std::min(8, 256 / wg), k / 256));
 }
@@ -6187,7 +6498,7 @@ int btr::pm_gemm_nt_splitk(int rows, int n, int k, const float *a, int lda, cons
   Compact cm{};
   cm.kz = cdiv(cdiv(k, slices), kBK) * kBK;
   cm.czs = part_stride;
-  const dim3 grid(btr_pm_gemm_grid(rows), cdiv(n, 128), cdiv(k, cm.kz));
+  const dim3 grid(pm_tiles64_grid(rows), cdiv(n, 128), cdiv(k, cm.kz));
   BTR_REQUIRE((int)grid.z == slices, "pm_gemm_nt_splitk: %d slices of %d do not tile k=%d",
               slices, cm.kz, k);
 #define BTR_SK(MM)                                                                               \

@@ -113,6 +113,10 @@ _SIGNATURES = {
                               _vp]),
     # point-wise MLP chains (used by fused_mlp.py)
     "btr_pm_gemm_grid": (_ci, [_ci]),
+    "btr_pm_weight_planes_bytes": (_sz, [_ci, _ci]),
+    "btr_pm_weight_planes": (_ci, [_ci, _ci, _vp, _ci, _vp, _vp]),
+    "btr_pm_gemm_nt_sm_supported": (_ci, [_ci, _ci, _ci]),
+    "btr_pm_gemm_nt_sm": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
     "btr_pm_gemm_nt": (_ci, [_ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
     "btr_pm_out": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "btr_pm_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp]),

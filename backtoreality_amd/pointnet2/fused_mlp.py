@@ -38,6 +38,20 @@ def _ceil4(v):
     return (v + 3) // 4 * 4
 
 
+def _gemm_nt(rows, n, k, A, lda, W, Y, pa, pb, part, bias, st):
+    """Y (rows, n) = f(A) . W^T for W (n, k) contiguous: the small-M kernel on the weight's bf16
+    planes where it applies (as csrc/sa_layer.hip pm_gemm_nt_auto does), else gemm_nt_kernel."""
+    if _lib.btr_pm_gemm_nt_sm_supported(rows, n, k):
+        planes = torch.empty((int(_lib.btr_pm_weight_planes_bytes(n, k)),), dtype=torch.uint8,
+                             device=A.device)
+        _call(_lib.btr_pm_weight_planes, n, k, _p(W), k, _p(planes), st)
+        _call(_lib.btr_pm_gemm_nt_sm, rows, n, k, _p(A), lda, _p(planes), _p(Y), n, _p(pa), _p(pb),
+              _p(part), _p(bias), st, key=(rows, n, k))
+    else:
+        _call(_lib.btr_pm_gemm_nt, rows, n, k, _p(A), lda, _p(W), k, _p(Y), n, _p(pa), _p(pb),
+              _p(part), _p(bias), st, key=(rows, n, k))
+
+
 def _f32(shape, dev):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
@@ -81,8 +95,7 @@ class PointwiseMLP(Function):
                 Y = _f32((rows, Np), dev)
                 if bn is not None:
                     part = _f32((grid, 2, Np), dev)
-                    _call(_lib.btr_pm_gemm_nt, rows, Np, K, _p(A), lda, _p(W2), K, _p(Y), Np,
-                          _p(pa), _p(pb), _p(part), None, st, key=(rows, Np, K))
+                    _gemm_nt(rows, Np, K, A, lda, W2, Y, pa, pb, part, None, st)
                     scale, shift, mean, invstd = (_f32((Np,), dev) for _ in range(4))
                     mom = float(bn.momentum) if bn.momentum is not None else \
                         1.0 / float(bn.num_batches_tracked.item() + 1)
@@ -104,8 +117,7 @@ class PointwiseMLP(Function):
                     if bias is not None:
                         bp = bias if Np == Nl else torch.cat(
                             [bias, torch.zeros(Np - Nl, device=dev)])
-                    _call(_lib.btr_pm_gemm_nt, rows, Np, K, _p(A), lda, _p(W2), K, _p(Y), Np,
-                          _p(pa), _p(pb), None, _p(bp), st, key=(rows, Np, K))
+                    _gemm_nt(rows, Np, K, A, lda, W2, Y, pa, pb, None, bp, st)
                     stats.append(None)
                     pa = pb = None
                 Ys.append(Y)
@@ -225,8 +237,7 @@ class PointwiseMLP(Function):
                 if l > 0 or need_x:
                     Wt = W2.t().contiguous()
                     Gn = _f32((rows, K), dev)
-                    _call(_lib.btr_pm_gemm_nt, rows, K, Np, _p(dY), Np, _p(Wt), Np, _p(Gn), K,
-                          None, None, None, None, st, key=(rows, K, Np))
+                    _gemm_nt(rows, K, Np, dY, Np, Wt, Gn, None, None, None, None, st)
                     if l > 0:
                         sc, sh, mu, isd = stats[l - 1]
                         part = _f32((1024, 2, K), dev)

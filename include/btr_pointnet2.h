@@ -576,6 +576,17 @@ int btr_pm_gemm_grid(int rows);
 int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
                    float *c, int ldc, const float *pa, const float *pb, float *part,
                    const float *bias, btr_stream_t stream);
+/* Round 5: the small-M form (csrc/sa_mlp.hip gemm_nt_sm_kernel; <= 16 384 rows, k <= 576): 32 x 64
+ * tiles, the whole k extent in at most two staged chunks, and the weights as three bf16 planes
+ * [3][n][ceil16(k)] (btr_pm_weight_planes; btr_pm_weight_planes_bytes() bytes) that every row
+ * tile loads as MFMA fragments instead of splitting W again.  Operands otherwise as btr_pm_gemm_nt;
+ * same bf16x6 products, the two k halves added in another order.  BTR_PM_SM=0: never supported. */
+size_t btr_pm_weight_planes_bytes(int n, int k);
+int btr_pm_weight_planes(int n, int k, const float *w, int ldw, void *planes, btr_stream_t stream);
+int btr_pm_gemm_nt_sm_supported(int rows, int n, int k);
+int btr_pm_gemm_nt_sm(int rows, int n, int k, const float *a, int lda, const void *planes,
+                      float *c, int ldc, const float *pa, const float *pb, float *part,
+                      const float *bias, btr_stream_t stream);
 int btr_pm_out(int b, int n, int c, int ldy, const float *y, const float *scale,
                const float *shift, int relu, float *out_bcn, float *out_cl, btr_stream_t stream);
 int btr_pm_rows(int b, int n, int c, int ldr, const float *x, float *rows, btr_stream_t stream);
