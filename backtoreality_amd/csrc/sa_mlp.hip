@@ -6377,10 +6377,13 @@ static int pm_tiles64_grid(int rows) {
 // 12.4 / 14.5, 4 096 x 256 x 512 21.1 / 24.3 -- and 8 192 x 256 x 256 23.0 / 19.4, 16 384 x 256 x
 // 256 40.4 / 21.8: with four and more tiles per CU each tile's own load -> split -> MFMA latency
 // chain and its private copy of the weight fragments cost more than gemm_nt_kernel's 256
-// fully parallel workgroups.  Hence <= 4 096 rows (BTR_PM_SM_ROWS overrides).
+// fully parallel workgroups.  Inside the FSB step (beside the next batch's sampling kernel) the
+// 4 096-row layers measured no gain either (3.98 vs 3.96 ms per step, three runs each): the default
+// is <= 2 048 rows -- GroupFree3D's 1 024-row layers, the proposal head (BTR_PM_SM_ROWS overrides).
 static bool pm_sm_rows(int rows) {
   const char *e = getenv("BTR_PM_SM");
-  static const int max_rows = getenv("BTR_PM_SM_ROWS") ? atoi(getenv("BTR_PM_SM_ROWS")) : 4096;
+  const char *mr = getenv("BTR_PM_SM_ROWS");   // (read per call, like BTR_PM_SM)
+  const int max_rows = mr ? atoi(mr) : 2048;
   return rows > 0 && rows <= max_rows && gemm_x6() && !(e && e[0] == '0');
 }
 // Rows of `part` a statistics GEMM of the chains writes (and bn_finalize reads): one per 32-row

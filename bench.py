@@ -571,7 +571,8 @@ def pmc_traffic(substr, grid=None):
 # every f32-MFMA GEMM entry point of the fused SA path (csrc/sa_mlp.hip): forward NT (plain,
 # recompute, pool-epilogue), dgrad NT (plain, pooled), wgrad TN (plain, pooled, recompute)
 GEMM_OPS = ("sa_gemm_nt", "sa_gemm_nt_rc", "sa_gemm_nt_poolfwd", "sa_gemm_nt_pool",
-            "sa_gemm_tn", "sa_gemm_tn_rc", "sa_gemm_tn_pool", "pm_gemm_nt", "sa_bwd_fused")
+            "sa_gemm_tn", "sa_gemm_tn_rc", "sa_gemm_tn_pool", "pm_gemm_nt", "pm_gemm_nt_sm",
+            "sa_bwd_fused")
 # sa_bwd_fused (csrc/sa_mlp.hip sa_bwd_fused_kernel) is TWO products per launch -- the weight
 # gradient and the input gradient of a layer over one pass of its rows -- and moves
 # dZ_l / Y_l (one of them twice: BatchNorm's backward needs both), Y_{l-1} and dZ_{l-1}
@@ -620,6 +621,11 @@ def roofline_objects(kernels, detail, detail_steps, pair_overhead_ms=0.0):
                                       "floor_us": BQ_LAUNCHES * 1.45 + nbytes / 6.3e12 * 1e6,
                                       "frac_of_floor": (BQ_LAUNCHES * 1.45 + nbytes / 6.3e12 * 1e6)
                                       / (ms * 1e3),
+                                      # ... i.e. the largest `frac` a launch of this size can
+                                      # show at all (the launch boundary alone is half the floor)
+                                      "attainable_frac": nbytes / (
+                                          BQ_LAUNCHES * 1.45e-6 + nbytes / 6.3e12) / 1e9
+                                      / HBM_PEAK_GBS,
                                       "shape": [b, n, m, s], "avg_ms": ms,
                                       "kernel": ("bqb_query_kernel" if bq_buckets else
                                                  "bq_grid_query_kernel (+grid build)"),
@@ -682,7 +688,13 @@ def roofline_objects(kernels, detail, detail_steps, pair_overhead_ms=0.0):
                                    "step that runs meanwhile); op_avg_ms: the whole FPS call incl. its "
                                    "spatial-sort launches and their queueing",
                            "streaming_GBs": b * (m - 1) * n * 20 / (ms * 1e-3) / 1e9,
-                           "iterations_per_s": b * (m - 1) / (ms * 1e-3)}
+                           "iterations_per_s": b * (m - 1) / (ms * 1e-3),
+                           # the number that can move: one scene's chain of m - 1 dependent steps
+                           # (box test -> touched buckets' L2 round trip -> distance update ->
+                           # wave arg-max -> one barrier -> block arg-max); cycles at the 2.4 GHz
+                           # nominal clock; the stage budget is profiles/r05_fps_phases.md
+                           "us_per_dependent_step": ms * 1e3 / max(1, m - 1),
+                           "cycles_per_dependent_step": ms * 1e-3 / max(1, m - 1) * 2.4e9}
     return res
 
 
