@@ -75,6 +75,11 @@ struct BnFin {
   float eps, momentum;
 };
 constexpr int kBnTickets = 8;  // tickets per statistics GEMM (column blocks of >= 64 channels, n <= 512)
+// sa_mlp.hip: per-point first layer of a set-abstraction MLP (see ppfl_gather_add_kernel)
+int ppfl_forward(int b, int n, int m, int s, int nl, int rows, float inv_radius, const float *xyz,
+                 const float *new_xyz, const int *idx, const float *P, const float *w0x, float *y0,
+                 float *relx, float *part, int grid, hipStream_t st);
+int ppfl_assemble(int nl, int c, const float *dwx, const float *dwf, float *dw, hipStream_t st);
 // sa_layer.hip: one weight-preparation launch for the layer calls between _begin and _end (issued
 // twice by the caller: a collecting pass before _launch, the real pass after it)
 void prep_batch_begin();

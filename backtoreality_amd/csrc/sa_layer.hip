@@ -83,6 +83,8 @@ struct PrepArgsT {
   // point-wise chains: the bf16x6 planes of W2 ([3][np][ceil16(kin)]) and of W2^T
   // ([3][kin][ceil16(np)]) for the small-M GEMM (csrc/sa_mlp.hip gemm_nt_sm_kernel); NULL: none
   __bf16 *wp2[ML], *wpt[ML];
+  // per-point first layer (c > 0 feature channels): W2 = [W_f (n, c) | W_x (n, 4)], Wt = W_f^T
+  int ppfl_c[ML];
   int layers;
   unsigned *tickets;   // BatchNorm-finalisation tickets of this call (see BnFin): cleared here
   int ntickets;
@@ -103,12 +105,14 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgsT<ML> a) {
   const float *w = a.w[0];
   float *w2 = a.w2[0], *wt = a.wt[0];
   __bf16 *wp2 = a.wp2[0], *wpt = a.wpt[0];
+  int pc = a.ppfl_c[0];
   long long *nbt = a.nbt[0];
   int n = a.n[0], np = a.np[0], kraw = a.kraw[0], kin = a.kin[0], first = 0;
 #pragma unroll
   for (int i = 1; i < ML; ++i)
     if (i < a.layers && (int)blockIdx.x >= a.first[i]) {
       w = a.w[i]; w2 = a.w2[i]; wt = a.wt[i]; nbt = a.nbt[i]; wp2 = a.wp2[i]; wpt = a.wpt[i];
+      pc = a.ppfl_c[i];
       n = a.n[i]; np = a.np[i]; kraw = a.kraw[i]; kin = a.kin[i]; first = a.first[i];
     }
   // (the element grid covers the 16-padded matrix: the planes' zero columns are written too)
@@ -117,8 +121,17 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgsT<ML> a) {
   const int e = ((int)blockIdx.x - first) * 256 + (int)threadIdx.x;
   if (e < total) {
     const int r = e / kp16, c = e - r * kp16;
-    const float v = (r < n && c < kraw) ? w[(size_t)r * kraw + c] : 0.f;
-    if (r < np && c < kin) {
+    float v = (r < n && c < kraw) ? w[(size_t)r * kraw + c] : 0.f;
+    if (pc > 0) {   // (kin = pc + 4, kraw = 3 + pc: columns [xyz | features])
+      if (r < np && c < pc) {
+        v = w[(size_t)r * kraw + 3 + c];
+        w2[(size_t)r * pc + c] = v;
+        wt[(size_t)c * np + r] = v;
+      } else if (r < np && c < kin) {
+        const int cc = c - pc;
+        w2[(size_t)np * pc + (size_t)r * 4 + cc] = cc < 3 ? w[(size_t)r * kraw + cc] : 0.f;
+      }
+    } else if (r < np && c < kin) {
       w2[(size_t)r * kin + c] = v;
       wt[(size_t)c * np + r] = v;
     }
@@ -194,7 +207,7 @@ inline bool prep_batch_take(const PrepArgsT<ML> &pa, bool eligible) {
     b.args.w[i] = pa.w[l]; b.args.w2[i] = pa.w2[l]; b.args.wt[i] = pa.wt[l];
     b.args.n[i] = pa.n[l]; b.args.np[i] = pa.np[l]; b.args.kraw[i] = pa.kraw[l];
     b.args.kin[i] = pa.kin[l]; b.args.nbt[i] = pa.nbt[l];
-    b.args.wp2[i] = pa.wp2[l]; b.args.wpt[i] = pa.wpt[l];
+    b.args.wp2[i] = pa.wp2[l]; b.args.wpt[i] = pa.wpt[l]; b.args.ppfl_c[i] = pa.ppfl_c[l];
     b.args.first[i] = b.blocks + pa.first[l];
   }
   b.blocks += pa.first[pa.layers];
@@ -456,12 +469,24 @@ inline int wgrad_partial_chunks(int rows, int n, int k) {
 
 // scratch layouts (recomputed identically by plan / forward / backward)
 struct SaFwdScratch {
-  size_t part, len_tmp, extg, exta, tickets, bytes;
+  size_t part, len_tmp, extg, exta, tickets, ppfl_p, bytes;
 };
 struct SaBwdScratch {
   size_t part, m1, m2, dcl, alpha, beta, pw[kMaxL], pw0, g[2], scat, dfeat_cl, gram, bytes;
   size_t scat_bytes;
+  size_t ppfl_s, ppfl_dwx, ppfl_dwf, ppfl_pw;   // per-point first layer: see sa_layer_backward_add
 };
+
+// Per-point first layer (csrc/sa_mlp.hip ppfl_gather_add_kernel): W_f f_j once per point, the rows
+// gather it.  A function of the description and the plan only (the plan's buffer sizes, the
+// forward and the backward must agree): feature input of >= 32 channels, no coordinate gradients
+// (the levels behind SA1; the vote aggregation's xyz gradient keeps the row-wise form).
+inline bool sa_ppfl(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
+  return (d.options & BTR_SA_OPT_PPFL) && !p.recompute && d.layers >= 2 && d.use_xyz &&
+         d.c >= 32 && d.c % 4 == 0 && p.k0p == d.c + 4 && !d.need_dxyz && !d.need_dnew_xyz &&
+         d.need_dfeat && d.width[0] % 4 == 0 && d.width[0] <= 128 &&
+         (!p.compact || d.n <= 8192);
+}
 
 // May the pooled (last) layer run without its stored output?  (see btr_sa_bwd_gram)
 inline bool sa_gram_ok(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
@@ -487,6 +512,7 @@ SaFwdScratch sa_fwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   s.extg = b.floats(ext);
   s.exta = b.take(ext);
   s.tickets = b.take(sizeof(unsigned) * kBnTickets * kMaxL);
+  s.ppfl_p = b.floats(sa_ppfl(d, p) ? (size_t)d.b * d.n * d.width[0] : 0);
   s.bytes = b.off;
   return s;
 }
@@ -531,6 +557,13 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
                            : btr_sa_scatter_workspace_bytes(d.b, d.n, d.m, d.s);
   s.scat = b.take(s.scat_bytes);
   s.dfeat_cl = b.floats((size_t)d.b * d.n * std::max(d.c, 1));
+  if (sa_ppfl(d, p)) {
+    const int nl = d.width[0];
+    s.ppfl_s = b.floats((size_t)d.b * d.n * nl);
+    s.ppfl_dwx = b.floats((size_t)nl * 4);
+    s.ppfl_dwf = b.floats((size_t)nl * d.c);
+    s.ppfl_pw = b.floats((size_t)btr_sa_gemm_tn_chunks(d.b * d.n, nl, d.c) * nl * d.c);
+  }
   s.bytes = b.off;
   return s;
 }
@@ -575,7 +608,9 @@ int btr_sa_layer_plan(const btr_sa_layer_t *dp, btr_sa_plan_t *p) {
   // neither stored nor read; y[L-1] then holds the arg-max rows' values only (b, m, width)
   if (sa_gram_ok(d, *p)) p->pool_grad = 2;
   Bump sv;
-  p->x0 = sv.floats((size_t)p->rows * p->k0p);
+  // (per-point first layer: the rows' relative coordinates [rows][4] + a copy of the features)
+  p->x0 = sv.floats(sa_ppfl(d, *p) ? (size_t)p->rows * 4 + (size_t)d.b * d.n * d.c
+                                   : (size_t)p->rows * p->k0p);
   for (int l = 0; l < L; ++l) {
     p->y[l] = sv.floats((p->recompute && l == 0) ? 0
                         : (p->pool_grad == 2 && l == L - 1) ? (size_t)d.b * d.m * d.width[l]
@@ -658,6 +693,8 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     blocks += cdiv((long long)ceil16(d.width[l]) * ceil16(p.kin[l]), 256);
     pa.nbt[l] = d.running_mean[l] ? d.num_batches_tracked[l] : nullptr;
   }
+  const bool ppfl = sa_ppfl(d, p);
+  if (ppfl) pa.ppfl_c[0] = d.c;
   pa.first[L] = blocks;
   unsigned *tickets = reinterpret_cast<unsigned *>(at_b(scratch, sc.tickets));
   pa.tickets = tickets;
@@ -681,10 +718,11 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     if (!(geom && geom->goff))   // (else: planned by btr_backbone_sampling)
       BTR_TRY(btr_sac_plan(d.b * d.m, d.s, idx, at_i(scratch, sc.len_tmp), cp.goff, cp.dims,
                            cp.cidx, cp.bgrp, cp.bw, stream));
-    BTR_TRY(btr_sac_gather(d.b, d.n, d.m, R, d.c, p.k0p, d.use_xyz, d.radius_div, xyz, new_xyz,
-                           feats_cl, cp.cidx, cp.bgrp, cp.dims, x0, stream));
+    if (!ppfl)
+      BTR_TRY(btr_sac_gather(d.b, d.n, d.m, R, d.c, p.k0p, d.use_xyz, d.radius_div, xyz, new_xyz,
+                             feats_cl, cp.cidx, cp.bgrp, cp.dims, x0, stream));
     btr_sac_bind(&cm);
-  } else {
+  } else if (!ppfl) {
     BTR_TRY(btr_sa_gather(d.b, d.n, d.m, d.s, d.c, p.k0p, d.use_xyz, d.radius_div, xyz, new_xyz,
                           feats_cl, idx, x0, stream));
   }
@@ -701,10 +739,28 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     float *y = at_f(saved, p.y[l]);
     float *st = at_f(saved, p.stats[l]);
     // BatchNorm finalisation by the statistics GEMM's last workgroup (false: a launch of its own)
-    const bool fin_fused = bnfin_arm(BnFin{
+    const bool fin_fused = !(ppfl && l == 0) && bnfin_arm(BnFin{
         tickets + kBnTickets * l, d.gamma[l], d.beta[l], st, st + nl, st + 2 * nl, st + 3 * nl,
         d.running_mean[l], d.running_var[l], nullptr, 0, (double)R, d.eps[l], d.momentum[l]}, R);
-    if (p.recompute && l == 0) {  // statistics only
+    if (ppfl && l == 0) {
+      // ---- per-point first layer: P = F W_f^T over the POINTS, the rows gather it (+ W_x rel);
+      // x0 = [the rows' relative coordinates (R, 4) | a copy of the features for the backward]
+      BTR_REQUIRE(feats_cl, "sa_layer_forward: features missing");
+      const float *w0f = w2, *w0x = w2 + (size_t)nl * d.c;
+      float *fcopy = x0 + (size_t)R * 4;
+      const size_t fbytes = sizeof(float) * (size_t)d.b * d.n * d.c;
+      const hipError_t ce = hipMemcpyAsync(fcopy, feats_cl, fbytes, hipMemcpyDeviceToDevice,
+                                           as_stream(stream));
+      if (ce != hipSuccess) return fail((int)ce, "sa_layer_forward: %s", hipGetErrorString(ce));
+      float *P = at_f(scratch, sc.ppfl_p);
+      btr_sac_bind(nullptr);   // (the product over the points is no compact-row GEMM)
+      BTR_TRY(btr_pm_gemm_nt(d.b * d.n, nl, d.c, feats_cl, d.c, w0f, d.c, P, nl, nullptr, nullptr,
+                             nullptr, nullptr, stream));
+      if (p.compact) btr_sac_bind(&cm);
+      BTR_TRY(ppfl_forward(d.b, d.n, d.m, d.s, nl, R,
+                           d.radius_div != 0.f ? 1.0f / d.radius_div : 1.0f, xyz, new_xyz,
+                           p.compact ? cp.cidx : idx, P, w0x, y, x0, part, grid, as_stream(stream)));
+    } else if (p.recompute && l == 0) {  // statistics only
       BTR_TRY(btr_sa_gemm_nt(R, nl, k, A, lda, w2, k, nullptr, nl, nullptr, nullptr, part, stream));
     } else if (p.recompute && l == 1) {
       BTR_TRY(btr_sa_gemm_nt_rc(R, nl, k, x0, at_f(saved, p.w2[0]), w2, k, y, nl, pscale, pshift,
@@ -786,6 +842,8 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   const int cl = d.width[L - 1];
   float *ylast = at_f(saved, p.y[L - 1]);
   const bool gram = p.pool_grad == 2;   // ylast = the arg-max rows' values (b, m, cl): ldy = 0
+  const bool ppfl = sa_ppfl(d, p);
+  bool ppfl_done = false;
   if (p.pool_grad)
     BTR_TRY(btr_sa_pool_bwd_coef(d.b, d.m, d.s, cl, gram ? 0 : cl, ylast, dout, out, arg, stat(L - 1, 2),
                                  stat(L - 1, 3), stat(L - 1, 0), stat(L - 1, 1), part, m1, m2,
@@ -867,6 +925,50 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       BTR_TRY(btr_sa_bn_relu_bwd_apply(R, nl, nl, dy, at_f(saved, p.y[l]), stat(l, 0), stat(l, 1),
                                        stat(l, 2), stat(l, 3), m1, m2, stream));
       lazy = false;
+    }
+    if (ppfl && l == 0) {
+      // ---- per-point first layer (csrc/sa_mlp.hip ppfl_gather_add_kernel): dY_0's rows are summed
+      // per POINT first -- the scatter the feature gradient needs anyway -- and the feature parts
+      // of both gradients become products over the points:
+      //   S[j] = sum of dY_0[r] over the rows r of point j          (n points x nl)
+      //   dW_f = S^T F,  dF = S W_f;   dW_x = dY_0^T rel  (k = 4, over the rows)
+      const int n0 = d.width[0], np = d.b * d.n;
+      float *relx = x0, *fcopy = x0 + (size_t)R * 4;
+      float *S = at_f(scratch, sc.ppfl_s);
+      float *dwx = at_f(scratch, sc.ppfl_dwx), *dwf = at_f(scratch, sc.ppfl_dwf);
+      btr_stream_t ws = stream;
+      if (side) {
+        (void)hipEventRecord(side->ready[0], hmain);
+        (void)hipStreamWaitEvent(side->s, side->ready[0], 0);
+        ws = (btr_stream_t)side->s;
+      }
+      BTR_TRY(btr_sa_gemm_tn(R, n0, 4, dy, n0, relx, 4, nullptr, nullptr, at_f(scratch, sc.pw[0]),
+                             dwx, ws));
+      if (side) {
+        (void)hipEventRecord(side->done[0], side->s);
+        last_done = 0;
+      }
+      const bool pre = geom && geom->scatter_ws;
+      void *ws2 = pre ? geom->scatter_ws : (char *)scratch + sc.scat;
+      const int mode = pre ? kScatterReduce : kScatterBoth;
+      if (p.compact)
+        BTR_TRY(sac_scatter_ex(d.b, d.n, d.m, n0, n0, 0, dy, cp.cidx, cp.goff, S, ws2,
+                               sc.scat_bytes, R, mode, hmain));
+      else
+        BTR_TRY(sa_scatter_ex(d.b, d.n, d.m, d.s, n0, n0, 0, d.radius_div, dy, idx, S, nullptr,
+                              nullptr, ws2, sc.scat_bytes, mode, hmain));
+      btr_sac_bind(nullptr);   // (products over the points: no compact rows)
+      BTR_TRY(btr_sa_gemm_tn(np, n0, d.c, S, n0, fcopy, d.c, nullptr, nullptr,
+                             at_f(scratch, sc.ppfl_pw), dwf, stream));
+      float *dfeat_cl = at_f(scratch, sc.dfeat_cl);
+      BTR_TRY(btr_pm_gemm_nt(np, d.c, n0, S, n0, at_f(saved, p.wt[0]), n0, dfeat_cl, d.c, nullptr,
+                             nullptr, nullptr, nullptr, stream));
+      if (p.compact) btr_sac_bind(&cm);
+      if (dfeat)
+        BTR_TRY(pm_out_add(d.b, d.n, d.c, d.c, dfeat_cl, nullptr, nullptr, 0, dfeat, nullptr,
+                           dfeat_add, dfeat_add_bstride, hmain));
+      ppfl_done = fused_any = true;   // (partials written on the main stream: see the join)
+      break;
     }
     float *dw = grads + p.dw[l];
     float *pw = at_f(scratch, sc.pw[l]);
@@ -964,6 +1066,9 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     (void)hipEventRecord(side->done[kMaxL], side->s);
     (void)hipStreamWaitEvent(hmain, side->done[kMaxL], 0);
   }
+  if (ppfl_done)   // dW_0 (n0, 3 + c) = [dW_x | dW_f], both final behind the reductions above
+    BTR_TRY(ppfl_assemble(d.width[0], d.c, at_f(scratch, sc.ppfl_dwx), at_f(scratch, sc.ppfl_dwf),
+                          grads + p.dw[0], hmain));
   return check_launch("sa_layer_backward");
 }
 

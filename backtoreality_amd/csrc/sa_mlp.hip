@@ -6364,6 +6364,166 @@ int btr::sac_scatter_ex(int b, int n, int m, int c, int ldx, int use_xyz, const 
 
 extern "C" {
 
+
+}  // extern "C"
+namespace btr {
+
+// ---- per-point first layer ("PPFL") --------------------------------------------------------------
+// The first convolution of a set-abstraction MLP acts on rows [xyz_j - c_i, f_j]: its feature part
+// W_f f_j depends on the NEIGHBOUR POINT j only, not on the centre i it is grouped under -- and a
+// level has 7 - 16 times as many (centre, neighbour) rows as points (SA2: 114 000 compact rows
+// over 16 384 points).  So
+//   P[j]  = W_f f_j                       one small GEMM over the points (btr_pm_gemm_nt)
+//   Y0[r] = P[j(r)] + W_x rel(r)          this kernel: a 512-byte gather + three FMAs per channel
+// replaces gathering the [3 + C]-wide rows (X0 written and read: 2 x 61 MB at SA2) and the
+// rows x n x (3 + C) product.  The kernel also leaves rel(r) = (xyz_j - c_i) / radius as 16-byte
+// rows (the weight gradient of W_x needs them) and the BatchNorm statistics partials of Y0 -- one
+// `part` row per workgroup, rows weighted as in gemm_nt_kernel (compact rows' first row stands
+// for 1 + S - len copies).  Same values as the row-wise product up to the order of the k sum.
+// Backward (csrc/sa_layer.hip): dY0's rows are summed per point FIRST (the scatter the feature
+// gradient needed anyway), then dF = S W_f and dW_f = S^T F are products over the points.
+struct PpflArgs {
+  const float *xyz, *new_xyz;   // (B, N, 3), (B, M, 3)
+  const int *idx;               // dense rows: (B, M, S) neighbour index;  compact: cidx[row]
+  const float *P;               // (B * N, nl)
+  const float *w0x;             // [nl][4]: the xyz columns of W0 (4th zero)
+  float *y0;                    // out (rows, nl)
+  float *relx;                  // out (rows, 4)
+  float *part;                  // out [gridDim.x][2][nl]
+  int N, M, S, nl, rows, rows_per_wg;
+  float inv_radius;
+};
+__global__ __launch_bounds__(256) void ppfl_gather_add_kernel(PpflArgs a, Compact cm) {
+  __shared__ double red[2][8][132];
+  const int q = threadIdx.x & 31, rr = threadIdx.x >> 5;   // 32 channel quads x 8 rows per pass
+  int R = a.rows, rows_per_wg = a.rows_per_wg;
+  if (cm.dims) {
+    R = cm.dims[0];
+    rows_per_wg = ((R + (int)gridDim.x - 1) / (int)gridDim.x + 7) / 8 * 8;
+  }
+  const int rbeg = blockIdx.x * rows_per_wg, rend = min(R, rbeg + rows_per_wg);
+  double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
+  for (int c0 = 0; c0 < a.nl; c0 += 128) {   // (nl <= 128 in every layer so far: one pass)
+    const int c = c0 + q * 4;
+    const bool live = c < a.nl;
+    float4 wx = make_float4(0.f, 0.f, 0.f, 0.f), wy = wx, wz = wx;
+    if (live) {   // W0x rows of this thread's four channels: [n][4] -> three per-axis quads
+      const float4 r0 = *reinterpret_cast<const float4 *>(a.w0x + (size_t)(c + 0) * 4);
+      const float4 r1 = *reinterpret_cast<const float4 *>(a.w0x + (size_t)(c + 1) * 4);
+      const float4 r2 = *reinterpret_cast<const float4 *>(a.w0x + (size_t)(c + 2) * 4);
+      const float4 r3 = *reinterpret_cast<const float4 *>(a.w0x + (size_t)(c + 3) * 4);
+      wx = make_float4(r0.x, r1.x, r2.x, r3.x);
+      wy = make_float4(r0.y, r1.y, r2.y, r3.y);
+      wz = make_float4(r0.z, r1.z, r2.z, r3.z);
+    }
+    if (c0 > 0)
+      for (int e = 0; e < 4; ++e) d1[e] = d2[e] = 0.0;
+    // four rows of this thread's slot per trip: their index -> coordinate / P loads are in flight
+    // together (one row at a time is a chain of two dependent memory round trips per 8 rows)
+    for (int r4 = rbeg + rr; r4 < rend; r4 += 32) {
+      int g[4], j[4];
+      float w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r4 + 8 * u;
+        g[u] = j[u] = 0;
+        w[u] = 1.f;
+        if (r < rend) {
+          j[u] = a.idx[r];
+          if (cm.bgrp) {
+            g[u] = cm.bgrp[r >> 3];
+            if ((r & 7) == 0) w[u] = cm.bw[r >> 3];
+          } else {
+            g[u] = r / a.S;
+          }
+        }
+      }
+      float rx[4], ry[4], rz[4];
+      float4 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int bi = g[u] / a.M;
+        const float *pj = a.xyz + ((size_t)bi * a.N + j[u]) * 3;
+        const float *ci = a.new_xyz + (size_t)g[u] * 3;
+        rx[u] = (pj[0] - ci[0]) * a.inv_radius;
+        ry[u] = (pj[1] - ci[1]) * a.inv_radius;
+        rz[u] = (pj[2] - ci[2]) * a.inv_radius;
+        p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) p[u] = *reinterpret_cast<const float4 *>(a.P + ((size_t)bi * a.N + j[u]) * a.nl + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r4 + 8 * u;
+        if (r >= rend) continue;
+        if (c0 == 0 && q == 0)
+          *reinterpret_cast<float4 *>(a.relx + (size_t)r * 4) = make_float4(rx[u], ry[u], rz[u], 0.f);
+        if (live) {
+          // the row-wise product's order: xyz columns first, then the feature sum
+          float4 y;
+          y.x = fmaf(rz[u], wz.x, fmaf(ry[u], wy.x, rx[u] * wx.x)) + p[u].x;
+          y.y = fmaf(rz[u], wz.y, fmaf(ry[u], wy.y, rx[u] * wx.y)) + p[u].y;
+          y.z = fmaf(rz[u], wz.z, fmaf(ry[u], wy.z, rx[u] * wx.z)) + p[u].z;
+          y.w = fmaf(rz[u], wz.w, fmaf(ry[u], wy.w, rx[u] * wx.w)) + p[u].w;
+          *reinterpret_cast<float4 *>(a.y0 + (size_t)r * a.nl + c) = y;
+          const float ww = w[u];
+          d1[0] += (double)(ww * y.x); d2[0] += (double)(ww * y.x * y.x);
+          d1[1] += (double)(ww * y.y); d2[1] += (double)(ww * y.y * y.y);
+          d1[2] += (double)(ww * y.z); d2[2] += (double)(ww * y.z * y.z);
+          d1[3] += (double)(ww * y.w); d2[3] += (double)(ww * y.w * y.w);
+        }
+      }
+    }
+    // the eight row slots of a channel: fixed order
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][rr][q * 4 + e] = d1[e];
+      red[1][rr][q * 4 + e] = d2[e];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * 128; t += 256) {
+      const int which = t >> 7, cc = t & 127;
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += red[which][k][cc];
+      if (c0 + cc < a.nl) a.part[((size_t)blockIdx.x * 2 + which) * a.nl + c0 + cc] = (float)s;
+    }
+    __syncthreads();
+  }
+}
+
+// dW0 (nl, 3 + c) dense rows = [dW_x (nl, 4) without its pad | dW_f (nl, c)]
+__global__ __launch_bounds__(256) void ppfl_assemble_kernel(int nl, int c, const float *__restrict__ dwx,
+                                                            const float *__restrict__ dwf,
+                                                            float *__restrict__ dw) {
+  const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  const int kr = 3 + c;
+  if (e >= nl * kr) return;
+  const int n = e / kr, k = e - n * kr;
+  dw[e] = k < 3 ? dwx[(size_t)n * 4 + k] : dwf[(size_t)n * c + (k - 3)];
+}
+
+// (internal.hpp) Y0 / relx / part of a PPFL first layer; `grid` = rows of `part` = workgroups
+int ppfl_forward(int b, int n, int m, int s, int nl, int rows, float inv_radius, const float *xyz,
+                 const float *new_xyz, const int *idx, const float *P, const float *w0x, float *y0,
+                 float *relx, float *part, int grid, hipStream_t st) {
+  BTR_REQUIRE(xyz && new_xyz && idx && P && w0x && y0 && relx && part && nl % 4 == 0 && grid > 0,
+              "ppfl_forward: bad arguments");
+  PpflArgs a{};
+  a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx; a.P = P; a.w0x = w0x; a.y0 = y0; a.relx = relx;
+  a.part = part; a.N = n; a.M = m; a.S = s; a.nl = nl; a.rows = rows;
+  a.rows_per_wg = cdiv(cdiv(rows, grid), 8) * 8;
+  a.inv_radius = inv_radius;
+  hipLaunchKernelGGL(ppfl_gather_add_kernel, dim3(grid), dim3(256), 0, st, a, cur_compact());
+  return check_launch("ppfl_forward");
+}
+int ppfl_assemble(int nl, int c, const float *dwx, const float *dwf, float *dw, hipStream_t st) {
+  hipLaunchKernelGGL(ppfl_assemble_kernel, dim3(cdiv(nl * (3 + c), 256)), dim3(256), 0, st, nl, c,
+                     dwx, dwf, dw);
+  return check_launch("ppfl_assemble");
+}
+}  // namespace btr
+extern "C" {
+
 // ------------------------------------------------------------- point-wise MLP chains (pm)
 // gemm_nt_kernel's row-tile workgroups (64-row tiles, grid-stride)
 static int pm_tiles64_grid(int rows) {

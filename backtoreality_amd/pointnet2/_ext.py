@@ -225,6 +225,7 @@ MAX_LAYERS = 8   # BTR_MAX_LAYERS
 _vp8, _ci8, _cf8, _sz8 = _vp * 8, _ci * 8, _cf * 8, _sz * 8
 SA_OPT_COMPACT, SA_OPT_RECOMPUTE, SA_OPT_POOL_EPILOGUE, SA_OPT_POOL_GRAD = 1, 2, 4, 8
 SA_OPT_POOL_GRAM = 16
+SA_OPT_PPFL = 64
 
 
 class SaLayer(ctypes.Structure):

@@ -432,6 +432,9 @@ def _sa_options():
         o |= _ext.SA_OPT_POOL_GRAM
         if os.environ.get("BTR_POOL_GRAM", "1") == "2":   # (every covered shape: csrc/sa_mlp.hip
             o |= 32                                        # reads it; here it only keys the caches)
+    # per-point first layer (whole-layer / whole-backbone calls; BTR_SA_PPFL=0: row-wise)
+    if os.environ.get("BTR_SA_PPFL", "1") != "0" and os.environ.get("BTR_GEMM", "") != "f32":
+        o |= _ext.SA_OPT_PPFL
     return o
 
 

@@ -608,8 +608,13 @@ enum {
   BTR_SA_OPT_RECOMPUTE = 2,     /* never store the first layer's output of a 4-column input      */
   BTR_SA_OPT_POOL_EPILOGUE = 4, /* group extrema from the last GEMM's epilogue                    */
   BTR_SA_OPT_POOL_GRAD = 8,     /* pooled gradient formed inside the GEMM operand staging        */
-  BTR_SA_OPT_POOL_GRAM = 16     /* pooled layer without its stored output (btr_sa_bwd_gram); the
+  BTR_SA_OPT_POOL_GRAM = 16,    /* pooled layer without its stored output (btr_sa_bwd_gram); the
                                    plan reports it as pool_grad == 2                              */
+  BTR_SA_OPT_PPFL = 64          /* per-point first layer: W_f f_j once per point instead of once
+                                   per (centre, neighbour) row, the gradients' feature parts as
+                                   products over the points (levels with >= 32 feature channels
+                                   and no coordinate gradient; csrc/sa_mlp.hip
+                                   ppfl_gather_add_kernel)                                        */
 };
 typedef struct {
   int b, n, m, s, c;            /* batch, points, centres, nsample, feature channels (may be 0)  */

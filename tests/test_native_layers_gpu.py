@@ -56,9 +56,11 @@ def test_sa_layer_call_equals_python_sequence(cuda, monkeypatch, N, npoint, radi
     if options == "plain":   # no compact rows / recompute / pooling epilogue / prologue gradient
         for k in ("BTR_SA_COMPACT", "BTR_SA_RECOMPUTE", "BTR_POOL_EPILOGUE", "BTR_POOLGRAD"):
             monkeypatch.setenv(k, "0")
-    # (the pooled layer's Gram-form backward exists in the whole-layer call only: the Python
-    # sequence reads Y_l; test_gram_form_equals_the_y_reading_form below compares the two)
+    # (the pooled layer's Gram-form backward and the per-point first layer exist in the whole-layer
+    # call only: the Python sequence reads Y_l and multiplies row by row;
+    # test_gram_form_equals_the_y_reading_form / test_per_point_first_layer below compare them)
     monkeypatch.setenv("BTR_POOL_GRAM", "0")
+    monkeypatch.setenv("BTR_SA_PPFL", "0")
     B = 2
     xyz = torch.from_numpy(np.stack([synthetic.make_scene(60 + i, N, use_height=False)[
         'point_clouds'] for i in range(B)], 0)).to(cuda)
@@ -131,6 +133,48 @@ def test_gram_form_equals_the_y_reading_form(cuda, monkeypatch, N, npoint, radiu
         else:
             rel = float((got - want).abs().max() / want.abs().max())
             assert rel < 2e-5, (k, rel)
+
+
+@pytest.mark.parametrize("N,npoint,radius,S,mlp,C", [
+    (4096, 1024, 0.4, 32, [128, 128, 128, 256], 128),    # SA2: compact rows
+    (2048, 512, 0.8, 16, [256, 128, 128, 256], 256),     # SA3 / SA4: dense rows of 16
+    (3000, 300, 0.5, 32, [64, 100, 128], 64),            # ragged, first layer of 100 columns
+])
+def test_per_point_first_layer(cuda, monkeypatch, N, npoint, radius, S, mlp, C):
+    """BTR_SA_OPT_PPFL (W_f f_j once per point, the rows gather it; dW_f / dF as products over the
+    points behind a per-point sum of dY_0) against the row-wise first layer: the same sums in
+    another order -- outputs, BatchNorm buffers and every gradient to float32 rounding."""
+    B = 2
+    xyz = torch.from_numpy(np.stack([synthetic.make_scene(70 + i, N, use_height=False)[
+        'point_clouds'] for i in range(B)], 0)).to(cuda)
+    torch.manual_seed(0)
+    feats = torch.randn(B, C, N, device=cuda)
+    sa = M.PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=S, mlp=list(mlp),
+                                 use_xyz=True, normalize_xyz=True).to(cuda)
+    with torch.no_grad():
+        for layer in sa.mlp_module:
+            layer.bn.bn.weight.uniform_(0.5, 1.5)
+            layer.bn.bn.bias.uniform_(-0.3, 0.3)
+    inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("BTR_SA_PPFL", flag)
+        res[flag] = _sa_run(copy.deepcopy(sa), xyz, feats, inds, False, True)
+    for k, want in res["0"].items():
+        got = res["1"][k]
+        assert (want is None) == (got is None), k
+        if want is None:
+            continue
+        # (Y_0 differs in its last bits, so a max-pool element within rounding of a tie may pick its
+        # other candidate: outputs stay at rounding, a gradient may move by one element's share --
+        # relative L2 as in tests/test_configs_gpu.py; without a flip everything sits at ~4e-7)
+        if k.startswith("d"):
+            rel = float((got.float() - want.float()).norm() / (want.float().norm() + 1e-30))
+            assert rel < 1e-2, (k, rel)
+        else:
+            rel = float((got.float() - want.float()).abs().max() /
+                        (want.float().abs().max() + 1e-30))
+            assert rel < 2e-6, (k, rel)
 
 
 def _chain_compare(run, mod, monkeypatch, summed=()):
