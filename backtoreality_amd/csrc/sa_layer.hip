@@ -484,7 +484,7 @@ struct SaBwdScratch {
 inline bool sa_ppfl(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   return (d.options & BTR_SA_OPT_PPFL) && !p.recompute && d.layers >= 2 && d.use_xyz &&
          d.c >= 32 && d.c % 4 == 0 && p.k0p == d.c + 4 && !d.need_dxyz && !d.need_dnew_xyz &&
-         d.need_dfeat && d.width[0] % 4 == 0 && d.width[0] <= 128 &&
+         d.width[0] % 4 == 0 && d.width[0] <= 128 &&
          (!p.compact || d.n <= 8192);
 }
 
@@ -960,13 +960,14 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       btr_sac_bind(nullptr);   // (products over the points: no compact rows)
       BTR_TRY(btr_sa_gemm_tn(np, n0, d.c, S, n0, fcopy, d.c, nullptr, nullptr,
                              at_f(scratch, sc.ppfl_pw), dwf, stream));
-      float *dfeat_cl = at_f(scratch, sc.dfeat_cl);
-      BTR_TRY(btr_pm_gemm_nt(np, d.c, n0, S, n0, at_f(saved, p.wt[0]), n0, dfeat_cl, d.c, nullptr,
-                             nullptr, nullptr, nullptr, stream));
-      if (p.compact) btr_sac_bind(&cm);
-      if (dfeat)
+      if (d.need_dfeat && dfeat) {
+        float *dfeat_cl = at_f(scratch, sc.dfeat_cl);
+        BTR_TRY(btr_pm_gemm_nt(np, d.c, n0, S, n0, at_f(saved, p.wt[0]), n0, dfeat_cl, d.c,
+                               nullptr, nullptr, nullptr, nullptr, stream));
         BTR_TRY(pm_out_add(d.b, d.n, d.c, d.c, dfeat_cl, nullptr, nullptr, 0, dfeat, nullptr,
                            dfeat_add, dfeat_add_bstride, hmain));
+      }
+      if (p.compact) btr_sac_bind(&cm);
       ppfl_done = fused_any = true;   // (partials written on the main stream: see the join)
       break;
     }
