@@ -384,34 +384,75 @@ __global__ __launch_bounds__(256) void colsum_final_multi_kernel(FinalArgs a) {
                (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// dst (cols, rows) = src (rows, cols)^T for up to 6 matrices in one launch (32 x 32 tiles)
+// Up to 6 weight matrices in one launch (32 x 32 tiles), per matrix src (rows, cols):
+//   tr = 1: dst (cols, rows) = src^T in f32 (dst may be NULL) and, when planes != NULL, the three
+//           bf16 pieces of src^T as planes [3][cols][kp], kp = ceil16(rows)
+//   tr = 0: planes [3][rows][kp] of src itself, kp = ceil16(cols)
+// (the small-M GEMM kernel of sa_mlp.hip loads its weight fragments straight from such planes; the
+// columns between the width and kp hold zeros)
 constexpr int kMaxTr = 6;
 struct TransposeArgs {
   const float *src[kMaxTr];
   float *dst[kMaxTr];
-  int rows[kMaxTr], cols[kMaxTr];
+  __bf16 *planes[kMaxTr];
+  int rows[kMaxTr], cols[kMaxTr], tr[kMaxTr];
   int first[kMaxTr + 1];
   int count;
 };
+__device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  auto widen = [](b2 b) { return __uint_as_float(__builtin_bit_cast(unsigned, b) << 16); };
+  const b2 bh = __builtin_convertvector(f2{v, 0.f}, b2);
+  const float r1 = v - widen(bh);
+  const b2 bm = __builtin_convertvector(f2{r1, 0.f}, b2);
+  const float r2 = r1 - widen(bm);
+  const b2 bl = __builtin_convertvector(f2{r2, 0.f}, b2);
+  h = bh.x; m = bm.x; l = bl.x;
+}
+inline int ceil16(int v) { return (v + 15) / 16 * 16; }
 __global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeArgs a) {
   __shared__ float t[32][33];
   const float *src = a.src[0];
   float *dst = a.dst[0];
-  int rows = a.rows[0], cols = a.cols[0], first = 0;
+  __bf16 *planes = a.planes[0];
+  int rows = a.rows[0], cols = a.cols[0], first = 0, tr = a.tr[0];
 #pragma unroll
   for (int i = 1; i < kMaxTr; ++i)
     if (i < a.count && (int)blockIdx.x >= a.first[i]) {
-      src = a.src[i]; dst = a.dst[i]; rows = a.rows[i]; cols = a.cols[i]; first = a.first[i];
+      src = a.src[i]; dst = a.dst[i]; planes = a.planes[i]; rows = a.rows[i]; cols = a.cols[i];
+      first = a.first[i]; tr = a.tr[i];
     }
   const int tc = (cols + 31) / 32;
-  const int tl = (int)blockIdx.x - first, tr = tl / tc;
-  const int r0 = tr * 32, c0 = (tl - tr * tc) * 32;
+  const int tl = (int)blockIdx.x - first, trow = tl / tc;
+  const int r0 = trow * 32, c0 = (tl - trow * tc) * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int r = ty; r < 32; r += 8)
     t[r][tx] = (r0 + r < rows && c0 + tx < cols) ? src[(size_t)(r0 + r) * cols + c0 + tx] : 0.f;
   __syncthreads();
-  for (int r = ty; r < 32; r += 8)
-    if (c0 + r < cols && r0 + tx < rows) dst[(size_t)(c0 + r) * rows + r0 + tx] = t[tx][r];
+  if (tr) {
+    const int kp = (rows + 15) / 16 * 16;
+    for (int r = ty; r < 32; r += 8) {
+      if (c0 + r >= cols) continue;
+      const float v = t[tx][r];
+      if (dst && r0 + tx < rows) dst[(size_t)(c0 + r) * rows + r0 + tx] = v;
+      if (planes && r0 + tx < kp) {
+        __bf16 h, m, l;
+        split3(v, h, m, l);
+        const size_t at = (size_t)(c0 + r) * kp + r0 + tx, ps = (size_t)cols * kp;
+        planes[at] = h; planes[ps + at] = m; planes[2 * ps + at] = l;
+      }
+    }
+  } else if (planes) {
+    const int kp = (cols + 15) / 16 * 16;
+    for (int r = ty; r < 32; r += 8) {
+      if (r0 + r >= rows || c0 + tx >= kp) continue;
+      __bf16 h, m, l;
+      split3(t[r][tx], h, m, l);
+      const size_t at = (size_t)(r0 + r) * kp + c0 + tx, ps = (size_t)rows * kp;
+      planes[at] = h; planes[ps + at] = m; planes[2 * ps + at] = l;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------ host helpers
@@ -463,10 +504,39 @@ int rows_to_bcp(hipStream_t s, int b, int p, int c, const float *a0, const float
   return check_launch("decoder rows_to_bcp");
 }
 
+// BTR_DECODER_SM=0: the projections / input-gradient GEMMs on gemm_nt_kernel's 64 x 128 tiles as
+// before; default: the small-M kernel on weight planes made once per call (1 024-row query GEMMs
+// of 288 - 864 columns: 13 - 35 us -> 6 - 12 us, profiles/r05_gf_*).  Needs e % 16 == 0 (sub-blocks
+// of the packed in_proj weights are addressed inside one set of planes).
+bool decoder_sm(const btr_decoder_layer_t &d) {
+  const char *e = getenv("BTR_DECODER_SM");
+  return !(e && e[0] == '0') && d.e % 16 == 0 && d.ff % 16 == 0;
+}
+// ... and only where it measured faster (same box, r05_gf_eager2 against r05_gf_eager): few rows and
+// a moderate output width.  1 024 x 288 x 288: 13.4 -> 8.6 us, 1 024 x 864 x 288 18 -> 13.6,
+// 1 024 x 288 x 864 34.4 -> 20.8; but 4 096 x 576 x 288 (keys) 21 -> 28 and 1 024 x 2 048 x 288
+// (feed-forward) 22 -> 24: every 32-row tile re-reads its 64 weight rows from L2.
+bool sm_shape(int rows, int n_out) { return rows <= 2048 && n_out <= 1024; }
+// forward planes: in_proj (3e, e), out_proj (e, e) of both attentions, linear1 (ff, e)
+struct FwdPlanes {
+  size_t sa_in, sa_out, ca_in, ca_out, l1, bytes;
+};
+FwdPlanes fwd_planes(const btr_decoder_layer_t &d, size_t base) {
+  FwdPlanes f{};
+  Bump b;
+  b.off = base;
+  const size_t e = d.e, ff = d.ff;
+  f.sa_in = b.take(3 * 3 * e * e * 2); f.sa_out = b.take(3 * e * e * 2);
+  f.ca_in = b.take(3 * 3 * e * e * 2); f.ca_out = b.take(3 * e * e * 2);
+  f.l1 = b.take(3 * ff * e * 2);
+  f.bytes = b.off - base;
+  return f;
+}
 struct BwdScratch {
   size_t dx3, dres3, df, dh, dx2f, dres2, do2, da2, dq2, dkv, dqp1, dkp, dres1, do1, da1, dqkv,
       dqp0, dsum;
   size_t t_sa_in, t_sa_out, t_ca_in, t_ca_out, t_l1, t_l2;
+  size_t p_sa_in, p_sa_out, p_ca_in, p_ca_out, p_l2;   // bf16 planes of the transposes (decoder_sm)
   size_t pw[8];
   size_t cs[8];      // column-sum partials of the 8 bias gradients
   size_t lnp[3];     // LayerNorm gamma / beta partials
@@ -502,6 +572,11 @@ BwdScratch bwd_scratch(const btr_decoder_layer_t &d) {
   s.t_sa_in = b.floats(3 * e * e); s.t_sa_out = b.floats(e * e);
   s.t_ca_in = b.floats(3 * e * e); s.t_ca_out = b.floats(e * e);
   s.t_l1 = b.floats(f * e); s.t_l2 = b.floats(f * e);
+  if (decoder_sm(d)) {
+    s.p_sa_in = b.take(3 * 3 * e * e * 2); s.p_sa_out = b.take(3 * e * e * 2);
+    s.p_ca_in = b.take(3 * 3 * e * e * 2); s.p_ca_out = b.take(3 * e * e * 2);
+    s.p_l2 = b.take(3 * f * e * 2);
+  }
   Lin l[7];
   linears(d, l);
   for (int i = 0; i < 7; ++i) {
@@ -549,6 +624,7 @@ int btr_decoder_layer_plan(const btr_decoder_layer_t *dp, btr_decoder_plan_t *p)
   p->saved_bytes = sv.off;
   Bump fs;   // forward scratch: the branch output that is normalised in (split-K: its planes)
   fs.floats(rq * e * (size_t)pm_splitk_slices((int)rq, d.e, d.ff));
+  if (decoder_sm(d)) fs.off += fwd_planes(d, fs.off).bytes;
   p->fwd_scratch_bytes = fs.off;
   p->bwd_scratch_bytes = bwd_scratch(d).bytes;
   size_t g = 0;   // flat gradients, floats
@@ -581,20 +657,51 @@ int btr_decoder_layer_forward(const btr_decoder_layer_t *dp, const btr_decoder_p
   float *kp = at_f(saved, p.kp), *kv = at_f(saved, p.kv), *a2 = at_f(saved, p.a2);
   float *x2 = at_f(saved, p.x2), *h = at_f(saved, p.h);
 
+  // ---- the weights as bf16 planes (one launch), for the small-M GEMM kernel
+  const bool sm = decoder_sm(d);
+  FwdPlanes fp{};
+  if (sm) {
+    Bump fs;
+    fs.floats((size_t)rq * e * (size_t)pm_splitk_slices(rq, d.e, d.ff));
+    fp = fwd_planes(d, fs.off);
+    TransposeArgs t{};
+    const float *src[5] = {d.sa_in_w, d.sa_out_w, d.ca_in_w, d.ca_out_w, d.lin1_w};
+    const size_t off[5] = {fp.sa_in, fp.sa_out, fp.ca_in, fp.ca_out, fp.l1};
+    const int rr[5] = {3 * e, e, 3 * e, e, f};
+    int blocks = 0;
+    for (int i = 0; i < 5; ++i) {
+      t.src[i] = src[i]; t.dst[i] = nullptr; t.planes[i] = (__bf16 *)((char *)scratch + off[i]);
+      t.rows[i] = rr[i]; t.cols[i] = e; t.tr[i] = 0;
+      t.first[i] = blocks;
+      blocks += cdiv(rr[i], 32) * cdiv(e, 32);
+    }
+    t.first[5] = blocks;
+    t.count = 5;
+    hipLaunchKernelGGL(transpose_multi_kernel, dim3(blocks), dim3(256), 0, hs, t);
+  }
+  // C (rows, n) = A (rows, k) . W^T + bias, W (n, k) rows `row0`.. of a weight whose planes start
+  // at `poff` (pitch e: every weight here has k = e columns)
+  auto proj = [&](int rows, int n, const float *a, const float *w, size_t poff, int row0,
+                  int nall, float *c, const float *bias) {
+    if (sm && sm_shape(rows, n))
+      return pm_gemm_nt_planes(rows, n, e, a, e,
+                               (const __bf16 *)((const char *)scratch + poff) + (size_t)row0 * e,
+                               e, (long long)nall * e, c, n, bias, hs);
+    return btr_pm_gemm_nt(rows, n, e, a, e, w + (size_t)row0 * e, e, c, n, nullptr, nullptr,
+                          nullptr, bias, stream);
+  };
   // ---- self-attention
   const float *qsrc = x_cl;
   if (qpos_cl) {
     BTR_TRY(add2(hs, (long long)rq * e, x_cl, qpos_cl, qp0));
     qsrc = qp0;
   }
-  BTR_TRY(btr_pm_gemm_nt(rq, 3 * e, e, qsrc, e, d.sa_in_w, e, qkv, 3 * e, nullptr, nullptr,
-                         nullptr, d.sa_in_b, stream));
+  BTR_TRY(proj(rq, 3 * e, qsrc, d.sa_in_w, fp.sa_in, 0, 3 * e, qkv, d.sa_in_b));
   BTR_TRY(attention_fwd_strided(d.pq, d.pq, d.b, d.heads, hd, qkv, 3 * e, (long long)d.pq * 3 * e,
                                 qkv + e, qkv + 2 * e, 3 * e, (long long)d.pq * 3 * e, a1, e,
                                 (long long)d.pq * e, at_f(saved, p.lse1), scale, d.dropout,
                                 attn_seed(d, 0), d.step, stream));
-  BTR_TRY(btr_pm_gemm_nt(rq, e, e, a1, e, d.sa_out_w, e, o, e, nullptr, nullptr, nullptr,
-                         d.sa_out_b, stream));
+  BTR_TRY(proj(rq, e, a1, d.sa_out_w, fp.sa_out, 0, e, o, d.sa_out_b));
   {
     LnFwd a{rq, e, x_cl, o, 1, 0, nullptr, make_drop(d, 0), d.ln_w[0], d.ln_b[0], d.ln_eps[0], x1,
             at_f(saved, p.xh1), at_f(saved, p.rs1), qpos_cl, qpos_cl ? qp1 : nullptr};
@@ -602,29 +709,25 @@ int btr_decoder_layer_forward(const btr_decoder_layer_t *dp, const btr_decoder_p
   }
   // ---- cross-attention
   const float *q2src = qpos_cl ? qp1 : x1;
-  BTR_TRY(btr_pm_gemm_nt(rq, e, e, q2src, e, d.ca_in_w, e, q2, e, nullptr, nullptr, nullptr,
-                         d.ca_in_b, stream));
+  BTR_TRY(proj(rq, e, q2src, d.ca_in_w, fp.ca_in, 0, 3 * e, q2, d.ca_in_b));
   const float *ksrc = key_cl;
   if (kpos_cl) {
     BTR_TRY(add2(hs, (long long)rk * e, key_cl, kpos_cl, kp));
     ksrc = kp;
   }
-  BTR_TRY(btr_pm_gemm_nt(rk, 2 * e, e, ksrc, e, d.ca_in_w + (size_t)e * e, e, kv, 2 * e, nullptr,
-                         nullptr, nullptr, d.ca_in_b + e, stream));
+  BTR_TRY(proj(rk, 2 * e, ksrc, d.ca_in_w, fp.ca_in, e, 3 * e, kv, d.ca_in_b + e));
   BTR_TRY(attention_fwd_strided(d.pq, d.pk, d.b, d.heads, hd, q2, e, (long long)d.pq * e, kv,
                                 kv + e, 2 * e, (long long)d.pk * 2 * e, a2, e,
                                 (long long)d.pq * e, at_f(saved, p.lse2), scale, d.dropout,
                                 attn_seed(d, 1), d.step, stream));
-  BTR_TRY(btr_pm_gemm_nt(rq, e, e, a2, e, d.ca_out_w, e, o, e, nullptr, nullptr, nullptr,
-                         d.ca_out_b, stream));
+  BTR_TRY(proj(rq, e, a2, d.ca_out_w, fp.ca_out, 0, e, o, d.ca_out_b));
   {
     LnFwd a{rq, e, x1, o, 1, 0, nullptr, make_drop(d, 1), d.ln_w[1], d.ln_b[1], d.ln_eps[1], x2,
             at_f(saved, p.xh2), at_f(saved, p.rs2), nullptr, nullptr};
     BTR_TRY(ln_forward(hs, a));
   }
   // ---- feed-forward
-  BTR_TRY(btr_pm_gemm_nt(rq, f, e, x2, e, d.lin1_w, e, h, f, nullptr, nullptr, nullptr, d.lin1_b,
-                         stream));
+  BTR_TRY(proj(rq, f, x2, d.lin1_w, fp.l1, 0, f, h, d.lin1_b));
   hipLaunchKernelGGL(relu_drop_kernel, dim3(cdiv((long long)rq * f / 4, 256)), dim3(256), 0, hs,
                      (long long)rq * f / 4, (float4 *)h, make_drop(d, 2));
   const int sk = pm_splitk_slices(rq, e, f);   // linear2: 288 columns, reduction over ff
@@ -665,15 +768,19 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
   Lin lin[7];
   linears(d, lin);
 
+  const bool sm = decoder_sm(d);
   {  // transposed weights: the input-gradient GEMMs are NT GEMMs on W^T
     TransposeArgs t{};
     const float *src[kMaxTr] = {d.sa_in_w, d.sa_out_w, d.ca_in_w, d.ca_out_w, d.lin1_w, d.lin2_w};
     float *dst[kMaxTr] = {S(sc.t_sa_in), S(sc.t_sa_out), S(sc.t_ca_in),
                           S(sc.t_ca_out), S(sc.t_l1), S(sc.t_l2)};
     const int rr[kMaxTr] = {3 * e, e, 3 * e, e, f, e}, cc[kMaxTr] = {e, e, e, e, e, f};
+    const size_t pl[kMaxTr] = {sc.p_sa_in, sc.p_sa_out, sc.p_ca_in, sc.p_ca_out, 0, sc.p_l2};
     int blocks = 0;
     for (int i = 0; i < kMaxTr; ++i) {
       t.src[i] = src[i]; t.dst[i] = dst[i]; t.rows[i] = rr[i]; t.cols[i] = cc[i];
+      t.tr[i] = 1;
+      t.planes[i] = (sm && i != 4) ? (__bf16 *)((char *)scratch + pl[i]) : nullptr;
       t.first[i] = blocks;
       blocks += cdiv(rr[i], 32) * cdiv(cc[i], 32);
     }
@@ -692,7 +799,14 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
                           nullptr, S(sc.pw[i]), dw, stream);
   };
   // dX (rows, k) = dY (rows, n) . W (n, k), as an NT GEMM on wt = W^T (k, n) (leading dim ldw)
-  auto dgrad = [&](int rows, int n, int k, const float *g, const float *wt, int ldw, float *dx) {
+  // (planes of wt: `poff` = start of the transposed weight's planes, col0 = first column of the
+  // block, nall = its rows: the pitch is ceil16(ldw), the plane stride nall * pitch)
+  auto dgrad = [&](int rows, int n, int k, const float *g, const float *wt, int ldw, float *dx,
+                   size_t poff, int col0, int nall) {
+    if (sm && sm_shape(rows, k) && n % 16 == 0 && col0 % 8 == 0)
+      return pm_gemm_nt_planes(rows, k, n, g, n,
+                               (const __bf16 *)((const char *)scratch + poff) + col0, ceil16(ldw),
+                               (long long)nall * ceil16(ldw), dx, k, nullptr, hs);
     return btr_pm_gemm_nt(rows, k, n, g, n, wt, ldw, dx, k, nullptr, nullptr, nullptr, nullptr,
                           stream);
   };
@@ -705,7 +819,7 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
     BTR_TRY(ln_backward(hs, a));
   }
   BTR_TRY(wgrad(6, S(sc.df), h, grads + p.g_lin2_w));
-  BTR_TRY(dgrad(rq, e, f, S(sc.df), S(sc.t_l2), e, S(sc.dh)));
+  BTR_TRY(dgrad(rq, e, f, S(sc.df), S(sc.t_l2), e, S(sc.dh), sc.p_l2, 0, f));
   hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(cdiv((long long)rq * f / 4, 256)), dim3(256), 0,
                      hs, (long long)rq * f / 4, (float4 *)S(sc.dh), (const float4 *)h,
                      make_drop(d, 2).keep_inv);
@@ -715,7 +829,8 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
     BTR_TRY(pm_gemm_nt_splitk(rq, e, f, S(sc.dh), f, S(sc.t_l1), f, S(sc.dx2f),
                               (long long)rq * e, sk, hs));
   else
-    BTR_TRY(dgrad(rq, f, e, S(sc.dh), S(sc.t_l1), f, S(sc.dx2f)));
+    BTR_TRY(btr_pm_gemm_nt(rq, e, f, S(sc.dh), f, S(sc.t_l1), f, S(sc.dx2f), e, nullptr, nullptr,
+                           nullptr, nullptr, stream));
   // ---- LayerNorm 2, cross-attention
   {
     LnBwd a{rq, e, S(sc.dres3), S(sc.dx2f), nullptr, sk, (long long)rq * e, at_f(saved, p.xh2), at_f(saved, p.rs2),
@@ -723,7 +838,7 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
     BTR_TRY(ln_backward(hs, a));
   }
   BTR_TRY(wgrad(4, S(sc.do2), a2, grads + p.g_ca_out_w));
-  BTR_TRY(dgrad(rq, e, e, S(sc.do2), S(sc.t_ca_out), e, S(sc.da2)));
+  BTR_TRY(dgrad(rq, e, e, S(sc.do2), S(sc.t_ca_out), e, S(sc.da2), sc.p_ca_out, 0, e));
   BTR_TRY(attention_bwd_strided(
       d.pq, d.pk, d.b, d.heads, hd, q2, e, (long long)d.pq * e, kv, kv + e, 2 * e,
       (long long)d.pk * 2 * e, a2, S(sc.da2), e, (long long)d.pq * e, at_f(saved, p.lse2),
@@ -731,9 +846,9 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
       (long long)d.pk * 2 * e, scale, d.dropout, attn_seed(d, 1), d.step, stream));
   BTR_TRY(wgrad(2, S(sc.dq2), qp1, grads + p.g_ca_in_w));
   BTR_TRY(wgrad(3, S(sc.dkv), kp, grads + p.g_ca_in_w + (size_t)e * e));
-  BTR_TRY(dgrad(rq, e, e, S(sc.dq2), S(sc.t_ca_in), 3 * e, S(sc.dqp1)));
+  BTR_TRY(dgrad(rq, e, e, S(sc.dq2), S(sc.t_ca_in), 3 * e, S(sc.dqp1), sc.p_ca_in, 0, e));
   if (dkey_bcp)
-    BTR_TRY(dgrad(rk, 2 * e, e, S(sc.dkv), S(sc.t_ca_in) + e, 3 * e, S(sc.dkp)));
+    BTR_TRY(dgrad(rk, 2 * e, e, S(sc.dkv), S(sc.t_ca_in) + e, 3 * e, S(sc.dkp), sc.p_ca_in, e, e));
   // ---- LayerNorm 1, self-attention
   {
     LnBwd a{rq, e, S(sc.dres2), S(sc.dqp1), nullptr, 1, 0, at_f(saved, p.xh1), at_f(saved, p.rs1),
@@ -741,7 +856,7 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
     BTR_TRY(ln_backward(hs, a));
   }
   BTR_TRY(wgrad(1, S(sc.do1), a1, grads + p.g_sa_out_w));
-  BTR_TRY(dgrad(rq, e, e, S(sc.do1), S(sc.t_sa_out), e, S(sc.da1)));
+  BTR_TRY(dgrad(rq, e, e, S(sc.do1), S(sc.t_sa_out), e, S(sc.da1), sc.p_sa_out, 0, e));
   BTR_TRY(attention_bwd_strided(
       d.pq, d.pq, d.b, d.heads, hd, qkv, 3 * e, (long long)d.pq * 3 * e, qkv + e, qkv + 2 * e,
       3 * e, (long long)d.pq * 3 * e, a1, S(sc.da1), e, (long long)d.pq * e, at_f(saved, p.lse1),
@@ -749,7 +864,7 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
       S(sc.dqkv) + 2 * e, 3 * e, (long long)d.pq * 3 * e, scale, d.dropout, attn_seed(d, 0),
       d.step, stream));
   BTR_TRY(wgrad(0, S(sc.dqkv), qp0, grads + p.g_sa_in_w));
-  BTR_TRY(dgrad(rq, 3 * e, e, S(sc.dqkv), S(sc.t_sa_in), 3 * e, S(sc.dqp0)));
+  BTR_TRY(dgrad(rq, 3 * e, e, S(sc.dqkv), S(sc.t_sa_in), 3 * e, S(sc.dqp0), sc.p_sa_in, 0, e));
   reduce_batch_flush(hs);
   flush.open = false;
 

@@ -1,0 +1,336 @@
+// gf_stack.hip -- the GroupFree3D decoder stack, one call per direction.
+//
+// reference: detection/GroupFree3D/models/detector.py:161-219 (the loop over the decoder layers:
+// position embeddings -> decoder layer -> prediction head -> next query position) and
+// detector.py:204-230 (the detached (center, pred_size) query position).
+//
+// Nothing is computed here that the per-module entry points do not compute: the host walks the
+// launches of btr_pm_chain_forward / _backward (position embeddings, prediction heads),
+// btr_decoder_layer_forward / _backward and btr_gf_head_decode in the order the module loop of
+// the reference runs them, on buffers cut out of one `saved` / `scratch` / `grads` allocation.
+// The step was paced by the host: 39 autograd nodes, ~0.1 ms of interpreter each way around ~10
+// launches of 5 - 20 us each (tools/host_profile_gf.py), 3 us of which is the launch itself
+// (tools/probe/launch_cost.hip).  One node instead of 30 leaves the launches.
+//
+// Data handed between the modules stays in channel-last rows (the layout every GEMM here reads):
+//   x[i]        (b*pq, e)   output of layer i  -> layer i+1, head i            (saved)
+//   qpos_cl[i]  (b*pq, e)   self position embedding of layer i                 (saved)
+//   kpos_cl[i]  (b*pk, e)   cross position embedding of layer i                (saved)
+// Backward, layer i (from the last): head i's chain gives d x[i] (+ the gradient arriving from
+// layer i+1, + the caller's gradient of the last output), the layer gives d x[i-1], d qpos_cl[i],
+// d key (which is d kpos_cl[i] as well: kp = key + kpos), the two embedding chains take theirs,
+// the key gradients of all layers are summed at the end.
+#include <algorithm>
+#include <cstring>
+
+#include "internal.hpp"
+
+namespace btr {
+namespace {
+
+constexpr size_t kAlign = 256;
+inline size_t up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t at = off;
+    off = up(off + bytes);
+    return at;
+  }
+  size_t floats(size_t n) { return take(n * sizeof(float)); }
+};
+inline float *at_f(void *base, size_t off) { return (float *)((char *)base + off); }
+inline void *at_v(void *base, size_t off) { return (void *)((char *)base + off); }
+
+#define BTR_TRY(call)              \
+  do {                             \
+    const int rc_ = (call);        \
+    if (rc_ != BTR_OK) return rc_; \
+  } while (0)
+
+constexpr int kMaxOps = 16;
+struct SumArgs {
+  const float4 *src[kMaxOps];
+  int count;
+  long long n4;
+  float4 *dst;
+};
+// dst = src[0] + src[1] + ... (in that order), 16 bytes per lane
+__global__ __launch_bounds__(256) void sum_rows_kernel(SumArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n4) return;
+  float4 s = a.src[0][i];
+  for (int k = 1; k < a.count; ++k) {
+    const float4 v = a.src[k][i];
+    s.x += v.x;
+    s.y += v.y;
+    s.z += v.z;
+    s.w += v.w;
+  }
+  a.dst[i] = s;
+}
+int sum_into(hipStream_t s, long long n, const float *const *src, int count, float *dst) {
+  SumArgs a{};
+  a.count = count;
+  a.n4 = n / 4;
+  a.dst = (float4 *)dst;
+  for (int k = 0; k < count; ++k) a.src[k] = (const float4 *)src[k];
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((a.n4 + 255) / 256)), dim3(256), 0, s, a);
+  return check_launch("gf_stack sum");
+}
+
+struct BwdScratch {
+  size_t sub;                 // the modules' own scratch (they run one after the other)
+  size_t dx[2];               // (b, e, pq): gradient of x[i] from layer i+1, ping-pong
+  size_t dhx;                 // (b, e, pq): gradient of x[i] from head i
+  size_t dsum;                // (b, e, pq): what layer i's backward is given
+  size_t dqpos;               // (b, e, pq)
+  size_t dkey[BTR_GF_MAX_DECODER_LAYERS];   // (b, e, pk) per layer
+  size_t bytes;
+};
+BwdScratch bwd_scratch(const btr_gf_stack_t &d, const btr_gf_stack_plan_t &p) {
+  BwdScratch s{};
+  Bump b;
+  size_t sub = 0;
+  for (int i = 0; i < d.layers; ++i) {
+    sub = std::max(sub, p.layer[i].bwd_scratch_bytes);
+    sub = std::max(sub, p.head[i].bwd_scratch_bytes);
+    if (d.has_qpos) sub = std::max(sub, p.qpos[i].bwd_scratch_bytes);
+    if (d.has_kpos) sub = std::max(sub, p.kpos[i].bwd_scratch_bytes);
+  }
+  s.sub = b.take(sub);
+  const size_t q = (size_t)d.b * d.pq * d.e, k = (size_t)d.b * d.pk * d.e;
+  s.dx[0] = b.floats(q);
+  s.dx[1] = b.floats(q);
+  s.dhx = b.floats(q);
+  s.dsum = b.floats(q);
+  s.dqpos = b.floats(q);
+  for (int i = 0; i < d.layers; ++i) s.dkey[i] = b.floats(k);
+  s.bytes = b.off;
+  return s;
+}
+
+int check(const btr_gf_stack_t &d) {
+  BTR_REQUIRE(d.layers > 0 && d.layers <= BTR_GF_MAX_DECODER_LAYERS, "gf_stack: %d layers",
+              d.layers);
+  BTR_REQUIRE(d.b > 0 && d.pq > 0 && d.pk > 0 && d.e > 0 && d.e % 4 == 0 && d.head_c > 0,
+              "gf_stack: bad sizes");
+  for (int i = 0; i < d.layers; ++i) {
+    const btr_decoder_layer_t &l = d.layer[i];
+    BTR_REQUIRE(l.b == d.b && l.pq == d.pq && l.pk == d.pk && l.e == d.e,
+                "gf_stack: layer %d sizes differ from the stack's", i);
+    const btr_pm_chain_t &h = d.head[i];
+    BTR_REQUIRE(h.b == d.b && h.n == d.pq && h.c == d.e && h.layers >= 1 &&
+                    h.width[h.layers - 1] == d.head_c && h.need_dx == 1,
+                "gf_stack: head %d is not a (b, e, pq) -> (b, head_c, pq) chain with need_dx", i);
+    if (d.has_qpos) {
+      const btr_pm_chain_t &c = d.qpos[i];
+      BTR_REQUIRE(c.b == d.b && c.n == d.pq && c.layers >= 1 && c.width[c.layers - 1] == d.e &&
+                      c.need_dx == 0,
+                  "gf_stack: query position embedding %d", i);
+    }
+    if (d.has_kpos) {
+      const btr_pm_chain_t &c = d.kpos[i];
+      BTR_REQUIRE(c.b == d.b && c.n == d.pk && c.layers >= 1 && c.width[c.layers - 1] == d.e &&
+                      c.need_dx == 0,
+                  "gf_stack: key position embedding %d", i);
+    }
+  }
+  return BTR_OK;
+}
+
+}  // namespace
+}  // namespace btr
+
+using namespace btr;
+
+extern "C" {
+
+// sizeof(btr_gf_stack_t) (0) / sizeof(btr_gf_stack_plan_t) (1): lets a binding written in another
+// language check its mirror of the two structs before it hands one over
+long long btr_gf_stack_sizeof(int which) {
+  return which == 0 ? (long long)sizeof(btr_gf_stack_t) : (long long)sizeof(btr_gf_stack_plan_t);
+}
+
+int btr_gf_stack_plan(const btr_gf_stack_t *dp, btr_gf_stack_plan_t *p) {
+  BTR_REQUIRE(dp && p, "gf_stack_plan: null pointer");
+  const btr_gf_stack_t &d = *dp;
+  BTR_TRY(check(d));
+  std::memset(p, 0, sizeof(*p));
+  Bump sv;
+  size_t g = 0, fs = 0;
+  const size_t q = (size_t)d.b * d.pq * d.e, k = (size_t)d.b * d.pk * d.e;
+  for (int i = 0; i < d.layers; ++i) {
+    BTR_TRY(btr_decoder_layer_plan(&d.layer[i], &p->layer[i]));
+    BTR_TRY(btr_pm_chain_plan(&d.head[i], &p->head[i]));
+    if (d.has_qpos) BTR_TRY(btr_pm_chain_plan(&d.qpos[i], &p->qpos[i]));
+    if (d.has_kpos) BTR_TRY(btr_pm_chain_plan(&d.kpos[i], &p->kpos[i]));
+    p->s_layer[i] = sv.take(p->layer[i].saved_bytes);
+    p->s_head[i] = sv.take(p->head[i].saved_bytes);
+    p->s_x[i] = sv.floats(q);
+    p->g_layer[i] = g;
+    g += p->layer[i].grads_floats;
+    p->g_head[i] = g;
+    g += p->head[i].grads_floats;
+    fs = std::max(fs, p->layer[i].fwd_scratch_bytes);
+    fs = std::max(fs, p->head[i].fwd_scratch_bytes);
+    if (d.has_qpos) {
+      p->s_qpos[i] = sv.take(p->qpos[i].saved_bytes);
+      p->s_qpos_cl[i] = sv.floats(q);
+      p->g_qpos[i] = g;
+      g += p->qpos[i].grads_floats;
+      fs = std::max(fs, p->qpos[i].fwd_scratch_bytes);
+    }
+    if (d.has_kpos) {
+      p->s_kpos[i] = sv.take(p->kpos[i].saved_bytes);
+      p->s_kpos_cl[i] = sv.floats(k);
+      p->g_kpos[i] = g;
+      g += p->kpos[i].grads_floats;
+      fs = std::max(fs, p->kpos[i].fwd_scratch_bytes);
+    }
+  }
+  p->saved_bytes = sv.off;
+  p->grads_floats = g;
+  // forward scratch: the modules' own + the (b, e, p) output an embedding chain also writes
+  p->fwd_scratch_bytes = up(fs) + up(std::max(q, k) * sizeof(float));
+  p->bwd_scratch_bytes = bwd_scratch(d, *p).bytes;
+  return BTR_OK;
+}
+
+int btr_gf_stack_forward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *pp,
+                         const float *query_cl, const float *key_cl, const float *qpos0_t,
+                         const float *key_xyz_t, const float *base_xyz, const float *mean_size,
+                         float *const *head_out, float *const *head_out_cl, float *const *center,
+                         float *const *heading_residuals, float *const *size_residuals,
+                         float *const *pred_size, float *const *query_pos,
+                         float *const *query_pos_t, float *last_bcp, float *last_cl, void *saved,
+                         void *scratch, btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && query_cl && key_cl && base_xyz && mean_size && head_out &&
+                  head_out_cl && center && heading_residuals && size_residuals && pred_size &&
+                  query_pos && query_pos_t && saved && scratch,
+              "gf_stack_forward: null pointer");
+  const btr_gf_stack_t &d = *dp;
+  const btr_gf_stack_plan_t &p = *pp;
+  BTR_REQUIRE(!d.has_qpos || qpos0_t, "gf_stack_forward: the first query position is missing");
+  BTR_REQUIRE(!d.has_kpos || key_xyz_t, "gf_stack_forward: the key position is missing");
+  hipStream_t hs = as_stream(stream);
+  size_t fs = 0;
+  for (int i = 0; i < d.layers; ++i) {
+    fs = std::max(fs, p.layer[i].fwd_scratch_bytes);
+    fs = std::max(fs, p.head[i].fwd_scratch_bytes);
+    if (d.has_qpos) fs = std::max(fs, p.qpos[i].fwd_scratch_bytes);
+    if (d.has_kpos) fs = std::max(fs, p.kpos[i].fwd_scratch_bytes);
+  }
+  float *bcp_dummy = at_f(scratch, up(fs));
+  const float *x = query_cl;
+  const float *qpos_t = qpos0_t;
+  const int L = d.layers;
+  for (int i = 0; i < L; ++i) {
+    BTR_REQUIRE(head_out[i] && head_out_cl[i] && center[i] && heading_residuals[i] &&
+                    size_residuals[i] && pred_size[i] && query_pos[i] && query_pos_t[i],
+                "gf_stack_forward: outputs of layer %d", i);
+    float *qpos_cl = nullptr, *kpos_cl = nullptr;
+    if (d.has_qpos) {
+      qpos_cl = at_f(saved, p.s_qpos_cl[i]);
+      BTR_TRY(btr_pm_chain_forward(&d.qpos[i], &p.qpos[i], qpos_t, nullptr, bcp_dummy, qpos_cl,
+                                   at_v(saved, p.s_qpos[i]), scratch, stream));
+    }
+    if (d.has_kpos) {
+      kpos_cl = at_f(saved, p.s_kpos_cl[i]);
+      BTR_TRY(btr_pm_chain_forward(&d.kpos[i], &p.kpos[i], key_xyz_t, nullptr, bcp_dummy, kpos_cl,
+                                   at_v(saved, p.s_kpos[i]), scratch, stream));
+    }
+    float *xo = at_f(saved, p.s_x[i]);
+    BTR_TRY(btr_decoder_layer_forward(&d.layer[i], &p.layer[i], x, key_cl, qpos_cl, kpos_cl,
+                                      i == L - 1 ? last_bcp : nullptr, xo,
+                                      at_v(saved, p.s_layer[i]), scratch, stream));
+    BTR_TRY(btr_pm_chain_forward(&d.head[i], &p.head[i], nullptr, xo, head_out[i], head_out_cl[i],
+                                 at_v(saved, p.s_head[i]), scratch, stream));
+    const int cp = p.head[i].np[d.head[i].layers - 1];
+    BTR_TRY(btr_gf_head_decode(d.b, d.pq, d.nh, d.ns, head_out_cl[i], (long long)d.pq * cp, cp, 1,
+                               base_xyz, mean_size, center[i], heading_residuals[i],
+                               size_residuals[i], pred_size[i], query_pos[i], query_pos_t[i],
+                               stream));
+    x = xo;
+    qpos_t = query_pos_t[i];
+  }
+  if (last_cl)
+    (void)hipMemcpyAsync(last_cl, x, (size_t)d.b * d.pq * d.e * sizeof(float),
+                         hipMemcpyDeviceToDevice, hs);
+  return check_launch("gf_stack_forward");
+}
+
+int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *pp,
+                          const float *query_cl, const float *key_cl,
+                          const float *const *dhead, const float *dlast_bcp, void *saved,
+                          float *grads, float *dquery_bcp, float *dkey_bcp, void *scratch,
+                          btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && query_cl && key_cl && dhead && saved && grads && scratch,
+              "gf_stack_backward: null pointer");
+  const btr_gf_stack_t &d = *dp;
+  const btr_gf_stack_plan_t &p = *pp;
+  hipStream_t hs = as_stream(stream);
+  const BwdScratch sc = bwd_scratch(d, p);
+  void *sub = at_v(scratch, sc.sub);
+  const long long q = (long long)d.b * d.pq * d.e, k = (long long)d.b * d.pk * d.e;
+  const int L = d.layers;
+  const float *dnext = dlast_bcp;   // gradient of x[i] from whatever consumes it besides head i
+  int flip = 0;
+  for (int i = L - 1; i >= 0; --i) {
+    const float *dx_in = nullptr;
+    if (dhead[i]) {
+      float *dhx = at_f(scratch, sc.dhx);
+      BTR_TRY(btr_pm_chain_backward(&d.head[i], &p.head[i], at_f(saved, p.s_x[i]), dhead[i],
+                                    at_v(saved, p.s_head[i]), grads + p.g_head[i], dhx, sub,
+                                    stream));
+      if (dnext) {
+        const float *src[2] = {dhx, dnext};
+        BTR_TRY(sum_into(hs, q, src, 2, at_f(scratch, sc.dsum)));
+        dx_in = at_f(scratch, sc.dsum);
+      } else
+        dx_in = dhx;
+    } else {
+      (void)hipMemsetAsync(grads + p.g_head[i], 0, p.head[i].grads_floats * sizeof(float), hs);
+      dx_in = dnext;
+    }
+    const float *x_in = i == 0 ? query_cl : at_f(saved, p.s_x[i - 1]);
+    const float *qpos_cl = d.has_qpos ? at_f(saved, p.s_qpos_cl[i]) : nullptr;
+    const float *kpos_cl = d.has_kpos ? at_f(saved, p.s_kpos_cl[i]) : nullptr;
+    float *dkey_i = at_f(scratch, sc.dkey[i]);
+    if (!dx_in) {   // nothing reaches this layer (and so none below it through x)
+      (void)hipMemsetAsync(grads + p.g_layer[i], 0, p.layer[i].grads_floats * sizeof(float), hs);
+      (void)hipMemsetAsync(dkey_i, 0, (size_t)k * sizeof(float), hs);
+      if (d.has_qpos)
+        (void)hipMemsetAsync(grads + p.g_qpos[i], 0, p.qpos[i].grads_floats * sizeof(float), hs);
+      if (d.has_kpos)
+        (void)hipMemsetAsync(grads + p.g_kpos[i], 0, p.kpos[i].grads_floats * sizeof(float), hs);
+      dnext = nullptr;
+      continue;
+    }
+    float *dx = i == 0 ? dquery_bcp : at_f(scratch, sc.dx[flip]);
+    flip ^= 1;
+    float *dqpos = d.has_qpos ? at_f(scratch, sc.dqpos) : nullptr;
+    BTR_TRY(btr_decoder_layer_backward(&d.layer[i], &p.layer[i], x_in, key_cl, qpos_cl, kpos_cl,
+                                       dx_in, at_v(saved, p.s_layer[i]), grads + p.g_layer[i], dx,
+                                       dkey_i, dqpos, sub, stream));
+    if (d.has_qpos)
+      BTR_TRY(btr_pm_chain_backward(&d.qpos[i], &p.qpos[i], nullptr, dqpos,
+                                    at_v(saved, p.s_qpos[i]), grads + p.g_qpos[i], nullptr, sub,
+                                    stream));
+    if (d.has_kpos)
+      BTR_TRY(btr_pm_chain_backward(&d.kpos[i], &p.kpos[i], nullptr, dkey_i,
+                                    at_v(saved, p.s_kpos[i]), grads + p.g_kpos[i], nullptr, sub,
+                                    stream));
+    dnext = dx;
+  }
+  if (dquery_bcp && !dnext)
+    (void)hipMemsetAsync(dquery_bcp, 0, (size_t)q * sizeof(float), hs);
+  if (dkey_bcp) {
+    const float *src[BTR_GF_MAX_DECODER_LAYERS];
+    for (int i = 0; i < L; ++i) src[i] = at_f(scratch, sc.dkey[L - 1 - i]);
+    BTR_TRY(sum_into(hs, k, src, L, dkey_bcp));
+  }
+  return check_launch("gf_stack_backward");
+}
+
+}  // extern "C"

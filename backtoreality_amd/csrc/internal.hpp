@@ -73,6 +73,7 @@ struct BnFin {
   int nbias;
   double count;
   float eps, momentum;
+  int fence;                   // 1: full device-scope fences around the ticket (BTR_BN_TICKET_FENCE=1)
 };
 constexpr int kBnTickets = 8;  // tickets per statistics GEMM (column blocks of >= 64 channels, n <= 512)
 // sa_mlp.hip: per-point first layer of a set-abstraction MLP (see ppfl_gather_add_kernel)
@@ -85,6 +86,9 @@ int ppfl_assemble(int nl, int c, const float *dwx, const float *dwf, float *dw, 
 void prep_batch_begin();
 void prep_batch_launch(hipStream_t st);
 void prep_batch_end();
+// sa_mlp.hip: the small-M NT GEMM on the bf16 planes of (a sub-block of) a weight matrix
+int pm_gemm_nt_planes(int rows, int n, int k, const float *a, int lda, const void *planes, int kp,
+                      long long ps, float *c, int ldc, const float *bias, hipStream_t s);
 bool bnfin_rows_ok(long long rows);   // would bnfin_arm() accept a GEMM over this many rows?
 bool bnfin_arm(const BnFin &fin, long long rows);
 

@@ -160,6 +160,115 @@ __device__ __forceinline__ float4 rc_y4(const float4 x, const float *__restrict_
   return make_float4(rc_dot4(x, w[0]), rc_dot4(x, w[1]), rc_dot4(x, w[2]), rc_dot4(x, w[3]));
 }
 
+// ---- the BatchNorm ticket (BnFin): which workgroup of a column block finished last
+// __threadfence() is `buffer_wbl2 sc1` + `buffer_inv sc1` on gfx950: EVERY wave of EVERY workgroup
+// walks its XCD's L2 to write the just-stored C tile back before the ticket may be taken, and the
+// statistics GEMMs of the 2 048-row chains ran 22 - 29 us where the same kernel without the ticket
+// takes 8 (r05 timeline).  The only data another workgroup reads are the `part` rows: they are
+// stored write-through (agent-scope stores, `sc1`) and read with agent-scope loads, so the order
+// partial sums -> ticket needs the stores' completion (s_waitcnt vmcnt(0): gfx9 counts stores) and
+// the workgroup barrier, not a cache walk.  C, scale, shift, ... reach their readers through the
+// kernel boundary as always.  fin.fence == 1 keeps the full fences beside it (same results).
+__device__ __forceinline__ void store_agent(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_agent(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// true in every thread of the workgroup that took the last ticket of its column block
+__device__ __forceinline__ bool bn_ticket_last(const BnFin &fin, int *s_last) {
+  if (fin.fence) __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *s_last = __hip_atomic_fetch_add(&fin.ticket[blockIdx.y], 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (fin.fence && *s_last) __threadfence();
+  return *s_last != 0;
+}
+
+// The finalisation itself, by the 256 threads of that workgroup: column block [n_blk, n_blk + BN),
+// `fr` = [2][8][BN] doubles of LDS.  reduce_partials' order: 64 slices of the workgroup axis, 8 groups
+// of 8, the 8 groups; thread (col, q) adds the groups q, q + G, ... on its own, thread (col, 0) the 8
+// groups.  With <= 64 row tiles (every launch the ticket accepts by default) a slice holds one
+// partial: all of a thread's loads are issued before the first add -- one trip to memory, where the
+// loop below makes eight dependent ones per group (~1 us each: they are write-through lines).
+template <int BN>
+__device__ __forceinline__ void bn_ticket_finalize(const BnFin &fin, const float *part, int N,
+                                                   int n_blk, double *fr) {
+  constexpr int G = 256 / BN;   // threads per column
+  const int tid = threadIdx.x;
+  const int col = tid % BN, q = tid / BN, n = n_blk + col;
+  const int nblk = gridDim.x;
+  if (nblk <= 64) {
+    float v1[8 / G][8], v2[8 / G][8];
+#pragma unroll
+    for (int gi = 0; gi < 8 / G; ++gi)
+#pragma unroll
+      for (int y = 0; y < 8; ++y) {
+        const int b = (q + gi * G) * 8 + y;
+        const bool on = n < N && b < nblk;
+        v1[gi][y] = on ? load_agent(&part[((size_t)b * 2 + 0) * N + n]) : 0.f;
+        v2[gi][y] = on ? load_agent(&part[((size_t)b * 2 + 1) * N + n]) : 0.f;
+      }
+#pragma unroll
+    for (int gi = 0; gi < 8 / G; ++gi) {
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int y = 0; y < 8; ++y) {
+        a1 += (double)v1[gi][y];
+        a2 += (double)v2[gi][y];
+      }
+      fr[(0 * 8 + q + gi * G) * BN + col] = a1;
+      fr[(1 * 8 + q + gi * G) * BN + col] = a2;
+    }
+  } else {
+    for (int g = q; g < 8; g += G) {
+      double a1 = 0.0, a2 = 0.0;
+      if (n < N)
+        for (int y = 0; y < 8; ++y) {
+          double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+          for (int b = g * 8 + y; b < nblk; b += 64) {
+            s1 += (double)load_agent(&part[((size_t)b * 2 + 0) * N + n]);
+            s2 += (double)load_agent(&part[((size_t)b * 2 + 1) * N + n]);
+          }
+          a1 += s1;
+          a2 += s2;
+        }
+      fr[(0 * 8 + g) * BN + col] = a1;
+      fr[(1 * 8 + g) * BN + col] = a2;
+    }
+  }
+  __syncthreads();
+  if (q == 0 && n < N) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      s1 += fr[(0 * 8 + g) * BN + col];
+      s2 += fr[(1 * 8 + g) * BN + col];
+    }
+    const double mean = s1 / fin.count;
+    double var = s2 / fin.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+    const float a = fin.gamma[n] * invstd;
+    fin.scale[n] = a;
+    fin.shift[n] = fin.beta[n] - (float)mean * a;
+    fin.mean[n] = (float)mean;
+    fin.invstd[n] = invstd;
+    if (fin.running_mean) {
+      const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+      float rm = (1.f - fin.momentum) * fin.running_mean[n] + fin.momentum * (float)mean;
+      if (fin.rbias && n < fin.nbias) rm += fin.momentum * fin.rbias[n];
+      fin.running_mean[n] = rm;
+      fin.running_var[n] = (1.f - fin.momentum) * fin.running_var[n] +
+                           fin.momentum * (float)unbiased;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------ NT GEMM (MFMA f32)
 // C[r][n] = sum_k f(A[r][k]) * W[n][k],  f(y) = PRO ? max(pa[k]*y + pb[k], 0) : y.
 // Workgroup = 4 waves, tile 128 rows x BN columns, K staged BK=32 at a time.  Lanes 0-31 of
@@ -642,68 +751,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #pragma unroll
       for (int w = 0; w < WM; ++w) s += red[(which * WM + w) * BN + col];
       if (n_blk + col < N)
-        part[((size_t)blockIdx.x * 2 + which) * N + n_blk + col] = (float)s;
+        store_agent(&part[((size_t)blockIdx.x * 2 + which) * N + n_blk + col], (float)s);
     }
     if constexpr (MM != 0) {
       if (fin.ticket) {
         // ---- the last workgroup of this column block finalises the BatchNorm (see BnFin)
         __shared__ int s_last;
-        __threadfence();   // this workgroup's partial sums are visible device-wide ...
-        __syncthreads();
-        if (tid == 0)      // ... before its ticket is
-          s_last = atomicAdd(&fin.ticket[blockIdx.y], 1u) == gridDim.x - 1;
-        __syncthreads();
-        if (!s_last) return;
-        __threadfence();   // (acquire: the other workgroups' partial sums)
-        // reduce_partials' order: 64 slices of the workgroup axis, 8 groups of 8, the 8 groups;
-        // thread (col, q) adds the groups q, q + G, ... on its own, thread (col, 0) the 8 groups
-        constexpr int G = 256 / BN;   // threads per column
+        if (!bn_ticket_last(fin, &s_last)) return;
         double *fr = reinterpret_cast<double *>(Pl);   // [2][8][BN], over the staging planes
         static_assert(3 * (BM + BN) * kLp * 2 >= 2 * 8 * BN * 8, "finalize scratch");
-        const int col = tid % BN, q = tid / BN, n = n_blk + col;
-        const int nblk = gridDim.x;
-        for (int g = q; g < 8; g += G) {
-          double a1 = 0.0, a2 = 0.0;
-          if (n < N)
-            for (int y = 0; y < 8; ++y) {
-              double s1 = 0.0, s2 = 0.0;
-#pragma unroll 4
-              for (int b = g * 8 + y; b < nblk; b += 64) {
-                s1 += (double)__builtin_nontemporal_load(&part[((size_t)b * 2 + 0) * N + n]);
-                s2 += (double)__builtin_nontemporal_load(&part[((size_t)b * 2 + 1) * N + n]);
-              }
-              a1 += s1;
-              a2 += s2;
-            }
-          fr[(0 * 8 + g) * BN + col] = a1;
-          fr[(1 * 8 + g) * BN + col] = a2;
-        }
-        __syncthreads();
-        if (q == 0 && n < N) {
-          double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-          for (int g = 0; g < 8; ++g) {
-            s1 += fr[(0 * 8 + g) * BN + col];
-            s2 += fr[(1 * 8 + g) * BN + col];
-          }
-          const double mean = s1 / fin.count;
-          double var = s2 / fin.count - mean * mean;
-          if (var < 0.0) var = 0.0;
-          const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
-          const float a = fin.gamma[n] * invstd;
-          fin.scale[n] = a;
-          fin.shift[n] = fin.beta[n] - (float)mean * a;
-          fin.mean[n] = (float)mean;
-          fin.invstd[n] = invstd;
-          if (fin.running_mean) {
-            const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
-            float rm = (1.f - fin.momentum) * fin.running_mean[n] + fin.momentum * (float)mean;
-            if (fin.rbias && n < fin.nbias) rm += fin.momentum * fin.rbias[n];
-            fin.running_mean[n] = rm;
-            fin.running_var[n] = (1.f - fin.momentum) * fin.running_var[n] +
-                                 fin.momentum * (float)unbiased;
-          }
-        }
+        bn_ticket_finalize<BN>(fin, part, N, n_blk, fr);
       }
     }
   }
@@ -730,7 +787,8 @@ struct SmArgs {
   const float *A;
   int lda;
   const __bf16 *Wp;    // planes [3][N][kp], kp = ceil16(K); rows n < N, columns k >= K are zero
-  int kp;
+  int kp;              // (a sub-block of a wider matrix: kp = its row pitch, ps = its plane stride)
+  long long ps;        // elements between two planes
   float *C;
   int ldc;
   int R, N, K;
@@ -771,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sm_kernel(SmArgs a, BnFin fin)
         for (int e = 0; e < 8; ++e) bfr[ks][q][e] = (__bf16)0.f;
         if (ncol < N && kk < a.kp && kh * (KC / 2) + ks * 16 < kc)
           bfr[ks][q] = *reinterpret_cast<const bf16x8 *>(
-              a.Wp + ((size_t)q * N + ncol) * a.kp + kk);
+              a.Wp + (size_t)q * a.ps + (size_t)ncol * a.kp + kk);
       }
     }
     // ---- A rows of the chunk: registers -> prologue -> three bf16 planes in LDS
@@ -854,8 +912,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sm_kernel(SmArgs a, BnFin fin)
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (h == 0 && ncol < N) {
-        a.part[((size_t)blockIdx.x * 2 + 0) * N + ncol] = s1;
-        a.part[((size_t)blockIdx.x * 2 + 1) * N + ncol] = s2;
+        store_agent(&a.part[((size_t)blockIdx.x * 2 + 0) * N + ncol], s1);
+        store_agent(&a.part[((size_t)blockIdx.x * 2 + 1) * N + ncol], s2);
       }
     }
     if (a.C != nullptr) {
@@ -881,58 +939,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_sm_kernel(SmArgs a, BnFin fin)
     if (fin.ticket) {
       // ---- the last workgroup of this column block finalises the BatchNorm (see gemm_nt_kernel)
       __shared__ int s_last;
-      __threadfence();
-      __syncthreads();
-      if (tid == 0) s_last = atomicAdd(&fin.ticket[blockIdx.y], 1u) == gridDim.x - 1;
-      __syncthreads();
-      if (!s_last) return;
-      __threadfence();
-      constexpr int BN = 64, G = 256 / BN;
-      double *fr = reinterpret_cast<double *>(Xp);   // [2][8][BN]
-      const int col = tid % BN, q = tid / BN, n = n_blk + col;
-      const int nblk = gridDim.x;
-      for (int g = q; g < 8; g += G) {
-        double a1 = 0.0, a2 = 0.0;
-        if (n < N)
-          for (int y = 0; y < 8; ++y) {
-            double u1 = 0.0, u2 = 0.0;
-#pragma unroll 4
-            for (int b = g * 8 + y; b < nblk; b += 64) {
-              u1 += (double)__builtin_nontemporal_load(&a.part[((size_t)b * 2 + 0) * N + n]);
-              u2 += (double)__builtin_nontemporal_load(&a.part[((size_t)b * 2 + 1) * N + n]);
-            }
-            a1 += u1;
-            a2 += u2;
-          }
-        fr[(0 * 8 + g) * BN + col] = a1;
-        fr[(1 * 8 + g) * BN + col] = a2;
-      }
-      __syncthreads();
-      if (q == 0 && n < N) {
-        double u1 = 0.0, u2 = 0.0;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-          u1 += fr[(0 * 8 + g) * BN + col];
-          u2 += fr[(1 * 8 + g) * BN + col];
-        }
-        const double mean = u1 / fin.count;
-        double var = u2 / fin.count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
-        const float sc = fin.gamma[n] * invstd;
-        fin.scale[n] = sc;
-        fin.shift[n] = fin.beta[n] - (float)mean * sc;
-        fin.mean[n] = (float)mean;
-        fin.invstd[n] = invstd;
-        if (fin.running_mean) {
-          const double unbiased = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
-          float rm = (1.f - fin.momentum) * fin.running_mean[n] + fin.momentum * (float)mean;
-          if (fin.rbias && n < fin.nbias) rm += fin.momentum * fin.rbias[n];
-          fin.running_mean[n] = rm;
-          fin.running_var[n] = (1.f - fin.momentum) * fin.running_var[n] +
-                               fin.momentum * (float)unbiased;
-        }
-      }
+      if (!bn_ticket_last(fin, &s_last)) return;
+      bn_ticket_finalize<64>(fin, a.part, N, n_blk, reinterpret_cast<double *>(Xp));
     }
   }
 }
@@ -5318,8 +5326,10 @@ bool bnfin_rows_ok(long long rows) {
 }
 bool bnfin_arm(const BnFin &fin, long long rows) {
   if (!fin.ticket || !bnfin_rows_ok(rows)) return false;
+  static const int fence = getenv("BTR_BN_TICKET_FENCE") && getenv("BTR_BN_TICKET_FENCE")[0] == '1';
   HostBnFin &h = host_bnfin();
   h.fin = fin;
+  h.fin.fence = fence;
   h.on = true;
   return true;
 }
@@ -6581,6 +6591,7 @@ int btr_pm_gemm_nt_sm(int rows, int n, int k, const float *a, int lda, const voi
   const BnFin fin = take_bnfin();
   SmArgs sa{};
   sa.A = a; sa.lda = lda; sa.Wp = (const __bf16 *)planes; sa.kp = ceil16i(k); sa.C = c; sa.ldc = ldc;
+  sa.ps = (long long)n * sa.kp;
   sa.R = rows; sa.N = n; sa.K = k; sa.pa = pa; sa.pb = pb; sa.part = part; sa.bias = bias;
   // (one 32-row tile per workgroup.  A persistent form -- ~2 workgroups per CU walking several row
   // tiles with the weight fragments kept in registers and the next tile's rows prefetched -- was
@@ -6600,6 +6611,30 @@ int btr_pm_gemm_nt_sm(int rows, int n, int k, const float *a, int lda, const voi
 #undef BTR_SM
   return check_launch("pm_gemm_nt_sm");
 }
+
+}  // extern "C"
+namespace btr {
+// (internal.hpp) C = A . W^T (+ bias) on the small-M kernel with W given as the planes of a
+// sub-block of a wider matrix: row pitch kp, plane stride ps (elements); any k % 4 == 0
+int pm_gemm_nt_planes(int rows, int n, int k, const float *a, int lda, const void *planes, int kp,
+                      long long ps, float *c, int ldc, const float *bias, hipStream_t s) {
+  if (rows <= 0 || n <= 0) return BTR_OK;
+  BTR_REQUIRE(a && planes && c && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
+                  kp % 8 == 0 && ps % 8 == 0,
+              "pm_gemm_nt_planes: bad arguments (%d x %d x %d)", rows, n, k);
+  SmArgs sa{};
+  sa.A = a; sa.lda = lda; sa.Wp = (const __bf16 *)planes; sa.kp = kp; sa.ps = ps; sa.C = c;
+  sa.ldc = ldc; sa.R = rows; sa.N = n; sa.K = k; sa.bias = bias;
+  const dim3 grid(cdiv(rows, 32), cdiv(n, 64));
+  const BnFin fin{};
+  if (bias)
+    hipLaunchKernelGGL((gemm_nt_sm_kernel<0, false, true>), grid, dim3(256), 0, s, sa, fin);
+  else
+    hipLaunchKernelGGL((gemm_nt_sm_kernel<0, false, false>), grid, dim3(256), 0, s, sa, fin);
+  return check_launch("pm_gemm_nt_planes");
+}
+}  // namespace btr
+extern "C" {
 
 // As btr_sa_gemm_nt on 64-row tiles (n > 64) with an optional bias row added to C (layers
 // without BatchNorm); part: [btr_pm_gemm_grid(rows)][2][n].

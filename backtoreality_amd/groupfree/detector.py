@@ -8,6 +8,7 @@ from ..votenet.backbone_module import Pointnet2Backbone
 from ..votenet.votenet_da import grad_reverse
 from .modules import (FPSModule, GeneralSamplingModule, PointsObjClsModule,
                       PositionEmbeddingLearned, PredictHead)
+from . import fused_stack
 from .transformer import TransformerDecoderLayer
 
 
@@ -132,6 +133,9 @@ class GroupFreeDetector(nn.Module):
         query = _project(self.decoder_query_proj, cluster_feature)
         key = _project(self.decoder_key_proj, points_features)
         key_pos = None if self.cross_position_embedding == 'none' else points_xyz
+        # the whole loop as one autograd node (csrc/gf_stack.hip) when it covers the configuration
+        if fused_stack.run(self, query, key, query_pos, key_pos, cluster_xyz, end_points):
+            return self._finish(end_points)
         for i in range(self.num_decoder_layers):
             prefix = 'last_' if i == self.num_decoder_layers - 1 else '%dhead_' % i
             query = self.decoder[i](query, key, query_pos, key_pos)
@@ -158,6 +162,9 @@ class GroupFreeDetector(nn.Module):
         # inputs['sampling']: optional handle of backbone_net.prefetch_sampling (the pyramid of
         # this cloud computed ahead, e.g. under the previous step's backward)
         return self.backbone_net(inputs['point_clouds'], {}, sampling=inputs.get('sampling'))
+
+    # the hooks below only act on the last layer's output (fused_stack.run calls them for it alone)
+    _hook_last_only = True
 
     def _after_decoder_layer(self, prefix, query, end_points):
         """Hook for the domain-adaptation variant."""

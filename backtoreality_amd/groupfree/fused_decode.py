@@ -59,21 +59,28 @@ class HeadDecode(Function):
     @staticmethod
     def backward(ctx, g_center, g_hres, g_sres, g_psize, _gq, _gqt):
         out, mean_size = ctx.saved_tensors
-        B, C, P, nh, ns = ctx.dims
-        o_hres, o_ss, o_sr = 4 + nh, 4 + 2 * nh, 4 + 2 * nh + ns
-        g = torch.zeros((B, P, C), dtype=out.dtype, device=out.device)
-        if g_center is not None:
-            g[..., 1:4] += g_center
-        if g_hres is not None:
-            g[..., o_hres:o_hres + nh] += g_hres * (math.pi / nh)
-        if g_sres is not None:
-            g[..., o_sr:o_sr + 3 * ns] += (g_sres * mean_size).reshape(B, P, 3 * ns)
-        if g_psize is not None:
-            pick = torch.argmax(out[:, o_ss:o_ss + ns, :], 1)                    # (B, P)
-            cols = o_sr + pick.unsqueeze(-1) * 3 + torch.arange(3, device=out.device)   # (B, P, 3)
-            g.scatter_add_(2, cols, g_psize * mean_size[pick])
+        g = fold_grads(out, mean_size, ctx.dims, g_center, g_hres, g_sres, g_psize)
         g_base = g_center if ctx.needs_input_grad[1] else None
-        return g.transpose(1, 2), g_base, None, None, None
+        return g, g_base, None, None, None
+
+
+def fold_grads(out, mean_size, dims, g_center, g_hres, g_sres, g_psize):
+    """Gradient w.r.t. the raw head output (B, C, P) of the gradients of the decoded tensors
+    (each may be None)."""
+    B, C, P, nh, ns = dims
+    o_hres, o_ss, o_sr = 4 + nh, 4 + 2 * nh, 4 + 2 * nh + ns
+    g = torch.zeros((B, P, C), dtype=out.dtype, device=out.device)
+    if g_center is not None:
+        g[..., 1:4] += g_center
+    if g_hres is not None:
+        g[..., o_hres:o_hres + nh] += g_hres * (math.pi / nh)
+    if g_sres is not None:
+        g[..., o_sr:o_sr + 3 * ns] += (g_sres * mean_size).reshape(B, P, 3 * ns)
+    if g_psize is not None:
+        pick = torch.argmax(out[:, o_ss:o_ss + ns, :], 1)                    # (B, P)
+        cols = o_sr + pick.unsqueeze(-1) * 3 + torch.arange(3, device=out.device)   # (B, P, 3)
+        g.scatter_add_(2, cols, g_psize * mean_size[pick])
+    return g.transpose(1, 2)
 
 
 def decode(out, base_xyz, mean_size, nh, ns):

@@ -1,0 +1,372 @@
+"""The decoder loop of GroupFreeDetector.forward as ONE autograd node (csrc/gf_stack.hip).
+
+The reference (detection/GroupFree3D/models/detector.py:161-219) runs, per decoder layer, two
+position embeddings (modules.py:50-65), the layer (transformer.py:36-76), the prediction head
+(modules.py:107-262) and the detached query-position bookkeeping (detector.py:204-230).  Each of
+those is already one library call per direction here (fused_mlp.PointwiseChain,
+fused_decoder.DecoderLayerFn, fused_decode.HeadDecode); the training step was nevertheless paced
+by the host, because every call sits in its own autograd node: ~0.1 ms of interpreter, allocator
+and ctypes work each way around ten launches of 5 - 20 us.  `run(...)` issues the same launches
+from two calls, btr_gf_stack_forward / btr_gf_stack_backward, on buffers cut out of one saved /
+scratch / gradient allocation: 30 nodes become one.  The results are those of the per-module path
+bit for bit (same kernels, same operand order in the gradient sums; tests/test_gf_stack_gpu.py).
+
+Covers what the per-module library paths cover (CUDA f32 tensors, training mode, ReLU layers,
+learned position embeddings or none); `BTR_FUSED_GF_STACK=0` disables it, and a HIP-graph capture
+keeps the per-module path (see fused_mlp._min_rows)."""
+import ctypes
+import os
+import weakref
+
+import torch
+from torch.autograd import Function
+
+from ..pointnet2 import _ext, fused_mlp
+from . import fused_attention, fused_decode, fused_decoder
+
+_call, _lib, _on, _p, _stream = _ext._call, _ext._lib, _ext._on, _ext._p, _ext._stream
+_ENTRIES = weakref.WeakKeyDictionary()   # detector -> {shape key: entry}
+_VP = ctypes.c_void_p
+CALLS = [0]   # forward calls that took this path (bench.py / tests read it)
+REFUSED = {}  # reason -> calls that stayed on the module loop
+
+
+def _no(why):
+    REFUSED[why] = REFUSED.get(why, 0) + 1
+    return False
+
+
+def enabled():
+    return os.environ.get("BTR_FUSED_GF_STACK", "1") != "0"
+
+
+def _f32(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def _u8(nbytes, dev):
+    return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
+
+
+def _transposed(xyz):
+    """(B, d, P) contiguous form of (B, P, d) coordinates (cached on the tensor by the head decode
+    kernel / the position embedding module)."""
+    cached = getattr(xyz, '_btr_t', None)
+    if cached is not None and cached[1] == xyz._version:
+        return cached[0]
+    x = xyz.transpose(1, 2).contiguous()
+    if not xyz.requires_grad:
+        xyz._btr_t = (x, xyz._version)
+    return x
+
+
+def _embed_chain(m):
+    from .modules import PositionEmbeddingLearned
+    if not isinstance(m, PositionEmbeddingLearned):
+        return None
+    head = m.position_embedding_head
+    return [(head[0], head[1], True), (head[3], None, False)]
+
+
+class _Entry(object):
+    """What is fixed for a detector and a set of shapes: the descriptor with its sizes filled in,
+    the plan, the block sizes of the flat gradient buffer."""
+    __slots__ = ("d", "plan", "layer_sizes", "chain_sizes", "ptrs", "metas")
+
+
+def _entry(det, key, B, Pq, Pk, E, qd, kd, p, specs):
+    cache = _ENTRIES.get(det)
+    if cache is None:
+        cache = _ENTRIES[det] = {}
+    ent = cache.get(key)
+    if ent is not None:
+        return ent
+    L = det.num_decoder_layers
+    d = _ext.GfStack()
+    head0 = det.prediction_heads[0]
+    d.layers, d.b, d.pq, d.pk, d.e = L, B, Pq, Pk, E
+    d.nh, d.ns = head0.num_heading_bin, head0.num_size_cluster
+    d.has_qpos, d.has_kpos = int(qd > 0), int(kd > 0)
+    for i in range(L):
+        layer = det.decoder[i]
+        ld = d.layer[i]
+        ld.b, ld.pq, ld.pk, ld.e = B, Pq, Pk, E
+        ld.heads, ld.ff, ld.dropout = layer.self_attn.num_heads, layer.linear1.out_features, p
+        for j, ln in enumerate((layer.norm1, layer.norm2, layer.norm3)):
+            ld.ln_eps[j] = float(ln.eps)
+        (qm, qp), (km, kp), (hm, hp) = specs[i]
+        if qm is not None:
+            fused_mlp.chain_static(d.qpos[i], B, qd, Pq, qm, qp, False)
+        if km is not None:
+            fused_mlp.chain_static(d.kpos[i], B, kd, Pk, km, kp, False)
+        fused_mlp.chain_static(d.head[i], B, E, Pq, hm, hp, True)
+    d.head_c = d.head[0].width[d.head[0].layers - 1]
+    plan = _ext.GfStackPlan()
+    assert _lib.btr_gf_stack_sizeof(0) == ctypes.sizeof(d) and \
+        _lib.btr_gf_stack_sizeof(1) == ctypes.sizeof(plan), "btr_gf_stack_t mirror out of date"
+    _call(_lib.btr_gf_stack_plan, ctypes.addressof(d), ctypes.addressof(plan))
+    ent = _Entry()
+    ent.d, ent.plan, ent.ptrs = d, plan, None
+    F = d.layer[0].ff
+    ent.layer_sizes = [3 * E * E, 3 * E, E * E, E, 3 * E * E, 3 * E, E * E, E, F * E, F, E * F, E,
+                       E, E, E, E, E, E]
+    assert sum(ent.layer_sizes) == plan.layer[0].grads_floats
+    ent.chain_sizes = []
+    for i in range(L):
+        (qm, _), (km, _), (hm, _) = specs[i]
+        ent.chain_sizes.append((
+            fused_mlp.chain_sizes(plan.qpos[i], len(qm)) if qm is not None else None,
+            fused_mlp.chain_sizes(plan.kpos[i], len(km)) if km is not None else None,
+            fused_mlp.chain_sizes(plan.head[i], len(hm))))
+    cache[key] = ent
+    return ent
+
+
+def _specs(det, E, qd, kd):
+    """Per layer ((metas, params) of the query / key position embedding and the head), or None
+    when a chain is not covered."""
+    specs = []
+    for i in range(det.num_decoder_layers):
+        layer = det.decoder[i]
+        row = []
+        for m, K in ((layer.self_posembed, qd), (layer.cross_posembed, kd)):
+            if K == 0:
+                if m is not None:
+                    return None
+                row.append((None, []))
+                continue
+            chain = _embed_chain(m)
+            spec = fused_mlp.chain_spec(K, chain) if chain is not None else None
+            if spec is None or chain[-1][0].out_channels != E:
+                return None
+            row.append(spec)
+        spec = fused_mlp.chain_spec(E, det.prediction_heads[i].chain())
+        if spec is None:
+            return None
+        row.append(spec)
+        specs.append(row)
+    return specs
+
+
+def _flat_params(det, specs):
+    """(parameters in descriptor order, positions of the heads' concatenated output layers)."""
+    params, cat_at = [], []
+    for i in range(det.num_decoder_layers):
+        params += list(fused_decoder._params(det.decoder[i]))
+        for _m, ps in specs[i]:
+            params += ps
+        cat_at.append(len(params) - 4)   # (W, bias, None, None) of the head's last layer
+    return params, cat_at
+
+
+def _set_pointers(ent, det, specs, params, cat_at):
+    """Parameter pointers into the cached descriptor -- only when one of them moved (they are the
+    optimizer's own tensors: fixed unless the model is reloaded or moved).  The heads' last layers
+    are concatenations made for this call: always set."""
+    ptrs = [0 if t is None else t.data_ptr() for t in params]
+    for i, at in enumerate(cat_at):
+        hd = ent.d.head[i]
+        hd.w[hd.layers - 1], hd.bias[hd.layers - 1] = ptrs[at], ptrs[at + 1]
+        ptrs[at] = ptrs[at + 1] = 0
+    for i in range(det.num_decoder_layers):   # BatchNorm buffers / momentum
+        for m, _ps in specs[i]:
+            if m is not None:
+                for spec in m:
+                    bn = spec["bn"]
+                    if bn is not None:
+                        ptrs += [bn.running_mean.data_ptr() if bn.running_mean is not None else 0,
+                                 bn.momentum]
+    if ptrs == ent.ptrs:
+        return
+    d = ent.d
+    at = 0
+    for i in range(det.num_decoder_layers):
+        ld = d.layer[i]
+        lp = params[at:at + 18]
+        at += 18
+        for name, t in zip(fused_decoder._FIELDS, lp[:12]):
+            assert t.is_contiguous()
+            setattr(ld, name, t.data_ptr())
+        for j in range(3):
+            ld.ln_w[j], ld.ln_b[j] = lp[12 + 2 * j].data_ptr(), lp[13 + 2 * j].data_ptr()
+        for (m, ps), cd in zip(specs[i], (d.qpos[i], d.kpos[i], d.head[i])):
+            if m is not None:
+                fused_mlp.chain_pointers(cd, m, params[at:at + len(ps)])
+            at += len(ps)
+    ent.ptrs = ptrs
+
+
+def _ptr_array(tensors):
+    return (_VP * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class DecoderStackFn(Function):
+    """(query (B,E,Pq), key (B,E,Pk), qpos0_t (B,d,Pq) | None, key_xyz_t (B,3,Pk) | None,
+    base_xyz (B,Pq,3), mean_size, meta, *parameters) -> per layer (head output (B,C,Pq), center,
+    heading_residuals, size_residuals, pred_size, query_pos, query_pos_t) [+ the last layer's
+    output (B,E,Pq) when meta["want_last"]]."""
+
+    @staticmethod
+    def forward(ctx, query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta, *params):
+        ent, p, want_last = meta["entry"], meta["p"], meta["want_last"]
+        plan = ent.plan
+        d = _ext.GfStack.from_buffer_copy(ent.d)   # this call's own copy (dropout seeds)
+        L, B, Pq, E = d.layers, d.b, d.pq, d.e
+        dev = query.device
+        step = None
+        if p > 0:
+            step = fused_attention.step_counter(dev)
+            for i in range(L):
+                d.layer[i].seed = fused_attention._next_seed()
+                d.layer[i].step = step.data_ptr()
+        C, nh, ns = d.head_c, d.nh, d.ns
+        Cp = plan.head[0].np[d.head[0].layers - 1]
+        outs, cls = [], _f32((L, B * Pq, Cp), dev)
+        qpos, qpos_t = _f32((L, B, Pq, 6), dev), _f32((L, B, 6, Pq), dev)
+        for i in range(L):
+            outs.append((_f32((B, C, Pq), dev), _f32((B, Pq, 3), dev), _f32((B, Pq, nh), dev),
+                         _f32((B, Pq, ns, 3), dev), _f32((B, Pq, 3), dev), qpos[i], qpos_t[i]))
+        last = _f32((B, E, Pq), dev) if want_last else None
+        last_cl = _f32((B * Pq, E), dev) if want_last else None
+        saved = _u8(plan.saved_bytes, dev)
+        scratch = _u8(plan.fwd_scratch_bytes, dev)
+        base = base_xyz.contiguous()
+        with _on(query) as dv:
+            st = _stream(dv)
+            x_cl, key_cl = fused_decoder._rows(query, st), fused_decoder._rows(key, st)
+            arrays = [_ptr_array([o[j] for o in outs]) for j in range(7)]
+            arrays.insert(1, _ptr_array([cls[i] for i in range(L)]))
+            _call(_lib.btr_gf_stack_forward, ctypes.addressof(d), ctypes.addressof(plan),
+                  _p(x_cl), _p(key_cl), _p(qpos0_t), _p(key_xyz_t), _p(base), _p(mean_size),
+                  *arrays, _p(last), _p(last_cl), _p(saved), _p(scratch), st)
+        for i in range(L):
+            _ext.attach_twin(outs[i][0], cls[i])
+        if want_last:
+            _ext.attach_twin(last, last_cl)
+        ctx.ent = (d, ent, step)
+        ctx.want_last = want_last
+        ctx.pshapes = [None if t is None else t.shape for t in params]
+        ctx.specs = meta["specs"]
+        ctx.save_for_backward(saved, x_cl, key_cl, mean_size, *[o[0] for o in outs])
+        flat = [t for o in outs for t in o]
+        ctx.mark_non_differentiable(*[t for o in outs for t in o[5:]])
+        ctx.set_materialize_grads(False)
+        return tuple(flat) + ((last,) if want_last else ())
+
+    @staticmethod
+    def backward(ctx, *g):
+        d, ent, _step = ctx.ent
+        plan = ent.plan
+        L, B, Pq, Pk, E = d.layers, d.b, d.pq, d.pk, d.e
+        saved, x_cl, key_cl, mean_size = ctx.saved_tensors[:4]
+        head_outs = ctx.saved_tensors[4:]
+        dev = saved.device
+        dims = (B, d.head_c, Pq, d.nh, d.ns)
+        dheads, g_base = [], None
+        for i in range(L):
+            gh, gc, ghr, gsr, gps = g[7 * i:7 * i + 5]
+            if gc is not None or ghr is not None or gsr is not None or gps is not None:
+                fold = fused_decode.fold_grads(head_outs[i], mean_size, dims, gc, ghr, gsr, gps)
+                gh = fold if gh is None else gh + fold
+                if gc is not None and ctx.needs_input_grad[4]:
+                    g_base = gc if g_base is None else g_base + gc
+            dheads.append(None if gh is None else gh.contiguous())
+        dlast = g[7 * L] if ctx.want_last else None
+        dlast = None if dlast is None else dlast.contiguous()
+        grads = _f32((plan.grads_floats,), dev)
+        scratch = _u8(plan.bwd_scratch_bytes, dev)
+        dquery = _f32((B, E, Pq), dev) if ctx.needs_input_grad[0] else None
+        dkey = _f32((B, E, Pk), dev) if ctx.needs_input_grad[1] else None
+        with _on(saved) as dv:
+            _call(_lib.btr_gf_stack_backward, ctypes.addressof(d), ctypes.addressof(plan),
+                  _p(x_cl), _p(key_cl), _ptr_array(dheads), _p(dlast), _p(saved), _p(grads),
+                  _p(dquery), _p(dkey), _p(scratch), _stream(dv))
+        res, at = [], 0
+        for i in range(L):
+            lg = grads.narrow(0, plan.g_layer[i], plan.layer[i].grads_floats)
+            res += [t.view(s) for t, s in zip(lg.split(ent.layer_sizes), ctx.pshapes[at:at + 18])]
+            at += 18
+            for (m, ps), cd, cp, off, sizes in zip(
+                    ctx.specs[i], (d.qpos[i], d.kpos[i], d.head[i]),
+                    (plan.qpos[i], plan.kpos[i], plan.head[i]),
+                    (plan.g_qpos[i], plan.g_kpos[i], plan.g_head[i]), ent.chain_sizes[i]):
+                if m is not None:
+                    cg = grads.narrow(0, off, cp.grads_floats)
+                    res += fused_mlp.chain_grad_views(cd, cp, sizes, ctx.pshapes[at:at + len(ps)],
+                                                      cg)
+                at += len(ps)
+        return (dquery, dkey, None, None, g_base, None, None) + tuple(res)
+
+
+def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
+    """The decoder loop of `det` on query (B,E,Pq) / key (B,E,Pk) features, the first query
+    position (B,Pq,3|6) | None and the key position (B,Pk,3) | None.  Fills end_points like the
+    module loop does and returns True, or returns False when this path does not cover the call."""
+    L = det.num_decoder_layers
+    if not (enabled() and fused_mlp.enabled() and fused_mlp.native_enabled() and
+            fused_decoder.enabled() and fused_decode.enabled() and
+            0 < L <= _ext.GF_MAX_DECODER_LAYERS and getattr(det, "_hook_last_only", False) and
+            query.is_cuda and query.dtype == torch.float32 and key.dtype == torch.float32 and
+            query.dim() == 3 and key.dim() == 3 and base_xyz.dtype == torch.float32):
+        return _no("disabled, not CUDA f32, or an override of the layer hook")
+    if fused_mlp._CAPTURE_PATH[0] or torch.cuda.is_current_stream_capturing() or \
+            os.environ.get("BTR_CHAIN_MIN_ROWS") is not None:
+        return _no("HIP-graph capture path or BTR_CHAIN_MIN_ROWS")
+    B, E, Pq = query.shape
+    Pk = key.shape[2]
+    if tuple(base_xyz.shape) != (B, Pq, 3):
+        return _no("base_xyz shape")
+    qd = 0 if query_pos is None else int(query_pos.shape[-1])
+    kd = 0 if key_pos is None else int(key_pos.shape[-1])
+    if qd not in (0, 6) or kd not in (0, 3):   # the head decode kernel writes (center, size)
+        return _no("query position must be (center, size) or none")
+    for pos, P in ((query_pos, Pq), (key_pos, Pk)):
+        if pos is not None and not (pos.dtype == torch.float32 and pos.dim() == 3 and
+                                    pos.shape[0] == B and pos.shape[1] == P and
+                                    not pos.requires_grad):
+            return _no("position tensors")
+    ps = set()
+    for i in range(L):
+        layer = det.decoder[i]
+        if not fused_decoder.covered(layer, query, key, None, None):
+            return _no("a decoder layer is not covered")
+        ps.add(float(layer.dropout.p) if layer.training else 0.0)
+    if len(ps) != 1:
+        return _no("dropout rates differ")
+    p = ps.pop()
+    head0 = det.prediction_heads[0]
+    for i in range(L):
+        h = det.prediction_heads[i]
+        if (h.num_heading_bin, h.num_size_cluster, h.num_class) != \
+                (head0.num_heading_bin, head0.num_size_cluster, head0.num_class) or \
+                h.mean_size_arr is not head0.mean_size_arr and \
+                not (h.mean_size_arr == head0.mean_size_arr).all():
+            return _no("prediction heads differ")
+    specs = _specs(det, E, qd, kd)
+    if specs is None:
+        return _no("a chain is not covered")
+    want_last = type(det)._after_decoder_layer is not _base_hook(det)
+    key_ = (B, Pq, Pk, E, qd, kd, p, tuple(tuple(len(m) if m is not None else 0 for m, _ in row)
+                                           for row in specs))
+    ent = _entry(det, key_, B, Pq, Pk, E, qd, kd, p, specs)
+    params, cat_at = _flat_params(det, specs)
+    _set_pointers(ent, det, specs, params, cat_at)
+    qpos0_t = _transposed(query_pos) if query_pos is not None else None
+    key_xyz_t = _transposed(key_pos) if key_pos is not None else None
+    mean_size = head0._mean_size_on(query.device)
+    meta = {"entry": ent, "p": p, "want_last": want_last, "specs": specs}
+    outs = DecoderStackFn.apply(query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta, *params)
+    CALLS[0] += 1
+    for i in range(L):
+        prefix = 'last_' if i == L - 1 else '%dhead_' % i
+        out, center, hres, sres, psize, qpos, qpos_t = outs[7 * i:7 * i + 7]
+        if i == L - 1 and want_last:
+            det._after_decoder_layer(prefix, outs[7 * L], end_points)
+        det.prediction_heads[i].publish(out, (center, hres, sres, psize, qpos, qpos_t), base_xyz,
+                                        end_points, prefix)
+    return True
+
+
+def _base_hook(det):
+    from .detector import GroupFreeDetector
+    return GroupFreeDetector._after_decoder_layer

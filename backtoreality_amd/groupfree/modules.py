@@ -132,30 +132,43 @@ class PredictHead(nn.Module):
                 np.ascontiguousarray(self.mean_size_arr, np.float32)).to(device)
         return self._mean_size
 
+    def _heads(self):
+        return (self.objectness_scores_head, self.center_residual_head, self.heading_class_head,
+                self.heading_residual_head, self.size_class_head, self.size_residual_head,
+                self.sem_cls_scores_head)
+
+    def chain(self):
+        """The head as one conv/BN/ReLU chain for fused_mlp.run_chain (and the decoder stack).
+        The seven output layers are 1x1 convolutions of the same `net`: one convolution with the
+        concatenated weights (116 output channels at ScanNet sizes) instead of seven of 1..66
+        channels; the parameters stay separate (state-dict keys of the reference)."""
+        return [(self.conv1, self.bn1, True), (self.conv2, self.bn2, True),
+                (_CatConv(self._heads()), None, False)]
+
     def forward(self, features, base_xyz, end_points, prefix=''):
-        B, P = features.shape[0], features.shape[-1]
-        # the seven output layers are 1x1 convolutions of the same `net`: one convolution with
-        # the concatenated weights (116 output channels at ScanNet sizes) instead of seven of
-        # 1..66 channels; the parameters stay separate (state-dict keys of the reference)
-        heads = (self.objectness_scores_head, self.center_residual_head, self.heading_class_head,
-                 self.heading_residual_head, self.size_class_head, self.size_residual_head,
-                 self.sem_cls_scores_head)
-        last = _CatConv(heads)
-        out = fused_mlp.run_chain(features, [(self.conv1, self.bn1, True),
-                                             (self.conv2, self.bn2, True), (last, None, False)])
+        chain = self.chain()
+        out = fused_mlp.run_chain(features, chain)
         if out is None:   # stock ops (CPU, eval mode, BTR_FUSED_MLP=0)
             net = F.relu(self.bn1(self.conv1(features)))
             net = F.relu(self.bn2(self.conv2(net)))
-            out = F.conv1d(net, last.weight, last.bias)
-        end_points[prefix + '_head_output'] = out   # (B, sum, P): what groupfree/fused_loss.py reads
-        out = out.transpose(2, 1)   # (B, P, sum)
+            out = F.conv1d(net, chain[-1][0].weight, chain[-1][0].bias)
+        dec = fused_decode.decode(out, base_xyz, self._mean_size_on(features.device),
+                                  self.num_heading_bin, self.num_size_cluster)
+        return self.publish(out, dec, base_xyz, end_points, prefix)
+
+    def publish(self, out_raw, dec, base_xyz, end_points, prefix):
+        """Fills end_points['<prefix>...'] from the raw head output (B, sum, P) and, when given,
+        the decoded tensors (center, heading_residuals, size_residuals, pred_size, query_pos,
+        query_pos_t) of fused_decode.decode; returns (center, pred_size)."""
+        B, P = out_raw.shape[0], out_raw.shape[-1]
+        heads = self._heads()
+        end_points[prefix + '_head_output'] = out_raw   # what groupfree/fused_loss.py reads
+        out = out_raw.transpose(2, 1)   # (B, P, sum)
         (objectness_scores, center_residual, heading_scores, heading_residuals_normalized,
          size_scores, size_residuals_flat, sem_cls_scores) = torch.split(
             out, [h.out_channels for h in heads], dim=2)
-        mean_size_2d = self._mean_size_on(features.device)
+        mean_size_2d = self._mean_size_on(out_raw.device)
         size_residuals_normalized = size_residuals_flat.reshape(B, P, self.num_size_cluster, 3)
-        dec = fused_decode.decode(end_points[prefix + '_head_output'], base_xyz, mean_size_2d,
-                                  self.num_heading_bin, self.num_size_cluster)
         if dec is not None:   # one launch (csrc/gf_loss.hip); also the next layer's query position
             center, heading_residuals, size_residuals, pred_size, qpos, qpos_t = dec
             qpos._btr_t = (qpos_t, qpos._version)
@@ -181,7 +194,6 @@ class PredictHead(nn.Module):
         # the fused per-head loss reads `_head_output`, not the entries above: it may only do so
         # while they still ARE this output's views and nothing was written to them in place
         # (views share the version counter of their base)
-        out_raw = end_points[prefix + '_head_output']
         out_raw._btr_head_views = (out_raw._version, base_xyz, {
             'objectness_scores': objectness_scores, 'heading_scores': heading_scores,
             'heading_residuals_normalized': heading_residuals_normalized,

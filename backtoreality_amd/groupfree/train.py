@@ -22,8 +22,10 @@ def build_model(cfg, device, input_feature_dim=0, num_proposal=256, seed=0,
                 domain_adaptation=False, center_refine=False, **kw):
     """Random-init GroupFreeDetector with the script defaults (train_GF_FSB.py:26-34,196-217:
     no height channel unless --use_height, 256 query points, KPS sampling, six decoder layers,
-    dropout 0.1)."""
+    dropout 0.1, 'loc_learned' / 'xyz_learned' position embeddings)."""
     torch.manual_seed(seed)
+    # (the scripts' default, train_GF_FSB.py:36; the class's own default is 'xyz_learned')
+    kw.setdefault('self_position_embedding', 'loc_learned')
     cls = GroupFreeDetector_DA_jitter if center_refine else (
         GroupFreeDetector_DA if domain_adaptation else GroupFreeDetector)
     net = cls(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
@@ -222,16 +224,31 @@ class GraphedPipelinedStep(object):
         return self.loss, self.end_points
 
 
-def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_norm=0.1):
+def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_norm=0.1,
+                  sampling_S=None, next_batch_S=None, sampling_T=None, next_batch_T=None):
     """One Back-to-Reality step of GroupFree3D (train_GF_BR.py:322-365): the SAME
     GroupFreeDetector_DA runs a source (virtual, fully labelled) and a target (real, centre
-    labels only) forward, then one `get_loss_DA`, one backward, clipping, one AdamW step."""
+    labels only) forward, then one `get_loss_DA`, one backward, clipping, one AdamW step.
+    `sampling_S/_T`, `next_batch_S/_T`: software pipelining as in votenet.train.train_step_br --
+    the target pyramid of this step runs on the side stream under the source forward, the NEXT
+    step's two pyramids under this step's forwards / backward; they come back as
+    end_points_S/_T['next_sampling']."""
+    from ..votenet.train import _prefetch_next, _source_inputs
     from .loss_helper import get_loss_DA
     loss_args = dict(LOSS_ARGS, **(loss_args or {}))
-    if batch_S['point_clouds'].is_cuda:
+    cuda = batch_S['point_clouds'].is_cuda
+    if cuda:
         fused_attention.bump_step(batch_S['point_clouds'].device)
-    end_points_S = net({'point_clouds': batch_S['point_clouds']})
-    end_points_T = net({'point_clouds': batch_T['point_clouds']})
+    core = net.module if hasattr(net, "module") else net
+    nxt = ({}, {})
+    inputs_T = {'point_clouds': batch_T['point_clouds']}
+    if cuda:
+        if sampling_T is None:
+            sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
+        inputs_T['sampling'] = sampling_T
+        _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
+    end_points_S = net(_source_inputs(batch_S, sampling_S))
+    end_points_T = net(inputs_T)
     for key in batch_S:
         assert key not in end_points_S
         end_points_S[key] = batch_S[key]
@@ -239,6 +256,8 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_no
         assert key not in end_points_T
         end_points_T[key] = batch_T[key]
     loss, end_points_S, end_points_T = get_loss_DA(end_points_S, end_points_T, cfg, **loss_args)
+    end_points_S.update(nxt[0])
+    end_points_T.update(nxt[1])
     _zero_grad(net, optimizer)
     backward(loss)
     _sync_grads(net)

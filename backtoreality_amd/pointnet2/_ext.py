@@ -151,6 +151,10 @@ _SIGNATURES = {
     "btr_gf_loss_part_floats": (_ci, [_ci, _ci, _ci]),
     "btr_gf_loss_fwd": (_ci, [_vp] * 21),
     "btr_gf_head_decode": (_ci, [_ci] * 4 + [_vp] + [ctypes.c_longlong] * 3 + [_vp] * 9),
+    "btr_gf_stack_sizeof": (ctypes.c_longlong, [_ci]),
+    "btr_gf_stack_plan": (_ci, [_vp, _vp]),
+    "btr_gf_stack_forward": (_ci, [_vp] * 21),
+    "btr_gf_stack_backward": (_ci, [_vp] * 12),
     # multi-tensor Adam / AdamW (csrc/optimizer.hip, used by votenet/train.py)
     "btr_adam_chunk": (_ci, []),
     "btr_adam_multi": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double,
@@ -309,6 +313,32 @@ class DecoderPlan(ctypes.Structure):
         "bwd_scratch_bytes", "g_sa_in_w", "g_sa_in_b", "g_sa_out_w", "g_sa_out_b", "g_ca_in_w",
         "g_ca_in_b", "g_ca_out_w", "g_ca_out_b", "g_lin1_w", "g_lin1_b", "g_lin2_w",
         "g_lin2_b")] + [("g_ln", _sz3), ("grads_floats", _sz)]
+
+
+GF_MAX_DECODER_LAYERS = 12   # BTR_GF_MAX_DECODER_LAYERS
+_szd = _sz * GF_MAX_DECODER_LAYERS
+
+
+class GfStack(ctypes.Structure):
+    """btr_gf_stack_t: the decoder layers with their position embeddings and prediction heads."""
+    _fields_ = [("layers", _ci), ("b", _ci), ("pq", _ci), ("pk", _ci), ("e", _ci), ("nh", _ci),
+                ("ns", _ci), ("head_c", _ci), ("has_qpos", _ci), ("has_kpos", _ci),
+                ("layer", DecoderLayer * GF_MAX_DECODER_LAYERS),
+                ("qpos", PmChain * GF_MAX_DECODER_LAYERS),
+                ("kpos", PmChain * GF_MAX_DECODER_LAYERS),
+                ("head", PmChain * GF_MAX_DECODER_LAYERS)]
+
+
+class GfStackPlan(ctypes.Structure):
+    _fields_ = [("layer", DecoderPlan * GF_MAX_DECODER_LAYERS),
+                ("qpos", PmPlan * GF_MAX_DECODER_LAYERS),
+                ("kpos", PmPlan * GF_MAX_DECODER_LAYERS),
+                ("head", PmPlan * GF_MAX_DECODER_LAYERS),
+                ("s_layer", _szd), ("s_qpos", _szd), ("s_kpos", _szd), ("s_head", _szd),
+                ("s_x", _szd), ("s_qpos_cl", _szd), ("s_kpos_cl", _szd),
+                ("saved_bytes", _sz), ("fwd_scratch_bytes", _sz), ("bwd_scratch_bytes", _sz),
+                ("g_layer", _szd), ("g_qpos", _szd), ("g_kpos", _szd), ("g_head", _szd),
+                ("grads_floats", _sz)]
 
 
 class AdamItem(ctypes.Structure):

@@ -276,6 +276,62 @@ def _u8(nbytes, dev):
     return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
 
 
+def chain_static(d, B, K0, N, layers, params, need_dx):
+    """The shape part of a btr_pm_chain_t: layers = [{"bn": BatchNorm | None, ...}], params =
+    (W, bias, gamma, beta) per layer."""
+    d.b, d.n, d.c, d.layers, d.need_dx = B, N, K0, len(layers), int(need_dx)
+    for l, spec in enumerate(layers):
+        d.width[l] = params[4 * l].shape[0]
+        d.has_bn[l] = 1 if spec["bn"] is not None else 0
+        d.eps[l] = float(spec["bn"].eps) if spec["bn"] is not None else 0.0
+
+
+def chain_pointers(d, layers, params):
+    """The per-call part: parameter / running-statistics pointers and the BatchNorm momentum."""
+    for l, spec in enumerate(layers):
+        W, bias, gamma, beta = params[4 * l:4 * l + 4]
+        bn = spec["bn"]
+        assert W.is_contiguous()
+        d.w[l] = W.data_ptr()
+        d.bias[l] = _p(bias)
+        d.gamma[l], d.beta[l] = _p(gamma), _p(beta)
+        track = bn is not None and bn.track_running_stats and bn.running_mean is not None
+        d.running_mean[l] = bn.running_mean.data_ptr() if track else None
+        d.running_var[l] = bn.running_var.data_ptr() if track else None
+        d.num_batches_tracked[l] = bn.num_batches_tracked.data_ptr() if track else None
+        if bn is not None:
+            d.momentum[l] = float(bn.momentum) if bn.momentum is not None else \
+                1.0 / float(bn.num_batches_tracked.item() + 1)
+
+
+def chain_sizes(plan, L):
+    """Block sizes of a chain's flat gradient buffer (btr_pm_plan_t dw / dgamma / dbeta, dbias)."""
+    sizes = []
+    for l in range(L):
+        sizes += [plan.np[l] * plan.kin[l], plan.np[l], plan.np[l]]
+    return sizes + [plan.np[l] for l in range(L)]
+
+
+def chain_grad_views(d, plan, sizes, pshapes, grads):
+    """[dW, dbias, dgamma, dbeta] per layer as views of the chain's flat gradient buffer."""
+    L = d.layers
+    parts = grads.split(sizes)
+    res = []
+    for l in range(L):
+        Nl = d.width[l]
+        wshape, bshape = pshapes[4 * l], pshapes[4 * l + 1]
+        dW = parts[3 * l].view(plan.np[l], plan.kin[l])[:Nl]
+        if plan.kin[l] != wshape[1]:    # first layer of an input padded to 4 columns
+            dW = dW[:, :wshape[1]]
+        dW = dW.reshape(wshape)
+        dbias = parts[3 * L + l][:Nl] if bshape is not None else None
+        if d.has_bn[l]:
+            res += [dW, dbias, parts[3 * l + 1][:Nl], parts[3 * l + 2][:Nl]]
+        else:
+            res += [dW, dbias, None, None]
+    return res
+
+
 class PointwiseChain(Function):
     """PointwiseMLP with the launch sequence in C++ (btr_pm_chain_forward / _backward,
     csrc/sa_layer.hip).  Same kernels; the bias gradient of a bare last layer is summed by
@@ -294,33 +350,12 @@ class PointwiseChain(Function):
         ent = cache.get(key)
         if ent is None:
             d = _ext.PmChain()
-            d.b, d.n, d.c, d.layers, d.need_dx = B, N, K0, L, int(need_dx)
-            for l, spec in enumerate(layers):
-                d.width[l] = params[4 * l].shape[0]
-                d.has_bn[l] = 1 if spec["bn"] is not None else 0
-                d.eps[l] = float(spec["bn"].eps) if spec["bn"] is not None else 0.0
+            chain_static(d, B, K0, N, layers, params, need_dx)
             plan = _ext.PmPlan()
             _call(_lib.btr_pm_chain_plan, ctypes.addressof(d), ctypes.addressof(plan))
-            sizes = []
-            for l in range(L):
-                sizes += [plan.np[l] * plan.kin[l], plan.np[l], plan.np[l]]
-            sizes += [plan.np[l] for l in range(L)]
-            ent = cache[key] = (d, plan, sizes)
+            ent = cache[key] = (d, plan, chain_sizes(plan, L))
         d, plan, sizes = ent
-        for l, spec in enumerate(layers):
-            W, bias, gamma, beta = params[4 * l:4 * l + 4]
-            bn = spec["bn"]
-            assert W.is_contiguous()
-            d.w[l] = W.data_ptr()
-            d.bias[l] = _p(bias)
-            d.gamma[l], d.beta[l] = _p(gamma), _p(beta)
-            track = bn is not None and bn.track_running_stats and bn.running_mean is not None
-            d.running_mean[l] = bn.running_mean.data_ptr() if track else None
-            d.running_var[l] = bn.running_var.data_ptr() if track else None
-            d.num_batches_tracked[l] = bn.num_batches_tracked.data_ptr() if track else None
-            if bn is not None:
-                d.momentum[l] = float(bn.momentum) if bn.momentum is not None else \
-                    1.0 / float(bn.num_batches_tracked.item() + 1)
+        chain_pointers(d, layers, params)
         x_cl = _ext.twin_of(x)
         if x_cl is not None and (x_cl.shape != (rows, K0) or not x_cl.is_contiguous() or K0 % 4):
             x_cl = None
@@ -357,21 +392,7 @@ class PointwiseChain(Function):
         with _on(dout) as dv:
             _call(_lib.btr_pm_chain_backward, ctypes.addressof(d), ctypes.addressof(plan),
                   _p(x_cl), _p(dout), _p(saved), _p(grads), _p(dx), _p(scratch), _stream(dv))
-        parts = grads.split(sizes)
-        res = []
-        for l in range(L):
-            Nl = d.width[l]
-            wshape, bshape = ctx.pshapes[4 * l], ctx.pshapes[4 * l + 1]
-            dW = parts[3 * l].view(plan.np[l], plan.kin[l])[:Nl]
-            if plan.kin[l] != wshape[1]:    # first layer of an input padded to 4 columns
-                dW = dW[:, :wshape[1]]
-            dW = dW.reshape(wshape)
-            dbias = parts[3 * L + l][:Nl] if bshape is not None else None
-            if d.has_bn[l]:
-                res += [dW, dbias, parts[3 * l + 1][:Nl], parts[3 * l + 2][:Nl]]
-            else:
-                res += [dW, dbias, None, None]
-        return (dx, None) + tuple(res)
+        return (dx, None) + tuple(chain_grad_views(d, plan, sizes, ctx.pshapes, grads))
 
 
 def _layer_ok(conv, bn, K, first):
@@ -432,13 +453,9 @@ def run_chain(x, chain):
     return out
 
 
-def _run_chain(x, chain):
-    if not (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
-        return None
-    if x.shape[0] * x.shape[2] < _min_rows():
-        PATHS["stock_small"] += 1
-        return None
-    K = x.shape[1]
+def chain_spec(K, chain):
+    """([{"bn", "relu"}], [W, bias, gamma, beta per layer]) of a chain on K input channels that
+    the library's chain entry points cover, else None."""
     metas, params = [], []
     for i, (conv, bn, relu) in enumerate(chain):
         if not _layer_ok(conv, bn, K, i == 0):
@@ -453,6 +470,19 @@ def _run_chain(x, chain):
         K = conv.out_channels
     if K > 512 and chain[-1][1] is not None:
         return None
+    return metas, params
+
+
+def _run_chain(x, chain):
+    if not (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
+        return None
+    if x.shape[0] * x.shape[2] < _min_rows():
+        PATHS["stock_small"] += 1
+        return None
+    spec = chain_spec(x.shape[1], chain)
+    if spec is None:
+        return None
+    metas, params = spec
     if native_enabled() and len(chain) <= _ext.MAX_LAYERS:
         cache = _CHAIN_CACHE.get(chain[0][0])
         if cache is None:

@@ -230,14 +230,19 @@ def main():
     batch = synthetic.make_batch(rank * B, B, args.points, cfg, device=dev, extent_scale=extent,
                                  center_jitter=jit, use_height=not gf)  # resident in HBM
     eager_step = None
+    gfbr_graph = None
     if gfbr:
-        batch_T = synthetic.make_batch(100000 + rank * B, B, args.points, cfg, device=dev,
-                                       use_height=False)
+        # two (source, target) batch pairs for the eager, software-pipelined loop; the graph
+        # replay (static input buffers) runs the first pair
+        batches_T = [synthetic.make_batch(100000 + 7000 * i + rank * B, B, args.points, cfg,
+                                          device=dev, use_height=False) for i in range(2)]
+        batch_T = batches_T[0]
+        br_step = gf_train.train_step_br
         train_step = eager_step = lambda n, o, b, c: gf_train.train_step_br(  # noqa: E731
             n, o, b, batch_T, c)[:2]
         if graphed:
             gs = gf_train.GraphedTrainStep(net, opt, batch, cfg, batch_T=batch_T)
-            train_step = lambda n, o, b, c: gs(b)  # noqa: E731
+            gfbr_graph = lambda n, o, b, c: gs(b)  # noqa: E731
     elif gf:
         train_step = eager_step = gf_train.train_step
         if graphed:
@@ -267,12 +272,10 @@ def main():
         torch.cuda.synchronize()
 
     # two distinct resident batches, alternated: nothing a step computes can be reused by the next
-    batches = [batch]
-    if not gfbr:
-        batches.append(synthetic.make_batch(500000 + rank * B, B, args.points, cfg, device=dev,
-                                            extent_scale=extent, center_jitter=jit,
-                                            use_height=not gf))
-    pipelined_loop = not gfbr and not args.sequential
+    batches = [batch, synthetic.make_batch(500000 + rank * B, B, args.points, cfg, device=dev,
+                                           extent_scale=extent, center_jitter=jit,
+                                           use_height=not gf)]
+    pipelined_loop = not args.sequential
     pipe_step = gf_train.train_step if gf else train.train_step
 
     def run_steps(n, record=None):
@@ -282,16 +285,20 @@ def main():
         (train.train_step(next_batch=)); the pyramid of the FIRST batch is computed here, at
         the head of the loop, i.e. inside whatever region times this call."""
         out = None
+        if gfbr and gfbr_graph is not None:   # the captured two-branch step (one batch pair)
+            for i in range(n):
+                out = gfbr_graph(ddp, opt, batches[0], cfg)
+            return out
         if not pipelined_loop:
             for i in range(n):
-                if br:
+                if br or gfbr:
                     out = br_step(ddp, opt, batches[i % 2], batches_T[i % 2], cfg)
                 else:
                     out = train_step(ddp, opt, batches[i % len(batches)], cfg)
             return out
         if n <= 0:
             return out
-        if br:   # the next step's SOURCE pyramid under this step's backward (the target's
+        if br or gfbr:   # the next step's SOURCE pyramid under this step's backward (the target's
             core = net.module if hasattr(net, "module") else net   # runs under the source forward)
             sampling = core.backbone_net.prefetch_sampling(batches[0]['point_clouds'])
             sampling_t = None   # first step: under the source forward, as in the plain step
@@ -348,7 +355,7 @@ def main():
         graphed_step = train.GraphedPipelinedStep(net, opt, batches[0], batches[1], cfg)
         barrier()
     gf_calibration = None
-    if pipelined_loop and gf and graphed:
+    if pipelined_loop and gf and not gfbr and graphed:
         # GroupFree3D: the eager loop is host-bound on a slow host (~1 000 launches per step),
         # a HIP-graph replay is paced by its node count (~13 us each); which one is faster
         # depends on the box.  The step is captured once, then -- unless --graph forces the
@@ -371,6 +378,22 @@ def main():
             gf_calibration = ms
             graphed_step = captured if ms["graph"] <= ms["eager"] else None
             graphed = graphed_step is not None
+    if gfbr and gfbr_graph is not None and not args.graph:
+        # graph replay of the two-branch step against the eager, software-pipelined loop: a few
+        # untimed steps of each, the faster one is timed (as for the single-branch step above)
+        ms, captured = {}, gfbr_graph
+        for name, g in (("graph", captured), ("eager", None)):
+            gfbr_graph = g
+            run_steps(2 if g is not None else 6)   # (the eager loop's first steps grow the
+            # caching allocator's pools and build the per-shape plans)
+            barrier()
+            tc = time.perf_counter()
+            run_steps(5)
+            barrier()
+            ms[name] = 1e3 * (time.perf_counter() - tc) / 5
+        gf_calibration = ms
+        gfbr_graph = captured if ms["graph"] <= ms["eager"] else None
+        graphed = gfbr_graph is not None
     run_steps(args.warmup)
     barrier()
     train.freeze_gc()  # host runtime hygiene (see train.freeze_gc); no effect on the GPU work
@@ -382,6 +405,9 @@ def main():
     from backtoreality_amd.pointnet2 import fused_mlp as _fm
     for k in _fm.PATHS:
         _fm.PATHS[k] = 0
+    from backtoreality_amd.groupfree import fused_stack as _fs
+    _fs.CALLS[0] = 0
+    _fs.REFUSED.clear()
     # the step clock: wall time between the barriers (what `value` is), and beside it a hipEvent
     # pair on the stream the steps are issued on (it closes after the joins of the
     # side streams, so both clocks see the same work)
@@ -392,6 +418,9 @@ def main():
     ev1.record()
     enqueue = time.perf_counter() - t0   # host side done (launches queued), GPU still running
     chain_paths = dict(_fm.PATHS)        # point-wise chains of the timed steps, by path taken
+    if _fs.CALLS[0] or _fs.REFUSED:      # GroupFree3D decoder loops: one-node form / module loop
+        chain_paths["decoder_stack"] = _fs.CALLS[0]
+        chain_paths["decoder_stack_refused"] = dict(_fs.REFUSED)
     barrier()
     elapsed = time.perf_counter() - t0
     gpu_elapsed_ms = ev0.elapsed_time(ev1)
@@ -414,7 +443,7 @@ def main():
         _ext.timing_begin(lambda op, key: op == "fps_kernel" and key[1] > 4096)
         t1 = time.perf_counter()
         for i in range(args.steps):
-            if br:
+            if br or gfbr:
                 br_step(ddp, opt, batches[i % 2], batches_T[i % 2], cfg)
             else:
                 train_step(ddp, opt, batches[i % len(batches)], cfg)
@@ -513,10 +542,10 @@ def main():
         # figure (round 1's `value`) always at top level when it was measured
         out["value_loop"] = "software-pipelined" if pipelined_loop else "sequential"
         if sequential is not None:
-            out["sequential_value"] = world * B * args.steps * (2 if br else 1) / sequential
+            out["sequential_value"] = world * B * args.steps * (2 if (br or gfbr) else 1) / sequential
             out["sequential_ms_per_step"] = 1e3 * sequential / args.steps
             out["sequential"] = {
-                "value": world * B * args.steps * (2 if br else 1) / sequential,
+                "value": world * B * args.steps * (2 if (br or gfbr) else 1) / sequential,
                 "unit": "scenes/s",
                 "ms_per_step": 1e3 * sequential / args.steps,
                 "note": "rank-0 clock; the same K steps without the cross-step overlap (every "

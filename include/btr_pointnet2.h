@@ -907,6 +907,75 @@ int btr_gf_head_decode(int b, int p, int nh, int ns, const float *out, long long
                        float *heading_residuals, float *size_residuals, float *pred_size,
                        float *query_pos, float *query_pos_t, btr_stream_t stream);
 
+/* ---- GroupFree3D: the decoder stack as one call per direction (csrc/gf_stack.hip) --------------
+ * reference: detection/GroupFree3D/models/detector.py:161-219 -- the loop over the decoder layers
+ *     query_pos -> self_posembed, key_pos -> cross_posembed (modules.py:50-65),
+ *     decoder[i](query, key, query_pos, key_pos)            (transformer.py:36-76),
+ *     prediction_heads[i](query, base_xyz)                   (modules.py:107-262),
+ *     query_pos <- (center, pred_size).detach()              (detector.py:204-230)
+ * -- and its autograd backward.  The host walks the same launches the per-module entry points
+ * above issue (btr_pm_chain_*, btr_decoder_layer_*, btr_gf_head_decode); what disappears is the
+ * interpreter between them: 30 autograd nodes per step, each ~0.1 ms of host time around ~10
+ * launches of 5 - 20 us, on a step that is paced by the host.
+ * Layer i: qpos[i] / kpos[i] are the position-embedding chains ((b, 3|6, pq) -> (b, e, pq) and
+ * (b, 3, pk) -> (b, e, pk); has_qpos / has_kpos = 0: none), layer[i] the decoder layer, head[i] the
+ * prediction head as ONE chain whose last layer is the concatenation of the seven output
+ * convolutions (head_c = 4 + 2 nh + 4 ns + classes channels, order as in btr_gf_loss_fwd).
+ * All chains carry need_dx as the backward needs it (head: 1, embeddings: 0). */
+#define BTR_GF_MAX_DECODER_LAYERS 12
+typedef struct {
+  int layers, b, pq, pk, e;
+  int nh, ns, head_c;
+  int has_qpos, has_kpos;
+  btr_decoder_layer_t layer[BTR_GF_MAX_DECODER_LAYERS];
+  btr_pm_chain_t qpos[BTR_GF_MAX_DECODER_LAYERS];
+  btr_pm_chain_t kpos[BTR_GF_MAX_DECODER_LAYERS];
+  btr_pm_chain_t head[BTR_GF_MAX_DECODER_LAYERS];
+} btr_gf_stack_t;
+
+typedef struct {
+  btr_decoder_plan_t layer[BTR_GF_MAX_DECODER_LAYERS];
+  btr_pm_plan_t qpos[BTR_GF_MAX_DECODER_LAYERS], kpos[BTR_GF_MAX_DECODER_LAYERS],
+      head[BTR_GF_MAX_DECODER_LAYERS];
+  /* byte offsets into `saved`: the modules' own blocks, then the rows handed between them --
+   * x[i] (b*pq, e) = output of layer i, qpos_cl[i] (b*pq, e) / kpos_cl[i] (b*pk, e) = embeddings */
+  size_t s_layer[BTR_GF_MAX_DECODER_LAYERS], s_qpos[BTR_GF_MAX_DECODER_LAYERS],
+      s_kpos[BTR_GF_MAX_DECODER_LAYERS], s_head[BTR_GF_MAX_DECODER_LAYERS];
+  size_t s_x[BTR_GF_MAX_DECODER_LAYERS], s_qpos_cl[BTR_GF_MAX_DECODER_LAYERS],
+      s_kpos_cl[BTR_GF_MAX_DECODER_LAYERS];
+  size_t saved_bytes, fwd_scratch_bytes, bwd_scratch_bytes;
+  /* float offsets into `grads`: each module's block, laid out as its own plan says */
+  size_t g_layer[BTR_GF_MAX_DECODER_LAYERS], g_qpos[BTR_GF_MAX_DECODER_LAYERS],
+      g_kpos[BTR_GF_MAX_DECODER_LAYERS], g_head[BTR_GF_MAX_DECODER_LAYERS];
+  size_t grads_floats;
+} btr_gf_stack_plan_t;
+
+/* sizeof(btr_gf_stack_t) (which = 0) / sizeof(btr_gf_stack_plan_t) (1), for bindings to check */
+long long btr_gf_stack_sizeof(int which);
+int btr_gf_stack_plan(const btr_gf_stack_t *d, btr_gf_stack_plan_t *plan);
+/* query_cl (b*pq, e), key_cl (b*pk, e): channel-last rows; qpos0_t (b, 3|6, pq): the first
+ * layer's query position, key_xyz_t (b, 3, pk): the key position (NULL without the embedding);
+ * base_xyz (b, pq, 3); mean_size (ns, 3).  Per layer i (arrays of `layers` pointers):
+ * head_out[i] (b, head_c, pq), head_out_cl[i] (b*pq, ceil4(head_c)), and what
+ * btr_gf_head_decode derives from it: center[i], heading_residuals[i], size_residuals[i],
+ * pred_size[i], query_pos[i] (b, pq, 6), query_pos_t[i] (b, 6, pq) (= layer i+1's embedding
+ * input).  last_bcp (b, e, pq) / last_cl: the last layer's output (may be NULL). */
+int btr_gf_stack_forward(const btr_gf_stack_t *d, const btr_gf_stack_plan_t *plan,
+                         const float *query_cl, const float *key_cl, const float *qpos0_t,
+                         const float *key_xyz_t, const float *base_xyz, const float *mean_size,
+                         float *const *head_out, float *const *head_out_cl, float *const *center,
+                         float *const *heading_residuals, float *const *size_residuals,
+                         float *const *pred_size, float *const *query_pos,
+                         float *const *query_pos_t, float *last_bcp, float *last_cl, void *saved,
+                         void *scratch, btr_stream_t stream);
+/* dhead[i] (b, head_c, pq) or NULL (that head received no gradient); dlast_bcp (b, e, pq) or NULL;
+ * grads: plan->grads_floats floats, fully written; dquery_bcp (b, e, pq), dkey_bcp (b, e, pk) */
+int btr_gf_stack_backward(const btr_gf_stack_t *d, const btr_gf_stack_plan_t *plan,
+                          const float *query_cl, const float *key_cl,
+                          const float *const *dhead, const float *dlast_bcp, void *saved,
+                          float *grads, float *dquery_bcp, float *dkey_bcp, void *scratch,
+                          btr_stream_t stream);
+
 /* ---- Adam / AdamW over many tensors in one launch (csrc/optimizer.hip) -----------------------
  * reference: optimizer.step() of train_Votenet_FSB.py:231 (Adam) and train_GF_FSB.py:319 (AdamW,
  * two parameter groups); update rule of torch's fused implementation (header of the source).
