@@ -18,6 +18,19 @@ for (B, N, M, r, S, scale) in ((8, 40000, 2048, 0.2, 64, 1.0), (4, 50000, 2048, 
     xyz = xyz.contiguous()
     inds = _ext.furthest_point_sampling(xyz, M).long()
     new_xyz = torch.gather(xyz, 1, inds.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    if os.environ.get("BQ_SORT"):   # experiment: centres in Morton order (what would a spatial
+        # order of the centres buy the bucket query?)
+        lo = xyz.amin(1, keepdim=True)
+        q = ((new_xyz - lo) / (xyz.amax(1, keepdim=True) - lo + 1e-9) * 1023).long().clamp(0, 1023)
+
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        key = spread(q[..., 0]) | (spread(q[..., 1]) << 1) | (spread(q[..., 2]) << 2)
+        order = key.argsort(1)
+        new_xyz = torch.gather(new_xyz, 1, order.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
     idx = _ext.ball_query(new_xyz, xyz, r, S)
     med, mn = timeit(lambda: _ext.ball_query(new_xyz, xyz, r, S), iters=20)
     print("B=%d N=%d scale %.1f build=%s: median %.1f us min %.1f us  checksum %d" % (
