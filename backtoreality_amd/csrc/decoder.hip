@@ -751,7 +751,27 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
                                const float *kpos_cl, const float *dout_bcp, void *saved,
                                float *grads, float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
                                void *scratch, btr_stream_t stream) {
-  BTR_REQUIRE(dp && pp && x_cl && key_cl && dout_bcp && saved && grads && scratch,
+  return decoder_layer_backward_rows(dp, pp, x_cl, key_cl, qpos_cl, kpos_cl, dout_bcp, nullptr,
+                                     nullptr, nullptr, saved, grads, dx_bcp, dkey_bcp, dqpos_bcp,
+                                     nullptr, scratch, stream);
+}
+
+}  // extern "C"
+
+namespace btr {
+// (internal.hpp) btr_decoder_layer_backward with the gradients handed over as channel-last rows:
+// the output gradient is dout_bcp (transposed here) or the row operands (g0 + g1) + g2 (g1, g2
+// optional); `out` (optional) names caller-owned row buffers for d res1 / d qp0 / d qp1 / d kp --
+// dx = res1 + qp0, dqpos = qp0 + qp1, dkey = kp -- instead of the layer's scratch, so a caller that
+// consumes rows (csrc/gf_stack.hip) passes dx_bcp / dkey_bcp / dqpos_bcp = NULL and no layout
+// kernel runs.
+int decoder_layer_backward_rows(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp,
+                                const float *x_cl, const float *key_cl, const float *qpos_cl,
+                                const float *kpos_cl, const float *dout_bcp, const float *g0,
+                                const float *g1, const float *g2, void *saved, float *grads,
+                                float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
+                                const DecoderRowsOut *out, void *scratch, btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && x_cl && key_cl && (dout_bcp || g0) && saved && grads && scratch,
               "decoder_layer_backward: null pointer");
   const btr_decoder_layer_t &d = *dp;
   const btr_decoder_plan_t &p = *pp;
@@ -811,10 +831,20 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
                           stream);
   };
 
+  // the four row tensors the module's input gradients are made of: the layer's scratch, or the
+  // caller's buffers
+  float *r_dres1 = out && out->dres1 ? out->dres1 : S(sc.dres1);
+  float *r_dqp0 = out && out->dqp0 ? out->dqp0 : S(sc.dqp0);
+  float *r_dqp1 = out && out->dqp1 ? out->dqp1 : S(sc.dqp1);
+  float *r_dkp = out && out->dkp ? out->dkp : S(sc.dkp);
   // ---- LayerNorm 3, feed-forward
-  BTR_TRY(btr_pm_rows(d.b, d.pq, e, e, dout_bcp, S(sc.dx3), stream));
+  if (dout_bcp) {
+    BTR_TRY(btr_pm_rows(d.b, d.pq, e, e, dout_bcp, S(sc.dx3), stream));
+    g0 = S(sc.dx3);
+    g1 = g2 = nullptr;
+  }
   {
-    LnBwd a{rq, e, S(sc.dx3), nullptr, nullptr, 0, 0, at_f(saved, p.xh3), at_f(saved, p.rs3),
+    LnBwd a{rq, e, g0, g1, g2, g1 ? 1 : 0, 0, at_f(saved, p.xh3), at_f(saved, p.rs3),
             d.ln_w[2], make_drop(d, 3), S(sc.dres3), S(sc.df), S(sc.lnp[2])};
     BTR_TRY(ln_backward(hs, a));
   }
@@ -846,13 +876,13 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
       (long long)d.pk * 2 * e, scale, d.dropout, attn_seed(d, 1), d.step, stream));
   BTR_TRY(wgrad(2, S(sc.dq2), qp1, grads + p.g_ca_in_w));
   BTR_TRY(wgrad(3, S(sc.dkv), kp, grads + p.g_ca_in_w + (size_t)e * e));
-  BTR_TRY(dgrad(rq, e, e, S(sc.dq2), S(sc.t_ca_in), 3 * e, S(sc.dqp1), sc.p_ca_in, 0, e));
-  if (dkey_bcp)
-    BTR_TRY(dgrad(rk, 2 * e, e, S(sc.dkv), S(sc.t_ca_in) + e, 3 * e, S(sc.dkp), sc.p_ca_in, e, e));
+  BTR_TRY(dgrad(rq, e, e, S(sc.dq2), S(sc.t_ca_in), 3 * e, r_dqp1, sc.p_ca_in, 0, e));
+  if (dkey_bcp || (out && out->dkp))
+    BTR_TRY(dgrad(rk, 2 * e, e, S(sc.dkv), S(sc.t_ca_in) + e, 3 * e, r_dkp, sc.p_ca_in, e, e));
   // ---- LayerNorm 1, self-attention
   {
-    LnBwd a{rq, e, S(sc.dres2), S(sc.dqp1), nullptr, 1, 0, at_f(saved, p.xh1), at_f(saved, p.rs1),
-            d.ln_w[0], make_drop(d, 0), S(sc.dres1), S(sc.do1), S(sc.lnp[0])};
+    LnBwd a{rq, e, S(sc.dres2), r_dqp1, nullptr, 1, 0, at_f(saved, p.xh1), at_f(saved, p.rs1),
+            d.ln_w[0], make_drop(d, 0), r_dres1, S(sc.do1), S(sc.lnp[0])};
     BTR_TRY(ln_backward(hs, a));
   }
   BTR_TRY(wgrad(1, S(sc.do1), a1, grads + p.g_sa_out_w));
@@ -864,7 +894,7 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
       S(sc.dqkv) + 2 * e, 3 * e, (long long)d.pq * 3 * e, scale, d.dropout, attn_seed(d, 0),
       d.step, stream));
   BTR_TRY(wgrad(0, S(sc.dqkv), qp0, grads + p.g_sa_in_w));
-  BTR_TRY(dgrad(rq, 3 * e, e, S(sc.dqkv), S(sc.t_sa_in), 3 * e, S(sc.dqp0), sc.p_sa_in, 0, e));
+  BTR_TRY(dgrad(rq, 3 * e, e, S(sc.dqkv), S(sc.t_sa_in), 3 * e, r_dqp0, sc.p_sa_in, 0, e));
   reduce_batch_flush(hs);
   flush.open = false;
 
@@ -904,11 +934,11 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_
     hipLaunchKernelGGL(colsum_final_multi_kernel, dim3(blocks), dim3(256), 0, hs, fa);
   }
   // ---- gradients of the module inputs, (B, E, P)
-  if (dx_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pq, e, S(sc.dres1), S(sc.dqp0), nullptr, dx_bcp));
+  if (dx_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pq, e, r_dres1, r_dqp0, nullptr, dx_bcp));
   if (dqpos_bcp && qpos_cl)
-    BTR_TRY(rows_to_bcp(hs, d.b, d.pq, e, S(sc.dqp0), S(sc.dqp1), nullptr, dqpos_bcp));
-  if (dkey_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pk, e, S(sc.dkp), nullptr, nullptr, dkey_bcp));
+    BTR_TRY(rows_to_bcp(hs, d.b, d.pq, e, r_dqp0, r_dqp1, nullptr, dqpos_bcp));
+  if (dkey_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pk, e, r_dkp, nullptr, nullptr, dkey_bcp));
   return check_launch("decoder_layer_backward");
 }
 
-}  // extern "C"
+}  // namespace btr

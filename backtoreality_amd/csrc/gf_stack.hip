@@ -79,13 +79,19 @@ int sum_into(hipStream_t s, long long n, const float *const *src, int count, flo
   return check_launch("gf_stack sum");
 }
 
+// Backward scratch.  Gradients travel between the modules as channel-last rows -- the layout the
+// layer's LayerNorm backward and the chains' GEMMs read -- so no (b, e, p) tensor is formed between
+// them (per layer: the head chain's pm_out, the sum kernel, the layer's pm_rows and its three
+// rows_to_bcp launches are gone; tests/test_gf_stack_gpu.py: still bit for bit the module loop's
+// numbers, the operands are added in the same order).
 struct BwdScratch {
   size_t sub;                 // the modules' own scratch (they run one after the other)
-  size_t dx[2];               // (b, e, pq): gradient of x[i] from layer i+1, ping-pong
-  size_t dhx;                 // (b, e, pq): gradient of x[i] from head i
-  size_t dsum;                // (b, e, pq): what layer i's backward is given
-  size_t dqpos;               // (b, e, pq)
-  size_t dkey[BTR_GF_MAX_DECODER_LAYERS];   // (b, e, pk) per layer
+  size_t dhx;                 // (b*pq, e): gradient of x[i] from head i
+  size_t pair[2][2];          // (b*pq, e) x 2: d res1, d qp0 of a layer (their sum = d x[i-1]), ping-pong
+  size_t dqp1;                // (b*pq, e): with d qp0 the gradient of the query position embedding
+  size_t dlast;               // (b*pq, e): the caller's gradient of the last output, as rows
+  size_t dkp[BTR_GF_MAX_DECODER_LAYERS];   // (b*pk, e) per layer: d key = d kpos
+  size_t ksum;                // (b*pk, e)
   size_t bytes;
 };
 BwdScratch bwd_scratch(const btr_gf_stack_t &d, const btr_gf_stack_plan_t &p) {
@@ -100,12 +106,13 @@ BwdScratch bwd_scratch(const btr_gf_stack_t &d, const btr_gf_stack_plan_t &p) {
   }
   s.sub = b.take(sub);
   const size_t q = (size_t)d.b * d.pq * d.e, k = (size_t)d.b * d.pk * d.e;
-  s.dx[0] = b.floats(q);
-  s.dx[1] = b.floats(q);
   s.dhx = b.floats(q);
-  s.dsum = b.floats(q);
-  s.dqpos = b.floats(q);
-  for (int i = 0; i < d.layers; ++i) s.dkey[i] = b.floats(k);
+  for (int a = 0; a < 2; ++a)
+    for (int c = 0; c < 2; ++c) s.pair[a][c] = b.floats(q);
+  s.dqp1 = b.floats(q);
+  s.dlast = b.floats(q);
+  for (int i = 0; i < d.layers; ++i) s.dkp[i] = b.floats(k);
+  s.ksum = b.floats(k);
   s.bytes = b.off;
   return s;
 }
@@ -274,61 +281,66 @@ int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *p
   void *sub = at_v(scratch, sc.sub);
   const long long q = (long long)d.b * d.pq * d.e, k = (long long)d.b * d.pk * d.e;
   const int L = d.layers;
-  const float *dnext = dlast_bcp;   // gradient of x[i] from whatever consumes it besides head i
+  // what reaches x[i] from above: the pair (d res1, d qp0) of layer i+1, or the caller's gradient
+  const float *up0 = nullptr, *up1 = nullptr;
+  if (dlast_bcp) {
+    BTR_TRY(btr_pm_rows(d.b, d.pq, d.e, d.e, dlast_bcp, at_f(scratch, sc.dlast), stream));
+    up0 = at_f(scratch, sc.dlast);
+  }
   int flip = 0;
   for (int i = L - 1; i >= 0; --i) {
-    const float *dx_in = nullptr;
+    const float *g0 = up0, *g1 = up1, *g2 = nullptr;
     if (dhead[i]) {
       float *dhx = at_f(scratch, sc.dhx);
-      BTR_TRY(btr_pm_chain_backward(&d.head[i], &p.head[i], at_f(saved, p.s_x[i]), dhead[i],
-                                    at_v(saved, p.s_head[i]), grads + p.g_head[i], dhx, sub,
-                                    stream));
-      if (dnext) {
-        const float *src[2] = {dhx, dnext};
-        BTR_TRY(sum_into(hs, q, src, 2, at_f(scratch, sc.dsum)));
-        dx_in = at_f(scratch, sc.dsum);
-      } else
-        dx_in = dhx;
+      BTR_TRY(pm_chain_backward_rows(&d.head[i], &p.head[i], at_f(saved, p.s_x[i]), dhead[i],
+                                     nullptr, nullptr, at_v(saved, p.s_head[i]),
+                                     grads + p.g_head[i], nullptr, dhx, sub, stream));
+      // (module loop: d x[i] = head's + the layer's / the caller's -- a + b = b + a exactly, and
+      // the layer's own two parts are added first as its rows_to_bcp did)
+      if (g0) g2 = dhx; else g0 = dhx;
     } else {
       (void)hipMemsetAsync(grads + p.g_head[i], 0, p.head[i].grads_floats * sizeof(float), hs);
-      dx_in = dnext;
     }
     const float *x_in = i == 0 ? query_cl : at_f(saved, p.s_x[i - 1]);
     const float *qpos_cl = d.has_qpos ? at_f(saved, p.s_qpos_cl[i]) : nullptr;
     const float *kpos_cl = d.has_kpos ? at_f(saved, p.s_kpos_cl[i]) : nullptr;
-    float *dkey_i = at_f(scratch, sc.dkey[i]);
-    if (!dx_in) {   // nothing reaches this layer (and so none below it through x)
+    float *dkp = at_f(scratch, sc.dkp[i]);
+    if (!g0) {   // nothing reaches this layer (and so none below it through x)
       (void)hipMemsetAsync(grads + p.g_layer[i], 0, p.layer[i].grads_floats * sizeof(float), hs);
-      (void)hipMemsetAsync(dkey_i, 0, (size_t)k * sizeof(float), hs);
+      (void)hipMemsetAsync(dkp, 0, (size_t)k * sizeof(float), hs);
       if (d.has_qpos)
         (void)hipMemsetAsync(grads + p.g_qpos[i], 0, p.qpos[i].grads_floats * sizeof(float), hs);
       if (d.has_kpos)
         (void)hipMemsetAsync(grads + p.g_kpos[i], 0, p.kpos[i].grads_floats * sizeof(float), hs);
-      dnext = nullptr;
+      up0 = up1 = nullptr;
       continue;
     }
-    float *dx = i == 0 ? dquery_bcp : at_f(scratch, sc.dx[flip]);
+    const DecoderRowsOut out{at_f(scratch, sc.pair[flip][0]), at_f(scratch, sc.pair[flip][1]),
+                             at_f(scratch, sc.dqp1), dkp};
     flip ^= 1;
-    float *dqpos = d.has_qpos ? at_f(scratch, sc.dqpos) : nullptr;
-    BTR_TRY(btr_decoder_layer_backward(&d.layer[i], &p.layer[i], x_in, key_cl, qpos_cl, kpos_cl,
-                                       dx_in, at_v(saved, p.s_layer[i]), grads + p.g_layer[i], dx,
-                                       dkey_i, dqpos, sub, stream));
+    BTR_TRY(decoder_layer_backward_rows(&d.layer[i], &p.layer[i], x_in, key_cl, qpos_cl, kpos_cl,
+                                        nullptr, g0, g1, g2, at_v(saved, p.s_layer[i]),
+                                        grads + p.g_layer[i], i == 0 ? dquery_bcp : nullptr,
+                                        nullptr, nullptr, &out, sub, stream));
     if (d.has_qpos)
-      BTR_TRY(btr_pm_chain_backward(&d.qpos[i], &p.qpos[i], nullptr, dqpos,
-                                    at_v(saved, p.s_qpos[i]), grads + p.g_qpos[i], nullptr, sub,
-                                    stream));
+      BTR_TRY(pm_chain_backward_rows(&d.qpos[i], &p.qpos[i], nullptr, nullptr, out.dqp0, out.dqp1,
+                                     at_v(saved, p.s_qpos[i]), grads + p.g_qpos[i], nullptr,
+                                     nullptr, sub, stream));
     if (d.has_kpos)
-      BTR_TRY(btr_pm_chain_backward(&d.kpos[i], &p.kpos[i], nullptr, dkey_i,
-                                    at_v(saved, p.s_kpos[i]), grads + p.g_kpos[i], nullptr, sub,
-                                    stream));
-    dnext = dx;
+      BTR_TRY(pm_chain_backward_rows(&d.kpos[i], &p.kpos[i], nullptr, nullptr, dkp, nullptr,
+                                     at_v(saved, p.s_kpos[i]), grads + p.g_kpos[i], nullptr,
+                                     nullptr, sub, stream));
+    up0 = out.dres1;
+    up1 = out.dqp0;
   }
-  if (dquery_bcp && !dnext)
+  if (dquery_bcp && !up0)
     (void)hipMemsetAsync(dquery_bcp, 0, (size_t)q * sizeof(float), hs);
-  if (dkey_bcp) {
+  if (dkey_bcp) {   // the layers' key gradients, last layer first (autograd's order), then (b, e, pk)
     const float *src[BTR_GF_MAX_DECODER_LAYERS];
-    for (int i = 0; i < L; ++i) src[i] = at_f(scratch, sc.dkey[L - 1 - i]);
-    BTR_TRY(sum_into(hs, k, src, L, dkey_bcp));
+    for (int i = 0; i < L; ++i) src[i] = at_f(scratch, sc.dkp[L - 1 - i]);
+    BTR_TRY(sum_into(hs, k, src, L, at_f(scratch, sc.ksum)));
+    BTR_TRY(btr_pm_out(d.b, d.pk, d.e, d.e, at_f(scratch, sc.ksum), nullptr, nullptr, 0, dkey_bcp,
+                       nullptr, stream));
   }
   return check_launch("gf_stack_backward");
 }

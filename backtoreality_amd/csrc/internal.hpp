@@ -86,6 +86,27 @@ int ppfl_assemble(int nl, int c, const float *dwx, const float *dwf, float *dw, 
 void prep_batch_begin();
 void prep_batch_launch(hipStream_t st);
 void prep_batch_end();
+// decoder.hip: btr_decoder_layer_backward on channel-last rows (see the definition)
+struct DecoderRowsOut {
+  float *dres1, *dqp0, *dqp1, *dkp;
+};
+int decoder_layer_backward_rows(const btr_decoder_layer_t *d, const btr_decoder_plan_t *p,
+                                const float *x_cl, const float *key_cl, const float *qpos_cl,
+                                const float *kpos_cl, const float *dout_bcp, const float *g0,
+                                const float *g1, const float *g2, void *saved, float *grads,
+                                float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
+                                const DecoderRowsOut *out, void *scratch, btr_stream_t stream);
+// sa_layer.hip: btr_pm_chain_backward with the output gradient as channel-last rows a0 (+ a1)
+// instead of dout (b, c, n), and / or the input gradient left as rows in dx_rows (leading
+// dimension = the padded input width) instead of dx (b, c, n)
+int pm_chain_backward_rows(const btr_pm_chain_t *d, const btr_pm_plan_t *p, const float *x_cl,
+                           const float *dout, const float *a0, const float *a1, void *saved,
+                           float *grads, float *dx, float *dx_rows, void *scratch,
+                           btr_stream_t stream);
+// sa_mlp.hip: rows[r][c] = a0[r][c] (+ a1[r][c]) for c < C, zero up to ldr; zero / colpart as
+// pm_rows_zero (same tiles, same summation order)
+int pm_rows_in(int b, int n, int c, int ldr, const float *a0, const float *a1, float *rows,
+               float *zero, int nzero, float *colpart, hipStream_t stream);
 // sa_mlp.hip: the small-M NT GEMM on the bf16 planes of (a sub-block of) a weight matrix
 int pm_gemm_nt_planes(int rows, int n, int k, const float *a, int lda, const void *planes, int kp,
                       long long ps, float *c, int ldc, const float *bias, hipStream_t s);

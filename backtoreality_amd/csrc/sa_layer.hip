@@ -1260,7 +1260,20 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
 int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, const float *x_cl,
                           const float *dout, void *saved, float *grads, float *dx,
                           void *scratch, btr_stream_t stream) {
-  BTR_REQUIRE(dp && pp && dout && saved && grads && scratch, "pm_chain_backward: null pointer");
+  return pm_chain_backward_rows(dp, pp, x_cl, dout, nullptr, nullptr, saved, grads, dx, nullptr,
+                                scratch, stream);
+}
+
+}  // extern "C"
+
+namespace btr {
+// (internal.hpp) the chain backward with row-form hand-overs on either side
+int pm_chain_backward_rows(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, const float *x_cl,
+                           const float *dout, const float *a0, const float *a1, void *saved,
+                           float *grads, float *dx, float *dx_rows, void *scratch,
+                           btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && (dout || a0) && saved && grads && scratch,
+              "pm_chain_backward: null pointer");
   const btr_pm_chain_t &d = *dp;
   const btr_pm_plan_t &p = *pp;
   const int L = d.layers, rows = p.rows;
@@ -1277,7 +1290,11 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
   // bias gradient of a bare last layer = column sums of dout: per-tile partials from the same
   // launch, then one small reduction
   const bool bare_bias = !d.has_bn[L - 1] && d.bias[L - 1];
-  BTR_TRY(pm_rows_zero(d.b, d.n, nl, npl, dout, g, grads + p.dbias[0],
+  if (dout)
+    BTR_TRY(pm_rows_zero(d.b, d.n, nl, npl, dout, g, grads + p.dbias[0],
+                         (int)(p.grads_floats - p.dbias[0]), bare_bias ? colsum : nullptr, hs));
+  else
+    BTR_TRY(pm_rows_in(d.b, d.n, nl, npl, a0, a1, g, grads + p.dbias[0],
                        (int)(p.grads_floats - p.dbias[0]), bare_bias ? colsum : nullptr, hs));
   // `lazy` / `fusable`: as in btr_sa_layer_backward -- a hidden layer behind a BatchNorm runs its
   // whole backward (dW_l, dZ_{l-1}, BatchNorm_{l-1}'s sums) as one btr_sa_bwd_fused call, which
@@ -1352,6 +1369,7 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
     if (l > 0 || d.need_dx) {
       float *gn = at_f(scratch, sc.g[flip]);
       flip ^= 1;
+      if (l == 0 && dx_rows) gn = dx_rows;   // the caller's rows (leading dimension kin[0])
       // gn is the buffer dY_{l+1} lived in: its weight gradient must be through with it
       if (side && l + 1 <= L - 1 && last_done == l + 1)
         (void)hipStreamWaitEvent(hs, side->done[l + 1], 0);
@@ -1370,8 +1388,10 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
                                      grads + p.dgamma[l - 1], grads + p.dbeta[l - 1], stream));
         dy = gn;
       } else {
-        BTR_REQUIRE(dx, "pm_chain_backward: dx missing");
-        BTR_TRY(btr_pm_out(d.b, d.n, d.c, p.kin[0], gn, nullptr, nullptr, 0, dx, nullptr, stream));
+        BTR_REQUIRE(dx || dx_rows, "pm_chain_backward: dx missing");
+        if (dx)
+          BTR_TRY(btr_pm_out(d.b, d.n, d.c, p.kin[0], gn, nullptr, nullptr, 0, dx, nullptr,
+                             stream));
       }
     }
   }
@@ -1386,6 +1406,9 @@ int btr_pm_chain_backward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, con
   }
   return check_launch("pm_chain_backward");
 }
+}  // namespace btr
+
+extern "C" {
 
 int btr_vote_assemble(int b, int n, int c, const float *net_cl, int ld_net,
                       const float *seed_xyz, const float *seed_cl, float *vote_xyz,

@@ -20,6 +20,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "internal.hpp"
 
 namespace btr {
@@ -159,6 +163,52 @@ __device__ __forceinline__ float4 rc_y4(const float4 x, const float *__restrict_
   const float4 *w = reinterpret_cast<const float4 *>(w0) + k;  // W0[k..k+3][0..3]
   return make_float4(rc_dot4(x, w[0]), rc_dot4(x, w[1]), rc_dot4(x, w[2]), rc_dot4(x, w[3]));
 }
+
+// ---- live timing of the GEMM family (btr_gemm_trace_begin / _end, include/btr_pointnet2.h) ------
+// bench.py's mlp_roofline used to time these launches from Python, which only the Python-sequenced
+// form of a layer can do -- a form that lacks what csrc/sa_layer.hip does beyond it (Gram-form
+// backward, per-point first layer), so the line's figure drifted from the rocprofv3 one.  While a
+// trace is open on the host thread, every entry point of the family records a HIP event pair on
+// its own stream around its launches (the outermost scope only: entry points call each other).
+// (Process-wide, not per thread: autograd runs the backward's calls on its own thread.  A scope is
+// "outermost" per thread.)
+struct GemmTraceState {
+  std::atomic<bool> on{false};
+  std::mutex mu;
+  std::vector<hipEvent_t> ev;   // pairs
+};
+inline GemmTraceState &gemm_trace_state() {
+  static GemmTraceState st;
+  return st;
+}
+struct GemmTrace {
+  hipStream_t s;
+  hipEvent_t stop;
+  explicit GemmTrace(hipStream_t stream) : s(stream), stop(nullptr) {
+    GemmTraceState &st = gemm_trace_state();
+    if (!st.on.load(std::memory_order_relaxed)) return;
+    static thread_local int depth = 0;
+    depth_ = &depth;
+    if (depth++ == 0) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
+        {
+          std::lock_guard<std::mutex> lock(st.mu);
+          st.ev.push_back(a);
+          st.ev.push_back(b);
+        }
+        (void)hipEventRecord(a, s);
+        stop = b;
+      }
+    }
+  }
+  ~GemmTrace() {
+    if (!depth_) return;
+    --*depth_;
+    if (stop) (void)hipEventRecord(stop, s);
+  }
+  int *depth_ = nullptr;
+};
 
 // ---- the BatchNorm ticket (BnFin): which workgroup of a column block finished last
 // __threadfence() is `buffer_wbl2 sc1` + `buffer_inv sc1` on gfx950: EVERY wave of EVERY workgroup
@@ -4551,6 +4601,7 @@ void reduce_batch_begin() {
   b.args.first[0] = b.wide.first[0] = 0;
 }
 void reduce_batch_flush(hipStream_t st) {
+  GemmTrace trace_(st);   // (the second half of the family's split-K products)
   ReduceBatch &b = reduce_batch();
   b.on = false;
   if (b.args.n > 0)
@@ -5245,6 +5296,52 @@ int pm_rows_zero(int b, int n, int c, int ldr, const float *x, float *rows, floa
   return check_launch("pm_rows");
 }
 
+// rows[b*N + n][c] = a0[b*N + n][c] (+ a1[...]) for c < C, zero for C <= c < ldr: pm_rows_kernel for
+// a gradient that already is channel-last rows (leading dimension C).  Same tiles, same zero /
+// colpart duties, the column sums added in the same order, so a chain backward fed this way
+// returns what it returns for the (B, C, N) form of the same values.
+__global__ __launch_bounds__(256) void pm_rows_in_kernel(int N, int C, int ldr,
+                                                         const float *__restrict__ a0,
+                                                         const float *__restrict__ a1,
+                                                         float *__restrict__ rows,
+                                                         float *__restrict__ zero, int nzero,
+                                                         float *__restrict__ colpart) {
+  __shared__ float red[4][64];
+  if (zero && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0.f;
+  const int bi = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = c0 + tx;
+  float cs = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + ty + 4 * i;
+    float v = 0.f;
+    if (n < N && c < C) {
+      const size_t at = ((size_t)bi * N + n) * C + c;
+      v = a0[at];
+      if (a1) v += a1[at];
+    }
+    if (n < N && c < ldr) rows[((size_t)bi * N + n) * ldr + c] = v;
+    cs += v;
+  }
+  if (colpart) {
+    red[ty][tx] = cs;
+    __syncthreads();
+    if (ty == 0 && c < ldr)
+      colpart[((size_t)bi * gridDim.x + blockIdx.x) * ldr + c] =
+          (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  }
+}
+int pm_rows_in(int b, int n, int c, int ldr, const float *a0, const float *a1, float *rows,
+               float *zero, int nzero, float *colpart, hipStream_t stream) {
+  if (b <= 0 || n <= 0 || c <= 0) return BTR_OK;
+  BTR_REQUIRE(a0 && rows && ldr >= c, "pm_rows_in: bad arguments");
+  hipLaunchKernelGGL(pm_rows_in_kernel, dim3(cdiv(n, 64), cdiv(ldr, 64), b), dim3(256), 0, stream,
+                     n, c, ldr, a0, a1, rows, zero, nzero, colpart);
+  return check_launch("pm_rows_in");
+}
+
 // (internal.hpp) pm_out with an operand added to the (B, C, N) output
 int pm_out_add(int b, int n, int c, int ldy, const float *y, const float *scale,
                const float *shift, int relu, float *out_bcn, float *out_cl, const float *add,
@@ -5488,6 +5585,7 @@ int btr_sa_gemm_nt_poolfwd_supported(int rows, int n, int s) {
 int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
                    float *c, int ldc, const float *pa, const float *pb, float *part,
                    btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
   BTR_REQUIRE(a && w && (c || part) && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt: k=%d lda=%d ldw=%d must be multiples of 4", k, lda, ldw);
@@ -5544,6 +5642,7 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
                            int ldw, float *c, int ldc, const float *pa, const float *pb,
                            float *part, int s, const float *gamma, float *gext,
                            unsigned char *aext, btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
   BTR_REQUIRE(a && w && part && pa && pb && gamma && gext && aext && k > 0 &&
                   k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
@@ -5694,6 +5793,7 @@ int btr_sa_pool_bwd_coef(int b, int m, int s, int c, int ldy, const float *y, co
 int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const float *w, int ldw,
                         float *c, int ldc, int s, const unsigned char *arg, const float *dcl,
                         const float *alpha, const float *beta, btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
   BTR_REQUIRE(y && w && c && arg && dcl && alpha && beta && s > 0 && k > 0 && k % 4 == 0 &&
                   ldy % 4 == 0 && ldw % 4 == 0,
@@ -5751,6 +5851,7 @@ int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
 int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, const float *w,
                       int ldw, float *c, int ldc, const float *pa, const float *pb, float *part,
                       btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
   BTR_REQUIRE(x0 && w0 && w && c && pa && pb && k > 0 && k % 4 == 0 && ldw % 4 == 0 &&
                   k <= kMaxK,
@@ -5783,6 +5884,7 @@ int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, 
 int btr_sa_gemm_tn_rc(int rows, int n, int k, const float *g, int ldg, const float *x0,
                       const float *w0, const float *pa, const float *pb, float *pw, float *dw,
                       btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   if (n <= 0 || k <= 0) return BTR_OK;
   BTR_REQUIRE(g && x0 && w0 && pa && pb && pw && dw && ldg % 4 == 0 && n % 4 == 0 && k % 4 == 0,
               "sa_gemm_tn_rc: sizes must be multiples of 4 (n=%d k=%d)", n, k);
@@ -5987,6 +6089,7 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
                      const float *mu_p, const float *is_p, const float *wt, int ldw, float *dz,
                      int ldz, float *pw, float *dw, float *spart, float *m1, float *m2,
                      float *dgamma, float *dbeta, btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   BTR_REQUIRE(btr_sa_bwd_fused_supported(rows, n, k), "sa_bwd_fused: shape %d x %d x %d", rows, n,
               k);
   const bool pooled = arg != nullptr;
@@ -6099,6 +6202,7 @@ int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float
                     const float *alpha, const float *beta, float *dz, int ldz, float *pw,
                     float *dw, float *gscratch, float *spart, float *m1, float *m2,
                     float *dgamma, float *dbeta, btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   BTR_REQUIRE(btr_sa_bwd_gram_supported(rows, n, k), "sa_bwd_gram: shape %d x %d x %d", rows, n, k);
   BTR_REQUIRE(x && pa && pb && mu_p && is_p && w && wt && arg && dcl && alpha && beta && dz &&
                   pw && dw && gscratch && spart && m1 && m2 && dgamma && dbeta &&
@@ -6155,6 +6259,7 @@ int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float
 int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float *x, int ldx,
                    const float *pa, const float *pb, float *pw, float *dw,
                    btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   if (n <= 0 || k <= 0) return BTR_OK;
   BTR_REQUIRE(g && x && pw && dw && ldg % 4 == 0 && ldx % 4 == 0 && n % 4 == 0 && k % 4 == 0,
               "sa_gemm_tn: sizes must be multiples of 4 (n=%d k=%d)", n, k);
@@ -6182,6 +6287,7 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
                         const unsigned char *arg, const float *dcl, const float *alpha,
                         const float *beta, const float *x, int ldx, const float *pa,
                         const float *pb, float *pw, float *dw, btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   if (n <= 0 || k <= 0) return BTR_OK;
   BTR_REQUIRE(y && x && pw && dw && arg && dcl && alpha && beta && s > 0 && ldy % 4 == 0 &&
                   ldx % 4 == 0 && n % 4 == 0 && k % 4 == 0,
@@ -6516,6 +6622,7 @@ __global__ __launch_bounds__(256) void ppfl_assemble_kernel(int nl, int c, const
 int ppfl_forward(int b, int n, int m, int s, int nl, int rows, float inv_radius, const float *xyz,
                  const float *new_xyz, const int *idx, const float *P, const float *w0x, float *y0,
                  float *relx, float *part, int grid, hipStream_t st) {
+  GemmTrace trace_((hipStream_t)st);
   BTR_REQUIRE(xyz && new_xyz && idx && P && w0x && y0 && relx && part && nl % 4 == 0 && grid > 0,
               "ppfl_forward: bad arguments");
   PpflArgs a{};
@@ -6527,6 +6634,7 @@ int ppfl_forward(int b, int n, int m, int s, int nl, int rows, float inv_radius,
   return check_launch("ppfl_forward");
 }
 int ppfl_assemble(int nl, int c, const float *dwx, const float *dwf, float *dw, hipStream_t st) {
+  GemmTrace trace_((hipStream_t)st);
   hipLaunchKernelGGL(ppfl_assemble_kernel, dim3(cdiv(nl * (3 + c), 256)), dim3(256), 0, st, nl, c,
                      dwx, dwf, dw);
   return check_launch("ppfl_assemble");
@@ -6572,6 +6680,32 @@ int btr_pm_weight_planes(int n, int k, const float *w, int ldw, void *planes,
                      as_stream(stream), n, k, kp, w, ldw, (__bf16 *)planes);
   return check_launch("pm_weight_planes");
 }
+// Live timing of the GEMM family: between _begin and _end every GEMM-family entry point called on
+// this host thread is bracketed by a HIP event pair on its stream.  _end synchronises the device,
+// returns the summed milliseconds and the number of pairs, and closes the trace.
+void btr_gemm_trace_begin(void) {
+  GemmTraceState &st = gemm_trace_state();
+  std::lock_guard<std::mutex> lock(st.mu);
+  for (hipEvent_t e : st.ev) (void)hipEventDestroy(e);
+  st.ev.clear();
+  st.on.store(true);
+}
+int btr_gemm_trace_end(double *total_ms, int *pairs) {
+  GemmTraceState &st = gemm_trace_state();
+  st.on.store(false);
+  (void)hipDeviceSynchronize();
+  std::lock_guard<std::mutex> lock(st.mu);
+  double ms = 0.0;
+  for (size_t i = 0; i + 1 < st.ev.size(); i += 2) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, st.ev[i], st.ev[i + 1]) == hipSuccess) ms += t;
+  }
+  if (total_ms) *total_ms = ms;
+  if (pairs) *pairs = (int)(st.ev.size() / 2);
+  for (hipEvent_t e : st.ev) (void)hipEventDestroy(e);
+  st.ev.clear();
+  return BTR_OK;
+}
 int btr_pm_gemm_nt_sm_supported(int rows, int n, int k) {
   return pm_sm_rows(rows) && n > 0 && k > 0 && k % 4 == 0 && k <= 2 * kSmKC && k <= kMaxK;
 }
@@ -6580,6 +6714,7 @@ int btr_pm_gemm_nt_sm_supported(int rows, int n, int k) {
 int btr_pm_gemm_nt_sm(int rows, int n, int k, const float *a, int lda, const void *planes,
                       float *c, int ldc, const float *pa, const float *pb, float *part,
                       const float *bias, btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
   BTR_REQUIRE(btr_pm_gemm_nt_sm_supported(rows, n, k), "pm_gemm_nt_sm: shape %d x %d x %d", rows,
               n, k);
@@ -6618,6 +6753,7 @@ namespace btr {
 // sub-block of a wider matrix: row pitch kp, plane stride ps (elements); any k % 4 == 0
 int pm_gemm_nt_planes(int rows, int n, int k, const float *a, int lda, const void *planes, int kp,
                       long long ps, float *c, int ldc, const float *bias, hipStream_t s) {
+  GemmTrace trace_((hipStream_t)s);
   if (rows <= 0 || n <= 0) return BTR_OK;
   BTR_REQUIRE(a && planes && c && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
                   kp % 8 == 0 && ps % 8 == 0,
@@ -6641,6 +6777,7 @@ extern "C" {
 int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float *w, int ldw,
                    float *c, int ldc, const float *pa, const float *pb, float *part,
                    const float *bias, btr_stream_t stream) {
+  GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
   BTR_REQUIRE(a && w && c && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
               "pm_gemm_nt: k=%d lda=%d ldw=%d must be multiples of 4", k, lda, ldw);

@@ -151,6 +151,8 @@ _SIGNATURES = {
     "btr_gf_loss_part_floats": (_ci, [_ci, _ci, _ci]),
     "btr_gf_loss_fwd": (_ci, [_vp] * 21),
     "btr_gf_head_decode": (_ci, [_ci] * 4 + [_vp] + [ctypes.c_longlong] * 3 + [_vp] * 9),
+    "btr_gemm_trace_begin": (None, []),
+    "btr_gemm_trace_end": (_ci, [_vp, _vp]),
     "btr_gf_stack_sizeof": (ctypes.c_longlong, [_ci]),
     "btr_gf_stack_plan": (_ci, [_vp, _vp]),
     "btr_gf_stack_forward": (_ci, [_vp] * 21),

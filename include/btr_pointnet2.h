@@ -907,6 +907,16 @@ int btr_gf_head_decode(int b, int p, int nh, int ns, const float *out, long long
                        float *heading_residuals, float *size_residuals, float *pred_size,
                        float *query_pos, float *query_pos_t, btr_stream_t stream);
 
+/* ---- measurement hook: live time of the GEMM family (csrc/sa_mlp.hip) ---------------------------
+ * Between _begin and _end every entry point of the grouped-MLP GEMM family called on this host
+ * thread -- btr_sa_gemm_nt / _rc / _poolfwd / _pool, btr_sa_gemm_tn / _rc / _pool, btr_sa_bwd_fused,
+ * btr_sa_bwd_gram, btr_pm_gemm_nt / _sm, the per-point first layer and the batched split-K
+ * reductions, whether a script or one of the whole-layer calls issues them -- is bracketed by a HIP
+ * event pair on its own stream.  _end synchronises the device, returns the summed milliseconds
+ * and the number of pairs (bench.py subtracts an empty pair's cost per pair), and closes the trace. */
+void btr_gemm_trace_begin(void);
+int btr_gemm_trace_end(double *total_ms, int *pairs);
+
 /* ---- GroupFree3D: the decoder stack as one call per direction (csrc/gf_stack.hip) --------------
  * reference: detection/GroupFree3D/models/detector.py:161-219 -- the loop over the decoder layers
  *     query_pos -> self_posembed, key_pos -> cross_posembed (modules.py:50-65),

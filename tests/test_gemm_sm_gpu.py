@@ -88,3 +88,29 @@ def test_small_m_gemm_is_bit_reproducible_and_refuses_large_shapes(cuda):
     assert not _lib.btr_pm_gemm_nt_sm_supported(4097, 256, 256)     # rows
     assert not _lib.btr_pm_gemm_nt_sm_supported(4096, 256, 516)     # k > 512
     assert not _lib.btr_pm_gemm_nt_sm_supported(4096, 256, 130)     # k not a multiple of 4
+
+
+@pytest.mark.gpu
+def test_gemm_trace_brackets_the_family(cuda):
+    """btr_gemm_trace_begin / _end: event pairs around the family's entry points, on whatever
+    host path calls them (here: two direct calls; bench.py: the whole-layer calls)."""
+    import ctypes
+    lib = _ext._lib
+    a = torch.randn(4096, 128, device=cuda)
+    w = torch.randn(128, 128, device=cuda)
+    c = torch.empty(4096, 128, device=cuda)
+    st = _ext._stream(0)
+    lib.btr_gemm_trace_begin()
+    for _ in range(2):
+        _ext._call(lib.btr_pm_gemm_nt, 4096, 128, 128, _ext._p(a), 128, _ext._p(w), 128, _ext._p(c),
+                   128, None, None, None, None, st)
+    ms, pairs = ctypes.c_double(0.0), ctypes.c_int(0)
+    assert lib.btr_gemm_trace_end(ctypes.addressof(ms), ctypes.addressof(pairs)) == 0
+    assert pairs.value == 2 and 0.0 < ms.value < 5.0
+    # closed: nothing is recorded any more
+    _ext._call(lib.btr_pm_gemm_nt, 4096, 128, 128, _ext._p(a), 128, _ext._p(w), 128, _ext._p(c),
+               128, None, None, None, None, st)
+    lib.btr_gemm_trace_begin()
+    assert lib.btr_gemm_trace_end(ctypes.addressof(ms), ctypes.addressof(pairs)) == 0
+    assert pairs.value == 0
+    torch.testing.assert_close(c, a @ w.t(), rtol=1e-4, atol=1e-3)

@@ -75,8 +75,11 @@ def main():
         # (two products per launch) and all split-K reductions
         # ... and the streaming forward / input-gradient kernel (round 4; the first r04_f / r04_h
         # tables left it out: their 1.92 / 1.79 ms, 0.61 / 0.65 were 2.5 / 2.4 ms, 0.47 / 0.49)
+        # ... and round 5's members: the Gram-form backward with its helper launches, the small-M
+        # NT kernel, the per-point first layer
         us = total("gemm_nt_kernel") + total("gemm_tn_") + total("sa_bwd_fused_kernel") + \
-            total("sa_fwd_stream_kernel") + total("reduce_chunks")
+            total("sa_fwd_stream_kernel") + total("reduce_chunks") + total("sa_bwd_gram") + \
+            total("gram_") + total("gemm_nt_sm_kernel") + total("ppfl_")
         ach = mlp["gflop_per_step"] * 1e9 / (us * 1e-6) / 1e12
         out.append(("mlp_roofline", mlp["ms_per_step"] * 1e3, us, mlp["frac"],
                     ach / MFMA_F32_PEAK_TF))
