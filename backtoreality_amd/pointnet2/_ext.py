@@ -445,13 +445,17 @@ def timing_end():
     """Stop recording; returns {(op, shape-key): [ms per launch, ...]} (synchronises).
     An event pair recorded by `_call` around a launch reads the kernel's duration PLUS the
     distance two back-to-back markers have on the stream (a few microseconds: as much as the
-    shortest kernels take).  That distance is measured here -- the median of 32 empty pairs on
-    the same stream -- and subtracted from those entries (never below zero); pairs the library
+    shortest kernels take).  That distance is measured here -- the lower quartile of 32 empty pairs
+    queued behind a backlog on the same stream -- and subtracted from those entries (never below zero); pairs the library
     records itself right around one kernel (fps_kernel, ball query) are left as they are."""
     global _TIMING, PAIR_OVERHEAD_MS
     rec, _TIMING = _TIMING or [], None
     empty = []
     if rec and torch.cuda.is_available():
+        # behind a backlog (a ~0.5 ms spin kernel), so that the markers' distance on the stream is
+        # the GPU's and not the host's pace of issuing them: on a busy host two record() calls
+        # were 37 us apart and the "overhead" wiped out the kernels it was subtracted from
+        torch.cuda._sleep(1000000)
         for _ in range(32):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
@@ -459,7 +463,7 @@ def timing_end():
             empty.append((a, b))
     torch.cuda.synchronize()
     gaps = sorted(a.elapsed_time(b) for a, b in empty)
-    PAIR_OVERHEAD_MS = gaps[len(gaps) // 2] if gaps else 0.0
+    PAIR_OVERHEAD_MS = gaps[len(gaps) // 4] if gaps else 0.0   # lower quartile
     out = {}
     for item in rec:
         op, key, e0, e1 = item[:4]

@@ -5,6 +5,8 @@ python tools/bwd_gram_ab.py"""
 import os
 import sys
 
+os.environ.setdefault("BTR_POOL_GRAM", "2")   # every k <= 128 layer, not only the producer/consumer shapes
+
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

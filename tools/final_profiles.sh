@@ -19,6 +19,9 @@ python tools/gemm_tn_ab.py > $O/gemm_tn_ab.txt 2>&1
 python tools/gemm_nt_small_ab.py > $O/gemm_nt_small_ab.txt 2>&1
 python tools/bwd_fused_ab.py > $O/bwd_fused_ab.txt 2>&1
 python tools/fps_prefix_ab.py > $O/fps_prefix_ab.txt 2>&1
+python tools/bwd_gram_ab.py > $O/bwd_gram_ab.txt 2>&1
+python tools/fwd_ws_ab.py > $O/fwd_ws_ab.txt 2>&1
+python tools/gemm_sm_ab.py > $O/gemm_sm_ab.txt 2>&1
 bash tools/pmc_kernels.sh tools/bwd_fused_ab.py sa_bwd_fused > $O/fused_sq_counters.md 2>/dev/null
 # what the step's streams cost each other
 { python tools/fps_interference.py 2>&1 | tail -2

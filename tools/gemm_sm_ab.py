@@ -4,6 +4,8 @@ python tools/gemm_sm_ab.py"""
 import os
 import sys
 
+os.environ.setdefault("BTR_PM_SM_ROWS", "16384")   # the kernel beyond its default row limit too
+
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
