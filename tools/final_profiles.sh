@@ -9,12 +9,12 @@ bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 bash tools/profile_pipelined.sh ${TAG}_pipe > $O/profile_pipelined.log 2>&1
 bash tools/probe/gemm_pmc.sh > $O/gemm_sq_counters.txt 2>&1
 bash tools/profile_gf.sh ${TAG}_gf_eager GF_ARGS=--no-graph > $O/profile_gf_eager.log 2>&1
-bash tools/profile_gf.sh ${TAG}_gf_graph > $O/profile_gf_graph.log 2>&1
+bash tools/profile_gf.sh ${TAG}_gf_graph GF_ARGS=--graph > $O/profile_gf_graph.log 2>&1
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_steps20.json
 for wl in c5 br cr gf gfbr; do
   python bench.py --workload $wl 2>/dev/null | tail -1 > $O/bench_$wl.json
 done
-python bench.py --workload gf --no-graph 2>/dev/null | tail -1 > $O/bench_gf_eager.json
+python bench.py --workload gf --graph 2>/dev/null | tail -1 > $O/bench_gf_graph.json
 python tools/gemm_tn_ab.py > $O/gemm_tn_ab.txt 2>&1
 python tools/gemm_nt_small_ab.py > $O/gemm_nt_small_ab.txt 2>&1
 python tools/bwd_fused_ab.py > $O/bwd_fused_ab.txt 2>&1
@@ -34,7 +34,7 @@ bash tools/pmc_kernels.sh tools/bwd_fused_ab.py sa_bwd_fused > $O/fused_sq_count
 { bash tools/ab_env2.sh "BTR_FPS_LDS_KB" 2; bash tools/ab_side.sh; BENCH_ARGS= bash tools/ab_gridcus.sh "256 248" | tail -6; } > $O/streams_ab.txt 2>&1
 python -c "
 import json
-for f in ('bench','bench_steps20','bench_c5','bench_br','bench_cr','bench_gf','bench_gf_eager','bench_gfbr'):
+for f in ('bench','bench_steps20','bench_c5','bench_br','bench_cr','bench_gf','bench_gf_graph','bench_gfbr'):
     try:
         d = json.load(open('$O/%s.json' % f))
         print(f, round(d['value'], 1), d['unit'], round(d['ms_per_step'], 3), 'ms host', round(d['host_enqueue_ms_per_step'], 2), d.get('chain_paths'))

@@ -33,7 +33,7 @@ def main():
         q = r[3] if qcol else 0
         idle = max(0, s - last_end)
         idle_total += idle
-        short = re.sub(r"\(.*", "", n)
+        short = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", ""))
         short = short.replace("void ", "").replace("at::native::", "")[:90]
         out.append("%8.1f %8.1f %8.1f  %5s  %s" % ((s - t0) / 1e3, (e - s) / 1e3, idle / 1e3,
                                                    q, short))
