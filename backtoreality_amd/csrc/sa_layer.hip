@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepArgsT<ML> a) {
         wt[(size_t)c * np + r] = v;
       } else if (r < np && c < kin) {
         const int cc = c - pc;
-        w2[(size_t)np * pc + (size_t)r * 4 + cc] = cc < 3 ? w[(size_t)r * kraw + cc] : 0.f;
+        const float wx = cc < 3 ? w[(size_t)r * kraw + cc] : 0.f;
+        w2[(size_t)np * pc + (size_t)r * 4 + cc] = wx;
+        wt[(size_t)c * np + r] = wx;   // W_x^T: rows pc .. pc + 3 behind W_f^T (coordinate gradient)
       }
     } else if (r < np && c < kin) {
       w2[(size_t)r * kin + c] = v;
@@ -479,11 +481,16 @@ struct SaBwdScratch {
 
 // Per-point first layer (csrc/sa_mlp.hip ppfl_gather_add_kernel): W_f f_j once per point, the rows
 // gather it.  A function of the description and the plan only (the plan's buffer sizes, the
-// forward and the backward must agree): feature input of >= 32 channels, no coordinate gradients
-// (the levels behind SA1; the vote aggregation's xyz gradient keeps the row-wise form).
+// forward and the backward must agree): feature input of >= 32 channels (the levels behind SA1).
 inline bool sa_ppfl(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   return (d.options & BTR_SA_OPT_PPFL) && !p.recompute && d.layers >= 2 && d.use_xyz &&
-         d.c >= 32 && d.c % 4 == 0 && p.k0p == d.c + 4 && !d.need_dxyz && !d.need_dnew_xyz &&
+         d.c >= 32 && d.c % 4 == 0 && p.k0p == d.c + 4 &&
+         // (not with coordinate gradients: the vote aggregation in this form -- d rel = dY_0 W_x as
+         // one more 4-column product, the branch below -- is parity-green and NEUTRAL, 95 against
+         // 96 us for its first layer's backward, 29 against 33 forward: five more launches at the
+         // 7 - 10 us floor of 32 768-row kernels, profiles/r05_g_*; BTR_SA_OPT_PPFL_XYZ enables it)
+         (!(d.need_dxyz || d.need_dnew_xyz) ||
+          (!p.compact && (d.options & BTR_SA_OPT_PPFL_XYZ))) &&
          d.width[0] % 4 == 0 && d.width[0] <= 128 &&
          (!p.compact || d.n <= 8192);
 }
@@ -574,6 +581,12 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
 using namespace btr;
 
 extern "C" {
+
+// 1 when the layer computes its first layer per point (BTR_SA_OPT_PPFL and a covered shape): what
+// the forward / backward of this (description, plan) pair do -- for tests and logs
+int btr_sa_layer_ppfl(const btr_sa_layer_t *dp, const btr_sa_plan_t *p) {
+  return dp && p && sa_ppfl(*dp, *p) ? 1 : 0;
+}
 
 int btr_sa_layer_plan(const btr_sa_layer_t *dp, btr_sa_plan_t *p) {
   BTR_REQUIRE(dp && p, "sa_layer_plan: null pointer");
@@ -937,6 +950,7 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       float *S = at_f(scratch, sc.ppfl_s);
       float *dwx = at_f(scratch, sc.ppfl_dwx), *dwf = at_f(scratch, sc.ppfl_dwf);
       btr_stream_t ws = stream;
+      const int prev_done = last_done;
       if (side) {
         (void)hipEventRecord(side->ready[0], hmain);
         (void)hipStreamWaitEvent(side->s, side->ready[0], 0);
@@ -966,6 +980,18 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
                                nullptr, nullptr, nullptr, nullptr, stream));
         BTR_TRY(pm_out_add(d.b, d.n, d.c, d.c, dfeat_cl, nullptr, nullptr, 0, dfeat, nullptr,
                            dfeat_add, dfeat_add_bstride, hmain));
+      }
+      if (d.need_dxyz || d.need_dnew_xyz) {
+        // d rel (rows x 4) = dY_0 W_x, then the coordinate part of the row-wise scatter alone (the
+        // inverted lists are there: built with the sampling or by the scatter of S above)
+        float *drel = at_f(scratch, sc.g[flip]);
+        // (the other gradient buffer: a side-stream weight gradient may still be reading it)
+        if (side && prev_done >= 1) (void)hipStreamWaitEvent(hmain, side->done[prev_done], 0);
+        BTR_TRY(btr_sa_gemm_nt(R, 4, n0, dy, n0, at_f(saved, p.wt[0]) + (size_t)d.c * n0, n0, drel,
+                               4, nullptr, nullptr, nullptr, stream));
+        BTR_TRY(sa_scatter_ex(d.b, d.n, d.m, d.s, 0, 4, 1, d.radius_div, drel, idx, nullptr,
+                              d.need_dxyz ? dxyz : nullptr, d.need_dnew_xyz ? dnew_xyz : nullptr,
+                              ws2, sc.scat_bytes, kScatterReduce, hmain));
       }
       if (p.compact) btr_sac_bind(&cm);
       ppfl_done = fused_any = true;   // (partials written on the main stream: see the join)

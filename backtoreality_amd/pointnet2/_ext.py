@@ -133,6 +133,7 @@ _SIGNATURES = {
                                             ctypes.c_ulonglong, _vp, _vp]),
     # whole-layer entry points (csrc/sa_layer.hip): description + plan by address
     "btr_sa_layer_plan": (_ci, [_vp, _vp]),
+    "btr_sa_layer_ppfl": (_ci, [_vp, _vp]),
     "btr_sa_layer_forward": (_ci, [_vp] * 11),
     "btr_sa_layer_backward": (_ci, [_vp] * 12),
     "btr_pm_chain_plan": (_ci, [_vp, _vp]),
@@ -232,6 +233,7 @@ _vp8, _ci8, _cf8, _sz8 = _vp * 8, _ci * 8, _cf * 8, _sz * 8
 SA_OPT_COMPACT, SA_OPT_RECOMPUTE, SA_OPT_POOL_EPILOGUE, SA_OPT_POOL_GRAD = 1, 2, 4, 8
 SA_OPT_POOL_GRAM = 16
 SA_OPT_PPFL = 64
+SA_OPT_PPFL_XYZ = 128
 
 
 class SaLayer(ctypes.Structure):

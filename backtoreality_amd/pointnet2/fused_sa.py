@@ -435,6 +435,8 @@ def _sa_options():
     # per-point first layer (whole-layer / whole-backbone calls; BTR_SA_PPFL=0: row-wise)
     if os.environ.get("BTR_SA_PPFL", "1") != "0" and os.environ.get("BTR_GEMM", "") != "f32":
         o |= _ext.SA_OPT_PPFL
+        if os.environ.get("BTR_SA_PPFL_XYZ") == "1":   # (vote aggregation too: measured neutral)
+            o |= _ext.SA_OPT_PPFL_XYZ
     return o
 
 

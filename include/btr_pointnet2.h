@@ -610,11 +610,15 @@ enum {
   BTR_SA_OPT_POOL_GRAD = 8,     /* pooled gradient formed inside the GEMM operand staging        */
   BTR_SA_OPT_POOL_GRAM = 16,    /* pooled layer without its stored output (btr_sa_bwd_gram); the
                                    plan reports it as pool_grad == 2                              */
-  BTR_SA_OPT_PPFL = 64          /* per-point first layer: W_f f_j once per point instead of once
+  BTR_SA_OPT_PPFL = 64,         /* per-point first layer: W_f f_j once per point instead of once
                                    per (centre, neighbour) row, the gradients' feature parts as
                                    products over the points (levels with >= 32 feature channels
                                    and no coordinate gradient; csrc/sa_mlp.hip
                                    ppfl_gather_add_kernel)                                        */
+  BTR_SA_OPT_PPFL_XYZ = 128     /* ... also where coordinate gradients are asked for (the vote
+                                   aggregation; dense rows): d rel = dY_0 W_x as one more 4-column
+                                   product.  Measured neutral, so the Python layer leaves it off
+                                   unless BTR_SA_PPFL_XYZ=1                                       */
 };
 typedef struct {
   int b, n, m, s, c;            /* batch, points, centres, nsample, feature channels (may be 0)  */
@@ -651,6 +655,8 @@ typedef struct {
 } btr_sa_plan_t;
 
 int btr_sa_layer_plan(const btr_sa_layer_t *d, btr_sa_plan_t *plan);
+/* 1 when this (description, plan) runs its first layer per point (BTR_SA_OPT_PPFL, covered shape) */
+int btr_sa_layer_ppfl(const btr_sa_layer_t *d, const btr_sa_plan_t *plan);
 /* out (b, width[L-1], m); out_cl (b, m, width[L-1]); feats_cl (b, n, c) channel-last or NULL */
 int btr_sa_layer_forward(const btr_sa_layer_t *d, const btr_sa_plan_t *plan, const float *xyz,
                          const float *new_xyz, const float *feats_cl, const int *idx, float *out,

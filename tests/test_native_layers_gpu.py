@@ -135,12 +135,14 @@ def test_gram_form_equals_the_y_reading_form(cuda, monkeypatch, N, npoint, radiu
             assert rel < 2e-5, (k, rel)
 
 
-@pytest.mark.parametrize("N,npoint,radius,S,mlp,C", [
-    (4096, 1024, 0.4, 32, [128, 128, 128, 256], 128),    # SA2: compact rows
-    (2048, 512, 0.8, 16, [256, 128, 128, 256], 256),     # SA3 / SA4: dense rows of 16
-    (3000, 300, 0.5, 32, [64, 100, 128], 64),            # ragged, first layer of 100 columns
+@pytest.mark.parametrize("N,npoint,radius,S,mlp,C,xyz_grad", [
+    (4096, 1024, 0.4, 32, [128, 128, 128, 256], 128, False),    # SA2: compact rows
+    (2048, 512, 0.8, 16, [256, 128, 128, 256], 256, False),     # SA3 / SA4: dense rows of 16
+    (3000, 300, 0.5, 32, [64, 100, 128], 64, False),            # ragged, first layer of 100 columns
+    (1024, 256, 0.3, 16, [256, 128, 128, 128], 256, True),      # vote aggregation: xyz gradient
+    (1500, 200, 0.6, 8, [32, 64, 64], 32, True),                # xyz gradient, ragged
 ])
-def test_per_point_first_layer(cuda, monkeypatch, N, npoint, radius, S, mlp, C):
+def test_per_point_first_layer(cuda, monkeypatch, N, npoint, radius, S, mlp, C, xyz_grad):
     """BTR_SA_OPT_PPFL (W_f f_j once per point, the rows gather it; dW_f / dF as products over the
     points behind a per-point sum of dY_0) against the row-wise first layer: the same sums in
     another order -- outputs, BatchNorm buffers and every gradient to float32 rounding."""
@@ -157,9 +159,15 @@ def test_per_point_first_layer(cuda, monkeypatch, N, npoint, radius, S, mlp, C):
             layer.bn.bn.bias.uniform_(-0.3, 0.3)
     inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
     res = {}
+    monkeypatch.setenv("BTR_SA_PPFL_XYZ", "1")   # (the form with coordinate gradients: off by default)
     for flag in ("0", "1"):
         monkeypatch.setenv("BTR_SA_PPFL", flag)
-        res[flag] = _sa_run(copy.deepcopy(sa), xyz, feats, inds, False, True)
+        mod = copy.deepcopy(sa)
+        res[flag] = _sa_run(mod, xyz, feats, inds, xyz_grad, True)
+        import ctypes
+        took = [_ext._lib.btr_sa_layer_ppfl(ctypes.addressof(ent[0]), ctypes.addressof(ent[1]))
+                for ent in fused_sa._LAYER_CACHE.get(mod, {}).values()]
+        assert took == [int(flag)], (flag, took)   # (the variant that actually ran)
     for k, want in res["0"].items():
         got = res["1"][k]
         assert (want is None) == (got is None), k
@@ -238,6 +246,10 @@ def test_proposal_chain_call_equals_python_sequence(cuda, monkeypatch):
                                         cfg.mean_size_arr, 64, 'vote_fps').to(cuda)
     xyz = torch.rand(2, 512, 3, device=cuda) * 2
     feats = torch.randn(2, 256, 512, device=cuda) * 0.1
+
+    # (the per-point first layer of the vote aggregation exists in the whole-layer call only:
+    # test_per_point_first_layer compares it with the row-wise form)
+    monkeypatch.setenv("BTR_SA_PPFL", "0")
 
     def run(m):   # vote aggregation (SA layer with coordinate gradients) + the head chain
         x = xyz.clone().requires_grad_(True)
