@@ -23,6 +23,7 @@ python tools/bwd_gram_ab.py > $O/bwd_gram_ab.txt 2>&1
 python tools/fwd_ws_ab.py > $O/fwd_ws_ab.txt 2>&1
 python tools/gemm_sm_ab.py > $O/gemm_sm_ab.txt 2>&1
 bash tools/pmc_kernels.sh tools/bwd_fused_ab.py sa_bwd_fused > $O/fused_sq_counters.md 2>/dev/null
+bash tools/pmc_kernels.sh tools/bwd_gram_ab.py sa_bwd_gram > $O/gram_sq_counters.md 2>/dev/null
 # what the step's streams cost each other
 { python tools/fps_interference.py 2>&1 | tail -2
   for m in "8 0 2000" "8 1 2000" "8 2 2000"; do
