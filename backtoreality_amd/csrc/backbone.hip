@@ -176,26 +176,28 @@ SaGeom level_geom(const btr_backbone_plan_t &p, const void *geom, int l) {
 }
 
 struct BwdScratch {
-  size_t dx[kMaxLv], dk[kMaxLv], df[kMaxLv + 1], ti, layer, bytes;
+  size_t dx[kMaxLv], dk[kMaxLv], df[kMaxLv + 1], ti, bytes;
+  // every layer call its OWN scratch (not the largest one shared): the split-K partials of all
+  // weight gradients stay alive until the one reduction launch at the end of the call
+  size_t layer_fp[kMaxLv], layer_sa[kMaxLv];
   size_t ti_bytes;
 };
 BwdScratch bwd_scratch(const btr_backbone_t &d, const btr_backbone_plan_t &p) {
   BwdScratch s{};
   const Dims dm = dims_of(d);
   Bump b;
-  size_t ti = 0, layer = 0;
+  size_t ti = 0;
   for (int j = 0; j < d.fps; ++j) {
     const int u = fp_unknown(d, j), k = fp_known(d, j);
     s.dx[j] = b.floats((size_t)d.b * d.fp[j].c * dm.n[u]);
     s.dk[j] = b.floats((size_t)d.b * fp_known_c(d, dm, j) * dm.n[k]);
     ti = std::max(ti, ti_grad_workspace_bytes(d.b, dm.n[u], dm.n[k]));
-    layer = std::max(layer, p.fp[j].bwd_scratch_bytes);
   }
   for (int l = 1; l < d.levels; ++l) s.df[l] = b.floats((size_t)d.b * dm.c[l] * dm.n[l]);
-  for (int l = 0; l < d.levels; ++l) layer = std::max(layer, p.sa[l].bwd_scratch_bytes);
   s.ti_bytes = ti;
   s.ti = b.take(ti);
-  s.layer = b.take(layer);
+  for (int j = 0; j < d.fps; ++j) s.layer_fp[j] = b.take(p.fp[j].bwd_scratch_bytes);
+  for (int l = 0; l < d.levels; ++l) s.layer_sa[l] = b.take(p.sa[l].bwd_scratch_bytes);
   s.bytes = b.off;
   return s;
 }
@@ -518,7 +520,16 @@ int btr_backbone_backward(const btr_backbone_t *dp, const btr_backbone_plan_t *p
   const int L = d.levels, F = d.fps;
   hipStream_t st = as_stream(stream);
   const BwdScratch sc = bwd_scratch(d, p);
-  void *layer_scratch = (char *)scratch + sc.layer;
+  // ONE launch for the split-K reductions of every weight gradient of the call (the layer calls'
+  // own scopes nest into this one: was one launch per layer call, 6 - 9 per step)
+  // (BTR_REDUCE_DEFER=0: per layer call, as before)
+  static const bool defer = !(getenv("BTR_REDUCE_DEFER") && getenv("BTR_REDUCE_DEFER")[0] == '0');
+  if (defer) reduce_batch_begin();
+  struct Flush {
+    hipStream_t s;
+    bool on;
+    ~Flush() { if (on) reduce_batch_flush(s); }
+  } flush_all{st, defer};
   auto ext_sa = [&](int l) { return dout_sa ? dout_sa[l - 1] : nullptr; };   // level l = 1..L
   auto ext_fp = [&](int j) { return dout_fp ? dout_fp[j] : nullptr; };
   // which levels / modules receive a gradient at all (a level without one is skipped together
@@ -554,7 +565,7 @@ int btr_backbone_backward(const btr_backbone_t *dp, const btr_backbone_plan_t *p
     float *dx = at_f(scratch, sc.dx[j]);
     BTR_TRY(btr_pm_chain_backward(&d.fp[j], &p.fp[j], at_f(saved, p.s_fpx[j]), dout,
                                   (char *)saved + p.s_fp[j], grads + p.gr_fp[j], dx,
-                                  layer_scratch, stream));
+                                  (char *)scratch + sc.layer_fp[j], stream));
     // known level's share: scatter the interpolated channels back through the 3-NN lists
     BTR_TRY(ti_grad_lists(d.b, c1, dm.n[u], dm.n[k], dx, (long long)d.fp[j].c * dm.n[u],
                           at_i(geom, p.g_nn_idx[j]), at_f(geom, p.g_nn_w[j]),
@@ -617,8 +628,8 @@ int btr_backbone_backward(const btr_backbone_t *dp, const btr_backbone_plan_t *p
     const SaGeom sg = level_geom(p, geom, l - 1);
     BTR_TRY(sa_layer_backward_add(&s, &p.sa[l - 1], at_i(geom, p.g_idx[l - 1]),
                                   at_f(out, p.o_sa[l - 1]), dout, (char *)saved + p.s_sa[l - 1],
-                                  grads + p.gr_sa[l - 1], dfeat, nullptr, nullptr, layer_scratch,
-                                  add, add_bs, &sg, stream));
+                                  grads + p.gr_sa[l - 1], dfeat, nullptr, nullptr,
+                                  (char *)scratch + sc.layer_sa[l - 1], add, add_bs, &sg, stream));
   }
   return check_launch("backbone_backward");
 }

@@ -80,7 +80,6 @@ constexpr int kBnTickets = 8;  // tickets per statistics GEMM (column blocks of 
 int ppfl_forward(int b, int n, int m, int s, int nl, int rows, float inv_radius, const float *xyz,
                  const float *new_xyz, const int *idx, const float *P, const float *w0x, float *y0,
                  float *relx, float *part, int grid, hipStream_t st);
-int ppfl_assemble(int nl, int c, const float *dwx, const float *dwf, float *dw, hipStream_t st);
 // sa_layer.hip: one weight-preparation launch for the layer calls between _begin and _end (issued
 // twice by the caller: a collecting pass before _launch, the real pass after it)
 void prep_batch_begin();
@@ -145,7 +144,7 @@ hipEvent_t *bq_call_events();
 // this host thread are collected and issued as ONE launch by the flush, on `stream` (all of
 // them must have been issued on that stream, each with its own partials buffer)
 void reduce_batch_begin();
-void reduce_unpad_next(int kpad, int kout);
+void reduce_unpad_next(int kpad, int kout, int ldo = 0, int coff = 0);   // (ldo = 0: kout)
 void reduce_batch_flush(hipStream_t stream);
 
 // sa_mlp.hip: btr_sa_scatter / btr_sac_scatter split in two: the inverted neighbour lists only

@@ -476,7 +476,7 @@ struct SaFwdScratch {
 struct SaBwdScratch {
   size_t part, m1, m2, dcl, alpha, beta, pw[kMaxL], pw0, g[2], scat, dfeat_cl, gram, bytes;
   size_t scat_bytes;
-  size_t ppfl_s, ppfl_dwx, ppfl_dwf, ppfl_pw;   // per-point first layer: see sa_layer_backward_add
+  size_t ppfl_s, ppfl_pw;   // per-point first layer: see sa_layer_backward_add
 };
 
 // Per-point first layer (csrc/sa_mlp.hip ppfl_gather_add_kernel): W_f f_j once per point, the rows
@@ -567,8 +567,6 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   if (sa_ppfl(d, p)) {
     const int nl = d.width[0];
     s.ppfl_s = b.floats((size_t)d.b * d.n * nl);
-    s.ppfl_dwx = b.floats((size_t)nl * 4);
-    s.ppfl_dwf = b.floats((size_t)nl * d.c);
     s.ppfl_pw = b.floats((size_t)btr_sa_gemm_tn_chunks(d.b * d.n, nl, d.c) * nl * d.c);
   }
   s.bytes = b.off;
@@ -856,7 +854,6 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
   float *ylast = at_f(saved, p.y[L - 1]);
   const bool gram = p.pool_grad == 2;   // ylast = the arg-max rows' values (b, m, cl): ldy = 0
   const bool ppfl = sa_ppfl(d, p);
-  bool ppfl_done = false;
   if (p.pool_grad)
     BTR_TRY(btr_sa_pool_bwd_coef(d.b, d.m, d.s, cl, gram ? 0 : cl, ylast, dout, out, arg, stat(L - 1, 2),
                                  stat(L - 1, 3), stat(L - 1, 0), stat(L - 1, 1), part, m1, m2,
@@ -948,7 +945,6 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       const int n0 = d.width[0], np = d.b * d.n;
       float *relx = x0, *fcopy = x0 + (size_t)R * 4;
       float *S = at_f(scratch, sc.ppfl_s);
-      float *dwx = at_f(scratch, sc.ppfl_dwx), *dwf = at_f(scratch, sc.ppfl_dwf);
       btr_stream_t ws = stream;
       const int prev_done = last_done;
       if (side) {
@@ -956,8 +952,12 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
         (void)hipStreamWaitEvent(side->s, side->ready[0], 0);
         ws = (btr_stream_t)side->s;
       }
+      // (both halves of dW_0 (n0, 3 + c) = [dW_x | dW_f] leave their split-K reductions in the
+      // parameter's layout: was a launch of its own behind them, ppfl_assemble_kernel)
+      reduce_unpad_next(4, 3, 3 + d.c, 0);
       BTR_TRY(btr_sa_gemm_tn(R, n0, 4, dy, n0, relx, 4, nullptr, nullptr, at_f(scratch, sc.pw[0]),
-                             dwx, ws));
+                             grads + p.dw[0], ws));
+      reduce_unpad_next(0, 0);
       if (side) {
         (void)hipEventRecord(side->done[0], side->s);
         last_done = 0;
@@ -972,8 +972,10 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
         BTR_TRY(sa_scatter_ex(d.b, d.n, d.m, d.s, n0, n0, 0, d.radius_div, dy, idx, S, nullptr,
                               nullptr, ws2, sc.scat_bytes, mode, hmain));
       btr_sac_bind(nullptr);   // (products over the points: no compact rows)
+      reduce_unpad_next(d.c, d.c, 3 + d.c, 3);
       BTR_TRY(btr_sa_gemm_tn(np, n0, d.c, S, n0, fcopy, d.c, nullptr, nullptr,
-                             at_f(scratch, sc.ppfl_pw), dwf, stream));
+                             at_f(scratch, sc.ppfl_pw), grads + p.dw[0], stream));
+      reduce_unpad_next(0, 0);
       if (d.need_dfeat && dfeat) {
         float *dfeat_cl = at_f(scratch, sc.dfeat_cl);
         BTR_TRY(btr_pm_gemm_nt(np, d.c, n0, S, n0, at_f(saved, p.wt[0]), n0, dfeat_cl, d.c,
@@ -994,7 +996,7 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
                               ws2, sc.scat_bytes, kScatterReduce, hmain));
       }
       if (p.compact) btr_sac_bind(&cm);
-      ppfl_done = fused_any = true;   // (partials written on the main stream: see the join)
+      fused_any = true;   // (partials written on the main stream: see the join)
       break;
     }
     float *dw = grads + p.dw[l];
@@ -1093,9 +1095,6 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     (void)hipEventRecord(side->done[kMaxL], side->s);
     (void)hipStreamWaitEvent(hmain, side->done[kMaxL], 0);
   }
-  if (ppfl_done)   // dW_0 (n0, 3 + c) = [dW_x | dW_f], both final behind the reductions above
-    BTR_TRY(ppfl_assemble(d.width[0], d.c, at_f(scratch, sc.ppfl_dwx), at_f(scratch, sc.ppfl_dwf),
-                          grads + p.dw[0], hmain));
   return check_launch("sa_layer_backward");
 }
 

@@ -4432,7 +4432,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(int total, int chunk
 // split-K reductions are collected (reduce_batch) and issued once, behind the last GEMM -- one
 // launch per call instead of one per layer (25 -> 9 per training step).  Same summation order
 // per element as reduce_chunks_kernel<16, 16>.
-constexpr int kMaxReduceSeg = 12;
+constexpr int kMaxReduceSeg = 32;   // (a whole backbone backward: 12 + 4 layers, their first-layer halves)
 struct ReduceArgs {
   const float *pw[kMaxReduceSeg];
   float *dw[kMaxReduceSeg];
@@ -4441,6 +4441,10 @@ struct ReduceArgs {
   // columns are written as dense [.][kout] rows -- a first layer's weight gradient without the
   // zero columns its 4-aligned input width added (see reduce_unpad_next)
   int kpad[kMaxReduceSeg], kout[kMaxReduceSeg];
+  // ... written with row pitch ldo at column offset coff (default: ldo = kout, coff = 0): a
+  // gradient that is one column block of a wider parameter (the per-point first layer's dW_x /
+  // dW_f halves of dW_0) goes straight into the parameter's layout
+  int ldo[kMaxReduceSeg], coff[kMaxReduceSeg];
   int n;
 };
 __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) {
@@ -4449,11 +4453,12 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) 
   const float *pw = a.pw[0];
   float *dw = a.dw[0];
   int total = a.total[0], chunks = a.chunks[0], first = 0, kpad = a.kpad[0], kout = a.kout[0];
+  int ldo = a.ldo[0], coff = a.coff[0];
 #pragma unroll
   for (int i = 1; i < kMaxReduceSeg; ++i)
     if (i < a.n && (int)blockIdx.x >= a.first[i]) {
       pw = a.pw[i]; dw = a.dw[i]; total = a.total[i]; chunks = a.chunks[i]; first = a.first[i];
-      kpad = a.kpad[i]; kout = a.kout[i];
+      kpad = a.kpad[i]; kout = a.kout[i]; ldo = a.ldo[i]; coff = a.coff[i];
     }
   // 16 slices of the chunk axis x 16 threads of four consecutive elements: a slice reads 256
   // contiguous bytes per chunk (one element per thread read 64: SA2's 16 MB of partials took
@@ -4484,7 +4489,7 @@ __global__ __launch_bounds__(256) void reduce_chunks_multi_kernel(ReduceArgs a) 
       dw[at] = (float)s;
     } else {
       const int row = at / kpad, col = at - row * kpad;
-      if (col < kout) dw[(size_t)row * kout + col] = (float)s;
+      if (col < kout) dw[(size_t)row * ldo + coff + col] = (float)s;
     }
   }
 }
@@ -4533,7 +4538,8 @@ struct ReduceBatch {
   ReduceArgs args;
   ReduceArgs wide;   // (total = number of float4, first = 256-thread blocks)
   bool on = false;
-  int next_kpad = 0, next_kout = 0;   // reduce_unpad_next
+  int depth = 0;   // nested scopes: the outermost one launches (btr_backbone_backward around its layers)
+  int next_kpad = 0, next_kout = 0, next_ldo = 0, next_coff = 0;   // reduce_unpad_next
 };
 inline ReduceBatch &reduce_batch() {
   static thread_local ReduceBatch b;
@@ -4544,11 +4550,13 @@ inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *
                                  hipStream_t st) {
   ReduceBatch &b = reduce_batch();
   const int kpad = b.next_kpad, kout = b.next_kout;
-  b.next_kpad = b.next_kout = 0;
+  const int ldo = b.next_ldo ? b.next_ldo : kout, coff = b.next_coff;
+  b.next_kpad = b.next_kout = b.next_ldo = b.next_coff = 0;
   if (kpad != 0 && !(b.on && b.args.n < kMaxReduceSeg)) {   // a launch of its own
     ReduceArgs a{};
     a.pw[0] = pw; a.dw[0] = dw; a.total[0] = total; a.chunks[0] = chunks;
-    a.kpad[0] = kpad; a.kout[0] = kout; a.first[1] = cdiv(total, 64); a.n = 1;
+    a.kpad[0] = kpad; a.kout[0] = kout; a.ldo[0] = ldo; a.coff[0] = coff;
+    a.first[1] = cdiv(total, 64); a.n = 1;
     hipLaunchKernelGGL(reduce_chunks_multi_kernel, dim3(a.first[1]), dim3(256), 0, st, a);
     return;
   }
@@ -4575,6 +4583,8 @@ inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *
     a.chunks[a.n] = chunks;
     a.kpad[a.n] = kpad;
     a.kout[a.n] = kout;
+    a.ldo[a.n] = ldo;
+    a.coff[a.n] = coff;
     a.first[a.n + 1] = a.first[a.n] + cdiv(total, 64);
     ++a.n;
     return;
@@ -4588,21 +4598,25 @@ inline void reduce_chunks_launch(int total, int chunks, const float *pw, float *
 }
 // (internal.hpp) the NEXT split-K reduction issued on this host thread writes dense [.][kout] rows
 // from its [.][kpad] partials
-void reduce_unpad_next(int kpad, int kout) {
+void reduce_unpad_next(int kpad, int kout, int ldo, int coff) {
   ReduceBatch &b = reduce_batch();
   b.next_kpad = kpad;
   b.next_kout = kout;
+  b.next_ldo = ldo;
+  b.next_coff = coff;
 }
 // (internal.hpp) collect the split-K reductions issued on this host thread until the flush
 void reduce_batch_begin() {
   ReduceBatch &b = reduce_batch();
+  if (b.depth++ > 0) return;   // inside an outer scope: keep collecting into it
   b.on = true;
   b.args.n = b.wide.n = 0;
   b.args.first[0] = b.wide.first[0] = 0;
 }
 void reduce_batch_flush(hipStream_t st) {
-  GemmTrace trace_(st);   // (the second half of the family's split-K products)
   ReduceBatch &b = reduce_batch();
+  if (b.depth > 0 && --b.depth > 0) return;   // the outer scope's flush launches
+  GemmTrace trace_(st);   // (the second half of the family's split-K products)
   b.on = false;
   if (b.args.n > 0)
     hipLaunchKernelGGL(reduce_chunks_multi_kernel, dim3(b.args.first[b.args.n]), dim3(256), 0, st,
@@ -6607,16 +6621,6 @@ __global__ __launch_bounds__(256) void ppfl_gather_add_kernel(PpflArgs a, Compac
   }
 }
 
-// dW0 (nl, 3 + c) dense rows = [dW_x (nl, 4) without its pad | dW_f (nl, c)]
-__global__ __launch_bounds__(256) void ppfl_assemble_kernel(int nl, int c, const float *__restrict__ dwx,
-                                                            const float *__restrict__ dwf,
-                                                            float *__restrict__ dw) {
-  const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  const int kr = 3 + c;
-  if (e >= nl * kr) return;
-  const int n = e / kr, k = e - n * kr;
-  dw[e] = k < 3 ? dwx[(size_t)n * 4 + k] : dwf[(size_t)n * c + (k - 3)];
-}
 
 // (internal.hpp) Y0 / relx / part of a PPFL first layer; `grid` = rows of `part` = workgroups
 int ppfl_forward(int b, int n, int m, int s, int nl, int rows, float inv_radius, const float *xyz,
@@ -6632,12 +6636,6 @@ int ppfl_forward(int b, int n, int m, int s, int nl, int rows, float inv_radius,
   a.inv_radius = inv_radius;
   hipLaunchKernelGGL(ppfl_gather_add_kernel, dim3(grid), dim3(256), 0, st, a, cur_compact());
   return check_launch("ppfl_forward");
-}
-int ppfl_assemble(int nl, int c, const float *dwx, const float *dwf, float *dw, hipStream_t st) {
-  GemmTrace trace_((hipStream_t)st);
-  hipLaunchKernelGGL(ppfl_assemble_kernel, dim3(cdiv(nl * (3 + c), 256)), dim3(256), 0, st, nl, c,
-                     dwx, dwf, dw);
-  return check_launch("ppfl_assemble");
 }
 }  // namespace btr
 extern "C" {
