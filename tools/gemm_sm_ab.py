@@ -50,7 +50,7 @@ def case(rows, n, k, pro, stats):
     tn, to = timed(new), timed(old)
     gf = 2.0 * rows * n * k / 1e9
     print("rows %6d n %3d k %4d pro %d stats %d: small-M %6.1f us (%5.1f TF), 64-row tiles %6.1f us "
-          "(%5.1f TF)" % (rows, n, k, pro, stats, tn, gf / tn * 1e-3, to, gf / to * 1e-3))
+          "(%5.1f TF)" % (rows, n, k, pro, stats, tn, gf / tn * 1e3, to, gf / to * 1e3))
 
 
 if __name__ == "__main__":
