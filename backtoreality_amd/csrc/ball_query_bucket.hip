@@ -591,13 +591,14 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   }();
   // BTR_BQ_FORM=2: the second form (bqb_query2_kernel).  MEASURED SLOWER, not the default -- same
   // box, kernel time from the rocprofv3 trace over the four shapes of tools/bq_ab.py
-  // (profiles/r05_bq_form_ab.txt): first form 28.2 us; second form 34.6 us at its natural 159
-  // registers and three workgroups per CU, 39.2 us capped to 128 registers (79 spilled) and 34.4 us
-  // with six buckets per trip (47 spilled) at four per CU.  Fewer dependent trips per wave did not
-  // shorten the kernel, and neither did handing it the centres in Morton order (BQ_SORT=1 in the
-  // tool: 45.3 -> 44.7 us stand-alone): the r04 reading "bound by its chain of dependent L2 round
-  // trips" does not hold up -- at ~200 MB of bucket lines per launch the query moves ~7 TB/s out
-  // of the L2s, which is where the time is.
+  // (profiles/r05_bq_form_ab*.txt): first form 28.2 us; second form 34.6 us at its natural 159
+  // registers and three workgroups per CU, 31.1 - 32.6 us in three shapes that fit four per CU
+  // without spills; a third form with two centres' loads in one basic block 47 - 63 us; centres in
+  // Morton order no change; centres drawn from a per-scene counter 196 us (returning device-scope
+  // atomics serialise across XCDs).  Neither fewer dependent trips nor more loads in flight nor
+  // locality shorten the kernel, and it is far from the L1 / L2 rates (10.8 / 3.2 TB/s,
+  // profiles/r05_bq_l2.md): the SQ counters (profiles/r05_bq_counters.md: a wave active 24 % of
+  // its life, four waves per SIMD) read as instruction-issue bound -- DESIGN.md 0, row 5.
   static const int form = [] {
     const char *e = getenv("BTR_BQ_FORM");
     return e && e[0] == '2' ? 2 : 1;
