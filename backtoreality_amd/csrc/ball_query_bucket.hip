@@ -597,8 +597,8 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   // Morton order no change; centres drawn from a per-scene counter 196 us (returning device-scope
   // atomics serialise across XCDs).  Neither fewer dependent trips nor more loads in flight nor
   // locality shorten the kernel, and it is far from the L1 / L2 rates (10.8 / 3.2 TB/s,
-  // profiles/r05_bq_l2.md): the SQ counters (profiles/r05_bq_counters.md: a wave active 24 % of
-  // its life, four waves per SIMD) read as instruction-issue bound -- DESIGN.md 0, row 5.
+  // profiles/r05_bq_l2.md) and from the issue rate (0.16 instructions per SIMD-cycle); its time
+  // follows the number of vector-memory requests.  DESIGN.md 0, row 5 keeps the reading current.
   static const int form = [] {
     const char *e = getenv("BTR_BQ_FORM");
     return e && e[0] == '2' ? 2 : 1;
