@@ -198,8 +198,8 @@ int btr_gf_stack_plan(const btr_gf_stack_t *dp, btr_gf_stack_plan_t *p) {
   }
   p->saved_bytes = sv.off;
   p->grads_floats = g;
-  // forward scratch: the modules' own + the (b, e, p) output an embedding chain also writes
-  p->fwd_scratch_bytes = up(fs) + up(std::max(q, k) * sizeof(float));
+  // forward scratch: the modules' own (they run one after the other)
+  p->fwd_scratch_bytes = up(fs);
   p->bwd_scratch_bytes = bwd_scratch(d, *p).bytes;
   return BTR_OK;
 }
@@ -221,14 +221,6 @@ int btr_gf_stack_forward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *pp
   BTR_REQUIRE(!d.has_qpos || qpos0_t, "gf_stack_forward: the first query position is missing");
   BTR_REQUIRE(!d.has_kpos || key_xyz_t, "gf_stack_forward: the key position is missing");
   hipStream_t hs = as_stream(stream);
-  size_t fs = 0;
-  for (int i = 0; i < d.layers; ++i) {
-    fs = std::max(fs, p.layer[i].fwd_scratch_bytes);
-    fs = std::max(fs, p.head[i].fwd_scratch_bytes);
-    if (d.has_qpos) fs = std::max(fs, p.qpos[i].fwd_scratch_bytes);
-    if (d.has_kpos) fs = std::max(fs, p.kpos[i].fwd_scratch_bytes);
-  }
-  float *bcp_dummy = at_f(scratch, up(fs));
   const float *x = query_cl;
   const float *qpos_t = qpos0_t;
   const int L = d.layers;
@@ -239,12 +231,12 @@ int btr_gf_stack_forward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *pp
     float *qpos_cl = nullptr, *kpos_cl = nullptr;
     if (d.has_qpos) {
       qpos_cl = at_f(saved, p.s_qpos_cl[i]);
-      BTR_TRY(btr_pm_chain_forward(&d.qpos[i], &p.qpos[i], qpos_t, nullptr, bcp_dummy, qpos_cl,
+      BTR_TRY(btr_pm_chain_forward(&d.qpos[i], &p.qpos[i], qpos_t, nullptr, nullptr, qpos_cl,
                                    at_v(saved, p.s_qpos[i]), scratch, stream));
     }
     if (d.has_kpos) {
       kpos_cl = at_f(saved, p.s_kpos_cl[i]);
-      BTR_TRY(btr_pm_chain_forward(&d.kpos[i], &p.kpos[i], key_xyz_t, nullptr, bcp_dummy, kpos_cl,
+      BTR_TRY(btr_pm_chain_forward(&d.kpos[i], &p.kpos[i], key_xyz_t, nullptr, nullptr, kpos_cl,
                                    at_v(saved, p.s_kpos[i]), scratch, stream));
     }
     float *xo = at_f(saved, p.s_x[i]);

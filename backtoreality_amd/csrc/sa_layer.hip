@@ -1191,7 +1191,7 @@ int btr_pm_chain_plan(const btr_pm_chain_t *dp, btr_pm_plan_t *p) {
 int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, const float *x_bcn,
                          const float *x_cl, float *out, float *out_cl, void *saved,
                          void *scratch, btr_stream_t stream) {
-  BTR_REQUIRE(dp && pp && (x_bcn || x_cl) && out && saved && scratch,
+  BTR_REQUIRE(dp && pp && (x_bcn || x_cl) && (out || out_cl) && saved && scratch,
               "pm_chain_forward: null pointer");
   const btr_pm_chain_t &d = *dp;
   const btr_pm_plan_t &p = *pp;
@@ -1247,10 +1247,16 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
   }  // else: the caller keeps x_cl alive and hands it to the backward again
   int lda = k0;
   const float *pscale = nullptr, *pshift = nullptr;
+  // a caller that only wants the channel-last rows of a chain whose last layer is a bare
+  // convolution (out == NULL: the decoder stack's position embeddings) gets them from the last
+  // GEMM itself -- no layout launch behind it
+  const bool direct = !out && out_cl && !d.has_bn[L - 1] && p.np[L - 1] == d.width[L - 1];
+  BTR_REQUIRE(out || direct, "pm_chain_forward: out == NULL needs a bare last layer of a width "
+                              "that is a multiple of 4");
   for (int l = 0; l < L; ++l) {
     const int np = p.np[l], k = p.kin[l];
     const float *w2 = at_f(saved, p.w2[l]);
-    float *y = at_f(saved, p.y[l]);
+    float *y = (direct && l == L - 1) ? out_cl : at_f(saved, p.y[l]);
     if (d.has_bn[l]) {
       float *st = at_f(saved, p.stats[l]);
       // (a convolution bias in front of the BatchNorm is skipped: it only moves the running mean)
@@ -1277,8 +1283,9 @@ int btr_pm_chain_forward(const btr_pm_chain_t *dp, const btr_pm_plan_t *pp, cons
     A = y;
     lda = np;
   }
-  BTR_TRY(btr_pm_out(d.b, d.n, d.width[L - 1], p.np[L - 1], A, pscale, pshift, pscale ? 1 : 0,
-                     out, out_cl, stream));
+  if (!direct)
+    BTR_TRY(btr_pm_out(d.b, d.n, d.width[L - 1], p.np[L - 1], A, pscale, pshift, pscale ? 1 : 0,
+                       out, out_cl, stream));
   return check_launch("pm_chain_forward");
 }
 

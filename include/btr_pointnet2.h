@@ -697,7 +697,8 @@ typedef struct {
 
 int btr_pm_chain_plan(const btr_pm_chain_t *d, btr_pm_plan_t *plan);
 /* x_bcn (b, c, n) or, when the producer kept it, x_cl (b*n, c) (then x_bcn may be NULL);
- * out (b, width[L-1], n), out_cl (b*n, width[L-1]) */
+ * out (b, width[L-1], n), out_cl (b*n, width[L-1]); out may be NULL when the last layer is a bare
+ * convolution of a width that is a multiple of 4 (its GEMM then writes out_cl itself) */
 int btr_pm_chain_forward(const btr_pm_chain_t *d, const btr_pm_plan_t *plan, const float *x_bcn,
                          const float *x_cl, float *out, float *out_cl, void *saved,
                          void *scratch, btr_stream_t stream);
