@@ -5,7 +5,7 @@ set -e
 TAG=${1:-pipe}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/$TAG
-rocprofv3 --kernel-trace --stats -d /tmp/$TAG -o r -- python3 $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-sequential > /tmp/$TAG.json 2>/tmp/$TAG.err
+rocprofv3 --kernel-trace --stats -d /tmp/$TAG -o r -- python3 $GRAFT_REPO_ROOT/bench.py ${PIPE_ARGS:---steps 16 --warmup 3} --no-cpu-baseline --no-sequential > /tmp/$TAG.json 2>/tmp/$TAG.err
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 DB=$(find /tmp/$TAG -name "*.db" | head -1)
