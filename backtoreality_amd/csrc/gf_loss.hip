@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64) void gf_final_kernel(GfDims d, int blocks_per_s
     const float total = (float)d.b * (float)d.p;
     o[4] = npos / total;
     o[5] = 1.f - npos / total;
+    o[6] = o[3];   // the word the returned loss TENSOR lives on: `loss *= w` leaves o[3] alone
   }
 }
 

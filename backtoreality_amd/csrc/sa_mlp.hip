@@ -172,14 +172,35 @@ __device__ __forceinline__ float4 rc_y4(const float4 x, const float *__restrict_
 // its own stream around its launches (the outermost scope only: entry points call each other).
 // (Process-wide, not per thread: autograd runs the backward's calls on its own thread.  A scope is
 // "outermost" per thread.)
+// Work accounting (round 6): every entry point also declares the work of ITS launches --
+// flops and operand bytes per row and the row count -- so that the roofline figure divides the
+// work that was executed by the time it took (the Python-sequenced formulation the line used
+// to price has more products and more bytes than the native step: Gram form, per-point first
+// layers).  Compact rows: the row count is a device value (Compact::dims[0]); the outermost
+// scope copies it to a pinned host slot on its stream BEFORE its start event, _end reads it.
+struct GemmWork {
+  double flops_per_row, bytes_per_row, bytes_fixed;
+  int rows;   // the host's count (dense bound for compact rows)
+  int slot;   // pinned slot holding the device row count, -1: rows is exact
+};
 struct GemmTraceState {
   std::atomic<bool> on{false};
   std::mutex mu;
   std::vector<hipEvent_t> ev;   // pairs
+  std::vector<GemmWork> work;
+  int *pinned = nullptr;        // kGemmTraceSlots ints, hipHostMalloc
+  int nslot = 0;
+  double flops = 0.0, bytes = 0.0, dense_flops = 0.0;   // totals of the last closed trace
 };
+constexpr int kGemmTraceSlots = 8192;
 inline GemmTraceState &gemm_trace_state() {
   static GemmTraceState st;
   return st;
+}
+const int *trace_compact_dims();   // Compact::dims bound on this host thread (or nullptr)
+inline int &gemm_trace_slot() {
+  static thread_local int slot = -1;   // the outermost open scope's pinned slot
+  return slot;
 }
 struct GemmTrace {
   hipStream_t s;
@@ -190,6 +211,18 @@ struct GemmTrace {
     static thread_local int depth = 0;
     depth_ = &depth;
     if (depth++ == 0) {
+      gemm_trace_slot() = -1;
+      if (const int *dims = trace_compact_dims()) {
+        int slot = -1;
+        {
+          std::lock_guard<std::mutex> lock(st.mu);
+          if (st.pinned && st.nslot < kGemmTraceSlots) slot = st.nslot++;
+        }
+        if (slot >= 0 &&
+            hipMemcpyAsync(st.pinned + slot, dims, sizeof(int), hipMemcpyDeviceToHost, s) ==
+                hipSuccess)
+          gemm_trace_slot() = slot;
+      }
       hipEvent_t a, b;
       if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
         {
@@ -206,6 +239,16 @@ struct GemmTrace {
     if (!depth_) return;
     --*depth_;
     if (stop) (void)hipEventRecord(stop, s);
+  }
+  // the work of this entry point's own launches (entry points that only sequence others add
+  // nothing); compact: the launches take their row count from the bound compact description
+  void work(int rows, double flops_per_row, double bytes_per_row, double bytes_fixed,
+            bool compact) const {
+    if (!depth_) return;
+    GemmTraceState &st = gemm_trace_state();
+    const int slot = (compact && trace_compact_dims()) ? gemm_trace_slot() : -1;
+    std::lock_guard<std::mutex> lock(st.mu);
+    st.work.push_back(GemmWork{flops_per_row, bytes_per_row, bytes_fixed, rows, slot});
   }
   int *depth_ = nullptr;
 };
@@ -227,8 +270,15 @@ __device__ __forceinline__ float load_agent(const float *p) {
 }
 // true in every thread of the workgroup that took the last ticket of its column block
 __device__ __forceinline__ bool bn_ticket_last(const BnFin &fin, int *s_last) {
+  // The fence-free order below is outside the HIP memory model: it holds where stores are counted
+  // by vmcnt and sc1 stores write through (gfx9: validated on gfx942 / gfx950).  Any other target
+  // gets the full fences whatever fin.fence says.
+#if defined(__gfx942__) || defined(__gfx950__)
   if (fin.fence) __threadfence();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+  __threadfence();
+#endif
   __syncthreads();
   if (threadIdx.x == 0)
     *s_last = __hip_atomic_fetch_add(&fin.ticket[blockIdx.y], 1u, __ATOMIC_RELAXED,
@@ -5378,6 +5428,7 @@ inline HostCompact &host_compact() {
   return hc;
 }
 inline Compact cur_compact() { return host_compact().on ? host_compact().dev : Compact{}; }
+const int *trace_compact_dims() { return host_compact().on ? host_compact().dev.dims : nullptr; }
 
 
 // the BatchNorm finalisation armed for the next statistics GEMM of this host thread (internal.hpp)
@@ -5601,6 +5652,7 @@ int btr_sa_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
                    btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
+  trace_.work(rows, 2.0 * n * k, 4.0 * (k + (c ? n : 0)), 4.0 * n * k, true);
   BTR_REQUIRE(a && w && (c || part) && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt: k=%d lda=%d ldw=%d must be multiples of 4", k, lda, ldw);
   BTR_REQUIRE((pa == nullptr) == (pb == nullptr), "sa_gemm_nt: pa/pb must come together");
@@ -5658,6 +5710,9 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
                            unsigned char *aext, btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
+  // (+ the extrema: a value and a position byte per s-row block and column)
+  trace_.work(rows, 2.0 * n * k, 4.0 * (k + (c ? n : 0)) + 5.0 * n / (s > 0 ? s : 1),
+              4.0 * n * k, true);
   BTR_REQUIRE(a && w && part && pa && pb && gamma && gext && aext && k > 0 &&
                   k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt_poolfwd: null pointer or k=%d lda=%d ldw=%d not multiples of 4", k,
@@ -5809,6 +5864,7 @@ int btr_sa_gemm_nt_pool(int rows, int n, int k, const float *y, int ldy, const f
                         const float *alpha, const float *beta, btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
+  trace_.work(rows, 2.0 * n * k, 4.0 * (k + n), 4.0 * n * k, true);
   BTR_REQUIRE(y && w && c && arg && dcl && alpha && beta && s > 0 && k > 0 && k % 4 == 0 &&
                   ldy % 4 == 0 && ldw % 4 == 0,
               "sa_gemm_nt_pool: bad arguments (k=%d ldy=%d ldw=%d s=%d)", k, ldy, ldw, s);
@@ -5867,6 +5923,8 @@ int btr_sa_gemm_nt_rc(int rows, int n, int k, const float *x0, const float *w0, 
                       btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
+  // (the first layer rebuilt from the 4-column input row: 2 * 4 * k flops per row more)
+  trace_.work(rows, 2.0 * n * k + 8.0 * k, 16.0 + 4.0 * n, 4.0 * n * k, true);
   BTR_REQUIRE(x0 && w0 && w && c && pa && pb && k > 0 && k % 4 == 0 && ldw % 4 == 0 &&
                   k <= kMaxK,
               "sa_gemm_nt_rc: null pointer or k=%d ldw=%d not multiples of 4", k, ldw);
@@ -5900,6 +5958,7 @@ int btr_sa_gemm_tn_rc(int rows, int n, int k, const float *g, int ldg, const flo
                       btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   if (n <= 0 || k <= 0) return BTR_OK;
+  trace_.work(rows, 2.0 * n * k + 8.0 * k, 4.0 * n + 16.0, 4.0 * n * k, true);
   BTR_REQUIRE(g && x0 && w0 && pa && pb && pw && dw && ldg % 4 == 0 && n % 4 == 0 && k % 4 == 0,
               "sa_gemm_tn_rc: sizes must be multiples of 4 (n=%d k=%d)", n, k);
   hipStream_t st = as_stream(stream);
@@ -6107,6 +6166,10 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
   BTR_REQUIRE(btr_sa_bwd_fused_supported(rows, n, k), "sa_bwd_fused: shape %d x %d x %d", rows, n,
               k);
   const bool pooled = arg != nullptr;
+  // two products per row (weight gradient, input gradient); read: Y_l (pooled) or dZ_l and Y_l,
+  // X_{l-1} (or its 4-column source); written: dZ_{l-1}
+  trace_.work(rows, 4.0 * n * k, 4.0 * ((pooled ? n : 2 * n) + (w0 ? 4 : k) + k), 8.0 * n * k,
+              true);
   BTR_REQUIRE(g && x && pa && pb && mu_p && is_p && wt && dz && pw && dw && spart && m1 && m2 &&
                   dgamma && dbeta && ldg % 4 == 0 && ldw % 4 == 0 && ldz % 4 == 0 &&
                   (w0 || ldx % 4 == 0),
@@ -6184,6 +6247,7 @@ static bool gram_ws(int n, int k) {
   const char *e = getenv("BTR_GRAM_WS");
   return n <= 128 && k <= 64 && !(e && e[0] == '0');
 }
+static int gram_chunks(int rows, int n, int k);
 int btr_sa_bwd_gram_supported(int rows, int n, int k) {
   const char *e = getenv("BTR_POOL_GRAM");   // (read per call: the tests toggle it)
   const bool off = e && e[0] == '0';
@@ -6191,8 +6255,17 @@ int btr_sa_bwd_gram_supported(int rows, int n, int k) {
   // BTR_POOL_GRAM=2: every shape the single-role kernel covers as well (k <= 128) -- measured
   // equal to the Y_l-reading form there (tools/bwd_gram_ab.py), so only the forward's store is won
   const bool all = e && e[0] == '2';
-  return !off && btr_sa_bwd_fused_supported(rows, n, k) && k <= 128 && !fused_split(n) &&
-         (all || gram_ws(n, k));
+  if (off || !btr_sa_bwd_fused_supported(rows, n, k) || k > 128 || fused_split(n) ||
+      !(all || gram_ws(n, k)))
+    return 0;
+  // the producer / consumer kernel keeps a chunk's block -> group table in LDS: beyond
+  // kFusedMaxChunks * grid_rounds() chunks of 8 * kGramWsMaxBlocks rows the plan must keep the
+  // Y_l-reading form (the same arithmetic as the BTR_REQUIRE in btr_sa_bwd_gram)
+  if (gram_ws(n, k)) {
+    const int chunks = gram_chunks(rows, n, k);
+    if (cdiv(cdiv(rows, chunks), 32) * 32 > 8 * kGramWsMaxBlocks) return 0;
+  }
+  return 1;
 }
 static int gram_chunks(int rows, int n, int k) {
   const int per_cu = (n > 128 || k > 64 || gram_ws(n, k)) ? 1 : 2;
@@ -6218,6 +6291,8 @@ int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float
                     float *dgamma, float *dbeta, btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   BTR_REQUIRE(btr_sa_bwd_gram_supported(rows, n, k), "sa_bwd_gram: shape %d x %d x %d", rows, n, k);
+  // per row: x M (k x k) and the Gram update x x^T (k x k); X read, dZ written
+  trace_.work(rows, 4.0 * k * k, 8.0 * k, 8.0 * n * k, true);
   BTR_REQUIRE(x && pa && pb && mu_p && is_p && w && wt && arg && dcl && alpha && beta && dz &&
                   pw && dw && gscratch && spart && m1 && m2 && dgamma && dbeta &&
                   ldx % 4 == 0 && ldw % 4 == 0 && ldz % 4 == 0 && s > 0,
@@ -6275,6 +6350,7 @@ int btr_sa_gemm_tn(int rows, int n, int k, const float *g, int ldg, const float 
                    btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   if (n <= 0 || k <= 0) return BTR_OK;
+  trace_.work(rows, 2.0 * n * k, 4.0 * (n + k), 4.0 * n * k, true);
   BTR_REQUIRE(g && x && pw && dw && ldg % 4 == 0 && ldx % 4 == 0 && n % 4 == 0 && k % 4 == 0,
               "sa_gemm_tn: sizes must be multiples of 4 (n=%d k=%d)", n, k);
   hipStream_t st = as_stream(stream);
@@ -6303,6 +6379,7 @@ int btr_sa_gemm_tn_pool(int rows, int n, int k, const float *y, int ldy, int s,
                         const float *pb, float *pw, float *dw, btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   if (n <= 0 || k <= 0) return BTR_OK;
+  trace_.work(rows, 2.0 * n * k, 4.0 * (n + k), 4.0 * n * k, true);
   BTR_REQUIRE(y && x && pw && dw && arg && dcl && alpha && beta && s > 0 && ldy % 4 == 0 &&
                   ldx % 4 == 0 && n % 4 == 0 && k % 4 == 0,
               "sa_gemm_tn_pool: sizes must be multiples of 4 (n=%d k=%d)", n, k);
@@ -6627,6 +6704,9 @@ int ppfl_forward(int b, int n, int m, int s, int nl, int rows, float inv_radius,
                  const float *new_xyz, const int *idx, const float *P, const float *w0x, float *y0,
                  float *relx, float *part, int grid, hipStream_t st) {
   GemmTrace trace_((hipStream_t)st);
+  // (no matrix product of its own: the per-point product is a btr_pm_gemm_nt call; per row the
+  // coordinate part's 3 multiply-adds per channel; the gathered product row read, Y0 written)
+  trace_.work(rows, 6.0 * nl, 8.0 * nl + 16.0, 0.0, true);
   BTR_REQUIRE(xyz && new_xyz && idx && P && w0x && y0 && relx && part && nl % 4 == 0 && grid > 0,
               "ppfl_forward: bad arguments");
   PpflArgs a{};
@@ -6686,6 +6766,12 @@ void btr_gemm_trace_begin(void) {
   std::lock_guard<std::mutex> lock(st.mu);
   for (hipEvent_t e : st.ev) (void)hipEventDestroy(e);
   st.ev.clear();
+  st.work.clear();
+  st.nslot = 0;
+  if (!st.pinned &&
+      hipHostMalloc((void **)&st.pinned, kGemmTraceSlots * sizeof(int), hipHostMallocDefault) !=
+          hipSuccess)
+    st.pinned = nullptr;   // (rows then fall back to the host's dense bound)
   st.on.store(true);
 }
 int btr_gemm_trace_end(double *total_ms, int *pairs) {
@@ -6702,6 +6788,25 @@ int btr_gemm_trace_end(double *total_ms, int *pairs) {
   if (pairs) *pairs = (int)(st.ev.size() / 2);
   for (hipEvent_t e : st.ev) (void)hipEventDestroy(e);
   st.ev.clear();
+  st.flops = st.bytes = st.dense_flops = 0.0;
+  for (const GemmWork &w : st.work) {
+    const double rows = (w.slot >= 0 && st.pinned) ? (double)st.pinned[w.slot] : (double)w.rows;
+    st.flops += rows * w.flops_per_row;
+    st.bytes += rows * w.bytes_per_row + w.bytes_fixed;
+    st.dense_flops += (double)w.rows * w.flops_per_row;
+  }
+  st.work.clear();
+  return BTR_OK;
+}
+// Work of the launches the last closed trace bracketed: flops (2 per multiply-add of the matrix
+// products as executed), algorithmic operand bytes (every operand and result of a launch once),
+// and the flops at the host's row counts (the dense bound where rows are compact).
+int btr_gemm_trace_work(double *flops, double *bytes, double *dense_flops) {
+  GemmTraceState &st = gemm_trace_state();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (flops) *flops = st.flops;
+  if (bytes) *bytes = st.bytes;
+  if (dense_flops) *dense_flops = st.dense_flops;
   return BTR_OK;
 }
 int btr_pm_gemm_nt_sm_supported(int rows, int n, int k) {
@@ -6714,6 +6819,7 @@ int btr_pm_gemm_nt_sm(int rows, int n, int k, const float *a, int lda, const voi
                       const float *bias, btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
+  trace_.work(rows, 2.0 * n * k, 4.0 * (n + k), 6.0 * n * k, false);
   BTR_REQUIRE(btr_pm_gemm_nt_sm_supported(rows, n, k), "pm_gemm_nt_sm: shape %d x %d x %d", rows,
               n, k);
   BTR_REQUIRE(a && planes && c && lda % 4 == 0 && ldc % 4 == 0,
@@ -6753,6 +6859,7 @@ int pm_gemm_nt_planes(int rows, int n, int k, const float *a, int lda, const voi
                       long long ps, float *c, int ldc, const float *bias, hipStream_t s) {
   GemmTrace trace_((hipStream_t)s);
   if (rows <= 0 || n <= 0) return BTR_OK;
+  trace_.work(rows, 2.0 * n * k, 4.0 * (n + k), 6.0 * n * k, false);
   BTR_REQUIRE(a && planes && c && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldc % 4 == 0 &&
                   kp % 8 == 0 && ps % 8 == 0,
               "pm_gemm_nt_planes: bad arguments (%d x %d x %d)", rows, n, k);
@@ -6777,6 +6884,7 @@ int btr_pm_gemm_nt(int rows, int n, int k, const float *a, int lda, const float 
                    const float *bias, btr_stream_t stream) {
   GemmTrace trace_((hipStream_t)stream);
   if (rows <= 0 || n <= 0) return BTR_OK;
+  trace_.work(rows, 2.0 * n * k, 4.0 * (n + k), 4.0 * n * k, false);
   BTR_REQUIRE(a && w && c && k > 0 && k % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
               "pm_gemm_nt: k=%d lda=%d ldw=%d must be multiples of 4", k, lda, ldw);
   BTR_REQUIRE((pa == nullptr) == (pb == nullptr), "pm_gemm_nt: pa/pb must come together");

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(
     part[(size_t)b * kNSums + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
 }
 
-// stats[0..12] = loss, vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg,
+// stats[0..13] (13: a second copy of the total for the loss tensor) = loss, vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg,
 // sem_cls, box, pos_ratio, neg_ratio, obj_acc;  norm[0..3] = 1/(sum+1e-6) of label, mask,
 // boxmask, votemask.
 __global__ void loss_reduce_kernel(LossDims d, const float *__restrict__ part,
@@ -325,6 +325,7 @@ __global__ void loss_reduce_kernel(LossDims d, const float *__restrict__ part,
   stats[10] = s[S_LABEL] / total;
   stats[11] = s[S_MASK] / total - s[S_LABEL] / total;
   stats[12] = s[S_ACC] * nm;
+  stats[13] = stats[0];   // the word the returned loss TENSOR lives on: `loss *= w` leaves [0] alone
   norm[0] = nl; norm[1] = nm; norm[2] = nb; norm[3] = nv;
 }
 

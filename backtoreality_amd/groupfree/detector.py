@@ -202,6 +202,8 @@ class GroupFreeDetector_DA(GroupFreeDetector):
             nn.Conv1d(128, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
             nn.Conv1d(128, 1, 1))
 
+    _hook_last_only = True   # (declared beside the hook it describes: fused_stack._hook_last_only)
+
     def _after_decoder_layer(self, prefix, query, end_points):
         if prefix == 'last_':
             end_points[prefix + 'local_d_pred'] = torch.sigmoid(

@@ -89,7 +89,7 @@ class FusedHeadsLoss(Function):
         npos = torch.empty((B,), dtype=torch.float32, device=dev)
         part = torch.empty((_lib.btr_gf_loss_part_floats(B, P, H),), dtype=torch.float32,
                            device=dev)
-        stats = torch.empty((8 * H + 6,), dtype=torch.float32, device=dev)
+        stats = torch.empty((8 * H + 7,), dtype=torch.float32, device=dev)
         grads = torch.empty((H, B, C, P), dtype=torch.float32, device=dev)
         ptrs = (ctypes.c_void_p * H)(*[h.data_ptr() for h in heads])
         with _ext._on(heads[0]) as dv:
@@ -105,7 +105,7 @@ class FusedHeadsLoss(Function):
         # the total: a 0-dim tensor on the statistics vector's storage -- no copy launch, and a
         # base tensor (not an autograd view of `stats`), so `loss *= w` style code still works
         loss = torch.empty((), dtype=torch.float32, device=stats.device).set_(
-            stats.untyped_storage(), stats.storage_offset() + 8 * H + 3, (), ())
+            stats.untyped_storage(), stats.storage_offset() + 8 * H + 6, (), ())
         return loss, stats, label, assign
 
     @staticmethod

@@ -305,7 +305,7 @@ def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
     L = det.num_decoder_layers
     if not (enabled() and fused_mlp.enabled() and fused_mlp.native_enabled() and
             fused_decoder.enabled() and fused_decode.enabled() and
-            0 < L <= _ext.GF_MAX_DECODER_LAYERS and getattr(det, "_hook_last_only", False) and
+            0 < L <= _ext.GF_MAX_DECODER_LAYERS and _hook_last_only(det) and
             query.is_cuda and query.dtype == torch.float32 and key.dtype == torch.float32 and
             query.dim() == 3 and key.dim() == 3 and base_xyz.dtype == torch.float32):
         return _no("disabled, not CUDA f32, or an override of the layer hook")
@@ -345,6 +345,13 @@ def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
     specs = _specs(det, E, qd, kd)
     if specs is None:
         return _no("a chain is not covered")
+    # momentum=None (cumulative average) changes with num_batches_tracked every call, and the
+    # cached descriptor is only refreshed when a pointer moved: the module loop handles it
+    for row in specs:
+        for m, _ps in row:
+            for spec in (m or ()):
+                if spec["bn"] is not None and spec["bn"].momentum is None:
+                    return _no("BatchNorm with momentum=None")
     want_last = type(det)._after_decoder_layer is not _base_hook(det)
     key_ = (B, Pq, Pk, E, qd, kd, p, tuple(tuple(len(m) if m is not None else 0 for m, _ in row)
                                            for row in specs))
@@ -370,3 +377,15 @@ def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
 def _base_hook(det):
     from .detector import GroupFreeDetector
     return GroupFreeDetector._after_decoder_layer
+
+
+def _hook_last_only(det):
+    """May the layer hook be called for the last layer alone?  True for the base class's no-op
+    and for a class that overrides `_after_decoder_layer` AND declares `_hook_last_only = True`
+    in its own body: an inherited flag says nothing about a subclass's new hook (a hook that
+    acts on every layer would silently see the last one only)."""
+    for klass in type(det).__mro__:
+        if '_after_decoder_layer' in klass.__dict__:
+            return klass.__dict__['_after_decoder_layer'] is _base_hook(det) or \
+                klass.__dict__.get('_hook_last_only', False) is True
+    return False

@@ -154,6 +154,7 @@ _SIGNATURES = {
     "btr_gf_head_decode": (_ci, [_ci] * 4 + [_vp] + [ctypes.c_longlong] * 3 + [_vp] * 9),
     "btr_gemm_trace_begin": (None, []),
     "btr_gemm_trace_end": (_ci, [_vp, _vp]),
+    "btr_gemm_trace_work": (_ci, [_vp, _vp, _vp]),
     "btr_gf_stack_sizeof": (ctypes.c_longlong, [_ci]),
     "btr_gf_stack_plan": (_ci, [_vp, _vp]),
     "btr_gf_stack_forward": (_ci, [_vp] * 21),

@@ -76,7 +76,7 @@ class FusedVoteNetLoss(Function):
         k2c = torch.empty((B, K2), dtype=torch.int32, device=dev)
         vote_arg = torch.empty((B, S1), dtype=torch.int8, device=dev)
         part = torch.empty((B, 16), dtype=torch.float32, device=dev)
-        stats = torch.empty((13,), dtype=torch.float32, device=dev)
+        stats = torch.empty((14,), dtype=torch.float32, device=dev)
         norm = torch.empty((4,), dtype=torch.float32, device=dev)
         i2v = torch.empty((B, K2), dtype=torch.int32, device=dev) if vote_mode else None
         w8 = (ctypes.c_float * 8)(*weights)
@@ -92,13 +92,15 @@ class FusedVoteNetLoss(Function):
         ctx.save_for_backward(net, agg_xyz, vote_xyz, seed_xyz, seed_inds, mean_size, norm,
                               objectness_label, objectness_mask, object_assignment, j1c, k2c,
                               vote_arg, *labels)
-        # (the first word of the statistics vector, not a clone: one copy launch per step less.
+        # (a word of the statistics vector, not a clone: one copy launch per step less.
         # NOT an autograd view of `stats` either -- a view created inside a Function refuses
         # every in-place op (`loss *= w`); a 0-dim tensor set on the same storage is a base
-        # tensor autograd treats like any other output.  `stats` itself is returned
-        # non-differentiable below)
+        # tensor autograd treats like any other output.  It is the vector's LAST word, a second
+        # copy of the total the kernel writes for this purpose: autograd does not know the two
+        # alias, so an in-place edit of the loss must not reach the reported stats[0..12].
+        # `stats` itself is returned non-differentiable below)
         loss = torch.empty((), dtype=torch.float32, device=dev).set_(
-            stats.untyped_storage(), stats.storage_offset(), (), ())
+            stats.untyped_storage(), stats.storage_offset() + 13, (), ())
         ctx.mark_non_differentiable(stats, objectness_label, objectness_mask, object_assignment)
         # (no zero-filled gradients for the statistics / label outputs: four fill launches)
         ctx.set_materialize_grads(False)

@@ -459,8 +459,15 @@ def main():
         (eager_step or train_step)(ddp, opt_eager, batch, cfg)
     _ms, _pairs = _ct.c_double(0.0), _ct.c_int(0)
     _ext._lib.btr_gemm_trace_end(_ct.addressof(_ms), _ct.addressof(_pairs))
+    _fl, _by, _dfl = _ct.c_double(0.0), _ct.c_double(0.0), _ct.c_double(0.0)
+    _ext._lib.btr_gemm_trace_work(_ct.addressof(_fl), _ct.addressof(_by), _ct.addressof(_dfl))
     native_gemm = {"ms_per_step": max(_ms.value - _pairs.value * pair_overhead_ms, 0.0) /
-                   detail_steps, "pairs_per_step": _pairs.value / detail_steps}
+                   detail_steps, "pairs_per_step": _pairs.value / detail_steps,
+                   # the work of exactly these launches, declared by the entry points themselves
+                   # (csrc/sa_mlp.hip GemmTrace::work; compact layers at the device's row count)
+                   "flops_per_step": _fl.value / detail_steps,
+                   "bytes_per_step": _by.value / detail_steps,
+                   "dense_rows_flops_per_step": _dfl.value / detail_steps}
     # Secondary figure (never `value`): the same K steps strictly one after the other -- every
     # step waits for its own sampling pyramid (8 of 256 CUs for ~2.2 ms) before anything else.
     sequential = None
@@ -553,22 +560,48 @@ def main():
         out["chain_paths"] = chain_paths
         out.update(roofline_objects(kernels or detail, detail, detail_steps, pair_overhead_ms))
         mlp = out.get("mlp_roofline")
-        if mlp and native_gemm["ms_per_step"] > 0:
-            # frac / achieved / hbm_*: the family's ALGORITHMIC work (flops and bytes of the
-            # launches the plain formulation makes: the instrumented steps) over the time the
-            # family takes in the steps as they are timed (the library's own event pairs)
+        if mlp and native_gemm["ms_per_step"] > 0 and native_gemm["flops_per_step"] > 0:
+            # frac / achieved / hbm_*: the work the timed launches EXECUTE (flops and operand
+            # bytes each GEMM-family entry point declares for its own launches) over the time
+            # those launches take in steps issued as the timed region issues them (the library's
+            # own event pairs).  The Python-sequenced formulation -- more products and more
+            # bytes: no Gram form, no per-point first layer -- stays beside it as sequenced_*,
+            # and its flops over the native time as effective_frac (work the native step avoids
+            # counts there, never in frac).
+            t = native_gemm["ms_per_step"] * 1e-3
+            seq_flops = mlp["gflop_per_step"] * 1e9
             mlp["sequenced_ms_per_step"] = mlp["ms_per_step"]
             mlp["sequenced_frac"] = mlp["frac"]
-            scale = mlp["ms_per_step"] / native_gemm["ms_per_step"]
-            for key in ("achieved", "frac", "hbm_achieved_GBs", "hbm_frac",
-                        "dense_rows_equivalent_frac"):
-                mlp[key] *= scale
+            mlp["sequenced_gflop_per_step"] = mlp["gflop_per_step"]
+            mlp["sequenced_algorithmic_bytes_per_step"] = mlp["algorithmic_bytes_per_step"]
+            mlp["effective_frac"] = seq_flops / t / 1e12 / MFMA_F32_PEAK_TF
+            mlp["achieved"] = native_gemm["flops_per_step"] / t / 1e12
+            mlp["frac"] = mlp["achieved"] / MFMA_F32_PEAK_TF
+            mlp["gflop_per_step"] = native_gemm["flops_per_step"] / 1e9
+            mlp["algorithmic_bytes_per_step"] = native_gemm["bytes_per_step"]
+            mlp["hbm_achieved_GBs"] = native_gemm["bytes_per_step"] / t / 1e9
+            mlp["hbm_frac"] = mlp["hbm_achieved_GBs"] / HBM_PEAK_GBS
+            mlp["dense_rows_gflop_per_step"] = native_gemm["dense_rows_flops_per_step"] / 1e9
+            mlp["dense_rows_equivalent_frac"] = (native_gemm["dense_rows_flops_per_step"] / t
+                                                 / 1e12 / MFMA_F32_PEAK_TF)
+            # SURVEY 8(d)'s figure for this workload (every padded neighbour a row, the plain
+            # three products per layer): 259 GFLOP per 8-scene batch at config[1]
+            if RUN_SHAPE == {"workload": "fsb", "points": 40000, "batch": 8}:
+                mlp["survey_8d_gflop_per_step"] = 259.0
+                mlp["survey_8d_frac"] = 259.0e9 / t / 1e12 / MFMA_F32_PEAK_TF
             mlp["ms_per_step"] = native_gemm["ms_per_step"]
             mlp["event_pairs_per_step"] = native_gemm["pairs_per_step"]
             mlp["clock"] = ("HIP event pairs recorded by the library around every GEMM-family entry "
                             "point (btr_gemm_trace_*), on the launches' own streams, in steps issued "
-                            "as in the timed region; flops / bytes: the launches of the "
-                            "Python-sequenced formulation (sequenced_*)")
+                            "as in the timed region; flops / bytes: what those launches execute "
+                            "(btr_gemm_trace_work), not the Python-sequenced formulation's")
+        if "roofline" in out and "ball_query_roofline" in out:
+            # the second number BASELINE's metric names (% of HBM bandwidth on ball_query), inside
+            # the object the driver parses
+            bqr = out["ball_query_roofline"]
+            out["roofline"]["ball_query"] = {k: bqr[k] for k in
+                                             ("frac", "avg_ms", "attainable_frac", "achieved",
+                                              "algorithmic_bytes", "traffic", "kernel", "shape")}
         if seq_kernels and "roofline" in out:
             # the same kernel when nothing shares the chip with it (the sequential loop below)
             ts = [t for (op, key), v in seq_kernels.items() if op == "fps_kernel" for t in v]

@@ -438,8 +438,9 @@ int btr_sa_bn_relu_bwd_rc_apply(long long rows, int c, int ldg, const float *g, 
  *   heading_residual_label (b,k2), size_class_label (b,k2) i64, size_residual_label (b,k2,3),
  *   sem_cls_label (b,k2) i64, mean_size (ns,3).
  * Outputs: objectness_label (b,k) i64, objectness_mask (b,k) f32, object_assignment (b,k) i64;
- *   stats[13] = loss, vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg,
- *   sem_cls, box, pos_ratio, neg_ratio, obj_acc.  Kept for the backward: j1c (b,k) i32,
+ *   stats[14] = loss, vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg,
+ *   sem_cls, box, pos_ratio, neg_ratio, obj_acc, loss once more (a word a caller may hand out as
+ *   the loss tensor and edit in place without touching the reported entries).  Kept for the backward: j1c (b,k) i32,
  *   k2c (b,k2) i32, vote_arg (b,s1) i8, part (b,16) f32, norm (4) f32.
  * weights8 (HOST pointer): weights of (vote, objectness, center, heading_cls, heading_reg,
  *   size_cls, size_reg, sem_cls) in loss/10 -- get_loss: {1, .5, 1, .1, 1, .1, 1, .1}.
@@ -880,9 +881,10 @@ int btr_decoder_layer_backward(const btr_decoder_layer_t *d, const btr_decoder_p
  * base_xyz (b, p, 3); seed_inds (b, s1) / sample_inds (b, p) int32; labels as the GroupFree3D
  * loader provides them (i64 class labels, f32 residuals); mean_size (ns, 3).
  * w_obj / w_box / w_sem: 10 * coefficient / (num_decoder_layers + 1) (loss_helper.py:312-316).
- * Outputs: objectness_label / object_assignment (b, p) i64; stats[8 heads + 6]: per head
+ * Outputs: objectness_label / object_assignment (b, p) i64; stats[8 heads + 7]: per head
  * (objectness, centre, heading cls, heading reg, size cls, size reg, box, semantic) then (sum
- * objectness, sum box, sum semantic, weighted total, pos_ratio, neg_ratio);
+ * objectness, sum box, sum semantic, weighted total, pos_ratio, neg_ratio, the weighted total once
+ * more: the word a caller may hand out as the loss tensor and edit in place);
  * grads (heads, b, c, p): d(weighted total) / d heads[h].  npos_part: b floats,
  * part: btr_gf_loss_part_floats(b, p, heads) floats of scratch. */
 typedef struct {
@@ -923,6 +925,12 @@ int btr_gf_head_decode(int b, int p, int nh, int ns, const float *out, long long
  * and the number of pairs (bench.py subtracts an empty pair's cost per pair), and closes the trace. */
 void btr_gemm_trace_begin(void);
 int btr_gemm_trace_end(double *total_ms, int *pairs);
+/* Work of the launches the last closed trace bracketed, as EXECUTED: every entry point declares the
+ * flops (2 per multiply-add of its matrix products) and the operand bytes (each operand and result
+ * once) of its own launches; rows of compact layers are the device's count (copied to the host on
+ * the launch's stream in front of its event pair).  dense_flops: the same launches at the host's
+ * row bounds (every padded neighbour a row, as in the reference's formulation). */
+int btr_gemm_trace_work(double *flops, double *bytes, double *dense_flops);
 
 /* ---- GroupFree3D: the decoder stack as one call per direction (csrc/gf_stack.hip) --------------
  * reference: detection/GroupFree3D/models/detector.py:161-219 -- the loop over the decoder layers

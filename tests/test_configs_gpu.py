@@ -33,6 +33,61 @@ def _worst_grad_dev(g_f, g_u):
     return max(l2(n) for n in g_u if float(g_u[n].abs().max()) > 1e-4 * gmax)
 
 
+# the modules of VoteNet(_DA) in FORWARD order; a parameter outside all of them (proposal head,
+# discriminators on the aggregated features) is downstream of every max-pool
+_STAGES = ('backbone_net.sa1.', 'backbone_net.sa2.', 'backbone_net.sa3.', 'backbone_net.sa4.',
+           'backbone_net.fp1.', 'backbone_net.fp2.', 'vgen.', 'pnet.vote_aggregation.')
+_POOLED = (0, 1, 2, 3, 7)      # the stages that end in a max-pool over the samples of a group
+
+
+def _stage(name):
+    for i, prefix in enumerate(_STAGES):
+        if name.startswith(prefix):
+            return i
+    return len(_STAGES)
+
+
+def _flip_aware_grad_check(g_f, g_u, tol=1e-2, upstream_tol=0.1, max_flips=2):
+    """Gradient comparison of two correct float32 paths that states what ONE flipped max-pool
+    decision may move instead of loosening the bound for everybody (the structure of
+    test_c5_scenes_with_a_near_tie_state_the_bound_per_flip, for any pooled layer):
+      * a pool element within rounding of a tie between two neighbours may be resolved either
+        way; the forward does not move, the flipped channel's ROW of that pooled layer's weight
+        gradient does, and so does everything the backward reaches behind it (upstream);
+      * the most downstream pooled layer with moved rows is where the flip sits: at most
+        `max_flips` of its rows may exceed `tol` (relative to the largest row);
+      * every parameter the backward reaches BEFORE that pool keeps `tol` in relative L2 -- on
+        inputs without a flip that is every parameter;
+      * parameters upstream of the flip keep `upstream_tol` (4 % was measured for one flip).
+    Returns (stage of the flip or None, moved rows there)."""
+    gmax = max(float(g.abs().max()) for g in g_u.values())
+
+    def l2(n):
+        return float((g_f[n] - g_u[n]).norm() / (g_u[n].norm() + 1e-20))
+    live = [n for n in g_u if float(g_u[n].abs().max()) > 1e-4 * gmax]
+    flip_stage, moved = None, 0
+    for st in reversed(_POOLED):
+        names = [n for n in g_u if n.startswith(_STAGES[st]) and n.endswith('.conv.weight')]
+        if not names:
+            continue
+        last = sorted(names)[-1]    # mlp_module.layerK.conv.weight with the largest K: pooled
+        wf, wu = g_f[last].flatten(1), g_u[last].flatten(1)
+        row_dev = (wf - wu).norm(dim=1) / float(wu.norm(dim=1).max())
+        m = int((row_dev > tol).sum())
+        if m:
+            flip_stage, moved, flipped = st, m, last
+            break
+    report = sorted(((l2(n), n) for n in live), reverse=True)[:12]
+    assert moved <= max_flips, (flip_stage, moved, report)
+    for n in live:
+        st = _stage(n)
+        if flip_stage is None or st > flip_stage:
+            assert l2(n) < tol, (n, l2(n), flip_stage, report)
+        elif n != flipped:
+            assert l2(n) < upstream_tol, (n, l2(n), flip_stage, report)
+    return flip_stage, moved
+
+
 def _votenet_step(cfg, batch, dev, fused, monkeypatch, num_proposal=256, vote_inds=None):
     """`vote_inds`: proposals to aggregate around (PointnetSAModuleVotes' `inds` hook) instead
     of the layer's own FPS over the computed votes."""
@@ -146,24 +201,22 @@ def _votenet_br_step(cfg, batch_S, batch_T, dev, fused, monkeypatch, vote_inds=N
     return loss.detach(), eS, eT, grads
 
 
-@pytest.mark.parametrize("first,grad_tol", [(24, 5e-2), (0, 5e-2)])
-def test_c3_back_to_reality_full_size_step(cuda, monkeypatch, first, grad_tol):
+@pytest.mark.parametrize("first", [24, 0])
+def test_c3_back_to_reality_full_size_step(cuda, monkeypatch, first):
     """C3 (BASELINE configs[2]) at its full per-GPU size: source AND target batch of 8 x 40 000
     points through the same VoteNet_DA (models/votenet_DA.py:123-176), get_loss_DA, one backward
     -- the fused HIP path against the nine-op + torch composition with both branches' proposals
     pinned to the op-by-op run's (as test_c5_matterport_80k_points): every sampling index equal,
-    features / discriminator outputs / every loss term 1e-4, gradients in relative L2.
-    Scenes: sixteen 40 000-point scenes hold ~2.6 M max-pool decisions, and two correct f32
-    paths may resolve one that sits within rounding of a tie differently -- nothing in the forward
-    moves, every gradient upstream of that pool does (test_c5_scenes_with_a_near_tie...).
-    tools/diag_c3_grads.py over five seed pairs: worst parameter 0.0055 (seeds 24 / 100024),
-    0.011 - 0.023 for the others, spread evenly over the BatchNorm parameters of all four SA
-    levels -- the signature of one element flipped downstream, not of a layer that is off (a
-    wrong gradient path shows as O(1)).  Which pairs come out clean depends on the last bits of
-    the forward: the pair that was clean before the per-point first layer reordered a sum no
-    longer is.  Both pairs -- 24 / 100024 and bench.py's own BR batches 0 / 100000 -- are held to
-    5e-2 with the forward / loss bounds unchanged; the gradients' float32 accuracy itself is
-    bounded against float64 in test_parity_fullsize_gpu.py."""
+    features / discriminator outputs / every loss term 1e-4, gradients at 1e-2 in relative L2.
+    Sixteen 40 000-point scenes hold ~2.6 M max-pool decisions, and two correct f32 paths may
+    resolve one that sits within rounding of a tie differently (tools/diag_c3_grads.py: which
+    seed pairs come out clean depends on the last bits of the forward).  Round 5 answered that
+    with a 5e-2 bound for every parameter; now the bound stays 1e-2 and a flip is treated as
+    what it is (_flip_aware_grad_check): at most two rows of ONE pooled layer's weight gradient
+    may move, everything the backward reaches before that pool keeps 1e-2, only the parameters
+    behind it get the per-flip bound (0.1, measured 0.006 - 0.023) -- and without a flip every
+    parameter keeps 1e-2.  A gradient path that is off by a few per cent in a layer the flip
+    does not reach, or anywhere on a clean pair, fails."""
     cfg = config.scannet_md40()
     batch_S = synthetic.make_batch(first, 8, 40000, cfg, device=cuda)
     batch_T = synthetic.make_batch(100000 + first, 8, 40000, cfg, device=cuda)
@@ -184,11 +237,9 @@ def test_c3_back_to_reality_full_size_step(cuda, monkeypatch, first, grad_tol):
                 assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (tag, k, a, b)
     assert abs(float(loss_f) - float(loss_u)) / abs(float(loss_u)) < 1e-4
     assert set(g_f) == set(g_u)
-    worst = _worst_grad_dev(g_f, g_u)
-    gmax = max(float(g.abs().max()) for g in g_u.values())
-    devs = sorted(((float((g_f[n] - g_u[n]).norm() / (g_u[n].norm() + 1e-20)), n) for n in g_u
-                   if float(g_u[n].abs().max()) > 1e-4 * gmax), reverse=True)
-    assert worst < grad_tol, devs[:12]
+    stage, moved = _flip_aware_grad_check(g_f, g_u)
+    print("c3 pair %d: flipped pool stage %r, rows moved %d, worst %.4f"
+          % (first, stage, moved, _worst_grad_dev(g_f, g_u)))
 
 
 def test_c4_groupfree_backbone_50k_no_features(cuda, monkeypatch):
