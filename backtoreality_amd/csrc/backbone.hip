@@ -451,8 +451,8 @@ int btr_backbone_forward(const btr_backbone_t *dp, const btr_backbone_plan_t *pp
   const float *feats = d.c > 0 ? at_f(geom, p.g_feat) : nullptr;
   // ---- the weight preparation of all levels and modules as ONE launch: a collecting pass over
   // the same calls (they add their layers and return), then the launch, then the real pass
-  // (BTR_PREP_BATCH=0: every call preps itself, six launches)
-  static const bool prep_batched = !(getenv("BTR_PREP_BATCH") && getenv("BTR_PREP_BATCH")[0] == '0');
+  // (instead of six launches, one per call)
+  constexpr bool prep_batched = true;
   struct PrepScope {
     bool on;
     ~PrepScope() { if (on) prep_batch_end(); }
@@ -522,8 +522,7 @@ int btr_backbone_backward(const btr_backbone_t *dp, const btr_backbone_plan_t *p
   const BwdScratch sc = bwd_scratch(d, p);
   // ONE launch for the split-K reductions of every weight gradient of the call (the layer calls'
   // own scopes nest into this one: was one launch per layer call, 6 - 9 per step)
-  // (BTR_REDUCE_DEFER=0: per layer call, as before)
-  static const bool defer = !(getenv("BTR_REDUCE_DEFER") && getenv("BTR_REDUCE_DEFER")[0] == '0');
+  constexpr bool defer = true;
   if (defer) reduce_batch_begin();
   struct Flush {
     hipStream_t s;

@@ -33,8 +33,8 @@ namespace btr {
 constexpr int kSuper = 16;          // buckets per super-bucket
 constexpr int kMaxSupers = 128;     // super-buckets per scene the query kernel can hold
 constexpr int kBqbWaves = 4;
-// candidate buckets loaded per dependent round trip: template parameter kTrip (BTR_BQ_TRIP = 2 |
-// 4 | 8 for A/B; default 4)
+// candidate buckets loaded per dependent round trip: template parameter kTrip (4; 2 and 8 measured
+// the same)
 
 __device__ __forceinline__ float wave_min_f32(float v) {
 #pragma unroll
@@ -236,306 +236,16 @@ __global__ __launch_bounds__(kBqbWaves * 64) void bqb_query_kernel(
   }
 }
 
-// ---- second form of the query kernel: the same tests and the same bitmap, fewer dependent trips
-// The first form walks, per centre, box loads -> candidate loads (four buckets per trip) -> the
-// next four ..., one centre after the other: ~5 dependent L2 round trips per centre, four centres
-// per wave, plus a prologue in which 40 threads each read 16 boxes one after the other
-// (profiles/r04_bq_counters.md: 74 % of the wave-cycles parked in s_waitcnt).  Here
-//   * prologue: one box per thread and pass, all passes' loads issued before the first is used,
-//     the union over the 16 boxes of a super-bucket by shuffles inside its 16 lanes;
-//   * a wave takes its centres four at a time: the coordinates of all four (one trip), then the
-//     bucket boxes of up to eight near super-buckets of all four (one trip: sixteen 16-byte loads in
-//     flight per lane), the candidate masks of all four parked in LDS;
-//   * per centre the candidate buckets K at a time, the next trip -- the next centre's first one
-//     included -- issued before the current one is tested, so a trip's latency overlaps the LDS
-//     atomics and the index extraction of the one before.
-// Same hit set and the same output as the first form by construction (same box test, same point
-// test, same bitmap walk).  Selected by BTR_BQ_FORM=2; measured slower (see bq_bucket_launch).
-constexpr int kCentres = 4;     // centres of a wave whose box tests share a trip
-constexpr int kNear = 8;        // near super-buckets per centre handled in the batched trip
-struct CentreMeta {
-  float cx, cy, cz;
-  int sup[kNear];
-  unsigned long long cand[2];   // candidate buckets of supers sup[0..3] / sup[4..7] (bit = lane)
-  unsigned long long rest[2];   // near super-buckets beyond the first kNear (rare)
-};
-template <int K, int OCC>
-__global__ __launch_bounds__(kBqbWaves * 64, OCC) void bqb_query2_kernel(
-    int B, int n, int np, int nb, int nsup, int m, int nsample, int words, int twords,
-    float radius2, float cull2, const float *__restrict__ new_xyz,
-    const float *__restrict__ spts, const Box8 *__restrict__ boxes, unsigned box_epoch,
-    int *__restrict__ idx) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int stale;
-  __shared__ CentreMeta metas[kBqbWaves][kCentres];
-  Box8 *sb = reinterpret_cast<Box8 *>(smem);
-  unsigned *maps = reinterpret_cast<unsigned *>(smem + sizeof(Box8) * nsup);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bi = blockIdx.x % B;
-  const int chunk = blockIdx.x / B;
-  const int nchunks = gridDim.x / B;
-  unsigned *bm = maps + (size_t)wave * (words + twords);
-  unsigned *top = bm + words;
-  for (int w = lane; w < words + twords; w += 64) bm[w] = 0u;
-  if (threadIdx.x == 0) stale = 0;
-  __syncthreads();
-  const float *sp = spts + (size_t)bi * np * 4;
-  const Box8 *bx = boxes + (size_t)bi * nb;
-  const Box8 none = Box8{3.0e38f, 3.0e38f, 3.0e38f, 0.f, -3.0e38f, -3.0e38f, -3.0e38f, 0.f};
-  {  // ---- super-bucket boxes: thread -> bucket threadIdx.x + 256 p; 16 lanes = one super-bucket
-    constexpr int kPass = 4;   // passes whose loads are in flight together (1 024 buckets)
-    bool bad = false;
-    for (int p0 = 0; p0 * kBqbWaves * 64 < nb; p0 += kPass) {
-    Box8 q[kPass];
-#pragma unroll
-    for (int p = 0; p < kPass; ++p) {
-      const int b = (int)threadIdx.x + kBqbWaves * 64 * (p0 + p);
-      q[p] = b < nb ? bx[b] : none;
-    }
-#pragma unroll
-    for (int p = 0; p < kPass; ++p) {
-      const int b = (int)threadIdx.x + kBqbWaves * 64 * (p0 + p);
-      if (kBqbWaves * 64 * (p0 + p) >= nb) break;
-      Box8 a = q[p];
-      if (b < nb)
-        bad |= box_epoch != 0u && (__float_as_uint(a.p0) != box_epoch ||
-                                   __float_as_uint(a.p1) != box_stamp_pos(bi * nb + b));
-#pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) {
-        a.x0 = fminf(a.x0, __shfl_xor(a.x0, off));
-        a.y0 = fminf(a.y0, __shfl_xor(a.y0, off));
-        a.z0 = fminf(a.z0, __shfl_xor(a.z0, off));
-        a.x1 = fmaxf(a.x1, __shfl_xor(a.x1, off));
-        a.y1 = fmaxf(a.y1, __shfl_xor(a.y1, off));
-        a.z1 = fmaxf(a.z1, __shfl_xor(a.z1, off));
-      }
-      if ((lane & 15) == 0 && b / kSuper < nsup) sb[b / kSuper] = a;
-    }
-    }
-    if (bad) atomicOr(&stale, 1);
-  }
-  __syncthreads();
-  const bool trusted = stale == 0;
-  if (!trusted) {   // (as in the first form: bound every super-bucket by its own points)
-    for (int s = threadIdx.x; s < nsup; s += kBqbWaves * 64) {
-      Box8 a = none;
-      for (int t = 0; t < min(kSuper, nb - s * kSuper); ++t) {
-        const float *bp = sp + (size_t)(s * kSuper + t) * 256;
-        for (int i = 0; i < 64; ++i) {
-          if (__float_as_int(bp[192 + i]) < 0) continue;
-          a.x0 = fminf(a.x0, bp[i]); a.x1 = fmaxf(a.x1, bp[i]);
-          a.y0 = fminf(a.y0, bp[64 + i]); a.y1 = fmaxf(a.y1, bp[64 + i]);
-          a.z0 = fminf(a.z0, bp[128 + i]); a.z1 = fmaxf(a.z1, bp[128 + i]);
-        }
-      }
-      sb[s] = a;
-    }
-    __syncthreads();
-  }
-
-  CentreMeta *meta = metas[wave];
-  const int per = nchunks * kBqbWaves;
-  // one trip of candidate points: K buckets, four coalesced loads each
-  struct Trip {
-    float px[K], py[K], pz[K];
-    int pk[K];
-    unsigned onmask;
-  };
-  // pops up to K candidate buckets of centre `ci` off its masks c0 / c1 (wave-uniform values, in
-  // registers) and issues their loads
-  auto issue = [&](int ci, unsigned long long &c0, unsigned long long &c1, Trip &t) {
-    t.onmask = 0u;
-    int first = 0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      int bb = first;
-      if (c0) {
-        const int sl = __builtin_ctzll(c0);
-        c0 &= c0 - 1;
-        bb = meta[ci].sup[sl >> 4] * kSuper + (sl & 15);
-        t.onmask |= 1u << k;
-      } else if (c1) {
-        const int sl = __builtin_ctzll(c1);
-        c1 &= c1 - 1;
-        bb = meta[ci].sup[4 + (sl >> 4)] * kSuper + (sl & 15);
-        t.onmask |= 1u << k;
-      }
-      bb = __builtin_amdgcn_readfirstlane(bb);
-      if (k == 0) first = bb;   // (a valid bucket to read for the unused slots)
-      const float *pp = sp + (size_t)bb * 256 + lane;
-      t.px[k] = pp[0];
-      t.py[k] = pp[64];
-      t.pz[k] = pp[128];
-      t.pk[k] = __float_as_int(pp[192]);
-    }
-  };
-  auto test = [&](const Trip &t, float cx, float cy, float cz) {
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-      if (((t.onmask >> k) & 1u) && t.pk[k] >= 0 &&
-          sq3(cx - t.px[k], cy - t.py[k], cz - t.pz[k]) < radius2) {
-        atomicOr(&bm[t.pk[k] >> 5], 1u << (t.pk[k] & 31));
-        atomicOr(&top[t.pk[k] >> 10], 1u << ((t.pk[k] >> 5) & 31));
-      }
-  };
-
-  for (int j0 = chunk * kBqbWaves + wave; j0 < m; j0 += per * kCentres) {
-    // ---- the batch: coordinates of up to four centres (one trip) ...
-    float ccx[kCentres], ccy[kCentres], ccz[kCentres];
-    int nc = 0;
-#pragma unroll
-    for (int i = 0; i < kCentres; ++i) {
-      const int j = j0 + i * per;
-      ccx[i] = ccy[i] = ccz[i] = 0.f;
-      if (j < m) {
-        const float *c = new_xyz + ((size_t)bi * m + j) * 3;
-        ccx[i] = c[0]; ccy[i] = c[1]; ccz[i] = c[2];
-        nc = i + 1;
-      }
-    }
-    // ---- ... the near super-buckets of each (boxes in LDS), and the bucket boxes of the first
-    // eight of them, all centres' loads in flight together
-    Box8 qb[kCentres][2];
-    int myb[kCentres][2];
-#pragma unroll
-    for (int i = 0; i < kCentres; ++i) {
-      if (i >= nc) break;
-      const float cx = ccx[i], cy = ccy[i], cz = ccz[i];
-      unsigned long long sm0 = __ballot(lane < nsup && box_d2(sb[lane], cx, cy, cz) < cull2);
-      unsigned long long sm1 = 0ull;
-      if (nsup > 64)
-        sm1 = __ballot(lane + 64 < nsup && box_d2(sb[min(lane + 64, nsup - 1)], cx, cy, cz) < cull2);
-      int sup[kNear];
-#pragma unroll
-      for (int q = 0; q < kNear; ++q) {
-        sup[q] = -1;
-        if (sm0) {
-          sup[q] = __builtin_ctzll(sm0);
-          sm0 &= sm0 - 1;
-        } else if (sm1) {
-          sup[q] = 64 + __builtin_ctzll(sm1);
-          sm1 &= sm1 - 1;
-        }
-      }
-      // (every lane writes the same wave-uniform values: no lane depends on LDS that only another
-      // lane wrote, which the compiler's per-thread view of memory would not have to re-read)
-      meta[i].cx = cx; meta[i].cy = cy; meta[i].cz = cz;
-#pragma unroll
-      for (int q = 0; q < kNear; ++q) meta[i].sup[q] = sup[q];
-      meta[i].rest[0] = sm0;
-      meta[i].rest[1] = sm1;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        int mys = sup[r * 4];
-        mys = (lane >> 4) == 1 ? sup[r * 4 + 1] : mys;
-        mys = (lane >> 4) == 2 ? sup[r * 4 + 2] : mys;
-        mys = (lane >> 4) == 3 ? sup[r * 4 + 3] : mys;
-        const int b = mys * kSuper + (lane & 15);
-        myb[i][r] = (mys >= 0 && b < nb) ? b : -1;
-        qb[i][r] = none;
-        if (trusted && myb[i][r] >= 0) qb[i][r] = bx[b];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < kCentres; ++i) {
-      if (i >= nc) break;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const bool cand = myb[i][r] >= 0 &&
-                          (!trusted || box_d2(qb[i][r], ccx[i], ccy[i], ccz[i]) < cull2);
-        meta[i].cand[r] = __ballot(cand);
-      }
-    }
-    // ---- per centre: candidate trips (software-pipelined), bitmap, extraction
-    Trip ta, tb;   // (a centre's first trip is always in ta)
-    unsigned long long c0 = meta[0].cand[0], c1 = meta[0].cand[1];
-    issue(0, c0, c1, ta);
-    for (int i = 0; i < nc; ++i) {
-      const float cx = meta[i].cx, cy = meta[i].cy, cz = meta[i].cz;
-      while (true) {
-        bool more = (c0 | c1) != 0ull;
-        if (more) issue(i, c0, c1, tb);
-        test(ta, cx, cy, cz);
-        if (!more) break;
-        more = (c0 | c1) != 0ull;
-        if (more) issue(i, c0, c1, ta);
-        test(tb, cx, cy, cz);
-        if (!more) break;
-      }
-      // near super-buckets beyond the first eight: the plain loop of the first form
-      unsigned long long rest[2] = {meta[i].rest[0], meta[i].rest[1]};
-      for (int h = 0; h < 2; ++h) {
-        unsigned long long smask = rest[h];
-        while (smask) {
-          int sup[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            sup[q] = smask ? 64 * h + __builtin_ctzll(smask) : -1;
-            smask &= smask - 1;
-          }
-          const int mys = sup[lane >> 4];
-          const int b = mys * kSuper + (lane & 15);
-          const bool cand =
-              mys >= 0 && b < nb && (!trusted || box_d2(bx[b], cx, cy, cz) < cull2);
-          unsigned long long bmask = __ballot(cand);
-          while (bmask) {
-            const int sl = __builtin_ctzll(bmask);
-            bmask &= bmask - 1;
-            const int bb = __builtin_amdgcn_readlane(b, sl);
-            const float *pp = sp + (size_t)bb * 256 + lane;
-            const int pk = __float_as_int(pp[192]);
-            if (pk >= 0 && sq3(cx - pp[0], cy - pp[64], cz - pp[128]) < radius2) {
-              atomicOr(&bm[pk >> 5], 1u << (pk & 31));
-              atomicOr(&top[pk >> 10], 1u << ((pk >> 5) & 31));
-            }
-          }
-        }
-      }
-      if (i + 1 < nc) {   // the next centre's first trip, under the extraction
-        c0 = meta[i + 1].cand[0];
-        c1 = meta[i + 1].cand[1];
-        issue(i + 1, c0, c1, ta);
-      }
-      // ---- first nsample set bits in index order (as in the first form)
-      const int j = j0 + i * per;
-      int *row = idx + ((size_t)bi * m + j) * nsample;
-      int base = 0;
-      int first = 0x7fffffff;
-      for (int t0 = 0; t0 < twords; t0 += 64) {
-        const int t = t0 + lane;
-        unsigned tw = t < twords ? top[t] : 0u;
-        int cnt = 0;
-        for (unsigned v = tw; v; v &= v - 1) cnt += __builtin_popcount(bm[(t << 5) + __builtin_ctz(v)]);
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int u = __shfl_up(incl, o);
-          if (lane >= o) incl += u;
-        }
-        int pos = base + incl - cnt;
-        base += __builtin_amdgcn_readlane(incl, 63);
-        if (tw) top[t] = 0u;
-        while (tw) {
-          const int w = (t << 5) + __builtin_ctz(tw);
-          tw &= tw - 1;
-          unsigned v = bm[w];
-          bm[w] = 0u;
-          while (v) {
-            const int k = (w << 5) + __builtin_ctz(v);
-            v &= v - 1;
-            first = min(first, k);
-            if (pos < nsample) row[pos] = k;
-            ++pos;
-          }
-        }
-      }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) first = min(first, __shfl_xor(first, o));
-      const int fill = base == 0 ? 0 : first;
-      for (int l = min(base, nsample) + lane; l < nsample; l += 64) row[l] = fill;
-    }
-  }
-}
+// A second form of the query kernel (all prologue passes in flight, the box tests of four centres
+// in one trip, candidate buckets eight per trip with the next trip issued before the current one is
+// tested) produced the same output and was SLOWER: 34.6 us against 28.2 at its natural 159
+// registers, 31.1 - 32.6 us in three shapes that fit four workgroups per CU; a third form with two
+// centres' loads in one basic block 47 - 63 us; centres in Morton order no change; centres drawn
+// from a per-scene counter 196 us (returning device-scope atomics serialise across XCDs):
+// profiles/r05_bq_form_ab*.txt.  Neither fewer dependent trips nor more loads in flight nor
+// locality shorten the kernel, and it is far from the L1 / L2 rates (10.8 / 3.2 TB/s,
+// profiles/r05_bq_l2.md) and from the issue rate (0.16 instructions per SIMD-cycle); its time
+// follows the number of vector-memory requests.  The second form was removed in round 6.
 
 struct BqbPlan {
   int nb, np, nsup, words, twords;
@@ -584,29 +294,9 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
                        own);
     boxes = own;
   }
-  static const int trip = [] {
-    const char *e = getenv("BTR_BQ_TRIP");
-    const int v = e ? atoi(e) : 4;
-    return (v == 2 || v == 8) ? v : 4;
-  }();
-  // BTR_BQ_FORM=2: the second form (bqb_query2_kernel).  MEASURED SLOWER, not the default -- same
-  // box, kernel time from the rocprofv3 trace over the four shapes of tools/bq_ab.py
-  // (profiles/r05_bq_form_ab*.txt): first form 28.2 us; second form 34.6 us at its natural 159
-  // registers and three workgroups per CU, 31.1 - 32.6 us in three shapes that fit four per CU
-  // without spills; a third form with two centres' loads in one basic block 47 - 63 us; centres in
-  // Morton order no change; centres drawn from a per-scene counter 196 us (returning device-scope
-  // atomics serialise across XCDs).  Neither fewer dependent trips nor more loads in flight nor
-  // locality shorten the kernel, and it is far from the L1 / L2 rates (10.8 / 3.2 TB/s,
-  // profiles/r05_bq_l2.md) and from the issue rate (0.16 instructions per SIMD-cycle); its time
-  // follows the number of vector-memory requests.  DESIGN.md 0, row 5 keeps the reading current.
-  static const int form = [] {
-    const char *e = getenv("BTR_BQ_FORM");
-    return e && e[0] == '2' ? 2 : 1;
-  }();
-  const void *fn = form == 2   ? (const void *)bqb_query2_kernel<8, 3>
-                   : trip == 2 ? (const void *)bqb_query_kernel<2>
-                   : trip == 8 ? (const void *)bqb_query_kernel<8>
-                               : (const void *)bqb_query_kernel<4>;
+  // (candidate buckets per L2 trip: 2 / 4 / 8 measured 51 - 53 us per call in the loop at every
+  // width -- seven waves per SIMD already hide the trips; four it is)
+  const void *fn = (const void *)bqb_query_kernel<4>;
   static size_t lds_set[64] = {};   // (per device: the attribute belongs to the function on a device)
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -622,27 +312,16 @@ int bq_bucket_launch(int b, int n, int m, float radius, int nsample, const float
   // one round of resident workgroups: a workgroup's time is its waves' chains of dependent L2
   // round trips (~4.5 us per centre), so the 2 048 workgroups of the benchmark shape -- 1 792 fit
   // the chip at once (LDS: seven per CU) -- spent a second round on the last 256 of them
-  // (BTR_BQ_WGS_PER_CU overrides the LDS-derived count; 0: the old fixed 2 048)
-  static const int wgs_env = getenv("BTR_BQ_WGS_PER_CU") ? atoi(getenv("BTR_BQ_WGS_PER_CU")) : -1;
   const int by_lds = (int)std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(p.lds + 64, 1));
   // (at most four per CU: inside the training loop the query shares the chip with the step's
   // kernels and their LDS -- benchmark shape, in the loop: 87 us at seven per CU, 69 at four, 77 at
   // three; alone 43 / 45 / 51.  The Matterport-shaped scenes fit three: 56 -> 37 us in the loop)
-  const int per_cu = wgs_env > 0 ? wgs_env : std::min(by_lds, form == 2 ? 3 : 4);
-  const int budget = wgs_env == 0 ? 2048 : per_cu * cu_mask_avail_cus();
+  const int per_cu = std::min(by_lds, 4);
+  const int budget = per_cu * grid_cus();
   const int chunks = std::max(1, std::min(cdiv(m, kBqbWaves), budget / std::max(1, b)));
-  if (form == 2) {
-    hipLaunchKernelGGL((bqb_query2_kernel<8, 3>), dim3(chunks * b), dim3(kBqbWaves * 64), p.lds, s,
-                       b, n, p.np, p.nb, p.nsup, m, nsample, p.words, p.twords, radius2, cull2,
-                       new_xyz, spts, boxes, epoch, idx);
-    return check_launch("ball_query(buckets)");
-  }
-#define BTR_BQB(T)                                                                              \
-  hipLaunchKernelGGL(bqb_query_kernel<T>, dim3(chunks * b), dim3(kBqbWaves * 64), p.lds, s, b, n, \
-                     p.np, p.nb, p.nsup, m, nsample, p.words, p.twords, radius2, cull2, new_xyz, \
-                     spts, boxes, epoch, idx)
-  if (trip == 2) BTR_BQB(2); else if (trip == 8) BTR_BQB(8); else BTR_BQB(4);
-#undef BTR_BQB
+  hipLaunchKernelGGL(bqb_query_kernel<4>, dim3(chunks * b), dim3(kBqbWaves * 64), p.lds, s, b, n,
+                     p.np, p.nb, p.nsup, m, nsample, p.words, p.twords, radius2, cull2, new_xyz,
+                     spts, boxes, epoch, idx);
   return check_launch("ball_query(buckets)");
 }
 

@@ -21,7 +21,7 @@
 
 namespace btr {
 
-struct GridMeta {       // per scene, written by bq_grid_bbox_kernel
+struct GridMeta {       // per scene, written by bq_grid_build_kernel
   float mnx, mny, mnz;  // grid origin
   float inv_cs;         // 1 / cell size
   int gx, gy, gz;       // cells per axis
@@ -30,154 +30,20 @@ struct GridMeta {       // per scene, written by bq_grid_bbox_kernel
 
 constexpr int kMaxCells = 1 << 18;
 
-// One block per scene: bounding box -> grid geometry.  cell size = 1.001 * radius (a point that
-// passes the f32 distance test lies within +-1 cell of the centre's cell on every axis); if
-// that would need more than kMaxCells cells the cell size grows until it fits (still >= r).
-__global__ __launch_bounds__(1024) void bq_grid_bbox_kernel(int n, float radius,
-                                                            const float *__restrict__ xyz,
-                                                            GridMeta *__restrict__ meta) {
-  __shared__ float red[6][16];
-  const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  xyz += (size_t)bi * n * 3;
-  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int k = tid; k < n; k += 1024)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float v = xyz[k * 3 + a];
-      mn[a] = fminf(mn[a], v);
-      mx[a] = fmaxf(mx[a], v);
-    }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
-      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
-    }
-    if (lane == 0) {
-      red[a][wave] = mn[a];
-      red[3 + a][wave] = mx[a];
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) {
-      lo[a] = red[a][0];
-      hi[a] = red[3 + a][0];
-      for (int w = 1; w < 16; ++w) {
-        lo[a] = fminf(lo[a], red[a][w]);
-        hi[a] = fmaxf(hi[a], red[3 + a][w]);
-      }
-    }
-    float cs = radius * 1.001f;
-    if (!(cs > 0.f)) cs = 1.f;
-    int g[3];
-    for (int it = 0; it < 64; ++it) {
-      double cells = 1.0;
-      for (int a = 0; a < 3; ++a) {
-        const float e = fmaxf(hi[a] - lo[a], 0.f);
-        const double q = floor((double)e / (double)cs) + 1.0;
-        g[a] = q > 1.0e6 ? 1000000 : (int)q;
-        cells *= (double)g[a];
-      }
-      if (cells <= (double)kMaxCells) break;
-      cs *= 1.26f;  // ~2x fewer cells per step
-    }
-    GridMeta m;
-    m.mnx = lo[0]; m.mny = lo[1]; m.mnz = lo[2];
-    m.inv_cs = 1.0f / cs;
-    m.gx = g[0]; m.gy = g[1]; m.gz = g[2];
-    m.ncell = g[0] * g[1] * g[2];
-    meta[bi] = m;
-  }
-}
-
 __device__ __forceinline__ int cell_coord(float v, float mn, float inv_cs, int g) {
   const int c = (int)floorf((v - mn) * inv_cs);
   return min(max(c, 0), g - 1);
 }
 
-__global__ __launch_bounds__(256) void bq_grid_count_kernel(int n, const float *__restrict__ xyz,
-                                                            const GridMeta *__restrict__ meta,
-                                                            int *__restrict__ cell_cnt) {
-  const int bi = blockIdx.y;
-  const GridMeta m = meta[bi];
-  xyz += (size_t)bi * n * 3;
-  int *cnt = cell_cnt + (size_t)bi * (kMaxCells + 1);
-  for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
-    const int cx = cell_coord(xyz[k * 3 + 0], m.mnx, m.inv_cs, m.gx);
-    const int cy = cell_coord(xyz[k * 3 + 1], m.mny, m.inv_cs, m.gy);
-    const int cz = cell_coord(xyz[k * 3 + 2], m.mnz, m.inv_cs, m.gz);
-    atomicAdd(cnt + (cz * m.gy + cy) * m.gx + cx, 1);
-  }
-}
-
-// Exclusive scan of the cell counts of one scene (ncell <= kMaxCells); cursor = offsets.
-__global__ __launch_bounds__(1024) void bq_grid_scan_kernel(const GridMeta *__restrict__ meta,
-                                                            int *__restrict__ cell_off,
-                                                            int *__restrict__ cursor) {
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = meta[bi].ncell;
-  int *c = cell_off + (size_t)bi * (kMaxCells + 1);
-  int *cur = cursor + (size_t)bi * kMaxCells;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < N; base += 1024) {
-    const int i = base + tid;
-    const int v = i < N ? c[i] : 0;
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(incl, off);
-      if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int pre = carry_s;
-    for (int w = 0; w < wave; ++w) pre += wsum[w];
-    const int excl = pre + incl - v;
-    if (i < N) {
-      c[i] = excl;
-      cur[i] = excl;
-    }
-    __syncthreads();
-    if (tid == 1023) carry_s = excl + v;
-    __syncthreads();
-  }
-  if (tid == 0) c[N] = carry_s;
-}
-
-// sorted[pos] = {x, y, z, bits(original index)}
-__global__ __launch_bounds__(256) void bq_grid_fill_kernel(int n, const float *__restrict__ xyz,
-                                                           const GridMeta *__restrict__ meta,
-                                                           int *__restrict__ cursor,
-                                                           float4 *__restrict__ sorted) {
-  const int bi = blockIdx.y;
-  const GridMeta m = meta[bi];
-  xyz += (size_t)bi * n * 3;
-  int *cur = cursor + (size_t)bi * kMaxCells;
-  float4 *out = sorted + (size_t)bi * n;
-  for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
-    const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-    const int cx = cell_coord(x, m.mnx, m.inv_cs, m.gx);
-    const int cy = cell_coord(y, m.mny, m.inv_cs, m.gy);
-    const int cz = cell_coord(z, m.mnz, m.inv_cs, m.gz);
-    const int pos = atomicAdd(cur + (cz * m.gy + cy) * m.gx + cx, 1);
-    out[pos] = make_float4(x, y, z, __int_as_float(k));
-  }
-}
-
-// ---------------------------------------------------------------- fused grid build (default)
+// ------------------------------------------------------------------------- the grid build
 // One workgroup of 1024 threads per scene does the whole build -- bounding box, cell histogram,
 // exclusive scan, scatter -- with the histogram / cursors in LDS (the points stay in L2
 // between the three passes): one launch of ~35 us instead of memset + four launches of ~95 us
 // whose count / fill passes hammer global atomics.  The grid must fit the LDS table
 // (kLdsCells cells = 144 KB): the cell edge grows past 1.001 r until it does (a 12 x 12 x 3 m
 // scene at r = 0.2 ends up with 0.25 m cells), which only changes how many candidates a
-// centre tests, never the result.  BTR_BQ_BUILD=multi keeps the multi-launch build.
+// centre tests, never the result.  (The memset + four-launch build with global atomics it
+// replaced was removed in round 6.)
 constexpr int kLdsCells = 36864;
 
 // Visits every point of a scene from a 1024-thread workgroup, four consecutive points (three
@@ -399,7 +265,7 @@ __global__ __launch_bounds__(256) void bq_grid_query_kernel(
 }
 
 struct GridPlan {
-  size_t meta_b, cell_b, cursor_b, sorted_b;
+  size_t meta_b, cell_b, sorted_b;
   int words;
 };
 
@@ -407,7 +273,6 @@ static GridPlan grid_plan(int b, int n) {
   GridPlan p;
   p.meta_b = (sizeof(GridMeta) * b + 255) / 256 * 256;
   p.cell_b = sizeof(int) * (size_t)b * (kMaxCells + 1);
-  p.cursor_b = sizeof(int) * (size_t)b * kMaxCells;
   p.sorted_b = sizeof(float4) * (size_t)b * n;
   p.words = (n + 31) / 32;
   return p;
@@ -420,25 +285,20 @@ bool bq_grid_supported(int n, int m, int nsample) {
 
 size_t bq_grid_workspace_bytes(int b, int n) {
   const GridPlan p = grid_plan(b, n);
-  return p.meta_b + p.cell_b + p.cursor_b + p.sorted_b;
+  return p.meta_b + p.cell_b + p.sorted_b;
 }
 
 int bq_grid_launch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                    const float *xyz, int *idx, void *ws, size_t ws_bytes, hipStream_t s) {
   const GridPlan p = grid_plan(b, n);
-  BTR_REQUIRE(ws && ws_bytes >= p.meta_b + p.cell_b + p.cursor_b + p.sorted_b,
+  BTR_REQUIRE(ws && ws_bytes >= p.meta_b + p.cell_b + p.sorted_b,
               "ball_query: workspace too small for the grid path");
   char *base = (char *)ws;
   GridMeta *meta = (GridMeta *)base;
   int *cell_off = (int *)(base + p.meta_b);
-  int *cursor = (int *)(base + p.meta_b + p.cell_b);
-  float4 *sorted = (float4 *)(base + p.meta_b + p.cell_b + p.cursor_b);
+  float4 *sorted = (float4 *)(base + p.meta_b + p.cell_b);
   hipError_t e = hipSuccess;
-  static const bool multi = [] {
-    const char *v = getenv("BTR_BQ_BUILD");
-    return v && v[0] == 'm';
-  }();
-  if (!multi) {
+  {
     static bool attr_set = false;
     if (!attr_set) {
       e = hipFuncSetAttribute((const void *)bq_grid_build_kernel,
@@ -450,17 +310,6 @@ int bq_grid_launch(int b, int n, int m, float radius, int nsample, const float *
     }
     hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(1024), sizeof(int) * kLdsCells, s, n,
                        radius, xyz, meta, cell_off, sorted);
-  } else {
-    e = hipMemsetAsync(cell_off, 0, p.cell_b, s);
-    if (e != hipSuccess)
-      return fail((int)e, "ball_query(grid) memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(bq_grid_bbox_kernel, dim3(b), dim3(1024), 0, s, n, radius, xyz, meta);
-    const int gn = std::min(cdiv(n, 256), 256);
-    hipLaunchKernelGGL(bq_grid_count_kernel, dim3(gn, b), dim3(256), 0, s, n, xyz, meta,
-                       cell_off);
-    hipLaunchKernelGGL(bq_grid_scan_kernel, dim3(b), dim3(1024), 0, s, meta, cell_off, cursor);
-    hipLaunchKernelGGL(bq_grid_fill_kernel, dim3(gn, b), dim3(256), 0, s, n, xyz, meta, cursor,
-                       sorted);
   }
   const size_t lds = sizeof(unsigned) * (size_t)p.words * 4;
   static size_t lds_set = 0;

@@ -53,8 +53,7 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {  // <= 10 bits -> ever
 // neighbours, so a bucket (64 consecutive points) never straddles one of the Z curve's jumps
 // and its bounding box is tighter -- 9.6 instead of 13.1 buckets pass the box test per sample
 // (2.63 -> 2.25 ms on 8 x 40000 -> 2048).  The order only affects speed, never the result (see
-// the header).  BTR_FPS_CURVE=morton: Z order.
-__device__ bool g_fps_morton = false;
+// the header).
 
 __device__ __forceinline__ int hilbert3(unsigned x0, unsigned x1, unsigned x2, int bits) {
   unsigned X[3] = {x0, x1, x2};
@@ -88,7 +87,6 @@ __device__ __forceinline__ int morton_cell(float x, float y, float z, float mnx,
   const int qx = min(top, max(0, (int)((x - mnx) * scale)));
   const int qy = min(top, max(0, (int)((y - mny) * scale)));
   const int qz = min(top, max(0, (int)((z - mnz) * scale)));
-  if (g_fps_morton) return (int)(spread3(qx) | (spread3(qy) << 1) | (spread3(qz) << 2));
   return hilbert3((unsigned)qx, (unsigned)qy, (unsigned)qz, bits);
 }
 
@@ -105,11 +103,12 @@ __device__ __forceinline__ float4 soa_point(const float *sp, size_t pos) {
 }
 
 // The counting sort: output spts = the bucket-SoA points {x, y, z, bits(original index)}
-// (read-only from here on; index -1 for padding) and tmin[np] = 1e10 (competing) or -1
-// (skipped by the |p|^2 <= 1e-3 rule, or padding), np = 64 * ceil(n / 64), both in curve order.
-// The min-dists live in their OWN array: the per-bucket write-back is then 2 full 128-B lines
-// instead of 64 dwords strewn over 8 lines -- with 16 waves doing it the strided form costs
-// ~1050 cycles per dependent bucket load, the contiguous one ~490 (tools/probe/lat_probe.hip).
+// (read-only from here on; index -1 for padding), np = 64 * ceil(n / 64), in curve order.
+// The running min-dists are the sampling kernel's own business (round 6: it derives their
+// initial values from the points and keeps them in LDS; the tail that does not fit lives in a
+// separate global array -- separate because a per-bucket write-back is then 2 full 128-B lines
+// instead of 64 dwords strewn over 8 lines: ~490 against ~1050 cycles per dependent bucket load
+// with 16 waves doing it, tools/probe/lat_probe.hip).
 // MANY workgroups per scene (a one-workgroup version streamed the scene three times through
 // a single CU: 157 us on 8 x 40000, all of it on the step's critical path).  meta[b] = 6 order-preserving uint keys (max of ~key(min), max of
 // key(max)) accumulated with integer atomics; cells[b][32768] = histogram -> exclusive scan
@@ -213,32 +212,28 @@ __global__ __launch_bounds__(kSortThreads) void fps_sortm_scan_kernel(int *__res
 
 __global__ __launch_bounds__(256) void fps_sortm_scatter_kernel(
     int n, int np, const float *__restrict__ dataset, const unsigned *__restrict__ meta,
-    int *__restrict__ cells, float4 *__restrict__ spts, float *__restrict__ tmin) {
+    int *__restrict__ cells, float4 *__restrict__ spts) {
   const int bi = blockIdx.y;
   dataset += (size_t)bi * n * 3;
   float *sp = (float *)(spts + (size_t)bi * np);
-  tmin += (size_t)bi * np;
   const SortBox bx = sort_box(meta + (size_t)bi * 8);
   for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
     const float x = dataset[k * 3], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2];
     const int c = morton_cell(x, y, z, bx.mnx, bx.mny, bx.mnz, bx.scale);
     const int pos = atomicAdd(&cells[(size_t)bi * kCells + c], 1);
-    const float mag = sq3(x, y, z);
     sp[soa_at(pos, 0)] = x;
     sp[soa_at(pos, 1)] = y;
     sp[soa_at(pos, 2)] = z;
     sp[soa_at(pos, 3)] = __int_as_float(k);
-    tmin[pos] = ((double)mag <= 1e-3) ? -1.f : 1e10f;  // sampling_gpu.cu:105-106
   }
-  // padding of the last bucket: index -1 (kept out of the bucket's bounding box), tmin < 0
-  // (never competes); the coordinates only have to be finite
+  // padding of the last bucket: index -1 (kept out of the bucket's bounding box; never
+  // competes); the coordinates only have to be finite
   if (blockIdx.x == 0 && n + (int)threadIdx.x < np) {
     const int pos = n + threadIdx.x;
     sp[soa_at(pos, 0)] = dataset[0];
     sp[soa_at(pos, 1)] = dataset[1];
     sp[soa_at(pos, 2)] = dataset[2];
     sp[soa_at(pos, 3)] = __int_as_float(-1);
-    tmin[pos] = -1.f;
   }
 }
 
@@ -274,6 +269,21 @@ __device__ __forceinline__ float rl_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// Initial min-dist of a point: 1e10 when it competes, -1 when the reference skips it (|p|^2 <= 1e-3
+// in double against the f32 magnitude, sampling_gpu.cu:105-106) or when it is padding (k < 0).
+__device__ __forceinline__ float fps_tmin0(float x, float y, float z, int k) {
+  return (k < 0 || (double)sq3(x, y, z) <= 1e-3) ? -1.f : 1e10f;
+}
+
+// The running min-dists of the first `lds_pts` points (curve order) live in dynamic LDS: the launch
+// already asked for >= 128 KB it never touched (a CU reservation by resource, see
+// fps_bucket_launch); with the min-dists there a touched bucket is three coordinate lines + the
+// index line from L2, one conflict-free LDS read and, where a min-dist changes, one LDS write --
+// no min-dist load, no write-back through L2 (the counters had the kernel at 2.4 x its algorithmic
+// bytes: min-dist lines written back again and again).  A 40 000-point scene fits whole (160 000
+// B of the CU's 163 840); points beyond lds_pts keep theirs in the global array `tmin`.
+extern __shared__ float fps_ltmin[];
+
 // One workgroup of NW waves per scene.  Every lane keeps the state of SL buckets: bucket b
 // lives in wave b % NW, lane (b / NW) % 64, slot b / (64 NW) (neighbouring buckets go to
 // different waves: the few buckets a late sample touches update in parallel -- each update is
@@ -288,7 +298,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
                                                              int *__restrict__ idxs,
                                                              unsigned long long *dbg = nullptr,
                                                              Box8 *__restrict__ boxes = nullptr,
-                                                             unsigned box_epoch = 0u) {
+                                                             unsigned box_epoch = 0u,
+                                                             int lds_pts = 0) {
   // PROF: s_memtime phase counters (tuning builds only; BTR_FPS_PROF=1 in tools/)
   unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, nact = 0, nuse = 0, nchg = 0;
 #define BTR_PH(i)                                                  \
@@ -299,10 +310,9 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
   }
   __shared__ BSlot slots[2][NW];
 
-  // latency chain: issue ahead of co-resident streaming waves -- unless the caller hides this
-  // kernel under other work anyway (box_epoch's top bit: see fps_bucket_launch, BTR_FPS_PRIO)
-  if (!(box_epoch & 0x80000000u)) __builtin_amdgcn_s_setprio(3);
-  box_epoch &= 0x7fffffffu;
+  // latency chain: issue ahead of co-resident streaming waves (without it 4.73 -> 4.77 ms per
+  // step in round 4: no reason to make it optional)
+  __builtin_amdgcn_s_setprio(3);
   const int bi = blockIdx.x;
   dataset += (size_t)bi * n * 3;
   spts += (size_t)bi * np;
@@ -314,6 +324,17 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
   const TieParams tp{bs, log2bs, (n + bs - 1) >> log2bs};
 
   const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
+  const int lds_bkts = __builtin_amdgcn_readfirstlane(lds_pts >> 6);  // buckets with LDS min-dists
+
+  // ---- initial min-dists, derived from the points (coalesced pass over the bucket-SoA array;
+  // it also pulls the scene into L2 for the per-lane box pass below)
+  for (int p = tid; p < np; p += NW * 64) {
+    const float *bp = (const float *)spts + (size_t)(p >> 6) * 256 + (p & 63);
+    const float t = fps_tmin0(bp[0], bp[64], bp[128], __float_as_int(bp[192]));
+    if ((p >> 6) < lds_bkts) fps_ltmin[p] = t;
+    else tmin[p] = t;
+  }
+  __syncthreads();   // (also orders the global tail's stores before the owner waves' loads)
 
   // ---- per-slot bucket state (registers; every loop over s is fully unrolled)
   float bx0[SL], by0[SL], bz0[SL], bx1[SL], by1[SL], bz1[SL];  // bounding box
@@ -329,17 +350,17 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
     mx[s] = my[s] = mz[s] = 0.f;
     if (myb < nb) {
       const float *bp = (const float *)spts + (size_t)myb * 256;
-      const float *tm = tmin + (size_t)myb * 64;
       float ax0 = bp[0], ax1 = ax0, ay0 = bp[64], ay1 = ay0, az0 = bp[128], az1 = az0;
-      bool any = tm[0] >= 0.f;
+      bool any = fps_tmin0(ax0, ay0, az0, __float_as_int(bp[192])) >= 0.f;
 #pragma unroll 8
       for (int i = 1; i < 64; ++i) {
-        if (__float_as_int(bp[192 + i]) < 0) continue;  // padding slot: not in the box
+        const int qk = __float_as_int(bp[192 + i]);
+        if (qk < 0) continue;  // padding slot: not in the box
         const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
         ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
         ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
         az0 = fminf(az0, qz); az1 = fmaxf(az1, qz);
-        any |= tm[i] >= 0.f;
+        any |= fps_tmin0(qx, qy, qz, qk) >= 0.f;
       }
       bx0[s] = ax0; bx1[s] = ax1; by0[s] = ay0; by1[s] = ay1; bz0[s] = az0; bz1[s] = az1;
       mhi[s] = any ? __float_as_uint(1e10f) + 1u : 0u;  // competing points start at 1e10
@@ -390,15 +411,17 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
       // runs under the first load's L2 latency.
       // (two register sets A/B, loop unrolled by two: loop-carried copies of the prefetched
       // registers would force the wait for the loads to the top of the loop)
+      // (the bucket index is wave-uniform: LDS or global min-dists is a scalar branch)
       auto fetch = [&](int b, size_t &o, float4 &p, float &t) {
-        const size_t bkt = (size_t)((s * 64 + b) * NW + wave);
-        const float *bp = (const float *)spts + bkt * 256 + lane;
-        o = bkt * 64 + lane;
+        const int bkt = (s * 64 + b) * NW + wave;
+        const float *bp = (const float *)spts + (size_t)bkt * 256 + lane;
+        o = (size_t)bkt * 64 + lane;
         p.x = bp[0];
         p.y = bp[64];
         p.z = bp[128];
         p.w = bp[192];
-        t = tmin[o];
+        if (bkt < lds_bkts) t = fps_ltmin[bkt * 64 + lane];
+        else t = tmin[o];
       };
       auto process = [&](int cb, size_t co, const float4 &p, float t0) {
         if (PROF) {
@@ -414,7 +437,10 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
         const float d = sq3(dx, dy, dz);
         const bool valid = t0 >= 0.f;
         const float t = valid ? fminf(d, t0) : t0;
-        if (t != t0) tmin[co] = t;
+        if (t != t0) {
+          if ((s * 64 + cb) * NW + wave < lds_bkts) fps_ltmin[co] = t;
+          else tmin[co] = t;
+        }
         if (PROF) {
           const unsigned long long ch = __ballot(t != t0);
           nuse += ch ? 1 : 0;
@@ -551,609 +577,13 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
 #undef BTR_PH
 }
 
-// ------------------------------------------- work-queue kernel (BTR_FPS_IMPL=queue, opt-in)
-// MEASURED AND NOT ADOPTED (MI355X, 8 x 40000 -> 2048): 2.71 ms against 2.22 ms for the
-// owner-wave kernel above; bit-exact in the whole index suite.  It removes the second trip of
-// the busiest wave (items/step per wave 1.17 max instead of 1.6 trips) but pays for it with a
-// second barrier, the queue exchange and a reduction over NW + Q candidates: s_memtime phase
-// counters (BTR_FPS_PROF=1 BTR_FPS_IMPL=queue), cycles per step on the busiest wave:
-// test+push 391, barrier A 669, pop+fetch+untouched-best 639, update 783, barrier B 235,
-// reduce+winner 762 = 3503, against 2600 for the owner-wave kernel.  Kept for A/B.
-// Same algorithm as fps_bucket_kernel above (bucket boxes, exact pruning, one sample per
-// step), other distribution of the per-step work.  There, bucket b is ALWAYS updated by its
-// owner wave b % NW: a late sample touches ~10 of 625 buckets, the busiest of the 16 waves makes
-// 1.6-2.0 dependent trips (L2 round trip + wave reduction each) while half of the waves make
-// none.  Here the owner lanes only run the box test; the touched buckets go through an LDS
-// queue and wave w updates queue items w, w + NW, ...: one trip per wave up to NW touched
-// buckets.  Per step:
-//   test (owner lanes, registers) -> push touched bucket ids (one LDS atomic per wave)
-//   -> barrier A -> pop -> load bucket (L2) | under that latency: best UNTOUCHED bucket of the
-//   wave's own lanes -> update min-dists, bucket arg-max -> record to LDS -> barrier B
-//   -> every wave reduces the NW untouched-bests + Q fresh records -> next sample.
-// The per-bucket winner records live in LDS (rec[]), so a record is written once by whoever
-// updated the bucket and read by the one wave-uniform broadcast read of the final winner;
-// owners keep only the box and the bucket's max key in registers.
-struct QRec {  // 32 B: two ds_write_b128 / ds_read_b128
-  unsigned hi, lo;
-  float x, y, z;
-  int k, pad0, pad1;
-};
-
-template <int NW, int SL, bool PROF = false>
-__global__ __launch_bounds__(NW * 64) void fps_queue_kernel(int n, int np, int m, int bs,
-                                                            int log2bs,
-                                                            const float *__restrict__ dataset,
-                                                            const float4 *__restrict__ spts,
-                                                            float *__restrict__ tmin,
-                                                            int *__restrict__ idxs,
-                                                            unsigned long long *dbg = nullptr) {
-  // PROF: s_memtime phase counters (tuning builds only; BTR_FPS_PROF=1)
-  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, nitem = 0;
-#define BTR_QPH(i)                                                 \
-  if (PROF) {                                                      \
-    const unsigned long long now = __builtin_amdgcn_s_memtime();   \
-    tph[i] += now - tlast;                                         \
-    tlast = now;                                                   \
-  }
-  constexpr int NB = NW * 64 * SL;  // bucket capacity of the workgroup
-  __shared__ QRec rec[NB];          // winner record of every bucket
-  __shared__ int queue[2][NB];      // touched bucket ids of this step (double-buffered)
-  __shared__ unsigned qhi[NB];      // max key of queue item i after its update
-  __shared__ uint2 slots[NW];       // (max key, bucket) of each wave's best untouched bucket
-  __shared__ int qcount[2];
-  constexpr int kOut = 2048;        // samples are collected in LDS and written out in chunks:
-  __shared__ int out_idx[kOut];     // no global store on the per-step chain
-
-  __builtin_amdgcn_s_setprio(3);  // latency chain: issue ahead of co-resident streaming waves
-  const int bi = blockIdx.x;
-  dataset += (size_t)bi * n * 3;
-  spts += (size_t)bi * np;
-  tmin += (size_t)bi * np;
-  idxs += (size_t)bi * m;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nb = np >> 6;
-  const TieParams tp{bs, log2bs, (n + bs - 1) >> log2bs};
-  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
-
-  // ---- owner state: bounding box + max key of the buckets this lane owns
-  float bx0[SL], by0[SL], bz0[SL], bx1[SL], by1[SL], bz1[SL];
-  unsigned mhi[SL];
-  int myb[SL];
-#pragma unroll
-  for (int s = 0; s < SL; ++s) {
-    myb[s] = (s * 64 + lane) * NW + wave;
-    bx0[s] = by0[s] = bz0[s] = bx1[s] = by1[s] = bz1[s] = 0.f;
-    mhi[s] = 0u;
-    if (myb[s] < nb) {
-      const float *bp = (const float *)spts + (size_t)myb[s] * 256;
-      const float *tm = tmin + (size_t)myb[s] * 64;
-      float ax0 = bp[0], ax1 = ax0, ay0 = bp[64], ay1 = ay0, az0 = bp[128], az1 = az0;
-      bool any = tm[0] >= 0.f;
-#pragma unroll 8
-      for (int i = 1; i < 64; ++i) {
-        if (__float_as_int(bp[192 + i]) < 0) continue;  // padding slot: not in the box
-        const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
-        ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
-        ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
-        az0 = fminf(az0, qz); az1 = fmaxf(az1, qz);
-        any |= tm[i] >= 0.f;
-      }
-      bx0[s] = ax0; bx1[s] = ax1; by0[s] = ay0; by1[s] = ay1; bz0[s] = az0; bz1[s] = az1;
-      mhi[s] = any ? __float_as_uint(1e10f) + 1u : 0u;  // competing points start at 1e10
-    }
-  }
-  if (tid == 0) {
-    out_idx[0] = 0;
-    qcount[0] = 0;
-    qcount[1] = 0;
-  }
-  float sx = x0, sy = y0, sz = z0;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  lds_barrier();
-  if (PROF) tlast = __builtin_amdgcn_s_memtime();
-
-  for (int j = 1; j < m; ++j) {
-    if ((j & (kOut - 1)) == 0) {  // flush a full chunk of samples
-      lds_barrier();
-      for (int i = tid; i < kOut; i += NW * 64) idxs[j - kOut + i] = out_idx[i];
-      lds_barrier();
-    }
-    const int par = j & 1;
-    int *q = queue[par];
-    // ---- A: box test on the owner lanes (lower bound of the distance from the sample to the
-    // bucket, rounded exactly like the point distance: see the header of this file)
-    bool act[SL];
-    int myslot[SL];
-    unsigned lane_hi = 0u;
-    int lane_b = 0;
-#pragma unroll
-    for (int s = 0; s < SL; ++s) {
-      const float ex = __builtin_amdgcn_fmed3f(sx, bx0[s], bx1[s]) - sx;
-      const float ey = __builtin_amdgcn_fmed3f(sy, by0[s], by1[s]) - sy;
-      const float ez = __builtin_amdgcn_fmed3f(sz, bz0[s], bz1[s]) - sz;
-      const float dbox = sq3(ex, ey, ez);
-      act[s] = (__float_as_uint(dbox) + 1u) < mhi[s];  // mhi == 0: none competes
-      // ---- B: push the touched buckets: one LDS atomic per wave and slot
-      const unsigned long long mask = __ballot(act[s]);
-      myslot[s] = 0;
-      if (mask) {
-        const int first = __builtin_ctzll(mask);
-        int base = 0;
-        if (lane == first) base = atomicAdd(&qcount[par], __builtin_popcountll(mask));
-        base = __builtin_amdgcn_readlane(base, first);
-        myslot[s] = base + __builtin_popcountll(mask & lt);
-        if (act[s]) q[myslot[s]] = myb[s];
-      }
-      // this lane's best UNTOUCHED bucket (its record in rec[] stays valid through the step)
-      const unsigned uh = act[s] ? 0u : mhi[s];
-      if (s == 0 || uh > lane_hi) {
-        lane_hi = uh;
-        lane_b = myb[s];
-      }
-    }
-    BTR_QPH(0)
-    // Min-dist stores of the previous step must have COMPLETED before another wave may load
-    // the same bucket (a bucket is updated by whichever wave pops it): they were issued a full
-    // reduction phase ago, so this wait is normally free.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    BTR_QPH(1)
-    lds_barrier();  // ---- barrier A: the queue of this step is complete
-    BTR_QPH(2)
-    if (tid == 0) qcount[par ^ 1] = 0;  // next step's counter (everyone finished reading it
-                                        // before arriving here)
-    const int Q = __builtin_amdgcn_readfirstlane(qcount[par]);
-
-    // ---- C: pop + update.  Item `it` of the queue belongs to wave it % NW.  Software
-    // pipelined like the kernel above: the next item's loads are in flight while the current
-    // one is reduced; the untouched-best of the wave runs under the first load's latency.
-    auto fetch = [&](int it, int &b, float4 &p, float &t) {
-      b = __builtin_amdgcn_readfirstlane(q[it]);
-      const float *bp = (const float *)spts + (size_t)b * 256 + lane;
-      p.x = bp[0];
-      p.y = bp[64];
-      p.z = bp[128];
-      p.w = bp[192];
-      t = tmin[(size_t)b * 64 + lane];
-    };
-    auto process = [&](int it, int b, const float4 &p, float t0) {
-      float dx, dy, dz;  // plain v_sub_f32 through asm: see fps_bucket_kernel
-      asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(p.x), "v"(sx));
-      asm("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(p.y), "v"(sy));
-      asm("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(p.z), "v"(sz));
-      const float d = sq3(dx, dy, dz);
-      const bool valid = t0 >= 0.f;
-      const float t = valid ? fminf(d, t0) : t0;
-      if (t != t0) tmin[(size_t)b * 64 + lane] = t;
-      const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
-      const unsigned mh = wave_max_u32(hi);
-      const unsigned long long cand = __ballot(hi == mh);
-      const int kk = __float_as_int(p.w);
-      int w;
-      if (__builtin_popcountll(cand) == 1) {
-        w = __builtin_ctzll(cand);
-      } else {  // exact tie (duplicated points) or an all-skipped bucket
-        const unsigned lo = (hi == mh) ? 0xffffffffu - fps_tk2(kk, tp.bs, tp.log2bs, tp.cpb) : 0u;
-        const unsigned ml = wave_max_u32(lo);
-        w = __builtin_ctzll(__ballot(hi == mh && lo == ml));
-      }
-      if (lane == w) {  // the winner lane publishes its own point: no readlanes
-        rec[b] = QRec{mh, 0xffffffffu - fps_tk2(kk, tp.bs, tp.log2bs, tp.cpb), p.x, p.y, p.z,
-                      kk, 0, 0};
-        qhi[it] = mh;
-      }
-    };
-    auto untouched_best = [&]() {
-      const unsigned wh = wave_max_u32(lane_hi);
-      const unsigned long long c = __ballot(lane_hi == wh);
-      int wl;
-      if (__builtin_popcountll(c) == 1) {
-        wl = __builtin_ctzll(c);
-      } else {  // several buckets hold the same max key: the tie key decides
-        const unsigned lo = (lane_hi == wh && wh != 0u) ? rec[lane_b].lo : 0u;
-        const unsigned ml = wave_max_u32(lo);
-        wl = __builtin_ctzll(__ballot(lane_hi == wh && lo == ml));
-      }
-      if (lane == wl) slots[wave] = make_uint2(wh, (unsigned)lane_b);
-    };
-    if (PROF) nitem += (Q > wave) ? (unsigned)((Q - wave + NW - 1) / NW) : 0u;
-    {
-      int it = wave;
-      if (it >= Q) {
-        untouched_best();
-      } else {
-        int bA, bB = 0, itA = it, itB = 0;
-        float4 pA, pB = make_float4(0.f, 0.f, 0.f, 0.f);
-        float tA, tB = 0.f;
-        fetch(itA, bA, pA, tA);
-        untouched_best();
-        BTR_QPH(3)
-        if (PROF) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          BTR_QPH(4)
-        }
-        for (;;) {
-          itB = itA + NW;
-          if (itB >= Q) {
-            process(itA, bA, pA, tA);
-            break;
-          }
-          fetch(itB, bB, pB, tB);
-          process(itA, bA, pA, tA);
-          itA = itB + NW;
-          if (itA >= Q) {
-            process(itB, bB, pB, tB);
-            break;
-          }
-          fetch(itA, bA, pA, tA);
-          process(itB, bB, pB, tB);
-        }
-      }
-    }
-    BTR_QPH(5)
-    lds_barrier();  // ---- barrier B: every record of this step is in LDS
-    BTR_QPH(6)
-
-    // owners pick up the new max key of their touched buckets (used by the next box test;
-    // the read runs under the reduction below)
-    unsigned nh[SL];
-#pragma unroll
-    for (int s = 0; s < SL; ++s) nh[s] = act[s] ? qhi[myslot[s]] : mhi[s];
-
-    // ---- D: every wave reduces the NW untouched-bests + the Q fresh records
-    unsigned gh = 0u, glo = 0u;
-    int gb = 0;
-    const int C = NW + Q;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-      const int ci = c0 + lane;
-      unsigned h = 0u;
-      int bkt = 0;
-      if (ci < NW) {
-        const uint2 v = slots[ci];
-        h = v.x;
-        bkt = (int)v.y;
-      } else if (ci < C) {
-        h = qhi[ci - NW];
-        bkt = q[ci - NW];
-      }
-      const unsigned ch = wave_max_u32(h);
-      const unsigned long long cand = __ballot(h == ch);
-      if (c0 == 0 && C <= 64 && __builtin_popcountll(cand) == 1) {  // the common case
-        gh = ch;
-        gb = __builtin_amdgcn_readlane(bkt, __builtin_ctzll(cand));
-        break;
-      }
-      if (ch == 0u) continue;
-      const unsigned lo = (h == ch) ? rec[bkt].lo : 0u;  // ties: the tie key decides
-      const unsigned cl = wave_max_u32(lo);
-      const int cw = __builtin_ctzll(__ballot(h == ch && lo == cl));
-      const int cb = __builtin_amdgcn_readlane(bkt, cw);
-      if (ch > gh || (ch == gh && cl > glo)) {
-        gh = ch;
-        glo = cl;
-        gb = cb;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < SL; ++s) mhi[s] = nh[s];
-    if (gh == 0u) {  // nothing competes: best=-1, besti=0 in the reference
-      sx = x0; sy = y0; sz = z0;
-      if (tid == 0) out_idx[j & (kOut - 1)] = 0;
-    } else {
-      const QRec win = rec[gb];  // wave-uniform address: broadcast read
-      sx = win.x; sy = win.y; sz = win.z;
-      if (tid == 0) out_idx[j & (kOut - 1)] = win.k;
-    }
-    BTR_QPH(7)
-  }
-  lds_barrier();
-  {
-    const int done = (m - 1) & ~(kOut - 1);  // first sample of the chunk still in LDS
-    for (int i = tid; done + i < m; i += NW * 64) idxs[done + i] = out_idx[i];
-  }
-  if (PROF && lane == 0 && dbg) {
-    unsigned long long *o = dbg + ((size_t)bi * NW + wave) * 16;
-    for (int i = 0; i < 8; ++i) o[i] = tph[i];
-    o[8] = nitem;
-  }
-#undef BTR_QPH
-}
-
-// ------------------------------------- multi-sample rounds (BTR_FPS_IMPL=pm, opt-in)
-// Exact FPS emitting SEVERAL samples per synchronisation round.
-//
-// Round-start invariant: every min-dist is exact for the samples chosen so far and each bucket
-// b knows B1(b) = its best key (hi, lo, point) and B2hi(b) = the second-best `hi` inside b.
-// Each wave publishes W1 = its best bucket (with that bucket's B2hi) and W2hi = the best `hi`
-// among its OTHER buckets.  Sort the NW wave winners: c_1 > c_2 > ...; U = max W2hi bounds
-// every point outside the winners' buckets.  c_1 is the next sample.  c_t (t >= 2) is the
-// sample after c_1..c_{t-1} if, for every r < t,
-//   (i)   hi(c_t) > U and hi(c_t) > 1          (nothing hidden can beat it; temp > 0)
-//   (ii)  fminf(d(c_r, c_t), temp(c_t)) == temp(c_t)   (its own min-dist is untouched)
-//   (iii) B2hi(bucket(c_r)) < hi(c_t)          (what remains in an accepted bucket is lower)
-// because min-dists only decrease: every other point was <= its bucket best <= c_t already,
-// points sharing a bucket with an accepted sample are bounded by (iii), the accepted samples
-// themselves drop to 0.  The chain stops at the first failure.  All accepted samples are then
-// applied in ONE pass over the touched buckets.  Comparisons on `hi` alone are conservative
-// (a tie on hi just ends the chain), so the emitted sequence is exactly the sequential one.
-struct MSlot {
-  unsigned hi, lo;
-  int k;
-  float x, y, z;
-  unsigned b2hi, w2hi;
-};
-
-// MEASURED AND NOT ADOPTED (MI355X, 8 x 40000 -> 2048): 2.26 ms against 2.23 ms for the
-// one-sample-per-step kernel; bit-exact in the whole index suite.  The scheme above on the
-// owner-wave kernel's machinery: touched buckets are updated with the software-pipelined
-// two-register-set loop (all accepted samples applied in one pass: t = min over the samples);
-// after the first barrier every wave RANKS its own candidate among the NW (one compare per
-// lane), the KMAX best go to sorted[rank], and after a second barrier the chain is validated
-// with one (earlier, later) pair per lane.  One bucket per lane (n <= NW * 64 * 64 points).
-// KMAX = 4: 3.0 samples per round, 681 rounds -- but 7 500 cycles per round (s_memtime,
-// BTR_FPS_PROF=1 BTR_FPS_IMPL=pm): box tests against 4 samples 520-840, bucket trips
-// 1 800-2 200 (1.9 per wave and round), wave arg-max 380, barrier 1 1 200-2 900 (the wave with
-// the most trips), rank 440-640, barrier 2 150-330, chain 1 200-2 100 = 2 500 cycles per SAMPLE
-// against 2 600 for one sample per step.  The number of bucket trips per sample is the same
-// either way (9.6; each an L2 round trip + three wave reductions), better balanced here (the
-// busiest wave makes ~1.2 trips per sample instead of 1.6), and that gain is spent on the second
-// barrier and on 16 waves sharing 4 SIMDs for the rank / chain arithmetic (an earlier form
-// where every wave extracted and validated the candidates itself, no second barrier, needed
-// 9 200 cycles per round: ~280 instructions x 16 waves is issue-bound).  What bounds FPS on
-// this machine is the trip: ~1 000 cycles of L2 latency + reductions per touched bucket.
-template <int NW, int KMAX, bool PROF = false>
-__global__ __launch_bounds__(NW * 64) void fps_bucket_pm_kernel(
-    int n, int np, int m, int bs, int log2bs, const float *__restrict__ dataset,
-    const float4 *__restrict__ spts, float *__restrict__ tmin, int *__restrict__ idxs,
-    unsigned long long *dbg) {
-  static_assert(NW <= 16 && KMAX <= NW && KMAX <= 8, "slots are reduced by one 16-lane row");
-  __shared__ MSlot slots[NW];      // one slot per wave: its winner this round
-  __shared__ MSlot sorted[KMAX];   // the KMAX best of them, in order
-  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, ntrip = 0;
-#define BTR_PMH(i)                                                 \
-  if (PROF) {                                                      \
-    const unsigned long long now = __builtin_amdgcn_s_memtime();   \
-    tph[i] += now - tlast;                                         \
-    tlast = now;                                                   \
-  }
-
-  __builtin_amdgcn_s_setprio(3);
-  const int bi = blockIdx.x;
-  dataset += (size_t)bi * n * 3;
-  spts += (size_t)bi * np;
-  tmin += (size_t)bi * np;
-  idxs += (size_t)bi * m;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nb = np >> 6;
-  const TieParams tp{bs, log2bs, (n + bs - 1) >> log2bs};
-  const float x0 = dataset[0], y0 = dataset[1], z0 = dataset[2];
-
-  float bx0 = 0.f, by0 = 0.f, bz0 = 0.f, bx1 = 0.f, by1 = 0.f, bz1 = 0.f;
-  unsigned mhi = 0u, mlo = 0u, mb2 = 0u;
-  int mk = 0;
-  float mx = 0.f, my = 0.f, mz = 0.f;
-  {
-    const int myb = lane * NW + wave;
-    if (myb < nb) {
-      const float *bp = (const float *)spts + (size_t)myb * 256;
-      const float *tm = tmin + (size_t)myb * 64;
-      float ax0 = bp[0], ax1 = ax0, ay0 = bp[64], ay1 = ay0, az0 = bp[128], az1 = az0;
-      bool any = tm[0] >= 0.f;
-#pragma unroll 8
-      for (int i = 1; i < 64; ++i) {
-        if (__float_as_int(bp[192 + i]) < 0) continue;
-        const float qx = bp[i], qy = bp[64 + i], qz = bp[128 + i];
-        ax0 = fminf(ax0, qx); ax1 = fmaxf(ax1, qx);
-        ay0 = fminf(ay0, qy); ay1 = fmaxf(ay1, qy);
-        az0 = fminf(az0, qz); az1 = fmaxf(az1, qz);
-        any |= tm[i] >= 0.f;
-      }
-      bx0 = ax0; bx1 = ax1; by0 = ay0; by1 = ay1; bz0 = az0; bz1 = az1;
-      mhi = mb2 = any ? __float_as_uint(1e10f) + 1u : 0u;   // (b2 = best: no chain until the
-    }                                                         // bucket has been through a pass)
-  }
-  if (tid == 0) idxs[0] = 0;
-  float ax[KMAX], ay[KMAX], az[KMAX];   // samples accepted in the previous round (wave-uniform)
-#pragma unroll
-  for (int a = 0; a < KMAX; ++a) { ax[a] = x0; ay[a] = y0; az[a] = z0; }
-  int nacc = 1;
-  unsigned long long rounds = 0;
-  int wl = 0;
-  unsigned wh = 0u, w2 = 0u;
-  bool fresh = false;
-
-  if (PROF) tlast = __builtin_amdgcn_s_memtime();
-  for (int j = 1; j < m;) {
-    // ---- box test against every accepted sample
-    bool active = false;
-#pragma unroll
-    for (int a = 0; a < KMAX; ++a) {
-      if (a < nacc) {
-        const float cx = fminf(fmaxf(ax[a], bx0), bx1);
-        const float cy = fminf(fmaxf(ay[a], by0), by1);
-        const float cz = fminf(fmaxf(az[a], bz0), bz1);
-        const float ex = cx - ax[a], ey = cy - ay[a], ez = cz - az[a];
-        active |= (__float_as_uint(sq3(ex, ey, ez)) + 1u) < mhi;
-      }
-    }
-    unsigned long long todo = __ballot(active);
-    const bool touched = todo != 0;
-    if (PROF) ntrip += __builtin_popcountll(todo);
-    BTR_PMH(0)
-    if (touched) {
-      auto fetch = [&](int b, size_t &o, float4 &p, float &t) {
-        const size_t bkt = (size_t)(b * NW + wave);
-        const float *bp = (const float *)spts + bkt * 256 + lane;
-        o = bkt * 64 + lane;
-        p.x = bp[0];
-        p.y = bp[64];
-        p.z = bp[128];
-        p.w = bp[192];
-        t = tmin[o];
-      };
-      auto process = [&](int cb, size_t co, const float4 &p, float t0) {
-        float dx, dy, dz;
-        asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(p.x), "v"(ax[0]));
-        asm("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(p.y), "v"(ay[0]));
-        asm("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(p.z), "v"(az[0]));
-        float d = sq3(dx, dy, dz);
-#pragma unroll
-        for (int a = 1; a < KMAX; ++a) {
-          if (a < nacc) {
-            const float ex = p.x - ax[a], ey = p.y - ay[a], ez = p.z - az[a];
-            d = fminf(d, sq3(ex, ey, ez));
-          }
-        }
-        const bool valid = t0 >= 0.f;
-        const float t = valid ? fminf(d, t0) : t0;
-        if (t != t0) tmin[co] = t;
-        const unsigned hi = valid ? __float_as_uint(t) + 1u : 0u;
-        const unsigned mh = wave_max_u32(hi);
-        const unsigned long long cand = __ballot(hi == mh);
-        const int kk = __float_as_int(p.w);
-        int w;
-        if (__builtin_popcountll(cand) == 1) {
-          w = __builtin_ctzll(cand);
-        } else {
-          const unsigned lo = (hi == mh) ? 0xffffffffu - fps_tk2(kk, tp.bs, tp.log2bs, tp.cpb)
-                                         : 0u;
-          const unsigned ml = wave_max_u32(lo);
-          w = __builtin_ctzll(__ballot(hi == mh && lo == ml));
-        }
-        const unsigned b2 = wave_max_u32(lane == w ? 0u : hi);   // second-best hi of the bucket
-        const int wk = __builtin_amdgcn_readlane(kk, w);
-        const unsigned wlo = 0xffffffffu - fps_tk2(wk, tp.bs, tp.log2bs, tp.cpb);
-        const float wx = rl_f(p.x, w), wy = rl_f(p.y, w), wz = rl_f(p.z, w);
-        const bool mine = lane == cb;
-        mhi = mine ? mh : mhi;
-        mlo = mine ? wlo : mlo;
-        mb2 = mine ? b2 : mb2;
-        mk = mine ? wk : mk;
-        mx = mine ? wx : mx;
-        my = mine ? wy : my;
-        mz = mine ? wz : mz;
-      };
-      int bA = __builtin_ctzll(todo), bB = 0;
-      todo &= todo - 1;
-      size_t oA, oB = 0;
-      float4 pA, pB = make_float4(0.f, 0.f, 0.f, 0.f);
-      float tA, tB = 0.f;
-      fetch(bA, oA, pA, tA);
-      for (;;) {
-        if (todo == 0) {
-          process(bA, oA, pA, tA);
-          break;
-        }
-        bB = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        fetch(bB, oB, pB, tB);
-        process(bA, oA, pA, tA);
-        if (todo == 0) {
-          process(bB, oB, pB, tB);
-          break;
-        }
-        bA = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        fetch(bA, oA, pA, tA);
-        process(bB, oB, pB, tB);
-      }
-    }
-    BTR_PMH(1)
-    // ---- wave winner and the bound for everything else in this wave
-    if (touched || !fresh) {
-      wl = wave_argmax(mhi, [&]() { return mlo; }, wh);
-      w2 = wave_max_u32(lane == wl ? 0u : mhi);
-    }
-    fresh = true;
-    // (single-buffered: a slot is rewritten after the NEXT round's second barrier at the
-    // earliest, `sorted` after the next round's first)
-    MSlot *sl = slots;
-    if (lane == wl) sl[wave] = MSlot{wh, mlo, mk, mx, my, mz, mb2, w2};
-    BTR_PMH(2)
-    lds_barrier();
-    BTR_PMH(3)
-
-    // ---- phase A: every wave ranks ITS candidate among the NW (one compare per lane); the
-    // KMAX best are copied to sorted[rank].  (Doing the whole extraction + validation in every
-    // wave was measured first: 16 waves x ~280 scalar-ish instructions on 4 SIMDs is issue-
-    // bound, 2 200-5 000 cycles per round; ranking is 10 instructions.)
-    const int r = lane & 15;
-    unsigned ehi = 0u, elo = 0u, ew2 = 0u;
-    if (r < NW) {
-      ehi = sl[r].hi;
-      elo = sl[r].lo;
-      ew2 = sl[r].w2hi;
-    }
-    const unsigned U = row16_max_u32(ew2);   // bounds every point hidden behind a wave winner
-    const unsigned mylo = (unsigned)__builtin_amdgcn_readlane((int)mlo, wl);
-    const bool gt = r != wave && r < NW &&
-                    (ehi > wh || (ehi == wh && (elo > mylo || (elo == mylo && r < wave))));
-    const int rank = __builtin_popcountll(__ballot(gt) & 0xFFFFull);
-    if (rank < KMAX && lane == wl) sorted[rank] = MSlot{wh, mlo, mk, mx, my, mz, mb2, w2};
-    BTR_PMH(4)
-    lds_barrier();
-    BTR_PMH(5)
-    // ---- phase B: chain validation, one (earlier, later) candidate pair per lane
-    const int limit = min(KMAX, m - j);
-    // lane p < KMAX*(KMAX-1)/2: pair (q, t), q < t, enumerated by t: (0,1) (0,2) (1,2) (0,3) ...
-    int pt = 1, pq = lane;
-#pragma unroll
-    for (int t = 1; t < KMAX; ++t)
-      if (pq >= pt && pt == t) { pq -= t; pt = t + 1; }
-    bool okp = true;
-    if (pt < KMAX) {
-      const MSlot cq = sorted[pq], ct = sorted[pt];
-      const float tt = __uint_as_float(ct.hi - 1u);
-      const float dx = ct.x - cq.x, dy = ct.y - cq.y, dz = ct.z - cq.z;   // point c_t, sample c_q
-      okp = (fminf(sq3(dx, dy, dz), tt) == tt) && (cq.b2hi < ct.hi);       // (ii), (iii)
-    }
-    // lane 32 + t: condition (i) of candidate t (and a strict drop from candidate t - 1: a tie on
-    // hi ends the chain)
-    bool oki = true;
-    if (lane >= 32 && lane < 32 + KMAX) {
-      const int t = lane - 32;
-      const unsigned ht = sorted[t].hi;
-      const unsigned hp = sorted[t > 0 ? t - 1 : 0].hi;
-      oki = t < limit && (t == 0 || (ht > U && ht > 1u && ht < hp));
-    }
-    const unsigned long long badp = __ballot(!okp), badi = __ballot(!oki) >> 32;
-    int A = 1;
-#pragma unroll
-    for (int t = 1; t < KMAX; ++t) {
-      const unsigned long long pairs = ((1ull << t) - 1ull) << (t * (t - 1) / 2);  // (q, t), q < t
-      if (A == t && !((badi >> t) & 1ull) && !(badp & pairs)) A = t + 1;
-    }
-    const MSlot c0 = sorted[0];
-    if (c0.hi == 0u) {   // nothing competes: best = -1, besti = 0 in the reference
-      A = 1;
-      ax[0] = x0; ay[0] = y0; az[0] = z0;
-      if (tid == 0) idxs[j] = 0;
-    } else {
-#pragma unroll
-      for (int a = 0; a < KMAX; ++a) {
-        const MSlot c = sorted[a < A ? a : 0];
-        ax[a] = c.x; ay[a] = c.y; az[a] = c.z;
-      }
-      if (tid < A) idxs[j + tid] = sorted[tid].k;
-    }
-    nacc = A;
-    j += nacc;
-    ++rounds;
-    BTR_PMH(6)
-  }
-  if (PROF) {
-    if (lane == 0 && dbg) {
-      unsigned long long *o = dbg + 8 + ((size_t)bi * NW + wave) * 16;
-      for (int i = 0; i < 7; ++i) o[i] = tph[i];
-      o[7] = ntrip;
-      o[8] = rounds;
-    }
-  } else if (dbg && tid == 0) {
-    dbg[bi] = rounds;
-  }
-#undef BTR_PMH
-}
+// Two exact alternatives to the owner-wave kernel were built, kept bit-exact in the whole index
+// suite through rounds 2 - 5 and measured slower or equal on 8 x 40 000 -> 2 048; they were removed
+// in round 6 (the numbers stay in DESIGN.md 7 and profiles/):
+//   * a work-queue distribution of the touched buckets (no second trip on the busiest wave, but a
+//     second barrier and the queue exchange): 2.71 vs 2.22 ms;
+//   * multi-sample rounds (up to 4 samples accepted per round when the runners-up provably
+//     survive the update): 2.26 vs 2.23 ms -- the bucket trips per SAMPLE are the same.
 
 struct FpsPlan {
   int nb, np;
@@ -1192,17 +622,6 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   float *sk = (float *)((char *)workspace + p.pts_bytes);  // the min-dist array
   fps_boxes_note(workspace, b, n, nullptr, 0u);   // (set again below by the kernel that writes them)
   {
-    static int curve_set = -1;
-    const char *cv = getenv("BTR_FPS_CURVE");
-    const int want = (cv && cv[0] == 'm') ? 1 : 0;
-    if (curve_set != want) {
-      const bool flag = want == 1;
-      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fps_morton), &flag, sizeof(bool), 0,
-                                   hipMemcpyHostToDevice, s);
-      curve_set = want;
-    }
-  }
-  {
     int *cells = (int *)((char *)workspace + p.pts_bytes + p.k_bytes);
     unsigned *meta = (unsigned *)(cells + (size_t)b * kCells);
     hipError_t e = hipMemsetAsync(cells, 0, p.sort_bytes, s);
@@ -1213,38 +632,52 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
                        cells);
     hipLaunchKernelGGL(fps_sortm_scan_kernel, dim3(b), dim3(kSortThreads), 0, s, cells);
     hipLaunchKernelGGL(fps_sortm_scatter_kernel, dim3(gx, b), dim3(256), 0, s, n, p.np, dataset,
-                       meta, cells, spts, sk);
+                       meta, cells, spts);
   }
   int rc = check_launch("furthest_point_sampling(sort)");
   if (rc) return rc;
-  if (getenv("BTR_FPS_PROF") && getenv("BTR_FPS_IMPL") && getenv("BTR_FPS_IMPL")[0] == 'q') {
-    static unsigned long long *dbg = nullptr;
-    if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 64 * 16 * 16);
-    hipLaunchKernelGGL((fps_queue_kernel<16, 1, true>), dim3(b), dim3(1024), 0, s, n, p.np, m, bs,
-                       log2bs, dataset, spts, sk, idxs, dbg);
-    (void)hipStreamSynchronize(s);
-    unsigned long long h[16 * 16];
-    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-    const char *names[8] = {"test+push", "store-wait", "barrierA", "pop+fetch+untouched",
-                            "load-wait", "process", "barrierB", "reduce+winner"};
-    for (int w = 0; w < 16; w += 5) {
-      fprintf(stderr, "[fps queue prof] scene 0 wave %2d:", w);
-      double tot = 0;
-      for (int i = 0; i < 8; ++i) {
-        fprintf(stderr, " %s %.0f", names[i], (double)h[w * 16 + i] / (m - 1));
-        tot += (double)h[w * 16 + i] / (m - 1);
+  // Dynamic LDS of the launch: the running min-dists (4 B per point, as many as fit) and, beyond
+  // them, a reservation.  A workgroup that holds most of its CU's 160 KB keeps every LDS-using
+  // workgroup of the other streams OFF that CU: the kernel sits on one CU per scene for 2 ms
+  // while the previous batch's training step runs on the other streams; whatever shares those
+  // CUs runs at a fraction of its speed (16 high-priority waves beside it), and a launch of
+  // equal row chunks ends with its slowest workgroup.  Eight sleeping 1024-thread workgroups
+  // alone cost the backbone forward 8 %, VALU-busy ones more than double it
+  // (tools/probe/occupant.hip, tools/fps_interference.py); round 4, same box, 20 steps: 4.54 ->
+  // 4.37 ms per step with 128 KB held, 64 KB: 4.49.  (A CU-masked queue does not do it: the
+  // dispatcher balances workgroups per shader engine, so taking one CU of 32 away slowed every
+  // launch on that queue by 16 %; removed in round 6.)
+  const int lds_kb = fps_lds_kb(p.np);
+  size_t dyn = (size_t)lds_kb << 10;
+  if (dyn > 0) {
+    // (the attribute belongs to the function ON A DEVICE: set once per device and size.  A
+    // runtime that refuses it leaves the min-dists in global memory: same results)
+    static int attr_kb[64] = {};   // largest size granted so far, -1: refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      dyn = 0;
+    } else {
+      if (attr_kb[dev] >= 0 && attr_kb[dev] < lds_kb) {
+        bool ok = true;
+        for (const void *f : {reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1>),
+                              reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1>),
+                              reinterpret_cast<const void *>(
+                                  &fps_bucket_kernel<kBucketWaves, 1, 1, true>)})
+          ok = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) ==
+                   hipSuccess && ok;
+        (void)hipGetLastError();
+        attr_kb[dev] = ok ? lds_kb : -1;
       }
-      fprintf(stderr, " | total %.0f cycles/step, items/step %.2f\n", tot,
-              (double)h[w * 16 + 8] / (m - 1));
+      if (attr_kb[dev] < lds_kb) dyn = 0;
     }
-    return check_launch("furthest_point_sampling(queue,prof)");
   }
-  if (getenv("BTR_FPS_PROF") && !(getenv("BTR_FPS_IMPL") && getenv("BTR_FPS_IMPL")[0] == 'p')) {
-    // tuning only: s_memtime phase counters of the default kernel
+  const int lds_pts = (int)std::min<size_t>((size_t)p.np, (dyn / sizeof(float)) & ~(size_t)63);
+  if (getenv("BTR_FPS_PROF")) {
+    // tuning only (tools/fps_prof.py): s_memtime phase counters of the kernel, scene 0
     static unsigned long long *dbg = nullptr;
     if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 64 * 16 * 8);
-    hipLaunchKernelGGL((fps_bucket_kernel<16, 1, 1, true>), dim3(b), dim3(1024), 0, s, n, p.np, m,
-                       bs, log2bs, dataset, spts, sk, idxs, dbg);
+    hipLaunchKernelGGL((fps_bucket_kernel<16, 1, 1, true>), dim3(b), dim3(1024), dyn, s, n, p.np,
+                       m, bs, log2bs, dataset, spts, sk, idxs, dbg, (Box8 *)nullptr, 0u, lds_pts);
     (void)hipStreamSynchronize(s);
     unsigned long long h[16 * 8];
     (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -1266,9 +699,9 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
         mx += mm;
         hist[std::min(mm, 7)]++;
       }
-      fprintf(stderr, "[fps prof] scene 0: touched buckets/step total %.2f, max over waves %.2f,"
-              " balanced would be %.2f; hist(max) =", tot / (steps - 1), mx / (steps - 1),
-              tot / (steps - 1) / 16.0);
+      fprintf(stderr, "[fps prof] scene 0 (%d of %d min-dists in LDS): touched buckets/step total "
+              "%.2f, max over waves %.2f, balanced would be %.2f; hist(max) =", lds_pts, p.np,
+              tot / (steps - 1), mx / (steps - 1), tot / (steps - 1) / 16.0);
       for (int i = 0; i < 8; ++i) fprintf(stderr, " %d", hist[i]);
       fprintf(stderr, "\n");
     }
@@ -1284,72 +717,6 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
     }
     return check_launch("furthest_point_sampling(bucket,prof)");
   }
-  {  // BTR_FPS_IMPL=queue: the work-queue kernel (measured slower, see its header)
-    const char *e = getenv("BTR_FPS_IMPL");
-    if (e && e[0] == 'q') {
-      if (p.nb <= kBucketWaves * 64)
-        hipLaunchKernelGGL((fps_queue_kernel<kBucketWaves, 1>), dim3(b), dim3(kBucketWaves * 64),
-                           0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
-      else
-        hipLaunchKernelGGL((fps_queue_kernel<kBucketWaves, 2>), dim3(b), dim3(kBucketWaves * 64),
-                           0, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs);
-      return check_launch("furthest_point_sampling(queue)");
-    }
-  }
-  {  // BTR_FPS_IMPL=pm: multi-sample rounds on the pipelined machinery (n <= 65 536; measured
-     // equal to the one-sample-per-step kernel below, see fps_bucket_pm_kernel)
-    const char *e = getenv("BTR_FPS_IMPL");
-    const bool pm = e && ((e[0] == 'p' && e[1] == 'm') || e[0] == 'm') &&   // "pm" / "multi"
-                    p.nb <= kBucketWaves * 64;
-    if (pm && getenv("BTR_FPS_PROF")) {   // tuning: s_memtime phase counters of scene 0
-      static unsigned long long *dbgp = nullptr;
-      if (!dbgp) (void)hipMalloc(&dbgp, sizeof(unsigned long long) * (8 + 64 * 16 * 16));
-      hipLaunchKernelGGL((fps_bucket_pm_kernel<kBucketWaves, 4, true>), dim3(b),
-                         dim3(kBucketWaves * 64), 0, s, n, p.np, m, bs, log2bs, dataset, spts, sk,
-                         idxs, dbgp);
-      (void)hipStreamSynchronize(s);
-      unsigned long long h[8 + 16 * 16];
-      (void)hipMemcpy(h, dbgp, sizeof(h), hipMemcpyDeviceToHost);
-      const char *names[7] = {"box-test", "bucket-trips", "wave-argmax+slot", "barrier-1",
-                              "rank", "barrier-2", "chain"};
-      for (int w = 0; w < 16; w += 5) {
-        const unsigned long long *o = h + 8 + w * 16;
-        const double rnd = (double)std::max<unsigned long long>(1, o[8]);
-        fprintf(stderr, "[fps pm prof] scene 0 wave %2d:", w);
-        double tot = 0;
-        for (int i = 0; i < 7; ++i) {
-          fprintf(stderr, " %s %.0f", names[i], (double)o[i] / rnd);
-          tot += (double)o[i] / rnd;
-        }
-        fprintf(stderr, " | %.0f cycles/round, %.0f rounds, %.2f trips/round\n", tot, rnd,
-                (double)o[7] / rnd);
-      }
-      return check_launch("furthest_point_sampling(bucket,pm,prof)");
-    }
-    if (pm) {
-      unsigned long long *rd = nullptr;
-      if (getenv("BTR_FPS_ROUNDS")) {
-        static unsigned long long *dbg3 = nullptr;
-        if (!dbg3) (void)hipMalloc(&dbg3, sizeof(unsigned long long) * 4096);
-        rd = dbg3;
-      }
-      hipEvent_t *ev = fps_kernel_events();
-      if (ev[0]) (void)hipEventRecord(ev[0], s);
-      hipLaunchKernelGGL((fps_bucket_pm_kernel<kBucketWaves, 4>), dim3(b),
-                         dim3(kBucketWaves * 64), 0, s, n, p.np, m, bs, log2bs, dataset, spts, sk,
-                         idxs, rd);
-      if (ev[1]) (void)hipEventRecord(ev[1], s);
-      ev[0] = ev[1] = nullptr;
-      if (rd) {
-        (void)hipStreamSynchronize(s);
-        unsigned long long h = 0;
-        (void)hipMemcpy(&h, rd, sizeof(h), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[fps] scene 0: %llu rounds for %d samples (%.2f samples/round)\n", h,
-                m - 1, (double)(m - 1) / (double)h);
-      }
-      return check_launch("furthest_point_sampling(bucket,pm)");
-    }
-  }
   // owner-wave kernel: 16 waves, one bucket per trip
   hipEvent_t *ev = fps_kernel_events();   // bench.py: event pair around THIS kernel only
   if (ev[0]) (void)hipEventRecord(ev[0], s);
@@ -1361,112 +728,59 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   static std::atomic<unsigned> epoch_counter{0x5a000000u};
   unsigned epoch = (epoch_counter.fetch_add(1u) + 1u) & 0x7fffffffu;
   if (epoch == 0u) epoch = (epoch_counter.fetch_add(1u) + 1u) & 0x7fffffffu;
-  // BTR_FPS_PRIO=0: no raised wave priority (rides in the epoch's top bit, stripped in the kernel
-  // before the boxes are stamped).  With priority 3 the eight FPS workgroups starve whatever
-  // shares their CUs; when the pyramid is hidden under a training step anyway, the step's own
-  // kernels are what should not wait.
-  const char *pe = getenv("BTR_FPS_PRIO");
-  const unsigned kflag = (pe && pe[0] == '0') ? 0x80000000u : 0u;
-  // BTR_CU_MASK: the sampling kernel alone moves to the stream that owns the reserved CUs (its
-  // sort launches and everything behind it stay where they are); fork / join with two events.
-  // Not while a HIP graph is captured (the events are not part of the capture's streams).
-  hipStream_t ks = s;
-  static thread_local hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-  if (hipStream_t fs = cu_mask_fps_stream()) {
-    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cst) == hipSuccess && cst == hipStreamCaptureStatusNone) {
-      if (!fork_ev) {
-        (void)hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&join_ev, hipEventDisableTiming);
-      }
-      (void)hipEventRecord(fork_ev, s);
-      (void)hipStreamWaitEvent(fs, fork_ev, 0);
-      ks = fs;
-    } else {
-      (void)hipGetLastError();
-    }
-  }
-  if (ev[0] && ks != s) (void)hipEventRecord(ev[0], ks);   // (time the kernel on ITS stream)
-  // The launch asks for 128 KB (BTR_FPS_LDS_KB = k: k KB, 0: none) of dynamic LDS it never
-  // touches, on top of its own 1 KB.  A workgroup that holds most of its CU's 160 KB keeps every
-  // LDS-using workgroup of the other streams OFF that CU: a CU reservation by resource.  Why:
-  // the kernel sits on one CU per scene for 2 ms while the previous batch's training step runs
-  // on the other streams; whatever shares those CUs runs at a fraction of its speed (16
-  // high-priority waves beside it), and a launch of equal row chunks ends with its slowest
-  // workgroup.  Eight sleeping 1024-thread workgroups alone cost the backbone forward 8 %, VALU-
-  // busy ones more than double it (tools/probe/occupant.hip, tools/fps_interference.py).  A
-  // CU-masked queue does not do it: the dispatcher balances workgroups per shader engine, so
-  // taking one CU of 32 away slows every launch on that queue by 16 % (BTR_CU_MASK).
-  // Same box, 20 steps: 4.54 -> 4.37 ms per step; 64 KB: 4.49.
-  static const int lds_kb = fps_lds_reserve_kb();
-  size_t dyn = (size_t)lds_kb << 10;
-  if (dyn > 0) {
-    // (the attribute belongs to the function ON A DEVICE: set once per device.  A runtime that
-    // refuses it leaves the launch as it was: the reservation is about speed only)
-    static signed char attr_state[64] = {};   // 0 unknown, 1 set, -1 refused
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
-      dyn = 0;
-    } else {
-      if (attr_state[dev] == 0) {
-        const hipError_t e1 = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        const hipError_t e2 = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        (void)hipGetLastError();
-        attr_state[dev] = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : -1;
-      }
-      if (attr_state[dev] != 1) dyn = 0;
-    }
-  }
   if (p.nb <= kBucketWaves * 64)
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       dyn, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
-                       (unsigned long long *)nullptr, boxes, epoch | kflag);
+                       dyn, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
+                       (unsigned long long *)nullptr, boxes, epoch, lds_pts);
   else
     hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       dyn, ks, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
-                       (unsigned long long *)nullptr, boxes, epoch | kflag);
-  if (ev[1]) (void)hipEventRecord(ev[1], ks);
+                       dyn, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
+                       (unsigned long long *)nullptr, boxes, epoch, lds_pts);
+  if (ev[1]) (void)hipEventRecord(ev[1], s);
   ev[0] = ev[1] = nullptr;
-  if (ks != s) {
-    (void)hipEventRecord(join_ev, ks);
-    (void)hipStreamWaitEvent(s, join_ev, 0);
-  }
   fps_boxes_note(workspace, b, n, boxes, epoch);
   return check_launch("furthest_point_sampling(bucket)");
 }
 
-// ---- the LDS reservation of the large-scene FPS launch (see btr_furthest_point_sampling's
-// bucket path): BTR_FPS_LDS_KB = k (0: none), default 128.  In a data-parallel run (WORLD_SIZE
-// > 1) the default drops to 96: RCCL's kernels need up to ~64 KB of LDS per workgroup, and the
-// all-reduce runs while the next batch's FPS holds its eight CUs -- with 96 KB taken a collective
-// workgroup still fits beside a scene (160 - 97 KB), so a ring of more channels than the 248 free
-// CUs' share never waits for the 2 ms sampling chain to end; the step's own LDS-heavy kernels (64
-// - 128 KB per workgroup pair) are still kept off those CUs.
+// ---- dynamic LDS of the large-scene FPS launch (fps_bucket_launch): the running min-dists and
+// the CU reservation.  fps_lds_reserve_kb(): the FLOOR the launch holds whatever the scene size --
+// BTR_FPS_LDS_KB = k (0: none), default 128; in a data-parallel run (WORLD_SIZE > 1) 96: RCCL's
+// kernels need up to ~64 KB of LDS per workgroup, and the all-reduce runs while the next batch's
+// FPS holds its eight CUs -- with 96 KB taken a collective workgroup still fits beside a scene
+// (160 - 97 KB), so a ring of more channels than the 248 free CUs' share never waits for the
+// 2 ms sampling chain to end; the step's own LDS-heavy kernels (64 - 128 KB per workgroup pair)
+// are still kept off those CUs.  fps_lds_kb(np): what a launch over np points asks for -- on a
+// single GPU enough for all np min-dists when that fits beside the kernel's 1 KB of slots (159
+// KB: 40 704 points), never less than the floor; with the environment variable or WORLD_SIZE > 1
+// exactly the floor (min-dists beyond it stay in global memory).  btr_fps_set_lds_kb(k): a
+// process-wide override for tests and A/B runs (k < 0: back to the rules above).
+constexpr int kFpsLdsMaxKb = 159;
+static std::atomic<int> g_fps_lds_override{-1};
 int fps_lds_reserve_kb() {
   static const int kb = [] {
     const char *e = getenv("BTR_FPS_LDS_KB");
     const char *w = getenv("WORLD_SIZE");
     const int v = e ? atoi(e) : (w && atoi(w) > 1 ? 96 : 128);
-    return v > 0 && v <= 156 ? v : 0;
+    return v > 0 && v <= kFpsLdsMaxKb ? v : 0;
   }();
   return kb;
 }
-
-// ---- CU partitioning (internal.hpp)
-int cu_mask_reserved() {
-  static const int c = [] {
-    const char *e = getenv("BTR_CU_MASK");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 && v <= 8 ? v : 0;
+int fps_lds_kb(int np) {
+  const int o = g_fps_lds_override.load(std::memory_order_relaxed);
+  if (o >= 0) return std::min(o, kFpsLdsMaxKb);
+  static const bool fixed = [] {
+    const char *w = getenv("WORLD_SIZE");
+    return getenv("BTR_FPS_LDS_KB") != nullptr || (w && atoi(w) > 1);
   }();
-  return c;
+  const int floor_kb = fps_lds_reserve_kb();
+  if (fixed || floor_kb == 0) return floor_kb;
+  const int need = (int)(((size_t)np * sizeof(float) + 1023) >> 10);
+  return std::max(floor_kb, std::min(need, kFpsLdsMaxKb));
 }
-// CUs left to the collective's kernels when they overlap the step (see cu_mask_avail_cus):
-// BTR_COMM_CUS, default 16 under WORLD_SIZE > 1 with BTR_DP=ddp, else 0.
+
+// ---- what the one-round grids count on (internal.hpp)
+// CUs left to the collective's kernels when they overlap the step: BTR_COMM_CUS, default 16
+// under WORLD_SIZE > 1 with BTR_DP=ddp, else 0.
 static int comm_cus() {
   if (const char *e = getenv("BTR_COMM_CUS")) {
     const int v = atoi(e);
@@ -1477,7 +791,7 @@ static int comm_cus() {
   const bool overlapped = dp && dp[0] == 'd' && dp[1] == 'd' && dp[2] == 'p' && dp[3] == 0;
   return (w && atoi(w) > 1 && overlapped) ? 16 : 0;
 }
-int cu_mask_avail_cus() {
+int grid_cus() {
   static const int avail = [] {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -1485,7 +799,7 @@ int cu_mask_avail_cus() {
         cus <= 0)
       cus = 256;   // (no device at hand: the build check, the CPU-side planning tests)
     (void)hipGetLastError();
-    if (const char *e = getenv("BTR_GRID_CUS")) {   // sizing only, no partition
+    if (const char *e = getenv("BTR_GRID_CUS")) {   // sizing only
       const int v = atoi(e);
       if (v >= 8 && v <= cus) return v;
     }
@@ -1498,40 +812,9 @@ int cu_mask_avail_cus() {
     // workgroups (one per channel) that hold their CU's LDS staging buffers for the whole
     // collective.  The flat all-reduce (the default wrapper) runs behind the backward, beside
     // nothing of the step but the FPS: no CUs are set aside for it.
-    return std::max(8, cus - 8 * std::max(1, cu_mask_reserved()) - comm_cus());
+    return std::max(8, cus - 8 - comm_cus());
   }();
   return avail;
-}
-hipStream_t cu_mask_create_stream(bool reserved) {
-  const int c = cu_mask_reserved();
-  hipStream_t st = nullptr;
-  if (c == 0) {
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    return st;
-  }
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-    return nullptr;
-  const int words = (cus + 31) / 32;
-  std::vector<uint32_t> mask(words, 0u);
-  for (int i = 0; i < cus; ++i) {
-    const bool low = i < 8 * c;   // bits 0 .. 8c-1: CUs 0 .. c-1 of each of the 8 XCDs
-    if (low == reserved) mask[i >> 5] |= 1u << (i & 31);
-  }
-  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  return st;
-}
-hipStream_t cu_mask_fps_stream() {
-  if (cu_mask_reserved() == 0) return nullptr;
-  static thread_local hipStream_t per_dev[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!per_dev[dev]) per_dev[dev] = cu_mask_create_stream(true);
-  return per_dev[dev];
 }
 
 // ---- which workspaces hold bucket boxes (internal.hpp): the last few launches of this thread
@@ -1574,12 +857,12 @@ const Box8 *fps_boxes_lookup(const void *workspace, int b, int n, unsigned *epoc
 
 }  // namespace btr
 
-extern "C" int btr_cu_mask_reserved(void) { return btr::cu_mask_reserved(); }
-extern "C" int btr_grid_cus(void) { return btr::cu_mask_avail_cus(); }
+extern "C" int btr_grid_cus(void) { return btr::grid_cus(); }
 extern "C" int btr_fps_lds_reserve_kb(void) { return btr::fps_lds_reserve_kb(); }
-extern "C" void *btr_cu_mask_create_stream(int reserved) {
-  return (void *)btr::cu_mask_create_stream(reserved != 0);
+extern "C" int btr_fps_lds_kb(int points) {
+  return btr::fps_lds_kb((points + 63) / 64 * 64);
 }
+extern "C" void btr_fps_set_lds_kb(int kb) { btr::g_fps_lds_override.store(kb); }
 
 extern "C" void btr_fps_time_next_kernel(void *start_event, void *stop_event) {
   btr::fps_kernel_events()[0] = (hipEvent_t)start_event;

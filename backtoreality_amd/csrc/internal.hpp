@@ -6,23 +6,16 @@
 
 namespace btr {
 
-// fps_bucket.hip: CU partitioning between the sampling kernel and everything else
-// (BTR_CU_MASK = c > 0: the large-scene FPS kernel -- one 1024-thread workgroup per scene, a
-// dependent chain of ~2 000 steps -- runs on a stream restricted to the first c CUs of every XCD,
-// every other stream the library or the training loop creates on the complement.  Without it
-// the eight FPS workgroups share their CUs with whatever the other streams put there, both slow
-// down, and a streaming kernel waits for the few workgroups that landed beside an FPS scene).
-// Mask bit i = CU (i / 8) of XCD (i % 8): tools/probe/cu_mask_probe.hip.
-int cu_mask_reserved();                       // c (0: off)
-// CUs a kernel of the step can land on (256 - 8c): grids sized as ONE round of resident workgroups
-// -- the row chunks of the streaming / fused / weight-gradient kernels -- count these, not the
-// device's, or the leftover workgroups wait for a second round on a partitioned chip
-int cu_mask_avail_cus();
-// KB of dynamic LDS the large-scene FPS launch asks for without using it (keeps the step's
-// LDS-using workgroups off its CUs); BTR_FPS_LDS_KB, default 128, 96 when WORLD_SIZE > 1
+// fps_bucket.hip: CUs a kernel of the step can land on (the device's minus the eight the next
+// batch's large-scene FPS holds, minus what an overlapped collective keeps): grids sized as ONE
+// round of resident workgroups -- the row chunks of the streaming / fused / weight-gradient
+// kernels -- count these, not the device's, or the leftover workgroups wait for a second round
+int grid_cus();
+// KB of dynamic LDS the large-scene FPS launch holds at least (its min-dists live there; what is
+// left over keeps the step's LDS-using workgroups off its CUs); BTR_FPS_LDS_KB, default 128, 96
+// when WORLD_SIZE > 1.  fps_lds_kb(np): what a launch over np points asks for
 int fps_lds_reserve_kb();
-hipStream_t cu_mask_fps_stream();             // the reserved CUs (one per device and host thread)
-hipStream_t cu_mask_create_stream(bool reserved);   // a NEW stream on the reserved / other CUs
+int fps_lds_kb(int np);
 
 // sa_mlp.hip: out_bcn (B, C, N) [and out_cl (B*N, C)] = f(scale * y + shift) [+ add];
 // add (optional): a (B, C, N)-shaped operand whose batch elements are add_bstride floats apart
@@ -73,7 +66,7 @@ struct BnFin {
   int nbias;
   double count;
   float eps, momentum;
-  int fence;                   // 1: full device-scope fences around the ticket (BTR_BN_TICKET_FENCE=1)
+  int fence;                   // 1: full device-scope fences around the ticket (not the default: +9 - 12 us per GEMM, same results)
 };
 constexpr int kBnTickets = 8;  // tickets per statistics GEMM (column blocks of >= 64 channels, n <= 512)
 // sa_mlp.hip: per-point first layer of a set-abstraction MLP (see ppfl_gather_add_kernel)

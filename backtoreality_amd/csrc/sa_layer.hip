@@ -391,12 +391,9 @@ __global__ __launch_bounds__(256) void vote_assemble_norm_bwd_kernel(
 // backward in one launch (sa_bwd_fused_kernel) few weight gradients are left to overlap, and a
 // launch of equal row chunks that shares CUs with another stream's waves ends with its slowest
 // workgroup -- same box, 20 steps: 4.39 -> 4.16 ms per VoteNet step, Back-to-Reality 10.43 -> 9.77.
-// calls with fewer rows keep their weight gradients in line (BTR_SIDE_MIN_ROWS / _SA override)
-inline long long side_min_rows(bool sa) {
-  static const long long chain = getenv("BTR_SIDE_MIN_ROWS") ? atoll(getenv("BTR_SIDE_MIN_ROWS")) : 8192;
-  static const long long layer = getenv("BTR_SIDE_MIN_ROWS_SA") ? atoll(getenv("BTR_SIDE_MIN_ROWS_SA")) : 0;
-  return sa ? layer : chain;
-}
+// calls with fewer rows keep their weight gradients in line: point-wise chains under 8 192 rows
+// (the fork / join calls cost the host more than two overlapped 10 us kernels return)
+inline long long side_min_rows(bool sa) { return sa ? 0 : 8192; }
 struct SideStream {
   hipStream_t s = nullptr;
   hipEvent_t ready[kMaxL + 1] = {}, done[kMaxL + 1] = {};
@@ -408,8 +405,10 @@ SideStream *side_stream() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   SideStream &c = ctx[dev];
   if (!c.s) {
-    c.s = cu_mask_create_stream(false);   // (BTR_CU_MASK: not on the sampling kernel's CUs)
-    if (!c.s) return nullptr;
+    if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) {
+      c.s = nullptr;
+      return nullptr;
+    }
     for (int i = 0; i <= kMaxL; ++i) {
       (void)hipEventCreateWithFlags(&c.ready[i], hipEventDisableTiming);
       (void)hipEventCreateWithFlags(&c.done[i], hipEventDisableTiming);
@@ -535,8 +534,7 @@ SaBwdScratch sa_bwd_scratch(const btr_sa_layer_t &d, const btr_sa_plan_t &p) {
   const size_t pw0 = p.recompute ? (size_t)btr_sa_rc_wgrad_blocks(p.rows, d.width[0]) * d.width[0] * 4 : 0;
   const int cl = d.width[d.layers - 1];
   // [rows of partial sums][2][maxc]: the BatchNorm-backward statistics passes write <= 1024 rows,
-  // btr_sa_bwd_fused writes one row per chunk and column slab (BTR_GRID_ROUNDS / _FUSED_SPLIT
-  // raise that count)
+  // btr_sa_bwd_fused writes one row per chunk
   int part_rows = 1024;
   for (int l = 1; l < d.layers; ++l)
     if (btr_sa_bwd_fused_supported(p.rows, d.width[l], p.kin[l]))
@@ -1035,8 +1033,7 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       // level: xyz carries no gradient): only the feature columns 3 .. 3 + c of dX0 are computed,
       // as a dense (rows, c) tile -- with k0p = 3 + c (132, 260) the xyz columns cost a whole
       // extra column block whose 124 other columns are padding
-      static const bool feat_off = getenv("BTR_DGRAD0_FEAT") && getenv("BTR_DGRAD0_FEAT")[0] == '0';
-      const bool feat_only = !feat_off && l == 0 && !pooled && d.use_xyz && d.c > 0 &&
+      const bool feat_only = l == 0 && !pooled && d.use_xyz && d.c > 0 &&
                              d.c % 4 == 0 && !d.need_dxyz && !d.need_dnew_xyz;
       const int gld = feat_only ? d.c : k;
       if (pooled)

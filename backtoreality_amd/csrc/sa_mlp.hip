@@ -2111,8 +2111,6 @@ struct StreamArgs {
   float *gext;
   unsigned char *aext;
   int hs;               // log2 of the 128-column slabs of n (n > 128: two workgroups per row chunk)
-  int nchunks;          // sa_fwd_ws_kernel: row chunks of the single-role grid (`part` rows)
-  int cpw;              // ... and how many of them a workgroup takes (2, or 1)
 };
 
 template <int BR, int KMAX, int PRO, bool STATS, int PS>
@@ -2352,355 +2350,16 @@ __global__ __launch_bounds__(256, 2) void sa_fwd_stream_kernel(StreamArgs a, Com
   }
 }
 
-// ---- ... with producer and consumer waves (see sa_bwd_gram_ws_kernel) ---------------------------
-// sa_fwd_stream_kernel runs staging (VALU), products (LDS reads + MFMA) and epilogue (VALU +
-// stores) one after the other in every wave, and needs ~3x its MFMA time per step (SA1's pooled
-// layer: 2.6 us per 32-row step and workgroup for 0.4 us of matrix issue).  Here a 512-thread
-// workgroup (one per CU) splits the roles: waves 0-3 load rows two steps ahead, apply the
-// prologue, split and write the bf16 planes of step i+1 (double-buffered); waves 4-7 own one
-// 32 x 32 output tile each, multiply step i out of the other plane buffer and run the epilogue of
-// step i-1 on a second accumulator set -- independent instruction streams the scheduler
-// interleaves, so the epilogue's VALU work issues in the shadow of the MFMAs.  One barrier per
-// step.  Same arithmetic, same summation order and the SAME statistics partials as
-// sa_fwd_stream_kernel: a workgroup takes two consecutive row chunks of that kernel's grid and
-// writes a `part` row for each, so bn_finalize_kernel and every caller stay as they are (results
-// bit-identical to the single-role kernel).  BTR_FWD_WS=0: the single-role kernel.
-template <int BR, int KMAX, int PRO, bool STATS, int PS>
-__global__ __launch_bounds__(512, (KMAX == 64 && PS == 0) ? 4 : 2) void sa_fwd_ws_kernel(StreamArgs a, Compact cm) {
-  static_assert((BR == 32 || BR == 64) && (KMAX == 64 || KMAX == 128), "tile shapes");
-  static_assert(PS == 0 || PS == 8 || PS == 16, "pooling epilogue: blocks of 8 / groups of 16");
-  constexpr int WR = BR / 32;           // row tiles (consumer waves along the rows)
-  constexpr int WC = 4 / WR;            // column tiles: n <= 32 * WC
-  constexpr int LX = KMAX + 8;          // bf16 pitch (conflict-free 16-byte row reads)
-  constexpr int KS = KMAX / 16;
-  constexpr int TPR = KMAX / 4;         // staging threads per row
-  constexpr int RP = 256 / TPR;         // rows per staging pass
-  constexpr int NP = BR / RP;           // staging passes
-  constexpr int LT = 36;
-  constexpr int XPB = 3 * BR * LX;
-  int R = a.R, rows_per_chunk = a.rows_per_chunk;   // (chunk = the single-role kernel's)
-  const int nchunks = a.nchunks;
-  if (cm.dims) {
-    R = cm.dims[0];
-    rows_per_chunk = ((R + nchunks - 1) / nchunks + BR - 1) / BR * BR;
-  }
-  const int N = a.N, K = a.K;
-  const int pair = (int)blockIdx.x >> a.hs, cb = ((int)blockIdx.x & ((1 << a.hs) - 1)) * 128;
-  __shared__ __attribute__((aligned(16))) __bf16 Xp[2 * XPB];
-  __shared__ __attribute__((aligned(16))) float Ts[4][32 * LT];
-  __shared__ double red[STATS ? 2 * WR * 32 * WC : 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // rows of this workgroup: chunks 2 * pair and 2 * pair + 1 of the single-role grid
-  // (a.cpw == 1, BTR_FWD_WS=2: one chunk per workgroup -- two workgroups per CU where the
-  // registers allow it)
-  const int c0 = a.cpw * pair;
-  const int rbeg = min(R, c0 * rows_per_chunk);
-  const int rmid = min(R, rbeg + rows_per_chunk);       // first row of the second chunk
-  const int rend = min(R, rbeg + a.cpw * rows_per_chunk);
-  const int nsteps = (rend - rbeg + BR - 1) / BR;
-  const int nsteps2 = (nsteps + 1) & ~1;
-  const std::integral_constant<int, 0> P0{};
-  const std::integral_constant<int, 1> P1{};
-  if (wave < 4) {
-    // ================================================================== producers
-    const int xc4 = (tid % TPR) * 4, xr = tid / TPR;
-    float4 fa = make_float4(1.f, 1.f, 1.f, 1.f), fb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (PRO && xc4 < K) {
-      fa = *reinterpret_cast<const float4 *>(a.pa + xc4);
-      fb = *reinterpret_cast<const float4 *>(a.pb + xc4);
-    }
-    float4 w0r[PRO == 3 ? 4 : 1];
-    if constexpr (PRO == 3) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        w0r[e] = (xc4 + e < K) ? *reinterpret_cast<const float4 *>(a.w0 + (size_t)(xc4 + e) * 4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float4 rx[2][NP];
-    auto fetch = [&](auto P, int r0) {
-      constexpr int p = decltype(P)::value;
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        const int row = xr + RP * j;
-        rx[p][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + row < rend && xc4 < K)
-          rx[p][j] = PRO == 3
-                         ? *reinterpret_cast<const float4 *>(a.A + (size_t)(r0 + row) * 4)
-                         : *reinterpret_cast<const float4 *>(a.A + (size_t)(r0 + row) * a.lda + xc4);
-      }
-    };
-    auto stage = [&](auto P, int r0) {
-      constexpr int p = decltype(P)::value;
-      __bf16 *xp = Xp + p * XPB;
-#pragma unroll
-      for (int j = 0; j < NP; ++j) {
-        const int row = xr + RP * j;
-        float4 x = rx[p][j];
-        const bool live = r0 + row < rend && xc4 < K;
-        if constexpr (PRO == 3) {
-          if (live)
-            x = make_float4(rc_dot4(x, w0r[0]), rc_dot4(x, w0r[1]), rc_dot4(x, w0r[2]),
-                            rc_dot4(x, w0r[3]));
-        }
-        if (PRO != 0 && live) {
-          x.x = fmaxf(fmaf(fa.x, x.x, fb.x), 0.f);
-          x.y = fmaxf(fmaf(fa.y, x.y, fb.y), 0.f);
-          x.z = fmaxf(fmaf(fa.z, x.z, fb.z), 0.f);
-          x.w = fmaxf(fmaf(fa.w, x.w, fb.w), 0.f);
-        }
-        if (!live) x = make_float4(0.f, 0.f, 0.f, 0.f);   // padded rows / columns stay exactly 0
-        const Split4 sp = split4(x);
-        const int at = row * LX + xc4;
-        *reinterpret_cast<bf16x4 *>(&xp[0 * BR * LX + at]) = sp.h;
-        *reinterpret_cast<bf16x4 *>(&xp[1 * BR * LX + at]) = sp.m;
-        *reinterpret_cast<bf16x4 *>(&xp[2 * BR * LX + at]) = sp.l;
-      }
-    };
-    fetch(P0, rbeg);
-    fetch(P1, rbeg + BR);
-    stage(P0, rbeg);
-    fetch(P0, rbeg + 2 * BR);
-    __syncthreads();
-    for (int i = 0; i < nsteps2; i += 2) {
-      const int r0 = rbeg + i * BR;
-      stage(P1, r0 + BR);
-      fetch(P1, r0 + 3 * BR);
-      __syncthreads();
-      stage(P0, r0 + 2 * BR);
-      fetch(P0, r0 + 4 * BR);
-      __syncthreads();
-    }
-  } else {
-    // ================================================================== consumers
-    const int cw = wave - 4;
-    const int wr = cw / WC, wc = cw % WC;
-    const int l31 = lane & 31, h = lane >> 5;
-    bf16x8 bdr[KS][3];
-    {
-      const int nr = cb + wc * 32 + l31;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int kb = ks * 16 + h * 8;
-        float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
-        if (nr < N && kb < K) w0 = *reinterpret_cast<const float4 *>(a.W + (size_t)nr * a.ldw + kb);
-        if (nr < N && kb + 4 < K)
-          w1 = *reinterpret_cast<const float4 *>(a.W + (size_t)nr * a.ldw + kb + 4);
-        const Split4 s0 = split4(w0), s1 = split4(w1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          bdr[ks][0][e] = s0.h[e]; bdr[ks][0][4 + e] = s1.h[e];
-          bdr[ks][1][e] = s0.m[e]; bdr[ks][1][4 + e] = s1.m[e];
-          bdr[ks][2][e] = s0.l[e]; bdr[ks][2][4 + e] = s1.l[e];
-        }
-      }
-    }
-    const int col = cb + wc * 32 + l31;
-    const float sg = (PS > 0 && col < N && a.gsign[col] < 0.f) ? -1.f : 1.f;
-    double d1 = 0.0, d2 = 0.0;
-    f32x16 acc[2];
-    float bwx[2][4];
-    const int oA = (wr * 32 + l31) * LX + h * 8;   // this lane's fragment row inside a plane
-    auto mma = [&](auto P) {
-      constexpr int p = decltype(P)::value;
-      const __bf16 *xp = Xp + p * XPB + oA;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks * 16 >= K) break;
-        bf16x8 af[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          af[q] = *reinterpret_cast<const bf16x8 *>(xp + q * BR * LX + ks * 16);
-        const bf16x8 *bd = bdr[ks];
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bd[0], acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bd[2], acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bd[1], acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bd[0], acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bd[1], acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bd[0], acc[p], 0, 0, 0);
-      }
-    };
-    // (weight - 1) of this wave's four 8-row blocks of the step at r0 (compact rows)
-    auto load_bw = [&](auto P, int r0) {
-      constexpr int p = decltype(P)::value;
-      if (STATS && cm.bw) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = r0 + wr * 32 + 8 * q;
-          bwx[p][q] = row < rend ? cm.bw[row >> 3] - 1.f : 0.f;
-        }
-      }
-    };
-    // epilogue of the step at r0 on accumulator set P: D layout col = lane & 31,
-    // row = (v & 3) + 8 * (v >> 2) + 4 * h
-    auto epilogue = [&](auto P, int r0) {
-      constexpr int p = decltype(P)::value;
-      const int wrow0 = r0 + wr * 32;
-      if constexpr (STATS) {   // rows >= rend hold exact zeros
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const float c = acc[p][v];
-          s1 += c;
-          s2 = fmaf(c, c, s2);
-          if (cm.bw && h == 0 && (v & 3) == 0) {
-            const float wx = bwx[p][v >> 2];
-            s1 = fmaf(wx, c, s1);
-            s2 = fmaf(wx * c, c, s2);
-          }
-        }
-        d1 += (double)s1;
-        d2 += (double)s2;
-      }
-      if constexpr (PS > 0) {
-        float bestv[4];
-        int bestr[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          float vmx = -3.0e38f;
-          int imx = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float c = acc[p][4 * b + q] * sg;
-            if (c > vmx) {
-              vmx = c;
-              imx = q;
-            }
-          }
-          const int mine = imx + 4 * h;
-          const float omx = __shfl_xor(vmx, 32);
-          const int oix = __shfl_xor(mine, 32);
-          const bool take = omx > vmx || (omx == vmx && oix < mine);
-          bestv[b] = take ? omx : vmx;
-          bestr[b] = take ? oix : mine;
-        }
-        if constexpr (PS == 8) {
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int grow = wrow0 + b * 8;
-            if (h == 0 && grow < rend && col < N) {
-              const size_t o = (size_t)(grow >> 3) * N + col;
-              a.gext[o] = bestv[b] * sg;
-              a.aext[o] = (unsigned char)bestr[b];
-            }
-          }
-        } else {
-#pragma unroll
-          for (int b = 0; b < 4; b += 2) {
-            const bool second = bestv[b + 1] > bestv[b];
-            const int grow = wrow0 + b * 8;
-            if (h == 0 && grow < rend && col < N) {
-              const size_t o = (size_t)(grow >> 4) * N + col;
-              a.gext[o] = (second ? bestv[b + 1] : bestv[b]) * sg;
-              a.aext[o] = (unsigned char)(second ? 8 + bestr[b + 1] : bestr[b]);
-            }
-          }
-        }
-      }
-      if (a.C != nullptr) {
-        float *T = Ts[cw];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) T[((v & 3) + 8 * (v >> 2) + 4 * h) * LT + l31] = acc[p][v];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the tile is private to the wave)
-        __builtin_amdgcn_wave_barrier();
-        const int rl = lane >> 3, c4 = (lane & 7) * 4;
-        const int colw = cb + wc * 32 + c4;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const float4 q4 = *reinterpret_cast<const float4 *>(&T[(it * 8 + rl) * LT + c4]);
-          const int row = wrow0 + it * 8 + rl;
-          if (row < rend && colw < N)
-            *reinterpret_cast<float4 *>(a.C + (size_t)row * a.ldc + colw) = q4;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    };
-    // statistics of the first chunk leave when the steps cross rmid (a multiple of BR)
-    double keep1 = 0.0, keep2 = 0.0;
-    bool first_done = false;
-    auto after_step = [&](int r0_done) {   // the step at r0_done has been added to d1 / d2
-      if (STATS && !first_done && r0_done + BR >= rmid) {
-        keep1 = d1;
-        keep2 = d2;
-        d1 = d2 = 0.0;
-        first_done = true;
-      }
-    };
-    load_bw(P0, rbeg);
-    __syncthreads();   // (the producers' first planes)
-    for (int i = 0; i < nsteps2; i += 2) {
-      const int r0 = rbeg + i * BR;
-      mma(P0);
-      load_bw(P1, r0 + BR);
-      if (i >= 1) {
-        epilogue(P1, r0 - BR);
-        after_step(r0 - BR);
-      }
-      __syncthreads();
-      mma(P1);
-      load_bw(P0, r0 + 2 * BR);
-      epilogue(P0, r0);
-      after_step(r0);
-      __syncthreads();
-    }
-    if (nsteps2 >= 1) {
-      epilogue(P1, rbeg + (nsteps2 - 1) * BR);
-      after_step(rbeg + (nsteps2 - 1) * BR);
-    }
-    if constexpr (STATS) {
-      if (!first_done) {   // (no rows at all in the second chunk)
-        keep1 = d1;
-        keep2 = d2;
-        d1 = d2 = 0.0;
-      }
-      // lanes' sums of chunk 0 and chunk 1 -> LDS, row tiles added in the single-role kernel's order
-      keep1 += __shfl_xor(keep1, 32);
-      keep2 += __shfl_xor(keep2, 32);
-      d1 += __shfl_xor(d1, 32);
-      d2 += __shfl_xor(d2, 32);
-      if (h == 0) {
-        red[(0 * WR + wr) * 32 * WC + wc * 32 + l31] = keep1;
-        red[(1 * WR + wr) * 32 * WC + wc * 32 + l31] = keep2;
-      }
-    }
-    // ---- the two `part` rows (three barriers the producers attend as well)
-    __syncthreads();
-    if constexpr (STATS) {
-      for (int c = (tid - 256); c < 2 * 32 * WC; c += 256) {
-        const int which = c / (32 * WC), ccol = c % (32 * WC);
-        double sum = 0.0;
-#pragma unroll
-        for (int w = 0; w < WR; ++w) sum += red[(which * WR + w) * 32 * WC + ccol];
-        if (cb + ccol < N && c0 < nchunks)
-          a.part[((size_t)c0 * 2 + which) * N + cb + ccol] = (float)sum;
-      }
-    }
-    __syncthreads();
-    if constexpr (STATS) {
-      if (h == 0) {
-        red[(0 * WR + wr) * 32 * WC + wc * 32 + l31] = d1;
-        red[(1 * WR + wr) * 32 * WC + wc * 32 + l31] = d2;
-      }
-    }
-    __syncthreads();
-    if constexpr (STATS) {
-      for (int c = (tid - 256); c < 2 * 32 * WC; c += 256) {
-        const int which = c / (32 * WC), ccol = c % (32 * WC);
-        double sum = 0.0;
-#pragma unroll
-        for (int w = 0; w < WR; ++w) sum += red[(which * WR + w) * 32 * WC + ccol];
-        if (cb + ccol < N && a.cpw == 2 && c0 + 1 < nchunks)
-          a.part[((size_t)(c0 + 1) * 2 + which) * N + cb + ccol] = (float)sum;
-      }
-    }
-    return;
-  }
-  // (producers: the consumers' three closing barriers)
-  __syncthreads();
-  __syncthreads();
-  __syncthreads();
-}
+// A producer / consumer form of this forward kernel (512 threads: four waves stage, four multiply
+// and run the previous step's epilogue; bit-identical results) was built in round 5 and measured
+// SLOWER on every layer but one (tools/fwd_ws_ab.py, alone on the chip; single-role / two chunks
+// per workgroup / one chunk per workgroup): SA1's pooled layer 706 560 x 128 x 64 with the Y store
+// 160 / 258 / 182 us, without 100 / 172 / 118; SA1's 64-wide layer 72 / 73 / 74; SA2's hidden layer
+// 40 / 37 / 37; SA2's pooled layer 68 / 83 / 90; SA3's 46 / 53 / 71 (profiles/r05_*_fwd_ws_ab.txt).
+// The forward step carries 24 (k = 64) or 48 MFMAs per wave against ~250 VALU instructions of
+// epilogue: it is bound by issue latency with two waves per SIMD either way, and splitting the
+// roles does not add waves -- unlike the pooled layer's backward (72 MFMAs per step), where it
+// does pay (sa_bwd_gram_ws_kernel).  Removed in round 6.
 
 // ---- single-launch inference set-abstraction layer ---------------------------------------------
 // eval mode (module.eval(), pointnet2_modules.py:210-272 under the evaluation pass of
@@ -2972,12 +2631,8 @@ struct FusedArgs {
   const unsigned char *garg;
   const float *gdcl, *galpha, *gbeta;
   int SSH, ldt;
-  // acc != 0: dZ_{l-1} += this launch's product (the second 128-column slab of a 256-wide layer
-  // under BTR_BWD_FUSED_SPLIT=1)
-  int acc;
   // GM 2: layer l's scale, shift, mean, invstd and finalised m1, m2
   const float *sc, *sh, *mu, *is, *m1, *m2;
-  int eager;   // measurement only (BTR_FUSED_EAGER=1)
 };
 
 // TNW = 2 / 4: n <= 64 / 128, two workgroups per CU.  TNW = 8: n <= 256 (the pooled layers of
@@ -3141,11 +2796,6 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
           sp_base[q] = cm.goff[g] - r0;
           sp_arg[q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
           sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
-          if (a.eager) {   // (A/B: BTR_FUSED_EAGER=1 forms the local row here, as before round 5)
-            const int lr = sp_base[q] + sp_arg[q];
-            sp_base[q] = (lr >= 0 && (lr >> 3) == slot) ? lr : -0x40000000;
-            sp_arg[q] = 0;
-          }
         }
         const int nblk = ((r0 + BR) >> 3) + slot;
         sp_ng[q] = (slot < 4 && (nblk << 3) < rend) ? cm.bgrp[nblk] : 0;
@@ -3161,11 +2811,6 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
           sp_base[q] = (g << a.SSH) - r0;
           sp_arg[q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
           sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
-          if (a.eager) {
-            const int lr = sp_base[q] + sp_arg[q];
-            sp_base[q] = (lr >= 0 && lr < BR && r0 + lr < rend) ? lr : -0x40000000;
-            sp_arg[q] = 0;
-          }
         }
       }
     }
@@ -3347,12 +2992,7 @@ __global__ __launch_bounds__(256, TNW == 8 ? 1 : 2) void sa_bwd_fused_kernel(Fus
         const float4 c1 = *reinterpret_cast<const float4 *>(&Cs[BR * LC + row * LC + xc4]);
         const float4 c = make_float4(c0.x + c1.x, c0.y + c1.y, c0.z + c1.z, c0.w + c1.w);
         float *zp = a.Z + (size_t)(r0 + row) * a.ldz + k0 + xc4;
-        if (a.acc) {
-          const float4 o = *reinterpret_cast<const float4 *>(zp);
-          *reinterpret_cast<float4 *>(zp) = make_float4(o.x + c.x, o.y + c.y, o.z + c.z, o.w + c.w);
-        } else {
-          *reinterpret_cast<float4 *>(zp) = c;
-        }
+        *reinterpret_cast<float4 *>(zp) = c;
         const float4 y = ykeep[p];
         const float gx = fmaf(fa.x, y.x, fb.x) > 0.f ? c.x : 0.f;
         const float gy = fmaf(fa.y, y.y, fb.y) > 0.f ? c.y : 0.f;
@@ -3443,7 +3083,6 @@ struct GramArgs {
   const unsigned char *garg;
   const float *gdcl;
   int SSH, ldt;
-  int dbg;   // measurement only (BTR_GRAM_DBG): 1 = consumers idle, 2 = producers idle
 };
 
 
@@ -3462,437 +3101,14 @@ __device__ __forceinline__ bf16x8 tr_read8_swz(const __bf16 *plane, int pitch, i
   return u.b;
 }
 
-// TNW = 2 / 4 / 8: n <= 64 / 128 / 256.  KF = 64 / 128: the layer's k extent (one or two 64-wide
-// k blocks; every workgroup stages all of X's columns and owns one block of dZ / G / sparse^T X).
-template <int TNW, int KF>
-__global__ __launch_bounds__(256, (TNW == 8 || KF == 128) ? 1 : 2) void sa_bwd_gram_kernel(
-    GramArgs a, Compact cm) {
-  constexpr int BR = 32;
-  constexpr int TN = 32 * TNW;
-  constexpr int LG = TN == 256 ? 288 : (TN == 128 ? 160 : 96);   // sparse planes (bf16 pitch)
-  constexpr int LXF = KF == 128 ? 160 : 96;                       // X planes
-  constexpr int LXW = KF + 8;                                     // weighted side rows
-  constexpr int LC = 68;
-  constexpr int KT = TNW >= 4 ? 2 : 1;
-  constexpr int NTW = TNW >= 4 ? TNW / 4 : 1;
-  constexpr int KB = KF / 64;          // k blocks staged
-  constexpr int GT = KF / 64;          // G tiles (32 x 32) per wave
-  int R = a.R, rows_per_chunk = a.rows_per_chunk;
-  if (cm.dims) {
-    R = cm.dims[0];
-    rows_per_chunk = ((R + (int)gridDim.z - 1) / (int)gridDim.z + 31) / 32 * 32;
-  }
-  const int N = a.N, K = a.K;
-  __shared__ __attribute__((aligned(16))) __bf16 Sp[3 * BR * LG];
-  __shared__ __attribute__((aligned(16))) __bf16 Xp[3 * BR * LXF];
-  __shared__ __attribute__((aligned(16))) __bf16 Xw[3 * 4 * LXW];
-  __shared__ __attribute__((aligned(16))) float Cs[2 * BR * LC];
-  // per-column coefficients of layer l-1 (scale, shift of every staged column; mean, invstd and c
-  // of the workgroup's own block): read back 16 bytes at a time where they are used -- as
-  // registers they cost the 128 x 64 variant its second workgroup per CU
-  __shared__ __attribute__((aligned(16))) float Cf[2 * KF + 3 * 64];
-  // (the raw pre-BN values of the own block, from the staging to the epilogue of a step)
-  __shared__ __attribute__((aligned(16))) float Yk[2 * 256 * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = TNW >= 4 ? wave * NTW : (wave >> 1);
-  const int wk = TNW >= 4 ? 0 : (wave & 1);
-  const int l31 = lane & 31, h = lane >> 5;
-  const int k0 = blockIdx.y * 64;
-  const int chunk = blockIdx.z;
-  const int rbeg = chunk * rows_per_chunk;
-  const int rend = min(R, rbeg + rows_per_chunk);
-  const float *__restrict__ X = a.X;
-  const bool cmw = cm.bw != nullptr;   // compact rows: rows = 0 (mod 8) carry a weight
-  for (int i = tid; i < 2 * KF + 3 * 64; i += 256) {
-    float v = 0.f;
-    if (i < 2 * KF) {
-      const int c = i % KF;
-      if (c < K) v = (i < KF ? a.pa : a.pb)[c];
-    } else {
-      const int j = i - 2 * KF, c = k0 + (j & 63);
-      if (c < K) v = (j < 64 ? a.mu_p : (j < 128 ? a.is_p : a.cvec))[c];
-    }
-    Cf[i] = v;
-  }
-
-  // ---- zero the sparse planes once (entries are written and cleared step by step)
-  for (int i = tid; i < 3 * BR * LG / 8; i += 256)
-    reinterpret_cast<float4 *>(Sp)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // ---- resident B operands of the two input-gradient products of this wave: (k half dj of the
-  // block, reduction half dnh): W_l^T rows for the sparse part, M rows for the dense part
-  const int dj = wave & 1, dnh = wave >> 1;
-  bf16x8 bdr[TN / 32][3], mdr[KF / 32][3];
-  {
-    const int kr = k0 + dj * 32 + (lane & 31);
-#pragma unroll
-    for (int kk = 0; kk < TN / 32; ++kk) {
-      const int nb = (dnh * (TN / 32) + kk) * 16 + (lane >> 5) * 8;
-      float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
-      if (kr < K && nb < N) w0 = *reinterpret_cast<const float4 *>(a.Wt + (size_t)kr * a.ldw + nb);
-      if (kr < K && nb + 4 < N)
-        w1 = *reinterpret_cast<const float4 *>(a.Wt + (size_t)kr * a.ldw + nb + 4);
-      const Split4 s0 = split4(w0), s1 = split4(w1);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        bdr[kk][0][e] = s0.h[e]; bdr[kk][0][4 + e] = s1.h[e];
-        bdr[kk][1][e] = s0.m[e]; bdr[kk][1][4 + e] = s1.m[e];
-        bdr[kk][2][e] = s0.l[e]; bdr[kk][2][4 + e] = s1.l[e];
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < KF / 32; ++kk) {
-      const int xb = (dnh * (KF / 32) + kk) * 16 + (lane >> 5) * 8;   // reduction index: x column
-      float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
-      if (kr < K && xb < K) w0 = *reinterpret_cast<const float4 *>(a.M + (size_t)kr * K + xb);
-      if (kr < K && xb + 4 < K) w1 = *reinterpret_cast<const float4 *>(a.M + (size_t)kr * K + xb + 4);
-      const Split4 s0 = split4(w0), s1 = split4(w1);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        mdr[kk][0][e] = s0.h[e]; mdr[kk][0][4 + e] = s1.h[e];
-        mdr[kk][1][e] = s0.m[e]; mdr[kk][1][4 + e] = s1.m[e];
-        mdr[kk][2][e] = s0.l[e]; mdr[kk][2][4 + e] = s1.l[e];
-      }
-    }
-  }
-
-  f32x16 acc[NTW][KT], gacc[GT];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t)
-#pragma unroll
-    for (int q = 0; q < KT; ++q)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[t][q][v] = 0.f;
-#pragma unroll
-  for (int t = 0; t < GT; ++t)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) gacc[t][v] = 0.f;
-
-  // ---- staging: thread -> rows xr, xr + 16, columns kcol(b) .. + 3 of every k block b (b = 0: the
-  // workgroup's own block, whose dZ columns the thread owns in the epilogue)
-  const int xc4 = (tid & 15) * 4, xr = tid >> 4;
-  auto kcol = [&](int b) { return (b == 0 ? k0 : (k0 ^ 64)) + xc4; };
-  auto cf4 = [&](int at) { return *reinterpret_cast<const float4 *>(&Cf[at]); };
-  float4 rx[KB][2];
-  float wx[2] = {1.f, 1.f};
-  const int sp_gi = tid / TN, sp_n = tid % TN;
-  constexpr int SPQ = 4 * TN / 256;
-  // (raw loads; the local row is formed when the step is staged: see sa_bwd_fused_kernel)
-  int sp_g[SPQ], sp_ng[SPQ], sp_base[SPQ], sp_arg[SPQ], cl_lr[SPQ];
-  float sp_dv[SPQ];
-#pragma unroll
-  for (int q = 0; q < SPQ; ++q) {
-    sp_g[q] = sp_ng[q] = 0;
-    sp_base[q] = -0x40000000;
-    sp_arg[q] = 0;
-    cl_lr[q] = -1;
-    sp_dv[q] = 0.f;
-  }
-  auto fetch = [&](int r0) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = xr + 16 * p;
-      wx[p] = 1.f;
-      if (cmw && (row & 7) == 0 && r0 + row < rend) wx[p] = cm.bw[(r0 + row) >> 3];
-#pragma unroll
-      for (int b = 0; b < KB; ++b) {
-        rx[b][p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + row < rend && kcol(b) < K)
-          rx[b][p] = *reinterpret_cast<const float4 *>(X + (size_t)(r0 + row) * a.ldx + kcol(b));
-      }
-    }
-    if (cm.bgrp) {
-#pragma unroll
-      for (int q = 0; q < SPQ; ++q) {
-        const int slot = sp_gi + (256 / TN) * q, blk = (r0 >> 3) + slot;
-        if (r0 != rbeg) sp_g[q] = sp_ng[q];
-        sp_base[q] = -0x40000000;
-        if (slot < 4 && (blk << 3) < rend && sp_n < N) {
-          const int g = sp_g[q];
-          sp_base[q] = cm.goff[g] - r0;
-          sp_arg[q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
-          sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
-        }
-        const int nblk = ((r0 + BR) >> 3) + slot;
-        sp_ng[q] = (slot < 4 && (nblk << 3) < rend) ? cm.bgrp[nblk] : 0;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < SPQ; ++q) {
-        const int slot = sp_gi + (256 / TN) * q;
-        const int g = (r0 >> a.SSH) + slot;
-        sp_base[q] = -0x40000000;
-        if ((slot << a.SSH) < BR && (g << a.SSH) < rend && sp_n < N) {
-          sp_base[q] = (g << a.SSH) - r0;
-          sp_arg[q] = (int)a.garg[(size_t)g * a.ldt + sp_n];
-          sp_dv[q] = a.gdcl[(size_t)g * a.ldt + sp_n];
-        }
-      }
-    }
-  };
-  if (cm.bgrp && rbeg < rend) {
-#pragma unroll
-    for (int q = 0; q < SPQ; ++q) {
-      const int slot = sp_gi + (256 / TN) * q, blk = (rbeg >> 3) + slot;
-      sp_g[q] = (slot < 4 && (blk << 3) < rend) ? cm.bgrp[blk] : 0;
-    }
-  }
-  const int p16 = lane & 15, grp = lane >> 4;
-  const int frow = 8 * (grp >> 1) + (p16 >> 2), fcol = 16 * (grp & 1) + 4 * (p16 & 3);
-  const bool wlane_tr = cmw && (p16 >> 2) == 0;   // transpose reads: this lane's first row is 0 (mod 8)
-  const bool wlane_row = cmw && (l31 & 7) == 0;   // row reads: this lane's row
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, sxa = s1;
-  if (rbeg < rend) fetch(rbeg);
-  __syncthreads();   // (the zeroed sparse planes)
-  for (int r0 = rbeg; r0 < rend; r0 += BR) {
-    // ---- sparse entries of this step: the three pieces of dcl at [local row][n]
-#pragma unroll
-    for (int q = 0; q < SPQ; ++q) {
-      const int slot = sp_gi + (256 / TN) * q;
-      const int lr0 = sp_base[q] + sp_arg[q];
-      const bool hit = cm.bgrp ? (lr0 >= 0 && (lr0 >> 3) == slot)
-                               : (lr0 >= 0 && lr0 < BR && r0 + lr0 < rend);
-      const int lr = hit ? lr0 : -1;
-      cl_lr[q] = lr;
-      if (lr >= 0) {
-        __bf16 eh, em, el;
-        split1(sp_dv[q], eh, em, el);
-        const int at = lr * LG + (swz(lr, sp_n * 2) >> 1);
-        Sp[0 * BR * LG + at] = eh;
-        Sp[1 * BR * LG + at] = em;
-        Sp[2 * BR * LG + at] = el;
-      }
-    }
-    // ---- X = relu(bn(Y_{l-1})): planes, weighted side rows, column sums
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = xr + 16 * p;
-#pragma unroll
-      for (int b = 0; b < KB; ++b) {
-        float4 x = rx[b][p];
-        const bool live = r0 + row < rend && kcol(b) < K;
-        // the raw pre-BN values of layer l-1: the epilogue's mask / xhat
-        if (b == 0) *reinterpret_cast<float4 *>(&Yk[(p * 256 + tid) * 4]) = x;
-        if (live) {
-          const float4 fab = cf4(kcol(b)), fbb = cf4(KF + kcol(b));
-          x.x = fmaxf(fmaf(fab.x, x.x, fbb.x), 0.f);
-          x.y = fmaxf(fmaf(fab.y, x.y, fbb.y), 0.f);
-          x.z = fmaxf(fmaf(fab.z, x.z, fbb.z), 0.f);
-          x.w = fmaxf(fmaf(fab.w, x.w, fbb.w), 0.f);
-        } else {
-          x = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const Split4 sp = split4(x);
-        const int at = row * LXF + (swz(row, kcol(b) * 2) >> 1);
-        *reinterpret_cast<bf16x4 *>(&Xp[0 * BR * LXF + at]) = sp.h;
-        *reinterpret_cast<bf16x4 *>(&Xp[1 * BR * LXF + at]) = sp.m;
-        *reinterpret_cast<bf16x4 *>(&Xp[2 * BR * LXF + at]) = sp.l;
-        const float w = wx[p];
-        if (b == 0) {
-          sxa.x = fmaf(w, x.x, sxa.x); sxa.y = fmaf(w, x.y, sxa.y);
-          sxa.z = fmaf(w, x.z, sxa.z); sxa.w = fmaf(w, x.w, sxa.w);
-        }
-        if (cmw && (row & 7) == 0) {
-          const Split4 sw = split4(make_float4(w * x.x, w * x.y, w * x.z, w * x.w));
-          const int aw = (row >> 3) * LXW + kcol(b);
-          *reinterpret_cast<bf16x4 *>(&Xw[0 * 4 * LXW + aw]) = sw.h;
-          *reinterpret_cast<bf16x4 *>(&Xw[1 * 4 * LXW + aw]) = sw.m;
-          *reinterpret_cast<bf16x4 *>(&Xw[2 * 4 * LXW + aw]) = sw.l;
-        }
-      }
-    }
-    const float wrow0 = wx[0], wrow1 = wx[1];   // (the fetch below overwrites wx)
-    __syncthreads();
-    if (r0 + BR < rend) fetch(r0 + BR);  // next rows in flight during the MFMAs
-    // ---- sparse^T X and G: reductions over the 32 rows (transpose reads).  Two passes, so that
-    // the fragments of one product are dead before the other's are loaded (register budget)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int trow = ks * 16 + frow;
-      {
-        bf16x8 af[3][NTW];
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-          for (int t = 0; t < NTW; ++t)
-            af[q][t] = tr_read8_swz(&Sp[q * BR * LG], LG, trow, (wn + t) * 32 + fcol);
-#pragma unroll
-        for (int t = 0; t < KT; ++t) {   // (one k tile's fragments at a time)
-          bf16x8 bf[3];
-#pragma unroll
-          for (int q = 0; q < 3; ++q)
-            bf[q] = tr_read8_swz(&Xp[q * BR * LXF], LXF, trow, k0 + (wk + t) * 32 + fcol);
-#define BTR_X6(QA, QB)                            \
-  _Pragma("unroll") for (int u = 0; u < NTW; ++u) \
-      acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[QA][u], bf[QB], acc[u][t], 0, 0, 0);
-          BTR_X6(2, 0)
-          BTR_X6(0, 2)
-          BTR_X6(1, 1)
-          BTR_X6(1, 0)
-          BTR_X6(0, 1)
-          BTR_X6(0, 0)
-#undef BTR_X6
-        }
-      }
-      {
-        bf16x8 ga[3][GT], gb[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-#pragma unroll
-          for (int t = 0; t < GT; ++t)
-            ga[q][t] =
-                tr_read8_swz(&Xp[q * BR * LXF], LXF, trow, ((wave >> 1) * GT + t) * 32 + fcol);
-          // B operand of G: weighted rows from the side planes
-          typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
-          const int col = k0 + (wave & 1) * 32 + fcol;
-          const __bf16 *b0 = wlane_tr ? &Xw[(q * 4 + (trow >> 3)) * LXW + col]
-                                      : &Xp[(q * BR + trow) * LXF + (swz(trow, col * 2) >> 1)];
-          const __bf16 *b1 = &Xp[(q * BR + trow + 4) * LXF + (swz(trow + 4, col * 2) >> 1)];
-          union {
-            s16x4 s[2];
-            bf16x8 b;
-          } u;
-          u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b0));
-          u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b1));
-          gb[q] = u.b;
-        }
-#define BTR_X6(QA, QB)                           \
-  _Pragma("unroll") for (int t = 0; t < GT; ++t) \
-      gacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[QA][t], gb[QB], gacc[t], 0, 0, 0);
-        BTR_X6(2, 0)
-        BTR_X6(0, 2)
-        BTR_X6(1, 1)
-        BTR_X6(1, 0)
-        BTR_X6(0, 1)
-        BTR_X6(0, 0)
-#undef BTR_X6
-      }
-    }
-    // ---- input gradient: C[32 rows][32 k of half dj] = sparse W (n half dnh) + (w x) M (x half dnh)
-    {
-      f32x16 cd;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) cd[v] = 0.f;
-#define BTR_X6D(B) \
-      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[2], (B)[0], cd, 0, 0, 0); \
-      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[0], (B)[2], cd, 0, 0, 0); \
-      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[1], (B)[1], cd, 0, 0, 0); \
-      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[1], (B)[0], cd, 0, 0, 0); \
-      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[0], (B)[1], cd, 0, 0, 0); \
-      cd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[0], (B)[0], cd, 0, 0, 0);
-#pragma unroll
-      for (int kk = 0; kk < TN / 32; ++kk) {
-        const int nb = (dnh * (TN / 32) + kk) * 16 + h * 8;   // first of this lane's 8 n
-        bf16x8 ad[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          ad[q] = *reinterpret_cast<const bf16x8 *>(
-              &Sp[(q * BR + l31) * LG + (swz(l31, nb * 2) >> 1)]);
-        BTR_X6D(bdr[kk])
-      }
-#pragma unroll
-      for (int kk = 0; kk < KF / 32; ++kk) {
-        const int xb = (dnh * (KF / 32) + kk) * 16 + h * 8;   // first of this lane's 8 x columns
-        bf16x8 ad[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          ad[q] = *reinterpret_cast<const bf16x8 *>(
-              wlane_row ? &Xw[(q * 4 + (l31 >> 3)) * LXW + xb]
-                        : &Xp[(q * BR + l31) * LXF + (swz(l31, xb * 2) >> 1)]);
-        BTR_X6D(mdr[kk])
-      }
-#undef BTR_X6D
-      float *T = Cs + dnh * (BR * LC);
-#pragma unroll
-      for (int v = 0; v < 16; ++v)
-        T[((v & 3) + 8 * (v >> 2) + 4 * h) * LC + dj * 32 + l31] = cd[v];
-    }
-    __syncthreads();
-    // ---- epilogue: the thread that staged X[row][k0 + xc4..] owns dZ[row][k0 + xc4..]
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = xr + 16 * p;
-      if (r0 + row < rend && k0 + xc4 < K) {
-        const float wr = p == 0 ? wrow0 : wrow1;
-        const float4 c0 = *reinterpret_cast<const float4 *>(&Cs[row * LC + xc4]);
-        const float4 c1 = *reinterpret_cast<const float4 *>(&Cs[BR * LC + row * LC + xc4]);
-        const float4 cv = cf4(2 * KF + 128 + xc4), fmu = cf4(2 * KF + xc4);
-        const float4 fis = cf4(2 * KF + 64 + xc4);
-        const float4 fa0 = cf4(k0 + xc4), fb0 = cf4(KF + k0 + xc4);
-        const float4 c = make_float4(fmaf(wr, cv.x, c0.x + c1.x), fmaf(wr, cv.y, c0.y + c1.y),
-                                     fmaf(wr, cv.z, c0.z + c1.z), fmaf(wr, cv.w, c0.w + c1.w));
-        *reinterpret_cast<float4 *>(a.Z + (size_t)(r0 + row) * a.ldz + k0 + xc4) = c;
-        const float4 y = *reinterpret_cast<const float4 *>(&Yk[(p * 256 + tid) * 4]);
-        const float gx = fmaf(fa0.x, y.x, fb0.x) > 0.f ? c.x : 0.f;
-        const float gy = fmaf(fa0.y, y.y, fb0.y) > 0.f ? c.y : 0.f;
-        const float gz = fmaf(fa0.z, y.z, fb0.z) > 0.f ? c.z : 0.f;
-        const float gw = fmaf(fa0.w, y.w, fb0.w) > 0.f ? c.w : 0.f;
-        s1.x += gx; s1.y += gy; s1.z += gz; s1.w += gw;
-        s2.x = fmaf(gx, (y.x - fmu.x) * fis.x, s2.x);
-        s2.y = fmaf(gy, (y.y - fmu.y) * fis.y, s2.y);
-        s2.z = fmaf(gz, (y.z - fmu.z) * fis.z, s2.z);
-        s2.w = fmaf(gw, (y.w - fmu.w) * fis.w, s2.w);
-      }
-    }
-    // ---- the sparse planes go back to zero (every wave is past its MFMA reads: the barrier above)
-#pragma unroll
-    for (int q = 0; q < SPQ; ++q)
-      if (cl_lr[q] >= 0) {
-        const int at = cl_lr[q] * LG + (swz(cl_lr[q], sp_n * 2) >> 1);
-        const __bf16 z = (__bf16)0.f;
-        Sp[0 * BR * LG + at] = z;
-        Sp[1 * BR * LG + at] = z;
-        Sp[2 * BR * LG + at] = z;
-      }
-  }
-  // ---- partials of this chunk: sparse^T X
-  {
-    float *out = a.pw + (size_t)chunk * N * K;
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-#pragma unroll
-      for (int q = 0; q < KT; ++q) {
-        const int col = k0 + (wk + q) * 32 + l31;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int row = (wn + t) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-          if (row < N && col < K) out[(size_t)row * K + col] = acc[t][q][v];
-        }
-      }
-  }
-  // ---- ... G block [K][64 of this workgroup]
-  {
-    float *out = a.gp + (size_t)chunk * K * K;
-    const int col = k0 + (wave & 1) * 32 + l31;
-#pragma unroll
-    for (int t = 0; t < GT; ++t)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int row = ((wave >> 1) * GT + t) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (row < K && col < K) out[(size_t)row * K + col] = gacc[t][v];
-      }
-  }
-  // ---- ... and the column sums: 16 row-threads per k column group, fixed order
-  __syncthreads();
-  float *red = Cs;   // [3][16 row threads][64 k]
-  *reinterpret_cast<float4 *>(&red[(0 * 16 + xr) * 64 + xc4]) = s1;
-  *reinterpret_cast<float4 *>(&red[(1 * 16 + xr) * 64 + xc4]) = s2;
-  *reinterpret_cast<float4 *>(&red[(2 * 16 + xr) * 64 + xc4]) = sxa;
-  __syncthreads();
-  if (tid < 192) {
-    const int which = tid >> 6, c = tid & 63;
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t += red[(which * 16 + q) * 64 + c];
-    if (k0 + c < K) {
-      if (which < 2) a.spart[((size_t)chunk * 2 + which) * K + k0 + c] = t;
-      else a.sxp[(size_t)chunk * K + k0 + c] = t;
-    }
-  }
-}
+// (A first, single-role form of the kernel -- 256 threads, every wave staging, multiplying and
+// finishing in turn, n <= 256 and k <= 128 -- equalled sa_bwd_fused_kernel at every shape: SA1's
+// pooled layer 266 us in Gram form against 270 us reading twice as much, 198 / 133 / 92 us against
+// 185 / 114 / 70 us at SA2 - SA4's 256 x 128, where its helper launches made it a net loss
+// (profiles/r05_h_bwd_gram_ab.txt).  Removed in round 6; the form below is the one that ships.)
 
 // ---- ... with producer and consumer waves -------------------------------------------------------
-// sa_bwd_gram_kernel above, like sa_bwd_fused_kernel, runs its three phases -- staging (VALU),
+// The single-role form, like sa_bwd_fused_kernel, ran its three phases -- staging (VALU),
 // products (LDS reads + MFMA), epilogue (VALU + stores) -- one after the other in every wave, two
 // barriers per 32-row step, and leaves it to the second workgroup of the CU to fill the gaps:
 // both forms need ~12 500 cycles per pair of steps for 4 600 cycles of MFMA issue, whatever the
@@ -4116,11 +3332,6 @@ __global__ __launch_bounds__(512, 1) void sa_bwd_gram_ws_kernel(GramArgs a, Comp
     __syncthreads();
     for (int i = 0; i < nsteps2; i += 2) {
       const int r0 = rbeg + i * BR;
-      if (a.dbg == 2) {
-        __syncthreads();
-        __syncthreads();
-        continue;
-      }
       // iteration i (even): consumers work on buffer 0
       if (i >= 1) epilogue(P1, r0 - BR);
       stage(P1, r0 + BR);
@@ -4301,11 +3512,6 @@ __global__ __launch_bounds__(512, 1) void sa_bwd_gram_ws_kernel(GramArgs a, Comp
     };
     __syncthreads();   // (the producers' first planes)
     for (int i = 0; i < nsteps2; i += 2) {
-      if (a.dbg == 1) {
-        __syncthreads();
-        __syncthreads();
-        continue;
-      }
       step(P0);
       __syncthreads();
       step(P1);
@@ -5452,17 +4658,8 @@ inline bool gemm_x6() {
   static const bool on = !(getenv("BTR_GEMM") && getenv("BTR_GEMM")[0] == 'f');
   return on;
 }
-// BTR_GEMM_TN=f32: the f32-input kernel for the plain weight-gradient GEMM only
-inline bool tn_x6() {
-  static const bool on = !(getenv("BTR_GEMM_TN") && getenv("BTR_GEMM_TN")[0] == 'f');
-  return on && gemm_x6();
-}
-// BTR_GEMM_TN_POOL=f32: the f32-input kernel for the pooled-gradient / first-layer-recompute
-// weight-gradient GEMMs only
-inline bool tn_pool_x6() {
-  static const bool on = !(getenv("BTR_GEMM_TN_POOL") && getenv("BTR_GEMM_TN_POOL")[0] == 'f');
-  return on && tn_x6();
-}
+inline bool tn_x6() { return gemm_x6(); }        // the plain weight-gradient GEMM
+inline bool tn_pool_x6() { return gemm_x6(); }   // the pooled-gradient / first-layer-recompute ones
 
 template <int W, bool P, bool GP, bool XR>
 inline void launch_tn(bool x6, dim3 grid, hipStream_t st, const float *g, int ldg, const float *x,
@@ -5488,10 +4685,9 @@ bool bnfin_rows_ok(long long rows) {
 }
 bool bnfin_arm(const BnFin &fin, long long rows) {
   if (!fin.ticket || !bnfin_rows_ok(rows)) return false;
-  static const int fence = getenv("BTR_BN_TICKET_FENCE") && getenv("BTR_BN_TICKET_FENCE")[0] == '1';
   HostBnFin &h = host_bnfin();
   h.fin = fin;
-  h.fin.fence = fence;
+  h.fin.fence = 0;   // (1: full fences around the ticket; same results, r05 A/B: +9 - 12 us per GEMM)
   h.on = true;
   return true;
 }
@@ -5503,42 +4699,15 @@ bool bnfin_arm(const BnFin &fin, long long rows) {
 // ticket path covers the tiny layers, and a streaming grid of few steps gains nothing).
 namespace btr {
 constexpr int kStreamMinRows = 16384;
-// BTR_FWD_STREAM_WIDE=0: only what the first form took (n <= 128, 8-row pooling blocks)
-static bool stream_wide() {
-  const char *e = getenv("BTR_FWD_STREAM_WIDE");
-  return !(e && e[0] == '0');
-}
 static bool stream_ok(int rows, int n, int k, int lda_ok, bool fin_armed) {
   const char *e = getenv("BTR_FWD_STREAM");   // (read per call: tests and A/B runs toggle it)
   const bool off = e && e[0] == '0';
   return !off && gemm_x6() && !fin_armed && lda_ok && rows >= kStreamMinRows && n % 4 == 0 &&
-         k % 4 == 0 && n <= (stream_wide() ? 256 : 128) && k <= 128 && !host_compact().dev.kz;
-}
-// BTR_FWD_WS=0: the single-role kernel for every layer (read per call: the tests compare the two)
-// MEASURED AND NOT ADOPTED (tools/fwd_ws_ab.py, same box, alone on the chip; single-role /
-// two chunks per workgroup / one chunk per workgroup): SA1's pooled layer 706 560 x 128 x 64 with
-// the Y store 160 / 258 / 182 us, without 100 / 172 / 118; SA1's 64-wide layer 72 / 73 / 74; SA2's
-// hidden layer 40 / 37 / 37; SA2's pooled layer 68 / 83 / 90; SA3's 46 / 53 / 71.  The forward
-// step carries 24 (k = 64) or 48 MFMAs per wave against ~250 VALU instructions of epilogue: it
-// is bound by issue latency with two waves per SIMD either way, and splitting the roles does not
-// add waves -- unlike the pooled layer's backward (72 MFMAs per step), where it does pay.
-// BTR_FWD_WS=1 / 2 select it; bit-identical results (tests/test_fwd_stream_gpu.py).
-static int fwd_ws() {
-  const char *e = getenv("BTR_FWD_WS");
-  return e ? atoi(e) : 0;
+         k % 4 == 0 && n <= 256 && k <= 128 && !host_compact().dev.kz;
 }
 template <int BR, int KMAX, int PRO, bool STATS, int PS>
 static void launch_stream(int gx, hipStream_t st, StreamArgs &a) {
   a.rows_per_chunk = cdiv(cdiv(a.R, gx), BR) * BR;
-  a.nchunks = gx;
-  if constexpr (STATS) {   // (the producer / consumer form: the layers' forward GEMMs)
-    if (fwd_ws()) {
-      a.cpw = fwd_ws() == 2 ? 1 : 2;
-      hipLaunchKernelGGL((sa_fwd_ws_kernel<BR, KMAX, PRO, STATS, PS>),
-                         dim3(cdiv(gx, a.cpw) << a.hs), dim3(512), 0, st, a, cur_compact());
-      return;
-    }
-  }
   hipLaunchKernelGGL((sa_fwd_stream_kernel<BR, KMAX, PRO, STATS, PS>), dim3(gx << a.hs), dim3(256),
                      0, st, a, cur_compact());
 }
@@ -5614,29 +4783,15 @@ static int ilog2(int v) {
 }
 
 // Number of workgroups (= rows of the `part` buffer) btr_sa_gemm_nt uses along rows.
-// BTR_GRID_ROUNDS = r (default 1): the row-chunked kernels launch r rounds of resident workgroups
-// instead of one -- smaller chunks the dispatcher hands to whichever CU frees up first, against
-// workgroups that share their CU with another stream's waves (the large-scene FPS) holding up
-// the whole launch
-static int grid_rounds() {
-  static const int r = [] {
-    const char *e = getenv("BTR_GRID_ROUNDS");
-    const int v = e ? atoi(e) : 1;
-    return v >= 1 && v <= 4 ? v : 1;
-  }();
-  return r;
-}
-static int gemm_wgs_per_cu() {   // BTR_GEMM_WGS_PER_CU (default 2): row chunks per CU of the NT kernels
-  static const int v = [] {
-    const char *e = getenv("BTR_GEMM_WGS_PER_CU");
-    const int x = e ? atoi(e) : 2;
-    return x >= 1 && x <= 8 ? x : 2;
-  }();
-  return v;
-}
+// One round of resident workgroups per launch, two row chunks per CU for the NT kernels (round 4,
+// same box: two / four rounds of smaller chunks helped the forward beside the pyramid by 34 us and
+// cost the backward more in partial sums, 4.58 -> 4.65 / 4.83 ms; three / four chunks per CU 4.11 /
+// 4.04 vs 3.98 ms).
+static constexpr int grid_rounds() { return 1; }
+static constexpr int gemm_wgs_per_cu() { return 2; }
 int btr_sa_gemm_grid(int rows) {
   return std::max(1, std::min(cdiv(rows, kBM),
-                              gemm_wgs_per_cu() * cu_mask_avail_cus() * grid_rounds()));
+                              gemm_wgs_per_cu() * grid_cus() * grid_rounds()));
 }
 
 // Whether the last layer's GEMM can emit the per-group extrema itself (pooling epilogue):
@@ -5699,7 +4854,7 @@ int btr_sa_bn_finalize(int n, int nblk, double count, float eps, float momentum,
 // c == NULL is accepted by btr_sa_gemm_nt_poolfwd exactly when this returns 1 (s: 8 for compact
 // rows' block extrema, else the group size; no in-kernel BatchNorm finalisation armed)
 int btr_sa_gemm_nt_poolfwd_nostore_supported(int rows, int n, int k, int s) {
-  if (!(s == 8 || (s == 16 && stream_wide())) || !stream_ok(rows, n, k, true, false)) return 0;
+  if (!(s == 8 || s == 16) || !stream_ok(rows, n, k, true, false)) return 0;
   if (n <= 64) return 0;            // (the instantiated streaming variants: try_stream)
   return s == 8 ? 1 : (k > 64 ? 1 : 0);
 }
@@ -5722,7 +4877,7 @@ int btr_sa_gemm_nt_poolfwd(int rows, int n, int k, const float *a, int lda, cons
   const int gx = btr_sa_gemm_grid(rows);
   hipStream_t st = as_stream(stream);
   const BnFin fin = take_bnfin();
-  if ((s == 8 || (s == 16 && stream_wide())) && stream_ok(rows, n, k, lda % 4 == 0, fin.ticket != nullptr) &&
+  if ((s == 8 || s == 16) && stream_ok(rows, n, k, lda % 4 == 0, fin.ticket != nullptr) &&
       try_stream(rows, n, k, a, lda, w, ldw, c, ldc, pa, pb, nullptr, part, s, gamma, gext, aext, 1,
                  st))
     return check_launch("sa_gemm_nt_poolfwd(stream)");
@@ -5893,21 +5048,17 @@ static int tn_tile_n(int n) { return n >= 128 ? 128 : 64; }
 
 int btr_sa_gemm_tn_chunks(int rows, int n, int k) {
   const int tiles = cdiv(n, tn_tile_n(n)) * cdiv(k, 64);
-  // two workgroups per CU in flight (BTR_TN_WGS_PER_CU; four until the weight gradients moved to
-  // the caller's stream: half the partials to write and reduce, same box 4.10 -> 4.02 ms per step;
-  // three 4.00, one 4.54 -- the fused backward's chunk count is capped by this one)
-  static const int per_cu = [] {
-    const char *e = getenv("BTR_TN_WGS_PER_CU");
-    const int v = e ? atoi(e) : 2;
-    return v >= 1 && v <= 8 ? v : 2;
-  }();
-  const int flight = per_cu * cu_mask_avail_cus() * grid_rounds();
+  // two workgroups per CU in flight (four until the weight gradients moved to the caller's
+  // stream: half the partials to write and reduce, same box 4.10 -> 4.02 ms per step; three 4.00,
+  // one 4.54 -- the fused backward's chunk count is capped by this one)
+  constexpr int per_cu = 2;
+  const int flight = per_cu * grid_cus() * grid_rounds();
   int chunks = std::max(1, std::min(flight / tiles, flight));
   // a workgroup (alone on its CU in these launches: one wave per SIMD, nothing to overlap with)
   // spends ~1.3 us per 32-row step: few-row GEMMs (the 1024-row decoder / head layers: 8 steps
   // per workgroup, 14 us) get chunks of down to 64 rows as long as the partials stay small
   // (<= 16 MB to write and reduce)
-  static const int min_rows = getenv("BTR_TN_CHUNK_ROWS") ? atoi(getenv("BTR_TN_CHUNK_ROWS")) : 64;
+  constexpr int min_rows = 64;
   const long long by_mem = std::max<long long>(4, (4ll << 20) / ((long long)n * k));
   const long long by_rows = std::max(1, rows / std::max(min_rows, 32));
   const long long cap = std::min<long long>(by_rows, std::max<long long>(by_mem, rows / 256));
@@ -6117,42 +5268,28 @@ int btr_sa_bn_relu_bwd_apply(long long rows, int c, int ld, float *g, const floa
 // x [rows][4] and w0 [k][4] when w0 != NULL (first-layer recompute).
 int btr_sa_bwd_fused_supported(int rows, int n, int k) {
   static const bool off = getenv("BTR_BWD_FUSED") && getenv("BTR_BWD_FUSED")[0] == '0';
-  // (n > 128: the one-workgroup-per-CU variant; BTR_BWD_FUSED_WIDE=0 keeps those layers on the
-  // separate calls)
-  static const bool wide_off =
-      getenv("BTR_BWD_FUSED_WIDE") && getenv("BTR_BWD_FUSED_WIDE")[0] == '0';
-  return !off && gemm_x6() && tn_pool_x6() && rows > 0 && n >= 32 && n <= (wide_off ? 128 : 256) &&
-         n % 4 == 0 && k >= 4 && k <= 512 && k % 4 == 0;
+  // (n > 128: the one-workgroup-per-CU variant)
+  return !off && gemm_x6() && rows > 0 && n >= 32 && n <= 256 && n % 4 == 0 && k >= 4 &&
+         k <= 512 && k % 4 == 0;
 }
 
-// BTR_BWD_FUSED_SPLIT=1 (measured, NOT the default): n > 128 as two launches of the 128-column
-// variant over the column slabs [0, 128) and [128, n) instead of one launch of the 256-column
-// variant (490 registers, one workgroup of four waves per CU: SA2's pooled layer moves its 233 MB
-// at 1.2 TB/s).  The weight gradient splits by rows of dW, the BatchNorm sums are linear in dZ
-// (each slab adds its own partial rows), and the second slab adds its product onto the first
-// one's dZ.  Same box, 20 steps: one launch 4.00 ms per step, two launches 4.05 (the second slab
-// re-reads X and dZ; with float atomics for the add instead of load + store: 4.31).
-static bool fused_split(int n) {
-  static const bool on =
-      getenv("BTR_BWD_FUSED_SPLIT") && getenv("BTR_BWD_FUSED_SPLIT")[0] == '1';
-  return n > 128 && on;
-}
-// row chunks of ONE launch
+// (n > 128 as two launches of the 128-column variant over column slabs instead of one launch of
+// the 256-column variant -- 490 registers, one workgroup of four waves per CU: SA2's pooled layer
+// moves its 233 MB at 1.2 TB/s -- was measured in round 4: one launch 4.00 ms per step, two
+// launches 4.05 (the second slab re-reads X and dZ; with float atomics for the add 4.31).  Removed.)
 static int fused_pass_chunks(int rows, int n, int k) {
   // one round of resident workgroups: the CUs x (2 workgroups per CU; the 256-column variant: one)
   // over the 64-wide k blocks -- more chunks only add partials to write and reduce and a second,
   // half-empty round
-  const int np = fused_split(n) ? 128 : n;
-  const int resident = cu_mask_avail_cus() * (np > 128 ? 1 : 2) * grid_rounds();
+  const int np = n;
+  const int resident = grid_cus() * (np > 128 ? 1 : 2) * grid_rounds();
   const int kblocks = (k + 63) / 64;
   const int want = std::max(32, resident / kblocks);
   return std::max(1, std::min(std::min(want, kFusedMaxChunks * grid_rounds()),
                               btr_sa_gemm_tn_chunks(rows, np, k)));
 }
-// Rows of `spart` ([.][2][k]) and chunk count `pw` ([.][n][k]) is sized for: both slabs' rows.
-int btr_sa_bwd_fused_chunks(int rows, int n, int k) {
-  return fused_pass_chunks(rows, n, k) * (fused_split(n) ? 2 : 1);
-}
+// Rows of `spart` ([.][2][k]) and chunk count `pw` ([.][n][k]) is sized for.
+int btr_sa_bwd_fused_chunks(int rows, int n, int k) { return fused_pass_chunks(rows, n, k); }
 
 int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const float *yl,
                      const float *sc, const float *sh, const float *mu, const float *is,
@@ -6181,7 +5318,6 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
   BTR_REQUIRE(n <= 128 || !w0, "sa_bwd_fused: first-layer recompute behind %d > 128 columns", n);
   hipStream_t st = as_stream(stream);
   const int chunks = fused_pass_chunks(rows, n, k);
-  const int passes = fused_split(n) ? 2 : 1;
   FusedArgs a{};
   a.G = g; a.Yl = yl; a.ldg = ldg; a.X = x; a.ldx = ldx; a.R = rows; a.N = n; a.K = k;
   a.rows_per_chunk = cdiv(cdiv(rows, chunks), 32) * 32;
@@ -6189,50 +5325,24 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
   a.Z = dz; a.ldz = ldz; a.pw = pw; a.spart = spart;
   a.garg = arg; a.gdcl = dcl; a.galpha = alpha; a.gbeta = beta; a.SSH = pooled ? ilog2(s) : 0;
   a.ldt = n;
-  {
-    const char *e = getenv("BTR_FUSED_EAGER");
-    a.eager = e && e[0] == '1';
-  }
   a.sc = sc; a.sh = sh; a.mu = mu; a.is = is; a.m1 = m1l; a.m2 = m2l;
   const dim3 grid(1, cdiv(k, 64), chunks);
 #define BTR_FUSED(W, GM, XR) \
   hipLaunchKernelGGL((sa_bwd_fused_kernel<W, GM, XR>), grid, dim3(256), 0, st, a, cur_compact())
-  for (int pass = 0; pass < passes; ++pass) {
-    // the column slab of this launch: every per-column operand moves n0 columns on
-    const int n0 = pass * 128, np = passes == 1 ? n : std::min(128, n - n0);
-    a.N = np;
-    a.G = g + n0;
-    a.Yl = yl ? yl + n0 : nullptr;
-    a.Wt = wt + n0;
-    a.garg = arg ? arg + n0 : nullptr;
-    a.gdcl = dcl ? dcl + n0 : nullptr;
-    a.galpha = alpha ? alpha + n0 : nullptr;
-    a.gbeta = beta ? beta + n0 : nullptr;
-    a.sc = sc ? sc + n0 : nullptr; a.sh = sh ? sh + n0 : nullptr;
-    a.mu = mu ? mu + n0 : nullptr; a.is = is ? is + n0 : nullptr;
-    a.m1 = m1l ? m1l + n0 : nullptr; a.m2 = m2l ? m2l + n0 : nullptr;
-    a.pw = pw + (size_t)pass * chunks * 128 * k;            // [chunks][np][k]
-    a.spart = spart + (size_t)pass * chunks * 2 * k;        // rows pass * chunks ..
-    a.acc = pass;
-    if (np > 128) {   // (no first-layer recompute behind a 256-wide layer: w0 is refused above)
-      if (pooled) BTR_FUSED(8, 1, false); else BTR_FUSED(8, 2, false);
-    } else if (np > 64) {
-      if (pooled) { if (w0) BTR_FUSED(4, 1, true); else BTR_FUSED(4, 1, false); }
-      else        { if (w0) BTR_FUSED(4, 2, true); else BTR_FUSED(4, 2, false); }
-    } else {
-      if (pooled) { if (w0) BTR_FUSED(2, 1, true); else BTR_FUSED(2, 1, false); }
-      else        { if (w0) BTR_FUSED(2, 2, true); else BTR_FUSED(2, 2, false); }
-    }
+  if (n > 128) {   // (no first-layer recompute behind a 256-wide layer: w0 is refused above)
+    if (pooled) BTR_FUSED(8, 1, false); else BTR_FUSED(8, 2, false);
+  } else if (n > 64) {
+    if (pooled) { if (w0) BTR_FUSED(4, 1, true); else BTR_FUSED(4, 1, false); }
+    else        { if (w0) BTR_FUSED(4, 2, true); else BTR_FUSED(4, 2, false); }
+  } else {
+    if (pooled) { if (w0) BTR_FUSED(2, 1, true); else BTR_FUSED(2, 1, false); }
+    else        { if (w0) BTR_FUSED(2, 2, true); else BTR_FUSED(2, 2, false); }
   }
 #undef BTR_FUSED
   const double count = host_compact().on ? host_compact().count : (double)rows;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(k, kRedCh)), dim3(256), 0, st, k,
-                     chunks * passes, count, spart, m1, m2, dgamma, dbeta);
-  for (int pass = 0; pass < passes; ++pass) {
-    const int n0 = pass * 128, np = passes == 1 ? n : std::min(128, n - n0);
-    reduce_chunks_launch(np * k, chunks, pw + (size_t)pass * chunks * 128 * k, dw + (size_t)n0 * k,
-                         st);
-  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(k, kRedCh)), dim3(256), 0, st, k, chunks,
+                     count, spart, m1, m2, dgamma, dbeta);
+  reduce_chunks_launch(n * k, chunks, pw, dw, st);
   return check_launch("sa_bwd_fused");
 }
 
@@ -6242,38 +5352,27 @@ int btr_sa_bwd_fused(int rows, int n, int k, const float *g, int ldg, const floa
 // w = W_l [n][k] (row-major, leading dimension k), wt = W_l^T [k][ldw]; arg / dcl / alpha / beta:
 // what btr_sa_pool_bwd_coef left.  pw: [btr_sa_bwd_gram_chunks()][n][k] floats, gscratch:
 // btr_sa_bwd_gram_scratch_floats() floats, spart: [chunks][2][k].
-// the producer / consumer form (sa_bwd_gram_ws_kernel): n <= 128, k <= 64; BTR_GRAM_WS=0: never
-static bool gram_ws(int n, int k) {
-  const char *e = getenv("BTR_GRAM_WS");
-  return n <= 128 && k <= 64 && !(e && e[0] == '0');
-}
+// the shapes of the producer / consumer kernel (sa_bwd_gram_ws_kernel)
+static bool gram_ws(int n, int k) { return n <= 128 && k <= 64; }
 static int gram_chunks(int rows, int n, int k);
 int btr_sa_bwd_gram_supported(int rows, int n, int k) {
   const char *e = getenv("BTR_POOL_GRAM");   // (read per call: the tests toggle it)
   const bool off = e && e[0] == '0';
-  // default: the shapes of the producer / consumer kernel (n <= 128, k <= 64: SA1's pooled layer);
-  // BTR_POOL_GRAM=2: every shape the single-role kernel covers as well (k <= 128) -- measured
-  // equal to the Y_l-reading form there (tools/bwd_gram_ab.py), so only the forward's store is won
-  const bool all = e && e[0] == '2';
-  if (off || !btr_sa_bwd_fused_supported(rows, n, k) || k > 128 || fused_split(n) ||
-      !(all || gram_ws(n, k)))
-    return 0;
-  // the producer / consumer kernel keeps a chunk's block -> group table in LDS: beyond
-  // kFusedMaxChunks * grid_rounds() chunks of 8 * kGramWsMaxBlocks rows the plan must keep the
-  // Y_l-reading form (the same arithmetic as the BTR_REQUIRE in btr_sa_bwd_gram)
-  if (gram_ws(n, k)) {
-    const int chunks = gram_chunks(rows, n, k);
-    if (cdiv(cdiv(rows, chunks), 32) * 32 > 8 * kGramWsMaxBlocks) return 0;
-  }
+  // the shapes of the producer / consumer kernel (n <= 128, k <= 64: SA1's pooled layer)
+  if (off || !btr_sa_bwd_fused_supported(rows, n, k) || !gram_ws(n, k)) return 0;
+  // the kernel keeps a chunk's block -> group table in LDS: beyond kFusedMaxChunks chunks of
+  // 8 * kGramWsMaxBlocks rows the plan must keep the Y_l-reading form (the same arithmetic as the
+  // BTR_REQUIRE in btr_sa_bwd_gram)
+  const int chunks = gram_chunks(rows, n, k);
+  if (cdiv(cdiv(rows, chunks), 32) * 32 > 8 * kGramWsMaxBlocks) return 0;
   return 1;
 }
 static int gram_chunks(int rows, int n, int k) {
-  const int per_cu = (n > 128 || k > 64 || gram_ws(n, k)) ? 1 : 2;
-  const int resident = cu_mask_avail_cus() * per_cu * grid_rounds();
+  const int resident = grid_cus() * grid_rounds();   // one 512-thread workgroup per CU
   const int kblocks = (k + 63) / 64;
   int want = std::max(32, resident / kblocks);
-  // (the producer / consumer form keeps a chunk's block -> group table in LDS)
-  if (gram_ws(n, k)) want = std::max(want, cdiv(rows, 8 * kGramWsMaxBlocks - 64));
+  // (a chunk's block -> group table lives in LDS)
+  want = std::max(want, cdiv(rows, 8 * kGramWsMaxBlocks - 64));
   return std::max(1, std::min(std::min(want, kFusedMaxChunks * grid_rounds()), cdiv(rows, 32)));
 }
 int btr_sa_bwd_gram_chunks(int rows, int n, int k) { return gram_chunks(rows, n, k); }
@@ -6301,7 +5400,7 @@ int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float
               "sa_bwd_gram: nsample %d must be 16, 32, 64 or 128", s);
   hipStream_t st = as_stream(stream);
   const int chunks = gram_chunks(rows, n, k);
-  BTR_REQUIRE(!gram_ws(n, k) || cdiv(cdiv(rows, chunks), 32) * 32 <= 8 * kGramWsMaxBlocks,
+  BTR_REQUIRE(cdiv(cdiv(rows, chunks), 32) * 32 <= 8 * kGramWsMaxBlocks,
               "sa_bwd_gram: %d rows in %d chunks exceed the block table", rows, chunks);
   const size_t kk = (size_t)k * k;
   float *M = gscratch, *cvec = M + kk, *gp = cvec + k, *sxp = gp + (size_t)chunks * kk;
@@ -6316,24 +5415,11 @@ int btr_sa_bwd_gram(int rows, int n, int k, const float *x, int ldx, const float
   a.pa = pa; a.pb = pb; a.mu_p = mu_p; a.is_p = is_p; a.Wt = wt; a.ldw = ldw; a.M = M;
   a.cvec = cvec; a.Z = dz; a.ldz = ldz; a.pw = pw; a.gp = gp; a.sxp = sxp; a.spart = spart;
   a.garg = arg; a.gdcl = dcl; a.SSH = ilog2(s); a.ldt = n;
-  {
-    const char *e = getenv("BTR_GRAM_DBG");
-    a.dbg = e ? atoi(e) : 0;
-  }
   const dim3 grid(1, cdiv(k, 64), chunks);
-#define BTR_GRAM(W, KF) \
-  hipLaunchKernelGGL((sa_bwd_gram_kernel<W, KF>), grid, dim3(256), 0, st, a, cur_compact())
-  if (gram_ws(n, k)) {
-    if (n > 64)
-      hipLaunchKernelGGL((sa_bwd_gram_ws_kernel<4>), grid, dim3(512), 0, st, a, cur_compact());
-    else
-      hipLaunchKernelGGL((sa_bwd_gram_ws_kernel<2>), grid, dim3(512), 0, st, a, cur_compact());
-  } else if (k <= 64) {
-    if (n > 128) BTR_GRAM(8, 64); else if (n > 64) BTR_GRAM(4, 64); else BTR_GRAM(2, 64);
-  } else {
-    if (n > 128) BTR_GRAM(8, 128); else if (n > 64) BTR_GRAM(4, 128); else BTR_GRAM(2, 128);
-  }
-#undef BTR_GRAM
+  if (n > 64)
+    hipLaunchKernelGGL((sa_bwd_gram_ws_kernel<4>), grid, dim3(512), 0, st, a, cur_compact());
+  else
+    hipLaunchKernelGGL((sa_bwd_gram_ws_kernel<2>), grid, dim3(512), 0, st, a, cur_compact());
   const double count = host_compact().on ? host_compact().count : (double)rows;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(k, kRedCh)), dim3(256), 0, st, k, chunks,
                      count, spart, m1, m2, dgamma, dbeta);
@@ -6724,7 +5810,7 @@ extern "C" {
 // gemm_nt_kernel's row-tile workgroups (64-row tiles, grid-stride)
 static int pm_tiles64_grid(int rows) {
   return std::max(1, std::min(cdiv(rows, 64),
-                              gemm_wgs_per_cu() * cu_mask_avail_cus() * grid_rounds()));
+                              gemm_wgs_per_cu() * grid_cus() * grid_rounds()));
 }
 // the small-M kernel (gemm_nt_sm_kernel): few rows, k in at most two staged chunks;
 // BTR_PM_SM=0: never (read per call: the tests compare the two kernels)

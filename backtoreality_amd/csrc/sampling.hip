@@ -618,22 +618,10 @@ static bool fps_force_stream() {
   return e && e[0] == 's' && e[1] == 't';  // "stream" ("single" selects a bucket variant)
 }
 
-// BTR_FPS_REGS=legacy keeps the first register-resident kernel (A/B); BTR_FPS_REGS_NW=1|4|8|16
-// overrides the number of waves per scene.
-static bool fps_regs_legacy() {
-  const char *e = getenv("BTR_FPS_REGS");
-  return e && e[0] == 'l';
-}
-
-static int fps_regs_waves(int n) {
-  int nw = n <= 512 ? 1 : 4;  // measured: tools/fps_small_ab.py
-  if (const char *e = getenv("BTR_FPS_REGS_NW")) {
-    const int v = atoi(e);
-    if (v == 1 || v == 4 || v == 8 || v == 16) nw = v;
-  }
-  if (nw == 1 && n > 1024) nw = 4;  // one wave holds at most 16 points per lane
-  return nw;
-}
+// waves per scene of the register-resident kernel (measured, tools/fps_small_ab.py: one wave up
+// to 512 points, four above -- 8 waves would be 3 % / 13 % faster at n = 2 048 / 4 096 and slower
+// below; a single-wave form of the 1 024-point level measured 355 vs 221 us)
+static int fps_regs_waves(int n) { return n <= 512 ? 1 : 4; }
 
 // BTR_FPS_PREFIX=0: the ordered entry point runs the plain kernels (A/B, tests)
 static bool fps_prefix_enabled() {
@@ -654,8 +642,8 @@ static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, 
   while ((1 << log2bs) < bs) ++log2bs;
   // register-resident kernels: at most 4 waves (one per SIMD) so the serial arg-max chain of
   // a step is never slowed by a co-resident wave
-  if (n <= kFpsRegsMaxN && !fps_regs_legacy()) {
-    int nw = fps_regs_waves(n);
+  if (n <= kFpsRegsMaxN) {
+    const int nw = fps_regs_waves(n);
     const int per = (n + nw * 64 - 1) / (nw * 64);
     // the caller expects an FPS-ordered cloud: check "the answer is 0..m-1" in parallel first
     int nslots = 0;
@@ -674,19 +662,10 @@ static int fps_dispatch(int b, int n, int m, const float *dataset, float *temp, 
   if (nw == NW && per <= PPT)    \
   return launch_fps_regs<NW, PPT>(b, n, m, bs, log2bs, dataset, idxs, s, verdict, nslots)
     BTR_FPS_REGS(1, 1); BTR_FPS_REGS(1, 2); BTR_FPS_REGS(1, 4); BTR_FPS_REGS(1, 8);
-    BTR_FPS_REGS(1, 16);
-    BTR_FPS_REGS(4, 1); BTR_FPS_REGS(4, 2); BTR_FPS_REGS(4, 4); BTR_FPS_REGS(4, 8);
-    BTR_FPS_REGS(4, 16);
-    BTR_FPS_REGS(8, 1); BTR_FPS_REGS(8, 2); BTR_FPS_REGS(8, 4); BTR_FPS_REGS(8, 8);
-    BTR_FPS_REGS(16, 1); BTR_FPS_REGS(16, 2); BTR_FPS_REGS(16, 4);
+    BTR_FPS_REGS(4, 4); BTR_FPS_REGS(4, 8); BTR_FPS_REGS(4, 16);
 #undef BTR_FPS_REGS
+    return fail(-1, "furthest_point_sampling: no register-resident kernel for n=%d", n);
   }
-  if (n <= 64) return launch_fps<64, 1, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
-  if (n <= 256) return launch_fps<256, 1, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
-  if (n <= 512) return launch_fps<256, 2, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
-  if (n <= 1024) return launch_fps<256, 4, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
-  if (n <= 2048) return launch_fps<256, 8, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
-  if (n <= kFpsRegsMaxN) return launch_fps<256, 16, true>(b, n, m, bs, log2bs, dataset, temp, idxs, s);
   if (fps_bucket_supported(n) && ws != nullptr && !fps_force_stream())
     return fps_bucket_launch(b, n, m, dataset, idxs, bs, log2bs, ws, ws_bytes, s);
   BTR_REQUIRE(temp != nullptr, "furthest_point_sampling: temp scratch required for n=%d", n);
@@ -764,7 +743,7 @@ int btr_furthest_point_sampling_ordered(int b, int n, int m, const float *datase
                                         size_t scratch_bytes, btr_stream_t stream) {
   const int bs = block_size > 0 ? block_size : btr_opt_n_threads(n);
   const size_t need = btr_fps_ordered_scratch_bytes(b, n, m);
-  if (need == 0 || fps_regs_legacy())   // not a shape the check covers: the plain call
+  if (need == 0)   // not a shape the check covers: the plain call
     return fps_with_own_workspace(b, n, m, dataset, temp, idxs, bs, stream);
   BTR_REQUIRE(scratch && scratch_bytes >= need,
               "furthest_point_sampling_ordered: %zu bytes of scratch required, got %zu", need,

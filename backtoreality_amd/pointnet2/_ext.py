@@ -40,10 +40,10 @@ _SIGNATURES = {
     "btr_furthest_point_sampling_workspace_bytes": (_sz, [_ci, _ci, _ci]),
     "btr_furthest_point_sampling_ws": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _sz, _vp]),
     "btr_backbone_fork_event": (None, [_vp, _ci]),
-    "btr_cu_mask_reserved": (_ci, []),
     "btr_grid_cus": (_ci, []),
     "btr_fps_lds_reserve_kb": (_ci, []),
-    "btr_cu_mask_create_stream": (_vp, [_ci]),
+    "btr_fps_lds_kb": (_ci, [_ci]),
+    "btr_fps_set_lds_kb": (None, [_ci]),
     "btr_fps_ordered_scratch_bytes": (_sz, [_ci, _ci, _ci]),
     "btr_furthest_point_sampling_ordered": (_ci, [_ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _sz,
                                                   _vp]),
@@ -533,25 +533,16 @@ def furthest_point_sampling(points, nsamples):
     return _fps(points, nsamples, 0, out)
 
 
-def cu_mask_reserved():
-    """c of BTR_CU_MASK (0: off): the large-scene FPS kernel owns the first c CUs of every XCD."""
-    return int(_lib.btr_cu_mask_reserved())
-
-
 def new_stream(device):
-    """A new torch stream for work that must stay off the sampling kernel's CUs: a plain
-    torch.cuda.Stream unless BTR_CU_MASK is set, then an ExternalStream around a HIP stream
-    created with the complement CU mask (include/btr_pointnet2.h btr_cu_mask_create_stream)."""
-    if not cu_mask_reserved():
-        prio = os.environ.get("BTR_SIDE_PRIO")   # (experiment: DESIGN 7.6)
-        if prio:
-            return torch.cuda.Stream(device=device, priority=int(prio))
-        return torch.cuda.Stream(device=device)
-    with torch.cuda.device(device):
-        ptr = _lib.btr_cu_mask_create_stream(0)
-    if not ptr:
-        raise RuntimeError("btr_cu_mask_create_stream failed")
-    return torch.cuda.ExternalStream(ptr, device=device)
+    """A new torch stream for the library's side work (the next batch's sampling pyramid)."""
+    return torch.cuda.Stream(device=device)
+
+
+def set_fps_lds_kb(kb):
+    """Process-wide override of the dynamic LDS the large-scene FPS launch asks for (its running
+    min-dists live there; 0: all of them in global memory; < 0: the default rules,
+    include/btr_pointnet2.h btr_fps_lds_kb).  Never changes a result."""
+    _idx.btr_fps_set_lds_kb(int(kb))   # (the library the index-producing ops run from: set_fmad)
 
 
 def mark_fps_ordered(points):

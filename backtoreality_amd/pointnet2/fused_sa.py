@@ -330,8 +330,7 @@ class FusedSAFunction(Function):
                     Wt = W2.t().contiguous()  # (K, Nl)
                     # first layer, nobody asks for the coordinate part: only the feature columns
                     # of dX0, as a dense (R, C) tile (see csrc/sa_layer.hip feat_only)
-                    feat_only = (os.environ.get("BTR_DGRAD0_FEAT", "1") != "0" and
-                                 l == 0 and not pooled and use_xyz and C > 0 and C % 4 == 0 and
+                    feat_only = (l == 0 and not pooled and use_xyz and C > 0 and C % 4 == 0 and
                                  not (need_xyz and use_xyz) and not (need_new and use_xyz))
                     gld = C if feat_only else K
                     G = _f32((R, gld), dev)
@@ -430,8 +429,6 @@ def _sa_options():
             os.environ.get("BTR_BWD_FUSED", "1") != "0" and
             os.environ.get("BTR_GEMM", "") != "f32"):
         o |= _ext.SA_OPT_POOL_GRAM
-        if os.environ.get("BTR_POOL_GRAM", "1") == "2":   # (every covered shape: csrc/sa_mlp.hip
-            o |= 32                                        # reads it; here it only keys the caches)
     # per-point first layer (whole-layer / whole-backbone calls; BTR_SA_PPFL=0: row-wise)
     if os.environ.get("BTR_SA_PPFL", "1") != "0" and os.environ.get("BTR_GEMM", "") != "f32":
         o |= _ext.SA_OPT_PPFL

@@ -209,7 +209,6 @@ class Pointnet2Backbone(nn.Module):
             streams = _SIDE_STREAMS[self] = {}
         key = (name, device)
         if key not in streams:
-            # (BTR_CU_MASK: a stream that stays off the large-scene FPS kernel's CUs)
             streams[key] = _ext.new_stream(device)
         return streams[key]
 

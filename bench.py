@@ -344,20 +344,6 @@ def main():
             sampling = out[1].get('next_sampling')
         return out
 
-    # BTR_CU_MASK = c: the large-scene FPS kernel owns c CUs of every XCD (the library routes it
-    # there, csrc/fps_bucket.hip); the training loop then has to stay off them as well -- every
-    # step is issued on a stream created with the complement mask instead of torch's default one
-    masked_main = None
-    if os.environ.get("BTR_MAIN_PRIO"):   # experiment: the step on a stream of its own priority
-        masked_main = torch.cuda.Stream(device=dev, priority=int(os.environ["BTR_MAIN_PRIO"]))
-        masked_main.wait_stream(torch.cuda.current_stream(dev))
-        _masked_ctx = torch.cuda.stream(masked_main)
-        _masked_ctx.__enter__()
-    elif _ext.cu_mask_reserved():
-        masked_main = _ext.new_stream(dev)
-        masked_main.wait_stream(torch.cuda.current_stream(dev))
-        _masked_ctx = torch.cuda.stream(masked_main)
-        _masked_ctx.__enter__()
     graphed_step = None
     if autotune:
         # One-time set-up, never timed: MIOpen's solver look-up (or search, for a shape that is
@@ -518,7 +504,6 @@ def main():
             # how long the host needed to queue the K steps (== ms_per_step: host-bound)
             "host_enqueue_ms_per_step": 1e3 * enqueue / args.steps,
             "higher_is_better": True,
-            "cu_mask_reserved_per_xcd": _ext.cu_mask_reserved(),
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",

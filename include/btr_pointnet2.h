@@ -136,24 +136,24 @@ int btr_ball_query_ws(int b, int n, int m, float radius, int nsample, const floa
                       const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
                       btr_stream_t stream);
 
-/* CU partitioning (csrc/fps_bucket.hip; environment BTR_CU_MASK = c in 1..8, default off): the
- * large-scene FPS kernel -- one workgroup per scene, ~2 000 dependent steps -- runs on the first
- * c CUs of every XCD, alone; every stream the library creates for itself excludes them.  A
- * caller that wants the partition to hold for its own work creates its streams with
- * btr_cu_mask_create_stream(0) (a new HIP stream on the other CUs; reserved = 1: on the
- * reserved ones) and issues its work there -- torch: torch.cuda.ExternalStream(ptr).
- * btr_cu_mask_reserved() returns c (0: off; the create call then returns a plain stream). */
-int btr_cu_mask_reserved(void);
-void *btr_cu_mask_create_stream(int reserved);
 /* What the library's one-round grids are sized for, and what the large-scene FPS launch holds
- * (both read once per process from the environment; no GPU needed to ask):
+ * (read once per process from the environment; no GPU needed to ask):
  * btr_grid_cus(): CUs a kernel of the training step counts on = device CUs (256 without a
  *   device) - 8 for the next batch's FPS scenes - BTR_COMM_CUS for a collective that overlaps
  *   the backward (default 16 when WORLD_SIZE > 1 and BTR_DP=ddp, else 0); BTR_GRID_CUS overrides.
- * btr_fps_lds_reserve_kb(): KB of LDS the FPS launch reserves on each of its CUs (BTR_FPS_LDS_KB;
- *   default 128, 96 when WORLD_SIZE > 1 so that an RCCL workgroup still fits beside a scene). */
+ * btr_fps_lds_reserve_kb(): KB of LDS the FPS launch holds at least on each of its CUs
+ *   (BTR_FPS_LDS_KB; default 128, 96 when WORLD_SIZE > 1 so that an RCCL workgroup still fits
+ *   beside a scene).  The running min-dists of the scene live in that LDS (4 B per point, curve
+ *   order; what does not fit stays in the global workspace), the rest keeps other LDS-using
+ *   workgroups off the CU.
+ * btr_fps_lds_kb(points): KB a launch over scenes of `points` points asks for: on one GPU enough
+ *   for all min-dists where they fit (159 KB: 40 704 points) and never below the floor; with
+ *   BTR_FPS_LDS_KB or WORLD_SIZE > 1 exactly the floor.
+ * btr_fps_set_lds_kb(kb): process-wide override (tests, A/B runs); kb < 0 restores the rules. */
 int btr_grid_cus(void);
 int btr_fps_lds_reserve_kb(void);
+int btr_fps_lds_kb(int points);
+void btr_fps_set_lds_kb(int kb);
 
 /* Measurement only (bench.py): the next btr_ball_query_buckets call -- or btr_ball_query_ws call
  * on a scene of more than 4096 points -- of this host thread records the two hipEvent_t around

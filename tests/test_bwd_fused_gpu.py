@@ -162,22 +162,13 @@ def _run_gram(dev, rows, n, k, s, seed=0, ldx_pad=0):
     return (dz, dw, dg, db, m1, m2), (dz_ref, dw_ref, s2_ref, s1_ref, s1_ref / rows, s2_ref / rows)
 
 
-@pytest.fixture(autouse=True)
-def _all_gram_shapes(monkeypatch):
-    # (the default policy takes the producer / consumer kernel's shapes only: n <= 128, k <= 64)
-    monkeypatch.setenv("BTR_POOL_GRAM", "2")
-
-
 @pytest.mark.parametrize("rows,n,k,s", [
     (4096, 128, 64, 64),       # SA1's pooled layer
-    (4096, 256, 128, 32),      # SA2's: the 256-wide variant, two k blocks
-    (4096, 256, 128, 16),      # SA3 / SA4
-    (2048, 128, 128, 16),      # vote aggregation
     (1040, 128, 64, 16),       # ragged rows (last step of 16)
     (1024, 100, 36, 16),       # n, k not multiples of 32
     (20000, 128, 64, 32),      # many chunks
     (2048, 64, 64, 16),        # the 64-column variant
-    (3008, 200, 100, 16),      # 256-wide variant on n = 200, k = 100
+    (4096, 128, 32, 16),       # half a k block
 ])
 def test_gram_backward_matches_float64(cuda, rows, n, k, s):
     got, ref = _run_gram(cuda, rows, n, k, s, ldx_pad=4 if k % 8 else 0)
@@ -191,6 +182,12 @@ def test_gram_backward_is_bit_reproducible(cuda):
         assert torch.equal(x, y)
 
 
-def test_gram_backward_refuses_wide_inputs(cuda):
-    assert not _lib.btr_sa_bwd_gram_supported(4096, 256, 256)   # k > 128: the Y_l-reading form
-    assert _lib.btr_sa_bwd_gram_supported(4096, 256, 128)
+def test_gram_backward_covers_the_producer_consumer_shapes_only(cuda):
+    """n <= 128, k <= 64 (SA1's pooled layer); wider layers keep the Y_l-reading form, and so does
+    a layer with more rows than the kernel's block -> group table can index per chunk (the plan
+    asks btr_sa_bwd_gram_supported, so the forward still stores Y_l there)."""
+    assert _lib.btr_sa_bwd_gram_supported(4096, 128, 64)
+    assert not _lib.btr_sa_bwd_gram_supported(4096, 256, 128)
+    assert not _lib.btr_sa_bwd_gram_supported(4096, 128, 128)
+    assert _lib.btr_sa_bwd_gram_supported(8 * 2048 * 64, 128, 64)          # the benchmark's SA1
+    assert not _lib.btr_sa_bwd_gram_supported(2000 * 2048 * 64, 128, 64)   # beyond the table

@@ -113,8 +113,7 @@ def _runtime_defaults(env):
     code = ("import ctypes; from backtoreality_amd import build; l = ctypes.CDLL(build.build()); "
             "print(l.btr_grid_cus(), l.btr_fps_lds_reserve_kb())")
     e = {k: v for k, v in os.environ.items()
-         if k not in ("WORLD_SIZE", "BTR_DP", "BTR_GRID_CUS", "BTR_FPS_LDS_KB", "BTR_COMM_CUS",
-                      "BTR_CU_MASK")}
+         if k not in ("WORLD_SIZE", "BTR_DP", "BTR_GRID_CUS", "BTR_FPS_LDS_KB", "BTR_COMM_CUS")}
     e.update(env)
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, check=True,
                          capture_output=True, text=True).stdout.split()

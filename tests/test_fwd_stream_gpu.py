@@ -106,49 +106,3 @@ def test_stream_pooling_epilogue_of_8_row_blocks(cuda, rows, n, k, ps):
     s1, s2 = _sums(part, nblk, n)
     r2 = (ref * ref).sum(0)
     assert float((s2 - r2).abs().max()) <= 1e-5 * float(r2.abs().max())
-
-
-@pytest.mark.parametrize("rows,n,k,ps", [
-    (20000, 128, 64, 8), (18008, 256, 128, 8), (32768, 128, 128, 16), (16400, 200, 100, 16),
-    (33000, 128, 128, 0), (16384, 64, 64, 0), (16390, 100, 36, 0), (70000, 128, 64, 8),
-])
-def test_producer_consumer_form_is_bit_identical(cuda, monkeypatch, rows, n, k, ps):
-    """sa_fwd_ws_kernel (producer and consumer waves, two row chunks per workgroup) against the
-    single-role sa_fwd_stream_kernel (BTR_FWD_WS=0): the same arithmetic in the same order --
-    output matrix, every statistics partial row, extrema and arg-max rows bit-identical, with and
-    without the C store."""
-    g = torch.Generator(device="cpu").manual_seed(n + k + ps)
-    rnd = lambda *s: torch.randn(*s, generator=g).to(cuda)
-    A, W = rnd(rows, k), rnd(n, k) * 0.3
-    pa, pb, gamma = rnd(k), rnd(k) * 0.3, rnd(n)
-    nblk = _lib.btr_sa_gemm_grid(rows)
-    res = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("BTR_FWD_WS", flag)
-        for store in (True, False):
-            if not store and (ps == 0 or not _lib.btr_sa_gemm_nt_poolfwd_nostore_supported(
-                    rows, n, k, ps)):
-                continue
-            C = torch.full((rows, n), float("nan"), device=cuda)
-            part = torch.full((nblk, 2, n), float("nan"), device=cuda)
-            out = [C, part]
-            with _ext._on(A) as d:
-                if ps:
-                    groups = rows // ps
-                    gext = torch.full((groups, n), float("nan"), device=cuda)
-                    aext = torch.full((groups, n), 255, dtype=torch.uint8, device=cuda)
-                    _ext._call(_lib.btr_sa_gemm_nt_poolfwd, rows, n, k, _p(A), k, _p(W), k,
-                               _p(C) if store else None, n, _p(pa), _p(pb), _p(part), ps,
-                               _p(gamma), _p(gext), _p(aext), _ext._stream(d))
-                    out += [gext, aext]
-                else:
-                    _ext._call(_lib.btr_sa_gemm_nt, rows, n, k, _p(A), k, _p(W), k, _p(C), n,
-                               _p(pa), _p(pb), _p(part), _ext._stream(d))
-            torch.cuda.synchronize()
-            res[(flag, store)] = out
-    for store in (True, False):
-        if ("0", store) not in res:
-            continue
-        for x, y in zip(res[("0", store)][(0 if store else 1):], res[("1", store)][(0 if store else 1):]):
-            assert torch.equal(x, y, ) or (torch.isnan(x) == torch.isnan(y)).all() and torch.equal(
-                torch.nan_to_num(x.float()), torch.nan_to_num(y.float()))

@@ -3,7 +3,7 @@ reduced in a fixed order) against a float64 evaluation, at ragged shapes: rows t
 the last 32-row step or the last chunk, n / k that do not fill the 128 / 64-wide tiles, with
 and without the BatchNorm + ReLU prologue on x.  The default kernel is the bf16x6 form whose
 operand fragments come through gfx950's LDS transpose read (csrc/sa_mlp.hip gemm_tn_x6_kernel);
-BTR_GEMM_TN=f32 selects the f32-input MFMA kernel -- both must sit at f32 rounding distance."""
+BTR_GEMM=f32 selects the f32-input MFMA kernels -- both must sit at f32 rounding distance."""
 import pytest
 import torch
 

@@ -294,16 +294,13 @@ def test_in_kernel_batchnorm_finalisation_at_every_size():
 
 @pytest.mark.parametrize("env", [
     {"BTR_GRID_CUS": "100"},                            # far fewer row chunks than the default
-    {"BTR_GRID_CUS": "256", "BTR_GRID_ROUNDS": "2"},    # more than one round of them
-    {"BTR_TN_WGS_PER_CU": "4", "BTR_GEMM_WGS_PER_CU": "3"},
-    {"BTR_FPS_LDS_KB": "0", "BTR_WGRAD_STREAM": "1"},   # the round-3 stream arrangement
-    {"BTR_BWD_FUSED_SPLIT": "1"},                       # 256-wide layers as two 128-column slabs
+    {"BTR_GRID_CUS": "256", "BTR_FPS_LDS_KB": "0"},     # every CU counted, no LDS held by the FPS
+    {"BTR_WGRAD_STREAM": "1"},                          # the round-3 stream arrangement
 ])
 def test_chunk_count_knobs_leave_the_results_alone(env):
     """The row-chunk counts of the streaming / fused / weight-gradient kernels are sized from the
-    CUs a launch can use (csrc/fps_bucket.hip cu_mask_avail_cus, BTR_GRID_CUS / _ROUNDS /
-    *_WGS_PER_CU); the partial-sum buffers are sized by the same functions at plan time and at
-    launch time.  This file's C-sequence-vs-Python-sequence comparisons (bit-identical outputs,
+    CUs a launch can use (csrc/fps_bucket.hip grid_cus, BTR_GRID_CUS); the partial-sum buffers
+    are sized by the same functions at plan time and at launch time.  This file's C-sequence-vs-Python-sequence comparisons (bit-identical outputs,
     gradients, running statistics) and the golden training step, in child processes with other
     chunk counts (the switches are read once per process)."""
     import os

@@ -74,29 +74,43 @@ def test_fps_tie_break_every_block_size(cuda, bs, N):
     np.testing.assert_array_equal(got, ref)
 
 
-def test_fps_full_size_and_both_large_kernels(cuda, monkeypatch):
+@pytest.fixture
+def fps_lds(cuda):
+    """Sets the dynamic LDS of the large-scene FPS launch for one test (btr_fps_set_lds_kb) and
+    restores the default rules afterwards."""
+    ext = _ext()
+    yield ext.set_fps_lds_kb
+    ext.set_fps_lds_kb(-1)
+
+
+def test_fps_full_size_and_both_large_kernels(cuda, monkeypatch, fps_lds):
     """BASELINE configs[1] size (B=8, N=40000, M=2048): the bucketed kernel and the streaming
-    kernel (BTR_FPS_IMPL=stream) both reproduce the oracle bit for bit."""
+    kernel (BTR_FPS_IMPL=stream) both reproduce the oracle bit for bit -- the bucketed kernel
+    with its running min-dists wholly in LDS (the default: 157 KB for 40 000 points), split
+    between LDS and the global workspace (128 KB: 32 768 points' worth; 20 KB) and wholly in
+    global memory (0): where a min-dist lives can never change an index."""
     xyz = _scene_xyz(8, 40000)
     ref = oracle.furthest_point_sampling(xyz, 2048)
     x = _t(xyz, cuda)
     got = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
     np.testing.assert_array_equal(got, ref)
+    assert _ext()._idx.btr_fps_lds_kb(40000) * 1024 >= 40000 * 4
+    for kb in (128, 20, 0):
+        fps_lds(kb)
+        got = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+    fps_lds(-1)
     monkeypatch.setenv("BTR_FPS_IMPL", "stream")
     got = _ext().furthest_point_sampling(x[:2], 600).cpu().numpy()
     np.testing.assert_array_equal(got, ref[:2, :600])
-    monkeypatch.setenv("BTR_FPS_IMPL", "queue")   # work-queue distribution of the bucket updates
-    got_q = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
-    np.testing.assert_array_equal(got_q, ref)
-    for impl in ("multi", "pm"):   # several samples per round (two implementations), still exact
-        monkeypatch.setenv("BTR_FPS_IMPL", impl)
-        got = _ext().furthest_point_sampling(x, 2048).cpu().numpy()
-        np.testing.assert_array_equal(got, ref)
 
 
-@pytest.mark.parametrize("impl", ["multi", "pm"])
-def test_fps_multi_sample_rounds_ties_and_skips(cuda, monkeypatch, impl):
-    monkeypatch.setenv("BTR_FPS_IMPL", impl)
+@pytest.mark.parametrize("lds_kb", [-1, 24, 0])
+def test_fps_bucketed_ties_and_skips_wherever_the_min_dists_live(cuda, fps_lds, lds_kb):
+    """Skipped points, duplicated points (exact ties) at several block sizes and a cloud of one
+    repeated point, with the min-dists in LDS (default), partly there (24 KB: 6 144 points) and
+    in global memory."""
+    fps_lds(lds_kb)
     rng = np.random.default_rng(12)
     xyz = rng.uniform(-3, 3, size=(2, 12000, 3)).astype(np.float32)
     xyz[:, 500:900] *= 0.004

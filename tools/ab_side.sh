@@ -10,6 +10,4 @@ print('$1  %.3f ms  seq %.3f ms  host %.2f ms' % (d['ms_per_step'], d.get('seque
 for i in 1 2; do
   BTR_WGRAD_STREAM=1 run "both on the side stream (old default)"
   BTR_WGRAD_STREAM=0 run "all on the callers stream         "
-  BTR_WGRAD_STREAM=1 BTR_SIDE_MIN_ROWS=100000000 run "SA layers side, chains main       "
-  BTR_WGRAD_STREAM=1 BTR_SIDE_MIN_ROWS_SA=100000000 run "chains side, SA layers main       "
 done

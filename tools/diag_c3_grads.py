@@ -47,6 +47,16 @@ def main():
             max(d for d, n in devs if not n.startswith("backbone_net.sa"))))
         for d, n in devs[:6]:
             print("   %.4f  %s" % (d, n))
+        # the flip-aware reading of tests/test_configs_gpu.py: rows of every pooled layer's weight
+        # gradient that moved by more than 1e-2 of the largest row, most downstream layer first
+        for prefix in ('pnet.vote_aggregation.', 'backbone_net.sa4.', 'backbone_net.sa3.',
+                       'backbone_net.sa2.', 'backbone_net.sa1.'):
+            last = sorted(n for n in gu if n.startswith(prefix) and n.endswith('.conv.weight'))[-1]
+            wf, wu = gf[last].flatten(1), gu[last].flatten(1)
+            row = (wf - wu).norm(dim=1) / float(wu.norm(dim=1).max())
+            top = row.topk(6)
+            print("   %-52s rows > 1e-2: %3d   largest %s" % (
+                last, int((row > 1e-2).sum()), ["%.3f" % float(v) for v in top.values]))
         sys.stdout.flush()
 
 

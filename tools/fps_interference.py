@@ -46,12 +46,6 @@ def run(concurrent, reps=20):
 
 
 from backtoreality_amd.pointnet2 import _ext  # noqa: E402
-if _ext.cu_mask_reserved():   # BTR_CU_MASK: everything but the FPS stays off the reserved CUs
-    _main = _ext.new_stream(dev)
-    _main.wait_stream(torch.cuda.current_stream(dev))
-    torch.cuda.stream(_main).__enter__()
-    print("CU partition: %d CUs per XCD reserved for the large-scene FPS" % _ext.cu_mask_reserved())
-
 occ = None
 if "--occupant" in sys.argv:   # a synthetic co-runner instead of the pyramid (tools/probe/occupant.hip)
     import ctypes

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the plain weight-gradient GEMM (btr_sa_gemm_tn: TN kernel + split-K reduction) at
-shapes of the benchmark steps (HIP events).  BTR_GEMM_TN=f32 for the f32-input kernel."""
+shapes of the benchmark steps (HIP events).  BTR_GEMM=f32 for the f32-input kernels."""
 import os
 import sys
 
@@ -45,7 +45,7 @@ POOL_SHAPES = [(8 * 2048 * 32, 32, 128, 64), (8 * 1024 * 32, 32, 256, 128),
 
 
 def run_pool(rows, s, n, k):
-    """btr_sa_gemm_tn_pool on plain rows (BTR_GEMM_TN_POOL=f32: the f32-input kernel)."""
+    """btr_sa_gemm_tn_pool on plain rows (BTR_GEMM=f32: the f32-input kernel)."""
     dev = torch.device("cuda")
     y = torch.randn(rows, n, device=dev)
     x = torch.randn(rows, k, device=dev)
