@@ -289,7 +289,12 @@ extern __shared__ float fps_ltmin[];
 // different waves: the few buckets a late sample touches update in parallel -- each update is
 // an L2 round trip plus a wave reduction, so 16 waves beat 4 here: measured 2.85 vs 5.4 ms on
 // 8 x 40000 -> 2048).
-template <int NW, int SL, int UB, bool PROF = false>
+// TM: where the running min-dists live -- 0: all in the global array, 1: all in LDS, 2: the first
+// lds_pts points in LDS, the rest global.  A template parameter, not a run-time branch, for the
+// two pure forms: with both paths in one instruction stream the compiler's s_waitcnt at the join
+// must cover the path with FEWER loads per trip, i.e. it waits for part of the prefetched
+// bucket -- measured: the mixed form 8 % slower than either pure form on a scene that fits.
+template <int NW, int SL, int UB, bool PROF = false, int TM = 2>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int m, int bs,
                                                              int log2bs,
                                                              const float *__restrict__ dataset,
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
   for (int p = tid; p < np; p += NW * 64) {
     const float *bp = (const float *)spts + (size_t)(p >> 6) * 256 + (p & 63);
     const float t = fps_tmin0(bp[0], bp[64], bp[128], __float_as_int(bp[192]));
-    if ((p >> 6) < lds_bkts) fps_ltmin[p] = t;
+    if (TM == 1 || (TM == 2 && (p >> 6) < lds_bkts)) fps_ltmin[p] = t;
     else tmin[p] = t;
   }
   __syncthreads();   // (also orders the global tail's stores before the owner waves' loads)
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
         p.y = bp[64];
         p.z = bp[128];
         p.w = bp[192];
-        if (bkt < lds_bkts) t = fps_ltmin[bkt * 64 + lane];
+        if (TM == 1 || (TM == 2 && bkt < lds_bkts)) t = fps_ltmin[bkt * 64 + lane];
         else t = tmin[o];
       };
       auto process = [&](int cb, size_t co, const float4 &p, float t0) {
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int np, int 
         const bool valid = t0 >= 0.f;
         const float t = valid ? fminf(d, t0) : t0;
         if (t != t0) {
-          if ((s * 64 + cb) * NW + wave < lds_bkts) fps_ltmin[co] = t;
+          if (TM == 1 || (TM == 2 && (s * 64 + cb) * NW + wave < lds_bkts)) fps_ltmin[co] = t;
           else tmin[co] = t;
         }
         if (PROF) {
@@ -601,6 +606,10 @@ static FpsPlan fps_plan(int b, int n) {
 }
 
 constexpr int kBucketWaves = 16;
+// Scenes whose min-dists do not all fit keep ALL of them global (tools/fps_lds_ab.py, 4 x 80 000
+// -> 2 048 alone: 2.84 ms all global, 3.06 ms with the first 40 704 in LDS -- see TM)
+constexpr bool kFpsLdsMixedDefault = false;
+static bool fps_lds_mixed();
 constexpr int kBucketMaxSlots = 2;
 constexpr int kBucketMaxN = kBucketMaxSlots * kBucketWaves * 64 * 64;  // 131072 points/scene
 
@@ -659,10 +668,14 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
     } else {
       if (attr_kb[dev] >= 0 && attr_kb[dev] < lds_kb) {
         bool ok = true;
-        for (const void *f : {reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1>),
-                              reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1>),
-                              reinterpret_cast<const void *>(
-                                  &fps_bucket_kernel<kBucketWaves, 1, 1, true>)})
+        for (const void *f :
+             {reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1, false, 0>),
+              reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1, false, 1>),
+              reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1, false, 2>),
+              reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1, false, 0>),
+              reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 2, 1, false, 2>),
+              reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1, true, 0>),
+              reinterpret_cast<const void *>(&fps_bucket_kernel<kBucketWaves, 1, 1, true, 1>)})
           ok = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) ==
                    hipSuccess && ok;
         (void)hipGetLastError();
@@ -671,13 +684,20 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
       if (attr_kb[dev] < lds_kb) dyn = 0;
     }
   }
-  const int lds_pts = (int)std::min<size_t>((size_t)p.np, (dyn / sizeof(float)) & ~(size_t)63);
+  int lds_pts = (int)std::min<size_t>((size_t)p.np, (dyn / sizeof(float)) & ~(size_t)63);
+  if (!fps_lds_mixed() && lds_pts < p.np) lds_pts = 0;   // (the reservation stays: dyn)
+  const int tm = lds_pts >= p.np ? 1 : (lds_pts == 0 ? 0 : 2);
   if (getenv("BTR_FPS_PROF")) {
     // tuning only (tools/fps_prof.py): s_memtime phase counters of the kernel, scene 0
     static unsigned long long *dbg = nullptr;
     if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 64 * 16 * 8);
-    hipLaunchKernelGGL((fps_bucket_kernel<16, 1, 1, true>), dim3(b), dim3(1024), dyn, s, n, p.np,
-                       m, bs, log2bs, dataset, spts, sk, idxs, dbg, (Box8 *)nullptr, 0u, lds_pts);
+    if (tm == 1)
+      hipLaunchKernelGGL((fps_bucket_kernel<16, 1, 1, true, 1>), dim3(b), dim3(1024), dyn, s, n,
+                         p.np, m, bs, log2bs, dataset, spts, sk, idxs, dbg, (Box8 *)nullptr, 0u,
+                         lds_pts);
+    else
+      hipLaunchKernelGGL((fps_bucket_kernel<16, 1, 1, true, 0>), dim3(b), dim3(1024), dyn, s, n,
+                         p.np, m, bs, log2bs, dataset, spts, sk, idxs, dbg, (Box8 *)nullptr, 0u, 0);
     (void)hipStreamSynchronize(s);
     unsigned long long h[16 * 8];
     (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -728,14 +748,16 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
   static std::atomic<unsigned> epoch_counter{0x5a000000u};
   unsigned epoch = (epoch_counter.fetch_add(1u) + 1u) & 0x7fffffffu;
   if (epoch == 0u) epoch = (epoch_counter.fetch_add(1u) + 1u) & 0x7fffffffu;
-  if (p.nb <= kBucketWaves * 64)
-    hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 1, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       dyn, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
-                       (unsigned long long *)nullptr, boxes, epoch, lds_pts);
-  else
-    hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, 2, 1>), dim3(b), dim3(kBucketWaves * 64),
-                       dyn, s, n, p.np, m, bs, log2bs, dataset, spts, sk, idxs,
-                       (unsigned long long *)nullptr, boxes, epoch, lds_pts);
+#define BTR_FPS_BUCKET(SLOTS, TMODE)                                                          \
+  hipLaunchKernelGGL((fps_bucket_kernel<kBucketWaves, SLOTS, 1, false, TMODE>), dim3(b),         \
+                     dim3(kBucketWaves * 64), dyn, s, n, p.np, m, bs, log2bs, dataset, spts, sk, \
+                     idxs, (unsigned long long *)nullptr, boxes, epoch, lds_pts)
+  if (p.nb <= kBucketWaves * 64) {
+    if (tm == 1) BTR_FPS_BUCKET(1, 1); else if (tm == 0) BTR_FPS_BUCKET(1, 0); else BTR_FPS_BUCKET(1, 2);
+  } else {
+    if (tm == 0) BTR_FPS_BUCKET(2, 0); else BTR_FPS_BUCKET(2, 2);
+  }
+#undef BTR_FPS_BUCKET
   if (ev[1]) (void)hipEventRecord(ev[1], s);
   ev[0] = ev[1] = nullptr;
   fps_boxes_note(workspace, b, n, boxes, epoch);
@@ -756,6 +778,10 @@ int fps_bucket_launch(int b, int n, int m, const float *dataset, int *idxs, int 
 // process-wide override for tests and A/B runs (k < 0: back to the rules above).
 constexpr int kFpsLdsMaxKb = 159;
 static std::atomic<int> g_fps_lds_override{-1};
+// A scene whose min-dists do not all fit: the first lds_pts of them in LDS and the rest global
+// (true), or all of them global as before round 6 (false; the launch still holds its LDS).  With
+// the override set the split form runs whenever the size asks for it (tests, A/B).
+static bool fps_lds_mixed() { return g_fps_lds_override.load(std::memory_order_relaxed) >= 0 || kFpsLdsMixedDefault; }
 int fps_lds_reserve_kb() {
   static const int kb = [] {
     const char *e = getenv("BTR_FPS_LDS_KB");

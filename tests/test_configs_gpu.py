@@ -33,59 +33,40 @@ def _worst_grad_dev(g_f, g_u):
     return max(l2(n) for n in g_u if float(g_u[n].abs().max()) > 1e-4 * gmax)
 
 
-# the modules of VoteNet(_DA) in FORWARD order; a parameter outside all of them (proposal head,
-# discriminators on the aggregated features) is downstream of every max-pool
-_STAGES = ('backbone_net.sa1.', 'backbone_net.sa2.', 'backbone_net.sa3.', 'backbone_net.sa4.',
-           'backbone_net.fp1.', 'backbone_net.fp2.', 'vgen.', 'pnet.vote_aggregation.')
-_POOLED = (0, 1, 2, 3, 7)      # the stages that end in a max-pool over the samples of a group
+def _gradients_as_close_to_float64_as_the_reference_formulation(g_f, g_u, g64, max_events=2):
+    """The gradient bar of a full-size step, read against a float64 evaluation of the same step
+    (tests/f64_path.py) instead of against the other float32 path.
 
+    Why: at 2 x 8 x 40 000 points the fused HIP path and the nine-op + torch composition agree
+    to 1e-4 on every forward quantity and to 1e-6 on the loss, and still differ by 1 - 3 % in
+    relative L2 on many gradient tensors.  Measured (tools/diag_c3_f64.py, profiles/
+    r06_e_diag_c3_f64.txt): that is not one flipped max-pool decision -- the deviation starts at
+    the proposal head's first layer and grows smoothly towards SA1, and the reference's OWN
+    float32 formulation sits just as far from float64 (seed pair 0: nine-op 0.45 - 1.7 %, fused
+    0.78 - 2.0 %, the two against each other 0.9 - 2.5 % = the two errors in quadrature).  A
+    detection loss pulls positives and negatives apart; its parameter gradients are sums that
+    cancel, and float32 defines them to ~1e2 x the forward's rounding.  So:
+      * every live parameter's gradient must be within 2 x the worst error of the nine-op float32
+        path (+ 5e-3) of float64 -- the fused path may be as inexact as the formulation it
+        replaces, not more;
+      * discrete events (a ReLU gate or a pool tie within rounding of its threshold) move ONE
+        tensor by more: at most `max_events` tensors may exceed the bound, none by 0.1.
+    A gradient path that is off in one layer moves that layer's weight, scale and shift and
+    everything upstream: more than two tensors.  Returns (yardstick, bound, the exceptions)."""
+    gmax = max(float(g.abs().max()) for g in g64.values())
+    live = [n for n in g64 if float(g64[n].abs().max()) > 1e-4 * gmax]
 
-def _stage(name):
-    for i, prefix in enumerate(_STAGES):
-        if name.startswith(prefix):
-            return i
-    return len(_STAGES)
-
-
-def _flip_aware_grad_check(g_f, g_u, tol=1e-2, upstream_tol=0.1, max_flips=2):
-    """Gradient comparison of two correct float32 paths that states what ONE flipped max-pool
-    decision may move instead of loosening the bound for everybody (the structure of
-    test_c5_scenes_with_a_near_tie_state_the_bound_per_flip, for any pooled layer):
-      * a pool element within rounding of a tie between two neighbours may be resolved either
-        way; the forward does not move, the flipped channel's ROW of that pooled layer's weight
-        gradient does, and so does everything the backward reaches behind it (upstream);
-      * the most downstream pooled layer with moved rows is where the flip sits: at most
-        `max_flips` of its rows may exceed `tol` (relative to the largest row);
-      * every parameter the backward reaches BEFORE that pool keeps `tol` in relative L2 -- on
-        inputs without a flip that is every parameter;
-      * parameters upstream of the flip keep `upstream_tol` (4 % was measured for one flip).
-    Returns (stage of the flip or None, moved rows there)."""
-    gmax = max(float(g.abs().max()) for g in g_u.values())
-
-    def l2(n):
-        return float((g_f[n] - g_u[n]).norm() / (g_u[n].norm() + 1e-20))
-    live = [n for n in g_u if float(g_u[n].abs().max()) > 1e-4 * gmax]
-    flip_stage, moved = None, 0
-    for st in reversed(_POOLED):
-        names = [n for n in g_u if n.startswith(_STAGES[st]) and n.endswith('.conv.weight')]
-        if not names:
-            continue
-        last = sorted(names)[-1]    # mlp_module.layerK.conv.weight with the largest K: pooled
-        wf, wu = g_f[last].flatten(1), g_u[last].flatten(1)
-        row_dev = (wf - wu).norm(dim=1) / float(wu.norm(dim=1).max())
-        m = int((row_dev > tol).sum())
-        if m:
-            flip_stage, moved, flipped = st, m, last
-            break
-    report = sorted(((l2(n), n) for n in live), reverse=True)[:12]
-    assert moved <= max_flips, (flip_stage, moved, report)
-    for n in live:
-        st = _stage(n)
-        if flip_stage is None or st > flip_stage:
-            assert l2(n) < tol, (n, l2(n), flip_stage, report)
-        elif n != flipped:
-            assert l2(n) < upstream_tol, (n, l2(n), flip_stage, report)
-    return flip_stage, moved
+    def l2(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+    err_f = {n: l2(g_f[n], g64[n]) for n in live}
+    err_u = {n: l2(g_u[n], g64[n]) for n in live}
+    yard = max(err_u.values())
+    bound = 2.0 * yard + 5e-3
+    over = sorted(((err_f[n], n) for n in live if err_f[n] > bound), reverse=True)
+    report = sorted(((err_f[n], err_u[n], n) for n in live), reverse=True)[:10]
+    assert len(over) <= max_events, (yard, bound, over, report)
+    assert all(e < 0.1 for e, _ in over), (yard, bound, over)
+    return yard, bound, over
 
 
 def _votenet_step(cfg, batch, dev, fused, monkeypatch, num_proposal=256, vote_inds=None):
@@ -182,69 +163,27 @@ def test_c5_scenes_with_a_near_tie_state_the_bound_per_flip(cuda, monkeypatch):
     assert moved <= 2, (moved, row_dev.topk(8), own.topk(8), {n: l2(n) for n in live})
 
 
-def _votenet_br_step(cfg, batch_S, batch_T, dev, fused, monkeypatch, vote_inds=None,
-                     vote_idx=None):
-    """One Back-to-Reality forward pair + get_loss_DA + backward (train_Votenet_BR.py:267-289).
-    `vote_inds`: (source, target) proposals for the two vote-aggregation calls, in call order;
-    `vote_idx`: the two calls' neighbour lists (the r = 0.3 ball query around the chosen votes).
-    Both ops sit downstream of COMPUTED floats (the votes), which two f32 paths reproduce to
-    ~4e-6: either may legitimately make another discrete choice there, so a
-    comparison of everything else pins them, as the golden tests do.  Returns the neighbour lists
-    this run's own ball queries produced as the last element."""
-    from backtoreality_amd.pointnet2 import pointnet2_utils
-    monkeypatch.setenv("BTR_FUSED_SA", "1" if fused else "0")
-    net = train.build_model(cfg, dev, seed=0, domain_adaptation=True)
-    sa = net.pnet.vote_aggregation
-    own = sa.forward
-    queue = list(vote_inds) if vote_inds is not None else None
-    idx_queue = list(vote_idx) if vote_idx is not None else None
-    made = []
-
-    def forward(xyz, features=None, inds=None):
-        real_bq = pointnet2_utils.ball_query
-
-        def bq(radius, nsample, xyz_, new_xyz_):
-            made.append(real_bq(radius, nsample, xyz_, new_xyz_))
-            return idx_queue.pop(0) if idx_queue is not None else made[-1]
-        pointnet2_utils.ball_query = bq
-        try:
-            return own(xyz, features, queue.pop(0) if queue is not None else inds)
-        finally:
-            pointnet2_utils.ball_query = real_bq
-    sa.forward = forward
-    eS = net({'point_clouds': batch_S['point_clouds']})
-    eT = net({'point_clouds': batch_T['point_clouds']})
-    eS.update(batch_S)
-    eT.update(batch_T)
-    loss, eS, eT = loss_helper.get_loss_DA(eS, eT, cfg)
-    loss.backward()
-    grads = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
-    return loss.detach(), eS, eT, grads, made
-
-
 @pytest.mark.parametrize("first", [24, 0])
 def test_c3_back_to_reality_full_size_step(cuda, monkeypatch, first):
     """C3 (BASELINE configs[2]) at its full per-GPU size: source AND target batch of 8 x 40 000
     points through the same VoteNet_DA (models/votenet_DA.py:123-176), get_loss_DA, one backward
     -- the fused HIP path against the nine-op + torch composition with both branches' proposals
     and vote-ball neighbour lists pinned to the op-by-op run's (the two ops downstream of computed
-    floats, as the golden tests pin them): every sampling index equal,
-    features / discriminator outputs / every loss term 1e-4, gradients at 1e-2 in relative L2.
-    Sixteen 40 000-point scenes hold ~2.6 M max-pool decisions, and two correct f32 paths may
-    resolve one that sits within rounding of a tie differently (tools/diag_c3_grads.py: which
-    seed pairs come out clean depends on the last bits of the forward).  Round 5 answered that
-    with a 5e-2 bound for every parameter; now the bound stays 1e-2 and a flip is treated as
-    what it is (_flip_aware_grad_check): at most two rows of ONE pooled layer's weight gradient
-    may move, everything the backward reaches before that pool keeps 1e-2, only the parameters
-    behind it get the per-flip bound (0.1, measured 0.006 - 0.023) -- and without a flip every
-    parameter keeps 1e-2.  A gradient path that is off by a few per cent in a layer the flip
-    does not reach, or anywhere on a clean pair, fails."""
+    floats, as the golden tests pin them): every sampling index equal, features / discriminator
+    outputs / every loss term 1e-4 -- and the gradients against a FLOAT64 evaluation of the same
+    step on the GPU: the fused path must be as close to it as the reference's own float32
+    formulation is (_gradients_as_close_to_float64_as_the_reference_formulation).  Round 5 held the
+    two float32 paths to 5e-2 against each other, which could not tell a flipped pool from a
+    gradient path that is 3 % off; the float64 yardstick shows what float32 defines (seed pair
+    24: nine-op 0.05 - 0.5 %, fused 0.5 - 1.1 % with one BatchNorm shift of SA4's pooled layer at
+    3 % -- one gate flipped; pair 0: both 0.5 - 2 %) and bounds the fused path by it."""
+    import f64_path
     cfg = config.scannet_md40()
     batch_S = synthetic.make_batch(first, 8, 40000, cfg, device=cuda)
     batch_T = synthetic.make_batch(100000 + first, 8, 40000, cfg, device=cuda)
-    loss_u, uS, uT, g_u, idx_u = _votenet_br_step(cfg, batch_S, batch_T, cuda, False, monkeypatch)
+    loss_u, uS, uT, g_u, idx_u = f64_path.br_step(cfg, batch_S, batch_T, cuda, fused=False)
     pins = (uS['aggregated_vote_inds'], uT['aggregated_vote_inds'])
-    loss_f, fS, fT, g_f, idx_f = _votenet_br_step(cfg, batch_S, batch_T, cuda, True, monkeypatch,
+    loss_f, fS, fT, g_f, idx_f = f64_path.br_step(cfg, batch_S, batch_T, cuda, fused=True,
                                                   vote_inds=pins, vote_idx=idx_u)
     assert len(idx_u) == len(idx_f) == 2
     # (reported, not asserted: how many neighbour slots the fused run's own queries, on its own
@@ -264,9 +203,15 @@ def test_c3_back_to_reality_full_size_step(cuda, monkeypatch, first):
                 assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (tag, k, a, b)
     assert abs(float(loss_f) - float(loss_u)) / abs(float(loss_u)) < 1e-4
     assert set(g_f) == set(g_u)
-    stage, moved = _flip_aware_grad_check(g_f, g_u)
-    print("c3 pair %d: flipped pool stage %r, rows moved %d, worst %.4f"
-          % (first, stage, moved, _worst_grad_dev(g_f, g_u)))
+    del uS, uT, fS, fT
+    loss64, _, _, g64, _ = f64_path.br_step(cfg, batch_S, batch_T, cuda, fused=False,
+                                            vote_inds=pins, vote_idx=idx_u, float64=True)
+    assert set(g64) == set(g_f)
+    for name, lv in (("fused", loss_f), ("nine-op", loss_u)):
+        assert abs(float(lv) - float(loss64)) <= 1e-5 * abs(float(loss64)), (name, lv, loss64)
+    yard, bound, over = _gradients_as_close_to_float64_as_the_reference_formulation(g_f, g_u, g64)
+    print("c3 pair %d: nine-op f32 worst gradient error vs float64 %.4f -> bound %.4f; fused "
+          "tensors beyond it: %s" % (first, yard, bound, over))
 
 
 def test_c4_groupfree_backbone_50k_no_features(cuda, monkeypatch):

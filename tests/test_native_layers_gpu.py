@@ -93,9 +93,8 @@ def test_sa_layer_call_equals_python_sequence(cuda, monkeypatch, N, npoint, radi
 
 @pytest.mark.parametrize("N,npoint,radius,S,mlp,C,feat_grad", [
     (8192, 1024, 0.2, 64, [1, 64, 64, 128], 1, False),        # SA1: compact rows + recompute
-    (4096, 512, 0.4, 32, [128, 128, 128, 256], 128, True),    # SA2: compact, 256-wide, 2 k blocks
-    (2048, 1024, 0.8, 16, [256, 128, 128, 256], 256, True),   # SA3 / SA4: groups of 16
-    (2048, 1024, 0.3, 16, [256, 128, 128, 128], 256, True),   # vote aggregation's widths
+    (4096, 512, 0.4, 32, [32, 64, 64, 128], 32, True),        # features, groups of 32
+    (4096, 512, 0.3, 64, [8, 32, 64, 128], 8, True),          # three layers behind 8 features
     (4096, 512, 0.4, 32, [16, 64, 100], 16, True),            # two layers, n = 100
 ])
 def test_gram_form_equals_the_y_reading_form(cuda, monkeypatch, N, npoint, radius, S, mlp, C,
@@ -117,7 +116,7 @@ def test_gram_form_equals_the_y_reading_form(cuda, monkeypatch, N, npoint, radiu
             layer.bn.bn.bias.uniform_(-0.3, 0.3)
     inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
     res, plans = {}, {}
-    for flag in ("0", "2"):   # (2: every shape the Gram form covers, not only the default policy's)
+    for flag in ("0", "2"):   # ("2": any value but "0" -- the Gram form wherever it applies)
         monkeypatch.setenv("BTR_POOL_GRAM", flag)
         mod = copy.deepcopy(sa)
         res[flag] = _sa_run(mod, xyz, feats, inds, False, feat_grad)

@@ -47,6 +47,24 @@ def main():
             max(d for d, n in devs if not n.startswith("backbone_net.sa"))))
         for d, n in devs[:6]:
             print("   %.4f  %s" % (d, n))
+        # where the deviation starts: worst relative L2 per module, in BACKWARD order (the heads
+        # first); a module the deviation has not reached yet sits at float32 rounding level
+        stages = ('backbone_net.sa1.', 'backbone_net.sa2.', 'backbone_net.sa3.',
+                  'backbone_net.sa4.', 'backbone_net.fp1.', 'backbone_net.fp2.', 'vgen.',
+                  'pnet.vote_aggregation.')
+        by = {}
+        for dv, n in devs:
+            st = next((p for p in stages if n.startswith(p)), n.split('.')[0] + '.' + n.split('.')[1])
+            if st not in by or dv > by[st][0]:
+                by[st] = (dv, n)
+        order = [k for k in by if k not in stages] + list(reversed(stages))
+        for k in order:
+            if k in by:
+                print("   stage %-28s worst %.5f  %s" % (k, by[k][0], by[k][1]))
+        for tag, f, u in (("S", fS, uS), ("T", fT, uT)):
+            for k in ('object_assignment', 'objectness_label', 'objectness_mask'):
+                if k in f and k in u:
+                    print("   %s %s differing entries: %d" % (tag, k, int((f[k] != u[k]).sum())))
         # the flip-aware reading of tests/test_configs_gpu.py: rows of every pooled layer's weight
         # gradient that moved by more than 1e-2 of the largest row, most downstream layer first
         for prefix in ('pnet.vote_aggregation.', 'backbone_net.sa4.', 'backbone_net.sa3.',
