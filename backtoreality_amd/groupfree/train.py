@@ -6,7 +6,7 @@ import os
 import torch
 
 from ..pointnet2 import fused_backbone
-from ..votenet.train import FastAdamW, _sync_grads, _zero_grad, backward
+from ..votenet.train import FastAdamW, _sync_grads, _zero_grad, backward, grad_sinks
 from .detector import GroupFreeDetector, GroupFreeDetector_DA, GroupFreeDetector_DA_jitter
 from . import fused_attention
 from .loss_helper import get_loss
@@ -247,8 +247,9 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, loss_args=None, clip_no
             sampling_T = core.backbone_net.prefetch_sampling(batch_T['point_clouds'])
         inputs_T['sampling'] = sampling_T
         _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
-    end_points_S = net(_source_inputs(batch_S, sampling_S))
-    end_points_T = net(inputs_T)
+    with grad_sinks(net):   # (one flat gradient per native node: votenet/train.py)
+        end_points_S = net(_source_inputs(batch_S, sampling_S))
+        end_points_T = net(inputs_T)
     for key in batch_S:
         assert key not in end_points_S
         end_points_S[key] = batch_S[key]
@@ -272,10 +273,11 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, loss_ar
     displacement; batches need 'center_jitter' (synthetic.make_batch(..., center_jitter=))."""
     from .loss_helper import get_loss_DA_jitter
     loss_args = dict(LOSS_ARGS, **(loss_args or {}))
-    end_points_S = net({'point_clouds': batch_S['point_clouds']}, batch_S['center_label'],
-                       batch_S['sem_cls_label'])
-    end_points_T = net({'point_clouds': batch_T['point_clouds']}, batch_T['center_label'],
-                       batch_T['sem_cls_label'])
+    with grad_sinks(net):
+        end_points_S = net({'point_clouds': batch_S['point_clouds']}, batch_S['center_label'],
+                           batch_S['sem_cls_label'])
+        end_points_T = net({'point_clouds': batch_T['point_clouds']}, batch_T['center_label'],
+                           batch_T['sem_cls_label'])
     for key in batch_S:
         end_points_S[key] = batch_S[key]
     for key in batch_T:

@@ -22,11 +22,12 @@ import torch
 from torch.autograd import Function
 
 if __package__:
-    from . import _ext, fused_mlp, fused_sa
+    from . import _ext, fused_mlp, fused_sa, grad_sink
 else:
     import pointnet2._ext as _ext
     import fused_mlp
     import fused_sa
+    import grad_sink
 _p = _ext._p
 
 
@@ -140,6 +141,32 @@ class Entry(object):
                                     (base + fp.dbeta[i], (fp.np[i],), None)]
         self.params = [t for ps in self.sa_params for t in ps] + \
                       [t for ps in self.fp_params for t in ps]
+        self._sink = None
+
+    def views(self, grads):
+        """The parameters' gradients as views of the call's flat gradient buffer."""
+        res = []
+        for view in self.grad_views:
+            if view is None:
+                res.append(None)
+                continue
+            off, padded, shape = view
+            if len(padded) == 1:
+                res.append(grads.as_strided(padded, (1,), off))
+                continue
+            n, k = (shape[0], shape[1]) if shape is not None else padded
+            res.append(grads.as_strided((n, k), (padded[1], 1), off).reshape(shape))
+            # (a level's first layer arrives as dense [n][k] rows -- padded[1] == k in
+            # grad_views -- so no view here is copied by the reshape)
+        return res
+
+    def sink(self, device):
+        """The flat gradient sink of this backbone (grad_sink.py), or None outside its scope."""
+        if not grad_sink.active() or not grad_sink.all_leaves(self.params):
+            return None
+        if self._sink is None or self._sink.tensor.device != device:
+            self._sink = grad_sink.Sink(self.plan.grads_floats, device, self.views)
+        return self._sink.bind(self.params)
 
     def bind(self):
         """Refresh the parameter / buffer pointers and BatchNorm momenta of the description
@@ -309,14 +336,15 @@ def sample(entry, pointcloud, stream=None, side=None):
 
 
 class FusedBackboneFn(Function):
-    """forward(cloud, sampling, entry, *params) -> (SA outputs..., FP outputs...) as (B, C, M)
+    """forward(cloud, sampling, entry, sink, *params) -> (SA outputs..., FP outputs...) as (B, C, M)
     views of one arena; their channel-last twins ((B, M, C) for the levels, (B*N, C) for the
     modules, as the layer-by-layer path attaches them) are left in `entry.last_twins`."""
 
     @staticmethod
-    def forward(ctx, cloud, sampling, entry, *params):
+    def forward(ctx, cloud, sampling, entry, sink, *params):
         d, plan = entry.d, entry.plan
         dev = cloud.device
+        ctx.to_sink = sink is not None
         entry.bind()
         out = torch.empty((plan.out_bytes // 4,), dtype=torch.float32, device=dev)
         saved = torch.empty((plan.saved_bytes,), dtype=torch.uint8, device=dev)
@@ -357,17 +385,6 @@ class FusedBackboneFn(Function):
             _ext._call(entry.lib.btr_backbone_backward, ctypes.addressof(d),
                        ctypes.addressof(plan), _p(geom), _p(out), dsa, dfp, _p(saved), _p(grads),
                        _p(scratch), _ext._stream(dv))
-        res = []
-        for view in entry.grad_views:
-            if view is None:
-                res.append(None)
-                continue
-            off, padded, shape = view
-            if len(padded) == 1:
-                res.append(grads.as_strided(padded, (1,), off))
-                continue
-            n, k = (shape[0], shape[1]) if shape is not None else padded
-            res.append(grads.as_strided((n, k), (padded[1], 1), off).reshape(shape))
-            # (a level's first layer arrives as dense [n][k] rows -- padded[1] == k in
-            # grad_views -- so no view here is copied by the reshape)
-        return (None, None, None) + tuple(res)
+        if ctx.to_sink:   # (one flat gradient for the sink, grad_sink.py)
+            return (None, None, None, grads) + (None,) * len(entry.grad_views)
+        return (None, None, None, None) + tuple(entry.views(grads))

@@ -24,9 +24,10 @@ import torch
 from torch.autograd import Function
 
 if __package__:
-    from . import _ext
+    from . import _ext, grad_sink
 else:
     import pointnet2._ext as _ext
+    import grad_sink
 _call, _lib, _on, _p, _stream = _ext._call, _ext._lib, _ext._on, _ext._p, _ext._stream
 
 
@@ -338,23 +339,16 @@ class PointwiseChain(Function):
     a kernel of the library instead of torch.sum (rounding-level difference)."""
 
     @staticmethod
-    def forward(ctx, x, meta, *params):
+    def forward(ctx, x, meta, sink, *params):
         layers = meta["layers"]
         L = len(layers)
         dev = x.device
         B, K0, N = x.shape
         rows = B * N
         need_dx = bool(ctx.needs_input_grad[0])
-        key = (B, K0, N, need_dx)
-        cache = meta["cache"]
-        ent = cache.get(key)
-        if ent is None:
-            d = _ext.PmChain()
-            chain_static(d, B, K0, N, layers, params, need_dx)
-            plan = _ext.PmPlan()
-            _call(_lib.btr_pm_chain_plan, ctypes.addressof(d), ctypes.addressof(plan))
-            ent = cache[key] = (d, plan, chain_sizes(plan, L))
-        d, plan, sizes = ent
+        ent = chain_entry(meta, x, params, need_dx)
+        ctx.to_sink = sink is not None
+        d, plan, sizes = ent[:3]
         chain_pointers(d, layers, params)
         x_cl = _ext.twin_of(x)
         if x_cl is not None and (x_cl.shape != (rows, K0) or not x_cl.is_contiguous() or K0 % 4):
@@ -369,7 +363,7 @@ class PointwiseChain(Function):
             _call(_lib.btr_pm_chain_forward, ctypes.addressof(d), ctypes.addressof(plan), _p(xb),
                   _p(x_cl), _p(out), _p(out_cl), _p(saved), _p(scratch), _stream(dv))
         _ext.attach_twin(out, out_cl)
-        ctx.plan = ent
+        ctx.plan = tuple(ent[:3])
         ctx.has_x_cl = x_cl is not None
         ctx.pshapes = [None if p is None else p.shape for p in params]
         if x_cl is not None:
@@ -392,7 +386,38 @@ class PointwiseChain(Function):
         with _on(dout) as dv:
             _call(_lib.btr_pm_chain_backward, ctypes.addressof(d), ctypes.addressof(plan),
                   _p(x_cl), _p(dout), _p(saved), _p(grads), _p(dx), _p(scratch), _stream(dv))
-        return (dx, None) + tuple(chain_grad_views(d, plan, sizes, ctx.pshapes, grads))
+        if ctx.to_sink:   # (one flat gradient for the sink, grad_sink.py)
+            return (dx, None, grads) + (None,) * len(ctx.pshapes)
+        return (dx, None, None) + tuple(chain_grad_views(d, plan, sizes, ctx.pshapes, grads))
+
+
+def chain_entry(meta, x, params, need_dx):
+    """[description, plan, gradient block sizes, sink | None] of a chain at this input shape."""
+    B, K0, N = x.shape
+    key = (B, K0, N, bool(need_dx))
+    cache = meta["cache"]
+    ent = cache.get(key)
+    if ent is None:
+        layers = meta["layers"]
+        d = _ext.PmChain()
+        chain_static(d, B, K0, N, layers, params, need_dx)
+        plan = _ext.PmPlan()
+        _call(_lib.btr_pm_chain_plan, ctypes.addressof(d), ctypes.addressof(plan))
+        ent = cache[key] = [d, plan, chain_sizes(plan, len(layers)), None]
+    return ent
+
+
+def chain_sink(meta, x, params):
+    """The flat gradient sink of this chain call (grad_sink.py), or None outside its scope."""
+    if not grad_sink.active() or not grad_sink.all_leaves(params):
+        return None
+    ent = chain_entry(meta, x, params, x.requires_grad)
+    if ent[3] is None or ent[3].tensor.device != x.device:
+        d, plan, sizes = ent[:3]
+        pshapes = [None if p is None else p.shape for p in params]
+        ent[3] = grad_sink.Sink(plan.grads_floats, x.device,
+                                lambda g: chain_grad_views(d, plan, sizes, pshapes, g))
+    return ent[3].bind(params)
 
 
 def _layer_ok(conv, bn, K, first):
@@ -488,6 +513,7 @@ def _run_chain(x, chain):
         if cache is None:
             cache = _CHAIN_CACHE[chain[0][0]] = {}
         PATHS["library"] += 1
-        return PointwiseChain.apply(x, {"layers": metas, "cache": cache}, *params)
+        meta = {"layers": metas, "cache": cache}
+        return PointwiseChain.apply(x, meta, chain_sink(meta, x, params), *params)
     PATHS["python"] += 1
     return PointwiseMLP.apply(x, {"layers": metas}, *params)

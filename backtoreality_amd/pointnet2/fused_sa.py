@@ -18,9 +18,11 @@ from torch.autograd import Function
 
 if __package__:
     from . import _ext
+    from . import grad_sink
     from . import pointnet2_utils
 else:  # top-level import, like the reference's scripts (sys.path.append(.../pointnet2))
     import pointnet2._ext as _ext
+    import grad_sink
     import pointnet2_utils
 _call, _lib, _on, _p, _stream = _ext._call, _ext._lib, _ext._on, _ext._p, _ext._stream
 
@@ -447,13 +449,14 @@ class FusedSALayer(Function):
     (saved / scratch / flat gradients) and one call each way.  Same kernels, same results."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, features, idx, meta, *params):
+    def forward(ctx, xyz, new_xyz, features, idx, meta, sink, *params):
         dev = xyz.device
         B, N, _ = xyz.shape
         M, S = idx.shape[1], idx.shape[2]
         C = features.shape[1] if features is not None else 0
         bns = meta["bns"]
         L = len(params) // 3
+        ctx.to_sink = sink is not None
         xyz = xyz.contiguous()
         new_xyz = new_xyz.contiguous()
         feats_cl = None
@@ -463,28 +466,8 @@ class FusedSALayer(Function):
                 feats_cl = None
             if feats_cl is None or feats_cl.shape != (B, N, C):
                 feats_cl = features.transpose(1, 2).contiguous()
-        need = ctx.needs_input_grad
-        key = (B, N, M, S, C, bool(need[0]), bool(need[1]), bool(need[2]), _sa_options())
-        cache = meta["cache"]
-        ent = cache.get(key)
-        if ent is None:
-            d = _ext.SaLayer()
-            d.b, d.n, d.m, d.s, d.c = B, N, M, S, C
-            d.use_xyz = 1 if meta["use_xyz"] else 0
-            d.radius_div = float(meta["radius_div"])
-            d.layers = L
-            for l in range(L):
-                d.width[l] = params[3 * l].shape[0]
-                d.eps[l] = float(bns[l].eps)
-            d.need_dxyz, d.need_dnew_xyz, d.need_dfeat = int(need[0]), int(need[1]), int(need[2])
-            d.options = key[-1]
-            plan = _ext.SaPlan()
-            _call(_lib.btr_sa_layer_plan, ctypes.addressof(d), ctypes.addressof(plan))
-            sizes = []
-            for l in range(L):
-                sizes += [d.width[l] * plan.kin[l], d.width[l], d.width[l]]
-            ent = cache[key] = (d, plan, sizes)
-        d, plan, sizes = ent
+        ent = _sa_entry(meta, B, N, M, S, C, ctx.needs_input_grad, params)
+        d, plan, sizes = ent[:3]
         for l in range(L):
             W, gamma, beta = params[3 * l:3 * l + 3]
             bn = bns[l]
@@ -506,7 +489,7 @@ class FusedSALayer(Function):
                   _p(xyz), _p(new_xyz), _p(feats_cl), _p(idx), _p(out), _p(out_cl), _p(saved),
                   _p(scratch), _stream(dv))
         _ext.attach_twin(out, out_cl)
-        ctx.plan = ent
+        ctx.plan = tuple(ent[:3])
         ctx.dims = (B, N, M, C)
         ctx.pshapes = [p.shape for p in params]
         ctx.save_for_backward(idx, saved, out)
@@ -528,19 +511,72 @@ class FusedSALayer(Function):
             _call(_lib.btr_sa_layer_backward, ctypes.addressof(d), ctypes.addressof(plan),
                   _p(idx), _p(out), _p(dout), _p(saved), _p(grads), _p(dfeat), _p(dxyz),
                   _p(dnew), _p(scratch), _stream(dv))
-        parts = grads.split(sizes)
-        res = []
-        for l in range(d.layers):
-            shape = ctx.pshapes[3 * l]
-            if l == 0 and not plan.recompute:
-                # written without the padding columns (csrc/sa_layer.hip reduce_unpad_next)
-                dW = parts[0][:d.width[0] * shape[1]].view(d.width[0], shape[1])
-            else:
-                dW = parts[3 * l].view(d.width[l], plan.kin[l])
-                if plan.kin[l] != shape[1]:
-                    dW = dW[:, :shape[1]]
-            res += [dW.reshape(shape), parts[3 * l + 1], parts[3 * l + 2]]
-        return (dxyz, dnew, dfeat, None, None) + tuple(res)
+        if ctx.to_sink:   # (one flat gradient for the sink, grad_sink.py)
+            return (dxyz, dnew, dfeat, None, None, grads) + (None,) * len(ctx.pshapes)
+        return (dxyz, dnew, dfeat, None, None, None) + tuple(
+            sa_grad_views(d, plan, sizes, ctx.pshapes, grads))
+
+
+def _sa_entry(meta, B, N, M, S, C, need, params):
+    """[description, plan, gradient block sizes, sink | None] of a fused SA layer at this shape
+    (`need`: which of xyz / new_xyz / features take a gradient)."""
+    key = (B, N, M, S, C, bool(need[0]), bool(need[1]), bool(need[2]), _sa_options())
+    cache = meta["cache"]
+    ent = cache.get(key)
+    if ent is None:
+        bns = meta["bns"]
+        L = len(params) // 3
+        d = _ext.SaLayer()
+        d.b, d.n, d.m, d.s, d.c = B, N, M, S, C
+        d.use_xyz = 1 if meta["use_xyz"] else 0
+        d.radius_div = float(meta["radius_div"])
+        d.layers = L
+        for l in range(L):
+            d.width[l] = params[3 * l].shape[0]
+            d.eps[l] = float(bns[l].eps)
+        d.need_dxyz, d.need_dnew_xyz, d.need_dfeat = int(need[0]), int(need[1]), int(need[2])
+        d.options = key[-1]
+        plan = _ext.SaPlan()
+        _call(_lib.btr_sa_layer_plan, ctypes.addressof(d), ctypes.addressof(plan))
+        sizes = []
+        for l in range(L):
+            sizes += [d.width[l] * plan.kin[l], d.width[l], d.width[l]]
+        ent = cache[key] = [d, plan, sizes, None]
+    return ent
+
+
+def _sa_sink(meta, xyz, new_xyz, features, idx, params):
+    """The flat gradient sink of this layer call (grad_sink.py), or None outside its scope."""
+    if not grad_sink.active() or not grad_sink.all_leaves(params):
+        return None
+    B, N, _ = xyz.shape
+    need = (xyz.requires_grad, new_xyz.requires_grad,
+            features is not None and features.requires_grad)
+    ent = _sa_entry(meta, B, N, idx.shape[1], idx.shape[2],
+                    features.shape[1] if features is not None else 0, need, params)
+    if ent[3] is None or ent[3].tensor.device != xyz.device:
+        d, plan, sizes = ent[:3]
+        pshapes = [p.shape for p in params]
+        ent[3] = grad_sink.Sink(plan.grads_floats, xyz.device,
+                                lambda g: sa_grad_views(d, plan, sizes, pshapes, g))
+    return ent[3].bind(params)
+
+
+def sa_grad_views(d, plan, sizes, pshapes, grads):
+    """[dW, dgamma, dbeta] per layer as views of a fused SA layer's flat gradient buffer."""
+    parts = grads.split(sizes)
+    res = []
+    for l in range(d.layers):
+        shape = pshapes[3 * l]
+        if l == 0 and not plan.recompute:
+            # written without the padding columns (csrc/sa_layer.hip reduce_unpad_next)
+            dW = parts[0][:d.width[0] * shape[1]].view(d.width[0], shape[1])
+        else:
+            dW = parts[3 * l].view(d.width[l], plan.kin[l])
+            if plan.kin[l] != shape[1]:
+                dW = dW[:, :shape[1]]
+        res += [dW.reshape(shape), parts[3 * l + 1], parts[3 * l + 2]]
+    return res
 
 
 def fused_eval_forward(module, xyz, new_xyz, features, idx):
@@ -703,5 +739,6 @@ def fused_group_mlp_max(module, xyz, new_xyz, features):
     meta = {"radius_div": g.radius if g.normalize_xyz else 1.0, "use_xyz": g.use_xyz, "bns": bns,
             "cache": cache}
     if native_enabled() and len(bns) <= _ext.MAX_LAYERS:
-        return FusedSALayer.apply(xyz, new_xyz, features, idx, meta, *params)
+        return FusedSALayer.apply(xyz, new_xyz, features, idx, meta,
+                                  _sa_sink(meta, xyz, new_xyz, features, idx, params), *params)
     return FusedSAFunction.apply(xyz, new_xyz, features, idx, meta, *params)

@@ -298,7 +298,8 @@ class Pointnet2Backbone(nn.Module):
             sampling = fused_backbone.sample(entry, pointcloud, side=side)
         elif sampling.event is not None:
             torch.cuda.current_stream(dev).wait_event(sampling.event)
-        outs = fused_backbone.FusedBackboneFn.apply(pointcloud, sampling, entry, *entry.params)
+        outs = fused_backbone.FusedBackboneFn.apply(pointcloud, sampling, entry,
+                                                    entry.sink(pointcloud.device), *entry.params)
         twins, entry.last_twins = entry.last_twins, None
         for o, t in zip(outs, twins):
             _ext.attach_twin(o, t)

@@ -160,6 +160,21 @@ def _zero_grad(net, optimizer):
             p.grad = None
 
 
+def grad_sinks(net):
+    """Context for the forwards of a step that runs the same parameters through TWO forwards
+    (Back-to-Reality): every native node hands autograd ONE flat gradient (pointnet2/
+    grad_sink.py) instead of a view per parameter, so the two branches' contributions are added
+    by a launch per node, not by 117 per-parameter launches.  Off (a null context) under torch's
+    DistributedDataParallel, whose reducer listens on the parameters' own gradient hooks, and
+    with BTR_GRAD_SINK=0."""
+    import contextlib
+    from ..pointnet2 import grad_sink
+    if os.environ.get("BTR_GRAD_SINK", "1") == "0" or \
+            isinstance(net, torch.nn.parallel.DistributedDataParallel):
+        return contextlib.nullcontext()
+    return grad_sink.scope()
+
+
 def _sync_grads(net):
     if isinstance(net, FlatGradParallel):
         net.sync_gradients()
@@ -657,8 +672,9 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, sampling_S=None, next_b
     nxt = ({}, {})
     if early:
         _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
-    end_points_S = net(_source_inputs(batch_S, sampling_S))
-    end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T})
+    with grad_sinks(net):
+        end_points_S = net(_source_inputs(batch_S, sampling_S))
+        end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T})
     for key in batch_S:
         end_points_S[key] = batch_S[key]
     for key in batch_T:
@@ -688,10 +704,11 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, samplin
     nxt = ({}, {})
     if early:
         _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
-    end_points_S = net(_source_inputs(batch_S, sampling_S), batch_S['center_label'],
-                       batch_S['sem_cls_label'])
-    end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T},
-                       batch_T['center_label'], batch_T['sem_cls_label'])
+    with grad_sinks(net):
+        end_points_S = net(_source_inputs(batch_S, sampling_S), batch_S['center_label'],
+                           batch_S['sem_cls_label'])
+        end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T},
+                           batch_T['center_label'], batch_T['sem_cls_label'])
     for key in batch_S:
         end_points_S[key] = batch_S[key]
     for key in batch_T:
