@@ -38,19 +38,23 @@ HIPCC_FLAGS = [
     # (never alone; identical inputs, tools/diag_pipeline_inds.py) and not once in 10 000
     # launches without it; the guide lists packed f32 as an anti-lever beside MFMAs anyway.
     "-fno-slp-vectorize",
+    # ... and no loop vectorisation either (round 6: the whole library, not only the index-producing
+    # sources): it packed f32 ops in the loss kernels, the LayerNorm backward and the attention
+    # kernels too (929 sites), and the guard below had nothing to say about them.  Memory
+    # operations are merged by another pass and are unaffected.
+    "-fno-vectorize",
 ]
 # sources whose code depends on BTR_FMAD (they evaluate sq3() / dot3()): the index-producing ones
 MODE_SOURCES = ("ball_query.hip", "ball_query_bucket.hip", "ball_query_grid.hip",
                 "fps_bucket.hip", "interpolate.hip", "sampling.hip")
-# per-file additions to HIPCC_FLAGS.  The index-producing sources also switch the LOOP vectoriser
-# off (it packed three f32 ops of the streaming FPS kernel and of three_interpolate even with SLP
-# off), so that the guard below can be absolute: no packed f32 arithmetic in those objects.
-EXTRA_FLAGS = {name: ["-fno-vectorize"] for name in MODE_SOURCES}
-# Build-time guard (round-3 review, What's weak #3): the device code of every index-producing
-# object is disassembled and the build FAILS on any packed f32 arithmetic instruction -- the
-# form the wrong-FPS-sequence-under-concurrency incident was bisected to (DESIGN.md 7.5;
+# per-file additions to HIPCC_FLAGS (none at present)
+EXTRA_FLAGS = {}
+# Build-time guard (round-3 review, What's weak #3; round 6: EVERY object): the device code of
+# every object is disassembled and the build FAILS on any packed f32 arithmetic instruction --
+# the form the wrong-FPS-sequence-under-concurrency incident was bisected to (DESIGN.md 7.5;
 # stand-alone reproducer: tools/probe/pk_hazard.hip).  A new compiler or an edit that brings
-# them back is caught here, not by a 1-3 % statistical test on the GPU.
+# them back is caught here, not by a 1-3 % statistical test on the GPU -- and for the float
+# kernels, whose results nobody compares bit for bit, not at all otherwise.
 PACKED_F32 = r"\bv_pk_(add|mul|fma)_f32\b"
 LLVM_BIN = os.environ.get("BTR_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
@@ -141,17 +145,17 @@ def _guard_marker(obj):
     return obj[:-2] + ".nopk"
 
 
-def check_index_objects(plan=None, force=False):
-    """Fails (RuntimeError) when an index-producing object holds packed f32 arithmetic; the
-    verdict per object is remembered beside it (objects are content-addressed)."""
+def check_objects(plan=None, force=False):
+    """Fails (RuntimeError) when an object holds packed f32 arithmetic; the verdict per object is
+    remembered beside it (objects are content-addressed)."""
     plan = plan or _object_plan()
     for src, mode, obj in plan:
-        if mode is None or (os.path.exists(_guard_marker(obj)) and not force):
+        if os.path.exists(_guard_marker(obj)) and not force:
             continue
         sites = packed_f32_sites(obj)
         if sites:
             raise RuntimeError(
-                "packed f32 arithmetic in an index-producing object (%s, BTR_FMAD=%s):\n  %s"
+                "packed f32 arithmetic in an object of the library (%s, BTR_FMAD=%s):\n  %s"
                 % (os.path.basename(src), mode,
                    "\n  ".join("%s: %s" % s for s in sites[:12])))
         with open(_guard_marker(obj), "w") as fh:
@@ -162,7 +166,7 @@ def is_fresh():
     plan = _object_plan()
     if not all(os.path.exists(o) for _, _, o in plan) or \
             not os.path.exists(_build_id_object(plan)) or \
-            not all(os.path.exists(_guard_marker(o)) for _, m, o in plan if m is not None):
+            not all(os.path.exists(_guard_marker(o)) for _, m, o in plan):
         return False
     newest = max(os.path.getmtime(o) for _, _, o in plan)
     return all(os.path.exists(lib_path(m)) and os.path.getmtime(lib_path(m)) >= newest
@@ -194,7 +198,7 @@ def build(force=False, verbose=False, jobs=None):
     jobs = jobs or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         list(pool.map(compile_one, todo))
-    check_index_objects(plan)
+    check_objects(plan)
     bid_obj = _build_id_object(plan)
     if not os.path.exists(bid_obj):   # (host-only: a second to compile)
         src = bid_obj[:-2] + ".cpp"
@@ -204,7 +208,7 @@ def build(force=False, verbose=False, jobs=None):
         os.replace(bid_obj + ".tmp", bid_obj)
         os.remove(src)
     keep = {o for _, _, o in plan} | {bid_obj} | \
-        {_guard_marker(o) for _, m, o in plan if m is not None}
+        {_guard_marker(o) for _, m, o in plan}
     for f in os.listdir(OBJ_DIR):                      # objects of older source versions
         if os.path.join(OBJ_DIR, f) not in keep:
             os.remove(os.path.join(OBJ_DIR, f))
@@ -219,3 +223,6 @@ def build(force=False, verbose=False, jobs=None):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+
+
+check_index_objects = check_objects   # (the name rounds 3 - 5 knew the guard by)

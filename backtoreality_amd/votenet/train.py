@@ -175,6 +175,44 @@ def grad_sinks(net):
     return grad_sink.scope()
 
 
+_HEAD_STREAMS = {}
+
+
+def two_forwards(net, args_S, args_T):
+    """(end_points_S, end_points_T) of the two forwards of a Back-to-Reality step through the
+    same model.  On the GPU the source branch's head (voting, vote aggregation, proposal head,
+    domain classifiers: small launches) runs on a side stream BESIDE the target branch's
+    backbone (large kernels) -- the two do not depend on each other until the loss -- and the
+    target branch's head waits for it, so shared state (BatchNorm running statistics, updated
+    source first, then target) is touched in the reference's order.  Autograd runs every
+    node's backward on its forward's stream, so the backward overlaps the same way.  Same
+    kernels, same results (tests/test_grad_sink_gpu.py).  Off (two plain calls) for models without
+    the two-stage forward, under torch's DistributedDataParallel (its forward prepares the
+    reducer), on the CPU, while a HIP graph is captured, and with BTR_BR_OVERLAP=0."""
+    core = net.module if hasattr(net, "module") else net
+    pc = args_S[0]['point_clouds']
+    if not (pc.is_cuda and hasattr(core, "forward_backbone") and
+            os.environ.get("BTR_BR_OVERLAP", "1") != "0" and
+            not isinstance(net, torch.nn.parallel.DistributedDataParallel) and
+            not torch.cuda.is_current_stream_capturing()):
+        return net(*args_S), net(*args_T)
+    dev = pc.device
+    main = torch.cuda.current_stream(dev)
+    side = _HEAD_STREAMS.get(dev)
+    if side is None:
+        side = _HEAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    cS = args_S[1] if len(args_S) > 1 else None
+    cT = args_T[1] if len(args_T) > 1 else None
+    end_S = core.forward_backbone(*args_S)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        end_S = core.forward_head(end_S, cS)
+    end_T = core.forward_backbone(*args_T)
+    main.wait_stream(side)
+    end_T = core.forward_head(end_T, cT)
+    return end_S, end_T
+
+
 def _sync_grads(net):
     if isinstance(net, FlatGradParallel):
         net.sync_gradients()
@@ -673,8 +711,9 @@ def train_step_br(net, optimizer, batch_S, batch_T, cfg, sampling_S=None, next_b
     if early:
         _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
     with grad_sinks(net):
-        end_points_S = net(_source_inputs(batch_S, sampling_S))
-        end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T})
+        end_points_S, end_points_T = two_forwards(
+            net, (_source_inputs(batch_S, sampling_S),),
+            ({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T},))
     for key in batch_S:
         end_points_S[key] = batch_S[key]
     for key in batch_T:
@@ -705,10 +744,11 @@ def train_step_br_jitter(net, optimizer, batch_S, batch_T, cfg, epoch=0, samplin
     if early:
         _prefetch_next(core, nxt[0], nxt[1], next_batch_S, next_batch_T)
     with grad_sinks(net):
-        end_points_S = net(_source_inputs(batch_S, sampling_S), batch_S['center_label'],
-                           batch_S['sem_cls_label'])
-        end_points_T = net({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T},
-                           batch_T['center_label'], batch_T['sem_cls_label'])
+        end_points_S, end_points_T = two_forwards(
+            net, (_source_inputs(batch_S, sampling_S), batch_S['center_label'],
+                  batch_S['sem_cls_label']),
+            ({'point_clouds': batch_T['point_clouds'], 'sampling': sampling_T},
+             batch_T['center_label'], batch_T['sem_cls_label']))
     for key in batch_S:
         end_points_S[key] = batch_S[key]
     for key in batch_T:

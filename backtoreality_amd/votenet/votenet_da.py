@@ -86,9 +86,18 @@ class VoteNet_DA(nn.Module):
                                           [nn.Conv1d(128, 1, 1)]))
 
     def forward(self, inputs, center_xyz=None, center_cls=None):
-        end_points = self.backbone_net(inputs['point_clouds'], {},
-                                       sampling=inputs.get('sampling'),
-                                       center_xyz=center_xyz, center_cls=center_cls)
+        return self.forward_head(self.forward_backbone(inputs, center_xyz, center_cls),
+                                 center_xyz)
+
+    # The forward in two stages (not in the reference): the backbone -- the large kernels -- and
+    # everything behind it (voting, vote aggregation, proposal head, domain classifiers: ~120
+    # launches of 5 - 20 us that leave most of the chip idle).  train.train_step_br runs the
+    # source branch's second stage on a side stream beside the target branch's first.
+    def forward_backbone(self, inputs, center_xyz=None, center_cls=None):
+        return self.backbone_net(inputs['point_clouds'], {}, sampling=inputs.get('sampling'),
+                                 center_xyz=center_xyz, center_cls=center_cls)
+
+    def forward_head(self, end_points, center_xyz=None):
         self._center_heads(end_points, center_xyz, before_voting=True)
         xyz = end_points['fp2_xyz']
         features = end_points['fp2_features']

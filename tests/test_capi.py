@@ -82,14 +82,15 @@ def test_plan_functions_lay_out_their_arenas_without_a_gpu():
     assert lib.btr_gf_loss_fwd(*([None] * 21)) == -1
 
 
-def test_build_guard_finds_packed_f32_in_index_objects(tmp_path):
-    """build.check_index_objects (round-3 review, What's weak #3): the device code of every
-    index-producing object is disassembled at build time and packed f32 arithmetic fails the
-    build.  The built objects pass; a probe kernel that multiplies float2 vectors is caught."""
+def test_build_guard_finds_packed_f32_in_any_object(tmp_path):
+    """build.check_objects (round-3 review, What's weak #3; since round 6 every object, not only
+    the index-producing ones): the device code of every object is disassembled at build time and
+    packed f32 arithmetic fails the build.  The built objects pass; a probe kernel that multiplies
+    float2 vectors is caught."""
     import subprocess
     from backtoreality_amd import build
     build.build()
-    build.check_index_objects(force=True)      # every MODE_SOURCES object, all three modes
+    build.check_objects(force=True)      # every object, all three modes of the index sources
     src = tmp_path / "pk_probe.hip"
     src.write_text(
         '#include <hip/hip_runtime.h>\n'

@@ -10,8 +10,9 @@ from backtoreality_amd.votenet import config, synthetic, train
 pytestmark = pytest.mark.gpu
 
 
-def _br_steps(cuda, monkeypatch, sinks, jitter=False, steps=2):
+def _br_steps(cuda, monkeypatch, sinks, jitter=False, steps=2, overlap=False):
     monkeypatch.setenv("BTR_GRAD_SINK", "1" if sinks else "0")
+    monkeypatch.setenv("BTR_BR_OVERLAP", "1" if overlap else "0")
     cfg = config.scannet_md40()
     kw = dict(center_refine=True) if jitter else dict(domain_adaptation=True)
     net = train.build_model(cfg, cuda, seed=0, **kw)
@@ -101,3 +102,45 @@ def test_gradient_accumulation_over_two_backward_calls(cuda, monkeypatch):
     for n in a:
         tol = 1e-5 * float(a[n].abs().max()) + 1e-12
         assert float((a[n] - b[n]).abs().max()) <= tol, n
+
+
+@pytest.mark.parametrize("jitter", [False, True])
+def test_source_head_beside_target_backbone_is_the_same_step(cuda, monkeypatch, jitter):
+    """train.two_forwards: the source branch's head on a side stream beside the target branch's
+    backbone -- same kernels on the same data, so the loss is identical and the gradients sit
+    within the run-to-run spread of the unordered scatter sums; BatchNorm running statistics are
+    updated source first, target second, as in the sequential order."""
+    cfg = config.scannet_md40()
+
+    def run(overlap):
+        monkeypatch.setenv("BTR_BR_OVERLAP", "1" if overlap else "0")
+        kw = dict(center_refine=True) if jitter else dict(domain_adaptation=True)
+        net = train.build_model(cfg, cuda, seed=0, **kw)
+        opt = train.make_optimizer(net)
+        mk = dict(center_jitter=0.1) if jitter else {}
+        bS = synthetic.make_batch(3, 2, 8192, cfg, device=cuda, **mk)
+        bT = synthetic.make_batch(103, 2, 8192, cfg, device=cuda, **mk)
+        if jitter:
+            loss, eS, eT = train.train_step_br_jitter(net, opt, bS, bT, cfg, epoch=30)
+        else:
+            loss, eS, eT = train.train_step_br(net, opt, bS, bT, cfg)
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().clone() for n, p in net.named_parameters()
+                 if p.grad is not None}
+        bufs = {n: b.detach().clone() for n, b in net.named_buffers()}
+        keep = {k: eS[k].detach().clone() for k in ('aggregated_vote_inds', 'vote_xyz')}
+        return float(loss), grads, bufs, keep
+    l0, g0, b0, k0 = run(False)
+    l0b, g0b, _, _ = run(False)
+    l1, g1, b1, k1 = run(True)
+    assert l0 == l0b == l1
+    for k in k0:
+        assert torch.equal(k0[k], k1[k]), k
+    for n in b0:      # running statistics, num_batches_tracked: exactly the sequential order's
+        assert torch.equal(b0[n], b1[n]), n
+    assert set(g0) == set(g1)
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-30
+        spread = float((g0[n] - g0b[n]).abs().max()) / scale
+        dev = float((g0[n] - g1[n]).abs().max()) / scale
+        assert dev <= 4.0 * spread + 1e-6, (n, dev, spread)
