@@ -320,6 +320,10 @@ def get_loss_DA(end_points_S, end_points_T, config):
 def _domain_loss(end_points_S, end_points_T):
     """Focal loss on the global domain classifier + squared loss on the local one, both
     through the gradient-reversal layers (loss_helper.py:618-650)."""
+    if end_points_S['global_d_pred'].is_cuda:
+        from . import fused_loss
+        if fused_loss.domain_loss_fusable(end_points_S, end_points_T):
+            return fused_loss.domain_loss(end_points_S, end_points_T, 3.0)   # (one launch each way)
     da_coefficient = 0.5
     g_S = end_points_S['global_d_pred']
     l_S = end_points_S['local_d_pred'].transpose(1, 2).contiguous()

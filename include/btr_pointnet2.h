@@ -474,6 +474,16 @@ int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
                          float *dagg, float *dvote, const float *weights8, int vote_mode,
                          const int *i2v, btr_stream_t stream);
 
+/* The domain-adaptation term of get_loss_DA (reference: detection/Votenet/models/loss_helper.py:
+ * 618-650 with FocalLoss, :466-545): per branch 0.5 * mean(e(l)^2 * objectness_label) + 0.5 *
+ * focal(softmax(global_d_pred), domain, gamma), e(l) = l (source, domain 0) / 1 - l (target,
+ * domain 1).  global_* (b, 2) logits, local_* (b, k) sigmoid outputs, label_* (b, k) i64.
+ * out[3] = (total, source part, target part); grads (4 b + 2 b k floats) = the gradient for a unit
+ * upstream gradient, [d global_S | d local_S | d global_T | d local_T].  One launch. */
+int btr_domain_loss(int b, int k, float gamma, const float *global_S, const float *local_S,
+                    const long long *label_S, const float *global_T, const float *local_T,
+                    const long long *label_T, float *out, float *grads, btr_stream_t stream);
+
 /* out (b,m,c) <- src (b,n,c)[idx (b,m)]: row gather of a channel-last tensor.  No counterpart of
  * its own in the reference: it does transpose + gather_points + transpose for `new_xyz`
  * (pointnet2/pointnet2_modules.py:238-240); same values. */

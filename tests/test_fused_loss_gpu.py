@@ -212,3 +212,29 @@ def test_fused_da_loss_matches_torch_composition(cuda, monkeypatch):
     for branch in range(2):
         for a, b in zip(g_f[branch], g_t[branch]):
             assert _close(a, b), (branch, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("B,K", [(8, 256), (3, 100), (1, 17)])
+def test_fused_domain_loss_matches_torch_composition(cuda, monkeypatch, B, K):
+    """loss_helper._domain_loss (the domain-adaptation term of get_loss_DA, reference
+    loss_helper.py:618-650): one launch each way against the torch composition -- value 1e-6,
+    every gradient 1e-5 of its largest entry, with an upstream gradient other than 1."""
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    mk = lambda *s: torch.randn(*s, generator=g).to(cuda)
+    base = {t: {'global_d_pred': mk(B, 2) * 2, 'local_d_pred': torch.sigmoid(mk(B, 1, K)),
+                'objectness_label': (torch.rand(B, K, generator=g) < 0.3).long().to(cuda)}
+            for t in "ST"}
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setenv("BTR_FUSED_LOSS", "1" if fused else "0")
+        ends = {t: {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 else v)
+                    for k, v in base[t].items()} for t in "ST"}
+        loss = loss_helper._domain_loss(ends["S"], ends["T"])
+        (loss * -3.5).backward()
+        res[fused] = (loss.detach(), [ends[t][k].grad for t in "ST"
+                                      for k in ('global_d_pred', 'local_d_pred')])
+    (lt, gt), (lf, gf) = res[False], res[True]
+    assert abs(float(lf) - float(lt)) <= 1e-6 * max(1.0, abs(float(lt)))
+    for a, b in zip(gf, gt):
+        assert a.shape == b.shape
+        assert _close(a, b), float((a - b).abs().max())
