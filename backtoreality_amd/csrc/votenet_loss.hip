@@ -458,14 +458,15 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(
 // ---------------------------------------------------------------- the domain-adaptation term
 // reference: detection/Votenet/models/loss_helper.py:618-650 (get_loss_DA) and :466-545
 // (FocalLoss, alpha = 1) -- per branch
-//   0.5 * mean_{b,k}( e(l)^2 * w ) + 0.5 * mean_b( -(1 - p_t)^gamma * log p_t ),
+//   coef * mean_{b,k}( e(l)^2 * w ) + coef * mean_b( -(1 - p_t)^gamma * log p_t ),
 // l = local_d_pred (b, 1, k) (sigmoid outputs), w = objectness_label, e(l) = l for the source
 // branch (domain 0) and 1 - l for the target (domain 1), p = softmax(global_d_pred (b, 2)),
-// t = the branch's domain.  ~25 element-wise / reduction launches forward and ~35 backward as
+// t = the branch's domain; coef = 0.5 (VoteNet's da_coefficient) or 1 (GroupFree3D's
+// loss_helper.py:673-712, the same terms unweighted).  ~25 element-wise / reduction launches forward and ~35 backward as
 // torch ops; here ONE workgroup computes the value and the gradient for a unit upstream
 // gradient (grads: [d gS (2b) | d lS (b k) | d gT (2b) | d lT (b k)]), the backward scales them.
 __global__ __launch_bounds__(256) void domain_loss_kernel(
-    int b, int k, float gamma, const float *__restrict__ gS, const float *__restrict__ lS,
+    int b, int k, float gamma, float coef, const float *__restrict__ gS, const float *__restrict__ lS,
     const long long *__restrict__ wS, const float *__restrict__ gT, const float *__restrict__ lT,
     const long long *__restrict__ wT, float *__restrict__ out, float *__restrict__ grads) {
   __shared__ float red[2][4];
@@ -480,8 +481,8 @@ __global__ __launch_bounds__(256) void domain_loss_kernel(
     const float ls = lS[i], et = 1.f - lT[i];
     accS += ls * ls * ws;
     accT += et * et * wt;
-    dlS[i] = ls * ws * inv_bk;      // 0.5 * 2 l w / (b k)
-    dlT[i] = -et * wt * inv_bk;     // 0.5 * 2 (1 - l) (-1) w / (b k)
+    dlS[i] = 2.f * coef * ls * ws * inv_bk;      // coef * 2 l w / (b k)
+    dlT[i] = -2.f * coef * et * wt * inv_bk;     // coef * 2 (1 - l) (-1) w / (b k)
   }
   // ---- global terms: focal loss on the two-way softmax of each scene
   float focS = 0.f, focT = 0.f;
@@ -499,14 +500,14 @@ __global__ __launch_bounds__(256) void domain_loss_kernel(
     // d f / d p_t = gamma (1 - p)^(gamma - 1) log p - (1 - p)^gamma / p
     const float dfdp = gamma * powf(omp, gamma - 1.f) * lg - powf(omp, gamma) / pt;
     // d p_t / d g_j = p_t (delta_tj - p_j)
-    const float c = 0.5f * inv_b * dfdp * pt;
+    const float c = coef * inv_b * dfdp * pt;
     float *dg = (branch ? dgT : dgS) + 2 * bi;
     dg[0] = c * ((branch ? 0.f : 1.f) - p0);
     dg[1] = c * ((branch ? 1.f : 0.f) - p1);
     if (branch) focT += f; else focS += f;
   }
-  float vS = 0.5f * accS * inv_bk + 0.5f * focS * inv_b;
-  float vT = 0.5f * accT * inv_bk + 0.5f * focT * inv_b;
+  float vS = coef * (accS * inv_bk + focS * inv_b);
+  float vT = coef * (accT * inv_bk + focT * inv_b);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     vS += __shfl_xor(vS, off);
@@ -535,14 +536,14 @@ extern "C" {
 // The domain-adaptation loss of a Back-to-Reality step and its gradient for a unit upstream
 // gradient: out[3] = (total, source part, target part); grads (4 b + 2 b k floats) =
 // [d global_S (b,2) | d local_S (b,k) | d global_T (b,2) | d local_T (b,k)].
-int btr_domain_loss(int b, int k, float gamma, const float *global_S, const float *local_S,
+int btr_domain_loss(int b, int k, float gamma, float coef, const float *global_S, const float *local_S,
                     const long long *label_S, const float *global_T, const float *local_T,
                     const long long *label_T, float *out, float *grads, btr_stream_t stream) {
   if (b <= 0 || k <= 0) return BTR_OK;
   BTR_REQUIRE(global_S && local_S && label_S && global_T && local_T && label_T && out && grads,
               "domain_loss: null pointer");
   hipLaunchKernelGGL(domain_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), b, k, gamma,
-                     global_S, local_S, label_S, global_T, local_T, label_T, out, grads);
+                     coef, global_S, local_S, label_S, global_T, local_T, label_T, out, grads);
   return check_launch("domain_loss");
 }
 

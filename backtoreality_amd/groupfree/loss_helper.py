@@ -385,6 +385,14 @@ def get_loss_DA(end_points_S, end_points_T, config, num_decoder_layers,
             box_loss_coef, sem_cls_loss_coef, query_points_obj_topk, center_loss_type,
             center_delta, size_loss_type, size_delta, heading_loss_type, heading_delta)
     loss = 0.5 * get_loss(end_points_S, *args)[0] + get_loss_weak(end_points_T, *args)[0]
+    if end_points_S['global_d_pred'].is_cuda:
+        from ..votenet import fused_loss as _fl
+        from . import fused_loss as _gfl
+        if _gfl.enabled() and _fl.domain_loss_fusable(end_points_S, end_points_T, 'last_'):
+            # (the same terms as VoteNet's domain loss, unweighted: one launch each way)
+            da_loss = _fl.domain_loss(end_points_S, end_points_T, 3.0, 1.0, 'last_')
+            end_points_S['DA_loss'] = da_loss
+            return loss + 10 * da_loss, end_points_S, end_points_T
     g_S, g_T = end_points_S['global_d_pred'], end_points_T['global_d_pred']
     source_dloss = softmax_focal_loss(g_S, torch.zeros(g_S.size(0), dtype=torch.long,
                                                        device=g_S.device), 3)

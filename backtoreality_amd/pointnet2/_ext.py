@@ -166,7 +166,7 @@ _SIGNATURES = {
     "btr_grad_sumsq_multi": (_ci, [_ci, _ci, _vp, _vp, _vp, _vp, _vp]),
     "btr_grad_norm_final": (_ci, [_ci, _vp, ctypes.c_float, _vp, _vp]),
     # fused VoteNet loss (used by votenet/fused_loss.py)
-    "btr_domain_loss": (_ci, [_ci, _ci, _cf] + [_vp] * 9),
+    "btr_domain_loss": (_ci, [_ci, _ci, _cf, _cf] + [_vp] * 9),
     "btr_votenet_loss_fwd": (_ci, [_ci] * 9 + [_vp] * 24 + [_vp, _ci, _vp, _vp]),
     "btr_votenet_loss_bwd": (_ci, [_ci] * 9 + [_vp] * 26 + [_vp, _ci, _vp, _vp]),
     "btr_gather_rows": (_ci, [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp]),

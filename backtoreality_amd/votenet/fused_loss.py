@@ -184,10 +184,10 @@ def get_loss(end_points, config):
 class FusedDomainLoss(Function):
     """The domain-adaptation term of get_loss_DA (loss_helper._domain_loss) as one launch each
     way: (global_S (B,2), local_S (B,1,K), label_S (B,K) i64, global_T, local_T, label_T) ->
-    the scalar 0.5 * (mean(l_S^2 w_S) + focal(g_S, 0) + mean((1 - l_T)^2 w_T) + focal(g_T, 1))."""
+    the scalar coef * (mean(l_S^2 w_S) + focal(g_S, 0) + mean((1 - l_T)^2 w_T) + focal(g_T, 1))."""
 
     @staticmethod
-    def forward(ctx, g_S, l_S, w_S, g_T, l_T, w_T, gamma):
+    def forward(ctx, g_S, l_S, w_S, g_T, l_T, w_T, gamma, coef):
         B, K = w_S.shape
         dev = g_S.device
         g_S, l_S, g_T, l_T = (t.contiguous() for t in (g_S, l_S, g_T, l_T))
@@ -196,7 +196,7 @@ class FusedDomainLoss(Function):
         grads = torch.empty((4 * B + 2 * B * K,), dtype=torch.float32, device=dev)
         p = _ext._p
         with _ext._on(g_S) as d:
-            _ext._call(_lib.btr_domain_loss, B, K, float(gamma), p(g_S), p(l_S), p(w_S), p(g_T),
+            _ext._call(_lib.btr_domain_loss, B, K, float(gamma), float(coef), p(g_S), p(l_S), p(w_S), p(g_T),
                        p(l_T), p(w_T), p(out), p(grads), _ext._stream(d))
         ctx.dims = (B, K, tuple(l_S.shape))
         ctx.save_for_backward(grads)
@@ -206,20 +206,21 @@ class FusedDomainLoss(Function):
     @staticmethod
     def backward(ctx, gout):
         if gout is None:
-            return (None,) * 7
+            return (None,) * 8
         (grads,) = ctx.saved_tensors
         B, K, lshape = ctx.dims
         g = grads * gout          # (one launch: the four gradients are slices of one buffer)
         dgS, dlS, dgT, dlT = g.split([2 * B, B * K, 2 * B, B * K])
         return (dgS.view(B, 2), dlS.view(lshape), None, dgT.view(B, 2), dlT.view(lshape), None,
-                None)
+                None, None)
 
 
-def domain_loss_fusable(end_points_S, end_points_T):
+def domain_loss_fusable(end_points_S, end_points_T, prefix=''):
+    """`prefix`: '' for VoteNet's end_points keys, 'last_' for GroupFree3D's last head."""
     if not enabled():
         return False
     for e in (end_points_S, end_points_T):
-        g, l, w = e['global_d_pred'], e['local_d_pred'], e['objectness_label']
+        g, l, w = e['global_d_pred'], e[prefix + 'local_d_pred'], e[prefix + 'objectness_label']
         if not (g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.shape[1] == 2 and
                 l.dtype == torch.float32 and l.dim() == 3 and l.shape[1] == 1 and
                 w.dtype == torch.int64 and w.dim() == 2 and
@@ -227,11 +228,12 @@ def domain_loss_fusable(end_points_S, end_points_T):
             return False
     S, T = end_points_S, end_points_T
     return S['global_d_pred'].shape == T['global_d_pred'].shape and \
-        S['local_d_pred'].shape == T['local_d_pred'].shape
+        S[prefix + 'local_d_pred'].shape == T[prefix + 'local_d_pred'].shape
 
 
-def domain_loss(end_points_S, end_points_T, gamma=3.0):
+def domain_loss(end_points_S, end_points_T, gamma=3.0, coef=0.5, prefix=''):
     return FusedDomainLoss.apply(
-        end_points_S['global_d_pred'], end_points_S['local_d_pred'],
-        end_points_S['objectness_label'], end_points_T['global_d_pred'],
-        end_points_T['local_d_pred'], end_points_T['objectness_label'], gamma)
+        end_points_S['global_d_pred'], end_points_S[prefix + 'local_d_pred'],
+        end_points_S[prefix + 'objectness_label'], end_points_T['global_d_pred'],
+        end_points_T[prefix + 'local_d_pred'], end_points_T[prefix + 'objectness_label'], gamma,
+        coef)

@@ -475,12 +475,12 @@ int btr_votenet_loss_bwd(int b, int k, int k2, int nh, int ns, int nc, int s1, i
                          const int *i2v, btr_stream_t stream);
 
 /* The domain-adaptation term of get_loss_DA (reference: detection/Votenet/models/loss_helper.py:
- * 618-650 with FocalLoss, :466-545): per branch 0.5 * mean(e(l)^2 * objectness_label) + 0.5 *
- * focal(softmax(global_d_pred), domain, gamma), e(l) = l (source, domain 0) / 1 - l (target,
- * domain 1).  global_* (b, 2) logits, local_* (b, k) sigmoid outputs, label_* (b, k) i64.
+ * 618-650 with FocalLoss, :466-545; GroupFree3D's loss_helper.py:673-712): per branch coef *
+ * mean(e(l)^2 * objectness_label) + coef * focal(softmax(global_d_pred), domain, gamma), e(l) = l
+ * (source, domain 0) / 1 - l (target, domain 1); coef 0.5 for VoteNet, 1 for GroupFree3D.  global_* (b, 2) logits, local_* (b, k) sigmoid outputs, label_* (b, k) i64.
  * out[3] = (total, source part, target part); grads (4 b + 2 b k floats) = the gradient for a unit
  * upstream gradient, [d global_S | d local_S | d global_T | d local_T].  One launch. */
-int btr_domain_loss(int b, int k, float gamma, const float *global_S, const float *local_S,
+int btr_domain_loss(int b, int k, float gamma, float coef, const float *global_S, const float *local_S,
                     const long long *label_S, const float *global_T, const float *local_T,
                     const long long *label_T, float *out, float *grads, btr_stream_t stream);
 

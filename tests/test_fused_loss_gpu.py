@@ -238,3 +238,14 @@ def test_fused_domain_loss_matches_torch_composition(cuda, monkeypatch, B, K):
     for a, b in zip(gf, gt):
         assert a.shape == b.shape
         assert _close(a, b), float((a - b).abs().max())
+    # GroupFree3D's form (loss_helper.py:673-712): the same terms unweighted, keys of its last head
+    gfe = {t: {'global_d_pred': base[t]['global_d_pred'].clone().requires_grad_(True),
+               'last_local_d_pred': base[t]['local_d_pred'].clone().requires_grad_(True),
+               'last_objectness_label': base[t]['objectness_label']} for t in "ST"}
+    assert fused_loss.domain_loss_fusable(gfe["S"], gfe["T"], 'last_')
+    l2 = fused_loss.domain_loss(gfe["S"], gfe["T"], 3.0, 1.0, 'last_')
+    (l2 * -3.5).backward()
+    assert abs(float(l2) - 2.0 * float(lt)) <= 2e-6 * max(1.0, abs(float(lt)))
+    g2 = [gfe[t][k].grad for t in "ST" for k in ('global_d_pred', 'last_local_d_pred')]
+    for a, b in zip(g2, gt):
+        assert _close(a, 2.0 * b), float((a - 2.0 * b).abs().max())
