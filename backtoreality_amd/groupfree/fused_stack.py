@@ -71,7 +71,7 @@ def _embed_chain(m):
 class _Entry(object):
     """What is fixed for a detector and a set of shapes: the descriptor with its sizes filled in,
     the plan, the block sizes of the flat gradient buffer."""
-    __slots__ = ("d", "plan", "layer_sizes", "chain_sizes", "ptrs", "metas")
+    __slots__ = ("d", "plan", "layer_sizes", "chain_sizes", "ptrs", "metas", "sink")
 
 
 def _entry(det, key, B, Pq, Pk, E, qd, kd, p, specs):
@@ -106,7 +106,7 @@ def _entry(det, key, B, Pq, Pk, E, qd, kd, p, specs):
         _lib.btr_gf_stack_sizeof(1) == ctypes.sizeof(plan), "btr_gf_stack_t mirror out of date"
     _call(_lib.btr_gf_stack_plan, ctypes.addressof(d), ctypes.addressof(plan))
     ent = _Entry()
-    ent.d, ent.plan, ent.ptrs = d, plan, None
+    ent.d, ent.plan, ent.ptrs, ent.sink = d, plan, None, None
     F = d.layer[0].ff
     ent.layer_sizes = [3 * E * E, 3 * E, E * E, E, 3 * E * E, 3 * E, E * E, E, F * E, F, E * F, E,
                        E, E, E, E, E, E]
@@ -207,8 +207,12 @@ class DecoderStackFn(Function):
     output (B,E,Pq) when meta["want_last"]]."""
 
     @staticmethod
-    def forward(ctx, query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta, *params):
+    def forward(ctx, query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta, sink, *params):
         ent, p, want_last = meta["entry"], meta["p"], meta["want_last"]
+        # (flat gradient sink, pointnet2/grad_sink.py: the leaf parameters' gradients leave as
+        # ONE buffer; computed operands -- the heads' concatenated last layers -- keep theirs)
+        ctx.leaf = [t is not None and t.is_leaf and t.requires_grad for t in params] \
+            if sink is not None else None
         plan = ent.plan
         d = _ext.GfStack.from_buffer_copy(ent.d)   # this call's own copy (dropout seeds)
         L, B, Pq, E = d.layers, d.b, d.pq, d.e
@@ -281,21 +285,44 @@ class DecoderStackFn(Function):
             _call(_lib.btr_gf_stack_backward, ctypes.addressof(d), ctypes.addressof(plan),
                   _p(x_cl), _p(key_cl), _ptr_array(dheads), _p(dlast), _p(saved), _p(grads),
                   _p(dquery), _p(dkey), _p(scratch), _stream(dv))
-        res, at = [], 0
-        for i in range(L):
-            lg = grads.narrow(0, plan.g_layer[i], plan.layer[i].grads_floats)
-            res += [t.view(s) for t, s in zip(lg.split(ent.layer_sizes), ctx.pshapes[at:at + 18])]
-            at += 18
-            for (m, ps), cd, cp, off, sizes in zip(
-                    ctx.specs[i], (d.qpos[i], d.kpos[i], d.head[i]),
-                    (plan.qpos[i], plan.kpos[i], plan.head[i]),
-                    (plan.g_qpos[i], plan.g_kpos[i], plan.g_head[i]), ent.chain_sizes[i]):
-                if m is not None:
-                    cg = grads.narrow(0, off, cp.grads_floats)
-                    res += fused_mlp.chain_grad_views(cd, cp, sizes, ctx.pshapes[at:at + len(ps)],
-                                                      cg)
-                at += len(ps)
-        return (dquery, dkey, None, None, g_base, None, None) + tuple(res)
+        res = _grad_views(d, ent, ctx.specs, ctx.pshapes, grads)
+        if ctx.leaf is not None:
+            res = [None if leaf else g for g, leaf in zip(res, ctx.leaf)]
+            return (dquery, dkey, None, None, g_base, None, None, grads) + tuple(res)
+        return (dquery, dkey, None, None, g_base, None, None, None) + tuple(res)
+
+
+def _grad_views(d, ent, specs, pshapes, grads):
+    """The parameters' gradients as views of the stack's flat gradient buffer (descriptor order)."""
+    plan = ent.plan
+    res, at = [], 0
+    for i in range(d.layers):
+        lg = grads.narrow(0, plan.g_layer[i], plan.layer[i].grads_floats)
+        res += [t.view(s) for t, s in zip(lg.split(ent.layer_sizes), pshapes[at:at + 18])]
+        at += 18
+        for (m, ps), cd, cp, off, sizes in zip(
+                specs[i], (d.qpos[i], d.kpos[i], d.head[i]),
+                (plan.qpos[i], plan.kpos[i], plan.head[i]),
+                (plan.g_qpos[i], plan.g_kpos[i], plan.g_head[i]), ent.chain_sizes[i]):
+            if m is not None:
+                cg = grads.narrow(0, off, cp.grads_floats)
+                res += fused_mlp.chain_grad_views(cd, cp, sizes, pshapes[at:at + len(ps)], cg)
+            at += len(ps)
+    return res
+
+
+def _stack_sink(ent, specs, params, device):
+    """The flat gradient sink of the decoder stack (one per detector and shape), or None outside
+    a grad_sink scope."""
+    from ..pointnet2 import grad_sink
+    if not grad_sink.active():
+        return None
+    if ent.sink is None or ent.sink.tensor.device != device:
+        d = ent.d
+        pshapes = [None if t is None else t.shape for t in params]
+        ent.sink = grad_sink.Sink(ent.plan.grads_floats, device,
+                                  lambda g: _grad_views(d, ent, specs, pshapes, g))
+    return ent.sink.bind(params)
 
 
 def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
@@ -362,7 +389,8 @@ def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
     key_xyz_t = _transposed(key_pos) if key_pos is not None else None
     mean_size = head0._mean_size_on(query.device)
     meta = {"entry": ent, "p": p, "want_last": want_last, "specs": specs}
-    outs = DecoderStackFn.apply(query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta, *params)
+    outs = DecoderStackFn.apply(query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta,
+                                _stack_sink(ent, specs, params, query.device), *params)
     CALLS[0] += 1
     for i in range(L):
         prefix = 'last_' if i == L - 1 else '%dhead_' % i

@@ -70,8 +70,8 @@ class Sink(object):
             return
         with torch.no_grad():
             for p, v in zip(self.params, self.views_of(flat)):
-                if p is None or v is None or not p.requires_grad:
-                    continue
+                if p is None or v is None or not (p.requires_grad and p.is_leaf):
+                    continue   # (a computed operand: its node returns that gradient itself)
                 if not v.is_contiguous():   # (a first layer behind a padded input width)
                     v = v.contiguous()
                 p.grad = v if p.grad is None else p.grad + v

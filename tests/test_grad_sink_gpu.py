@@ -144,3 +144,46 @@ def test_source_head_beside_target_backbone_is_the_same_step(cuda, monkeypatch, 
         spread = float((g0[n] - g0b[n]).abs().max()) / scale
         dev = float((g0[n] - g1[n]).abs().max()) / scale
         assert dev <= 4.0 * spread + 1e-6, (n, dev, spread)
+
+
+def test_groupfree_two_branch_step_with_sinks(cuda, monkeypatch):
+    """GroupFree3D's Back-to-Reality step: the decoder stack's node carries computed operands (the
+    heads' concatenated last layers) beside ~300 leaf parameters -- the sink takes the leaves, the
+    node keeps returning the computed operands' gradients.  Dropout off (its masks are drawn per
+    call); one step from the same weights: loss identical, gradients within the run-to-run
+    spread, and the per-parameter accumulation launches gone."""
+    from backtoreality_amd.groupfree import train as gf_train
+    from backtoreality_amd.pointnet2 import grad_sink
+    cfg = config.scannet_md40()
+    bS = synthetic.make_batch(0, 2, 8192, cfg, use_height=False, device=cuda)
+    bT = synthetic.make_batch(50, 2, 8192, cfg, use_height=False, device=cuda)
+    calls = []
+    orig = grad_sink.Sink._distribute
+
+    def spy(self, t):
+        calls.append(int(t.numel()))
+        return orig(self, t)
+
+    monkeypatch.setattr(grad_sink.Sink, "_distribute", spy)
+
+    def run(sinks):
+        monkeypatch.setenv("BTR_GRAD_SINK", "1" if sinks else "0")
+        torch.manual_seed(0)
+        net = gf_train.build_model(cfg, cuda, domain_adaptation=True, dropout=0.0)
+        opt = gf_train.make_optimizer(net)
+        loss, _, _ = gf_train.train_step_br(net, opt, bS, bT, cfg)
+        torch.cuda.synchronize()
+        assert not [n for n, p in net.named_parameters() if p.grad is None]
+        return float(loss), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    l0, g0 = run(False)
+    assert calls == []
+    l0b, g0b = run(False)
+    l1, g1 = run(True)
+    assert len(calls) >= 3 and max(calls) > 1000000, calls   # backbone, chains, the decoder stack
+    assert l0 == l0b == l1
+    for n in g0:
+        assert g1[n].shape == g0[n].shape and g1[n].is_contiguous(), n
+        scale = float(g0[n].abs().max()) + 1e-30
+        spread = float((g0[n] - g0b[n]).abs().max()) / scale
+        dev = float((g0[n] - g1[n]).abs().max()) / scale
+        assert dev <= 4.0 * spread + 1e-6, (n, dev, spread)
