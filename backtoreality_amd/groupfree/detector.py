@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from ..pointnet2 import fused_mlp
 from ..votenet.backbone_module import Pointnet2Backbone
-from ..votenet.votenet_da import grad_reverse
+from ..votenet.votenet_da import _run_head, grad_reverse
 from .modules import (FPSModule, GeneralSamplingModule, PointsObjClsModule,
                       PositionEmbeddingLearned, PredictHead)
 from . import fused_stack
@@ -207,10 +207,10 @@ class GroupFreeDetector_DA(GroupFreeDetector):
     def _after_decoder_layer(self, prefix, query, end_points):
         if prefix == 'last_':
             end_points[prefix + 'local_d_pred'] = torch.sigmoid(
-                self.decoder_netD(grad_reverse(query)))
+                _run_head(self.decoder_netD, grad_reverse(query)))
 
     def _finish(self, end_points):
-        g = self.global_netD1(grad_reverse(end_points['seed_features']))   # (B,128,num_seed)
+        g = _run_head(self.global_netD1, grad_reverse(end_points['seed_features']))  # (B,128,num_seed)
         end_points['global_d_pred'] = self.global_netD2(torch.mean(g, dim=2))
         return end_points
 
@@ -233,5 +233,5 @@ class GroupFreeDetector_DA_jitter(GroupFreeDetector_DA):
         end_points = self.backbone_net(inputs['point_clouds'], {}, center_xyz=center_xyz,
                                        center_cls=center_cls)
         if center_xyz is not None:
-            end_points['jitter_pred'] = self.jitter_net(end_points['center_features'])
+            end_points['jitter_pred'] = _run_head(self.jitter_net, end_points['center_features'])
         return end_points
