@@ -5,8 +5,6 @@ python tools/bwd_gram_ab.py"""
 import os
 import sys
 
-os.environ.setdefault("BTR_POOL_GRAM", "2")   # every k <= 128 layer, not only the producer/consumer shapes
-
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -84,8 +82,8 @@ def case(rows, n, k, s, ps):
 
 
 if __name__ == "__main__":
+    # (the Gram form covers n <= 128, k <= 64 since round 6; profiles/r05_h_bwd_gram_ab.txt keeps
+    # the single-role kernel's numbers at the 256 x 128 layers)
     case(706560, 128, 64, 64, 8)      # SA1 pooled layer (compact-row count, dense form)
-    case(114688, 256, 128, 32, 8)     # SA2
-    case(65536, 256, 128, 16, 16)     # SA3
-    case(32768, 256, 128, 16, 16)     # SA4
-    case(32768, 128, 128, 16, 16)     # vote aggregation
+    case(262144, 128, 64, 32, 8)
+    case(65536, 64, 64, 16, 8)

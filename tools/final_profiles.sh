@@ -20,7 +20,6 @@ python tools/gemm_nt_small_ab.py > $O/gemm_nt_small_ab.txt 2>&1
 python tools/bwd_fused_ab.py > $O/bwd_fused_ab.txt 2>&1
 python tools/fps_prefix_ab.py > $O/fps_prefix_ab.txt 2>&1
 python tools/bwd_gram_ab.py > $O/bwd_gram_ab.txt 2>&1
-python tools/fwd_ws_ab.py > $O/fwd_ws_ab.txt 2>&1
 python tools/gemm_sm_ab.py > $O/gemm_sm_ab.txt 2>&1
 bash tools/pmc_kernels.sh tools/bwd_fused_ab.py sa_bwd_fused > $O/fused_sq_counters.md 2>/dev/null
 bash tools/pmc_kernels.sh tools/bwd_gram_ab.py sa_bwd_gram > $O/gram_sq_counters.md 2>/dev/null
@@ -33,6 +32,8 @@ bash tools/pmc_kernels.sh tools/bwd_gram_ab.py sa_bwd_gram > $O/gram_sq_counters
   echo "BTR_FPS_LDS_KB=0:"; BTR_FPS_LDS_KB=0 python tools/fps_interference.py 2>&1 | tail -2; } > $O/fps_interference.txt
 { python tools/phase_times.py 2>&1 | tail -11; echo; python tools/phase_times.py --sequential 2>&1 | tail -11; } > $O/phase_times.txt
 { bash tools/ab_env2.sh "BTR_FPS_LDS_KB" 2; bash tools/ab_side.sh; BENCH_ARGS= bash tools/ab_gridcus.sh "256 248" | tail -6; } > $O/streams_ab.txt 2>&1
+{ bash tools/ab_sink.sh; bash tools/ab_br_overlap.sh; } > $O/two_branch_ab.txt 2>&1
+python tools/fps_lds_ab.py > $O/fps_lds_ab.txt 2>&1
 python -c "
 import json
 for f in ('bench','bench_steps20','bench_c5','bench_br','bench_cr','bench_gf','bench_gf_graph','bench_gfbr'):
