@@ -332,27 +332,3 @@ def evaluate_one_epoch(net, batches, cfg, config_dict=None, ap_iou_thresholds=(0
         net.train(was_training)
     stats = {k: float(v) / max(nb, 1) for k, v in sorted(stat.items())}
     return stats, {thr: {p: c.compute_metrics() for p, c in d.items()} for thr, d in calcs.items()}
-
-
-TUNABLEOP_FILE = __import__("os").path.join(
-    __import__("os").path.dirname(__import__("os").path.abspath(__file__)), "tunableop_gfx950.csv")
-
-
-def enable_gemm_tuning(filename=None):
-    """PyTorch TunableOp with the tuning results shipped next to this file: every GEMM shape of
-    the decoder / heads (attention `bmm`s, FFN and projection `mm`s) then runs the rocBLAS /
-    hipBLASLt solution that was fastest when the file was generated (`PYTORCH_TUNABLEOP_TUNING=1
-    python bench.py --workload gf`, 80 s) instead of the default heuristic: 17.3 -> 16.5 ms per
-    step.  Nothing is tuned at run time; a file written by other library versions is ignored by
-    TunableOp's validators.  Returns True when the results were loaded."""
-    try:
-        import torch.cuda.tunable as tunable
-        tunable.enable(True)
-        tunable.tuning_enable(False)
-        if hasattr(tunable, "write_file_on_exit"):
-            tunable.write_file_on_exit(False)
-        return bool(tunable.read_file(filename or TUNABLEOP_FILE))
-    except Exception as e:  # an optimisation only: never a reason to stop
-        import warnings
-        warnings.warn("TunableOp results not loaded: %r" % (e,))
-        return False

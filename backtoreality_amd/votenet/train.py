@@ -441,10 +441,6 @@ def make_optimizer(net, lr=1e-3, weight_decay=0.0, capturable=False):
                capturable=bool(capturable and fused))
 
 
-MIOPEN_DB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                             "miopen_db")
-
-
 # ------------------------------------------------ epoch-level schedules of the training scripts
 def get_current_lr(epoch, base_lr=0.001, decay_steps=(80, 120, 160), decay_rates=(0.1, 0.1, 0.1)):
     """Step schedule of train_Votenet_*.py (:191-196; defaults :55-60)."""
@@ -475,19 +471,16 @@ def make_bn_momentum_scheduler(net, start_epoch=0, bn_decay_step=20, bn_decay_ra
     return BNMomentumScheduler(net, bn_lambda=bn_lambda, last_epoch=start_epoch - 1)
 
 
-def enable_conv_autotune(use_shipped_db=True):
+def enable_conv_autotune():
     """`torch.backends.cudnn.benchmark = True` like the reference's GroupFree3D scripts
     (train_GF_FSB.py:454-455): on ROCm MIOpen then times its solvers for every new convolution
-    shape (the 1x1 convolutions of the FP / voting / proposal layers) the first time it sees
-    it and uses the fastest from then on -- 0.15-0.9 ms per step here (FSB 9.44 -> 9.30 ms,
-    Back-to-Reality 18.0 -> 17.3 ms).  The search costs 20-60 s per process on a fresh machine;
-    `use_shipped_db` points MIOpen's user find-db (MIOPEN_USER_DB_PATH, unless already set) at
-    backtoreality_amd/miopen_db/, which holds the search results for the bench workloads on
-    gfx950 / this MIOpen build (tools/miopen_db.sh regenerates it), so that they are looked
-    up instead.  Call before the first convolution runs.  The hand-written kernels are not
-    affected."""
-    if use_shipped_db and "MIOPEN_USER_DB_PATH" not in os.environ and os.path.isdir(MIOPEN_DB_DIR):
-        os.environ["MIOPEN_USER_DB_PATH"] = MIOPEN_DB_DIR
+    shape the first time it sees it and uses the fastest from then on (20-60 s of search per
+    process on a fresh machine).  No eager step of this package runs a stock convolution any
+    more -- the 1x1 conv chains, domain classifiers and heads run on the point-wise chain
+    kernels -- so this only matters for a step captured into a HIP graph (`bench.py --graph`),
+    which keeps its chains of < 2 048 rows on the stock ops.  (Rounds 1 - 5 shipped a MIOpen
+    find-db and a TunableOp file for those paths; removed in round 6 with the eager loop the
+    default everywhere.)  Call before the first convolution runs."""
     torch.backends.cudnn.enabled = True
     torch.backends.cudnn.benchmark = True
 

@@ -37,12 +37,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--conv-autotune", action="store_true", help="(default; kept for old scripts)")
     p.add_argument("--no-conv-autotune", action="store_true",
-                   help="do not turn on torch.backends.cudnn.benchmark: MIOpen then picks the "
-                        "solvers of the stock FP / voting / proposal convolutions by heuristic "
-                        "(FSB 9.44 instead of 9.30 ms/step).  With it (default, like the "
-                        "reference's GroupFree3D scripts) MIOpen looks the fastest solver up in "
-                        "the find-db shipped in backtoreality_amd/miopen_db/ (or searches for "
-                        "20-60 s in an extra untimed priming step when a shape is not in it)")
+                   help="(--graph only) do not turn on torch.backends.cudnn.benchmark for the "
+                        "stock convolutions a captured step keeps; the eager steps have none")
     p.add_argument("--sequential", action="store_true",
                    help="time the strictly sequential loop (every step computes its own sampling "
                         "pyramid first) instead of the software-pipelined one")
@@ -192,10 +188,11 @@ def main():
         rccl_ranks = int(ones.item())
         assert rccl_ranks == args.gpus, "all-reduce saw %d ranks" % rccl_ranks
 
-    # MIOpen solver look-up for the stock convolutions that are left: none in the FSB step (its
-    # 1x1 conv chains run on this package's kernels), the domain classifiers of the BR / CR
-    # steps and GroupFree3D's decoder / heads
-    autotune = not args.no_conv_autotune and args.workload != "fsb"
+    # MIOpen's solver search for stock convolutions: none is left in any eager step (every 1x1
+    # conv chain runs on this package's kernels); only a captured step (--graph) keeps its
+    # < 2 048-row chains on the stock ops, and there the search happens in the priming step
+    autotune = not args.no_conv_autotune and (args.graph or args.graph_calibrate) and \
+        args.workload != "fsb"
     if autotune:   # before the first convolution runs (train.enable_conv_autotune)
         train.enable_conv_autotune()
     c5 = args.workload == "c5"
@@ -211,8 +208,6 @@ def main():
     gfbr = args.workload == "gfbr"
     if gf:
         from backtoreality_amd.groupfree import train as gf_train
-        if autotune:     # shipped GEMM solution choices (TunableOp)
-            gf_train.enable_gemm_tuning()
         if args.points == 40000 and args.batch == 8:      # configs[3]: 4 x 50 000 points
             args.points, args.batch = 50000, 4
         net = gf_train.build_model(cfg, dev, domain_adaptation=gfbr)
@@ -346,9 +341,8 @@ def main():
 
     graphed_step = None
     if autotune:
-        # One-time set-up, never timed: MIOpen's solver look-up (or search, for a shape that is
-        # not in the shipped find-db) for the stock convolution layers happens in this priming
-        # step, whatever --warmup is.
+        # One-time set-up, never timed: MIOpen's solver search for the stock convolution layers of
+        # a captured step happens in this priming step, whatever --warmup is.
         (eager_step or train_step)(ddp, opt_eager, batch, cfg)
         barrier()
     if pipelined_loop and not gf and not br and fsb_graph:

@@ -12,7 +12,6 @@ from backtoreality_amd.votenet import config, synthetic, train
 
 dev = torch.device("cuda:0")
 cfg = config.scannet_md40()
-gf_train.enable_gemm_tuning()
 net = gf_train.build_model(cfg, dev)
 opt_cap = gf_train.make_optimizer(net, capturable=True)
 opt = gf_train.make_optimizer(net)
