@@ -9,6 +9,10 @@ python -m pytest tests -m gpu -q --durations=10 > $O/gputests.txt 2>&1
 grep -E "passed|failed" $O/gputests.txt
 bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1
 bash tools/profile_pipelined.sh ${TAG}_pipe > $O/profile_pipelined.log 2>&1
+python tools/step_table.py gpurun_out/${TAG}_pipe/timeline.txt > $O/step_table.md 2>/dev/null
+cp gpurun_out/${TAG}_pipe/one_step.md $O/pipelined_one_step.md
+cp gpurun_out/${TAG}_pipe/timeline.txt $O/pipelined_timeline.txt
+cp gpurun_out/${TAG}_pipe/kernel_stats.md $O/pipelined_kernel_stats.md
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_steps20.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_steps20_b.json
 for wl in c5 br cr gf gfbr; do
