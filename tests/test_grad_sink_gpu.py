@@ -50,7 +50,7 @@ def test_sinks_leave_the_same_gradients_and_parameters(cuda, monkeypatch, jitter
         scale = float(g0[n].abs().max()) + 1e-30
         spread = float((g0[n] - g0b[n]).abs().max()) / scale
         dev = float((g0[n] - g1[n]).abs().max()) / scale
-        assert dev <= 4.0 * spread + 1e-6, (n, dev, spread)
+        assert dev <= 4.0 * spread + 2e-5, (n, dev, spread)
     # (the parameters after Adam's first update are NOT compared: an entry whose gradient is at
     # the summation noise gets lr * g / (|g| + eps) with either sign from two runs of the same
     # configuration -- tests/test_parity_fullsize_gpu.py states that for whole training curves)
@@ -143,7 +143,7 @@ def test_source_head_beside_target_backbone_is_the_same_step(cuda, monkeypatch, 
         scale = float(g0[n].abs().max()) + 1e-30
         spread = float((g0[n] - g0b[n]).abs().max()) / scale
         dev = float((g0[n] - g1[n]).abs().max()) / scale
-        assert dev <= 4.0 * spread + 1e-6, (n, dev, spread)
+        assert dev <= 4.0 * spread + 2e-5, (n, dev, spread)
 
 
 def test_groupfree_two_branch_step_with_sinks(cuda, monkeypatch):
@@ -186,4 +186,4 @@ def test_groupfree_two_branch_step_with_sinks(cuda, monkeypatch):
         scale = float(g0[n].abs().max()) + 1e-30
         spread = float((g0[n] - g0b[n]).abs().max()) / scale
         dev = float((g0[n] - g1[n]).abs().max()) / scale
-        assert dev <= 4.0 * spread + 1e-6, (n, dev, spread)
+        assert dev <= 4.0 * spread + 2e-5, (n, dev, spread)
