@@ -120,20 +120,24 @@ class Pointnet2Backbone(nn.Module):
         if entry is not None:
             entry.lib.btr_backbone_fork_event(None, 0)
 
-    def prefetch_sampling(self, pointcloud, after=None):
+    def prefetch_sampling(self, pointcloud, after=None, slot=0):
         """Start the sampling pyramid of `pointcloud` on the side stream NOW and return a
         handle to pass to forward(..., sampling=handle).  Sampling depends on coordinates
         only, so a caller that runs several forwards per step (the Back-to-Reality step runs a
         source and a target branch, train_Votenet_BR.py:277-278) can overlap the second
         branch's FPS with the first branch's forward.  Same indices as computing them inline.
         `after`: an event of the current stream the side stream waits for instead of the
-        stream's whole queue (arm_fork_event)."""
+        stream's whole queue (arm_fork_event).  `slot`: which of the module's prefetch streams
+        (a loop that keeps TWO pyramids in flight -- batches i + 1 and i + 2 -- alternates 0 / 1:
+        a pyramid is a chain of dependent steps on one CU per scene, so two of them run beside
+        each other at the speed of one)."""
         if not pointcloud.is_cuda or os.environ.get("BTR_OVERLAP_FPS", "1") == "0":
             return None
         entry = self._native_entry(pointcloud)
         if entry is not None:   # one library call for the whole pyramid
             main = torch.cuda.current_stream(pointcloud.device)
-            side = self._get_side_stream(pointcloud.device, "_prefetch_stream")
+            side = self._get_side_stream(pointcloud.device,
+                                         "_prefetch_stream" if not slot else "_prefetch_stream%d" % slot)
             if after is not None:
                 side.wait_event(after)
             else:

@@ -560,31 +560,61 @@ def train_step(net, optimizer, batch, cfg, sampling=None, next_batch=None, crite
     return loss, end_points
 
 
-def train_one_epoch(net, optimizer, batches, cfg, criterion=None, on_step=None):
+def pyramids_in_flight(pointcloud):
+    """How many sampling pyramids train_one_epoch keeps in flight for clouds of this size: 1, or 2
+    for scenes of more than 65 536 points.  A pyramid is a chain of ~2 000 dependent arg-max steps
+    on ONE CU per scene, so two of them run beside each other at the speed of one; that pays
+    exactly when the pyramid, not the step's own kernels, paces the loop -- the Matterport-shaped
+    workload (4 x 80 000 points: 3.3 ms of FPS in the loop against 2.9 ms of main-stream work):
+    3.90 -> 3.00 ms per step with two in flight; at 8 x 40 000 the main stream paces the loop and a
+    second pyramid only costs (3.64 -> 3.73 ms; tools/ab_two_pyramids.py, profiles/
+    r06_w_two_pyramids.txt)."""
+    return 2 if pointcloud.is_cuda and pointcloud.shape[1] > 65536 else 1
+
+
+def train_one_epoch(net, optimizer, batches, cfg, criterion=None, on_step=None, depth=None):
     """The training loop of train_Votenet_FSB.py:211-244 over `batches` (an iterable of batch
     dicts resident on the model's device), software-pipelined: while step i runs, the sampling
-    pyramid of batch i+1 -- coordinates only, independent of the weights -- is computed on a
-    side stream (train_step(sampling=, next_batch=)); the first batch's pyramid is computed at
-    the head of the loop.  Same results as calling train_step batch by batch.  This is the
+    pyramids of the next `depth` batches -- coordinates only, independent of the weights -- are
+    computed on side streams (backbone_net.prefetch_sampling(slot=), train_step(sampling=)); the
+    first `depth` pyramids are computed at the head of the loop.  `depth`: None = by the cloud
+    size (pyramids_in_flight).  Same results as calling train_step batch by batch.  This is the
     loop bench.py times.  `on_step(i, loss, end_points)`: the caller's statistics hook (the
     reference's `.item()` logging, FSB:234-237); nothing here synchronises with the device.
     Returns the last (loss, end_points)."""
+    import collections
     it = iter(batches)
-    try:
-        cur = next(it)
-    except StopIteration:
+    first = next(it, None)
+    if first is None:
         return None
     core = net.module if hasattr(net, "module") else net
-    sampling = core.backbone_net.prefetch_sampling(cur['point_clouds'])
-    out, i = None, 0
-    while cur is not None:
+    if depth is None:
+        depth = pyramids_in_flight(first['point_clouds'])
+    depth = max(1, int(depth))
+    ahead, issued = collections.deque(), [0]
+
+    def issue(batch):
+        handle = core.backbone_net.prefetch_sampling(batch['point_clouds'],
+                                                     slot=issued[0] % depth)
+        issued[0] += 1
+        ahead.append((batch, handle))
+
+    issue(first)
+    while len(ahead) < depth:
         nxt = next(it, None)
-        out = train_step(net, optimizer, cur, cfg, sampling=sampling, next_batch=nxt,
-                         criterion=criterion)
-        sampling = out[1].get('next_sampling')
+        if nxt is None:
+            break
+        issue(nxt)
+    out, i = None, 0
+    while ahead:
+        cur, sampling = ahead.popleft()
+        nxt = next(it, None)
+        if nxt is not None:   # issued before this step's forward: the whole step to hide under
+            issue(nxt)
+        out = train_step(net, optimizer, cur, cfg, sampling=sampling, criterion=criterion)
         if on_step is not None:
             on_step(i, out[0], out[1])
-        cur, i = nxt, i + 1
+        i += 1
     return out
 
 

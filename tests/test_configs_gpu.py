@@ -292,6 +292,45 @@ def test_sampling_prefetch_gives_identical_training(cuda):
     np.testing.assert_allclose(l1[1], l0[1], rtol=1e-2)
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_train_one_epoch_with_pyramids_in_flight(cuda, depth):
+    """train.train_one_epoch keeps `depth` sampling pyramids in flight on alternating prefetch
+    streams (2 by default for scenes of more than 65 536 points): every step must consume the
+    pyramid of ITS batch -- indices bit-identical to the plain loop's on five distinct batches,
+    first loss bit-identical -- and the default depth must follow the cloud size."""
+    cfg = config.scannet_md40()
+    batches = [synthetic.make_batch(10 * i, 2, 20000, cfg, device=cuda) for i in range(5)]
+    assert train.pyramids_in_flight(batches[0]['point_clouds']) == 1
+    assert train.pyramids_in_flight(torch.empty(1, 70000, 4, device=cuda)) == 2
+
+    def plain():
+        net = train.build_model(cfg, cuda, seed=0)
+        opt = train.make_optimizer(net)
+        out = []
+        for b in batches:
+            loss, end = train.train_step(net, opt, b, cfg)
+            out.append((float(loss), end['sa1_inds'].clone(), end['sa2_inds'].clone(),
+                        end['aggregated_vote_inds'].shape))
+        return out
+
+    def piped():
+        net = train.build_model(cfg, cuda, seed=0)
+        opt = train.make_optimizer(net)
+        out = []
+        train.train_one_epoch(net, opt, iter(batches), cfg, depth=depth,
+                              on_step=lambda i, loss, end: out.append(
+                                  (float(loss), end['sa1_inds'].clone(), end['sa2_inds'].clone(),
+                                   end['aggregated_vote_inds'].shape)))
+        return out
+
+    a, b = plain(), piped()
+    assert len(a) == len(b) == 5
+    for (la, i1a, i2a, sa), (lb, i1b, i2b, sb) in zip(a, b):
+        assert torch.equal(i1a, i1b) and torch.equal(i2a, i2b) and sa == sb
+    assert a[0][0] == b[0][0], (a[0][0], b[0][0])
+    np.testing.assert_allclose(b[1][0], a[1][0], rtol=1e-2)
+
+
 @pytest.mark.parametrize("jitter", [False, True])
 def test_back_to_reality_prefetch_gives_identical_training(cuda, jitter):
     """The same for the two-branch steps (train_step_br / train_step_br_jitter): both pyramids
