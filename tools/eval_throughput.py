@@ -41,7 +41,28 @@ def forward_prefetched(n):
             s = nxt
 
 
-for name, fn in (("forward only", forward_only), ("forward, pyramid prefetched", forward_prefetched)):
+def forward_depth(depth):
+    """`depth` pyramids in flight on alternating prefetch streams (the inference forward is ~1 ms
+    of main-stream work against 2.2 - 2.7 ms of dependent FPS steps per pyramid)"""
+    def run(n):
+        import collections
+        bb = net.backbone_net
+        q = collections.deque()
+        with torch.no_grad():
+            for j in range(depth):
+                q.append(bb.prefetch_sampling(batches[j % 4]['point_clouds'], slot=j % depth))
+            for i in range(n):
+                s = q.popleft()
+                q.append(bb.prefetch_sampling(batches[(i + depth) % 4]['point_clouds'],
+                                              slot=(i + depth) % depth))
+                net({'point_clouds': batches[i % 4]['point_clouds'], 'sampling': s})
+    return run
+
+
+for name, fn in (("forward only", forward_only), ("forward, pyramid prefetched", forward_prefetched),
+                 ("forward, 2 pyramids in flight", forward_depth(2)),
+                 ("forward, 3 pyramids in flight", forward_depth(3)),
+                 ("forward, 4 pyramids in flight", forward_depth(4))):
     fn(3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
