@@ -208,6 +208,7 @@ class DecoderStackFn(Function):
 
     @staticmethod
     def forward(ctx, query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta, sink, *params):
+        _ext.RUNNING_STATS_EPOCH[0] += 1   # running statistics move through raw pointers
         ent, p, want_last = meta["entry"], meta["p"], meta["want_last"]
         # (flat gradient sink, pointnet2/grad_sink.py: the leaf parameters' gradients leave as
         # ONE buffer; computed operands -- the heads' concatenated last layers -- keep theirs)

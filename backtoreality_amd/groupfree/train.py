@@ -162,6 +162,7 @@ class GraphedTrainStep(object):
                     if v is not dst[k]:
                         dst[k].copy_(v, non_blocking=True)
         self.graph.replay()
+        fused_backbone._ext.RUNNING_STATS_EPOCH[0] += 1   # the replay moves running statistics
         return self.loss, self.end_points
 
 
@@ -221,6 +222,7 @@ class GraphedPipelinedStep(object):
         if next_batch is not None:
             self.nxt_pc.copy_(next_batch['point_clouds'], non_blocking=True)
         self.graph.replay()
+        fused_backbone._ext.RUNNING_STATS_EPOCH[0] += 1   # the replay moves running statistics
         return self.loss, self.end_points
 
 

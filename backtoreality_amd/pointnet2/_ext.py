@@ -534,6 +534,13 @@ def furthest_point_sampling(points, nsamples):
     return _fps(points, nsamples, 0, out)
 
 
+# Bumped by every library call that writes BatchNorm running statistics or parameters through raw
+# pointers (training forwards, graph replays, the native Adam step): tensor version counters do
+# not see those writes, so constants derived from them for the inference forward
+# (fused_sa._eval_constants, fused_mlp._eval_chain_constants) carry this in their cache key.
+RUNNING_STATS_EPOCH = [0]
+
+
 def new_stream(device):
     """A new torch stream for the library's side work (the next batch's sampling pyramid)."""
     return torch.cuda.Stream(device=device)

@@ -342,6 +342,7 @@ class FusedBackboneFn(Function):
 
     @staticmethod
     def forward(ctx, cloud, sampling, entry, sink, *params):
+        _ext.RUNNING_STATS_EPOCH[0] += 1   # running statistics move through raw pointers
         d, plan = entry.d, entry.plan
         dev = cloud.device
         ctx.to_sink = sink is not None

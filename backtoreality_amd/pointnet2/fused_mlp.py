@@ -63,6 +63,7 @@ class PointwiseMLP(Function):
 
     @staticmethod
     def forward(ctx, x, meta, *params):
+        _ext.RUNNING_STATS_EPOCH[0] += 1   # running statistics move through raw pointers
         layers = meta["layers"]
         L = len(layers)
         dev = x.device
@@ -340,6 +341,7 @@ class PointwiseChain(Function):
 
     @staticmethod
     def forward(ctx, x, meta, sink, *params):
+        _ext.RUNNING_STATS_EPOCH[0] += 1   # running statistics move through raw pointers
         layers = meta["layers"]
         L = len(layers)
         dev = x.device
@@ -465,7 +467,7 @@ def _min_rows():
     return 2048
 
 
-PATHS = {"library": 0, "python": 0, "stock": 0, "stock_small": 0}   # run_chain decisions (bench.py reports them)
+PATHS = {"library": 0, "library_eval": 0, "python": 0, "stock": 0, "stock_small": 0}   # run_chain decisions (bench.py reports them)
 
 
 def run_chain(x, chain):
@@ -498,9 +500,122 @@ def chain_spec(K, chain):
     return metas, params
 
 
+def _eval_ok(K, chain):
+    """The chain in inference mode (running statistics, no graph recorded) is covered."""
+    import torch.nn as nn
+    for i, (conv, bn, relu) in enumerate(chain):
+        if conv.kernel_size not in ((1,), (1, 1)) or conv.stride not in ((1,), (1, 1)) or \
+                conv.groups != 1 or conv.in_channels != K:
+            return False
+        if bn is None:
+            if relu or i != len(chain) - 1:
+                return False
+        elif not relu or not isinstance(bn, (nn.BatchNorm1d, nn.BatchNorm2d)) or bn.training or \
+                bn.weight is None or bn.running_mean is None or conv.out_channels % 4 != 0 or \
+                conv.out_channels > 512:
+            return False
+        K = conv.out_channels
+    return True
+
+
+def _eval_chain_constants(chain, k0p):
+    """Per layer [W (ceil4(width), k_in) zero-padded, a, b, bias, weight planes | None] of a
+    chain in inference mode: BatchNorm on its running statistics after a convolution with bias
+    is  a * (W x) + b  with  a = gamma / sqrt(running_var + eps),
+    b = beta + (bias - running_mean) * a;  a layer without BatchNorm keeps its bias.  Cached
+    per chain under the tensors' version counters and _ext.RUNNING_STATS_EPOCH (the library's
+    writes through raw pointers), as fused_sa._eval_constants."""
+    tensors = []
+    for conv, bn, _ in chain:
+        tensors += [conv.weight, conv.bias]
+        if bn is not None:
+            tensors += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    key = (k0p, _ext.RUNNING_STATS_EPOCH[0]) + tuple(
+        None if t is None else (t.data_ptr(), t._version) for t in tensors)
+    cache = _CHAIN_CACHE.get(chain[0][0])
+    if cache is None:
+        cache = _CHAIN_CACHE[chain[0][0]] = {}
+    hit = cache.get("eval")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    res, K = [], k0p
+    with torch.no_grad():
+        for conv, bn, _ in chain:
+            W, bias = conv.weight, conv.bias
+            Nl = W.shape[0]
+            Np = _ceil4(Nl)
+            W2 = W.reshape(Nl, -1)
+            if tuple(W2.shape) != (Np, K):
+                Wp = torch.zeros((Np, K), dtype=torch.float32, device=W.device)
+                Wp[:Nl, :W2.shape[1]] = W2
+                W2 = Wp
+            a = b = bp = None
+            if bn is not None:
+                a = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+                shift = bn.running_mean if bias is None else bn.running_mean - bias
+                b = (bn.bias - shift * a).contiguous()
+            elif bias is not None:
+                bp = bias if Np == Nl else torch.cat(
+                    [bias, torch.zeros(Np - Nl, dtype=torch.float32, device=W.device)])
+                bp = bp.contiguous()
+            res.append([W2.contiguous(), a, b, bp, None])
+            K = Np
+    cache["eval"] = (key, res)
+    return res
+
+
+def _eval_chain(x, chain):
+    """Inference-mode forward of a chain (module.eval() under no_grad, the evaluation pass of
+    the reference, train_Votenet_FSB.py:246-293): one GEMM launch per layer with the previous
+    layer's BatchNorm (running statistics) + ReLU applied while its operand is staged, between
+    one layout launch on either side -- instead of conv, batch_norm and relu per layer on the
+    stock ops."""
+    dev = x.device
+    B, K0, N = x.shape
+    rows = B * N
+    K0p = _ceil4(K0)
+    consts = _eval_chain_constants(chain, K0p)
+    with _on(x) as d:
+        st = _stream(d)
+        A = _ext.twin_of(x) if K0p == K0 else None
+        if A is not None and A.is_contiguous() and A.numel() == rows * K0 and A.shape[-1] == K0:
+            A = A.view(rows, K0)
+        else:
+            A = _f32((rows, K0p), dev)
+            _call(_lib.btr_pm_rows, B, N, K0, K0p, _p(x.contiguous()), _p(A), st)
+        lda, K = K0p, K0p
+        pa = pb = None
+        for c in consts:
+            W2, a, b, bias = c[:4]
+            Np = W2.shape[0]
+            Y = _f32((rows, Np), dev)
+            if _lib.btr_pm_gemm_nt_sm_supported(rows, Np, K):
+                if c[4] is None:
+                    c[4] = torch.empty((int(_lib.btr_pm_weight_planes_bytes(Np, K)),),
+                                       dtype=torch.uint8, device=dev)
+                    _call(_lib.btr_pm_weight_planes, Np, K, _p(W2), K, _p(c[4]), st)
+                _call(_lib.btr_pm_gemm_nt_sm, rows, Np, K, _p(A), lda, _p(c[4]), _p(Y), Np, _p(pa),
+                      _p(pb), None, _p(bias), st, key=(rows, Np, K))
+            else:
+                _call(_lib.btr_pm_gemm_nt, rows, Np, K, _p(A), lda, _p(W2), K, _p(Y), Np, _p(pa),
+                      _p(pb), None, _p(bias), st, key=(rows, Np, K))
+            pa, pb = a, b
+            A, lda, K = Y, Np, Np
+        NL = chain[-1][0].out_channels
+        out = _f32((B, NL, N), dev)
+        out_cl = _f32((rows, NL), dev)
+        _call(_lib.btr_pm_out, B, N, NL, lda, _p(A), _p(pa), _p(pb), 1 if pa is not None else 0,
+              _p(out), _p(out_cl), st)
+    _ext.attach_twin(out, out_cl)
+    return out
+
+
 def _run_chain(x, chain):
     if not (enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
         return None
+    if not torch.is_grad_enabled() and _eval_ok(x.shape[1], chain):
+        PATHS["library_eval"] += 1
+        return _eval_chain(x, chain)
     if x.shape[0] * x.shape[2] < _min_rows():
         PATHS["stock_small"] += 1
         return None

@@ -144,6 +144,12 @@ class _SingleScaleSA(nn.Module):
             mlp_spec[0] += 3
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
+    def train(self, mode: bool = True):
+        # constants derived from the running statistics for the inference forward
+        # (fused_sa._eval_constants) do not outlive a mode switch
+        self._btr_eval_consts = None
+        return super().train(mode)
+
     def _group_and_pool(self, xyz, new_xyz, features):
         if new_xyz is not None and fused_sa.can_fuse(self, xyz, features):
             # MI355X fast path: grouping + shared MLP + max-pool as fused HIP kernels

@@ -365,6 +365,7 @@ class _FastStep(object):
         for gi, (group, _, _) in enumerate(work):
             gr.lr[gi], gr.wd[gi] = float(group['lr']), float(group['weight_decay'])
         norm = None
+        _ext.RUNNING_STATS_EPOCH[0] += 1   # parameters move through raw pointers
         with _ext._on(first) as dv:
             stream = _ext._stream(dv)
             for t0, t1, c0, nchunks, gp in st['blocks']:
@@ -694,6 +695,7 @@ class GraphedPipelinedStep(object):
         if next_batch is not None:
             self.nxt_pc.copy_(next_batch['point_clouds'], non_blocking=True)
         self.graph.replay()
+        fused_backbone._ext.RUNNING_STATS_EPOCH[0] += 1   # the replay moves running statistics
         return self.loss
 
 

@@ -84,3 +84,120 @@ def test_module_eval_path_takes_the_single_launch(cuda, monkeypatch):
         _, ref, inds2 = sa(xyz, feats, inds)
     assert torch.equal(inds, inds2)
     assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+def _head(cin, widths, last=None, seed=0):
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    mods, c = [], cin
+    for w in widths:
+        mods += [nn.Conv1d(c, w, 1), nn.BatchNorm1d(w), nn.ReLU()]
+        c = w
+    if last is not None:
+        mods.append(nn.Conv1d(c, last, 1))
+    seq = nn.Sequential(*mods)
+    for m in seq:
+        if isinstance(m, nn.BatchNorm1d):   # statistics and affine that are not the defaults
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    return seq
+
+
+@pytest.mark.parametrize("B,N,cin,widths,last", [
+    (8, 1024, 256, (256, 256), 259),    # voting module
+    (8, 256, 128, (128, 128), 79),      # proposal head (ragged last width)
+    (8, 1024, 256, (256, 128), None),   # global domain classifier: BatchNorm last
+    (3, 64, 138, (64,), 3),             # jitter_net: input width not a multiple of 4
+    (2, 20000, 4, (32, 32), None),      # many rows: the large-M kernel
+])
+def test_eval_chain_matches_the_stock_modules(cuda, B, N, cin, widths, last):
+    """A conv/BN/ReLU head under eval() + no_grad on the library's chain kernels
+    (fused_mlp._eval_chain) against the same nn.Sequential in float64."""
+    from backtoreality_amd.pointnet2 import fused_mlp
+    from backtoreality_amd.votenet.votenet_da import _run_head
+    seq = _head(cin, widths, last, seed=cin + N).to(cuda).eval()
+    x = torch.randn(B, cin, N, device=cuda)
+    ref = copy_f64(seq)(x.double())
+    before = fused_mlp.PATHS["library_eval"]
+    with torch.no_grad():
+        out = _run_head(seq, x)
+        again = _run_head(seq, x)
+    assert fused_mlp.PATHS["library_eval"] == before + 2
+    assert out.shape == ref.shape and torch.equal(out, again)
+    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-5, err
+    twin = _ext.twin_of(out)
+    assert twin is not None and torch.equal(twin.view(B, N, -1).transpose(1, 2), out)
+
+
+def copy_f64(seq):
+    import copy
+    return copy.deepcopy(seq).double()
+
+
+def test_eval_constants_follow_the_training_writes(cuda):
+    """The cached inference constants (fused_mlp._eval_chain_constants,
+    fused_sa._eval_constants) are rebuilt after the library moved running statistics or
+    parameters through raw pointers (a training forward; the native Adam step) and after
+    in-place loads: eval output == the stock modules' on the live tensors each time."""
+    from backtoreality_amd.pointnet2 import fused_mlp
+    from backtoreality_amd.votenet.votenet_da import _run_head
+    seq = _head(128, (128, 128), 1, seed=5).to(cuda)
+    x = torch.randn(4, 128, 512, device=cuda)
+
+    def check():
+        seq.eval()
+        with torch.no_grad():
+            out = _run_head(seq, x)
+        ref = copy_f64(seq)(x.double())
+        err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-5, err
+        return out
+
+    o0 = check()
+    seq.train()
+    before = fused_mlp.PATHS["library"]
+    _run_head(seq, x * 3 + 1).sum().backward()      # native training forward: running stats move
+    assert fused_mlp.PATHS["library"] == before + 1
+    o1 = check()
+    assert not torch.equal(o0, o1)
+    sd = {k: v.clone() for k, v in seq.state_dict().items()}
+    sd["1.running_mean"] += 0.5
+    sd["0.weight"] *= 1.1
+    seq.load_state_dict(sd)
+    o2 = check()
+    assert not torch.equal(o1, o2)
+    _ext.RUNNING_STATS_EPOCH[0] += 1                 # (what the native Adam step does)
+    with torch.no_grad():
+        seq[0].weight.data.view(-1)[:8].zero_()      # .data writes bump no version counter
+    check()
+
+
+def test_sa_module_eval_constants_follow_the_training_writes(cuda, monkeypatch):
+    from backtoreality_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(3)
+    m = PointnetSAModuleVotes(npoint=128, radius=0.4, nsample=16, mlp=[1, 32, 32, 64],
+                              use_xyz=True, normalize_xyz=True).to(cuda)
+    xyz = torch.rand(2, 2048, 3, device=cuda)
+    f = torch.randn(2, 1, 2048, device=cuda)
+
+    def evaluate(fused):
+        m.eval()
+        with monkeypatch.context() as mp:
+            if not fused:
+                mp.setenv("BTR_FUSED_SA", "0")
+            with torch.no_grad():
+                return m(xyz, f)[1]
+
+    a0 = evaluate(True)
+    assert getattr(m, "_btr_eval_consts", None) is not None
+    torch.testing.assert_close(a0, evaluate(False), rtol=1e-4, atol=1e-4)
+    m.train()
+    assert m._btr_eval_consts is None
+    for _ in range(3):
+        m(xyz, f * 2 + 1)[1].sum().backward()        # running statistics move natively
+    a1 = evaluate(True)
+    assert not torch.equal(a0, a1)
+    torch.testing.assert_close(a1, evaluate(False), rtol=1e-4, atol=1e-4)

@@ -67,9 +67,11 @@ for name, fn in (("forward only", forward_only), ("forward, pyramid prefetched",
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fn(20)
+    th = (time.perf_counter() - t0) / 20     # host done enqueuing
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
-    print("%-30s %.2f ms per batch = %.0f scenes/s" % (name, dt * 1e3, B / dt))
+    print("%-30s %.2f ms per batch = %.0f scenes/s (host enqueue %.2f ms)" % (
+        name, dt * 1e3, B / dt, th * 1e3))
 train.evaluate_one_epoch(net, batches[:1], cfg)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
