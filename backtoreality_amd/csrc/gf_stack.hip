@@ -221,42 +221,56 @@ int btr_gf_stack_forward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *pp
   BTR_REQUIRE(!d.has_qpos || qpos0_t, "gf_stack_forward: the first query position is missing");
   BTR_REQUIRE(!d.has_kpos || key_xyz_t, "gf_stack_forward: the key position is missing");
   hipStream_t hs = as_stream(stream);
-  const float *x = query_cl;
-  const float *qpos_t = qpos0_t;
   const int L = d.layers;
-  for (int i = 0; i < L; ++i) {
+  for (int i = 0; i < L; ++i)
     BTR_REQUIRE(head_out[i] && head_out_cl[i] && center[i] && heading_residuals[i] &&
                     size_residuals[i] && pred_size[i] && query_pos[i] && query_pos_t[i],
                 "gf_stack_forward: outputs of layer %d", i);
-    float *qpos_cl = nullptr, *kpos_cl = nullptr;
-    if (d.has_qpos) {
-      qpos_cl = at_f(saved, p.s_qpos_cl[i]);
-      BTR_TRY(btr_pm_chain_forward(&d.qpos[i], &p.qpos[i], qpos_t, nullptr, nullptr, qpos_cl,
-                                   at_v(saved, p.s_qpos[i]), scratch, stream));
+  auto body = [&](hipStream_t bs) -> int {
+    btr_stream_t stream = (btr_stream_t)bs;
+    const float *x = query_cl;
+    const float *qpos_t = qpos0_t;
+    for (int i = 0; i < L; ++i) {
+      float *qpos_cl = nullptr, *kpos_cl = nullptr;
+      if (d.has_qpos) {
+        qpos_cl = at_f(saved, p.s_qpos_cl[i]);
+        BTR_TRY(btr_pm_chain_forward(&d.qpos[i], &p.qpos[i], qpos_t, nullptr, nullptr, qpos_cl,
+                                     at_v(saved, p.s_qpos[i]), scratch, stream));
+      }
+      if (d.has_kpos) {
+        kpos_cl = at_f(saved, p.s_kpos_cl[i]);
+        BTR_TRY(btr_pm_chain_forward(&d.kpos[i], &p.kpos[i], key_xyz_t, nullptr, nullptr, kpos_cl,
+                                     at_v(saved, p.s_kpos[i]), scratch, stream));
+      }
+      float *xo = at_f(saved, p.s_x[i]);
+      BTR_TRY(btr_decoder_layer_forward(&d.layer[i], &p.layer[i], x, key_cl, qpos_cl, kpos_cl,
+                                        i == L - 1 ? last_bcp : nullptr, xo,
+                                        at_v(saved, p.s_layer[i]), scratch, stream));
+      BTR_TRY(btr_pm_chain_forward(&d.head[i], &p.head[i], nullptr, xo, head_out[i],
+                                   head_out_cl[i], at_v(saved, p.s_head[i]), scratch, stream));
+      const int cp = p.head[i].np[d.head[i].layers - 1];
+      BTR_TRY(btr_gf_head_decode(d.b, d.pq, d.nh, d.ns, head_out_cl[i], (long long)d.pq * cp, cp,
+                                 1, base_xyz, mean_size, center[i], heading_residuals[i],
+                                 size_residuals[i], pred_size[i], query_pos[i], query_pos_t[i],
+                                 stream));
+      x = xo;
+      qpos_t = query_pos_t[i];
     }
-    if (d.has_kpos) {
-      kpos_cl = at_f(saved, p.s_kpos_cl[i]);
-      BTR_TRY(btr_pm_chain_forward(&d.kpos[i], &p.kpos[i], key_xyz_t, nullptr, nullptr, kpos_cl,
-                                   at_v(saved, p.s_kpos[i]), scratch, stream));
-    }
-    float *xo = at_f(saved, p.s_x[i]);
-    BTR_TRY(btr_decoder_layer_forward(&d.layer[i], &p.layer[i], x, key_cl, qpos_cl, kpos_cl,
-                                      i == L - 1 ? last_bcp : nullptr, xo,
-                                      at_v(saved, p.s_layer[i]), scratch, stream));
-    BTR_TRY(btr_pm_chain_forward(&d.head[i], &p.head[i], nullptr, xo, head_out[i], head_out_cl[i],
-                                 at_v(saved, p.s_head[i]), scratch, stream));
-    const int cp = p.head[i].np[d.head[i].layers - 1];
-    BTR_TRY(btr_gf_head_decode(d.b, d.pq, d.nh, d.ns, head_out_cl[i], (long long)d.pq * cp, cp, 1,
-                               base_xyz, mean_size, center[i], heading_residuals[i],
-                               size_residuals[i], pred_size[i], query_pos[i], query_pos_t[i],
-                               stream));
-    x = xo;
-    qpos_t = query_pos_t[i];
-  }
-  if (last_cl)
-    (void)hipMemcpyAsync(last_cl, x, (size_t)d.b * d.pq * d.e * sizeof(float),
-                         hipMemcpyDeviceToDevice, hs);
-  return check_launch("gf_stack_forward");
+    if (last_cl)
+      (void)hipMemcpyAsync(last_cl, x, (size_t)d.b * d.pq * d.e * sizeof(float),
+                           hipMemcpyDeviceToDevice, bs);
+    return check_launch("gf_stack_forward");
+  };
+  // everything the launches depend on: the descriptor (sizes, parameter pointers, seeds), the
+  // plan's offsets follow from it; the arguments; the contents of the pointer arrays
+  uint64_t key = hash_bytes(0x9f57ac1e5eedull, &d, sizeof(d));
+  const void *args[] = {query_cl, key_cl, qpos0_t, key_xyz_t, base_xyz, mean_size,
+                        last_bcp, last_cl, saved, scratch};
+  key = hash_bytes(key, args, sizeof(args));
+  float *const *arrays[] = {head_out, head_out_cl, center, heading_residuals, size_residuals,
+                            pred_size, query_pos, query_pos_t};
+  for (auto *a : arrays) key = hash_bytes(key, a, sizeof(float *) * L);
+  return graph_run(key, hs, body, nullptr);
 }
 
 int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *pp,
@@ -268,73 +282,81 @@ int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *p
               "gf_stack_backward: null pointer");
   const btr_gf_stack_t &d = *dp;
   const btr_gf_stack_plan_t &p = *pp;
-  hipStream_t hs = as_stream(stream);
-  const BwdScratch sc = bwd_scratch(d, p);
-  void *sub = at_v(scratch, sc.sub);
-  const long long q = (long long)d.b * d.pq * d.e, k = (long long)d.b * d.pk * d.e;
-  const int L = d.layers;
-  // what reaches x[i] from above: the pair (d res1, d qp0) of layer i+1, or the caller's gradient
-  const float *up0 = nullptr, *up1 = nullptr;
-  if (dlast_bcp) {
-    BTR_TRY(btr_pm_rows(d.b, d.pq, d.e, d.e, dlast_bcp, at_f(scratch, sc.dlast), stream));
-    up0 = at_f(scratch, sc.dlast);
-  }
-  int flip = 0;
-  for (int i = L - 1; i >= 0; --i) {
-    const float *g0 = up0, *g1 = up1, *g2 = nullptr;
-    if (dhead[i]) {
-      float *dhx = at_f(scratch, sc.dhx);
-      BTR_TRY(pm_chain_backward_rows(&d.head[i], &p.head[i], at_f(saved, p.s_x[i]), dhead[i],
-                                     nullptr, nullptr, at_v(saved, p.s_head[i]),
-                                     grads + p.g_head[i], nullptr, dhx, sub, stream));
-      // (module loop: d x[i] = head's + the layer's / the caller's -- a + b = b + a exactly, and
-      // the layer's own two parts are added first as its rows_to_bcp did)
-      if (g0) g2 = dhx; else g0 = dhx;
-    } else {
-      (void)hipMemsetAsync(grads + p.g_head[i], 0, p.head[i].grads_floats * sizeof(float), hs);
+  hipStream_t hs0 = as_stream(stream);
+  auto body = [&](hipStream_t hs) -> int {
+    btr_stream_t stream = (btr_stream_t)hs;
+    const BwdScratch sc = bwd_scratch(d, p);
+    void *sub = at_v(scratch, sc.sub);
+    const long long q = (long long)d.b * d.pq * d.e, k = (long long)d.b * d.pk * d.e;
+    const int L = d.layers;
+    // what reaches x[i] from above: the pair (d res1, d qp0) of layer i+1, or the caller's gradient
+    const float *up0 = nullptr, *up1 = nullptr;
+    if (dlast_bcp) {
+      BTR_TRY(btr_pm_rows(d.b, d.pq, d.e, d.e, dlast_bcp, at_f(scratch, sc.dlast), stream));
+      up0 = at_f(scratch, sc.dlast);
     }
-    const float *x_in = i == 0 ? query_cl : at_f(saved, p.s_x[i - 1]);
-    const float *qpos_cl = d.has_qpos ? at_f(saved, p.s_qpos_cl[i]) : nullptr;
-    const float *kpos_cl = d.has_kpos ? at_f(saved, p.s_kpos_cl[i]) : nullptr;
-    float *dkp = at_f(scratch, sc.dkp[i]);
-    if (!g0) {   // nothing reaches this layer (and so none below it through x)
-      (void)hipMemsetAsync(grads + p.g_layer[i], 0, p.layer[i].grads_floats * sizeof(float), hs);
-      (void)hipMemsetAsync(dkp, 0, (size_t)k * sizeof(float), hs);
+    int flip = 0;
+    for (int i = L - 1; i >= 0; --i) {
+      const float *g0 = up0, *g1 = up1, *g2 = nullptr;
+      if (dhead[i]) {
+        float *dhx = at_f(scratch, sc.dhx);
+        BTR_TRY(pm_chain_backward_rows(&d.head[i], &p.head[i], at_f(saved, p.s_x[i]), dhead[i],
+                                       nullptr, nullptr, at_v(saved, p.s_head[i]),
+                                       grads + p.g_head[i], nullptr, dhx, sub, stream));
+        // (module loop: d x[i] = head's + the layer's / the caller's -- a + b = b + a exactly, and
+        // the layer's own two parts are added first as its rows_to_bcp did)
+        if (g0) g2 = dhx; else g0 = dhx;
+      } else {
+        (void)hipMemsetAsync(grads + p.g_head[i], 0, p.head[i].grads_floats * sizeof(float), hs);
+      }
+      const float *x_in = i == 0 ? query_cl : at_f(saved, p.s_x[i - 1]);
+      const float *qpos_cl = d.has_qpos ? at_f(saved, p.s_qpos_cl[i]) : nullptr;
+      const float *kpos_cl = d.has_kpos ? at_f(saved, p.s_kpos_cl[i]) : nullptr;
+      float *dkp = at_f(scratch, sc.dkp[i]);
+      if (!g0) {   // nothing reaches this layer (and so none below it through x)
+        (void)hipMemsetAsync(grads + p.g_layer[i], 0, p.layer[i].grads_floats * sizeof(float), hs);
+        (void)hipMemsetAsync(dkp, 0, (size_t)k * sizeof(float), hs);
+        if (d.has_qpos)
+          (void)hipMemsetAsync(grads + p.g_qpos[i], 0, p.qpos[i].grads_floats * sizeof(float), hs);
+        if (d.has_kpos)
+          (void)hipMemsetAsync(grads + p.g_kpos[i], 0, p.kpos[i].grads_floats * sizeof(float), hs);
+        up0 = up1 = nullptr;
+        continue;
+      }
+      const DecoderRowsOut out{at_f(scratch, sc.pair[flip][0]), at_f(scratch, sc.pair[flip][1]),
+                               at_f(scratch, sc.dqp1), dkp};
+      flip ^= 1;
+      BTR_TRY(decoder_layer_backward_rows(&d.layer[i], &p.layer[i], x_in, key_cl, qpos_cl, kpos_cl,
+                                          nullptr, g0, g1, g2, at_v(saved, p.s_layer[i]),
+                                          grads + p.g_layer[i], i == 0 ? dquery_bcp : nullptr,
+                                          nullptr, nullptr, &out, sub, stream));
       if (d.has_qpos)
-        (void)hipMemsetAsync(grads + p.g_qpos[i], 0, p.qpos[i].grads_floats * sizeof(float), hs);
+        BTR_TRY(pm_chain_backward_rows(&d.qpos[i], &p.qpos[i], nullptr, nullptr, out.dqp0, out.dqp1,
+                                       at_v(saved, p.s_qpos[i]), grads + p.g_qpos[i], nullptr,
+                                       nullptr, sub, stream));
       if (d.has_kpos)
-        (void)hipMemsetAsync(grads + p.g_kpos[i], 0, p.kpos[i].grads_floats * sizeof(float), hs);
-      up0 = up1 = nullptr;
-      continue;
+        BTR_TRY(pm_chain_backward_rows(&d.kpos[i], &p.kpos[i], nullptr, nullptr, dkp, nullptr,
+                                       at_v(saved, p.s_kpos[i]), grads + p.g_kpos[i], nullptr,
+                                       nullptr, sub, stream));
+      up0 = out.dres1;
+      up1 = out.dqp0;
     }
-    const DecoderRowsOut out{at_f(scratch, sc.pair[flip][0]), at_f(scratch, sc.pair[flip][1]),
-                             at_f(scratch, sc.dqp1), dkp};
-    flip ^= 1;
-    BTR_TRY(decoder_layer_backward_rows(&d.layer[i], &p.layer[i], x_in, key_cl, qpos_cl, kpos_cl,
-                                        nullptr, g0, g1, g2, at_v(saved, p.s_layer[i]),
-                                        grads + p.g_layer[i], i == 0 ? dquery_bcp : nullptr,
-                                        nullptr, nullptr, &out, sub, stream));
-    if (d.has_qpos)
-      BTR_TRY(pm_chain_backward_rows(&d.qpos[i], &p.qpos[i], nullptr, nullptr, out.dqp0, out.dqp1,
-                                     at_v(saved, p.s_qpos[i]), grads + p.g_qpos[i], nullptr,
-                                     nullptr, sub, stream));
-    if (d.has_kpos)
-      BTR_TRY(pm_chain_backward_rows(&d.kpos[i], &p.kpos[i], nullptr, nullptr, dkp, nullptr,
-                                     at_v(saved, p.s_kpos[i]), grads + p.g_kpos[i], nullptr,
-                                     nullptr, sub, stream));
-    up0 = out.dres1;
-    up1 = out.dqp0;
-  }
-  if (dquery_bcp && !up0)
-    (void)hipMemsetAsync(dquery_bcp, 0, (size_t)q * sizeof(float), hs);
-  if (dkey_bcp) {   // the layers' key gradients, last layer first (autograd's order), then (b, e, pk)
-    const float *src[BTR_GF_MAX_DECODER_LAYERS];
-    for (int i = 0; i < L; ++i) src[i] = at_f(scratch, sc.dkp[L - 1 - i]);
-    BTR_TRY(sum_into(hs, k, src, L, at_f(scratch, sc.ksum)));
-    BTR_TRY(btr_pm_out(d.b, d.pk, d.e, d.e, at_f(scratch, sc.ksum), nullptr, nullptr, 0, dkey_bcp,
-                       nullptr, stream));
-  }
-  return check_launch("gf_stack_backward");
+    if (dquery_bcp && !up0)
+      (void)hipMemsetAsync(dquery_bcp, 0, (size_t)q * sizeof(float), hs);
+    if (dkey_bcp) {   // the layers' key gradients, last layer first (autograd's order), then (b, e, pk)
+      const float *src[BTR_GF_MAX_DECODER_LAYERS];
+      for (int i = 0; i < L; ++i) src[i] = at_f(scratch, sc.dkp[L - 1 - i]);
+      BTR_TRY(sum_into(hs, k, src, L, at_f(scratch, sc.ksum)));
+      BTR_TRY(btr_pm_out(d.b, d.pk, d.e, d.e, at_f(scratch, sc.ksum), nullptr, nullptr, 0, dkey_bcp,
+                         nullptr, stream));
+    }
+    return check_launch("gf_stack_backward");
+  };
+  uint64_t key = hash_bytes(0xbac4b0a2d5eedull, &d, sizeof(d));
+  const void *args[] = {query_cl, key_cl, dlast_bcp, saved, grads, dquery_bcp, dkey_bcp, scratch};
+  key = hash_bytes(key, args, sizeof(args));
+  key = hash_bytes(key, dhead, sizeof(float *) * d.layers);
+  return graph_run(key, hs0, body, nullptr);
 }
 
 }  // extern "C"

@@ -2,6 +2,9 @@
 // (not part of the C ABI).  The whole-backbone entry points (backbone.hip) sequence the
 // whole-layer ones (sa_layer.hip) and need a few of their pieces with extra operands.
 #pragma once
+#include <cstdint>
+#include <functional>
+
 #include "common.hpp"
 
 namespace btr {
@@ -16,6 +19,19 @@ int grid_cus();
 // when WORLD_SIZE > 1.  fps_lds_kb(np): what a launch over np points asks for
 int fps_lds_reserve_kb();
 int fps_lds_kb(int np);
+
+// graph_cache.hip: body(stream) -- a fixed sequence of launches on `stream`, determined entirely by
+// what the caller hashed into `key` (hash_bytes over its descriptor and every argument) -- issued
+// launch by launch the first time a key is seen, captured into a HIP graph the second time, and
+// replayed from then on.  *how (optional): 0 issued, 1 captured + launched, 2 replayed.  Issued as
+// always inside somebody else's capture, while the GEMM trace is on, or with BTR_GRAPHS=0.
+int graph_run(uint64_t key, hipStream_t stream, const std::function<int(hipStream_t)> &body,
+              int *how);
+uint64_t hash_bytes(uint64_t h, const void *p, size_t n);
+bool graph_capturing();     // this host thread is inside graph_run's capture
+bool graphs_enabled();
+// sa_mlp.hip: btr_gemm_trace_begin() is in effect (its event pairs do not belong in a graph)
+bool gemm_trace_active();
 
 // sa_mlp.hip: out_bcn (B, C, N) [and out_cl (B*N, C)] = f(scale * y + shift) [+ add];
 // add (optional): a (B, C, N)-shaped operand whose batch elements are add_bstride floats apart

@@ -202,6 +202,7 @@ inline int &gemm_trace_slot() {
   static thread_local int slot = -1;   // the outermost open scope's pinned slot
   return slot;
 }
+bool gemm_trace_active() { return gemm_trace_state().on.load(std::memory_order_relaxed); }
 struct GemmTrace {
   hipStream_t s;
   hipEvent_t stop;

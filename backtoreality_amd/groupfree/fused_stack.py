@@ -13,7 +13,17 @@ bit for bit (same kernels, same operand order in the gradient sums; tests/test_g
 
 Covers what the per-module library paths cover (CUDA f32 tensors, training mode, ReLU layers,
 learned position embeddings or none); `BTR_FUSED_GF_STACK=0` disables it, and a HIP-graph capture
-keeps the per-module path (see fused_mlp._min_rows)."""
+keeps the per-module path (see fused_mlp._min_rows).
+
+Round 6: the two calls replay as HIP graphs (csrc/graph_cache.hip: ~700 launches of 5 - 20 us cost
+the host 15 us per call instead of ~3 us per launch, and the queue ~1.1 us between two dependent
+kernels instead of 2.5 - 3.5).  A graph replays exact pointers, and the caching allocator does not
+hand the same addresses to consecutive steps (tools/diag_gf_ptrs.py: 16 distinct argument tuples
+in 16 steps), so a call works on a SLOT of buffers that live as long as the detector: inputs are
+copied / laid out into it, the library writes its outputs there, and what autograd and the caller
+see is ONE clone of the slot's output block -- nothing handed out aliases a slot.  A slot is busy
+from its forward to the end of its backward (two forwards before a backward -- the two-branch
+steps -- take two slots); `BTR_GF_SLOTS=0` keeps the per-call allocations."""
 import ctypes
 import os
 import weakref
@@ -48,6 +58,111 @@ def _u8(nbytes, dev):
     return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
 
 
+def _slots_enabled():
+    return os.environ.get("BTR_GF_SLOTS", "1") != "0"
+
+
+_MAX_SLOTS = 4
+
+
+def _up64(n):
+    return (int(n) + 63) // 64 * 64
+
+
+class _OutBlock(object):
+    """The stack's outputs as views of one flat f32 buffer (pieces start on 256-byte bounds)."""
+
+    def __init__(self, flat, L, B, Pq, E, C, Cp, nh, ns, want_last):
+        at = [0]
+
+        def take(*shape):
+            n = 1
+            for v in shape:
+                n *= v
+            t = flat[at[0]:at[0] + n].view(shape)
+            at[0] += _up64(n)
+            return t
+        self.cls = take(L, B * Pq, Cp)
+        self.qpos, self.qpos_t = take(L, B, Pq, 6), take(L, B, 6, Pq)
+        self.outs = []
+        for i in range(L):
+            self.outs.append((take(B, C, Pq), take(B, Pq, 3), take(B, Pq, nh), take(B, Pq, ns, 3),
+                              take(B, Pq, 3), self.qpos[i], self.qpos_t[i]))
+        self.last = take(B, E, Pq) if want_last else None
+        self.last_cl = take(B * Pq, E) if want_last else None
+
+    @staticmethod
+    def floats(L, B, Pq, E, C, Cp, nh, ns, want_last):
+        n = _up64(L * B * Pq * Cp) + 2 * _up64(L * B * Pq * 6)
+        n += L * (_up64(B * C * Pq) + 2 * _up64(B * Pq * 3) + _up64(B * Pq * nh) +
+                  _up64(B * Pq * ns * 3))
+        if want_last:
+            n += 2 * _up64(B * E * Pq)
+        return n
+
+
+class _Slot(object):
+    """The buffers of one decoder-stack call in flight (see the module docstring)."""
+
+    def __init__(self, ent, dev, want_last, qd, kd, cat_shapes):
+        d, plan = ent.d, ent.plan
+        L, B, Pq, Pk, E = d.layers, d.b, d.pq, d.pk, d.e
+        C, nh, ns = d.head_c, d.nh, d.ns
+        Cp = plan.head[0].np[d.head[0].layers - 1]
+        self.busy = False
+        self.dims = (L, B, Pq, E, C, Cp, nh, ns, want_last)
+        self.x_cl, self.key_cl = _f32((B * Pq, E), dev), _f32((B * Pk, E), dev)
+        self.qpos0_t = _f32((B, qd, Pq), dev) if qd else None
+        self.key_xyz_t = _f32((B, kd, Pk), dev) if kd else None
+        self.base = _f32((B, Pq, 3), dev)
+        self.cat = [(_f32(ws, dev), _f32(bs, dev)) for ws, bs in cat_shapes]
+        self.out_flat = _f32((_OutBlock.floats(*self.dims),), dev)
+        self.out = _OutBlock(self.out_flat, *self.dims)
+        self.saved = _u8(plan.saved_bytes, dev)
+        self.scratch = _u8(max(plan.fwd_scratch_bytes, plan.bwd_scratch_bytes), dev)
+        self.dheads = _f32((L, B, C, Pq), dev)
+        self.dlast = _f32((B, E, Pq), dev) if want_last else None
+        self.grads = _f32((plan.grads_floats,), dev)
+        self.dquery, self.dkey = _f32((B, E, Pq), dev), _f32((B, E, Pk), dev)
+        self.seeds = [fused_attention._next_seed() for _ in range(L)]
+        self.d = None          # this slot's descriptor (seeds, the heads' concatenated layers)
+        self.ptrs = None       # ent.ptrs the descriptor was made from
+        self.fwd_arrays = None
+
+
+class _Lease(object):
+    """Frees its slot when the autograd node that holds it goes away (or at the end of the
+    backward, whichever is first)."""
+    __slots__ = ("slot",)
+
+    def __init__(self, slot):
+        self.slot = slot
+        slot.busy = True
+
+    def release(self):
+        if self.slot is not None:
+            self.slot.busy = False
+            self.slot = None
+
+    def __del__(self):
+        self.release()
+
+
+def _acquire(ent, dev, stream, want_last, qd, kd, cat_shapes):
+    """A free slot of `ent` for calls on `stream`, or None (slots off, or _MAX_SLOTS in flight:
+    the call then allocates per call and is issued launch by launch)."""
+    if not _slots_enabled():
+        return None
+    pool = ent.slots.setdefault((dev, stream, want_last), [])
+    for s in pool:
+        if not s.busy:
+            return s
+    if len(pool) >= _MAX_SLOTS:
+        return None
+    pool.append(_Slot(ent, dev, want_last, qd, kd, cat_shapes))
+    return pool[-1]
+
+
 def _transposed(xyz):
     """(B, d, P) contiguous form of (B, P, d) coordinates (cached on the tensor by the head decode
     kernel / the position embedding module)."""
@@ -71,7 +186,7 @@ def _embed_chain(m):
 class _Entry(object):
     """What is fixed for a detector and a set of shapes: the descriptor with its sizes filled in,
     the plan, the block sizes of the flat gradient buffer."""
-    __slots__ = ("d", "plan", "layer_sizes", "chain_sizes", "ptrs", "metas", "sink")
+    __slots__ = ("d", "plan", "layer_sizes", "chain_sizes", "ptrs", "metas", "sink", "slots")
 
 
 def _entry(det, key, B, Pq, Pk, E, qd, kd, p, specs):
@@ -106,7 +221,7 @@ def _entry(det, key, B, Pq, Pk, E, qd, kd, p, specs):
         _lib.btr_gf_stack_sizeof(1) == ctypes.sizeof(plan), "btr_gf_stack_t mirror out of date"
     _call(_lib.btr_gf_stack_plan, ctypes.addressof(d), ctypes.addressof(plan))
     ent = _Entry()
-    ent.d, ent.plan, ent.ptrs, ent.sink = d, plan, None, None
+    ent.d, ent.plan, ent.ptrs, ent.sink, ent.slots = d, plan, None, None, {}
     F = d.layer[0].ff
     ent.layer_sizes = [3 * E * E, 3 * E, E * E, E, 3 * E * E, 3 * E, E * E, E, F * E, F, E * F, E,
                        E, E, E, E, E, E]
@@ -196,6 +311,25 @@ def _set_pointers(ent, det, specs, params, cat_at):
     ent.ptrs = ptrs
 
 
+def _slot_descriptor(slot, ent, p, dev):
+    """The slot's own copy of the descriptor: the entry's (sizes, parameter pointers) with the
+    slot's dropout seeds and the heads' last layers read from the slot's copies.  Remade when a
+    parameter pointer moved (ent.ptrs is replaced then)."""
+    if slot.d is not None and slot.ptrs is ent.ptrs:
+        return
+    d = _ext.GfStack.from_buffer_copy(ent.d)
+    step = fused_attention.step_counter(dev) if p > 0 else None
+    for i in range(d.layers):
+        if p > 0:
+            d.layer[i].seed = slot.seeds[i]
+            d.layer[i].step = step.data_ptr()
+        hd = d.head[i]
+        hd.w[hd.layers - 1] = slot.cat[i][0].data_ptr()
+        hd.bias[hd.layers - 1] = slot.cat[i][1].data_ptr()
+    slot.d, slot.ptrs = d, ent.ptrs
+    slot.fwd_arrays = _fwd_arrays(slot.out)
+
+
 def _ptr_array(tensors):
     return (_VP * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
@@ -215,57 +349,80 @@ class DecoderStackFn(Function):
         ctx.leaf = [t is not None and t.is_leaf and t.requires_grad for t in params] \
             if sink is not None else None
         plan = ent.plan
-        d = _ext.GfStack.from_buffer_copy(ent.d)   # this call's own copy (dropout seeds)
-        L, B, Pq, E = d.layers, d.b, d.pq, d.e
+        slot = meta.get("slot")
         dev = query.device
-        step = None
-        if p > 0:
-            step = fused_attention.step_counter(dev)
-            for i in range(L):
-                d.layer[i].seed = fused_attention._next_seed()
-                d.layer[i].step = step.data_ptr()
+        step = fused_attention.step_counter(dev) if p > 0 else None
+        if slot is not None:
+            ctx.lease = _Lease(slot)
+            d = slot.d
+        else:
+            ctx.lease = None
+            d = _ext.GfStack.from_buffer_copy(ent.d)   # this call's own copy (dropout seeds)
+            if p > 0:
+                for i in range(d.layers):
+                    d.layer[i].seed = fused_attention._next_seed()
+                    d.layer[i].step = step.data_ptr()
+        L, B, Pq, E = d.layers, d.b, d.pq, d.e
         C, nh, ns = d.head_c, d.nh, d.ns
         Cp = plan.head[0].np[d.head[0].layers - 1]
-        outs, cls = [], _f32((L, B * Pq, Cp), dev)
-        qpos, qpos_t = _f32((L, B, Pq, 6), dev), _f32((L, B, 6, Pq), dev)
-        for i in range(L):
-            outs.append((_f32((B, C, Pq), dev), _f32((B, Pq, 3), dev), _f32((B, Pq, nh), dev),
-                         _f32((B, Pq, ns, 3), dev), _f32((B, Pq, 3), dev), qpos[i], qpos_t[i]))
-        last = _f32((B, E, Pq), dev) if want_last else None
-        last_cl = _f32((B * Pq, E), dev) if want_last else None
-        saved = _u8(plan.saved_bytes, dev)
-        scratch = _u8(plan.fwd_scratch_bytes, dev)
-        base = base_xyz.contiguous()
+        dims = (L, B, Pq, E, C, Cp, nh, ns, want_last)
         with _on(query) as dv:
             st = _stream(dv)
-            x_cl, key_cl = fused_decoder._rows(query, st), fused_decoder._rows(key, st)
-            arrays = [_ptr_array([o[j] for o in outs]) for j in range(7)]
-            arrays.insert(1, _ptr_array([cls[i] for i in range(L)]))
+            if slot is not None:
+                # inputs into the slot (a layout launch or a copy each), outputs out of it (one
+                # clone): every pointer the library sees is the slot's
+                x_cl, key_cl = _rows_into(query, slot.x_cl, st), _rows_into(key, slot.key_cl, st)
+                if qpos0_t is not None:
+                    qpos0_t = slot.qpos0_t.copy_(qpos0_t)
+                if key_xyz_t is not None:
+                    key_xyz_t = slot.key_xyz_t.copy_(key_xyz_t)
+                base = slot.base.copy_(base_xyz)
+                torch._foreach_copy_([t for wb in slot.cat for t in wb],
+                                     [params[at + j] for at in meta["cat_at"] for j in (0, 1)])
+                ob, saved, scratch = slot.out, slot.saved, slot.scratch
+                arrays = slot.fwd_arrays
+            else:
+                x_cl, key_cl = fused_decoder._rows(query, st), fused_decoder._rows(key, st)
+                base = base_xyz.contiguous()
+                ob = _OutBlock(_f32((_OutBlock.floats(*dims),), dev), *dims)
+                saved = _u8(plan.saved_bytes, dev)
+                scratch = _u8(plan.fwd_scratch_bytes, dev)
+                arrays = _fwd_arrays(ob)
             _call(_lib.btr_gf_stack_forward, ctypes.addressof(d), ctypes.addressof(plan),
                   _p(x_cl), _p(key_cl), _p(qpos0_t), _p(key_xyz_t), _p(base), _p(mean_size),
-                  *arrays, _p(last), _p(last_cl), _p(saved), _p(scratch), st)
+                  *arrays, _p(ob.last), _p(ob.last_cl), _p(saved), _p(scratch), st)
+        if slot is not None:   # (the backward reads the slot's own copies)
+            ob = _OutBlock(slot.out_flat.clone(), *dims)
+            ctx.save_for_backward(mean_size)
+        else:
+            ctx.save_for_backward(mean_size, saved, x_cl, key_cl, *[o[0] for o in ob.outs])
+        outs = ob.outs
         for i in range(L):
-            _ext.attach_twin(outs[i][0], cls[i])
+            _ext.attach_twin(outs[i][0], ob.cls[i])
         if want_last:
-            _ext.attach_twin(last, last_cl)
+            _ext.attach_twin(ob.last, ob.last_cl)
         ctx.ent = (d, ent, step)
         ctx.want_last = want_last
         ctx.pshapes = [None if t is None else t.shape for t in params]
         ctx.specs = meta["specs"]
-        ctx.save_for_backward(saved, x_cl, key_cl, mean_size, *[o[0] for o in outs])
         flat = [t for o in outs for t in o]
         ctx.mark_non_differentiable(*[t for o in outs for t in o[5:]])
         ctx.set_materialize_grads(False)
-        return tuple(flat) + ((last,) if want_last else ())
+        return tuple(flat) + ((ob.last,) if want_last else ())
 
     @staticmethod
     def backward(ctx, *g):
         d, ent, _step = ctx.ent
         plan = ent.plan
         L, B, Pq, Pk, E = d.layers, d.b, d.pq, d.pk, d.e
-        saved, x_cl, key_cl, mean_size = ctx.saved_tensors[:4]
-        head_outs = ctx.saved_tensors[4:]
-        dev = saved.device
+        mean_size = ctx.saved_tensors[0]
+        lease = ctx.lease
+        slot = lease.slot if lease is not None else None
+        if lease is not None and slot is None:
+            raise RuntimeError("decoder stack: this call's buffers were released by an earlier "
+                               "backward (retain_graph is not supported with BTR_GF_SLOTS=1)")
+        head_outs = [o[0] for o in slot.out.outs] if slot is not None else ctx.saved_tensors[4:]
+        dev = mean_size.device
         dims = (B, d.head_c, Pq, d.nh, d.ns)
         dheads, g_base = [], None
         for i in range(L):
@@ -275,22 +432,60 @@ class DecoderStackFn(Function):
                 gh = fold if gh is None else gh + fold
                 if gc is not None and ctx.needs_input_grad[4]:
                     g_base = gc if g_base is None else g_base + gc
-            dheads.append(None if gh is None else gh.contiguous())
+            dheads.append(gh)
         dlast = g[7 * L] if ctx.want_last else None
-        dlast = None if dlast is None else dlast.contiguous()
-        grads = _f32((plan.grads_floats,), dev)
-        scratch = _u8(plan.bwd_scratch_bytes, dev)
-        dquery = _f32((B, E, Pq), dev) if ctx.needs_input_grad[0] else None
-        dkey = _f32((B, E, Pk), dev) if ctx.needs_input_grad[1] else None
+        need_q, need_k = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if slot is not None:
+            have = [i for i in range(L) if dheads[i] is not None]
+            if have:
+                torch._foreach_copy_([slot.dheads[i] for i in have], [dheads[i] for i in have])
+            dheads = [slot.dheads[i] if dheads[i] is not None else None for i in range(L)]
+            if dlast is not None:
+                dlast = slot.dlast.copy_(dlast)
+            saved, x_cl, key_cl = slot.saved, slot.x_cl, slot.key_cl
+            grads, scratch = slot.grads, slot.scratch
+            dquery = slot.dquery if need_q else None
+            dkey = slot.dkey if need_k else None
+        else:
+            dheads = [None if t is None else t.contiguous() for t in dheads]
+            dlast = None if dlast is None else dlast.contiguous()
+            saved, x_cl, key_cl = ctx.saved_tensors[1:4]
+            grads = _f32((plan.grads_floats,), dev)
+            scratch = _u8(plan.bwd_scratch_bytes, dev)
+            dquery = _f32((B, E, Pq), dev) if need_q else None
+            dkey = _f32((B, E, Pk), dev) if need_k else None
         with _on(saved) as dv:
             _call(_lib.btr_gf_stack_backward, ctypes.addressof(d), ctypes.addressof(plan),
                   _p(x_cl), _p(key_cl), _ptr_array(dheads), _p(dlast), _p(saved), _p(grads),
                   _p(dquery), _p(dkey), _p(scratch), _stream(dv))
+        if slot is not None:
+            # (autograd may keep what it is handed -- a parameter's .grad -- beyond this slot's
+            # next call: the gradient block leaves as a copy)
+            grads = grads.clone()
+            lease.release()
         res = _grad_views(d, ent, ctx.specs, ctx.pshapes, grads)
         if ctx.leaf is not None:
             res = [None if leaf else g for g, leaf in zip(res, ctx.leaf)]
             return (dquery, dkey, None, None, g_base, None, None, grads) + tuple(res)
         return (dquery, dkey, None, None, g_base, None, None, None) + tuple(res)
+
+
+def _fwd_arrays(ob):
+    """The eight per-layer pointer arrays of btr_gf_stack_forward for an output block."""
+    arrays = [_ptr_array([o[j] for o in ob.outs]) for j in range(7)]
+    arrays.insert(1, _ptr_array([ob.cls[i] for i in range(len(ob.outs))]))
+    return arrays
+
+
+def _rows_into(t, dst, st):
+    """fused_decoder._rows into a given buffer: a copy of the twin the producer kept, else the
+    layout launch."""
+    B, C, P = t.shape
+    cl = _ext.twin_of(t)
+    if cl is not None and cl.numel() == dst.numel() and cl.shape[-1] == C and cl.is_contiguous():
+        return dst.copy_(cl.view(B * P, C))
+    _call(_lib.btr_pm_rows, B, P, C, C, _p(t.contiguous()), _p(dst), st)
+    return dst
 
 
 def _grad_views(d, ent, specs, pshapes, grads):
@@ -386,10 +581,22 @@ def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
     ent = _entry(det, key_, B, Pq, Pk, E, qd, kd, p, specs)
     params, cat_at = _flat_params(det, specs)
     _set_pointers(ent, det, specs, params, cat_at)
-    qpos0_t = _transposed(query_pos) if query_pos is not None else None
-    key_xyz_t = _transposed(key_pos) if key_pos is not None else None
     mean_size = head0._mean_size_on(query.device)
-    meta = {"entry": ent, "p": p, "want_last": want_last, "specs": specs}
+    meta = {"entry": ent, "p": p, "want_last": want_last, "specs": specs, "cat_at": cat_at}
+    slot = None
+    if not torch.cuda.is_current_stream_capturing():
+        slot = _acquire(ent, query.device, torch.cuda.current_stream(query.device).cuda_stream,
+                        want_last, qd, kd,
+                        [(params[at].shape, params[at + 1].shape) for at in cat_at])
+    if slot is not None:
+        _slot_descriptor(slot, ent, p, query.device)
+        meta["slot"] = slot
+        # (the slot's copies are made inside the node: transposed views, no cached tensors)
+        qpos0_t = query_pos.transpose(1, 2) if query_pos is not None else None
+        key_xyz_t = key_pos.transpose(1, 2) if key_pos is not None else None
+    else:
+        qpos0_t = _transposed(query_pos) if query_pos is not None else None
+        key_xyz_t = _transposed(key_pos) if key_pos is not None else None
     outs = DecoderStackFn.apply(query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta,
                                 _stack_sink(ent, specs, params, query.device), *params)
     CALLS[0] += 1

@@ -156,6 +156,8 @@ _SIGNATURES = {
     "btr_gemm_trace_end": (_ci, [_vp, _vp]),
     "btr_gemm_trace_work": (_ci, [_vp, _vp, _vp]),
     "btr_gf_stack_sizeof": (ctypes.c_longlong, [_ci]),
+    "btr_graph_stats": (None, [_vp] * 3),
+    "btr_graph_clear": (None, []),
     "btr_gf_stack_plan": (_ci, [_vp, _vp]),
     "btr_gf_stack_forward": (_ci, [_vp] * 21),
     "btr_gf_stack_backward": (_ci, [_vp] * 12),
@@ -532,6 +534,15 @@ def furthest_point_sampling(points, nsamples):
     if nsamples <= 0 or B == 0:
         return out
     return _fps(points, nsamples, 0, out)
+
+
+def graph_stats():
+    """{replays, captures, eager}: calls of the graph-capable entry points (the GroupFree3D decoder
+    stack) replayed from a captured HIP graph / captured / issued launch by launch since load."""
+    v = (ctypes.c_longlong * 3)()
+    base = ctypes.addressof(v)
+    _lib.btr_graph_stats(base, base + 8, base + 16)
+    return {"replays": int(v[0]), "captures": int(v[1]), "eager": int(v[2])}
 
 
 # Bumped by every library call that writes BatchNorm running statistics or parameters through raw

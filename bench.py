@@ -417,6 +417,7 @@ def main():
     if _fs.CALLS[0] or _fs.REFUSED:      # GroupFree3D decoder loops: one-node form / module loop
         chain_paths["decoder_stack"] = _fs.CALLS[0]
         chain_paths["decoder_stack_refused"] = dict(_fs.REFUSED)
+        chain_paths["decoder_stack_graphs"] = _ext.graph_stats()   # since load (incl. warm-up)
     barrier()
     elapsed = time.perf_counter() - t0
     gpu_elapsed_ms = ev0.elapsed_time(ev1)

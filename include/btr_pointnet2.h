@@ -1010,6 +1010,20 @@ int btr_gf_stack_backward(const btr_gf_stack_t *d, const btr_gf_stack_plan_t *pl
                           const float *const *dhead, const float *dlast_bcp, void *saved,
                           float *grads, float *dquery_bcp, float *dkey_bcp, void *scratch,
                           btr_stream_t stream);
+/* Replayed HIP graphs (csrc/graph_cache.hip).  btr_gf_stack_forward / _backward issue 280 / 420
+ * launches of 5 - 20 us; a call whose descriptor, arguments and pointer-array contents are ALL
+ * the same bytes as an earlier call's is captured into a HIP graph the second time it is seen and
+ * replayed from then on (host: ~15 us per call instead of ~3 us per launch; idle time between
+ * two dependent kernels ~1.1 us instead of 2.5 - 3.5).  A caller gets replays by keeping its
+ * buffers and seeds (the dropout step counter lives in device memory, so a replay still draws
+ * new masks); nothing else changes -- same launches, same results.  Calls inside somebody
+ * else's stream capture, with the GEMM trace on, or with BTR_GRAPHS=0 are issued launch by launch.
+ * A captured graph holds the raw pointers of its call: btr_graph_clear() before freeing buffers
+ * that may be reused at the same address with different contents is NOT needed (the key is the
+ * pointers, not the contents), but it releases the graphs' memory.
+ * btr_graph_stats: calls replayed / captured / issued launch by launch since load. */
+void btr_graph_stats(long long *replays, long long *captures, long long *eager);
+void btr_graph_clear(void);
 
 /* ---- Adam / AdamW over many tensors in one launch (csrc/optimizer.hip) -----------------------
  * reference: optimizer.step() of train_Votenet_FSB.py:231 (Adam) and train_GF_FSB.py:319 (AdamW,
