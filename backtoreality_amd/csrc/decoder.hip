@@ -644,6 +644,58 @@ int btr_decoder_layer_forward(const btr_decoder_layer_t *dp, const btr_decoder_p
                               const float *x_cl, const float *key_cl, const float *qpos_cl,
                               const float *kpos_cl, float *out_bcp, float *out_cl, void *saved,
                               void *scratch, btr_stream_t stream) {
+  return decoder_layer_forward_ex(dp, pp, x_cl, key_cl, qpos_cl, kpos_cl, out_bcp, out_cl, saved,
+                                  scratch, 0, stream);
+}
+
+int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp,
+                               const float *x_cl, const float *key_cl, const float *qpos_cl,
+                               const float *kpos_cl, const float *dout_bcp, void *saved,
+                               float *grads, float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
+                               void *scratch, btr_stream_t stream) {
+  return decoder_layer_backward_rows(dp, pp, x_cl, key_cl, qpos_cl, kpos_cl, dout_bcp, nullptr,
+                                     nullptr, nullptr, saved, grads, dx_bcp, dkey_bcp, dqpos_bcp,
+                                     nullptr, scratch, stream);
+}
+
+}  // extern "C"
+
+namespace btr {
+// (internal.hpp) the key / value rows of the cross-attention on their own: kp = key + kpos,
+// kv = kp Wkv^T + bkv (saved: kp, kv) -- they depend on nothing the layer computes, so a caller
+// may issue them ahead on another stream.  Only where the layer itself would use the plain NT
+// GEMM for them (decoder_kv_separable): the small-M kernel reads weight planes that the layer's
+// first launch prepares in its scratch, and the two kernels add in a different order.
+bool decoder_kv_separable(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp) {
+  return !(decoder_sm(*dp) && sm_shape(pp->rk, 2 * dp->e));
+}
+int decoder_layer_kv(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp,
+                     const float *key_cl, const float *kpos_cl, void *saved,
+                     btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && key_cl && saved, "decoder_layer_kv: null pointer");
+  const btr_decoder_layer_t &d = *dp;
+  const btr_decoder_plan_t &p = *pp;
+  BTR_REQUIRE(decoder_kv_separable(dp, pp), "decoder_layer_kv: not separable at these sizes");
+  hipStream_t hs = as_stream(stream);
+  const int rk = p.rk, e = d.e;
+  float *kp = at_f(saved, p.kp), *kv = at_f(saved, p.kv);
+  const float *ksrc = key_cl;
+  if (kpos_cl) {
+    BTR_TRY(add2(hs, (long long)rk * e, key_cl, kpos_cl, kp));
+    ksrc = kp;
+  }
+  BTR_TRY(btr_pm_gemm_nt(rk, 2 * e, e, ksrc, e, d.ca_in_w + (size_t)e * e, e, kv, 2 * e, nullptr,
+                         nullptr, nullptr, d.ca_in_b + e, stream));
+  return check_launch("decoder_layer_kv");
+}
+
+// (internal.hpp) btr_decoder_layer_forward; kv_ready != 0: the cross-attention's key / value rows
+// (saved: kp, kv) are there already -- decoder_layer_kv ran, on whatever stream, and the caller
+// ordered it before this call
+int decoder_layer_forward_ex(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp,
+                             const float *x_cl, const float *key_cl, const float *qpos_cl,
+                             const float *kpos_cl, float *out_bcp, float *out_cl, void *saved,
+                             void *scratch, int kv_ready, btr_stream_t stream) {
   BTR_REQUIRE(dp && pp && x_cl && key_cl && out_cl && saved && scratch,
               "decoder_layer_forward: null pointer");
   const btr_decoder_layer_t &d = *dp;
@@ -710,12 +762,14 @@ int btr_decoder_layer_forward(const btr_decoder_layer_t *dp, const btr_decoder_p
   // ---- cross-attention
   const float *q2src = qpos_cl ? qp1 : x1;
   BTR_TRY(proj(rq, e, q2src, d.ca_in_w, fp.ca_in, 0, 3 * e, q2, d.ca_in_b));
-  const float *ksrc = key_cl;
-  if (kpos_cl) {
-    BTR_TRY(add2(hs, (long long)rk * e, key_cl, kpos_cl, kp));
-    ksrc = kp;
+  if (!kv_ready) {
+    const float *ksrc = key_cl;
+    if (kpos_cl) {
+      BTR_TRY(add2(hs, (long long)rk * e, key_cl, kpos_cl, kp));
+      ksrc = kp;
+    }
+    BTR_TRY(proj(rk, 2 * e, ksrc, d.ca_in_w, fp.ca_in, e, 3 * e, kv, d.ca_in_b + e));
   }
-  BTR_TRY(proj(rk, 2 * e, ksrc, d.ca_in_w, fp.ca_in, e, 3 * e, kv, d.ca_in_b + e));
   BTR_TRY(attention_fwd_strided(d.pq, d.pk, d.b, d.heads, hd, q2, e, (long long)d.pq * e, kv,
                                 kv + e, 2 * e, (long long)d.pk * 2 * e, a2, e,
                                 (long long)d.pq * e, at_f(saved, p.lse2), scale, d.dropout,
@@ -746,19 +800,6 @@ int btr_decoder_layer_forward(const btr_decoder_layer_t *dp, const btr_decoder_p
   return check_launch("decoder_layer_forward");
 }
 
-int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp,
-                               const float *x_cl, const float *key_cl, const float *qpos_cl,
-                               const float *kpos_cl, const float *dout_bcp, void *saved,
-                               float *grads, float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
-                               void *scratch, btr_stream_t stream) {
-  return decoder_layer_backward_rows(dp, pp, x_cl, key_cl, qpos_cl, kpos_cl, dout_bcp, nullptr,
-                                     nullptr, nullptr, saved, grads, dx_bcp, dkey_bcp, dqpos_bcp,
-                                     nullptr, scratch, stream);
-}
-
-}  // extern "C"
-
-namespace btr {
 // (internal.hpp) btr_decoder_layer_backward with the gradients handed over as channel-last rows:
 // the output gradient is dout_bcp (transposed here) or the row operands (g0 + g1) + g2 (g1, g2
 // optional); `out` (optional) names caller-owned row buffers for d res1 / d qp0 / d qp1 / d kp --
@@ -771,8 +812,34 @@ int decoder_layer_backward_rows(const btr_decoder_layer_t *dp, const btr_decoder
                                 const float *g1, const float *g2, void *saved, float *grads,
                                 float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
                                 const DecoderRowsOut *out, void *scratch, btr_stream_t stream) {
-  BTR_REQUIRE(dp && pp && x_cl && key_cl && (dout_bcp || g0) && saved && grads && scratch,
+  return decoder_layer_backward_parts(dp, pp, x_cl, key_cl, qpos_cl, kpos_cl, dout_bcp, g0, g1, g2,
+                                      saved, grads, dx_bcp, dkey_bcp, dqpos_bcp, out, scratch,
+                                      kDecoderBwdChain | kDecoderBwdRest | kDecoderBwdKey, stream);
+}
+
+// The layer's backward in two parts that may run on two streams (csrc/gf_stack.hip):
+//   kDecoderBwdChain: what the gradient of the layer's INPUT waits for -- the LayerNorm backwards,
+//       the input-gradient GEMMs, the attention backwards (writes every dY of the seven linear
+//       maps into the scratch on its way);
+//   kDecoderBwdRest: what only the parameters wait for -- the seven weight gradients with their
+//       reduction, the bias and LayerNorm parameter gradients;
+//   kDecoderBwdKey: the key / value rows' input gradient (d kp: only the keys and their position
+//       embedding wait for it).
+// Rest and Key read the dY the chain left in the SAME scratch: issue them after the chain (same
+// stream, or others ordered behind it) and keep the scratch until they are through.
+// All three = the one-call backward: the same launches with the same operands, the later parts'
+// after the chain's (they were interleaved; no result depends on that).
+int decoder_layer_backward_parts(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp,
+                                 const float *x_cl, const float *key_cl, const float *qpos_cl,
+                                 const float *kpos_cl, const float *dout_bcp, const float *g0,
+                                 const float *g1, const float *g2, void *saved, float *grads,
+                                 float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
+                                 const DecoderRowsOut *out, void *scratch, int parts,
+                                 btr_stream_t stream) {
+  BTR_REQUIRE(dp && pp && x_cl && key_cl && saved && grads && scratch,
               "decoder_layer_backward: null pointer");
+  BTR_REQUIRE(!(parts & kDecoderBwdChain) || dout_bcp || g0,
+              "decoder_layer_backward: no output gradient");
   const btr_decoder_layer_t &d = *dp;
   const btr_decoder_plan_t &p = *pp;
   hipStream_t hs = as_stream(stream);
@@ -787,37 +854,7 @@ int decoder_layer_backward_rows(const btr_decoder_layer_t *dp, const btr_decoder
   const float *a2 = at_f(saved, p.a2), *x2 = at_f(saved, p.x2), *h = at_f(saved, p.h);
   Lin lin[7];
   linears(d, lin);
-
   const bool sm = decoder_sm(d);
-  {  // transposed weights: the input-gradient GEMMs are NT GEMMs on W^T
-    TransposeArgs t{};
-    const float *src[kMaxTr] = {d.sa_in_w, d.sa_out_w, d.ca_in_w, d.ca_out_w, d.lin1_w, d.lin2_w};
-    float *dst[kMaxTr] = {S(sc.t_sa_in), S(sc.t_sa_out), S(sc.t_ca_in),
-                          S(sc.t_ca_out), S(sc.t_l1), S(sc.t_l2)};
-    const int rr[kMaxTr] = {3 * e, e, 3 * e, e, f, e}, cc[kMaxTr] = {e, e, e, e, e, f};
-    const size_t pl[kMaxTr] = {sc.p_sa_in, sc.p_sa_out, sc.p_ca_in, sc.p_ca_out, 0, sc.p_l2};
-    int blocks = 0;
-    for (int i = 0; i < kMaxTr; ++i) {
-      t.src[i] = src[i]; t.dst[i] = dst[i]; t.rows[i] = rr[i]; t.cols[i] = cc[i];
-      t.tr[i] = 1;
-      t.planes[i] = (sm && i != 4) ? (__bf16 *)((char *)scratch + pl[i]) : nullptr;
-      t.first[i] = blocks;
-      blocks += cdiv(rr[i], 32) * cdiv(cc[i], 32);
-    }
-    t.first[kMaxTr] = blocks;
-    t.count = kMaxTr;
-    hipLaunchKernelGGL(transpose_multi_kernel, dim3(blocks), dim3(256), 0, hs, t);
-  }
-  reduce_batch_begin();
-  struct Flush {
-    hipStream_t s;
-    bool open = true;
-    ~Flush() { if (open) reduce_batch_flush(s); }
-  } flush{hs};
-  auto wgrad = [&](int i, const float *g, const float *x, float *dw) {
-    return btr_sa_gemm_tn(lin[i].rows, lin[i].n, lin[i].k, g, lin[i].n, x, lin[i].k, nullptr,
-                          nullptr, S(sc.pw[i]), dw, stream);
-  };
   // dX (rows, k) = dY (rows, n) . W (n, k), as an NT GEMM on wt = W^T (k, n) (leading dim ldw)
   // (planes of wt: `poff` = start of the transposed weight's planes, col0 = first column of the
   // block, nall = its rows: the pitch is ceil16(ldw), the plane stride nall * pitch)
@@ -830,114 +867,151 @@ int decoder_layer_backward_rows(const btr_decoder_layer_t *dp, const btr_decoder
     return btr_pm_gemm_nt(rows, k, n, g, n, wt, ldw, dx, k, nullptr, nullptr, nullptr, nullptr,
                           stream);
   };
-
   // the four row tensors the module's input gradients are made of: the layer's scratch, or the
   // caller's buffers
   float *r_dres1 = out && out->dres1 ? out->dres1 : S(sc.dres1);
   float *r_dqp0 = out && out->dqp0 ? out->dqp0 : S(sc.dqp0);
   float *r_dqp1 = out && out->dqp1 ? out->dqp1 : S(sc.dqp1);
   float *r_dkp = out && out->dkp ? out->dkp : S(sc.dkp);
-  // ---- LayerNorm 3, feed-forward
-  if (dout_bcp) {
-    BTR_TRY(btr_pm_rows(d.b, d.pq, e, e, dout_bcp, S(sc.dx3), stream));
-    g0 = S(sc.dx3);
-    g1 = g2 = nullptr;
-  }
-  {
-    LnBwd a{rq, e, g0, g1, g2, g1 ? 1 : 0, 0, at_f(saved, p.xh3), at_f(saved, p.rs3),
-            d.ln_w[2], make_drop(d, 3), S(sc.dres3), S(sc.df), S(sc.lnp[2])};
-    BTR_TRY(ln_backward(hs, a));
-  }
-  BTR_TRY(wgrad(6, S(sc.df), h, grads + p.g_lin2_w));
-  BTR_TRY(dgrad(rq, e, f, S(sc.df), S(sc.t_l2), e, S(sc.dh), sc.p_l2, 0, f));
-  hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(cdiv((long long)rq * f / 4, 256)), dim3(256), 0,
-                     hs, (long long)rq * f / 4, (float4 *)S(sc.dh), (const float4 *)h,
-                     make_drop(d, 2).keep_inv);
-  BTR_TRY(wgrad(5, S(sc.dh), x2, grads + p.g_lin1_w));
-  const int sk = pm_splitk_slices(rq, e, f);   // dX2 = dH W1: 288 columns, reduction over ff
-  if (sk > 1)
-    BTR_TRY(pm_gemm_nt_splitk(rq, e, f, S(sc.dh), f, S(sc.t_l1), f, S(sc.dx2f),
-                              (long long)rq * e, sk, hs));
-  else
-    BTR_TRY(btr_pm_gemm_nt(rq, e, f, S(sc.dh), f, S(sc.t_l1), f, S(sc.dx2f), e, nullptr, nullptr,
-                           nullptr, nullptr, stream));
-  // ---- LayerNorm 2, cross-attention
-  {
-    LnBwd a{rq, e, S(sc.dres3), S(sc.dx2f), nullptr, sk, (long long)rq * e, at_f(saved, p.xh2), at_f(saved, p.rs2),
-            d.ln_w[1], make_drop(d, 1), S(sc.dres2), S(sc.do2), S(sc.lnp[1])};
-    BTR_TRY(ln_backward(hs, a));
-  }
-  BTR_TRY(wgrad(4, S(sc.do2), a2, grads + p.g_ca_out_w));
-  BTR_TRY(dgrad(rq, e, e, S(sc.do2), S(sc.t_ca_out), e, S(sc.da2), sc.p_ca_out, 0, e));
-  BTR_TRY(attention_bwd_strided(
-      d.pq, d.pk, d.b, d.heads, hd, q2, e, (long long)d.pq * e, kv, kv + e, 2 * e,
-      (long long)d.pk * 2 * e, a2, S(sc.da2), e, (long long)d.pq * e, at_f(saved, p.lse2),
-      S(sc.dsum), S(sc.dq2), e, (long long)d.pq * e, S(sc.dkv), S(sc.dkv) + e, 2 * e,
-      (long long)d.pk * 2 * e, scale, d.dropout, attn_seed(d, 1), d.step, stream));
-  BTR_TRY(wgrad(2, S(sc.dq2), qp1, grads + p.g_ca_in_w));
-  BTR_TRY(wgrad(3, S(sc.dkv), kp, grads + p.g_ca_in_w + (size_t)e * e));
-  BTR_TRY(dgrad(rq, e, e, S(sc.dq2), S(sc.t_ca_in), 3 * e, r_dqp1, sc.p_ca_in, 0, e));
-  if (dkey_bcp || (out && out->dkp))
-    BTR_TRY(dgrad(rk, 2 * e, e, S(sc.dkv), S(sc.t_ca_in) + e, 3 * e, r_dkp, sc.p_ca_in, e, e));
-  // ---- LayerNorm 1, self-attention
-  {
-    LnBwd a{rq, e, S(sc.dres2), r_dqp1, nullptr, 1, 0, at_f(saved, p.xh1), at_f(saved, p.rs1),
-            d.ln_w[0], make_drop(d, 0), r_dres1, S(sc.do1), S(sc.lnp[0])};
-    BTR_TRY(ln_backward(hs, a));
-  }
-  BTR_TRY(wgrad(1, S(sc.do1), a1, grads + p.g_sa_out_w));
-  BTR_TRY(dgrad(rq, e, e, S(sc.do1), S(sc.t_sa_out), e, S(sc.da1), sc.p_sa_out, 0, e));
-  BTR_TRY(attention_bwd_strided(
-      d.pq, d.pq, d.b, d.heads, hd, qkv, 3 * e, (long long)d.pq * 3 * e, qkv + e, qkv + 2 * e,
-      3 * e, (long long)d.pq * 3 * e, a1, S(sc.da1), e, (long long)d.pq * e, at_f(saved, p.lse1),
-      S(sc.dsum), S(sc.dqkv), 3 * e, (long long)d.pq * 3 * e, S(sc.dqkv) + e,
-      S(sc.dqkv) + 2 * e, 3 * e, (long long)d.pq * 3 * e, scale, d.dropout, attn_seed(d, 0),
-      d.step, stream));
-  BTR_TRY(wgrad(0, S(sc.dqkv), qp0, grads + p.g_sa_in_w));
-  BTR_TRY(dgrad(rq, 3 * e, e, S(sc.dqkv), S(sc.t_sa_in), 3 * e, r_dqp0, sc.p_sa_in, 0, e));
-  reduce_batch_flush(hs);
-  flush.open = false;
 
-  {  // bias gradients (column sums of the 7 dY) and the LayerNorm parameter gradients
-    ColsumArgs c{};
-    const float *g[7] = {S(sc.dqkv), S(sc.do1), S(sc.dq2), S(sc.dkv), S(sc.do2), S(sc.dh),
-                         S(sc.df)};
-    int blocks = 0;
-    for (int i = 0; i < 7; ++i) {
-      c.g[i] = g[i]; c.part[i] = S(sc.cs[i]); c.rows[i] = lin[i].rows; c.c[i] = lin[i].n;
-      c.ld[i] = lin[i].n;
-      c.first[i] = blocks;
-      blocks += cdiv(lin[i].n, 64) * cdiv(lin[i].rows, kCsRows);
+  if (parts & kDecoderBwdChain) {
+    {  // transposed weights: the input-gradient GEMMs are NT GEMMs on W^T
+      TransposeArgs t{};
+      const float *src[kMaxTr] = {d.sa_in_w, d.sa_out_w, d.ca_in_w, d.ca_out_w, d.lin1_w, d.lin2_w};
+      float *dst[kMaxTr] = {S(sc.t_sa_in), S(sc.t_sa_out), S(sc.t_ca_in),
+                            S(sc.t_ca_out), S(sc.t_l1), S(sc.t_l2)};
+      const int rr[kMaxTr] = {3 * e, e, 3 * e, e, f, e}, cc[kMaxTr] = {e, e, e, e, e, f};
+      const size_t pl[kMaxTr] = {sc.p_sa_in, sc.p_sa_out, sc.p_ca_in, sc.p_ca_out, 0, sc.p_l2};
+      int blocks = 0;
+      for (int i = 0; i < kMaxTr; ++i) {
+        t.src[i] = src[i]; t.dst[i] = dst[i]; t.rows[i] = rr[i]; t.cols[i] = cc[i];
+        t.tr[i] = 1;
+        t.planes[i] = (sm && i != 4) ? (__bf16 *)((char *)scratch + pl[i]) : nullptr;
+        t.first[i] = blocks;
+        blocks += cdiv(rr[i], 32) * cdiv(cc[i], 32);
+      }
+      t.first[kMaxTr] = blocks;
+      t.count = kMaxTr;
+      hipLaunchKernelGGL(transpose_multi_kernel, dim3(blocks), dim3(256), 0, hs, t);
     }
-    c.first[7] = blocks;
-    c.count = 7;
-    hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(256), 0, hs, c);
-    FinalArgs fa{};
-    float *out[7] = {grads + p.g_sa_in_b, grads + p.g_sa_out_b, grads + p.g_ca_in_b,
-                     grads + p.g_ca_in_b + e, grads + p.g_ca_out_b, grads + p.g_lin1_b,
-                     grads + p.g_lin2_b};
-    blocks = 0;
-    for (int i = 0; i < 7; ++i) {
-      fa.part[i] = S(sc.cs[i]); fa.out[i] = out[i]; fa.chunks[i] = cdiv(lin[i].rows, kCsRows);
-      fa.c[i] = lin[i].n;
-      fa.first[i] = blocks;
-      blocks += cdiv(lin[i].n, 64);
+    // ---- LayerNorm 3, feed-forward
+    if (dout_bcp) {
+      BTR_TRY(btr_pm_rows(d.b, d.pq, e, e, dout_bcp, S(sc.dx3), stream));
+      g0 = S(sc.dx3);
+      g1 = g2 = nullptr;
     }
-    for (int i = 0; i < 3; ++i) {
-      fa.part[7 + i] = S(sc.lnp[i]); fa.out[7 + i] = grads + p.g_ln[i];
-      fa.chunks[7 + i] = ln_blocks(rq); fa.c[7 + i] = 2 * e;
-      fa.first[7 + i] = blocks;
-      blocks += cdiv(2 * e, 64);
+    {
+      LnBwd a{rq, e, g0, g1, g2, g1 ? 1 : 0, 0, at_f(saved, p.xh3), at_f(saved, p.rs3),
+              d.ln_w[2], make_drop(d, 3), S(sc.dres3), S(sc.df), S(sc.lnp[2])};
+      BTR_TRY(ln_backward(hs, a));
     }
-    fa.first[10] = blocks;
-    fa.count = 10;
-    hipLaunchKernelGGL(colsum_final_multi_kernel, dim3(blocks), dim3(256), 0, hs, fa);
+    BTR_TRY(dgrad(rq, e, f, S(sc.df), S(sc.t_l2), e, S(sc.dh), sc.p_l2, 0, f));
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(cdiv((long long)rq * f / 4, 256)), dim3(256), 0,
+                       hs, (long long)rq * f / 4, (float4 *)S(sc.dh), (const float4 *)h,
+                       make_drop(d, 2).keep_inv);
+    const int sk = pm_splitk_slices(rq, e, f);   // dX2 = dH W1: 288 columns, reduction over ff
+    if (sk > 1)
+      BTR_TRY(pm_gemm_nt_splitk(rq, e, f, S(sc.dh), f, S(sc.t_l1), f, S(sc.dx2f),
+                                (long long)rq * e, sk, hs));
+    else
+      BTR_TRY(btr_pm_gemm_nt(rq, e, f, S(sc.dh), f, S(sc.t_l1), f, S(sc.dx2f), e, nullptr, nullptr,
+                             nullptr, nullptr, stream));
+    // ---- LayerNorm 2, cross-attention
+    {
+      LnBwd a{rq, e, S(sc.dres3), S(sc.dx2f), nullptr, sk, (long long)rq * e, at_f(saved, p.xh2), at_f(saved, p.rs2),
+              d.ln_w[1], make_drop(d, 1), S(sc.dres2), S(sc.do2), S(sc.lnp[1])};
+      BTR_TRY(ln_backward(hs, a));
+    }
+    BTR_TRY(dgrad(rq, e, e, S(sc.do2), S(sc.t_ca_out), e, S(sc.da2), sc.p_ca_out, 0, e));
+    BTR_TRY(attention_bwd_strided(
+        d.pq, d.pk, d.b, d.heads, hd, q2, e, (long long)d.pq * e, kv, kv + e, 2 * e,
+        (long long)d.pk * 2 * e, a2, S(sc.da2), e, (long long)d.pq * e, at_f(saved, p.lse2),
+        S(sc.dsum), S(sc.dq2), e, (long long)d.pq * e, S(sc.dkv), S(sc.dkv) + e, 2 * e,
+        (long long)d.pk * 2 * e, scale, d.dropout, attn_seed(d, 1), d.step, stream));
+    BTR_TRY(dgrad(rq, e, e, S(sc.dq2), S(sc.t_ca_in), 3 * e, r_dqp1, sc.p_ca_in, 0, e));
+    // ---- LayerNorm 1, self-attention
+    {
+      LnBwd a{rq, e, S(sc.dres2), r_dqp1, nullptr, 1, 0, at_f(saved, p.xh1), at_f(saved, p.rs1),
+              d.ln_w[0], make_drop(d, 0), r_dres1, S(sc.do1), S(sc.lnp[0])};
+      BTR_TRY(ln_backward(hs, a));
+    }
+    BTR_TRY(dgrad(rq, e, e, S(sc.do1), S(sc.t_sa_out), e, S(sc.da1), sc.p_sa_out, 0, e));
+    BTR_TRY(attention_bwd_strided(
+        d.pq, d.pq, d.b, d.heads, hd, qkv, 3 * e, (long long)d.pq * 3 * e, qkv + e, qkv + 2 * e,
+        3 * e, (long long)d.pq * 3 * e, a1, S(sc.da1), e, (long long)d.pq * e, at_f(saved, p.lse1),
+        S(sc.dsum), S(sc.dqkv), 3 * e, (long long)d.pq * 3 * e, S(sc.dqkv) + e,
+        S(sc.dqkv) + 2 * e, 3 * e, (long long)d.pq * 3 * e, scale, d.dropout, attn_seed(d, 0),
+        d.step, stream));
+    BTR_TRY(dgrad(rq, 3 * e, e, S(sc.dqkv), S(sc.t_sa_in), 3 * e, r_dqp0, sc.p_sa_in, 0, e));
+    // ---- gradients of the module inputs, (B, E, P)
+    if (dx_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pq, e, r_dres1, r_dqp0, nullptr, dx_bcp));
+    if (dqpos_bcp && qpos_cl)
+      BTR_TRY(rows_to_bcp(hs, d.b, d.pq, e, r_dqp0, r_dqp1, nullptr, dqpos_bcp));
   }
-  // ---- gradients of the module inputs, (B, E, P)
-  if (dx_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pq, e, r_dres1, r_dqp0, nullptr, dx_bcp));
-  if (dqpos_bcp && qpos_cl)
-    BTR_TRY(rows_to_bcp(hs, d.b, d.pq, e, r_dqp0, r_dqp1, nullptr, dqpos_bcp));
-  if (dkey_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pk, e, r_dkp, nullptr, nullptr, dkey_bcp));
+
+  if (parts & kDecoderBwdRest) {
+    {
+      reduce_batch_begin();
+      struct Flush {
+        hipStream_t s;
+        bool open = true;
+        ~Flush() { if (open) reduce_batch_flush(s); }
+      } flush{hs};
+      auto wgrad = [&](int i, const float *g, const float *x, float *dw) {
+        return btr_sa_gemm_tn(lin[i].rows, lin[i].n, lin[i].k, g, lin[i].n, x, lin[i].k, nullptr,
+                              nullptr, S(sc.pw[i]), dw, stream);
+      };
+      BTR_TRY(wgrad(6, S(sc.df), h, grads + p.g_lin2_w));
+      BTR_TRY(wgrad(5, S(sc.dh), x2, grads + p.g_lin1_w));
+      BTR_TRY(wgrad(4, S(sc.do2), a2, grads + p.g_ca_out_w));
+      BTR_TRY(wgrad(2, S(sc.dq2), qp1, grads + p.g_ca_in_w));
+      BTR_TRY(wgrad(3, S(sc.dkv), kp, grads + p.g_ca_in_w + (size_t)e * e));
+      BTR_TRY(wgrad(1, S(sc.do1), a1, grads + p.g_sa_out_w));
+      BTR_TRY(wgrad(0, S(sc.dqkv), qp0, grads + p.g_sa_in_w));
+      reduce_batch_flush(hs);
+      flush.open = false;
+    }
+    {  // bias gradients (column sums of the 7 dY) and the LayerNorm parameter gradients
+      ColsumArgs c{};
+      const float *g[7] = {S(sc.dqkv), S(sc.do1), S(sc.dq2), S(sc.dkv), S(sc.do2), S(sc.dh),
+                           S(sc.df)};
+      int blocks = 0;
+      for (int i = 0; i < 7; ++i) {
+        c.g[i] = g[i]; c.part[i] = S(sc.cs[i]); c.rows[i] = lin[i].rows; c.c[i] = lin[i].n;
+        c.ld[i] = lin[i].n;
+        c.first[i] = blocks;
+        blocks += cdiv(lin[i].n, 64) * cdiv(lin[i].rows, kCsRows);
+      }
+      c.first[7] = blocks;
+      c.count = 7;
+      hipLaunchKernelGGL(colsum_multi_kernel, dim3(blocks), dim3(256), 0, hs, c);
+      FinalArgs fa{};
+      float *outp[7] = {grads + p.g_sa_in_b, grads + p.g_sa_out_b, grads + p.g_ca_in_b,
+                        grads + p.g_ca_in_b + e, grads + p.g_ca_out_b, grads + p.g_lin1_b,
+                        grads + p.g_lin2_b};
+      blocks = 0;
+      for (int i = 0; i < 7; ++i) {
+        fa.part[i] = S(sc.cs[i]); fa.out[i] = outp[i]; fa.chunks[i] = cdiv(lin[i].rows, kCsRows);
+        fa.c[i] = lin[i].n;
+        fa.first[i] = blocks;
+        blocks += cdiv(lin[i].n, 64);
+      }
+      for (int i = 0; i < 3; ++i) {
+        fa.part[7 + i] = S(sc.lnp[i]); fa.out[7 + i] = grads + p.g_ln[i];
+        fa.chunks[7 + i] = ln_blocks(rq); fa.c[7 + i] = 2 * e;
+        fa.first[7 + i] = blocks;
+        blocks += cdiv(2 * e, 64);
+      }
+      fa.first[10] = blocks;
+      fa.count = 10;
+      hipLaunchKernelGGL(colsum_final_multi_kernel, dim3(blocks), dim3(256), 0, hs, fa);
+    }
+  }
+  if (parts & kDecoderBwdKey) {
+    if (dkey_bcp || (out && out->dkp))
+      BTR_TRY(dgrad(rk, 2 * e, e, S(sc.dkv), S(sc.t_ca_in) + e, 3 * e, r_dkp, sc.p_ca_in, e, e));
+    if (dkey_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pk, e, r_dkp, nullptr, nullptr, dkey_bcp));
+  }
   return check_launch("decoder_layer_backward");
 }
 

@@ -194,6 +194,33 @@ int graph_run(uint64_t key, hipStream_t stream, const std::function<int(hipStrea
   return BTR_OK;
 }
 
+// A side stream of a caller's stream, with events for the hand-overs, owned by the library and
+// kept for the process's lifetime (one per device and caller stream).
+SideLane *side_lane(hipStream_t main) {
+  static std::mutex mu;
+  static std::unordered_map<uint64_t, SideLane *> lanes;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const uint64_t k = ((uint64_t)(uintptr_t)main << 6) ^ (uint64_t)dev;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = lanes.find(k);
+  if (it != lanes.end()) return it->second;
+  SideLane *l = new SideLane();
+  // (stream priorities measured no different: lowest 3.52 ms, default 3.47, highest 3.51 for the
+  // decoder stack's backward, profiles/r06_gf_lanes.txt)
+  bool ok = hipStreamCreateWithFlags(&l->s[0], hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&l->s[1], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < SideLane::kEvents; ++i)
+    ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    delete l;
+    l = nullptr;
+  }
+  lanes.emplace(k, l);
+  return l;
+}
+
 }  // namespace btr
 
 extern "C" {

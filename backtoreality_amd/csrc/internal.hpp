@@ -28,6 +28,12 @@ int fps_lds_kb(int np);
 int graph_run(uint64_t key, hipStream_t stream, const std::function<int(hipStream_t)> &body,
               int *how);
 uint64_t hash_bytes(uint64_t h, const void *p, size_t n);
+struct SideLane {
+  static constexpr int kEvents = 4 * BTR_GF_MAX_DECODER_LAYERS + 2;
+  hipStream_t s[2] = {};   // two side streams
+  hipEvent_t ev[kEvents] = {};
+};
+SideLane *side_lane(hipStream_t main);   // the library's side streams of `main` (NULL: none)
 bool graph_capturing();     // this host thread is inside graph_run's capture
 bool graphs_enabled();
 // sa_mlp.hip: btr_gemm_trace_begin() is in effect (its event pairs do not belong in a graph)
@@ -104,6 +110,23 @@ int decoder_layer_backward_rows(const btr_decoder_layer_t *d, const btr_decoder_
                                 const float *g1, const float *g2, void *saved, float *grads,
                                 float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
                                 const DecoderRowsOut *out, void *scratch, btr_stream_t stream);
+// decoder.hip: the same in two parts for two streams (see the definition), and the forward with
+// the cross-attention's key / value rows computed by a separate call
+enum { kDecoderBwdChain = 1, kDecoderBwdRest = 2, kDecoderBwdKey = 4 };
+int decoder_layer_backward_parts(const btr_decoder_layer_t *d, const btr_decoder_plan_t *p,
+                                 const float *x_cl, const float *key_cl, const float *qpos_cl,
+                                 const float *kpos_cl, const float *dout_bcp, const float *g0,
+                                 const float *g1, const float *g2, void *saved, float *grads,
+                                 float *dx_bcp, float *dkey_bcp, float *dqpos_bcp,
+                                 const DecoderRowsOut *out, void *scratch, int parts,
+                                 btr_stream_t stream);
+bool decoder_kv_separable(const btr_decoder_layer_t *d, const btr_decoder_plan_t *p);
+int decoder_layer_kv(const btr_decoder_layer_t *d, const btr_decoder_plan_t *p,
+                     const float *key_cl, const float *kpos_cl, void *saved, btr_stream_t stream);
+int decoder_layer_forward_ex(const btr_decoder_layer_t *d, const btr_decoder_plan_t *p,
+                             const float *x_cl, const float *key_cl, const float *qpos_cl,
+                             const float *kpos_cl, float *out_bcp, float *out_cl, void *saved,
+                             void *scratch, int kv_ready, btr_stream_t stream);
 // sa_layer.hip: btr_pm_chain_backward with the output gradient as channel-last rows a0 (+ a1)
 // instead of dout (b, c, n), and / or the input gradient left as rows in dx_rows (leading
 // dimension = the padded input width) instead of dx (b, c, n)

@@ -129,3 +129,60 @@ def test_eval_mode_keeps_the_module_loop(cuda, monkeypatch):
     with torch.no_grad():
         ep = net({'point_clouds': batch['point_clouds']})
     assert fused_stack.CALLS[0] == calls and 'last_center' in ep
+
+
+def _several_steps(cuda, monkeypatch, graphs, n=5, cls=None):
+    """n forward + backward passes of one detector on two alternating batches with new dropout
+    masks every time; the decoder stack's calls are replayed HIP graphs on three lanes from the
+    third pass on (graphs) or single launches on one stream (not graphs).  (No parameter update:
+    the backbone's backward is not bit-reproducible -- float atomics -- and the query points are
+    a top-k of its output, so two runs that update would part ways for reasons outside the
+    stack.)"""
+    monkeypatch.setenv("BTR_FUSED_GF_STACK", "1")
+    monkeypatch.setenv("BTR_GRAPHS", "1" if graphs else "0")
+    monkeypatch.setattr(fused_attention, "_calls", itertools.count())
+    cfg = config.scannet_md40()
+    batches = [synthetic.make_batch(s, 2, 8192, cfg, use_height=False, device=cuda)
+               for s in (3, 4)]
+    torch.manual_seed(0)
+    cls = cls or groupfree.GroupFreeDetector
+    net = cls(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster, cfg.mean_size_arr,
+              input_feature_dim=0, num_proposal=256, dropout=0.1,
+              self_position_embedding='loc_learned',
+              cross_position_embedding='xyz_learned').to(cuda)
+    before, calls = _ext.graph_stats(), fused_stack.CALLS[0]
+    out = []
+    for it in range(n):
+        fused_attention.bump_step(cuda)           # new dropout masks every step
+        batch = batches[it % 2]
+        for p in net.parameters():
+            p.grad = None
+        end_points = net({'point_clouds': batch['point_clouds']})
+        end_points.update(batch)
+        loss, end_points = groupfree.get_loss(end_points, cfg, **LOSS_ARGS)
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()
+                 if p.grad is not None and k.startswith(('decoder.', 'prediction_heads.'))}
+        out.append((float(loss), end_points['last_center'].detach().clone(), grads))
+    after = _ext.graph_stats()
+    assert fused_stack.CALLS[0] - calls == n
+    return out, {k: after[k] - before[k] for k in after}
+
+
+@pytest.mark.gpu
+def test_replayed_graphs_on_three_lanes_equal_the_single_launches(cuda, monkeypatch):
+    """csrc/graph_cache.hip + the lanes of csrc/gf_stack.hip: the same launches with the same
+    operands, so every step's loss, predictions and decoder / head gradients are the single-stream
+    sequence's bit for bit -- including the steps that only replay."""
+    step0 = int(fused_attention.step_counter(cuda).item())
+    a, used = _several_steps(cuda, monkeypatch, True)
+    fused_attention.step_counter(cuda).fill_(step0)      # the same masks for the second run
+    b, unused = _several_steps(cuda, monkeypatch, False)
+    assert used["captures"] >= 20 and used["replays"] >= 2 * used["captures"], used
+    assert unused["captures"] == 0 and unused["replays"] == 0, unused
+    for it, ((la, ca, ga), (lb, cb, gb)) in enumerate(zip(a, b)):
+        assert torch.equal(ca, cb), it
+        assert len(ga) >= 150 and set(ga) == set(gb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), (it, k)
+        assert abs(la - lb) <= 1e-6 * abs(lb), (it, la, lb)   # (the backbone's float atomics)

@@ -97,5 +97,59 @@ int main(int argc, char **argv) {
     CK(hipGraphExecDestroy(ge));
     CK(hipGraphDestroy(g));
   }
+  {  // two LINEAR graphs on two streams, launched back to back: do they overlap?
+    hipGraph_t g[2];
+    hipGraphExec_t ge[2];
+    hipStream_t st[2] = {s, s2};
+    for (int j = 0; j < 2; ++j) {
+      CK(hipStreamBeginCapture(st[j], hipStreamCaptureModeRelaxed));
+      chain(st[j], N / 2);
+      CK(hipStreamEndCapture(st[j], &g[j]));
+      CK(hipGraphInstantiate(&ge[j], g[j], nullptr, nullptr, 0));
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+      const int R = 10;
+      double t0 = now();
+      for (int r = 0; r < R; ++r) {
+        CK(hipEventRecord(ev, s));
+        CK(hipStreamWaitEvent(s2, ev, 0));
+        CK(hipGraphLaunch(ge[1], s2));
+        CK(hipEventRecord(ev2, s2));
+        CK(hipGraphLaunch(ge[0], s));
+        CK(hipStreamWaitEvent(s, ev2, 0));
+      }
+      double t1 = now();
+      CK(hipDeviceSynchronize());
+      double t2 = now();
+      printf("two linear graphs of %d kernels on two streams (fork / join around them): host %.1f us "
+             "per round, to idle %.2f us per kernel\n", N / 2, (t1 - t0) / R, (t2 - t0) / R / N);
+    }
+    // the same with 6 + 6 short graphs per round (the decoder stack's per-layer segments)
+    hipGraph_t h[2];
+    hipGraphExec_t he[2];
+    for (int j = 0; j < 2; ++j) {
+      CK(hipStreamBeginCapture(st[j], hipStreamCaptureModeRelaxed));
+      chain(st[j], N / 12);
+      CK(hipStreamEndCapture(st[j], &h[j]));
+      CK(hipGraphInstantiate(&he[j], h[j], nullptr, nullptr, 0));
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+      const int R = 10;
+      double t0 = now();
+      for (int r = 0; r < R; ++r)
+        for (int seg = 0; seg < 6; ++seg) {
+          CK(hipGraphLaunch(he[0], s));
+          CK(hipEventRecord(ev, s));
+          CK(hipStreamWaitEvent(s2, ev, 0));
+          CK(hipGraphLaunch(he[1], s2));
+          CK(hipEventRecord(ev2, s2));
+        }
+      double t1 = now();
+      CK(hipDeviceSynchronize());
+      double t2 = now();
+      printf("6 x (graph of %d on main, event, graph of %d on side): host %.1f us per round, to idle "
+             "%.2f us per kernel\n", N / 12, N / 12, (t1 - t0) / R, (t2 - t0) / R / (N / 12 * 12));
+    }
+  }
   return 0;
 }
