@@ -45,7 +45,7 @@ Cache &cache() {
   static Cache c;
   return c;
 }
-constexpr size_t kMaxGraphs = 48;
+constexpr size_t kMaxGraphs = 512;   // (a two-branch GroupFree3D step holds 2 x 37 segments)
 
 thread_local int g_capturing = 0;
 

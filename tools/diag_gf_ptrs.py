@@ -18,7 +18,8 @@ from backtoreality_amd.votenet import config, synthetic, train  # noqa: E402
 
 dev = torch.device("cuda:0")
 cfg = config.scannet_md40()
-net = gf_train.build_model(cfg, dev)
+BR = len(sys.argv) > 1 and sys.argv[1] == "br"   # the two-branch step (two calls in flight)
+net = gf_train.build_model(cfg, dev, domain_adaptation=BR)
 opt = gf_train.make_optimizer(net)
 B, N = 4, 50000
 batches = [synthetic.make_batch(s, B, N, cfg, use_height=False, device=dev) for s in (0, 1)]
@@ -46,6 +47,19 @@ fused_stack._call = spy
 
 
 def loop(n):
+    if BR:   # bench.py's software-pipelined two-branch loop
+        batches_T = loop.batches_T
+        sampling = net.backbone_net.prefetch_sampling(batches[0]['point_clouds'])
+        sampling_t = None
+        for i in range(n):
+            last = i + 1 >= n
+            out = gf_train.train_step_br(net, opt, batches[i % 2], batches_T[i % 2], cfg,
+                                         sampling_S=sampling, sampling_T=sampling_t,
+                                         next_batch_S=None if last else batches[(i + 1) % 2],
+                                         next_batch_T=None if last else batches_T[(i + 1) % 2])
+            sampling = out[1].get('next_sampling')
+            sampling_t = out[2].get('next_sampling')
+        return
     sampling = net.backbone_net.prefetch_sampling(batches[0]['point_clouds'])
     for i in range(n):
         out = gf_train.train_step(net, opt, batches[i % 2], cfg, sampling=sampling,
@@ -53,6 +67,8 @@ def loop(n):
         sampling = out[1].get('next_sampling')
 
 
+loop.batches_T = [synthetic.make_batch(100000 + 7000 * i, B, N, cfg, use_height=False, device=dev)
+                  for i in range(2)] if BR else None
 loop(6)
 torch.cuda.synchronize()
 train.freeze_gc()
@@ -60,6 +76,7 @@ for k in seen:
     seen[k].clear()
 loop(16)
 torch.cuda.synchronize()
+print("graphs:", _ext.graph_stats())
 for name, calls in seen.items():
     print("%s: %d calls, %d distinct argument tuples" % (name, len(calls), len(set(calls))))
     if not calls:
