@@ -608,7 +608,9 @@ int btr_sa_layer_plan(const btr_sa_layer_t *dp, btr_sa_plan_t *p) {
                d.width[L - 1] > 64 && epi_allowed && p->pool_grad && !d.need_dxyz &&
                !d.need_dnew_xyz && (!d.need_dfeat || d.n <= 8192) &&
                (long long)d.b * ((d.m + 63) / 64) <= 1024;
-  p->recompute = (d.options & BTR_SA_OPT_RECOMPUTE) && p->k0p == 4 && L >= 3 && !any_in;
+  // (inference: the first layer's statistics-only launch would be for nothing)
+  p->recompute = (d.options & BTR_SA_OPT_RECOMPUTE) && p->k0p == 4 && L >= 3 && !any_in &&
+                 !(d.options & BTR_SA_OPT_EVAL);
   p->pool_epilogue = epi_allowed && L >= 2 &&
                      btr_sa_gemm_nt_poolfwd_supported(p->rows, d.width[L - 1],
                                                       p->compact ? 8 : d.s);
@@ -702,6 +704,16 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     blocks += cdiv((long long)ceil16(d.width[l]) * ceil16(p.kin[l]), 256);
     pa.nbt[l] = d.running_mean[l] ? d.num_batches_tracked[l] : nullptr;
   }
+  // Inference (BTR_SA_OPT_EVAL): gamma[l] / beta[l] are the affine map of BatchNorm on its running
+  // statistics, derived by the caller -- no finaliser runs, nothing is tracked; the statistics
+  // epilogues still write their partial sums into the scratch (nobody reads them)
+  const bool eval = (d.options & BTR_SA_OPT_EVAL) != 0;
+  if (eval)
+    for (int l = 0; l < L; ++l) {
+      BTR_REQUIRE(!d.running_mean[l] && !d.running_var[l],
+                  "sa_layer_forward: inference mode tracks no statistics");
+      pa.nbt[l] = nullptr;
+    }
   const bool ppfl = sa_ppfl(d, p);
   if (ppfl) pa.ppfl_c[0] = d.c;
   pa.first[L] = blocks;
@@ -748,9 +760,9 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
     float *y = at_f(saved, p.y[l]);
     float *st = at_f(saved, p.stats[l]);
     // BatchNorm finalisation by the statistics GEMM's last workgroup (false: a launch of its own)
-    const bool fin_fused = !(ppfl && l == 0) && bnfin_arm(BnFin{
+    const bool fin_fused = eval || (!(ppfl && l == 0) && bnfin_arm(BnFin{
         tickets + kBnTickets * l, d.gamma[l], d.beta[l], st, st + nl, st + 2 * nl, st + 3 * nl,
-        d.running_mean[l], d.running_var[l], nullptr, 0, (double)R, d.eps[l], d.momentum[l]}, R);
+        d.running_mean[l], d.running_var[l], nullptr, 0, (double)R, d.eps[l], d.momentum[l]}, R));
     if (ppfl && l == 0) {
       // ---- per-point first layer: P = F W_f^T over the POINTS, the rows gather it (+ W_x rel);
       // x0 = [the rows' relative coordinates (R, 4) | a copy of the features for the backward]
@@ -758,9 +770,11 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
       const float *w0f = w2, *w0x = w2 + (size_t)nl * d.c;
       float *fcopy = x0 + (size_t)R * 4;
       const size_t fbytes = sizeof(float) * (size_t)d.b * d.n * d.c;
-      const hipError_t ce = hipMemcpyAsync(fcopy, feats_cl, fbytes, hipMemcpyDeviceToDevice,
-                                           as_stream(stream));
-      if (ce != hipSuccess) return fail((int)ce, "sa_layer_forward: %s", hipGetErrorString(ce));
+      if (!eval) {   // (the backward's copy of the features)
+        const hipError_t ce = hipMemcpyAsync(fcopy, feats_cl, fbytes, hipMemcpyDeviceToDevice,
+                                             as_stream(stream));
+        if (ce != hipSuccess) return fail((int)ce, "sa_layer_forward: %s", hipGetErrorString(ce));
+      }
       float *P = at_f(scratch, sc.ppfl_p);
       btr_sac_bind(nullptr);   // (the product over the points is no compact-row GEMM)
       BTR_TRY(btr_pm_gemm_nt(d.b * d.n, nl, d.c, feats_cl, d.c, w0f, d.c, P, nl, nullptr, nullptr,
@@ -788,8 +802,8 @@ int btr::sa_layer_forward_geom(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
                                  d.running_mean[l], d.running_var[l], stream));
     A = y;
     lda = nl;
-    pscale = st;
-    pshift = st + nl;
+    pscale = eval ? d.gamma[l] : st;
+    pshift = eval ? d.beta[l] : st + nl;
   }
   btr_sac_bind(nullptr);
   const int cl = d.width[L - 1];
@@ -825,6 +839,7 @@ int btr::sa_layer_backward_add(const btr_sa_layer_t *dp, const btr_sa_plan_t *pp
                                const SaGeom *geom, btr_stream_t stream) {
   BTR_REQUIRE(dp && pp && idx && out && dout && saved && grads && scratch,
               "sa_layer_backward: null pointer");
+  BTR_REQUIRE(!(dp->options & BTR_SA_OPT_EVAL), "sa_layer_backward: an inference-mode layer");
   const btr_sa_layer_t &d = *dp;
   const btr_sa_plan_t &p = *pp;
   const int L = d.layers, R = p.rows;

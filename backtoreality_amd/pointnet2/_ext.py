@@ -238,6 +238,7 @@ SA_OPT_COMPACT, SA_OPT_RECOMPUTE, SA_OPT_POOL_EPILOGUE, SA_OPT_POOL_GRAD = 1, 2,
 SA_OPT_POOL_GRAM = 16
 SA_OPT_PPFL = 64
 SA_OPT_PPFL_XYZ = 128
+SA_OPT_EVAL = 256
 
 
 class SaLayer(ctypes.Structure):

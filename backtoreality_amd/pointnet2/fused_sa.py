@@ -582,7 +582,7 @@ def sa_grad_views(d, plan, sizes, pshapes, grads):
 
 
 def _eval_constants(module, k0):
-    """[(W (width, k_in) with layer 0 padded to k0 columns, a, b)] per MLP layer of a
+    """[(W (width, k_in) with layer 0 padded to k0 columns (k0 None: as it is), a, b)] per MLP layer of a
     set-abstraction module in inference mode, where BatchNorm with running statistics is the
     affine map  y_bn = (y - running_mean) / sqrt(running_var + eps) * gamma + beta = a*y + b.
     Derived once per evaluation pass instead of with ~7 small torch launches per layer and call
@@ -605,7 +605,7 @@ def _eval_constants(module, k0):
         for l in layers:
             W, bn = l.conv.weight, l.bn.bn
             W2 = W.reshape(W.shape[0], -1)
-            if W2.shape[1] != K:  # layer 0 with a padded input width
+            if K is not None and W2.shape[1] != K:  # layer 0 with a padded input width
                 Wp = torch.zeros((W.shape[0], K), dtype=torch.float32, device=W.device)
                 Wp[:, :W2.shape[1]] = W2
                 W2 = Wp
@@ -656,6 +656,12 @@ def fused_eval_forward(module, xyz, new_xyz, features, idx):
                   _p(out_cl), _stream(d))
         _ext.attach_twin(out, out_cl)
         return out
+    if native_enabled() and len(layers) <= _ext.MAX_LAYERS and \
+            all(w % 4 == 0 for w in widths) and idx.dtype == torch.int32:
+        # the training forward's kernels (compact rows, per-point first layer, streaming GEMMs,
+        # pool in the last GEMM's epilogue) with the running-statistics affine map handed in and
+        # no finaliser: ONE library call (csrc/sa_layer.hip, BTR_SA_OPT_EVAL)
+        return _native_eval_forward(module, xyz, new_xyz, feats_cl, idx, B, N, M, S, C, widths)
     with _on(xyz) as d:
         st = _stream(d)
         A = _f32((R, K0p), dev)
@@ -675,6 +681,48 @@ def fused_eval_forward(module, xyz, new_xyz, features, idx):
         arg = torch.empty((B * M, CL), dtype=torch.uint8, device=dev)
         _call(_lib.btr_sa_pool, B, M, S, CL, CL, _p(A), _p(pa), _p(pb),
               _p(out), _p(out_cl), _p(arg), st)
+    _ext.attach_twin(out, out_cl)
+    return out
+
+
+def _native_eval_forward(module, xyz, new_xyz, feats_cl, idx, B, N, M, S, C, widths):
+    g = module.grouper
+    dev = xyz.device
+    consts = _eval_constants(module, None)
+    opts = _sa_options() | _ext.SA_OPT_EVAL
+    cache = module.__dict__.setdefault('_btr_eval_plans', {})
+    key = (B, N, M, S, C, opts)
+    ent = cache.get(key)
+    L = len(widths)
+    if ent is None:
+        d = _ext.SaLayer()
+        d.b, d.n, d.m, d.s, d.c = B, N, M, S, C
+        d.use_xyz = 1 if g.use_xyz else 0
+        d.radius_div = float(g.radius if g.normalize_xyz else 1.0)
+        d.layers = L
+        for l in range(L):
+            d.width[l] = widths[l]
+            d.eps[l] = float(module.mlp_module[l].bn.bn.eps)
+        d.options = opts
+        plan = _ext.SaPlan()
+        _call(_lib.btr_sa_layer_plan, ctypes.addressof(d), ctypes.addressof(plan))
+        # (saved / scratch live with the module: an evaluation pass calls every layer once per
+        # batch, nothing is kept for a backward)
+        ent = cache[key] = [d, plan, _u8(plan.saved_bytes, dev), _u8(plan.fwd_scratch_bytes, dev)]
+    d, plan, saved, scratch = ent
+    if saved.device != dev:
+        saved, scratch = ent[2], ent[3] = _u8(plan.saved_bytes, dev), _u8(plan.fwd_scratch_bytes, dev)
+    for l in range(L):
+        W, a, b = consts[l]
+        d.w[l], d.gamma[l], d.beta[l] = W.data_ptr(), a.data_ptr(), b.data_ptr()
+        d.running_mean[l] = d.running_var[l] = d.num_batches_tracked[l] = None
+    CL = widths[-1]
+    out = _f32((B, CL, M), dev)
+    out_cl = _f32((B, M, CL), dev)
+    with _on(xyz) as dv:
+        _call(_lib.btr_sa_layer_forward, ctypes.addressof(d), ctypes.addressof(plan), _p(xyz),
+              _p(new_xyz), _p(feats_cl), _p(idx.contiguous()), _p(out), _p(out_cl), _p(saved),
+              _p(scratch), _stream(dv))
     _ext.attach_twin(out, out_cl)
     return out
 

@@ -626,10 +626,18 @@ enum {
                                    products over the points (levels with >= 32 feature channels
                                    and no coordinate gradient; csrc/sa_mlp.hip
                                    ppfl_gather_add_kernel)                                        */
-  BTR_SA_OPT_PPFL_XYZ = 128     /* ... also where coordinate gradients are asked for (the vote
+  BTR_SA_OPT_PPFL_XYZ = 128,    /* ... also where coordinate gradients are asked for (the vote
                                    aggregation; dense rows): d rel = dY_0 W_x as one more 4-column
                                    product.  Measured neutral, so the Python layer leaves it off
                                    unless BTR_SA_PPFL_XYZ=1                                       */
+  BTR_SA_OPT_EVAL = 256         /* inference (module.eval() under no_grad, the evaluation pass of
+                                   train_Votenet_FSB.py:246-293): gamma[l] / beta[l] ARE the
+                                   affine map y -> a y + b of BatchNorm on its running statistics
+                                   (a = gamma / sqrt(running_var + eps), b = beta - running_mean
+                                   a, derived by the caller), running_mean / running_var /
+                                   num_batches_tracked NULL; the forward is the training forward's
+                                   kernels (compact rows, per-point first layer, streaming GEMMs,
+                                   pool in the epilogue) minus the finalisers; no backward        */
 };
 typedef struct {
   int b, n, m, s, c;            /* batch, points, centres, nsample, feature channels (may be 0)  */

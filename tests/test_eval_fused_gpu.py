@@ -201,3 +201,41 @@ def test_sa_module_eval_constants_follow_the_training_writes(cuda, monkeypatch):
     a1 = evaluate(True)
     assert not torch.equal(a0, a1)
     torch.testing.assert_close(a1, evaluate(False), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("npoint,nsample,mlp,N,C", [
+    (1024, 32, [128, 128, 128, 256], 2048, 128),   # SA2: compact rows, per-point first layer
+    (512, 16, [256, 128, 128, 256], 1024, 256),    # SA3: dense rows
+    (256, 16, [128, 128, 128, 128], 1024, 128),    # vote aggregation's widths
+])
+def test_native_eval_layer_matches_the_stock_modules(cuda, monkeypatch, npoint, nsample, mlp, N,
+                                                      C):
+    """Inference through ONE btr_sa_layer_forward call (BTR_SA_OPT_EVAL: the training forward's
+    kernels with the running-statistics affine map handed in) against the nine-op path of the
+    same module, and against the launch sequence issued from Python (BTR_NATIVE_LAYERS=0)."""
+    from backtoreality_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(npoint)
+    m = PointnetSAModuleVotes(npoint=npoint, radius=0.4, nsample=nsample, mlp=list(mlp),
+                              use_xyz=True, normalize_xyz=True).to(cuda)
+    for layer in m.mlp_module:
+        bn = layer.bn.bn
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.data.uniform_(-1.5, 1.5)      # both signs: the pooled extremum flips with it
+        bn.bias.data.normal_(0, 0.2)
+    m.eval()
+    xyz = torch.rand(2, N, 3, device=cuda)
+    f = torch.randn(2, C, N, device=cuda)
+
+    def run(**env):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            with torch.no_grad():
+                return m(xyz, f)[1]
+
+    native = run()
+    assert "_btr_eval_plans" in m.__dict__ and len(m._btr_eval_plans) == 1
+    torch.testing.assert_close(native, run(BTR_FUSED_SA="0"), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(native, run(BTR_NATIVE_LAYERS="0"), rtol=2e-5, atol=2e-5)
+    assert torch.equal(native, run())

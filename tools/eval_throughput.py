@@ -59,10 +59,13 @@ def forward_depth(depth):
     return run
 
 
-for name, fn in (("forward only", forward_only), ("forward, pyramid prefetched", forward_prefetched),
-                 ("forward, 2 pyramids in flight", forward_depth(2)),
-                 ("forward, 3 pyramids in flight", forward_depth(3)),
-                 ("forward, 4 pyramids in flight", forward_depth(4))):
+CASES = (("forward only", forward_only), ("forward, pyramid prefetched", forward_prefetched),
+         ("forward, 2 pyramids in flight", forward_depth(2)),
+         ("forward, 3 pyramids in flight", forward_depth(3)),
+         ("forward, 4 pyramids in flight", forward_depth(4)))
+if os.environ.get("EVAL_ONLY") == "forward":   # (tools/profile_eval.sh: one case under the profiler)
+    CASES = CASES[:1]
+for name, fn in CASES:
     fn(3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -72,6 +75,8 @@ for name, fn in (("forward only", forward_only), ("forward, pyramid prefetched",
     dt = (time.perf_counter() - t0) / 20
     print("%-30s %.2f ms per batch = %.0f scenes/s (host enqueue %.2f ms)" % (
         name, dt * 1e3, B / dt, th * 1e3))
+if os.environ.get("EVAL_ONLY"):
+    sys.exit(0)
 train.evaluate_one_epoch(net, batches[:1], cfg)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
