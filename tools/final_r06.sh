@@ -18,6 +18,8 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > 
 for wl in c5 br cr gf gfbr; do
   python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$wl.json
 done
+python tools/eval_throughput.py 2>&1 | grep -v amdgpu.ids > $O/eval_times.txt
+bash tools/gf_lanes_ab.sh > $O/gf_lanes.txt 2>&1
 python tools/fps_lds_ab.py > $O/fps_lds_ab.txt 2>&1
 python tools/fps_prof.py > $O/fps_prof.txt 2>&1
 { python tools/phase_times.py 2>&1 | tail -11; } > $O/phase_times.txt
