@@ -83,6 +83,10 @@ def compute_points_obj_cls_loss_hard_topk(end_points, topk):
     end_points['points_hard_topk%d_neg_ratio' % topk] = \
         1 - end_points['points_hard_topk%d_pos_ratio' % topk]
 
+    if fused_loss.focal_sum_fusable(logits, label) and K > 0:
+        # every label is 0 or 1, so the weights (label >= 0) / count are 1 / K for every point:
+        # the focal terms, their sum and its gradient as one launch each way
+        return fused_loss.focal_sum(logits.reshape(B, K), label, 1.0 / K, 1.0 / B)
     weights = (label >= 0).float()
     weights = weights / torch.clamp(weights.sum(dim=1, keepdim=True), min=1.0)
     loss = sigmoid_focal_loss(logits.view(B, K, 1), label.unsqueeze(-1).float(), weights)

@@ -97,3 +97,29 @@ def test_fused_loss_is_refused_once_the_published_entries_stop_being_its_inputs(
     with torch.no_grad():
         end['proposal_objectness_scores'].add_(1.0)                  # in-place edit of a view
     assert not fused_loss.can_fuse(end, cfg, prefixes, kinds)
+
+
+@pytest.mark.parametrize("B,K", [(4, 1024), (2, 1000), (1, 37)])
+def test_focal_sum_matches_the_torch_composition(B, K):
+    """The seed points' objectness term (loss_helper.py:17-78 after the labels are made) as one
+    launch each way against sigmoid_focal_loss + the weights / sum / division around it: value
+    1e-6, gradient 1e-5 (relative to its largest entry), including saturated logits."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * K)
+    logits = (torch.randn(B, 1, K, generator=g) * 4).to(dev)
+    logits[0, 0, :4] = torch.tensor([40.0, -40.0, 0.0, 1e-4], device=dev)
+    label = (torch.rand(B, K, generator=g) < 0.2).long().to(dev)
+    a = logits.clone().requires_grad_(True)
+    weights = (label >= 0).float()
+    weights = weights / torch.clamp(weights.sum(dim=1, keepdim=True), min=1.0)
+    ref = loss_helper.sigmoid_focal_loss(a.view(B, K, 1), label.unsqueeze(-1).float(),
+                                         weights).sum() / B
+    (ref * 1.7).backward()
+    b = logits.clone().requires_grad_(True)
+    assert fused_loss.focal_sum_fusable(b, label)
+    out = fused_loss.focal_sum(b.reshape(B, K), label, 1.0 / K, 1.0 / B)
+    (out * 1.7).backward()
+    assert abs(float(out) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-9
+    err = (a.grad - b.grad).abs().max().item() / a.grad.abs().max().item()
+    assert err < 1e-5, err
+    assert torch.isfinite(b.grad).all()
