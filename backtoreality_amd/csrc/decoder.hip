@@ -645,7 +645,7 @@ int btr_decoder_layer_forward(const btr_decoder_layer_t *dp, const btr_decoder_p
                               const float *kpos_cl, float *out_bcp, float *out_cl, void *saved,
                               void *scratch, btr_stream_t stream) {
   return decoder_layer_forward_ex(dp, pp, x_cl, key_cl, qpos_cl, kpos_cl, out_bcp, out_cl, saved,
-                                  scratch, 0, stream);
+                                  scratch, 0, kDecoderFwdSelf | kDecoderFwdRest, stream);
 }
 
 int btr_decoder_layer_backward(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp,
@@ -691,13 +691,17 @@ int decoder_layer_kv(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp
 
 // (internal.hpp) btr_decoder_layer_forward; kv_ready != 0: the cross-attention's key / value rows
 // (saved: kp, kv) are there already -- decoder_layer_kv ran, on whatever stream, and the caller
-// ordered it before this call
+// ordered it before this call.  parts: kDecoderFwdSelf = the weight planes, the self-attention
+// with its LayerNorm and the cross-attention's query rows (nothing of it reads a key);
+// kDecoderFwdRest = everything from the key / value rows on; both = the whole layer.  A caller
+// that waits for the keys between the two calls hides that wait behind the first
 int decoder_layer_forward_ex(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp,
                              const float *x_cl, const float *key_cl, const float *qpos_cl,
                              const float *kpos_cl, float *out_bcp, float *out_cl, void *saved,
-                             void *scratch, int kv_ready, btr_stream_t stream) {
+                             void *scratch, int kv_ready, int parts, btr_stream_t stream) {
   BTR_REQUIRE(dp && pp && x_cl && key_cl && out_cl && saved && scratch,
               "decoder_layer_forward: null pointer");
+  const bool part_self = (parts & kDecoderFwdSelf) != 0, part_rest = (parts & kDecoderFwdRest) != 0;
   const btr_decoder_layer_t &d = *dp;
   const btr_decoder_plan_t &p = *pp;
   hipStream_t hs = as_stream(stream);
@@ -716,6 +720,8 @@ int decoder_layer_forward_ex(const btr_decoder_layer_t *dp, const btr_decoder_pl
     Bump fs;
     fs.floats((size_t)rq * e * (size_t)pm_splitk_slices(rq, d.e, d.ff));
     fp = fwd_planes(d, fs.off);
+  }
+  if (sm && part_self) {
     TransposeArgs t{};
     const float *src[5] = {d.sa_in_w, d.sa_out_w, d.ca_in_w, d.ca_out_w, d.lin1_w};
     const size_t off[5] = {fp.sa_in, fp.sa_out, fp.ca_in, fp.ca_out, fp.l1};
@@ -742,26 +748,30 @@ int decoder_layer_forward_ex(const btr_decoder_layer_t *dp, const btr_decoder_pl
     return btr_pm_gemm_nt(rows, n, e, a, e, w + (size_t)row0 * e, e, c, n, nullptr, nullptr,
                           nullptr, bias, stream);
   };
-  // ---- self-attention
-  const float *qsrc = x_cl;
-  if (qpos_cl) {
-    BTR_TRY(add2(hs, (long long)rq * e, x_cl, qpos_cl, qp0));
-    qsrc = qp0;
+  if (part_self) {
+    // ---- self-attention
+    const float *qsrc = x_cl;
+    if (qpos_cl) {
+      BTR_TRY(add2(hs, (long long)rq * e, x_cl, qpos_cl, qp0));
+      qsrc = qp0;
+    }
+    BTR_TRY(proj(rq, 3 * e, qsrc, d.sa_in_w, fp.sa_in, 0, 3 * e, qkv, d.sa_in_b));
+    BTR_TRY(attention_fwd_strided(d.pq, d.pq, d.b, d.heads, hd, qkv, 3 * e,
+                                  (long long)d.pq * 3 * e, qkv + e, qkv + 2 * e, 3 * e,
+                                  (long long)d.pq * 3 * e, a1, e, (long long)d.pq * e,
+                                  at_f(saved, p.lse1), scale, d.dropout, attn_seed(d, 0), d.step,
+                                  stream));
+    BTR_TRY(proj(rq, e, a1, d.sa_out_w, fp.sa_out, 0, e, o, d.sa_out_b));
+    {
+      LnFwd a{rq, e, x_cl, o, 1, 0, nullptr, make_drop(d, 0), d.ln_w[0], d.ln_b[0], d.ln_eps[0],
+              x1, at_f(saved, p.xh1), at_f(saved, p.rs1), qpos_cl, qpos_cl ? qp1 : nullptr};
+      BTR_TRY(ln_forward(hs, a));
+    }
+    // ---- cross-attention: the query rows
+    const float *q2src = qpos_cl ? qp1 : x1;
+    BTR_TRY(proj(rq, e, q2src, d.ca_in_w, fp.ca_in, 0, 3 * e, q2, d.ca_in_b));
   }
-  BTR_TRY(proj(rq, 3 * e, qsrc, d.sa_in_w, fp.sa_in, 0, 3 * e, qkv, d.sa_in_b));
-  BTR_TRY(attention_fwd_strided(d.pq, d.pq, d.b, d.heads, hd, qkv, 3 * e, (long long)d.pq * 3 * e,
-                                qkv + e, qkv + 2 * e, 3 * e, (long long)d.pq * 3 * e, a1, e,
-                                (long long)d.pq * e, at_f(saved, p.lse1), scale, d.dropout,
-                                attn_seed(d, 0), d.step, stream));
-  BTR_TRY(proj(rq, e, a1, d.sa_out_w, fp.sa_out, 0, e, o, d.sa_out_b));
-  {
-    LnFwd a{rq, e, x_cl, o, 1, 0, nullptr, make_drop(d, 0), d.ln_w[0], d.ln_b[0], d.ln_eps[0], x1,
-            at_f(saved, p.xh1), at_f(saved, p.rs1), qpos_cl, qpos_cl ? qp1 : nullptr};
-    BTR_TRY(ln_forward(hs, a));
-  }
-  // ---- cross-attention
-  const float *q2src = qpos_cl ? qp1 : x1;
-  BTR_TRY(proj(rq, e, q2src, d.ca_in_w, fp.ca_in, 0, 3 * e, q2, d.ca_in_b));
+  if (!part_rest) return check_launch("decoder_layer_forward");
   if (!kv_ready) {
     const float *ksrc = key_cl;
     if (kpos_cl) {

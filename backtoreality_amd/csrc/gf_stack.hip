@@ -383,30 +383,32 @@ int btr_gf_stack_forward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *pp
       ln.signal(1 + i, 1);
     }
   }
-  // ---- main lane: per layer, query position embedding -> layer -> head -> decoded boxes
+  // ---- main lane: per layer, query position embedding -> layer -> head -> decoded boxes.  The
+  // first layer is two segments with the wait for its keys between them (the embedding and the
+  // self-attention do not read a key: the side lane's first segment hides behind them); the
+  // later layers' keys are long there when the main lane arrives.
   for (int i = 0; i < L; ++i) {
-    if (ahead) ln.wait(1 + i, 0);
-    BTR_TRY(ln.run(i, 0, [&](hipStream_t bs) -> int {
+    const float *x = i == 0 ? query_cl : at_f(saved, p.s_x[i - 1]);
+    const float *qpos_t = i == 0 ? qpos0_t : query_pos_t[i - 1];
+    float *qpos_cl = d.has_qpos ? at_f(saved, p.s_qpos_cl[i]) : nullptr;
+    float *kpos_cl = d.has_kpos ? at_f(saved, p.s_kpos_cl[i]) : nullptr;
+    float *xo = at_f(saved, p.s_x[i]);
+    const bool split = ahead && i == 0;
+    auto first = [&](hipStream_t bs, int parts) -> int {
       btr_stream_t stream = (btr_stream_t)bs;
-      const float *x = i == 0 ? query_cl : at_f(saved, p.s_x[i - 1]);
-      const float *qpos_t = i == 0 ? qpos0_t : query_pos_t[i - 1];
-      float *qpos_cl = nullptr, *kpos_cl = nullptr;
-      if (d.has_qpos) {
-        qpos_cl = at_f(saved, p.s_qpos_cl[i]);
+      if (d.has_qpos)
         BTR_TRY(btr_pm_chain_forward(&d.qpos[i], &p.qpos[i], qpos_t, nullptr, nullptr, qpos_cl,
                                      at_v(saved, p.s_qpos[i]), scr_main, stream));
-      }
-      if (d.has_kpos) {
-        kpos_cl = at_f(saved, p.s_kpos_cl[i]);
-        if (!ahead)
-          BTR_TRY(btr_pm_chain_forward(&d.kpos[i], &p.kpos[i], key_xyz_t, nullptr, nullptr,
-                                       kpos_cl, at_v(saved, p.s_kpos[i]), scr_main, stream));
-      }
-      float *xo = at_f(saved, p.s_x[i]);
-      BTR_TRY(decoder_layer_forward_ex(&d.layer[i], &p.layer[i], x, key_cl, qpos_cl, kpos_cl,
-                                       i == L - 1 ? last_bcp : nullptr, xo,
-                                       at_v(saved, p.s_layer[i]), scr_main, ahead ? 1 : 0,
-                                       stream));
+      if (d.has_kpos && !ahead)
+        BTR_TRY(btr_pm_chain_forward(&d.kpos[i], &p.kpos[i], key_xyz_t, nullptr, nullptr,
+                                     kpos_cl, at_v(saved, p.s_kpos[i]), scr_main, stream));
+      return decoder_layer_forward_ex(&d.layer[i], &p.layer[i], x, key_cl, qpos_cl, kpos_cl,
+                                      i == L - 1 ? last_bcp : nullptr, xo,
+                                      at_v(saved, p.s_layer[i]), scr_main, ahead ? 1 : 0, parts,
+                                      stream);
+    };
+    auto second = [&](hipStream_t bs) -> int {
+      btr_stream_t stream = (btr_stream_t)bs;
       BTR_TRY(btr_pm_chain_forward(&d.head[i], &p.head[i], nullptr, xo, head_out[i],
                                    head_out_cl[i], at_v(saved, p.s_head[i]), scr_main, stream));
       const int cp = p.head[i].np[d.head[i].layers - 1];
@@ -418,7 +420,24 @@ int btr_gf_stack_forward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *pp
         (void)hipMemcpyAsync(last_cl, xo, (size_t)d.b * d.pq * d.e * sizeof(float),
                              hipMemcpyDeviceToDevice, bs);
       return check_launch("gf_stack_forward");
-    }));
+    };
+    if (split) {
+      BTR_TRY(ln.run(50 + i, 0, [&](hipStream_t bs) -> int { return first(bs, kDecoderFwdSelf); }));
+      ln.wait(1 + i, 0);
+      BTR_TRY(ln.run(i, 0, [&](hipStream_t bs) -> int {
+        BTR_TRY(decoder_layer_forward_ex(&d.layer[i], &p.layer[i], x, key_cl, qpos_cl, kpos_cl,
+                                         i == L - 1 ? last_bcp : nullptr, xo,
+                                         at_v(saved, p.s_layer[i]), scr_main, 1, kDecoderFwdRest,
+                                         (btr_stream_t)bs));
+        return second(bs);
+      }));
+    } else {
+      if (ahead) ln.wait(1 + i, 0);
+      BTR_TRY(ln.run(i, 0, [&](hipStream_t bs) -> int {
+        BTR_TRY(first(bs, kDecoderFwdSelf | kDecoderFwdRest));
+        return second(bs);
+      }));
+    }
   }
   ln.report("gf_stack_forward");
   return BTR_OK;

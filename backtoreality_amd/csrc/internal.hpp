@@ -126,7 +126,8 @@ int decoder_layer_kv(const btr_decoder_layer_t *d, const btr_decoder_plan_t *p,
 int decoder_layer_forward_ex(const btr_decoder_layer_t *d, const btr_decoder_plan_t *p,
                              const float *x_cl, const float *key_cl, const float *qpos_cl,
                              const float *kpos_cl, float *out_bcp, float *out_cl, void *saved,
-                             void *scratch, int kv_ready, btr_stream_t stream);
+                             void *scratch, int kv_ready, int parts, btr_stream_t stream);
+enum { kDecoderFwdSelf = 1, kDecoderFwdRest = 2 };
 // sa_layer.hip: btr_pm_chain_backward with the output gradient as channel-last rows a0 (+ a1)
 // instead of dout (b, c, n), and / or the input gradient left as rows in dx_rows (leading
 // dimension = the padded input width) instead of dx (b, c, n)
