@@ -116,6 +116,7 @@ class _Slot(object):
         self.key_xyz_t = _f32((B, kd, Pk), dev) if kd else None
         self.base = _f32((B, Pq, 3), dev)
         self.cat = [(_f32(ws, dev), _f32(bs, dev)) for ws, bs in cat_shapes]
+        self.cat_views = None   # the seven layers' places in them (made on first use)
         self.out_flat = _f32((_OutBlock.floats(*self.dims),), dev)
         self.out = _OutBlock(self.out_flat, *self.dims)
         self.saved = _u8(plan.saved_bytes, dev)
@@ -237,9 +238,10 @@ def _entry(det, key, B, Pq, Pk, E, qd, kd, p, specs):
     return ent
 
 
-def _specs(det, E, qd, kd):
+def _specs(det, E, qd, kd, standin_device=None):
     """Per layer ((metas, params) of the query / key position embedding and the head), or None
-    when a chain is not covered."""
+    when a chain is not covered.  standin_device: the heads' concatenated output layers appear as
+    shape-only stand-ins (the slot path fills its own copy from the seven layers, `_head_subs`)."""
     specs = []
     for i in range(det.num_decoder_layers):
         layer = det.decoder[i]
@@ -255,12 +257,26 @@ def _specs(det, E, qd, kd):
             if spec is None or chain[-1][0].out_channels != E:
                 return None
             row.append(spec)
-        spec = fused_mlp.chain_spec(E, det.prediction_heads[i].chain())
+        head = det.prediction_heads[i]
+        last = head.cat_standin(standin_device) if standin_device is not None else None
+        spec = fused_mlp.chain_spec(E, head.chain(last))
         if spec is None:
             return None
         row.append(spec)
         specs.append(row)
     return specs
+
+
+def _head_subs(det):
+    """(weight, bias) of the seven output layers of every prediction head, head by head, and the
+    rows each takes in the head's concatenated layer."""
+    subs, rows = [], []
+    for i in range(det.num_decoder_layers):
+        heads = det.prediction_heads[i]._heads()
+        rows.append([h.out_channels for h in heads])
+        for h in heads:
+            subs += [h.weight, h.bias]
+    return subs, rows
 
 
 def _flat_params(det, specs):
@@ -344,6 +360,13 @@ class DecoderStackFn(Function):
     def forward(ctx, query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta, sink, *params):
         _ext.RUNNING_STATS_EPOCH[0] += 1   # running statistics move through raw pointers
         ent, p, want_last = meta["entry"], meta["p"], meta["want_last"]
+        # (slot path: the seven output layers of every head follow the descriptor-order
+        # parameters; the concatenated layers among those are shape-only stand-ins)
+        nsub = meta.get("nsub", 0)
+        subs = params[len(params) - nsub:] if nsub else ()
+        if nsub:
+            params = params[:len(params) - nsub]
+        ctx.subs = (nsub, meta.get("sub_rows"), meta["cat_at"])
         # (flat gradient sink, pointnet2/grad_sink.py: the leaf parameters' gradients leave as
         # ONE buffer; computed operands -- the heads' concatenated last layers -- keep theirs)
         ctx.leaf = [t is not None and t.is_leaf and t.requires_grad for t in params] \
@@ -377,8 +400,11 @@ class DecoderStackFn(Function):
                 if key_xyz_t is not None:
                     key_xyz_t = slot.key_xyz_t.copy_(key_xyz_t)
                 base = slot.base.copy_(base_xyz)
-                torch._foreach_copy_([t for wb in slot.cat for t in wb],
-                                     [params[at + j] for at in meta["cat_at"] for j in (0, 1)])
+                if slot.cat_views is None:
+                    slot.cat_views = [v for (W, b), rows in zip(slot.cat, meta["sub_rows"])
+                                      for wv, bv in zip(W.split(rows, 0), b.split(rows, 0))
+                                      for v in (wv, bv)]
+                torch._foreach_copy_(slot.cat_views, list(subs))
                 ob, saved, scratch = slot.out, slot.saved, slot.scratch
                 arrays = slot.fwd_arrays
             else:
@@ -464,10 +490,18 @@ class DecoderStackFn(Function):
             grads = grads.clone()
             lease.release()
         res = _grad_views(d, ent, ctx.specs, ctx.pshapes, grads)
+        nsub, sub_rows, cat_at = ctx.subs
+        gsubs = []
+        if nsub:   # the concatenated layers' gradients, cut into the seven layers' own
+            for rows, at in zip(sub_rows, cat_at):
+                for wv, bv in zip(res[at].split(rows, 0), res[at + 1].split(rows, 0)):
+                    gsubs += [wv, bv]
+                res[at] = res[at + 1] = None
         if ctx.leaf is not None:
             res = [None if leaf else g for g, leaf in zip(res, ctx.leaf)]
-            return (dquery, dkey, None, None, g_base, None, None, grads) + tuple(res)
-        return (dquery, dkey, None, None, g_base, None, None, None) + tuple(res)
+            return (dquery, dkey, None, None, g_base, None, None, grads) + tuple(res) + \
+                tuple(gsubs)
+        return (dquery, dkey, None, None, g_base, None, None, None) + tuple(res) + tuple(gsubs)
 
 
 def _fwd_arrays(ob):
@@ -565,7 +599,10 @@ def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
                 h.mean_size_arr is not head0.mean_size_arr and \
                 not (h.mean_size_arr == head0.mean_size_arr).all():
             return _no("prediction heads differ")
-    specs = _specs(det, E, qd, kd)
+    # Slot path (replayed graphs need every pointer to repeat): the heads' concatenated output
+    # layers are shape-only stand-ins here, the slot fills its own copy from the seven layers
+    slotted = _slots_enabled() and not torch.cuda.is_current_stream_capturing()
+    specs = _specs(det, E, qd, kd, query.device if slotted else None)
     if specs is None:
         return _no("a chain is not covered")
     # momentum=None (cumulative average) changes with num_batches_tracked every call, and the
@@ -580,17 +617,23 @@ def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
                                            for row in specs))
     ent = _entry(det, key_, B, Pq, Pk, E, qd, kd, p, specs)
     params, cat_at = _flat_params(det, specs)
-    _set_pointers(ent, det, specs, params, cat_at)
-    mean_size = head0._mean_size_on(query.device)
-    meta = {"entry": ent, "p": p, "want_last": want_last, "specs": specs, "cat_at": cat_at}
     slot = None
-    if not torch.cuda.is_current_stream_capturing():
+    if slotted:
         slot = _acquire(ent, query.device, torch.cuda.current_stream(query.device).cuda_stream,
                         want_last, qd, kd,
                         [(params[at].shape, params[at + 1].shape) for at in cat_at])
+        if slot is None:   # every slot in flight: this call concatenates as the module loop does
+            specs = _specs(det, E, qd, kd)
+            params, cat_at = _flat_params(det, specs)
+    _set_pointers(ent, det, specs, params, cat_at)
+    mean_size = head0._mean_size_on(query.device)
+    meta = {"entry": ent, "p": p, "want_last": want_last, "specs": specs, "cat_at": cat_at}
+    subs = []
     if slot is not None:
         _slot_descriptor(slot, ent, p, query.device)
         meta["slot"] = slot
+        subs, meta["sub_rows"] = _head_subs(det)
+        meta["nsub"] = len(subs)
         # (the slot's copies are made inside the node: transposed views, no cached tensors)
         qpos0_t = query_pos.transpose(1, 2) if query_pos is not None else None
         key_xyz_t = key_pos.transpose(1, 2) if key_pos is not None else None
@@ -598,7 +641,7 @@ def run(det, query, key, query_pos, key_pos, base_xyz, end_points):
         qpos0_t = _transposed(query_pos) if query_pos is not None else None
         key_xyz_t = _transposed(key_pos) if key_pos is not None else None
     outs = DecoderStackFn.apply(query, key, qpos0_t, key_xyz_t, base_xyz, mean_size, meta,
-                                _stack_sink(ent, specs, params, query.device), *params)
+                                _stack_sink(ent, specs, params, query.device), *params, *subs)
     CALLS[0] += 1
     for i in range(L):
         prefix = 'last_' if i == L - 1 else '%dhead_' % i

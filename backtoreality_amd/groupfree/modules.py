@@ -137,13 +137,28 @@ class PredictHead(nn.Module):
                 self.heading_residual_head, self.size_class_head, self.size_residual_head,
                 self.sem_cls_scores_head)
 
-    def chain(self):
+    def chain(self, last=None):
         """The head as one conv/BN/ReLU chain for fused_mlp.run_chain (and the decoder stack).
         The seven output layers are 1x1 convolutions of the same `net`: one convolution with the
         concatenated weights (116 output channels at ScanNet sizes) instead of seven of 1..66
-        channels; the parameters stay separate (state-dict keys of the reference)."""
+        channels; the parameters stay separate (state-dict keys of the reference).  `last`: a
+        stand-in for the concatenated layer (the decoder stack's slots keep their own copy of it
+        and fill it from the seven layers themselves: no torch.cat)."""
         return [(self.conv1, self.bn1, True), (self.conv2, self.bn2, True),
-                (_CatConv(self._heads()), None, False)]
+                (last if last is not None else _CatConv(self._heads()), None, False)]
+
+    def cat_standin(self, device):
+        """A _CatConv-shaped object whose weight / bias only carry the shapes (never read)."""
+        s = self.__dict__.get('_cat_standin')
+        if s is None or s.weight.device != device:
+            heads = self._heads()
+            s = _CatConv.__new__(_CatConv)
+            n = sum(h.out_channels for h in heads)
+            s.weight = torch.empty((n, heads[0].in_channels, 1), dtype=torch.float32, device=device)
+            s.bias = torch.empty((n,), dtype=torch.float32, device=device)
+            s.in_channels, s.out_channels = heads[0].in_channels, n
+            self.__dict__['_cat_standin'] = s
+        return s
 
     def forward(self, features, base_xyz, end_points, prefix=''):
         chain = self.chain()
