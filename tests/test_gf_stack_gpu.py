@@ -186,3 +186,44 @@ def test_replayed_graphs_on_three_lanes_equal_the_single_launches(cuda, monkeypa
         for k in ga:
             assert torch.equal(ga[k], gb[k]), (it, k)
         assert abs(la - lb) <= 1e-6 * abs(lb), (it, la, lb)   # (the backbone's float atomics)
+
+
+@pytest.mark.gpu
+def test_cached_coverage_checks_follow_the_modules(cuda, monkeypatch):
+    """run() keeps the outcome of its coverage checks with the detector; a module whose state
+    changes between two calls (a dropout rate, a BatchNorm put into eval mode, a replaced
+    parameter) must be seen by the next call."""
+    monkeypatch.setenv("BTR_FUSED_GF_STACK", "1")
+    cfg = config.scannet_md40()
+    batch = synthetic.make_batch(3, 2, 8192, cfg, use_height=False, device=cuda)
+    torch.manual_seed(0)
+    net = groupfree.GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                      cfg.mean_size_arr, input_feature_dim=0, num_proposal=256,
+                                      dropout=0.1, self_position_embedding='loc_learned',
+                                      cross_position_embedding='xyz_learned').to(cuda)
+
+    def took():
+        calls = fused_stack.CALLS[0]
+        ep = net({'point_clouds': batch['point_clouds']})
+        return fused_stack.CALLS[0] - calls, ep
+
+    assert took()[0] == 1 and took()[0] == 1
+    net.decoder[2].dropout1.p = 0.3                     # rates differ inside a layer
+    assert took()[0] == 0
+    net.decoder[2].dropout1.p = 0.1
+    assert took()[0] == 1
+    net.prediction_heads[1].bn1.eval()                  # a chain that is no longer covered
+    assert took()[0] == 0
+    net.prediction_heads[1].bn1.train()
+    assert took()[0] == 1
+    # a replaced parameter object: the next call must read the new one
+    head = net.prediction_heads[5].center_residual_head
+    _, before = took()
+    with torch.no_grad():
+        head.weight = torch.nn.Parameter(head.weight.detach().clone() * 0.0)
+        head.bias = torch.nn.Parameter(head.bias.detach().clone() * 0.0 + 0.25)
+    n, after = took()
+    assert n == 1
+    assert not torch.equal(before['last_center'], after['last_center'])
+    assert torch.allclose(after['last_center'] - after['last_base_xyz'],
+                          torch.full_like(after['last_center'], 0.25), atol=1e-6)
