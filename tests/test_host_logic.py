@@ -354,3 +354,59 @@ def test_fast_adamw_with_folded_clipping_equals_clip_then_adamw():
         assert torch.allclose(total, ref)
     for a, b in zip(net_a.parameters(), net_b.parameters()):
         assert torch.equal(a, b)
+
+
+def test_decoder_stack_host_logic():
+    """The host side of the GroupFree3D decoder stack's slots (groupfree/fused_stack.py), no GPU:
+    the output block's layout, the lease of a slot, the state signature that guards the cached
+    coverage checks, the eval constants' cache key."""
+    from backtoreality_amd import groupfree
+    from backtoreality_amd.groupfree import fused_stack
+    from backtoreality_amd.votenet import config
+    dims = (6, 4, 256, 288, 97, 100, 1, 18, True)
+    n = fused_stack._OutBlock.floats(*dims)
+    flat = torch.arange(n, dtype=torch.float32)
+    ob = fused_stack._OutBlock(flat, *dims)
+    L, B, Pq, E, C, Cp, nh, ns, _ = dims
+    assert ob.cls.shape == (L, B * Pq, Cp) and ob.last.shape == (B, E, Pq)
+    assert len(ob.outs) == L and ob.outs[3][0].shape == (B, C, Pq)
+    pieces = [ob.cls, ob.qpos, ob.qpos_t, ob.last, ob.last_cl] + [t for o in ob.outs for t in o[:5]]
+    spans = sorted((int(t.reshape(-1)[0]), int(t.reshape(-1)[0]) + t.numel()) for t in pieces)
+    assert all(a % 64 == 0 for a, _ in spans)                      # 256-byte bounds
+    assert all(b <= c for (_, b), (c, _) in zip(spans, spans[1:]))   # disjoint
+    assert spans[-1][1] <= n
+    assert ob.outs[2][5].data_ptr() == ob.qpos[2].data_ptr()         # query_pos are views of qpos
+
+    class S(object):
+        busy = False
+    s = S()
+    lease = fused_stack._Lease(s)
+    assert s.busy
+    lease.release()
+    lease.release()
+    assert not s.busy and lease.slot is None
+    lease = fused_stack._Lease(s)
+    del lease                                                          # freed with its holder
+    assert not s.busy
+
+    cfg = config.scannet_md40()
+    det = groupfree.GroupFreeDetector(cfg.num_class, cfg.num_heading_bin, cfg.num_size_cluster,
+                                      cfg.mean_size_arr, input_feature_dim=0, num_proposal=64,
+                                      dropout=0.1)
+    a = fused_stack._state_signature(det)
+    assert a == fused_stack._state_signature(det)
+    det.decoder[1].dropout2.p = 0.2
+    b = fused_stack._state_signature(det)
+    assert b != a
+    det.decoder[1].dropout2.p = 0.1
+    det.prediction_heads[0].bn2.eval()
+    assert fused_stack._state_signature(det) != a
+    det.prediction_heads[0].bn2.train()
+    assert fused_stack._state_signature(det) == a
+    conv = det.prediction_heads[3].sem_cls_scores_head
+    conv.weight = torch.nn.Parameter(conv.weight.detach().clone())
+    assert fused_stack._state_signature(det) != a
+    subs, rows = fused_stack._head_subs(det)
+    assert len(subs) == 14 * det.num_decoder_layers and subs[-2] is \
+        det.prediction_heads[-1].sem_cls_scores_head.weight
+    assert sum(rows[0]) == det.prediction_heads[0].cat_standin(torch.device("cpu")).out_channels
