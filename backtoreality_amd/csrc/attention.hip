@@ -167,12 +167,16 @@ __device__ __forceinline__ void tile_store(const TileRegs<VEC> &t, const TileMap
 }
 
 // KS: k-steps of the d reduction (2 * KS >= d); NT: 32-wide tiles over the d output columns
-template <int KS, int NT, bool VEC>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
+// NW: waves of the workgroup (they split the keys).  4: one wave per SIMD; 8: two -- with 256
+// workgroups or fewer on 256 CUs a SIMD's only wave waited 63 % of its cycles (profiles/
+// r06_attn_pmc.md: loads, LDS round trips, the MFMA results its own VALU work needs) and nothing
+// else ran on its matrix unit meanwhile.
+template <int KS, int NT, bool VEC, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(AttnArgs a) {
   constexpr int LDK = 2 * KS + 1;   // odd: fragment reads walk down the rows without conflicts
   constexpr int LDV = 32 * NT;
   constexpr int WAVE_F = kMT * LDK + kMT * LDV + 64;   // K tile, V tile, per-query exchange
-  __shared__ __attribute__((aligned(16))) float smem[4 * WAVE_F];
+  __shared__ __attribute__((aligned(16))) float smem[NW * WAVE_F];
   typedef float acc16 __attribute__((ext_vector_type(16)));
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.h, h = bh - b * a.h;
@@ -207,15 +211,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
     tile_fetch<VEC>(kt, tm, kp, a.kv_sl, w * kMT, a.lk, a.d, lane);
     tile_fetch<VEC>(vt, tm, vp, a.kv_sl, w * kMT, a.lk, a.d, lane);
   }
-  for (int tile = w; tile < ntiles; tile += 4) {   // the four waves split the keys
+  for (int tile = w; tile < ntiles; tile += NW) {   // the waves split the keys
     const int k0 = tile * kMT;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();               // previous tile's LDS reads are done
     tile_store<VEC, false>(kt, tm, Kt, LDK, a.d, lane);
     tile_store<VEC, true>(vt, tm, Vt, LDV, a.d, lane);
-    if (tile + 4 < ntiles) {       // next tile's loads fly under this one's math
-      tile_fetch<VEC>(kt, tm, kp, a.kv_sl, k0 + 4 * kMT, a.lk, a.d, lane);
-      tile_fetch<VEC>(vt, tm, vp, a.kv_sl, k0 + 4 * kMT, a.lk, a.d, lane);
+    if (tile + NW < ntiles) {       // next tile's loads fly under this one's math
+      tile_fetch<VEC>(kt, tm, kp, a.kv_sl, k0 + NW * kMT, a.lk, a.d, lane);
+      tile_fetch<VEC>(vt, tm, vp, a.kv_sl, k0 + NW * kMT, a.lk, a.d, lane);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -270,14 +274,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
                                                      0, 0, 0);
     }
   }
-  // ---- merge the four waves' partial (m, l, O) and write
+  // ---- merge the waves' partial (m, l, O) and write
   l += __shfl_xor(l, 32);
   __syncthreads();   // every wave is done with its tiles: the LDS is reused
   constexpr int LDO = 32 * NT + 1;
-  float *Om = smem;                       // [4][32][LDO]
-  float *Mm = smem + 4 * kMT * LDO;       // [4][32]
-  float *Lm = Mm + 4 * kMT;               // [4][32]
-  static_assert(4 * kMT * LDO + 8 * kMT <= 4 * WAVE_F, "merge buffers fit the tile storage");
+  float *Om = smem;                       // [NW][32][LDO]
+  float *Mm = smem + NW * kMT * LDO;      // [NW][32]
+  float *Lm = Mm + NW * kMT;              // [NW][32]
+  static_assert(NW * kMT * LDO + 2 * NW * kMT <= NW * WAVE_F, "merge buffers fit the tile storage");
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -288,12 +292,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
     Lm[w * kMT + l31] = l;
   }
   __syncthreads();
+  if (tid >= 256) return;   // (32 rows x 8 column slices write)
   const int row = tid >> 3, sub = tid & 7;
   const int i = q0 + row;
-  float M = fmaxf(fmaxf(Mm[row], Mm[kMT + row]), fmaxf(Mm[2 * kMT + row], Mm[3 * kMT + row]));
-  float f[4], L = 0.f;
+  float M = -INFINITY;
 #pragma unroll
-  for (int ww = 0; ww < 4; ++ww) {
+  for (int ww = 0; ww < NW; ++ww) M = fmaxf(M, Mm[ww * kMT + row]);
+  float f[NW], L = 0.f;
+#pragma unroll
+  for (int ww = 0; ww < NW; ++ww) {
     f[ww] = __expf(Mm[ww * kMT + row] - M);
     L = fmaf(Lm[ww * kMT + row], f[ww], L);
   }
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
     for (int c = sub; c < a.d; c += 8) {
       float acc = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < 4; ++ww) acc = fmaf(Om[(ww * kMT + row) * LDO + c], f[ww], acc);
+      for (int ww = 0; ww < NW; ++ww) acc = fmaf(Om[(ww * kMT + row) * LDO + c], f[ww], acc);
       op[c] = acc * inv;
     }
     if (sub == 0) a.lse[(long long)bh * a.lq + i] = M + __logf(L);
@@ -315,12 +322,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
 // split the keys and their partial dQ are summed through LDS.  Per key tile:
 //   S^T = K Q^T,  dP^T = V dO^T  (both in the forward's transposed layout: a lane = one query)
 //   dS = P * (keep ? dP / (1 - p) : 0  -  D),   dQ += dS K   (dS as the A operand in place)
-template <int KS, int NT, bool VEC>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
+template <int KS, int NT, bool VEC, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
   constexpr int LDT = 2 * KS + 1;
   constexpr int WAVE_F = 2 * kMT * LDT + 32;
   constexpr int LDO = 32 * NT + 1;
-  constexpr int SMEM = (4 * WAVE_F > 4 * kMT * LDO) ? 4 * WAVE_F : 4 * kMT * LDO;
+  constexpr int SMEM = (NW * WAVE_F > NW * kMT * LDO) ? NW * WAVE_F : NW * kMT * LDO;
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
   typedef float acc16 __attribute__((ext_vector_type(16)));
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -362,15 +369,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
     tile_fetch<VEC>(kt, tm, kp, a.kv_sl, w * kMT, a.lk, a.d, lane);
     tile_fetch<VEC>(vt, tm, vp, a.kv_sl, w * kMT, a.lk, a.d, lane);
   }
-  for (int tile = w; tile < ntiles; tile += 4) {
+  for (int tile = w; tile < ntiles; tile += NW) {
     const int k0 = tile * kMT;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     tile_store<VEC, false>(kt, tm, Kt, LDT, a.d, lane);
     tile_store<VEC, false>(vt, tm, Vt, LDT, a.d, lane);
-    if (tile + 4 < ntiles) {
-      tile_fetch<VEC>(kt, tm, kp, a.kv_sl, k0 + 4 * kMT, a.lk, a.d, lane);
-      tile_fetch<VEC>(vt, tm, vp, a.kv_sl, k0 + 4 * kMT, a.lk, a.d, lane);
+    if (tile + NW < ntiles) {
+      tile_fetch<VEC>(kt, tm, kp, a.kv_sl, k0 + NW * kMT, a.lk, a.d, lane);
+      tile_fetch<VEC>(vt, tm, vp, a.kv_sl, k0 + NW * kMT, a.lk, a.d, lane);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -401,20 +408,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnArgs a) {
     }
   }
   __syncthreads();
-  float *Om = smem;   // [4][32][LDO]
+  float *Om = smem;   // [NW][32][LDO]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int v = 0; v < 16; ++v)
       Om[(w * kMT + mfma_row(v, hh)) * LDO + 32 * nt + l31] = dq[nt][v];
   __syncthreads();
+  if (tid >= 256) return;
   const int row = tid >> 3, sub = tid & 7;
   const int i = q0 + row;
   if (i < a.lq) {
     float *dqp = a.dq + (long long)i * a.dq_sl + (long long)b * a.dq_sb + (long long)h * a.d;
-    for (int c = sub; c < a.d; c += 8)
-      dqp[c] = ((Om[row * LDO + c] + Om[(kMT + row) * LDO + c]) +
-                (Om[(2 * kMT + row) * LDO + c] + Om[(3 * kMT + row) * LDO + c])) * a.scale;
+    for (int c = sub; c < a.d; c += 8) {
+      float acc = (Om[row * LDO + c] + Om[(kMT + row) * LDO + c]) +
+                  (Om[(2 * kMT + row) * LDO + c] + Om[(3 * kMT + row) * LDO + c]);
+      if (NW == 8)
+        acc += (Om[(4 * kMT + row) * LDO + c] + Om[(5 * kMT + row) * LDO + c]) +
+               (Om[(6 * kMT + row) * LDO + c] + Om[(7 * kMT + row) * LDO + c]);
+      dqp[c] = acc * a.scale;
+    }
   }
 }
 
@@ -541,6 +554,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnArgs a) {
   }
 }
 
+// BTR_ATTN_WAVES=4: never the eight-wave form (read per call: the tests toggle it).  Measured at
+// the decoder's shapes (4 x 8 heads, d = 36; tools/attn_bench.py): 256 queries x 1 024 keys forward
+// 45.3 -> 37.3 us, 256 x 256 16.8 -> 17.5 (one key tile per wave: nothing to overlap)
+bool wide_waves(long long workgroups, int lk) {
+  const char *e = getenv("BTR_ATTN_WAVES");
+  if (e && e[0] == '4') return false;
+  return workgroups <= 512 && lk >= 16 * kMT;
+}
+
 // 16-byte loads of the q / k / v / dout rows are possible
 bool vec_ok(const AttnArgs &a) {
   auto al = [](const void *p) { return p == nullptr || ((size_t)p & 15) == 0; };
@@ -601,10 +623,17 @@ int btr::attention_fwd_strided(int lq, int lk, int b, int h, int d, const float 
   hipStream_t s = as_stream(stream);
   {
     const bool vec = vec_ok(a);
+    // eight waves where the grid leaves CUs a single workgroup (<= 2 per CU) and every wave
+    // still gets a key tile
+    const bool wide = wide_waves((long long)grid.x * grid.y, lk);
 #define BTR_ATTN_M(KS, NT)                                                                   \
   do {                                                                                       \
-    if (vec) hipLaunchKernelGGL((attn_fwd_mfma_kernel<KS, NT, true>), grid, dim3(256), 0, s, a); \
-    else hipLaunchKernelGGL((attn_fwd_mfma_kernel<KS, NT, false>), grid, dim3(256), 0, s, a);    \
+    if (vec && wide)                                                                         \
+      hipLaunchKernelGGL((attn_fwd_mfma_kernel<KS, NT, true, 8>), grid, dim3(512), 0, s, a); \
+    else if (vec)                                                                            \
+      hipLaunchKernelGGL((attn_fwd_mfma_kernel<KS, NT, true, 4>), grid, dim3(256), 0, s, a); \
+    else                                                                                     \
+      hipLaunchKernelGGL((attn_fwd_mfma_kernel<KS, NT, false, 4>), grid, dim3(256), 0, s, a); \
   } while (0)
     if (d <= 16) BTR_ATTN_M(8, 1);
     else if (d <= 32) BTR_ATTN_M(16, 1);
@@ -658,13 +687,20 @@ int btr::attention_bwd_strided(int lq, int lk, int b, int h, int d, const float 
   const dim3 gq(cdiv(lq, kMT), b * h), gk(cdiv(lk, kMT), b * h);
   {
     const bool vec = vec_ok(a);
+    // (the eight-wave form of the dQ kernel measured no faster inside the decoder stack: 3.59
+    // against 3.56 ms per backward; BTR_ATTN_WAVES=8 selects it)
+    const char *we = getenv("BTR_ATTN_WAVES");
+    const bool wide = we && we[0] == '8' && wide_waves((long long)gq.x * gq.y, lk);
 #define BTR_ATTN_M(KS, NT)                                                                     \
   do {                                                                                         \
     if (vec) {                                                                                 \
-      hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<KS, NT, true>), gq, dim3(256), 0, s, a);     \
+      if (wide)                                                                                \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<KS, NT, true, 8>), gq, dim3(512), 0, s, a); \
+      else                                                                                     \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<KS, NT, true, 4>), gq, dim3(256), 0, s, a); \
       hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<KS, NT, true>), gk, dim3(256), 0, s, a);    \
     } else {                                                                                   \
-      hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<KS, NT, false>), gq, dim3(256), 0, s, a);    \
+      hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<KS, NT, false, 4>), gq, dim3(256), 0, s, a); \
       hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<KS, NT, false>), gk, dim3(256), 0, s, a);   \
     }                                                                                          \
   } while (0)

@@ -19,7 +19,9 @@ for db in sys.argv[2:]:
             "select kernel_name, grid_size, counter_name, avg(value), avg(duration), count(*) "
             "from counters_collection where kernel_name like ? group by kernel_name, grid_size, "
             "counter_name", ('%' + pat + '%',)):
-        short = name.split('(')[0].replace('void ', '').replace('btr::', '')
+        import re
+        m = re.search(r'(\w+_kernel(<[^>]*>)?)', name)
+        short = m.group(1) if m else name.split('(')[0].replace('void ', '').replace('btr::', '')
         agg.setdefault((short, grid), {'n': n}).setdefault('dur', dur)
         agg[(short, grid)][cn] = v
 print("| kernel | grid | us (profiled) | waves | wait_any | wait_inst | active | lds_stall | "
