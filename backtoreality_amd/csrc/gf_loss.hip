@@ -295,16 +295,21 @@ __global__ __launch_bounds__(256) void gf_head_decode_kernel(DecodeArgs a) {
 // ~40 element-wise / reduction launches forward and ~30 backward as torch ops on 4 096 floats;
 // here ONE workgroup computes the value and d value / d x for a unit upstream gradient (fixed
 // summation order: thread-strided partial sums, wave shuffles, four waves in order).
-__global__ __launch_bounds__(256) void focal_sum_kernel(int n, const float *__restrict__ x,
+__global__ __launch_bounds__(256) void focal_sum_kernel(int n, int period,
+                                                        const float *__restrict__ x,
                                                         const long long *__restrict__ label,
                                                         float w, float scale, float gamma,
                                                         float alpha, float *__restrict__ out,
                                                         float *__restrict__ grad) {
+  // workgroup g: elements [g n, (g + 1) n) of x, their labels label[i % period] (the same labels
+  // for every group: one objectness target for all prediction heads)
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long base = (long long)blockIdx.x * n;
   float acc = 0.f;
-  for (int i = tid; i < n; i += 256) {
-    const float xi = x[i], t = (float)label[i];
+  for (int j = tid; j < n; j += 256) {
+    const long long i = base + j;
+    const float xi = x[i], t = (float)label[i % period];
     const float p = 1.f / (1.f + expf(-xi));
     const float a = t * alpha + (1.f - t) * (1.f - alpha);
     const float pt = t * (1.f - p) + (1.f - t) * p;
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void focal_sum_kernel(int n, const float *__re
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
   if (lane == 0) red[wave] = acc;
   __syncthreads();
-  if (tid == 0) out[0] = scale * (((red[0] + red[1]) + red[2]) + red[3]);
+  if (tid == 0) out[blockIdx.x] = scale * (((red[0] + red[1]) + red[2]) + red[3]);
 }
 
 }  // namespace
@@ -377,14 +382,16 @@ int btr_gf_loss_fwd(const btr_gf_loss_t *dp, const float *const *heads, const fl
   return check_launch("gf_loss_fwd");
 }
 
-// value[0] = scale * sum_i focal(x_i, label_i) * w and grad[i] = d value / d x_i (unit upstream
-// gradient); label in {0, 1}
-int btr_focal_sum(int n, const float *x, const long long *label, float w, float scale,
-                  float gamma, float alpha, float *value, float *grad, btr_stream_t stream) {
-  if (n <= 0) return BTR_OK;
-  BTR_REQUIRE(x && label && value && grad, "focal_sum: null pointer");
-  hipLaunchKernelGGL(focal_sum_kernel, dim3(1), dim3(256), 0, as_stream(stream), n, x, label, w,
-                     scale, gamma, alpha, value, grad);
+// value[g] = scale * sum over group g's n elements of focal(x_i, label_{i % period}) * w and
+// grad[i] = d value[g(i)] / d x_i (unit upstream gradient); label in {0, 1}; x holds groups * n
+// elements
+int btr_focal_sum(int groups, int n, int period, const float *x, const long long *label, float w,
+                  float scale, float gamma, float alpha, float *value, float *grad,
+                  btr_stream_t stream) {
+  if (n <= 0 || groups <= 0) return BTR_OK;
+  BTR_REQUIRE(x && label && value && grad && period > 0, "focal_sum: null pointer");
+  hipLaunchKernelGGL(focal_sum_kernel, dim3(groups), dim3(256), 0, as_stream(stream), n, period,
+                     x, label, w, scale, gamma, alpha, value, grad);
   return check_launch("focal_sum");
 }
 

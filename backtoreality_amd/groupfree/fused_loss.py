@@ -146,36 +146,42 @@ def heads_loss(end_points, config, prefixes, coefs, deltas, mean_size):
 
 
 class FusedFocalSum(Function):
-    """scale * sum(sigmoid_focal_loss(logits, label) * w) over all points as one launch each way
-    (csrc/gf_loss.hip focal_sum_kernel): logits (n,) f32, label (n,) i64 in {0, 1}."""
+    """scale * sum(sigmoid_focal_loss(logits, label) * w) per group as one launch each way
+    (csrc/gf_loss.hip focal_sum_kernel): logits (groups, n) f32, label (n,) i64 in {0, 1} shared
+    by the groups -> (groups,) sums."""
 
     @staticmethod
     def forward(ctx, logits, label, w, scale, gamma, alpha):
-        x = logits.contiguous().view(-1)
+        groups = logits.shape[0]
+        x = logits.contiguous().view(groups, -1)
         label = label.contiguous().view(-1)
-        out = torch.empty((1,), dtype=torch.float32, device=x.device)
+        n = x.shape[1]
+        assert label.numel() == n
+        out = torch.empty((groups,), dtype=torch.float32, device=x.device)
         grad = torch.empty_like(x)
         with _ext._on(x) as d:
-            _ext._call(_lib.btr_focal_sum, x.numel(), _ext._p(x), _ext._p(label), float(w),
+            _ext._call(_lib.btr_focal_sum, groups, n, n, _ext._p(x), _ext._p(label), float(w),
                        float(scale), float(gamma), float(alpha), _ext._p(out), _ext._p(grad),
                        _ext._stream(d))
         ctx.shape = logits.shape
         ctx.save_for_backward(grad)
         ctx.set_materialize_grads(False)
-        return out[0]
+        return out
 
     @staticmethod
     def backward(ctx, gout):
         if gout is None:
             return (None,) * 6
         (grad,) = ctx.saved_tensors
-        return (grad * gout).view(ctx.shape), None, None, None, None, None
+        return (grad * gout.view(-1, 1)).view(ctx.shape), None, None, None, None, None
 
 
 def focal_sum_fusable(logits, label):
     return enabled() and logits.is_cuda and logits.dtype == torch.float32 and \
-        label.dtype == torch.int64 and logits.numel() == label.numel()
+        label.dtype == torch.int64 and label.numel() > 0 and \
+        logits.numel() % label.numel() == 0
 
 
 def focal_sum(logits, label, w, scale, gamma=2.0, alpha=0.25):
+    """logits (groups, ...) with label.numel() elements per group -> (groups,) sums."""
     return FusedFocalSum.apply(logits, label, w, scale, gamma, alpha)

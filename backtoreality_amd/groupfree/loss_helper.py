@@ -86,7 +86,7 @@ def compute_points_obj_cls_loss_hard_topk(end_points, topk):
     if fused_loss.focal_sum_fusable(logits, label) and K > 0:
         # every label is 0 or 1, so the weights (label >= 0) / count are 1 / K for every point:
         # the focal terms, their sum and its gradient as one launch each way
-        return fused_loss.focal_sum(logits.reshape(B, K), label, 1.0 / K, 1.0 / B)
+        return fused_loss.focal_sum(logits.reshape(1, B * K), label, 1.0 / K, 1.0 / B)[0]
     weights = (label >= 0).float()
     weights = weights / torch.clamp(weights.sum(dim=1, keepdim=True), min=1.0)
     loss = sigmoid_focal_loss(logits.view(B, K, 1), label.unsqueeze(-1).float(), weights)
@@ -269,6 +269,8 @@ def compute_points_obj_cls_loss_hard_topk_weak(end_points, topk):
     end_points['points_hard_topk%d_pos_ratio' % topk] = torch.sum(label.float()) / float(total)
     end_points['points_hard_topk%d_neg_ratio' % topk] = \
         1 - end_points['points_hard_topk%d_pos_ratio' % topk]
+    if fused_loss.focal_sum_fusable(logits, label) and K > 0:   # (as the fully supervised form)
+        return fused_loss.focal_sum(logits.reshape(1, B * K), label, 1.0 / K, 1.0 / B)[0]
     weights = (label >= 0).float()
     weights = weights / torch.clamp(weights.sum(dim=1, keepdim=True), min=1.0)
     loss = sigmoid_focal_loss(logits.view(B, K, 1), label.unsqueeze(-1).float(), weights)
@@ -288,10 +290,14 @@ def compute_objectness_loss_based_on_query_points_weak(end_points, num_decoder_l
     weights = mask / torch.clamp(mask.sum(dim=1, keepdim=True), min=1.0)
     prefixes = head_prefixes(num_decoder_layers)
     scores = _stack(end_points, prefixes, 'objectness_scores')
-    loss = sigmoid_focal_loss(scores.reshape(-1, K, 1),
-                              label.unsqueeze(-1).float().repeat(len(prefixes), 1, 1),
-                              weights.repeat(len(prefixes), 1))
-    loss = loss.view(len(prefixes), -1).sum(1) / B
+    if fused_loss.focal_sum_fusable(scores, label) and K > 0:
+        # (every weight is 1 / K: one launch for the seven heads' sums and their gradient)
+        loss = fused_loss.focal_sum(scores.reshape(len(prefixes), B * K), label, 1.0 / K, 1.0 / B)
+    else:
+        loss = sigmoid_focal_loss(scores.reshape(-1, K, 1),
+                                  label.unsqueeze(-1).float().repeat(len(prefixes), 1, 1),
+                                  weights.repeat(len(prefixes), 1))
+        loss = loss.view(len(prefixes), -1).sum(1) / B
     for h, prefix in enumerate(prefixes):
         end_points[prefix + 'objectness_label'] = label
         end_points[prefix + 'objectness_mask'] = weights   # (normalised in place upstream)

@@ -924,11 +924,15 @@ int btr_gf_loss_fwd(const btr_gf_loss_t *d, const float *const *heads, const flo
 /* ---- GroupFree3D: objectness of the seed points (csrc/gf_loss.hip) -----------------------------
  * reference: detection/GroupFree3D/models/loss_helper.py:17-78 (compute_points_obj_cls_loss_hard_topk)
  * with SigmoidFocalClassificationLoss (losses.py:21-81), after the labels are made:
- *   value[0] = scale * sum_i a_i pt_i^gamma bce_i w,   grad[i] = d value / d x_i
+ *   value[g] = scale * sum_{i in group g} a_i pt_i^gamma bce_i w,   grad[i] = d value[g(i)] / d x_i
  * (p = sigmoid(x), a = t alpha + (1-t)(1-alpha), pt = t(1-p) + (1-t)p, bce = max(x,0) - x t +
- * log1p(exp(-|x|)), t = label in {0, 1}); one launch instead of ~70 element-wise ones. */
-int btr_focal_sum(int n, const float *x, const long long *label, float w, float scale,
-                  float gamma, float alpha, float *value, float *grad, btr_stream_t stream);
+ * log1p(exp(-|x|)), t = label[i % period] in {0, 1}); x: groups * n logits, group g = elements
+ * [g n, (g+1) n) -- one group for the seed points, one per prediction head for the query points'
+ * objectness of the weakly supervised branch (loss_helper.py:416-476: the same labels for every
+ * head, period = n); one launch instead of ~70 element-wise ones. */
+int btr_focal_sum(int groups, int n, int period, const float *x, const long long *label, float w,
+                  float scale, float gamma, float alpha, float *value, float *grad,
+                  btr_stream_t stream);
 
 /* ---- GroupFree3D: decode of one PredictHead's raw output (csrc/gf_loss.hip) --------------------
  * reference: detection/GroupFree3D/models/modules.py:233-262 and the query-position bookkeeping of

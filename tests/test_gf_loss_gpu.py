@@ -117,9 +117,34 @@ def test_focal_sum_matches_the_torch_composition(B, K):
     (ref * 1.7).backward()
     b = logits.clone().requires_grad_(True)
     assert fused_loss.focal_sum_fusable(b, label)
-    out = fused_loss.focal_sum(b.reshape(B, K), label, 1.0 / K, 1.0 / B)
+    out = fused_loss.focal_sum(b.reshape(1, B * K), label, 1.0 / K, 1.0 / B)[0]
     (out * 1.7).backward()
     assert abs(float(out) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-9
     err = (a.grad - b.grad).abs().max().item() / a.grad.abs().max().item()
     assert err < 1e-5, err
     assert torch.isfinite(b.grad).all()
+
+
+def test_focal_sum_per_head_matches_the_torch_composition():
+    """The weakly supervised branch's objectness of the query points (loss_helper.py:416-476): one
+    label per query for all seven heads, one sum per head."""
+    dev = torch.device("cuda:0")
+    H, B, K = 7, 4, 256
+    g = torch.Generator().manual_seed(11)
+    scores = (torch.randn(H, B, K, 1, generator=g) * 3).to(dev)
+    label = (torch.rand(B, K, generator=g) < 0.3).long().to(dev)
+    coef = torch.linspace(0.5, 2.0, H, device=dev)
+    a = scores.clone().requires_grad_(True)
+    mask = torch.ones((B, K), device=dev)
+    weights = mask / torch.clamp(mask.sum(dim=1, keepdim=True), min=1.0)
+    ref = loss_helper.sigmoid_focal_loss(a.reshape(-1, K, 1),
+                                         label.unsqueeze(-1).float().repeat(H, 1, 1),
+                                         weights.repeat(H, 1)).view(H, -1).sum(1) / B
+    (ref * coef).sum().backward()
+    b = scores.clone().requires_grad_(True)
+    assert fused_loss.focal_sum_fusable(b, label)
+    out = fused_loss.focal_sum(b.reshape(H, B * K), label, 1.0 / K, 1.0 / B)
+    (out * coef).sum().backward()
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-9)
+    err = (a.grad - b.grad).abs().max().item() / a.grad.abs().max().item()
+    assert err < 1e-5, err
