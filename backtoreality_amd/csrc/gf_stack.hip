@@ -169,12 +169,17 @@ struct Lanes {
   hipStream_t main = nullptr;
   SideLane *lane = nullptr;
   uint64_t key = 0;
-  // BTR_GF_LANES=1 | 2 | 3 (default 3): how many streams the three lanes are mapped onto (the
-  // events order them on any number; 1 = replayed graphs on the caller's stream alone)
+  // BTR_GF_LANES=1 | 2 | 3 (default 2): how many streams the three lanes are mapped onto (the
+  // events order them on any number; 1 = replayed graphs on the caller's stream alone).  Two and
+  // three measure the same on a quiet process (8.66 ms per GroupFree3D step), but with three the
+  // process holds five streams -- the caller's, the sampling prefetch, two side lanes, the capture
+  // stream -- on four hardware queues, and a lane that lands on the prefetch stream's queue waits
+  // behind a 2.2 ms FPS kernel: runs of the same build spread 8.66 - 9.25 ms with three, 8.66 -
+  // 8.67 with two (profiles/r06_gf_lanes_spread.txt)
   static int count() {
     static const int n = [] {
       const char *e = getenv("BTR_GF_LANES");
-      const int v = e ? atoi(e) : 3;
+      const int v = e ? atoi(e) : 2;
       return v < 1 ? 1 : (v > 3 ? 3 : v);
     }();
     return n;
@@ -183,6 +188,7 @@ struct Lanes {
     if (which >= count()) which = count() - 1;
     return lane && which ? lane->s[which - 1] : main;
   }
+  hipStream_t other_side() const { return count() >= 3 ? lane->s[1] : lane->s[0]; }
   // BTR_LANE_DEBUG=1: an event pair around every segment; report() waits for the lanes and prints
   // when each segment started and how long it took on the GPU (a profiler's interception makes
   // the host the bottleneck, and the overlap it then shows is the host's, not the queues')
@@ -221,7 +227,7 @@ struct Lanes {
   void report(const char *what) const {
     if (!debug() || !lane || marks.empty()) return;
     (void)hipStreamSynchronize(lane->s[0]);
-    (void)hipStreamSynchronize(lane->s[1]);
+    (void)hipStreamSynchronize(other_side());
     (void)hipStreamSynchronize(main);
     fprintf(stderr, "lanes of %s (us after the first segment's start: start + duration)\n", what);
     for (const Mark &m : marks) {
@@ -246,7 +252,7 @@ Lanes lanes_of(hipStream_t hs, uint64_t key) {
   const bool outer = hipStreamIsCapturing(hs, &st) == hipSuccess &&
                      st != hipStreamCaptureStatusNone;
   if (graphs_enabled() && !outer && !graph_capturing() && !gemm_trace_active())
-    l.lane = side_lane(hs);
+    l.lane = side_lane(hs, Lanes::count() >= 3 ? 2 : 1);
   return l;
 }
 

@@ -196,7 +196,7 @@ int graph_run(uint64_t key, hipStream_t stream, const std::function<int(hipStrea
 
 // A side stream of a caller's stream, with events for the hand-overs, owned by the library and
 // kept for the process's lifetime (one per device and caller stream).
-SideLane *side_lane(hipStream_t main) {
+SideLane *side_lane(hipStream_t main, int nstreams) {
   static std::mutex mu;
   static std::unordered_map<uint64_t, SideLane *> lanes;
   int dev = 0;
@@ -204,12 +204,21 @@ SideLane *side_lane(hipStream_t main) {
   const uint64_t k = ((uint64_t)(uintptr_t)main << 6) ^ (uint64_t)dev;
   std::lock_guard<std::mutex> lock(mu);
   auto it = lanes.find(k);
-  if (it != lanes.end()) return it->second;
+  if (it != lanes.end()) {
+    SideLane *l = it->second;   // (a second stream asked for later: made then)
+    if (l && nstreams >= 2 && !l->s[1] &&
+        hipStreamCreateWithFlags(&l->s[1], hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    return l;
+  }
   SideLane *l = new SideLane();
   // (stream priorities measured no different: lowest 3.52 ms, default 3.47, highest 3.51 for the
   // decoder stack's backward, profiles/r06_gf_lanes.txt)
   bool ok = hipStreamCreateWithFlags(&l->s[0], hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&l->s[1], hipStreamNonBlocking) == hipSuccess;
+            (nstreams < 2 ||
+             hipStreamCreateWithFlags(&l->s[1], hipStreamNonBlocking) == hipSuccess);
   for (int i = 0; ok && i < SideLane::kEvents; ++i)
     ok = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) {

@@ -30,10 +30,11 @@ int graph_run(uint64_t key, hipStream_t stream, const std::function<int(hipStrea
 uint64_t hash_bytes(uint64_t h, const void *p, size_t n);
 struct SideLane {
   static constexpr int kEvents = 4 * BTR_GF_MAX_DECODER_LAYERS + 2;
-  hipStream_t s[2] = {};   // two side streams
+  hipStream_t s[2] = {};   // side streams (the second only when asked for)
   hipEvent_t ev[kEvents] = {};
 };
-SideLane *side_lane(hipStream_t main);   // the library's side streams of `main` (NULL: none)
+// the library's side stream(s) of `main` (nstreams 1 or 2; NULL: none)
+SideLane *side_lane(hipStream_t main, int nstreams);
 bool graph_capturing();     // this host thread is inside graph_run's capture
 bool graphs_enabled();
 // sa_mlp.hip: btr_gemm_trace_begin() is in effect (its event pairs do not belong in a graph)
