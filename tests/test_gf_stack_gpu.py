@@ -139,6 +139,7 @@ def _several_steps(cuda, monkeypatch, graphs, n=5, cls=None):
     a top-k of its output, so two runs that update would part ways for reasons outside the
     stack.)"""
     monkeypatch.setenv("BTR_FUSED_GF_STACK", "1")
+    monkeypatch.setenv("BTR_GF_SLOTS", "1")
     monkeypatch.setenv("BTR_GRAPHS", "1" if graphs else "0")
     monkeypatch.setattr(fused_attention, "_calls", itertools.count())
     cfg = config.scannet_md40()
