@@ -70,7 +70,24 @@ struct GfDims {
   int b, p, k2, nh, ns, nc, heads, c;
   float w_obj, w_box, w_sem;   // 10 * coef / (num_decoder_layers + 1)
   float d_center, d_heading, d_size;
+  int weak;   // centre labels only (loss_helper.py:479-554): see gf_heads_kernel
 };
+
+// #positives per scene from given labels (the weakly supervised branch makes its labels itself)
+__global__ __launch_bounds__(256) void gf_npos_kernel(int P, const long long *__restrict__ label,
+                                                      float *__restrict__ npos_part) {
+  __shared__ int red[256];
+  const int b = blockIdx.x;
+  int cnt = 0;
+  for (int k = threadIdx.x; k < P; k += 256) cnt += label[(size_t)b * P + k] != 0 ? 1 : 0;
+  red[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) npos_part[b] = (float)red[0];
+}
 
 // log-sum-exp cross entropy of t[o .. o+n) (LDS column `lane`) with target `tg`; the scores are
 // replaced by coef * (softmax - onehot)
@@ -129,6 +146,22 @@ __global__ __launch_bounds__(64) void gf_heads_kernel(
       t[0][lane] = d.w_obj / (float)d.b * aw * w * (2.f * pt * dpt * bce + pt * pt * (pr - lab));
     }
     const float cb = d.w_box * lab / npos;   // box terms: masked by the label, / #positives
+    const int o_hc = 4, o_hr = 4 + d.nh, o_sc = 4 + 2 * d.nh, o_sr = o_sc + d.ns;
+    const int o_sem = o_sr + 3 * d.ns;
+    const int sc = (int)size_class_label[ga];
+    if (d.weak) {
+      // ---- weak labels: the centre with a dead zone of 5 % of the class's mean size
+      // (clamp(smooth-L1 - margin, min = 0) per component; autograd's clamp passes the gradient
+      // at 0), the size class and the semantic class; no heading, no size residual
+      for (int j = 0; j < 3; ++j) {
+        const float e = center_label[ga * 3 + j] - (base_xyz[q * 3 + j] + t[1 + j][lane]);
+        const float v = sl1(e, d.d_center) - 0.05f * mean_size[sc * 3 + j];
+        term[1] += fmaxf(v, 0.f) * lab;
+        t[1 + j][lane] = v >= 0.f ? -cb * sl1_grad(e, d.d_center) : 0.f;
+      }
+      for (int i = 0; i < 2 * d.nh; ++i) t[o_hc + i][lane] = 0.f;
+      for (int i = 0; i < 3 * d.ns; ++i) t[o_sr + i][lane] = 0.f;
+    } else {
     // ---- centre (smooth-L1 of gt - (base + residual))
     for (int j = 0; j < 3; ++j) {
       const float e = center_label[ga * 3 + j] - (base_xyz[q * 3 + j] + t[1 + j][lane]);
@@ -136,8 +169,6 @@ __global__ __launch_bounds__(64) void gf_heads_kernel(
       t[1 + j][lane] = -cb * sl1_grad(e, d.d_center);
     }
     // ---- heading class / residual
-    const int o_hc = 4, o_hr = 4 + d.nh, o_sc = 4 + 2 * d.nh, o_sr = o_sc + d.ns;
-    const int o_sem = o_sr + 3 * d.ns;
     const int hc = (int)heading_class_label[ga];
     {
       const float pred = t[o_hr + hc][lane];
@@ -147,8 +178,7 @@ __global__ __launch_bounds__(64) void gf_heads_kernel(
       t[o_hr + hc][lane] = cb * d.d_heading * sl1_grad(e, d.d_heading);
     }
     term[2] = ce_inplace(t, lane, o_hc, d.nh, hc, 0.1f * cb) * lab;
-    // ---- size class / residual
-    const int sc = (int)size_class_label[ga];
+    // ---- size residual
     {
       float g3[3];
       for (int j = 0; j < 3; ++j) {
@@ -160,6 +190,8 @@ __global__ __launch_bounds__(64) void gf_heads_kernel(
       for (int i = 0; i < 3 * d.ns; ++i) t[o_sr + i][lane] = 0.f;
       for (int j = 0; j < 3; ++j) t[o_sr + 3 * sc + j][lane] = g3[j];
     }
+    }
+    // ---- size class
     term[4] = ce_inplace(t, lane, o_sc, d.ns, sc, 0.1f * cb) * lab;
     // ---- semantic class
     term[6] = ce_inplace(t, lane, o_sem, d.nc, (int)sem_cls_label[ga], d.w_sem * lab / npos) * lab;
@@ -364,7 +396,7 @@ int btr_gf_loss_fwd(const btr_gf_loss_t *dp, const float *const *heads, const fl
               kMaxC);
   hipStream_t hs = as_stream(stream);
   GfDims d{s.b, s.p, s.k2, s.nh, s.ns, s.nc, s.heads, s.c, s.w_obj, s.w_box, s.w_sem,
-           s.center_delta, s.heading_delta, s.size_delta};
+           s.center_delta, s.heading_delta, s.size_delta, 0};
   HeadPtrs hp{};
   for (int i = 0; i < s.heads; ++i) {
     BTR_REQUIRE(heads[i], "gf_loss_fwd: head %d is null", i);
@@ -380,6 +412,43 @@ int btr_gf_loss_fwd(const btr_gf_loss_t *dp, const float *const *heads, const fl
                      size_residual_label, sem_cls_label, mean_size, part, grads);
   hipLaunchKernelGGL(gf_final_kernel, dim3(1), dim3(64), 0, hs, d, gx, part, npos_part, stats);
   return check_launch("gf_loss_fwd");
+}
+
+// The weakly supervised per-head loss (centre labels only): objectness_label / object_assignment
+// (b, p) are INPUTS (the caller made them: nearest labelled centre, positive within 0.3 m).
+int btr_gf_loss_weak_fwd(const btr_gf_loss_t *dp, const float *const *heads,
+                         const float *base_xyz, const long long *objectness_label,
+                         const long long *object_assignment, const float *center_label,
+                         const long long *size_class_label, const long long *sem_cls_label,
+                         const float *mean_size, float *npos_part, float *part, float *stats,
+                         float *grads, btr_stream_t stream) {
+  BTR_REQUIRE(dp && heads && base_xyz && objectness_label && object_assignment && center_label &&
+                  size_class_label && sem_cls_label && mean_size && npos_part && part && stats &&
+                  grads,
+              "gf_loss_weak_fwd: null pointer");
+  const btr_gf_loss_t &s = *dp;
+  BTR_REQUIRE(s.b > 0 && s.b < 65536 && s.p > 0 && s.k2 > 0 && s.nh > 0 && s.ns > 0 && s.nc > 0 &&
+                  s.heads >= 1 && s.heads <= kMaxHeads,
+              "gf_loss_weak_fwd: bad sizes");
+  BTR_REQUIRE(s.c == 4 + 2 * s.nh + 4 * s.ns + s.nc && s.c <= kMaxC,
+              "gf_loss_weak_fwd: %d channels for nh=%d ns=%d nc=%d (max %d)", s.c, s.nh, s.ns,
+              s.nc, kMaxC);
+  hipStream_t hs = as_stream(stream);
+  GfDims d{s.b, s.p, s.k2, s.nh, s.ns, s.nc, s.heads, s.c, s.w_obj, s.w_box, s.w_sem,
+           s.center_delta, s.heading_delta, s.size_delta, 1};
+  HeadPtrs hp{};
+  for (int i = 0; i < s.heads; ++i) {
+    BTR_REQUIRE(heads[i], "gf_loss_weak_fwd: head %d is null", i);
+    hp.p[i] = heads[i];
+  }
+  hipLaunchKernelGGL(gf_npos_kernel, dim3(s.b), dim3(256), 0, hs, s.p, objectness_label,
+                     npos_part);
+  const int gx = cdiv(s.p, 64);
+  hipLaunchKernelGGL(gf_heads_kernel, dim3(gx, s.b, s.heads), dim3(64), 0, hs, d, hp, base_xyz,
+                     objectness_label, object_assignment, npos_part, center_label, nullptr,
+                     nullptr, size_class_label, nullptr, sem_cls_label, mean_size, part, grads);
+  hipLaunchKernelGGL(gf_final_kernel, dim3(1), dim3(64), 0, hs, d, gx, part, npos_part, stats);
+  return check_launch("gf_loss_weak_fwd");
 }
 
 // value[g] = scale * sum over group g's n elements of focal(x_i, label_{i % period}) * w and

@@ -117,6 +117,107 @@ class FusedHeadsLoss(Function):
         return (None,) * ctx.n_static + tuple(g.unbind(0))
 
 
+_WEAK_LABELS = (('center_label', torch.float32), ('size_class_label', torch.int64),
+                ('sem_cls_label', torch.int64))
+
+
+def can_fuse_weak(end_points, config, prefixes, center_kind):
+    """can_fuse for the weakly supervised loss: the centre, size-class and semantic labels only."""
+    if not enabled() or center_kind != 'smoothl1' or len(prefixes) > 8:
+        return False
+    heads = [end_points.get(p + HEAD_KEY) for p in prefixes]
+    if any(h is None or not h.is_cuda or h.dtype != torch.float32 or h.dim() != 3 for h in heads):
+        return False
+    c = 4 + 2 * config.num_heading_bin + 4 * config.num_size_cluster + config.num_class
+    if any(tuple(h.shape) != tuple(heads[0].shape) for h in heads) or heads[0].shape[1] != c or \
+            c > 192 or end_points['center_label'].shape[2] != 3:
+        return False
+    base0 = end_points.get(prefixes[0] + 'base_xyz')
+    for p, h in zip(prefixes, heads):
+        if end_points.get(p + 'base_xyz') is not base0:
+            return False
+        tied = getattr(h, '_btr_head_views', None)
+        if tied is None or tied[0] != h._version or tied[1] is not base0 or \
+                any(end_points.get(p + k) is not v for k, v in tied[2].items()) or \
+                end_points.get(p + 'center') is None:
+            return False
+    return all(k in end_points and end_points[k].is_cuda and end_points[k].dtype == dt
+               for k, dt in _WEAK_LABELS)
+
+
+class FusedWeakHeadsLoss(Function):
+    """(dims, base_xyz, label, assignment, mean_size, center_label, size_class_label,
+    sem_cls_label, *heads) -> (weighted total, stats): the weakly supervised per-head loss
+    (csrc/gf_loss.hip, btr_gf_loss_weak_fwd) and its gradient w.r.t. the raw head outputs."""
+
+    @staticmethod
+    def forward(ctx, dims, base_xyz, label, assign, mean_size, center_label, size_class_label,
+                sem_cls_label, *heads):
+        nh, ns, nc, w_obj, w_box, w_sem, center_delta = dims
+        H = len(heads)
+        B, C, P = heads[0].shape
+        dev = heads[0].device
+        heads = [h.contiguous() for h in heads]
+        d = _ext.GfLoss()
+        d.b, d.p, d.k2, d.nh, d.ns, d.nc, d.heads, d.c = B, P, center_label.shape[1], nh, ns, nc, H, C
+        d.s1 = d.n = 1
+        d.w_obj, d.w_box, d.w_sem = w_obj, w_box, w_sem
+        d.center_delta, d.heading_delta, d.size_delta = center_delta, 1.0, 1.0
+        npos = torch.empty((B,), dtype=torch.float32, device=dev)
+        part = torch.empty((_lib.btr_gf_loss_part_floats(B, P, H),), dtype=torch.float32,
+                           device=dev)
+        stats = torch.empty((8 * H + 7,), dtype=torch.float32, device=dev)
+        grads = torch.empty((H, B, C, P), dtype=torch.float32, device=dev)
+        ptrs = (ctypes.c_void_p * H)(*[h.data_ptr() for h in heads])
+        with _ext._on(heads[0]) as dv:
+            _ext._call(_lib.btr_gf_loss_weak_fwd, ctypes.addressof(d), ctypes.addressof(ptrs),
+                       _p(base_xyz.contiguous()), _p(label.contiguous()), _p(assign.contiguous()),
+                       _p(center_label.contiguous()), _p(size_class_label.contiguous()),
+                       _p(sem_cls_label.contiguous()), _p(mean_size), _p(npos), _p(part),
+                       _p(stats), _p(grads), _ext._stream(dv))
+        ctx.n_static = 8
+        ctx.save_for_backward(grads)
+        ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
+        loss = torch.empty((), dtype=torch.float32, device=stats.device).set_(
+            stats.untyped_storage(), stats.storage_offset() + 8 * H + 6, (), ())
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, gtotal, *_unused):
+        grads, = ctx.saved_tensors
+        if gtotal is None:
+            return (None,) * (ctx.n_static + grads.shape[0])
+        g = grads * gtotal.to(torch.float32)
+        return (None,) * ctx.n_static + tuple(g.unbind(0))
+
+
+def weak_heads_loss(end_points, config, prefixes, coefs, center_delta, mean_size, label,
+                    assignment, weights):
+    """Fills the per-head entries of `end_points` like compute_objectness_loss_based_on_query_
+    points_weak + compute_center_and_sem_cls_loss and returns 10 / (L + 1) * (obj_coef * sum
+    objectness + box_coef * sum box + sem_coef * sum sem)."""
+    H = len(prefixes)
+    scale = 10.0 / H
+    dims = (config.num_heading_bin, config.num_size_cluster, config.num_class,
+            scale * coefs[0], scale * coefs[1], scale * coefs[2], float(center_delta))
+    heads = [end_points[p + HEAD_KEY] for p in prefixes]
+    total, stats = FusedWeakHeadsLoss.apply(
+        dims, end_points[prefixes[0] + 'base_xyz'], label, assignment, mean_size,
+        *[end_points[k] for k, _ in _WEAK_LABELS], *heads)
+    for h, prefix in enumerate(prefixes):
+        end_points[prefix + 'objectness_label'] = label
+        end_points[prefix + 'objectness_mask'] = weights
+        end_points[prefix + 'object_assignment'] = assignment
+        for j, name in ((0, 'objectness_loss'), (1, 'center_loss'), (4, 'size_cls_loss'),
+                        (6, 'box_loss'), (7, 'sem_cls_loss')):
+            end_points[prefix + name] = stats[8 * h + j]
+    end_points['sum_heads_objectness_loss'] = stats[8 * H]
+    end_points['sum_heads_box_loss'] = stats[8 * H + 1]
+    end_points['sum_heads_sem_cls_loss'] = stats[8 * H + 2]
+    return total
+
+
 def heads_loss(end_points, config, prefixes, coefs, deltas, mean_size):
     """Fills the per-head entries of `end_points` like the two reference functions and returns
     10 / (L + 1) * (obj_coef * sum objectness + box_coef * sum box + sem_coef * sum sem)."""

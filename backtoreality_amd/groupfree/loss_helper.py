@@ -361,6 +361,24 @@ def get_loss_weak(end_points, config, num_decoder_layers, query_points_generator
         end_points['query_points_generation_loss'] = gen_loss
     else:
         gen_loss = 0.0
+    prefixes = head_prefixes(num_decoder_layers)
+    if fused_loss.can_fuse_weak(end_points, config, prefixes, center_loss_type):
+        # the targets as the reference makes them (nearest labelled centre, positive within
+        # 0.3 m), then all heads' objectness / centre / size-class / semantic terms and their
+        # gradient in three launches (csrc/gf_loss.hip, weak mode)
+        xyz = end_points['query_points_xyz']
+        gt_center = end_points['center_label'][:, :, 0:3]
+        B, K = xyz.shape[:2]
+        d2 = torch.sum((xyz.unsqueeze(2) - gt_center.unsqueeze(1)) ** 2, dim=-1)      # (B,K,K2)
+        dist1, assignment = torch.min(d2, dim=2)
+        label = (torch.sqrt(dist1 + 1e-6) < 0.3).long()
+        weights = torch.full((B, K), 1.0 / K, device=xyz.device)
+        heads_total = fused_loss.weak_heads_loss(
+            end_points, config, prefixes, (obj_loss_coef, box_loss_coef, sem_cls_loss_coef),
+            center_delta, _mean_size(config, xyz.device), label, assignment, weights)
+        loss = query_points_generator_loss_coef * gen_loss * 10 + heads_total
+        end_points['loss'] = loss
+        return loss, end_points
     obj_sum, end_points = compute_objectness_loss_based_on_query_points_weak(end_points,
                                                                              num_decoder_layers)
     end_points['sum_heads_objectness_loss'] = obj_sum

@@ -151,6 +151,7 @@ _SIGNATURES = {
     # GroupFree3D per-head loss (csrc/gf_loss.hip, used by groupfree/fused_loss.py)
     "btr_gf_loss_part_floats": (_ci, [_ci, _ci, _ci]),
     "btr_gf_loss_fwd": (_ci, [_vp] * 21),
+    "btr_gf_loss_weak_fwd": (_ci, [_vp] * 14),
     "btr_focal_sum": (_ci, [_ci, _ci, _ci, _vp, _vp] + [ctypes.c_float] * 4 + [_vp, _vp, _vp]),
     "btr_gf_head_decode": (_ci, [_ci] * 4 + [_vp] + [ctypes.c_longlong] * 3 + [_vp] * 9),
     "btr_gemm_trace_begin": (None, []),

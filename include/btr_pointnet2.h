@@ -921,6 +921,20 @@ int btr_gf_loss_fwd(const btr_gf_loss_t *d, const float *const *heads, const flo
                     long long *object_assignment, float *npos_part, float *part, float *stats,
                     float *grads, btr_stream_t stream);
 
+/* The weakly supervised form (centre labels only; loss_helper.py:416-554:
+ * compute_objectness_loss_based_on_query_points_weak + compute_center_and_sem_cls_loss, smooth-L1):
+ * objectness_label / object_assignment (b, p) i64 are INPUTS here (nearest labelled centre,
+ * positive within 0.3 m: made by the caller); the centre term is clamp(smooth-L1 - 0.05 *
+ * mean_size[size class], min = 0) per component, the box term centre + 0.1 * size class, there is
+ * no heading or size-residual term (their statistics are 0, their gradients 0).  d->s1 / d->n and
+ * the heading / residual deltas are not read.  Outputs as btr_gf_loss_fwd. */
+int btr_gf_loss_weak_fwd(const btr_gf_loss_t *d, const float *const *heads,
+                         const float *base_xyz, const long long *objectness_label,
+                         const long long *object_assignment, const float *center_label,
+                         const long long *size_class_label, const long long *sem_cls_label,
+                         const float *mean_size, float *npos_part, float *part, float *stats,
+                         float *grads, btr_stream_t stream);
+
 /* ---- GroupFree3D: objectness of the seed points (csrc/gf_loss.hip) -----------------------------
  * reference: detection/GroupFree3D/models/loss_helper.py:17-78 (compute_points_obj_cls_loss_hard_topk)
  * with SigmoidFocalClassificationLoss (losses.py:21-81), after the labels are made:

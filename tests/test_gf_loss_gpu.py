@@ -148,3 +148,45 @@ def test_focal_sum_per_head_matches_the_torch_composition():
     assert torch.allclose(out, ref, rtol=1e-6, atol=1e-9)
     err = (a.grad - b.grad).abs().max().item() / a.grad.abs().max().item()
     assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("B,P,layers", [(4, 256, 6), (2, 100, 2)])
+def test_weak_heads_loss_and_gradient_match_the_torch_composition(B, P, layers, monkeypatch):
+    """get_loss_weak (centre labels only, loss_helper.py:416-606) through btr_gf_loss_weak_fwd
+    against the torch composition: every published term, the labels, the gradient of every
+    head's raw output (dead-zone centre term, no heading / size-residual gradient)."""
+    dev = torch.device("cuda:0")
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setenv("BTR_FUSED_GF_LOSS", "1" if fused else "0")
+        cfg, end, heads = _end_points(dev, B, P, layers, seed=5)
+        # query points near the labelled centres, so that a fair share is positive
+        centre = end['center_label'][:, :, 0:3]
+        pick = torch.randint(0, centre.shape[1], (B, P), device=dev)
+        end['query_points_xyz'] = torch.gather(centre, 1, pick.unsqueeze(2).expand(-1, -1, 3)) + \
+            torch.randn(B, P, 3, device=dev) * 0.2
+        end['seed_xyz'] = torch.rand(B, 1024, 3, device=dev) * 4 - 2
+        end['seeds_obj_cls_logits'] = torch.randn(B, 1, 1024, device=dev)
+        prefixes = loss_helper.head_prefixes(layers)
+        assert fused_loss.can_fuse_weak(end, cfg, prefixes, 'smoothl1') == fused
+        loss, end = loss_helper.get_loss_weak(
+            end, cfg, num_decoder_layers=layers, query_points_generator_loss_coef=0.8,
+            obj_loss_coef=0.1, box_loss_coef=1, sem_cls_loss_coef=0.1, query_points_obj_topk=4)
+        loss.backward()
+        out[fused] = (float(loss), end, [h.grad.clone() for h in heads])
+    (lf, ef, gf), (lt, et, gt) = out[True], out[False]
+    assert abs(lf - lt) <= 1e-5 * abs(lt), (lf, lt)
+    assert float(et['last_objectness_label'].float().mean()) > 0.05
+    for prefix in loss_helper.head_prefixes(layers):
+        assert torch.equal(ef[prefix + 'objectness_label'], et[prefix + 'objectness_label'])
+        assert torch.equal(ef[prefix + 'object_assignment'], et[prefix + 'object_assignment'])
+        assert torch.allclose(ef[prefix + 'objectness_mask'], et[prefix + 'objectness_mask'])
+        for key in ('objectness_loss', 'center_loss', 'size_cls_loss', 'box_loss', 'sem_cls_loss'):
+            a, b = float(ef[prefix + key]), float(et[prefix + key])
+            assert abs(a - b) <= 2e-5 * abs(b) + 1e-7, (prefix, key, a, b)
+    for key in ('sum_heads_objectness_loss', 'sum_heads_box_loss', 'sum_heads_sem_cls_loss'):
+        np.testing.assert_allclose(float(ef[key]), float(et[key]), rtol=2e-5)
+    for a, b in zip(gf, gt):
+        scale = float(b.abs().max())
+        assert scale > 0
+        assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
