@@ -104,6 +104,7 @@ int sum_into(hipStream_t s, long long n, const float *const *src, int count, flo
 struct BwdScratch {
   size_t layer[2];            // a decoder layer's own scratch, layers alternate (the side lane reads it)
   size_t head;                // the head chains' (lane 2, before the embedding chains)
+  size_t head_last;           // the last layer's head chain's (it runs on the main lane, beside them)
   size_t side;                // the position-embedding chains' (lane 2)
   size_t dhx[BTR_GF_MAX_DECODER_LAYERS];   // (b*pq, e) per layer: gradient of x[i] from head i
   size_t pair[2][2];          // (b*pq, e) x 2: d res1, d qp0 of a layer (their sum = d x[i-1]), ping-pong
@@ -126,6 +127,7 @@ BwdScratch bwd_scratch(const btr_gf_stack_t &d, const btr_gf_stack_plan_t &p) {
   s.layer[0] = b.take(layer);
   s.layer[1] = b.take(layer);
   s.head = b.take(head);
+  s.head_last = b.take(head);
   s.side = b.take(side);
   const size_t q = (size_t)d.b * d.pq * d.e, k = (size_t)d.b * d.pk * d.e;
   for (int i = 0; i < d.layers; ++i) s.dhx[i] = b.floats(q);
@@ -482,16 +484,20 @@ int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *p
   ln.signal(0, 0);
   ln.wait(0, 2);
   for (int i = L - 1; i >= 0; --i) {
-    BTR_TRY(ln.run(200 + i, 2, [&](hipStream_t bs) -> int {
+    // (the last layer's head chain is what the main lane starts from: on its own stream, without
+    // the hand-over; the others run beside it)
+    const int hl = i == L - 1 ? 0 : 2;
+    BTR_TRY(ln.run(200 + i, hl, [&](hipStream_t bs) -> int {
       if (dhead[i])
         return pm_chain_backward_rows(&d.head[i], &p.head[i], at_f(saved, p.s_x[i]), dhead[i],
                                       nullptr, nullptr, at_v(saved, p.s_head[i]),
                                       grads + p.g_head[i], nullptr, at_f(scratch, sc.dhx[i]),
-                                      at_v(scratch, sc.head), (btr_stream_t)bs);
+                                      at_v(scratch, i == L - 1 ? sc.head_last : sc.head),
+                                      (btr_stream_t)bs);
       (void)hipMemsetAsync(grads + p.g_head[i], 0, p.head[i].grads_floats * sizeof(float), bs);
       return check_launch("gf_stack_backward");
     }));
-    ln.signal(H(i), 2);
+    ln.signal(H(i), hl);
   }
   // what reaches x[i] from above: the pair (d res1, d qp0) of layer i+1, or the caller's gradient
   const float *up0 = dlast_bcp ? at_f(scratch, sc.dlast) : nullptr, *up1 = nullptr;
@@ -549,10 +555,13 @@ int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *p
                                             (btr_stream_t)bs);
       }));
     ln.signal(R(i), 1);
-    // ---- lane 2: the key rows' gradient, the two position-embedding chains
-    ln.wait(M(i), 2);
+    // ---- lane 2: the key rows' gradient, the two position-embedding chains.  (Layer 0's go onto
+    // the caller's stream: nothing is left for it to do but wait for the side lanes, and the
+    // parameter gradients of layer 0 run beside them instead of in front of them)
+    const int cl = i == 0 ? 0 : 2;
+    ln.wait(M(i), cl);
     if (reached)
-      BTR_TRY(ln.run(300 + i, 2, [&](hipStream_t bs) -> int {
+      BTR_TRY(ln.run(300 + i, cl, [&](hipStream_t bs) -> int {
         btr_stream_t st = (btr_stream_t)bs;
         BTR_TRY(decoder_layer_backward_parts(&d.layer[i], &p.layer[i], x_in, key_cl, qpos_cl,
                                              kpos_cl, nullptr, nullptr, nullptr, nullptr,
@@ -569,7 +578,7 @@ int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *p
                                          nullptr, at_v(scratch, sc.side), st));
         return check_launch("gf_stack_backward");
       }));
-    ln.signal(C(i), 2);
+    ln.signal(C(i), cl);
     if (reached) {
       up0 = out.dres1;
       up1 = out.dqp0;

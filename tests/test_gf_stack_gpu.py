@@ -228,3 +228,21 @@ def test_cached_coverage_checks_follow_the_modules(cuda, monkeypatch):
     assert not torch.equal(before['last_center'], after['last_center'])
     assert torch.allclose(after['last_center'] - after['last_base_xyz'],
                           torch.full_like(after['last_center'], 0.25), atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", ["2", "3"])
+def test_lanes_reproduce_every_pass(cuda, monkeypatch, lanes):
+    """A race between the decoder stack's lanes shows as a pass that differs from an earlier pass
+    over the same batch (no dropout, no updates: tools/gf_lanes_soak.py, shortened).  It caught
+    the one this code had: two head chains' backwards on two streams sharing one scratch."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BTR_GF_LANES=lanes, BTR_GRAPHS="1", BTR_GF_SLOTS="1",
+               BTR_FUSED_GF_STACK="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gf_lanes_soak.py"), "40"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "40 passes, 0 with a difference" in out.stdout
