@@ -669,7 +669,25 @@ int btr::attention_bwd_strided(int lq, int lk, int b, int h, int d, const float 
                                long long dkv_sb, float scale, float dropout_p,
                                unsigned long long seed, const long long *step,
                                btr_stream_t stream) {
+  return attention_bwd_strided_parts(lq, lk, b, h, d, q, q_sl, q_sb, k, v, kv_sl, kv_sb, out,
+                                     dout, o_sl, o_sb, lse, dsum, dq, dq_sl, dq_sb, dk, dv,
+                                     dkv_sl, dkv_sb, scale, dropout_p, seed, step,
+                                     kAttnBwdQ | kAttnBwdKV, stream);
+}
+
+// parts: kAttnBwdQ = the dQ kernel (it also writes dsum = rowsum(dO * O), which the other reads);
+// kAttnBwdKV = the dK / dV kernel -- after the first, on the same stream or one ordered behind it
+int btr::attention_bwd_strided_parts(int lq, int lk, int b, int h, int d, const float *q,
+                                     long long q_sl, long long q_sb, const float *k,
+                                     const float *v, long long kv_sl, long long kv_sb,
+                                     const float *out, const float *dout, long long o_sl,
+                                     long long o_sb, const float *lse, float *dsum, float *dq,
+                                     long long dq_sl, long long dq_sb, float *dk, float *dv,
+                                     long long dkv_sl, long long dkv_sb, float scale,
+                                     float dropout_p, unsigned long long seed,
+                                     const long long *step, int parts, btr_stream_t stream) {
   if (lq <= 0 || b <= 0 || h <= 0) return BTR_OK;
+  const bool do_q = (parts & kAttnBwdQ) != 0, do_kv = (parts & kAttnBwdKV) != 0;
   BTR_REQUIRE(q && k && v && out && dout && lse && dsum && dq && dk && dv && lk > 0 &&
                   btr_attention_supported(d),
               "attention_bwd: null pointer, no keys or head width %d not in 1..64", d);
@@ -694,14 +712,17 @@ int btr::attention_bwd_strided(int lq, int lk, int b, int h, int d, const float 
 #define BTR_ATTN_M(KS, NT)                                                                     \
   do {                                                                                         \
     if (vec) {                                                                                 \
-      if (wide)                                                                                \
+      if (do_q && wide)                                                                        \
         hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<KS, NT, true, 8>), gq, dim3(512), 0, s, a); \
-      else                                                                                     \
+      else if (do_q)                                                                           \
         hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<KS, NT, true, 4>), gq, dim3(256), 0, s, a); \
-      hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<KS, NT, true>), gk, dim3(256), 0, s, a);    \
+      if (do_kv)                                                                               \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<KS, NT, true>), gk, dim3(256), 0, s, a);  \
     } else {                                                                                   \
-      hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<KS, NT, false, 4>), gq, dim3(256), 0, s, a); \
-      hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<KS, NT, false>), gk, dim3(256), 0, s, a);   \
+      if (do_q)                                                                                \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<KS, NT, false, 4>), gq, dim3(256), 0, s, a); \
+      if (do_kv)                                                                               \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<KS, NT, false>), gk, dim3(256), 0, s, a); \
     }                                                                                          \
   } while (0)
     if (d <= 16) BTR_ATTN_M(8, 1);

@@ -534,7 +534,7 @@ FwdPlanes fwd_planes(const btr_decoder_layer_t &d, size_t base) {
 }
 struct BwdScratch {
   size_t dx3, dres3, df, dh, dx2f, dres2, do2, da2, dq2, dkv, dqp1, dkp, dres1, do1, da1, dqkv,
-      dqp0, dsum;
+      dqp0, dsum, dsum2;
   size_t t_sa_in, t_sa_out, t_ca_in, t_ca_out, t_l1, t_l2;
   size_t p_sa_in, p_sa_out, p_ca_in, p_ca_out, p_l2;   // bf16 planes of the transposes (decoder_sm)
   size_t pw[8];
@@ -569,6 +569,7 @@ BwdScratch bwd_scratch(const btr_decoder_layer_t &d) {
   s.dres1 = b.floats(rq * e); s.do1 = b.floats(rq * e); s.da1 = b.floats(rq * e);
   s.dqkv = b.floats(rq * 3 * e); s.dqp0 = b.floats(rq * e);
   s.dsum = b.floats((size_t)d.b * d.heads * d.pq);
+  s.dsum2 = b.floats((size_t)d.b * d.heads * d.pq);
   s.t_sa_in = b.floats(3 * e * e); s.t_sa_out = b.floats(e * e);
   s.t_ca_in = b.floats(3 * e * e); s.t_ca_out = b.floats(e * e);
   s.t_l1 = b.floats(f * e); s.t_l2 = b.floats(f * e);
@@ -831,12 +832,15 @@ int decoder_layer_backward_rows(const btr_decoder_layer_t *dp, const btr_decoder
 //   kDecoderBwdChain: what the gradient of the layer's INPUT waits for -- the LayerNorm backwards,
 //       the input-gradient GEMMs, the attention backwards (writes every dY of the seven linear
 //       maps into the scratch on its way);
+//   kDecoderBwdKey: the cross-attention's d k / d v (88 us at 256 queries x 1 024 keys: the
+//       layer's input gradient needs d q only) and the key / value rows' input gradient (d kp:
+//       only the keys and their position embedding wait for it);
 //   kDecoderBwdRest: what only the parameters wait for -- the seven weight gradients with their
-//       reduction, the bias and LayerNorm parameter gradients;
-//   kDecoderBwdKey: the key / value rows' input gradient (d kp: only the keys and their position
-//       embedding wait for it).
-// Rest and Key read the dY the chain left in the SAME scratch: issue them after the chain (same
-// stream, or others ordered behind it) and keep the scratch until they are through.
+//       reduction, the bias and LayerNorm parameter gradients.  Reads the d k / d v rows: after
+//       kDecoderBwdKey.
+// Key and Rest read what the chain left in the SAME scratch: issue them after the chain (same
+// stream, or others ordered behind it), Rest behind Key, and keep the scratch until they are
+// through.
 // All three = the one-call backward: the same launches with the same operands, the later parts'
 // after the chain's (they were interleaved; no result depends on that).
 int decoder_layer_backward_parts(const btr_decoder_layer_t *dp, const btr_decoder_plan_t *pp,
@@ -933,11 +937,14 @@ int decoder_layer_backward_parts(const btr_decoder_layer_t *dp, const btr_decode
       BTR_TRY(ln_backward(hs, a));
     }
     BTR_TRY(dgrad(rq, e, e, S(sc.do2), S(sc.t_ca_out), e, S(sc.da2), sc.p_ca_out, 0, e));
-    BTR_TRY(attention_bwd_strided(
+    // (cross-attention: d q2 only -- its d k / d v go to the keys and to parameters, nothing the
+    // layer's input gradient waits for: kDecoderBwdKey.  The row sums D live in their own
+    // buffer, the self-attention below must not overwrite them before that part has run)
+    BTR_TRY(attention_bwd_strided_parts(
         d.pq, d.pk, d.b, d.heads, hd, q2, e, (long long)d.pq * e, kv, kv + e, 2 * e,
         (long long)d.pk * 2 * e, a2, S(sc.da2), e, (long long)d.pq * e, at_f(saved, p.lse2),
-        S(sc.dsum), S(sc.dq2), e, (long long)d.pq * e, S(sc.dkv), S(sc.dkv) + e, 2 * e,
-        (long long)d.pk * 2 * e, scale, d.dropout, attn_seed(d, 1), d.step, stream));
+        S(sc.dsum2), S(sc.dq2), e, (long long)d.pq * e, S(sc.dkv), S(sc.dkv) + e, 2 * e,
+        (long long)d.pk * 2 * e, scale, d.dropout, attn_seed(d, 1), d.step, kAttnBwdQ, stream));
     BTR_TRY(dgrad(rq, e, e, S(sc.dq2), S(sc.t_ca_in), 3 * e, r_dqp1, sc.p_ca_in, 0, e));
     // ---- LayerNorm 1, self-attention
     {
@@ -959,6 +966,18 @@ int decoder_layer_backward_parts(const btr_decoder_layer_t *dp, const btr_decode
       BTR_TRY(rows_to_bcp(hs, d.b, d.pq, e, r_dqp0, r_dqp1, nullptr, dqpos_bcp));
   }
 
+  if (parts & kDecoderBwdKey) {
+    // the cross-attention's d k / d v (from the D the chain's d q kernel left), then the key
+    // rows' input gradient
+    BTR_TRY(attention_bwd_strided_parts(
+        d.pq, d.pk, d.b, d.heads, hd, q2, e, (long long)d.pq * e, kv, kv + e, 2 * e,
+        (long long)d.pk * 2 * e, a2, S(sc.da2), e, (long long)d.pq * e, at_f(saved, p.lse2),
+        S(sc.dsum2), S(sc.dq2), e, (long long)d.pq * e, S(sc.dkv), S(sc.dkv) + e, 2 * e,
+        (long long)d.pk * 2 * e, scale, d.dropout, attn_seed(d, 1), d.step, kAttnBwdKV, stream));
+    if (dkey_bcp || (out && out->dkp))
+      BTR_TRY(dgrad(rk, 2 * e, e, S(sc.dkv), S(sc.t_ca_in) + e, 3 * e, r_dkp, sc.p_ca_in, e, e));
+    if (dkey_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pk, e, r_dkp, nullptr, nullptr, dkey_bcp));
+  }
   if (parts & kDecoderBwdRest) {
     {
       reduce_batch_begin();
@@ -1016,11 +1035,6 @@ int decoder_layer_backward_parts(const btr_decoder_layer_t *dp, const btr_decode
       fa.count = 10;
       hipLaunchKernelGGL(colsum_final_multi_kernel, dim3(blocks), dim3(256), 0, hs, fa);
     }
-  }
-  if (parts & kDecoderBwdKey) {
-    if (dkey_bcp || (out && out->dkp))
-      BTR_TRY(dgrad(rk, 2 * e, e, S(sc.dkv), S(sc.t_ca_in) + e, 3 * e, r_dkp, sc.p_ca_in, e, e));
-    if (dkey_bcp) BTR_TRY(rows_to_bcp(hs, d.b, d.pk, e, r_dkp, nullptr, nullptr, dkey_bcp));
   }
   return check_launch("decoder_layer_backward");
 }

@@ -171,17 +171,16 @@ struct Lanes {
   hipStream_t main = nullptr;
   SideLane *lane = nullptr;
   uint64_t key = 0;
-  // BTR_GF_LANES=1 | 2 | 3 (default 2): how many streams the three lanes are mapped onto (the
-  // events order them on any number; 1 = replayed graphs on the caller's stream alone).  Two and
-  // three measure the same on a quiet process (8.66 ms per GroupFree3D step), but with three the
-  // process holds five streams -- the caller's, the sampling prefetch, two side lanes, the capture
-  // stream -- on four hardware queues, and a lane that lands on the prefetch stream's queue waits
-  // behind a 2.2 ms FPS kernel: runs of the same build spread 8.66 - 9.25 ms with three, 8.66 -
-  // 8.67 with two (profiles/r06_gf_lanes_spread.txt)
+  // BTR_GF_LANES=1 | 2 | 3 (default 3): how many streams the three lanes are mapped onto (the
+  // events order them on any number; 1 = replayed graphs on the caller's stream alone).  With the
+  // cross-attention's d k / d v kernel on lane 2 the side work of a layer (115 + 131 + 130 us) is
+  // as long as the main lane's (~360 us): on ONE side stream it becomes the critical path (step
+  // 8.9 ms against 8.3 - 8.7 with a stream per lane, same box; profiles/r06_gf_lanes_spread.txt
+  // has the earlier comparison, when the side work was 290 us and two streams sufficed)
   static int count() {
     static const int n = [] {
       const char *e = getenv("BTR_GF_LANES");
-      const int v = e ? atoi(e) : 2;
+      const int v = e ? atoi(e) : 3;
       return v < 1 ? 1 : (v > 3 ? 3 : v);
     }();
     return n;
@@ -481,6 +480,7 @@ int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *p
   auto M = [&](int i) { return 1 + L + i; };
   auto R = [&](int i) { return 1 + 2 * L + i; };
   auto C = [&](int i) { return 1 + 3 * L + i; };
+  auto Kd = [&](int i) { return 1 + 4 * L + i; };   // the cross-attention's d k / d v are there
   ln.signal(0, 0);
   ln.wait(0, 2);
   for (int i = L - 1; i >= 0; --i) {
@@ -544,8 +544,24 @@ int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *p
                                           nullptr, nullptr, &out, sub, kDecoderBwdChain, st);
     }));
     ln.signal(M(i), 0);
-    // ---- lane 1: the parameter gradients of the layer
+    // ---- lane 2 first: the cross-attention's d k / d v and the key rows' gradient (88 + 27 us
+    // that the layer's input gradient does not wait for).  (Layer 0's lane-2 work goes onto the
+    // caller's stream: nothing is left for it to do but wait for the side lanes, and the
+    // parameter gradients of layer 0 run beside it instead of in front of it)
+    const int cl = i == 0 ? 0 : 2;
+    ln.wait(M(i), cl);
+    if (reached)
+      BTR_TRY(ln.run(500 + i, cl, [&](hipStream_t bs) -> int {
+        return decoder_layer_backward_parts(&d.layer[i], &p.layer[i], x_in, key_cl, qpos_cl,
+                                            kpos_cl, nullptr, nullptr, nullptr, nullptr,
+                                            at_v(saved, p.s_layer[i]), grads + p.g_layer[i],
+                                            nullptr, nullptr, nullptr, &out, sub, kDecoderBwdKey,
+                                            (btr_stream_t)bs);
+      }));
+    ln.signal(Kd(i), cl);
+    // ---- lane 1: the parameter gradients of the layer (the d k / d v rows among their operands)
     ln.wait(M(i), 1);
+    ln.wait(Kd(i), 1);
     if (reached)
       BTR_TRY(ln.run(100 + i, 1, [&](hipStream_t bs) -> int {
         return decoder_layer_backward_parts(&d.layer[i], &p.layer[i], x_in, key_cl, qpos_cl,
@@ -555,19 +571,10 @@ int btr_gf_stack_backward(const btr_gf_stack_t *dp, const btr_gf_stack_plan_t *p
                                             (btr_stream_t)bs);
       }));
     ln.signal(R(i), 1);
-    // ---- lane 2: the key rows' gradient, the two position-embedding chains.  (Layer 0's go onto
-    // the caller's stream: nothing is left for it to do but wait for the side lanes, and the
-    // parameter gradients of layer 0 run beside them instead of in front of them)
-    const int cl = i == 0 ? 0 : 2;
-    ln.wait(M(i), cl);
+    // ---- lane 2 again: the two position-embedding chains
     if (reached)
       BTR_TRY(ln.run(300 + i, cl, [&](hipStream_t bs) -> int {
         btr_stream_t st = (btr_stream_t)bs;
-        BTR_TRY(decoder_layer_backward_parts(&d.layer[i], &p.layer[i], x_in, key_cl, qpos_cl,
-                                             kpos_cl, nullptr, nullptr, nullptr, nullptr,
-                                             at_v(saved, p.s_layer[i]), grads + p.g_layer[i],
-                                             nullptr, nullptr, nullptr, &out, sub, kDecoderBwdKey,
-                                             st));
         if (d.has_qpos)
           BTR_TRY(pm_chain_backward_rows(&d.qpos[i], &p.qpos[i], nullptr, nullptr, out.dqp0,
                                          out.dqp1, at_v(saved, p.s_qpos[i]), grads + p.g_qpos[i],

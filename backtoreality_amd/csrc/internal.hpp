@@ -29,7 +29,7 @@ int graph_run(uint64_t key, hipStream_t stream, const std::function<int(hipStrea
               int *how);
 uint64_t hash_bytes(uint64_t h, const void *p, size_t n);
 struct SideLane {
-  static constexpr int kEvents = 4 * BTR_GF_MAX_DECODER_LAYERS + 2;
+  static constexpr int kEvents = 5 * BTR_GF_MAX_DECODER_LAYERS + 2;
   hipStream_t s[2] = {};   // side streams (the second only when asked for)
   hipEvent_t ev[kEvents] = {};
 };
@@ -229,5 +229,16 @@ int attention_bwd_strided(int lq, int lk, int b, int h, int d, const float *q, l
                           long long dq_sl, long long dq_sb, float *dk, float *dv,
                           long long dkv_sl, long long dkv_sb, float scale, float dropout_p,
                           unsigned long long seed, const long long *step, btr_stream_t stream);
+
+enum { kAttnBwdQ = 1, kAttnBwdKV = 2 };
+int attention_bwd_strided_parts(int lq, int lk, int b, int h, int d, const float *q,
+                                long long q_sl, long long q_sb, const float *k, const float *v,
+                                long long kv_sl, long long kv_sb, const float *out,
+                                const float *dout, long long o_sl, long long o_sb,
+                                const float *lse, float *dsum, float *dq, long long dq_sl,
+                                long long dq_sb, float *dk, float *dv, long long dkv_sl,
+                                long long dkv_sb, float scale, float dropout_p,
+                                unsigned long long seed, const long long *step, int parts,
+                                btr_stream_t stream);
 
 }  // namespace btr
