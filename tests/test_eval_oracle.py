@@ -47,3 +47,70 @@ def test_parse_and_ap_match_reference(gold, tag, cname):
                            rtol=0, atol=1e-12)
     for thr in (0.25, 0.5):
         ec.check_metrics(gold, key, thr, eo.metrics(pred, gt, thr), 1e-9)
+
+
+def test_eval_det_host_logic_matches_the_oracle(monkeypatch):
+    """votenet/ap_helper.eval_det (integer class codes, one masked arg-max per class instead of the
+    reference's per-detection loop) against the oracle's restatement of utils/eval_det.py, the
+    IoU kernel replaced by the oracle's IoU: scenes as SceneDetections (arrays, the tuples are not
+    read) and as plain lists must give the same rec / prec / ap; an in-place change of a
+    SceneDetections makes its tuples the truth again."""
+    import torch
+    from backtoreality_amd.pointnet2 import _ext
+    from backtoreality_amd.votenet import ap_helper
+
+    def iou(c1, c2):
+        a, b = c1.numpy(), c2.numpy()
+        out = np.zeros((a.shape[0], a.shape[1], b.shape[1]))
+        for s, i, j in np.ndindex(*out.shape):
+            if np.ptp(a[s, i]) > 0 and np.ptp(b[s, j]) > 0:      # (padding boxes are all zero)
+                out[s, i, j] = eo.box3d_iou(a[s, i], b[s, j])
+        return torch.from_numpy(out)
+    monkeypatch.setattr(_ext, "box3d_iou", iou)
+    rng = np.random.default_rng(7)
+    box = lambda c: eo.get_3d_box(rng.uniform(0.5, 1.5, 3), rng.uniform(-3, 3), c)
+    C, cpu = 4, torch.device("cpu")
+    for per_class in (True, False):
+        compact, plain, gt = {}, {}, {}
+        for s in range(6):
+            centres = rng.uniform(-2, 2, (rng.integers(0, 5), 3))
+            gt[s] = [(int(rng.integers(0, C + 1)), box(c)) for c in centres]   # class C: gt only
+            n = int(rng.integers(0, 7)) if s != 3 else 0
+            src = [int(rng.integers(len(centres))) if len(centres) and rng.random() < 0.7 else -1
+                   for _ in range(n)]                     # a shifted ground-truth box or a stray
+            boxes = np.stack([gt[s][g][1] + rng.normal(0, 0.05, 3) if g >= 0
+                              else box(rng.uniform(-2, 2, 3)) for g in src]) \
+                if n else np.zeros((0, 8, 3))
+            if per_class:
+                sc = rng.random((C, n)).astype(np.float32)
+                cur = [(ii, b, x) for ii in range(C) for b, x in zip(list(boxes), sc[ii])]
+                arrays = (boxes, np.repeat(np.arange(C), n), sc.reshape(-1).astype(np.float64),
+                          np.tile(np.arange(n), C))
+            else:
+                cl = np.array([gt[s][g][0] % C if g >= 0 and rng.random() < 0.8
+                               else rng.integers(0, C) for g in src], dtype=np.int64)
+                sc = rng.random(n).astype(np.float32)
+                cur = [(c, b, x) for c, b, x in zip(cl.tolist(), list(boxes), sc)]
+                arrays = (boxes, cl.astype(np.int64), sc.astype(np.float64), np.arange(n))
+            plain[s] = list(cur)
+            compact[s] = ap_helper.SceneDetections(cur, arrays)
+            assert compact[s].compact is not None and compact[s] == plain[s]
+        del plain[5], compact[5]                                  # a scene without detections
+        want = eo.eval_det(plain, gt, 0.25)
+        assert any(np.asarray(v).size and float(v) > 0 for v in want[2].values())
+        for pred in (compact, plain):
+            got = ap_helper.eval_det(pred, gt, 0.25, device=cpu)
+            for w, g in zip(want, got):
+                assert sorted(w) == sorted(g)
+                for k in w:
+                    assert np.allclose(np.asarray(w[k], float), np.asarray(g[k], float),
+                                       rtol=0, atol=1e-12, equal_nan=True), (per_class, k)
+        # edited in place: the arrays are dropped and the edited tuples are evaluated
+        s = next(k for k in compact if len(compact[k]))
+        compact[s].pop()
+        plain[s].pop()
+        assert compact[s].compact is None
+        got = ap_helper.eval_det(compact, gt, 0.25, device=cpu)
+        want = eo.eval_det(plain, gt, 0.25)
+        for k in want[2]:
+            assert np.allclose(float(want[2][k]), float(got[2][k]), atol=1e-12, equal_nan=True)
