@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""cProfile of the host side of the eager GroupFree3D two-branch step (train_step_br)."""
+"""cProfile of the host side of the eager GroupFree3D two-branch step (train_step_br); with
+GF_PLAIN=1 of the fully supervised step (train_step)."""
 import cProfile, io, os, pstats, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +9,8 @@ from backtoreality_amd.groupfree import train as gf_train
 from backtoreality_amd.votenet import config, synthetic, train
 dev = torch.device("cuda:0")
 cfg = config.scannet_md40()
-net = gf_train.build_model(cfg, dev, domain_adaptation=True)
+PLAIN = os.environ.get("GF_PLAIN") == "1"
+net = gf_train.build_model(cfg, dev, domain_adaptation=not PLAIN)
 opt = gf_train.make_optimizer(net)
 B, N = 4, 50000
 bS = [synthetic.make_batch(s, B, N, cfg, use_height=False, device=dev) for s in (0, 1)]
@@ -17,7 +19,10 @@ bT = [synthetic.make_batch(s, B, N, cfg, use_height=False, device=dev) for s in 
 
 def loop(n):
     for i in range(n):
-        gf_train.train_step_br(net, opt, bS[i % 2], bT[i % 2], cfg)
+        if PLAIN:
+            gf_train.train_step(net, opt, bS[i % 2], cfg)
+        else:
+            gf_train.train_step_br(net, opt, bS[i % 2], bT[i % 2], cfg)
 
 
 loop(5)
