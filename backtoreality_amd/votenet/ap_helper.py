@@ -211,8 +211,8 @@ def _scene_arrays(dets, code_of):
     """One scene's detection list -> (boxes (n,8,3), class code, score, box index per entry).
     A SceneDetections that still carries its arrays is read without touching the tuples;
     any other list is walked (the same box listed once per class is stored once)."""
-    compact = dets.compact if type(dets) is SceneDetections else None
-    if compact is not None:
+    compact = getattr(dets, 'compact', None) if type(dets) is SceneDetections else None
+    if compact is not None and len(compact[1]) == len(dets):
         boxes, cls, score, box = compact
         vals, first, inv = np.unique(cls, return_index=True, return_inverse=True)
         codes = np.empty(vals.size, dtype=np.int64)
