@@ -309,8 +309,10 @@ def evaluate_one_epoch(net, batches, cfg, config_dict=None, ap_iou_thresholds=(0
     prefixes = (['last_', 'proposal_'] + ['%dhead_' % i for i in range(n - 1)]) if n > 0 \
         else ['proposal_']
     assert sorted(prefixes) == sorted(head_prefixes(n))
-    calcs = {thr: {p: ap_helper.APCalculator(ap_iou_thresh=thr) for p in prefixes}
-             for thr in ap_iou_thresholds}
+    # (one calculator per head: the IoUs and the matching candidates do not depend on the
+    # threshold, compute_metrics(thresholds) evaluates them once)
+    ap_iou_thresholds = list(ap_iou_thresholds)
+    calcs = {p: ap_helper.APCalculator(ap_iou_thresh=ap_iou_thresholds[0]) for p in prefixes}
     was_training = net.training
     net.eval()
     stat, nb = {}, 0
@@ -326,11 +328,10 @@ def evaluate_one_epoch(net, batches, cfg, config_dict=None, ap_iou_thresholds=(0
                     stat[key] = stat.get(key, 0) + v.detach()
             gt = ap_helper.parse_groundtruths(end_points, config_dict)
             for p in prefixes:
-                pred = ap_helper.parse_predictions(end_points, config_dict, p)
-                for thr in ap_iou_thresholds:
-                    calcs[thr][p].step(pred, gt)
+                calcs[p].step(ap_helper.parse_predictions(end_points, config_dict, p), gt)
             nb += 1
     finally:
         net.train(was_training)
     stats = {k: float(v) / max(nb, 1) for k, v in sorted(stat.items())}
-    return stats, {thr: {p: c.compute_metrics() for p, c in d.items()} for thr, d in calcs.items()}
+    per_head = {p: c.compute_metrics(ap_iou_thresholds) for p, c in calcs.items()}
+    return stats, {thr: {p: per_head[p][thr] for p in prefixes} for thr in ap_iou_thresholds}

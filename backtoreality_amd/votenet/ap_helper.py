@@ -241,7 +241,12 @@ def eval_det(pred_all, gt_all, ovthresh=0.25, device=None):
     picks it) is evaluated without a per-detection loop: a detection's best ground-truth box
     does not depend on the matching state, so the first detection per (scene, box) in score
     order is the true positive.  Classes are any hashable; inside they are integer codes in
-    order of first appearance (predictions, then ground truths)."""
+    order of first appearance (predictions, then ground truths).
+    `ovthresh` may be a sequence of thresholds: the IoUs and every detection's best ground-truth
+    box do not depend on it, so they are computed once and the result is {threshold: (rec, prec,
+    ap)} (GroupFree3D evaluates every head at 0.25 and 0.5, train_GF_FSB.py:384-445)."""
+    many = isinstance(ovthresh, (tuple, list))
+    thresholds = list(ovthresh) if many else [ovthresh]
     device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     scenes = sorted(set(pred_all.keys()) | set(gt_all.keys()), key=lambda s: (str(type(s)), s))
     S = len(scenes)
@@ -275,12 +280,13 @@ def eval_det(pred_all, gt_all, ovthresh=0.25, device=None):
     pscene = np.repeat(np.arange(S, dtype=np.int64), [len(a[1]) for a in per_scene])
     by_code = np.argsort(pcode, kind="stable")   # entries of one class, in list order
     start = np.searchsorted(pcode[by_code], np.arange(len(classes) + 1))
-    rec, prec, ap = {}, {}, {}
+    out = {thr: ({}, {}, {}) for thr in thresholds}
     for code, c in enumerate(classes):
         sel = by_code[start[code]:start[code + 1]]
         if sel.size == 0:
             if code >= pred_codes:               # only the ground truths have it
-                rec[c], prec[c], ap[c] = 0, 0, 0
+                for rec, prec, ap in out.values():
+                    rec[c], prec[c], ap[c] = 0, 0, 0
             continue
         order = sel[np.argsort(-pscore[sel], kind="stable")]
         nd = order.size
@@ -294,19 +300,20 @@ def eval_det(pred_all, gt_all, ovthresh=0.25, device=None):
             ovmax[rows] = sub[np.arange(best.size), best]
             jmax[rows] = best
         npos = int(np.sum(gmat == code))
-        hit = ovmax > ovthresh
-        tp = np.zeros(nd)
-        keys = sc[hit] * (G + 1) + jmax[hit]
-        _, first = np.unique(keys, return_index=True)
-        tp[np.nonzero(hit)[0][first]] = 1.0
-        fp = 1.0 - tp
-        fp = np.cumsum(fp)
-        tp = np.cumsum(tp)
-        with np.errstate(all="ignore"):
-            rec[c] = tp / float(npos)
-            prec[c] = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
-            ap[c] = voc_ap(rec[c], prec[c])
-    return rec, prec, ap
+        for thr, (rec, prec, ap) in out.items():
+            hit = ovmax > thr
+            tp = np.zeros(nd)
+            keys = sc[hit] * (G + 1) + jmax[hit]
+            _, first = np.unique(keys, return_index=True)
+            tp[np.nonzero(hit)[0][first]] = 1.0
+            fp = 1.0 - tp
+            fp = np.cumsum(fp)
+            tp = np.cumsum(tp)
+            with np.errstate(all="ignore"):
+                rec[c] = tp / float(npos)
+                prec[c] = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+                ap[c] = voc_ap(rec[c], prec[c])
+    return out if many else out[ovthresh]
 
 
 class APCalculator(object):
@@ -326,8 +333,16 @@ class APCalculator(object):
             self.pred_map_cls[self.scan_cnt] = batch_pred_map_cls[i]
             self.scan_cnt += 1
 
-    def compute_metrics(self):
-        rec, prec, ap = eval_det(self.pred_map_cls, self.gt_map_cls, ovthresh=self.ap_iou_thresh)
+    def compute_metrics(self, ap_iou_thresh=None):
+        """The reference's metrics dict at this calculator's threshold; with a sequence of
+        thresholds, {threshold: metrics dict} from one pass over the boxes (see eval_det)."""
+        if isinstance(ap_iou_thresh, (tuple, list)):
+            res = eval_det(self.pred_map_cls, self.gt_map_cls, ovthresh=list(ap_iou_thresh))
+            return {thr: self._metrics(*res[thr]) for thr in ap_iou_thresh}
+        thr = self.ap_iou_thresh if ap_iou_thresh is None else ap_iou_thresh
+        return self._metrics(*eval_det(self.pred_map_cls, self.gt_map_cls, ovthresh=thr))
+
+    def _metrics(self, rec, prec, ap):
         ret_dict = {}
         for key in sorted(ap.keys()):
             clsname = self.class2type_map[key] if self.class2type_map else str(key)

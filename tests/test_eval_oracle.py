@@ -105,6 +105,15 @@ def test_eval_det_host_logic_matches_the_oracle(monkeypatch):
                 for k in w:
                     assert np.allclose(np.asarray(w[k], float), np.asarray(g[k], float),
                                        rtol=0, atol=1e-12, equal_nan=True), (per_class, k)
+        # several thresholds from one pass: the same as one call per threshold
+        both = ap_helper.eval_det(compact, gt, [0.25, 0.5], device=cpu)
+        for thr in (0.25, 0.5):
+            w = eo.eval_det(plain, gt, thr)
+            for k in w[2]:
+                assert np.allclose(float(w[2][k]), float(both[thr][2][k]), atol=1e-12,
+                                   equal_nan=True), (thr, k)
+                assert np.allclose(np.asarray(w[0][k], float), np.asarray(both[thr][0][k], float),
+                                   atol=1e-12, equal_nan=True)
         # edited in place: the arrays are dropped and the edited tuples are evaluated
         s = next(k for k in compact if len(compact[k]))
         compact[s].pop()

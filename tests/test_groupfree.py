@@ -566,6 +566,25 @@ def test_groupfree_evaluate_one_epoch(cuda):
     assert sorted(metrics) == [0.25, 0.5]
     assert sorted(metrics[0.25]) == ['0head_', 'last_', 'proposal_']
     assert 'mAP' in metrics[0.5]['last_']
+    # both thresholds come from one pass over the boxes: the same as a calculator per threshold
+    from backtoreality_amd.votenet import ap_helper, train
+    cd = dict(train.EVAL_CONFIG_DICT, conf_thresh=0.0, dataset_config=cfg)
+    calc = {thr: ap_helper.APCalculator(ap_iou_thresh=thr) for thr in (0.25, 0.5)}
+    net.eval()
+    with torch.no_grad():
+        for batch in batches:
+            end = net({'point_clouds': batch['point_clouds']})
+            end.update(batch)
+            pred = ap_helper.parse_predictions(end, cd, 'last_')
+            gt = ap_helper.parse_groundtruths(end, cd)
+            for c in calc.values():
+                c.step(pred, gt)
+    for thr in (0.25, 0.5):
+        want = calc[thr].compute_metrics()
+        got = metrics[thr]['last_']
+        assert sorted(want) == sorted(got)
+        for k in want:
+            assert np.allclose(float(want[k]), float(got[k]), rtol=0, atol=1e-12, equal_nan=True)
 
 
 @pytest.mark.gpu
