@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""cProfile of the host side of the VoteNet CenterRefine step (train_step_br_jitter)."""
+"""cProfile of the host side of the VoteNet CenterRefine step (train_step_br_jitter); with
+BR_PLAIN=1 of the Back-to-Reality step without the centre branch (train_step_br)."""
 import cProfile, io, os, pstats, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,7 +8,8 @@ import torch
 from backtoreality_amd.votenet import config, synthetic, train
 dev = torch.device("cuda:0")
 cfg = config.scannet_md40()
-net = train.build_model(cfg, dev, domain_adaptation=True, center_refine=True)
+PLAIN = os.environ.get('BR_PLAIN') == '1'
+net = train.build_model(cfg, dev, domain_adaptation=True, center_refine=not PLAIN)
 opt = train.make_optimizer(net)
 jit = 0.1
 bS = [synthetic.make_batch(s, 8, 40000, cfg, device=dev, center_jitter=jit) for s in (0, 1)]
@@ -16,7 +18,10 @@ bT = [synthetic.make_batch(s, 8, 40000, cfg, device=dev, center_jitter=jit) for 
 
 def loop(n):
     for i in range(n):
-        train.train_step_br_jitter(net, opt, bS[i % 2], bT[i % 2], cfg, epoch=30)
+        if PLAIN:
+            train.train_step_br(net, opt, bS[i % 2], bT[i % 2], cfg)
+        else:
+            train.train_step_br_jitter(net, opt, bS[i % 2], bT[i % 2], cfg, epoch=30)
 
 
 loop(5)
